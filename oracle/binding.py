@@ -1,0 +1,282 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package trgt_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+METRICS = {"indel": 0, "edit": 1, "linear": 2, "affine": 3, "affine2p": 4}
+MEMORY = {"high": 0, "med": 1, "low": 2, "ultralow": 3}
+
+
+class WfaParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "metric", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2", "span", "pattern_begin_free",
+        "pattern_end_free", "text_begin_free", "text_end_free", "scope", "memory_mode", "heuristic",
+        "h_min_wavefront_length", "h_max_distance_threshold", "h_steps_between_cutoffs", "bialign_min_score",
+        "bialign_min_length")]
+
+
+class LocusParams(C.Structure):
+    _fields_ = [("flank_len", C.c_int32), ("min_flank_id_frac", C.c_double), ("max_depth", C.c_int32),
+                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("ploidy", C.c_int32)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("hmm.cpp", "wfa.cpp", "locus.cpp", "oracle.h", "oracle_internal.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_hmm_purity.restype = C.c_double
+    return _LIB
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(0, np.uint8)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def motif_blob(motifs):
+    motifs = [m.encode() if isinstance(m, str) else bytes(m) for m in motifs]
+    off = np.zeros(len(motifs) + 1, np.uint32)
+    off[1:] = np.cumsum([len(m) for m in motifs])
+    return _u8(b"".join(motifs)), off
+
+
+def wfa_params(metric="affine", x=0, o1=0, e1=0, o2=0, e2=0, span="end2end", pbf=0, pef=0, tbf=0, tef=0,
+               scope="alignment", memory="high", heuristic="default", min_score=250, min_length=100):
+    p = WfaParams()
+    lib().orc_wfa_default_params(C.byref(p))
+    p.metric = METRICS[metric]
+    if metric in ("linear", "affine", "affine2p"):
+        p.mismatch, p.gap_open1, p.gap_ext1, p.gap_open2, p.gap_ext2 = x, o1, e1, o2, e2
+    p.span = 1 if span == "endsfree" else 0
+    p.pattern_begin_free, p.pattern_end_free, p.text_begin_free, p.text_end_free = pbf, pef, tbf, tef
+    p.scope = 1 if scope == "alignment" else 0
+    p.memory_mode = MEMORY[memory]
+    if heuristic == "none":
+        p.heuristic = 0
+    elif heuristic != "default":
+        p.heuristic = 1
+        p.h_min_wavefront_length, p.h_max_distance_threshold, p.h_steps_between_cutoffs = heuristic
+    p.bialign_min_score, p.bialign_min_length = min_score, min_length
+    return p
+
+
+def wfa_align(p, pattern, text):
+    pa, te = _u8(pattern), _u8(text)
+    ops = np.zeros(len(pa) + len(te) + 1, np.uint8)
+    score, ops_len, n_match = C.c_int32(), C.c_int32(), C.c_int32()
+    span4 = np.zeros(4, np.uint32)
+    cells = C.c_int64()
+    st = lib().orc_wfa_align(C.byref(p), _p(pa), len(pa), _p(te), len(te), C.byref(score), _p(ops), C.byref(ops_len),
+                             C.byref(n_match), _p(span4), C.byref(cells))
+    return dict(status=st, score=score.value, ops=bytes(ops[:ops_len.value]).decode(), n_match=n_match.value,
+                span=[int(v) for v in span4], cells=cells.value)
+
+
+def cigar_string(ops):
+    out, i = [], 0
+    while i < len(ops):
+        j = i
+        while j < len(ops) and ops[j] == ops[i]:
+            j += 1
+        out.append("%d%s" % (j - i, ops[i]))
+        i = j
+    return "".join(out)
+
+
+def cigar_rle(ops, show_mismatches=True):
+    o = _u8(ops.encode())
+    out = np.zeros(len(o) + 1, np.uint32)
+    n = lib().orc_cigar_rle(_p(o), len(o), int(show_mismatches), _p(out), len(out))
+    return [int(v) for v in out[:n]]
+
+
+def cigar_score(p, ops, clipped=None):
+    o = _u8(ops.encode())
+    if clipped is None:
+        return lib().orc_cigar_score(C.byref(p), _p(o), len(o))
+    return lib().orc_cigar_score_clipped(C.byref(p), _p(o), len(o), int(clipped))
+
+
+# ------------------------------------------------------------------ HMM
+def hmm_label(motifs, seq):
+    mb, mo = motif_blob(motifs)
+    s = _u8(seq.encode())
+    cap = 64 + (len(s) + 2) * (max(len(m) for m in motifs) + 6)
+    path = np.zeros(cap, np.int32)
+    n = lib().orc_hmm_label(_p(mb), _p(mo), len(motifs), _p(s), len(s), _p(path), cap)
+    assert n >= 0
+    return path[:n].copy()
+
+
+def hmm_remove_imperfect(motifs, path, seq, max_motif_len=6):
+    mb, mo = motif_blob(motifs)
+    s = _u8(seq.encode())
+    path = np.ascontiguousarray(path, np.int32)
+    out = np.zeros(len(path) * 3 + 16, np.int32)
+    n = lib().orc_hmm_remove_imperfect(_p(mb), _p(mo), len(motifs), _p(path), len(path), _p(s), len(s), max_motif_len,
+                                       _p(out), len(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def hmm_label_motifs(motifs, path):
+    mb, mo = motif_blob(motifs)
+    path = np.ascontiguousarray(path, np.int32)
+    out = np.zeros(3 * (len(path) + 1), np.int32)
+    n = lib().orc_hmm_label_motifs(_p(mb), _p(mo), len(motifs), _p(path), len(path), _p(out), len(path) + 1)
+    assert n >= 0
+    return out[:3 * n].reshape(-1, 3).copy()
+
+
+def hmm_purity(motifs, path, seq):
+    mb, mo = motif_blob(motifs)
+    s = _u8(seq.encode())
+    path = np.ascontiguousarray(path, np.int32)
+    e, m = C.c_int32(), C.c_int32()
+    p = lib().orc_hmm_purity(_p(mb), _p(mo), len(motifs), _p(path), len(path), _p(s), len(s), C.byref(e), C.byref(m))
+    return p, e.value, m.value
+
+
+def hmm_events(motifs, path, seq):
+    mb, mo = motif_blob(motifs)
+    s = _u8(seq.encode())
+    path = np.ascontiguousarray(path, np.int32)
+    out = np.zeros(len(path) * 4 + 64, np.uint8)
+    n = lib().orc_hmm_events(_p(mb), _p(mo), len(motifs), _p(path), len(path), _p(s), len(s), _p(out), len(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def hmm_base_match(motifs, state):
+    mb, mo = motif_blob(motifs)
+    return chr(lib().orc_hmm_base_match(_p(mb), _p(mo), len(motifs), state))
+
+
+def hmm_annotate(motifs, seq):
+    """label_with_hmm for one allele (tr.rs:463-488)."""
+    mb, mo = motif_blob(motifs)
+    s = _u8(seq.encode() if isinstance(seq, str) else seq)
+    cap = 64 + (len(s) + 2) * (max(len(m) for m in motifs) + 6)
+    path = np.zeros(cap, np.int32)
+    spans = np.zeros(3 * (len(s) + 2), np.int32)
+    counts = np.zeros(len(motifs), np.int32)
+    pl, ns, e, m = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    pur, cells = C.c_double(), C.c_int64()
+    rc = lib().orc_hmm_annotate(_p(mb), _p(mo), len(motifs), _p(s), len(s), _p(path), cap, C.byref(pl), _p(spans),
+                                len(s) + 2, C.byref(ns), _p(counts), C.byref(pur), C.byref(e), C.byref(m), C.byref(cells))
+    assert rc == 0
+    return dict(path=path[:pl.value].copy(), spans=spans[:3 * ns.value].reshape(-1, 3).copy(), counts=counts,
+                purity=pur.value, edit=e.value, maxd=m.value, cells=cells.value)
+
+
+def hmm_batch(batch, n_threads=1, want_path=True):
+    """batch: dict with the product-ABI arrays (see trgt_amd.hmm.pack_hmm_batch)."""
+    n = len(batch["job_set"])
+    path = np.zeros(int(batch["path_off"][-1]) if want_path else 0, np.uint16)
+    path_len = np.zeros(n, np.uint32)
+    spans = np.zeros(3 * int(batch["span_off"][-1]), np.int32)
+    n_spans = np.zeros(n, np.uint32)
+    counts = np.zeros(int(batch["count_off"][-1]), np.uint32)
+    purity = np.zeros(n, np.float64)
+    edit = np.zeros(n, np.int32)
+    maxd = np.zeros(n, np.int32)
+    cells = C.c_int64()
+    lib().orc_hmm_batch(len(batch["set_motif_begin"]) - 1, _p(batch["motif_blob"]), _p(batch["motif_off"]),
+                        _p(batch["set_motif_begin"]), C.c_int64(n), _p(batch["job_set"]), _p(batch["seq_blob"]),
+                        _p(batch["seq_off"]), _p(batch["seq_len"]), _p(path) if want_path else None, _p(batch["path_off"]),
+                        _p(path_len), _p(spans), _p(batch["span_off"]), _p(n_spans), _p(counts), _p(batch["count_off"]),
+                        _p(purity), _p(edit), _p(maxd), C.byref(cells), n_threads)
+    return dict(path=path, path_len=path_len, spans=spans, n_spans=n_spans, counts=counts, purity=purity, edit=edit,
+                maxd=maxd, cells=cells.value)
+
+
+def wfa_batch(p, batch, n_threads=1, want_ops=True):
+    """batch: dict(seqs, pat_off, pat_len, txt_off, txt_len, cigar_off, ops_off) -- product ABI layout."""
+    n = len(batch["pat_len"])
+    status = np.zeros(n, np.int32)
+    score = np.zeros(n, np.int32)
+    n_match = np.zeros(n, np.int32)
+    span4 = np.zeros(4 * n, np.uint32)
+    cigar = np.zeros(int(batch["cigar_off"][-1]), np.uint32)
+    cigar_len = np.zeros(n, np.uint32)
+    ops = np.zeros(int(batch["ops_off"][-1]) if want_ops else 0, np.uint8)
+    ops_len = np.zeros(n, np.uint32)
+    cells = C.c_int64()
+    lib().orc_wfa_batch(C.byref(p), C.c_int64(n), _p(batch["seqs"]), _p(batch["pat_off"]), _p(batch["pat_len"]),
+                        _p(batch["txt_off"]), _p(batch["txt_len"]), _p(status), _p(score), _p(n_match), _p(span4), _p(cigar),
+                        _p(batch["cigar_off"]), _p(cigar_len), _p(ops) if want_ops else None, _p(batch["ops_off"]),
+                        _p(ops_len), C.byref(cells), n_threads)
+    return dict(status=status, score=score, n_match=n_match, span4=span4.reshape(-1, 4), cigar=cigar, cigar_len=cigar_len,
+                ops=ops, ops_len=ops_len, cells=cells.value)
+
+
+def find_spans(piece, reads, mism=2, gapo=5, gape=1, threshold=175.0):
+    blob = _u8(b"".join(reads))
+    lens = np.array([len(r) for r in reads], np.uint32)
+    off = np.zeros(len(reads), np.uint64)
+    off[1:] = np.cumsum(lens[:-1])
+    pc = _u8(piece)
+    st = np.zeros(len(reads), np.int32)
+    en = np.zeros(len(reads), np.int32)
+    used = np.zeros(len(reads), np.int32)
+    cells = C.c_int64()
+    lib().orc_find_spans(_p(pc), len(pc), C.c_int64(len(reads)), _p(blob), _p(off), _p(lens), mism, gapo, gape,
+                         C.c_double(threshold), _p(st), _p(en), _p(used), C.byref(cells))
+    return st, en, used, cells.value
+
+
+def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250, min_flank_id_frac=0.7, max_depth=250,
+                  scoring=(2, 5, 1), ploidy=2):
+    p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], ploidy)
+    mb, mo = motif_blob(motifs)
+    blob = _u8(b"".join(reads))
+    lens = np.array([len(r) for r in reads], np.uint32)
+    off = np.zeros(len(reads), np.uint64)
+    if len(reads) > 1:
+        off[1:] = np.cumsum(lens[:-1])
+    lf, rf, tr = _u8(left_flank), _u8(right_flank), _u8(ref_tr)
+    n = len(reads)
+    ss, se = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    cap = int(lens.max()) + 8 if n else 8
+    a0, a1 = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    gt_size, gt_ci, by_hap = np.zeros(2, np.int32), np.zeros(4, np.int32), np.zeros(2, np.int32)
+    kept, cls = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    n_alleles, n_sp = C.c_int32(), C.c_int32()
+    scap = 64 * 1024
+    mc, ms, ap = C.create_string_buffer(scap), C.create_string_buffer(scap), C.create_string_buffer(scap)
+    stats = np.zeros(8, np.int64)
+    rc = lib().orc_locus_analyze(C.byref(p), _p(lf), len(lf), _p(rf), len(rf), _p(tr), len(tr), _p(mb), _p(mo), len(motifs),
+                                 C.c_int64(n), _p(blob), _p(off), _p(lens), _p(ss), _p(se), C.byref(n_alleles), a0, a1, cap,
+                                 _p(gt_size), _p(gt_ci), C.byref(n_sp), _p(kept), _p(cls), _p(by_hap), mc, ms, ap, scap,
+                                 _p(stats))
+    assert rc == 0, rc
+    na, k = n_alleles.value, n_sp.value
+    alleles = [a0.value.decode(), a1.value.decode()][:na]
+    return dict(span_start=ss, span_end=se, n_alleles=na, alleles=alleles, gt_size=gt_size[:na].copy(),
+                gt_ci=gt_ci[:2 * na].reshape(-1, 2).copy(), kept_read=kept[:k].copy(), classification=cls[:k].copy(),
+                num_spanning=by_hap[:na].copy(), MC=mc.value.decode(), MS=ms.value.decode(), AP=ap.value.decode(),
+                AL=",".join(str(len(a)) for a in alleles),
+                ALLR=",".join("%d-%d" % (gt_ci[2 * i], gt_ci[2 * i + 1]) for i in range(na)),
+                SD=",".join(str(int(v)) for v in by_hap[:na]),
+                stats=dict(wfa_cells=int(stats[0]), viterbi_cells=int(stats[1]), n_wfa_flank=int(stats[2]),
+                           n_wfa_cons=int(stats[3]), bytes_io=int(stats[4])))

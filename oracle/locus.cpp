@@ -1,0 +1,364 @@
+// oracle/locus.cpp -- CPU ORACLE (test infrastructure, never shipped / never on
+// the product path).  Restatement of the callers that sit either side of the
+// WFA/HMM hot path in PacificBiosciences/trgt v3.0.0, restricted to what
+// synthetic (already clipped, no HP tag, no SNV, no methylation) reads reach:
+//   find_spans / find_tr_spans      src/trgt/genotype/span_locater.rs:7-68
+//   get_spanning_reads              src/trgt/workflows/tr.rs:111-184
+//   utils::align                    src/utils/align.rs:14-28
+//   repair_consensus & friends      src/trgt/genotype/consensus.rs:5-154
+//   genotype_size::genotype         src/trgt/genotype/genotype_size.rs:6-125
+//   diploid / haploid genotype      diploid.rs:5-103, haploid.rs:3-30
+//   label_with_hmm, allele assembly src/trgt/workflows/tr.rs:77-101,454-492
+//   MC / MS / AP / AL / ALLR / SD   src/trgt/writers/write_vcf.rs:286-377
+// genotype_flank::genotype (tr.rs:70-75) returns None for such reads (no HP
+// tags -> get_trs_with_hp None; no mismatch offsets -> one candidate genotype,
+// genotype_flank.rs:70-95), so it is inert here and not restated.
+#include "oracle_internal.h"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace orc {
+
+static orc_wfa_params flank_params(int mism, int gapo, int gape) {  // genotype.rs:66-80
+  orc_wfa_params p;
+  orc_wfa_default_params(&p);
+  p.metric = 3; p.mismatch = mism; p.gap_open1 = gapo; p.gap_ext1 = gape;
+  p.span = 1; p.pattern_begin_free = 0; p.pattern_end_free = 0; p.text_begin_free = -1; p.text_end_free = -1;
+  p.scope = 1; p.memory_mode = 0; p.heuristic = 0;
+  return p;
+}
+static orc_wfa_params consensus_params() {  // genotype.rs:82-86: BiWFA affine(2,5,1), default heuristic
+  orc_wfa_params p;
+  orc_wfa_default_params(&p);
+  p.metric = 3; p.mismatch = 2; p.gap_open1 = 5; p.gap_ext1 = 1;
+  p.span = 0; p.scope = 1; p.memory_mode = 3;
+  return p;
+}
+
+// span_locater.rs:9-27 for one read
+SpanOpt find_span(const uint8_t* piece, int plen, const uint8_t* s, int slen, const orc_wfa_params& fp, double threshold,
+                  bool* used_wfa, int64_t* cells) {
+  SpanOpt r;
+  if (used_wfa) *used_wfa = false;
+  for (int st = 0; st + plen <= slen; ++st)
+    if (std::memcmp(s + st, piece, (size_t)plen) == 0) { r.start = st; r.end = st + plen; return r; }
+  if (used_wfa) *used_wfa = true;
+  WfaResult a = wfa_align(fp, piece, plen, s, slen);
+  if (cells) *cells += a.cells;
+  const int nm = cigar_count_matches(a.ops);
+  if ((double)(size_t)nm >= threshold) {
+    uint32_t s4[4];
+    alignment_span(fp, a.ops, plen, slen, s4);
+    r.start = (int)s4[2]; r.end = (int)s4[3];
+  }
+  return r;
+}
+
+// ---- diploid.rs / haploid.rs ---------------------------------------------
+struct TrSize { int size, ci_lo, ci_hi; };
+
+static double dip_penalty(int sa, int la, const std::vector<int>& sizes, const std::vector<int>& counts) {
+  double penalty = 0.0;
+  const double max_frac = (std::abs(sa - la) <= 100) ? 0.25 : 0.05;
+  for (size_t i = 0; i < sizes.size(); ++i) {
+    const int st = sizes[i] != sa ? 10 + 2 * std::abs(sa - sizes[i]) : 0;
+    const int lt = sizes[i] != la ? 10 + 2 * std::abs(la - sizes[i]) : 0;
+    const double term = (double)std::min(st, lt) + max_frac * (double)std::max(st, lt);
+    penalty += term * (double)counts[i];
+  }
+  return penalty;
+}
+
+static std::vector<TrSize> diploid_genotype(const std::vector<int>& sizes, const std::vector<int>& counts) {
+  struct Cand { int a, b; double pen; };
+  std::vector<Cand> c;
+  for (size_t si = 0; si < sizes.size(); ++si)
+    for (size_t li = si; li < sizes.size(); ++li) c.push_back({sizes[si], sizes[li], dip_penalty(sizes[si], sizes[li], sizes, counts)});
+  std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) { return x.pen < y.pen; });
+  int short_size = std::min(c[0].a, c[0].b), long_size = std::max(c[0].a, c[0].b);
+  if (short_size != long_size && sizes.size() >= 2) {
+    int coverage = 0;
+    for (int x : counts) coverage += x;
+    std::vector<size_t> idx(sizes.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return counts[a] > counts[b]; });
+    const double top_frac = (double)counts[idx[0]] / (double)coverage;
+    const int max_len = *std::max_element(sizes.begin(), sizes.end()), min_len = *std::min_element(sizes.begin(), sizes.end());
+    if (top_frac > 0.60 && max_len - min_len <= 6) { short_size = long_size = sizes[idx[0]]; }
+  }
+  TrSize s{short_size, short_size, short_size}, l{long_size, long_size, long_size};
+  for (int size : sizes) {  // get_ci
+    if (std::abs(size - short_size) <= std::abs(size - long_size)) { s.ci_lo = std::min(s.ci_lo, size); s.ci_hi = std::max(s.ci_hi, size); }
+    else { l.ci_lo = std::min(l.ci_lo, size); l.ci_hi = std::max(l.ci_hi, size); }
+  }
+  return {s, l};
+}
+
+static std::vector<TrSize> haploid_genotype(const std::vector<int>& sizes, const std::vector<int>& counts) {
+  int best = -1; double best_pen = 0;
+  for (size_t a = 0; a < sizes.size(); ++a) {
+    double pen = 0.0;
+    for (size_t i = 0; i < sizes.size(); ++i) {
+      const double term = sizes[i] != sizes[a] ? 10.0 + 2.0 * (double)std::abs(sizes[a] - sizes[i]) : 0.0;
+      pen += term * (double)counts[i];
+    }
+    if (best < 0 || pen < best_pen) { best = (int)a; best_pen = pen; }  // stable sort + first
+  }
+  return {TrSize{sizes[best], *std::min_element(sizes.begin(), sizes.end()), *std::max_element(sizes.begin(), sizes.end())}};
+}
+
+// ---- utils::align + consensus.rs ------------------------------------------
+typedef std::vector<std::pair<int, char>> Cigar;
+
+static std::vector<Cigar> align_all(const std::string& backbone, const std::vector<std::string>& seqs, int64_t* cells, int64_t* n_aln) {
+  const orc_wfa_params cp = consensus_params();
+  std::vector<Cigar> out;
+  for (auto& s : seqs) {
+    WfaResult r = wfa_align(cp, (const uint8_t*)backbone.data(), (int)backbone.size(), (const uint8_t*)s.data(), (int)s.size());
+    if (cells) *cells += r.cells;
+    if (n_aln) *n_aln += 1;
+    Cigar c;
+    for (uint32_t e : cigar_rle(r.ops, true)) {  // get_sam_cigar(true) + decode_sam_cigar
+      static const char* dec = "MIDNSHP=X";
+      const uint32_t code = e & 0xF;
+      c.push_back({(int)(e >> 4), code <= 8 ? dec[code] : '?'});
+    }
+    out.push_back(c);
+  }
+  return out;
+}
+
+static std::string repair_consensus(const std::string& reference, const std::vector<std::string>& seqs, const std::vector<Cigar>& aligns) {
+  std::vector<std::array<int, 5>> ref_counts(reference.size(), std::array<int, 5>{0, 0, 0, 0, 0});
+  std::vector<std::vector<std::string>> ref_inserts(reference.size() + 1);
+  auto base_idx = [](char b) { switch (b) { case 'A': return 0; case 'T': return 1; case 'C': return 2; case 'G': return 3; default: assert(!"unexpected base"); return 0; } };
+  for (size_t si = 0; si < aligns.size(); ++si) {
+    const std::string& seq = seqs[si];
+    size_t x = 0, y = 0;
+    for (auto& op : aligns[si]) {
+      const size_t n = (size_t)op.first;
+      switch (op.second) {
+        case '=': case 'M': case 'X':
+          for (size_t i = 0; i < n; ++i) ref_counts[y + i][base_idx(seq[x + i])] += 1;
+          x += n; y += n; break;
+        case 'D':
+          for (size_t i = 0; i < n; ++i) ref_counts[y + i][4] += 1;
+          y += n; break;
+        case 'I': ref_inserts[y].push_back(seq.substr(x, n)); x += n; break;
+        default: assert(!"unexpected cigar op");
+      }
+    }
+  }
+  std::string consensus;
+  for (size_t pos = 0; pos < reference.size(); ++pos) {
+    int best = 0;  // max_by_key returns the LAST maximum
+    for (int i = 1; i < 5; ++i)
+      if (ref_counts[pos][i] >= ref_counts[pos][best]) best = i;
+    if (ref_inserts[pos].size() > seqs.size() / 2) {  // get_ins_consensus
+      auto& ins = ref_inserts[pos];
+      std::sort(ins.begin(), ins.end());
+      const size_t without = seqs.size() - ins.size();
+      std::string top; size_t top_count = 0;
+      for (size_t i = 0; i < ins.size();) {
+        size_t j = i;
+        while (j < ins.size() && ins[j] == ins[i]) ++j;
+        if (j - i > top_count) { top_count = j - i; top = ins[i]; }  // stable desc sort, first
+        i = j;
+      }
+      if (top_count > without) consensus += top;
+    }
+    if (best != 4) consensus.push_back("ATCG"[best]);
+  }
+  return consensus;
+}
+
+struct SizeGt {
+  std::vector<TrSize> gt; std::vector<std::string> alleles; std::vector<int> classification;
+};
+
+// genotype_size::genotype
+static SizeGt genotype_size(int ploidy, const std::vector<std::string>& seqs, int64_t* cells, int64_t* n_aln) {
+  SizeGt out;
+  std::vector<int> lens;
+  for (auto& s : seqs) lens.push_back((int)s.size());
+  std::sort(lens.begin(), lens.end());
+  std::vector<int> ulen, ucnt;
+  for (size_t i = 0; i < lens.size();) { size_t j = i; while (j < lens.size() && lens[j] == lens[i]) ++j; ulen.push_back(lens[i]); ucnt.push_back((int)(j - i)); i = j; }
+  out.gt = ploidy == 1 ? haploid_genotype(ulen, ucnt) : diploid_genotype(ulen, ucnt);
+  std::vector<int> allele_lens;
+  for (auto& a : out.gt) allele_lens.push_back(a.size);
+  std::vector<std::string> sorted = seqs;  // get_seq_hist
+  std::sort(sorted.begin(), sorted.end());
+  std::vector<std::string> useq; std::vector<int> cnt;
+  for (size_t i = 0; i < sorted.size();) { size_t j = i; while (j < sorted.size() && sorted[j] == sorted[i]) ++j; useq.push_back(sorted[i]); cnt.push_back((int)(j - i)); i = j; }
+  auto closest = [&](int allele) { int c = -1; for (auto& s : useq) { const int l = (int)s.size(); if (c < 0) { c = l; continue; } if (std::abs(c - allele) > std::abs(l - allele)) c = l; } return c; };
+  auto most_freq = [&](int length) { int best = -1; for (size_t i = 0; i < useq.size(); ++i) if ((int)useq[i].size() == length && (best < 0 || cnt[i] >= cnt[best])) best = (int)i; return useq[best]; };
+  std::vector<std::string> alleles;  // consensus::get_consensus
+  alleles.push_back(most_freq(closest(allele_lens[0])));
+  if (allele_lens.size() != 1 && allele_lens[0] != allele_lens[1]) alleles.push_back(most_freq(closest(allele_lens[1])));
+  // split()
+  std::vector<std::pair<std::vector<std::string>, std::vector<int>>> by_allele;
+  if (allele_lens.size() == 1) by_allele.push_back({useq, cnt});
+  else {
+    const int a1 = allele_lens[0], a2 = allele_lens[1];
+    std::pair<std::vector<std::string>, std::vector<int>> g1, g2;
+    for (size_t i = 0; i < useq.size(); ++i) {
+      const int l = (int)useq[i].size();
+      if (std::abs(l - a1) <= std::abs(l - a2)) { g1.first.push_back(useq[i]); g1.second.push_back(cnt[i]); }
+      if (std::abs(l - a2) < std::abs(l - a1)) { g2.first.push_back(useq[i]); g2.second.push_back(cnt[i]); }
+    }
+    by_allele.push_back(g1); by_allele.push_back(g2);
+  }
+  for (size_t ai = 0; ai < alleles.size(); ++ai) {
+    auto& g = by_allele[ai];
+    int coverage = 0, ref_count = 0;
+    for (int c : g.second) coverage += c;
+    for (size_t i = 0; i < g.first.size(); ++i) if (g.first[i] == alleles[ai]) { ref_count = g.second[i]; break; }
+    if (!(2 * ref_count >= coverage)) {
+      auto aligns = align_all(alleles[ai], g.first, cells, n_aln);
+      alleles[ai] = repair_consensus(alleles[ai], g.first, aligns);
+    }
+  }
+  if (ploidy == 2 && alleles.size() == 1) alleles.push_back(alleles[0]);
+  out.classification.assign(seqs.size(), 0);
+  int tie = 1;
+  for (size_t i = 0; i < seqs.size(); ++i) {
+    if (alleles.size() == 2) {
+      const int d1 = std::abs((int)seqs[i].size() - (int)alleles[0].size()), d2 = std::abs((int)seqs[i].size() - (int)alleles[1].size());
+      if (d1 < d2) out.classification[i] = 0;
+      else if (d1 > d2) out.classification[i] = 1;
+      else { tie = (tie + 1) % 2; out.classification[i] = tie; }
+    }
+  }
+  out.alleles = alleles;
+  return out;
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+
+int orc_find_spans(const uint8_t* piece, int piece_len, int64_t n_reads, const uint8_t* read_blob, const uint64_t* read_off,
+                   const uint32_t* read_len, int mism, int gapo, int gape, double threshold, int32_t* start, int32_t* end,
+                   int32_t* used_wfa, int64_t* cells) {
+  const orc_wfa_params fp = flank_params(mism, gapo, gape);
+  int64_t c = 0;
+  for (int64_t i = 0; i < n_reads; ++i) {
+    bool used = false;
+    SpanOpt s = find_span(piece, piece_len, read_blob + read_off[i], (int)read_len[i], fp, threshold, &used, &c);
+    start[i] = s.start; end[i] = s.end;
+    if (used_wfa) used_wfa[i] = used;
+  }
+  if (cells) *cells = c;
+  return 0;
+}
+
+int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
+                      const uint8_t* ref_tr, int ref_tr_len,
+                      const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs, int64_t n_reads,
+                      const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len, int32_t* span_start,
+                      int32_t* span_end, int32_t* n_alleles, char* allele0, char* allele1, int allele_cap, int32_t* gt_size,
+                      int32_t* gt_ci, int32_t* n_spanning, int32_t* kept_read, int32_t* classification, int32_t* num_spanning_by_hap,
+                      char* mc, char* ms, char* ap, int str_cap, int64_t* stats) {
+  const int F = p->flank_len;
+  int64_t wfa_cells = 0, vit_cells = 0, n_flank_wfa = 0, n_cons = 0, bytes_io = 0;
+  *n_alleles = 0; *n_spanning = 0;
+  if (allele0) allele0[0] = 0;
+  if (allele1) allele1[0] = 0;
+  if (mc) mc[0] = 0;
+  if (ms) ms[0] = 0;
+  if (ap) ap[0] = 0;
+  // find_tr_spans
+  const uint8_t* lf_piece = left_flank + (lf_len - F);
+  const uint8_t* rf_piece = right_flank;
+  const double threshold = (double)(size_t)F * p->min_flank_id_frac;
+  const orc_wfa_params fp = flank_params(p->mism, p->gapo, p->gape);
+  struct RS { int64_t read; int s, e; };
+  std::vector<RS> rs;
+  for (int64_t i = 0; i < n_reads; ++i) {
+    const uint8_t* s = read_blob + read_off[i];
+    const int slen = (int)read_len[i];
+    bytes_io += slen;
+    bool u1 = false, u2 = false;
+    SpanOpt l = find_span(lf_piece, F, s, slen, fp, threshold, &u1, &wfa_cells);
+    SpanOpt r = find_span(rf_piece, F, s, slen, fp, threshold, &u2, &wfa_cells);
+    n_flank_wfa += (int)u1 + (int)u2;
+    span_start[i] = span_end[i] = -1;
+    if (l.some() && r.some() && l.end <= r.start) { span_start[i] = l.end; span_end[i] = r.start; }
+    if (span_start[i] >= 0) rs.push_back({i, span_start[i], span_end[i]});
+  }
+  auto finish = [&]() {
+    if (stats) { stats[0] = wfa_cells; stats[1] = vit_cells; stats[2] = n_flank_wfa; stats[3] = n_cons; stats[4] = bytes_io; }
+    return 0;
+  };
+  if (rs.empty()) return finish();
+  // get_spanning_reads: flank check, stable sort by span length, uniform downsample
+  std::vector<RS> kept;
+  for (auto& x : rs)
+    if (x.s >= F && (int)read_len[x.read] - x.e >= F) kept.push_back(x);
+  if (kept.empty()) return finish();
+  std::stable_sort(kept.begin(), kept.end(), [](const RS& a, const RS& b) { return (a.e - a.s) < (b.e - b.s); });
+  if ((int)kept.size() > p->max_depth) {  // uniform_downsample (tr.rs:172-184)
+    const double num = (double)kept.size();
+    double fast = 0.0;
+    const double step = num / (double)p->max_depth;
+    for (int i = 0; i < p->max_depth; ++i) {
+      const size_t ind = (size_t)std::floor(fast);
+      if (ind != (size_t)i) std::swap(kept[i], kept[ind]);
+      fast += step;
+    }
+    kept.resize((size_t)p->max_depth);
+  }
+  std::vector<std::string> trs;
+  for (auto& x : kept) trs.emplace_back((const char*)read_blob + read_off[x.read] + x.s, (size_t)(x.e - x.s));
+  SizeGt g = genotype_size(p->ploidy, trs, &wfa_cells, &n_cons);
+  // label_with_hmm
+  auto motifs = motifs_from_blob(motif_blob, motif_off, n_motifs);
+  for (auto& m : motifs) { m = replace_invalid_bases(m, "ATCGN"); bytes_io += (int64_t)m.size(); }
+  Hmm hmm = build_hmm(motifs);
+  std::vector<Annotation> ann;
+  for (auto& a : g.alleles) { ann.push_back(annotate_allele(hmm, motifs, a, nullptr, &vit_cells)); bytes_io += (int64_t)a.size(); }
+  int by_hap[2] = {0, 0};
+  for (int c : g.classification) by_hap[c] += 1;
+  std::vector<int> order;
+  for (size_t i = 0; i < g.gt.size(); ++i) order.push_back((int)i);
+  const std::string tr((const char*)ref_tr, (size_t)ref_tr_len);
+  if (g.gt.size() != 1 && g.alleles[0] != tr && g.alleles[1] == tr) {  // put reference allele first (tr.rs:95-101)
+    std::swap(order[0], order[1]);
+    for (int& c : g.classification) c = 1 - c;
+  }
+  *n_alleles = (int)g.gt.size();
+  *n_spanning = (int)kept.size();
+  for (size_t i = 0; i < kept.size(); ++i) { kept_read[i] = (int32_t)kept[i].read; classification[i] = g.classification[i]; }
+  std::string smc, sms, sap;
+  for (size_t oi = 0; oi < order.size(); ++oi) {
+    const int a = order[oi];
+    char* dst = oi == 0 ? allele0 : allele1;
+    if ((int)g.alleles[a].size() + 1 > allele_cap) return -1;
+    std::memcpy(dst, g.alleles[a].c_str(), g.alleles[a].size() + 1);
+    gt_size[oi] = g.gt[a].size; gt_ci[2 * oi] = g.gt[a].ci_lo; gt_ci[2 * oi + 1] = g.gt[a].ci_hi;
+    num_spanning_by_hap[oi] = by_hap[a];
+    if (oi) { smc += ","; sms += ","; sap += ","; }
+    for (size_t m = 0; m < ann[a].motif_counts.size(); ++m) { if (m) smc += "_"; smc += std::to_string(ann[a].motif_counts[m]); }
+    if (ann[a].labels.empty()) sms += ".";
+    else for (size_t l = 0; l < ann[a].labels.size(); ++l) {
+      if (l) sms += "_";
+      auto& sp = ann[a].labels[l];
+      sms += std::to_string(sp.motif_index) + "(" + std::to_string(sp.start) + "-" + std::to_string(sp.end) + ")";
+    }
+    if (std::isnan(ann[a].purity)) sap += ".";
+    else { char b[64]; std::snprintf(b, sizeof b, "%.6f", ann[a].purity); sap += b; }
+  }
+  if ((int)smc.size() + 1 > str_cap || (int)sms.size() + 1 > str_cap || (int)sap.size() + 1 > str_cap) return -1;
+  std::memcpy(mc, smc.c_str(), smc.size() + 1);
+  std::memcpy(ms, sms.c_str(), sms.size() + 1);
+  std::memcpy(ap, sap.c_str(), sap.size() + 1);
+  return finish();
+}
+
+}  // extern "C"
