@@ -1,0 +1,231 @@
+/*
+ * include/trgt_hip.h -- C ABI of libtrgt_hip.so: the MI355X (gfx950) batch
+ * implementation of TRGT's per-locus alignment/DP hot path.
+ *
+ * What each entry point replaces in PacificBiosciences/trgt v3.0.0
+ * (paths relative to the reference root):
+ *
+ *   trgt_wfa_batch        the WFA2-lib C calls bound by wfa2-sys and wrapped by
+ *                         src/wfaligner.rs: wavefront_aligner_new (:371),
+ *                         wavefront_aligner_set_alignment_end_to_end (:467),
+ *                         wavefront_aligner_set_alignment_free_ends (:479-485),
+ *                         wavefront_align (:492-498, :519-525),
+ *                         cigar_get_CIGAR (:944-949), cigar_count_matches (:999)
+ *                         and the direct struct reads cigar->{operations,
+ *                         begin_offset,end_offset,score} (:531,:600-611,:875-881)
+ *                         -- one call per *batch* instead of one per alignment.
+ *   trgt_find_spans_batch find_spans / find_tr_spans, src/trgt/genotype/
+ *                         span_locater.rs:7-68 (exact 250-mer search + WFA
+ *                         ends-free fallback through THREAD_WFA_FLANK,
+ *                         src/commands/genotype.rs:66-80).
+ *   trgt_hmm_batch        build_hmm + Hmm::label + calc_purity +
+ *                         remove_imperfect_motifs + label_motifs + count_motifs
+ *                         + collapse_labels as composed by label_with_hmm,
+ *                         src/trgt/workflows/tr.rs:454-492 (src/hmm/, all files).
+ *   trgt_locus_batch      analyze_tr for pre-clipped reads,
+ *                         src/trgt/workflows/tr.rs:24-109 (size genotyper).
+ *
+ * Conventions
+ *   - Plain C, caller-owned buffers, no exceptions cross the boundary.  Every
+ *     function returns TRGT_OK (0) or a negative TRGT_ERR_*; the message is
+ *     available from trgt_hip_last_error().
+ *   - "blob" pointers (sequence bytes) and all OUTPUT pointers may be HOST or
+ *     DEVICE (HBM) pointers; the library detects which (hipPointerGetAttributes)
+ *     and uses device memory in place.  Offset / length / index arrays that
+ *     describe the batch are HOST pointers (the planner reads them).
+ *   - A ctx is bound to one GPU and one HIP stream and is single-threaded
+ *     (mirrors the thread_local aligners of src/commands/genotype.rs:94-103).
+ *     Calls are synchronous from the caller's point of view.
+ *   - There is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point fails with TRGT_ERR_NO_DEVICE.
+ */
+#ifndef TRGT_HIP_H
+#define TRGT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRGT_HIP_ABI_VERSION 1
+
+#define TRGT_OK 0
+#define TRGT_ERR_INVALID (-1)     /* bad argument */
+#define TRGT_ERR_HIP (-2)         /* HIP runtime error */
+#define TRGT_ERR_UNSUPPORTED (-3) /* valid request outside the kernels' limits */
+#define TRGT_ERR_NO_DEVICE (-4)   /* no GPU / extension built without device code */
+#define TRGT_ERR_NOMEM (-5)
+
+/* per-job alignment status == WF_STATUS_* of WFA2-lib (wfaligner.rs:126-159) */
+#define TRGT_WF_COMPLETED 0
+#define TRGT_WF_PARTIAL 1
+#define TRGT_WF_MAX_STEPS (-100)
+#define TRGT_WF_OOM (-200)
+#define TRGT_WF_UNATTAINABLE (-300)
+
+typedef struct trgt_hip_ctx trgt_hip_ctx;
+
+int trgt_hip_abi_version(void);
+/* device: HIP ordinal (>= 0).  There is no CPU device. */
+int trgt_hip_create(int device, trgt_hip_ctx** out);
+void trgt_hip_destroy(trgt_hip_ctx* ctx);
+const char* trgt_hip_last_error(const trgt_hip_ctx* ctx); /* ctx may be NULL: last create() error */
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream. */
+int trgt_hip_set_stream(trgt_hip_ctx* ctx, void* hip_stream);
+/* Upper bound (bytes) for the per-call device workspace (wavefront history, back-pointers). 0 = default (32 GiB). */
+int trgt_hip_set_workspace_limit(trgt_hip_ctx* ctx, uint64_t bytes);
+
+/* ---- kernel timing (HIP events on the ctx stream, for bench.py's roofline) ---- */
+#define TRGT_K_FLANK_SCAN 0   /* exact flank search            */
+#define TRGT_K_WFA 1          /* wavefront alignment kernel     */
+#define TRGT_K_HMM 2          /* Viterbi + traceback + decode   */
+#define TRGT_K_COUNT 3
+int trgt_hip_timing_enable(trgt_hip_ctx* ctx, int on);
+int trgt_hip_timing_reset(trgt_hip_ctx* ctx);
+/* accumulated device time (ms), number of launches, and DP work items (wavefront offsets / Viterbi cells) */
+int trgt_hip_timing_get(trgt_hip_ctx* ctx, int kernel, double* ms, int64_t* launches, int64_t* cells);
+
+/* ------------------------------------------------------------------ WFA */
+/* Mirrors the attribute set the wrapper configures (wfaligner.rs:161-380). */
+typedef struct trgt_wfa_params {
+  int32_t metric;      /* 0 indel, 1 edit, 2 gap-linear, 3 gap-affine, 4 gap-affine-2p (DistanceMetric, :79-85) */
+  int32_t mismatch;    /* x */
+  int32_t gap_open1;   /* o1 */
+  int32_t gap_ext1;    /* e1 (gap-linear: the indel penalty) */
+  int32_t gap_open2;
+  int32_t gap_ext2;
+  int32_t span;        /* 0 end-to-end (:489-501), 1 ends-free (:503-528) */
+  int32_t pattern_begin_free, pattern_end_free, text_begin_free, text_end_free; /* -1 = that sequence's length */
+  int32_t scope;       /* AlignmentScope: 0 Score, 1 Alignment (:52-56) */
+  int32_t memory_mode; /* MemoryModel: 0 High, 1 Med, 2 Low, 3 UltraLow = BiWFA (:4-10) */
+  int32_t heuristic;   /* 0 Heuristic::None, 1 Heuristic::WFadaptive (:68-77); others -> TRGT_ERR_UNSUPPORTED */
+  int32_t h_min_wavefront_length, h_max_distance_threshold, h_steps_between_cutoffs;
+  int32_t bialign_min_score;  /* WF_BIALIGN_FALLBACK_MIN_SCORE, 250 */
+  int32_t bialign_min_length; /* WF_BIALIGN_FALLBACK_MIN_LENGTH, 100 (0 disables) */
+} trgt_wfa_params;
+
+/* wavefront_aligner_attr_default: affine(4,6,2), alignment scope, end-to-end, wfadaptive(10,50,1), memory high */
+void trgt_wfa_default_params(trgt_wfa_params* p);
+
+/* n_jobs alignments of pattern j = seqs[pat_off[j] .. +pat_len[j]) vs text j.
+ * Outputs (each may be NULL):
+ *   status[j]    WF status;  score[j] cigar.score (INT32_MIN when failed / never set)
+ *   n_match[j]   cigar_count_matches;  span4[4j..] = pattern_start,pattern_end,text_start,text_end
+ *   cigar        run-length CIGAR as cigar_get_CIGAR(show_mismatches=true): len<<4 | {7 '=',8 'X',1 'I',2 'D'},
+ *                job j at cigar[cigar_off[j] ..], capacity pat_len+txt_len+1 entries; cigar_len[j] entries used
+ *   ops          expanded M/X/I/D bytes at ops[ops_off[j] ..], capacity pat_len+txt_len; ops_len[j]
+ */
+int trgt_wfa_batch(trgt_hip_ctx* ctx, const trgt_wfa_params* p, int64_t n_jobs,
+                   const uint8_t* seqs, const uint64_t* pat_off, const uint32_t* pat_len,
+                   const uint64_t* txt_off, const uint32_t* txt_len,
+                   int32_t* status, int32_t* score, int32_t* n_match, uint32_t* span4,
+                   uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len,
+                   uint8_t* ops, const uint64_t* ops_off, uint32_t* ops_len);
+
+/* --------------------------------------------------------- flank location */
+typedef struct trgt_span_params {
+  int32_t flank_len;         /* Params::search_flank_len (tr.rs:20), 250 */
+  double min_flank_id_frac;  /* Params::min_flank_id_frac, 0.7 */
+  int32_t mism, gapo, gape;  /* --aln-scoring 2,5,1 (genotype.rs:75-77) */
+} trgt_span_params;
+
+/* find_tr_spans for n_loci loci.  Locus l owns reads [locus_read_begin[l], locus_read_begin[l+1]).
+ * flank_blob holds, per locus, the left flank then the right flank (any length >= flank_len):
+ * left flank of locus l = flank_blob[lf_off[l] .. +lf_len[l]), right = flank_blob[rf_off[l] .. +rf_len[l]).
+ * span_start/span_end: per read, -1/-1 = None.  lf_hit/rf_hit (optional, per read): 0 none, 1 exact, 2 WFA. */
+int trgt_find_spans_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t n_loci,
+                          const uint8_t* flank_blob, const uint64_t* lf_off, const uint32_t* lf_len,
+                          const uint64_t* rf_off, const uint32_t* rf_len,
+                          const uint64_t* locus_read_begin,
+                          const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len,
+                          int32_t* span_start, int32_t* span_end, uint8_t* lf_hit, uint8_t* rf_hit);
+
+/* ------------------------------------------------------------------ HMM */
+/* n_sets motif sets (one per locus): set s owns motifs [set_motif_begin[s], set_motif_begin[s+1]);
+ * motif m = motif_blob[motif_off[m] .. motif_off[m+1]).  Motif bytes outside ATCGN are replaced as
+ * replace_invalid_bases(m, ATCGN) does (tr.rs:455-460).
+ * Job j labels seq j with the HMM of set job_set[j]; sequence bytes outside ATCG are replaced as
+ * replace_invalid_bases(seq, ATCG) does (tr.rs:465).
+ * Outputs (path may be NULL):
+ *   path        Hmm::label state path (u16), job j at path[path_off[j] ..], path_len[j] entries;
+ *               capacity per job >= trgt_hmm_path_capacity(seq_len, longest motif of the set)
+ *   spans3      collapsed MS spans (motif_index,start,end) at spans3[3*span_off[j] ..], capacity seq_len[j]+1;
+ *               n_spans[j] == 0 means labels = None
+ *   motif_counts  MC per motif at motif_counts[count_off[j] .. + #motifs of the set]
+ *   purity      AP (NaN for an empty allele); edit_dist / max_dist: the integers calc_purity divides
+ */
+int trgt_hmm_batch(trgt_hip_ctx* ctx, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                   const uint32_t* set_motif_begin,
+                   int64_t n_jobs, const uint32_t* job_set,
+                   const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len,
+                   uint16_t* path, const uint64_t* path_off, uint32_t* path_len,
+                   int32_t* spans3, const uint64_t* span_off, uint32_t* n_spans,
+                   uint32_t* motif_counts, const uint64_t* count_off,
+                   double* purity, int32_t* edit_dist, int32_t* max_dist);
+uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_len);
+
+/* ----------------------------------------------------------------- locus */
+typedef struct trgt_locus_params {
+  int32_t flank_len;         /* 250 */
+  double min_flank_id_frac;  /* 0.7 */
+  int32_t max_depth;         /* 250 */
+  int32_t mism, gapo, gape;  /* 2,5,1 */
+  int32_t host_threads;      /* threads for the host glue between GPU stages (0 = hardware concurrency) */
+} trgt_locus_params;
+
+typedef struct trgt_locus_batch_in {   /* Locus (locus.rs:13-23) x n_loci, reads already clipped (tr.rs:33-34) */
+  int64_t n_loci;
+  const uint8_t* flank_blob;           /* host or device */
+  const uint64_t* lf_off; const uint32_t* lf_len;   /* left_flank  */
+  const uint64_t* rf_off; const uint32_t* rf_len;   /* right_flank */
+  const uint8_t* tr_blob; const uint64_t* tr_off; const uint32_t* tr_len;  /* locus.tr (reference allele), host */
+  const uint8_t* motif_blob; const uint32_t* motif_off; const uint32_t* set_motif_begin; /* motifs, host */
+  const uint8_t* ploidy;               /* per locus 1 or 2 (0 = skip, tr.rs:29-31) */
+  const uint64_t* locus_read_begin;    /* CSR over reads */
+  const uint8_t* read_blob;            /* host or device */
+  const uint64_t* read_off; const uint32_t* read_len;
+} trgt_locus_batch_in;
+
+typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x n_loci; all HOST, caller-allocated */
+  int32_t* span_start; int32_t* span_end;   /* per input read (find_tr_spans), -1 = None */
+  int32_t* n_alleles;                       /* per locus: 0 (LocusResult::empty), 1 or 2 */
+  uint8_t* allele_blob; const uint64_t* allele_off; /* per locus 2 slots, each of capacity allele_cap[l] */
+  const uint32_t* allele_cap; uint32_t* allele_len; /* allele_len[2l+a] */
+  int32_t* ci;                              /* [4 per locus]: lo,hi of allele 0; lo,hi of allele 1 */
+  int32_t* num_spanning;                    /* [2 per locus] */
+  int32_t* classification;                  /* per input read: allele index of each kept spanning read, -1 otherwise */
+  int32_t* read_rank;                       /* per input read: position in LocusResult.reads order, -1 otherwise */
+  /* annotations (Annotation, spans.rs:20-25) */
+  int32_t* spans3; const uint64_t* span_off; uint32_t* n_spans;   /* span_off[2l+a], capacity allele_cap[l]+1 */
+  uint32_t* motif_counts; const uint64_t* count_off;              /* count_off[2l+a] */
+  double* purity;                           /* [2 per locus] */
+  int64_t* stats;                           /* optional [16]: see DESIGN.md */
+} trgt_locus_batch_out;
+
+int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,
+                     trgt_locus_batch_out* out);
+
+/* ------------------------------------------------- synthetic workload */
+typedef struct trgt_synth_params {
+  uint64_t seed;           /* 20250509 */
+  int32_t config;          /* 2 = cfg2/cfg4 single-motif STR loci, 3 = cfg3 long pathogenic-like alleles */
+  int32_t reads_per_locus; /* 30 */
+  int32_t context_len;     /* 500 */
+  int32_t flank_len;       /* 250 */
+  int32_t max_allele_bp;   /* 200 (cfg2) / 10000 (cfg3) */
+  double sub_rate, del_rate, ins_rate, stutter_rate, truncate_rate; /* 5e-4, 2.5e-4, 2.5e-4, 0.05, 0.10 */
+} trgt_synth_params;
+void trgt_synth_default_params(trgt_synth_params* p, int config);
+/* Two-phase: sizes first (all outputs NULL except the size fields), then fill.  Locus indices are global
+ * (first_locus .. first_locus+n_loci) so any shard regenerates exactly its own loci. */
+typedef struct trgt_synth_sizes { uint64_t flank_bytes, tr_bytes, motif_bytes, n_motifs, n_reads, read_bytes; } trgt_synth_sizes;
+int trgt_synth_sizes_for(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci, trgt_synth_sizes* sz);
+int trgt_synth_fill(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci,
+                    uint8_t* flank_blob, uint64_t* lf_off, uint32_t* lf_len, uint64_t* rf_off, uint32_t* rf_len,
+                    uint8_t* tr_blob, uint64_t* tr_off, uint32_t* tr_len,
+                    uint8_t* motif_blob, uint32_t* motif_off, uint32_t* set_motif_begin, uint8_t* ploidy,
+                    uint64_t* locus_read_begin, uint8_t* read_blob, uint64_t* read_off, uint32_t* read_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""Parity of the HIP motif-HMM path (trgt_hmm_batch through the C ABI) against the CPU oracle and the
+reference's own known-answer tests.  Bit-exact: state paths, spans, counts, and the f64 purity bits."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rand_dna, rand_motif, repeat_allele
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hmm_kats.json")))["kats"]
+
+
+@pytest.fixture(scope="module")
+def hmm():
+    from trgt_amd import hmm as H
+    return H
+
+
+def _same(oracle, H, motif_sets, jobs, want_path=True):
+    batch = H.pack_hmm_batch(motif_sets, jobs)
+    got = H.hmm_batch(batch, want_path=want_path)
+    ref = oracle.hmm_batch(batch, n_threads=4, want_path=want_path)
+    assert np.array_equal(got["n_spans"], ref["n_spans"])
+    assert np.array_equal(got["path_len"], ref["path_len"])
+    assert np.array_equal(got["edit"], ref["edit"]) and np.array_equal(got["maxd"], ref["maxd"])
+    assert np.array_equal(got["purity"].view(np.uint64), ref["purity"].view(np.uint64))  # bit-exact incl. NaN payload sign
+    assert np.array_equal(got["counts"], ref["counts"])
+    for j in range(len(jobs)):
+        so, ns = int(batch["span_off"][j]), int(ref["n_spans"][j])
+        assert np.array_equal(got["spans"][3 * so:3 * (so + ns)], ref["spans"][3 * so:3 * (so + ns)]), j
+        if want_path:
+            po, pl = int(batch["path_off"][j]), int(ref["path_len"][j])
+            assert np.array_equal(got["path"][po:po + pl], ref["path"][po:po + pl]), j
+    return got
+
+
+def test_reference_kats_through_abi(oracle, hmm):
+    for kat in KATS:
+        if "summary" in kat and not kat["remove_imperfect"]:
+            path = hmm.build_hmm(kat["motifs"]).label(kat["query"])
+            sp = oracle.hmm_label_motifs(kat["motifs"], path)
+            out = []
+            for m, s, e in sp.tolist():
+                if out and out[-1][2] == m:
+                    out[-1][1] = e
+                else:
+                    out.append([s, e, m])
+            assert out == kat["summary"], kat["id"]
+        elif "purity" in kat:
+            a = hmm.label_with_hmm(kat["motifs"], [kat["query"]])[0]
+            if kat["purity"] is None:
+                assert math.isnan(a.purity) and a.labels is None
+            else:
+                assert a.purity == kat["purity"][0] / kat["purity"][1], kat["id"]
+
+
+def test_kat_spans_after_remove_imperfect(hmm):
+    # builder.rs:218-240 / 252-273 via the fused label_with_hmm path: skip spans dropped, spans collapsed
+    for kat in KATS:
+        if kat.get("remove_imperfect"):
+            a = hmm.label_with_hmm(kat["motifs"], [kat["query"]])[0]
+            want = [[s, e, m] for s, e, m in kat["summary"] if m < len(kat["motifs"])]
+            got = [[s.start, s.end, s.motif_index] for s in (a.labels or [])]
+            merged = []
+            for s, e, m in want:  # collapse_labels merges abutting same-motif spans
+                if merged and merged[-1][2] == m and merged[-1][1] == s:
+                    merged[-1][1] = e
+                else:
+                    merged.append([s, e, m])
+            assert got == merged, kat["id"]
+
+
+def test_random_single_motif_str(oracle, hmm):
+    rng = np.random.default_rng(20250509)
+    sets, jobs = [], []
+    for s in range(300):
+        sets.append([rand_motif(rng, 3, 6, allow_n=False)])
+        for _ in range(2):
+            jobs.append((s, repeat_allele(rng, sets[-1], int(rng.integers(1, 201)), err=0.01)))
+    _same(oracle, hmm, sets, jobs)
+
+
+def test_random_multi_motif_and_n(oracle, hmm):
+    rng = np.random.default_rng(7)
+    sets, jobs = [], []
+    for s in range(120):
+        sets.append([rand_motif(rng, 1, 12) for _ in range(int(rng.integers(1, 6)))])
+        for _ in range(2):
+            jobs.append((s, repeat_allele(rng, sets[-1], int(rng.integers(0, 400)), err=0.03)))
+    _same(oracle, hmm, sets, jobs)
+
+
+def test_edge_cases(oracle, hmm):
+    sets = [[b"A"], [b"N"], [b"CAG", b"CCG"], [b"GCN"], [b"AC"], [b"ACGTACGTACGTACGTACGTAAAA"]]
+    jobs = [(0, b""), (0, b"A"), (0, b"AAAAAAAAAA"), (0, b"CCCC"), (1, b"ACGTACGT"), (2, b""), (2, b"C"),
+            (2, b"CAGCAGCAGTTTTTTTTCCGCCGCCG"), (3, b"GCAGCCGCTGAG"), (4, b"ACACACACAC"), (4, b"CACACA"), (4, b"T"),
+            (5, b"ACGTACGTACGTACGTACGTAAAA" * 3), (2, b"CAGNNNCAGRYCAG"), (0, b"NNNN")]
+    _same(oracle, hmm, sets, jobs)
+
+
+def test_many_motifs_multi_wave_workgroup(oracle, hmm):
+    # S = 170 (RFC1-like 10-motif set) -> 192-thread workgroups
+    rng = np.random.default_rng(3)
+    sets = [[b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"]]
+    assert hmm.num_states(sets[0]) > 128
+    jobs = [(0, repeat_allele(rng, sets[0], n, err=0.02)) for n in (5, 60, 333, 1000)]
+    _same(oracle, hmm, sets, jobs)
+
+
+def test_long_allele_10kb(oracle, hmm):
+    rng = np.random.default_rng(11)
+    sets = [[b"CAG"], [b"GGCCTG", b"CCG"]]
+    jobs = [(0, repeat_allele(rng, sets[0], 10000, err=0.005)), (1, repeat_allele(rng, sets[1], 6000, err=0.01))]
+    _same(oracle, hmm, sets, jobs)
+
+
+def test_device_resident_inputs(oracle, hmm):
+    import torch
+    rng = np.random.default_rng(5)
+    sets = [[b"CAG"]]
+    jobs = [(0, repeat_allele(rng, sets[0], 150)) for _ in range(64)]
+    batch = hmm.pack_hmm_batch(sets, jobs)
+    dev = torch.from_numpy(batch["seq_blob"]).cuda()
+    got = hmm.hmm_batch(batch, want_path=False, seq_blob_dev=dev)
+    ref = oracle.hmm_batch(batch, want_path=False)
+    assert np.array_equal(got["purity"].view(np.uint64), ref["purity"].view(np.uint64))
+    assert np.array_equal(got["counts"], ref["counts"])

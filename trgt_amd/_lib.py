@@ -1,0 +1,170 @@
+"""ctypes loader for trgt_amd/libtrgt_hip.so (the C ABI declared in include/trgt_hip.h).
+
+The library is built in-tree by `make -C trgt_amd/csrc` (hipcc, gfx950).  Loading fails loudly when
+it is missing; creating a context fails loudly when no gfx950 GPU is visible -- there is no fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtrgt_hip.so")
+_LIB = None
+_CTX = {}
+
+
+class TrgtHipError(RuntimeError):
+    pass
+
+
+class WfaParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "metric", "mismatch", "gap_open1", "gap_ext1", "gap_open2", "gap_ext2", "span", "pattern_begin_free",
+        "pattern_end_free", "text_begin_free", "text_end_free", "scope", "memory_mode", "heuristic",
+        "h_min_wavefront_length", "h_max_distance_threshold", "h_steps_between_cutoffs", "bialign_min_score",
+        "bialign_min_length")]
+
+
+class SpanParams(C.Structure):
+    _fields_ = [("flank_len", C.c_int32), ("min_flank_id_frac", C.c_double), ("mism", C.c_int32), ("gapo", C.c_int32),
+                ("gape", C.c_int32)]
+
+
+class LocusParams(C.Structure):
+    _fields_ = [("flank_len", C.c_int32), ("min_flank_id_frac", C.c_double), ("max_depth", C.c_int32),
+                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("host_threads", C.c_int32)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("config", C.c_int32), ("reads_per_locus", C.c_int32), ("context_len", C.c_int32),
+                ("flank_len", C.c_int32), ("max_allele_bp", C.c_int32), ("sub_rate", C.c_double), ("del_rate", C.c_double),
+                ("ins_rate", C.c_double), ("stutter_rate", C.c_double), ("truncate_rate", C.c_double)]
+
+
+class SynthSizes(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("flank_bytes", "tr_bytes", "motif_bytes", "n_motifs", "n_reads", "read_bytes")]
+
+
+_VP = C.c_void_p
+
+
+class LocusBatchIn(C.Structure):
+    _fields_ = [("n_loci", C.c_int64)] + [(n, _VP) for n in (
+        "flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off",
+        "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len")]
+
+
+class LocusBatchOut(C.Structure):
+    _fields_ = [(n, _VP) for n in (
+        "span_start", "span_end", "n_alleles", "allele_blob", "allele_off", "allele_cap", "allele_len", "ci",
+        "num_spanning", "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off",
+        "purity", "stats")]
+
+
+EXPORTS = [
+    "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
+    "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
+    "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity",
+    "trgt_locus_batch", "trgt_synth_default_params", "trgt_synth_sizes_for", "trgt_synth_fill",
+]
+
+
+def build_extension(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 into trgt_amd/libtrgt_hip.so (hipcc cross-compiles on CPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["-B"] if force else [])
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise TrgtHipError("building libtrgt_hip.so failed")
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise TrgtHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the TRGT hot path)" % _SO)
+        L = C.CDLL(_SO)
+        L.trgt_hip_last_error.restype = C.c_char_p
+        L.trgt_hip_last_error.argtypes = [_VP]
+        L.trgt_hip_create.argtypes = [C.c_int, C.POINTER(_VP)]
+        L.trgt_hip_destroy.argtypes = [_VP]
+        L.trgt_hip_destroy.restype = None
+        L.trgt_hip_set_stream.argtypes = [_VP, _VP]
+        L.trgt_hip_set_workspace_limit.argtypes = [_VP, C.c_uint64]
+        L.trgt_hip_timing_enable.argtypes = [_VP, C.c_int]
+        L.trgt_hip_timing_reset.argtypes = [_VP]
+        L.trgt_hip_timing_get.argtypes = [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.trgt_hmm_path_capacity.restype = C.c_uint64
+        L.trgt_hmm_path_capacity.argtypes = [C.c_uint32, C.c_uint32]
+        L.trgt_hmm_batch.argtypes = [_VP, C.c_int32, _VP, _VP, _VP, C.c_int64] + [_VP] * 15
+        L.trgt_wfa_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 15
+        L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
+        L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
+        L.trgt_synth_sizes_for.argtypes = [_VP, C.c_int64, C.c_int64, _VP]
+        L.trgt_synth_fill.argtypes = [_VP, C.c_int64, C.c_int64] + [_VP] * 17
+        L.trgt_synth_default_params.argtypes = [_VP, C.c_int]
+        L.trgt_synth_default_params.restype = None
+        L.trgt_wfa_default_params.argtypes = [_VP]
+        L.trgt_wfa_default_params.restype = None
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """One GPU + one HIP stream (mirrors the thread_local aligners of src/commands/genotype.rs:94-103)."""
+
+    def __init__(self, device=0):
+        h = _VP()
+        rc = lib().trgt_hip_create(int(device), C.byref(h))
+        if rc != 0:
+            raise TrgtHipError("trgt_hip_create(device=%d) failed (%d): %s" % (device, rc, lib().trgt_hip_last_error(None).decode()))
+        self.handle = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise TrgtHipError("libtrgt_hip error %d: %s" % (rc, lib().trgt_hip_last_error(self.handle).decode()))
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().trgt_hip_set_stream(self.handle, _VP(stream_ptr)))
+
+    def timing_enable(self, on=True):
+        self.check(lib().trgt_hip_timing_enable(self.handle, int(on)))
+
+    def timing_reset(self):
+        self.check(lib().trgt_hip_timing_reset(self.handle))
+
+    def timing_get(self, kernel):
+        ms, n, cells = C.c_double(), C.c_int64(), C.c_int64()
+        self.check(lib().trgt_hip_timing_get(self.handle, kernel, C.byref(ms), C.byref(n), C.byref(cells)))
+        return ms.value, n.value, cells.value
+
+    def close(self):
+        if self.handle:
+            lib().trgt_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def context(device=0):
+    """Process-wide context per device."""
+    if device not in _CTX:
+        _CTX[device] = Context(device)
+    return _CTX[device]
+
+
+def ptr(a):
+    """void* of a numpy array (host) or a torch tensor (host or HBM); None -> NULL."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return _VP(a.data_ptr())
+    return a.ctypes.data_as(_VP)

@@ -1,0 +1,152 @@
+// trgt_amd/csrc/common.hpp -- shared host-side plumbing of libtrgt_hip.so:
+// the opaque ctx, error propagation across the C ABI, host/device pointer
+// classification, a small device-buffer pool and per-kernel HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/trgt_hip.h"
+
+struct trgt_hip_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  uint64_t ws_limit = 32ull << 30;
+  int num_cus = 256;
+  // cached device buffers, indexed by slot
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  std::vector<Buf> pool;
+  // timing
+  bool timing = false;
+  double k_ms[TRGT_K_COUNT] = {0, 0, 0};
+  int64_t k_launches[TRGT_K_COUNT] = {0, 0, 0};
+  int64_t k_cells[TRGT_K_COUNT] = {0, 0, 0};
+  struct Pending { int k; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+};
+
+namespace trgt {
+
+inline int fail(trgt_hip_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define TRGT_HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return trgt::fail((ctx), TRGT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                          \
+  } while (0)
+
+inline bool is_device_ptr(const void* p) {
+  if (p == nullptr) return false;
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// pool slot ids (each call site owns a range so buffers are reused call to call)
+enum Slot {
+  S_HMM_SEQ = 0, S_HMM_DESC, S_HMM_MODEL, S_HMM_JOBS, S_HMM_BP, S_HMM_PATH, S_HMM_SPANS, S_HMM_NSP, S_HMM_CNT, S_HMM_PUR,
+  S_HMM_EDIT, S_HMM_MAXD, S_HMM_PLEN, S_HMM_VISITS, S_HMM_MOTIFS,
+  S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
+  S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS,
+  S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
+  S_FS_WFAJOBS, S_FS_SPAN, S_FS_NMATCH,
+  S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3,
+  S_COUNT
+};
+
+inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
+  if ((int)c->pool.size() < S_COUNT) c->pool.resize(S_COUNT);
+  auto& b = c->pool[slot];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    if (b.p) { TRGT_HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      return fail(c, TRGT_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+  }
+  *out = b.p;
+  return TRGT_OK;
+}
+
+// Input that may live on the host or on the device.  dev() returns a device pointer valid until the next
+// use of the same slot (uploading on the ctx stream when the caller's pointer is a host pointer).
+template <typename T>
+inline int dev_in(trgt_hip_ctx* c, int slot, const T* p, size_t count, const T** out) {
+  if (is_device_ptr(p)) { *out = p; return TRGT_OK; }
+  void* d = nullptr;
+  int rc = dev_get(c, slot, count * sizeof(T), &d);
+  if (rc) return rc;
+  if (count) TRGT_HIP_TRY(c, hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  *out = (const T*)d;
+  return TRGT_OK;
+}
+
+// Output that may live on the host or on the device.
+template <typename T>
+struct DevOut {
+  T* user = nullptr; T* dev = nullptr; size_t count = 0; bool staged = false;
+  int init(trgt_hip_ctx* c, int slot, T* p, size_t n) {
+    user = p; count = n; staged = false; dev = nullptr;
+    if (p == nullptr) return TRGT_OK;
+    if (is_device_ptr(p)) { dev = p; return TRGT_OK; }
+    void* d = nullptr;
+    int rc = dev_get(c, slot, n * sizeof(T), &d);
+    if (rc) return rc;
+    dev = (T*)d; staged = true;
+    return TRGT_OK;
+  }
+  int finish(trgt_hip_ctx* c) {
+    if (staged && count) TRGT_HIP_TRY(c, hipMemcpyAsync(user, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return TRGT_OK;
+  }
+};
+
+// ---- kernel timing: events on the ctx stream, resolved lazily ---------------------------------
+struct KTimer {
+  trgt_hip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr; bool on;
+  KTimer(trgt_hip_ctx* c_, int k_) : c(c_), k(k_), on(c_->timing) {
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+  }
+  void stop(int64_t cells) {
+    if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({k, a, b}); c->k_launches[k] += 1; c->k_cells[k] += cells; }
+  }
+};
+inline void resolve_timing(trgt_hip_ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0;
+    (void)hipEventSynchronize(p.b);
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->k_ms[p.k] += ms;
+    (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+  }
+  c->pending.clear();
+}
+
+}  // namespace trgt
+
+// entry points implemented in other translation units
+namespace trgt {
+struct HmmHostModel;
+}

@@ -1,0 +1,528 @@
+// trgt_amd/csrc/hmm.hip -- motif-segmentation HMM on gfx950: log-space Viterbi
+// fill, traceback and MS/MC/AP decoding, one allele per workgroup.
+//
+// Replaces (PacificBiosciences/trgt v3.0.0): build_hmm (src/hmm/builder.rs:4-173),
+// Hmm::label (hmm_model.rs:54-156), calc_purity/get_events (purity.rs:6-41,
+// events.rs:17-117), remove_imperfect_motifs (operations.rs:6-80), label_motifs
+// (hmm_model.rs:158-200), count_motifs/collapse_labels (utils.rs:3-27) as composed
+// by label_with_hmm (src/trgt/workflows/tr.rs:454-492).
+//
+// Kernel shape (see DESIGN.md "K4/K5"): one workgroup per allele, one thread per
+// HMM state (workgroup = 64*ceil(S/64) threads; S = 17..26 for one STR motif is a
+// single wavefront).  The two live score columns sit in LDS as f64; per base the
+// emitting states update in parallel, then the silent states are evaluated level
+// by level of their (acyclic) dependency order, so every f64 sum is formed exactly
+// as the reference forms it: (prev + ln p) + emission, first strict maximum wins.
+// No log() is evaluated on the device: the ln tables come from the host libm.
+// Back-pointers are one byte per (base, state), written once to HBM (coalesced
+// across the states of a column) and re-read in LDS-staged chunks by the traceback,
+// which also classifies events (purity) and collects motif visits on the fly.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "common.hpp"
+
+namespace trgt {
+
+// ------------------------------------------------------------ host model
+struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
+  uint32_t S, n_blocks, n_levels, max_mlen;
+  uint64_t off_inlp;    // f64 [4][S]   ln transition probabilities, predecessor-list order of the reference
+  uint64_t off_em;      // f64 [5][S]   ln emissions over # A T C G
+  uint64_t off_inst;    // u16 [4][S]   predecessor states
+  uint64_t off_block;   // i16 [S]      motif block of the state (-1 outside)
+  uint64_t off_nin;     // u8  [S]      #predecessors (0xFF: run-end state, predecessors = block ends)
+  uint64_t off_level;   // u8  [S]      0 emitting, >=1 silent evaluation level
+  uint64_t off_flags;   // u8  [S]      bit0 any finite emission, bit1 emits a base
+  uint64_t off_blocks;  // u32 [4][n_blocks]  start,end,mlen,motif byte offset
+  uint64_t off_motifs;  // sanitised motif bytes
+};
+
+struct HmmJobDev {
+  uint32_t set, seq_len, job_index, path_cap;
+  uint64_t seq_off, bp_off, path_off, span_off, count_off, visit_off;
+};
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// build_hmm restated as flat tables (builder.rs:4-173); predecessor ORDER is part of the contract
+// because the first strict maximum wins in calc_viterbi_score (hmm_model.rs:79-88).
+static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_t>& blob, HmmSetDev& d) {
+  uint32_t S = 7, max_mlen = 0;
+  for (auto& m : motifs) { S += 3 * (uint32_t)m.size() + 1; max_mlen = std::max<uint32_t>(max_mlen, (uint32_t)m.size()); }
+  const uint32_t nb = (uint32_t)motifs.size() + 1;
+  const double NINF = -std::numeric_limits<double>::infinity();
+  std::vector<double> inlp(4 * (size_t)S, NINF), em(5 * (size_t)S, NINF);
+  std::vector<uint16_t> inst(4 * (size_t)S, 0);
+  std::vector<int16_t> block(S, -1);
+  std::vector<uint8_t> nin(S, 0), level(S, 0), flags(S, 0);
+  std::vector<uint32_t> blocks(4 * (size_t)nb, 0);
+  std::string mbytes;
+  auto set_ems = [&](uint32_t st, const double (&p)[5]) { for (int i = 0; i < 5; ++i) em[(size_t)i * S + st] = std::log(p[i]); };
+  auto set_trans = [&](uint32_t st, std::initializer_list<uint32_t> ins, std::initializer_list<double> ps) {
+    nin[st] = (uint8_t)ins.size();
+    int j = 0;
+    for (uint32_t s : ins) inst[(size_t)(j++) * S + st] = (uint16_t)s;
+    j = 0;
+    for (double p : ps) inlp[(size_t)(j++) * S + st] = std::log(p);
+  };
+  const double SILENT[5] = {0, 0, 0, 0, 0}, TERM[5] = {1, 0, 0, 0, 0}, UNI[5] = {0.00, 0.25, 0.25, 0.25, 0.25};
+  const uint32_t start = 0, end = S - 1, rs = 1, re = S - 2;
+  set_ems(start, TERM); set_ems(end, TERM);
+  set_trans(end, {re}, {0.10});
+  set_ems(rs, SILENT);
+  set_trans(rs, {start, re}, {1.00, 1.00});
+  const double rs_to_ms = 1.00, me_to_re = 0.50;
+  uint32_t ms = rs + 1;
+  for (size_t mi = 0; mi < motifs.size(); ++mi) {
+    const std::string& motif = motifs[mi];
+    const uint32_t n = (uint32_t)motif.size(), me = ms + 3 * n;
+    set_ems(ms, SILENT);
+    set_trans(ms, {rs, me}, {rs_to_ms, 1.0 - me_to_re});
+    // define_motif_block (builder.rs:80-173)
+    const uint32_t m0 = ms + 1, i0 = m0 + n, d0 = i0 + n;
+    const double match_prob = 0.90, ins_to_ins = 0.25, match_to_indel = (1.00 - match_prob) / 2.00, del_to_match = 0.50;
+    const double seed = 2.00 * (1.00 - match_prob) / (double)((size_t)n * (size_t)(n - 1));
+    for (uint32_t k = 0; k < n; ++k) {
+      double e[5] = {0.00, 0.03, 0.03, 0.03, 0.03};
+      switch (motif[k]) {
+        case 'A': e[1] = 0.90; break;
+        case 'T': e[2] = 0.90; break;
+        case 'C': e[3] = 0.90; break;
+        case 'G': e[4] = 0.90; break;
+        default: e[1] = e[2] = e[3] = e[4] = 0.25; break;  // 'N'
+      }
+      set_ems(m0 + k, e);
+      if (k == 0) set_trans(m0, {ms}, {match_prob});
+      else if (k == 1) set_trans(m0 + 1, {m0, ms, i0}, {match_prob, seed * (double)(n - k), 1.0 - ins_to_ins});
+      else set_trans(m0 + k, {m0 + k - 1, ms, i0 + k - 1, d0 + k - 2}, {match_prob, seed * (double)(n - k), 1.0 - ins_to_ins, del_to_match});
+    }
+    for (uint32_t k = 0; k < n; ++k) { set_ems(i0 + k, UNI); set_trans(i0 + k, {i0 + k, m0 + k}, {ins_to_ins, match_to_indel}); }
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+      set_ems(d0 + k, SILENT);
+      if (k == 0) set_trans(d0, {m0}, {match_to_indel});
+      else set_trans(d0 + k, {m0 + k, d0 + k - 1}, {match_to_indel, 1.0 - del_to_match});
+    }
+    set_ems(me, SILENT);
+    if (n > 1) set_trans(me, {m0 + n - 1, i0 + n - 1, d0 + n - 2}, {match_prob, 1.0 - ins_to_ins, 1.0});
+    else set_trans(me, {m0 + n - 1, i0 + n - 1}, {match_prob, 1.0 - ins_to_ins});
+    for (uint32_t s = ms; s <= me; ++s) block[s] = (int16_t)mi;
+    blocks[0 * nb + mi] = ms; blocks[1 * nb + mi] = me; blocks[2 * nb + mi] = n; blocks[3 * nb + mi] = (uint32_t)mbytes.size();
+    mbytes += motif;
+    ms = me + 1;
+  }
+  // skip block (builder.rs:41-53)
+  const uint32_t skip = ms + 1, me_skip = ms + 2;
+  set_ems(ms, SILENT);
+  set_trans(ms, {rs, me_skip}, {rs_to_ms, 1.0 - me_to_re});
+  set_ems(skip, UNI);
+  set_trans(skip, {ms, skip}, {1.0, 0.5});
+  set_ems(me_skip, SILENT);
+  set_trans(me_skip, {skip}, {1.0 - 0.5});
+  for (uint32_t s = ms; s <= me_skip; ++s) block[s] = (int16_t)(nb - 1);
+  blocks[0 * nb + nb - 1] = ms; blocks[1 * nb + nb - 1] = me_skip; blocks[2 * nb + nb - 1] = 0; blocks[3 * nb + nb - 1] = (uint32_t)mbytes.size();
+  // run end: predecessors are the block ends in block order, each ln(me_to_re) (builder.rs:55-57)
+  set_ems(re, SILENT);
+  nin[re] = 0xFF;
+  inlp[re] = std::log(me_to_re);
+  // flags + silent evaluation levels (any topological order gives identical values; hmm_model.rs:206-240)
+  for (uint32_t s = 0; s < S; ++s) {
+    bool any = false, base = false;
+    for (int i = 0; i < 5; ++i) if (std::isfinite(em[(size_t)i * S + s])) { any = true; if (i) base = true; }
+    flags[s] = (any ? 1 : 0) | (base ? 2 : 0);
+  }
+  uint32_t n_levels = 0;
+  {
+    std::vector<int> lev(S, -1);
+    for (uint32_t s = 0; s < S; ++s) if (flags[s] & 1) lev[s] = 0;
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (uint32_t s = 0; s < S; ++s) {
+        if (lev[s] >= 0) continue;
+        int mx = 0; bool ready = true;
+        auto see = [&](uint32_t p) { if (flags[p] & 1) return; if (lev[p] < 0) ready = false; else mx = std::max(mx, lev[p]); };
+        if (nin[s] == 0xFF) for (uint32_t b = 0; b < nb; ++b) see(blocks[1 * nb + b]);
+        else for (int j = 0; j < nin[s]; ++j) see(inst[(size_t)j * S + s]);
+        if (ready) { lev[s] = mx + 1; changed = true; }
+      }
+    }
+    for (uint32_t s = 0; s < S; ++s) { level[s] = (uint8_t)lev[s]; n_levels = std::max<uint32_t>(n_levels, (uint32_t)lev[s]); }
+  }
+  // serialise
+  const uint64_t base = align_up(blob.size(), 16);
+  uint64_t o = base;
+  d.S = S; d.n_blocks = nb; d.n_levels = n_levels; d.max_mlen = max_mlen;
+  d.off_inlp = o; o += 8ull * 4 * S;
+  d.off_em = o; o += 8ull * 5 * S;
+  d.off_inst = o; o += 2ull * 4 * S;
+  d.off_block = o; o += 2ull * S; o = align_up(o, 4);
+  d.off_blocks = o; o += 4ull * 4 * nb;
+  d.off_nin = o; o += S;
+  d.off_level = o; o += S;
+  d.off_flags = o; o += S;
+  d.off_motifs = o; o += mbytes.size();
+  blob.resize(align_up(o, 16), 0);
+  std::memcpy(&blob[d.off_inlp], inlp.data(), 8ull * 4 * S);
+  std::memcpy(&blob[d.off_em], em.data(), 8ull * 5 * S);
+  std::memcpy(&blob[d.off_inst], inst.data(), 2ull * 4 * S);
+  std::memcpy(&blob[d.off_block], block.data(), 2ull * S);
+  std::memcpy(&blob[d.off_blocks], blocks.data(), 4ull * 4 * nb);
+  std::memcpy(&blob[d.off_nin], nin.data(), S);
+  std::memcpy(&blob[d.off_level], level.data(), S);
+  std::memcpy(&blob[d.off_flags], flags.data(), S);
+  if (!mbytes.empty()) std::memcpy(&blob[d.off_motifs], mbytes.data(), mbytes.size());
+}
+
+// --------------------------------------------------------------- kernel
+constexpr int HMM_STAGE_BYTES = 8192;  // LDS staging window for back-pointer columns during traceback
+
+__device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
+  // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
+  if (i == 0 || i == L - 1) return 0;
+  const uint8_t b = seq[i - 1];
+  return b == 'A' ? 1 : b == 'T' ? 2 : b == 'C' ? 3 : b == 'G' ? 4 : ((i - 1) & 3) + 1;
+}
+
+__global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets,
+                                   const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
+                                   uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws,
+                                   uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
+                                   int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
+                                   uint32_t* __restrict__ counts, double* __restrict__ purity,
+                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const HmmJobDev job = jobs[blockIdx.x];
+  const HmmSetDev set = sets[job.set];
+  const int S = (int)set.S, nb = (int)set.n_blocks, n_motifs = nb - 1;
+  const int qlen = (int)job.seq_len, L = qlen + 2;
+  const int Spad = (S + 15) & ~15;
+  const double NINF = -__builtin_huge_val();
+
+  for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = 0;
+  if (qlen == 0) {  // Hmm::label returns an empty path; calc_purity returns NaN (hmm_model.rs:145-147, purity.rs:7-9)
+    if (tid == 0) {
+      if (path_len) path_len[job.job_index] = 0;
+      n_spans[job.job_index] = 0;
+      purity[job.job_index] = __builtin_nan("");
+      if (edit_out) edit_out[job.job_index] = 0;
+      if (maxd_out) maxd_out[job.job_index] = 0;
+    }
+    return;
+  }
+  // ---- LDS carve-up (all dynamic, 16-byte aligned pieces; no static LDS in front of it)
+  int* tb = reinterpret_cast<int*>(lds);  // traceback state shared between the walker and the stagers
+  int &tb_state = tb[0], &tb_idx = tb[1], &tb_done = tb[2], &tb_npath = tb[3], &tb_nvisit = tb[4], &tb_edit = tb[5],
+      &tb_ref = tb[6], &tb_next = tb[7], &tb_vb1 = tb[8];
+  double* sc0 = reinterpret_cast<double*>(lds + 64);
+  double* sc1 = sc0 + S;
+  uint16_t* l_inst = reinterpret_cast<uint16_t*>(sc1 + S);           // [4][S]
+  int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
+  uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
+  uint32_t* l_blocks = reinterpret_cast<uint32_t*>(lds + 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15));  // [4][nb]
+  uint8_t* l_stage = lds + 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15);
+
+  const double* g_inlp = reinterpret_cast<const double*>(model + set.off_inlp);
+  const double* g_em = reinterpret_cast<const double*>(model + set.off_em);
+  const uint16_t* g_inst = reinterpret_cast<const uint16_t*>(model + set.off_inst);
+  const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
+  const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
+  const uint8_t* g_motifs = model + set.off_motifs;
+  for (int i = tid; i < 4 * S; i += nthr) l_inst[i] = g_inst[i];
+  for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; }
+  for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
+
+  // ---- my state's tables in registers
+  const bool act = tid < S;
+  const int st = act ? tid : 0;
+  const int n_in = model[set.off_nin + st];
+  const int level = model[set.off_level + st];
+  const int n_levels = (int)set.n_levels;
+  double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
+  const double em0 = g_em[0 * S + st], em1 = g_em[1 * S + st], em2 = g_em[2 * S + st], em3 = g_em[3 * S + st], em4 = g_em[4 * S + st];
+  const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
+  const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
+  uint8_t* __restrict__ bp = bp_ws + job.bp_off;
+  __syncthreads();
+
+  // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
+  double* prev = sc0;
+  double* cur = sc1;
+  int sym_next = hmm_code(seq, 0, L);
+  for (int i = 0; i < L; ++i) {
+    const int sym = sym_next;
+    if (i + 1 < L) sym_next = hmm_code(seq, i + 1, L);
+    double best = NINF;
+    int bpi = 0xFF;
+    if (act && level == 0) {
+      const double em = sym == 0 ? em0 : sym == 1 ? em1 : sym == 2 ? em2 : sym == 3 ? em3 : em4;
+      if (i == 0) {
+        if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
+      } else {
+        if (n_in > 0) { const double v = (prev[p0] + lp0) + em; if (v > best) { best = v; bpi = 0; } }
+        if (n_in > 1) { const double v = (prev[p1] + lp1) + em; if (v > best) { best = v; bpi = 1; } }
+        if (n_in > 2) { const double v = (prev[p2] + lp2) + em; if (v > best) { best = v; bpi = 2; } }
+        if (n_in > 3) { const double v = (prev[p3] + lp3) + em; if (v > best) { best = v; bpi = 3; } }
+      }
+      cur[st] = best;
+    }
+    __syncthreads();
+    for (int lev = 1; lev <= n_levels; ++lev) {
+      if (act && level == lev) {
+        if (n_in == 0xFF) {  // run-end state: predecessors are the block end states, in block order
+          for (int b = 0; b < nb; ++b) {
+            const double v = (cur[l_blocks[1 * nb + b]] + lp0) + 0.0;
+            if (v > best) { best = v; bpi = b; }
+          }
+        } else {
+          if (n_in > 0) { const double v = (cur[p0] + lp0) + 0.0; if (v > best) { best = v; bpi = 0; } }
+          if (n_in > 1) { const double v = (cur[p1] + lp1) + 0.0; if (v > best) { best = v; bpi = 1; } }
+          if (n_in > 2) { const double v = (cur[p2] + lp2) + 0.0; if (v > best) { best = v; bpi = 2; } }
+          if (n_in > 3) { const double v = (cur[p3] + lp3) + 0.0; if (v > best) { best = v; bpi = 3; } }
+        }
+        cur[st] = best;
+      }
+      __syncthreads();
+    }
+    if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
+    double* t = prev; prev = cur; cur = t;
+  }
+  if (tid == 0) {
+    tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
+  }
+  __syncthreads();
+
+  // ---- traceback (hmm_model.rs:125-142) fused with get_events/calc_purity (events.rs:17-86, purity.rs:6-41)
+  //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
+  const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
+  uint16_t* pbuf = path ? path + job.path_off : nullptr;
+  uint32_t* visits = visit_ws + job.visit_off;
+  const int pcap = (int)job.path_cap;
+  while (true) {
+    if (tb_done) break;
+    const int c1 = tb_idx + 1, c0 = max(0, c1 - cols_per_chunk);
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * Spad);
+      uint4* dst = reinterpret_cast<uint4*>(l_stage);
+      const int n16 = (c1 - c0) * Spad / 16;
+      for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int state = tb_state, idx = tb_idx, np = tb_npath, nv = tb_nvisit, edit = tb_edit, ref = tb_ref, nxt = tb_next, vb1 = tb_vb1;
+      while (state != 0 && idx >= c0) {
+        if (pbuf && np < pcap) pbuf[pcap - 1 - np] = (uint16_t)state;
+        ++np;
+        const int blk = l_block[state];
+        if (blk >= 0) {
+          const int bstart = (int)l_blocks[0 * nb + blk], bend = (int)l_blocks[1 * nb + blk];
+          if (state == bstart) {  // MotifStart + implied leading deletions (events.rs:42-48)
+            const int dels = nxt - state - 1;
+            edit += dels; ref += dels;
+            visits[3 * nv + 0] = (uint32_t)blk; visits[3 * nv + 1] = (uint32_t)idx; visits[3 * nv + 2] = (uint32_t)vb1;
+            ++nv;
+          } else if (state == bend) {
+            vb1 = idx;  // bases of this visit are query[.. idx)
+          } else if (blk == nb - 1) {  // Skip
+            ++edit; ++ref;
+          } else {
+            const int mlen = (int)l_blocks[2 * nb + blk];
+            const int off = state - bstart - 1;
+            const int kind = off / mlen;
+            if (kind == 0) {  // match state: Match iff query base == motif base or motif base is N (events.rs:66-73)
+              const int expected = g_motifs[l_blocks[3 * nb + blk] + off];
+              const int base = "#ATCG"[hmm_code(seq, idx, L)];
+              ++ref;
+              if (!(base == expected || expected == 'N')) ++edit;
+            } else if (kind == 1) { ++edit; }            // Ins
+            else { ++edit; ++ref; }                      // Del
+          }
+        }
+        const int b = l_stage[(size_t)(idx - c0) * Spad + state];
+        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[b * S + state];
+        if (l_flags[state] & 1) --idx;
+        nxt = state;
+        state = prv;
+      }
+      if (state == 0) { if (pbuf && np < pcap) pbuf[pcap - 1 - np] = 0; ++np; tb_done = 1; }
+      tb_state = state; tb_idx = idx; tb_npath = np; tb_nvisit = nv; tb_edit = edit; tb_ref = ref; tb_next = nxt; tb_vb1 = vb1;
+    }
+    __syncthreads();
+  }
+  const int np = tb_npath;
+  // ---- state path: shift the reversed tail to the front (forward order)
+  if (pbuf) {
+    const int n = min(np, pcap), shift = pcap - n;
+    for (int base = 0; base < n; base += nthr) {
+      const int f = base + tid;
+      uint16_t v = 0;
+      if (f < n) v = pbuf[shift + f];
+      __syncthreads();
+      if (f < n) pbuf[f] = v;
+      __syncthreads();
+    }
+  }
+  // ---- decode (thread 0): purity, remove_imperfect_motifs(.., 6), label_motifs, skip filter, counts, collapse
+  if (tid == 0) {
+    if (path_len) path_len[job.job_index] = (uint32_t)np;
+    const int edit = tb_edit, mx = max(tb_ref, qlen);
+    purity[job.job_index] = ((double)mx - (double)edit) / (double)mx;
+    if (edit_out) edit_out[job.job_index] = edit;
+    if (maxd_out) maxd_out[job.job_index] = mx;
+    int32_t* sp = spans3 + 3 * job.span_off;
+    int ns = 0, cum = 0, last_motif = -1, last_end = -1;
+    for (int v = tb_nvisit - 1; v >= 0; --v) {
+      const int blk = (int)visits[3 * v + 0], b0 = (int)visits[3 * v + 1], b1 = (int)visits[3 * v + 2];
+      const int cnt = b1 - b0;
+      bool keep = true;
+      const int mlen = (int)l_blocks[2 * nb + blk];
+      if (blk != nb - 1 && mlen <= 6) {  // only STR motif copies can be removed (operations.rs:45-57)
+        if (cnt < mlen) keep = false;
+        else {
+          const uint8_t* mot = g_motifs + l_blocks[3 * nb + blk];
+          for (int j = 0; j < mlen; ++j) {
+            const int obs = "#ATCG"[hmm_code(seq, b0 + j + 1, L)];
+            if (mot[j] != 'N' && obs != mot[j]) keep = false;
+          }
+        }
+      }
+      const int start = cum, end = cum + cnt;
+      cum = end;
+      const int motif = keep ? blk : nb - 1;
+      if (motif < n_motifs) {
+        counts[job.count_off + motif] += 1;
+        if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
+        else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
+        last_end = end;
+      }
+    }
+    n_spans[job.job_index] = (uint32_t)ns;
+  }
+}
+
+static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
+  size_t o = 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
+  const size_t spad = (S + 15) & ~15u;
+  if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
+  return o + 64;
+}
+
+}  // namespace trgt
+
+using namespace trgt;
+
+extern "C" uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_len) {
+  if (seq_len == 0) return 1;
+  return (uint64_t)(seq_len + 2) * (max_motif_len + 4) + 8;
+}
+
+extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                              const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
+                              const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
+                              const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
+                              uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                              int32_t* edit_dist, int32_t* max_dist) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
+                                                    !seq_len || !spans3 || !span_off || !n_spans || !motif_counts ||
+                                                    !count_off || !purity)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: null argument");
+  if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
+  if (n_jobs == 0) return TRGT_OK;
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  // ---- models
+  std::vector<uint8_t> blob;
+  std::vector<HmmSetDev> sets((size_t)n_sets);
+  for (int s = 0; s < n_sets; ++s) {
+    std::vector<std::string> motifs;
+    for (uint32_t m = set_motif_begin[s]; m < set_motif_begin[s + 1]; ++m) {
+      std::string mot((const char*)motif_blob + motif_off[m], motif_off[m + 1] - motif_off[m]);
+      if (mot.empty()) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: empty motif in set %d", s);
+      static const char allowed[] = "ATCGN";  // replace_invalid_bases(m, ATCGN)
+      for (size_t i = 0; i < mot.size(); ++i)
+        if (!std::strchr("ATCGN", mot[i]) || mot[i] == 0) mot[i] = allowed[i % 5];
+      motifs.push_back(mot);
+    }
+    if (motifs.empty()) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: set %d has no motif", s);
+    build_set(motifs, blob, sets[s]);
+    if (sets[s].S > 1024)
+      return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, sets[s].S);
+    if (sets[s].n_blocks > 254) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has too many motifs", s);
+  }
+  // ---- jobs, grouped by workgroup size (64 * ceil(S/64))
+  std::vector<HmmJobDev> jobs((size_t)n_jobs);
+  uint64_t bp_total = 0, visit_total = 0, seq_total = 0, span_total = 0, count_total = 0, path_total = 0;
+  int64_t cells = 0;
+  for (int64_t j = 0; j < n_jobs; ++j) {
+    if ((int32_t)job_set[j] >= n_sets) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: job %lld bad set", (long long)j);
+    const HmmSetDev& sd = sets[job_set[j]];
+    HmmJobDev& jd = jobs[(size_t)j];
+    jd.set = job_set[j]; jd.seq_len = seq_len[j]; jd.job_index = (uint32_t)j;
+    jd.seq_off = seq_off[j]; jd.span_off = span_off[j]; jd.count_off = count_off[j];
+    jd.path_off = path ? path_off[j] : 0;
+    jd.path_cap = (uint32_t)std::min<uint64_t>(trgt_hmm_path_capacity(seq_len[j], sd.max_mlen), 0xFFFFFFFFull);
+    const uint64_t spad = (sd.S + 15) & ~15u;
+    jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)seq_len[j] + 2), 16);
+    jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
+    seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
+    span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
+    count_total = std::max<uint64_t>(count_total, count_off[j] + (sd.n_blocks - 1));
+    if (path) path_total = std::max<uint64_t>(path_total, path_off[j] + jd.path_cap);
+    cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
+  }
+  if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
+  std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) {
+    return (sets[a.set].S + 63) / 64 < (sets[b.set].S + 63) / 64;
+  });
+  // ---- device buffers
+  const uint8_t* d_seq = nullptr;
+  int rc;
+  if ((rc = dev_in(c, S_HMM_SEQ, seq_blob, (size_t)seq_total, &d_seq))) return rc;
+  void *d_sets = nullptr, *d_model = nullptr, *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
+  if ((rc = dev_get(c, S_HMM_DESC, sets.size() * sizeof(HmmSetDev), &d_sets))) return rc;
+  if ((rc = dev_get(c, S_HMM_MODEL, blob.size(), &d_model))) return rc;
+  if ((rc = dev_get(c, S_HMM_JOBS, jobs.size() * sizeof(HmmJobDev), &d_jobs))) return rc;
+  if ((rc = dev_get(c, S_HMM_BP, (size_t)bp_total, &d_bp))) return rc;
+  if ((rc = dev_get(c, S_HMM_VISITS, (size_t)visit_total * 4, &d_visits))) return rc;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, sets.data(), sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_model, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
+  DevOut<uint16_t> o_path; DevOut<uint32_t> o_plen, o_nsp, o_cnt; DevOut<int32_t> o_spans, o_edit, o_maxd; DevOut<double> o_pur;
+  if ((rc = o_path.init(c, S_HMM_PATH, path, (size_t)path_total))) return rc;
+  if ((rc = o_plen.init(c, S_HMM_PLEN, path_len, (size_t)n_jobs))) return rc;
+  if ((rc = o_spans.init(c, S_HMM_SPANS, spans3, (size_t)span_total * 3))) return rc;
+  if ((rc = o_nsp.init(c, S_HMM_NSP, n_spans, (size_t)n_jobs))) return rc;
+  if ((rc = o_cnt.init(c, S_HMM_CNT, motif_counts, (size_t)count_total))) return rc;
+  if ((rc = o_pur.init(c, S_HMM_PUR, purity, (size_t)n_jobs))) return rc;
+  if ((rc = o_edit.init(c, S_HMM_EDIT, edit_dist, (size_t)n_jobs))) return rc;
+  if ((rc = o_maxd.init(c, S_HMM_MAXD, max_dist, (size_t)n_jobs))) return rc;
+  // ---- one launch per workgroup-size class
+  size_t i = 0;
+  while (i < jobs.size()) {
+    const uint32_t cls = (sets[jobs[i].set].S + 63) / 64;
+    size_t e = i;
+    uint32_t maxS = 0, maxnb = 0;
+    while (e < jobs.size() && (sets[jobs[e].set].S + 63) / 64 == cls) {
+      maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); ++e;
+    }
+    const size_t lds = hmm_lds_bytes(maxS, maxnb);
+    if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
+    if (lds > 64 * 1024)
+      TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KTimer t(c, TRGT_K_HMM);
+    hipLaunchKernelGGL(hmm_viterbi_kernel, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
+                       (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
+                       (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
+                       o_pur.dev, o_edit.dev, o_maxd.dev);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    t.stop(i == 0 ? cells : 0);
+    i = e;
+  }
+  if ((rc = o_path.finish(c)) || (rc = o_plen.finish(c)) || (rc = o_spans.finish(c)) || (rc = o_nsp.finish(c)) ||
+      (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
+    return rc;
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TRGT_OK;
+}
