@@ -86,7 +86,17 @@ def lib():
         if not os.path.exists(_SO):
             raise TrgtHipError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the TRGT hot path)" % _SO)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.
+        # Importing torch first makes our library bind to that already-loaded runtime instead of pulling a
+        # second copy from /opt/rocm (two runtimes in one process leave the later one without a GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_SO)
+        missing = [n for n in EXPORTS if not hasattr(L, n)]
+        if missing:
+            raise TrgtHipError("%s does not export %s (stale build?)" % (_SO, ", ".join(missing)))
         L.trgt_hip_last_error.restype = C.c_char_p
         L.trgt_hip_last_error.argtypes = [_VP]
         L.trgt_hip_create.argtypes = [C.c_int, C.POINTER(_VP)]
