@@ -1,0 +1,202 @@
+"""Parity of the HIP wavefront aligner (trgt_wfa_batch through the C ABI) against the reference's own
+known-answer tests and, on seeded random inputs, against the CPU oracle.  Bit-exact: status, score, CIGAR,
+operation strings, count_matches and alignment spans."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import mutate, rand_dna, repeat_allele
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wfa_kats.json")))["kats"]
+
+
+@pytest.fixture(scope="module")
+def W():
+    from trgt_amd import wfaligner
+    return wfaligner
+
+
+def build(W, d):
+    b = W.WFAligner.builder(W.AlignmentScope.Alignment if d["scope"] == "alignment" else W.AlignmentScope.Score,
+                            {"high": W.MemoryModel.MemoryHigh, "med": W.MemoryModel.MemoryMed, "low": W.MemoryModel.MemoryLow,
+                             "ultralow": W.MemoryModel.MemoryUltraLow}[d["memory"]])
+    m = d["metric"]
+    if m == "indel":
+        b = b.indel()
+    elif m == "edit":
+        b = b.edit()
+    elif m == "linear":
+        b = b.linear(d["x"], d["e1"])
+    elif m == "affine":
+        b = b.affine(d["x"], d["o1"], d["e1"])
+    else:
+        b = b.affine2p(d["x"], d["o1"], d["e1"], d["o2"], d["e2"])
+    if d["heuristic"] == "none":
+        b = b.with_heuristic(W.Heuristic.none())
+    return b.build()
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[k["id"] for k in KATS])
+def test_reference_kat(W, kat):
+    d = kat["params"]
+    al = build(W, d)
+    p, t = kat["pattern"].encode(), kat["text"].encode()
+    if d["span"] == "endsfree":
+        st = al.align_ends_free(p, d["pbf"], d["pef"], t, d["tbf"], d["tef"])
+    else:
+        st = al.align_end_to_end(p, t)
+    assert int(st) == kat["status"]
+    if "score" in kat:
+        assert al.score() == kat["score"]
+    if "cigar" in kat:
+        assert al.cigar_string() == kat["cigar"]
+    if "ops" in kat:
+        assert al.cigar_operations().decode() == kat["ops"]
+    if "span" in kat:
+        (xs, xe), (ys, ye) = al.get_alignment_span()
+        assert [xs, xe, ys, ye] == kat["span"]
+    if "cigar_score" in kat:
+        assert al.cigar_score() == kat["cigar_score"]
+    for flank, want in kat.get("clipped", []):
+        assert al.cigar_score_clipped(flank) == want
+    for flank, want in kat.get("clipped_cigar", []):
+        assert al.cigar_string(flank) == want
+    if "sam_true" in kat:
+        assert al.get_sam_cigar(True) == kat["sam_true"]
+        assert al.get_sam_cigar(False) == kat["sam_false"]
+        assert W.WFAligner.decode_sam_cigar(al.get_sam_cigar(True))[0][1] in "=X"
+
+
+def _check_batch(oracle, got, op, pats, txts):
+    n = len(pats)
+    blob = b"".join(pats) + b"".join(txts)
+    plen = np.array([len(x) for x in pats], np.uint32)
+    tlen = np.array([len(x) for x in txts], np.uint32)
+    pat_off = np.zeros(n, np.uint64)
+    pat_off[1:] = np.cumsum(plen[:-1], dtype=np.uint64)
+    txt_off = np.zeros(n, np.uint64)
+    txt_off[1:] = np.cumsum(tlen[:-1], dtype=np.uint64)
+    txt_off += np.uint64(int(plen.sum()))
+    coff = got["cigar_off"]
+    batch = dict(seqs=np.frombuffer(blob, np.uint8).copy(), pat_off=pat_off, pat_len=plen, txt_off=txt_off, txt_len=tlen,
+                 cigar_off=coff, ops_off=coff)
+    ref = oracle.wfa_batch(op, batch, n_threads=8)
+    assert np.array_equal(got["status"], ref["status"])
+    assert np.array_equal(got["score"], ref["score"])
+    assert np.array_equal(got["n_match"], ref["n_match"])
+    assert np.array_equal(got["span4"], ref["span4"])
+    assert np.array_equal(got["cigar_len"], ref["cigar_len"])
+    assert np.array_equal(got["ops_len"], ref["ops_len"])
+    for j in range(n):
+        o, cl, ol = int(coff[j]), int(ref["cigar_len"][j]), int(ref["ops_len"][j])
+        assert np.array_equal(got["cigar"][o:o + cl], ref["cigar"][o:o + cl]), j
+        assert bytes(got["ops"][o:o + ol]) == bytes(ref["ops"][o:o + ol]), j
+    return ref
+
+
+def test_flank_style_ends_free_random(oracle, W):
+    # THREAD_WFA_FLANK: affine(2,5,1), Heuristic::None, MemoryHigh; align_ends_free(piece,0,0,read,|read|,|read|)
+    rng = np.random.default_rng(20250509)
+    pats, txts = [], []
+    for i in range(160):
+        flank = rand_dna(rng, 250)
+        left, right = rand_dna(rng, int(rng.integers(0, 400))), rand_dna(rng, int(rng.integers(0, 600)))
+        f = mutate(rng, flank, *([0.004, 0.002, 0.002] if i % 4 else [0.05, 0.02, 0.02]))
+        read = left + f + right
+        if i % 10 == 0:   # truncated read: only part of the flank is present
+            cut = int(rng.integers(1, 250))
+            read = f[cut:] + right if i % 20 == 0 else left + f[:cut]
+        if i % 33 == 0:
+            read = rand_dna(rng, int(rng.integers(1, 300)))  # flank absent
+        pats.append(flank)
+        txts.append(read)
+    al = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryHigh).affine(2, 5, 1).with_heuristic(W.Heuristic.none()).build()
+    got = al.align_ends_free_batch(pats, 0, 0, txts, -1, -1)
+    op = oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, span="endsfree", pbf=0, pef=0, tbf=-1, tef=-1, heuristic="none")
+    _check_batch(oracle, got, op, pats, txts)
+
+
+@pytest.mark.parametrize("metric,pen", [("indel", {}), ("edit", {}), ("linear", dict(x=6, e1=2)), ("affine", dict(x=6, o1=4, e1=2)),
+                                         ("affine", dict(x=2, o1=5, e1=1)), ("affine2p", dict(x=8, o1=4, e1=2, o2=24, e2=1))])
+@pytest.mark.parametrize("heur", ["none", "default"])
+def test_end_to_end_random_all_metrics(oracle, W, metric, pen, heur):
+    rng = np.random.default_rng(hash((metric, heur)) % 2**32)
+    pats, txts = [], []
+    for i in range(60):
+        a = rand_dna(rng, int(rng.integers(0, 300)))
+        b = mutate(rng, a, 0.03, 0.02, 0.02) if i % 5 else rand_dna(rng, int(rng.integers(0, 120)))
+        pats.append(a)
+        txts.append(b)
+    b_ = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryHigh)
+    b_ = {"indel": lambda: b_.indel(), "edit": lambda: b_.edit(), "linear": lambda: b_.linear(pen["x"], pen["e1"]),
+          "affine": lambda: b_.affine(pen["x"], pen["o1"], pen["e1"]),
+          "affine2p": lambda: b_.affine2p(pen["x"], pen["o1"], pen["e1"], pen["o2"], pen["e2"])}[metric]()
+    if heur == "none":
+        b_ = b_.with_heuristic(W.Heuristic.none())
+    got = b_.build().align_end_to_end_batch(pats, txts)
+    op = oracle.wfa_params(metric=metric, heuristic=heur, **pen)
+    _check_batch(oracle, got, op, pats, txts)
+
+
+@pytest.mark.parametrize("min_length", [100, 0])
+def test_consensus_style_biwfa_random(oracle, W, min_length):
+    # THREAD_WFA_CONSENSUS: BiWFA affine(2,5,1) + default wfadaptive heuristic, end-to-end, STR alleles
+    rng = np.random.default_rng(99 + min_length)
+    pats, txts = [], []
+    for i in range(120):
+        motif = [rand_dna(rng, int(rng.integers(2, 7)))]
+        backbone = repeat_allele(rng, motif, int(rng.integers(20, 420)), err=0.0)
+        read = mutate(rng, backbone, 0.01, 0.01, 0.01)
+        if i % 3 == 0:  # stutter: +-1..3 motif copies
+            k = len(motif[0]) * int(rng.integers(1, 4))
+            read = read[:len(read) // 2] + (motif[0] * 3)[:k] + read[len(read) // 2:] if i % 2 else read[k:]
+        pats.append(backbone)
+        txts.append(read)
+    al = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(2, 5, 1).build()
+    p = al._params("end2end")
+    p.bialign_min_length = min_length
+    got = al._run_batch(p, pats, txts)
+    op = oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, memory="ultralow", heuristic="default", min_length=min_length)
+    ref = _check_batch(oracle, got, op, pats, txts)
+    assert (ref["status"] == 0).all()
+
+
+def test_edit_distance_score_only_biwfa(oracle, W):
+    # THREAD_WFA_ED: edit, Score scope, BiWFA + default heuristic (genotype_cluster.rs:238-248, len1*len2 <= 10000)
+    rng = np.random.default_rng(4)
+    pats, txts = [], []
+    for i in range(200):
+        a = rand_dna(rng, int(rng.integers(0, 100)))
+        b = mutate(rng, a, 0.05, 0.03, 0.03) if i % 4 else rand_dna(rng, int(rng.integers(0, 100)))
+        pats.append(a)
+        txts.append(b)
+    al = W.WFAligner.builder(W.AlignmentScope.Score, W.MemoryModel.MemoryUltraLow).edit().build()
+    got = al.align_end_to_end_batch(pats, txts)
+    op = oracle.wfa_params(metric="edit", scope="score", memory="ultralow", heuristic="default")
+    ref = _check_batch(oracle, got, op, pats, txts)
+    # sanity: plain DP edit distance on a few pairs
+    for j in range(0, 200, 37):
+        a, b = pats[j], txts[j]
+        prev = list(range(len(b) + 1))
+        for x in range(1, len(a) + 1):
+            cur = [x] + [0] * len(b)
+            for y in range(1, len(b) + 1):
+                cur[y] = min(prev[y] + 1, cur[y - 1] + 1, prev[y - 1] + (a[x - 1] != b[y - 1]))
+            prev = cur
+        assert int(ref["score"][j]) == prev[len(b)]
+
+
+def test_long_expanded_alleles_biwfa(oracle, W):
+    rng = np.random.default_rng(8)
+    pats, txts = [], []
+    for n in (1500, 4000, 9000):
+        bb = repeat_allele(rng, [b"GGCCTG"], n, err=0.0)
+        pats.append(bb)
+        txts.append(mutate(rng, bb, 0.004, 0.003, 0.003))
+    al = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(2, 5, 1).build()
+    got = al.align_end_to_end_batch(pats, txts)
+    op = oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, memory="ultralow", heuristic="default")
+    _check_batch(oracle, got, op, pats, txts)

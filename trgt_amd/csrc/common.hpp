@@ -30,6 +30,7 @@ struct trgt_hip_ctx {
   int64_t k_cells[TRGT_K_COUNT] = {0, 0, 0};
   struct Pending { int k; hipEvent_t a, b; };
   std::vector<Pending> pending;
+  void* last_wfa_cells_dev = nullptr;
 };
 
 namespace trgt {

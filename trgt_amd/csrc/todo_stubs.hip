@@ -1,7 +1,6 @@
 // TEMPORARY: entry points not implemented yet fail loudly (no fallback).  Removed as each lands.
 #include "common.hpp"
 extern "C" {
-int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params*, int64_t, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, const uint32_t*, int32_t*, int32_t*, int32_t*, uint32_t*, uint32_t*, const uint64_t*, uint32_t*, uint8_t*, const uint64_t*, uint32_t*) { return trgt::fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: not built yet"); }
 int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params*, int64_t, const uint8_t*, const uint64_t*, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, int32_t*, int32_t*, uint8_t*, uint8_t*) { return trgt::fail(c, TRGT_ERR_UNSUPPORTED, "trgt_find_spans_batch: not built yet"); }
 int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params*, const trgt_locus_batch_in*, trgt_locus_batch_out*) { return trgt::fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: not built yet"); }
 void trgt_synth_default_params(trgt_synth_params*, int) {}

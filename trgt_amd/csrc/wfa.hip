@@ -1,0 +1,564 @@
+// trgt_amd/csrc/wfa.hip -- batch wavefront alignment kernel (WFA / BiWFA) and trgt_wfa_batch.
+//
+// Replaces the per-alignment WFA2-lib calls behind src/wfaligner.rs of PacificBiosciences/trgt
+// v3.0.0 (wavefront_align :492-498/:519-525, cigar_get_CIGAR :944-949, cigar_count_matches :999,
+// get_alignment_span :864-908) with one launch per batch.  See wfa_engine.hpp for the wavefront
+// machinery; this file holds the back-trace, the BiWFA driver (breakpoint search + recursion as
+// an explicit stack), the per-job epilogue and the host-side planner.
+#include <algorithm>
+
+#include "wfa_engine.hpp"
+#include "wfa_host.hpp"
+
+namespace trgt {
+namespace wfa {
+
+// ------------------------------------------------------------------ back-trace (thread 0)
+struct RleOut { uint32_t* buf; uint32_t cap; };
+
+__device__ __forceinline__ uint32_t op_code(char op) { return op == 'M' ? 7u : op == 'X' ? 8u : op == 'I' ? 1u : 2u; }
+
+__device__ __forceinline__ void rle_push(uint32_t* buf, int& n, uint32_t cap, uint32_t code, int len) {
+  if (len <= 0) return;
+  if (n > 0 && (buf[n - 1] & 0xF) == code) { buf[n - 1] += (uint32_t)len << 4; return; }
+  if ((uint32_t)n < cap) buf[n++] = ((uint32_t)len << 4) | code;
+}
+
+__device__ __forceinline__ long long bt_cand(const Inst& I, int c, int s, int k, int add, int type) {
+  if (s < 0 || s >= I.n_slots) return (long long)OFF_NULL;
+  const WfDesc d = I.gdesc[(size_t)s * 5 + c];
+  if (d.base == NOBASE || k < d.lo || k > d.hi) return (long long)OFF_NULL;
+  return (((long long)(I.arena[d.base + (uint32_t)(k - d.lo_alloc)] + add)) << 4) | type;  // BACKTRACE_TYPE_BITS_SET
+}
+
+// wavefront_backtrace_{linear,affine}: candidates encoded (offset << 4 | type), maximum wins.
+// Emits the operations in reverse order, run-length encoded, into tmp[0..*ntmp).
+__device__ __noinline__ void wf_backtrace(const Inst& I, const Pen& pen, uint32_t* tmp, int& ntmp, uint32_t cap) {
+  const int plen = I.plen, tlen = I.tlen, metric = pen.metric;
+  const int x = pen.x, o1 = pen.o1, e1 = pen.e1, o2 = pen.o2, e2 = pen.e2;
+  const bool lin = metric <= M_LINEAR;
+  int mt = I.ce, s = I.end_score, k = I.end_k, off = I.end_off;
+  int h = off, v = off - k;
+  ntmp = 0;
+  if (I.ce == CM) {  // ending deletions / insertions of an ends-free alignment
+    rle_push(tmp, ntmp, cap, 2u, plen - v);
+    rle_push(tmp, ntmp, cap, 1u, tlen - h);
+  }
+  while (v > 0 && h > 0 && s > 0) {
+    long long best = (long long)OFF_NULL;
+    if (lin) {
+      if (metric != M_INDEL) best = max(best, bt_cand(I, CM, s - x, k, +1, 9));
+      best = max(best, bt_cand(I, CM, s - o1, k - 1, +1, 1));
+      best = max(best, bt_cand(I, CM, s - o1, k + 1, 0, 5));
+    } else {
+      if (mt == CM) best = max(best, bt_cand(I, CM, s - x, k, +1, 9));
+      if (mt == CM || mt == CD1) { best = max(best, bt_cand(I, CD1, s - e1, k + 1, 0, 6)); best = max(best, bt_cand(I, CM, s - o1 - e1, k + 1, 0, 5)); }
+      if (mt == CM || mt == CI1) { best = max(best, bt_cand(I, CI1, s - e1, k - 1, +1, 2)); best = max(best, bt_cand(I, CM, s - o1 - e1, k - 1, +1, 1)); }
+      if (metric == M_AFFINE2P) {
+        if (mt == CM || mt == CD2) { best = max(best, bt_cand(I, CD2, s - e2, k + 1, 0, 8)); best = max(best, bt_cand(I, CM, s - o2 - e2, k + 1, 0, 7)); }
+        if (mt == CM || mt == CI2) { best = max(best, bt_cand(I, CI2, s - e2, k - 1, +1, 4)); best = max(best, bt_cand(I, CM, s - o2 - e2, k - 1, +1, 3)); }
+      }
+    }
+    if (best < 0) break;
+    const int best_off = (int)(best >> 4), type = (int)(best & 0xF);
+    if (mt == CM) {
+      rle_push(tmp, ntmp, cap, 7u, off - best_off);
+      off = best_off; h = off; v = off - k;
+      if (v <= 0 || h <= 0) break;
+    }
+    switch (type) {
+      case 9: rle_push(tmp, ntmp, cap, 8u, 1); s -= x; mt = CM; --off; break;
+      case 1: rle_push(tmp, ntmp, cap, 1u, 1); s -= lin ? o1 : (o1 + e1); mt = CM; --k; --off; break;
+      case 2: rle_push(tmp, ntmp, cap, 1u, 1); s -= e1; mt = CI1; --k; --off; break;
+      case 3: rle_push(tmp, ntmp, cap, 1u, 1); s -= o2 + e2; mt = CM; --k; --off; break;
+      case 4: rle_push(tmp, ntmp, cap, 1u, 1); s -= e2; mt = CI2; --k; --off; break;
+      case 5: rle_push(tmp, ntmp, cap, 2u, 1); s -= lin ? o1 : (o1 + e1); mt = CM; ++k; break;
+      case 6: rle_push(tmp, ntmp, cap, 2u, 1); s -= e1; mt = CD1; ++k; break;
+      case 7: rle_push(tmp, ntmp, cap, 2u, 1); s -= o2 + e2; mt = CM; ++k; break;
+      default: rle_push(tmp, ntmp, cap, 2u, 1); s -= e2; mt = CD2; ++k; break;
+    }
+    h = off; v = off - k;
+  }
+  if (mt == CM && v > 0 && h > 0) {
+    const int n = min(v, h);
+    rle_push(tmp, ntmp, cap, 7u, n);
+    v -= n; h -= n;
+  }
+  rle_push(tmp, ntmp, cap, 2u, v);
+  rle_push(tmp, ntmp, cap, 1u, h);
+}
+
+// append the reversed run list to the job's forward CIGAR (merging equal neighbours like cigar_get_CIGAR does)
+__device__ __forceinline__ void rle_append_reversed(uint32_t* out, int& n, uint32_t cap, const uint32_t* tmp, int ntmp) {
+  for (int i = ntmp - 1; i >= 0; --i) rle_push(out, n, cap, tmp[i] & 0xF, (int)(tmp[i] >> 4));
+}
+
+// ------------------------------------------------------------------ BiWFA
+// wavefront_bialign_breakpoint_{indel2indel,m2m}.  All threads.
+__device__ __noinline__ void bp_check(int i0, int i1, bool fwd, int s0, int s1, const WfDesc& w0, const WfDesc& w1, int comp,
+                         int gap_open) {
+  const Inst& A0 = sh.inst[i0];
+  const Inst& A1 = sh.inst[i1];
+  const int plen = A0.plen, tlen = A0.tlen, tid = threadIdx.x, T = blockDim.x;
+  const int lo0 = w0.lo, hi0 = w0.hi, lo1 = (tlen - plen) - w1.hi, hi1 = (tlen - plen) - w1.lo;
+  if (hi1 < lo0 || hi0 < lo1) return;
+  if (!(s0 + s1 - gap_open < sh.bp.score)) return;
+  const int min_hi = min(hi0, hi1), max_lo = max(lo0, lo1);
+  __syncthreads();
+  if (tid == 0) sh.red.bp_k = INT32_MAX;
+  __syncthreads();
+  for (int kb = max_lo; kb <= min_hi; kb += T) {
+    const int k0 = kb + tid;
+    bool ok = false;
+    if (k0 <= min_hi) {
+      const int k1 = (tlen - plen) - k0;
+      const int32_t h0 = A0.arena[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = A1.arena[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
+      if (h0 + h1 >= tlen) {
+        const int hh = fwd ? h0 : h1, kk = fwd ? k0 : k1;
+        ok = !((hh - kk) > plen || hh > tlen);
+      }
+    }
+    red_first(ok, k0, &sh.red.bp_k);
+  }
+  __syncthreads();
+  if (tid == 0 && sh.red.bp_k != INT32_MAX) {
+    const int k0 = sh.red.bp_k, k1 = (tlen - plen) - k0;
+    const int32_t h0 = A0.arena[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = A1.arena[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
+    Breakpoint& bp = sh.bp;
+    if (fwd) { bp.score_f = s0; bp.score_r = s1; bp.k_f = k0; bp.off_f = h0; }
+    else { bp.score_f = s1; bp.score_r = s0; bp.k_f = k1; bp.off_f = h1; }
+    bp.score = s0 + s1 - gap_open; bp.comp = comp;
+  }
+  __syncthreads();
+}
+
+// wavefront_bialign_overlap.  All threads.
+__device__ __noinline__ void bi_overlap(const Pen& pen, int i0, int i1, int s0, int s1, bool fwd) {
+  const WfDesc m0 = fetch_raw(i0, CM, s0);
+  if (m0.base == NOBASE) return;
+  WfDesc d10 = null_desc(), i10 = null_desc(), d20 = null_desc(), i20 = null_desc();
+  if (pen.metric >= M_AFFINE) { d10 = fetch_raw(i0, CD1, s0); i10 = fetch_raw(i0, CI1, s0); }
+  if (pen.metric == M_AFFINE2P) { d20 = fetch_raw(i0, CD2, s0); i20 = fetch_raw(i0, CI2, s0); }
+  for (int i = 0; i < pen.scope; ++i) {
+    const int si = s1 - i;
+    if (si < 0) break;
+    if (pen.metric == M_AFFINE2P && s0 + si - pen.o2 < sh.bp.score) {
+      const WfDesc d21 = fetch_raw(i1, CD2, si);
+      if (d20.base != NOBASE && d21.base != NOBASE) bp_check(i0, i1, fwd, s0, si, d20, d21, CD2, pen.o2);
+      const WfDesc i21 = fetch_raw(i1, CI2, si);
+      if (i20.base != NOBASE && i21.base != NOBASE) bp_check(i0, i1, fwd, s0, si, i20, i21, CI2, pen.o2);
+    }
+    if (pen.metric >= M_AFFINE && s0 + si - pen.o1 < sh.bp.score) {
+      const WfDesc d11 = fetch_raw(i1, CD1, si);
+      if (d10.base != NOBASE && d11.base != NOBASE) bp_check(i0, i1, fwd, s0, si, d10, d11, CD1, pen.o1);
+      const WfDesc i11 = fetch_raw(i1, CI1, si);
+      if (i10.base != NOBASE && i11.base != NOBASE) bp_check(i0, i1, fwd, s0, si, i10, i11, CI1, pen.o1);
+    }
+    if (s0 + si >= sh.bp.score) continue;
+    const WfDesc m1 = fetch_raw(i1, CM, si);
+    if (m1.base != NOBASE) bp_check(i0, i1, fwd, s0, si, m0, m1, CM, 0);
+  }
+}
+
+struct BlockWs {  // carved from the workgroup's HBM workspace
+  WfDesc* gdesc; int32_t* arena_u; int32_t* arena_f; int32_t* arena_r; uint32_t* rle_tmp; uint32_t* rle_out; uint32_t* run_start;
+};
+
+__device__ __forceinline__ void setup_inst(int ii, const KArgs& a, const BlockWs& ws, const uint8_t* P, int pl,
+                                           const uint8_t* T, int tl, int rev, int span, int pbf, int pef, int tbf, int tef,
+                                           int cb, int ce) {
+  Inst& I = sh.inst[ii];
+  I.pp = P; I.tp = T; I.plen = pl; I.tlen = tl; I.rev = rev;
+  I.span = span; I.pbf = pbf; I.pef = pef; I.tbf = tbf; I.tef = tef; I.cb = cb; I.ce = ce;
+  I.modular = ii != I_UNI;
+  I.gdesc = ws.gdesc; I.n_slots = ii == I_UNI ? (int)a.uni_slots : INT32_MAX;
+  I.arena = ii == I_UNI ? ws.arena_u : (ii == I_FWD ? ws.arena_f : ws.arena_r);
+  I.arena_cap = a.arena_uni_cap; I.stride = a.ring_stride; I.bump = 0;
+}
+
+// wavefront_bialign_find_breakpoint.  All threads.
+template <int METRIC>
+__device__ __noinline__ int bi_find_breakpoint(const KArgs& a, const BlockWs& ws, const uint8_t* P, const uint8_t* T, const Seg seg) {
+  const KParams& kp = a.kp;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    setup_inst(I_FWD, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, CM);
+    setup_inst(I_REV, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 1, 0, 0, 0, 0, 0, seg.ce, CM);
+    sh.bp.score = INT32_MAX;
+  }
+  __syncthreads();
+  const int max_antidiagonal = seg.pl + seg.tl - 1;
+  int sf = 0, sr = 0, fak = 0, rak = 0, mak = 0;
+  wf_init(I_FWD, kp);
+  if (sh.inst[I_FWD].status == ST_OOM) return ST_OOM;
+  wf_extend_only(I_FWD, 0, true);
+  if (wf_post_extend(I_FWD, 0, kp, true, &fak)) return sh.inst[I_FWD].status;
+  wf_init(I_REV, kp);
+  if (sh.inst[I_REV].status == ST_OOM) return ST_OOM;
+  wf_extend_only(I_REV, 0, true);
+  if (wf_post_extend(I_REV, 0, kp, true, &rak)) return sh.inst[I_REV].status;
+  bool last_forward = false;
+  while (true) {
+    if (fak + rak >= max_antidiagonal) break;
+    ++sf;
+    if (wf_step<METRIC>(I_FWD, sf, kp, true, &mak)) return sh.inst[I_FWD].status;
+    if (fak < mak) fak = mak;
+    last_forward = true;
+    if (fak + rak >= max_antidiagonal) break;
+    ++sr;
+    if (wf_step<METRIC>(I_REV, sr, kp, true, &mak)) return sh.inst[I_REV].status;
+    if (rak < mak) rak = mak;
+    last_forward = false;
+  }
+  const int scope = kp.pen.scope;
+  const int gap_opening = METRIC == M_AFFINE ? kp.pen.o1 : (METRIC == M_AFFINE2P ? max(kp.pen.o1, kp.pen.o2) : 0);
+  while (true) {
+    if (last_forward) {
+      const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
+      if (sf + min_sr - gap_opening >= sh.bp.score) break;
+      bi_overlap(kp.pen, I_FWD, I_REV, sf, sr, true);
+      ++sr;
+      if (wf_step<METRIC>(I_REV, sr, kp, false, nullptr)) return sh.inst[I_REV].status;  // only a dead front ends phase 2
+    }
+    const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
+    if (min_sf + sr - gap_opening >= sh.bp.score) break;
+    bi_overlap(kp.pen, I_REV, I_FWD, sr, sf, false);
+    ++sf;
+    if (wf_step<METRIC>(I_FWD, sf, kp, false, nullptr)) return sh.inst[I_FWD].status;
+    last_forward = true;
+  }
+  return ST_OK;
+}
+
+__device__ __forceinline__ int classic_score(int metric, int s) { return metric <= M_EDIT ? s : -s; }
+
+// wavefront_bialign_base.  All threads.  Returns false on failure (sh.status set).
+template <int METRIC>
+__device__ __noinline__ bool bi_base(const KArgs& a, const BlockWs& ws, const uint8_t* P, const uint8_t* T, const Seg seg, bool want_cigar) {
+  __syncthreads();
+  if (threadIdx.x == 0) setup_inst(I_UNI, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, seg.ce);
+  __syncthreads();
+  const int st = wf_run<METRIC>(I_UNI, a.kp);
+  if (threadIdx.x == 0) {
+    if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
+    else if (want_cigar) {
+      int nt = 0;
+      wf_backtrace(sh.inst[I_UNI], a.kp.pen, ws.rle_tmp, nt, a.rle_cap);
+      rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
+    }
+  }
+  __syncthreads();
+  return st == ST_END_REACHED;
+}
+
+// ------------------------------------------------------------------ kernel
+template <int METRIC>
+__global__ void __launch_bounds__(256) wfa_kernel(const KArgs a) {
+  extern __shared__ unsigned char lds_seq[];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const KParams& kp = a.kp;
+  BlockWs ws;
+  {
+    uint8_t* base = a.ws + (size_t)blockIdx.x * a.ws_per_block;
+    ws.gdesc = reinterpret_cast<WfDesc*>(base + a.off_gdesc);
+    ws.arena_u = reinterpret_cast<int32_t*>(base + a.off_arena_u);
+    ws.arena_f = reinterpret_cast<int32_t*>(base + a.off_arena_f);
+    ws.arena_r = reinterpret_cast<int32_t*>(base + a.off_arena_r);
+    ws.rle_tmp = reinterpret_cast<uint32_t*>(base + a.off_rle_tmp);
+    ws.rle_out = reinterpret_cast<uint32_t*>(base + a.off_rle_out);
+    ws.run_start = reinterpret_cast<uint32_t*>(base + a.off_run_start);
+  }
+  const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  unsigned long long cells_acc = 0;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) sh.job = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    const uint32_t j = (uint32_t)sh.job;
+    if (j >= n_jobs) break;
+    const JobDev job = a.jobs[j];
+    const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
+    const uint8_t* P = a.pat_base + job.pat_off;
+    const uint8_t* Tx = a.txt_base + job.txt_off;
+    // stage the two sequences in LDS when they fit (extension = byte compares against LDS)
+    const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
+    if (pl_pad + (uint32_t)tlen <= a.lds_seq_cap) {
+      for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
+      for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
+      P = lds_seq; Tx = lds_seq + pl_pad;
+    }
+    if (tid == 0) { sh.status = TRGT_WF_COMPLETED; sh.score = INT32_MIN; sh.rle_n = 0; sh.sp = 0; sh.cells = 0; sh.top_bp = 0; }
+    __syncthreads();
+    if (!kp.biwfa) {
+      // ---- unidirectional (wavefront_unialign): MemoryHigh / Med / Low
+      if (tid == 0) {
+        const int sp = kp.span;
+        auto fr = [](int v, int len) { return v < 0 ? len : v; };
+        setup_inst(I_UNI, a, ws, P, plen, Tx, tlen, 0, sp, sp ? fr(kp.pbf, plen) : 0, sp ? fr(kp.pef, plen) : 0,
+                   sp ? fr(kp.tbf, tlen) : 0, sp ? fr(kp.tef, tlen) : 0, CM, CM);
+      }
+      __syncthreads();
+      const int st = wf_run<METRIC>(I_UNI, kp);
+      if (tid == 0) {
+        if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
+        else {
+          sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
+          if (kp.scope_alignment) {
+            int nt = 0;
+            wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
+            rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
+          }
+        }
+      }
+    } else if (!kp.scope_alignment) {
+      // ---- BiWFA score only (wavefront_bialign_compute_score)
+      Seg seg; seg.pb = 0; seg.pl = plen; seg.tb = 0; seg.tl = tlen; seg.cb = CM; seg.ce = CM; seg.rem = INT32_MAX; seg.top = 1;
+      const int st = bi_find_breakpoint<METRIC>(a, ws, P, Tx, seg);
+      if (st == ST_END_REACHED) {
+        if (bi_base<METRIC>(a, ws, P, Tx, seg, false) && tid == 0) sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
+      } else if (tid == 0) {
+        if (st != ST_OK) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
+        else sh.score = classic_score(METRIC, sh.bp.score);
+      }
+    } else {
+      // ---- BiWFA alignment (wavefront_bialign_alignment), recursion as an explicit stack, left half first
+      if (tid == 0) {
+        Seg s0; s0.pb = 0; s0.pl = plen; s0.tb = 0; s0.tl = tlen; s0.cb = CM; s0.ce = CM;
+        s0.rem = max(plen, tlen) <= kp.bi_min_length ? 0 : INT32_MAX; s0.top = 1;
+        sh.stack[0] = s0; sh.sp = 1;
+      }
+      __syncthreads();
+      while (true) {
+        __syncthreads();
+        if (sh.sp == 0 || sh.status != TRGT_WF_COMPLETED) break;
+        const Seg seg = sh.stack[sh.sp - 1];
+        __syncthreads();
+        if (tid == 0) sh.sp -= 1;
+        __syncthreads();
+        if (seg.tl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 2u, seg.pl); continue; }
+        if (seg.pl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 1u, seg.tl); continue; }
+        if (seg.rem <= kp.bi_min_score) { bi_base<METRIC>(a, ws, P, Tx, seg, true); continue; }
+        const int st = bi_find_breakpoint<METRIC>(a, ws, P, Tx, seg);
+        if (st == ST_END_REACHED) { bi_base<METRIC>(a, ws, P, Tx, seg, true); continue; }
+        if (st != ST_OK) { if (tid == 0) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE; continue; }
+        if (tid == 0) {
+          const Breakpoint bp = sh.bp;
+          const int bh = bp.off_f, bv = bp.off_f - bp.k_f;
+          if (seg.top) { sh.top_bp = 1; sh.score = classic_score(METRIC, bp.score); }
+          if (sh.sp + 2 > 64) sh.status = TRGT_WF_OOM;
+          else {
+            Seg r; r.pb = seg.pb + bv; r.pl = seg.pl - bv; r.tb = seg.tb + bh; r.tl = seg.tl - bh; r.cb = bp.comp; r.ce = seg.ce; r.rem = bp.score_r; r.top = 0;
+            Seg l; l.pb = seg.pb; l.pl = bv; l.tb = seg.tb; l.tl = bh; l.cb = seg.cb; l.ce = bp.comp; l.rem = bp.score_f; l.top = 0;
+            sh.stack[sh.sp++] = r; sh.stack[sh.sp++] = l;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations
+    const int ok = sh.status == TRGT_WF_COMPLETED;
+    const int nrun = ok ? sh.rle_n : 0;
+    if (tid == 0) {
+      const uint32_t o = job.out_index;
+      if (a.status) a.status[o] = sh.status;
+      if (a.score) a.score[o] = ok ? sh.score : INT32_MIN;
+      uint32_t pi = 0, ti = 0, ps = 0, pe = 0, ts = 0, te = 0, nm = 0, total = 0;
+      bool started = false;
+      for (int r = 0; r < nrun; ++r) {
+        const uint32_t e = ws.rle_out[r], len = e >> 4, code = e & 0xF;
+        ws.run_start[r] = total;
+        total += len;
+        if (code == 1u) ti += len;
+        else if (code == 2u) pi += len;
+        else { if (!started) { ps = pi; ts = ti; started = true; } pi += len; ti += len; pe = pi; te = ti; if (code == 7u) nm += len; }
+      }
+      if (kp.span == 0) { ps = 0; pe = (uint32_t)plen; ts = 0; te = (uint32_t)tlen; }
+      if (a.n_match) a.n_match[o] = (int32_t)nm;
+      if (a.span4) { a.span4[4 * o + 0] = ps; a.span4[4 * o + 1] = pe; a.span4[4 * o + 2] = ts; a.span4[4 * o + 3] = te; }
+      if (a.cigar_len) a.cigar_len[o] = (uint32_t)nrun;
+      if (a.ops_len) a.ops_len[o] = total;
+      sh.top_bp = (int)total;
+      cells_acc += sh.cells;
+    }
+    __syncthreads();
+    if (a.cigar) for (int r = tid; r < nrun; r += T) a.cigar[job.cigar_off + r] = ws.rle_out[r];
+    if (a.ops && nrun > 0) {
+      const uint32_t total = (uint32_t)sh.top_bp;
+      for (uint32_t p = tid; p < total; p += T) {
+        int lo = 0, hi = nrun - 1;  // last run whose start <= p
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ws.run_start[mid] <= p) lo = mid; else hi = mid - 1; }
+        const uint32_t code = ws.rle_out[lo] & 0xF;
+        a.ops[job.ops_off + p] = code == 7u ? 'M' : code == 8u ? 'X' : code == 1u ? 'I' : 'D';
+      }
+    }
+  }
+  if (tid == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
+}
+
+}  // namespace wfa
+
+// ------------------------------------------------------------------ host planner
+static int gap_cost(const trgt_wfa_params& p, int64_t len) {
+  if (len <= 0) return 0;
+  int64_t c;
+  switch (p.metric) {
+    case 0: case 1: c = len; break;
+    case 2: c = (int64_t)p.gap_ext1 * len; break;
+    case 3: c = p.gap_open1 + (int64_t)p.gap_ext1 * len; break;
+    default: c = std::min<int64_t>(p.gap_open1 + (int64_t)p.gap_ext1 * len, p.gap_open2 + (int64_t)p.gap_ext2 * len); break;
+  }
+  return (int)std::min<int64_t>(c, 1 << 28);
+}
+
+int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
+  using namespace wfa;
+  if (p.metric < 0 || p.metric > 4) return fail(c, TRGT_ERR_INVALID, "wfa: bad metric %d", p.metric);
+  if (p.heuristic != 0 && p.heuristic != 1) return fail(c, TRGT_ERR_UNSUPPORTED, "wfa: only Heuristic::None and WFadaptive are implemented");
+  if (p.memory_mode == 3 && p.span != 0) return fail(c, TRGT_ERR_UNSUPPORTED, "wfa: BiWFA is end-to-end only (as used by TRGT)");
+  if (p.metric >= 2 && (p.mismatch <= 0 || p.gap_ext1 <= 0 || (p.metric >= 3 && p.gap_open1 < 0)))
+    return fail(c, TRGT_ERR_INVALID, "wfa: penalties must be positive");
+  KArgs a;
+  std::memset(&a, 0, sizeof a);
+  Pen& pen = a.kp.pen;
+  pen.metric = p.metric;
+  switch (p.metric) {
+    case 0: pen.x = -1; pen.o1 = 1; pen.e1 = -1; pen.o2 = pen.e2 = -1; pen.scope = 2; pen.ncomp = 1; break;
+    case 1: pen.x = 1; pen.o1 = 1; pen.e1 = -1; pen.o2 = pen.e2 = -1; pen.scope = 2; pen.ncomp = 1; break;
+    case 2: pen.x = p.mismatch; pen.o1 = p.gap_ext1; pen.e1 = -1; pen.o2 = pen.e2 = -1; pen.scope = std::max(pen.x, pen.o1) + 1; pen.ncomp = 1; break;
+    case 3: pen.x = p.mismatch; pen.o1 = p.gap_open1; pen.e1 = p.gap_ext1; pen.o2 = pen.e2 = -1; pen.scope = std::max(pen.x, pen.o1 + pen.e1) + 1; pen.ncomp = 3; break;
+    default: pen.x = p.mismatch; pen.o1 = p.gap_open1; pen.e1 = p.gap_ext1; pen.o2 = p.gap_open2; pen.e2 = p.gap_ext2;
+      pen.scope = std::max(pen.x, std::max(pen.o1 + pen.e1, pen.o2 + pen.e2)) + 1; pen.ncomp = 5; break;
+  }
+  if (pen.scope > RING) return fail(c, TRGT_ERR_UNSUPPORTED, "wfa: penalties need a score scope of %d (> %d)", pen.scope, RING);
+  a.kp.span = p.span; a.kp.pbf = p.pattern_begin_free; a.kp.pef = p.pattern_end_free; a.kp.tbf = p.text_begin_free; a.kp.tef = p.text_end_free;
+  a.kp.scope_alignment = p.scope != 0; a.kp.biwfa = p.memory_mode == 3; a.kp.heuristic = p.heuristic;
+  a.kp.h_min_len = p.h_min_wavefront_length; a.kp.h_max_dist = p.h_max_distance_threshold; a.kp.h_steps = p.h_steps_between_cutoffs;
+  a.kp.bi_min_score = p.bialign_min_score; a.kp.bi_min_length = p.bialign_min_length;
+  // ---- workspace plan from the batch maxima
+  const int64_t mp = L.max_plen, mt = L.max_tlen, msum = L.max_sum;
+  int64_t score_bound;
+  const bool text_free = p.span == 1 && (p.text_begin_free < 0) && (p.text_end_free < 0);
+  if (text_free) score_bound = gap_cost(p, mp) + 2;          // delete the whole pattern anywhere in the free text
+  else score_bound = (int64_t)gap_cost(p, mp) + gap_cost(p, mt) + 2;
+  if (a.kp.biwfa && a.kp.scope_alignment) {                   // base cases: score <= 250 unless the heuristic misleads; min-length fallback
+    const int64_t small = (int64_t)gap_cost(p, std::min<int64_t>(mp, p.bialign_min_length)) + gap_cost(p, std::min<int64_t>(mt, p.bialign_min_length)) + 2;
+    score_bound = std::min<int64_t>(score_bound, std::max<int64_t>(small, 4 * (int64_t)p.bialign_min_score + 64));
+  }
+  score_bound = std::min<int64_t>(score_bound, 1 << 20);
+  const uint64_t per_level = (uint64_t)pen.ncomp * (uint64_t)std::min<int64_t>(msum + 3, 2 * score_bound + 3 + (p.span ? msum : 0));
+  uint64_t arena_ints = std::min<uint64_t>((uint64_t)(score_bound + 1) * per_level + 64, (1ull << 30) / 4);  // <= 1 GiB per workgroup
+  const uint64_t ring_stride = (uint64_t)msum + 4;
+  const uint64_t ring_ints = a.kp.biwfa ? (uint64_t)pen.scope * pen.ncomp * ring_stride : 0;
+  auto al = [](uint64_t v) { return (v + 255) & ~255ull; };
+  uint64_t off = 0;
+  a.uni_slots = (uint32_t)(score_bound + 1);
+  a.off_gdesc = off; off = al(off + (uint64_t)a.uni_slots * 5 * sizeof(WfDesc));
+  a.off_arena_u = off; off = al(off + arena_ints * 4);
+  a.off_arena_f = off; off = al(off + ring_ints * 4);
+  a.off_arena_r = off; off = al(off + ring_ints * 4);
+  a.rle_cap = (uint32_t)(msum + 4);
+  a.off_rle_tmp = off; off = al(off + (uint64_t)a.rle_cap * 4);
+  a.off_rle_out = off; off = al(off + (uint64_t)a.rle_cap * 4);
+  a.off_run_start = off; off = al(off + (uint64_t)a.rle_cap * 4);
+  a.ws_per_block = off;
+  a.arena_uni_cap = (uint32_t)std::min<uint64_t>(arena_ints, 0xFFFFFFF0ull);
+  a.ring_stride = (uint32_t)ring_stride;
+  const int threads = L.threads > 0 ? L.threads : (p.span == 1 ? 256 : 64);
+  int64_t blocks = std::min<int64_t>(L.n_jobs_host, (int64_t)c->num_cus * (threads >= 256 ? 8 : 16));
+  blocks = std::min<int64_t>(blocks, (int64_t)(c->ws_limit / std::max<uint64_t>(a.ws_per_block, 1)));
+  if (blocks < 1) {
+    // shrink the per-workgroup arena to what the limit allows; overflowing jobs report TRGT_WF_OOM
+    const uint64_t fixed = a.ws_per_block - al(arena_ints * 4);
+    if (c->ws_limit <= fixed + 4096) return fail(c, TRGT_ERR_NOMEM, "wfa: workspace limit %llu B too small", (unsigned long long)c->ws_limit);
+    arena_ints = (c->ws_limit - fixed - 4096) / 4;
+    return fail(c, TRGT_ERR_NOMEM, "wfa: one workgroup needs %llu B of workspace, limit is %llu B", (unsigned long long)a.ws_per_block,
+                (unsigned long long)c->ws_limit);
+  }
+  void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
+  int rc;
+  if ((rc = dev_get(c, S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
+  if ((rc = dev_get(c, S_WFA_COUNTER, 16, &d_counter))) return rc;
+  if ((rc = dev_get(c, S_WFA_CELLS, 16, &d_cells))) return rc;
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
+  a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
+  a.jobs = L.jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host; a.n_jobs_dev = L.n_jobs_dev;
+  a.pat_base = L.pat_base; a.txt_base = L.txt_base;
+  a.status = L.status; a.score = L.score; a.n_match = L.n_match; a.span4 = L.span4; a.cigar = L.cigar; a.cigar_len = L.cigar_len;
+  a.ops = L.ops; a.ops_len = L.ops_len;
+  const uint64_t seq_need = ((uint64_t)mp + 15) / 16 * 16 + (uint64_t)mt + 16;
+  a.lds_seq_cap = (uint32_t)std::min<uint64_t>(seq_need, 32 * 1024);
+  if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
+  const size_t lds = a.lds_seq_cap;
+  KTimer t(c, TRGT_K_WFA);
+  const dim3 grid((unsigned)blocks), block((unsigned)threads);
+  switch (p.metric) {
+    case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;
+    case 1: hipLaunchKernelGGL(wfa_kernel<1>, grid, block, lds, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(wfa_kernel<2>, grid, block, lds, c->stream, a); break;
+    case 3: hipLaunchKernelGGL(wfa_kernel<3>, grid, block, lds, c->stream, a); break;
+    default: hipLaunchKernelGGL(wfa_kernel<4>, grid, block, lds, c->stream, a); break;
+  }
+  TRGT_HIP_TRY(c, hipGetLastError());
+  t.stop(0);
+  c->last_wfa_cells_dev = d_cells;
+  return TRGT_OK;
+}
+
+}  // namespace trgt
+
+using namespace trgt;
+
+extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs,
+                              const uint64_t* pat_off, const uint32_t* pat_len, const uint64_t* txt_off,
+                              const uint32_t* txt_len, int32_t* status, int32_t* score, int32_t* n_match, uint32_t* span4,
+                              uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
+                              const uint64_t* ops_off, uint32_t* ops_len) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: null argument");
+  if ((cigar && (!cigar_off || !cigar_len)) || (ops && (!ops_off || !ops_len)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: cigar/ops need their offset and length arrays");
+  if (n_jobs == 0) return TRGT_OK;
+  if (n_jobs > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: too many jobs");
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<JobDev> jobs((size_t)n_jobs);
+  WfaLaunch L;
+  uint64_t seq_total = 0, cigar_total = 0, ops_total = 0;
+  for (int64_t j = 0; j < n_jobs; ++j) {
+    JobDev& jd = jobs[(size_t)j];
+    jd.pat_off = pat_off[j]; jd.txt_off = txt_off[j]; jd.pat_len = pat_len[j]; jd.txt_len = txt_len[j]; jd.out_index = (uint32_t)j;
+    jd.cigar_off = cigar ? cigar_off[j] : 0; jd.ops_off = ops ? ops_off[j] : 0;
+    L.max_plen = std::max<int64_t>(L.max_plen, pat_len[j]); L.max_tlen = std::max<int64_t>(L.max_tlen, txt_len[j]);
+    L.max_sum = std::max<int64_t>(L.max_sum, (int64_t)pat_len[j] + txt_len[j]);
+    seq_total = std::max<uint64_t>(seq_total, std::max(pat_off[j] + pat_len[j], txt_off[j] + txt_len[j]));
+    if (cigar) cigar_total = std::max<uint64_t>(cigar_total, cigar_off[j] + pat_len[j] + txt_len[j] + 1);
+    if (ops) ops_total = std::max<uint64_t>(ops_total, ops_off[j] + pat_len[j] + txt_len[j]);
+  }
+  if (L.max_sum > (1 << 27)) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: sequences too long");
+  int rc;
+  const uint8_t* d_seq = nullptr;
+  if ((rc = dev_in(c, S_WFA_SEQ, seqs, (size_t)seq_total, &d_seq))) return rc;
+  void* d_jobs = nullptr;
+  if ((rc = dev_get(c, S_WFA_JOBS, jobs.size() * sizeof(JobDev), &d_jobs))) return rc;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), hipMemcpyHostToDevice, c->stream));
+  DevOut<int32_t> o_status, o_score, o_nm; DevOut<uint32_t> o_span, o_cigar, o_clen, o_olen; DevOut<uint8_t> o_ops;
+  if ((rc = o_status.init(c, S_WFA_STATUS, status, (size_t)n_jobs)) || (rc = o_score.init(c, S_WFA_SCORE, score, (size_t)n_jobs)) ||
+      (rc = o_nm.init(c, S_WFA_NMATCH, n_match, (size_t)n_jobs)) || (rc = o_span.init(c, S_WFA_SPAN, span4, (size_t)n_jobs * 4)) ||
+      (rc = o_cigar.init(c, S_WFA_CIGAR, cigar, (size_t)cigar_total)) || (rc = o_clen.init(c, S_WFA_CLEN, cigar_len, (size_t)n_jobs)) ||
+      (rc = o_ops.init(c, S_WFA_OPS, ops, (size_t)ops_total)) || (rc = o_olen.init(c, S_WFA_OLEN, ops_len, (size_t)n_jobs)))
+    return rc;
+  L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.n_jobs_dev = nullptr;
+  L.pat_base = d_seq; L.txt_base = d_seq;
+  L.status = o_status.dev; L.score = o_score.dev; L.n_match = o_nm.dev; L.span4 = o_span.dev; L.cigar = o_cigar.dev;
+  L.cigar_len = o_clen.dev; L.ops = o_ops.dev; L.ops_len = o_olen.dev;
+  if ((rc = wfa_launch(c, *p, L))) return rc;
+  if ((rc = o_status.finish(c)) || (rc = o_score.finish(c)) || (rc = o_nm.finish(c)) || (rc = o_span.finish(c)) ||
+      (rc = o_cigar.finish(c)) || (rc = o_clen.finish(c)) || (rc = o_ops.finish(c)) || (rc = o_olen.finish(c)))
+    return rc;
+  unsigned long long cells = 0;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
+  return TRGT_OK;
+}

@@ -1,0 +1,497 @@
+// trgt_amd/csrc/wfa_engine.hpp -- device-side wavefront alignment engine for gfx950.
+//
+// One workgroup works on one alignment at a time (persistent workgroups pull jobs from a global
+// counter because job cost varies by 100x).  Diagonals k of a wavefront are mapped to consecutive
+// lanes, T = blockDim.x diagonals per strip, so every wavefront read / write is a coalesced
+// 4-byte-per-lane access and the trim / termination reductions are one wave ballot + one LDS
+// atomic per wave.  The wavefront history needed by the back-trace is written ONCE to the
+// workgroup's HBM workspace (4 bytes per offset: the "4*W" term of the roofline model); the
+// descriptors (lo, hi, base) of the last 32 score levels are mirrored in LDS so that the
+// recurrences never wait on a descriptor load.  Sequences are staged into LDS when they fit.
+//
+// Semantics restated from WFA2-lib (un-vendored dependency of the reference):
+// recurrences / trimming / termination / back-trace priorities / wfadaptive cut-off / BiWFA
+// breakpoint search exactly as SURVEY.md Appendix A describes them and as the reference's
+// known-answer tests (src/wfaligner.rs:1136-1828) pin them.
+#pragma once
+#include "common.hpp"
+
+namespace trgt {
+namespace wfa {
+
+constexpr int32_t OFF_NULL = INT32_MIN / 2;  // WAVEFRONT_OFFSET_NULL
+constexpr uint32_t NOBASE = 0xFFFFFFFFu;
+constexpr int RING = 32;                      // LDS mirror depth of wavefront descriptors (>= max_score_scope)
+constexpr int KBIAS = 1 << 30;
+enum { CM = 0, CI1 = 1, CI2 = 2, CD1 = 3, CD2 = 4 };
+enum { ST_OK = 0, ST_END_REACHED = 1, ST_END_UNREACHABLE = 2, ST_OOM = 3 };
+enum { M_INDEL = 0, M_EDIT = 1, M_LINEAR = 2, M_AFFINE = 3, M_AFFINE2P = 4 };
+enum { I_FWD = 0, I_REV = 1, I_UNI = 2 };
+
+struct WfDesc { int lo, hi, lo_alloc; uint32_t base; };  // base == NOBASE: wavefront pointer is NULL; lo > hi: ->null
+
+struct Pen { int metric, x, o1, e1, o2, e2, scope, ncomp; };
+
+struct KParams {  // by-value kernel argument
+  Pen pen;
+  int span, pbf, pef, tbf, tef;  // -1 = sequence length
+  int scope_alignment, biwfa, heuristic, h_min_len, h_max_dist, h_steps, bi_min_score, bi_min_length;
+};
+
+struct Inst {  // one unidirectional aligner (forward / reverse / base)
+  const uint8_t* pp; const uint8_t* tp;
+  int plen, tlen, rev;
+  int span, pbf, pef, tbf, tef, cb, ce;
+  int modular;
+  WfDesc* gdesc; int n_slots;           // global descriptor history (full-history instance only)
+  int32_t* arena; uint32_t arena_cap, bump, stride;
+  int num_null_steps, steps_wait, status, end_score, end_k, end_off, cur;
+};
+
+struct Red {
+  int lo[5], hi[5];
+  unsigned long long term_key;  // (k + KBIAS) << 32 | offset, minimum = first terminating diagonal
+  int end_val, max_ak, min_dist, cand_lo, cand_hi, bp_k, flag, oom;
+};
+
+struct Breakpoint { int score, score_f, score_r, k_f, off_f, comp; };
+struct Seg { int pb, pl, tb, tl, cb, ce, rem, top; };
+
+struct Shared {
+  Inst inst[3];
+  WfDesc ring[3][RING * 5];
+  Red red;
+  Breakpoint bp;
+  Seg stack[64];
+  int sp, job, status, score, top_bp, rle_n, rle_tmp_n;
+  unsigned long long cells;
+};
+
+// Workgroup state lives in one file-scope LDS object so that the (non-inlined) engine functions address it as LDS.
+__shared__ Shared g_sh;
+#define sh g_sh
+
+__device__ __forceinline__ uint8_t seq_at(const uint8_t* p, int len, int rev, int i) { return p[rev ? len - 1 - i : i]; }
+
+__device__ __forceinline__ WfDesc null_desc() { WfDesc d; d.lo = 1; d.hi = -1; d.lo_alloc = 1; d.base = NOBASE; return d; }
+
+// wavefront_compute_get_*wavefront: NULL pointer or ->null are replaced by the canonical null wavefront
+__device__ __forceinline__ WfDesc fetch(int ii, int c, int s) {
+  if (s < 0) return null_desc();
+  WfDesc d = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+  if (d.base == NOBASE || d.lo > d.hi) return null_desc();
+  return d;
+}
+// raw pointer semantics (may be ->null); valid for s within the last RING levels
+__device__ __forceinline__ WfDesc fetch_raw(int ii, int c, int s) {
+  if (s < 0) return null_desc();
+  return sh.ring[ii][(s & (RING - 1)) * 5 + c];
+}
+__device__ __forceinline__ int32_t wf_get(const int32_t* __restrict__ arena, const WfDesc& d, int k) {
+  return (k >= d.lo && k <= d.hi) ? arena[d.base + (uint32_t)(k - d.lo_alloc)] : OFF_NULL;
+}
+__device__ __forceinline__ bool in_bounds(int32_t off, int k, int plen, int tlen) {
+  return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+}
+__device__ __forceinline__ void lim(const WfDesc& w, int dlo, int dhi, int& lo, int& hi) {
+  if (lo > w.lo + dlo) lo = w.lo + dlo;
+  if (hi < w.hi + dhi) hi = w.hi + dhi;
+}
+// wave-level "first / last lane with valid" -> LDS min/max (lanes hold ascending k)
+__device__ __forceinline__ void red_range(bool valid, int k, int* lo, int* hi) {
+  const unsigned long long m = __ballot(valid);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)m) - 1) atomicMin(lo, k);
+    if (lane == 63 - __clzll((long long)m)) atomicMax(hi, k);
+  }
+}
+__device__ __forceinline__ void red_first(bool valid, int k, int* lo) {
+  const unsigned long long m = __ballot(valid);
+  if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicMin(lo, k);
+}
+__device__ __forceinline__ void red_last(bool valid, int k, int* hi) {
+  const unsigned long long m = __ballot(valid);
+  if (m && (int)(threadIdx.x & 63) == 63 - __clzll((long long)m)) atomicMax(hi, k);
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ void red_reset(Red& r) {
+  for (int c = 0; c < 5; ++c) { r.lo[c] = INT32_MAX; r.hi[c] = INT32_MIN; }
+  r.term_key = ~0ull; r.end_val = OFF_NULL; r.max_ak = 0; r.min_dist = INT32_MAX; r.cand_lo = INT32_MAX; r.cand_hi = INT32_MIN;
+  r.bp_k = INT32_MAX; r.oom = 0;
+}
+
+// Extend one M cell (wavefront_extend_matches_packed_*), update termination / antidiagonal reductions.
+__device__ __forceinline__ int32_t extend_cell(const Inst& I, Red& red, int k, int32_t off, bool want_ak, int ak) {
+  int v = off - k, h = off;
+  const int plen = I.plen, tlen = I.tlen, rev = I.rev;
+  const uint8_t* pp = I.pp; const uint8_t* tp = I.tp;
+  while (v < plen && h < tlen && seq_at(pp, plen, rev, v) == seq_at(tp, tlen, rev, h)) { ++v; ++h; }
+  off = h;
+  if (I.span == 1) {  // wavefront_termination_endsfree
+    if ((h >= tlen && plen - v <= I.pef) || (v >= plen && tlen - h <= I.tef))
+      atomicMin(&red.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)off);
+  }
+  if (k == ak && I.ce == CM) red.end_val = off;
+  if (want_ak) atomicMax(&red.max_ak, 2 * off - k);
+  return off;
+}
+
+// thread 0: publish a finished descriptor (LDS mirror + global history)
+__device__ __forceinline__ void put_desc(int ii, int c, int s, const WfDesc& d) {
+  sh.ring[ii][(s & (RING - 1)) * 5 + c] = d;
+  Inst& I = sh.inst[ii];
+  if (!I.modular && s < I.n_slots) I.gdesc[(size_t)s * 5 + c] = d;
+}
+
+// thread 0: allocate `width` offsets for (score s, component slot ci of ncomp)
+__device__ __forceinline__ uint32_t wf_alloc(Inst& I, Red& red, int s, int ci, int ncomp, int scope, int width) {
+  if (width < 0) width = 0;
+  if (I.modular) {
+    if ((uint32_t)width > I.stride) { red.oom = 1; return 0; }
+    return (uint32_t)((s % scope) * ncomp + ci) * I.stride;
+  }
+  if (s >= I.n_slots || (unsigned long long)I.bump + (unsigned)width > I.arena_cap) { red.oom = 1; return 0; }
+  const uint32_t b = I.bump;
+  I.bump += (uint32_t)width;
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront_unialign_init: wavefront zero (+ heuristic clear).  All threads.
+__device__ __noinline__ void wf_init(int ii, const KParams& kp) {
+  Inst& I = sh.inst[ii];
+  const int tid = threadIdx.x, T = blockDim.x;
+  __syncthreads();
+  if (tid == 0) {
+    I.num_null_steps = 0; I.status = ST_OK; I.end_score = -1; I.steps_wait = kp.h_steps; I.bump = 0; I.cur = 0;
+    red_reset(sh.red);
+    for (int c = 0; c < 5; ++c) put_desc(ii, c, 0, null_desc());
+    const int ncomp = kp.pen.ncomp;
+    WfDesc d;
+    if (I.span == 0) {
+      d.lo = d.hi = d.lo_alloc = 0;
+      static const int slot_of[5] = {0, 1, 3, 2, 4};  // component -> allocation slot (M, I1, D1, I2, D2)
+      d.base = wf_alloc(I, sh.red, 0, slot_of[I.cb], ncomp, kp.pen.scope, 1);
+      if (!sh.red.oom) { I.arena[d.base] = 0; put_desc(ii, I.cb, 0, d); }
+      sh.cells += 1;
+    } else {
+      d.lo = d.lo_alloc = -I.pbf; d.hi = I.tbf;
+      d.base = wf_alloc(I, sh.red, 0, 0, ncomp, kp.pen.scope, I.tbf + I.pbf + 1);
+      if (!sh.red.oom) put_desc(ii, CM, 0, d);
+      sh.cells += (unsigned long long)(I.tbf + I.pbf + 1);
+    }
+  }
+  __syncthreads();
+  if (sh.red.oom) { if (tid == 0) I.status = ST_OOM; __syncthreads(); return; }
+  if (I.span == 1) {
+    const WfDesc d = sh.ring[ii][CM];
+    for (int k = d.lo + tid; k <= d.hi; k += T) I.arena[d.base + (uint32_t)(k - d.lo_alloc)] = k > 0 ? k : 0;
+  }
+  __syncthreads();
+}
+
+// Extension of an existing M wavefront (score 0).  All threads.
+__device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
+  Inst& I = sh.inst[ii];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const WfDesc d = fetch_raw(ii, CM, s);
+  if (tid == 0) red_reset(sh.red);
+  __syncthreads();
+  if (d.base != NOBASE) {
+    const int ak = I.tlen - I.plen;
+    for (int k = d.lo + tid; k <= d.hi; k += T) {
+      int32_t off = I.arena[d.base + (uint32_t)(k - d.lo_alloc)];
+      if (off < 0) continue;
+      off = extend_cell(I, sh.red, k, off, want_ak, ak);
+      I.arena[d.base + (uint32_t)(k - d.lo_alloc)] = off;
+    }
+    if (I.ce != CM && tid == 0) {  // end component other than M at score 0: its single cell
+      const WfDesc e = fetch_raw(ii, I.ce, s);
+      if (e.base != NOBASE && ak >= e.lo && ak <= e.hi) sh.red.end_val = I.arena[e.base + (uint32_t)(ak - e.lo_alloc)];
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront_compute_{edit,linear,affine,affine2p} fused with the extension of the new M wavefront.
+// All threads.  On return the descriptors of score s are published and the reductions hold the
+// termination / antidiagonal data of M[s].
+template <int METRIC>
+__device__ __noinline__ void wf_compute_extend(int ii, int s, const KParams& kp, bool want_ak) {
+  Inst& I = sh.inst[ii];
+  Red& red = sh.red;
+  const Pen& pen = kp.pen;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int plen = I.plen, tlen = I.tlen, ak = tlen - plen;
+  constexpr int NCOMP = METRIC <= M_LINEAR ? 1 : (METRIC == M_AFFINE ? 3 : 5);
+  // ---- inputs (uniform)
+  WfDesc m_mis = null_desc(), m_o1 = null_desc(), m_o2 = null_desc(), i1e = null_desc(), d1e = null_desc(), i2e = null_desc(), d2e = null_desc();
+  int lo, hi;
+  bool all_null;
+  if (METRIC <= M_EDIT) {
+    m_mis = fetch_raw(ii, CM, s - 1);  // raw: wavefront_compute_edit uses the previous wavefront as is
+    if (m_mis.base == NOBASE) m_mis = null_desc();
+    lo = m_mis.lo - 1; hi = m_mis.hi + 1;
+    all_null = false;
+  } else if (METRIC == M_LINEAR) {
+    m_mis = fetch(ii, CM, s - pen.x); m_o1 = fetch(ii, CM, s - pen.o1);
+    all_null = m_mis.base == NOBASE && m_o1.base == NOBASE;
+    lo = m_mis.lo; hi = m_mis.hi; lim(m_o1, -1, +1, lo, hi);
+  } else {
+    m_mis = fetch(ii, CM, s - pen.x); m_o1 = fetch(ii, CM, s - pen.o1 - pen.e1);
+    i1e = fetch(ii, CI1, s - pen.e1); d1e = fetch(ii, CD1, s - pen.e1);
+    all_null = m_mis.base == NOBASE && m_o1.base == NOBASE && i1e.base == NOBASE && d1e.base == NOBASE;
+    lo = m_mis.lo; hi = m_mis.hi;
+    lim(m_o1, -1, +1, lo, hi); lim(i1e, +1, +1, lo, hi); lim(d1e, -1, -1, lo, hi);
+    if (METRIC == M_AFFINE2P) {
+      m_o2 = fetch(ii, CM, s - pen.o2 - pen.e2); i2e = fetch(ii, CI2, s - pen.e2); d2e = fetch(ii, CD2, s - pen.e2);
+      all_null = all_null && m_o2.base == NOBASE && i2e.base == NOBASE && d2e.base == NOBASE;
+      lim(m_o2, -1, +1, lo, hi); lim(i2e, +1, +1, lo, hi); lim(d2e, -1, -1, lo, hi);
+    }
+  }
+  __syncthreads();  // everyone has read the ring before thread 0 overwrites the slot of score s
+  if (all_null) {  // wavefront_compute_allocate_output_null
+    if (tid == 0) {
+      I.num_null_steps += 1;
+      for (int c = 0; c < 5; ++c) put_desc(ii, c, s, null_desc());
+      red_reset(red);
+      I.cur = s;
+    }
+    __syncthreads();
+    return;
+  }
+  const bool has_i1 = m_o1.base != NOBASE || i1e.base != NOBASE, has_d1 = m_o1.base != NOBASE || d1e.base != NOBASE;
+  const bool has_i2 = m_o2.base != NOBASE || i2e.base != NOBASE, has_d2 = m_o2.base != NOBASE || d2e.base != NOBASE;
+  const int width = hi - lo + 1;
+  if (tid == 0) {
+    I.num_null_steps = 0;
+    red_reset(red);
+    for (int c = 0; c < 5; ++c) put_desc(ii, c, s, null_desc());
+    WfDesc d; d.lo = d.lo_alloc = lo; d.hi = hi;
+    d.base = wf_alloc(I, red, s, 0, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CM] = d;
+    if (NCOMP >= 3) {
+      d.base = wf_alloc(I, red, s, 1, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CI1] = d;
+      d.base = wf_alloc(I, red, s, 2, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CD1] = d;
+    }
+    if (NCOMP == 5) {
+      d.base = wf_alloc(I, red, s, 3, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CI2] = d;
+      d.base = wf_alloc(I, red, s, 4, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CD2] = d;
+    }
+    sh.cells += (unsigned long long)(width > 0 ? width : 0) * NCOMP;
+  }
+  __syncthreads();
+  if (red.oom) { if (tid == 0) { I.status = ST_OOM; I.cur = s; } __syncthreads(); return; }
+  const uint32_t bM = sh.ring[ii][(s & (RING - 1)) * 5 + CM].base;
+  const uint32_t bI1 = sh.ring[ii][(s & (RING - 1)) * 5 + CI1].base, bD1 = sh.ring[ii][(s & (RING - 1)) * 5 + CD1].base;
+  const uint32_t bI2 = sh.ring[ii][(s & (RING - 1)) * 5 + CI2].base, bD2 = sh.ring[ii][(s & (RING - 1)) * 5 + CD2].base;
+  int32_t* __restrict__ A = I.arena;
+  // ---- strips of T diagonals
+  for (int kb = lo; kb <= hi; kb += T) {
+    const int k = kb + tid;
+    const bool act = k <= hi;
+    const uint32_t idx = (uint32_t)(k - lo);
+    int32_t mx = OFF_NULL, ins1 = OFF_NULL, del1 = OFF_NULL, ins2 = OFF_NULL, del2 = OFF_NULL;
+    if (act) {
+      if (METRIC == M_EDIT) {
+        const int32_t ins = wf_get(A, m_mis, k - 1), del = wf_get(A, m_mis, k + 1), mis = wf_get(A, m_mis, k);
+        mx = max(del, max(ins, mis) + 1);
+      } else if (METRIC == M_INDEL) {
+        const int32_t ins = wf_get(A, m_mis, k - 1), del = wf_get(A, m_mis, k + 1);
+        mx = max(del, ins + 1);
+      } else if (METRIC == M_LINEAR) {
+        const int32_t ins = wf_get(A, m_o1, k - 1), del = wf_get(A, m_o1, k + 1), mis = wf_get(A, m_mis, k);
+        mx = max(del, max(mis, ins) + 1);
+      } else {
+        ins1 = max(wf_get(A, m_o1, k - 1), wf_get(A, i1e, k - 1)) + 1;
+        del1 = max(wf_get(A, m_o1, k + 1), wf_get(A, d1e, k + 1));
+        const int32_t mis = wf_get(A, m_mis, k) + 1;
+        int32_t ins = ins1, del = del1;
+        if (METRIC == M_AFFINE2P) {
+          ins2 = max(wf_get(A, m_o2, k - 1), wf_get(A, i2e, k - 1)) + 1;
+          del2 = max(wf_get(A, m_o2, k + 1), wf_get(A, d2e, k + 1));
+          ins = max(ins1, ins2); del = max(del1, del2);
+        }
+        mx = max(del, max(mis, ins));
+        A[bI1 + idx] = ins1; A[bD1 + idx] = del1;
+        if (METRIC == M_AFFINE2P) { A[bI2 + idx] = ins2; A[bD2 + idx] = del2; }
+      }
+      if (!in_bounds(mx, k, plen, tlen)) mx = OFF_NULL;  // "adjust offset out of boundaries"
+      if (mx >= 0) mx = extend_cell(I, red, k, mx, want_ak, ak);
+      A[bM + idx] = mx;
+      if (NCOMP >= 3 && k == ak && I.ce != CM)
+        red.end_val = I.ce == CI1 ? ins1 : I.ce == CD1 ? del1 : I.ce == CI2 ? ins2 : del2;
+    }
+    // wavefront_compute_trim_ends: first / last in-bounds diagonal of every component
+    red_range(act && mx >= 0, k, &red.lo[CM], &red.hi[CM]);
+    if (NCOMP >= 3) {
+      red_range(act && in_bounds(ins1, k, plen, tlen), k, &red.lo[CI1], &red.hi[CI1]);
+      red_range(act && in_bounds(del1, k, plen, tlen), k, &red.lo[CD1], &red.hi[CD1]);
+    }
+    if (NCOMP == 5) {
+      red_range(act && in_bounds(ins2, k, plen, tlen), k, &red.lo[CI2], &red.hi[CI2]);
+      red_range(act && in_bounds(del2, k, plen, tlen), k, &red.lo[CD2], &red.hi[CD2]);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    auto fin = [&](int c, bool exists) {
+      WfDesc d = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+      if (!exists) d = null_desc();
+      else if (red.lo[c] == INT32_MAX) { d.hi = d.lo - 1; }  // nothing in bounds: ->null (lo > hi)
+      else { d.lo = red.lo[c]; d.hi = red.hi[c]; }
+      put_desc(ii, c, s, d);
+    };
+    fin(CM, true);
+    if (NCOMP >= 3) { fin(CI1, has_i1); fin(CD1, has_d1); }
+    if (NCOMP == 5) { fin(CI2, has_i2); fin(CD2, has_d2); }
+    if (METRIC <= M_EDIT && red.lo[CM] == INT32_MAX) I.num_null_steps = INT32_MAX;
+    I.cur = s;
+  }
+  __syncthreads();
+}
+
+// wf_distance_end2end / _endsfree for the wfadaptive cut-off
+__device__ __forceinline__ int wf_dist(const Inst& I, int32_t off, int k) {
+  if (off < 0) return -OFF_NULL;
+  const int left_v = I.plen - (off - k), left_h = I.tlen - off;
+  if (I.span == 0) return max(left_v, left_h);
+  return min(max(left_h, left_v - I.pef), max(left_v, left_h - I.tef));
+}
+
+// wavefront_heuristic_cufoff (wfadaptive).  All threads.
+__device__ __noinline__ void wf_heuristic_cutoff(int ii, int s, const KParams& kp) {
+  Inst& I = sh.inst[ii];
+  Red& red = sh.red;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const WfDesc m = fetch_raw(ii, CM, s);
+  if (m.base == NOBASE || m.lo > m.hi) return;  // uniform
+  __syncthreads();
+  if (tid == 0) { I.steps_wait -= 1; red.min_dist = max(I.plen, I.tlen); red.cand_lo = INT32_MAX; red.cand_hi = INT32_MIN; }
+  __syncthreads();
+  const bool run = I.steps_wait <= 0 && (m.hi - m.lo + 1) >= kp.h_min_len;
+  if (run) {
+    const int32_t* __restrict__ A = I.arena;
+    for (int kb = m.lo; kb <= m.hi; kb += T) {
+      const int k = kb + tid;
+      int d = INT32_MAX;
+      if (k <= m.hi) d = wf_dist(I, A[m.base + (uint32_t)(k - m.lo_alloc)], k);
+      d = wave_min(d);
+      if ((tid & 63) == 0) atomicMin(&red.min_dist, d);
+    }
+    __syncthreads();
+    const int min_d = red.min_dist, ak = I.tlen - I.plen, thr = kp.h_max_dist;
+    const int top_limit = min(ak, m.hi), bottom_limit = max(ak, m.lo);  // wf_heuristic_wfadaptive_reduce
+    for (int kb = m.lo; kb <= m.hi; kb += T) {
+      const int k = kb + tid;
+      bool keep = false;
+      if (k <= m.hi) keep = wf_dist(I, A[m.base + (uint32_t)(k - m.lo_alloc)], k) - min_d <= thr;
+      red_first(keep && k < top_limit, k, &red.cand_lo);
+      red_last(keep && k > bottom_limit, k, &red.cand_hi);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    WfDesc d = m;
+    if (run) {
+      const int ak = I.tlen - I.plen;
+      const int top_limit = min(ak, m.hi);
+      int lo_red = m.lo;
+      if (top_limit > m.lo) lo_red = red.cand_lo != INT32_MAX ? red.cand_lo : top_limit;
+      d.lo = lo_red;
+      const int bottom_limit = max(ak, d.lo);
+      int hi_red = m.hi;
+      if (m.hi > bottom_limit) hi_red = (red.cand_hi != INT32_MIN && red.cand_hi > bottom_limit) ? red.cand_hi : bottom_limit;
+      d.hi = hi_red;
+      I.steps_wait = kp.h_steps;
+    }
+    put_desc(ii, CM, s, d);
+    if (kp.pen.metric > M_LINEAR) {  // wavefront_heuristic_equate
+      auto equate = [&](int c) {
+        WfDesc e = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+        if (e.base == NOBASE) return;
+        if (d.lo > e.lo) e.lo = d.lo;
+        if (d.hi < e.hi) e.hi = d.hi;
+        put_desc(ii, c, s, e);
+      };
+      equate(CI1); equate(CD1);
+      if (kp.pen.metric == M_AFFINE2P) { equate(CI2); equate(CD2); }
+    }
+  }
+  __syncthreads();
+}
+
+// Post-extension part of wavefront_extend_{end2end,end2end_max,endsfree}.  All threads; returns 1 when done.
+__device__ __noinline__ int wf_post_extend(int ii, int s, const KParams& kp, bool act_on_end, int* max_ak) {
+  Inst& I = sh.inst[ii];
+  Red& red = sh.red;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid == 0) {
+    int done = 0, cont_heur = 0;
+    const WfDesc m = fetch_raw(ii, CM, s);
+    const bool m_ptr = m.base != NOBASE, m_null = m.lo > m.hi;
+    bool stop_here = false;
+    if (I.status == ST_OOM) { done = 1; stop_here = true; }
+    if (!stop_here && (!m_ptr || m_null)) {
+      if (!m_ptr || kp.pen.metric <= M_EDIT) {
+        if (I.num_null_steps > kp.pen.scope) { I.status = ST_END_UNREACHABLE; I.end_score = s; done = 1; stop_here = true; }
+      }
+      if (!stop_here && !m_ptr) stop_here = true;  // not done, nothing to extend
+    }
+    if (!stop_here) {
+      bool end_reached = false;
+      if (I.span == 1) {
+        if (red.term_key != ~0ull) {
+          end_reached = true;
+          I.end_score = s; I.end_k = (int)(red.term_key >> 32) - KBIAS; I.end_off = (int)(red.term_key & 0xFFFFFFFFu);
+        }
+      } else {
+        const int ak = I.tlen - I.plen;
+        const WfDesc e = fetch_raw(ii, I.ce, s);
+        if (e.base != NOBASE && ak >= e.lo && ak <= e.hi && red.end_val >= I.tlen) {
+          end_reached = true; I.end_score = s; I.end_k = ak; I.end_off = I.tlen;
+        }
+      }
+      if (end_reached && act_on_end) { I.status = ST_END_REACHED; done = 1; }
+      else cont_heur = kp.heuristic != 0;
+    }
+    red.flag = done | (cont_heur << 1);
+  }
+  __syncthreads();
+  const int f = red.flag;
+  const int mak = red.max_ak;
+  if (f & 2) wf_heuristic_cutoff(ii, s, kp);
+  if (max_ak) *max_ak = (f & 1) ? 0 : mak;
+  return f & 1;
+}
+
+// One score step: compute + extend + post.  All threads.
+template <int METRIC>
+__device__ __forceinline__ int wf_step(int ii, int s, const KParams& kp, bool act_on_end, int* max_ak) {
+  wf_compute_extend<METRIC>(ii, s, kp, max_ak != nullptr);
+  return wf_post_extend(ii, s, kp, act_on_end, max_ak);
+}
+
+// wavefront_unialign.  All threads; returns status.
+template <int METRIC>
+__device__ int wf_run(int ii, const KParams& kp) {
+  wf_init(ii, kp);
+  if (sh.inst[ii].status == ST_OOM) return ST_OOM;
+  wf_extend_only(ii, 0, false);
+  if (wf_post_extend(ii, 0, kp, true, nullptr)) return sh.inst[ii].status;
+  for (int s = 1;; ++s)
+    if (wf_step<METRIC>(ii, s, kp, true, nullptr)) return sh.inst[ii].status;
+}
+
+}  // namespace wfa
+}  // namespace trgt
