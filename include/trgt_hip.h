@@ -215,15 +215,22 @@ typedef struct trgt_synth_params {
   double sub_rate, del_rate, ins_rate, stutter_rate, truncate_rate; /* 5e-4, 2.5e-4, 2.5e-4, 0.05, 0.10 */
 } trgt_synth_params;
 void trgt_synth_default_params(trgt_synth_params* p, int config);
-/* Two-phase: sizes first (all outputs NULL except the size fields), then fill.  Locus indices are global
- * (first_locus .. first_locus+n_loci) so any shard regenerates exactly its own loci. */
-typedef struct trgt_synth_sizes { uint64_t flank_bytes, tr_bytes, motif_bytes, n_motifs, n_reads, read_bytes; } trgt_synth_sizes;
-int trgt_synth_sizes_for(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci, trgt_synth_sizes* sz);
-int trgt_synth_fill(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci,
-                    uint8_t* flank_blob, uint64_t* lf_off, uint32_t* lf_len, uint64_t* rf_off, uint32_t* rf_len,
-                    uint8_t* tr_blob, uint64_t* tr_off, uint32_t* tr_len,
-                    uint8_t* motif_blob, uint32_t* motif_off, uint32_t* set_motif_begin, uint8_t* ploidy,
-                    uint64_t* locus_read_begin, uint8_t* read_blob, uint64_t* read_off, uint32_t* read_len);
+/* Library-owned synthetic batch in exactly the trgt_locus_batch_in layout (host memory).  Locus indices are
+ * global (first_locus .. first_locus+n_loci): the per-locus RNG is splitmix64 seeded with
+ * seed ^ (locus_index+1)*0x9E3779B97F4A7C15, so any shard regenerates exactly its own loci. */
+typedef struct trgt_synth_batch {
+  int64_t n_loci, n_reads, n_motifs;
+  uint64_t flank_bytes, tr_bytes, motif_bytes, read_bytes;
+  uint8_t* flank_blob; uint64_t* lf_off; uint32_t* lf_len; uint64_t* rf_off; uint32_t* rf_len;
+  uint8_t* tr_blob; uint64_t* tr_off; uint32_t* tr_len;
+  uint8_t* motif_blob; uint32_t* motif_off; uint32_t* set_motif_begin; uint8_t* ploidy;
+  uint64_t* locus_read_begin; uint8_t* read_blob; uint64_t* read_off; uint32_t* read_len;
+  uint32_t* true_allele_len;   /* [2 * n_loci] ground truth (bp) */
+  uint8_t* read_hap;           /* per read: haplotype 0/1 */
+  uint8_t* read_truncated;     /* per read: 1 if cut (must end up with span None) */
+} trgt_synth_batch;
+int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci, int threads, trgt_synth_batch** out);
+void trgt_synth_free(trgt_synth_batch* b);
 
 #ifdef __cplusplus
 }

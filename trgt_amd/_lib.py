@@ -41,8 +41,13 @@ class SynthParams(C.Structure):
                 ("ins_rate", C.c_double), ("stutter_rate", C.c_double), ("truncate_rate", C.c_double)]
 
 
-class SynthSizes(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("flank_bytes", "tr_bytes", "motif_bytes", "n_motifs", "n_reads", "read_bytes")]
+class SynthBatch(C.Structure):
+    _fields_ = ([(n, C.c_int64) for n in ("n_loci", "n_reads", "n_motifs")] +
+                [(n, C.c_uint64) for n in ("flank_bytes", "tr_bytes", "motif_bytes", "read_bytes")] +
+                [(n, C.c_void_p) for n in ("flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len",
+                                           "motif_blob", "motif_off", "set_motif_begin", "ploidy", "locus_read_begin",
+                                           "read_blob", "read_off", "read_len", "true_allele_len", "read_hap",
+                                           "read_truncated")])
 
 
 _VP = C.c_void_p
@@ -65,7 +70,7 @@ EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity",
-    "trgt_locus_batch", "trgt_synth_default_params", "trgt_synth_sizes_for", "trgt_synth_fill",
+    "trgt_locus_batch", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 
@@ -113,8 +118,9 @@ def lib():
         L.trgt_wfa_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 15
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
         L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
-        L.trgt_synth_sizes_for.argtypes = [_VP, C.c_int64, C.c_int64, _VP]
-        L.trgt_synth_fill.argtypes = [_VP, C.c_int64, C.c_int64] + [_VP] * 17
+        L.trgt_synth_generate.argtypes = [_VP, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.POINTER(SynthBatch))]
+        L.trgt_synth_free.argtypes = [C.POINTER(SynthBatch)]
+        L.trgt_synth_free.restype = None
         L.trgt_synth_default_params.argtypes = [_VP, C.c_int]
         L.trgt_synth_default_params.restype = None
         L.trgt_wfa_default_params.argtypes = [_VP]

@@ -1,0 +1,412 @@
+// trgt_amd/csrc/locus.hip -- trgt_locus_batch: the per-locus genotyper contract for a whole batch.
+//
+// Replaces analyze_tr (PacificBiosciences/trgt v3.0.0 src/trgt/workflows/tr.rs:24-109) for reads that
+// are already clipped (tr.rs:33-34), Genotyper::Size, no HP tags / SNV offsets / methylation:
+//   stage A (GPU)   find_tr_spans                          span_locater.rs:32-68   -> spans.hip
+//   host glue       get_spanning_reads                     tr.rs:111-184
+//                   genotype_size::genotype up to the      genotype_size.rs:6-64, diploid.rs:5-103,
+//                   "needs consensus repair" decision      haploid.rs:3-30, consensus.rs:113-154
+//   stage B (GPU)   utils::align (BiWFA affine 2,5,1)      utils/align.rs:14-28    -> wfa.hip
+//   host glue       repair_consensus, classification,      consensus.rs:5-111, genotype_size.rs:42-61,
+//                   reference allele first                 tr.rs:95-101
+//   stage C (GPU)   label_with_hmm                         tr.rs:454-492           -> hmm.hip
+// genotype_flank::genotype (tr.rs:70-75) returns None for such reads and is not on this path.
+// The host glue is integer / byte work of a few microseconds per locus, spread over host threads;
+// moving it onto the device is SURVEY.md 8(f) row 1.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <thread>
+
+#include "wfa_host.hpp"
+
+namespace trgt {
+
+int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
+                      const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
+                      const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit);
+
+namespace {
+
+struct Seg { const uint8_t* p; uint32_t n; };
+inline int cmp_seg(const Seg& a, const Seg& b) {
+  const int c = std::memcmp(a.p, b.p, std::min(a.n, b.n));
+  return c ? c : (a.n < b.n ? -1 : (a.n > b.n ? 1 : 0));
+}
+inline bool eq_seg(const Seg& a, const Seg& b) { return a.n == b.n && std::memcmp(a.p, b.p, a.n) == 0; }
+inline uint32_t adiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+struct ConsensusJob { int allele; std::vector<int> members; };  // members: indices into LocusWork::uniq
+
+struct LocusWork {
+  std::vector<uint32_t> kept;       // input-read index of every kept spanning read, LocusResult.reads order
+  std::vector<Seg> trs;             // their repeat segments
+  int n_gt = 0;
+  uint32_t size[2] = {0, 0}; uint32_t ci[4] = {0, 0, 0, 0};
+  std::vector<Seg> uniq; std::vector<uint32_t> ucount;
+  std::vector<std::string> alleles;
+  std::vector<ConsensusJob> repairs;
+  std::vector<int> cls;
+};
+
+// diploid::genotype (diploid.rs:5-103)
+void genotype_diploid(const std::vector<uint32_t>& sizes, const std::vector<uint32_t>& counts, LocusWork& w) {
+  double best_pen = 0; bool have = false; uint32_t bs = 0, bl = 0;
+  for (size_t si = 0; si < sizes.size(); ++si)
+    for (size_t li = si; li < sizes.size(); ++li) {
+      const uint32_t sa = sizes[si], la = sizes[li];
+      const double max_frac = adiff(sa, la) <= 100 ? 0.25 : 0.05;
+      double pen = 0.0;
+      for (size_t i = 0; i < sizes.size(); ++i) {
+        const uint32_t st = sizes[i] != sa ? 10 + 2 * adiff(sa, sizes[i]) : 0, lt = sizes[i] != la ? 10 + 2 * adiff(la, sizes[i]) : 0;
+        const double term = (double)std::min(st, lt) + max_frac * (double)std::max(st, lt);
+        pen += term * (double)counts[i];
+      }
+      if (!have || pen < best_pen) { have = true; best_pen = pen; bs = sa; bl = la; }  // stable sort, first minimum
+    }
+  uint32_t short_size = std::min(bs, bl), long_size = std::max(bs, bl);
+  if (short_size != long_size && sizes.size() >= 2) {
+    uint64_t coverage = 0;
+    size_t top = 0;
+    for (size_t i = 0; i < counts.size(); ++i) { coverage += counts[i]; if (counts[i] > counts[top]) top = i; }  // stable desc sort, first
+    const double top_frac = (double)counts[top] / (double)coverage;
+    const uint32_t range = *std::max_element(sizes.begin(), sizes.end()) - *std::min_element(sizes.begin(), sizes.end());
+    if (top_frac > 0.60 && range <= 6) short_size = long_size = sizes[top];
+  }
+  w.n_gt = 2; w.size[0] = short_size; w.size[1] = long_size;
+  w.ci[0] = w.ci[1] = short_size; w.ci[2] = w.ci[3] = long_size;
+  for (uint32_t s : sizes) {
+    if (adiff(s, short_size) <= adiff(s, long_size)) { w.ci[0] = std::min(w.ci[0], s); w.ci[1] = std::max(w.ci[1], s); }
+    else { w.ci[2] = std::min(w.ci[2], s); w.ci[3] = std::max(w.ci[3], s); }
+  }
+}
+
+// haploid::genotype (haploid.rs:3-30)
+void genotype_haploid(const std::vector<uint32_t>& sizes, const std::vector<uint32_t>& counts, LocusWork& w) {
+  size_t best = 0; double best_pen = 0;
+  for (size_t a = 0; a < sizes.size(); ++a) {
+    double pen = 0.0;
+    for (size_t i = 0; i < sizes.size(); ++i) {
+      const double term = sizes[i] != sizes[a] ? 10.0 + 2.0 * (double)adiff(sizes[a], sizes[i]) : 0.0;
+      pen += term * (double)counts[i];
+    }
+    if (a == 0 || pen < best_pen) { best = a; best_pen = pen; }
+  }
+  w.n_gt = 1; w.size[0] = sizes[best];
+  w.ci[0] = *std::min_element(sizes.begin(), sizes.end()); w.ci[1] = *std::max_element(sizes.begin(), sizes.end());
+}
+
+// genotype_size::genotype up to the point where consensus alignments are needed (genotype_size.rs:6-37)
+void genotype_size_front(int ploidy, LocusWork& w) {
+  std::vector<uint32_t> lens;
+  for (auto& s : w.trs) lens.push_back(s.n);
+  std::sort(lens.begin(), lens.end());
+  std::vector<uint32_t> ulen, ucnt;
+  for (size_t i = 0; i < lens.size();) { size_t j = i; while (j < lens.size() && lens[j] == lens[i]) ++j; ulen.push_back(lens[i]); ucnt.push_back((uint32_t)(j - i)); i = j; }
+  if (ploidy == 1) genotype_haploid(ulen, ucnt, w); else genotype_diploid(ulen, ucnt, w);
+  // get_seq_hist: unique sequences in byte-lexicographic order
+  std::vector<Seg> sorted = w.trs;
+  std::sort(sorted.begin(), sorted.end(), [](const Seg& a, const Seg& b) { return cmp_seg(a, b) < 0; });
+  for (size_t i = 0; i < sorted.size();) {
+    size_t j = i;
+    while (j < sorted.size() && eq_seg(sorted[j], sorted[i])) ++j;
+    w.uniq.push_back(sorted[i]); w.ucount.push_back((uint32_t)(j - i));
+    i = j;
+  }
+  auto closest = [&](uint32_t target) { uint32_t c = w.uniq[0].n; for (auto& s : w.uniq) if (adiff(c, target) > adiff(s.n, target)) c = s.n; return c; };
+  auto most_frequent = [&](uint32_t len) { int best = -1; for (size_t i = 0; i < w.uniq.size(); ++i) if (w.uniq[i].n == len && (best < 0 || w.ucount[i] >= w.ucount[best])) best = (int)i; return best; };
+  std::vector<int> pick{most_frequent(closest(w.size[0]))};
+  if (w.n_gt != 1 && w.size[0] != w.size[1]) pick.push_back(most_frequent(closest(w.size[1])));
+  for (size_t a = 0; a < pick.size(); ++a) {
+    w.alleles.emplace_back((const char*)w.uniq[pick[a]].p, w.uniq[pick[a]].n);
+    // split(): members of this allele's group
+    ConsensusJob job; job.allele = (int)a;
+    uint64_t coverage = 0, ref_count = 0;
+    for (size_t i = 0; i < w.uniq.size(); ++i) {
+      bool in;
+      if (w.n_gt == 1) in = true;
+      else {
+        const uint32_t d1 = adiff(w.uniq[i].n, w.size[0]), d2 = adiff(w.uniq[i].n, w.size[1]);
+        in = a == 0 ? d1 <= d2 : d2 < d1;
+      }
+      if (!in) continue;
+      job.members.push_back((int)i);
+      coverage += w.ucount[i];
+      if ((int)i == pick[a]) ref_count = w.ucount[i];
+    }
+    if (!(2 * ref_count >= coverage)) w.repairs.push_back(std::move(job));
+  }
+}
+
+// repair_consensus (consensus.rs:5-111); cigars[m] = run-length CIGAR (len<<4|code) of member m vs the backbone
+std::string repair_consensus(const std::string& backbone, const std::vector<Seg>& seqs, const std::vector<std::vector<uint32_t>>& cigars) {
+  const size_t L = backbone.size(), n = seqs.size();
+  std::vector<std::array<int, 5>> votes(L, std::array<int, 5>{0, 0, 0, 0, 0});
+  std::vector<std::vector<std::string>> inserts(L + 1);
+  for (size_t m = 0; m < n; ++m) {
+    size_t x = 0, y = 0;
+    for (uint32_t e : cigars[m]) {
+      const size_t len = e >> 4; const uint32_t code = e & 0xF;
+      if (code == 7 || code == 8 || code == 0) {
+        for (size_t i = 0; i < len; ++i) {
+          const uint8_t b = seqs[m].p[x + i];
+          const int bi = b == 'A' ? 0 : b == 'T' ? 1 : b == 'C' ? 2 : 3;
+          votes[y + i][bi] += 1;
+        }
+        x += len; y += len;
+      } else if (code == 2) { for (size_t i = 0; i < len; ++i) votes[y + i][4] += 1; y += len; }
+      else if (code == 1) { inserts[y].emplace_back((const char*)seqs[m].p + x, len); x += len; }
+    }
+  }
+  std::string out;
+  for (size_t pos = 0; pos < L; ++pos) {
+    int best = 0;
+    for (int i = 1; i < 5; ++i) if (votes[pos][i] >= votes[pos][best]) best = i;  // max_by_key: last maximum
+    if (inserts[pos].size() > n / 2) {
+      auto& ins = inserts[pos];
+      std::sort(ins.begin(), ins.end());
+      const size_t without = n - ins.size();
+      size_t top_count = 0; const std::string* top = nullptr;
+      for (size_t i = 0; i < ins.size();) { size_t j = i; while (j < ins.size() && ins[j] == ins[i]) ++j; if (j - i > top_count) { top_count = j - i; top = &ins[i]; } i = j; }
+      if (top_count > without) out += *top;
+    }
+    if (best != 4) out.push_back("ATCG"[best]);
+  }
+  return out;
+}
+
+template <typename F>
+void parallel_for(int64_t n, int threads, F f) {
+  if (threads <= 1 || n < 64) { for (int64_t i = 0; i < n; ++i) f(i); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    const int64_t b = t * chunk, e = std::min<int64_t>(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([=]() { for (int64_t i = b; i < e; ++i) f(i); });
+  }
+  for (auto& x : th) x.join();
+}
+
+struct GatherArgs { const uint8_t* reads; const uint64_t* src_off; const uint64_t* dst_off; const uint32_t* len; uint64_t n; uint8_t* out; };
+__global__ void gather_segments_kernel(const GatherArgs a) {  // one wavefront per segment
+  const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= a.n) return;
+  const uint8_t* __restrict__ src = a.reads + a.src_off[s];
+  uint8_t* __restrict__ dst = a.out + a.dst_off[s];
+  for (uint32_t i = threadIdx.x & 63; i < a.len[s]; i += 64) dst[i] = src[i];
+}
+
+inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+}  // namespace trgt
+
+using namespace trgt;
+
+extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
+  const int64_t nl = in->n_loci;
+  if (nl < 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: negative n_loci");
+  if (nl == 0) return TRGT_OK;
+  if (!in->flank_blob || !in->lf_off || !in->lf_len || !in->rf_off || !in->rf_len || !in->tr_blob || !in->tr_off || !in->tr_len ||
+      !in->motif_blob || !in->motif_off || !in->set_motif_begin || !in->ploidy || !in->locus_read_begin || !in->read_blob ||
+      !in->read_off || !in->read_len || !out->span_start || !out->span_end || !out->n_alleles || !out->allele_blob ||
+      !out->allele_off || !out->allele_cap || !out->allele_len || !out->ci || !out->num_spanning || !out->classification ||
+      !out->read_rank || !out->spans3 || !out->span_off || !out->n_spans || !out->motif_counts || !out->count_off || !out->purity)
+    return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null field");
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  const int F = p->flank_len;
+  const int64_t nr = (int64_t)in->locus_read_begin[nl];
+  int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+  int64_t t0 = now_ns(), tA = 0, tB = 0, tC = 0, tHost = 0;
+  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0;
+  for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
+  for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
+  if (nr == 0) return TRGT_OK;
+  // ---------------- stage A: flank location on the GPU
+  trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
+  std::vector<uint8_t> lf_hit((size_t)nr), rf_hit((size_t)nr);
+  int rc = trgt_find_spans_batch(c, &sp, nl, in->flank_blob, in->lf_off, in->lf_len, in->rf_off, in->rf_len, in->locus_read_begin,
+                                 in->read_blob, in->read_off, in->read_len, out->span_start, out->span_end, lf_hit.data(), rf_hit.data());
+  if (rc) return rc;
+  for (int64_t r = 0; r < nr; ++r) stat_flank_jobs += (lf_hit[r] != 1) + (rf_hit[r] != 1);
+  tA = now_ns() - t0;
+  // ---------------- host: spanning reads (tr.rs:111-184); repeat segments gathered from HBM when the reads live there
+  int64_t th0 = now_ns();
+  std::vector<LocusWork> work((size_t)nl);
+  const bool reads_on_device = is_device_ptr(in->read_blob);
+  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len;
+  std::vector<uint64_t> locus_seg_begin((size_t)nl + 1, 0);
+  for (int64_t l = 0; l < nl; ++l) {
+    LocusWork& w = work[(size_t)l];
+    locus_seg_begin[l] = seg_src.size();
+    if (in->ploidy[l] == 0) continue;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+    struct K { uint32_t read, s, e; };
+    std::vector<K> ks;
+    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+      const int32_t s = out->span_start[r], e = out->span_end[r];
+      if (s < 0) continue;
+      if (s >= F && (int64_t)in->read_len[r] - e >= F) ks.push_back({(uint32_t)r, (uint32_t)s, (uint32_t)e});
+    }
+    std::stable_sort(ks.begin(), ks.end(), [](const K& a, const K& b) { return (a.e - a.s) < (b.e - b.s); });
+    if ((int64_t)ks.size() > p->max_depth) {  // uniform_downsample (tr.rs:172-184)
+      const double step = (double)ks.size() / (double)p->max_depth;
+      double fast = 0.0;
+      for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
+      ks.resize((size_t)p->max_depth);
+    }
+    uint64_t dst = seg_dst.empty() ? 0 : seg_dst.back() + seg_len.back();
+    for (auto& k : ks) {
+      w.kept.push_back(k.read);
+      seg_src.push_back(in->read_off[k.read] + k.s); seg_dst.push_back(dst); seg_len.push_back(k.e - k.s);
+      dst += k.e - k.s;
+    }
+  }
+  locus_seg_begin[nl] = seg_src.size();
+  stat_spanning = (int64_t)seg_src.size();
+  std::vector<uint8_t> seg_bytes;
+  const uint8_t* seg_base = nullptr;
+  if (!seg_src.empty()) {
+    const uint64_t total = seg_dst.back() + seg_len.back();
+    if (reads_on_device) {
+      seg_bytes.resize((size_t)total + 1);
+      void *d_src, *d_dst, *d_len, *d_out;
+      if ((rc = dev_get(c, S_LOCUS_0, seg_src.size() * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, seg_dst.size() * 8, &d_dst)) ||
+          (rc = dev_get(c, S_LOCUS_2, seg_len.size() * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)total + 1, &d_out)))
+        return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), seg_src.size() * 8, hipMemcpyHostToDevice, c->stream));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), seg_dst.size() * 8, hipMemcpyHostToDevice, c->stream));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, c->stream));
+      GatherArgs ga{in->read_blob, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)seg_src.size(), (uint8_t*)d_out};
+      hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((seg_src.size() + 3) / 4)), dim3(256), 0, c->stream, ga);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      TRGT_HIP_TRY(c, hipMemcpyAsync(seg_bytes.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      seg_base = seg_bytes.data();
+    }
+  }
+  // ---------------- host: length genotyping front half, threaded over loci
+  parallel_for(nl, threads, [&](int64_t l) {
+    LocusWork& w = work[(size_t)l];
+    if (w.kept.empty()) return;
+    for (uint64_t s = locus_seg_begin[l]; s < locus_seg_begin[l + 1]; ++s)
+      w.trs.push_back(reads_on_device ? Seg{seg_base + seg_dst[s], seg_len[s]} : Seg{in->read_blob + seg_src[s], seg_len[s]});
+    genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, w);
+  });
+  tHost += now_ns() - th0;
+  // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
+  int64_t tb0 = now_ns();
+  struct JobRef { int64_t locus; int repair, member; };
+  std::vector<JobRef> jrefs;
+  std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
+  for (int64_t l = 0; l < nl; ++l)
+    for (size_t ri = 0; ri < work[(size_t)l].repairs.size(); ++ri) {
+      LocusWork& w = work[(size_t)l];
+      const std::string& bb = w.alleles[w.repairs[ri].allele];
+      const uint64_t bo = cblob.size();
+      cblob.insert(cblob.end(), bb.begin(), bb.end());
+      for (size_t m = 0; m < w.repairs[ri].members.size(); ++m) {
+        const Seg& s = w.uniq[w.repairs[ri].members[m]];
+        poff.push_back(bo); plen.push_back((uint32_t)bb.size());
+        toff.push_back(cblob.size()); tlen.push_back(s.n);
+        cblob.insert(cblob.end(), s.p, s.p + s.n);
+        coff.push_back(coff.empty() ? 0 : coff.back() + plen[plen.size() - 2] + tlen[tlen.size() - 2] + 1);
+        jrefs.push_back({l, (int)ri, (int)m});
+      }
+    }
+  std::vector<uint32_t> cigars, clen(jrefs.size());
+  if (!jrefs.empty()) {
+    trgt_wfa_params wp;
+    trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
+    wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+    cigars.resize((size_t)(coff.back() + plen.back() + tlen.back() + 1));
+    rc = trgt_wfa_batch(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
+                        nullptr, nullptr, cigars.data(), coff.data(), clen.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    stat_cons_jobs = (int64_t)jrefs.size();
+  }
+  tB = now_ns() - tb0;
+  // ---------------- host: repair_consensus, classification, reference allele first, output assembly
+  th0 = now_ns();
+  {
+    size_t j = 0;
+    for (int64_t l = 0; l < nl; ++l) {
+      LocusWork& w = work[(size_t)l];
+      for (size_t ri = 0; ri < w.repairs.size(); ++ri) {
+        std::vector<Seg> seqs; std::vector<std::vector<uint32_t>> cg;
+        for (size_t m = 0; m < w.repairs[ri].members.size(); ++m, ++j) {
+          seqs.push_back(w.uniq[w.repairs[ri].members[m]]);
+          cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
+        }
+        w.alleles[w.repairs[ri].allele] = repair_consensus(w.alleles[w.repairs[ri].allele], seqs, cg);
+      }
+    }
+  }
+  int bad = 0;
+  parallel_for(nl, threads, [&](int64_t l) {
+    LocusWork& w = work[(size_t)l];
+    if (w.kept.empty()) return;
+    const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
+    if (ploidy == 2 && w.alleles.size() == 1) w.alleles.push_back(w.alleles[0]);
+    w.cls.assign(w.trs.size(), 0);
+    int tie = 1;
+    if (w.alleles.size() == 2)
+      for (size_t i = 0; i < w.trs.size(); ++i) {
+        const uint32_t d1 = adiff(w.trs[i].n, (uint32_t)w.alleles[0].size()), d2 = adiff(w.trs[i].n, (uint32_t)w.alleles[1].size());
+        if (d1 < d2) w.cls[i] = 0; else if (d1 > d2) w.cls[i] = 1; else { tie = (tie + 1) % 2; w.cls[i] = tie; }
+      }
+    int by_hap[2] = {0, 0};
+    for (int cc : w.cls) by_hap[cc] += 1;
+    int order[2] = {0, 1};
+    const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};
+    auto is_ref = [&](const std::string& a) { return a.size() == ref.n && std::memcmp(a.data(), ref.p, ref.n) == 0; };
+    if (w.n_gt != 1 && !is_ref(w.alleles[0]) && is_ref(w.alleles[1])) {  // tr.rs:95-101
+      order[0] = 1; order[1] = 0;
+      for (int& cc : w.cls) cc = 1 - cc;
+    }
+    out->n_alleles[l] = w.n_gt;
+    for (int oi = 0; oi < w.n_gt; ++oi) {
+      const int a = order[oi];
+      const std::string& s = w.alleles[a];
+      if (s.size() > out->allele_cap[l]) { bad = 1; return; }
+      std::memcpy(out->allele_blob + out->allele_off[2 * l + oi], s.data(), s.size());
+      out->allele_len[2 * l + oi] = (uint32_t)s.size();
+      out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
+      out->num_spanning[2 * l + oi] = by_hap[a];
+    }
+    for (size_t i = 0; i < w.kept.size(); ++i) { out->classification[w.kept[i]] = w.cls[i]; out->read_rank[w.kept[i]] = (int32_t)i; }
+  });
+  if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
+  tHost += now_ns() - th0;
+  // ---------------- stage C: label_with_hmm for every allele
+  int64_t tc0 = now_ns();
+  std::vector<uint32_t> job_set, seq_len, nsp; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<double> pur;
+  std::vector<int64_t> slot;
+  for (int64_t l = 0; l < nl; ++l)
+    for (int a = 0; a < out->n_alleles[l]; ++a) {
+      job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
+      span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+    }
+  for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
+  if (!job_set.empty()) {
+    nsp.resize(job_set.size()); pur.resize(job_set.size());
+    rc = trgt_hmm_batch(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
+                        out->allele_blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(),
+                        nsp.data(), out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
+  }
+  tC = now_ns() - tc0;
+  if (out->stats) {
+    int64_t* s = out->stats;
+    s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = (int64_t)job_set.size();
+    s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
+    for (int i = 9; i < 16; ++i) s[i] = 0;
+  }
+  return TRGT_OK;
+}

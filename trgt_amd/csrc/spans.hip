@@ -1,0 +1,212 @@
+// trgt_amd/csrc/spans.hip -- trgt_find_spans_batch: locate the repeat inside every read.
+//
+// Replaces find_spans / find_tr_spans of PacificBiosciences/trgt v3.0.0
+// (src/trgt/genotype/span_locater.rs:7-68): per read and per flank piece, the leftmost exact
+// occurrence (windows().position(), :10-12), else a gap-affine ends-free wavefront alignment of the
+// piece against the whole read (THREAD_WFA_FLANK, src/commands/genotype.rs:66-80; :14-26) accepted
+// when count_matches() >= flank_len * min_flank_id_frac; the two flank hits are combined into the
+// repeat span (:52-66).
+//
+// Three launches on the ctx stream, no host round trip in between:
+//   1. flank_scan_kernel   one wavefront per (read, side): 64 candidate starts per round, 4-byte
+//                          filter then full verify, ballot -> leftmost hit.  Misses are appended
+//                          to a device-side job list (atomic counter).
+//   2. wfa_kernel          (wfa.hip) persistent workgroups drain that list.
+//   3. span_combine_kernel per read: threshold test and (lf.end, rf.start) combination.
+#include <algorithm>
+
+#include "wfa_host.hpp"
+
+namespace trgt {
+
+struct ScanArgs {
+  const uint8_t* flank_blob; const uint8_t* read_blob;
+  const uint64_t* piece_off;   // [2 * n_loci] left piece, right piece (offsets into flank_blob)
+  const uint64_t* read_off; const uint32_t* read_len; const uint32_t* read_locus;
+  uint64_t n_jobs;             // 2 * n_reads
+  int32_t flank_len;
+  int32_t* pos;                // [n_jobs] leftmost exact start or -1
+  JobDev* wfa_jobs; uint32_t* wfa_count;
+};
+
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
+  const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= a.n_jobs) return;  // whole wave exits together
+  const int lane = threadIdx.x & 63;
+  const uint64_t r = j >> 1;
+  const int side = (int)(j & 1);
+  const int F = a.flank_len, n = (int)a.read_len[r];
+  const uint8_t* __restrict__ piece = a.flank_blob + a.piece_off[2 * (uint64_t)a.read_locus[r] + side];
+  const uint8_t* __restrict__ read = a.read_blob + a.read_off[r];
+  int found = -1;
+  if (n >= F) {
+    const int last = n - F;  // last candidate start
+    const uint32_t head = F >= 4 ? load_u32(piece) : 0;
+    for (int base = 0; base <= last && found < 0; base += 64) {
+      const int p = base + lane;
+      bool hit = false;
+      if (p <= last) {
+        hit = F < 4 || load_u32(read + p) == head;
+        if (hit) {
+          int i = F >= 4 ? 4 : 0;
+          for (; i + 4 <= F; i += 4)
+            if (load_u32(read + p + i) != load_u32(piece + i)) { hit = false; break; }
+          if (hit)
+            for (; i < F; ++i)
+              if (read[p + i] != piece[i]) { hit = false; break; }
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (m) found = base + (__ffsll((long long)m) - 1);
+    }
+  }
+  if (lane == 0) {
+    a.pos[j] = found;
+    if (found < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
+      const uint32_t slot = atomicAdd(a.wfa_count, 1u);
+      JobDev jd;
+      jd.pat_off = a.piece_off[2 * (uint64_t)a.read_locus[r] + side]; jd.txt_off = a.read_off[r];
+      jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
+      a.wfa_jobs[slot] = jd;
+    }
+  }
+}
+
+struct CombineArgs {
+  uint64_t n_reads; int32_t flank_len; double threshold;
+  const int32_t* pos; const int32_t* n_match; const uint32_t* span4;
+  int32_t* span_start; int32_t* span_end; uint8_t* lf_hit; uint8_t* rf_hit;
+};
+
+__global__ void span_combine_kernel(const CombineArgs a) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n_reads) return;
+  int s[2], e[2], hit[2];
+  for (int side = 0; side < 2; ++side) {
+    const uint64_t j = 2 * r + side;
+    s[side] = e[side] = -1; hit[side] = 0;
+    if (a.pos[j] >= 0) { s[side] = a.pos[j]; e[side] = a.pos[j] + a.flank_len; hit[side] = 1; }
+    else if ((double)(uint64_t)(uint32_t)a.n_match[j] >= a.threshold && a.n_match[j] >= 0) {  // span_locater.rs:18-22
+      s[side] = (int)a.span4[4 * j + 2]; e[side] = (int)a.span4[4 * j + 3]; hit[side] = 2;
+    }
+  }
+  int ss = -1, ee = -1;
+  if (hit[0] && hit[1] && e[0] <= s[1]) { ss = e[0]; ee = s[1]; }  // :59-65
+  a.span_start[r] = ss; a.span_end[r] = ee;
+  if (a.lf_hit) a.lf_hit[r] = (uint8_t)hit[0];
+  if (a.rf_hit) a.rf_hit[r] = (uint8_t)hit[1];
+}
+
+// Device-side part shared with trgt_locus_batch: everything already resident, results left on the device.
+int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
+                      const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
+                      const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit) {
+  const uint64_t n_jobs = 2ull * (uint64_t)n_reads;
+  void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
+  int rc;
+  if ((rc = dev_get(c, S_FS_POS, n_jobs * 4, &d_pos)) || (rc = dev_get(c, S_FS_WFAJOBS, n_jobs * sizeof(JobDev), &d_wjobs)) ||
+      (rc = dev_get(c, S_FS_COUNT, 16, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
+      (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
+    return rc;
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 16, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_nmatch, 0xFF, n_jobs * 4, c->stream));
+  ScanArgs sa;
+  sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
+  sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos;
+  sa.wfa_jobs = (JobDev*)d_wjobs; sa.wfa_count = (uint32_t*)d_count;
+  {
+    KTimer t(c, TRGT_K_FLANK_SCAN);
+    hipLaunchKernelGGL(flank_scan_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, sa);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    t.stop(0);
+  }
+  trgt_wfa_params wp;
+  trgt_wfa_default_params(&wp);  // THREAD_WFA_FLANK (genotype.rs:66-80)
+  wp.metric = 3; wp.mismatch = p.mism; wp.gap_open1 = p.gapo; wp.gap_ext1 = p.gape;
+  wp.span = 1; wp.pattern_begin_free = 0; wp.pattern_end_free = 0; wp.text_begin_free = -1; wp.text_end_free = -1;
+  wp.scope = 1; wp.memory_mode = 0; wp.heuristic = 0;
+  WfaLaunch L;
+  L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
+  L.pat_base = d_flank; L.txt_base = d_reads;
+  L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
+  L.threads = 256;
+  L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
+  if ((rc = wfa_launch(c, wp, L))) return rc;
+  CombineArgs ca;
+  ca.n_reads = (uint64_t)n_reads; ca.flank_len = p.flank_len;
+  ca.threshold = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;  // span_locater.rs:46
+  ca.pos = (const int32_t*)d_pos; ca.n_match = (const int32_t*)d_nmatch; ca.span4 = (const uint32_t*)d_span4;
+  ca.span_start = d_span_start; ca.span_end = d_span_end; ca.lf_hit = d_lf_hit; ca.rf_hit = d_rf_hit;
+  hipLaunchKernelGGL(span_combine_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, ca);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  (void)n_loci;
+  return TRGT_OK;
+}
+
+}  // namespace trgt
+
+using namespace trgt;
+
+extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p, int64_t n_loci, const uint8_t* flank_blob,
+                                     const uint64_t* lf_off, const uint32_t* lf_len, const uint64_t* rf_off,
+                                     const uint32_t* rf_len, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                                     const uint64_t* read_off, const uint32_t* read_len, int32_t* span_start,
+                                     int32_t* span_end, uint8_t* lf_hit, uint8_t* rf_hit) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (!p || n_loci < 0 || (n_loci > 0 && (!flank_blob || !lf_off || !lf_len || !rf_off || !rf_len || !locus_read_begin ||
+                                          !read_blob || !read_off || !read_len || !span_start || !span_end)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_find_spans_batch: null argument");
+  if (n_loci == 0) return TRGT_OK;
+  if (p->flank_len <= 0) return fail(c, TRGT_ERR_INVALID, "trgt_find_spans_batch: flank_len must be positive");
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t n_reads = (int64_t)locus_read_begin[n_loci];
+  if (n_reads == 0) return TRGT_OK;
+  if (2 * n_reads > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_find_spans_batch: too many reads in one call");
+  std::vector<uint64_t> piece_off(2 * (size_t)n_loci);
+  std::vector<uint32_t> read_locus((size_t)n_reads);
+  uint64_t flank_total = 0, read_total = 0;
+  uint32_t max_read_len = 0;
+  for (int64_t l = 0; l < n_loci; ++l) {
+    if ((int64_t)lf_len[l] < p->flank_len || (int64_t)rf_len[l] < p->flank_len)
+      return fail(c, TRGT_ERR_INVALID, "trgt_find_spans_batch: locus %lld flank shorter than flank_len", (long long)l);
+    piece_off[2 * l] = lf_off[l] + lf_len[l] - (uint64_t)p->flank_len;  // lf[lf.len()-F..]  (span_locater.rs:38)
+    piece_off[2 * l + 1] = rf_off[l];                                    // rf[..F]           (:39)
+    flank_total = std::max<uint64_t>(flank_total, std::max(lf_off[l] + lf_len[l], rf_off[l] + rf_len[l]));
+    for (uint64_t r = locus_read_begin[l]; r < locus_read_begin[l + 1]; ++r) read_locus[r] = (uint32_t)l;
+  }
+  for (int64_t r = 0; r < n_reads; ++r) {
+    read_total = std::max<uint64_t>(read_total, read_off[r] + read_len[r]);
+    max_read_len = std::max(max_read_len, read_len[r]);
+  }
+  int rc;
+  const uint8_t *d_flank = nullptr, *d_reads = nullptr;
+  const uint64_t *d_piece = nullptr, *d_roff = nullptr;
+  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr;
+  if ((rc = dev_in(c, S_FS_FLANK, flank_blob, (size_t)flank_total, &d_flank)) ||
+      (rc = dev_in(c, S_FS_READS, read_blob, (size_t)read_total, &d_reads)) ||
+      (rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
+      (rc = dev_in(c, S_FS_LIST, read_off, (size_t)n_reads, &d_roff)) ||
+      (rc = dev_in(c, S_FS_OUT0, read_len, (size_t)n_reads, &d_rlen)) ||
+      (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)n_reads, &d_rloc)))
+    return rc;
+  DevOut<int32_t> o_s, o_e; DevOut<uint8_t> o_l, o_r;
+  if ((rc = o_s.init(c, S_LOCUS_0, span_start, (size_t)n_reads)) || (rc = o_e.init(c, S_LOCUS_1, span_end, (size_t)n_reads)) ||
+      (rc = o_l.init(c, S_FS_HIT0, lf_hit, (size_t)n_reads)) || (rc = o_r.init(c, S_FS_HIT1, rf_hit, (size_t)n_reads)))
+    return rc;
+  if ((rc = find_spans_device(c, *p, n_loci, n_reads, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, o_s.dev,
+                              o_e.dev, o_l.dev, o_r.dev)))
+    return rc;
+  if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
+  unsigned long long cells = 0;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
+  return TRGT_OK;
+}

@@ -8,7 +8,6 @@
 #include <algorithm>
 
 #include "wfa_engine.hpp"
-#include "wfa_host.hpp"
 
 namespace trgt {
 namespace wfa {

@@ -15,6 +15,7 @@
 // known-answer tests (src/wfaligner.rs:1136-1828) pin them.
 #pragma once
 #include "common.hpp"
+#include "wfa_host.hpp"
 
 namespace trgt {
 namespace wfa {
@@ -36,6 +37,18 @@ struct KParams {  // by-value kernel argument
   Pen pen;
   int span, pbf, pef, tbf, tef;  // -1 = sequence length
   int scope_alignment, biwfa, heuristic, h_min_len, h_max_dist, h_steps, bi_min_score, bi_min_length;
+};
+
+struct KArgs {
+  KParams kp;
+  const JobDev* jobs; const uint32_t* n_jobs_dev; uint32_t n_jobs;
+  const uint8_t* pat_base; const uint8_t* txt_base;
+  unsigned int* counter;
+  uint8_t* ws; uint64_t ws_per_block;
+  uint64_t off_gdesc, off_arena_u, off_arena_f, off_arena_r, off_rle_tmp, off_rle_out, off_run_start;
+  uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap;
+  int32_t* status; int32_t* score; int32_t* n_match; uint32_t* span4; uint32_t* cigar; uint32_t* cigar_len; uint8_t* ops; uint32_t* ops_len;
+  unsigned long long* cells_out;
 };
 
 struct Inst {  // one unidirectional aligner (forward / reverse / base)

@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's per-locus genotyper contract over the GPU batch ABI trgt_locus_batch.
+
+Reference (PacificBiosciences/trgt v3.0.0):
+  Params        src/trgt/workflows/tr.rs:17-22       -> Params
+  Locus         src/trgt/locus.rs:13-23              -> the arrays of a batch (see pack / trgt_amd.synth.generate)
+  analyze       src/trgt/workflows/tr.rs:24-109      -> analyze_batch (size genotyper, pre-clipped reads)
+  LocusResult / Allele  workflows/locus_result.rs:6-23 -> LocusResult / Allele
+  find_tr_spans src/trgt/genotype/span_locater.rs:32-68 -> find_tr_spans_batch
+  encode_* of write_vcf.rs:286-377                   -> LocusResult.vcf_fields()
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .hmm import Annotation, Span, encode_ap, encode_mc, encode_ms
+
+
+@dataclass
+class Params:  # tr.rs:17-22 (+ --aln-scoring of cli.rs:271-280)
+    min_flank_id_frac: float = 0.7
+    search_flank_len: int = 250
+    max_depth: int = 250
+    aln_scoring: Tuple[int, int, int] = (2, 5, 1)
+    host_threads: int = 0
+
+
+@dataclass
+class Allele:  # locus_result.rs:6-12
+    seq: bytes
+    annotation: Annotation
+    ci: Tuple[int, int]
+    num_spanning: int
+    meth: Optional[float] = None
+
+
+@dataclass
+class LocusResult:  # locus_result.rs:16-22
+    genotype: List[Allele]
+    reads: List[int]                 # indices of the kept spanning reads (into the locus' input reads), output order
+    tr_spans: List[Tuple[int, int]]
+    classification: List[int]
+
+    def vcf_fields(self):  # write_vcf.rs:286-377
+        g = self.genotype
+        ann = [a.annotation for a in g]
+        return dict(AL=",".join(str(len(a.seq)) for a in g), ALLR=",".join("%d-%d" % a.ci for a in g),
+                    SD=",".join(str(a.num_spanning) for a in g), MC=encode_mc(ann), MS=encode_ms(ann), AP=encode_ap(ann))
+
+
+def pack(loci):
+    """loci: list of dict(left_flank, right_flank, tr, motifs, ploidy, reads).  Returns the ABI arrays (host)."""
+    flank, tr, motifs, reads = bytearray(), bytearray(), bytearray(), bytearray()
+    lf_off, lf_len, rf_off, rf_len, tr_off, tr_len, motif_off, set_begin, ploidy, lrb, read_off, read_len = ([] for _ in range(12))
+    motif_off.append(0)
+    set_begin.append(0)
+    lrb.append(0)
+    for L in loci:
+        lf_off.append(len(flank)); lf_len.append(len(L["left_flank"])); flank += L["left_flank"]
+        rf_off.append(len(flank)); rf_len.append(len(L["right_flank"])); flank += L["right_flank"]
+        tr_off.append(len(tr)); tr_len.append(len(L["tr"])); tr += L["tr"]
+        for m in L["motifs"]:
+            motifs += m if isinstance(m, bytes) else m.encode()
+            motif_off.append(len(motifs))
+        set_begin.append(len(motif_off) - 1)
+        ploidy.append(L.get("ploidy", 2))
+        for r in L["reads"]:
+            read_off.append(len(reads)); read_len.append(len(r)); reads += r
+        lrb.append(len(read_off))
+    u8 = lambda b: np.frombuffer(bytes(b), np.uint8).copy() if len(b) else np.zeros(1, np.uint8)
+    return dict(n_loci=len(loci), n_reads=len(read_off), flank_blob=u8(flank), lf_off=np.array(lf_off, np.uint64),
+                lf_len=np.array(lf_len, np.uint32), rf_off=np.array(rf_off, np.uint64), rf_len=np.array(rf_len, np.uint32),
+                tr_blob=u8(tr), tr_off=np.array(tr_off, np.uint64), tr_len=np.array(tr_len, np.uint32), motif_blob=u8(motifs),
+                motif_off=np.array(motif_off, np.uint32), set_motif_begin=np.array(set_begin, np.uint32),
+                ploidy=np.array(ploidy, np.uint8), locus_read_begin=np.array(lrb, np.uint64), read_blob=u8(reads),
+                read_off=np.array(read_off, np.uint64), read_len=np.array(read_len, np.uint32))
+
+
+def find_tr_spans_batch(batch, params=Params(), ctx=None, flank_dev=None, reads_dev=None):
+    """span_locater.rs:32-68 for every read of the batch.  *_dev: optional torch uint8 tensors already in HBM."""
+    ctx = ctx or _lib.context()
+    sp = _lib.SpanParams(params.search_flank_len, params.min_flank_id_frac, *params.aln_scoring)
+    n = int(batch["n_reads"])
+    ss, se = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lh, rh = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    p = _lib.ptr
+    ctx.check(_lib.lib().trgt_find_spans_batch(
+        ctx.handle, C.byref(sp), int(batch["n_loci"]), p(flank_dev if flank_dev is not None else batch["flank_blob"]),
+        p(batch["lf_off"]), p(batch["lf_len"]), p(batch["rf_off"]), p(batch["rf_len"]), p(batch["locus_read_begin"]),
+        p(reads_dev if reads_dev is not None else batch["read_blob"]), p(batch["read_off"]), p(batch["read_len"]), p(ss), p(se),
+        p(lh), p(rh)))
+    return ss, se, lh, rh
+
+
+class BatchOutputs:
+    """Caller-owned output buffers of trgt_locus_batch, reusable across calls of the same batch shape."""
+
+    def __init__(self, batch):
+        nl, nr = int(batch["n_loci"]), int(batch["n_reads"])
+        lrb = batch["locus_read_begin"]
+        rl = batch["read_len"]
+        cap = np.zeros(nl, np.uint32)
+        for l in range(nl):
+            a, b = int(lrb[l]), int(lrb[l + 1])
+            cap[l] = (int(rl[a:b].max()) if b > a else 0) + 8
+        self.allele_cap = cap
+        cap2 = np.repeat(cap.astype(np.uint64), 2)
+        self.allele_off = np.zeros(2 * nl, np.uint64)
+        self.allele_off[1:] = np.cumsum(cap2[:-1])
+        self.allele_blob = np.zeros(int(cap2.sum()) + 8, np.uint8)
+        self.allele_len = np.zeros(2 * nl, np.uint32)
+        self.span_off = np.zeros(2 * nl, np.uint64)
+        self.span_off[1:] = np.cumsum(cap2[:-1] + 1)
+        self.spans3 = np.zeros(3 * (int((cap2 + 1).sum()) + 8), np.int32)
+        self.n_spans = np.zeros(2 * nl, np.uint32)
+        nm = np.diff(batch["set_motif_begin"]).astype(np.uint64)
+        nm2 = np.repeat(nm, 2)
+        self.count_off = np.zeros(2 * nl, np.uint64)
+        self.count_off[1:] = np.cumsum(nm2[:-1])
+        self.motif_counts = np.zeros(int(nm2.sum()) + 8, np.uint32)
+        self.n_motifs = nm.astype(np.int64)
+        self.purity = np.zeros(2 * nl, np.float64)
+        self.span_start, self.span_end = np.zeros(nr, np.int32), np.zeros(nr, np.int32)
+        self.n_alleles = np.zeros(nl, np.int32)
+        self.ci = np.zeros(4 * nl, np.int32)
+        self.num_spanning = np.zeros(2 * nl, np.int32)
+        self.classification, self.read_rank = np.zeros(nr, np.int32), np.zeros(nr, np.int32)
+        self.stats = np.zeros(16, np.int64)
+        p = _lib.ptr
+        self.c_out = _lib.LocusBatchOut(*[p(getattr(self, n)).value for n in (
+            "span_start", "span_end", "n_alleles", "allele_blob", "allele_off", "allele_cap", "allele_len", "ci", "num_spanning",
+            "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off", "purity", "stats")])
+
+
+def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, reads_dev=None):
+    """trgt_locus_batch on a packed batch.  Returns the (reusable) BatchOutputs."""
+    ctx = ctx or _lib.context()
+    out = outputs or BatchOutputs(batch)
+    p = _lib.ptr
+    cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
+        flank_dev if flank_dev is not None else batch["flank_blob"], batch["lf_off"], batch["lf_len"], batch["rf_off"],
+        batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
+        batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
+        reads_dev if reads_dev is not None else batch["read_blob"], batch["read_off"], batch["read_len"])])
+    lp = _lib.LocusParams(params.search_flank_len, params.min_flank_id_frac, params.max_depth, params.aln_scoring[0],
+                          params.aln_scoring[1], params.aln_scoring[2], params.host_threads)
+    ctx.check(_lib.lib().trgt_locus_batch(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out)))
+    return out
+
+
+def locus_result(batch, out, l):
+    """Unpack locus l of a finished batch into the reference's LocusResult shape."""
+    a0, a1 = int(batch["locus_read_begin"][l]), int(batch["locus_read_begin"][l + 1])
+    geno = []
+    for a in range(int(out.n_alleles[l])):
+        s = 2 * l + a
+        seq = bytes(out.allele_blob[int(out.allele_off[s]):int(out.allele_off[s]) + int(out.allele_len[s])])
+        so, ns = int(out.span_off[s]), int(out.n_spans[s])
+        labels = [Span(int(x), int(y), int(z)) for x, y, z in out.spans3[3 * so:3 * (so + ns)].reshape(-1, 3)] or None
+        co = int(out.count_off[s])
+        counts = [int(v) for v in out.motif_counts[co:co + int(out.n_motifs[l])]]
+        geno.append(Allele(seq, Annotation(labels, counts, float(out.purity[s])), (int(out.ci[4 * l + 2 * a]), int(out.ci[4 * l + 2 * a + 1])),
+                           int(out.num_spanning[2 * l + a])))
+    rank = out.read_rank[a0:a1]
+    kept = [int(i) for i in np.argsort(np.where(rank >= 0, rank, 1 << 30), kind="stable")[:int((rank >= 0).sum())]]
+    return LocusResult(geno, kept, [(int(out.span_start[a0 + i]), int(out.span_end[a0 + i])) for i in kept],
+                       [int(out.classification[a0 + i]) for i in kept])
+
+
+def analyze_batch(loci, params=Params(), ctx=None):
+    """analyze() for a list of loci (dicts, see pack) -> list of LocusResult."""
+    batch = pack(loci)
+    out = run_batch(batch, params, ctx)
+    return [locus_result(batch, out, l) for l in range(len(loci))]
