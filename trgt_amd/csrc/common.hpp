@@ -25,9 +25,9 @@ struct trgt_hip_ctx {
   std::vector<Buf> pool;
   // timing
   bool timing = false;
-  double k_ms[TRGT_K_COUNT] = {0, 0, 0};
-  int64_t k_launches[TRGT_K_COUNT] = {0, 0, 0};
-  int64_t k_cells[TRGT_K_COUNT] = {0, 0, 0};
+  double k_ms[TRGT_K_COUNT] = {0, 0, 0, 0};
+  int64_t k_launches[TRGT_K_COUNT] = {0, 0, 0, 0};
+  int64_t k_cells[TRGT_K_COUNT] = {0, 0, 0, 0};
   struct Pending { int k; hipEvent_t a, b; };
   std::vector<Pending> pending;
   void* last_wfa_cells_dev = nullptr;

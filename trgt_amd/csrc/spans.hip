@@ -137,6 +137,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   L.pat_base = d_flank; L.txt_base = d_reads;
   L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
   L.threads = 256;
+  L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
   if ((rc = wfa_launch(c, wp, L))) return rc;
   CombineArgs ca;
@@ -207,6 +208,6 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
   unsigned long long cells = 0;
   TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
+  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells;
   return TRGT_OK;
 }

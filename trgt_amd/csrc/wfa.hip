@@ -489,7 +489,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   a.lds_seq_cap = (uint32_t)std::min<uint64_t>(seq_need, 32 * 1024);
   if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
   const size_t lds = a.lds_seq_cap;
-  KTimer t(c, TRGT_K_WFA);
+  KTimer t(c, L.timer_slot);
   const dim3 grid((unsigned)blocks), block((unsigned)threads);
   switch (p.metric) {
     case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;
