@@ -77,7 +77,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from trgt_amd import _lib, locus, synth
+    from trgt_amd import _lib, locus, shard, synth
 
     # ---- synthetic shard of this rank (untimed)
     host_threads = args.host_threads or max(1, (os.cpu_count() or 8) // max(1, world))
@@ -107,10 +107,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ctx.timing_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
 
     if rank == 0:
         names = {_lib_k: n for n, _lib_k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3))}
