@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
 
 #include "common.hpp"
 
@@ -151,8 +152,7 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
     for (uint32_t s = 0; s < S; ++s) { level[s] = (uint8_t)lev[s]; n_levels = std::max<uint32_t>(n_levels, (uint32_t)lev[s]); }
   }
   // serialise
-  const uint64_t base = align_up(blob.size(), 16);
-  uint64_t o = base;
+  uint64_t o = 0;  // offsets relative to this set's blob; the caller rebases them
   d.S = S; d.n_blocks = nb; d.n_levels = n_levels; d.max_mlen = max_mlen;
   d.off_inlp = o; o += 8ull * 4 * S;
   d.off_em = o; o += 8ull * 5 * S;
@@ -432,24 +432,57 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
   if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
   if (n_jobs == 0) return TRGT_OK;
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
-  // ---- models
-  std::vector<uint8_t> blob;
+  // ---- models (host libm ln tables), built in parallel over motif sets
   std::vector<HmmSetDev> sets((size_t)n_sets);
-  for (int s = 0; s < n_sets; ++s) {
-    std::vector<std::string> motifs;
-    for (uint32_t m = set_motif_begin[s]; m < set_motif_begin[s + 1]; ++m) {
-      std::string mot((const char*)motif_blob + motif_off[m], motif_off[m + 1] - motif_off[m]);
-      if (mot.empty()) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: empty motif in set %d", s);
-      static const char allowed[] = "ATCGN";  // replace_invalid_bases(m, ATCGN)
-      for (size_t i = 0; i < mot.size(); ++i)
-        if (!std::strchr("ATCGN", mot[i]) || mot[i] == 0) mot[i] = allowed[i % 5];
-      motifs.push_back(mot);
+  std::vector<std::vector<uint8_t>> blobs((size_t)n_sets);
+  std::vector<int> set_err((size_t)n_sets, 0);
+  {
+    const int nthr = (int)std::min<int64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), std::max(1, n_sets / 64));
+    auto work = [&](int t) {
+      for (int s = t; s < n_sets; s += nthr) {
+        std::vector<std::string> motifs;
+        for (uint32_t m = set_motif_begin[s]; m < set_motif_begin[s + 1]; ++m) {
+          std::string mot((const char*)motif_blob + motif_off[m], motif_off[m + 1] - motif_off[m]);
+          if (mot.empty()) { set_err[s] = 1; break; }
+          static const char allowed[] = "ATCGN";  // replace_invalid_bases(m, ATCGN)
+          for (size_t i = 0; i < mot.size(); ++i)
+            if (mot[i] == 0 || !std::strchr("ATCGN", mot[i])) mot[i] = allowed[i % 5];
+          motifs.push_back(mot);
+        }
+        if (set_err[s]) continue;
+        if (motifs.empty()) { set_err[s] = 2; continue; }
+        build_set(motifs, blobs[s], sets[s]);
+        if (sets[s].S > 1024) set_err[s] = 3;
+        else if (sets[s].n_blocks > 254) set_err[s] = 4;
+      }
+    };
+    if (nthr <= 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthr; ++t) th.emplace_back(work, t);
+      for (auto& x : th) x.join();
     }
-    if (motifs.empty()) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: set %d has no motif", s);
-    build_set(motifs, blob, sets[s]);
-    if (sets[s].S > 1024)
-      return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, sets[s].S);
-    if (sets[s].n_blocks > 254) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has too many motifs", s);
+  }
+  std::vector<uint8_t> blob;
+  {
+    uint64_t total = 0;
+    for (int s = 0; s < n_sets; ++s) {
+      if (set_err[s] == 1) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: empty motif in set %d", s);
+      if (set_err[s] == 2) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: set %d has no motif", s);
+      if (set_err[s] == 3) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, sets[s].S);
+      if (set_err[s] == 4) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has too many motifs", s);
+      total += blobs[s].size();
+    }
+    blob.resize((size_t)total);
+    uint64_t pos = 0;
+    for (int s = 0; s < n_sets; ++s) {
+      std::memcpy(blob.data() + pos, blobs[s].data(), blobs[s].size());
+      HmmSetDev& d = sets[s];
+      d.off_inlp += pos; d.off_em += pos; d.off_inst += pos; d.off_block += pos; d.off_nin += pos; d.off_level += pos;
+      d.off_flags += pos; d.off_blocks += pos; d.off_motifs += pos;
+      pos += blobs[s].size();
+      std::vector<uint8_t>().swap(blobs[s]);
+    }
   }
   // ---- jobs, grouped by workgroup size (64 * ceil(S/64))
   std::vector<HmmJobDev> jobs((size_t)n_jobs);

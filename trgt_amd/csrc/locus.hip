@@ -223,6 +223,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int F = p->flank_len;
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min(threads, 32);  // a few microseconds of work per locus: more threads only add spawn cost
   int64_t t0 = now_ns(), tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0;
   for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
