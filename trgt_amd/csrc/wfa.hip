@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "wfa_engine.hpp"
+#include "wfa_fast.hpp"
 
 namespace trgt {
 namespace wfa {
@@ -252,7 +253,7 @@ __device__ __noinline__ bool bi_base(const KArgs& a, const BlockWs& ws, const ui
 
 // ------------------------------------------------------------------ kernel
 template <int METRIC>
-__global__ void __launch_bounds__(256) wfa_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_seq[];
   const int tid = threadIdx.x, T = blockDim.x;
   const KParams& kp = a.kp;
@@ -281,10 +282,12 @@ __global__ void __launch_bounds__(256) wfa_kernel(const KArgs a) {
     const uint8_t* Tx = a.txt_base + job.txt_off;
     // stage the two sequences in LDS when they fit (extension = byte compares against LDS)
     const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
+    bool staged = false;
     if (pl_pad + (uint32_t)tlen <= a.lds_seq_cap) {
       for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
       for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
       P = lds_seq; Tx = lds_seq + pl_pad;
+      staged = true;
     }
     if (tid == 0) { sh.status = TRGT_WF_COMPLETED; sh.score = INT32_MIN; sh.rle_n = 0; sh.sp = 0; sh.cells = 0; sh.top_bp = 0; }
     __syncthreads();
@@ -297,12 +300,31 @@ __global__ void __launch_bounds__(256) wfa_kernel(const KArgs a) {
                    sp ? fr(kp.tbf, tlen) : 0, sp ? fr(kp.tef, tlen) : 0, CM, CM);
       }
       __syncthreads();
-      const int st = wf_run<METRIC>(I_UNI, kp);
+      int st;
+      if (METRIC == M_AFFINE && staged && a.fast_wcap > 0 && (uint32_t)(plen + tlen + 6) <= a.fast_wcap) {
+        // 4-byte sliding windows of both sequences (see wfa_fast.hpp), built from the LDS byte copies
+        uint16_t* ring = reinterpret_cast<uint16_t*>(lds_seq + a.lds_seq_cap);
+        uint32_t* P4 = reinterpret_cast<uint32_t*>(lds_seq + a.lds_seq_cap + a.fast_ring_bytes);
+        uint32_t* T4 = P4 + plen + 1;
+        for (int i = tid; i <= plen; i += T) {
+          uint32_t wv = 0;
+          for (int b = 0; b < 4; ++b) if (i + b < plen) wv |= (uint32_t)lds_seq[i + b] << (8 * b);
+          P4[i] = wv;
+        }
+        for (int i = tid; i <= tlen; i += T) {
+          uint32_t wv = 0;
+          for (int b = 0; b < 4; ++b) if (i + b < tlen) wv |= (uint32_t)lds_seq[pl_pad + i + b] << (8 * b);
+          T4[i] = wv;
+        }
+        st = wf_run_lds_affine(kp, P4, T4, ring, (int)a.fast_wcap);
+      }
+      else
+        st = wf_run<METRIC>(I_UNI, kp);
       if (tid == 0) {
         if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
         else {
           sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
-          if (kp.scope_alignment) {
+          if (kp.scope_alignment && !a.fast_dbg) {
             int nt = 0;
             wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
             rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
@@ -486,11 +508,23 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   a.status = L.status; a.score = L.score; a.n_match = L.n_match; a.span4 = L.span4; a.cigar = L.cigar; a.cigar_len = L.cigar_len;
   a.ops = L.ops; a.ops_len = L.ops_len;
   const uint64_t seq_need = ((uint64_t)mp + 15) / 16 * 16 + (uint64_t)mt + 16;
-  a.lds_seq_cap = (uint32_t)std::min<uint64_t>(seq_need, 32 * 1024);
+  a.lds_seq_cap = (uint32_t)((std::min<uint64_t>(seq_need, 32 * 1024) + 15) & ~15ull);
   if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
-  const size_t lds = a.lds_seq_cap;
+  size_t lds = a.lds_seq_cap;
+  a.fast_wcap = 0; a.fast_ring_bytes = 0;
+  a.fast_dbg = getenv("TRGT_DBG_SKIP_BT") ? 1 : 0;
+  if (p.metric == 3 && p.heuristic == 0 && !a.kp.biwfa && a.lds_seq_cap > 0 && mt + score_bound < 65000) {
+    // LDS fast path (wfa_fast.hpp): ring of the live wavefronts as 16-bit offsets
+    const uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
+    const uint64_t ring_bytes = (uint64_t)(std::max(pen.x, pen.o1 + pen.e1) + 1 + 2 * (pen.e1 + 1)) * wcap * 2;
+    const uint64_t win_bytes = 4ull * (uint64_t)(mp + mt + 8);
+    if (a.lds_seq_cap + ring_bytes + win_bytes <= 96 * 1024) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds += (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
+  }
   KTimer t(c, L.timer_slot);
   const dim3 grid((unsigned)blocks), block((unsigned)threads);
+  if (lds > 64 * 1024) {
+    if (p.metric == 3) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)wfa_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   switch (p.metric) {
     case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;
     case 1: hipLaunchKernelGGL(wfa_kernel<1>, grid, block, lds, c->stream, a); break;

@@ -46,7 +46,7 @@ struct KArgs {
   unsigned int* counter;
   uint8_t* ws; uint64_t ws_per_block;
   uint64_t off_gdesc, off_arena_u, off_arena_f, off_arena_r, off_rle_tmp, off_rle_out, off_run_start;
-  uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap;
+  uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg;
   int32_t* status; int32_t* score; int32_t* n_match; uint32_t* span4; uint32_t* cigar; uint32_t* cigar_len; uint8_t* ops; uint32_t* ops_len;
   unsigned long long* cells_out;
 };
@@ -74,6 +74,7 @@ struct Shared {
   Inst inst[3];
   WfDesc ring[3][RING * 5];
   Red red;
+  Red red3[3];  // triple-buffered reductions of the LDS fast path (wfa_fast.hpp)
   Breakpoint bp;
   Seg stack[64];
   int sp, job, status, score, top_bp, rle_n, rle_tmp_n;

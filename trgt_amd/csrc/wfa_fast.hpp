@@ -1,0 +1,188 @@
+// trgt_amd/csrc/wfa_fast.hpp -- LDS-resident fast path of the wavefront aligner for the case that
+// dominates TRGT's batches: exact (Heuristic::None) unidirectional gap-affine alignment, i.e.
+// THREAD_WFA_FLANK (src/commands/genotype.rs:66-80): a 250-bp flank piece against a ~1.2-kb read
+// with both text ends free, ~1450 live diagonals per score level.
+//
+// What changes relative to the generic engine (results are identical, see tests/test_wfa_gpu.py):
+//   * the live wavefronts -- M of the last max(x, o+e)+1 levels, I and D of the last e+1 levels --
+//     sit in an LDS ring as 16-bit "offset+1" values (0 = NULL), indexed directly by diagonal, so the
+//     recurrences read LDS, never HBM; pattern and text bytes are read from LDS too;
+//   * the wavefront history needed by the back-trace is streamed to the HBM arena write-only
+//     (coalesced 4-byte stores, one per offset: the 4*W term of the roofline model);
+//   * ONE workgroup barrier per score level: every thread derives the trimmed descriptor of the level
+//     it just helped to compute from a triple-buffered reduction block, so there is no serial
+//     "thread 0 publishes, everyone waits" section in the loop.
+#pragma once
+#include "wfa_engine.hpp"
+
+namespace trgt {
+namespace wfa {
+
+__device__ __forceinline__ uint16_t enc16(int32_t off) { return off < 0 ? (uint16_t)0 : (uint16_t)(off + 1); }
+__device__ __forceinline__ int32_t dec16(uint16_t e) { return e ? (int32_t)e - 1 : OFF_NULL; }
+__device__ __forceinline__ int32_t ring_get(const uint16_t* arr, int wcap, int koff, const WfDesc& d, int slot, int k) {
+  return (k >= d.lo && k <= d.hi) ? dec16(arr[slot * wcap + k + koff]) : OFF_NULL;
+}
+
+// P, T: LDS copies of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  All threads; returns ST_*.
+__device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32_t* P4, const uint32_t* T4, uint16_t* ring, int wcap) {
+  Inst& I = sh.inst[I_UNI];
+  const int tid = threadIdx.x, nT = blockDim.x;
+  const int plen = I.plen, tlen = I.tlen, ak = tlen - plen, koff = plen + 2;  // one pad cell each side: k-1 / k+1 reads never leave the slot
+  const int x = kp.pen.x, oe = kp.pen.o1 + kp.pen.e1, e = kp.pen.e1, scope = kp.pen.scope;
+  const int RM = max(x, oe) + 1, RI = e + 1;
+  uint16_t* Mr = ring;
+  uint16_t* Ir = ring + RM * wcap;
+  uint16_t* Dr = Ir + RI * wcap;
+  int32_t* __restrict__ A = I.arena;
+  const uint32_t cap = I.arena_cap;
+  const int n_slots = I.n_slots, span = I.span, pef = I.pef, tef = I.tef;
+
+  // Extension over 4-byte sliding windows: P4[i] = pattern bytes i..i+3 (zero padded), T4 likewise.  One aligned LDS
+  // dword per sequence covers four bases; most diagonals stop inside the first window, so the common case is straight-line.
+  auto extend = [&](int k, int32_t off, Red& red) -> int32_t {
+    int v = off - k, h = off;
+    int n;
+    do {
+      const uint32_t xw = P4[v] ^ T4[h];
+      n = xw ? (__builtin_ctz(xw) >> 3) : 4;
+      n = min(n, min(plen - v, tlen - h));
+      v += n; h += n;
+    } while (n == 4);
+    if (span == 1) {
+      if ((h >= tlen && plen - v <= pef) || (v >= plen && tlen - h <= tef))
+        atomicMin(&red.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)h);
+    } else if (k == ak) red.end_val = h;
+    return h;
+  };
+
+  __syncthreads();
+  if (tid == 0) {
+    for (int r = 0; r < 3; ++r) red_reset(sh.red3[r]);
+    I.status = ST_OK; I.end_score = -1; I.num_null_steps = 0;
+  }
+  __syncthreads();
+  // ---- score 0 (wavefront_unialign_init + first extension)
+  WfDesc lastM, lastI = null_desc(), lastD = null_desc();
+  lastM.lo = lastM.lo_alloc = span ? -I.pbf : 0;
+  lastM.hi = span ? I.tbf : 0;
+  lastM.base = 0;
+  uint32_t bump = (uint32_t)(lastM.hi - lastM.lo + 1);
+  unsigned long long cells = bump;
+  int status = ST_OK, num_null = 0, s = 0;
+  bool computed = true;
+  if (bump > cap || n_slots < 1) status = ST_OOM;
+  else {
+    Red& red = sh.red3[0];
+    for (int kb = lastM.lo; kb <= lastM.hi; kb += nT) {
+      const int k = kb + tid;
+      if (k <= lastM.hi) {
+        int32_t off = span ? (k > 0 ? k : 0) : 0;
+        off = extend(k, off, red);
+        Mr[k + koff] = enc16(off);
+        A[(uint32_t)(k - lastM.lo)] = off;
+      }
+    }
+  }
+  while (status == ST_OK) {
+    __syncthreads();  // the one barrier per level: level s is complete in LDS, its reductions are final
+    const Red& red = sh.red3[s % 3];
+    if (s > 0 && computed) {  // wavefront_compute_trim_ends, derived redundantly by every thread
+      if (red.lo[CM] == INT32_MAX) lastM.hi = lastM.lo - 1; else { lastM.lo = red.lo[CM]; lastM.hi = red.hi[CM]; }
+      if (lastI.base != NOBASE) { if (red.lo[CI1] == INT32_MAX) lastI.hi = lastI.lo - 1; else { lastI.lo = red.lo[CI1]; lastI.hi = red.hi[CI1]; } }
+      if (lastD.base != NOBASE) { if (red.lo[CD1] == INT32_MAX) lastD.hi = lastD.lo - 1; else { lastD.lo = red.lo[CD1]; lastD.hi = red.hi[CD1]; } }
+    }
+    bool end_reached = false;
+    int end_k = 0, end_off = 0;
+    if (lastM.base != NOBASE) {
+      if (span == 1) {
+        if (red.term_key != ~0ull) { end_reached = true; end_k = (int)(red.term_key >> 32) - KBIAS; end_off = (int)(red.term_key & 0xFFFFFFFFu); }
+      } else if (ak >= lastM.lo && ak <= lastM.hi && red.end_val >= tlen) { end_reached = true; end_k = ak; end_off = tlen; }
+    }
+    if (tid == 0) {
+      put_desc(I_UNI, CM, s, lastM); put_desc(I_UNI, CI1, s, lastI); put_desc(I_UNI, CD1, s, lastD);
+      put_desc(I_UNI, CI2, s, null_desc()); put_desc(I_UNI, CD2, s, null_desc());
+      red_reset(sh.red3[(s + 2) % 3]);
+      if (end_reached) { I.end_score = s; I.end_k = end_k; I.end_off = end_off; }
+    }
+    if (end_reached) { status = ST_END_REACHED; break; }
+    if (lastM.base == NOBASE && num_null > scope) { status = ST_END_UNREACHABLE; break; }
+    // ---- next level
+    ++s;
+    auto getd = [&](int c, int lvl) -> WfDesc {
+      if (lvl < 0) return null_desc();
+      WfDesc d = lvl == s - 1 ? (c == CM ? lastM : c == CI1 ? lastI : lastD) : sh.ring[I_UNI][(lvl & (RING - 1)) * 5 + c];
+      if (d.base == NOBASE || d.lo > d.hi) return null_desc();
+      return d;
+    };
+    const WfDesc m_mis = getd(CM, s - x), m_o = getd(CM, s - oe), ie = getd(CI1, s - e), de = getd(CD1, s - e);
+    if (m_mis.base == NOBASE && m_o.base == NOBASE && ie.base == NOBASE && de.base == NOBASE) {
+      ++num_null; computed = false;
+      lastM = null_desc(); lastI = null_desc(); lastD = null_desc();
+      continue;
+    }
+    num_null = 0; computed = true;
+    int lo = m_mis.lo, hi = m_mis.hi;
+    lim(m_o, -1, +1, lo, hi); lim(ie, +1, +1, lo, hi); lim(de, -1, -1, lo, hi);
+    const uint32_t w = (uint32_t)max(0, hi - lo + 1);
+    if (s >= n_slots || (unsigned long long)bump + 3ull * w > cap) { status = ST_OOM; break; }
+    const uint32_t bM = bump, bI = bump + w, bD = bump + 2 * w;
+    bump += 3 * w; cells += 3ull * w;
+    const bool has_i = m_o.base != NOBASE || ie.base != NOBASE, has_d = m_o.base != NOBASE || de.base != NOBASE;
+    lastM.lo = lastM.lo_alloc = lo; lastM.hi = hi; lastM.base = bM;
+    lastI = lastM; lastI.base = bI; if (!has_i) lastI = null_desc();
+    lastD = lastM; lastD.base = bD; if (!has_d) lastD = null_desc();
+    // Branch-light strip loop in the encoded domain (enc = offset + 1, 0 = NULL):
+    //   ins = max(Mo[k-1], Ie[k-1]) (+1 if non-NULL), del = max(Mo[k+1], De[k+1]), mis = Mm[k] (+1 if non-NULL)
+    const uint16_t* pMo = Mr + ((s - oe) % RM + RM) % RM * wcap + koff;
+    const uint16_t* pMm = Mr + ((s - x) % RM + RM) % RM * wcap + koff;
+    const uint16_t* pIe = Ir + ((s - e) % RI + RI) % RI * wcap + koff;
+    const uint16_t* pDe = Dr + ((s - e) % RI + RI) % RI * wcap + koff;
+    uint16_t* qM = Mr + (s % RM) * wcap + koff;
+    uint16_t* qI = Ir + (s % RI) * wcap + koff;
+    uint16_t* qD = Dr + (s % RI) * wcap + koff;
+    const int lo_mo = m_o.lo, lo_mm = m_mis.lo, lo_ie = ie.lo, lo_de = de.lo;
+    const unsigned n_mo = m_o.base == NOBASE ? 0u : (unsigned)(m_o.hi - m_o.lo + 1), n_mm = m_mis.base == NOBASE ? 0u : (unsigned)(m_mis.hi - m_mis.lo + 1);
+    const unsigned n_ie = ie.base == NOBASE ? 0u : (unsigned)(ie.hi - ie.lo + 1), n_de = de.base == NOBASE ? 0u : (unsigned)(de.hi - de.lo + 1);
+    int32_t* __restrict__ hM = A + bM - lo;
+    int32_t* __restrict__ hI = A + bI - lo;
+    int32_t* __restrict__ hD = A + bD - lo;
+    Red& rn = sh.red3[s % 3];
+    int fM = INT32_MAX, lM = INT32_MIN, fI = INT32_MAX, lI = INT32_MIN, fD = INT32_MAX, lD = INT32_MIN;  // per-lane first / last in-bounds k
+    for (int k = lo + tid; k <= hi; k += nT) {
+      unsigned a = pMo[k - 1], b = pIe[k - 1], c = pMo[k + 1], d = pDe[k + 1], m = pMm[k];
+      a = (unsigned)(k - 1 - lo_mo) < n_mo ? a : 0u;
+      b = (unsigned)(k - 1 - lo_ie) < n_ie ? b : 0u;
+      c = (unsigned)(k + 1 - lo_mo) < n_mo ? c : 0u;
+      d = (unsigned)(k + 1 - lo_de) < n_de ? d : 0u;
+      m = (unsigned)(k - lo_mm) < n_mm ? m : 0u;
+      const unsigned mi = max(a, b);
+      const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
+      unsigned mx = max(del, max(mis, ins));
+      int32_t off = (int32_t)mx - 1;
+      const bool okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+      if (okM) { off = extend(k, off, rn); mx = (unsigned)off + 1u; } else { mx = 0u; off = OFF_NULL; }
+      qI[k] = (uint16_t)ins; qD[k] = (uint16_t)del; qM[k] = (uint16_t)mx;
+      const int32_t vi = ins ? (int32_t)ins - 1 : OFF_NULL, vd = del ? (int32_t)del - 1 : OFF_NULL;
+      hI[k] = vi; hD[k] = vd; hM[k] = off;  // history for the back-trace: written once, never re-read by this loop
+      // wavefront_compute_trim_ends bookkeeping: k only grows per lane, so "first" is set once and "last" overwritten
+      const bool okI = in_bounds(vi, k, plen, tlen), okD = in_bounds(vd, k, plen, tlen);
+      fM = okM ? min(fM, k) : fM; lM = okM ? k : lM;
+      fI = okI ? min(fI, k) : fI; lI = okI ? k : lI;
+      fD = okD ? min(fD, k) : fD; lD = okD ? k : lD;
+    }
+    fM = wave_min(fM); lM = wave_max(lM); fI = wave_min(fI); lI = wave_max(lI); fD = wave_min(fD); lD = wave_max(lD);
+    if ((tid & 63) == 0) {
+      if (fM != INT32_MAX) { atomicMin(&rn.lo[CM], fM); atomicMax(&rn.hi[CM], lM); }
+      if (fI != INT32_MAX) { atomicMin(&rn.lo[CI1], fI); atomicMax(&rn.hi[CI1], lI); }
+      if (fD != INT32_MAX) { atomicMin(&rn.lo[CD1], fD); atomicMax(&rn.hi[CD1], lD); }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { I.status = status; sh.cells += cells; }
+  __syncthreads();
+  return status;
+}
+
+}  // namespace wfa
+}  // namespace trgt
