@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -31,9 +32,15 @@ struct trgt_hip_ctx {
   struct Pending { int k; hipEvent_t a, b; };
   std::vector<Pending> pending;
   void* last_wfa_cells_dev = nullptr;
+  int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host-side phase timers of the last call (diagnostics)
 };
 
 namespace trgt {
+
+inline int64_t wall_ns() {
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
 
 inline int fail(trgt_hip_ctx* c, int code, const char* fmt, ...) {
   char buf[512];

@@ -402,6 +402,17 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   }
 }
 
+// Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
+__global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const uint64_t* __restrict__ job_span_off,
+                                      const uint32_t* __restrict__ n_spans, const uint64_t* __restrict__ packed_off,
+                                      int32_t* __restrict__ packed, uint64_t n_jobs) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
+  const int32_t* src = spans3 + 3 * job_span_off[j];
+  int32_t* dst = packed + 3 * packed_off[j];
+  for (uint32_t i = 0; i < 3 * n_spans[j]; ++i) dst[i] = src[i];
+}
+
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   size_t o = 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
@@ -432,6 +443,7 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
   if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
   if (n_jobs == 0) return TRGT_OK;
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t t_hmm0 = wall_ns();
   // ---- models (host libm ln tables), built in parallel over motif sets
   std::vector<HmmSetDev> sets((size_t)n_sets);
   std::vector<std::vector<uint8_t>> blobs((size_t)n_sets);
@@ -484,6 +496,7 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
       std::vector<uint8_t>().swap(blobs[s]);
     }
   }
+  c->dbg_ns[0] = wall_ns() - t_hmm0;
   // ---- jobs, grouped by workgroup size (64 * ceil(S/64))
   std::vector<HmmJobDev> jobs((size_t)n_jobs);
   uint64_t bp_total = 0, visit_total = 0, seq_total = 0, span_total = 0, count_total = 0, path_total = 0;
@@ -509,6 +522,7 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
   std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) {
     return (sets[a.set].S + 63) / 64 < (sets[b.set].S + 63) / 64;
   });
+  c->dbg_ns[1] = wall_ns() - t_hmm0;
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
   int rc;
@@ -523,14 +537,30 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_model, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   DevOut<uint16_t> o_path; DevOut<uint32_t> o_plen, o_nsp, o_cnt; DevOut<int32_t> o_spans, o_edit, o_maxd; DevOut<double> o_pur;
+  // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the
+  // spans actually produced are copied back (packed); a device buffer is written in the caller's layout directly.
+  const bool spans_on_host = !is_device_ptr(spans3);
+  std::vector<uint64_t> tight_off;
+  uint64_t tight_total = 0;
+  if (spans_on_host) {
+    tight_off.resize((size_t)n_jobs);
+    for (int64_t j = 0; j < n_jobs; ++j) { tight_off[(size_t)j] = tight_total; tight_total += (uint64_t)seq_len[j] + 1; }
+    for (auto& jd : jobs) jd.span_off = tight_off[jd.job_index];
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
+  }
   if ((rc = o_path.init(c, S_HMM_PATH, path, (size_t)path_total))) return rc;
   if ((rc = o_plen.init(c, S_HMM_PLEN, path_len, (size_t)n_jobs))) return rc;
-  if ((rc = o_spans.init(c, S_HMM_SPANS, spans3, (size_t)span_total * 3))) return rc;
+  if (spans_on_host) {
+    void* d = nullptr;
+    if ((rc = dev_get(c, S_HMM_SPANS, (size_t)tight_total * 12, &d))) return rc;
+    o_spans.user = spans3; o_spans.dev = (int32_t*)d; o_spans.count = 0; o_spans.staged = false;  // copied back packed, below
+  } else if ((rc = o_spans.init(c, S_HMM_SPANS, spans3, (size_t)span_total * 3))) return rc;
   if ((rc = o_nsp.init(c, S_HMM_NSP, n_spans, (size_t)n_jobs))) return rc;
   if ((rc = o_cnt.init(c, S_HMM_CNT, motif_counts, (size_t)count_total))) return rc;
   if ((rc = o_pur.init(c, S_HMM_PUR, purity, (size_t)n_jobs))) return rc;
   if ((rc = o_edit.init(c, S_HMM_EDIT, edit_dist, (size_t)n_jobs))) return rc;
   if ((rc = o_maxd.init(c, S_HMM_MAXD, max_dist, (size_t)n_jobs))) return rc;
+  c->dbg_ns[2] = wall_ns() - t_hmm0;
   // ---- one launch per workgroup-size class
   size_t i = 0;
   while (i < jobs.size()) {
@@ -553,9 +583,32 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
     t.stop(i == 0 ? cells : 0);
     i = e;
   }
+  if (spans_on_host) {
+    std::vector<uint32_t> h_nsp((size_t)n_jobs);
+    TRGT_HIP_TRY(c, hipMemcpyAsync(h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> poff((size_t)n_jobs);
+    uint64_t ptotal = 0;
+    for (int64_t j = 0; j < n_jobs; ++j) { poff[(size_t)j] = ptotal; ptotal += h_nsp[(size_t)j]; }
+    void *d_poff = nullptr, *d_toff = nullptr, *d_packed = nullptr;
+    if ((rc = dev_get(c, S_HMM_MOTIFS, (size_t)n_jobs * 16, &d_poff))) return rc;
+    d_toff = (uint8_t*)d_poff + (size_t)n_jobs * 8;
+    if ((rc = dev_get(c, S_HMM_BP, (size_t)ptotal * 12 + 16, &d_packed))) return rc;  // the back-pointer workspace is free again
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_poff, poff.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_toff, tight_off.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)o_spans.dev,
+                       (const uint64_t*)d_toff, (const uint32_t*)o_nsp.dev, (const uint64_t*)d_poff, (int32_t*)d_packed, (uint64_t)n_jobs);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    std::vector<int32_t> h_packed((size_t)ptotal * 3 + 1);
+    TRGT_HIP_TRY(c, hipMemcpyAsync(h_packed.data(), d_packed, (size_t)ptotal * 12, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int64_t j = 0; j < n_jobs; ++j)
+      std::memcpy(spans3 + 3 * span_off[j], h_packed.data() + 3 * poff[(size_t)j], (size_t)h_nsp[(size_t)j] * 12);
+  }
   if ((rc = o_path.finish(c)) || (rc = o_plen.finish(c)) || (rc = o_spans.finish(c)) || (rc = o_nsp.finish(c)) ||
       (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
     return rc;
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->dbg_ns[3] = wall_ns() - t_hmm0;
   return TRGT_OK;
 }

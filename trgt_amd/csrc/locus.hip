@@ -39,17 +39,21 @@ inline int cmp_seg(const Seg& a, const Seg& b) {
 inline bool eq_seg(const Seg& a, const Seg& b) { return a.n == b.n && std::memcmp(a.p, b.p, a.n) == 0; }
 inline uint32_t adiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
 
-struct ConsensusJob { int allele; std::vector<int> members; };  // members: indices into LocusWork::uniq
+struct Repair { int64_t locus; int allele; std::vector<Seg> members; std::string result; };  // rare: no majority sequence
 
-struct LocusWork {
-  std::vector<uint32_t> kept;       // input-read index of every kept spanning read, LocusResult.reads order
-  std::vector<Seg> trs;             // their repeat segments
-  int n_gt = 0;
+struct LocusWork {                  // plain data: no per-locus heap traffic on the common path
+  uint64_t seg_begin = 0, seg_end = 0;  // kept spanning reads = flat segment range, LocusResult.reads order
+  int n_gt = 0, n_pick = 0;
   uint32_t size[2] = {0, 0}; uint32_t ci[4] = {0, 0, 0, 0};
-  std::vector<Seg> uniq; std::vector<uint32_t> ucount;
-  std::vector<std::string> alleles;
-  std::vector<ConsensusJob> repairs;
-  std::vector<int> cls;
+  Seg pick[2] = {{nullptr, 0}, {nullptr, 0}};   // consensus::get_consensus picks (point into the segment bytes)
+  int repair[2] = {-1, -1};                      // index into the per-thread repair list, -1 = keep the pick
+  int repair_thread = 0;
+};
+
+struct Scratch {                    // per host thread, reused across loci
+  std::vector<uint32_t> lens, ulen, ucnt, ucount;
+  std::vector<Seg> trs, sorted, uniq;
+  std::vector<Repair> repairs;
 };
 
 // diploid::genotype (diploid.rs:5-103)
@@ -100,44 +104,55 @@ void genotype_haploid(const std::vector<uint32_t>& sizes, const std::vector<uint
 }
 
 // genotype_size::genotype up to the point where consensus alignments are needed (genotype_size.rs:6-37)
-void genotype_size_front(int ploidy, LocusWork& w) {
-  std::vector<uint32_t> lens;
-  for (auto& s : w.trs) lens.push_back(s.n);
+void genotype_size_front(int ploidy, int64_t locus, int thread, LocusWork& w, Scratch& sc) {
+  auto& lens = sc.lens; auto& ulen = sc.ulen; auto& ucnt = sc.ucnt;
+  lens.clear(); ulen.clear(); ucnt.clear();
+  for (auto& s : sc.trs) lens.push_back(s.n);
   std::sort(lens.begin(), lens.end());
-  std::vector<uint32_t> ulen, ucnt;
   for (size_t i = 0; i < lens.size();) { size_t j = i; while (j < lens.size() && lens[j] == lens[i]) ++j; ulen.push_back(lens[i]); ucnt.push_back((uint32_t)(j - i)); i = j; }
   if (ploidy == 1) genotype_haploid(ulen, ucnt, w); else genotype_diploid(ulen, ucnt, w);
   // get_seq_hist: unique sequences in byte-lexicographic order
-  std::vector<Seg> sorted = w.trs;
+  auto& sorted = sc.sorted; auto& uniq = sc.uniq; auto& ucount = sc.ucount;
+  sorted = sc.trs; uniq.clear(); ucount.clear();
   std::sort(sorted.begin(), sorted.end(), [](const Seg& a, const Seg& b) { return cmp_seg(a, b) < 0; });
   for (size_t i = 0; i < sorted.size();) {
     size_t j = i;
     while (j < sorted.size() && eq_seg(sorted[j], sorted[i])) ++j;
-    w.uniq.push_back(sorted[i]); w.ucount.push_back((uint32_t)(j - i));
+    uniq.push_back(sorted[i]); ucount.push_back((uint32_t)(j - i));
     i = j;
   }
-  auto closest = [&](uint32_t target) { uint32_t c = w.uniq[0].n; for (auto& s : w.uniq) if (adiff(c, target) > adiff(s.n, target)) c = s.n; return c; };
-  auto most_frequent = [&](uint32_t len) { int best = -1; for (size_t i = 0; i < w.uniq.size(); ++i) if (w.uniq[i].n == len && (best < 0 || w.ucount[i] >= w.ucount[best])) best = (int)i; return best; };
-  std::vector<int> pick{most_frequent(closest(w.size[0]))};
-  if (w.n_gt != 1 && w.size[0] != w.size[1]) pick.push_back(most_frequent(closest(w.size[1])));
-  for (size_t a = 0; a < pick.size(); ++a) {
-    w.alleles.emplace_back((const char*)w.uniq[pick[a]].p, w.uniq[pick[a]].n);
+  auto closest = [&](uint32_t target) { uint32_t c = uniq[0].n; for (auto& s : uniq) if (adiff(c, target) > adiff(s.n, target)) c = s.n; return c; };
+  auto most_frequent = [&](uint32_t len) { int best = -1; for (size_t i = 0; i < uniq.size(); ++i) if (uniq[i].n == len && (best < 0 || ucount[i] >= ucount[best])) best = (int)i; return best; };
+  int pick[2] = {most_frequent(closest(w.size[0])), -1};
+  w.n_pick = 1;
+  if (w.n_gt != 1 && w.size[0] != w.size[1]) { pick[1] = most_frequent(closest(w.size[1])); w.n_pick = 2; }
+  w.repair_thread = thread;
+  for (int a = 0; a < w.n_pick; ++a) {
+    w.pick[a] = uniq[pick[a]];
     // split(): members of this allele's group
-    ConsensusJob job; job.allele = (int)a;
     uint64_t coverage = 0, ref_count = 0;
-    for (size_t i = 0; i < w.uniq.size(); ++i) {
+    for (size_t i = 0; i < uniq.size(); ++i) {
       bool in;
       if (w.n_gt == 1) in = true;
       else {
-        const uint32_t d1 = adiff(w.uniq[i].n, w.size[0]), d2 = adiff(w.uniq[i].n, w.size[1]);
+        const uint32_t d1 = adiff(uniq[i].n, w.size[0]), d2 = adiff(uniq[i].n, w.size[1]);
         in = a == 0 ? d1 <= d2 : d2 < d1;
       }
       if (!in) continue;
-      job.members.push_back((int)i);
-      coverage += w.ucount[i];
-      if ((int)i == pick[a]) ref_count = w.ucount[i];
+      coverage += ucount[i];
+      if ((int)i == pick[a]) ref_count = ucount[i];
     }
-    if (!(2 * ref_count >= coverage)) w.repairs.push_back(std::move(job));
+    if (!(2 * ref_count >= coverage)) {
+      Repair r; r.locus = locus; r.allele = a;
+      for (size_t i = 0; i < uniq.size(); ++i) {
+        bool in;
+        if (w.n_gt == 1) in = true;
+        else { const uint32_t d1 = adiff(uniq[i].n, w.size[0]), d2 = adiff(uniq[i].n, w.size[1]); in = a == 0 ? d1 <= d2 : d2 < d1; }
+        if (in) r.members.push_back(uniq[i]);
+      }
+      w.repair[a] = (int)sc.repairs.size();
+      sc.repairs.push_back(std::move(r));
+    }
   }
 }
 
@@ -179,14 +194,14 @@ std::string repair_consensus(const std::string& backbone, const std::vector<Seg>
 }
 
 template <typename F>
-void parallel_for(int64_t n, int threads, F f) {
-  if (threads <= 1 || n < 64) { for (int64_t i = 0; i < n; ++i) f(i); return; }
+void parallel_for(int64_t n, int threads, F f) {  // f(index, thread)
+  if (threads <= 1 || n < 64) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
   std::vector<std::thread> th;
   const int64_t chunk = (n + threads - 1) / threads;
   for (int t = 0; t < threads; ++t) {
     const int64_t b = t * chunk, e = std::min<int64_t>(n, b + chunk);
     if (b >= e) break;
-    th.emplace_back([=]() { for (int64_t i = b; i < e; ++i) f(i); });
+    th.emplace_back([=]() { for (int64_t i = b; i < e; ++i) f(i, t); });
   }
   for (auto& x : th) x.join();
 }
@@ -241,83 +256,86 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   int64_t th0 = now_ns();
   std::vector<LocusWork> work((size_t)nl);
   const bool reads_on_device = is_device_ptr(in->read_blob);
-  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len;
-  std::vector<uint64_t> locus_seg_begin((size_t)nl + 1, 0);
-  for (int64_t l = 0; l < nl; ++l) {
-    LocusWork& w = work[(size_t)l];
-    locus_seg_begin[l] = seg_src.size();
-    if (in->ploidy[l] == 0) continue;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len, seg_read;
+  seg_src.reserve((size_t)nr); seg_dst.reserve((size_t)nr); seg_len.reserve((size_t)nr); seg_read.reserve((size_t)nr);
+  {
     struct K { uint32_t read, s, e; };
     std::vector<K> ks;
-    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
-      const int32_t s = out->span_start[r], e = out->span_end[r];
-      if (s < 0) continue;
-      if (s >= F && (int64_t)in->read_len[r] - e >= F) ks.push_back({(uint32_t)r, (uint32_t)s, (uint32_t)e});
-    }
-    std::stable_sort(ks.begin(), ks.end(), [](const K& a, const K& b) { return (a.e - a.s) < (b.e - b.s); });
-    if ((int64_t)ks.size() > p->max_depth) {  // uniform_downsample (tr.rs:172-184)
-      const double step = (double)ks.size() / (double)p->max_depth;
-      double fast = 0.0;
-      for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
-      ks.resize((size_t)p->max_depth);
-    }
-    uint64_t dst = seg_dst.empty() ? 0 : seg_dst.back() + seg_len.back();
-    for (auto& k : ks) {
-      w.kept.push_back(k.read);
-      seg_src.push_back(in->read_off[k.read] + k.s); seg_dst.push_back(dst); seg_len.push_back(k.e - k.s);
-      dst += k.e - k.s;
+    uint64_t dst = 0;
+    for (int64_t l = 0; l < nl; ++l) {
+      LocusWork& w = work[(size_t)l];
+      w.seg_begin = w.seg_end = seg_src.size();
+      if (in->ploidy[l] == 0) continue;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+      ks.clear();
+      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+        const int32_t s = out->span_start[r], e = out->span_end[r];
+        if (s < 0) continue;
+        if (s >= F && (int64_t)in->read_len[r] - e >= F) ks.push_back({(uint32_t)r, (uint32_t)s, (uint32_t)e});
+      }
+      std::stable_sort(ks.begin(), ks.end(), [](const K& a, const K& b) { return (a.e - a.s) < (b.e - b.s); });
+      if ((int64_t)ks.size() > p->max_depth) {  // uniform_downsample (tr.rs:172-184)
+        const double step = (double)ks.size() / (double)p->max_depth;
+        double fast = 0.0;
+        for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
+        ks.resize((size_t)p->max_depth);
+      }
+      for (auto& k : ks) {
+        seg_read.push_back(k.read);
+        seg_src.push_back(in->read_off[k.read] + k.s); seg_dst.push_back(dst); seg_len.push_back(k.e - k.s);
+        dst += k.e - k.s;
+      }
+      w.seg_end = seg_src.size();
     }
   }
-  locus_seg_begin[nl] = seg_src.size();
   stat_spanning = (int64_t)seg_src.size();
   std::vector<uint8_t> seg_bytes;
   const uint8_t* seg_base = nullptr;
-  if (!seg_src.empty()) {
+  if (!seg_src.empty() && reads_on_device) {
     const uint64_t total = seg_dst.back() + seg_len.back();
-    if (reads_on_device) {
-      seg_bytes.resize((size_t)total + 1);
-      void *d_src, *d_dst, *d_len, *d_out;
-      if ((rc = dev_get(c, S_LOCUS_0, seg_src.size() * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, seg_dst.size() * 8, &d_dst)) ||
-          (rc = dev_get(c, S_LOCUS_2, seg_len.size() * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)total + 1, &d_out)))
-        return rc;
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), seg_src.size() * 8, hipMemcpyHostToDevice, c->stream));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), seg_dst.size() * 8, hipMemcpyHostToDevice, c->stream));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, c->stream));
-      GatherArgs ga{in->read_blob, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)seg_src.size(), (uint8_t*)d_out};
-      hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((seg_src.size() + 3) / 4)), dim3(256), 0, c->stream, ga);
-      TRGT_HIP_TRY(c, hipGetLastError());
-      TRGT_HIP_TRY(c, hipMemcpyAsync(seg_bytes.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-      seg_base = seg_bytes.data();
-    }
+    seg_bytes.resize((size_t)total + 1);
+    void *d_src, *d_dst, *d_len, *d_out;
+    if ((rc = dev_get(c, S_LOCUS_0, seg_src.size() * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, seg_dst.size() * 8, &d_dst)) ||
+        (rc = dev_get(c, S_LOCUS_2, seg_len.size() * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)total + 1, &d_out)))
+      return rc;
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), seg_src.size() * 8, hipMemcpyHostToDevice, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), seg_dst.size() * 8, hipMemcpyHostToDevice, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, c->stream));
+    GatherArgs ga{in->read_blob, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)seg_src.size(), (uint8_t*)d_out};
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((seg_src.size() + 3) / 4)), dim3(256), 0, c->stream, ga);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    TRGT_HIP_TRY(c, hipMemcpyAsync(seg_bytes.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    seg_base = seg_bytes.data();
   }
-  // ---------------- host: length genotyping front half, threaded over loci
-  parallel_for(nl, threads, [&](int64_t l) {
+  auto seg_of = [&](uint64_t s) { return reads_on_device ? Seg{seg_base + seg_dst[s], seg_len[s]} : Seg{in->read_blob + seg_src[s], seg_len[s]}; };
+  // ---------------- host: length genotyping front half, threaded over loci (per-thread scratch, no per-locus allocation)
+  std::vector<Scratch> scratch((size_t)std::max(1, threads));
+  parallel_for(nl, threads, [&](int64_t l, int t) {
     LocusWork& w = work[(size_t)l];
-    if (w.kept.empty()) return;
-    for (uint64_t s = locus_seg_begin[l]; s < locus_seg_begin[l + 1]; ++s)
-      w.trs.push_back(reads_on_device ? Seg{seg_base + seg_dst[s], seg_len[s]} : Seg{in->read_blob + seg_src[s], seg_len[s]});
-    genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, w);
+    if (w.seg_begin == w.seg_end) return;
+    Scratch& sc = scratch[(size_t)t];
+    sc.trs.clear();
+    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(seg_of(s));
+    genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, l, t, w, sc);
   });
   tHost += now_ns() - th0;
   // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
   int64_t tb0 = now_ns();
-  struct JobRef { int64_t locus; int repair, member; };
+  struct JobRef { Repair* rep; int member; };
   std::vector<JobRef> jrefs;
   std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
-  for (int64_t l = 0; l < nl; ++l)
-    for (size_t ri = 0; ri < work[(size_t)l].repairs.size(); ++ri) {
-      LocusWork& w = work[(size_t)l];
-      const std::string& bb = w.alleles[w.repairs[ri].allele];
+  for (auto& sc : scratch)
+    for (auto& rep : sc.repairs) {
+      const Seg bb = work[(size_t)rep.locus].pick[rep.allele];
       const uint64_t bo = cblob.size();
-      cblob.insert(cblob.end(), bb.begin(), bb.end());
-      for (size_t m = 0; m < w.repairs[ri].members.size(); ++m) {
-        const Seg& s = w.uniq[w.repairs[ri].members[m]];
-        poff.push_back(bo); plen.push_back((uint32_t)bb.size());
+      cblob.insert(cblob.end(), bb.p, bb.p + bb.n);
+      for (size_t m = 0; m < rep.members.size(); ++m) {
+        const Seg& s = rep.members[m];
+        coff.push_back(coff.empty() ? 0 : coff.back() + plen.back() + tlen.back() + 1);
+        poff.push_back(bo); plen.push_back(bb.n);
         toff.push_back(cblob.size()); tlen.push_back(s.n);
         cblob.insert(cblob.end(), s.p, s.p + s.n);
-        coff.push_back(coff.empty() ? 0 : coff.back() + plen[plen.size() - 2] + tlen[tlen.size() - 2] + 1);
-        jrefs.push_back({l, (int)ri, (int)m});
+        jrefs.push_back({&rep, (int)m});
       }
     }
   std::vector<uint32_t> cigars, clen(jrefs.size());
@@ -336,51 +354,55 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   th0 = now_ns();
   {
     size_t j = 0;
-    for (int64_t l = 0; l < nl; ++l) {
-      LocusWork& w = work[(size_t)l];
-      for (size_t ri = 0; ri < w.repairs.size(); ++ri) {
-        std::vector<Seg> seqs; std::vector<std::vector<uint32_t>> cg;
-        for (size_t m = 0; m < w.repairs[ri].members.size(); ++m, ++j) {
-          seqs.push_back(w.uniq[w.repairs[ri].members[m]]);
-          cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
-        }
-        w.alleles[w.repairs[ri].allele] = repair_consensus(w.alleles[w.repairs[ri].allele], seqs, cg);
-      }
+    while (j < jrefs.size()) {  // jobs of one repair are contiguous
+      Repair* rep = jrefs[j].rep;
+      std::vector<std::vector<uint32_t>> cg;
+      for (size_t m = 0; m < rep->members.size(); ++m, ++j)
+        cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
+      const Seg bb = work[(size_t)rep->locus].pick[rep->allele];
+      rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
     }
   }
+  std::vector<int8_t> seg_cls(seg_src.size(), 0);
   int bad = 0;
-  parallel_for(nl, threads, [&](int64_t l) {
+  parallel_for(nl, threads, [&](int64_t l, int) {
     LocusWork& w = work[(size_t)l];
-    if (w.kept.empty()) return;
+    if (w.seg_begin == w.seg_end) return;
     const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
-    if (ploidy == 2 && w.alleles.size() == 1) w.alleles.push_back(w.alleles[0]);
-    w.cls.assign(w.trs.size(), 0);
-    int tie = 1;
-    if (w.alleles.size() == 2)
-      for (size_t i = 0; i < w.trs.size(); ++i) {
-        const uint32_t d1 = adiff(w.trs[i].n, (uint32_t)w.alleles[0].size()), d2 = adiff(w.trs[i].n, (uint32_t)w.alleles[1].size());
-        if (d1 < d2) w.cls[i] = 0; else if (d1 > d2) w.cls[i] = 1; else { tie = (tie + 1) % 2; w.cls[i] = tie; }
-      }
+    Seg al[2];
+    for (int a = 0; a < w.n_pick; ++a) {
+      if (w.repair[a] >= 0) { const std::string& r = scratch[(size_t)w.repair_thread].repairs[(size_t)w.repair[a]].result; al[a] = Seg{(const uint8_t*)r.data(), (uint32_t)r.size()}; }
+      else al[a] = w.pick[a];
+    }
+    int n_al = w.n_pick;
+    if (ploidy == 2 && n_al == 1) { al[1] = al[0]; n_al = 2; }
     int by_hap[2] = {0, 0};
-    for (int cc : w.cls) by_hap[cc] += 1;
+    int tie = 1;
+    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
+      int cc = 0;
+      if (n_al == 2) {
+        const uint32_t d1 = adiff(seg_len[s], al[0].n), d2 = adiff(seg_len[s], al[1].n);
+        if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
+      }
+      seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
+    }
     int order[2] = {0, 1};
     const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};
-    auto is_ref = [&](const std::string& a) { return a.size() == ref.n && std::memcmp(a.data(), ref.p, ref.n) == 0; };
-    if (w.n_gt != 1 && !is_ref(w.alleles[0]) && is_ref(w.alleles[1])) {  // tr.rs:95-101
-      order[0] = 1; order[1] = 0;
-      for (int& cc : w.cls) cc = 1 - cc;
-    }
+    bool flip = false;
+    if (w.n_gt != 1 && !eq_seg(al[0], ref) && eq_seg(al[1], ref)) { order[0] = 1; order[1] = 0; flip = true; }  // tr.rs:95-101
     out->n_alleles[l] = w.n_gt;
     for (int oi = 0; oi < w.n_gt; ++oi) {
       const int a = order[oi];
-      const std::string& s = w.alleles[a];
-      if (s.size() > out->allele_cap[l]) { bad = 1; return; }
-      std::memcpy(out->allele_blob + out->allele_off[2 * l + oi], s.data(), s.size());
-      out->allele_len[2 * l + oi] = (uint32_t)s.size();
+      if (al[a].n > out->allele_cap[l]) { bad = 1; return; }
+      std::memcpy(out->allele_blob + out->allele_off[2 * l + oi], al[a].p, al[a].n);
+      out->allele_len[2 * l + oi] = al[a].n;
       out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
       out->num_spanning[2 * l + oi] = by_hap[a];
     }
-    for (size_t i = 0; i < w.kept.size(); ++i) { out->classification[w.kept[i]] = w.cls[i]; out->read_rank[w.kept[i]] = (int32_t)i; }
+    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
+      out->classification[seg_read[s]] = flip ? 1 - seg_cls[s] : seg_cls[s];
+      out->read_rank[seg_read[s]] = (int32_t)(s - w.seg_begin);
+    }
   });
   if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
   tHost += now_ns() - th0;
@@ -407,7 +429,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = (int64_t)job_set.size();
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
-    for (int i = 9; i < 16; ++i) s[i] = 0;
+    for (int i = 0; i < 4; ++i) s[9 + i] = c->dbg_ns[i];
+    for (int i = 13; i < 16; ++i) s[i] = 0;
   }
   return TRGT_OK;
 }

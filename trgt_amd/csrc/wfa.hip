@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
           for (int b = 0; b < 4; ++b) if (i + b < tlen) wv |= (uint32_t)lds_seq[pl_pad + i + b] << (8 * b);
           T4[i] = wv;
         }
-        st = wf_run_lds_affine(kp, P4, T4, ring, (int)a.fast_wcap);
+        st = wf_run_lds_affine(kp, P4, T4, ring, (int)a.fast_wcap, ws.arena_u);
       }
       else
         st = wf_run<METRIC>(I_UNI, kp);

@@ -25,7 +25,8 @@ __device__ __forceinline__ int32_t ring_get(const uint16_t* arr, int wcap, int k
 }
 
 // P, T: LDS copies of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  All threads; returns ST_*.
-__device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32_t* P4, const uint32_t* T4, uint16_t* ring, int wcap) {
+__device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32_t* P4, const uint32_t* T4, uint16_t* ring, int wcap,
+                                                 int32_t* __restrict__ A) {
   Inst& I = sh.inst[I_UNI];
   const int tid = threadIdx.x, nT = blockDim.x;
   const int plen = I.plen, tlen = I.tlen, ak = tlen - plen, koff = plen + 2;  // one pad cell each side: k-1 / k+1 reads never leave the slot
@@ -34,7 +35,6 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
   uint16_t* Mr = ring;
   uint16_t* Ir = ring + RM * wcap;
   uint16_t* Dr = Ir + RI * wcap;
-  int32_t* __restrict__ A = I.arena;
   const uint32_t cap = I.arena_cap;
   const int n_slots = I.n_slots, span = I.span, pef = I.pef, tef = I.tef;
 
@@ -70,6 +70,7 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
   uint32_t bump = (uint32_t)(lastM.hi - lastM.lo + 1);
   unsigned long long cells = bump;
   int status = ST_OK, num_null = 0, s = 0;
+  int slM = 0, slI = 0;  // s % RM, s % RI kept incrementally
   bool computed = true;
   if (bump > cap || n_slots < 1) status = ST_OOM;
   else {
@@ -109,6 +110,7 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     if (lastM.base == NOBASE && num_null > scope) { status = ST_END_UNREACHABLE; break; }
     // ---- next level
     ++s;
+    slM = slM + 1 == RM ? 0 : slM + 1; slI = slI + 1 == RI ? 0 : slI + 1;
     auto getd = [&](int c, int lvl) -> WfDesc {
       if (lvl < 0) return null_desc();
       WfDesc d = lvl == s - 1 ? (c == CM ? lastM : c == CI1 ? lastI : lastD) : sh.ring[I_UNI][(lvl & (RING - 1)) * 5 + c];
@@ -134,13 +136,15 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     lastD = lastM; lastD.base = bD; if (!has_d) lastD = null_desc();
     // Branch-light strip loop in the encoded domain (enc = offset + 1, 0 = NULL):
     //   ins = max(Mo[k-1], Ie[k-1]) (+1 if non-NULL), del = max(Mo[k+1], De[k+1]), mis = Mm[k] (+1 if non-NULL)
-    const uint16_t* pMo = Mr + ((s - oe) % RM + RM) % RM * wcap + koff;
-    const uint16_t* pMm = Mr + ((s - x) % RM + RM) % RM * wcap + koff;
-    const uint16_t* pIe = Ir + ((s - e) % RI + RI) % RI * wcap + koff;
-    const uint16_t* pDe = Dr + ((s - e) % RI + RI) % RI * wcap + koff;
-    uint16_t* qM = Mr + (s % RM) * wcap + koff;
-    uint16_t* qI = Ir + (s % RI) * wcap + koff;
-    uint16_t* qD = Dr + (s % RI) * wcap + koff;
+    const int slMo = slM - oe < 0 ? slM - oe + RM : slM - oe, slMm = slM - x < 0 ? slM - x + RM : slM - x;  // oe, x < RM
+    const int slIe = slI - e < 0 ? slI - e + RI : slI - e;
+    const uint16_t* pMo = Mr + slMo * wcap + koff;
+    const uint16_t* pMm = Mr + slMm * wcap + koff;
+    const uint16_t* pIe = Ir + slIe * wcap + koff;
+    const uint16_t* pDe = Dr + slIe * wcap + koff;
+    uint16_t* qM = Mr + slM * wcap + koff;
+    uint16_t* qI = Ir + slI * wcap + koff;
+    uint16_t* qD = Dr + slI * wcap + koff;
     const int lo_mo = m_o.lo, lo_mm = m_mis.lo, lo_ie = ie.lo, lo_de = de.lo;
     const unsigned n_mo = m_o.base == NOBASE ? 0u : (unsigned)(m_o.hi - m_o.lo + 1), n_mm = m_mis.base == NOBASE ? 0u : (unsigned)(m_mis.hi - m_mis.lo + 1);
     const unsigned n_ie = ie.base == NOBASE ? 0u : (unsigned)(ie.hi - ie.lo + 1), n_de = de.base == NOBASE ? 0u : (unsigned)(de.hi - de.lo + 1);
@@ -148,7 +152,9 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     int32_t* __restrict__ hI = A + bI - lo;
     int32_t* __restrict__ hD = A + bD - lo;
     Red& rn = sh.red3[s % 3];
-    int fM = INT32_MAX, lM = INT32_MIN, fI = INT32_MAX, lI = INT32_MIN, fD = INT32_MAX, lD = INT32_MIN;  // per-lane first / last in-bounds k
+    // per-lane first / last in-bounds diagonal of M, I, D as biased 16-bit values (kb = k + koff); "last" is stored
+    // complemented so that a single packed unsigned min reduces everything: t0 = (fM, fI), t1 = (fD, ~lM), t2 = (~lI, ~lD)
+    unsigned fM = 0xFFFFu, fI = 0xFFFFu, fD = 0xFFFFu, nlM = 0xFFFFu, nlI = 0xFFFFu, nlD = 0xFFFFu;
     for (int k = lo + tid; k <= hi; k += nT) {
       unsigned a = pMo[k - 1], b = pIe[k - 1], c = pMo[k + 1], d = pDe[k + 1], m = pMm[k];
       a = (unsigned)(k - 1 - lo_mo) < n_mo ? a : 0u;
@@ -167,15 +173,27 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
       hI[k] = vi; hD[k] = vd; hM[k] = off;  // history for the back-trace: written once, never re-read by this loop
       // wavefront_compute_trim_ends bookkeeping: k only grows per lane, so "first" is set once and "last" overwritten
       const bool okI = in_bounds(vi, k, plen, tlen), okD = in_bounds(vd, k, plen, tlen);
-      fM = okM ? min(fM, k) : fM; lM = okM ? k : lM;
-      fI = okI ? min(fI, k) : fI; lI = okI ? k : lI;
-      fD = okD ? min(fD, k) : fD; lD = okD ? k : lD;
+      const unsigned kb = (unsigned)(k + koff), nkb = 0xFFFFu - kb;
+      fM = okM ? min(fM, kb) : fM; nlM = okM ? nkb : nlM;
+      fI = okI ? min(fI, kb) : fI; nlI = okI ? nkb : nlI;
+      fD = okD ? min(fD, kb) : fD; nlD = okD ? nkb : nlD;
     }
-    fM = wave_min(fM); lM = wave_max(lM); fI = wave_min(fI); lI = wave_max(lI); fD = wave_min(fD); lD = wave_max(lD);
-    if ((tid & 63) == 0) {
-      if (fM != INT32_MAX) { atomicMin(&rn.lo[CM], fM); atomicMax(&rn.hi[CM], lM); }
-      if (fI != INT32_MAX) { atomicMin(&rn.lo[CI1], fI); atomicMax(&rn.hi[CI1], lI); }
-      if (fD != INT32_MAX) { atomicMin(&rn.lo[CD1], fD); atomicMax(&rn.hi[CD1], lD); }
+    {
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      union U { unsigned u; us2 v; };
+      U t0, t1, t2;
+      t0.u = fM | (fI << 16); t1.u = fD | (nlM << 16); t2.u = nlI | (nlD << 16);
+      for (int o = 32; o > 0; o >>= 1) {
+        U a0, a1, a2;
+        a0.u = __shfl_xor(t0.u, o); a1.u = __shfl_xor(t1.u, o); a2.u = __shfl_xor(t2.u, o);
+        t0.v = __builtin_elementwise_min(t0.v, a0.v); t1.v = __builtin_elementwise_min(t1.v, a1.v); t2.v = __builtin_elementwise_min(t2.v, a2.v);
+      }
+      if ((tid & 63) == 0) {
+        const unsigned rfM = t0.u & 0xFFFFu, rfI = t0.u >> 16, rfD = t1.u & 0xFFFFu, rlM = 0xFFFFu - (t1.u >> 16), rlI = 0xFFFFu - (t2.u & 0xFFFFu), rlD = 0xFFFFu - (t2.u >> 16);
+        if (rfM != 0xFFFFu) { atomicMin(&rn.lo[CM], (int)rfM - koff); atomicMax(&rn.hi[CM], (int)rlM - koff); }
+        if (rfI != 0xFFFFu) { atomicMin(&rn.lo[CI1], (int)rfI - koff); atomicMax(&rn.hi[CI1], (int)rlI - koff); }
+        if (rfD != 0xFFFFu) { atomicMin(&rn.lo[CD1], (int)rfD - koff); atomicMax(&rn.hi[CD1], (int)rlD - koff); }
+      }
     }
   }
   __syncthreads();
