@@ -256,38 +256,47 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   int64_t th0 = now_ns();
   std::vector<LocusWork> work((size_t)nl);
   const bool reads_on_device = is_device_ptr(in->read_blob);
-  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len, seg_read;
-  seg_src.reserve((size_t)nr); seg_dst.reserve((size_t)nr); seg_len.reserve((size_t)nr); seg_read.reserve((size_t)nr);
-  {
-    struct K { uint32_t read, s, e; };
-    std::vector<K> ks;
-    uint64_t dst = 0;
-    for (int64_t l = 0; l < nl; ++l) {
-      LocusWork& w = work[(size_t)l];
-      w.seg_begin = w.seg_end = seg_src.size();
-      if (in->ploidy[l] == 0) continue;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
-      ks.clear();
-      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
-        const int32_t s = out->span_start[r], e = out->span_end[r];
-        if (s < 0) continue;
-        if (s >= F && (int64_t)in->read_len[r] - e >= F) ks.push_back({(uint32_t)r, (uint32_t)s, (uint32_t)e});
+  // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
+  // each locus writes its selection into its own read range of `sel`
+  struct K { uint32_t read, s, e; };
+  std::vector<K> sel((size_t)nr);
+  std::vector<uint32_t> n_sel((size_t)nl, 0);
+  parallel_for(nl, threads, [&](int64_t l, int) {
+    if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+    K* ks = sel.data() + in->locus_read_begin[l];
+    uint32_t n = 0;
+    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+      const int32_t s = out->span_start[r], e = out->span_end[r];
+      if (s < 0) continue;
+      if (s >= F && (int64_t)in->read_len[r] - e >= F) {
+        const K k{(uint32_t)r, (uint32_t)s, (uint32_t)e};
+        uint32_t i = n++;  // stable insertion sort by span length
+        while (i > 0 && (ks[i - 1].e - ks[i - 1].s) > (k.e - k.s)) { ks[i] = ks[i - 1]; --i; }
+        ks[i] = k;
       }
-      std::stable_sort(ks.begin(), ks.end(), [](const K& a, const K& b) { return (a.e - a.s) < (b.e - b.s); });
-      if ((int64_t)ks.size() > p->max_depth) {  // uniform_downsample (tr.rs:172-184)
-        const double step = (double)ks.size() / (double)p->max_depth;
-        double fast = 0.0;
-        for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
-        ks.resize((size_t)p->max_depth);
-      }
-      for (auto& k : ks) {
-        seg_read.push_back(k.read);
-        seg_src.push_back(in->read_off[k.read] + k.s); seg_dst.push_back(dst); seg_len.push_back(k.e - k.s);
-        dst += k.e - k.s;
-      }
-      w.seg_end = seg_src.size();
     }
-  }
+    if ((int64_t)n > p->max_depth) {
+      const double step = (double)n / (double)p->max_depth;
+      double fast = 0.0;
+      for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
+      n = (uint32_t)p->max_depth;
+    }
+    n_sel[(size_t)l] = n;
+  });
+  // pass 2: flat segment arrays (LocusResult.reads order within each locus)
+  uint64_t n_seg = 0;
+  for (int64_t l = 0; l < nl; ++l) { work[(size_t)l].seg_begin = n_seg; n_seg += n_sel[(size_t)l]; work[(size_t)l].seg_end = n_seg; }
+  std::vector<uint64_t> seg_src((size_t)n_seg), seg_dst((size_t)n_seg); std::vector<uint32_t> seg_len((size_t)n_seg), seg_read((size_t)n_seg);
+  parallel_for(nl, threads, [&](int64_t l, int) {
+    const K* ks = sel.data() + in->locus_read_begin[l];
+    uint64_t s = work[(size_t)l].seg_begin;
+    for (uint32_t i = 0; i < n_sel[(size_t)l]; ++i, ++s) {
+      seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
+    }
+  });
+  { uint64_t dst = 0; for (uint64_t s = 0; s < n_seg; ++s) { seg_dst[s] = dst; dst += seg_len[s]; } }
   stat_spanning = (int64_t)seg_src.size();
+  c->dbg_ns[4] = now_ns() - th0;
   std::vector<uint8_t> seg_bytes;
   const uint8_t* seg_base = nullptr;
   if (!seg_src.empty() && reads_on_device) {
@@ -307,6 +316,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
     seg_base = seg_bytes.data();
   }
+  c->dbg_ns[5] = now_ns() - th0;
   auto seg_of = [&](uint64_t s) { return reads_on_device ? Seg{seg_base + seg_dst[s], seg_len[s]} : Seg{in->read_blob + seg_src[s], seg_len[s]}; };
   // ---------------- host: length genotyping front half, threaded over loci (per-thread scratch, no per-locus allocation)
   std::vector<Scratch> scratch((size_t)std::max(1, threads));
@@ -318,6 +328,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(seg_of(s));
     genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, l, t, w, sc);
   });
+  c->dbg_ns[6] = now_ns() - th0;
   tHost += now_ns() - th0;
   // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
   int64_t tb0 = now_ns();
@@ -405,6 +416,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
   });
   if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
+  c->dbg_ns[7] = now_ns() - th0;
   tHost += now_ns() - th0;
   // ---------------- stage C: label_with_hmm for every allele
   int64_t tc0 = now_ns();
@@ -429,8 +441,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = (int64_t)job_set.size();
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
-    for (int i = 0; i < 4; ++i) s[9 + i] = c->dbg_ns[i];
-    for (int i = 13; i < 16; ++i) s[i] = 0;
+    for (int i = 0; i < 7; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
   }
   return TRGT_OK;
 }
