@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,8 @@ struct trgt_hip_ctx {
   std::vector<Pending> pending;
   void* last_wfa_cells_dev = nullptr;
   int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host-side phase timers of the last call (diagnostics)
+  std::mutex* stage_a_mutex = nullptr;  // set while two lanes share the GPU: serialises the dominant GPU stage so the lanes interleave
+  trgt_hip_ctx* aux = nullptr;  // second lane (own stream + buffers) used by trgt_locus_batch to overlap host glue with GPU stages
 };
 
 namespace trgt {

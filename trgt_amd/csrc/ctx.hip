@@ -40,6 +40,7 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
 
 void trgt_hip_destroy(trgt_hip_ctx* c) {
   if (!c) return;
+  if (c->aux) { trgt_hip_destroy(c->aux); c->aux = nullptr; }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   trgt::resolve_timing(c);

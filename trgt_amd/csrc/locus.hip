@@ -222,7 +222,7 @@ inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanosec
 
 using namespace trgt;
 
-extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
   const int64_t nl = in->n_loci;
@@ -247,8 +247,13 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   // ---------------- stage A: flank location on the GPU
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
   std::vector<uint8_t> lf_hit((size_t)nr), rf_hit((size_t)nr);
-  int rc = trgt_find_spans_batch(c, &sp, nl, in->flank_blob, in->lf_off, in->lf_len, in->rf_off, in->rf_len, in->locus_read_begin,
-                                 in->read_blob, in->read_off, in->read_len, out->span_start, out->span_end, lf_hit.data(), rf_hit.data());
+  int rc;
+  {
+    std::unique_lock<std::mutex> lk;
+    if (c->stage_a_mutex) lk = std::unique_lock<std::mutex>(*c->stage_a_mutex);
+    rc = trgt_find_spans_batch(c, &sp, nl, in->flank_blob, in->lf_off, in->lf_len, in->rf_off, in->rf_len, in->locus_read_begin,
+                               in->read_blob, in->read_off, in->read_len, out->span_start, out->span_end, lf_hit.data(), rf_hit.data());
+  }
   if (rc) return rc;
   for (int64_t r = 0; r < nr; ++r) stat_flank_jobs += (lf_hit[r] != 1) + (rf_hit[r] != 1);
   tA = now_ns() - t0;
@@ -442,6 +447,78 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = (int64_t)job_set.size();
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
     for (int i = 0; i < 7; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
+  }
+  return TRGT_OK;
+}
+
+// Public entry point.  Large batches are cut into chunks that two host threads ("lanes", each with its own stream and
+// device buffers) work through alternately, so the host glue / transfers of one chunk overlap the GPU stages of the
+// other.  Chunks touch disjoint locus / read ranges of the caller's buffers, so no synchronisation is needed.
+extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
+  const int64_t nl = in->n_loci;
+  const int64_t CHUNK = 2500;
+  const char* env = getenv("TRGT_LOCUS_LANES");
+  const int lanes = env ? atoi(env) : 2;
+  if (nl < 2 * CHUNK || lanes < 2 || !in->locus_read_begin) return locus_batch_impl(c, p, in, out);
+  if (!c->aux) {
+    int rc = trgt_hip_create(c->device, &c->aux);
+    if (rc) return fail(c, rc, "trgt_locus_batch: cannot create the second lane: %s", trgt_hip_last_error(nullptr));
+  }
+  c->aux->timing = c->timing; c->aux->ws_limit = c->ws_limit / 2;
+  const uint64_t saved_limit = c->ws_limit;
+  c->ws_limit = saved_limit / 2;
+  const int64_t n_chunks = (nl + CHUNK - 1) / CHUNK;
+  trgt_hip_ctx* lane_ctx[2] = {c, c->aux};
+  int lane_rc[2] = {0, 0};
+  int64_t lane_stats[2][16];
+  std::memset(lane_stats, 0, sizeof lane_stats);
+  trgt_locus_params lp = *p;
+  int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+  lp.host_threads = std::max(1, std::min(threads, 32) / 2);
+  const int64_t t0 = now_ns();
+  std::mutex stage_a;
+  c->stage_a_mutex = &stage_a; c->aux->stage_a_mutex = &stage_a;
+  auto worker = [&](int lane) {
+    trgt_hip_ctx* cc = lane_ctx[lane];
+    for (int64_t ch = lane; ch < n_chunks && lane_rc[lane] == 0; ch += 2) {
+      const int64_t l0 = ch * CHUNK, l1 = std::min(nl, l0 + CHUNK), n = l1 - l0;
+      const uint64_t r0 = in->locus_read_begin[l0];
+      std::vector<uint64_t> lrb((size_t)n + 1);
+      for (int64_t i = 0; i <= n; ++i) lrb[(size_t)i] = in->locus_read_begin[l0 + i] - r0;
+      trgt_locus_batch_in si = *in;
+      si.n_loci = n;
+      si.lf_off += l0; si.lf_len += l0; si.rf_off += l0; si.rf_len += l0; si.tr_off += l0; si.tr_len += l0;
+      si.set_motif_begin += l0; si.ploidy += l0; si.locus_read_begin = lrb.data(); si.read_off += r0; si.read_len += r0;
+      trgt_locus_batch_out so = *out;
+      int64_t st[16];
+      so.span_start += r0; so.span_end += r0; so.classification += r0; so.read_rank += r0;
+      so.n_alleles += l0; so.allele_off += 2 * l0; so.allele_cap += l0; so.allele_len += 2 * l0; so.ci += 4 * l0; so.num_spanning += 2 * l0;
+      so.span_off += 2 * l0; so.n_spans += 2 * l0; so.count_off += 2 * l0; so.purity += 2 * l0;
+      so.stats = st;
+      const int rc = locus_batch_impl(cc, &lp, &si, &so);
+      if (rc) { lane_rc[lane] = rc; break; }
+      for (int i = 0; i < 8; ++i) lane_stats[lane][i] += st[i];
+    }
+  };
+  std::thread t1(worker, 1);
+  worker(0);
+  t1.join();
+  c->stage_a_mutex = nullptr; c->aux->stage_a_mutex = nullptr;
+  c->ws_limit = saved_limit;
+  if (lane_rc[1]) c->err = c->aux->err;
+  if (lane_rc[0] || lane_rc[1]) return lane_rc[0] ? lane_rc[0] : lane_rc[1];
+  // fold the second lane's kernel timers into the caller's ctx
+  resolve_timing(c->aux);
+  for (int k = 0; k < TRGT_K_COUNT; ++k) {
+    c->k_ms[k] += c->aux->k_ms[k]; c->k_launches[k] += c->aux->k_launches[k]; c->k_cells[k] += c->aux->k_cells[k];
+    c->aux->k_ms[k] = 0; c->aux->k_launches[k] = 0; c->aux->k_cells[k] = 0;
+  }
+  if (out->stats) {
+    for (int i = 0; i < 8; ++i) out->stats[i] = lane_stats[0][i] + lane_stats[1][i];
+    out->stats[8] = now_ns() - t0;
+    for (int i = 9; i < 16; ++i) out->stats[i] = 0;
   }
   return TRGT_OK;
 }
