@@ -250,7 +250,7 @@ static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const t
   int rc;
   {
     std::unique_lock<std::mutex> lk;
-    if (c->stage_a_mutex) lk = std::unique_lock<std::mutex>(*c->stage_a_mutex);
+    if (c->stage_a_mutex && getenv("TRGT_SERIAL_A")) lk = std::unique_lock<std::mutex>(*c->stage_a_mutex);
     rc = trgt_find_spans_batch(c, &sp, nl, in->flank_blob, in->lf_off, in->lf_len, in->rf_off, in->rf_len, in->locus_read_begin,
                                in->read_blob, in->read_off, in->read_len, out->span_start, out->span_end, lf_hit.data(), rf_hit.data());
   }
@@ -460,7 +460,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int64_t nl = in->n_loci;
   const int64_t CHUNK = 2500;
   const char* env = getenv("TRGT_LOCUS_LANES");
-  const int lanes = env ? atoi(env) : 2;
+  const int lanes = env ? atoi(env) : 1;  // measured: a persistent WFA kernel leaves no room for the other lane's kernels, so 2 lanes do not pay
   if (nl < 2 * CHUNK || lanes < 2 || !in->locus_read_begin) return locus_batch_impl(c, p, in, out);
   if (!c->aux) {
     int rc = trgt_hip_create(c->device, &c->aux);

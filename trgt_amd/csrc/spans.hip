@@ -132,14 +132,19 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   wp.metric = 3; wp.mismatch = p.mism; wp.gap_open1 = p.gapo; wp.gap_ext1 = p.gape;
   wp.span = 1; wp.pattern_begin_free = 0; wp.pattern_end_free = 0; wp.text_begin_free = -1; wp.text_end_free = -1;
   wp.scope = 1; wp.memory_mode = 0; wp.heuristic = 0;
+  // The number of fallback alignments is known only on the device; read it back (4 bytes) so that the WFA grid is exact.
+  uint32_t n_wfa = 0;
+  c->last_wfa_cells_dev = nullptr;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(&n_wfa, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   WfaLaunch L;
-  L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
+  L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_wfa; L.n_jobs_dev = nullptr;
   L.pat_base = d_flank; L.txt_base = d_reads;
   L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
   L.threads = 256;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
-  if ((rc = wfa_launch(c, wp, L))) return rc;
+  if (n_wfa > 0 && (rc = wfa_launch(c, wp, L))) return rc;
   CombineArgs ca;
   ca.n_reads = (uint64_t)n_reads; ca.flank_len = p.flank_len;
   ca.threshold = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;  // span_locater.rs:46
@@ -206,7 +211,7 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
     return rc;
   if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
   unsigned long long cells = 0;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells;
   return TRGT_OK;

@@ -44,6 +44,7 @@ struct KArgs {
   const JobDev* jobs; const uint32_t* n_jobs_dev; uint32_t n_jobs;
   const uint8_t* pat_base; const uint8_t* txt_base;
   unsigned int* counter;
+  unsigned int* slot_flags; uint32_t n_slots_ws, jobs_per_block;  // workspace slots are acquired per resident workgroup
   uint8_t* ws; uint64_t ws_per_block;
   uint64_t off_gdesc, off_arena_u, off_arena_f, off_arena_r, off_rle_tmp, off_rle_out, off_run_start;
   uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg;
