@@ -127,6 +127,13 @@ def main():
             bytes_per_launch = float(batch["read_len"].sum()) + 8.0 * n_reads
         else:
             bytes_per_launch = 4.0 * cells / max(launches, 1)
+        traffic = None  # measured HBM bytes per launch of the same kernel / workload, when a PMC profile is committed
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("loci_per_gpu") == args.loci and dom in tj["kernels"]:
+                traffic = int(tj["kernels"][dom]["bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
         avg_ms = ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         res = {
@@ -139,7 +146,7 @@ def main():
                        "loci_per_gpu": args.loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
                        "host_threads_per_rank": host_threads},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "dp_cells_per_launch": int(cells / max(launches, 1)),
                          "dp_cells_per_s": round(cells / max(ms, 1e-9) * 1e3, 1)},
