@@ -18,11 +18,6 @@ struct RleOut { uint32_t* buf; uint32_t cap; };
 
 __device__ __forceinline__ uint32_t op_code(char op) { return op == 'M' ? 7u : op == 'X' ? 8u : op == 'I' ? 1u : 2u; }
 
-__device__ __forceinline__ void rle_push(uint32_t* buf, int& n, uint32_t cap, uint32_t code, int len) {
-  if (len <= 0) return;
-  if (n > 0 && (buf[n - 1] & 0xF) == code) { buf[n - 1] += (uint32_t)len << 4; return; }
-  if ((uint32_t)n < cap) buf[n++] = ((uint32_t)len << 4) | code;
-}
 
 __device__ __forceinline__ long long bt_cand(const Inst& I, int c, int s, int k, int add, int type) {
   if (s < 0 || s >= I.n_slots) return (long long)OFF_NULL;
@@ -311,6 +306,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
       }
       __syncthreads();
       int st;
+      bool fast_bt = false;
       if (METRIC == M_AFFINE && staged && a.fast_wcap > 0 && (uint32_t)(plen + tlen + 6) <= a.fast_wcap) {
         // 4-byte sliding windows of both sequences (see wfa_fast.hpp), built from the LDS byte copies
         uint16_t* ring = reinterpret_cast<uint16_t*>(lds_seq + a.lds_seq_cap);
@@ -327,6 +323,24 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
           T4[i] = wv;
         }
         st = wf_run_lds_affine(kp, P4, T4, ring, (int)a.fast_wcap, ws.arena_u);
+        // back-trace by wave 0 with the level descriptors staged in the (now idle) ring area of LDS
+        const int es = sh.inst[I_UNI].end_score;
+        if (st == ST_END_REACHED && kp.scope_alignment && !a.fast_dbg && (uint32_t)(es + 1) * 3 * sizeof(WfDesc) <= a.fast_ring_bytes) {
+          WfDesc* ld = reinterpret_cast<WfDesc*>(ring);
+          __syncthreads();
+          for (int i = tid; i < (es + 1) * 3; i += T) {
+            const int lvl = i / 3, c3 = i - lvl * 3;
+            ld[i] = ws.gdesc[(size_t)lvl * 5 + (c3 == 0 ? CM : c3 == 1 ? CI1 : CD1)];
+          }
+          __syncthreads();
+          if (tid < 64) {
+            int nt = 0;
+            wf_backtrace_fast_affine(kp, ld, ws.arena_u, ws.rle_tmp, nt, a.rle_cap);
+            if (tid == 0) sh.rle_tmp_n = nt;
+          }
+          fast_bt = true;
+          __syncthreads();
+        }
       }
       else
         st = wf_run<METRIC>(I_UNI, kp);
@@ -336,7 +350,8 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
           sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
           if (kp.scope_alignment && !a.fast_dbg) {
             int nt = 0;
-            wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
+            if (fast_bt) nt = sh.rle_tmp_n;
+            else wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
             rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
           }
         }

@@ -86,6 +86,13 @@ struct Shared {
 __shared__ Shared g_sh;
 #define sh g_sh
 
+// run-length CIGAR building block (len << 4 | code), merging equal neighbours
+__device__ __forceinline__ void rle_push(uint32_t* buf, int& n, uint32_t cap, uint32_t code, int len) {
+  if (len <= 0) return;
+  if (n > 0 && (buf[n - 1] & 0xF) == code) { buf[n - 1] += (uint32_t)len << 4; return; }
+  if ((uint32_t)n < cap) buf[n++] = ((uint32_t)len << 4) | code;
+}
+
 __device__ __forceinline__ uint8_t seq_at(const uint8_t* p, int len, int rev, int i) { return p[rev ? len - 1 - i : i]; }
 
 __device__ __forceinline__ WfDesc null_desc() { WfDesc d; d.lo = 1; d.hi = -1; d.lo_alloc = 1; d.base = NOBASE; return d; }

@@ -202,5 +202,88 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
   return status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Back-trace of the fast path (gap-affine, single piece).  Same candidate encoding and priorities as
+// wf_backtrace (wavefront_backtrace_affine: (offset << 4 | type), maximum wins), but executed by the 64 lanes of
+// wave 0 with the level descriptors in LDS, and with gap runs resolved 64 steps per memory round trip: along a pure
+// gap-extension chain the next cells are known in advance -- (s - j*e, k + j) for deletions, (s - j*e, k - j) with the
+// offset falling by one for insertions -- so lane j fetches step j's two candidates and a ballot finds where the
+// chain stops.  Long deletion runs are what the back-trace of a read that lacks the flank consists of.
+// ld: LDS copy of the descriptors, ld[s * 3 + {0: M, 1: I1, 2: D1}].  Runs are pushed (reversed) by lane 0.
+__device__ __forceinline__ long long bt_cand_lds(const WfDesc* ld, const int32_t* __restrict__ A, int cidx, int s, int k, int add, int type) {
+  if (s < 0) return (long long)OFF_NULL;
+  const WfDesc d = ld[s * 3 + cidx];
+  if (d.base == NOBASE || k < d.lo || k > d.hi) return (long long)OFF_NULL;
+  return (((long long)(A[d.base + (uint32_t)(k - d.lo_alloc)] + add)) << 4) | type;
+}
+
+__device__ __forceinline__ void wf_backtrace_fast_affine(const KParams& kp, const WfDesc* ld, const int32_t* __restrict__ A,
+                                                         uint32_t* tmp, int& ntmp_out, uint32_t cap) {
+  const Inst& I = sh.inst[I_UNI];
+  const int lane = threadIdx.x & 63;
+  const int plen = I.plen, tlen = I.tlen;
+  const int x = kp.pen.x, oe = kp.pen.o1 + kp.pen.e1, e = kp.pen.e1;
+  int mt = CM, s = I.end_score, k = I.end_k, off = I.end_off;
+  int h = off, v = off - k, nt = 0;
+  if (lane == 0) { rle_push(tmp, nt, cap, 2u, plen - v); rle_push(tmp, nt, cap, 1u, tlen - h); }
+  while (v > 0 && h > 0 && s > 0) {
+    if (mt == CM) {
+      long long best = bt_cand_lds(ld, A, 0, s - x, k, +1, 9);
+      best = max(best, bt_cand_lds(ld, A, 2, s - e, k + 1, 0, 6));
+      best = max(best, bt_cand_lds(ld, A, 0, s - oe, k + 1, 0, 5));
+      best = max(best, bt_cand_lds(ld, A, 1, s - e, k - 1, +1, 2));
+      best = max(best, bt_cand_lds(ld, A, 0, s - oe, k - 1, +1, 1));
+      if (best < 0) break;
+      const int best_off = (int)(best >> 4), type = (int)(best & 0xF);
+      if (lane == 0) rle_push(tmp, nt, cap, 7u, off - best_off);
+      off = best_off; h = off; v = off - k;
+      if (v <= 0 || h <= 0) break;
+      switch (type) {
+        case 9: if (lane == 0) rle_push(tmp, nt, cap, 8u, 1); s -= x; --off; break;
+        case 1: if (lane == 0) rle_push(tmp, nt, cap, 1u, 1); s -= oe; --k; --off; break;
+        case 2: if (lane == 0) rle_push(tmp, nt, cap, 1u, 1); s -= e; mt = CI1; --k; --off; break;
+        case 5: if (lane == 0) rle_push(tmp, nt, cap, 2u, 1); s -= oe; ++k; break;
+        default: if (lane == 0) rle_push(tmp, nt, cap, 2u, 1); s -= e; mt = CD1; ++k; break;
+      }
+      h = off; v = off - k;
+    } else {
+      const bool del = mt == CD1;
+      // ---- lane j inspects step j of the gap-extension chain
+      const int sj = s - lane * e, kj = del ? k + lane : k - lane;
+      const bool alive = (del ? (v - lane > 0 && h > 0) : (h - lane > 0 && v > 0)) && sj > 0;
+      long long ce = (long long)OFF_NULL, co = (long long)OFF_NULL;
+      if (alive) {
+        ce = del ? bt_cand_lds(ld, A, 2, sj - e, kj + 1, 0, 6) : bt_cand_lds(ld, A, 1, sj - e, kj - 1, +1, 2);
+        co = del ? bt_cand_lds(ld, A, 0, sj - oe, kj + 1, 0, 5) : bt_cand_lds(ld, A, 0, sj - oe, kj - 1, +1, 1);
+      }
+      const bool cont = alive && ce >= 0 && ce > co;  // the extension candidate is the maximum
+      const unsigned long long stop = __ballot(!cont);
+      const int j = stop ? __ffsll((long long)stop) - 1 : 64;
+      if (j > 0) {  // j pure extension steps
+        if (lane == 0) rle_push(tmp, nt, cap, del ? 2u : 1u, j);
+        s -= j * e;
+        if (del) { k += j; } else { k -= j; off -= j; }
+        h = off; v = off - k;
+        continue;
+      }
+      // ---- the chain stops right here: one ordinary step (gap open, or no source at all)
+      const long long cext = del ? bt_cand_lds(ld, A, 2, s - e, k + 1, 0, 6) : bt_cand_lds(ld, A, 1, s - e, k - 1, +1, 2);
+      const long long copn = del ? bt_cand_lds(ld, A, 0, s - oe, k + 1, 0, 5) : bt_cand_lds(ld, A, 0, s - oe, k - 1, +1, 1);
+      const long long best = max(cext, copn);
+      if (best < 0) break;
+      if (lane == 0) rle_push(tmp, nt, cap, del ? 2u : 1u, 1);
+      if (best == cext) s -= e; else { s -= oe; mt = CM; }
+      if (del) ++k; else { --k; --off; }
+      h = off; v = off - k;
+    }
+  }
+  if (lane == 0) {
+    if (mt == CM && v > 0 && h > 0) { const int n = min(v, h); rle_push(tmp, nt, cap, 7u, n); v -= n; h -= n; }
+    rle_push(tmp, nt, cap, 2u, v);
+    rle_push(tmp, nt, cap, 1u, h);
+    ntmp_out = nt;
+  }
+}
+
 }  // namespace wfa
 }  // namespace trgt
