@@ -27,18 +27,10 @@
 namespace trgt {
 
 // ------------------------------------------------------------ host model
-struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
-  uint32_t S, n_blocks, n_levels, max_mlen;
-  uint64_t off_inlp;    // f64 [4][S]   ln transition probabilities, predecessor-list order of the reference
-  uint64_t off_em;      // f64 [5][S]   ln emissions over # A T C G
-  uint64_t off_inst;    // u16 [4][S]   predecessor states
-  uint64_t off_block;   // i16 [S]      motif block of the state (-1 outside)
-  uint64_t off_nin;     // u8  [S]      #predecessors (0xFF: run-end state, predecessors = block ends)
-  uint64_t off_level;   // u8  [S]      0 emitting, >=1 silent evaluation level
-  uint64_t off_flags;   // u8  [S]      bit0 any finite emission, bit1 emits a base
-  uint64_t off_blocks;  // u32 [4][n_blocks]  start,end,mlen,motif byte offset
-  uint64_t off_motifs;  // sanitised motif bytes
-};
+
+}  // namespace trgt
+#include "hmm_host.hpp"
+namespace trgt {
 
 struct HmmJobDev {
   uint32_t set, seq_len, job_index, path_cap;
@@ -420,32 +412,13 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   return o + 64;
 }
 
-}  // namespace trgt
 
-using namespace trgt;
-
-extern "C" uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_len) {
-  if (seq_len == 0) return 1;
-  return (uint64_t)(seq_len + 2) * (max_motif_len + 4) + 8;
-}
-
-extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
-                              const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
-                              const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
-                              const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
-                              uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
-                              int32_t* edit_dist, int32_t* max_dist) {
-  if (!c) return TRGT_ERR_INVALID;
-  if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
-                                                    !seq_len || !spans3 || !span_off || !n_spans || !motif_counts ||
-                                                    !count_off || !purity)))
-    return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: null argument");
-  if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
-  if (n_jobs == 0) return TRGT_OK;
-  TRGT_HIP_TRY(c, hipSetDevice(c->device));
-  const int64_t t_hmm0 = wall_ns();
-  // ---- models (host libm ln tables), built in parallel over motif sets
-  std::vector<HmmSetDev> sets((size_t)n_sets);
+// All motif-set models of a batch (host side).  Thread-safe: touches no ctx state.
+int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin, HmmModels& out) {
+  char msg[160];
+  out.rc = 0;
+  std::vector<HmmSetDev>& sets = out.sets;
+  sets.assign((size_t)n_sets, HmmSetDev());
   std::vector<std::vector<uint8_t>> blobs((size_t)n_sets);
   std::vector<int> set_err((size_t)n_sets, 0);
   {
@@ -475,14 +448,14 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
       for (auto& x : th) x.join();
     }
   }
-  std::vector<uint8_t> blob;
+  std::vector<uint8_t>& blob = out.blob;
   {
     uint64_t total = 0;
     for (int s = 0; s < n_sets; ++s) {
-      if (set_err[s] == 1) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: empty motif in set %d", s);
-      if (set_err[s] == 2) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: set %d has no motif", s);
-      if (set_err[s] == 3) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, sets[s].S);
-      if (set_err[s] == 4) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: set %d has too many motifs", s);
+      if (set_err[s] == 1) { snprintf(msg, sizeof msg, "trgt_hmm_batch: empty motif in set %d", s); out.err = msg; return out.rc = TRGT_ERR_INVALID; }
+      if (set_err[s] == 2) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has no motif", s); out.err = msg; return out.rc = TRGT_ERR_INVALID; }
+      if (set_err[s] == 3) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, sets[s].S); out.err = msg; return out.rc = TRGT_ERR_UNSUPPORTED; }
+      if (set_err[s] == 4) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has too many motifs", s); out.err = msg; return out.rc = TRGT_ERR_UNSUPPORTED; }
       total += blobs[s].size();
     }
     blob.resize((size_t)total);
@@ -496,6 +469,44 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
       std::vector<uint8_t>().swap(blobs[s]);
     }
   }
+  return 0;
+}
+
+}  // namespace trgt
+
+using namespace trgt;
+
+extern "C" uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_len) {
+  if (seq_len == 0) return 1;
+  return (uint64_t)(seq_len + 2) * (max_motif_len + 4) + 8;
+}
+
+int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                              const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
+                              const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
+                              const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
+                              uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                              int32_t* edit_dist, int32_t* max_dist) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
+                                                    !seq_len || !spans3 || !span_off || !n_spans || !motif_counts ||
+                                                    !count_off || !purity)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: null argument");
+  if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
+  if (n_jobs == 0) return TRGT_OK;
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t t_hmm0 = wall_ns();
+  // ---- models (host libm ln tables): built here unless the caller prepared them ahead of time (trgt_locus_batch does,
+  //      concurrently with the flank-location stage)
+  HmmModels local_models;
+  const HmmModels* mp = premade;
+  if (!mp) {
+    const int mrc = hmm_build_models(n_sets, motif_blob, motif_off, set_motif_begin, local_models);
+    if (mrc) return fail(c, mrc, "%s", local_models.err.c_str());
+    mp = &local_models;
+  } else if (mp->rc) return fail(c, mp->rc, "%s", mp->err.c_str());
+  const std::vector<HmmSetDev>& sets = mp->sets;
+  const std::vector<uint8_t>& blob = mp->blob;
   c->dbg_ns[0] = wall_ns() - t_hmm0;
   // ---- jobs, grouped by workgroup size (64 * ceil(S/64))
   std::vector<HmmJobDev> jobs((size_t)n_jobs);
@@ -611,4 +622,14 @@ extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* mo
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->dbg_ns[3] = wall_ns() - t_hmm0;
   return TRGT_OK;
+}
+
+extern "C" int trgt_hmm_batch(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                              const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
+                              const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
+                              const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
+                              uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                              int32_t* edit_dist, int32_t* max_dist) {
+  return hmm_batch_impl(c, nullptr, n_sets, motif_blob, motif_off, set_motif_begin, n_jobs, job_set, seq_blob, seq_off, seq_len, path,
+                        path_off, path_len, spans3, span_off, n_spans, motif_counts, count_off, purity, edit_dist, max_dist);
 }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <thread>
 
+#include "hmm_host.hpp"
 #include "wfa_host.hpp"
 
 namespace trgt {
@@ -244,6 +245,10 @@ static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const t
   for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
   for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
   if (nr == 0) return TRGT_OK;
+  // The motif-HMM tables depend only on the catalog: build them on a host thread while the GPU locates flanks.
+  HmmModels models;
+  std::thread model_thread([&]() { hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
   // ---------------- stage A: flank location on the GPU
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
   std::vector<uint8_t> lf_hit((size_t)nr), rf_hit((size_t)nr);
@@ -435,7 +440,8 @@ static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const t
   for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
   if (!job_set.empty()) {
     nsp.resize(job_set.size()); pur.resize(job_set.size());
-    rc = trgt_hmm_batch(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
+    if (model_thread.joinable()) model_thread.join();
+    rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
                         out->allele_blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(),
                         nsp.data(), out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr);
     if (rc) return rc;

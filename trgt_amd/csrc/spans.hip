@@ -141,7 +141,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_wfa; L.n_jobs_dev = nullptr;
   L.pat_base = d_flank; L.txt_base = d_reads;
   L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
-  L.threads = 256;
+  L.threads = getenv("TRGT_FLANK_THREADS") ? atoi(getenv("TRGT_FLANK_THREADS")) : 256;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
   if (n_wfa > 0 && (rc = wfa_launch(c, wp, L))) return rc;
