@@ -56,7 +56,7 @@ def cpu_baseline(batch, seconds_budget=15.0, max_loci=4000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--loci", type=int, default=10000, help="loci per GPU per step")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -96,6 +96,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()  # setup: primes the library's device-buffer pool and code objects (part of the untimed set-up, like the H2D upload)
     for _ in range(args.warmup):
         step()
     ctx.timing_enable(True)

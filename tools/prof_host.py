@@ -5,7 +5,7 @@ from trgt_amd import _lib, locus, synth
 b = synth.generate(10000)
 rd = torch.from_numpy(b["read_blob"]).cuda(); fd = torch.from_numpy(b["flank_blob"]).cuda()
 ctx = _lib.Context(0); out = locus.BatchOutputs(b); p = locus.Params(host_threads=32)
-for i in range(4):
+for i in range(8):
     t = time.perf_counter(); locus.run_batch(b, p, ctx, out, flank_dev=fd, reads_dev=rd); dt = time.perf_counter() - t
     s = out.stats
     print("step %.1f ms | inside %.1f: flank %.1f cons %.1f hmm %.1f host %.1f | hmm: model %.1f jobs %.1f bufs %.1f | glue: select %.1f +gather %.1f +front %.1f ; back %.1f" % (
