@@ -18,13 +18,23 @@
 namespace trgt {
 namespace wfa {
 
+// Explicit global address space for the write-only history stream: a generic (flat) store would bump lgkmcnt as well,
+// and every LDS wait in front of the per-level barrier would then also wait for the HBM stores to retire.
+typedef __attribute__((address_space(1))) int32_t g_i32;
+
 __device__ __forceinline__ uint16_t enc16(int32_t off) { return off < 0 ? (uint16_t)0 : (uint16_t)(off + 1); }
 __device__ __forceinline__ int32_t dec16(uint16_t e) { return e ? (int32_t)e - 1 : OFF_NULL; }
 __device__ __forceinline__ int32_t ring_get(const uint16_t* arr, int wcap, int koff, const WfDesc& d, int slot, int k) {
   return (k >= d.lo && k <= d.hi) ? dec16(arr[slot * wcap + k + koff]) : OFF_NULL;
 }
 
-// P, T: LDS copies of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  All threads; returns ST_*.
+__device__ __forceinline__ void fred_reset(FastRed& r) {
+  r.lo[0] = r.lo[1] = r.lo[2] = INT32_MAX; r.hi[0] = r.hi[1] = r.hi[2] = INT32_MIN;
+  r.term_key = ~0ull; r.end_val = OFF_NULL;
+}
+
+// P4, T4: LDS 4-byte sliding windows of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  A: history arena (HBM).
+// All threads; returns ST_*.
 __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32_t* P4, const uint32_t* T4, uint16_t* ring, int wcap,
                                                  int32_t* __restrict__ A) {
   Inst& I = sh.inst[I_UNI];
@@ -36,11 +46,13 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
   uint16_t* Ir = ring + RM * wcap;
   uint16_t* Dr = Ir + RI * wcap;
   const uint32_t cap = I.arena_cap;
-  const int n_slots = I.n_slots, span = I.span, pef = I.pef, tef = I.tef;
+  const int n_slots = I.n_slots, span = I.span, pef = I.pef, tef = I.tef, pbf = I.pbf, tbf = I.tbf;
+  WfDesc* const gdesc = I.gdesc;
+  WfDesc* const lring = sh.ring[I_UNI];
 
   // Extension over 4-byte sliding windows: P4[i] = pattern bytes i..i+3 (zero padded), T4 likewise.  One aligned LDS
   // dword per sequence covers four bases; most diagonals stop inside the first window, so the common case is straight-line.
-  auto extend = [&](int k, int32_t off, Red& red) -> int32_t {
+  auto extend = [&](int k, int32_t off, FastRed& red) -> int32_t {
     int v = off - k, h = off;
     int n;
     do {
@@ -58,14 +70,14 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
 
   __syncthreads();
   if (tid == 0) {
-    for (int r = 0; r < 3; ++r) red_reset(sh.red3[r]);
+    for (int r = 0; r < 3; ++r) fred_reset(sh.fred[r]);
     I.status = ST_OK; I.end_score = -1; I.num_null_steps = 0;
   }
   __syncthreads();
   // ---- score 0 (wavefront_unialign_init + first extension)
   WfDesc lastM, lastI = null_desc(), lastD = null_desc();
-  lastM.lo = lastM.lo_alloc = span ? -I.pbf : 0;
-  lastM.hi = span ? I.tbf : 0;
+  lastM.lo = lastM.lo_alloc = span ? -pbf : 0;
+  lastM.hi = span ? tbf : 0;
   lastM.base = 0;
   uint32_t bump = (uint32_t)(lastM.hi - lastM.lo + 1);
   unsigned long long cells = bump;
@@ -74,36 +86,42 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
   bool computed = true;
   if (bump > cap || n_slots < 1) status = ST_OOM;
   else {
-    Red& red = sh.red3[0];
+    FastRed& red = sh.fred[0];
     for (int kb = lastM.lo; kb <= lastM.hi; kb += nT) {
       const int k = kb + tid;
       if (k <= lastM.hi) {
         int32_t off = span ? (k > 0 ? k : 0) : 0;
         off = extend(k, off, red);
         Mr[k + koff] = enc16(off);
-        A[(uint32_t)(k - lastM.lo)] = off;
+        ((g_i32*)A)[(uint32_t)(k - lastM.lo)] = off;
       }
     }
   }
   while (status == ST_OK) {
     __syncthreads();  // the one barrier per level: level s is complete in LDS, its reductions are final
-    const Red& red = sh.red3[s % 3];
+    // ---- everything the next level needs from LDS is fetched up front (one wait): this level's reductions and the
+    //      descriptors of the older levels that feed level s+1
+    const FastRed R = sh.fred[s % 3];
+    const int sn = s + 1;
+    const WfDesc r_mm = lring[((sn - x) & (RING - 1)) * 5 + CM], r_mo = lring[((sn - oe) & (RING - 1)) * 5 + CM];
+    const WfDesc r_ie = lring[((sn - e) & (RING - 1)) * 5 + CI1], r_de = lring[((sn - e) & (RING - 1)) * 5 + CD1];
     if (s > 0 && computed) {  // wavefront_compute_trim_ends, derived redundantly by every thread
-      if (red.lo[CM] == INT32_MAX) lastM.hi = lastM.lo - 1; else { lastM.lo = red.lo[CM]; lastM.hi = red.hi[CM]; }
-      if (lastI.base != NOBASE) { if (red.lo[CI1] == INT32_MAX) lastI.hi = lastI.lo - 1; else { lastI.lo = red.lo[CI1]; lastI.hi = red.hi[CI1]; } }
-      if (lastD.base != NOBASE) { if (red.lo[CD1] == INT32_MAX) lastD.hi = lastD.lo - 1; else { lastD.lo = red.lo[CD1]; lastD.hi = red.hi[CD1]; } }
+      if (R.lo[0] == INT32_MAX) lastM.hi = lastM.lo - 1; else { lastM.lo = R.lo[0]; lastM.hi = R.hi[0]; }
+      if (lastI.base != NOBASE) { if (R.lo[1] == INT32_MAX) lastI.hi = lastI.lo - 1; else { lastI.lo = R.lo[1]; lastI.hi = R.hi[1]; } }
+      if (lastD.base != NOBASE) { if (R.lo[2] == INT32_MAX) lastD.hi = lastD.lo - 1; else { lastD.lo = R.lo[2]; lastD.hi = R.hi[2]; } }
     }
     bool end_reached = false;
     int end_k = 0, end_off = 0;
     if (lastM.base != NOBASE) {
       if (span == 1) {
-        if (red.term_key != ~0ull) { end_reached = true; end_k = (int)(red.term_key >> 32) - KBIAS; end_off = (int)(red.term_key & 0xFFFFFFFFu); }
-      } else if (ak >= lastM.lo && ak <= lastM.hi && red.end_val >= tlen) { end_reached = true; end_k = ak; end_off = tlen; }
+        if (R.term_key != ~0ull) { end_reached = true; end_k = (int)(R.term_key >> 32) - KBIAS; end_off = (int)(R.term_key & 0xFFFFFFFFu); }
+      } else if (ak >= lastM.lo && ak <= lastM.hi && R.end_val >= tlen) { end_reached = true; end_k = ak; end_off = tlen; }
     }
-    if (tid == 0) {
-      put_desc(I_UNI, CM, s, lastM); put_desc(I_UNI, CI1, s, lastI); put_desc(I_UNI, CD1, s, lastD);
-      put_desc(I_UNI, CI2, s, null_desc()); put_desc(I_UNI, CD2, s, null_desc());
-      red_reset(sh.red3[(s + 2) % 3]);
+    if (tid == 0) {  // publish level s: LDS mirror for the recurrences of later levels, HBM copy for the back-trace
+      WfDesc* lr = lring + (s & (RING - 1)) * 5;
+      lr[CM] = lastM; lr[CI1] = lastI; lr[CD1] = lastD;
+      if (s < n_slots) { WfDesc* g = gdesc + (size_t)s * 5; g[CM] = lastM; g[CI1] = lastI; g[CD1] = lastD; }
+      fred_reset(sh.fred[(s + 2) % 3]);
       if (end_reached) { I.end_score = s; I.end_k = end_k; I.end_off = end_off; }
     }
     if (end_reached) { status = ST_END_REACHED; break; }
@@ -111,13 +129,13 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     // ---- next level
     ++s;
     slM = slM + 1 == RM ? 0 : slM + 1; slI = slI + 1 == RI ? 0 : slI + 1;
-    auto getd = [&](int c, int lvl) -> WfDesc {
-      if (lvl < 0) return null_desc();
-      WfDesc d = lvl == s - 1 ? (c == CM ? lastM : c == CI1 ? lastI : lastD) : sh.ring[I_UNI][(lvl & (RING - 1)) * 5 + c];
-      if (d.base == NOBASE || d.lo > d.hi) return null_desc();
+    auto pick = [&](const WfDesc& ringd, const WfDesc& last, int lvl) -> WfDesc {  // branch-free select + null normalisation
+      WfDesc d = lvl == s - 1 ? last : ringd;
+      const bool bad = lvl < 0 || d.base == NOBASE || d.lo > d.hi;
+      d.lo = bad ? 1 : d.lo; d.hi = bad ? -1 : d.hi; d.lo_alloc = bad ? 1 : d.lo_alloc; d.base = bad ? NOBASE : d.base;
       return d;
     };
-    const WfDesc m_mis = getd(CM, s - x), m_o = getd(CM, s - oe), ie = getd(CI1, s - e), de = getd(CD1, s - e);
+    const WfDesc m_mis = pick(r_mm, lastM, s - x), m_o = pick(r_mo, lastM, s - oe), ie = pick(r_ie, lastI, s - e), de = pick(r_de, lastD, s - e);
     if (m_mis.base == NOBASE && m_o.base == NOBASE && ie.base == NOBASE && de.base == NOBASE) {
       ++num_null; computed = false;
       lastM = null_desc(); lastI = null_desc(); lastD = null_desc();
@@ -132,8 +150,10 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     bump += 3 * w; cells += 3ull * w;
     const bool has_i = m_o.base != NOBASE || ie.base != NOBASE, has_d = m_o.base != NOBASE || de.base != NOBASE;
     lastM.lo = lastM.lo_alloc = lo; lastM.hi = hi; lastM.base = bM;
-    lastI = lastM; lastI.base = bI; if (!has_i) lastI = null_desc();
-    lastD = lastM; lastD.base = bD; if (!has_d) lastD = null_desc();
+    lastI = lastM; lastI.base = has_i ? bI : NOBASE;
+    lastD = lastM; lastD.base = has_d ? bD : NOBASE;
+    if (!has_i) { lastI.lo = lastI.lo_alloc = 1; lastI.hi = -1; }
+    if (!has_d) { lastD.lo = lastD.lo_alloc = 1; lastD.hi = -1; }
     // Branch-light strip loop in the encoded domain (enc = offset + 1, 0 = NULL):
     //   ins = max(Mo[k-1], Ie[k-1]) (+1 if non-NULL), del = max(Mo[k+1], De[k+1]), mis = Mm[k] (+1 if non-NULL)
     const int slMo = slM - oe < 0 ? slM - oe + RM : slM - oe, slMm = slM - x < 0 ? slM - x + RM : slM - x;  // oe, x < RM
@@ -148,10 +168,10 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
     const int lo_mo = m_o.lo, lo_mm = m_mis.lo, lo_ie = ie.lo, lo_de = de.lo;
     const unsigned n_mo = m_o.base == NOBASE ? 0u : (unsigned)(m_o.hi - m_o.lo + 1), n_mm = m_mis.base == NOBASE ? 0u : (unsigned)(m_mis.hi - m_mis.lo + 1);
     const unsigned n_ie = ie.base == NOBASE ? 0u : (unsigned)(ie.hi - ie.lo + 1), n_de = de.base == NOBASE ? 0u : (unsigned)(de.hi - de.lo + 1);
-    int32_t* __restrict__ hM = A + bM - lo;
-    int32_t* __restrict__ hI = A + bI - lo;
-    int32_t* __restrict__ hD = A + bD - lo;
-    Red& rn = sh.red3[s % 3];
+    g_i32* __restrict__ hM = (g_i32*)(A + bM - lo);
+    g_i32* __restrict__ hI = (g_i32*)(A + bI - lo);
+    g_i32* __restrict__ hD = (g_i32*)(A + bD - lo);
+    FastRed& rn = sh.fred[s % 3];
     // per-lane first / last in-bounds diagonal of M, I, D as biased 16-bit values (kb = k + koff); "last" is stored
     // complemented so that a single packed unsigned min reduces everything: t0 = (fM, fI), t1 = (fD, ~lM), t2 = (~lI, ~lD)
     unsigned fM = 0xFFFFu, fI = 0xFFFFu, fD = 0xFFFFu, nlM = 0xFFFFu, nlI = 0xFFFFu, nlD = 0xFFFFu;
@@ -190,9 +210,9 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
       }
       if ((tid & 63) == 0) {
         const unsigned rfM = t0.u & 0xFFFFu, rfI = t0.u >> 16, rfD = t1.u & 0xFFFFu, rlM = 0xFFFFu - (t1.u >> 16), rlI = 0xFFFFu - (t2.u & 0xFFFFu), rlD = 0xFFFFu - (t2.u >> 16);
-        if (rfM != 0xFFFFu) { atomicMin(&rn.lo[CM], (int)rfM - koff); atomicMax(&rn.hi[CM], (int)rlM - koff); }
-        if (rfI != 0xFFFFu) { atomicMin(&rn.lo[CI1], (int)rfI - koff); atomicMax(&rn.hi[CI1], (int)rlI - koff); }
-        if (rfD != 0xFFFFu) { atomicMin(&rn.lo[CD1], (int)rfD - koff); atomicMax(&rn.hi[CD1], (int)rlD - koff); }
+        if (rfM != 0xFFFFu) { atomicMin(&rn.lo[0], (int)rfM - koff); atomicMax(&rn.hi[0], (int)rlM - koff); }
+        if (rfI != 0xFFFFu) { atomicMin(&rn.lo[1], (int)rfI - koff); atomicMax(&rn.hi[1], (int)rlI - koff); }
+        if (rfD != 0xFFFFu) { atomicMin(&rn.lo[2], (int)rfD - koff); atomicMax(&rn.hi[2], (int)rlD - koff); }
       }
     }
   }
