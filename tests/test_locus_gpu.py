@@ -111,3 +111,20 @@ def test_empty_and_degenerate_loci(oracle, mods):
     b = locus.pack(loci)
     out = locus.run_batch(b)
     _compare(oracle, locus, b, out, locus.Params(), range(4))
+
+
+def test_reference_example_locus_matches_tutorial_vcf(oracle, mods):
+    # the reference's own end-to-end golden (docs/tutorial.md:29-46): reads of example/sample.bam, clipped as analyze_tr does
+    from test_oracle_example_e1 import load_e1
+    locus, _ = mods
+    e1, want = load_e1()
+    L = dict(left_flank=e1["left_flank"].encode(), right_flank=e1["right_flank"].encode(), tr=e1["tr"].encode(),
+             motifs=[m.encode() for m in e1["motifs"]], reads=[r.encode() for r in e1["reads"]])
+    res = locus.analyze_batch([L, L])
+    for r in res:
+        assert [a.seq.decode() for a in r.genotype] == [want["alt"], want["alt"]]
+        f = r.vcf_fields()
+        for k in ("AL", "ALLR", "SD", "MC", "MS", "AP"):
+            assert f[k] == want[k], k
+    b = locus.pack([L])
+    _compare(oracle, locus, b, locus.run_batch(b), locus.Params(), range(1))
