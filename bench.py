@@ -118,10 +118,10 @@ def main():
         stats = out.stats
         n_reads = int(batch["n_reads"])
         # ALGORITHMIC bytes per launch of the dominant kernel (DESIGN.md "Roofline model"):
-        if dom == "wfa_flank":      # 4 B per wavefront offset written once + pattern/text in + (n_match, span) out per job
+        if dom == "wfa_flank":      # 2 B per wavefront offset (16-bit history) written once + pattern/text in + (n_match, span) out per job
             jobs = int(stats[0])
             mean_read = float(batch["read_len"].mean())
-            bytes_per_launch = 4.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)
+            bytes_per_launch = 2.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)
         elif dom == "hmm_viterbi":  # 1 B per back-pointer cell + allele in + annotation out
             bytes_per_launch = 1.0 * cells / max(launches, 1) + float(out.allele_len.sum()) * 2
         elif dom == "flank_scan":   # every read byte once + 4 B per (read, side)
@@ -140,7 +140,7 @@ def main():
         res = {
             "metric": "loci/s", "value": round(world * args.loci * args.steps / dt, 1), "unit": "loci/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+u8 (WFA), f64 (HMM)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16+u8 (WFA), f64 (HMM)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic single-motif STR loci per GPU (motif 3-6 bp, allele <= 200 bp), "
                                    "30 reads/locus HiFi-like, 10%% truncated reads (SURVEY.md Appendix E), seed 20250509" % args.loci,

@@ -8,7 +8,6 @@
 #include <algorithm>
 
 #include "wfa_engine.hpp"
-#include "wfa_fast.hpp"
 
 namespace trgt {
 namespace wfa {
@@ -287,12 +286,10 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     const uint8_t* Tx = a.txt_base + job.txt_off;
     // stage the two sequences in LDS when they fit (extension = byte compares against LDS)
     const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
-    bool staged = false;
     if (pl_pad + (uint32_t)tlen <= a.lds_seq_cap) {
       for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
       for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
       P = lds_seq; Tx = lds_seq + pl_pad;
-      staged = true;
     }
     if (tid == 0) { sh.status = TRGT_WF_COMPLETED; sh.score = INT32_MIN; sh.rle_n = 0; sh.sp = 0; sh.cells = 0; sh.top_bp = 0; }
     __syncthreads();
@@ -305,53 +302,14 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
                    sp ? fr(kp.tbf, tlen) : 0, sp ? fr(kp.tef, tlen) : 0, CM, CM);
       }
       __syncthreads();
-      int st;
-      bool fast_bt = false;
-      if (METRIC == M_AFFINE && staged && a.fast_wcap > 0 && (uint32_t)(plen + tlen + 6) <= a.fast_wcap) {
-        // 4-byte sliding windows of both sequences (see wfa_fast.hpp), built from the LDS byte copies
-        uint16_t* ring = reinterpret_cast<uint16_t*>(lds_seq + a.lds_seq_cap);
-        uint32_t* P4 = reinterpret_cast<uint32_t*>(lds_seq + a.lds_seq_cap + a.fast_ring_bytes);
-        uint32_t* T4 = P4 + plen + 1;
-        for (int i = tid; i <= plen; i += T) {
-          uint32_t wv = 0;
-          for (int b = 0; b < 4; ++b) if (i + b < plen) wv |= (uint32_t)lds_seq[i + b] << (8 * b);
-          P4[i] = wv;
-        }
-        for (int i = tid; i <= tlen; i += T) {
-          uint32_t wv = 0;
-          for (int b = 0; b < 4; ++b) if (i + b < tlen) wv |= (uint32_t)lds_seq[pl_pad + i + b] << (8 * b);
-          T4[i] = wv;
-        }
-        st = wf_run_lds_affine(kp, P4, T4, ring, (int)a.fast_wcap, ws.arena_u);
-        // back-trace by wave 0 with the level descriptors staged in the (now idle) ring area of LDS
-        const int es = sh.inst[I_UNI].end_score;
-        if (st == ST_END_REACHED && kp.scope_alignment && !a.fast_dbg && (uint32_t)(es + 1) * 3 * sizeof(WfDesc) <= a.fast_ring_bytes) {
-          WfDesc* ld = reinterpret_cast<WfDesc*>(ring);
-          __syncthreads();
-          for (int i = tid; i < (es + 1) * 3; i += T) {
-            const int lvl = i / 3, c3 = i - lvl * 3;
-            ld[i] = ws.gdesc[(size_t)lvl * 5 + (c3 == 0 ? CM : c3 == 1 ? CI1 : CD1)];
-          }
-          __syncthreads();
-          if (tid < 64) {
-            int nt = 0;
-            wf_backtrace_fast_affine(kp, ld, ws.arena_u, ws.rle_tmp, nt, a.rle_cap);
-            if (tid == 0) sh.rle_tmp_n = nt;
-          }
-          fast_bt = true;
-          __syncthreads();
-        }
-      }
-      else
-        st = wf_run<METRIC>(I_UNI, kp);
+      const int st = wf_run<METRIC>(I_UNI, kp);
       if (tid == 0) {
         if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
         else {
           sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
-          if (kp.scope_alignment && !a.fast_dbg) {
+          if (kp.scope_alignment) {
             int nt = 0;
-            if (fast_bt) nt = sh.rle_tmp_n;
-            else wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
+            wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
             rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
           }
         }
@@ -444,6 +402,11 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
 }
 
 }  // namespace wfa
+}  // namespace trgt
+
+#include "wfa_fast.hpp"  // the dedicated LDS-resident kernel for exact unidirectional gap-affine batches
+
+namespace trgt {
 
 // ------------------------------------------------------------------ host planner
 static int gap_cost(const trgt_wfa_params& p, int64_t len) {
@@ -541,7 +504,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   size_t lds = a.lds_seq_cap;
   a.fast_wcap = 0; a.fast_ring_bytes = 0;
   a.fast_dbg = getenv("TRGT_DBG_SKIP_BT") ? 1 : 0;
-  if (p.metric == 3 && p.heuristic == 0 && !a.kp.biwfa && a.lds_seq_cap > 0 && mt + score_bound < 65000) {
+  if (p.metric == 3 && p.heuristic == 0 && !a.kp.biwfa && a.lds_seq_cap > 0 && mt + score_bound < 65000 && threads % 64 == 0 && threads <= 256) {
     // LDS fast path (wfa_fast.hpp): ring of the live wavefronts as 16-bit offsets
     const uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
     const uint64_t ring_bytes = (uint64_t)(std::max(pen.x, pen.o1 + pen.e1) + 1 + 2 * (pen.e1 + 1)) * wcap * 2;
@@ -552,9 +515,11 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
   const int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));
   const dim3 grid((unsigned)grid_blocks), block((unsigned)threads);
-  if (lds > 64 * 1024) {
-    if (p.metric == 3) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)wfa_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  if (a.fast_wcap > 0) {
+    // every job of this batch qualifies for the dedicated LDS-resident kernel (wfa_fast.hpp)
+    if (lds > 48 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)wfa_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wfa_fast_kernel, grid, block, lds, c->stream, a);
+  } else
   switch (p.metric) {
     case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;
     case 1: hipLaunchKernelGGL(wfa_kernel<1>, grid, block, lds, c->stream, a); break;
@@ -564,6 +529,24 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
+#ifdef TRGT_WFA_PROF
+  if (a.fast_wcap > 0) {
+    unsigned long long h[32], lv[8], z[32] = {0};
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(wfa::g_wfa_prof), sizeof h));
+    TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_prof), z, sizeof h));
+    TRGT_HIP_TRY(c, hipMemcpyFromSymbol(lv, HIP_SYMBOL(wfa::g_wfa_lvprof), sizeof lv));
+    TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_lvprof), z, sizeof lv));
+    const double lt = (double)(lv[0] + lv[1] + lv[2] + lv[3]) + 1e-9;
+    const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) + 1e-9;
+    fprintf(stderr, "[wfa prof] jobs=%lld grid=%lld thr=%d | fetch %.1f%% stage %.1f%% levels %.1f%% backtrace %.1f%% sync %.1f%% epilogue+idle %.1f%% | "
+            "mean end_score %.1f | long(>40) %llu mean score %.1f, %.1f%% of level time | Mcycles/wg %.1f | level loop (thread 0): barrier %.1f%% "
+            "prologue %.1f%% strips %.1f%% record %.1f%%\n",
+            (long long)L.n_jobs_host, (long long)grid_blocks, threads, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot,
+            100 * h[4] / tot, 100 * h[5] / tot, h[6] ? (double)h[7] / h[6] : 0.0, h[16], h[16] ? (double)h[17] / h[16] : 0.0,
+            h[2] ? 100.0 * h[18] / h[2] : 0.0, tot / 1e6 / (double)grid_blocks, 100 * lv[0] / lt, 100 * lv[1] / lt, 100 * lv[2] / lt, 100 * lv[3] / lt);
+  }
+#endif
   c->last_wfa_cells_dev = d_cells;
   return TRGT_OK;
 }

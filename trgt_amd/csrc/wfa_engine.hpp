@@ -68,11 +68,6 @@ struct Red {
   int end_val, max_ak, min_dist, cand_lo, cand_hi, bp_k, flag, oom;
 };
 
-struct FastRed {  // reductions of one score level of the LDS fast path (triple-buffered, 48 bytes)
-  int lo[3], hi[3];
-  unsigned long long term_key;
-  int end_val, pad[3];
-};
 
 struct Breakpoint { int score, score_f, score_r, k_f, off_f, comp; };
 struct Seg { int pb, pl, tb, tl, cb, ce, rem, top; };
@@ -81,7 +76,6 @@ struct Shared {
   Inst inst[3];
   WfDesc ring[3][RING * 5];
   Red red;
-  FastRed fred[3];  // triple-buffered reductions of the LDS fast path (wfa_fast.hpp)
   Breakpoint bp;
   Seg stack[64];
   int sp, job, status, score, top_bp, rle_n, rle_tmp_n;

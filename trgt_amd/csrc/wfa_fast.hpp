@@ -1,18 +1,24 @@
-// trgt_amd/csrc/wfa_fast.hpp -- LDS-resident fast path of the wavefront aligner for the case that
-// dominates TRGT's batches: exact (Heuristic::None) unidirectional gap-affine alignment, i.e.
-// THREAD_WFA_FLANK (src/commands/genotype.rs:66-80): a 250-bp flank piece against a ~1.2-kb read
-// with both text ends free, ~1450 live diagonals per score level.
+// trgt_amd/csrc/wfa_fast.hpp -- dedicated LDS-resident kernel for the alignments that dominate TRGT's batches:
+// exact (Heuristic::None) unidirectional gap-affine WFA, i.e. THREAD_WFA_FLANK (src/commands/genotype.rs:66-80):
+// a 250-bp flank piece against a ~1-kb read with both text ends free, ~1300 live diagonals per score level.
+// Included by wfa.hip after the generic engine; the host planner there launches it whenever a whole batch qualifies.
 //
-// What changes relative to the generic engine (results are identical, see tests/test_wfa_gpu.py):
+// What differs from the generic engine (results are identical, see tests/test_wfa_gpu.py):
 //   * the live wavefronts -- M of the last max(x, o+e)+1 levels, I and D of the last e+1 levels --
-//     sit in an LDS ring as 16-bit "offset+1" values (0 = NULL), indexed directly by diagonal, so the
-//     recurrences read LDS, never HBM; pattern and text bytes are read from LDS too;
-//   * the wavefront history needed by the back-trace is streamed to the HBM arena write-only
-//     (coalesced 4-byte stores, one per offset: the 4*W term of the roofline model);
-//   * ONE workgroup barrier per score level: every thread derives the trimmed descriptor of the level
-//     it just helped to compute from a triple-buffered reduction block, so there is no serial
-//     "thread 0 publishes, everyone waits" section in the loop.
+//     sit in an LDS ring as 16-bit "offset+1" values (0 = NULL), indexed directly by the biased diagonal
+//     kb = k + plen + 2, so the recurrences read LDS, never HBM; pattern and text are read from LDS too;
+//   * the wavefront history needed by the back-trace is streamed to the HBM arena write-only, in the same
+//     16-bit encoding (coalesced 2-byte stores, one per offset: the 2*W term of the roofline model);
+//   * ONE workgroup barrier per score level and no atomics on the per-level path: every wave finds the first / last
+//     in-bounds diagonal of its strips with ballots on the scalar unit and leaves one 16-byte record in LDS; after
+//     the barrier every wave folds the records (packed 16-bit min) and derives the next level's descriptors itself,
+//     on the scalar unit, from (lo | hi << 16) words -- there is no "thread 0 publishes, everyone waits" section;
+//   * strips that lie inside all four source ranges (the common case) run a body without range masks;
+//   * it is a kernel of its own: nothing of the BiWFA / heuristic machinery is live, so the per-level state stays in
+//     SGPRs and the strip loop in registers (inside the generic kernel the same code spilled, and every spill reload in
+//     the strip loop is an s_waitcnt vmcnt(0) that also waits for the history stores in flight).
 #pragma once
+#include <type_traits>
 #include "wfa_engine.hpp"
 
 namespace trgt {
@@ -20,206 +26,258 @@ namespace wfa {
 
 // Explicit global address space for the write-only history stream: a generic (flat) store would bump lgkmcnt as well,
 // and every LDS wait in front of the per-level barrier would then also wait for the HBM stores to retire.
-typedef __attribute__((address_space(1))) int32_t g_i32;
+typedef __attribute__((address_space(1))) uint16_t g_u16;
 
-__device__ __forceinline__ uint16_t enc16(int32_t off) { return off < 0 ? (uint16_t)0 : (uint16_t)(off + 1); }
-__device__ __forceinline__ int32_t dec16(uint16_t e) { return e ? (int32_t)e - 1 : OFF_NULL; }
-__device__ __forceinline__ int32_t ring_get(const uint16_t* arr, int wcap, int koff, const WfDesc& d, int slot, int k) {
-  return (k >= d.lo && k <= d.hi) ? dec16(arr[slot * wcap + k + koff]) : OFF_NULL;
+#ifdef TRGT_WFA_PROF
+// Developer-only build (make PROF=1): thread 0 of every workgroup splits its shader-clock time over the phases of a job
+// (g_wfa_prof) and over the phases of a score level (g_wfa_lvprof).
+__device__ unsigned long long g_wfa_prof[32];
+__device__ unsigned long long g_wfa_lvprof[8];
+#define PROF_DECL unsigned long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_MARK(i) do { const unsigned long long n_ = clock64(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
+#define LV_DECL unsigned long long lv_t = clock64(), lv_acc[5] = {0, 0, 0, 0, 0}
+#define LV_MARK(i) do { const unsigned long long n_ = clock64(); lv_acc[i] += n_ - lv_t; lv_t = n_; } while (0)
+#define LV_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_wfa_lvprof[i_], lv_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define LV_DECL
+#define LV_MARK(i)
+#define LV_FLUSH
+#endif
+
+// Packed descriptor of one wavefront component: biased lo | biased hi << 16; lo > hi = null.
+__device__ __forceinline__ int pd_lo(uint32_t d) { return (int)(d & 0xFFFFu); }
+__device__ __forceinline__ int pd_hi(uint32_t d) { return (int)(d >> 16); }
+__device__ __forceinline__ bool pd_null(uint32_t d) { return pd_lo(d) > pd_hi(d); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  union U { uint32_t u; us2 v; } x, y, r;
+  x.u = a; y.u = b; r.v = __builtin_elementwise_min(x.v, y.v);
+  return r.u;
 }
 
-__device__ __forceinline__ void fred_reset(FastRed& r) {
-  r.lo[0] = r.lo[1] = r.lo[2] = INT32_MAX; r.hi[0] = r.hi[1] = r.hi[2] = INT32_MIN;
-  r.term_key = ~0ull; r.end_val = OFF_NULL;
-}
+// History descriptor of one level in HBM: FD_STRIDE dwords {M, I, D packed ranges (trimmed), base, lo_alloc | width << 16}.
+// Offsets of component c (0 M, 1 I, 2 D) of diagonal kb sit at A16[base + c * width + (kb - lo_alloc)].
+constexpr int FD_STRIDE = 8, FD_LDS_STRIDE = 5;
 
-// P4, T4: LDS 4-byte sliding windows of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  A: history arena (HBM).
-// All threads; returns ST_*.
-__device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32_t* P4, const uint32_t* T4, uint16_t* ring, int wcap,
-                                                 int32_t* __restrict__ A) {
-  Inst& I = sh.inst[I_UNI];
-  const int tid = threadIdx.x, nT = blockDim.x;
-  const int plen = I.plen, tlen = I.tlen, ak = tlen - plen, koff = plen + 2;  // one pad cell each side: k-1 / k+1 reads never leave the slot
-  const int x = kp.pen.x, oe = kp.pen.o1 + kp.pen.e1, e = kp.pen.e1, scope = kp.pen.scope;
+struct FastTerm {  // termination record of one score level (triple-buffered)
+  unsigned long long term_key;  // (k + KBIAS) << 32 | offset, minimum = first terminating diagonal
+  int end_val, pad;
+};
+
+struct FastShared {
+  uint4 fdesc[RING];    // packed descriptors {M, I, D, -} of the last RING levels
+  uint4 wred[2][16];    // per-wave trim records, double-buffered
+  FastTerm fterm[3];
+  int job, slot, rle_n, total_ops;
+};
+__shared__ FastShared g_fsh;
+
+struct FastJob { int plen, tlen, span, pbf, pef, tbf, tef, n_slots; uint32_t cap; };  // all wave-uniform
+struct FastEnd { int status, score, k, off; unsigned long long cells; };
+
+// P4, T4: LDS 4-byte sliding windows of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  A16: history arena,
+// gd: history descriptors (both HBM, uniform pointers).  All threads (blockDim.x a multiple of 64).
+__device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJob& J, const uint32_t* P4, const uint32_t* T4, uint16_t* ring,
+                                                     int wcap, g_u16* A16, uint32_t* gd) {
+  FastShared& fs = g_fsh;
+  const int tid = threadIdx.x, nT = blockDim.x, lane = tid & 63;
+  const int wave = rfl(tid >> 6), nW = nT >> 6;
+  const int plen = J.plen, tlen = J.tlen, koff = plen + 2;  // one pad cell each side: kb-1 / kb+1 reads never leave the slot
+  const int ak_b = tlen - plen + koff;
+  const int x = pen.x, oe = pen.o1 + pen.e1, e = pen.e1, scope = pen.scope;
   const int RM = max(x, oe) + 1, RI = e + 1;
-  uint16_t* Mr = ring;
-  uint16_t* Ir = ring + RM * wcap;
-  uint16_t* Dr = Ir + RI * wcap;
-  const uint32_t cap = I.arena_cap;
-  const int n_slots = I.n_slots, span = I.span, pef = I.pef, tef = I.tef, pbf = I.pbf, tbf = I.tbf;
-  WfDesc* const gdesc = I.gdesc;
-  WfDesc* const lring = sh.ring[I_UNI];
+  uint16_t* const Mr = ring;
+  uint16_t* const Ir = ring + RM * wcap;
+  uint16_t* const Dr = Ir + RI * wcap;
+  const uint32_t cap = J.cap;
+  const int n_slots = J.n_slots, span = J.span, pef = J.pef, tef = J.tef, pbf = J.pbf, tbf = J.tbf;
+  const uint32_t PDN = (uint32_t)(koff + 1) | ((uint32_t)(koff - 1) << 16);  // the canonical null wavefront (lo = 1, hi = -1)
 
   // Extension over 4-byte sliding windows: P4[i] = pattern bytes i..i+3 (zero padded), T4 likewise.  One aligned LDS
   // dword per sequence covers four bases; most diagonals stop inside the first window, so the common case is straight-line.
-  auto extend = [&](int k, int32_t off, FastRed& red) -> int32_t {
+  auto extend = [&](int k, int32_t off, FastTerm& tm) -> int32_t {
     int v = off - k, h = off;
-    int n;
+    uint32_t n;
     do {
       const uint32_t xw = P4[v] ^ T4[h];
-      n = xw ? (__builtin_ctz(xw) >> 3) : 4;
-      n = min(n, min(plen - v, tlen - h));
-      v += n; h += n;
-    } while (n == 4);
+      n = min(min((uint32_t)(__ffs((int)xw) - 1) >> 3, 4u), (uint32_t)min(plen - v, tlen - h));
+      v += (int)n; h += (int)n;
+    } while (n == 4u);
     if (span == 1) {
       if ((h >= tlen && plen - v <= pef) || (v >= plen && tlen - h <= tef))
-        atomicMin(&red.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)h);
-    } else if (k == ak) red.end_val = h;
+        atomicMin(&tm.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)h);
+    } else if (k + koff == ak_b) tm.end_val = h;
     return h;
   };
 
   __syncthreads();
-  if (tid == 0) {
-    for (int r = 0; r < 3; ++r) fred_reset(sh.fred[r]);
-    I.status = ST_OK; I.end_score = -1; I.num_null_steps = 0;
-  }
+  if (tid == 0)
+    for (int r = 0; r < 3; ++r) { fs.fterm[r].term_key = ~0ull; fs.fterm[r].end_val = OFF_NULL; }
   __syncthreads();
-  // ---- score 0 (wavefront_unialign_init + first extension)
-  WfDesc lastM, lastI = null_desc(), lastD = null_desc();
-  lastM.lo = lastM.lo_alloc = span ? -pbf : 0;
-  lastM.hi = span ? tbf : 0;
-  lastM.base = 0;
-  uint32_t bump = (uint32_t)(lastM.hi - lastM.lo + 1);
+  // ---- score 0 (wavefront_unialign_init + first extension); level 0 is never trimmed
+  uint32_t cM, cI = PDN, cD = PDN;      // packed (trimmed) descriptors of the current level s
+  uint32_t lo_c, w_c, base_c = 0;       // computed range / history base of the current level
+  {
+    const int lo0 = span ? -pbf : 0, hi0 = span ? tbf : 0;
+    cM = (uint32_t)(lo0 + koff) | ((uint32_t)(hi0 + koff) << 16);
+    lo_c = (uint32_t)(lo0 + koff); w_c = (uint32_t)(hi0 - lo0 + 1);
+  }
+  uint32_t bump = w_c;
   unsigned long long cells = bump;
   int status = ST_OK, num_null = 0, s = 0;
-  int slM = 0, slI = 0;  // s % RM, s % RI kept incrementally
+  int slM = 0, slI = 0, s3 = 0;  // s % RM, s % RI, s % 3 kept incrementally
   bool computed = true;
   if (bump > cap || n_slots < 1) status = ST_OOM;
   else {
-    FastRed& red = sh.fred[0];
-    for (int kb = lastM.lo; kb <= lastM.hi; kb += nT) {
-      const int k = kb + tid;
-      if (k <= lastM.hi) {
+    FastTerm& tm = fs.fterm[0];
+    const int hi_b = pd_hi(cM);
+    g_u16* const h0 = A16 - lo_c;
+    for (int kb0 = (int)lo_c + wave * 64; kb0 <= hi_b; kb0 += nT) {
+      const int kb = kb0 + lane;
+      if (kb <= hi_b) {
+        const int k = kb - koff;
         int32_t off = span ? (k > 0 ? k : 0) : 0;
-        off = extend(k, off, red);
-        Mr[k + koff] = enc16(off);
-        ((g_i32*)A)[(uint32_t)(k - lastM.lo)] = off;
+        off = extend(k, off, tm);
+        Mr[kb] = (uint16_t)(off + 1);
+        h0[(unsigned)kb] = (uint16_t)(off + 1);
       }
     }
   }
+  int end_k = 0, end_off = 0;
+  LV_DECL;
   while (status == ST_OK) {
-    __syncthreads();  // the one barrier per level: level s is complete in LDS, its reductions are final
-    // ---- everything the next level needs from LDS is fetched up front (one wait): this level's reductions and the
+    LV_MARK(3);
+    __syncthreads();  // the one barrier per level: level s is complete in LDS, its trim / termination records are final
+    LV_MARK(0);
+    // ---- everything the next level needs from LDS is fetched up front (one wait): this level's records and the
     //      descriptors of the older levels that feed level s+1
-    const FastRed R = sh.fred[s % 3];
     const int sn = s + 1;
-    const WfDesc r_mm = lring[((sn - x) & (RING - 1)) * 5 + CM], r_mo = lring[((sn - oe) & (RING - 1)) * 5 + CM];
-    const WfDesc r_ie = lring[((sn - e) & (RING - 1)) * 5 + CI1], r_de = lring[((sn - e) & (RING - 1)) * 5 + CD1];
-    if (s > 0 && computed) {  // wavefront_compute_trim_ends, derived redundantly by every thread
-      if (R.lo[0] == INT32_MAX) lastM.hi = lastM.lo - 1; else { lastM.lo = R.lo[0]; lastM.hi = R.hi[0]; }
-      if (lastI.base != NOBASE) { if (R.lo[1] == INT32_MAX) lastI.hi = lastI.lo - 1; else { lastI.lo = R.lo[1]; lastI.hi = R.hi[1]; } }
-      if (lastD.base != NOBASE) { if (R.lo[2] == INT32_MAX) lastD.hi = lastD.lo - 1; else { lastD.lo = R.lo[2]; lastD.hi = R.hi[2]; } }
+    const FastTerm Tm = fs.fterm[s3];
+    const uint4 fa = fs.fdesc[(sn - x) & (RING - 1)], fb = fs.fdesc[(sn - oe) & (RING - 1)], fc = fs.fdesc[(sn - e) & (RING - 1)];
+    if (s > 0 && computed) {  // wavefront_compute_trim_ends from the per-wave records
+      uint4 r = fs.wred[s & 1][0];
+      for (int w = 1; w < nW; ++w) {
+        const uint4 q = fs.wred[s & 1][w];
+        r.x = pk_min_u16(r.x, q.x); r.y = pk_min_u16(r.y, q.y); r.z = pk_min_u16(r.z, q.z);
+      }
+      const uint32_t rx = rfl(r.x), ry = rfl(r.y), rz = rfl(r.z);
+      cM = (rx & 0xFFFFu) == 0xFFFFu ? PDN : rx ^ 0xFFFF0000u;
+      cI = (ry & 0xFFFFu) == 0xFFFFu ? PDN : ry ^ 0xFFFF0000u;
+      cD = (rz & 0xFFFFu) == 0xFFFFu ? PDN : rz ^ 0xFFFF0000u;
     }
     bool end_reached = false;
-    int end_k = 0, end_off = 0;
-    if (lastM.base != NOBASE) {
+    if (computed) {
       if (span == 1) {
-        if (R.term_key != ~0ull) { end_reached = true; end_k = (int)(R.term_key >> 32) - KBIAS; end_off = (int)(R.term_key & 0xFFFFFFFFu); }
-      } else if (ak >= lastM.lo && ak <= lastM.hi && R.end_val >= tlen) { end_reached = true; end_k = ak; end_off = tlen; }
+        const uint32_t tk_hi = rfl((uint32_t)(Tm.term_key >> 32)), tk_lo = rfl((uint32_t)Tm.term_key);
+        if ((tk_hi & tk_lo) != 0xFFFFFFFFu) { end_reached = true; end_k = (int)tk_hi - KBIAS; end_off = (int)tk_lo; }
+      } else if (ak_b >= pd_lo(cM) && ak_b <= pd_hi(cM) && rfl(Tm.end_val) >= tlen) { end_reached = true; end_k = ak_b - koff; end_off = tlen; }
     }
-    if (tid == 0) {  // publish level s: LDS mirror for the recurrences of later levels, HBM copy for the back-trace
-      WfDesc* lr = lring + (s & (RING - 1)) * 5;
-      lr[CM] = lastM; lr[CI1] = lastI; lr[CD1] = lastD;
-      if (s < n_slots) { WfDesc* g = gdesc + (size_t)s * 5; g[CM] = lastM; g[CI1] = lastI; g[CD1] = lastD; }
-      fred_reset(sh.fred[(s + 2) % 3]);
-      if (end_reached) { I.end_score = s; I.end_k = end_k; I.end_off = end_off; }
-    }
+    if (tid == 0) {  // publish level s: LDS ring for the recurrences of later levels, HBM copy for the back-trace
+      fs.fdesc[s & (RING - 1)] = make_uint4(cM, cI, cD, 0u);
+      if (s < n_slots) {
+        uint32_t* g = gd + (size_t)s * FD_STRIDE;
+        *reinterpret_cast<uint4*>(g) = make_uint4(cM, cI, cD, base_c);
+        g[4] = lo_c | (w_c << 16);
+      }
+      FastTerm& nx = fs.fterm[s3 == 0 ? 2 : s3 - 1];  // (s + 2) % 3
+      nx.term_key = ~0ull; nx.end_val = OFF_NULL;
+    }  // (nothing in this block may depend on end_reached: a shared condition lets the compiler thread the uniform exit
+       //  below through this divergent branch, and the whole per-level state then counts as divergent -> VGPRs)
     if (end_reached) { status = ST_END_REACHED; break; }
-    if (lastM.base == NOBASE && num_null > scope) { status = ST_END_UNREACHABLE; break; }
+    if (!computed && num_null > scope) { status = ST_END_UNREACHABLE; break; }
     // ---- next level
     ++s;
-    slM = slM + 1 == RM ? 0 : slM + 1; slI = slI + 1 == RI ? 0 : slI + 1;
-    auto pick = [&](const WfDesc& ringd, const WfDesc& last, int lvl) -> WfDesc {  // branch-free select + null normalisation
-      WfDesc d = lvl == s - 1 ? last : ringd;
-      const bool bad = lvl < 0 || d.base == NOBASE || d.lo > d.hi;
-      d.lo = bad ? 1 : d.lo; d.hi = bad ? -1 : d.hi; d.lo_alloc = bad ? 1 : d.lo_alloc; d.base = bad ? NOBASE : d.base;
-      return d;
+    slM = slM + 1 == RM ? 0 : slM + 1; slI = slI + 1 == RI ? 0 : slI + 1; s3 = s3 == 2 ? 0 : s3 + 1;
+    auto sel = [&](uint32_t ringv, uint32_t cur, int lvl) -> uint32_t {  // wavefront_compute_get_*: NULL / ->null become the canonical null
+      const uint32_t d = lvl == s - 1 ? cur : rfl(ringv);
+      return (lvl < 0 || pd_null(d)) ? PDN : d;
     };
-    const WfDesc m_mis = pick(r_mm, lastM, s - x), m_o = pick(r_mo, lastM, s - oe), ie = pick(r_ie, lastI, s - e), de = pick(r_de, lastD, s - e);
-    if (m_mis.base == NOBASE && m_o.base == NOBASE && ie.base == NOBASE && de.base == NOBASE) {
+    const uint32_t m_mis = sel(fa.x, cM, s - x), m_o = sel(fb.x, cM, s - oe), ie = sel(fc.y, cI, s - e), de = sel(fc.z, cD, s - e);
+    if (pd_null(m_mis) && pd_null(m_o) && pd_null(ie) && pd_null(de)) {
       ++num_null; computed = false;
-      lastM = null_desc(); lastI = null_desc(); lastD = null_desc();
+      cM = cI = cD = PDN; lo_c = 0; w_c = 0; base_c = 0;
       continue;
     }
     num_null = 0; computed = true;
-    int lo = m_mis.lo, hi = m_mis.hi;
-    lim(m_o, -1, +1, lo, hi); lim(ie, +1, +1, lo, hi); lim(de, -1, -1, lo, hi);
+    // wavefront_compute_limits_input (null wavefronts take part with lo = 1, hi = -1, exactly as in the library)
+    const int lo = min(min(pd_lo(m_mis), pd_lo(m_o) - 1), min(pd_lo(ie) + 1, pd_lo(de) - 1));
+    const int hi = max(max(pd_hi(m_mis), pd_hi(m_o) + 1), max(pd_hi(ie) + 1, pd_hi(de) - 1));
     const uint32_t w = (uint32_t)max(0, hi - lo + 1);
     if (s >= n_slots || (unsigned long long)bump + 3ull * w > cap) { status = ST_OOM; break; }
-    const uint32_t bM = bump, bI = bump + w, bD = bump + 2 * w;
+    const uint32_t bM = bump;
     bump += 3 * w; cells += 3ull * w;
-    const bool has_i = m_o.base != NOBASE || ie.base != NOBASE, has_d = m_o.base != NOBASE || de.base != NOBASE;
-    lastM.lo = lastM.lo_alloc = lo; lastM.hi = hi; lastM.base = bM;
-    lastI = lastM; lastI.base = has_i ? bI : NOBASE;
-    lastD = lastM; lastD.base = has_d ? bD : NOBASE;
-    if (!has_i) { lastI.lo = lastI.lo_alloc = 1; lastI.hi = -1; }
-    if (!has_d) { lastD.lo = lastD.lo_alloc = 1; lastD.hi = -1; }
-    // Branch-light strip loop in the encoded domain (enc = offset + 1, 0 = NULL):
-    //   ins = max(Mo[k-1], Ie[k-1]) (+1 if non-NULL), del = max(Mo[k+1], De[k+1]), mis = Mm[k] (+1 if non-NULL)
+    lo_c = (uint32_t)lo; w_c = w; base_c = bM;
     const int slMo = slM - oe < 0 ? slM - oe + RM : slM - oe, slMm = slM - x < 0 ? slM - x + RM : slM - x;  // oe, x < RM
     const int slIe = slI - e < 0 ? slI - e + RI : slI - e;
-    const uint16_t* pMo = Mr + slMo * wcap + koff;
-    const uint16_t* pMm = Mr + slMm * wcap + koff;
-    const uint16_t* pIe = Ir + slIe * wcap + koff;
-    const uint16_t* pDe = Dr + slIe * wcap + koff;
-    uint16_t* qM = Mr + slM * wcap + koff;
-    uint16_t* qI = Ir + slI * wcap + koff;
-    uint16_t* qD = Dr + slI * wcap + koff;
-    const int lo_mo = m_o.lo, lo_mm = m_mis.lo, lo_ie = ie.lo, lo_de = de.lo;
-    const unsigned n_mo = m_o.base == NOBASE ? 0u : (unsigned)(m_o.hi - m_o.lo + 1), n_mm = m_mis.base == NOBASE ? 0u : (unsigned)(m_mis.hi - m_mis.lo + 1);
-    const unsigned n_ie = ie.base == NOBASE ? 0u : (unsigned)(ie.hi - ie.lo + 1), n_de = de.base == NOBASE ? 0u : (unsigned)(de.hi - de.lo + 1);
-    g_i32* __restrict__ hM = (g_i32*)(A + bM - lo);
-    g_i32* __restrict__ hI = (g_i32*)(A + bI - lo);
-    g_i32* __restrict__ hD = (g_i32*)(A + bD - lo);
-    FastRed& rn = sh.fred[s % 3];
-    // per-lane first / last in-bounds diagonal of M, I, D as biased 16-bit values (kb = k + koff); "last" is stored
-    // complemented so that a single packed unsigned min reduces everything: t0 = (fM, fI), t1 = (fD, ~lM), t2 = (~lI, ~lD)
-    unsigned fM = 0xFFFFu, fI = 0xFFFFu, fD = 0xFFFFu, nlM = 0xFFFFu, nlI = 0xFFFFu, nlD = 0xFFFFu;
-    for (int k = lo + tid; k <= hi; k += nT) {
-      unsigned a = pMo[k - 1], b = pIe[k - 1], c = pMo[k + 1], d = pDe[k + 1], m = pMm[k];
-      a = (unsigned)(k - 1 - lo_mo) < n_mo ? a : 0u;
-      b = (unsigned)(k - 1 - lo_ie) < n_ie ? b : 0u;
-      c = (unsigned)(k + 1 - lo_mo) < n_mo ? c : 0u;
-      d = (unsigned)(k + 1 - lo_de) < n_de ? d : 0u;
-      m = (unsigned)(k - lo_mm) < n_mm ? m : 0u;
-      const unsigned mi = max(a, b);
-      const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
-      unsigned mx = max(del, max(mis, ins));
-      int32_t off = (int32_t)mx - 1;
-      const bool okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
-      if (okM) { off = extend(k, off, rn); mx = (unsigned)off + 1u; } else { mx = 0u; off = OFF_NULL; }
-      qI[k] = (uint16_t)ins; qD[k] = (uint16_t)del; qM[k] = (uint16_t)mx;
-      const int32_t vi = ins ? (int32_t)ins - 1 : OFF_NULL, vd = del ? (int32_t)del - 1 : OFF_NULL;
-      hI[k] = vi; hD[k] = vd; hM[k] = off;  // history for the back-trace: written once, never re-read by this loop
-      // wavefront_compute_trim_ends bookkeeping: k only grows per lane, so "first" is set once and "last" overwritten
-      const bool okI = in_bounds(vi, k, plen, tlen), okD = in_bounds(vd, k, plen, tlen);
-      const unsigned kb = (unsigned)(k + koff), nkb = 0xFFFFu - kb;
-      fM = okM ? min(fM, kb) : fM; nlM = okM ? nkb : nlM;
-      fI = okI ? min(fI, kb) : fI; nlI = okI ? nkb : nlI;
-      fD = okD ? min(fD, kb) : fD; nlD = okD ? nkb : nlD;
+    const uint16_t* const pMo = Mr + slMo * wcap;
+    const uint16_t* const pMm = Mr + slMm * wcap;
+    const uint16_t* const pIe = Ir + slIe * wcap;
+    const uint16_t* const pDe = Dr + slIe * wcap;
+    uint16_t* const qM = Mr + slM * wcap;
+    uint16_t* const qI = Ir + slI * wcap;
+    uint16_t* const qD = Dr + slI * wcap;
+    const int lo_mo = pd_lo(m_o), hi_mo = pd_hi(m_o), lo_mm = pd_lo(m_mis), hi_mm = pd_hi(m_mis);
+    const int lo_ie = pd_lo(ie), hi_ie = pd_hi(ie), lo_de = pd_lo(de), hi_de = pd_hi(de);
+    const unsigned n_mo = (unsigned)max(0, hi_mo - lo_mo + 1), n_mm = (unsigned)max(0, hi_mm - lo_mm + 1);
+    const unsigned n_ie = (unsigned)max(0, hi_ie - lo_ie + 1), n_de = (unsigned)max(0, hi_de - lo_de + 1);
+    g_u16* const hM = A16 + ((long long)bM - lo);
+    g_u16* const hI = hM + w;
+    g_u16* const hD = hI + w;
+    FastTerm& tn = fs.fterm[s3];
+    // first / last in-bounds diagonal of M, I, D seen by this wave (biased; "last" kept complemented so that one packed
+    // unsigned min folds a record): scalar registers, updated from ballots
+    uint32_t fM = 0xFFFFu, fI = 0xFFFFu, fD = 0xFFFFu, nlM = 0xFFFFu, nlI = 0xFFFFu, nlD = 0xFFFFu;
+    // strips whose 64 diagonals (and their k-1 / k+1 neighbours) lie inside all four source ranges need no masks
+    const int in_lo = max(max(lo_mo + 1, lo_ie + 1), max(lo_de - 1, lo_mm));
+    const int in_hi = min(min(hi_mo - 1, hi_ie + 1), min(hi_de - 1, hi_mm));
+    LV_MARK(1);
+    for (int kb0 = lo + wave * 64; kb0 <= hi; kb0 += nT) {
+      const int kb = kb0 + lane;
+      bool okM = false, okI = false, okD = false;
+      auto body = [&](auto masked) {
+        unsigned a = pMo[kb - 1], b = pIe[kb - 1], c = pMo[kb + 1], d = pDe[kb + 1], m = pMm[kb];
+        if constexpr (decltype(masked)::value) {
+          a = (unsigned)(kb - 1 - lo_mo) < n_mo ? a : 0u;
+          b = (unsigned)(kb - 1 - lo_ie) < n_ie ? b : 0u;
+          c = (unsigned)(kb + 1 - lo_mo) < n_mo ? c : 0u;
+          d = (unsigned)(kb + 1 - lo_de) < n_de ? d : 0u;
+          m = (unsigned)(kb - lo_mm) < n_mm ? m : 0u;
+        }
+        // encoded domain (enc = offset + 1, 0 = NULL): ins = max(Mo[k-1], Ie[k-1]) + 1, del = max(Mo[k+1], De[k+1]), mis = Mm[k] + 1
+        const unsigned mi = max(a, b);
+        const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
+        unsigned mx = max(del, max(mis, ins));
+        const int k = kb - koff;
+        int32_t off = (int32_t)mx - 1;
+        okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+        if (okM) { off = extend(k, off, tn); mx = (unsigned)off + 1u; } else mx = 0u;
+        qI[kb] = (uint16_t)ins; qD[kb] = (uint16_t)del; qM[kb] = (uint16_t)mx;
+        hI[(unsigned)kb] = (uint16_t)ins; hD[(unsigned)kb] = (uint16_t)del; hM[(unsigned)kb] = (uint16_t)mx;  // history: written once
+        okI = (ins - 1u) <= (uint32_t)tlen && (ins - 1u - (uint32_t)k) <= (uint32_t)plen;
+        okD = (del - 1u) <= (uint32_t)tlen && (del - 1u - (uint32_t)k) <= (uint32_t)plen;
+      };
+      if (kb0 >= in_lo && kb0 + 63 <= in_hi) { body(std::false_type{}); }  // kb0 + 63 <= in_hi <= hi: all 64 lanes are live
+      else if (kb <= hi) { body(std::true_type{}); }
+      // wavefront_compute_trim_ends bookkeeping on the scalar unit: kb0 only grows, so "first" is a min and "last" overwrites
+      const unsigned long long mM = __ballot(okM), mI = __ballot(okI), mD = __ballot(okD);
+      if (mM) { fM = min(fM, (uint32_t)(kb0 + __builtin_ctzll(mM))); nlM = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mM)); }
+      if (mI) { fI = min(fI, (uint32_t)(kb0 + __builtin_ctzll(mI))); nlI = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mI)); }
+      if (mD) { fD = min(fD, (uint32_t)(kb0 + __builtin_ctzll(mD))); nlD = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mD)); }
     }
-    {
-      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-      union U { unsigned u; us2 v; };
-      U t0, t1, t2;
-      t0.u = fM | (fI << 16); t1.u = fD | (nlM << 16); t2.u = nlI | (nlD << 16);
-      for (int o = 32; o > 0; o >>= 1) {
-        U a0, a1, a2;
-        a0.u = __shfl_xor(t0.u, o); a1.u = __shfl_xor(t1.u, o); a2.u = __shfl_xor(t2.u, o);
-        t0.v = __builtin_elementwise_min(t0.v, a0.v); t1.v = __builtin_elementwise_min(t1.v, a1.v); t2.v = __builtin_elementwise_min(t2.v, a2.v);
-      }
-      if ((tid & 63) == 0) {
-        const unsigned rfM = t0.u & 0xFFFFu, rfI = t0.u >> 16, rfD = t1.u & 0xFFFFu, rlM = 0xFFFFu - (t1.u >> 16), rlI = 0xFFFFu - (t2.u & 0xFFFFu), rlD = 0xFFFFu - (t2.u >> 16);
-        if (rfM != 0xFFFFu) { atomicMin(&rn.lo[0], (int)rfM - koff); atomicMax(&rn.hi[0], (int)rlM - koff); }
-        if (rfI != 0xFFFFu) { atomicMin(&rn.lo[1], (int)rfI - koff); atomicMax(&rn.hi[1], (int)rlI - koff); }
-        if (rfD != 0xFFFFu) { atomicMin(&rn.lo[2], (int)rfD - koff); atomicMax(&rn.hi[2], (int)rlD - koff); }
-      }
-    }
+    LV_MARK(2);
+    if (lane == 0) fs.wred[s & 1][wave] = make_uint4(fM | (nlM << 16), fI | (nlI << 16), fD | (nlD << 16), 0u);
+    // keeps the join of this divergent branch out of the loop's latch block: the uniformity analysis taints every phi of a
+    // block where divergent paths join, and the latch block holds the phis of the whole (uniform) per-level state
+    asm volatile("" ::: "memory");
   }
-  __syncthreads();
-  if (tid == 0) { I.status = status; sh.cells += cells; }
-  __syncthreads();
-  return status;
+  LV_FLUSH;
+  FastEnd E;
+  E.status = status; E.score = s; E.k = end_k; E.off = end_off; E.cells = cells;
+  return E;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,30 +287,36 @@ __device__ __forceinline__ int wf_run_lds_affine(const KParams& kp, const uint32
 // gap-extension chain the next cells are known in advance -- (s - j*e, k + j) for deletions, (s - j*e, k - j) with the
 // offset falling by one for insertions -- so lane j fetches step j's two candidates and a ballot finds where the
 // chain stops.  Long deletion runs are what the back-trace of a read that lacks the flank consists of.
-// ld: LDS copy of the descriptors, ld[s * 3 + {0: M, 1: I1, 2: D1}].  Runs are pushed (reversed) by lane 0.
-__device__ __forceinline__ long long bt_cand_lds(const WfDesc* ld, const int32_t* __restrict__ A, int cidx, int s, int k, int add, int type) {
+// ld: descriptors, ld[s * STRIDE + {0: M, 1: I1, 2: D1, 3: base, 4: lo_alloc | width << 16}].  Runs are pushed (reversed) by lane 0.
+template <int STRIDE>
+__device__ __forceinline__ long long bt_cand_fast(const uint32_t* ld, const uint16_t* __restrict__ A16, int cidx, int s, int kb, int add, int type) {
   if (s < 0) return (long long)OFF_NULL;
-  const WfDesc d = ld[s * 3 + cidx];
-  if (d.base == NOBASE || k < d.lo || k > d.hi) return (long long)OFF_NULL;
-  return (((long long)(A[d.base + (uint32_t)(k - d.lo_alloc)] + add)) << 4) | type;
+  const uint32_t* d = ld + s * STRIDE;
+  const uint32_t r = d[cidx];
+  if (kb < pd_lo(r) || kb > pd_hi(r)) return (long long)OFF_NULL;
+  const uint32_t base = d[3], law = d[4];
+  const uint32_t enc = A16[base + (uint32_t)cidx * (law >> 16) + (uint32_t)(kb - (int)(law & 0xFFFFu))];
+  if (enc == 0u) return (long long)OFF_NULL;
+  return (((long long)((int)enc - 1 + add)) << 4) | type;
 }
 
-__device__ __forceinline__ void wf_backtrace_fast_affine(const KParams& kp, const WfDesc* ld, const int32_t* __restrict__ A,
-                                                         uint32_t* tmp, int& ntmp_out, uint32_t cap) {
-  const Inst& I = sh.inst[I_UNI];
+template <int STRIDE>
+__device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen, int tlen, const FastEnd& E, const uint32_t* ld,
+                                                        const uint16_t* __restrict__ A16, uint32_t* tmp, uint32_t cap) {
   const int lane = threadIdx.x & 63;
-  const int plen = I.plen, tlen = I.tlen;
-  const int x = kp.pen.x, oe = kp.pen.o1 + kp.pen.e1, e = kp.pen.e1;
-  int mt = CM, s = I.end_score, k = I.end_k, off = I.end_off;
+  const int koff = plen + 2;
+  const int x = pen.x, oe = pen.o1 + pen.e1, e = pen.e1;
+  int mt = CM, s = E.score, k = E.k, off = E.off;
   int h = off, v = off - k, nt = 0;
+  auto cand = [&](int cidx, int ss, int kk, int add, int type) { return bt_cand_fast<STRIDE>(ld, A16, cidx, ss, kk + koff, add, type); };
   if (lane == 0) { rle_push(tmp, nt, cap, 2u, plen - v); rle_push(tmp, nt, cap, 1u, tlen - h); }
   while (v > 0 && h > 0 && s > 0) {
     if (mt == CM) {
-      long long best = bt_cand_lds(ld, A, 0, s - x, k, +1, 9);
-      best = max(best, bt_cand_lds(ld, A, 2, s - e, k + 1, 0, 6));
-      best = max(best, bt_cand_lds(ld, A, 0, s - oe, k + 1, 0, 5));
-      best = max(best, bt_cand_lds(ld, A, 1, s - e, k - 1, +1, 2));
-      best = max(best, bt_cand_lds(ld, A, 0, s - oe, k - 1, +1, 1));
+      long long best = cand(0, s - x, k, +1, 9);
+      best = max(best, cand(2, s - e, k + 1, 0, 6));
+      best = max(best, cand(0, s - oe, k + 1, 0, 5));
+      best = max(best, cand(1, s - e, k - 1, +1, 2));
+      best = max(best, cand(0, s - oe, k - 1, +1, 1));
       if (best < 0) break;
       const int best_off = (int)(best >> 4), type = (int)(best & 0xF);
       if (lane == 0) rle_push(tmp, nt, cap, 7u, off - best_off);
@@ -273,8 +337,8 @@ __device__ __forceinline__ void wf_backtrace_fast_affine(const KParams& kp, cons
       const bool alive = (del ? (v - lane > 0 && h > 0) : (h - lane > 0 && v > 0)) && sj > 0;
       long long ce = (long long)OFF_NULL, co = (long long)OFF_NULL;
       if (alive) {
-        ce = del ? bt_cand_lds(ld, A, 2, sj - e, kj + 1, 0, 6) : bt_cand_lds(ld, A, 1, sj - e, kj - 1, +1, 2);
-        co = del ? bt_cand_lds(ld, A, 0, sj - oe, kj + 1, 0, 5) : bt_cand_lds(ld, A, 0, sj - oe, kj - 1, +1, 1);
+        ce = del ? cand(2, sj - e, kj + 1, 0, 6) : cand(1, sj - e, kj - 1, +1, 2);
+        co = del ? cand(0, sj - oe, kj + 1, 0, 5) : cand(0, sj - oe, kj - 1, +1, 1);
       }
       const bool cont = alive && ce >= 0 && ce > co;  // the extension candidate is the maximum
       const unsigned long long stop = __ballot(!cont);
@@ -287,8 +351,8 @@ __device__ __forceinline__ void wf_backtrace_fast_affine(const KParams& kp, cons
         continue;
       }
       // ---- the chain stops right here: one ordinary step (gap open, or no source at all)
-      const long long cext = del ? bt_cand_lds(ld, A, 2, s - e, k + 1, 0, 6) : bt_cand_lds(ld, A, 1, s - e, k - 1, +1, 2);
-      const long long copn = del ? bt_cand_lds(ld, A, 0, s - oe, k + 1, 0, 5) : bt_cand_lds(ld, A, 0, s - oe, k - 1, +1, 1);
+      const long long cext = del ? cand(2, s - e, k + 1, 0, 6) : cand(1, s - e, k - 1, +1, 2);
+      const long long copn = del ? cand(0, s - oe, k + 1, 0, 5) : cand(0, s - oe, k - 1, +1, 1);
       const long long best = max(cext, copn);
       if (best < 0) break;
       if (lane == 0) rle_push(tmp, nt, cap, del ? 2u : 1u, 1);
@@ -301,8 +365,154 @@ __device__ __forceinline__ void wf_backtrace_fast_affine(const KParams& kp, cons
     if (mt == CM && v > 0 && h > 0) { const int n = min(v, h); rle_push(tmp, nt, cap, 7u, n); v -= n; h -= n; }
     rle_push(tmp, nt, cap, 2u, v);
     rle_push(tmp, nt, cap, 1u, h);
-    ntmp_out = nt;
   }
+  return nt;  // meaningful on lane 0
+}
+
+// ------------------------------------------------------------------------------------------------
+// The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
+// acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): byte copies of both sequences | ring | windows.
+__global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
+  extern __shared__ unsigned char lds_dyn[];
+  FastShared& fs = g_fsh;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const Pen pen = a.kp.pen;
+  if (tid == 0) {
+    uint32_t i = (blockIdx.x * 2654435761u) % a.n_slots_ws;
+    while (atomicCAS(&a.slot_flags[i], 0u, 1u) != 0u) i = i + 1 == a.n_slots_ws ? 0 : i + 1;
+    fs.slot = (int)i;
+  }
+  __syncthreads();
+  const uint32_t ws_slot = rfl((uint32_t)fs.slot);
+  uint8_t* const wsb = a.ws + (size_t)ws_slot * a.ws_per_block;
+  uint32_t* const gd = reinterpret_cast<uint32_t*>(wsb + a.off_gdesc);
+  uint16_t* const A16g = reinterpret_cast<uint16_t*>(wsb + a.off_arena_u);
+  uint32_t* const rle_tmp = reinterpret_cast<uint32_t*>(wsb + a.off_rle_tmp);
+  uint32_t* const rle_out = reinterpret_cast<uint32_t*>(wsb + a.off_rle_out);
+  uint32_t* const run_start = reinterpret_cast<uint32_t*>(wsb + a.off_run_start);
+  uint8_t* const lds_seq = lds_dyn;
+  uint16_t* const ring = reinterpret_cast<uint16_t*>(lds_dyn + a.lds_seq_cap);
+  uint32_t* const P4 = reinterpret_cast<uint32_t*>(lds_dyn + a.lds_seq_cap + a.fast_ring_bytes);
+  const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  unsigned long long cells_acc = 0;
+  PROF_DECL;
+  for (uint32_t jb = 0; jb < a.jobs_per_block; ++jb) {
+    PROF_MARK(5);
+    __syncthreads();
+    if (tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    const uint32_t j = rfl((uint32_t)fs.job);
+    if (j >= n_jobs) break;
+    PROF_MARK(0);
+    const JobDev job = a.jobs[j];
+    const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
+    const uint8_t* const P = a.pat_base + job.pat_off;
+    const uint8_t* const Tx = a.txt_base + job.txt_off;
+    const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
+    uint32_t* const T4 = P4 + plen + 1;
+    // byte copies, then the 4-byte sliding windows built from them
+    for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
+    for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
+    __syncthreads();
+    for (int i = tid; i <= plen; i += T) {
+      uint32_t wv = 0;
+      for (int b = 0; b < 4; ++b) if (i + b < plen) wv |= (uint32_t)lds_seq[i + b] << (8 * b);
+      P4[i] = wv;
+    }
+    for (int i = tid; i <= tlen; i += T) {
+      uint32_t wv = 0;
+      for (int b = 0; b < 4; ++b) if (i + b < tlen) wv |= (uint32_t)lds_seq[pl_pad + i + b] << (8 * b);
+      T4[i] = wv;
+    }
+    FastJob J;
+    {
+      const int sp = a.kp.span;
+      auto fr = [](int v, int len) { return v < 0 ? len : v; };
+      J.plen = plen; J.tlen = tlen; J.span = sp;
+      J.pbf = sp ? fr(a.kp.pbf, plen) : 0; J.pef = sp ? fr(a.kp.pef, plen) : 0;
+      J.tbf = sp ? fr(a.kp.tbf, tlen) : 0; J.tef = sp ? fr(a.kp.tef, tlen) : 0;
+      J.n_slots = (int)a.uni_slots; J.cap = a.arena_uni_cap;
+    }
+    PROF_MARK(1);
+    const FastEnd E = wf_run_lds_affine(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
+#ifdef TRGT_WFA_PROF
+    const unsigned long long pf_t2 = pf_t;
+#endif
+    PROF_MARK(2);
+#ifdef TRGT_WFA_PROF
+    if (tid == 0) {
+      pf_acc[6] += 1; pf_acc[7] += (unsigned long long)E.score;
+      if (E.score > 40) { atomicAdd(&g_wfa_prof[16], 1ull); atomicAdd(&g_wfa_prof[17], (unsigned long long)E.score); atomicAdd(&g_wfa_prof[18], pf_t - pf_t2); }
+    }
+#endif
+    cells_acc += E.cells;
+    const bool ok = E.status == ST_END_REACHED;
+    int nrun = 0;
+    if (ok && a.kp.scope_alignment && !a.fast_dbg) {
+      // back-trace by wave 0; the level descriptors are staged in the (now idle) ring area of LDS when they fit
+      const bool fits = (uint32_t)(E.score + 1) * FD_LDS_STRIDE * 4u <= a.fast_ring_bytes;
+      __syncthreads();  // every wave has left the level loop (ring idle), thread 0's descriptor stores are done
+      int nt = 0;
+      if (fits) {
+        uint32_t* ld = reinterpret_cast<uint32_t*>(ring);
+        for (int i = tid; i < (E.score + 1) * FD_LDS_STRIDE; i += T) {
+          const int lvl = i / FD_LDS_STRIDE, c5 = i - lvl * FD_LDS_STRIDE;
+          ld[i] = gd[(size_t)lvl * FD_STRIDE + c5];
+        }
+        __syncthreads();
+        if (tid < 64) nt = wf_backtrace_fast_affine<FD_LDS_STRIDE>(pen, plen, tlen, E, ld, A16g, rle_tmp, a.rle_cap);
+      } else if (tid < 64) {
+        nt = wf_backtrace_fast_affine<FD_STRIDE>(pen, plen, tlen, E, gd, A16g, rle_tmp, a.rle_cap);
+      }
+      if (tid == 0) fs.rle_n = nt;
+      __syncthreads();
+      nrun = rfl(fs.rle_n);
+      for (int r = tid; r < nrun; r += T) rle_out[r] = rle_tmp[nrun - 1 - r];  // forward order (runs are already merged)
+      PROF_MARK(3);
+    }
+    __syncthreads();
+    PROF_MARK(4);
+    // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations (as in wfa_kernel)
+    if (tid == 0) {
+      const uint32_t o = job.out_index;
+      if (a.status) a.status[o] = ok ? TRGT_WF_COMPLETED : (E.status == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE);
+      if (a.score) a.score[o] = ok ? -E.score : INT32_MIN;
+      uint32_t pi = 0, ti = 0, ps = 0, pe = 0, ts = 0, te = 0, nm = 0, total = 0;
+      bool started = false;
+      for (int r = 0; r < nrun; ++r) {
+        const uint32_t en = rle_out[r], len = en >> 4, code = en & 0xF;
+        run_start[r] = total;
+        total += len;
+        if (code == 1u) ti += len;
+        else if (code == 2u) pi += len;
+        else { if (!started) { ps = pi; ts = ti; started = true; } pi += len; ti += len; pe = pi; te = ti; if (code == 7u) nm += len; }
+      }
+      if (a.kp.span == 0) { ps = 0; pe = (uint32_t)plen; ts = 0; te = (uint32_t)tlen; }
+      if (a.n_match) a.n_match[o] = (int32_t)nm;
+      if (a.span4) { a.span4[4 * o + 0] = ps; a.span4[4 * o + 1] = pe; a.span4[4 * o + 2] = ts; a.span4[4 * o + 3] = te; }
+      if (a.cigar_len) a.cigar_len[o] = (uint32_t)nrun;
+      if (a.ops_len) a.ops_len[o] = total;
+      fs.total_ops = (int)total;
+    }
+    if (a.cigar) for (int r = tid; r < nrun; r += T) a.cigar[job.cigar_off + r] = rle_out[r];
+    if (a.ops && nrun > 0) {
+      __syncthreads();
+      const uint32_t total = (uint32_t)fs.total_ops;
+      for (uint32_t p = tid; p < total; p += T) {
+        int lo = 0, hi = nrun - 1;  // last run whose start <= p
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (run_start[mid] <= p) lo = mid; else hi = mid - 1; }
+        const uint32_t code = rle_out[lo] & 0xF;
+        a.ops[job.ops_off + p] = code == 7u ? 'M' : code == 8u ? 'X' : code == 1u ? 'I' : 'D';
+      }
+    }
+  }
+  if (tid == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
+#ifdef TRGT_WFA_PROF
+  PROF_MARK(5);
+  if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_wfa_prof[i], pf_acc[i]);
+#endif
+  __syncthreads();
+  if (tid == 0) { __threadfence(); atomicExch(&a.slot_flags[ws_slot], 0u); }
 }
 
 }  // namespace wfa
