@@ -59,6 +59,21 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   return r.u;
 }
 
+// v_ffbl_b32 returns -1 for a zero input, which is exactly what the extension wants ("no mismatch in this window" -> a byte
+// index >= 4 after the shift); __builtin_ctz would be undefined there and __ffs costs a compare + select.
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t v) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// History stream: raw buffer stores (resource + per-lane byte offset + scalar byte offset) need no per-store address
+// arithmetic.  The resource base sits HIST_BIAS elements below the arena so that the scalar offset of a level whose lowest
+// biased diagonal exceeds its bump offset stays non-negative.
+constexpr int HIST_BIAS = 1 << 16;
+__device__ __forceinline__ void hist_store(__amdgpu_buffer_rsrc_t rs, uint32_t kb2, uint32_t soff, uint32_t enc) {
+  __builtin_amdgcn_raw_buffer_store_b16((short)enc, rs, (int)kb2, (int)soff, 0);
+}
+
 // History descriptor of one level in HBM: FD_STRIDE dwords {M, I, D packed ranges (trimmed), base, lo_alloc | width << 16}.
 // Offsets of component c (0 M, 1 I, 2 D) of diagonal kb sit at A16[base + c * width + (kb - lo_alloc)].
 constexpr int FD_STRIDE = 8, FD_LDS_STRIDE = 5;
@@ -96,6 +111,10 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   const uint32_t cap = J.cap;
   const int n_slots = J.n_slots, span = J.span, pef = J.pef, tef = J.tef, pbf = J.pbf, tbf = J.tbf;
   const uint32_t PDN = (uint32_t)(koff + 1) | ((uint32_t)(koff - 1) << 16);  // the canonical null wavefront (lo = 1, hi = -1)
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A16 - HIST_BIAS), 0, -1, 0x00020000);
+  // which sources are "the level just finished" (taken from registers) rather than an older one (taken from the LDS ring)
+  const bool mis_cur = x == 1, o_cur = oe == 1, e_cur = e == 1;
+  const int W2 = wcap * 2, RMW = RM * W2, RIW = RI * W2, XW = x * W2, OEW = oe * W2, EW = e * W2;  // ring geometry in bytes
 
   // Extension over 4-byte sliding windows: P4[i] = pattern bytes i..i+3 (zero padded), T4 likewise.  One aligned LDS
   // dword per sequence covers four bases; most diagonals stop inside the first window, so the common case is straight-line.
@@ -104,7 +123,7 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     uint32_t n;
     do {
       const uint32_t xw = P4[v] ^ T4[h];
-      n = min(min((uint32_t)(__ffs((int)xw) - 1) >> 3, 4u), (uint32_t)min(plen - v, tlen - h));
+      n = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - v, tlen - h));
       v += (int)n; h += (int)n;
     } while (n == 4u);
     if (span == 1) {
@@ -115,6 +134,7 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   };
 
   __syncthreads();
+  if (tid < RING) fs.fdesc[tid] = make_uint4(PDN, PDN, PDN, 0u);  // levels "-1 .. -RING" are null: no lvl < 0 tests later
   if (tid == 0)
     for (int r = 0; r < 3; ++r) { fs.fterm[r].term_key = ~0ull; fs.fterm[r].end_val = OFF_NULL; }
   __syncthreads();
@@ -129,13 +149,13 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   uint32_t bump = w_c;
   unsigned long long cells = bump;
   int status = ST_OK, num_null = 0, s = 0;
-  int slM = 0, slI = 0, s3 = 0;  // s % RM, s % RI, s % 3 kept incrementally
+  int oM = 0, oI = 0, s3 = 0;  // byte offsets of the slots of level s in the M / I,D rings; s % 3
   bool computed = true;
   if (bump > cap || n_slots < 1) status = ST_OOM;
   else {
     FastTerm& tm = fs.fterm[0];
     const int hi_b = pd_hi(cM);
-    g_u16* const h0 = A16 - lo_c;
+    const uint32_t so0 = 2u * (uint32_t)(HIST_BIAS - (int)lo_c);
     for (int kb0 = (int)lo_c + wave * 64; kb0 <= hi_b; kb0 += nT) {
       const int kb = kb0 + lane;
       if (kb <= hi_b) {
@@ -143,7 +163,7 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
         int32_t off = span ? (k > 0 ? k : 0) : 0;
         off = extend(k, off, tm);
         Mr[kb] = (uint16_t)(off + 1);
-        h0[(unsigned)kb] = (uint16_t)(off + 1);
+        hist_store(hrs, 2u * (uint32_t)kb, so0, (uint32_t)(off + 1));
       }
     }
   }
@@ -191,13 +211,11 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     if (!computed && num_null > scope) { status = ST_END_UNREACHABLE; break; }
     // ---- next level
     ++s;
-    slM = slM + 1 == RM ? 0 : slM + 1; slI = slI + 1 == RI ? 0 : slI + 1; s3 = s3 == 2 ? 0 : s3 + 1;
-    auto sel = [&](uint32_t ringv, uint32_t cur, int lvl) -> uint32_t {  // wavefront_compute_get_*: NULL / ->null become the canonical null
-      const uint32_t d = lvl == s - 1 ? cur : rfl(ringv);
-      return (lvl < 0 || pd_null(d)) ? PDN : d;
-    };
-    const uint32_t m_mis = sel(fa.x, cM, s - x), m_o = sel(fb.x, cM, s - oe), ie = sel(fc.y, cI, s - e), de = sel(fc.z, cD, s - e);
-    if (pd_null(m_mis) && pd_null(m_o) && pd_null(ie) && pd_null(de)) {
+    oM = oM + W2 == RMW ? 0 : oM + W2; oI = oI + W2 == RIW ? 0 : oI + W2; s3 = s3 == 2 ? 0 : s3 + 1;
+    // wavefront_compute_get_*: the ring holds canonical descriptors (a NULL or ->null wavefront is PDN, and so is every
+    // level below 0), so a source is a plain select between registers and the ring word fetched above
+    const uint32_t m_mis = mis_cur ? cM : rfl(fa.x), m_o = o_cur ? cM : rfl(fb.x), ie = e_cur ? cI : rfl(fc.y), de = e_cur ? cD : rfl(fc.z);
+    if ((((m_mis ^ PDN) | (m_o ^ PDN)) | ((ie ^ PDN) | (de ^ PDN))) == 0u) {
       ++num_null; computed = false;
       cM = cI = cD = PDN; lo_c = 0; w_c = 0; base_c = 0;
       continue;
@@ -207,35 +225,37 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     const int lo = min(min(pd_lo(m_mis), pd_lo(m_o) - 1), min(pd_lo(ie) + 1, pd_lo(de) - 1));
     const int hi = max(max(pd_hi(m_mis), pd_hi(m_o) + 1), max(pd_hi(ie) + 1, pd_hi(de) - 1));
     const uint32_t w = (uint32_t)max(0, hi - lo + 1);
-    if (s >= n_slots || (unsigned long long)bump + 3ull * w > cap) { status = ST_OOM; break; }
+    if (s >= n_slots || 3u * w > cap - bump) { status = ST_OOM; break; }  // bump <= cap always
     const uint32_t bM = bump;
     bump += 3 * w; cells += 3ull * w;
     lo_c = (uint32_t)lo; w_c = w; base_c = bM;
-    const int slMo = slM - oe < 0 ? slM - oe + RM : slM - oe, slMm = slM - x < 0 ? slM - x + RM : slM - x;  // oe, x < RM
-    const int slIe = slI - e < 0 ? slI - e + RI : slI - e;
-    const uint16_t* const pMo = Mr + slMo * wcap;
-    const uint16_t* const pMm = Mr + slMm * wcap;
-    const uint16_t* const pIe = Ir + slIe * wcap;
-    const uint16_t* const pDe = Dr + slIe * wcap;
-    uint16_t* const qM = Mr + slM * wcap;
-    uint16_t* const qI = Ir + slI * wcap;
-    uint16_t* const qD = Dr + slI * wcap;
+    const int oMo = oM - OEW < 0 ? oM - OEW + RMW : oM - OEW, oMm = oM - XW < 0 ? oM - XW + RMW : oM - XW;  // oe, x < RM
+    const int oIe = oI - EW < 0 ? oI - EW + RIW : oI - EW;
+    const uint16_t* const pMo = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Mr) + oMo);
+    const uint16_t* const pMm = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Mr) + oMm);
+    const uint16_t* const pIe = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Ir) + oIe);
+    const uint16_t* const pDe = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Dr) + oIe);
+    uint16_t* const qM = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(Mr) + oM);
+    uint16_t* const qI = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(Ir) + oI);
+    uint16_t* const qD = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(Dr) + oI);
     const int lo_mo = pd_lo(m_o), hi_mo = pd_hi(m_o), lo_mm = pd_lo(m_mis), hi_mm = pd_hi(m_mis);
     const int lo_ie = pd_lo(ie), hi_ie = pd_hi(ie), lo_de = pd_lo(de), hi_de = pd_hi(de);
     const unsigned n_mo = (unsigned)max(0, hi_mo - lo_mo + 1), n_mm = (unsigned)max(0, hi_mm - lo_mm + 1);
     const unsigned n_ie = (unsigned)max(0, hi_ie - lo_ie + 1), n_de = (unsigned)max(0, hi_de - lo_de + 1);
-    g_u16* const hM = A16 + ((long long)bM - lo);
-    g_u16* const hI = hM + w;
-    g_u16* const hD = hI + w;
+    const uint32_t soM = 2u * (uint32_t)((int)bM - lo + HIST_BIAS), soI = soM + 2u * w, soD = soI + 2u * w;  // history: scalar byte offsets
     FastTerm& tn = fs.fterm[s3];
     // first / last in-bounds diagonal of M, I, D seen by this wave (biased; "last" kept complemented so that one packed
     // unsigned min folds a record): scalar registers, updated from ballots
-    uint32_t fM = 0xFFFFu, fI = 0xFFFFu, fD = 0xFFFFu, nlM = 0xFFFFu, nlI = 0xFFFFu, nlD = 0xFFFFu;
+    // (the first and the last non-empty ballot of each component plus their strip origins; decoded after the loop)
+    unsigned long long fmM = 0, fmI = 0, fmD = 0, lmM = 0, lmI = 0, lmD = 0;
+    int fkM = 0, fkI = 0, fkD = 0, lkM = 0, lkI = 0, lkD = 0;
     // strips whose 64 diagonals (and their k-1 / k+1 neighbours) lie inside all four source ranges need no masks
     const int in_lo = max(max(lo_mo + 1, lo_ie + 1), max(lo_de - 1, lo_mm));
     const int in_hi = min(min(hi_mo - 1, hi_ie + 1), min(hi_de - 1, hi_mm));
     LV_MARK(1);
-    for (int kb0 = lo + wave * 64; kb0 <= hi; kb0 += nT) {
+    // wave w takes strips nW-1-w, 2nW-1-w, ...: the ragged last strip then falls on the last wave, not on wave 0, which
+    // also carries thread 0's publishing work
+    for (int kb0 = lo + (nW - 1 - wave) * 64; kb0 <= hi; kb0 += nT) {
       const int kb = kb0 + lane;
       bool okM = false, okI = false, okD = false;
       auto body = [&](auto masked) {
@@ -256,18 +276,23 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
         okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
         if (okM) { off = extend(k, off, tn); mx = (unsigned)off + 1u; } else mx = 0u;
         qI[kb] = (uint16_t)ins; qD[kb] = (uint16_t)del; qM[kb] = (uint16_t)mx;
-        hI[(unsigned)kb] = (uint16_t)ins; hD[(unsigned)kb] = (uint16_t)del; hM[(unsigned)kb] = (uint16_t)mx;  // history: written once
+        const uint32_t kb2 = 2u * (uint32_t)kb;
+        hist_store(hrs, kb2, soI, ins); hist_store(hrs, kb2, soD, del); hist_store(hrs, kb2, soM, mx);  // history: written once
         okI = (ins - 1u) <= (uint32_t)tlen && (ins - 1u - (uint32_t)k) <= (uint32_t)plen;
         okD = (del - 1u) <= (uint32_t)tlen && (del - 1u - (uint32_t)k) <= (uint32_t)plen;
       };
       if (kb0 >= in_lo && kb0 + 63 <= in_hi) { body(std::false_type{}); }  // kb0 + 63 <= in_hi <= hi: all 64 lanes are live
       else if (kb <= hi) { body(std::true_type{}); }
-      // wavefront_compute_trim_ends bookkeeping on the scalar unit: kb0 only grows, so "first" is a min and "last" overwrites
+      // wavefront_compute_trim_ends bookkeeping on the scalar unit: kb0 only grows, so the first non-empty ballot is kept and
+      // the last one overwritten
       const unsigned long long mM = __ballot(okM), mI = __ballot(okI), mD = __ballot(okD);
-      if (mM) { fM = min(fM, (uint32_t)(kb0 + __builtin_ctzll(mM))); nlM = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mM)); }
-      if (mI) { fI = min(fI, (uint32_t)(kb0 + __builtin_ctzll(mI))); nlI = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mI)); }
-      if (mD) { fD = min(fD, (uint32_t)(kb0 + __builtin_ctzll(mD))); nlD = 0xFFFFu - (uint32_t)(kb0 + 63 - __builtin_clzll(mD)); }
+      fkM = fmM ? fkM : kb0; fmM = fmM ? fmM : mM; lkM = mM ? kb0 : lkM; lmM = mM ? mM : lmM;
+      fkI = fmI ? fkI : kb0; fmI = fmI ? fmI : mI; lkI = mI ? kb0 : lkI; lmI = mI ? mI : lmI;
+      fkD = fmD ? fkD : kb0; fmD = fmD ? fmD : mD; lkD = mD ? kb0 : lkD; lmD = mD ? mD : lmD;
     }
+    const uint32_t fM = fmM ? (uint32_t)(fkM + __builtin_ctzll(fmM)) : 0xFFFFu, nlM = lmM ? 0xFFFFu - (uint32_t)(lkM + 63 - __builtin_clzll(lmM)) : 0xFFFFu;
+    const uint32_t fI = fmI ? (uint32_t)(fkI + __builtin_ctzll(fmI)) : 0xFFFFu, nlI = lmI ? 0xFFFFu - (uint32_t)(lkI + 63 - __builtin_clzll(lmI)) : 0xFFFFu;
+    const uint32_t fD = fmD ? (uint32_t)(fkD + __builtin_ctzll(fmD)) : 0xFFFFu, nlD = lmD ? 0xFFFFu - (uint32_t)(lkD + 63 - __builtin_clzll(lmD)) : 0xFFFFu;
     LV_MARK(2);
     if (lane == 0) fs.wred[s & 1][wave] = make_uint4(fM | (nlM << 16), fI | (nlI << 16), fD | (nlD << 16), 0u);
     // keeps the join of this divergent branch out of the loop's latch block: the uniformity analysis taints every phi of a
