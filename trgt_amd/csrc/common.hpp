@@ -34,8 +34,13 @@ struct trgt_hip_ctx {
   std::vector<Pending> pending;
   void* last_wfa_cells_dev = nullptr;
   int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host-side phase timers of the last call (diagnostics)
-  std::mutex* stage_a_mutex = nullptr;  // set while two lanes share the GPU: serialises the dominant GPU stage so the lanes interleave
-  trgt_hip_ctx* aux = nullptr;  // second lane (own stream + buffers) used by trgt_locus_batch to overlap host glue with GPU stages
+  // trgt_locus_batch pipelines chunks of loci: stage A of chunk k+1 runs on `stream` while the host glue of chunk k and its
+  // small transfers / gather kernel use `stream2`; pinned host buffers (slot-indexed like `pool`) make those copies asynchronous
+  hipStream_t stream2 = nullptr;
+  struct PinBuf { void* p = nullptr; size_t cap = 0; };
+  std::vector<PinBuf> pinned;
+  void* host_pool = nullptr;  // trgt::HostPool*, created on first use
+  int host_pool_threads = 0;
 };
 
 namespace trgt {
@@ -76,12 +81,14 @@ enum Slot {
   S_HMM_SEQ = 0, S_HMM_DESC, S_HMM_MODEL, S_HMM_JOBS, S_HMM_BP, S_HMM_PATH, S_HMM_SPANS, S_HMM_NSP, S_HMM_CNT, S_HMM_PUR,
   S_HMM_EDIT, S_HMM_MAXD, S_HMM_PLEN, S_HMM_VISITS, S_HMM_MOTIFS,
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
-  S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS,
+  S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
   S_FS_WFAJOBS, S_FS_SPAN, S_FS_NMATCH,
-  S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3,
+  S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_COUNT
 };
+// pinned host buffer slots
+enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_SEG0, P_SEG_LAST = P_SEG0 + 15, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   if ((int)c->pool.size() < S_COUNT) c->pool.resize(S_COUNT);
@@ -95,6 +102,25 @@ inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
       (void)hipGetLastError();
       b.p = nullptr;
       return fail(c, TRGT_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+  }
+  *out = b.p;
+  return TRGT_OK;
+}
+
+inline int pin_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
+  if ((int)c->pinned.size() < P_COUNT) c->pinned.resize(P_COUNT);
+  auto& b = c->pinned[slot];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    if (b.p) { TRGT_HIP_TRY(c, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      return fail(c, TRGT_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
     }
     b.cap = want;
   }

@@ -1,5 +1,6 @@
 // trgt_amd/csrc/ctx.hip -- ctx lifetime, stream binding, timing accessors.
 #include "common.hpp"
+#include "host_pool.hpp"
 
 static std::string g_create_err;
 
@@ -40,9 +41,12 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
 
 void trgt_hip_destroy(trgt_hip_ctx* c) {
   if (!c) return;
-  if (c->aux) { trgt_hip_destroy(c->aux); c->aux = nullptr; }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  delete static_cast<trgt::HostPool*>(c->host_pool);
+  for (auto& b : c->pinned)
+    if (b.p) (void)hipHostFree(b.p);
   trgt::resolve_timing(c);
   for (auto& b : c->pool)
     if (b.p) (void)hipFree(b.p);

@@ -11,8 +11,13 @@
 //                   reference allele first                 tr.rs:95-101
 //   stage C (GPU)   label_with_hmm                         tr.rs:454-492           -> hmm.hip
 // genotype_flank::genotype (tr.rs:70-75) returns None for such reads and is not on this path.
-// The host glue is integer / byte work of a few microseconds per locus, spread over host threads;
+// The host glue is integer / byte work of a few microseconds per locus, spread over a persistent pool of host threads;
 // moving it onto the device is SURVEY.md 8(f) row 1.
+//
+// Chunking inside one call (TRGT_LOCUS_CHUNKS, default 1): stage A of every chunk is enqueued up front on the ctx stream
+// (nothing in it waits for the host), each followed by an asynchronous copy of its spans into pinned memory and an event.
+// The host then walks the chunks: wait for the event, select the spanning reads, gather their repeat segments, run the
+// genotyper, stages B and C (second stream) -- while the GPU is already locating flanks for the next chunks.
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -21,6 +26,7 @@
 #include <thread>
 
 #include "hmm_host.hpp"
+#include "host_pool.hpp"
 #include "wfa_host.hpp"
 
 namespace trgt {
@@ -194,19 +200,6 @@ std::string repair_consensus(const std::string& backbone, const std::vector<Seg>
   return out;
 }
 
-template <typename F>
-void parallel_for(int64_t n, int threads, F f) {  // f(index, thread)
-  if (threads <= 1 || n < 64) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
-  std::vector<std::thread> th;
-  const int64_t chunk = (n + threads - 1) / threads;
-  for (int t = 0; t < threads; ++t) {
-    const int64_t b = t * chunk, e = std::min<int64_t>(n, b + chunk);
-    if (b >= e) break;
-    th.emplace_back([=]() { for (int64_t i = b; i < e; ++i) f(i, t); });
-  }
-  for (auto& x : th) x.join();
-}
-
 struct GatherArgs { const uint8_t* reads; const uint64_t* src_off; const uint64_t* dst_off; const uint32_t* len; uint64_t n; uint8_t* out; };
 __global__ void gather_segments_kernel(const GatherArgs a) {  // one wavefront per segment
   const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -218,12 +211,20 @@ __global__ void gather_segments_kernel(const GatherArgs a) {  // one wavefront p
 
 inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+HostPool* host_pool(trgt_hip_ctx* c, int threads) {
+  if (c->host_pool && c->host_pool_threads != threads) { delete static_cast<HostPool*>(c->host_pool); c->host_pool = nullptr; }
+  if (!c->host_pool) { c->host_pool = new HostPool(threads); c->host_pool_threads = threads; }
+  return static_cast<HostPool*>(c->host_pool);
+}
+
+constexpr int MAX_CHUNKS = P_SEG_LAST - P_SEG0 + 1;
+
 }  // namespace
 }  // namespace trgt
 
 using namespace trgt;
 
-static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
   const int64_t nl = in->n_loci;
@@ -237,294 +238,327 @@ static int locus_batch_impl(trgt_hip_ctx* c, const trgt_locus_params* p, const t
     return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null field");
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
   const int F = p->flank_len;
+  if (F <= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: flank_len must be positive");
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
+  if (2 * nr > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: too many reads in one call");
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-  threads = std::min(threads, 32);  // a few microseconds of work per locus: more threads only add spawn cost
-  int64_t t0 = now_ns(), tA = 0, tB = 0, tC = 0, tHost = 0;
-  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0;
+  threads = std::min(threads, 32);  // a few microseconds of work per locus: more threads only add wake-up cost
+  HostPool* pool = host_pool(c, threads);
+  const int64_t t0 = now_ns();
+  int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
+  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0;
   for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
   for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
   if (nr == 0) return TRGT_OK;
+  if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   // The motif-HMM tables depend only on the catalog: build them on a host thread while the GPU locates flanks.
   HmmModels models;
   std::thread model_thread([&]() { hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
-  // ---------------- stage A: flank location on the GPU
-  trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
-  std::vector<uint8_t> lf_hit((size_t)nr), rf_hit((size_t)nr);
-  int rc;
-  {
-    std::unique_lock<std::mutex> lk;
-    if (c->stage_a_mutex && getenv("TRGT_SERIAL_A")) lk = std::unique_lock<std::mutex>(*c->stage_a_mutex);
-    rc = trgt_find_spans_batch(c, &sp, nl, in->flank_blob, in->lf_off, in->lf_len, in->rf_off, in->rf_len, in->locus_read_begin,
-                               in->read_blob, in->read_off, in->read_len, out->span_start, out->span_end, lf_hit.data(), rf_hit.data());
+
+  // ---------------- chunk plan
+  // Default: one chunk.  Measured on MI355X: the flank-location kernel is persistent and fills the LDS of every CU,
+  // so kernels of another stream do not start next to it, while every extra launch adds a tail of long alignments.
+  int n_chunks = 1;
+  if (const char* e = getenv("TRGT_LOCUS_CHUNKS")) n_chunks = atoi(e);
+  n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, MAX_CHUNKS), nl / 512));
+  std::vector<int64_t> cl((size_t)n_chunks + 1);
+  for (int k = 0; k <= n_chunks; ++k) cl[(size_t)k] = nl * k / n_chunks;
+
+  // ---------------- stage A for every chunk: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
+  std::vector<uint64_t> piece_off(2 * (size_t)nl);
+  std::vector<uint32_t> read_locus((size_t)nr);
+  uint64_t flank_total = 0, read_total = 0;
+  uint32_t max_read_len = 0;
+  for (int64_t l = 0; l < nl; ++l) {
+    if ((int64_t)in->lf_len[l] < F || (int64_t)in->rf_len[l] < F)
+      return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: locus %lld flank shorter than flank_len", (long long)l);
+    piece_off[2 * l] = in->lf_off[l] + in->lf_len[l] - (uint64_t)F;  // lf[lf.len()-F..]  (span_locater.rs:38)
+    piece_off[2 * l + 1] = in->rf_off[l];                            // rf[..F]           (:39)
+    flank_total = std::max<uint64_t>(flank_total, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
+    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) read_locus[r] = (uint32_t)l;
   }
-  if (rc) return rc;
-  for (int64_t r = 0; r < nr; ++r) stat_flank_jobs += (lf_hit[r] != 1) + (rf_hit[r] != 1);
-  tA = now_ns() - t0;
-  // ---------------- host: spanning reads (tr.rs:111-184); repeat segments gathered from HBM when the reads live there
-  int64_t th0 = now_ns();
+  for (int64_t r = 0; r < nr; ++r) {
+    read_total = std::max<uint64_t>(read_total, in->read_off[r] + in->read_len[r]);
+    max_read_len = std::max(max_read_len, in->read_len[r]);
+  }
+  int rc;
+  const uint8_t *d_flank = nullptr, *d_reads = nullptr;
+  const uint64_t *d_piece = nullptr, *d_roff = nullptr;
+  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr;
+  void *d_ss = nullptr, *d_se = nullptr, *d_hl = nullptr, *d_hr = nullptr;
+  void *h_ss = nullptr, *h_se = nullptr, *h_hl = nullptr, *h_hr = nullptr, *h_cells = nullptr;
+  if ((rc = dev_in(c, S_FS_FLANK, in->flank_blob, (size_t)flank_total, &d_flank)) ||
+      (rc = dev_in(c, S_FS_READS, in->read_blob, (size_t)read_total, &d_reads)) ||
+      (rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
+      (rc = dev_in(c, S_FS_LIST, in->read_off, (size_t)nr, &d_roff)) ||
+      (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen)) ||
+      (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc)) ||
+      (rc = dev_get(c, S_LOCUS_4, (size_t)nr * 4, &d_ss)) || (rc = dev_get(c, S_LOCUS_5, (size_t)nr * 4, &d_se)) ||
+      (rc = dev_get(c, S_FS_HIT0, (size_t)nr, &d_hl)) || (rc = dev_get(c, S_FS_HIT1, (size_t)nr, &d_hr)) ||
+      (rc = pin_get(c, P_SPAN_S, (size_t)nr * 4, &h_ss)) || (rc = pin_get(c, P_SPAN_E, (size_t)nr * 4, &h_se)) ||
+      (rc = pin_get(c, P_HIT_L, (size_t)nr, &h_hl)) || (rc = pin_get(c, P_HIT_R, (size_t)nr, &h_hr)) ||
+      (rc = pin_get(c, P_CELLS, 8 * (size_t)MAX_CHUNKS, &h_cells)))
+    return rc;
+  trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
+  std::vector<hipEvent_t> ev((size_t)n_chunks, nullptr);
+  struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } ev_guard{ev};
+  std::memset(h_cells, 0, 8 * (size_t)MAX_CHUNKS);
+  for (int k = 0; k < n_chunks; ++k) {
+    const int64_t r0 = (int64_t)in->locus_read_begin[cl[(size_t)k]], r1 = (int64_t)in->locus_read_begin[cl[(size_t)k + 1]], n = r1 - r0;
+    TRGT_HIP_TRY(c, hipEventCreateWithFlags(&ev[(size_t)k], hipEventDisableTiming));
+    if (n > 0) {
+      if ((rc = find_spans_device(c, sp, cl[(size_t)k + 1] - cl[(size_t)k], n, d_flank, d_piece, d_reads, d_roff + r0, d_rlen + r0, d_rloc + r0,
+                                  max_read_len, (int32_t*)d_ss + r0, (int32_t*)d_se + r0, (uint8_t*)d_hl + r0, (uint8_t*)d_hr + r0)))
+        return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync((int32_t*)h_ss + r0, (int32_t*)d_ss + r0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipMemcpyAsync((int32_t*)h_se + r0, (int32_t*)d_se + r0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)h_hl + r0, (uint8_t*)d_hl + r0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)h_hr + r0, (uint8_t*)d_hr + r0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+      if (c->last_wfa_cells_dev)
+        TRGT_HIP_TRY(c, hipMemcpyAsync((uint64_t*)h_cells + k, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    TRGT_HIP_TRY(c, hipEventRecord(ev[(size_t)k], c->stream));
+  }
+
+  // ---------------- host, chunk by chunk while the GPU works ahead: spanning reads (tr.rs:111-184), repeat segments gathered
+  // from HBM when the reads live there, front half of the length genotyper
   std::vector<LocusWork> work((size_t)nl);
   const bool reads_on_device = is_device_ptr(in->read_blob);
-  // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
-  // each locus writes its selection into its own read range of `sel`
   struct K { uint32_t read, s, e; };
   std::vector<K> sel((size_t)nr);
   std::vector<uint32_t> n_sel((size_t)nl, 0);
-  parallel_for(nl, threads, [&](int64_t l, int) {
-    if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
-    K* ks = sel.data() + in->locus_read_begin[l];
-    uint32_t n = 0;
-    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
-      const int32_t s = out->span_start[r], e = out->span_end[r];
-      if (s < 0) continue;
-      if (s >= F && (int64_t)in->read_len[r] - e >= F) {
-        const K k{(uint32_t)r, (uint32_t)s, (uint32_t)e};
-        uint32_t i = n++;  // stable insertion sort by span length
-        while (i > 0 && (ks[i - 1].e - ks[i - 1].s) > (k.e - k.s)) { ks[i] = ks[i - 1]; --i; }
-        ks[i] = k;
+  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len, seg_read; std::vector<const uint8_t*> seg_ptr;
+  seg_src.reserve((size_t)nr); seg_dst.reserve((size_t)nr); seg_len.reserve((size_t)nr); seg_read.reserve((size_t)nr); seg_ptr.reserve((size_t)nr);
+  std::vector<Scratch> scratch((size_t)pool->size());
+  c->dbg_ns[7] = 0;
+  int64_t t_sel = 0, t_gather = 0, t_front = 0, t_wait = 0;
+  // stages B, host back half and C for the loci [l0, l1) (their front half is done); runs on whatever c->stream is at the call
+  std::vector<int8_t> seg_cls((size_t)nr, 0);
+  int64_t stat_hmm_jobs = 0;
+  auto finish_range = [&](int64_t l0, int64_t l1, const std::vector<size_t>& rep_begin) -> int {
+    int rc;
+    // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
+    int64_t tb0 = now_ns();
+    struct JobRef { Repair* rep; int member; };
+    std::vector<JobRef> jrefs;
+    std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
+    for (size_t t = 0; t < scratch.size(); ++t)
+      for (size_t ri = rep_begin[t]; ri < scratch[t].repairs.size(); ++ri) {
+        Repair& rep = scratch[t].repairs[ri];
+        const Seg bb = work[(size_t)rep.locus].pick[rep.allele];
+        const uint64_t bo = cblob.size();
+        cblob.insert(cblob.end(), bb.p, bb.p + bb.n);
+        for (size_t m = 0; m < rep.members.size(); ++m) {
+          const Seg& s = rep.members[m];
+          coff.push_back(coff.empty() ? 0 : coff.back() + plen.back() + tlen.back() + 1);
+          poff.push_back(bo); plen.push_back(bb.n);
+          toff.push_back(cblob.size()); tlen.push_back(s.n);
+          cblob.insert(cblob.end(), s.p, s.p + s.n);
+          jrefs.push_back({&rep, (int)m});
+        }
+      }
+    std::vector<uint32_t> cigars, clen(jrefs.size());
+    if (!jrefs.empty()) {
+      trgt_wfa_params wp;
+      trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
+      wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+      cigars.resize((size_t)(coff.back() + plen.back() + tlen.back() + 1));
+      rc = trgt_wfa_batch(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
+                          nullptr, nullptr, cigars.data(), coff.data(), clen.data(), nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      stat_cons_jobs += (int64_t)jrefs.size();
+    }
+    tB += now_ns() - tb0;
+    // ---------------- host: repair_consensus, classification, reference allele first, output assembly
+    int64_t th0 = now_ns();
+    {
+      size_t j = 0;
+      while (j < jrefs.size()) {  // jobs of one repair are contiguous
+        Repair* rep = jrefs[j].rep;
+        std::vector<std::vector<uint32_t>> cg;
+        for (size_t m = 0; m < rep->members.size(); ++m, ++j)
+          cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
+        const Seg bb = work[(size_t)rep->locus].pick[rep->allele];
+        rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
       }
     }
-    if ((int64_t)n > p->max_depth) {
-      const double step = (double)n / (double)p->max_depth;
-      double fast = 0.0;
-      for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
-      n = (uint32_t)p->max_depth;
-    }
-    n_sel[(size_t)l] = n;
-  });
-  // pass 2: flat segment arrays (LocusResult.reads order within each locus)
-  uint64_t n_seg = 0;
-  for (int64_t l = 0; l < nl; ++l) { work[(size_t)l].seg_begin = n_seg; n_seg += n_sel[(size_t)l]; work[(size_t)l].seg_end = n_seg; }
-  std::vector<uint64_t> seg_src((size_t)n_seg), seg_dst((size_t)n_seg); std::vector<uint32_t> seg_len((size_t)n_seg), seg_read((size_t)n_seg);
-  parallel_for(nl, threads, [&](int64_t l, int) {
-    const K* ks = sel.data() + in->locus_read_begin[l];
-    uint64_t s = work[(size_t)l].seg_begin;
-    for (uint32_t i = 0; i < n_sel[(size_t)l]; ++i, ++s) {
-      seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
-    }
-  });
-  { uint64_t dst = 0; for (uint64_t s = 0; s < n_seg; ++s) { seg_dst[s] = dst; dst += seg_len[s]; } }
-  stat_spanning = (int64_t)seg_src.size();
-  c->dbg_ns[4] = now_ns() - th0;
-  std::vector<uint8_t> seg_bytes;
-  const uint8_t* seg_base = nullptr;
-  if (!seg_src.empty() && reads_on_device) {
-    const uint64_t total = seg_dst.back() + seg_len.back();
-    seg_bytes.resize((size_t)total + 1);
-    void *d_src, *d_dst, *d_len, *d_out;
-    if ((rc = dev_get(c, S_LOCUS_0, seg_src.size() * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, seg_dst.size() * 8, &d_dst)) ||
-        (rc = dev_get(c, S_LOCUS_2, seg_len.size() * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)total + 1, &d_out)))
-      return rc;
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), seg_src.size() * 8, hipMemcpyHostToDevice, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), seg_dst.size() * 8, hipMemcpyHostToDevice, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, c->stream));
-    GatherArgs ga{in->read_blob, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)seg_src.size(), (uint8_t*)d_out};
-    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((seg_src.size() + 3) / 4)), dim3(256), 0, c->stream, ga);
-    TRGT_HIP_TRY(c, hipGetLastError());
-    TRGT_HIP_TRY(c, hipMemcpyAsync(seg_bytes.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    seg_base = seg_bytes.data();
-  }
-  c->dbg_ns[5] = now_ns() - th0;
-  auto seg_of = [&](uint64_t s) { return reads_on_device ? Seg{seg_base + seg_dst[s], seg_len[s]} : Seg{in->read_blob + seg_src[s], seg_len[s]}; };
-  // ---------------- host: length genotyping front half, threaded over loci (per-thread scratch, no per-locus allocation)
-  std::vector<Scratch> scratch((size_t)std::max(1, threads));
-  parallel_for(nl, threads, [&](int64_t l, int t) {
-    LocusWork& w = work[(size_t)l];
-    if (w.seg_begin == w.seg_end) return;
-    Scratch& sc = scratch[(size_t)t];
-    sc.trs.clear();
-    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(seg_of(s));
-    genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, l, t, w, sc);
-  });
-  c->dbg_ns[6] = now_ns() - th0;
-  tHost += now_ns() - th0;
-  // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
-  int64_t tb0 = now_ns();
-  struct JobRef { Repair* rep; int member; };
-  std::vector<JobRef> jrefs;
-  std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
-  for (auto& sc : scratch)
-    for (auto& rep : sc.repairs) {
-      const Seg bb = work[(size_t)rep.locus].pick[rep.allele];
-      const uint64_t bo = cblob.size();
-      cblob.insert(cblob.end(), bb.p, bb.p + bb.n);
-      for (size_t m = 0; m < rep.members.size(); ++m) {
-        const Seg& s = rep.members[m];
-        coff.push_back(coff.empty() ? 0 : coff.back() + plen.back() + tlen.back() + 1);
-        poff.push_back(bo); plen.push_back(bb.n);
-        toff.push_back(cblob.size()); tlen.push_back(s.n);
-        cblob.insert(cblob.end(), s.p, s.p + s.n);
-        jrefs.push_back({&rep, (int)m});
+    std::atomic<int> bad{0};
+    pool->parallel_for(l1 - l0, 64, [&](int64_t li, int) {
+      const int64_t l = l0 + li;
+      LocusWork& w = work[(size_t)l];
+      if (w.seg_begin == w.seg_end) return;
+      const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
+      Seg al[2];
+      for (int a = 0; a < w.n_pick; ++a) {
+        if (w.repair[a] >= 0) { const std::string& r = scratch[(size_t)w.repair_thread].repairs[(size_t)w.repair[a]].result; al[a] = Seg{(const uint8_t*)r.data(), (uint32_t)r.size()}; }
+        else al[a] = w.pick[a];
       }
+      int n_al = w.n_pick;
+      if (ploidy == 2 && n_al == 1) { al[1] = al[0]; n_al = 2; }
+      int by_hap[2] = {0, 0};
+      int tie = 1;
+      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
+        int cc = 0;
+        if (n_al == 2) {
+          const uint32_t d1 = adiff(seg_len[s], al[0].n), d2 = adiff(seg_len[s], al[1].n);
+          if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
+        }
+        seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
+      }
+      int order[2] = {0, 1};
+      const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};
+      bool flip = false;
+      if (w.n_gt != 1 && !eq_seg(al[0], ref) && eq_seg(al[1], ref)) { order[0] = 1; order[1] = 0; flip = true; }  // tr.rs:95-101
+      out->n_alleles[l] = w.n_gt;
+      for (int oi = 0; oi < w.n_gt; ++oi) {
+        const int a = order[oi];
+        if (al[a].n > out->allele_cap[l]) { bad = 1; return; }
+        std::memcpy(out->allele_blob + out->allele_off[2 * l + oi], al[a].p, al[a].n);
+        out->allele_len[2 * l + oi] = al[a].n;
+        out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
+        out->num_spanning[2 * l + oi] = by_hap[a];
+      }
+      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
+        out->classification[seg_read[s]] = flip ? 1 - seg_cls[s] : seg_cls[s];
+        out->read_rank[seg_read[s]] = (int32_t)(s - w.seg_begin);
+      }
+    });
+    if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
+    c->dbg_ns[7] += now_ns() - th0;
+    tHost += now_ns() - th0;
+    // ---------------- stage C: label_with_hmm for every allele
+    int64_t tc0 = now_ns();
+    std::vector<uint32_t> job_set, seq_len, nsp; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<double> pur;
+    std::vector<int64_t> slot;
+    for (int64_t l = l0; l < l1; ++l)
+      for (int a = 0; a < out->n_alleles[l]; ++a) {
+        job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
+        span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+      }
+    for (int64_t s = 2 * l0; s < 2 * l1; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
+    if (!job_set.empty()) {
+      nsp.resize(job_set.size()); pur.resize(job_set.size());
+      if (model_thread.joinable()) model_thread.join();
+      rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
+                          out->allele_blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(),
+                          nsp.data(), out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr);
+      if (rc) return rc;
+      for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
     }
-  std::vector<uint32_t> cigars, clen(jrefs.size());
-  if (!jrefs.empty()) {
-    trgt_wfa_params wp;
-    trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
-    wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
-    cigars.resize((size_t)(coff.back() + plen.back() + tlen.back() + 1));
-    rc = trgt_wfa_batch(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
-                        nullptr, nullptr, cigars.data(), coff.data(), clen.data(), nullptr, nullptr, nullptr);
+    tC += now_ns() - tc0;
+    stat_hmm_jobs += (int64_t)job_set.size();
+    return TRGT_OK;
+
+  };
+  for (int k = 0; k < n_chunks; ++k) {
+    const int64_t l0 = cl[(size_t)k], l1 = cl[(size_t)k + 1];
+    const int64_t r0 = (int64_t)in->locus_read_begin[l0], r1 = (int64_t)in->locus_read_begin[l1];
+    int64_t tw = now_ns();
+    TRGT_HIP_TRY(c, hipEventSynchronize(ev[(size_t)k]));
+    t_wait += now_ns() - tw;
+    int64_t th0 = now_ns();
+    std::memcpy(out->span_start + r0, (int32_t*)h_ss + r0, (size_t)(r1 - r0) * 4);
+    std::memcpy(out->span_end + r0, (int32_t*)h_se + r0, (size_t)(r1 - r0) * 4);
+    for (int64_t r = r0; r < r1; ++r) stat_flank_jobs += (((uint8_t*)h_hl)[r] != 1) + (((uint8_t*)h_hr)[r] != 1);
+    // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
+    // each locus writes its selection into its own read range of `sel`
+    pool->parallel_for(l1 - l0, 32, [&](int64_t li, int) {
+      const int64_t l = l0 + li;
+      if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+      K* ks = sel.data() + in->locus_read_begin[l];
+      uint32_t n = 0;
+      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+        const int32_t s = out->span_start[r], e = out->span_end[r];
+        if (s < 0) continue;
+        if (s >= F && (int64_t)in->read_len[r] - e >= F) {
+          const K kk{(uint32_t)r, (uint32_t)s, (uint32_t)e};
+          uint32_t i = n++;  // stable insertion sort by span length
+          while (i > 0 && (ks[i - 1].e - ks[i - 1].s) > (kk.e - kk.s)) { ks[i] = ks[i - 1]; --i; }
+          ks[i] = kk;
+        }
+      }
+      if ((int64_t)n > p->max_depth) {
+        const double step = (double)n / (double)p->max_depth;
+        double fast = 0.0;
+        for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
+        n = (uint32_t)p->max_depth;
+      }
+      n_sel[(size_t)l] = n;
+    });
+    // pass 2: flat segment arrays (LocusResult.reads order within each locus), appended to the batch-wide lists
+    const uint64_t seg0 = seg_src.size();
+    uint64_t n_seg = seg0;
+    for (int64_t l = l0; l < l1; ++l) { work[(size_t)l].seg_begin = n_seg; n_seg += n_sel[(size_t)l]; work[(size_t)l].seg_end = n_seg; }
+    seg_src.resize((size_t)n_seg); seg_dst.resize((size_t)n_seg); seg_len.resize((size_t)n_seg); seg_read.resize((size_t)n_seg); seg_ptr.resize((size_t)n_seg);
+    pool->parallel_for(l1 - l0, 64, [&](int64_t li, int) {
+      const int64_t l = l0 + li;
+      const K* ks = sel.data() + in->locus_read_begin[l];
+      uint64_t s = work[(size_t)l].seg_begin;
+      for (uint32_t i = 0; i < n_sel[(size_t)l]; ++i, ++s) {
+        seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
+      }
+    });
+    uint64_t chunk_bytes = 0;
+    for (uint64_t s = seg0; s < n_seg; ++s) { seg_dst[s] = chunk_bytes; chunk_bytes += seg_len[s]; }  // offsets inside this chunk's byte buffer
+    t_sel += now_ns() - th0;
+    int64_t tg0 = now_ns();
+    if (n_seg > seg0 && reads_on_device) {
+      const size_t ns = (size_t)(n_seg - seg0);
+      void *d_src, *d_dst, *d_len, *d_out, *h_seg;
+      if ((rc = dev_get(c, S_LOCUS_0, ns * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, ns * 8, &d_dst)) ||
+          (rc = dev_get(c, S_LOCUS_2, ns * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)chunk_bytes + 1, &d_out)) ||
+          (rc = pin_get(c, P_SEG0 + k, (size_t)chunk_bytes + 1, &h_seg)))
+        return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data() + seg0, ns * 8, hipMemcpyHostToDevice, c->stream2));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data() + seg0, ns * 8, hipMemcpyHostToDevice, c->stream2));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data() + seg0, ns * 4, hipMemcpyHostToDevice, c->stream2));
+      GatherArgs ga{d_reads, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)ns, (uint8_t*)d_out};
+      hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream2, ga);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)chunk_bytes, hipMemcpyDeviceToHost, c->stream2));
+      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
+      for (uint64_t s = seg0; s < n_seg; ++s) seg_ptr[s] = (const uint8_t*)h_seg + seg_dst[s];
+    } else {
+      for (uint64_t s = seg0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s];
+    }
+    t_gather += now_ns() - tg0;
+    // front half of the length genotyper, threaded over loci (per-thread scratch, no per-locus allocation)
+    int64_t tf0 = now_ns();
+    std::vector<size_t> rep_begin(scratch.size());
+    for (size_t t = 0; t < scratch.size(); ++t) rep_begin[t] = scratch[t].repairs.size();
+    pool->parallel_for(l1 - l0, 16, [&](int64_t li, int t) {
+      const int64_t l = l0 + li;
+      LocusWork& w = work[(size_t)l];
+      if (w.seg_begin == w.seg_end) return;
+      Scratch& sc = scratch[(size_t)t];
+      sc.trs.clear();
+      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(Seg{seg_ptr[s], seg_len[s]});
+      genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, l, t, w, sc);
+    });
+    t_front += now_ns() - tf0;
+    // stages B and C of this chunk on the second stream, next to stage A of the following chunks
+    std::swap(c->stream, c->stream2);
+    rc = finish_range(l0, l1, rep_begin);
+    std::swap(c->stream, c->stream2);
     if (rc) return rc;
-    stat_cons_jobs = (int64_t)jrefs.size();
   }
-  tB = now_ns() - tb0;
-  // ---------------- host: repair_consensus, classification, reference allele first, output assembly
-  th0 = now_ns();
+  // stage A is complete (the last event has fired): its kernel time is whatever the host did not cover
+  tA = t_wait;
+  tHost += t_sel + t_gather + t_front;
+  c->dbg_ns[4] = t_sel; c->dbg_ns[5] = t_gather; c->dbg_ns[6] = t_front;
   {
-    size_t j = 0;
-    while (j < jrefs.size()) {  // jobs of one repair are contiguous
-      Repair* rep = jrefs[j].rep;
-      std::vector<std::vector<uint32_t>> cg;
-      for (size_t m = 0; m < rep->members.size(); ++m, ++j)
-        cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
-      const Seg bb = work[(size_t)rep->locus].pick[rep->allele];
-      rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
-    }
+    unsigned long long cells = 0;
+    for (int k = 0; k < n_chunks; ++k) cells += ((uint64_t*)h_cells)[k];
+    if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells;
   }
-  std::vector<int8_t> seg_cls(seg_src.size(), 0);
-  int bad = 0;
-  parallel_for(nl, threads, [&](int64_t l, int) {
-    LocusWork& w = work[(size_t)l];
-    if (w.seg_begin == w.seg_end) return;
-    const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
-    Seg al[2];
-    for (int a = 0; a < w.n_pick; ++a) {
-      if (w.repair[a] >= 0) { const std::string& r = scratch[(size_t)w.repair_thread].repairs[(size_t)w.repair[a]].result; al[a] = Seg{(const uint8_t*)r.data(), (uint32_t)r.size()}; }
-      else al[a] = w.pick[a];
-    }
-    int n_al = w.n_pick;
-    if (ploidy == 2 && n_al == 1) { al[1] = al[0]; n_al = 2; }
-    int by_hap[2] = {0, 0};
-    int tie = 1;
-    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
-      int cc = 0;
-      if (n_al == 2) {
-        const uint32_t d1 = adiff(seg_len[s], al[0].n), d2 = adiff(seg_len[s], al[1].n);
-        if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
-      }
-      seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
-    }
-    int order[2] = {0, 1};
-    const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};
-    bool flip = false;
-    if (w.n_gt != 1 && !eq_seg(al[0], ref) && eq_seg(al[1], ref)) { order[0] = 1; order[1] = 0; flip = true; }  // tr.rs:95-101
-    out->n_alleles[l] = w.n_gt;
-    for (int oi = 0; oi < w.n_gt; ++oi) {
-      const int a = order[oi];
-      if (al[a].n > out->allele_cap[l]) { bad = 1; return; }
-      std::memcpy(out->allele_blob + out->allele_off[2 * l + oi], al[a].p, al[a].n);
-      out->allele_len[2 * l + oi] = al[a].n;
-      out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
-      out->num_spanning[2 * l + oi] = by_hap[a];
-    }
-    for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
-      out->classification[seg_read[s]] = flip ? 1 - seg_cls[s] : seg_cls[s];
-      out->read_rank[seg_read[s]] = (int32_t)(s - w.seg_begin);
-    }
-  });
-  if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
-  c->dbg_ns[7] = now_ns() - th0;
-  tHost += now_ns() - th0;
-  // ---------------- stage C: label_with_hmm for every allele
-  int64_t tc0 = now_ns();
-  std::vector<uint32_t> job_set, seq_len, nsp; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<double> pur;
-  std::vector<int64_t> slot;
-  for (int64_t l = 0; l < nl; ++l)
-    for (int a = 0; a < out->n_alleles[l]; ++a) {
-      job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
-      span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
-    }
-  for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
-  if (!job_set.empty()) {
-    nsp.resize(job_set.size()); pur.resize(job_set.size());
-    if (model_thread.joinable()) model_thread.join();
-    rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
-                        out->allele_blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(),
-                        nsp.data(), out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr);
-    if (rc) return rc;
-    for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
-  }
-  tC = now_ns() - tc0;
+  const int64_t stat_spanning = (int64_t)seg_src.size();
+
   if (out->stats) {
     int64_t* s = out->stats;
-    s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = (int64_t)job_set.size();
+    s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
     for (int i = 0; i < 7; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
-  }
-  return TRGT_OK;
-}
-
-// Public entry point.  Large batches are cut into chunks that two host threads ("lanes", each with its own stream and
-// device buffers) work through alternately, so the host glue / transfers of one chunk overlap the GPU stages of the
-// other.  Chunks touch disjoint locus / read ranges of the caller's buffers, so no synchronisation is needed.
-extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
-  if (!c) return TRGT_ERR_INVALID;
-  if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
-  const int64_t nl = in->n_loci;
-  const int64_t CHUNK = 2500;
-  const char* env = getenv("TRGT_LOCUS_LANES");
-  const int lanes = env ? atoi(env) : 1;  // measured: a persistent WFA kernel leaves no room for the other lane's kernels, so 2 lanes do not pay
-  if (nl < 2 * CHUNK || lanes < 2 || !in->locus_read_begin) return locus_batch_impl(c, p, in, out);
-  if (!c->aux) {
-    int rc = trgt_hip_create(c->device, &c->aux);
-    if (rc) return fail(c, rc, "trgt_locus_batch: cannot create the second lane: %s", trgt_hip_last_error(nullptr));
-  }
-  c->aux->timing = c->timing; c->aux->ws_limit = c->ws_limit / 2;
-  const uint64_t saved_limit = c->ws_limit;
-  c->ws_limit = saved_limit / 2;
-  const int64_t n_chunks = (nl + CHUNK - 1) / CHUNK;
-  trgt_hip_ctx* lane_ctx[2] = {c, c->aux};
-  int lane_rc[2] = {0, 0};
-  int64_t lane_stats[2][16];
-  std::memset(lane_stats, 0, sizeof lane_stats);
-  trgt_locus_params lp = *p;
-  int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-  lp.host_threads = std::max(1, std::min(threads, 32) / 2);
-  const int64_t t0 = now_ns();
-  std::mutex stage_a;
-  c->stage_a_mutex = &stage_a; c->aux->stage_a_mutex = &stage_a;
-  auto worker = [&](int lane) {
-    trgt_hip_ctx* cc = lane_ctx[lane];
-    for (int64_t ch = lane; ch < n_chunks && lane_rc[lane] == 0; ch += 2) {
-      const int64_t l0 = ch * CHUNK, l1 = std::min(nl, l0 + CHUNK), n = l1 - l0;
-      const uint64_t r0 = in->locus_read_begin[l0];
-      std::vector<uint64_t> lrb((size_t)n + 1);
-      for (int64_t i = 0; i <= n; ++i) lrb[(size_t)i] = in->locus_read_begin[l0 + i] - r0;
-      trgt_locus_batch_in si = *in;
-      si.n_loci = n;
-      si.lf_off += l0; si.lf_len += l0; si.rf_off += l0; si.rf_len += l0; si.tr_off += l0; si.tr_len += l0;
-      si.set_motif_begin += l0; si.ploidy += l0; si.locus_read_begin = lrb.data(); si.read_off += r0; si.read_len += r0;
-      trgt_locus_batch_out so = *out;
-      int64_t st[16];
-      so.span_start += r0; so.span_end += r0; so.classification += r0; so.read_rank += r0;
-      so.n_alleles += l0; so.allele_off += 2 * l0; so.allele_cap += l0; so.allele_len += 2 * l0; so.ci += 4 * l0; so.num_spanning += 2 * l0;
-      so.span_off += 2 * l0; so.n_spans += 2 * l0; so.count_off += 2 * l0; so.purity += 2 * l0;
-      so.stats = st;
-      const int rc = locus_batch_impl(cc, &lp, &si, &so);
-      if (rc) { lane_rc[lane] = rc; break; }
-      for (int i = 0; i < 8; ++i) lane_stats[lane][i] += st[i];
-    }
-  };
-  std::thread t1(worker, 1);
-  worker(0);
-  t1.join();
-  c->stage_a_mutex = nullptr; c->aux->stage_a_mutex = nullptr;
-  c->ws_limit = saved_limit;
-  if (lane_rc[1]) c->err = c->aux->err;
-  if (lane_rc[0] || lane_rc[1]) return lane_rc[0] ? lane_rc[0] : lane_rc[1];
-  // fold the second lane's kernel timers into the caller's ctx
-  resolve_timing(c->aux);
-  for (int k = 0; k < TRGT_K_COUNT; ++k) {
-    c->k_ms[k] += c->aux->k_ms[k]; c->k_launches[k] += c->aux->k_launches[k]; c->k_cells[k] += c->aux->k_cells[k];
-    c->aux->k_ms[k] = 0; c->aux->k_launches[k] = 0; c->aux->k_cells[k] = 0;
-  }
-  if (out->stats) {
-    for (int i = 0; i < 8; ++i) out->stats[i] = lane_stats[0][i] + lane_stats[1][i];
-    out->stats[8] = now_ns() - t0;
-    for (int i = 9; i < 16; ++i) out->stats[i] = 0;
   }
   return TRGT_OK;
 }

@@ -132,19 +132,18 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   wp.metric = 3; wp.mismatch = p.mism; wp.gap_open1 = p.gapo; wp.gap_ext1 = p.gape;
   wp.span = 1; wp.pattern_begin_free = 0; wp.pattern_end_free = 0; wp.text_begin_free = -1; wp.text_end_free = -1;
   wp.scope = 1; wp.memory_mode = 0; wp.heuristic = 0;
-  // The number of fallback alignments is known only on the device; read it back (4 bytes) so that the WFA grid is exact.
-  uint32_t n_wfa = 0;
+  // The number of fallback alignments is known only on the device: the kernel reads it there (n_jobs_dev), the planner sizes
+  // the workspace for the upper bound (every job falls back), and nothing here waits for the GPU -- trgt_locus_batch enqueues
+  // this function chunk after chunk.
   c->last_wfa_cells_dev = nullptr;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(&n_wfa, d_count, 4, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   WfaLaunch L;
-  L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_wfa; L.n_jobs_dev = nullptr;
+  L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
   L.pat_base = d_flank; L.txt_base = d_reads;
   L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
   L.threads = getenv("TRGT_FLANK_THREADS") ? atoi(getenv("TRGT_FLANK_THREADS")) : 256;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
-  if (n_wfa > 0 && (rc = wfa_launch(c, wp, L))) return rc;
+  if ((rc = wfa_launch(c, wp, L))) return rc;
   CombineArgs ca;
   ca.n_reads = (uint64_t)n_reads; ca.flank_len = p.flank_len;
   ca.threshold = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;  // span_locater.rs:46

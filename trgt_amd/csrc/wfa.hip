@@ -487,9 +487,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
-  if ((rc = dev_get(c, S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
-  if ((rc = dev_get(c, S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
-  if ((rc = dev_get(c, S_WFA_CELLS, 16, &d_cells))) return rc;
+  if ((rc = dev_get(c, L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
+  if ((rc = dev_get(c, L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
+  if ((rc = dev_get(c, L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 16, &d_cells))) return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
   TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
@@ -509,11 +509,23 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     const uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
     const uint64_t ring_bytes = (uint64_t)(std::max(pen.x, pen.o1 + pen.e1) + 1 + 2 * (pen.e1 + 1)) * wcap * 2;
     const uint64_t win_bytes = 4ull * (uint64_t)(mp + mt + 8);
-    if (a.lds_seq_cap + ring_bytes + win_bytes <= 96 * 1024) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds += (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
+    // (the byte copies of the two sequences are staged in the ring area, which is idle until level 0 is written)
+    if (ring_bytes + win_bytes <= 96 * 1024 && seq_need <= ring_bytes) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds = (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
   }
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
-  const int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));
+  int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));
+  if (a.fast_wcap > 0) {
+    // Persistent workgroups: launch exactly as many as can be resident (LDS- and register-bound, 4 per CU at most).  Workgroups
+    // waiting for dispatch would do no work anyway, and while they wait the dispatcher keeps kernels of other streams (the
+    // gather / HMM kernels of an earlier chunk) from starting.
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wfa_fast_kernel, threads, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
+    int64_t per_cu = occ;
+    if (const char* e = getenv("TRGT_WFA_GRID_PER_CU")) per_cu = atoi(e);
+    if (getenv("TRGT_WFA_DEBUG")) fprintf(stderr, "[wfa] fast kernel lds=%zu occupancy=%d per_cu=%lld threads=%d\n", lds, occ, (long long)per_cu, threads);
+    grid_blocks = std::min<int64_t>(grid_blocks, (int64_t)c->num_cus * per_cu);
+  }
   const dim3 grid((unsigned)grid_blocks), block((unsigned)threads);
   if (a.fast_wcap > 0) {
     // every job of this batch qualifies for the dedicated LDS-resident kernel (wfa_fast.hpp)
@@ -595,6 +607,7 @@ extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t
       (rc = o_ops.init(c, S_WFA_OPS, ops, (size_t)ops_total)) || (rc = o_olen.init(c, S_WFA_OLEN, ops_len, (size_t)n_jobs)))
     return rc;
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.n_jobs_dev = nullptr;
+  L.buffer_set = 1;  // trgt_locus_batch runs consensus alignments next to a flank-location launch (set 0) of a later chunk
   L.pat_base = d_seq; L.txt_base = d_seq;
   L.status = o_status.dev; L.score = o_score.dev; L.n_match = o_nm.dev; L.span4 = o_span.dev; L.cigar = o_cigar.dev;
   L.cigar_len = o_clen.dev; L.ops = o_ops.dev; L.ops_len = o_olen.dev;

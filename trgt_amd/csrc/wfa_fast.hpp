@@ -396,7 +396,7 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
-// acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): byte copies of both sequences | ring | windows.
+// acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring (first used to stage the sequence bytes) | windows.
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
   FastShared& fs = g_fsh;
@@ -415,9 +415,9 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   uint32_t* const rle_tmp = reinterpret_cast<uint32_t*>(wsb + a.off_rle_tmp);
   uint32_t* const rle_out = reinterpret_cast<uint32_t*>(wsb + a.off_rle_out);
   uint32_t* const run_start = reinterpret_cast<uint32_t*>(wsb + a.off_run_start);
-  uint8_t* const lds_seq = lds_dyn;
-  uint16_t* const ring = reinterpret_cast<uint16_t*>(lds_dyn + a.lds_seq_cap);
-  uint32_t* const P4 = reinterpret_cast<uint32_t*>(lds_dyn + a.lds_seq_cap + a.fast_ring_bytes);
+  uint8_t* const lds_seq = lds_dyn;  // byte copies live in the ring area: it is idle until level 0 is written
+  uint16_t* const ring = reinterpret_cast<uint16_t*>(lds_dyn);
+  uint32_t* const P4 = reinterpret_cast<uint32_t*>(lds_dyn + a.fast_ring_bytes);
   const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
   unsigned long long cells_acc = 0;
   PROF_DECL;
