@@ -88,7 +88,7 @@ enum Slot {
   S_COUNT
 };
 // pinned host buffer slots
-enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_SEG0, P_SEG_LAST = P_SEG0 + 15, P_COUNT };
+enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_SEG0, P_SEG_LAST = P_SEG0 + 15, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   if ((int)c->pool.size() < S_COUNT) c->pool.resize(S_COUNT);

@@ -537,15 +537,31 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
   int rc;
-  if ((rc = dev_in(c, S_HMM_SEQ, seq_blob, (size_t)seq_total, &d_seq))) return rc;
+  if (is_device_ptr(seq_blob)) d_seq = seq_blob;
+  else {
+    // host sequences: upload them packed (the caller's blob is usually sparse: one max-length slot per allele)
+    uint64_t tight = 0;
+    for (int64_t j = 0; j < n_jobs; ++j) tight += seq_len[j];
+    void *h_tight = nullptr, *d_tight = nullptr;
+    if ((rc = pin_get(c, P_HMM_SEQ, (size_t)tight + 16, &h_tight)) || (rc = dev_get(c, S_HMM_SEQ, (size_t)tight + 16, &d_tight))) return rc;
+    std::vector<uint64_t> toff((size_t)n_jobs);
+    uint64_t o = 0;
+    for (int64_t j = 0; j < n_jobs; ++j) { toff[(size_t)j] = o; std::memcpy((uint8_t*)h_tight + o, seq_blob + seq_off[j], seq_len[j]); o += seq_len[j]; }
+    for (auto& jd : jobs) jd.seq_off = toff[jd.job_index];
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_tight, h_tight, (size_t)tight, hipMemcpyHostToDevice, c->stream));
+    d_seq = (const uint8_t*)d_tight;
+  }
   void *d_sets = nullptr, *d_model = nullptr, *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
-  if ((rc = dev_get(c, S_HMM_DESC, sets.size() * sizeof(HmmSetDev), &d_sets))) return rc;
-  if ((rc = dev_get(c, S_HMM_MODEL, blob.size(), &d_model))) return rc;
+  if (mp->d_sets && mp->d_blob) { d_sets = const_cast<void*>(mp->d_sets); d_model = const_cast<void*>(mp->d_blob); }
+  else {
+    if ((rc = dev_get(c, S_HMM_DESC, sets.size() * sizeof(HmmSetDev), &d_sets))) return rc;
+    if ((rc = dev_get(c, S_HMM_MODEL, blob.size(), &d_model))) return rc;
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, sets.data(), sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_model, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+  }
   if ((rc = dev_get(c, S_HMM_JOBS, jobs.size() * sizeof(HmmJobDev), &d_jobs))) return rc;
   if ((rc = dev_get(c, S_HMM_BP, (size_t)bp_total, &d_bp))) return rc;
   if ((rc = dev_get(c, S_HMM_VISITS, (size_t)visit_total * 4, &d_visits))) return rc;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, sets.data(), sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_model, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   DevOut<uint16_t> o_path; DevOut<uint32_t> o_plen, o_nsp, o_cnt; DevOut<int32_t> o_spans, o_edit, o_maxd; DevOut<double> o_pur;
   // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the

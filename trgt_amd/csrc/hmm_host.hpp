@@ -20,7 +20,10 @@ struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
   uint64_t off_motifs;  // sanitised motif bytes
 };
 
-struct HmmModels { std::vector<HmmSetDev> sets; std::vector<uint8_t> blob; int rc = 0; std::string err; };
+struct HmmModels {
+  std::vector<HmmSetDev> sets; std::vector<uint8_t> blob; int rc = 0; std::string err;
+  const void* d_sets = nullptr; const void* d_blob = nullptr;  // optional device copies made ahead of time by the caller
+};
 
 int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin, HmmModels& out);
 

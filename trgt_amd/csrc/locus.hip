@@ -247,13 +247,26 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int64_t t0 = now_ns();
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_cons_jobs = 0;
-  for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
-  for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
-  if (nr == 0) return TRGT_OK;
+  auto init_outputs = [&]() {
+    for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
+    for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
+  };
+  if (nr == 0) { init_outputs(); return TRGT_OK; }
   if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   // The motif-HMM tables depend only on the catalog: build them on a host thread while the GPU locates flanks.
+  // They are uploaded from the same thread (second stream), so stage C finds them in HBM.
   HmmModels models;
-  std::thread model_thread([&]() { hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models); });
+  const hipStream_t upload_stream = c->stream2;
+  std::thread model_thread([&, upload_stream]() {
+    if (hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models)) return;
+    void *d_sets = nullptr, *d_blob = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    if (dev_get(c, S_HMM_DESC, models.sets.size() * sizeof(HmmSetDev), &d_sets) || dev_get(c, S_HMM_MODEL, models.blob.size(), &d_blob)) return;
+    if (hipMemcpyAsync(d_sets, models.sets.data(), models.sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, upload_stream) != hipSuccess ||
+        hipMemcpyAsync(d_blob, models.blob.data(), models.blob.size(), hipMemcpyHostToDevice, upload_stream) != hipSuccess ||
+        hipStreamSynchronize(upload_stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    models.d_sets = d_sets; models.d_blob = d_blob;
+  });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
 
   // ---------------- chunk plan
@@ -270,17 +283,26 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   std::vector<uint32_t> read_locus((size_t)nr);
   uint64_t flank_total = 0, read_total = 0;
   uint32_t max_read_len = 0;
-  for (int64_t l = 0; l < nl; ++l) {
-    if ((int64_t)in->lf_len[l] < F || (int64_t)in->rf_len[l] < F)
-      return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: locus %lld flank shorter than flank_len", (long long)l);
-    piece_off[2 * l] = in->lf_off[l] + in->lf_len[l] - (uint64_t)F;  // lf[lf.len()-F..]  (span_locater.rs:38)
-    piece_off[2 * l + 1] = in->rf_off[l];                            // rf[..F]           (:39)
-    flank_total = std::max<uint64_t>(flank_total, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
-    for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) read_locus[r] = (uint32_t)l;
-  }
-  for (int64_t r = 0; r < nr; ++r) {
-    read_total = std::max<uint64_t>(read_total, in->read_off[r] + in->read_len[r]);
-    max_read_len = std::max(max_read_len, in->read_len[r]);
+  {
+    struct alignas(64) Acc { uint64_t flank = 0, read = 0; uint32_t max_len = 0; };  // one cache line per worker
+    std::vector<Acc> acc((size_t)pool->size());
+    std::atomic<int64_t> short_flank{-1};
+    pool->parallel_for(nl, 256, [&](int64_t l, int t) {
+      if ((int64_t)in->lf_len[l] < F || (int64_t)in->rf_len[l] < F) { short_flank = l; return; }
+      piece_off[2 * l] = in->lf_off[l] + in->lf_len[l] - (uint64_t)F;  // lf[lf.len()-F..]  (span_locater.rs:38)
+      piece_off[2 * l + 1] = in->rf_off[l];                            // rf[..F]           (:39)
+      uint64_t rt = 0; uint32_t ml = 0;
+      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+        read_locus[r] = (uint32_t)l;
+        rt = std::max<uint64_t>(rt, in->read_off[r] + in->read_len[r]);
+        ml = std::max(ml, in->read_len[r]);
+      }
+      Acc& a = acc[(size_t)t];
+      a.flank = std::max<uint64_t>(a.flank, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
+      a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml);
+    });
+    if (short_flank >= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: locus %lld flank shorter than flank_len", (long long)short_flank.load());
+    for (const Acc& a : acc) { flank_total = std::max(flank_total, a.flank); read_total = std::max(read_total, a.read); max_read_len = std::max(max_read_len, a.max_len); }
   }
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
@@ -320,6 +342,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
     TRGT_HIP_TRY(c, hipEventRecord(ev[(size_t)k], c->stream));
   }
+  init_outputs();  // host-only work: done while the GPU is already busy
 
   // ---------------- host, chunk by chunk while the GPU works ahead: spanning reads (tr.rs:111-184), repeat segments gathered
   // from HBM when the reads live there, front half of the length genotyper
