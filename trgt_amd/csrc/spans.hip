@@ -8,9 +8,10 @@
 // repeat span (:52-66).
 //
 // Three launches on the ctx stream, no host round trip in between:
-//   1. flank_scan_kernel   one wavefront per (read, side): 64 candidate starts per round, 4-byte
-//                          filter then full verify, ballot -> leftmost hit.  Misses are appended
-//                          to a device-side job list (atomic counter).
+//   1. flank_scan_wide_kernel  one wavefront per read, both pieces at once: 1024 read bytes per round, 16 candidate
+//                          windows per lane from one 20-byte load, 4-byte filter, cooperative verify in increasing
+//                          position -> leftmost hit.  Misses are appended to a device-side job list (atomic counter).
+//                          (flank_scan_kernel, one wavefront per (read, side), remains for flank_len < 4.)
 //   2. wfa_kernel          (wfa.hip) persistent workgroups drain that list.
 //   3. span_combine_kernel per read: threshold test and (lf.end, rf.start) combination.
 #include <algorithm>
@@ -78,6 +79,90 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
   }
 }
 
+// One wavefront per READ, both flank pieces at once (flank_len >= 4).  A round covers 1024 read bytes: every lane loads 20
+// consecutive bytes (16 + 4 of overlap), forms its 16 candidate 4-byte windows with byte-align shifts and compares each with
+// the heads of the two pieces; candidates are then verified in increasing position, cooperatively (lane i compares dword i of
+// the piece), so the first full match is the leftmost occurrence, exactly windows().position() (span_locater.rs:10-12).
+// A workgroup walks SCAN_READS_PER_WG reads (one per wave at a time) and collects its fallback jobs in LDS; one global atomic
+// per workgroup reserves their slots in the job list (a per-job atomic on a single counter was most of this kernel's time).
+constexpr int SCAN_READS_PER_WG = 64;
+__global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) {
+  __shared__ JobDev l_jobs[2 * SCAN_READS_PER_WG];
+  __shared__ uint32_t l_n, l_base;
+  if (threadIdx.x == 0) l_n = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint64_t n_reads = a.n_jobs >> 1;
+  const uint64_t r_begin = (uint64_t)blockIdx.x * SCAN_READS_PER_WG, r_end = r_begin + SCAN_READS_PER_WG < n_reads ? r_begin + SCAN_READS_PER_WG : n_reads;
+  for (uint64_t r = r_begin + (threadIdx.x >> 6); r < r_end; r += 4) {
+  const int F = a.flank_len, n = (int)a.read_len[r];
+  const uint64_t po0 = a.piece_off[2 * (uint64_t)a.read_locus[r]], po1 = a.piece_off[2 * (uint64_t)a.read_locus[r] + 1];
+  const uint8_t* __restrict__ piece[2] = {a.flank_blob + po0, a.flank_blob + po1};
+  const uint8_t* __restrict__ read = a.read_blob + a.read_off[r];
+  int found[2] = {-1, -1};
+  if (n >= F) {
+    const int last = n - F;  // last candidate start
+    const uint32_t head[2] = {load_u32(piece[0]), load_u32(piece[1])};
+    const int nd = F >> 2;   // full dwords of a piece
+    for (int base = 0; base <= last && (found[0] < 0 || found[1] < 0); base += 1024) {
+      const int off = base + 16 * lane;
+      uint32_t w[5] = {0, 0, 0, 0, 0};
+      if (off + 20 <= n) {
+        uint4 q;
+        __builtin_memcpy(&q, read + off, 16);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; w[4] = load_u32(read + off + 16);
+      } else if (off < n) {
+        for (int b = 0; b < 20 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
+      }
+      uint32_t m[2] = {0, 0};  // bit s: candidate start off + s matches the head of piece 0 / 1
+#pragma unroll
+      for (int s16 = 0; s16 < 16; ++s16) {
+        const uint32_t win = (s16 & 3) == 0 ? w[s16 >> 2] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 1], w[s16 >> 2], s16 & 3);
+        const bool valid = off + s16 <= last;
+        m[0] |= (uint32_t)(valid && win == head[0]) << s16;
+        m[1] |= (uint32_t)(valid && win == head[1]) << s16;
+      }
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (found[side] >= 0) continue;
+        uint32_t mm = m[side];
+        for (;;) {
+          const unsigned long long lanes = __ballot(mm != 0u);
+          if (!lanes) break;
+          const int lq = __ffsll((long long)lanes) - 1;
+          const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)mm, lq);
+          const int sq = __ffs((int)mq) - 1;
+          const int p = base + 16 * lq + sq;
+          bool ok = true;  // lane i verifies dwords i, i + 64, ... and the last lane the tail bytes
+          for (int i = lane; i < nd; i += 64) ok = ok && load_u32(read + p + 4 * i) == load_u32(piece[side] + 4 * i);
+          if (lane == 63)
+            for (int i = nd * 4; i < F; ++i) ok = ok && read[p + i] == piece[side][i];
+          if (__ballot(!ok) == 0ull) { found[side] = p; break; }
+          if (lane == lq) mm &= mm - 1u;  // drop this candidate
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    for (int side = 0; side < 2; ++side) {
+      const uint64_t j = 2 * r + side;
+      a.pos[j] = found[side];
+      if (found[side] < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
+        const uint32_t slot = atomicAdd(&l_n, 1u);
+        JobDev jd;
+        jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
+        jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
+        l_jobs[slot] = jd;
+      }
+    }
+  }
+  }  // reads of this workgroup
+  __syncthreads();
+  if (threadIdx.x == 0 && l_n) l_base = atomicAdd(a.wfa_count, l_n);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < l_n; i += blockDim.x) a.wfa_jobs[l_base + i] = l_jobs[i];
+}
+
 struct CombineArgs {
   uint64_t n_reads; int32_t flank_len; double threshold;
   const int32_t* pos; const int32_t* n_match; const uint32_t* span4;
@@ -123,7 +208,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   sa.wfa_jobs = (JobDev*)d_wjobs; sa.wfa_count = (uint32_t*)d_count;
   {
     KTimer t(c, TRGT_K_FLANK_SCAN);
-    hipLaunchKernelGGL(flank_scan_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, sa);
+    if (p.flank_len >= 4) hipLaunchKernelGGL(flank_scan_wide_kernel, dim3((unsigned)((n_reads + SCAN_READS_PER_WG - 1) / SCAN_READS_PER_WG)), dim3(256), 0, c->stream, sa);
+    else hipLaunchKernelGGL(flank_scan_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, sa);
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(0);
   }
