@@ -59,6 +59,21 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   return r.u;
 }
 
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  union U { uint32_t u; us2 v; } x, y, r;
+  x.u = a; y.u = b; r.v = __builtin_elementwise_max(x.v, y.v);
+  return r.u;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  union U { uint32_t u; us2 v; } x, y, r;
+  x.u = a; y.u = b; r.v = x.v + y.v;
+  return r.u;
+}
+// (x + (x != 0)) on both halves: the "+1 unless NULL" of the encoded domain
+__device__ __forceinline__ uint32_t pk_inc_nz(uint32_t x) { return pk_add_u16(x, pk_min_u16(x, 0x00010001u)); }
+
 // v_ffbl_b32 returns -1 for a zero input, which is exactly what the extension wants ("no mismatch in this window" -> a byte
 // index >= 4 after the shift); __builtin_ctz would be undefined there and __ffs costs a compare + select.
 __device__ __forceinline__ uint32_t ffbl_raw(uint32_t v) {
@@ -225,10 +240,13 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     const int lo = min(min(pd_lo(m_mis), pd_lo(m_o) - 1), min(pd_lo(ie) + 1, pd_lo(de) - 1));
     const int hi = max(max(pd_hi(m_mis), pd_hi(m_o) + 1), max(pd_hi(ie) + 1, pd_hi(de) - 1));
     const uint32_t w = (uint32_t)max(0, hi - lo + 1);
-    if (s >= n_slots || 3u * w > cap - bump) { status = ST_OOM; break; }  // bump <= cap always
-    const uint32_t bM = bump;
-    bump += 3 * w; cells += 3ull * w;
-    lo_c = (uint32_t)lo; w_c = w; base_c = bM;
+    // history placement: component stride and (base - lo) are kept even, so that the pair of diagonals a lane owns in the packed
+    // strips below is one aligned dword in LDS and in HBM alike
+    const uint32_t wp = w + (w & 1u);
+    if (s >= n_slots || 3u * wp + 1u > cap - bump) { status = ST_OOM; break; }  // bump <= cap always
+    const uint32_t bM = bump + ((bump ^ (uint32_t)lo) & 1u);
+    bump = bM + 3 * wp; cells += 3ull * w;
+    lo_c = (uint32_t)lo; w_c = wp; base_c = bM;
     const int oMo = oM - OEW < 0 ? oM - OEW + RMW : oM - OEW, oMm = oM - XW < 0 ? oM - XW + RMW : oM - XW;  // oe, x < RM
     const int oIe = oI - EW < 0 ? oI - EW + RIW : oI - EW;
     const uint16_t* const pMo = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Mr) + oMo);
@@ -242,59 +260,112 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     const int lo_ie = pd_lo(ie), hi_ie = pd_hi(ie), lo_de = pd_lo(de), hi_de = pd_hi(de);
     const unsigned n_mo = (unsigned)max(0, hi_mo - lo_mo + 1), n_mm = (unsigned)max(0, hi_mm - lo_mm + 1);
     const unsigned n_ie = (unsigned)max(0, hi_ie - lo_ie + 1), n_de = (unsigned)max(0, hi_de - lo_de + 1);
-    const uint32_t soM = 2u * (uint32_t)((int)bM - lo + HIST_BIAS), soI = soM + 2u * w, soD = soI + 2u * w;  // history: scalar byte offsets
+    const uint32_t soM = 2u * (uint32_t)((int)bM - lo + HIST_BIAS), soI = soM + 2u * wp, soD = soI + 2u * wp;  // history: scalar byte offsets
     FastTerm& tn = fs.fterm[s3];
-    // first / last in-bounds diagonal of M, I, D seen by this wave (biased; "last" kept complemented so that one packed
-    // unsigned min folds a record): scalar registers, updated from ballots
-    // (the first and the last non-empty ballot of each component plus their strip origins; decoded after the loop)
-    unsigned long long fmM = 0, fmI = 0, fmD = 0, lmM = 0, lmI = 0, lmD = 0;
-    int fkM = 0, fkI = 0, fkD = 0, lkM = 0, lkI = 0, lkD = 0;
-    // strips whose 64 diagonals (and their k-1 / k+1 neighbours) lie inside all four source ranges need no masks
+    // first / last in-bounds diagonal of M, I, D seen by this wave (biased), scalar registers updated from ballots
+    int fM = 0xFFFF, fI = 0xFFFF, fD = 0xFFFF, lM = 0, lI = 0, lD = 0;
+    auto note = [](unsigned long long m, int kbase, int& f, int& l) {  // ballot over 64 consecutive diagonals
+      if (m) { f = min(f, kbase + (int)__builtin_ctzll(m)); l = max(l, kbase + 63 - (int)__builtin_clzll(m)); }
+    };
+    auto note2 = [](unsigned long long mA, unsigned long long mB, int kbase, int& f, int& l) {  // even / odd diagonals of a 128-wide strip
+      if ((mA & mB) == ~0ull) { f = min(f, kbase); l = max(l, kbase + 127); return; }
+      if (mA) { f = min(f, kbase + 2 * (int)__builtin_ctzll(mA)); l = max(l, kbase + 2 * (63 - (int)__builtin_clzll(mA))); }
+      if (mB) { f = min(f, kbase + 1 + 2 * (int)__builtin_ctzll(mB)); l = max(l, kbase + 1 + 2 * (63 - (int)__builtin_clzll(mB))); }
+    };
+    // strips whose diagonals (and their k-1 / k+1 neighbours) lie inside all four source ranges need no masks
     const int in_lo = max(max(lo_mo + 1, lo_ie + 1), max(lo_de - 1, lo_mm));
     const int in_hi = min(min(hi_mo - 1, hi_ie + 1), min(hi_de - 1, hi_mm));
     LV_MARK(1);
-    // wave w takes strips nW-1-w, 2nW-1-w, ...: the ragged last strip then falls on the last wave, not on wave 0, which
-    // also carries thread 0's publishing work
-    for (int kb0 = lo + (nW - 1 - wave) * 64; kb0 <= hi; kb0 += nT) {
-      const int kb = kb0 + lane;
-      bool okM = false, okI = false, okD = false;
-      auto body = [&](auto masked) {
-        unsigned a = pMo[kb - 1], b = pIe[kb - 1], c = pMo[kb + 1], d = pDe[kb + 1], m = pMm[kb];
-        if constexpr (decltype(masked)::value) {
-          a = (unsigned)(kb - 1 - lo_mo) < n_mo ? a : 0u;
-          b = (unsigned)(kb - 1 - lo_ie) < n_ie ? b : 0u;
-          c = (unsigned)(kb + 1 - lo_mo) < n_mo ? c : 0u;
-          d = (unsigned)(kb + 1 - lo_de) < n_de ? d : 0u;
-          m = (unsigned)(kb - lo_mm) < n_mm ? m : 0u;
+    // One diagonal per lane, every source masked by its range: the strips at the two ends of a wavefront.
+    // Encoded domain (enc = offset + 1, 0 = NULL): ins = max(Mo[k-1], Ie[k-1]) + 1, del = max(Mo[k+1], De[k+1]), mis = Mm[k] + 1.
+    auto edge = [&](int kb, bool& okM, bool& okI, bool& okD) {
+      unsigned a = pMo[kb - 1], b = pIe[kb - 1], c = pMo[kb + 1], d = pDe[kb + 1], m = pMm[kb];
+      a = (unsigned)(kb - 1 - lo_mo) < n_mo ? a : 0u;
+      b = (unsigned)(kb - 1 - lo_ie) < n_ie ? b : 0u;
+      c = (unsigned)(kb + 1 - lo_mo) < n_mo ? c : 0u;
+      d = (unsigned)(kb + 1 - lo_de) < n_de ? d : 0u;
+      m = (unsigned)(kb - lo_mm) < n_mm ? m : 0u;
+      const unsigned mi = max(a, b);
+      const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
+      unsigned mx = max(del, max(mis, ins));
+      const int k = kb - koff;
+      int32_t off = (int32_t)mx - 1;
+      okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+      if (okM) { off = extend(k, off, tn); mx = (unsigned)off + 1u; } else mx = 0u;
+      qI[kb] = (uint16_t)ins; qD[kb] = (uint16_t)del; qM[kb] = (uint16_t)mx;
+      const uint32_t kb2 = 2u * (uint32_t)kb;
+      hist_store(hrs, kb2, soI, ins); hist_store(hrs, kb2, soD, del); hist_store(hrs, kb2, soM, mx);  // history: written once
+      okI = (ins - 1u) <= (uint32_t)tlen && (ins - 1u - (uint32_t)k) <= (uint32_t)plen;
+      okD = (del - 1u) <= (uint32_t)tlen && (del - 1u - (uint32_t)k) <= (uint32_t)plen;
+    };
+    // wave w takes the 128-diagonal strips nW-1-w, 2nW-1-w, ...: the ragged last strip then falls on the last wave, not on wave 0,
+    // which also carries thread 0's publishing work.  Strips start on even diagonals.
+    for (int kb0 = (lo & ~1) + (nW - 1 - wave) * 128; kb0 <= hi; kb0 += 2 * nT) {
+      if (kb0 >= in_lo && kb0 + 127 <= in_hi) {
+        // ---- interior strip: a lane owns the diagonals kbA = kb0 + 2*lane and kbA + 1; recurrences on packed 16-bit pairs,
+        //      the two extension chains are independent (their LDS round trips overlap)
+        const int kbA = kb0 + 2 * lane;
+        const uint32_t* const dMo = reinterpret_cast<const uint32_t*>(pMo + kbA);
+        const uint32_t mo0 = dMo[-1], mo1 = dMo[0], mo2 = dMo[1];   // Mo[kbA-2 .. kbA+3]
+        const uint32_t* const dIe = reinterpret_cast<const uint32_t*>(pIe + kbA);
+        const uint32_t ie0 = dIe[-1], ie1 = dIe[0];                 // Ie[kbA-2 .. kbA+1]
+        const uint32_t* const dDe = reinterpret_cast<const uint32_t*>(pDe + kbA);
+        const uint32_t de1 = dDe[0], de2 = dDe[1];                  // De[kbA .. kbA+3]
+        const uint32_t mm1 = *reinterpret_cast<const uint32_t*>(pMm + kbA);  // Mm[kbA], Mm[kbA+1]
+        const uint32_t insS = pk_max_u16(__builtin_amdgcn_alignbit(mo1, mo0, 16), __builtin_amdgcn_alignbit(ie1, ie0, 16));  // sources at k-1
+        const uint32_t del = pk_max_u16(__builtin_amdgcn_alignbit(mo2, mo1, 16), __builtin_amdgcn_alignbit(de2, de1, 16));   // sources at k+1
+        const uint32_t ins = pk_inc_nz(insS), mis = pk_inc_nz(mm1);
+        const uint32_t mxp = pk_max_u16(del, pk_max_u16(mis, ins));
+        const int kA = kbA - koff, kB = kA + 1;
+        int32_t offA = (int32_t)(mxp & 0xFFFFu) - 1, offB = (int32_t)(mxp >> 16) - 1;
+        const bool okMA = (uint32_t)offA <= (uint32_t)tlen && (uint32_t)(offA - kA) <= (uint32_t)plen;
+        const bool okMB = (uint32_t)offB <= (uint32_t)tlen && (uint32_t)(offB - kB) <= (uint32_t)plen;
+        // first window of both chains (cells that are not in bounds read window 0 and discard it)
+        int vA = okMA ? offA - kA : 0, hA = okMA ? offA : 0, vB = okMB ? offB - kB : 0, hB = okMB ? offB : 0;
+        const uint32_t xA = P4[vA] ^ T4[hA], xB = P4[vB] ^ T4[hB];
+        uint32_t nA = min(min(ffbl_raw(xA) >> 3, 4u), (uint32_t)min(plen - vA, tlen - hA));
+        uint32_t nB = min(min(ffbl_raw(xB) >> 3, 4u), (uint32_t)min(plen - vB, tlen - hB));
+        vA += (int)nA; hA += (int)nA; vB += (int)nB; hB += (int)nB;
+        bool cA = okMA && nA == 4u, cB = okMB && nB == 4u;
+        while (cA || cB) {  // rare: a run of 4+ matches
+          if (cA) { const uint32_t xw = P4[vA] ^ T4[hA]; nA = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - vA, tlen - hA)); vA += (int)nA; hA += (int)nA; cA = nA == 4u; }
+          if (cB) { const uint32_t xw = P4[vB] ^ T4[hB]; nB = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - vB, tlen - hB)); vB += (int)nB; hB += (int)nB; cB = nB == 4u; }
         }
-        // encoded domain (enc = offset + 1, 0 = NULL): ins = max(Mo[k-1], Ie[k-1]) + 1, del = max(Mo[k+1], De[k+1]), mis = Mm[k] + 1
-        const unsigned mi = max(a, b);
-        const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
-        unsigned mx = max(del, max(mis, ins));
-        const int k = kb - koff;
-        int32_t off = (int32_t)mx - 1;
-        okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
-        if (okM) { off = extend(k, off, tn); mx = (unsigned)off + 1u; } else mx = 0u;
-        qI[kb] = (uint16_t)ins; qD[kb] = (uint16_t)del; qM[kb] = (uint16_t)mx;
-        const uint32_t kb2 = 2u * (uint32_t)kb;
-        hist_store(hrs, kb2, soI, ins); hist_store(hrs, kb2, soD, del); hist_store(hrs, kb2, soM, mx);  // history: written once
-        okI = (ins - 1u) <= (uint32_t)tlen && (ins - 1u - (uint32_t)k) <= (uint32_t)plen;
-        okD = (del - 1u) <= (uint32_t)tlen && (del - 1u - (uint32_t)k) <= (uint32_t)plen;
-      };
-      if (kb0 >= in_lo && kb0 + 63 <= in_hi) { body(std::false_type{}); }  // kb0 + 63 <= in_hi <= hi: all 64 lanes are live
-      else if (kb <= hi) { body(std::true_type{}); }
-      // wavefront_compute_trim_ends bookkeeping on the scalar unit: kb0 only grows, so the first non-empty ballot is kept and
-      // the last one overwritten
-      const unsigned long long mM = __ballot(okM), mI = __ballot(okI), mD = __ballot(okD);
-      fkM = fmM ? fkM : kb0; fmM = fmM ? fmM : mM; lkM = mM ? kb0 : lkM; lmM = mM ? mM : lmM;
-      fkI = fmI ? fkI : kb0; fmI = fmI ? fmI : mI; lkI = mI ? kb0 : lkI; lmI = mI ? mI : lmI;
-      fkD = fmD ? fkD : kb0; fmD = fmD ? fmD : mD; lkD = mD ? kb0 : lkD; lmD = mD ? mD : lmD;
+        if (span == 1) {  // wavefront_termination_endsfree
+          if (okMA && ((hA >= tlen && plen - vA <= pef) || (vA >= plen && tlen - hA <= tef)))
+            atomicMin(&tn.term_key, ((unsigned long long)(unsigned)(kA + KBIAS) << 32) | (unsigned)hA);
+          if (okMB && ((hB >= tlen && plen - vB <= pef) || (vB >= plen && tlen - hB <= tef)))
+            atomicMin(&tn.term_key, ((unsigned long long)(unsigned)(kB + KBIAS) << 32) | (unsigned)hB);
+        } else {
+          if (okMA && kbA == ak_b) tn.end_val = hA;
+          if (okMB && kbA + 1 == ak_b) tn.end_val = hB;
+        }
+        const uint32_t mq = (okMA ? (uint32_t)hA + 1u : 0u) | ((okMB ? (uint32_t)hB + 1u : 0u) << 16);
+        *reinterpret_cast<uint32_t*>(qI + kbA) = ins; *reinterpret_cast<uint32_t*>(qD + kbA) = del; *reinterpret_cast<uint32_t*>(qM + kbA) = mq;
+        const uint32_t kb2 = 2u * (uint32_t)kbA;
+        __builtin_amdgcn_raw_buffer_store_b32((int)ins, hrs, (int)kb2, (int)soI, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((int)del, hrs, (int)kb2, (int)soD, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((int)mq, hrs, (int)kb2, (int)soM, 0);
+        const uint32_t iA = (ins & 0xFFFFu) - 1u, iB = (ins >> 16) - 1u, dA = (del & 0xFFFFu) - 1u, dB = (del >> 16) - 1u;
+        const bool okIA = iA <= (uint32_t)tlen && (iA - (uint32_t)kA) <= (uint32_t)plen, okIB = iB <= (uint32_t)tlen && (iB - (uint32_t)kB) <= (uint32_t)plen;
+        const bool okDA = dA <= (uint32_t)tlen && (dA - (uint32_t)kA) <= (uint32_t)plen, okDB = dB <= (uint32_t)tlen && (dB - (uint32_t)kB) <= (uint32_t)plen;
+        note2(__ballot(okMA), __ballot(okMB), kb0, fM, lM);
+        note2(__ballot(okIA), __ballot(okIB), kb0, fI, lI);
+        note2(__ballot(okDA), __ballot(okDB), kb0, fD, lD);
+      } else {
+        // ---- edge strip: two passes of 64 consecutive diagonals, one per lane, every source masked
+        for (int half = 0; half < 2; ++half) {
+          const int kbs = kb0 + 64 * half, kb = kbs + lane;
+          if (kbs > hi) break;
+          bool okM = false, okI = false, okD = false;
+          if (kb >= lo && kb <= hi) edge(kb, okM, okI, okD);
+          note(__ballot(okM), kbs, fM, lM); note(__ballot(okI), kbs, fI, lI); note(__ballot(okD), kbs, fD, lD);
+        }
+      }
     }
-    const uint32_t fM = fmM ? (uint32_t)(fkM + __builtin_ctzll(fmM)) : 0xFFFFu, nlM = lmM ? 0xFFFFu - (uint32_t)(lkM + 63 - __builtin_clzll(lmM)) : 0xFFFFu;
-    const uint32_t fI = fmI ? (uint32_t)(fkI + __builtin_ctzll(fmI)) : 0xFFFFu, nlI = lmI ? 0xFFFFu - (uint32_t)(lkI + 63 - __builtin_clzll(lmI)) : 0xFFFFu;
-    const uint32_t fD = fmD ? (uint32_t)(fkD + __builtin_ctzll(fmD)) : 0xFFFFu, nlD = lmD ? 0xFFFFu - (uint32_t)(lkD + 63 - __builtin_clzll(lmD)) : 0xFFFFu;
+    const uint32_t nlM = 0xFFFFu - (uint32_t)lM, nlI = 0xFFFFu - (uint32_t)lI, nlD = 0xFFFFu - (uint32_t)lD;  // "last" complemented: one packed min folds a record
     LV_MARK(2);
-    if (lane == 0) fs.wred[s & 1][wave] = make_uint4(fM | (nlM << 16), fI | (nlI << 16), fD | (nlD << 16), 0u);
+    if (lane == 0) fs.wred[s & 1][wave] = make_uint4((uint32_t)fM | (nlM << 16), (uint32_t)fI | (nlI << 16), (uint32_t)fD | (nlD << 16), 0u);
     // keeps the join of this divergent branch out of the loop's latch block: the uniformity analysis taints every phi of a
     // block where divergent paths join, and the latch block holds the phis of the whole (uniform) per-level state
     asm volatile("" ::: "memory");
