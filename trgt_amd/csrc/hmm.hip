@@ -168,7 +168,7 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
 }
 
 // --------------------------------------------------------------- kernel
-constexpr int HMM_STAGE_BYTES = 8192;  // LDS staging window for back-pointer columns during traceback
+constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
   // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
@@ -177,13 +177,18 @@ __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, 
   return b == 'A' ? 1 : b == 'T' ? 2 : b == 'C' ? 3 : b == 'G' ? 4 : ((i - 1) & 3) + 1;
 }
 
+// STAGE: the allele, the motif bytes, the motif-visit list and the motif counts live in LDS (alleles up to HMM_STAGE_QLEN bases).
+// The fill reads one base per column and the traceback / decode of thread 0 is a chain of dependent loads: served from HBM each
+// of them costs a memory round trip, which was most of this kernel's time.
+constexpr int HMM_STAGE_QLEN = 2048;
+template <bool STAGE>
 __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets,
                                    const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
                                    uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws,
                                    uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
                                    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
                                    uint32_t* __restrict__ counts, double* __restrict__ purity,
-                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out) {
+                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, uint32_t stage_qcap) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const HmmJobDev job = jobs[blockIdx.x];
@@ -222,6 +227,19 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
   const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
   const uint8_t* g_motifs = model + set.off_motifs;
+  // staged copies (STAGE): sequence | motif bytes | visits | counts, behind the back-pointer staging window
+  uint8_t* l_seq = l_stage + (HMM_STAGE_BYTES > Spad ? HMM_STAGE_BYTES : Spad);
+  uint8_t* l_mot = l_seq + ((stage_qcap + 2 + 15) & ~15u);
+  const int mot_bytes = (S - 7 - n_motifs) / 3;
+  uint32_t* l_vis = reinterpret_cast<uint32_t*>(l_mot + ((mot_bytes + 15) & ~15));
+  uint32_t* l_cnt = l_vis + 3 * (stage_qcap + 3);
+  if (STAGE) {
+    const uint8_t* gs = seq_blob + job.seq_off;
+    for (int i = tid; i < qlen; i += nthr) l_seq[i] = gs[i];
+    for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
+    for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
+  }
+  const uint8_t* const motif_bytes = STAGE ? l_mot : g_motifs;
   for (int i = tid; i < 4 * S; i += nthr) l_inst[i] = g_inst[i];
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; }
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
@@ -235,7 +253,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
   const double em0 = g_em[0 * S + st], em1 = g_em[1 * S + st], em2 = g_em[2 * S + st], em3 = g_em[3 * S + st], em4 = g_em[4 * S + st];
   const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
-  const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
+  const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
   __syncthreads();
 
@@ -290,7 +308,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
   const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
-  uint32_t* visits = visit_ws + job.visit_off;
+  uint32_t* visits = STAGE ? l_vis : visit_ws + job.visit_off;
   const int pcap = (int)job.path_cap;
   while (true) {
     if (tb_done) break;
@@ -324,7 +342,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
             const int off = state - bstart - 1;
             const int kind = off / mlen;
             if (kind == 0) {  // match state: Match iff query base == motif base or motif base is N (events.rs:66-73)
-              const int expected = g_motifs[l_blocks[3 * nb + blk] + off];
+              const int expected = motif_bytes[l_blocks[3 * nb + blk] + off];
               const int base = "#ATCG"[hmm_code(seq, idx, L)];
               ++ref;
               if (!(base == expected || expected == 'N')) ++edit;
@@ -373,7 +391,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (blk != nb - 1 && mlen <= 6) {  // only STR motif copies can be removed (operations.rs:45-57)
         if (cnt < mlen) keep = false;
         else {
-          const uint8_t* mot = g_motifs + l_blocks[3 * nb + blk];
+          const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
           for (int j = 0; j < mlen; ++j) {
             const int obs = "#ATCG"[hmm_code(seq, b0 + j + 1, L)];
             if (mot[j] != 'N' && obs != mot[j]) keep = false;
@@ -384,13 +402,17 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       cum = end;
       const int motif = keep ? blk : nb - 1;
       if (motif < n_motifs) {
-        counts[job.count_off + motif] += 1;
+        if (STAGE) l_cnt[motif] += 1; else counts[job.count_off + motif] += 1;
         if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
         else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
         last_end = end;
       }
     }
     n_spans[job.job_index] = (uint32_t)ns;
+  }
+  if (STAGE) {
+    __syncthreads();
+    for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   }
 }
 
@@ -405,10 +427,11 @@ __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const 
   for (uint32_t i = 0; i < 3 * n_spans[j]; ++i) dst[i] = src[i];
 }
 
-static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
+static size_t hmm_lds_bytes(uint32_t S, uint32_t nb, uint32_t stage_qcap) {
   size_t o = 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
+  if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * ((size_t)stage_qcap + 3) + 4 * (size_t)nb;
   return o + 64;
 }
 
@@ -530,9 +553,8 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
     cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
   }
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
-  std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) {
-    return (sets[a.set].S + 63) / 64 < (sets[b.set].S + 63) / 64;
-  });
+  auto job_class = [&](const HmmJobDev& j) { return 2u * ((sets[j.set].S + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
+  std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
   c->dbg_ns[1] = wall_ns() - t_hmm0;
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
@@ -591,21 +613,30 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   // ---- one launch per workgroup-size class
   size_t i = 0;
   while (i < jobs.size()) {
-    const uint32_t cls = (sets[jobs[i].set].S + 63) / 64;
+    const uint32_t jc = job_class(jobs[i]), cls = jc >> 1;
+    const bool stage = (jc & 1u) == 0;
     size_t e = i;
-    uint32_t maxS = 0, maxnb = 0;
-    while (e < jobs.size() && (sets[jobs[e].set].S + 63) / 64 == cls) {
-      maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); ++e;
+    uint32_t maxS = 0, maxnb = 0, maxq = 0;
+    while (e < jobs.size() && job_class(jobs[e]) == jc) {
+      maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); maxq = std::max(maxq, jobs[e].seq_len); ++e;
     }
-    const size_t lds = hmm_lds_bytes(maxS, maxnb);
+    const uint32_t qcap = stage ? maxq : 0;
+    const size_t lds = hmm_lds_bytes(maxS, maxnb, qcap);
     if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
     if (lds > 64 * 1024)
-      TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      TRGT_HIP_TRY(c, hipFuncSetAttribute(stage ? (const void*)hmm_viterbi_kernel<true> : (const void*)hmm_viterbi_kernel<false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTimer t(c, TRGT_K_HMM);
-    hipLaunchKernelGGL(hmm_viterbi_kernel, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
-                       (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
-                       (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
-                       o_pur.dev, o_edit.dev, o_maxd.dev);
+    if (stage)
+      hipLaunchKernelGGL(hmm_viterbi_kernel<true>, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
+                         (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
+                         (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
+                         o_pur.dev, o_edit.dev, o_maxd.dev, qcap);
+    else
+      hipLaunchKernelGGL(hmm_viterbi_kernel<false>, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
+                         (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
+                         (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
+                         o_pur.dev, o_edit.dev, o_maxd.dev, 0u);
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(i == 0 ? cells : 0);
     i = e;
