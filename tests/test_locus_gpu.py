@@ -128,3 +128,27 @@ def test_reference_example_locus_matches_tutorial_vcf(oracle, mods):
             assert f[k] == want[k], k
     b = locus.pack([L])
     _compare(oracle, locus, b, locus.run_batch(b), locus.Params(), range(1))
+
+
+def test_flank_scan_shapes(oracle, mods):
+    # the scan kernel walks a read in rounds of 1024 bytes, 16 candidate windows per lane: reads around the round size, flanks at
+    # the very ends, repeated flank heads (many false 4-byte candidates) and flank lengths that are not a multiple of 4
+    locus, _ = mods
+    rng = np.random.default_rng(7)
+    dna = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    for F in (250, 37, 6):
+        lf, rf = dna(F), dna(F)
+        lf = lf[:4] * 3 + lf[12:] if F > 16 else lf          # the head of the left piece repeats inside it
+        reads = []
+        for n_left, n_tr, n_right in ((0, 30, 0), (1, 0, 1), (700, 300, 10), (1024 - F, 5, 1024), (1500, 60, 1500), (2, 9, 3000), (1023, 1, 1)):
+            reads.append(dna(n_left) + lf + b"CAG" * (n_tr // 3) + rf + dna(n_right))
+        reads.append(lf[:4] * 40 + lf + b"CAG" * 4 + rf)      # decoy heads in front of the true occurrence
+        reads.append(dna(300) + lf[:-1] + b"N" + b"CAG" * 4 + rf)  # left piece present with one mismatch only
+        reads.append(lf[: F - 1])                               # shorter than the flank
+        loci = [dict(left_flank=dna(20) + lf, right_flank=rf + dna(20), tr=b"CAG" * 5, motifs=[b"CAG"], reads=reads)]
+        b = locus.pack(loci)
+        params = locus.Params(search_flank_len=F)
+        ss, se, lh, rh = locus.find_tr_spans_batch(b, params)
+        ref = oracle.locus_analyze(loci[0]["left_flank"], loci[0]["right_flank"], loci[0]["tr"], loci[0]["motifs"], reads, flank_len=F,
+                                   min_flank_id_frac=params.min_flank_id_frac, max_depth=params.max_depth, scoring=params.aln_scoring)
+        assert np.array_equal(ss, ref["span_start"]) and np.array_equal(se, ref["span_end"]), F

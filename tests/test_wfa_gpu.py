@@ -200,3 +200,42 @@ def test_long_expanded_alleles_biwfa(oracle, W):
     got = al.align_end_to_end_batch(pats, txts)
     op = oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, memory="ultralow", heuristic="default")
     _check_batch(oracle, got, op, pats, txts)
+
+
+@pytest.mark.parametrize("pen", [(1, 0, 1), (1, 3, 1), (3, 2, 2), (4, 6, 2), (2, 5, 1), (5, 1, 3), (7, 9, 1)])
+@pytest.mark.parametrize("span", ["end2end", "endsfree", "textfree"])
+def test_dedicated_affine_kernel_penalties_and_shapes(oracle, W, pen, span):
+    # exact unidirectional gap-affine batches run on wfa_fast_kernel: ring depth, "current level" sources (x = 1, o + e = 1, e = 1),
+    # score-level parity (e > 1) and every ends-free shape are exercised here, next to degenerate sequences
+    x, o, e = pen
+    rng = np.random.default_rng(1000 * x + 100 * o + 10 * e + len(span))
+    pats, txts = [], []
+    for i in range(70):
+        a = rand_dna(rng, int(rng.integers(1, 260)))
+        if i % 7 == 0:
+            b = rand_dna(rng, int(rng.integers(1, 200)))
+        else:
+            b = rand_dna(rng, int(rng.integers(0, 150))) + mutate(rng, a, 0.03, 0.015, 0.015) + rand_dna(rng, int(rng.integers(0, 150)))
+        if i % 11 == 0:
+            a, b = b, a            # pattern longer than text
+        if i == 3:
+            a, b = b"A", b"A"
+        if i == 4:
+            a, b = b"ACGTACGTAC", b"T"
+        if i == 5:
+            a, b = b"G" * 130, b"G" * 129 + b"C" + b"G" * 40   # long runs: many 4-byte windows per extension
+        if span == "endsfree" and (len(a) < 6 or len(b) < 41):   # fixed free-end lengths must not exceed the sequences
+            a, b = a + rand_dna(rng, 6), b + rand_dna(rng, 41)
+        pats.append(bytes(a))
+        txts.append(bytes(b))
+    al = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryHigh).affine(x, o, e).with_heuristic(W.Heuristic.none()).build()
+    if span == "end2end":
+        got = al.align_end_to_end_batch(pats, txts)
+        op = oracle.wfa_params(metric="affine", x=x, o1=o, e1=e, heuristic="none")
+    elif span == "textfree":
+        got = al.align_ends_free_batch(pats, 0, 0, txts, -1, -1)
+        op = oracle.wfa_params(metric="affine", x=x, o1=o, e1=e, span="endsfree", pbf=0, pef=0, tbf=-1, tef=-1, heuristic="none")
+    else:
+        got = al.align_ends_free_batch(pats, 3, 5, txts, 40, 7)
+        op = oracle.wfa_params(metric="affine", x=x, o1=o, e1=e, span="endsfree", pbf=3, pef=5, tbf=40, tef=7, heuristic="none")
+    _check_batch(oracle, got, op, pats, txts)
