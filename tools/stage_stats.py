@@ -10,5 +10,5 @@ out = locus.BatchOutputs(b)
 for i in range(4):
     locus.run_batch(b, outputs=out, flank_dev=fd, reads_dev=rd)
 s = out.stats
-names = ["A_gpu_flank", "B_consensus", "C_hmm", "host_glue", "total", "d0", "d1", "d2", "select", "select+gather", "..+front", "back"]
+names = ["A_wait", "B_consensus", "C_hmm", "host_glue", "total", "setup", "+uploads", "+enqueueA", "select", "gather", "front", "back"]
 print({n: round(float(v) / 1e6, 2) for n, v in zip(names, s[4:16])})

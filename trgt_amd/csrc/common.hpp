@@ -85,10 +85,13 @@ enum Slot {
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
   S_FS_WFAJOBS, S_FS_SPAN, S_FS_NMATCH,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
+  S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
+  S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED,
   S_COUNT
 };
 // pinned host buffer slots
-enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_SEG0, P_SEG_LAST = P_SEG0 + 15, P_COUNT };
+enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_SEG0, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
+               P_GT_RANK, P_GT_NSPAN, P_GT_TOFF, P_GT_PACKED, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   if ((int)c->pool.size() < S_COUNT) c->pool.resize(S_COUNT);

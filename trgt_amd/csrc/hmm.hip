@@ -29,6 +29,8 @@ namespace trgt {
 // ------------------------------------------------------------ host model
 
 }  // namespace trgt
+#include <memory>
+
 #include "hmm_host.hpp"
 namespace trgt {
 
@@ -177,6 +179,15 @@ __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, 
   return b == 'A' ? 1 : b == 'T' ? 2 : b == 'C' ? 3 : b == 'G' ? 4 : ((i - 1) & 3) + 1;
 }
 
+// Workgroup synchronisation of the Viterbi kernel.  Most motif sets need at most 64 states, i.e. a single wavefront: its lanes run in
+// lockstep and the LDS unit serves one wave's accesses in order, so a compiler-level fence is all that is needed -- whereas
+// __syncthreads() also waits for every global store in flight (the back-pointer column written at the end of each step), a
+// memory round trip per step.
+__device__ __forceinline__ void hmm_sync(int nthr) {
+  if (nthr == 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  else __syncthreads();
+}
+
 // STAGE: the allele, the motif bytes, the motif-visit list and the motif counts live in LDS (alleles up to HMM_STAGE_QLEN bases).
 // The fill reads one base per column and the traceback / decode of thread 0 is a chain of dependent loads: served from HBM each
 // of them costs a memory round trip, which was most of this kernel's time.
@@ -253,9 +264,11 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
   const double em0 = g_em[0 * S + st], em1 = g_em[1 * S + st], em2 = g_em[2 * S + st], em3 = g_em[3 * S + st], em4 = g_em[4 * S + st];
   const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
+  // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
+  const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
-  __syncthreads();
+  hmm_sync(nthr);
 
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
@@ -271,14 +284,17 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (i == 0) {
         if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
       } else {
-        if (n_in > 0) { const double v = (prev[p0] + lp0) + em; if (v > best) { best = v; bpi = 0; } }
-        if (n_in > 1) { const double v = (prev[p1] + lp1) + em; if (v > best) { best = v; bpi = 1; } }
-        if (n_in > 2) { const double v = (prev[p2] + lp2) + em; if (v > best) { best = v; bpi = 2; } }
-        if (n_in > 3) { const double v = (prev[p3] + lp3) + em; if (v > best) { best = v; bpi = 3; } }
+        // all four predecessor scores are fetched first (one LDS wait instead of four); same sums, same strict '>' in the same order
+        const double s0 = prev[q0], s1 = prev[q1], s2 = prev[q2], s3 = prev[q3];
+        const double v0 = (s0 + lp0) + em, v1 = (s1 + lp1) + em, v2 = (s2 + lp2) + em, v3 = (s3 + lp3) + em;
+        if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+        if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+        if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+        if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
       }
       cur[st] = best;
     }
-    __syncthreads();
+    hmm_sync(nthr);
     for (int lev = 1; lev <= n_levels; ++lev) {
       if (act && level == lev) {
         if (n_in == 0xFF) {  // run-end state: predecessors are the block end states, in block order
@@ -287,14 +303,16 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
             if (v > best) { best = v; bpi = b; }
           }
         } else {
-          if (n_in > 0) { const double v = (cur[p0] + lp0) + 0.0; if (v > best) { best = v; bpi = 0; } }
-          if (n_in > 1) { const double v = (cur[p1] + lp1) + 0.0; if (v > best) { best = v; bpi = 1; } }
-          if (n_in > 2) { const double v = (cur[p2] + lp2) + 0.0; if (v > best) { best = v; bpi = 2; } }
-          if (n_in > 3) { const double v = (cur[p3] + lp3) + 0.0; if (v > best) { best = v; bpi = 3; } }
+          const double s0 = cur[q0], s1 = cur[q1], s2 = cur[q2], s3 = cur[q3];
+          const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0, v2 = (s2 + lp2) + 0.0, v3 = (s3 + lp3) + 0.0;
+          if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+          if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+          if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+          if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
         }
         cur[st] = best;
       }
-      __syncthreads();
+      hmm_sync(nthr);
     }
     if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
     double* t = prev; prev = cur; cur = t;
@@ -302,7 +320,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
   }
-  __syncthreads();
+  hmm_sync(nthr);
 
   // ---- traceback (hmm_model.rs:125-142) fused with get_events/calc_purity (events.rs:17-86, purity.rs:6-41)
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
@@ -319,7 +337,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       const int n16 = (c1 - c0) * Spad / 16;
       for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
     }
-    __syncthreads();
+    hmm_sync(nthr);
     if (tid == 0) {
       int state = tb_state, idx = tb_idx, np = tb_npath, nv = tb_nvisit, edit = tb_edit, ref = tb_ref, nxt = tb_next, vb1 = tb_vb1;
       while (state != 0 && idx >= c0) {
@@ -359,7 +377,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (state == 0) { if (pbuf && np < pcap) pbuf[pcap - 1 - np] = 0; ++np; tb_done = 1; }
       tb_state = state; tb_idx = idx; tb_npath = np; tb_nvisit = nv; tb_edit = edit; tb_ref = ref; tb_next = nxt; tb_vb1 = vb1;
     }
-    __syncthreads();
+    hmm_sync(nthr);
   }
   const int np = tb_npath;
   // ---- state path: shift the reversed tail to the front (forward order)
@@ -369,9 +387,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       const int f = base + tid;
       uint16_t v = 0;
       if (f < n) v = pbuf[shift + f];
-      __syncthreads();
+      hmm_sync(nthr);
       if (f < n) pbuf[f] = v;
-      __syncthreads();
+      hmm_sync(nthr);
     }
   }
   // ---- decode (thread 0): purity, remove_imperfect_motifs(.., 6), label_motifs, skip filter, counts, collapse
@@ -411,7 +429,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     n_spans[job.job_index] = (uint32_t)ns;
   }
   if (STAGE) {
-    __syncthreads();
+    hmm_sync(nthr);
     for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   }
 }
@@ -504,12 +522,40 @@ extern "C" uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_
   return (uint64_t)(seq_len + 2) * (max_motif_len + 4) + 8;
 }
 
+// State of an enqueued HMM batch between hmm_enqueue (uploads + kernel launches, no host wait for the kernels) and
+// hmm_collect (result copies).  One batch per ctx may be pending: the device buffers are the ctx's pool slots.
+struct trgt::HmmPending {
+  int64_t n_jobs = 0;
+  bool spans_on_host = false;
+  std::vector<uint64_t> tight_off;
+  std::vector<HmmJobDev> jobs;   // upload sources stay alive until the batch is collected
+  HmmModels local_models;
+  int32_t* spans3 = nullptr; const uint64_t* span_off = nullptr;
+  DevOut<uint16_t> o_path; DevOut<uint32_t> o_plen, o_nsp, o_cnt; DevOut<int32_t> o_spans, o_edit, o_maxd; DevOut<double> o_pur;
+};
+
+void trgt::hmm_pending_free(HmmPending* p) { delete p; }
+
 int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
-                              const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
-                              const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
-                              const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
-                              uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
-                              int32_t* edit_dist, int32_t* max_dist) {
+                         const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
+                         const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
+                         const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
+                         uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                         int32_t* edit_dist, int32_t* max_dist) {
+  HmmPending* pend = nullptr;
+  int rc = hmm_enqueue(c, premade, n_sets, motif_blob, motif_off, set_motif_begin, n_jobs, job_set, seq_blob, seq_off, seq_len, path, path_off,
+                       path_len, spans3, span_off, n_spans, motif_counts, count_off, purity, edit_dist, max_dist, &pend);
+  if (rc) return rc;
+  return hmm_collect(c, pend);
+}
+
+int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                      const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
+                      const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
+                      const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
+                      uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                      int32_t* edit_dist, int32_t* max_dist, HmmPending** out_pending) {
+  *out_pending = nullptr;
   if (!c) return TRGT_ERR_INVALID;
   if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
                                                     !seq_len || !spans3 || !span_off || !n_spans || !motif_counts ||
@@ -518,10 +564,11 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
   if (n_jobs == 0) return TRGT_OK;
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
-  const int64_t t_hmm0 = wall_ns();
+  std::unique_ptr<HmmPending> P(new HmmPending());
+  P->n_jobs = n_jobs; P->spans3 = spans3; P->span_off = span_off;
   // ---- models (host libm ln tables): built here unless the caller prepared them ahead of time (trgt_locus_batch does,
   //      concurrently with the flank-location stage)
-  HmmModels local_models;
+  HmmModels& local_models = P->local_models;
   const HmmModels* mp = premade;
   if (!mp) {
     const int mrc = hmm_build_models(n_sets, motif_blob, motif_off, set_motif_begin, local_models);
@@ -530,9 +577,9 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   } else if (mp->rc) return fail(c, mp->rc, "%s", mp->err.c_str());
   const std::vector<HmmSetDev>& sets = mp->sets;
   const std::vector<uint8_t>& blob = mp->blob;
-  c->dbg_ns[0] = wall_ns() - t_hmm0;
   // ---- jobs, grouped by workgroup size (64 * ceil(S/64))
-  std::vector<HmmJobDev> jobs((size_t)n_jobs);
+  std::vector<HmmJobDev>& jobs = P->jobs;
+  jobs.resize((size_t)n_jobs);
   uint64_t bp_total = 0, visit_total = 0, seq_total = 0, span_total = 0, count_total = 0, path_total = 0;
   int64_t cells = 0;
   for (int64_t j = 0; j < n_jobs; ++j) {
@@ -555,7 +602,6 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
   auto job_class = [&](const HmmJobDev& j) { return 2u * ((sets[j.set].S + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
   std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
-  c->dbg_ns[1] = wall_ns() - t_hmm0;
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
   int rc;
@@ -585,11 +631,12 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   if ((rc = dev_get(c, S_HMM_BP, (size_t)bp_total, &d_bp))) return rc;
   if ((rc = dev_get(c, S_HMM_VISITS, (size_t)visit_total * 4, &d_visits))) return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
-  DevOut<uint16_t> o_path; DevOut<uint32_t> o_plen, o_nsp, o_cnt; DevOut<int32_t> o_spans, o_edit, o_maxd; DevOut<double> o_pur;
+  auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
   // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the
   // spans actually produced are copied back (packed); a device buffer is written in the caller's layout directly.
   const bool spans_on_host = !is_device_ptr(spans3);
-  std::vector<uint64_t> tight_off;
+  P->spans_on_host = spans_on_host;
+  std::vector<uint64_t>& tight_off = P->tight_off;
   uint64_t tight_total = 0;
   if (spans_on_host) {
     tight_off.resize((size_t)n_jobs);
@@ -609,7 +656,6 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
   if ((rc = o_pur.init(c, S_HMM_PUR, purity, (size_t)n_jobs))) return rc;
   if ((rc = o_edit.init(c, S_HMM_EDIT, edit_dist, (size_t)n_jobs))) return rc;
   if ((rc = o_maxd.init(c, S_HMM_MAXD, max_dist, (size_t)n_jobs))) return rc;
-  c->dbg_ns[2] = wall_ns() - t_hmm0;
   // ---- one launch per workgroup-size class
   size_t i = 0;
   while (i < jobs.size()) {
@@ -641,6 +687,19 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
     t.stop(i == 0 ? cells : 0);
     i = e;
   }
+  *out_pending = P.release();
+  return TRGT_OK;
+}
+
+int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
+  if (!pend) return TRGT_OK;  // an empty batch
+  std::unique_ptr<HmmPending> P(pend);
+  const int64_t n_jobs = P->n_jobs;
+  const bool spans_on_host = P->spans_on_host;
+  std::vector<uint64_t>& tight_off = P->tight_off;
+  int32_t* spans3 = P->spans3; const uint64_t* span_off = P->span_off;
+  auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
+  int rc;
   if (spans_on_host) {
     std::vector<uint32_t> h_nsp((size_t)n_jobs);
     TRGT_HIP_TRY(c, hipMemcpyAsync(h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
@@ -667,7 +726,6 @@ int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_se
       (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
     return rc;
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->dbg_ns[3] = wall_ns() - t_hmm0;
   return TRGT_OK;
 }
 

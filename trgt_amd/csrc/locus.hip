@@ -14,10 +14,11 @@
 // The host glue is integer / byte work of a few microseconds per locus, spread over a persistent pool of host threads;
 // moving it onto the device is SURVEY.md 8(f) row 1.
 //
-// Chunking inside one call (TRGT_LOCUS_CHUNKS, default 1): stage A of every chunk is enqueued up front on the ctx stream
-// (nothing in it waits for the host), each followed by an asynchronous copy of its spans into pinned memory and an event.
-// The host then walks the chunks: wait for the event, select the spanning reads, gather their repeat segments, run the
-// genotyper, stages B and C (second stream) -- while the GPU is already locating flanks for the next chunks.
+// Flow of one call: stage A of the whole batch is enqueued (nothing in it waits for the host), then -- when the reads live in
+// HBM -- the device genotyper (locus_gt.hpp: spanning reads, length genotyper, consensus pick, classification) and the copies of
+// everything the host needs into pinned memory.  While the GPU works the host builds the HMM tables and initialises outputs.
+// Loci the device genotyper hands back (an allele without majority support needs stage B; oversized loci) go through the host
+// path below; the HMM batch of all other loci is already running by then.
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -27,6 +28,7 @@
 
 #include "hmm_host.hpp"
 #include "host_pool.hpp"
+#include "locus_gt.hpp"
 #include "wfa_host.hpp"
 
 namespace trgt {
@@ -217,7 +219,28 @@ HostPool* host_pool(trgt_hip_ctx* c, int threads) {
   return static_cast<HostPool*>(c->host_pool);
 }
 
-constexpr int MAX_CHUNKS = P_SEG_LAST - P_SEG0 + 1;
+// Exclusive prefix over the allele lengths (one workgroup) and the packing of the alleles into one dense buffer for the D2H copy
+__global__ void __launch_bounds__(1024) allele_prefix_kernel(const uint32_t* __restrict__ len, uint64_t* __restrict__ off, int64_t n) {
+  __shared__ uint64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024, b = t * per, e = b + per < n ? b + per : n;
+  uint64_t sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += len[i];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) { uint64_t run = 0; for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; } off[n] = run; }
+  __syncthreads();
+  uint64_t run = part[t];
+  for (int64_t i = b; i < e; ++i) { off[i] = run; run += len[i]; }
+}
+__global__ void allele_pack_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ len,
+                                   const uint64_t* __restrict__ dst_off, uint8_t* __restrict__ packed, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint8_t* s = blob + src_off[i];
+  uint8_t* d = packed + dst_off[i];
+  for (uint32_t b = threadIdx.x & 63; b < len[i]; b += 64) d[b] = s[b];
+}
 
 }  // namespace
 }  // namespace trgt
@@ -246,10 +269,11 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
-  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0;
+  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0;
   auto init_outputs = [&]() {
     for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
     for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
+    for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
   };
   if (nr == 0) { init_outputs(); return TRGT_OK; }
   if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -268,23 +292,16 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     models.d_sets = d_sets; models.d_blob = d_blob;
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
+  HmmPending* hmm_pending = nullptr;
+  struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending};
 
-  // ---------------- chunk plan
-  // Default: one chunk.  Measured on MI355X: the flank-location kernel is persistent and fills the LDS of every CU,
-  // so kernels of another stream do not start next to it, while every extra launch adds a tail of long alignments.
-  int n_chunks = 1;
-  if (const char* e = getenv("TRGT_LOCUS_CHUNKS")) n_chunks = atoi(e);
-  n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_chunks, MAX_CHUNKS), nl / 512));
-  std::vector<int64_t> cl((size_t)n_chunks + 1);
-  for (int k = 0; k <= n_chunks; ++k) cl[(size_t)k] = nl * k / n_chunks;
-
-  // ---------------- stage A for every chunk: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
+  // ---------------- stage A: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
   std::vector<uint64_t> piece_off(2 * (size_t)nl);
   std::vector<uint32_t> read_locus((size_t)nr);
-  uint64_t flank_total = 0, read_total = 0;
+  uint64_t flank_total = 0, read_total = 0, tr_total = 0, allele_total = 0;
   uint32_t max_read_len = 0;
   {
-    struct alignas(64) Acc { uint64_t flank = 0, read = 0; uint32_t max_len = 0; };  // one cache line per worker
+    struct alignas(64) Acc { uint64_t flank = 0, read = 0, tr = 0, allele = 0; uint32_t max_len = 0; };  // one cache line per worker
     std::vector<Acc> acc((size_t)pool->size());
     std::atomic<int64_t> short_flank{-1};
     pool->parallel_for(nl, 256, [&](int64_t l, int t) {
@@ -300,10 +317,18 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       Acc& a = acc[(size_t)t];
       a.flank = std::max<uint64_t>(a.flank, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
       a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml);
+      a.tr = std::max<uint64_t>(a.tr, in->tr_off[l] + in->tr_len[l]);
+      a.allele = std::max<uint64_t>(a.allele, std::max(out->allele_off[2 * l], out->allele_off[2 * l + 1]) + out->allele_cap[l]);
     });
     if (short_flank >= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: locus %lld flank shorter than flank_len", (long long)short_flank.load());
-    for (const Acc& a : acc) { flank_total = std::max(flank_total, a.flank); read_total = std::max(read_total, a.read); max_read_len = std::max(max_read_len, a.max_len); }
+    for (const Acc& a : acc) {
+      flank_total = std::max(flank_total, a.flank); read_total = std::max(read_total, a.read); max_read_len = std::max(max_read_len, a.max_len);
+      tr_total = std::max(tr_total, a.tr); allele_total = std::max(allele_total, a.allele);
+    }
   }
+  c->dbg_ns[0] = now_ns() - t0;  // set-up: thread pool, model thread, piece / read-locus tables
+  const bool reads_on_device = is_device_ptr(in->read_blob);
+  const bool dev_gt = reads_on_device && !getenv("TRGT_HOST_GENOTYPER");
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
   const uint64_t *d_piece = nullptr, *d_roff = nullptr;
@@ -320,64 +345,240 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       (rc = dev_get(c, S_FS_HIT0, (size_t)nr, &d_hl)) || (rc = dev_get(c, S_FS_HIT1, (size_t)nr, &d_hr)) ||
       (rc = pin_get(c, P_SPAN_S, (size_t)nr * 4, &h_ss)) || (rc = pin_get(c, P_SPAN_E, (size_t)nr * 4, &h_se)) ||
       (rc = pin_get(c, P_HIT_L, (size_t)nr, &h_hl)) || (rc = pin_get(c, P_HIT_R, (size_t)nr, &h_hr)) ||
-      (rc = pin_get(c, P_CELLS, 8 * (size_t)MAX_CHUNKS, &h_cells)))
+      (rc = pin_get(c, P_CELLS, 64, &h_cells)))
     return rc;
-  trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
-  std::vector<hipEvent_t> ev((size_t)n_chunks, nullptr);
-  struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } ev_guard{ev};
-  std::memset(h_cells, 0, 8 * (size_t)MAX_CHUNKS);
-  for (int k = 0; k < n_chunks; ++k) {
-    const int64_t r0 = (int64_t)in->locus_read_begin[cl[(size_t)k]], r1 = (int64_t)in->locus_read_begin[cl[(size_t)k + 1]], n = r1 - r0;
-    TRGT_HIP_TRY(c, hipEventCreateWithFlags(&ev[(size_t)k], hipEventDisableTiming));
-    if (n > 0) {
-      if ((rc = find_spans_device(c, sp, cl[(size_t)k + 1] - cl[(size_t)k], n, d_flank, d_piece, d_reads, d_roff + r0, d_rlen + r0, d_rloc + r0,
-                                  max_read_len, (int32_t*)d_ss + r0, (int32_t*)d_se + r0, (uint8_t*)d_hl + r0, (uint8_t*)d_hr + r0)))
-        return rc;
-      TRGT_HIP_TRY(c, hipMemcpyAsync((int32_t*)h_ss + r0, (int32_t*)d_ss + r0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipMemcpyAsync((int32_t*)h_se + r0, (int32_t*)d_se + r0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)h_hl + r0, (uint8_t*)d_hl + r0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)h_hr + r0, (uint8_t*)d_hr + r0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-      if (c->last_wfa_cells_dev)
-        TRGT_HIP_TRY(c, hipMemcpyAsync((uint64_t*)h_cells + k, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    TRGT_HIP_TRY(c, hipEventRecord(ev[(size_t)k], c->stream));
+  // device genotyper: inputs it needs beyond stage A's, and its outputs (device + pinned mirrors)
+  struct GtDev {
+    const uint64_t* lrb = nullptr; const uint8_t* ploidy = nullptr; const uint8_t* tr = nullptr; const uint64_t* tr_off = nullptr;
+    const uint32_t* tr_len = nullptr; const uint64_t* al_off = nullptr; const uint32_t* al_cap = nullptr;
+    void *need = nullptr, *nal = nullptr, *blob = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr,
+         *toff = nullptr, *packed = nullptr;
+  } g;
+  struct GtHost { void *need = nullptr, *nal = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr, *toff = nullptr, *packed = nullptr; } gh;
+  if (dev_gt) {
+    if ((rc = dev_in(c, S_GT_LRB, in->locus_read_begin, (size_t)nl + 1, &g.lrb)) || (rc = dev_in(c, S_GT_PLOIDY, in->ploidy, (size_t)nl, &g.ploidy)) ||
+        (rc = dev_in(c, S_GT_TR, in->tr_blob, (size_t)tr_total, &g.tr)) || (rc = dev_in(c, S_GT_TROFF, in->tr_off, (size_t)nl, &g.tr_off)) ||
+        (rc = dev_in(c, S_GT_TRLEN, in->tr_len, (size_t)nl, &g.tr_len)) || (rc = dev_in(c, S_GT_ALOFF, out->allele_off, 2 * (size_t)nl, &g.al_off)) ||
+        (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap)) ||
+        (rc = dev_get(c, S_GT_NEED, (size_t)nl, &g.need)) || (rc = dev_get(c, S_GT_NAL, (size_t)nl * 4, &g.nal)) ||
+        (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_ALEN, 2 * (size_t)nl * 4, &g.alen)) ||
+        (rc = dev_get(c, S_GT_CI, 4 * (size_t)nl * 4, &g.ci)) || (rc = dev_get(c, S_GT_NSP, 2 * (size_t)nl * 4, &g.nsp)) ||
+        (rc = dev_get(c, S_GT_CLS, (size_t)nr * 4, &g.cls)) || (rc = dev_get(c, S_GT_RANK, (size_t)nr * 4, &g.rank)) ||
+        (rc = dev_get(c, S_GT_NSPAN, (size_t)nl * 4, &g.nspan)) || (rc = dev_get(c, S_GT_TOFF, (2 * (size_t)nl + 1) * 8, &g.toff)) ||
+        (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)) ||
+        (rc = pin_get(c, P_GT_NEED, (size_t)nl, &gh.need)) || (rc = pin_get(c, P_GT_NAL, (size_t)nl * 4, &gh.nal)) ||
+        (rc = pin_get(c, P_GT_ALEN, 2 * (size_t)nl * 4, &gh.alen)) || (rc = pin_get(c, P_GT_CI, 4 * (size_t)nl * 4, &gh.ci)) ||
+        (rc = pin_get(c, P_GT_NSP, 2 * (size_t)nl * 4, &gh.nsp)) || (rc = pin_get(c, P_GT_CLS, (size_t)nr * 4, &gh.cls)) ||
+        (rc = pin_get(c, P_GT_RANK, (size_t)nr * 4, &gh.rank)) || (rc = pin_get(c, P_GT_NSPAN, (size_t)nl * 4, &gh.nspan)) ||
+        (rc = pin_get(c, P_GT_TOFF, (2 * (size_t)nl + 1) * 8, &gh.toff)))
+      return rc;
   }
+  c->dbg_ns[1] = now_ns() - t0;  // + uploads of the offset tables, buffer (re)allocation
+  trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
+  hipEvent_t evA = nullptr;
+  struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
+  TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
+  *(uint64_t*)h_cells = 0;
+  if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
+                              (uint8_t*)d_hl, (uint8_t*)d_hr)))
+    return rc;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(h_ss, d_ss, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(h_se, d_se, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(h_hl, d_hl, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(h_hr, d_hr, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  if (dev_gt) {
+    gt::GtArgs ga;
+    ga.reads = d_reads; ga.read_off = d_roff; ga.read_len = d_rlen; ga.locus_read_begin = g.lrb;
+    ga.span_start = (const int32_t*)d_ss; ga.span_end = (const int32_t*)d_se;
+    ga.ploidy = g.ploidy; ga.tr_blob = g.tr; ga.tr_off = g.tr_off; ga.tr_len = g.tr_len; ga.allele_off = g.al_off; ga.allele_cap = g.al_cap;
+    ga.n_loci = nl; ga.flank_len = F; ga.max_depth = p->max_depth;
+    ga.need_host = (uint8_t*)g.need; ga.n_alleles = (int32_t*)g.nal; ga.allele_blob = (uint8_t*)g.blob; ga.allele_len = (uint32_t*)g.alen;
+    ga.ci = (int32_t*)g.ci; ga.num_spanning = (int32_t*)g.nsp; ga.classification = (int32_t*)g.cls; ga.read_rank = (int32_t*)g.rank;
+    ga.n_spanning_reads = (uint32_t*)g.nspan;
+    hipLaunchKernelGGL(gt::locus_genotype_kernel, dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
+    hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
+                       (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
+    TRGT_HIP_TRY(c, hipGetLastError());
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.need, g.need, (size_t)nl, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nal, g.nal, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.alen, g.alen, 2 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.ci, g.ci, 4 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nsp, g.nsp, 2 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.cls, g.cls, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.rank, g.rank, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nspan, g.nspan, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.toff, g.toff, (2 * (size_t)nl + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  TRGT_HIP_TRY(c, hipEventRecord(evA, c->stream));
+  c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
   init_outputs();  // host-only work: done while the GPU is already busy
 
-  // ---------------- host, chunk by chunk while the GPU works ahead: spanning reads (tr.rs:111-184), repeat segments gathered
-  // from HBM when the reads live there, front half of the length genotyper
-  std::vector<LocusWork> work((size_t)nl);
-  const bool reads_on_device = is_device_ptr(in->read_blob);
-  struct K { uint32_t read, s, e; };
-  std::vector<K> sel((size_t)nr);
-  std::vector<uint32_t> n_sel((size_t)nl, 0);
-  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len, seg_read; std::vector<const uint8_t*> seg_ptr;
-  seg_src.reserve((size_t)nr); seg_dst.reserve((size_t)nr); seg_len.reserve((size_t)nr); seg_read.reserve((size_t)nr); seg_ptr.reserve((size_t)nr);
-  std::vector<Scratch> scratch((size_t)pool->size());
-  c->dbg_ns[7] = 0;
-  int64_t t_sel = 0, t_gather = 0, t_front = 0, t_wait = 0;
-  // stages B, host back half and C for the loci [l0, l1) (their front half is done); runs on whatever c->stream is at the call
-  std::vector<int8_t> seg_cls((size_t)nr, 0);
-  int64_t stat_hmm_jobs = 0;
-  auto finish_range = [&](int64_t l0, int64_t l1, const std::vector<size_t>& rep_begin) -> int {
-    int rc;
-    // ---------------- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
+  // ---------------- wait for the GPU, publish spans
+  {
+    const int64_t tw = now_ns();
+    TRGT_HIP_TRY(c, hipEventSynchronize(evA));
+    tA = now_ns() - tw;
+  }
+  int64_t th_begin = now_ns();
+  std::memcpy(out->span_start, h_ss, (size_t)nr * 4);
+  std::memcpy(out->span_end, h_se, (size_t)nr * 4);
+  {
+    std::vector<int64_t> part((size_t)pool->size() * 8, 0);
+    pool->parallel_for(nr, 8192, [&](int64_t r, int t) { part[(size_t)t * 8] += (((const uint8_t*)h_hl)[r] != 1) + (((const uint8_t*)h_hr)[r] != 1); });
+    for (int t = 0; t < pool->size(); ++t) stat_flank_jobs += part[(size_t)t * 8];
+  }
+  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)*(uint64_t*)h_cells;
+  // ---------------- loci for the host path: all of them without the device genotyper, else the ones it handed back
+  std::vector<int64_t> R;
+  std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;  // HMM jobs of the device-genotyped loci
+  std::vector<uint32_t> nsp; std::vector<double> pur;
+  if (dev_gt) {
+    const uint8_t* need = (const uint8_t*)gh.need;
+    {
+      const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];  // the alleles come back packed: a second, exact-size copy
+      if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
+      if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
+      std::memcpy(out->n_alleles, gh.nal, (size_t)nl * 4); std::memcpy(out->allele_len, gh.alen, 2 * (size_t)nl * 4);
+      std::memcpy(out->ci, gh.ci, 4 * (size_t)nl * 4); std::memcpy(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4);
+      std::memcpy(out->classification, gh.cls, (size_t)nr * 4); std::memcpy(out->read_rank, gh.rank, (size_t)nr * 4);
+      const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
+      pool->parallel_for(nl, 256, [&](int64_t l, int) {
+        if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
+        for (int a = 0; a < out->n_alleles[l]; ++a)
+          std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
+      });
+      for (int64_t l = 0; l < nl; ++l) {
+        if (need[l]) continue;
+        stat_spanning += ((const uint32_t*)gh.nspan)[l];
+        for (int a = 0; a < out->n_alleles[l]; ++a) {
+          job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
+          span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+        }
+      }
+      // stage C for these loci starts now, on alleles that already sit in HBM; it is collected after the host path of the others
+      if (!job_set.empty()) {
+        nsp.resize(job_set.size()); pur.resize(job_set.size());
+        if (model_thread.joinable()) model_thread.join();
+        const int64_t tc0 = now_ns();
+        rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
+                         (const uint8_t*)g.blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(), nsp.data(),
+                         out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr, &hmm_pending);
+        if (rc) return rc;
+        tC += now_ns() - tc0;
+        stat_hmm_jobs += (int64_t)job_set.size();
+      }
+    }
+  } else {
+    for (int64_t l = 0; l < nl; ++l) R.push_back(l);
+  }
+  tHost += now_ns() - th_begin;
+
+  // ---------------- host path for the loci in R (second stream for its GPU work: gather, consensus alignments, HMM)
+  const int64_t nR = (int64_t)R.size();
+  if (nR > 0) {
+    std::vector<LocusWork> work((size_t)nR);
+    struct K { uint32_t read, s, e; };
+    std::vector<K> sel((size_t)nr);
+    std::vector<uint32_t> n_sel((size_t)nR, 0);
+    std::vector<Scratch> scratch((size_t)pool->size());
+    int64_t th0 = now_ns();
+    // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
+    // each locus writes its selection into its own read range of `sel`
+    pool->parallel_for(nR, 32, [&](int64_t li, int) {
+      const int64_t l = R[(size_t)li];
+      if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
+      K* ks = sel.data() + in->locus_read_begin[l];
+      uint32_t n = 0;
+      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
+        const int32_t s = out->span_start[r], e = out->span_end[r];
+        if (s < 0) continue;
+        if (s >= F && (int64_t)in->read_len[r] - e >= F) {
+          const K kk{(uint32_t)r, (uint32_t)s, (uint32_t)e};
+          uint32_t i = n++;  // stable insertion sort by span length
+          while (i > 0 && (ks[i - 1].e - ks[i - 1].s) > (kk.e - kk.s)) { ks[i] = ks[i - 1]; --i; }
+          ks[i] = kk;
+        }
+      }
+      if ((int64_t)n > p->max_depth) {
+        const double step = (double)n / (double)p->max_depth;
+        double fast = 0.0;
+        for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
+        n = (uint32_t)p->max_depth;
+      }
+      n_sel[(size_t)li] = n;
+    });
+    // pass 2: flat segment arrays (LocusResult.reads order within each locus)
+    uint64_t n_seg = 0;
+    for (int64_t li = 0; li < nR; ++li) { work[(size_t)li].seg_begin = n_seg; n_seg += n_sel[(size_t)li]; work[(size_t)li].seg_end = n_seg; }
+    std::vector<uint64_t> seg_src((size_t)n_seg), seg_dst((size_t)n_seg); std::vector<uint32_t> seg_len((size_t)n_seg), seg_read((size_t)n_seg);
+    std::vector<const uint8_t*> seg_ptr((size_t)n_seg);
+    pool->parallel_for(nR, 64, [&](int64_t li, int) {
+      const int64_t l = R[(size_t)li];
+      const K* ks = sel.data() + in->locus_read_begin[l];
+      uint64_t s = work[(size_t)li].seg_begin;
+      for (uint32_t i = 0; i < n_sel[(size_t)li]; ++i, ++s) {
+        seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
+      }
+    });
+    uint64_t seg_bytes = 0;
+    for (uint64_t s = 0; s < n_seg; ++s) { seg_dst[s] = seg_bytes; seg_bytes += seg_len[s]; }
+    stat_spanning += (int64_t)n_seg;
+    c->dbg_ns[4] = now_ns() - th0;
+    int64_t tg0 = now_ns();
+    if (n_seg > 0 && reads_on_device) {
+      void *d_src, *d_dst, *d_len, *d_out, *h_seg;
+      if ((rc = dev_get(c, S_LOCUS_0, (size_t)n_seg * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, (size_t)n_seg * 8, &d_dst)) ||
+          (rc = dev_get(c, S_LOCUS_2, (size_t)n_seg * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)seg_bytes + 1, &d_out)) ||
+          (rc = pin_get(c, P_SEG0, (size_t)seg_bytes + 1, &h_seg)))
+        return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, c->stream2));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, c->stream2));
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, c->stream2));
+      GatherArgs ga{d_reads, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)n_seg, (uint8_t*)d_out};
+      hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream2, ga);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)seg_bytes, hipMemcpyDeviceToHost, c->stream2));
+      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
+      for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = (const uint8_t*)h_seg + seg_dst[s];
+    } else {
+      for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s];
+    }
+    c->dbg_ns[5] = now_ns() - tg0;
+    // front half of the length genotyper, threaded over loci (per-thread scratch, no per-locus allocation)
+    int64_t tf0 = now_ns();
+    pool->parallel_for(nR, 16, [&](int64_t li, int t) {
+      LocusWork& w = work[(size_t)li];
+      if (w.seg_begin == w.seg_end) return;
+      Scratch& sc = scratch[(size_t)t];
+      sc.trs.clear();
+      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(Seg{seg_ptr[s], seg_len[s]});
+      genotype_size_front(in->ploidy[R[(size_t)li]] == 1 ? 1 : 2, li, t, w, sc);
+    });
+    c->dbg_ns[6] = now_ns() - tf0;
+    tHost += now_ns() - th0;
+    // ---- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
+    std::swap(c->stream, c->stream2);
+    struct SwapBack { trgt_hip_ctx* c; ~SwapBack() { std::swap(c->stream, c->stream2); } } swap_back{c};
     int64_t tb0 = now_ns();
     struct JobRef { Repair* rep; int member; };
     std::vector<JobRef> jrefs;
     std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
-    for (size_t t = 0; t < scratch.size(); ++t)
-      for (size_t ri = rep_begin[t]; ri < scratch[t].repairs.size(); ++ri) {
-        Repair& rep = scratch[t].repairs[ri];
+    for (auto& sc : scratch)
+      for (auto& rep : sc.repairs) {
         const Seg bb = work[(size_t)rep.locus].pick[rep.allele];
         const uint64_t bo = cblob.size();
         cblob.insert(cblob.end(), bb.p, bb.p + bb.n);
         for (size_t m = 0; m < rep.members.size(); ++m) {
-          const Seg& s = rep.members[m];
+          const Seg& sg = rep.members[m];
           coff.push_back(coff.empty() ? 0 : coff.back() + plen.back() + tlen.back() + 1);
           poff.push_back(bo); plen.push_back(bb.n);
-          toff.push_back(cblob.size()); tlen.push_back(s.n);
-          cblob.insert(cblob.end(), s.p, s.p + s.n);
+          toff.push_back(cblob.size()); tlen.push_back(sg.n);
+          cblob.insert(cblob.end(), sg.p, sg.p + sg.n);
           jrefs.push_back({&rep, (int)m});
         }
       }
@@ -390,11 +591,11 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       rc = trgt_wfa_batch(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
                           nullptr, nullptr, cigars.data(), coff.data(), clen.data(), nullptr, nullptr, nullptr);
       if (rc) return rc;
-      stat_cons_jobs += (int64_t)jrefs.size();
+      stat_cons_jobs = (int64_t)jrefs.size();
     }
-    tB += now_ns() - tb0;
-    // ---------------- host: repair_consensus, classification, reference allele first, output assembly
-    int64_t th0 = now_ns();
+    tB = now_ns() - tb0;
+    // ---- host: repair_consensus, classification, reference allele first, output assembly
+    th0 = now_ns();
     {
       size_t j = 0;
       while (j < jrefs.size()) {  // jobs of one repair are contiguous
@@ -406,10 +607,11 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
       }
     }
+    std::vector<int8_t> seg_cls((size_t)n_seg, 0);
     std::atomic<int> bad{0};
-    pool->parallel_for(l1 - l0, 64, [&](int64_t li, int) {
-      const int64_t l = l0 + li;
-      LocusWork& w = work[(size_t)l];
+    pool->parallel_for(nR, 64, [&](int64_t li, int) {
+      const int64_t l = R[(size_t)li];
+      LocusWork& w = work[(size_t)li];
       if (w.seg_begin == w.seg_end) return;
       const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
       Seg al[2];
@@ -442,141 +644,48 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
         out->num_spanning[2 * l + oi] = by_hap[a];
       }
+      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; }
       for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
         out->classification[seg_read[s]] = flip ? 1 - seg_cls[s] : seg_cls[s];
         out->read_rank[seg_read[s]] = (int32_t)(s - w.seg_begin);
       }
     });
     if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
-    c->dbg_ns[7] += now_ns() - th0;
+    c->dbg_ns[7] = now_ns() - th0;
     tHost += now_ns() - th0;
-    // ---------------- stage C: label_with_hmm for every allele
-    int64_t tc0 = now_ns();
-    std::vector<uint32_t> job_set, seq_len, nsp; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<double> pur;
-    std::vector<int64_t> slot;
-    for (int64_t l = l0; l < l1; ++l)
+  }
+  // ---------------- stage C results of the device-genotyped loci
+  if (hmm_pending) {
+    const int64_t tc0 = now_ns();
+    HmmPending* pend = hmm_pending; hmm_pending = nullptr;
+    rc = hmm_collect(c, pend);
+    if (rc) return rc;
+    for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
+    tC += now_ns() - tc0;
+  }
+  // ---------------- stage C for the host-path loci: label_with_hmm for every allele
+  if (nR > 0) {
+    const int64_t tc0 = now_ns();
+    std::vector<uint32_t> js, sl, ns2; std::vector<uint64_t> so, spo, co; std::vector<double> pu; std::vector<int64_t> sl2;
+    for (int64_t li = 0; li < nR; ++li) {
+      const int64_t l = R[(size_t)li];
       for (int a = 0; a < out->n_alleles[l]; ++a) {
-        job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
-        span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+        js.push_back((uint32_t)l); so.push_back(out->allele_off[2 * l + a]); sl.push_back(out->allele_len[2 * l + a]);
+        spo.push_back(out->span_off[2 * l + a]); co.push_back(out->count_off[2 * l + a]); sl2.push_back(2 * l + a);
       }
-    for (int64_t s = 2 * l0; s < 2 * l1; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
-    if (!job_set.empty()) {
-      nsp.resize(job_set.size()); pur.resize(job_set.size());
+    }
+    if (!js.empty()) {
+      ns2.resize(js.size()); pu.resize(js.size());
       if (model_thread.joinable()) model_thread.join();
-      rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
-                          out->allele_blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(),
-                          nsp.data(), out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr);
+      rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)js.size(), js.data(),
+                          out->allele_blob, so.data(), sl.data(), nullptr, nullptr, nullptr, out->spans3, spo.data(), ns2.data(),
+                          out->motif_counts, co.data(), pu.data(), nullptr, nullptr);
       if (rc) return rc;
-      for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
+      for (size_t j = 0; j < sl2.size(); ++j) { out->n_spans[sl2[j]] = ns2[j]; out->purity[sl2[j]] = pu[j]; }
+      stat_hmm_jobs += (int64_t)js.size();
     }
     tC += now_ns() - tc0;
-    stat_hmm_jobs += (int64_t)job_set.size();
-    return TRGT_OK;
-
-  };
-  for (int k = 0; k < n_chunks; ++k) {
-    const int64_t l0 = cl[(size_t)k], l1 = cl[(size_t)k + 1];
-    const int64_t r0 = (int64_t)in->locus_read_begin[l0], r1 = (int64_t)in->locus_read_begin[l1];
-    int64_t tw = now_ns();
-    TRGT_HIP_TRY(c, hipEventSynchronize(ev[(size_t)k]));
-    t_wait += now_ns() - tw;
-    int64_t th0 = now_ns();
-    std::memcpy(out->span_start + r0, (int32_t*)h_ss + r0, (size_t)(r1 - r0) * 4);
-    std::memcpy(out->span_end + r0, (int32_t*)h_se + r0, (size_t)(r1 - r0) * 4);
-    for (int64_t r = r0; r < r1; ++r) stat_flank_jobs += (((uint8_t*)h_hl)[r] != 1) + (((uint8_t*)h_hr)[r] != 1);
-    // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
-    // each locus writes its selection into its own read range of `sel`
-    pool->parallel_for(l1 - l0, 32, [&](int64_t li, int) {
-      const int64_t l = l0 + li;
-      if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
-      K* ks = sel.data() + in->locus_read_begin[l];
-      uint32_t n = 0;
-      for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
-        const int32_t s = out->span_start[r], e = out->span_end[r];
-        if (s < 0) continue;
-        if (s >= F && (int64_t)in->read_len[r] - e >= F) {
-          const K kk{(uint32_t)r, (uint32_t)s, (uint32_t)e};
-          uint32_t i = n++;  // stable insertion sort by span length
-          while (i > 0 && (ks[i - 1].e - ks[i - 1].s) > (kk.e - kk.s)) { ks[i] = ks[i - 1]; --i; }
-          ks[i] = kk;
-        }
-      }
-      if ((int64_t)n > p->max_depth) {
-        const double step = (double)n / (double)p->max_depth;
-        double fast = 0.0;
-        for (int i = 0; i < p->max_depth; ++i) { const size_t ind = (size_t)std::floor(fast); if (ind != (size_t)i) std::swap(ks[i], ks[ind]); fast += step; }
-        n = (uint32_t)p->max_depth;
-      }
-      n_sel[(size_t)l] = n;
-    });
-    // pass 2: flat segment arrays (LocusResult.reads order within each locus), appended to the batch-wide lists
-    const uint64_t seg0 = seg_src.size();
-    uint64_t n_seg = seg0;
-    for (int64_t l = l0; l < l1; ++l) { work[(size_t)l].seg_begin = n_seg; n_seg += n_sel[(size_t)l]; work[(size_t)l].seg_end = n_seg; }
-    seg_src.resize((size_t)n_seg); seg_dst.resize((size_t)n_seg); seg_len.resize((size_t)n_seg); seg_read.resize((size_t)n_seg); seg_ptr.resize((size_t)n_seg);
-    pool->parallel_for(l1 - l0, 64, [&](int64_t li, int) {
-      const int64_t l = l0 + li;
-      const K* ks = sel.data() + in->locus_read_begin[l];
-      uint64_t s = work[(size_t)l].seg_begin;
-      for (uint32_t i = 0; i < n_sel[(size_t)l]; ++i, ++s) {
-        seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
-      }
-    });
-    uint64_t chunk_bytes = 0;
-    for (uint64_t s = seg0; s < n_seg; ++s) { seg_dst[s] = chunk_bytes; chunk_bytes += seg_len[s]; }  // offsets inside this chunk's byte buffer
-    t_sel += now_ns() - th0;
-    int64_t tg0 = now_ns();
-    if (n_seg > seg0 && reads_on_device) {
-      const size_t ns = (size_t)(n_seg - seg0);
-      void *d_src, *d_dst, *d_len, *d_out, *h_seg;
-      if ((rc = dev_get(c, S_LOCUS_0, ns * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, ns * 8, &d_dst)) ||
-          (rc = dev_get(c, S_LOCUS_2, ns * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)chunk_bytes + 1, &d_out)) ||
-          (rc = pin_get(c, P_SEG0 + k, (size_t)chunk_bytes + 1, &h_seg)))
-        return rc;
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data() + seg0, ns * 8, hipMemcpyHostToDevice, c->stream2));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data() + seg0, ns * 8, hipMemcpyHostToDevice, c->stream2));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data() + seg0, ns * 4, hipMemcpyHostToDevice, c->stream2));
-      GatherArgs ga{d_reads, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)ns, (uint8_t*)d_out};
-      hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream2, ga);
-      TRGT_HIP_TRY(c, hipGetLastError());
-      TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)chunk_bytes, hipMemcpyDeviceToHost, c->stream2));
-      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
-      for (uint64_t s = seg0; s < n_seg; ++s) seg_ptr[s] = (const uint8_t*)h_seg + seg_dst[s];
-    } else {
-      for (uint64_t s = seg0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s];
-    }
-    t_gather += now_ns() - tg0;
-    // front half of the length genotyper, threaded over loci (per-thread scratch, no per-locus allocation)
-    int64_t tf0 = now_ns();
-    std::vector<size_t> rep_begin(scratch.size());
-    for (size_t t = 0; t < scratch.size(); ++t) rep_begin[t] = scratch[t].repairs.size();
-    pool->parallel_for(l1 - l0, 16, [&](int64_t li, int t) {
-      const int64_t l = l0 + li;
-      LocusWork& w = work[(size_t)l];
-      if (w.seg_begin == w.seg_end) return;
-      Scratch& sc = scratch[(size_t)t];
-      sc.trs.clear();
-      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(Seg{seg_ptr[s], seg_len[s]});
-      genotype_size_front(in->ploidy[l] == 1 ? 1 : 2, l, t, w, sc);
-    });
-    t_front += now_ns() - tf0;
-    // stages B and C of this chunk on the second stream, next to stage A of the following chunks
-    std::swap(c->stream, c->stream2);
-    rc = finish_range(l0, l1, rep_begin);
-    std::swap(c->stream, c->stream2);
-    if (rc) return rc;
   }
-  // stage A is complete (the last event has fired): its kernel time is whatever the host did not cover
-  tA = t_wait;
-  tHost += t_sel + t_gather + t_front;
-  c->dbg_ns[4] = t_sel; c->dbg_ns[5] = t_gather; c->dbg_ns[6] = t_front;
-  {
-    unsigned long long cells = 0;
-    for (int k = 0; k < n_chunks; ++k) cells += ((uint64_t*)h_cells)[k];
-    if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells;
-  }
-  const int64_t stat_spanning = (int64_t)seg_src.size();
-
   if (out->stats) {
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
