@@ -122,12 +122,15 @@ def main():
             jobs = int(stats[0])
             mean_read = float(batch["read_len"].mean())
             bytes_per_launch = 2.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)
+            survey_bytes_per_launch = 4.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)  # SURVEY 8(d) prices an offset at 4 B
         elif dom == "hmm_viterbi":  # 1 B per back-pointer cell + allele in + annotation out
             bytes_per_launch = 1.0 * cells / max(launches, 1) + float(out.allele_len.sum()) * 2
         elif dom == "flank_scan":   # every read byte once + 4 B per (read, side)
             bytes_per_launch = float(batch["read_len"].sum()) + 8.0 * n_reads
         else:
             bytes_per_launch = 4.0 * cells / max(launches, 1)
+        if dom != "wfa_flank":
+            survey_bytes_per_launch = bytes_per_launch
         traffic = None  # measured HBM bytes per launch of the same kernel / workload, when a PMC profile is committed
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -149,11 +152,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "dp_cells_per_launch": int(cells / max(launches, 1)),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_wavefront_offset": 2,
+                         "frac_at_survey_4B_per_offset": round(survey_bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_ms > 0 else 0.0,
+                         "dp_cells_per_launch": int(cells / max(launches, 1)),
                          "dp_cells_per_s": round(cells / max(ms, 1e-9) * 1e3, 1)},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kt.items()},
-            "stage_ms_last_step": {"gpu_flank": round(stats[4] / 1e6, 2), "gpu_consensus": round(stats[5] / 1e6, 2),
-                                   "gpu_hmm": round(stats[6] / 1e6, 2), "host_glue": round(stats[7] / 1e6, 2),
+            # host-visible wall time of the last step: blocked on stage A + device genotyper; consensus alignments of the loci
+            # handed back to the host path; HMM enqueue / collect (its kernel overlaps the host path); host glue; whole call
+            "stage_ms_last_step": {"wait_flank_location_and_genotyper": round(stats[4] / 1e6, 2), "consensus": round(stats[5] / 1e6, 2),
+                                   "hmm_host_visible": round(stats[6] / 1e6, 2), "host_glue": round(stats[7] / 1e6, 2),
                                    "total": round(stats[8] / 1e6, 2)},
             "work_per_step": {"flank_wfa_jobs": int(stats[0]), "consensus_jobs": int(stats[1]), "spanning_reads": int(stats[2]),
                               "hmm_jobs": int(stats[3])},

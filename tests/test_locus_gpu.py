@@ -13,6 +13,17 @@ def mods():
     return locus, synth
 
 
+def _run_both(locus, b, params=None):
+    """trgt_locus_batch with the reads on the host (host glue path) and resident in HBM (device genotyper + host path for the
+    loci it hands back); both must give the oracle's results."""
+    import torch
+    params = params or locus.Params()
+    yield "host", locus.run_batch(b, params)
+    reads_dev = torch.from_numpy(b["read_blob"]).cuda()
+    flank_dev = torch.from_numpy(b["flank_blob"]).cuda()
+    yield "device", locus.run_batch(b, params, flank_dev=flank_dev, reads_dev=reads_dev)
+
+
 def _oracle_locus(oracle, b, l, params):
     a0, a1 = int(b["locus_read_begin"][l]), int(b["locus_read_begin"][l + 1])
     reads = [bytes(b["read_blob"][int(b["read_off"][r]):int(b["read_off"][r]) + int(b["read_len"][r])]) for r in range(a0, a1)]
@@ -63,23 +74,23 @@ def test_find_spans_matches_oracle(oracle, mods):
 def test_locus_batch_matches_oracle_cfg2(oracle, mods):
     locus, synth = mods
     b = synth.generate(160, first_locus=0)
-    out = locus.run_batch(b)
-    _compare(oracle, locus, b, out, locus.Params(), range(160))
-    # genotype sanity against the generator's ground truth: allele lengths recovered for nearly every locus
-    ok = 0
-    for l in range(160):
-        got = sorted(int(v) for v in out.allele_len[2 * l:2 * l + 2])
-        ok += got == sorted(int(v) for v in b["true_allele_len"][2 * l:2 * l + 2])
-    assert ok >= 120
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(160))
+        # genotype sanity against the generator's ground truth: allele lengths recovered for nearly every locus
+        ok = 0
+        for l in range(160):
+            got = sorted(int(v) for v in out.allele_len[2 * l:2 * l + 2])
+            ok += got == sorted(int(v) for v in b["true_allele_len"][2 * l:2 * l + 2])
+        assert ok >= 120, mode
 
 
 def test_locus_batch_noisy_reads_trigger_consensus_repair(oracle, mods):
     # high error + stutter rates: no majority sequence -> utils::align (BiWFA) + repair_consensus path
     locus, synth = mods
     b = synth.generate(60, first_locus=5000, sub_rate=0.004, ins_rate=0.004, del_rate=0.004, stutter_rate=0.3)
-    out = locus.run_batch(b)
-    n_repair = _compare(oracle, locus, b, out, locus.Params(), range(60))
-    assert n_repair > 5 and int(out.stats[1]) > 0
+    for mode, out in _run_both(locus, b):
+        n_repair = _compare(oracle, locus, b, out, locus.Params(), range(60))
+        assert n_repair > 5 and int(out.stats[1]) > 0, mode
 
 
 def test_locus_batch_device_resident_reads_and_downsampling(oracle, mods):
@@ -109,8 +120,8 @@ def test_empty_and_degenerate_loci(oracle, mods):
     assert len(res[2].genotype) == 1 and res[2].genotype[0].seq == b"CAG" * 5 and res[2].vcf_fields()["MC"] == "5"
     assert [a.seq for a in res[3].genotype] == [b"", b""] and res[3].vcf_fields()["AP"] == ".,." and res[3].vcf_fields()["MS"] == ".,."
     b = locus.pack(loci)
-    out = locus.run_batch(b)
-    _compare(oracle, locus, b, out, locus.Params(), range(4))
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(4))
 
 
 def test_reference_example_locus_matches_tutorial_vcf(oracle, mods):
@@ -127,7 +138,9 @@ def test_reference_example_locus_matches_tutorial_vcf(oracle, mods):
         for k in ("AL", "ALLR", "SD", "MC", "MS", "AP"):
             assert f[k] == want[k], k
     b = locus.pack([L])
-    _compare(oracle, locus, b, locus.run_batch(b), locus.Params(), range(1))
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(1))
+        assert {k: v for k, v in locus.locus_result(b, out, 0).vcf_fields().items() if k in want} == {k: want[k] for k in ("AL", "ALLR", "SD", "MC", "MS", "AP")}, mode
 
 
 def test_flank_scan_shapes(oracle, mods):
@@ -152,3 +165,26 @@ def test_flank_scan_shapes(oracle, mods):
         ref = oracle.locus_analyze(loci[0]["left_flank"], loci[0]["right_flank"], loci[0]["tr"], loci[0]["motifs"], reads, flank_len=F,
                                    min_flank_id_frac=params.min_flank_id_frac, max_depth=params.max_depth, scoring=params.aln_scoring)
         assert np.array_equal(ss, ref["span_start"]) and np.array_equal(se, ref["span_end"]), F
+
+
+def test_device_genotyper_envelope(oracle, mods):
+    # loci the device genotyper must hand back or treat specially: haploid, no spanning read, > 256 reads, repeat segments that do
+    # not fit its LDS staging (long alleles), homozygous and well separated heterozygous loci, ties between allele lengths
+    locus, _ = mods
+    rng = np.random.default_rng(11)
+    dna = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    lf, rf = dna(250), dna(250)
+    mk = lambda k, m=b"CAG": dna(int(rng.integers(250, 300))) + lf + m * k + rf + dna(int(rng.integers(250, 300)))
+    loci = [
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 5, motifs=[b"CAG"], ploidy=1, reads=[mk(k) for k in (7, 7, 8, 7, 6, 7)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 5, motifs=[b"CAG"], reads=[dna(700) for _ in range(5)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 9, motifs=[b"CAG"], reads=[mk(9 if i % 2 else 14) for i in range(300)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 5, motifs=[b"CAG"], reads=[mk(700 + (i % 2)) for i in range(12)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 10, motifs=[b"CAG"], reads=[mk(10) for _ in range(20)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 10, motifs=[b"CAG"], reads=[mk(10 if i < 10 else 40) for i in range(20)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 11, motifs=[b"CAG"], reads=[mk(k) for k in (10, 12, 10, 12, 11, 10, 12)]),
+        dict(left_flank=lf, right_flank=rf, tr=b"AT" * 6, motifs=[b"AT"], reads=[mk(k, b"AT") for k in (5, 6, 7, 5, 6, 7)]),
+    ]
+    b = locus.pack(loci)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
