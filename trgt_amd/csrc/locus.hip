@@ -423,79 +423,34 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     tA = now_ns() - tw;
   }
   int64_t th_begin = now_ns();
-  std::memcpy(out->span_start, h_ss, (size_t)nr * 4);
-  std::memcpy(out->span_end, h_se, (size_t)nr * 4);
-  {
-    std::vector<int64_t> part((size_t)pool->size() * 8, 0);
-    pool->parallel_for(nr, 8192, [&](int64_t r, int t) { part[(size_t)t * 8] += (((const uint8_t*)h_hl)[r] != 1) + (((const uint8_t*)h_hr)[r] != 1); });
-    for (int t = 0; t < pool->size(); ++t) stat_flank_jobs += part[(size_t)t * 8];
-  }
-  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)*(uint64_t*)h_cells;
   // ---------------- loci for the host path: all of them without the device genotyper, else the ones it handed back
   std::vector<int64_t> R;
-  std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;  // HMM jobs of the device-genotyped loci
-  std::vector<uint32_t> nsp; std::vector<double> pur;
-  if (dev_gt) {
-    const uint8_t* need = (const uint8_t*)gh.need;
-    {
-      const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];  // the alleles come back packed: a second, exact-size copy
-      if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
-      if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-      for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
-      std::memcpy(out->n_alleles, gh.nal, (size_t)nl * 4); std::memcpy(out->allele_len, gh.alen, 2 * (size_t)nl * 4);
-      std::memcpy(out->ci, gh.ci, 4 * (size_t)nl * 4); std::memcpy(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4);
-      std::memcpy(out->classification, gh.cls, (size_t)nr * 4); std::memcpy(out->read_rank, gh.rank, (size_t)nr * 4);
-      const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
-      pool->parallel_for(nl, 256, [&](int64_t l, int) {
-        if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
-        for (int a = 0; a < out->n_alleles[l]; ++a)
-          std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
-      });
-      for (int64_t l = 0; l < nl; ++l) {
-        if (need[l]) continue;
-        stat_spanning += ((const uint32_t*)gh.nspan)[l];
-        for (int a = 0; a < out->n_alleles[l]; ++a) {
-          job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(out->allele_len[2 * l + a]);
-          span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
-        }
-      }
-      // stage C for these loci starts now, on alleles that already sit in HBM; it is collected after the host path of the others
-      if (!job_set.empty()) {
-        nsp.resize(job_set.size()); pur.resize(job_set.size());
-        if (model_thread.joinable()) model_thread.join();
-        const int64_t tc0 = now_ns();
-        rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
-                         (const uint8_t*)g.blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(), nsp.data(),
-                         out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr, &hmm_pending);
-        if (rc) return rc;
-        tC += now_ns() - tc0;
-        stat_hmm_jobs += (int64_t)job_set.size();
-      }
-    }
-  } else {
-    for (int64_t l = 0; l < nl; ++l) R.push_back(l);
-  }
-  tHost += now_ns() - th_begin;
-
-  // ---------------- host path for the loci in R (second stream for its GPU work: gather, consensus alignments, HMM)
+  if (dev_gt) { const uint8_t* need = (const uint8_t*)gh.need; for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l); }
+  else { R.resize((size_t)nl); for (int64_t l = 0; l < nl; ++l) R[(size_t)l] = l; }
   const int64_t nR = (int64_t)R.size();
+  const int32_t* const sp_s = (const int32_t*)h_ss; const int32_t* const sp_e = (const int32_t*)h_se;  // spans (pinned copies)
+  // host path, first part: spanning reads of the loci in R and the gather of their repeat segments (second stream), enqueued
+  // before anything else so that it does not have to share the GPU with the HMM batch below
+  std::vector<LocusWork> work((size_t)nR);
+  struct K { uint32_t read, s, e; };
+  std::vector<uint64_t> sel_begin((size_t)nR + 1, 0);
+  for (int64_t li = 0; li < nR; ++li) sel_begin[(size_t)li + 1] = sel_begin[(size_t)li] + (in->locus_read_begin[R[(size_t)li] + 1] - in->locus_read_begin[R[(size_t)li]]);
+  std::vector<K> sel((size_t)sel_begin[(size_t)nR]);
+  std::vector<uint32_t> n_sel((size_t)nR, 0);
+  std::vector<Scratch> scratch((size_t)pool->size());
+  std::vector<uint64_t> seg_src, seg_dst; std::vector<uint32_t> seg_len, seg_read; std::vector<const uint8_t*> seg_ptr;
+  uint64_t n_seg = 0, seg_bytes = 0;
+  void* h_seg = nullptr;
   if (nR > 0) {
-    std::vector<LocusWork> work((size_t)nR);
-    struct K { uint32_t read, s, e; };
-    std::vector<K> sel((size_t)nr);
-    std::vector<uint32_t> n_sel((size_t)nR, 0);
-    std::vector<Scratch> scratch((size_t)pool->size());
     int64_t th0 = now_ns();
-    // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184);
-    // each locus writes its selection into its own read range of `sel`
+    // pass 1 (parallel over loci): filter (tr.rs:139-145), stable sort by span length (:157), uniform downsample (:172-184)
     pool->parallel_for(nR, 32, [&](int64_t li, int) {
       const int64_t l = R[(size_t)li];
       if (in->ploidy[l] == 0) return;  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31)
-      K* ks = sel.data() + in->locus_read_begin[l];
+      K* ks = sel.data() + sel_begin[(size_t)li];
       uint32_t n = 0;
       for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) {
-        const int32_t s = out->span_start[r], e = out->span_end[r];
+        const int32_t s = sp_s[r], e = sp_e[r];
         if (s < 0) continue;
         if (s >= F && (int64_t)in->read_len[r] - e >= F) {
           const K kk{(uint32_t)r, (uint32_t)s, (uint32_t)e};
@@ -513,25 +468,20 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       n_sel[(size_t)li] = n;
     });
     // pass 2: flat segment arrays (LocusResult.reads order within each locus)
-    uint64_t n_seg = 0;
     for (int64_t li = 0; li < nR; ++li) { work[(size_t)li].seg_begin = n_seg; n_seg += n_sel[(size_t)li]; work[(size_t)li].seg_end = n_seg; }
-    std::vector<uint64_t> seg_src((size_t)n_seg), seg_dst((size_t)n_seg); std::vector<uint32_t> seg_len((size_t)n_seg), seg_read((size_t)n_seg);
-    std::vector<const uint8_t*> seg_ptr((size_t)n_seg);
+    seg_src.resize((size_t)n_seg); seg_dst.resize((size_t)n_seg); seg_len.resize((size_t)n_seg); seg_read.resize((size_t)n_seg); seg_ptr.resize((size_t)n_seg);
     pool->parallel_for(nR, 64, [&](int64_t li, int) {
-      const int64_t l = R[(size_t)li];
-      const K* ks = sel.data() + in->locus_read_begin[l];
+      const K* ks = sel.data() + sel_begin[(size_t)li];
       uint64_t s = work[(size_t)li].seg_begin;
       for (uint32_t i = 0; i < n_sel[(size_t)li]; ++i, ++s) {
         seg_read[s] = ks[i].read; seg_src[s] = in->read_off[ks[i].read] + ks[i].s; seg_len[s] = ks[i].e - ks[i].s;
       }
     });
-    uint64_t seg_bytes = 0;
     for (uint64_t s = 0; s < n_seg; ++s) { seg_dst[s] = seg_bytes; seg_bytes += seg_len[s]; }
     stat_spanning += (int64_t)n_seg;
     c->dbg_ns[4] = now_ns() - th0;
-    int64_t tg0 = now_ns();
     if (n_seg > 0 && reads_on_device) {
-      void *d_src, *d_dst, *d_len, *d_out, *h_seg;
+      void *d_src, *d_dst, *d_len, *d_out;
       if ((rc = dev_get(c, S_LOCUS_0, (size_t)n_seg * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, (size_t)n_seg * 8, &d_dst)) ||
           (rc = dev_get(c, S_LOCUS_2, (size_t)n_seg * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)seg_bytes + 1, &d_out)) ||
           (rc = pin_get(c, P_SEG0, (size_t)seg_bytes + 1, &h_seg)))
@@ -543,12 +493,71 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream2, ga);
       TRGT_HIP_TRY(c, hipGetLastError());
       TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)seg_bytes, hipMemcpyDeviceToHost, c->stream2));
-      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
-      for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = (const uint8_t*)h_seg + seg_dst[s];
-    } else {
-      for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s];
     }
-    c->dbg_ns[5] = now_ns() - tg0;
+  }
+  // ---------------- stage C for the device-genotyped loci starts now, on alleles that already sit in HBM; it is collected after
+  // the host path of the others
+  std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
+  std::vector<uint32_t> nsp; std::vector<double> pur;
+  if (dev_gt) {
+    const uint8_t* need = (const uint8_t*)gh.need;
+    const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
+    job_set.reserve(2 * (size_t)nl); seq_off.reserve(2 * (size_t)nl); seq_len.reserve(2 * (size_t)nl); span_off.reserve(2 * (size_t)nl);
+    count_off.reserve(2 * (size_t)nl); slot.reserve(2 * (size_t)nl);
+    for (int64_t l = 0; l < nl; ++l) {
+      if (need[l]) continue;
+      stat_spanning += ((const uint32_t*)gh.nspan)[l];
+      for (int a = 0; a < nal[l]; ++a) {
+        job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(alen[2 * l + a]);
+        span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+      }
+    }
+    if (!job_set.empty()) {
+      nsp.resize(job_set.size()); pur.resize(job_set.size());
+      if (model_thread.joinable()) model_thread.join();
+      const int64_t tc0 = now_ns();
+      rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
+                       (const uint8_t*)g.blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(), nsp.data(),
+                       out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr, &hmm_pending);
+      if (rc) return rc;
+      tC += now_ns() - tc0;
+      stat_hmm_jobs += (int64_t)job_set.size();
+    }
+  }
+  // ---------------- publish spans and the device genotyper's results (the GPU is busy with the HMM batch meanwhile)
+  std::memcpy(out->span_start, h_ss, (size_t)nr * 4);
+  std::memcpy(out->span_end, h_se, (size_t)nr * 4);
+  {
+    std::vector<int64_t> part((size_t)pool->size() * 8, 0);
+    pool->parallel_for(nr, 8192, [&](int64_t r, int t) { part[(size_t)t * 8] += (((const uint8_t*)h_hl)[r] != 1) + (((const uint8_t*)h_hr)[r] != 1); });
+    for (int t = 0; t < pool->size(); ++t) stat_flank_jobs += part[(size_t)t * 8];
+  }
+  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)*(uint64_t*)h_cells;
+  if (dev_gt) {
+    const uint8_t* need = (const uint8_t*)gh.need;
+    const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];  // the alleles come back packed: a second, exact-size copy
+    if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
+    if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream2));
+    std::memcpy(out->n_alleles, gh.nal, (size_t)nl * 4); std::memcpy(out->allele_len, gh.alen, 2 * (size_t)nl * 4);
+    std::memcpy(out->ci, gh.ci, 4 * (size_t)nl * 4); std::memcpy(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4);
+    std::memcpy(out->classification, gh.cls, (size_t)nr * 4); std::memcpy(out->read_rank, gh.rank, (size_t)nr * 4);
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));  // gathered segments of R and the packed alleles are here
+    const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
+    pool->parallel_for(nl, 256, [&](int64_t l, int) {
+      if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
+      for (int a = 0; a < out->n_alleles[l]; ++a)
+        std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
+    });
+  } else if (n_seg > 0 && reads_on_device) {
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  }
+  tHost += now_ns() - th_begin;
+
+  // ---------------- host path for the loci in R, second part (second stream for its GPU work: consensus alignments)
+  if (nR > 0) {
+    int64_t th0 = now_ns();
+    if (n_seg > 0 && reads_on_device) { for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = (const uint8_t*)h_seg + seg_dst[s]; }
+    else { for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s]; }
     // front half of the length genotyper, threaded over loci (per-thread scratch, no per-locus allocation)
     int64_t tf0 = now_ns();
     pool->parallel_for(nR, 16, [&](int64_t li, int t) {
