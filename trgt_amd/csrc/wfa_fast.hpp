@@ -384,46 +384,69 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
 // offset falling by one for insertions -- so lane j fetches step j's two candidates and a ballot finds where the
 // chain stops.  Long deletion runs are what the back-trace of a read that lacks the flank consists of.
 // ld: descriptors, ld[s * STRIDE + {0: M, 1: I1, 2: D1, 3: base, 4: lo_alloc | width << 16}].  Runs are pushed (reversed) by lane 0.
+// A candidate is located first (descriptor lookups, no memory access to the history) and its offset fetched afterwards, so that
+// the loads of all candidates of a step go out back to back and the step costs ONE memory round trip, not one per candidate.
+struct BtLoc { uint32_t idx; bool ok; };
 template <int STRIDE>
-__device__ __forceinline__ long long bt_cand_fast(const uint32_t* ld, const uint16_t* __restrict__ A16, int cidx, int s, int kb, int add, int type) {
-  if (s < 0) return (long long)OFF_NULL;
+__device__ __forceinline__ BtLoc bt_locate(const uint32_t* ld, int cidx, int s, int kb) {
+  BtLoc r; r.idx = 0; r.ok = false;
+  if (s < 0) return r;
   const uint32_t* d = ld + s * STRIDE;
-  const uint32_t r = d[cidx];
-  if (kb < pd_lo(r) || kb > pd_hi(r)) return (long long)OFF_NULL;
+  const uint32_t rg = d[cidx];
+  if (kb < pd_lo(rg) || kb > pd_hi(rg)) return r;
   const uint32_t base = d[3], law = d[4];
-  const uint32_t enc = A16[base + (uint32_t)cidx * (law >> 16) + (uint32_t)(kb - (int)(law & 0xFFFFu))];
-  if (enc == 0u) return (long long)OFF_NULL;
+  r.idx = base + (uint32_t)cidx * (law >> 16) + (uint32_t)(kb - (int)(law & 0xFFFFu));
+  r.ok = true;
+  return r;
+}
+__device__ __forceinline__ long long bt_value(const BtLoc& l, uint32_t enc, int add, int type) {
+  if (!l.ok || enc == 0u) return (long long)OFF_NULL;
   return (((long long)((int)enc - 1 + add)) << 4) | type;
 }
 
 template <int STRIDE>
 __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen, int tlen, const FastEnd& E, const uint32_t* ld,
-                                                        const uint16_t* __restrict__ A16, uint32_t* tmp, uint32_t cap) {
+                                                        const uint16_t* __restrict__ A16, uint32_t* tmp, uint32_t cap, uint32_t* lruns, uint32_t lcap) {
   const int lane = threadIdx.x & 63;
   const int koff = plen + 2;
   const int x = pen.x, oe = pen.o1 + pen.e1, e = pen.e1;
   int mt = CM, s = E.score, k = E.k, off = E.off;
   int h = off, v = off - k, nt = 0;
-  auto cand = [&](int cidx, int ss, int kk, int add, int type) { return bt_cand_fast<STRIDE>(ld, A16, cidx, ss, kk + koff, add, type); };
-  if (lane == 0) { rle_push(tmp, nt, cap, 2u, plen - v); rle_push(tmp, nt, cap, 1u, tlen - h); }
+  // run-length builder with the open run in registers: the run list in HBM is write-only (rle_push would read the last entry
+  // back, a memory round trip per operation); uniform values, lane 0 stores
+  uint32_t cur_code = 0; int cur_len = 0;
+  auto push = [&](uint32_t code, int len) {
+    if (len <= 0) return;
+    if (cur_len > 0 && code == cur_code) { cur_len += len; return; }
+    if (cur_len > 0) {
+      const uint32_t run = ((uint32_t)cur_len << 4) | cur_code;
+      if (lane == 0 && (uint32_t)nt < cap) { tmp[nt] = run; if ((uint32_t)nt < lcap) lruns[nt] = run; }  // HBM copy: write-only; LDS copy: what the epilogue reads
+      if ((uint32_t)nt < cap) ++nt;
+    }
+    cur_code = code; cur_len = len;
+  };
+  auto loc = [&](int cidx, int ss, int kk) { return bt_locate<STRIDE>(ld, cidx, ss, kk + koff); };
+  push(2u, plen - v); push(1u, tlen - h);
   while (v > 0 && h > 0 && s > 0) {
     if (mt == CM) {
-      long long best = cand(0, s - x, k, +1, 9);
-      best = max(best, cand(2, s - e, k + 1, 0, 6));
-      best = max(best, cand(0, s - oe, k + 1, 0, 5));
-      best = max(best, cand(1, s - e, k - 1, +1, 2));
-      best = max(best, cand(0, s - oe, k - 1, +1, 1));
+      const BtLoc l0 = loc(0, s - x, k), l1 = loc(2, s - e, k + 1), l2 = loc(0, s - oe, k + 1), l3 = loc(1, s - e, k - 1), l4 = loc(0, s - oe, k - 1);
+      const uint32_t e0 = A16[l0.idx], e1 = A16[l1.idx], e2 = A16[l2.idx], e3 = A16[l3.idx], e4 = A16[l4.idx];  // index 0 when not located
+      long long best = bt_value(l0, e0, +1, 9);
+      best = max(best, bt_value(l1, e1, 0, 6));
+      best = max(best, bt_value(l2, e2, 0, 5));
+      best = max(best, bt_value(l3, e3, +1, 2));
+      best = max(best, bt_value(l4, e4, +1, 1));
       if (best < 0) break;
       const int best_off = (int)(best >> 4), type = (int)(best & 0xF);
-      if (lane == 0) rle_push(tmp, nt, cap, 7u, off - best_off);
+      push(7u, off - best_off);
       off = best_off; h = off; v = off - k;
       if (v <= 0 || h <= 0) break;
       switch (type) {
-        case 9: if (lane == 0) rle_push(tmp, nt, cap, 8u, 1); s -= x; --off; break;
-        case 1: if (lane == 0) rle_push(tmp, nt, cap, 1u, 1); s -= oe; --k; --off; break;
-        case 2: if (lane == 0) rle_push(tmp, nt, cap, 1u, 1); s -= e; mt = CI1; --k; --off; break;
-        case 5: if (lane == 0) rle_push(tmp, nt, cap, 2u, 1); s -= oe; ++k; break;
-        default: if (lane == 0) rle_push(tmp, nt, cap, 2u, 1); s -= e; mt = CD1; ++k; break;
+        case 9: push(8u, 1); s -= x; --off; break;
+        case 1: push(1u, 1); s -= oe; --k; --off; break;
+        case 2: push(1u, 1); s -= e; mt = CI1; --k; --off; break;
+        case 5: push(2u, 1); s -= oe; ++k; break;
+        default: push(2u, 1); s -= e; mt = CD1; ++k; break;
       }
       h = off; v = off - k;
     } else {
@@ -432,37 +455,45 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
       const int sj = s - lane * e, kj = del ? k + lane : k - lane;
       const bool alive = (del ? (v - lane > 0 && h > 0) : (h - lane > 0 && v > 0)) && sj > 0;
       long long ce = (long long)OFF_NULL, co = (long long)OFF_NULL;
-      if (alive) {
-        ce = del ? cand(2, sj - e, kj + 1, 0, 6) : cand(1, sj - e, kj - 1, +1, 2);
-        co = del ? cand(0, sj - oe, kj + 1, 0, 5) : cand(0, sj - oe, kj - 1, +1, 1);
+      {
+        BtLoc le = del ? loc(2, sj - e, kj + 1) : loc(1, sj - e, kj - 1), lo = del ? loc(0, sj - oe, kj + 1) : loc(0, sj - oe, kj - 1);
+        if (!alive) { le.ok = false; le.idx = 0; lo.ok = false; lo.idx = 0; }
+        const uint32_t ee = A16[le.idx], eo = A16[lo.idx];
+        ce = del ? bt_value(le, ee, 0, 6) : bt_value(le, ee, +1, 2);
+        co = del ? bt_value(lo, eo, 0, 5) : bt_value(lo, eo, +1, 1);
       }
       const bool cont = alive && ce >= 0 && ce > co;  // the extension candidate is the maximum
       const unsigned long long stop = __ballot(!cont);
       const int j = stop ? __ffsll((long long)stop) - 1 : 64;
       if (j > 0) {  // j pure extension steps
-        if (lane == 0) rle_push(tmp, nt, cap, del ? 2u : 1u, j);
+        push(del ? 2u : 1u, j);
         s -= j * e;
         if (del) { k += j; } else { k -= j; off -= j; }
         h = off; v = off - k;
         continue;
       }
       // ---- the chain stops right here: one ordinary step (gap open, or no source at all)
-      const long long cext = del ? cand(2, s - e, k + 1, 0, 6) : cand(1, s - e, k - 1, +1, 2);
-      const long long copn = del ? cand(0, s - oe, k + 1, 0, 5) : cand(0, s - oe, k - 1, +1, 1);
+      const BtLoc lx = del ? loc(2, s - e, k + 1) : loc(1, s - e, k - 1), ln = del ? loc(0, s - oe, k + 1) : loc(0, s - oe, k - 1);
+      const uint32_t ex = A16[lx.idx], en = A16[ln.idx];
+      const long long cext = del ? bt_value(lx, ex, 0, 6) : bt_value(lx, ex, +1, 2);
+      const long long copn = del ? bt_value(ln, en, 0, 5) : bt_value(ln, en, +1, 1);
       const long long best = max(cext, copn);
       if (best < 0) break;
-      if (lane == 0) rle_push(tmp, nt, cap, del ? 2u : 1u, 1);
+      push(del ? 2u : 1u, 1);
       if (best == cext) s -= e; else { s -= oe; mt = CM; }
       if (del) ++k; else { --k; --off; }
       h = off; v = off - k;
     }
   }
-  if (lane == 0) {
-    if (mt == CM && v > 0 && h > 0) { const int n = min(v, h); rle_push(tmp, nt, cap, 7u, n); v -= n; h -= n; }
-    rle_push(tmp, nt, cap, 2u, v);
-    rle_push(tmp, nt, cap, 1u, h);
+  if (mt == CM && v > 0 && h > 0) { const int n = min(v, h); push(7u, n); v -= n; h -= n; }
+  push(2u, v);
+  push(1u, h);
+  if (cur_len > 0) {
+    const uint32_t run = ((uint32_t)cur_len << 4) | cur_code;
+    if (lane == 0 && (uint32_t)nt < cap) { tmp[nt] = run; if ((uint32_t)nt < lcap) lruns[nt] = run; }
+    if ((uint32_t)nt < cap) ++nt;
   }
-  return nt;  // meaningful on lane 0
+  return nt;  // uniform
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -544,9 +575,17 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     cells_acc += E.cells;
     const bool ok = E.status == ST_END_REACHED;
     int nrun = 0;
+    // The run list of the back-trace (reversed) lives in the idle ring area of LDS, behind the staged descriptors, with the run
+    // start positions behind it; the HBM copies are only read when a list does not fit there.
+    uint32_t* lruns = reinterpret_cast<uint32_t*>(ring);
+    uint32_t lcap = 0;
     if (ok && a.kp.scope_alignment && !a.fast_dbg) {
       // back-trace by wave 0; the level descriptors are staged in the (now idle) ring area of LDS when they fit
-      const bool fits = (uint32_t)(E.score + 1) * FD_LDS_STRIDE * 4u <= a.fast_ring_bytes;
+      const uint32_t ld_bytes = ((uint32_t)(E.score + 1) * FD_LDS_STRIDE * 4u + 15u) & ~15u;
+      const bool fits = ld_bytes <= a.fast_ring_bytes;
+      const uint32_t run_base = fits ? ld_bytes : 0u;
+      lruns = reinterpret_cast<uint32_t*>(lds_dyn + run_base);
+      lcap = (a.fast_ring_bytes - run_base) / 8u;  // runs [0, lcap), run starts [lcap, 2 lcap)
       __syncthreads();  // every wave has left the level loop (ring idle), thread 0's descriptor stores are done
       int nt = 0;
       if (fits) {
@@ -556,16 +595,19 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
           ld[i] = gd[(size_t)lvl * FD_STRIDE + c5];
         }
         __syncthreads();
-        if (tid < 64) nt = wf_backtrace_fast_affine<FD_LDS_STRIDE>(pen, plen, tlen, E, ld, A16g, rle_tmp, a.rle_cap);
+        if (tid < 64) nt = wf_backtrace_fast_affine<FD_LDS_STRIDE>(pen, plen, tlen, E, ld, A16g, rle_tmp, a.rle_cap, lruns, lcap);
       } else if (tid < 64) {
-        nt = wf_backtrace_fast_affine<FD_STRIDE>(pen, plen, tlen, E, gd, A16g, rle_tmp, a.rle_cap);
+        nt = wf_backtrace_fast_affine<FD_STRIDE>(pen, plen, tlen, E, gd, A16g, rle_tmp, a.rle_cap, lruns, lcap);
       }
       if (tid == 0) fs.rle_n = nt;
       __syncthreads();
       nrun = rfl(fs.rle_n);
-      for (int r = tid; r < nrun; r += T) rle_out[r] = rle_tmp[nrun - 1 - r];  // forward order (runs are already merged)
+      if ((uint32_t)nrun > lcap) for (int r = tid; r < nrun; r += T) rle_out[r] = rle_tmp[nrun - 1 - r];  // forward order, through HBM
       PROF_MARK(3);
     }
+    const bool lds_runs = (uint32_t)nrun <= lcap;
+    uint32_t* const lstart = lruns + lcap;
+    auto run_at = [&](int r) -> uint32_t { return lds_runs ? lruns[nrun - 1 - r] : rle_out[r]; };  // forward order
     __syncthreads();
     PROF_MARK(4);
     // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations (as in wfa_kernel)
@@ -576,8 +618,8 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       uint32_t pi = 0, ti = 0, ps = 0, pe = 0, ts = 0, te = 0, nm = 0, total = 0;
       bool started = false;
       for (int r = 0; r < nrun; ++r) {
-        const uint32_t en = rle_out[r], len = en >> 4, code = en & 0xF;
-        run_start[r] = total;
+        const uint32_t en = run_at(r), len = en >> 4, code = en & 0xF;
+        if (a.ops) { if (lds_runs) lstart[r] = total; else run_start[r] = total; }
         total += len;
         if (code == 1u) ti += len;
         else if (code == 2u) pi += len;
@@ -590,14 +632,14 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       if (a.ops_len) a.ops_len[o] = total;
       fs.total_ops = (int)total;
     }
-    if (a.cigar) for (int r = tid; r < nrun; r += T) a.cigar[job.cigar_off + r] = rle_out[r];
+    if (a.cigar) for (int r = tid; r < nrun; r += T) a.cigar[job.cigar_off + r] = run_at(r);
     if (a.ops && nrun > 0) {
       __syncthreads();
       const uint32_t total = (uint32_t)fs.total_ops;
       for (uint32_t p = tid; p < total; p += T) {
         int lo = 0, hi = nrun - 1;  // last run whose start <= p
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (run_start[mid] <= p) lo = mid; else hi = mid - 1; }
-        const uint32_t code = rle_out[lo] & 0xF;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((lds_runs ? lstart[mid] : run_start[mid]) <= p) lo = mid; else hi = mid - 1; }
+        const uint32_t code = run_at(lo) & 0xF;
         a.ops[job.ops_off + p] = code == 7u ? 'M' : code == 8u ? 'X' : code == 1u ? 'I' : 'D';
       }
     }
