@@ -99,7 +99,8 @@ struct FastTerm {  // termination record of one score level (triple-buffered)
 };
 
 struct FastShared {
-  uint4 fdesc[RING];    // packed descriptors {M, I, D, -} of the last RING levels
+  uint4 fdesc[RING];    // packed descriptors {M, I, D, history base} of the last RING levels
+  uint32_t flaw[RING];  // ... and their lo_alloc | width << 16: a back-trace of fewer than RING levels needs nothing from HBM but offsets
   uint4 wred[2][16];    // per-wave trim records, double-buffered
   FastTerm fterm[3];
   int job, slot, rle_n, total_ops;
@@ -212,7 +213,8 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
       } else if (ak_b >= pd_lo(cM) && ak_b <= pd_hi(cM) && rfl(Tm.end_val) >= tlen) { end_reached = true; end_k = ak_b - koff; end_off = tlen; }
     }
     if (tid == 0) {  // publish level s: LDS ring for the recurrences of later levels, HBM copy for the back-trace
-      fs.fdesc[s & (RING - 1)] = make_uint4(cM, cI, cD, 0u);
+      fs.fdesc[s & (RING - 1)] = make_uint4(cM, cI, cD, base_c);
+      fs.flaw[s & (RING - 1)] = lo_c | (w_c << 16);
       if (s < n_slots) {
         uint32_t* g = gd + (size_t)s * FD_STRIDE;
         *reinterpret_cast<uint4*>(g) = make_uint4(cM, cI, cD, base_c);
@@ -394,7 +396,7 @@ __device__ __forceinline__ BtLoc bt_locate(const uint32_t* ld, int cidx, int s, 
   const uint32_t* d = ld + s * STRIDE;
   const uint32_t rg = d[cidx];
   if (kb < pd_lo(rg) || kb > pd_hi(rg)) return r;
-  const uint32_t base = d[3], law = d[4];
+  const uint32_t base = d[3], law = STRIDE == 4 ? g_fsh.flaw[s] : d[4];  // STRIDE 4: the fdesc / flaw rings themselves (score < RING)
   r.idx = base + (uint32_t)cidx * (law >> 16) + (uint32_t)(kb - (int)(law & 0xFFFFu));
   r.ok = true;
   return r;
@@ -581,14 +583,17 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     uint32_t lcap = 0;
     if (ok && a.kp.scope_alignment && !a.fast_dbg) {
       // back-trace by wave 0; the level descriptors are staged in the (now idle) ring area of LDS when they fit
-      const uint32_t ld_bytes = ((uint32_t)(E.score + 1) * FD_LDS_STRIDE * 4u + 15u) & ~15u;
+      const bool in_ring = E.score < RING;  // every level's descriptor is still in the LDS rings: nothing to stage
+      const uint32_t ld_bytes = in_ring ? 0u : ((uint32_t)(E.score + 1) * FD_LDS_STRIDE * 4u + 15u) & ~15u;
       const bool fits = ld_bytes <= a.fast_ring_bytes;
       const uint32_t run_base = fits ? ld_bytes : 0u;
       lruns = reinterpret_cast<uint32_t*>(lds_dyn + run_base);
       lcap = (a.fast_ring_bytes - run_base) / 8u;  // runs [0, lcap), run starts [lcap, 2 lcap)
       __syncthreads();  // every wave has left the level loop (ring idle), thread 0's descriptor stores are done
       int nt = 0;
-      if (fits) {
+      if (in_ring) {
+        if (tid < 64) nt = wf_backtrace_fast_affine<4>(pen, plen, tlen, E, reinterpret_cast<const uint32_t*>(fs.fdesc), A16g, rle_tmp, a.rle_cap, lruns, lcap);
+      } else if (fits) {
         uint32_t* ld = reinterpret_cast<uint32_t*>(ring);
         for (int i = tid; i < (E.score + 1) * FD_LDS_STRIDE; i += T) {
           const int lvl = i / FD_LDS_STRIDE, c5 = i - lvl * FD_LDS_STRIDE;
