@@ -27,7 +27,9 @@ struct ScanArgs {
   uint64_t n_jobs;             // 2 * n_reads
   int32_t flank_len;
   int32_t* pos;                // [n_jobs] leftmost exact start or -1
-  JobDev* wfa_jobs; uint32_t* wfa_count;
+  JobDev* wfa_jobs; uint32_t* wfa_count;  // fallback alignments: job list and its length (wfa_count[0])
+  JobDev* wfa_jobs_long; uint32_t long_tlen;  // reads longer than long_tlen go to a second list (wfa_count[1]): they would not fit the
+                                              // LDS budget of the dedicated kernel and must not drag the whole batch onto the generic one
 };
 
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {
@@ -70,11 +72,12 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
   if (lane == 0) {
     a.pos[j] = found;
     if (found < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
-      const uint32_t slot = atomicAdd(a.wfa_count, 1u);
+      const bool lng = (uint32_t)n > a.long_tlen;
+      const uint32_t slot = atomicAdd(a.wfa_count + (lng ? 1 : 0), 1u);
       JobDev jd;
       jd.pat_off = a.piece_off[2 * (uint64_t)a.read_locus[r] + side]; jd.txt_off = a.read_off[r];
       jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
-      a.wfa_jobs[slot] = jd;
+      (lng ? a.wfa_jobs_long : a.wfa_jobs)[slot] = jd;
     }
   }
 }
@@ -148,11 +151,11 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
       const uint64_t j = 2 * r + side;
       a.pos[j] = found[side];
       if (found[side] < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
-        const uint32_t slot = atomicAdd(&l_n, 1u);
         JobDev jd;
         jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
         jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
-        l_jobs[slot] = jd;
+        if ((uint32_t)n > a.long_tlen) a.wfa_jobs_long[atomicAdd(a.wfa_count + 1, 1u)] = jd;  // rare: straight to the second list
+        else l_jobs[atomicAdd(&l_n, 1u)] = jd;
       }
     }
   }
@@ -206,6 +209,14 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
   sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos;
   sa.wfa_jobs = (JobDev*)d_wjobs; sa.wfa_count = (uint32_t*)d_count;
+  // reads up to long_tlen keep the dedicated kernel at 4 workgroups per CU (LDS: ring + windows <= ~39 KB per alignment)
+  const int ring_slots = std::max(p.mism, p.gapo + p.gape) + 1 + 2 * (p.gape + 1);
+  const int64_t fit = 39000 / (2 * (int64_t)ring_slots + 4) - p.flank_len - 16;
+  const uint32_t long_tlen = (uint32_t)std::max<int64_t>(fit, 64);
+  const bool has_long = max_read_len > long_tlen;
+  void* d_wjobs_long = nullptr;
+  if (has_long && (rc = dev_get(c, S_FS_WFAJOBS_LONG, n_jobs * sizeof(JobDev), &d_wjobs_long))) return rc;
+  sa.wfa_jobs_long = (JobDev*)d_wjobs_long; sa.long_tlen = has_long ? long_tlen : 0xFFFFFFFFu;
   {
     KTimer t(c, TRGT_K_FLANK_SCAN);
     if (p.flank_len >= 4) hipLaunchKernelGGL(flank_scan_wide_kernel, dim3((unsigned)((n_reads + SCAN_READS_PER_WG - 1) / SCAN_READS_PER_WG)), dim3(256), 0, c->stream, sa);
@@ -225,11 +236,19 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   WfaLaunch L;
   L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
   L.pat_base = d_flank; L.txt_base = d_reads;
-  L.max_plen = p.flank_len; L.max_tlen = max_read_len; L.max_sum = (int64_t)p.flank_len + max_read_len;
+  const uint32_t short_max = has_long ? long_tlen : max_read_len;
+  L.max_plen = p.flank_len; L.max_tlen = short_max; L.max_sum = (int64_t)p.flank_len + short_max;
   L.threads = getenv("TRGT_FLANK_THREADS") ? atoi(getenv("TRGT_FLANK_THREADS")) : 256;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
   if ((rc = wfa_launch(c, wp, L))) return rc;
+  if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
+    WfaLaunch L2 = L;
+    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1;
+    L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
+    L2.keep_cells = true;
+    if ((rc = wfa_launch(c, wp, L2))) return rc;
+  }
   CombineArgs ca;
   ca.n_reads = (uint64_t)n_reads; ca.flank_len = p.flank_len;
   ca.threshold = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;  // span_locater.rs:46

@@ -492,7 +492,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   if ((rc = dev_get(c, L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 16, &d_cells))) return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
+  if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
   a.jobs = L.jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host; a.n_jobs_dev = L.n_jobs_dev;
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
