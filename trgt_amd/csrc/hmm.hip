@@ -192,17 +192,27 @@ __device__ __forceinline__ void hmm_sync(int nthr) {
 // The fill reads one base per column and the traceback / decode of thread 0 is a chain of dependent loads: served from HBM each
 // of them costs a memory round trip, which was most of this kernel's time.
 constexpr int HMM_STAGE_QLEN = 2048;
-template <bool STAGE>
+// SUB: lanes per allele.  64 (or more: one thread per state, several waves for large motif sets) is the general case; SUB = 32
+// packs TWO alleles into one wave when the model has at most 32 states (a single STR motif of up to 8 bases): the kernel is bound
+// by instruction issue and most passes of a column keep only one or two lanes busy, so halving the waves nearly halves its time.
+// The two halves run the same code on their own LDS regions; their control flow may diverge (different allele lengths).
+template <bool STAGE, int SUB>
 __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets,
                                    const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
                                    uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws,
                                    uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
                                    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
                                    uint32_t* __restrict__ counts, double* __restrict__ purity,
-                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, uint32_t stage_qcap) {
-  extern __shared__ __align__(16) unsigned char lds[];
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const HmmJobDev job = jobs[blockIdx.x];
+                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, uint32_t stage_qcap,
+                                   uint32_t n_launch_jobs, uint32_t lds_per_job) {
+  extern __shared__ __align__(16) unsigned char lds_all[];
+  const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
+  const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
+  const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
+  const uint32_t jidx = SUB == 32 ? blockIdx.x * 2u + (uint32_t)grp : blockIdx.x;
+  if (jidx >= n_launch_jobs) return;
+  unsigned char* const lds = lds_all + (size_t)grp * lds_per_job;
+  const HmmJobDev job = jobs[jidx];
   const HmmSetDev set = sets[job.set];
   const int S = (int)set.S, nb = (int)set.n_blocks, n_motifs = nb - 1;
   const int qlen = (int)job.seq_len, L = qlen + 2;
@@ -268,7 +278,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
-  hmm_sync(nthr);
+  hmm_sync(sync_n);
 
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
@@ -294,7 +304,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       }
       cur[st] = best;
     }
-    hmm_sync(nthr);
+    hmm_sync(sync_n);
     for (int lev = 1; lev <= n_levels; ++lev) {
       if (act && level == lev) {
         if (n_in == 0xFF) {  // run-end state: predecessors are the block end states, in block order
@@ -312,7 +322,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         }
         cur[st] = best;
       }
-      hmm_sync(nthr);
+      hmm_sync(sync_n);
     }
     if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
     double* t = prev; prev = cur; cur = t;
@@ -320,7 +330,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
   }
-  hmm_sync(nthr);
+  hmm_sync(sync_n);
 
   // ---- traceback (hmm_model.rs:125-142) fused with get_events/calc_purity (events.rs:17-86, purity.rs:6-41)
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
@@ -337,7 +347,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       const int n16 = (c1 - c0) * Spad / 16;
       for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
     }
-    hmm_sync(nthr);
+    hmm_sync(sync_n);
     if (tid == 0) {
       int state = tb_state, idx = tb_idx, np = tb_npath, nv = tb_nvisit, edit = tb_edit, ref = tb_ref, nxt = tb_next, vb1 = tb_vb1;
       while (state != 0 && idx >= c0) {
@@ -377,7 +387,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (state == 0) { if (pbuf && np < pcap) pbuf[pcap - 1 - np] = 0; ++np; tb_done = 1; }
       tb_state = state; tb_idx = idx; tb_npath = np; tb_nvisit = nv; tb_edit = edit; tb_ref = ref; tb_next = nxt; tb_vb1 = vb1;
     }
-    hmm_sync(nthr);
+    hmm_sync(sync_n);
   }
   const int np = tb_npath;
   // ---- state path: shift the reversed tail to the front (forward order)
@@ -387,9 +397,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       const int f = base + tid;
       uint16_t v = 0;
       if (f < n) v = pbuf[shift + f];
-      hmm_sync(nthr);
+      hmm_sync(sync_n);
       if (f < n) pbuf[f] = v;
-      hmm_sync(nthr);
+      hmm_sync(sync_n);
     }
   }
   // ---- decode (thread 0): purity, remove_imperfect_motifs(.., 6), label_motifs, skip filter, counts, collapse
@@ -429,7 +439,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     n_spans[job.job_index] = (uint32_t)ns;
   }
   if (STAGE) {
-    hmm_sync(nthr);
+    hmm_sync(sync_n);
     for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   }
 }
@@ -600,7 +610,8 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
   }
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
-  auto job_class = [&](const HmmJobDev& j) { return 2u * ((sets[j.set].S + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
+  // class 0: at most 32 states (two alleles per wave); else the number of waves per allele; odd = allele too long for LDS staging
+  auto job_class = [&](const HmmJobDev& j) { const uint32_t S_ = sets[j.set].S; return 2u * (S_ <= 32 ? 0u : (S_ + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
   std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
@@ -667,22 +678,23 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
       maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); maxq = std::max(maxq, jobs[e].seq_len); ++e;
     }
     const uint32_t qcap = stage ? maxq : 0;
-    const size_t lds = hmm_lds_bytes(maxS, maxnb, qcap);
+    const bool half = cls == 0;  // two alleles per wave
+    const size_t lds_job = (hmm_lds_bytes(maxS, maxnb, qcap) + 15) & ~(size_t)15;
+    const size_t lds = half ? 2 * lds_job : lds_job;
     if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
-    if (lds > 64 * 1024)
-      TRGT_HIP_TRY(c, hipFuncSetAttribute(stage ? (const void*)hmm_viterbi_kernel<true> : (const void*)hmm_viterbi_kernel<false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* kfn = half ? (stage ? (const void*)hmm_viterbi_kernel<true, 32> : (const void*)hmm_viterbi_kernel<false, 32>)
+                           : (stage ? (const void*)hmm_viterbi_kernel<true, 64> : (const void*)hmm_viterbi_kernel<false, 64>);
+    if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTimer t(c, TRGT_K_HMM);
-    if (stage)
-      hipLaunchKernelGGL(hmm_viterbi_kernel<true>, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
-                         (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
-                         (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
-                         o_pur.dev, o_edit.dev, o_maxd.dev, qcap);
-    else
-      hipLaunchKernelGGL(hmm_viterbi_kernel<false>, dim3((unsigned)(e - i)), dim3(64 * cls), lds, c->stream,
-                         (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq,
-                         (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev,
-                         o_pur.dev, o_edit.dev, o_maxd.dev, 0u);
+    const uint32_t nj = (uint32_t)(e - i);
+    const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * cls);
+#define TRGT_HMM_LAUNCH(ST, SB)                                                                                                     \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<ST, SB>), grid, block, lds, c->stream, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, \
+                       (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev,    \
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, qcap, nj, (uint32_t)lds_job)
+    if (half) { if (stage) TRGT_HMM_LAUNCH(true, 32); else TRGT_HMM_LAUNCH(false, 32); }
+    else { if (stage) TRGT_HMM_LAUNCH(true, 64); else TRGT_HMM_LAUNCH(false, 64); }
+#undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(i == 0 ? cells : 0);
     i = e;
