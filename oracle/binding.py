@@ -26,7 +26,8 @@ class WfaParams(C.Structure):
 
 class LocusParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("min_flank_id_frac", C.c_double), ("max_depth", C.c_int32),
-                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("ploidy", C.c_int32)]
+                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("ploidy", C.c_int32),
+                ("genotyper", C.c_int32), ("min_read_qual", C.c_double)]
 
 
 def build(force=False):
@@ -246,8 +247,9 @@ def find_spans(piece, reads, mism=2, gapo=5, gape=1, threshold=175.0):
 
 
 def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250, min_flank_id_frac=0.7, max_depth=250,
-                  scoring=(2, 5, 1), ploidy=2):
-    p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], ploidy)
+                  scoring=(2, 5, 1), ploidy=2, genotyper=0, min_read_qual=0.98, read_qual=None):
+    p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], ploidy, genotyper, min_read_qual)
+    rq = None if read_qual is None else np.ascontiguousarray(read_qual, np.float64)
     mb, mo = motif_blob(motifs)
     blob = _u8(b"".join(reads))
     lens = np.array([len(r) for r in reads], np.uint32)
@@ -268,7 +270,7 @@ def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250,
     rc = lib().orc_locus_analyze(C.byref(p), _p(lf), len(lf), _p(rf), len(rf), _p(tr), len(tr), _p(mb), _p(mo), len(motifs),
                                  C.c_int64(n), _p(blob), _p(off), _p(lens), _p(ss), _p(se), C.byref(n_alleles), a0, a1, cap,
                                  _p(gt_size), _p(gt_ci), C.byref(n_sp), _p(kept), _p(cls), _p(by_hap), mc, ms, ap, scap,
-                                 _p(stats))
+                                 _p(stats), _p(rq) if rq is not None else None)
     assert rc == 0, rc
     na, k = n_alleles.value, n_sp.value
     alleles = [a0.value.decode(), a1.value.decode()][:na]
@@ -279,4 +281,22 @@ def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250,
                 ALLR=",".join("%d-%d" % (gt_ci[2 * i], gt_ci[2 * i + 1]) for i in range(na)),
                 SD=",".join(str(int(v)) for v in by_hap[:na]),
                 stats=dict(wfa_cells=int(stats[0]), viterbi_cells=int(stats[1]), n_wfa_flank=int(stats[2]),
-                           n_wfa_cons=int(stats[3]), bytes_io=int(stats[4])))
+                           n_wfa_cons=int(stats[3]), bytes_io=int(stats[4]), n_wfa_ed=int(stats[5]),
+                           n_purity=int(stats[6])))
+
+
+def ward_linkage(dists, n):
+    """kodama-style linkage(.., Method::Ward) on a condensed matrix.  Returns (steps[n-1,3] = cluster1, cluster2, size;
+    dissimilarity[n-1]; the matrix as the call leaves it)."""
+    d = np.ascontiguousarray(dists, np.float64).copy()
+    st = np.zeros((max(n - 1, 1), 3), np.int32)
+    di = np.zeros(max(n - 1, 1), np.float64)
+    k = lib().orc_ward_linkage(_p(d), int(n), _p(st), _p(di))
+    return st[:k], di[:k], d
+
+
+def cluster_groups(dists, n):
+    d = np.ascontiguousarray(dists, np.float64).copy()
+    g = np.zeros(n, np.int32)
+    k = lib().orc_cluster_groups(_p(d), int(n), _p(g))
+    return k, g, d

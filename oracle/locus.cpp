@@ -9,6 +9,14 @@
 //   genotype_size::genotype         src/trgt/genotype/genotype_size.rs:6-125
 //   diploid / haploid genotype      diploid.rs:5-103, haploid.rs:3-30
 //   label_with_hmm, allele assembly src/trgt/workflows/tr.rs:77-101,454-492
+//   filter_impure_trs               src/trgt/workflows/tr.rs:400-452
+//   genotype_cluster::genotype      src/trgt/genotype/genotype_cluster.rs:12-286
+//   Ward linkage                    kodama 0.3.0 (crates.io, Cargo.lock:839-842) -- UN-VENDORED: restated from the
+//                                   published NN-chain algorithm (Muellner 2011, fastcluster; kodama is its Rust port).
+//                                   PARITY UNPINNED: the reference holds no test of cluster(); the dendrogram is checked
+//                                   against scipy.cluster.hierarchy.linkage(method="ward") in tests/test_oracle_cluster.py,
+//                                   the in-place mutation of the distance matrix (read back by central_read,
+//                                   genotype_cluster.rs:27-29,74,82-83) follows the NN-chain update order.
 //   MC / MS / AP / AL / ALLR / SD   src/trgt/writers/write_vcf.rs:286-377
 // genotype_flank::genotype (tr.rs:70-75) returns None for such reads (no HP
 // tags -> get_trs_with_hp None; no mismatch offsets -> one candidate genotype,
@@ -238,6 +246,218 @@ static SizeGt genotype_size(int ploidy, const std::vector<std::string>& seqs, in
   return out;
 }
 
+// ---- kodama 0.3.0 linkage(dists, n, Method::Ward), restated --------------------------------------------------------
+// Ward in kodama: square the condensed matrix in place, NN-chain with Lance-Williams updates written into the
+// surviving (larger-index) cluster's row/column, stable sort of the steps by dissimilarity, SciPy-style relabelling
+// through a union-find, then sqrt of the step dissimilarities.  The matrix stays mutated (squared + updated).
+struct WardStep { int c1, c2; double diss; int size; };
+
+static inline size_t cidx(int n, int i, int j) {  // i < j
+  return (size_t)n * (size_t)i - (size_t)i * ((size_t)i + 1) / 2 + (size_t)(j - i - 1);
+}
+
+std::vector<WardStep> ward_linkage(std::vector<double>& dis, int n) {
+  std::vector<WardStep> steps;
+  for (double& d : dis) d = d * d;
+  if (n < 2) return steps;
+  std::vector<char> active((size_t)n, 1);
+  std::vector<int> sizes((size_t)n, 1), chain;
+  auto D = [&](int i, int j) -> double& { return dis[cidx(n, i, j)]; };
+  for (int it = 0; it < n - 1; ++it) {
+    int a, b; double mn;
+    if (chain.size() < 4) {
+      a = 0; while (!active[(size_t)a]) ++a;
+      chain.clear(); chain.push_back(a);
+      b = a + 1; while (!active[(size_t)b]) ++b;
+      mn = D(a, b);
+      for (int i = b + 1; i < n; ++i) if (active[(size_t)i] && D(a, i) < mn) { mn = D(a, i); b = i; }
+    } else {
+      chain.pop_back(); chain.pop_back();
+      b = chain.back(); chain.pop_back();
+      a = chain.back();
+      mn = a < b ? D(a, b) : D(b, a);
+    }
+    while (true) {
+      chain.push_back(b);
+      for (int x = 0; x < b; ++x) if (active[(size_t)x] && D(x, b) < mn) { mn = D(x, b); a = x; }
+      for (int x = b + 1; x < n; ++x) if (active[(size_t)x] && D(b, x) < mn) { mn = D(b, x); a = x; }
+      b = a;
+      a = chain.back();
+      if (b == chain[chain.size() - 2]) break;
+    }
+    if (a > b) std::swap(a, b);
+    const double sa = (double)sizes[(size_t)a], sb = (double)sizes[(size_t)b];
+    auto upd = [&](double da, double& db, int x) {
+      const double sx = (double)sizes[(size_t)x];
+      const double num = ((sx + sa) * da) + ((sx + sb) * db) - (sx * mn);
+      db = num / (sa + sb + sx);
+    };
+    for (int x = 0; x < a; ++x) if (active[(size_t)x]) upd(D(x, a), D(x, b), x);
+    for (int x = a + 1; x < b; ++x) if (active[(size_t)x]) upd(D(a, x), D(x, b), x);
+    for (int x = b + 1; x < n; ++x) if (active[(size_t)x]) upd(D(a, x), D(b, x), x);
+    sizes[(size_t)b] += sizes[(size_t)a];
+    active[(size_t)a] = 0;
+    steps.push_back({a, b, mn, sizes[(size_t)b]});
+  }
+  std::stable_sort(steps.begin(), steps.end(), [](const WardStep& x, const WardStep& y) { return x.diss < y.diss; });
+  std::vector<int> parent((size_t)(2 * n - 1), -1);
+  auto find = [&](int x) { int r = x; while (parent[(size_t)r] >= 0) r = parent[(size_t)r]; while (parent[(size_t)x] >= 0) { const int nx = parent[(size_t)x]; parent[(size_t)x] = r; x = nx; } return r; };
+  auto csize = [&](int label) { return label < n ? 1 : steps[(size_t)(label - n)].size; };
+  for (size_t i = 0; i < steps.size(); ++i) {
+    int ra = find(steps[i].c1), rb = find(steps[i].c2);
+    if (ra > rb) std::swap(ra, rb);
+    steps[i] = {ra, rb, steps[i].diss, csize(ra) + csize(rb)};
+    parent[(size_t)ra] = parent[(size_t)rb] = n + (int)i;
+  }
+  for (auto& s : steps) s.diss = std::sqrt(s.diss);
+  return steps;
+}
+
+// genotype_cluster.rs:154-227
+static std::vector<std::vector<int>> cluster_groups(int n, std::vector<double>& dists) {
+  if (n == 2) return {{0}, {1}};
+  std::vector<WardStep> steps = ward_linkage(dists, n);
+  auto csize = [&](int label) { return label < n ? 1 : steps[(size_t)(label - n)].size; };
+  double cutoff = 0.0;
+  const int min_cluster = std::max(2, (int)std::round(0.01 * (double)n));
+  for (size_t i = steps.size(); i-- > 0;) {
+    if (std::min(csize(steps[i].c1), csize(steps[i].c2)) >= min_cluster) { cutoff = steps[i].diss - 0.0001; break; }
+  }
+  std::vector<std::vector<int>> out;
+  if (cutoff == 0.0) {
+    out.resize(2);
+    for (int i = 0; i < n; ++i) out[(size_t)(i & 1)].push_back(i);
+    return out;
+  }
+  int num_groups = 0;
+  std::vector<int> member((size_t)(2 * n - 1), -1);
+  for (size_t i = steps.size(); i-- > 0;) {
+    const int c = (int)i + n;
+    if (steps[i].diss <= cutoff) {
+      if (member[(size_t)c] < 0) member[(size_t)c] = num_groups++;
+      member[(size_t)steps[i].c1] = member[(size_t)c];
+      member[(size_t)steps[i].c2] = member[(size_t)c];
+    }
+  }
+  std::vector<int> g((size_t)n);
+  for (int i = 0; i < n; ++i) g[(size_t)i] = member[(size_t)i] >= 0 ? member[(size_t)i] : num_groups++;
+  out.resize((size_t)num_groups);
+  for (int i = 0; i < n; ++i) out[(size_t)g[(size_t)i]].push_back(i);
+  return out;
+}
+
+static orc_wfa_params ed_params() {  // genotype.rs:88-92: Score scope, BiWFA, edit, default heuristic
+  orc_wfa_params p;
+  orc_wfa_default_params(&p);
+  p.metric = 1; p.span = 0; p.scope = 0; p.memory_mode = 3;
+  return p;
+}
+
+static double get_dist(const std::string& a, const std::string& b, int64_t* cells, int64_t* n_ed) {  // genotype_cluster.rs:238-248
+  const int diff = std::abs((int)a.size() - (int)b.size());
+  int dist;
+  if (a.size() * b.size() > 10000) dist = diff;
+  else {
+    static const orc_wfa_params ep = ed_params();
+    WfaResult r = wfa_align(ep, (const uint8_t*)a.data(), (int)a.size(), (const uint8_t*)b.data(), (int)b.size());
+    if (cells) *cells += r.cells;
+    if (n_ed) *n_ed += 1;
+    dist = r.score;
+  }
+  return std::sqrt((double)dist);
+}
+
+static int central_read(int n, const std::vector<int>& group, const std::vector<double>& dists) {  // :12-39
+  const size_t gs = group.size();
+  if (gs <= 2) return group[0];
+  std::vector<double> sums(gs, 0.0);
+  for (size_t i = 0; i + 1 < gs; ++i)
+    for (size_t j = i + 1; j < gs; ++j) {
+      const size_t i1 = (size_t)group[i], i2 = (size_t)group[j];
+      const size_t mi = (size_t)n * i1 - i1 * (i1 + 3) / 2 + i2 - 1;
+      sums[i] += dists[mi]; sums[j] += dists[mi];
+    }
+  size_t best = 0;
+  for (size_t i = 1; i < gs; ++i) if (sums[i] < sums[best]) best = i;  // min_by: first minimum
+  return group[best];
+}
+
+struct ClusterGt { std::vector<TrSize> gt; std::vector<std::string> alleles; std::vector<int> classification; };
+
+static ClusterGt genotype_cluster(int ploidy, const std::vector<std::string>& trs, int64_t* cells, int64_t* n_aln, int64_t* n_ed) {
+  const int n = (int)trs.size();
+  std::vector<double> dists;
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) dists.push_back(get_dist(trs[(size_t)i], trs[(size_t)j], cells, n_ed));
+  auto make_consensus = [&](const std::vector<int>& group, std::string& allele, TrSize& size) {
+    std::vector<std::string> seqs;
+    for (int i : group) seqs.push_back(trs[(size_t)i]);
+    const std::string& backbone = trs[(size_t)central_read(n, group, dists)];
+    auto aligns = align_all(backbone, seqs, cells, n_aln);
+    allele = repair_consensus(backbone, seqs, aligns);
+    int lo = (int)seqs[0].size(), hi = lo;
+    for (auto& s : seqs) { lo = std::min(lo, (int)s.size()); hi = std::max(hi, (int)s.size()); }
+    size = TrSize{(int)allele.size(), lo, hi};
+  };
+  ClusterGt out;
+  if (ploidy == 1 || n == 1) {
+    std::vector<int> group;
+    for (int i = 0; i < n; ++i) group.push_back(i);
+    std::string allele; TrSize size;
+    make_consensus(group, allele, size);
+    out.classification.assign((size_t)n, 0);
+    if (ploidy == 1) { out.gt = {size}; out.alleles = {allele}; }
+    else { out.gt = {size, size}; out.alleles = {allele, allele}; }
+    return out;
+  }
+  std::vector<std::vector<int>> groups = cluster_groups(n, dists);
+  std::stable_sort(groups.begin(), groups.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() < b.size(); });
+  std::vector<int> group1 = groups.back(); groups.pop_back();
+  std::vector<int> group2 = groups.back(); groups.pop_back();
+  std::string allele1, allele2; TrSize size1, size2;
+  make_consensus(group1, allele1, size1);
+  make_consensus(group2, allele2, size2);
+  auto outlier = [](size_t len1, size_t len2, size_t cov1, size_t cov2) {
+    const size_t d = len1 > len2 ? len1 - len2 : len2 - len1;
+    return d < 100 && std::min(cov1, cov2) * 4 < std::max(cov1, cov2);
+  };
+  if (outlier(allele1.size(), allele2.size(), group1.size(), group2.size())) {
+    group1.clear(); group2.clear();
+    for (int i = 0; i < n; ++i) (i % 2 == 0 ? group1 : group2).push_back(i);
+    make_consensus(group1, allele1, size1);
+    make_consensus(group2, allele2, size2);
+    out.classification.resize((size_t)n);
+    for (int i = 0; i < n; ++i) out.classification[(size_t)i] = i % 2;
+    if (allele1.size() > allele2.size()) {
+      for (int& c : out.classification) c = 1 - c;
+      out.gt = {size2, size1}; out.alleles = {allele2, allele1};
+    } else { out.gt = {size1, size2}; out.alleles = {allele1, allele2}; }
+    return out;
+  }
+  out.classification.assign((size_t)n, 2);
+  for (int i : group1) out.classification[(size_t)i] = 0;
+  for (int i : group2) out.classification[(size_t)i] = 1;
+  for (int i = 0; i < n; ++i) {
+    int tie = 1;  // re-initialised per read (genotype_cluster.rs:125): an exact tie always lands on allele 0
+    if (out.classification[(size_t)i] == 2) {
+      const double d1 = get_dist(trs[(size_t)i], allele1, cells, n_ed), d2 = get_dist(trs[(size_t)i], allele2, cells, n_ed);
+      if (d1 < d2) out.classification[(size_t)i] = 0;
+      else if (d2 < d1) out.classification[(size_t)i] = 1;
+      else { tie = (tie + 1) % 2; out.classification[(size_t)i] = tie; }
+    }
+  }
+  if (allele1.size() > allele2.size()) {
+    for (int& c : out.classification) c = 1 - c;
+    out.gt = {size2, size1}; out.alleles = {allele2, allele1};
+  } else { out.gt = {size1, size2}; out.alleles = {allele1, allele2}; }
+  return out;
+}
+
+static inline int64_t total_cmp_key(double d) {  // f64::total_cmp
+  int64_t b; std::memcpy(&b, &d, 8);
+  b ^= (int64_t)((uint64_t)(b >> 63) >> 1);
+  return b;
+}
+
 }  // namespace orc
 
 using namespace orc;
@@ -258,15 +478,33 @@ int orc_find_spans(const uint8_t* piece, int piece_len, int64_t n_reads, const u
   return 0;
 }
 
+// kodama-style Ward linkage on a condensed matrix (mutated in place); steps4 = n-1 x (cluster1, cluster2, size), diss = n-1 doubles
+int orc_ward_linkage(double* dists, int n, int32_t* steps3, double* diss) {
+  std::vector<double> d(dists, dists + (size_t)n * (size_t)(n - 1) / 2);
+  std::vector<WardStep> st = ward_linkage(d, n);
+  std::copy(d.begin(), d.end(), dists);
+  for (size_t i = 0; i < st.size(); ++i) { steps3[3 * i] = st[i].c1; steps3[3 * i + 1] = st[i].c2; steps3[3 * i + 2] = st[i].size; diss[i] = st[i].diss; }
+  return (int)st.size();
+}
+
+// genotype_cluster::cluster (genotype_cluster.rs:154-227): group id per sequence, groups numbered in the reference's order
+int orc_cluster_groups(double* dists, int n, int32_t* group_of) {
+  std::vector<double> d(dists, dists + (size_t)n * (size_t)(n - 1) / 2);
+  auto groups = cluster_groups(n, d);
+  std::copy(d.begin(), d.end(), dists);
+  for (size_t g = 0; g < groups.size(); ++g) for (int i : groups[g]) group_of[i] = (int32_t)g;
+  return (int)groups.size();
+}
+
 int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
                       const uint8_t* ref_tr, int ref_tr_len,
                       const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs, int64_t n_reads,
                       const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len, int32_t* span_start,
                       int32_t* span_end, int32_t* n_alleles, char* allele0, char* allele1, int allele_cap, int32_t* gt_size,
                       int32_t* gt_ci, int32_t* n_spanning, int32_t* kept_read, int32_t* classification, int32_t* num_spanning_by_hap,
-                      char* mc, char* ms, char* ap, int str_cap, int64_t* stats) {
+                      char* mc, char* ms, char* ap, int str_cap, int64_t* stats, const double* read_qual) {
   const int F = p->flank_len;
-  int64_t wfa_cells = 0, vit_cells = 0, n_flank_wfa = 0, n_cons = 0, bytes_io = 0;
+  int64_t wfa_cells = 0, vit_cells = 0, n_flank_wfa = 0, n_cons = 0, bytes_io = 0, n_ed = 0, n_purity = 0;
   *n_alleles = 0; *n_spanning = 0;
   if (allele0) allele0[0] = 0;
   if (allele1) allele1[0] = 0;
@@ -293,7 +531,7 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
     if (span_start[i] >= 0) rs.push_back({i, span_start[i], span_end[i]});
   }
   auto finish = [&]() {
-    if (stats) { stats[0] = wfa_cells; stats[1] = vit_cells; stats[2] = n_flank_wfa; stats[3] = n_cons; stats[4] = bytes_io; }
+    if (stats) { stats[0] = wfa_cells; stats[1] = vit_cells; stats[2] = n_flank_wfa; stats[3] = n_cons; stats[4] = bytes_io; stats[5] = n_ed; stats[6] = n_purity; }
     return 0;
   };
   if (rs.empty()) return finish();
@@ -314,13 +552,40 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
     }
     kept.resize((size_t)p->max_depth);
   }
-  std::vector<std::string> trs;
-  for (auto& x : kept) trs.emplace_back((const char*)read_blob + read_off[x.read] + x.s, (size_t)(x.e - x.s));
-  SizeGt g = genotype_size(p->ploidy, trs, &wfa_cells, &n_cons);
-  // label_with_hmm
   auto motifs = motifs_from_blob(motif_blob, motif_off, n_motifs);
   for (auto& m : motifs) { m = replace_invalid_bases(m, "ATCGN"); bytes_io += (int64_t)m.size(); }
   Hmm hmm = build_hmm(motifs);
+  if (p->min_read_qual < 0.9) {  // filter_impure_trs (tr.rs:37-50, 400-452)
+    const size_t max_filter = std::max<size_t>(1, (size_t)std::round(0.1 * (double)kept.size()));
+    std::vector<std::pair<double, RS>> pr;
+    for (auto& x : kept) {
+      const double rq = read_qual ? read_qual[x.read] : std::nan("");
+      double purity = 1.0;
+      if (!(rq >= 0.9)) {  // None (NaN) or below the cut-off
+        const std::string seq = replace_invalid_bases(std::string((const char*)read_blob + read_off[x.read] + x.s, (size_t)(x.e - x.s)), "ATCG");
+        if (seq.empty()) purity = std::nan("");
+        else { std::vector<int> labels = hmm_label(hmm, seq, &vit_cells); purity = hmm_purity(hmm, motifs, labels, seq, nullptr, nullptr); }
+        ++n_purity;
+      }
+      pr.push_back({purity, x});
+    }
+    std::stable_sort(pr.begin(), pr.end(), [](const std::pair<double, RS>& a, const std::pair<double, RS>& b) { return total_cmp_key(a.first) < total_cmp_key(b.first); });
+    kept.clear();
+    size_t num_filtered = 0;
+    for (auto& q : pr) {
+      if (q.first >= 0.9 || num_filtered >= max_filter) kept.push_back(q.second);
+      else ++num_filtered;
+    }
+    if (kept.empty()) return finish();
+  }
+  std::vector<std::string> trs;
+  for (auto& x : kept) trs.emplace_back((const char*)read_blob + read_off[x.read] + x.s, (size_t)(x.e - x.s));
+  SizeGt g;
+  if (p->genotyper == 1) {
+    ClusterGt cg = genotype_cluster(p->ploidy, trs, &wfa_cells, &n_cons, &n_ed);
+    g.gt = cg.gt; g.alleles = cg.alleles; g.classification = cg.classification;
+  } else g = genotype_size(p->ploidy, trs, &wfa_cells, &n_cons);
+  // label_with_hmm
   std::vector<Annotation> ann;
   for (auto& a : g.alleles) { ann.push_back(annotate_allele(hmm, motifs, a, nullptr, &vit_cells)); bytes_io += (int64_t)a.size(); }
   int by_hap[2] = {0, 0};

@@ -135,11 +135,14 @@ typedef struct orc_locus_params {
   int32_t max_depth;          /* 250 */
   int32_t mism, gapo, gape;   /* --aln-scoring 2,5,1 */
   int32_t ploidy;             /* 1 or 2 */
+  int32_t genotyper;          /* 0 Genotyper::Size, 1 Genotyper::Cluster (locus.rs:25-29) */
+  double  min_read_qual;      /* Params::min_read_qual; < 0.9 switches filter_impure_trs on (tr.rs:37-50) */
 } orc_locus_params;
 
-/* analyze_tr restricted to pre-clipped reads, size genotyper, no HP/SNV/meth
- * (tr.rs:24-109 minus BAM).  Text outputs are written as NUL-terminated
- * strings into caller buffers. */
+/* analyze_tr restricted to pre-clipped reads, no HP/SNV/meth (tr.rs:24-109
+ * minus BAM); size or cluster genotyper.  Text outputs are written as
+ * NUL-terminated strings into caller buffers.  read_qual: per input read,
+ * NaN = None; NULL = every read None (HiFiRead::read_qual, reads/read.rs). */
 int orc_locus_analyze(const orc_locus_params* p,
                       const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
                       const uint8_t* ref_tr, int ref_tr_len,
@@ -151,7 +154,13 @@ int orc_locus_analyze(const orc_locus_params* p,
                       int32_t* n_spanning, int32_t* kept_read, int32_t* classification, /* per spanning read */
                       int32_t* num_spanning_by_hap,                /* [2] */
                       char* mc, char* ms, char* ap, int str_cap,   /* VCF encodings write_vcf.rs:286-343 */
-                      int64_t* stats /* [8]: wfa_cells, viterbi_cells, n_wfa_flank, n_wfa_cons, bytes_io */);
+                      int64_t* stats /* [8]: wfa_cells, viterbi_cells, n_wfa_flank, n_wfa_cons, bytes_io, n_wfa_ed, n_purity */,
+                      const double* read_qual);
+
+/* Ward linkage as kodama 0.3.0's linkage(.., Method::Ward) performs it (PARITY UNPINNED, see locus.cpp): dists is
+ * the condensed matrix, overwritten as kodama overwrites it.  Returns the number of steps (n-1). */
+int orc_ward_linkage(double* dists, int n, int32_t* steps3 /* cluster1, cluster2, size */, double* dissimilarity);
+int orc_cluster_groups(double* dists, int n, int32_t* group_of);
 
 #ifdef __cplusplus
 }
