@@ -23,7 +23,10 @@
  *                         + collapse_labels as composed by label_with_hmm,
  *                         src/trgt/workflows/tr.rs:454-492 (src/hmm/, all files).
  *   trgt_locus_batch      analyze_tr for pre-clipped reads,
- *                         src/trgt/workflows/tr.rs:24-109 (size genotyper).
+ *                         src/trgt/workflows/tr.rs:24-109: get_spanning_reads,
+ *                         filter_impure_trs (:400-452), Genotyper::Size
+ *                         (genotype_size.rs:6-64) or Genotyper::Cluster
+ *                         (genotype_cluster.rs:58-152), label_with_hmm.
  *
  * Conventions
  *   - Plain C, caller-owned buffers, no exceptions cross the boundary.  Every
@@ -46,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 1
+#define TRGT_HIP_ABI_VERSION 2
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -150,7 +153,8 @@ int trgt_find_spans_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t 
  *   path        Hmm::label state path (u16), job j at path[path_off[j] ..], path_len[j] entries;
  *               capacity per job >= trgt_hmm_path_capacity(seq_len, longest motif of the set)
  *   spans3      collapsed MS spans (motif_index,start,end) at spans3[3*span_off[j] ..], capacity seq_len[j]+1;
- *               n_spans[j] == 0 means labels = None
+ *               n_spans[j] == 0 means labels = None.  spans3 may be NULL when only purity / counts are wanted
+ *               (filter_impure_trs, tr.rs:400-452, needs nothing else)
  *   motif_counts  MC per motif at motif_counts[count_off[j] .. + #motifs of the set]
  *   purity      AP (NaN for an empty allele); edit_dist / max_dist: the integers calc_purity divides
  */
@@ -171,7 +175,11 @@ typedef struct trgt_locus_params {
   int32_t max_depth;         /* 250 */
   int32_t mism, gapo, gape;  /* 2,5,1 */
   int32_t host_threads;      /* threads for the host glue between GPU stages (0 = hardware concurrency) */
+  double min_read_qual;      /* Params::min_read_qual (tr.rs:19, --min-read-quality, default 0.98): below MIN_RQ_FOR_PURITY = 0.9
+                                the purity filter filter_impure_trs runs on the spanning reads (tr.rs:37-50) */
 } trgt_locus_params;
+/* flank_len 250, min_flank_id_frac 0.7, max_depth 250, scoring 2,5,1, host_threads 0, min_read_qual 0.98 (cli.rs:271-344) */
+void trgt_locus_default_params(trgt_locus_params* p);
 
 typedef struct trgt_locus_batch_in {   /* Locus (locus.rs:13-23) x n_loci, reads already clipped (tr.rs:33-34) */
   int64_t n_loci;
@@ -184,6 +192,9 @@ typedef struct trgt_locus_batch_in {   /* Locus (locus.rs:13-23) x n_loci, reads
   const uint64_t* locus_read_begin;    /* CSR over reads */
   const uint8_t* read_blob;            /* host or device */
   const uint64_t* read_off; const uint32_t* read_len;
+  const uint8_t* genotyper;            /* optional, per locus: 0 Genotyper::Size, 1 Genotyper::Cluster (locus.rs:25-29); NULL = all Size */
+  const double* read_qual;             /* optional, per read: HiFiRead::read_qual, NaN = None; NULL = None for every read.
+                                          Only looked at when min_read_qual < 0.9. */
 } trgt_locus_batch_in;
 
 typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x n_loci; all HOST, caller-allocated */
@@ -208,11 +219,11 @@ int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_l
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {
   uint64_t seed;           /* 20250509 */
-  int32_t config;          /* 2 = cfg2/cfg4 single-motif STR loci, 3 = cfg3 long pathogenic-like alleles */
+  int32_t config;          /* 2 / 4 = single-motif STR loci (cfg2, cfg4), 5 = compound / N-motif loci for the cluster genotyper */
   int32_t reads_per_locus; /* 30 */
   int32_t context_len;     /* 500 */
   int32_t flank_len;       /* 250 */
-  int32_t max_allele_bp;   /* 200 (cfg2) / 10000 (cfg3) */
+  int32_t max_allele_bp;   /* 200 (cfg2) / 300 (cfg5); larger values give cfg3-like long alleles */
   double sub_rate, del_rate, ins_rate, stutter_rate, truncate_rate; /* 5e-4, 2.5e-4, 2.5e-4, 0.05, 0.10 */
 } trgt_synth_params;
 void trgt_synth_default_params(trgt_synth_params* p, int config);
@@ -229,6 +240,7 @@ typedef struct trgt_synth_batch {
   uint32_t* true_allele_len;   /* [2 * n_loci] ground truth (bp) */
   uint8_t* read_hap;           /* per read: haplotype 0/1 */
   uint8_t* read_truncated;     /* per read: 1 if cut (must end up with span None) */
+  uint8_t* genotyper;          /* per locus: 0 size, 1 cluster (cfg5) */
 } trgt_synth_batch;
 int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci, int threads, trgt_synth_batch** out);
 void trgt_synth_free(trgt_synth_batch* b);

@@ -32,9 +32,12 @@ def _oracle_locus(oracle, b, l, params):
     tr = bytes(b["tr_blob"][int(b["tr_off"][l]):int(b["tr_off"][l]) + int(b["tr_len"][l])])
     m0, m1 = int(b["set_motif_begin"][l]), int(b["set_motif_begin"][l + 1])
     motifs = [bytes(b["motif_blob"][int(b["motif_off"][m]):int(b["motif_off"][m + 1])]) for m in range(m0, m1)]
+    gt = int(b["genotyper"][l]) if b.get("genotyper") is not None else 0
+    rq = b["read_qual"][a0:a1] if b.get("read_qual") is not None else None
     return oracle.locus_analyze(lf, rf, tr, motifs, reads, flank_len=params.search_flank_len,
                                 min_flank_id_frac=params.min_flank_id_frac, max_depth=params.max_depth,
-                                scoring=params.aln_scoring, ploidy=int(b["ploidy"][l]))
+                                scoring=params.aln_scoring, ploidy=int(b["ploidy"][l]), genotyper=gt,
+                                min_read_qual=params.min_read_qual, read_qual=rq)
 
 
 def _compare(oracle, locus, b, out, params, loci):
@@ -188,3 +191,91 @@ def test_device_genotyper_envelope(oracle, mods):
     b = locus.pack(loci)
     for mode, out in _run_both(locus, b):
         _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+
+
+def test_cluster_genotyper_cfg5_matches_oracle(oracle, mods):
+    # compound / N-containing motif sets, Genotyper::Cluster -- n(n-1)/2 edit-distance alignments,
+    # Ward linkage, a consensus alignment for every read, outlier assignment (genotype_cluster.rs:58-152)
+    locus, synth = mods
+    b = synth.generate(48, first_locus=300, config=5)
+    assert b["genotyper"].all()
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(48))
+        assert int(out.stats[15]) > 0 and int(out.stats[1]) > 48 * 10, mode  # edit-distance and consensus jobs ran on the GPU
+    # short alleles: |a|*|b| <= MAX_OPS for every pair, so the whole distance matrix comes from edit-distance alignments
+    b = synth.generate(24, first_locus=7000, config=5, max_allele_bp=90)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(24))
+        assert int(out.stats[15]) > 24 * 200, mode
+    # noisy reads: outlier clusters, consensus repair with insertions
+    b = synth.generate(24, first_locus=900, config=5, sub_rate=0.004, ins_rate=0.004, del_rate=0.004, stutter_rate=0.3)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(24))
+
+
+def test_cluster_genotyper_shapes(oracle, mods):
+    # the branches of genotype_cluster::genotype: haploid, a single read, two reads, homozygous (even / odd split), a small far
+    # group of outlier reads, alleles long enough for the |a|*|b| > MAX_OPS shortcut, size and cluster loci mixed in one batch
+    locus, _ = mods
+    rng = np.random.default_rng(23)
+    dna = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    lf, rf = dna(250), dna(250)
+    mk = lambda rep: dna(int(rng.integers(250, 300))) + lf + rep + rf + dna(int(rng.integers(250, 300)))
+    noisy = lambda rep: bytes(int(rng.choice(list(b"ACGT"))) if rng.random() < 0.03 else c for c in rep)
+    base = dict(left_flank=lf, right_flank=rf, motifs=[b"CAG", b"CCG"], genotyper="cluster")
+    loci = [
+        dict(base, tr=b"CAG" * 8, ploidy=1, reads=[mk(noisy(b"CAG" * 8)) for _ in range(9)]),
+        dict(base, tr=b"CAG" * 8, reads=[mk(b"CAG" * 9)]),
+        dict(base, tr=b"CAG" * 8, reads=[mk(b"CAG" * 9), mk(b"CAG" * 12)]),
+        dict(base, tr=b"CAG" * 8, reads=[mk(b"CAG" * 8) for _ in range(11)]),
+        dict(base, tr=b"CAG" * 8, reads=[mk(noisy(b"CAG" * 8 + b"CCG" * (3 if i % 2 else 9))) for i in range(24)]),
+        dict(base, tr=b"CAG" * 8, reads=[mk(b"CAG" * (8 if i < 14 else 11)) for i in range(16)] + [mk(noisy(b"CAG" * 30)), mk(dna(20))]),
+        dict(base, tr=b"CAG" * 60, reads=[mk(noisy(b"CAG" * (60 if i % 2 else 75))) for i in range(14)]),
+        dict(base, tr=b"CAG" * 8, genotyper="size", reads=[mk(b"CAG" * (8 if i % 2 else 10)) for i in range(12)]),
+        dict(base, tr=b"CAG" * 10, reads=[mk(b"CAG" * 10) for _ in range(13)] + [mk(b"CAG" * 12)]),
+        dict(base, tr=b"", motifs=[b"A"], reads=[mk(b"") for _ in range(4)]),
+    ]
+    b = locus.pack(loci)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+    res = locus.analyze_batch(loci)
+    assert len(res[0].genotype) == 1 and len(res[1].genotype) == 2 and res[1].genotype[0].seq == res[1].genotype[1].seq == b"CAG" * 9
+    assert [len(a.seq) for a in res[2].genotype] == [27, 36]
+
+
+def test_filter_impure_trs_matches_oracle(oracle, mods):
+    # --min-read-quality below 0.9 switches the HMM purity filter on (tr.rs:37-50, 400-452): reads without an rq >= 0.9 are scored,
+    # the list is re-ordered by purity and at most max(1, round(0.1 n)) impure reads are dropped
+    locus, synth = mods
+    b = synth.generate(40, first_locus=4000, sub_rate=0.01, ins_rate=0.004, del_rate=0.004)
+    rng = np.random.default_rng(3)
+    nr = int(b["n_reads"])
+    params = locus.Params(min_read_qual=0.5)
+    for rq in (None, np.where(rng.random(nr) < 0.5, 0.999, np.where(rng.random(nr) < 0.5, 0.7, np.nan))):
+        bb = dict(b)
+        bb["read_qual"] = rq
+        for mode, out in _run_both(locus, bb, params):
+            _compare(oracle, locus, bb, out, params, range(40))
+    # hand-made loci with impure repeats: some reads must be dropped, the rest re-ordered by purity
+    dna = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    lf, rf = dna(250), dna(250)
+    def impure(rep, k):
+        rep = bytearray(rep)
+        for i in rng.choice(len(rep), size=k, replace=False):
+            rep[i] = ord("T") if rep[i] != ord("T") else ord("A")
+        return bytes(rep)
+    mk = lambda rep: dna(int(rng.integers(250, 300))) + lf + rep + rf + dna(int(rng.integers(250, 300)))
+    loci = []
+    for n_reads, n_bad in ((12, 2), (30, 5), (4, 4), (25, 1)):
+        reads = [mk(impure(b"CAG" * 20, 14) if i < n_bad else impure(b"CAG" * 20, int(rng.integers(0, 3)))) for i in range(n_reads)]
+        order = rng.permutation(n_reads)
+        loci.append(dict(left_flank=lf, right_flank=rf, tr=b"CAG" * 20, motifs=[b"CAG"], reads=[reads[i] for i in order],
+                         read_qual=[None if rng.random() < 0.5 else 0.6 for _ in range(n_reads)]))
+    bh = locus.pack(loci)
+    for mode, out in _run_both(locus, bh, params):
+        _compare(oracle, locus, bh, out, params, range(len(loci)))
+        assert int(((out.span_start >= 0) & (out.read_rank < 0)).sum()) >= 4, mode
+    # cluster genotyper behind the filter
+    b5 = synth.generate(10, first_locus=40, config=5, sub_rate=0.01)
+    for mode, out in _run_both(locus, b5, params):
+        _compare(oracle, locus, b5, out, params, range(10))

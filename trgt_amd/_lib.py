@@ -32,7 +32,8 @@ class SpanParams(C.Structure):
 
 class LocusParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("min_flank_id_frac", C.c_double), ("max_depth", C.c_int32),
-                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("host_threads", C.c_int32)]
+                ("mism", C.c_int32), ("gapo", C.c_int32), ("gape", C.c_int32), ("host_threads", C.c_int32),
+                ("min_read_qual", C.c_double)]
 
 
 class SynthParams(C.Structure):
@@ -47,7 +48,7 @@ class SynthBatch(C.Structure):
                 [(n, C.c_void_p) for n in ("flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len",
                                            "motif_blob", "motif_off", "set_motif_begin", "ploidy", "locus_read_begin",
                                            "read_blob", "read_off", "read_len", "true_allele_len", "read_hap",
-                                           "read_truncated")])
+                                           "read_truncated", "genotyper")])
 
 
 _VP = C.c_void_p
@@ -56,7 +57,7 @@ _VP = C.c_void_p
 class LocusBatchIn(C.Structure):
     _fields_ = [("n_loci", C.c_int64)] + [(n, _VP) for n in (
         "flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off",
-        "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len")]
+        "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len", "genotyper", "read_qual")]
 
 
 class LocusBatchOut(C.Structure):
@@ -70,7 +71,7 @@ EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity",
-    "trgt_locus_batch", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
+    "trgt_locus_batch", "trgt_locus_default_params", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 
@@ -118,6 +119,8 @@ def lib():
         L.trgt_wfa_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 15
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
         L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
+        L.trgt_locus_default_params.argtypes = [_VP]
+        L.trgt_locus_default_params.restype = None
         L.trgt_synth_generate.argtypes = [_VP, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.POINTER(SynthBatch))]
         L.trgt_synth_free.argtypes = [C.POINTER(SynthBatch)]
         L.trgt_synth_free.restype = None

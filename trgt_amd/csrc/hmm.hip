@@ -568,7 +568,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   *out_pending = nullptr;
   if (!c) return TRGT_ERR_INVALID;
   if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
-                                                    !seq_len || !spans3 || !span_off || !n_spans || !motif_counts ||
+                                                    !seq_len || (spans3 && !span_off) || !n_spans || !motif_counts ||
                                                     !count_off || !purity)))
     return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: null argument");
   if (path && !path_off) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: path without path_off");
@@ -597,14 +597,14 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const HmmSetDev& sd = sets[job_set[j]];
     HmmJobDev& jd = jobs[(size_t)j];
     jd.set = job_set[j]; jd.seq_len = seq_len[j]; jd.job_index = (uint32_t)j;
-    jd.seq_off = seq_off[j]; jd.span_off = span_off[j]; jd.count_off = count_off[j];
+    jd.seq_off = seq_off[j]; jd.span_off = spans3 ? span_off[j] : 0; jd.count_off = count_off[j];
     jd.path_off = path ? path_off[j] : 0;
     jd.path_cap = (uint32_t)std::min<uint64_t>(trgt_hmm_path_capacity(seq_len[j], sd.max_mlen), 0xFFFFFFFFull);
     const uint64_t spad = (sd.S + 15) & ~15u;
     jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)seq_len[j] + 2), 16);
     jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
-    span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
+    if (spans3) span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
     count_total = std::max<uint64_t>(count_total, count_off[j] + (sd.n_blocks - 1));
     if (path) path_total = std::max<uint64_t>(path_total, path_off[j] + jd.path_cap);
     cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
@@ -645,8 +645,10 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
   // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the
   // spans actually produced are copied back (packed); a device buffer is written in the caller's layout directly.
-  const bool spans_on_host = !is_device_ptr(spans3);
-  P->spans_on_host = spans_on_host;
+  // spans3 == NULL: the caller only wants purity / counts (filter_impure_trs); the spans stay in the tight device layout
+  const bool discard_spans = spans3 == nullptr;
+  const bool spans_on_host = discard_spans || !is_device_ptr(spans3);
+  P->spans_on_host = spans_on_host && !discard_spans;
   std::vector<uint64_t>& tight_off = P->tight_off;
   uint64_t tight_total = 0;
   if (spans_on_host) {

@@ -57,6 +57,7 @@ struct LocusWork {                  // plain data: no per-locus heap traffic on 
   Seg pick[2] = {{nullptr, 0}, {nullptr, 0}};   // consensus::get_consensus picks (point into the segment bytes)
   int repair[2] = {-1, -1};                      // index into the per-thread repair list, -1 = keep the pick
   int repair_thread = 0;
+  int cluster = -1;                              // Genotyper::Cluster: index into the call's ClusterLocus list
 };
 
 struct Scratch {                    // per host thread, reused across loci
@@ -202,6 +203,8 @@ std::string repair_consensus(const std::string& backbone, const std::vector<Seg>
   return out;
 }
 
+#include "locus_cluster.hpp"
+
 struct GatherArgs { const uint8_t* reads; const uint64_t* src_off; const uint64_t* dst_off; const uint32_t* len; uint64_t n; uint8_t* out; };
 __global__ void gather_segments_kernel(const GatherArgs a) {  // one wavefront per segment
   const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -247,6 +250,13 @@ __global__ void allele_pack_kernel(const uint8_t* __restrict__ blob, const uint6
 
 using namespace trgt;
 
+extern "C" void trgt_locus_default_params(trgt_locus_params* p) {  // cli.rs:271-344
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  p->flank_len = 250; p->min_flank_id_frac = 0.7; p->max_depth = 250; p->mism = 2; p->gapo = 5; p->gape = 1; p->host_threads = 0;
+  p->min_read_qual = 0.98;
+}
+
 extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
@@ -269,7 +279,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
-  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0;
+  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
   auto init_outputs = [&]() {
     for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
     for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
@@ -328,7 +338,10 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   }
   c->dbg_ns[0] = now_ns() - t0;  // set-up: thread pool, model thread, piece / read-locus tables
   const bool reads_on_device = is_device_ptr(in->read_blob);
-  const bool dev_gt = reads_on_device && !getenv("TRGT_HOST_GENOTYPER");
+  // filter_impure_trs (tr.rs:37-50) sits between get_spanning_reads and the genotyper: with it on, every locus takes the host path
+  const bool impure_filter = p->min_read_qual < 0.9;
+  const bool dev_gt = reads_on_device && !getenv("TRGT_HOST_GENOTYPER") && !impure_filter;
+  auto is_cluster = [&](int64_t l) { return in->genotyper && in->genotyper[l] == 1; };
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
   const uint64_t *d_piece = nullptr, *d_roff = nullptr;
@@ -425,7 +438,11 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   int64_t th_begin = now_ns();
   // ---------------- loci for the host path: all of them without the device genotyper, else the ones it handed back
   std::vector<int64_t> R;
-  if (dev_gt) { const uint8_t* need = (const uint8_t*)gh.need; for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l); }
+  if (dev_gt) {
+    uint8_t* need = (uint8_t*)gh.need;
+    if (in->genotyper) for (int64_t l = 0; l < nl; ++l) if (in->genotyper[l] == 1) need[l] = 1;  // Genotyper::Cluster: host-driven rounds
+    for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
+  }
   else { R.resize((size_t)nl); for (int64_t l = 0; l < nl; ++l) R[(size_t)l] = l; }
   const int64_t nR = (int64_t)R.size();
   const int32_t* const sp_s = (const int32_t*)h_ss; const int32_t* const sp_e = (const int32_t*)h_se;  // spans (pinned copies)
@@ -467,6 +484,52 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       }
       n_sel[(size_t)li] = n;
     });
+    // filter_impure_trs (tr.rs:400-452): purity of the repeat segment of every read without a quality >= 0.9 (one HMM batch),
+    // stable sort by purity (f64::total_cmp), drop at most max(1, round(0.1 n)) reads below 0.9
+    if (impure_filter) {
+      std::vector<uint32_t> pj_set, pj_len, pj_nsp; std::vector<uint64_t> pj_off, pj_cnt_off; std::vector<double> pj_pur;
+      std::vector<uint64_t> pj_begin((size_t)nR + 1, 0);
+      uint64_t cnt_total = 0;
+      for (int64_t li = 0; li < nR; ++li) {
+        const int64_t l = R[(size_t)li];
+        const K* ks = sel.data() + sel_begin[(size_t)li];
+        const uint32_t nm = in->set_motif_begin[l + 1] - in->set_motif_begin[l];
+        for (uint32_t i = 0; i < n_sel[(size_t)li]; ++i) {
+          const double rq = in->read_qual ? in->read_qual[ks[i].read] : std::nan("");
+          if (rq >= 0.9) continue;  // Some(rq) with rq >= cutoff keeps purity 1.0; None (NaN) and low qualities are scored
+          pj_set.push_back((uint32_t)l); pj_off.push_back(in->read_off[ks[i].read] + ks[i].s); pj_len.push_back(ks[i].e - ks[i].s);
+          pj_cnt_off.push_back(cnt_total); cnt_total += nm;
+        }
+        pj_begin[(size_t)li + 1] = pj_set.size();
+      }
+      if (!pj_set.empty()) {
+        pj_nsp.resize(pj_set.size()); pj_pur.resize(pj_set.size());
+        std::vector<uint32_t> pj_counts((size_t)cnt_total + 1);
+        if (model_thread.joinable()) model_thread.join();
+        rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)pj_set.size(), pj_set.data(),
+                            reads_on_device ? d_reads : in->read_blob, pj_off.data(), pj_len.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                            pj_nsp.data(), pj_counts.data(), pj_cnt_off.data(), pj_pur.data(), nullptr, nullptr);
+        if (rc) return rc;
+        stat_hmm_jobs += (int64_t)pj_set.size();
+      }
+      auto total_key = [](double d) { int64_t b; std::memcpy(&b, &d, 8); b ^= (int64_t)((uint64_t)(b >> 63) >> 1); return b; };
+      pool->parallel_for(nR, 32, [&](int64_t li, int) {
+        K* ks = sel.data() + sel_begin[(size_t)li];
+        const uint32_t n = n_sel[(size_t)li];
+        if (n == 0) return;
+        std::vector<std::pair<double, K>> pr((size_t)n);
+        uint64_t j = pj_begin[(size_t)li];
+        for (uint32_t i = 0; i < n; ++i) {
+          const double rq = in->read_qual ? in->read_qual[ks[i].read] : std::nan("");
+          pr[i] = {rq >= 0.9 ? 1.0 : pj_pur[(size_t)j++], ks[i]};
+        }
+        std::stable_sort(pr.begin(), pr.end(), [&](const std::pair<double, K>& a, const std::pair<double, K>& b) { return total_key(a.first) < total_key(b.first); });
+        const size_t max_filter = std::max<size_t>(1, (size_t)std::round(0.1 * (double)n));
+        size_t filtered = 0; uint32_t m = 0;
+        for (auto& q : pr) { if (q.first >= 0.9 || filtered >= max_filter) ks[m++] = q.second; else ++filtered; }
+        n_sel[(size_t)li] = m;
+      });
+    }
     // pass 2: flat segment arrays (LocusResult.reads order within each locus)
     for (int64_t li = 0; li < nR; ++li) { work[(size_t)li].seg_begin = n_seg; n_seg += n_sel[(size_t)li]; work[(size_t)li].seg_end = n_seg; }
     seg_src.resize((size_t)n_seg); seg_dst.resize((size_t)n_seg); seg_len.resize((size_t)n_seg); seg_read.resize((size_t)n_seg); seg_ptr.resize((size_t)n_seg);
@@ -560,9 +623,21 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     else { for (uint64_t s = 0; s < n_seg; ++s) seg_ptr[s] = in->read_blob + seg_src[s]; }
     // front half of the length genotyper, threaded over loci (per-thread scratch, no per-locus allocation)
     int64_t tf0 = now_ns();
+    std::vector<ClusterLocus> cl_loci;
+    std::vector<std::vector<Seg>> cl_trs;
+    for (int64_t li = 0; li < nR; ++li) {
+      LocusWork& w = work[(size_t)li];
+      if (w.seg_begin == w.seg_end || !is_cluster(R[(size_t)li])) continue;
+      w.cluster = (int)cl_loci.size();
+      ClusterLocus L; L.li = li; L.ploidy = in->ploidy[R[(size_t)li]] == 1 ? 1 : 2; L.n = (int)(w.seg_end - w.seg_begin);
+      cl_loci.push_back(std::move(L));
+      cl_trs.emplace_back();
+      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) cl_trs.back().push_back(Seg{seg_ptr[s], seg_len[s]});
+    }
+    for (size_t k = 0; k < cl_loci.size(); ++k) cl_loci[k].trs = cl_trs[k].data();
     pool->parallel_for(nR, 16, [&](int64_t li, int t) {
       LocusWork& w = work[(size_t)li];
-      if (w.seg_begin == w.seg_end) return;
+      if (w.seg_begin == w.seg_end || w.cluster >= 0) return;
       Scratch& sc = scratch[(size_t)t];
       sc.trs.clear();
       for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) sc.trs.push_back(Seg{seg_ptr[s], seg_len[s]});
@@ -602,6 +677,13 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       if (rc) return rc;
       stat_cons_jobs = (int64_t)jrefs.size();
     }
+    // ---- Genotyper::Cluster loci: distance matrix, Ward linkage, consensus rounds, outlier assignment (locus_cluster.hpp)
+    if (!cl_loci.empty()) {
+      ClusterBatch cb(c, pool, cl_loci);
+      if ((rc = cb.run())) return rc;
+      stat_cons_jobs += cb.n_cons;
+      stat_ed_jobs = cb.n_ed;
+    }
     tB = now_ns() - tb0;
     // ---- host: repair_consensus, classification, reference allele first, output assembly
     th0 = now_ns();
@@ -624,21 +706,28 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       if (w.seg_begin == w.seg_end) return;
       const int ploidy = in->ploidy[l] == 1 ? 1 : 2;
       Seg al[2];
-      for (int a = 0; a < w.n_pick; ++a) {
-        if (w.repair[a] >= 0) { const std::string& r = scratch[(size_t)w.repair_thread].repairs[(size_t)w.repair[a]].result; al[a] = Seg{(const uint8_t*)r.data(), (uint32_t)r.size()}; }
-        else al[a] = w.pick[a];
-      }
-      int n_al = w.n_pick;
-      if (ploidy == 2 && n_al == 1) { al[1] = al[0]; n_al = 2; }
       int by_hap[2] = {0, 0};
-      int tie = 1;
-      for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
-        int cc = 0;
-        if (n_al == 2) {
-          const uint32_t d1 = adiff(seg_len[s], al[0].n), d2 = adiff(seg_len[s], al[1].n);
-          if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
+      if (w.cluster >= 0) {  // genotype_cluster::genotype results
+        const ClusterLocus& L = cl_loci[(size_t)w.cluster];
+        w.n_gt = L.n_gt;
+        for (int a = 0; a < L.n_gt; ++a) { al[a] = Seg{(const uint8_t*)L.allele[a].data(), (uint32_t)L.allele[a].size()}; w.ci[2 * a] = L.ci[2 * a]; w.ci[2 * a + 1] = L.ci[2 * a + 1]; }
+        for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) { const int cc = L.cls[(size_t)(s - w.seg_begin)]; seg_cls[s] = (int8_t)cc; by_hap[cc] += 1; }
+      } else {
+        for (int a = 0; a < w.n_pick; ++a) {
+          if (w.repair[a] >= 0) { const std::string& r = scratch[(size_t)w.repair_thread].repairs[(size_t)w.repair[a]].result; al[a] = Seg{(const uint8_t*)r.data(), (uint32_t)r.size()}; }
+          else al[a] = w.pick[a];
         }
-        seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
+        int n_al = w.n_pick;
+        if (ploidy == 2 && n_al == 1) { al[1] = al[0]; n_al = 2; }
+        int tie = 1;
+        for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
+          int cc = 0;
+          if (n_al == 2) {
+            const uint32_t d1 = adiff(seg_len[s], al[0].n), d2 = adiff(seg_len[s], al[1].n);
+            if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
+          }
+          seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
+        }
       }
       int order[2] = {0, 1};
       const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};
@@ -699,7 +788,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
-    for (int i = 0; i < 7; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
+    for (int i = 0; i < 6; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
+    s[15] = stat_ed_jobs;
   }
   return TRGT_OK;
 }

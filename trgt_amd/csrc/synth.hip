@@ -31,6 +31,8 @@ struct Rng {
 
 struct LocusData {
   std::string motif, left, right, tr;  // contexts of context_len bases, reference allele
+  std::vector<std::string> motifs;     // the locus' motif set (cfg2: the one motif)
+  uint8_t genotyper = 0;               // 0 size, 1 cluster
   uint32_t allele_len[2];
   std::vector<std::string> reads;
   std::vector<uint8_t> hap, trunc;
@@ -66,7 +68,71 @@ std::string channel(Rng& g, const std::string& in, const trgt_synth_params& p) {
   return out;
 }
 
+// cfg5: 2-10 motifs of length 2-12, at least one containing N, alleles <= max_allele_bp (300) built as
+// consecutive runs of every motif (N positions filled uniformly per copy), Genotyper::Cluster.  Same draw order as cfg2:
+// motifs, copy numbers, flanks, reads.
+void gen_locus_compound(const trgt_synth_params& p, int64_t idx, LocusData& L) {
+  Rng g(p.seed ^ ((uint64_t)(idx + 1) * 0x9E3779B97F4A7C15ull));
+  const int nm = g.range(2, 10);
+  L.motifs.resize((size_t)nm);
+  for (auto& m : L.motifs) {
+    const int n = g.range(2, 12);
+    do { m.assign((size_t)n, 'A'); for (int i = 0; i < n; ++i) m[(size_t)i] = g.base(); } while (n > 1 && is_power_of_shorter_unit(m));
+  }
+  { std::string& m = L.motifs[g.below((uint32_t)nm)]; m[g.below((uint32_t)m.size())] = 'N'; }
+  L.genotyper = 1;
+  std::vector<int> copies[2];
+  for (int m = 0; m < nm; ++m) {
+    const int cap = std::max(1, (p.max_allele_bp / nm) / (int)L.motifs[(size_t)m].size());
+    const int c1 = g.range(1, cap);
+    const double r = g.real();
+    int delta = 0;
+    if (r >= 0.30) { const int mag = g.range(1, 5); delta = (g.next() & 1) ? mag : -mag; }
+    copies[0].push_back(c1); copies[1].push_back(std::min(cap, std::max(1, c1 + delta)));
+  }
+  struct Unit { size_t start, len; };
+  std::string allele[2]; std::vector<Unit> units[2];
+  for (int a = 0; a < 2; ++a) {
+    for (int m = 0; m < nm; ++m)
+      for (int k = 0; k < copies[a][(size_t)m]; ++k) {
+        units[a].push_back({allele[a].size(), L.motifs[(size_t)m].size()});
+        for (char ch : L.motifs[(size_t)m]) allele[a].push_back(ch == 'N' ? g.base() : ch);
+      }
+    L.allele_len[a] = (uint32_t)allele[a].size();
+  }
+  L.tr = allele[0];
+  L.left.resize((size_t)p.context_len); L.right.resize((size_t)p.context_len);
+  for (auto& ch : L.left) ch = g.base();
+  for (auto& ch : L.right) ch = g.base();
+  const int R = p.reads_per_locus;
+  std::vector<uint8_t> hap((size_t)R);
+  while (true) {
+    int cnt1 = 0;
+    for (int i = 0; i < R; ++i) { hap[(size_t)i] = (uint8_t)(g.next() & 1); cnt1 += hap[(size_t)i]; }
+    const int need = std::min(5, R / 2);
+    if (cnt1 >= need && R - cnt1 >= need) break;
+  }
+  L.reads.resize((size_t)R); L.hap = hap; L.trunc.assign((size_t)R, 0);
+  for (int i = 0; i < R; ++i) {
+    const int h = hap[(size_t)i];
+    std::string rep = allele[h];
+    if (g.real() < p.stutter_rate) {  // one unit copied or dropped
+      const Unit u = units[h][g.below((uint32_t)units[h].size())];
+      if (g.next() & 1) rep.insert(u.start + u.len, allele[h].substr(u.start, u.len));
+      else if (units[h].size() > 1) rep.erase(u.start, u.len);
+    }
+    std::string rd = channel(g, L.left + rep + L.right, p);
+    if (g.real() < p.truncate_rate && rd.size() > 2) {
+      const size_t cut = 1 + g.below((uint32_t)(rd.size() - 1));
+      rd = cut >= rd.size() - cut ? rd.substr(0, cut) : rd.substr(cut);
+      L.trunc[(size_t)i] = 1;
+    }
+    L.reads[(size_t)i].swap(rd);
+  }
+}
+
 void gen_locus(const trgt_synth_params& p, int64_t idx, LocusData& L) {
+  if (p.config == 5) { gen_locus_compound(p, idx, L); return; }
   Rng g(p.seed ^ ((uint64_t)(idx + 1) * 0x9E3779B97F4A7C15ull));
   // motif
   const int n = g.range(3, 6);
@@ -93,6 +159,7 @@ void gen_locus(const trgt_synth_params& p, int64_t idx, LocusData& L) {
     L.allele_len[a] = (uint32_t)allele[a].size();
   }
   L.tr = allele[0];  // the reference allele of the synthetic locus
+  L.motifs.assign(1, L.motif);
   // flanks / context
   L.left.resize((size_t)p.context_len);
   L.right.resize((size_t)p.context_len);
@@ -138,13 +205,13 @@ extern "C" {
 void trgt_synth_default_params(trgt_synth_params* p, int config) {
   std::memset(p, 0, sizeof *p);
   p->seed = 20250509ull; p->config = config; p->reads_per_locus = 30; p->context_len = 500; p->flank_len = 250;
-  p->max_allele_bp = 200;
+  p->max_allele_bp = config == 5 ? 300 : 200;
   p->sub_rate = 5e-4; p->del_rate = 2.5e-4; p->ins_rate = 2.5e-4; p->stutter_rate = 0.05; p->truncate_rate = 0.10;
 }
 
 int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t n_loci, int threads, trgt_synth_batch** out) {
   if (!p || !out || n_loci < 0 || p->context_len < p->flank_len || p->reads_per_locus < 1) return TRGT_ERR_INVALID;
-  if (p->config != 2 && p->config != 4) return TRGT_ERR_UNSUPPORTED;  // cfg2 / cfg4 single-motif STR loci
+  if (p->config != 2 && p->config != 4 && p->config != 5) return TRGT_ERR_UNSUPPORTED;  // cfg2 / cfg4 STR loci, cfg5 compound loci
   std::vector<LocusData> loci((size_t)n_loci);
   if (threads < 1) threads = (int)std::max(1u, std::thread::hardware_concurrency());
   threads = (int)std::min<int64_t>(threads, std::max<int64_t>(1, n_loci));
@@ -158,7 +225,7 @@ int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t
   const int F = p->flank_len;
   std::vector<uint64_t> lf_off, rf_off, tr_off, lrb{0}, read_off;
   std::vector<uint32_t> lf_len, rf_len, tr_len, motif_off{0}, set_begin{0}, read_len, true_len;
-  std::vector<uint8_t> ploidy, hap, trunc;
+  std::vector<uint8_t> ploidy, hap, trunc, genotyper;
   std::string flank, tr, motifs;
   uint64_t read_bytes = 0, n_reads = 0;
   for (auto& L : loci) { for (auto& r : L.reads) read_bytes += r.size(); n_reads += L.reads.size(); }
@@ -168,8 +235,9 @@ int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t
     lf_off.push_back(flank.size()); lf_len.push_back((uint32_t)F); flank += L.left.substr(L.left.size() - (size_t)F);
     rf_off.push_back(flank.size()); rf_len.push_back((uint32_t)F); flank += L.right.substr(0, (size_t)F);
     tr_off.push_back(tr.size()); tr_len.push_back((uint32_t)L.tr.size()); tr += L.tr;
-    motifs += L.motif; motif_off.push_back((uint32_t)motifs.size()); set_begin.push_back((uint32_t)motif_off.size() - 1);
-    ploidy.push_back(2);
+    for (auto& m : L.motifs) { motifs += m; motif_off.push_back((uint32_t)motifs.size()); }
+    set_begin.push_back((uint32_t)motif_off.size() - 1);
+    ploidy.push_back(2); genotyper.push_back(L.genotyper);
     true_len.push_back(L.allele_len[0]); true_len.push_back(L.allele_len[1]);
     for (size_t i = 0; i < L.reads.size(); ++i) {
       read_off.push_back(rpos); read_len.push_back((uint32_t)L.reads[i].size());
@@ -189,6 +257,7 @@ int trgt_synth_generate(const trgt_synth_params* p, int64_t first_locus, int64_t
   b->tr_off = dup(tr_off); b->tr_len = dup(tr_len); b->motif_off = dup(motif_off); b->set_motif_begin = dup(set_begin);
   b->ploidy = dup(ploidy); b->locus_read_begin = dup(lrb); b->read_blob = read_blob; b->read_off = dup(read_off);
   b->read_len = dup(read_len); b->true_allele_len = dup(true_len); b->read_hap = dup(hap); b->read_truncated = dup(trunc);
+  b->genotyper = dup(genotyper);
   *out = b;
   return TRGT_OK;
 }
@@ -197,7 +266,7 @@ void trgt_synth_free(trgt_synth_batch* b) {
   if (!b) return;
   void* ptrs[] = {b->flank_blob, b->lf_off, b->lf_len, b->rf_off, b->rf_len, b->tr_blob, b->tr_off, b->tr_len, b->motif_blob,
                   b->motif_off, b->set_motif_begin, b->ploidy, b->locus_read_begin, b->read_blob, b->read_off, b->read_len,
-                  b->true_allele_len, b->read_hap, b->read_truncated};
+                  b->true_allele_len, b->read_hap, b->read_truncated, b->genotyper};
   for (void* q : ptrs) std::free(q);
   std::free(b);
 }

@@ -3,7 +3,7 @@
 Reference (PacificBiosciences/trgt v3.0.0):
   Params        src/trgt/workflows/tr.rs:17-22       -> Params
   Locus         src/trgt/locus.rs:13-23              -> the arrays of a batch (see pack / trgt_amd.synth.generate)
-  analyze       src/trgt/workflows/tr.rs:24-109      -> analyze_batch (size genotyper, pre-clipped reads)
+  analyze       src/trgt/workflows/tr.rs:24-109      -> analyze_batch (size / cluster genotyper, pre-clipped reads)
   LocusResult / Allele  workflows/locus_result.rs:6-23 -> LocusResult / Allele
   find_tr_spans src/trgt/genotype/span_locater.rs:32-68 -> find_tr_spans_batch
   encode_* of write_vcf.rs:286-377                   -> LocusResult.vcf_fields()
@@ -26,6 +26,7 @@ class Params:  # tr.rs:17-22 (+ --aln-scoring of cli.rs:271-280)
     max_depth: int = 250
     aln_scoring: Tuple[int, int, int] = (2, 5, 1)
     host_threads: int = 0
+    min_read_qual: float = 0.98   # --min-read-quality (cli.rs); < 0.9 switches filter_impure_trs on (tr.rs:37-50)
 
 
 @dataclass
@@ -52,13 +53,18 @@ class LocusResult:  # locus_result.rs:16-22
 
 
 def pack(loci):
-    """loci: list of dict(left_flank, right_flank, tr, motifs, ploidy, reads).  Returns the ABI arrays (host)."""
+    """loci: list of dict(left_flank, right_flank, tr, motifs, ploidy, reads[, genotyper ("size" | "cluster"), read_qual]).
+    Returns the ABI arrays (host)."""
     flank, tr, motifs, reads = bytearray(), bytearray(), bytearray(), bytearray()
     lf_off, lf_len, rf_off, rf_len, tr_off, tr_len, motif_off, set_begin, ploidy, lrb, read_off, read_len = ([] for _ in range(12))
     motif_off.append(0)
     set_begin.append(0)
     lrb.append(0)
+    genotyper, read_qual = [], []
     for L in loci:
+        genotyper.append(1 if L.get("genotyper", "size") in (1, "cluster") else 0)
+        rq = L.get("read_qual")
+        read_qual += [float("nan") if q is None else float(q) for q in (rq if rq is not None else [None] * len(L["reads"]))]
         lf_off.append(len(flank)); lf_len.append(len(L["left_flank"])); flank += L["left_flank"]
         rf_off.append(len(flank)); rf_len.append(len(L["right_flank"])); flank += L["right_flank"]
         tr_off.append(len(tr)); tr_len.append(len(L["tr"])); tr += L["tr"]
@@ -76,7 +82,8 @@ def pack(loci):
                 tr_blob=u8(tr), tr_off=np.array(tr_off, np.uint64), tr_len=np.array(tr_len, np.uint32), motif_blob=u8(motifs),
                 motif_off=np.array(motif_off, np.uint32), set_motif_begin=np.array(set_begin, np.uint32),
                 ploidy=np.array(ploidy, np.uint8), locus_read_begin=np.array(lrb, np.uint64), read_blob=u8(reads),
-                read_off=np.array(read_off, np.uint64), read_len=np.array(read_len, np.uint32))
+                read_off=np.array(read_off, np.uint64), read_len=np.array(read_len, np.uint32),
+                genotyper=np.array(genotyper, np.uint8), read_qual=np.array(read_qual, np.float64))
 
 
 def find_tr_spans_batch(batch, params=Params(), ctx=None, flank_dev=None, reads_dev=None):
@@ -144,9 +151,11 @@ def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, re
         flank_dev if flank_dev is not None else batch["flank_blob"], batch["lf_off"], batch["lf_len"], batch["rf_off"],
         batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
         batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
-        reads_dev if reads_dev is not None else batch["read_blob"], batch["read_off"], batch["read_len"])])
+        reads_dev if reads_dev is not None else batch["read_blob"], batch["read_off"], batch["read_len"])],
+        p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
+        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
     lp = _lib.LocusParams(params.search_flank_len, params.min_flank_id_frac, params.max_depth, params.aln_scoring[0],
-                          params.aln_scoring[1], params.aln_scoring[2], params.host_threads)
+                          params.aln_scoring[1], params.aln_scoring[2], params.host_threads, params.min_read_qual)
     ctx.check(_lib.lib().trgt_locus_batch(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out)))
     return out
 

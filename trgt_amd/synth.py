@@ -15,7 +15,7 @@ _FIELDS = [("flank_blob", np.uint8, "flank_bytes"), ("lf_off", np.uint64, "n_loc
            ("motif_off", np.uint32, "n_motifs+1"), ("set_motif_begin", np.uint32, "n_loci+1"), ("ploidy", np.uint8, "n_loci"),
            ("locus_read_begin", np.uint64, "n_loci+1"), ("read_blob", np.uint8, "read_bytes"), ("read_off", np.uint64, "n_reads"),
            ("read_len", np.uint32, "n_reads"), ("true_allele_len", np.uint32, "2*n_loci"), ("read_hap", np.uint8, "n_reads"),
-           ("read_truncated", np.uint8, "n_reads")]
+           ("read_truncated", np.uint8, "n_reads"), ("genotyper", np.uint8, "n_loci")]
 
 
 def default_params(config=2, **overrides):
