@@ -36,7 +36,7 @@ namespace trgt {
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
                       const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
-                      uint8_t* d_lf_hit, uint8_t* d_rf_hit);
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len);
 
 namespace {
 
@@ -307,7 +307,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
 
   // ---------------- stage A: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
   std::vector<uint64_t> piece_off(2 * (size_t)nl);
-  std::vector<uint32_t> read_locus((size_t)nr);
+  std::vector<uint32_t> read_locus((size_t)nr), heavy_len((size_t)nl);
   uint64_t flank_total = 0, read_total = 0, tr_total = 0, allele_total = 0;
   uint32_t max_read_len = 0;
   {
@@ -324,6 +324,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         rt = std::max<uint64_t>(rt, in->read_off[r] + in->read_len[r]);
         ml = std::max(ml, in->read_len[r]);
       }
+      heavy_len[(size_t)l] = heavy_read_len(ml, F);
       Acc& a = acc[(size_t)t];
       a.flank = std::max<uint64_t>(a.flank, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
       a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml);
@@ -345,7 +346,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
   const uint64_t *d_piece = nullptr, *d_roff = nullptr;
-  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr;
+  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr, *d_heavy = nullptr;
   void *d_ss = nullptr, *d_se = nullptr, *d_hl = nullptr, *d_hr = nullptr;
   void *h_ss = nullptr, *h_se = nullptr, *h_hl = nullptr, *h_hr = nullptr, *h_cells = nullptr;
   if ((rc = dev_in(c, S_FS_FLANK, in->flank_blob, (size_t)flank_total, &d_flank)) ||
@@ -354,6 +355,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       (rc = dev_in(c, S_FS_LIST, in->read_off, (size_t)nr, &d_roff)) ||
       (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen)) ||
       (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc)) ||
+      (rc = dev_in(c, S_FS_HEAVY, heavy_len.data(), (size_t)nl, &d_heavy)) ||
       (rc = dev_get(c, S_LOCUS_4, (size_t)nr * 4, &d_ss)) || (rc = dev_get(c, S_LOCUS_5, (size_t)nr * 4, &d_se)) ||
       (rc = dev_get(c, S_FS_HIT0, (size_t)nr, &d_hl)) || (rc = dev_get(c, S_FS_HIT1, (size_t)nr, &d_hr)) ||
       (rc = pin_get(c, P_SPAN_S, (size_t)nr * 4, &h_ss)) || (rc = pin_get(c, P_SPAN_E, (size_t)nr * 4, &h_se)) ||
@@ -393,7 +395,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
   *(uint64_t*)h_cells = 0;
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
-                              (uint8_t*)d_hl, (uint8_t*)d_hr)))
+                              (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy)))
     return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_ss, d_ss, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_se, d_se, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));

@@ -27,7 +27,12 @@ struct ScanArgs {
   uint64_t n_jobs;             // 2 * n_reads
   int32_t flank_len;
   int32_t* pos;                // [n_jobs] leftmost exact start or -1
-  JobDev* wfa_jobs; uint32_t* wfa_count;  // fallback alignments: job list and its length (wfa_count[0])
+  JobDev* wfa_jobs; uint32_t* wfa_count;  // fallback alignments: two-ended job list.  Reads shorter than heavy_len[locus] cannot hold
+                                          // both flanks: their alignments run to high scores and cost 10-100x the others, so they
+                                          // are appended from the front (wfa_count[0]) and drained first; the rest from the back
+                                          // (wfa_jobs[jobs_cap - 1 - k], wfa_count[2]).  Longest-first keeps the tail of the
+                                          // persistent alignment kernel short (12.45 vs 13.0 ms on the 10k-locus batch).
+  const uint32_t* heavy_len; uint32_t jobs_cap;
   JobDev* wfa_jobs_long; uint32_t long_tlen;  // reads longer than long_tlen go to a second list (wfa_count[1]): they would not fit the
                                               // LDS budget of the dedicated kernel and must not drag the whole batch onto the generic one
 };
@@ -90,9 +95,9 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
 // per workgroup reserves their slots in the job list (a per-job atomic on a single counter was most of this kernel's time).
 constexpr int SCAN_READS_PER_WG = 64;
 __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) {
-  __shared__ JobDev l_jobs[2 * SCAN_READS_PER_WG];
-  __shared__ uint32_t l_n, l_base;
-  if (threadIdx.x == 0) l_n = 0;
+  __shared__ JobDev l_jobs[2 * SCAN_READS_PER_WG];  // expensive jobs fill it from the front, the others from the back
+  __shared__ uint32_t l_n, l_n2, l_base, l_base2;
+  if (threadIdx.x == 0) { l_n = 0; l_n2 = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t n_reads = a.n_jobs >> 1;
@@ -155,15 +160,18 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
         jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
         jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
         if ((uint32_t)n > a.long_tlen) a.wfa_jobs_long[atomicAdd(a.wfa_count + 1, 1u)] = jd;  // rare: straight to the second list
-        else l_jobs[atomicAdd(&l_n, 1u)] = jd;
+        else if (!a.heavy_len || (uint32_t)n < a.heavy_len[a.read_locus[r]]) l_jobs[atomicAdd(&l_n, 1u)] = jd;
+        else l_jobs[2 * SCAN_READS_PER_WG - 1 - atomicAdd(&l_n2, 1u)] = jd;
       }
     }
   }
   }  // reads of this workgroup
   __syncthreads();
   if (threadIdx.x == 0 && l_n) l_base = atomicAdd(a.wfa_count, l_n);
+  if (threadIdx.x == 64 && l_n2) l_base2 = atomicAdd(a.wfa_count + 2, l_n2);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < l_n; i += blockDim.x) a.wfa_jobs[l_base + i] = l_jobs[i];
+  for (uint32_t i = threadIdx.x; i < l_n2; i += blockDim.x) a.wfa_jobs[a.jobs_cap - 1u - (l_base2 + i)] = l_jobs[2 * SCAN_READS_PER_WG - 1 - i];
 }
 
 struct CombineArgs {
@@ -195,7 +203,7 @@ __global__ void span_combine_kernel(const CombineArgs a) {
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
                       const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
-                      uint8_t* d_lf_hit, uint8_t* d_rf_hit) {
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len) {
   const uint64_t n_jobs = 2ull * (uint64_t)n_reads;
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
@@ -209,6 +217,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
   sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos;
   sa.wfa_jobs = (JobDev*)d_wjobs; sa.wfa_count = (uint32_t*)d_count;
+  sa.heavy_len = d_heavy_len; sa.jobs_cap = (uint32_t)n_jobs;
   // reads up to long_tlen keep the dedicated kernel at 4 workgroups per CU (LDS: ring + windows <= ~39 KB per alignment)
   const int ring_slots = std::max(p.mism, p.gapo + p.gape) + 1 + 2 * (p.gape + 1);
   const int64_t fit = 39000 / (2 * (int64_t)ring_slots + 4) - p.flank_len - 16;
@@ -235,6 +244,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   c->last_wfa_cells_dev = nullptr;
   WfaLaunch L;
   L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
+  L.n_jobs2_dev = (const uint32_t*)d_count + 2; L.jobs_cap = (uint32_t)n_jobs;
   L.pat_base = d_flank; L.txt_base = d_reads;
   const uint32_t short_max = has_long ? long_tlen : max_read_len;
   L.max_plen = p.flank_len; L.max_tlen = short_max; L.max_sum = (int64_t)p.flank_len + short_max;
@@ -244,7 +254,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   if ((rc = wfa_launch(c, wp, L))) return rc;
   if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
     WfaLaunch L2 = L;
-    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1;
+    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
     L2.keep_cells = true;
     if ((rc = wfa_launch(c, wp, L2))) return rc;
@@ -280,7 +290,7 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
   if (n_reads == 0) return TRGT_OK;
   if (2 * n_reads > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_find_spans_batch: too many reads in one call");
   std::vector<uint64_t> piece_off(2 * (size_t)n_loci);
-  std::vector<uint32_t> read_locus((size_t)n_reads);
+  std::vector<uint32_t> read_locus((size_t)n_reads), heavy_len((size_t)n_loci);
   uint64_t flank_total = 0, read_total = 0;
   uint32_t max_read_len = 0;
   for (int64_t l = 0; l < n_loci; ++l) {
@@ -289,7 +299,9 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
     piece_off[2 * l] = lf_off[l] + lf_len[l] - (uint64_t)p->flank_len;  // lf[lf.len()-F..]  (span_locater.rs:38)
     piece_off[2 * l + 1] = rf_off[l];                                    // rf[..F]           (:39)
     flank_total = std::max<uint64_t>(flank_total, std::max(lf_off[l] + lf_len[l], rf_off[l] + rf_len[l]));
-    for (uint64_t r = locus_read_begin[l]; r < locus_read_begin[l + 1]; ++r) read_locus[r] = (uint32_t)l;
+    uint32_t ml = 0;
+    for (uint64_t r = locus_read_begin[l]; r < locus_read_begin[l + 1]; ++r) { read_locus[r] = (uint32_t)l; ml = std::max(ml, read_len[r]); }
+    heavy_len[(size_t)l] = heavy_read_len(ml, p->flank_len);
   }
   for (int64_t r = 0; r < n_reads; ++r) {
     read_total = std::max<uint64_t>(read_total, read_off[r] + read_len[r]);
@@ -298,8 +310,9 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
   const uint64_t *d_piece = nullptr, *d_roff = nullptr;
-  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr;
-  if ((rc = dev_in(c, S_FS_FLANK, flank_blob, (size_t)flank_total, &d_flank)) ||
+  const uint32_t *d_rlen = nullptr, *d_rloc = nullptr, *d_heavy = nullptr;
+  if ((rc = dev_in(c, S_FS_HEAVY, heavy_len.data(), heavy_len.size(), &d_heavy)) ||
+      (rc = dev_in(c, S_FS_FLANK, flank_blob, (size_t)flank_total, &d_flank)) ||
       (rc = dev_in(c, S_FS_READS, read_blob, (size_t)read_total, &d_reads)) ||
       (rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
       (rc = dev_in(c, S_FS_LIST, read_off, (size_t)n_reads, &d_roff)) ||
@@ -311,7 +324,7 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
       (rc = o_l.init(c, S_FS_HIT0, lf_hit, (size_t)n_reads)) || (rc = o_r.init(c, S_FS_HIT1, rf_hit, (size_t)n_reads)))
     return rc;
   if ((rc = find_spans_device(c, *p, n_loci, n_reads, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, o_s.dev,
-                              o_e.dev, o_l.dev, o_r.dev)))
+                              o_e.dev, o_l.dev, o_r.dev, d_heavy)))
     return rc;
   if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
   unsigned long long cells = 0;

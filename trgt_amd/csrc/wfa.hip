@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     ws.rle_out = reinterpret_cast<uint32_t*>(base + a.off_rle_out);
     ws.run_start = reinterpret_cast<uint32_t*>(base + a.off_run_start);
   }
-  const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  const uint32_t n_front = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  const uint32_t n_jobs = n_front + (a.n_jobs2_dev ? *a.n_jobs2_dev : 0u);
   unsigned long long cells_acc = 0;
   for (uint32_t jb = 0; jb < a.jobs_per_block; ++jb) {
     __syncthreads();
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     __syncthreads();
     const uint32_t j = (uint32_t)sh.job;
     if (j >= n_jobs) break;
-    const JobDev job = a.jobs[j];
+    const JobDev job = a.jobs[j < n_front ? j : a.jobs_cap - 1u - (j - n_front)];
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* P = a.pat_base + job.pat_off;
     const uint8_t* Tx = a.txt_base + job.txt_off;
@@ -495,6 +496,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
   a.jobs = L.jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host; a.n_jobs_dev = L.n_jobs_dev;
+  a.n_jobs2_dev = L.n_jobs2_dev; a.jobs_cap = L.jobs_cap;
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
   a.status = L.status; a.score = L.score; a.n_match = L.n_match; a.span4 = L.span4; a.cigar = L.cigar; a.cigar_len = L.cigar_len;
   a.ops = L.ops; a.ops_len = L.ops_len;

@@ -42,6 +42,7 @@ struct KParams {  // by-value kernel argument
 struct KArgs {
   KParams kp;
   const JobDev* jobs; const uint32_t* n_jobs_dev; uint32_t n_jobs;
+  const uint32_t* n_jobs2_dev; uint32_t jobs_cap;   // optional second part of the list, stored downwards from jobs[jobs_cap - 1]
   const uint8_t* pat_base; const uint8_t* txt_base;
   unsigned int* counter;
   unsigned int* slot_flags; uint32_t n_slots_ws, jobs_per_block;  // workspace slots are acquired per resident workgroup

@@ -522,7 +522,8 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   uint8_t* const lds_seq = lds_dyn;  // byte copies live in the ring area: it is idle until level 0 is written
   uint16_t* const ring = reinterpret_cast<uint16_t*>(lds_dyn);
   uint32_t* const P4 = reinterpret_cast<uint32_t*>(lds_dyn + a.fast_ring_bytes);
-  const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  const uint32_t n_front = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  const uint32_t n_jobs = n_front + (a.n_jobs2_dev ? *a.n_jobs2_dev : 0u);
   unsigned long long cells_acc = 0;
   PROF_DECL;
   for (uint32_t jb = 0; jb < a.jobs_per_block; ++jb) {
@@ -533,7 +534,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     const uint32_t j = rfl((uint32_t)fs.job);
     if (j >= n_jobs) break;
     PROF_MARK(0);
-    const JobDev job = a.jobs[j];
+    const JobDev job = a.jobs[j < n_front ? j : a.jobs_cap - 1u - (j - n_front)];
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* const P = a.pat_base + job.pat_off;
     const uint8_t* const Tx = a.txt_base + job.txt_off;

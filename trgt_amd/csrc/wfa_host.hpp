@@ -10,8 +10,18 @@ struct JobDev {  // one alignment: pattern / text inside pat_base / txt_base, ou
 };
 
 
+// A read shorter than this cannot contain the repeat of its locus with both flanks around it (the longest read of the locus is
+// the yardstick): at least one of its flank alignments ends with a long gap, i.e. runs through many score levels.
+inline uint32_t heavy_read_len(uint32_t locus_max_read_len, int flank_len) {
+  const uint32_t margin = (uint32_t)flank_len + (uint32_t)flank_len / 5;
+  return locus_max_read_len > margin ? locus_max_read_len - margin : 0;
+}
+
 struct WfaLaunch {  // everything device-resident
   const JobDev* jobs_dev = nullptr; int64_t n_jobs_host = 0; const uint32_t* n_jobs_dev = nullptr;
+  // two-ended list: jobs expected to be expensive are appended from the front (count *n_jobs_dev) and are drained first,
+  // the others from the back (jobs_dev[jobs_cap - 1 - k], count *n_jobs2_dev)
+  const uint32_t* n_jobs2_dev = nullptr; uint32_t jobs_cap = 0;
   const uint8_t* pat_base = nullptr; const uint8_t* txt_base = nullptr;
   int64_t max_plen = 0, max_tlen = 0, max_sum = 0;
   int threads = 0;
