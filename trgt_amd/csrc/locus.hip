@@ -653,7 +653,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     int64_t tb0 = now_ns();
     struct JobRef { Repair* rep; int member; };
     std::vector<JobRef> jrefs;
-    std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff, coff; std::vector<uint32_t> plen, tlen;
+    std::vector<uint8_t> cblob; std::vector<uint64_t> poff, toff; std::vector<uint32_t> plen, tlen;
     for (auto& sc : scratch)
       for (auto& rep : sc.repairs) {
         const Seg bb = work[(size_t)rep.locus].pick[rep.allele];
@@ -661,21 +661,19 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         cblob.insert(cblob.end(), bb.p, bb.p + bb.n);
         for (size_t m = 0; m < rep.members.size(); ++m) {
           const Seg& sg = rep.members[m];
-          coff.push_back(coff.empty() ? 0 : coff.back() + plen.back() + tlen.back() + 1);
           poff.push_back(bo); plen.push_back(bb.n);
           toff.push_back(cblob.size()); tlen.push_back(sg.n);
           cblob.insert(cblob.end(), sg.p, sg.p + sg.n);
           jrefs.push_back({&rep, (int)m});
         }
       }
-    std::vector<uint32_t> cigars, clen(jrefs.size());
+    PackedCigars pcig;
     if (!jrefs.empty()) {
       trgt_wfa_params wp;
       trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
       wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
-      cigars.resize((size_t)(coff.back() + plen.back() + tlen.back() + 1));
-      rc = trgt_wfa_batch(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
-                          nullptr, nullptr, cigars.data(), coff.data(), clen.data(), nullptr, nullptr, nullptr);
+      rc = wfa_batch_impl(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pcig);
       if (rc) return rc;
       stat_cons_jobs = (int64_t)jrefs.size();
     }
@@ -695,7 +693,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         Repair* rep = jrefs[j].rep;
         std::vector<std::vector<uint32_t>> cg;
         for (size_t m = 0; m < rep->members.size(); ++m, ++j)
-          cg.emplace_back(cigars.begin() + coff[j], cigars.begin() + coff[j] + clen[j]);  // failed alignment -> empty CIGAR
+          cg.emplace_back(pcig.data.begin() + (ptrdiff_t)pcig.off[j], pcig.data.begin() + (ptrdiff_t)pcig.off[j + 1]);  // failed alignment -> empty CIGAR
         const Seg bb = work[(size_t)rep->locus].pick[rep->allele];
         rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
       }

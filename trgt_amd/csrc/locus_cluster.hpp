@@ -48,8 +48,9 @@ inline void ward_nnchain(double* dists, int n, std::vector<MergeStep>& steps) {
       nearest = succ[(size_t)tip]; best = D.at((size_t)tip, (size_t)nearest);
       for (int i = succ[(size_t)nearest]; i < n; i = succ[(size_t)i]) { const double v = D.at((size_t)tip, (size_t)i); if (v < best) { best = v; nearest = i; } }
     } else {
+      nearest = chain[chain.size() - 3];  // drop the merged pair and the element before it; that element is looked at again
       chain.resize(chain.size() - 3);
-      tip = chain.back(); nearest = chain[chain.size()];  // the element just dropped third-from-last: still in the buffer
+      tip = chain.back();
       best = D.sym((size_t)tip, (size_t)nearest);
     }
     // grow the chain until two clusters are each other's nearest neighbour; ties keep the previous chain element
@@ -183,10 +184,9 @@ struct ClusterBatch {
   // make_consensus (:41-56) for the listed (locus, group) pairs: one alignment batch, then repair_consensus per group
   int consensus_round(const std::vector<std::pair<int, int>>& todo) {
     if (todo.empty()) return TRGT_OK;
-    std::vector<uint64_t> po, to, co; std::vector<uint32_t> pl, tl;
+    std::vector<uint64_t> po, to; std::vector<uint32_t> pl, tl;
     std::vector<size_t> first(todo.size() + 1, 0);
     std::vector<int> backbone(todo.size());
-    uint64_t cig = 0;
     for (size_t t = 0; t < todo.size(); ++t) {
       ClusterLocus& L = loci[(size_t)todo[t].first];
       const std::vector<int>& g = L.group[todo[t].second];
@@ -195,16 +195,15 @@ struct ClusterBatch {
       for (int i : g) {
         po.push_back(L.blob_off + L.seg_off[(size_t)bb]); pl.push_back(L.trs[bb].n);
         to.push_back(L.blob_off + L.seg_off[(size_t)i]); tl.push_back(L.trs[i].n);
-        co.push_back(cig); cig += (uint64_t)L.trs[bb].n + L.trs[i].n + 1;
       }
       first[t + 1] = po.size();
     }
     trgt_wfa_params wp;
     trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
     wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
-    std::vector<uint32_t> cigars((size_t)cig), clen(po.size());
-    const int rc = trgt_wfa_batch(c, &wp, (int64_t)po.size(), blob.data(), po.data(), pl.data(), to.data(), tl.data(), nullptr, nullptr, nullptr,
-                                  nullptr, cigars.data(), co.data(), clen.data(), nullptr, nullptr, nullptr);
+    PackedCigars pc;
+    const int rc = wfa_batch_impl(c, &wp, (int64_t)po.size(), blob.data(), po.data(), pl.data(), to.data(), tl.data(), nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pc);
     if (rc) return rc;
     n_cons += (int64_t)po.size();
     pool->parallel_for((int64_t)todo.size(), 4, [&](int64_t t, int) {
@@ -216,7 +215,7 @@ struct ClusterBatch {
       for (size_t m = 0; m < g.size(); ++m) {
         const size_t j = first[(size_t)t] + m;
         seqs.push_back(L.trs[g[m]]);
-        cg.emplace_back(cigars.begin() + (ptrdiff_t)co[j], cigars.begin() + (ptrdiff_t)(co[j] + clen[j]));
+        cg.emplace_back(pc.data.begin() + (ptrdiff_t)pc.off[j], pc.data.begin() + (ptrdiff_t)pc.off[j + 1]);
         lo = std::min(lo, L.trs[g[m]].n); hi = std::max(hi, L.trs[g[m]].n);  // get_ci (:229-233)
       }
       const Seg bb = L.trs[backbone[(size_t)t]];

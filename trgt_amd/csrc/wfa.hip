@@ -569,16 +569,32 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
 
 using namespace trgt;
 
-extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs,
-                              const uint64_t* pat_off, const uint32_t* pat_len, const uint64_t* txt_off,
-                              const uint32_t* txt_len, int32_t* status, int32_t* score, int32_t* n_match, uint32_t* span4,
-                              uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
-                              const uint64_t* ops_off, uint32_t* ops_len) {
+namespace trgt {
+namespace {
+// run-length CIGARs of a batch, gathered into one dense buffer on the device: only the entries actually produced cross PCIe
+__global__ void cigar_pack_kernel(const uint32_t* __restrict__ cigar, const JobDev* __restrict__ jobs, const uint32_t* __restrict__ clen,
+                                  const uint64_t* __restrict__ dst_off, uint32_t* __restrict__ packed, uint64_t n) {
+  const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const uint32_t* src = cigar + jobs[j].cigar_off;
+  uint32_t* dst = packed + dst_off[j];
+  for (uint32_t i = threadIdx.x & 63; i < clen[j]; i += 64) dst[i] = src[i];
+}
+}  // namespace
+
+// trgt_wfa_batch proper.  packed != nullptr: the caller wants the run-length CIGARs as one dense array (job j =
+// packed->data[packed->off[j] .. packed->off[j + 1])) instead of the worst-case-sized slots of the public ABI -- the internal
+// callers (consensus alignments of trgt_locus_batch) read a few runs per job, not plen + tlen + 1.
+int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
+                   const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
+                   int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
+                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: null argument");
   if ((cigar && (!cigar_off || !cigar_len)) || (ops && (!ops_off || !ops_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: cigar/ops need their offset and length arrays");
+  if (packed) { packed->data.clear(); packed->off.assign((size_t)n_jobs + 1, 0); }
   if (n_jobs == 0) return TRGT_OK;
   if (n_jobs > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: too many jobs");
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
@@ -589,6 +605,7 @@ extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t
     JobDev& jd = jobs[(size_t)j];
     jd.pat_off = pat_off[j]; jd.txt_off = txt_off[j]; jd.pat_len = pat_len[j]; jd.txt_len = txt_len[j]; jd.out_index = (uint32_t)j;
     jd.cigar_off = cigar ? cigar_off[j] : 0; jd.ops_off = ops ? ops_off[j] : 0;
+    if (packed) { jd.cigar_off = cigar_total; cigar_total += (uint64_t)pat_len[j] + txt_len[j] + 1; }
     L.max_plen = std::max<int64_t>(L.max_plen, pat_len[j]); L.max_tlen = std::max<int64_t>(L.max_tlen, txt_len[j]);
     L.max_sum = std::max<int64_t>(L.max_sum, (int64_t)pat_len[j] + txt_len[j]);
     seq_total = std::max<uint64_t>(seq_total, std::max(pat_off[j] + pat_len[j], txt_off[j] + txt_len[j]));
@@ -603,9 +620,17 @@ extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t
   if ((rc = dev_get(c, S_WFA_JOBS, jobs.size() * sizeof(JobDev), &d_jobs))) return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), hipMemcpyHostToDevice, c->stream));
   DevOut<int32_t> o_status, o_score, o_nm; DevOut<uint32_t> o_span, o_cigar, o_clen, o_olen; DevOut<uint8_t> o_ops;
+  std::vector<uint32_t> h_clen;
+  if (packed) {  // device-only CIGAR slots; the lengths come back first
+    void* d = nullptr;
+    if ((rc = dev_get(c, S_WFA_CIGAR, (size_t)cigar_total * 4, &d))) return rc;
+    o_cigar.dev = (uint32_t*)d;
+    h_clen.resize((size_t)n_jobs);
+    cigar_len = h_clen.data();
+  }
   if ((rc = o_status.init(c, S_WFA_STATUS, status, (size_t)n_jobs)) || (rc = o_score.init(c, S_WFA_SCORE, score, (size_t)n_jobs)) ||
       (rc = o_nm.init(c, S_WFA_NMATCH, n_match, (size_t)n_jobs)) || (rc = o_span.init(c, S_WFA_SPAN, span4, (size_t)n_jobs * 4)) ||
-      (rc = o_cigar.init(c, S_WFA_CIGAR, cigar, (size_t)cigar_total)) || (rc = o_clen.init(c, S_WFA_CLEN, cigar_len, (size_t)n_jobs)) ||
+      (!packed && (rc = o_cigar.init(c, S_WFA_CIGAR, cigar, (size_t)cigar_total))) || (rc = o_clen.init(c, S_WFA_CLEN, cigar_len, (size_t)n_jobs)) ||
       (rc = o_ops.init(c, S_WFA_OPS, ops, (size_t)ops_total)) || (rc = o_olen.init(c, S_WFA_OLEN, ops_len, (size_t)n_jobs)))
     return rc;
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.n_jobs_dev = nullptr;
@@ -621,5 +646,31 @@ extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t
   TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
+  if (packed) {
+    uint64_t total = 0;
+    for (int64_t j = 0; j < n_jobs; ++j) { packed->off[(size_t)j] = total; total += h_clen[(size_t)j]; }
+    packed->off[(size_t)n_jobs] = total;
+    packed->data.resize((size_t)total);
+    if (total) {
+      void *d_poff = nullptr, *d_packed = nullptr;
+      if ((rc = dev_get(c, S_WFA_POFF, (size_t)n_jobs * 8, &d_poff)) || (rc = dev_get(c, S_WFA_PACKED, (size_t)total * 4, &d_packed))) return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d_poff, packed->off.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(cigar_pack_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, (const uint32_t*)o_cigar.dev,
+                         (const JobDev*)d_jobs, (const uint32_t*)o_clen.dev, (const uint64_t*)d_poff, (uint32_t*)d_packed, (uint64_t)n_jobs);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      TRGT_HIP_TRY(c, hipMemcpyAsync(packed->data.data(), d_packed, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  }
   return TRGT_OK;
+}
+}  // namespace trgt
+
+extern "C" int trgt_wfa_batch(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs,
+                              const uint64_t* pat_off, const uint32_t* pat_len, const uint64_t* txt_off,
+                              const uint32_t* txt_len, int32_t* status, int32_t* score, int32_t* n_match, uint32_t* span4,
+                              uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
+                              const uint64_t* ops_off, uint32_t* ops_len) {
+  return trgt::wfa_batch_impl(c, p, n_jobs, seqs, pat_off, pat_len, txt_off, txt_len, status, score, n_match, span4, cigar, cigar_off,
+                              cigar_len, ops, ops_off, ops_len, nullptr);
 }

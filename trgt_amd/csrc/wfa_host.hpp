@@ -1,5 +1,6 @@
 // trgt_amd/csrc/wfa_host.hpp -- job record and host-side launch descriptor of the WFA kernel (no device code).
 #pragma once
+#include <vector>
 #include "common.hpp"
 
 namespace trgt {
@@ -35,5 +36,13 @@ struct WfaLaunch {  // everything device-resident
 // Enqueue the WFA kernel on the ctx stream (asynchronous).  The number of wavefront offsets computed is
 // accumulated in device memory at ctx->last_wfa_cells_dev.
 int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L);
+
+// Run-length CIGARs of a whole batch in one dense array: job j = data[off[j] .. off[j + 1]) (len << 4 | code, as cigar_get_CIGAR).
+struct PackedCigars { std::vector<uint32_t> data; std::vector<uint64_t> off; };
+// trgt_wfa_batch with an optional dense CIGAR result (packed != nullptr replaces cigar / cigar_off / cigar_len).
+int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
+                   const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
+                   int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
+                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed);
 
 }  // namespace trgt
