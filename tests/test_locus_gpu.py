@@ -279,3 +279,65 @@ def test_filter_impure_trs_matches_oracle(oracle, mods):
     b5 = synth.generate(10, first_locus=40, config=5, sub_rate=0.01)
     for mode, out in _run_both(locus, b5, params):
         _compare(oracle, locus, b5, out, params, range(10))
+
+
+def _cfg3_loci(rng, sets, long_lo, long_hi, n_reads):
+    """allele 1 = 10-40 copies in total, allele 2 = log-uniform total length built as consecutive runs
+    of each motif (N filled uniformly), 1 % of the units carry a substitution; reads with HiFi-like errors."""
+    from helpers import mutate, rand_dna
+    fill = lambda m: bytes(b if b != ord("N") else int(rng.choice(list(b"ACGT"))) for b in m)
+    def allele(motifs, total_len):
+        out = bytearray()
+        per = max(1, total_len // len(motifs))
+        for m in motifs:
+            run = bytearray()
+            while len(run) < per:
+                u = bytearray(fill(m))
+                if rng.random() < 0.01:
+                    u[int(rng.integers(0, len(u)))] = int(rng.choice(list(b"ACGT")))
+                run += u
+            out += run
+        return bytes(out)
+    loci = []
+    for s in sets:
+        motifs = [m.encode() for m in s["motifs"]]
+        mean_len = sum(len(m) for m in motifs) / len(motifs)
+        a1 = allele(motifs, int(int(rng.integers(10, 41)) * mean_len))
+        a2 = allele(motifs, int(np.exp(rng.uniform(np.log(long_lo), np.log(long_hi)))))
+        lf, rf = rand_dna(rng, 250), rand_dna(rng, 250)
+        lc, rc = rand_dna(rng, 250), rand_dna(rng, 250)
+        reads = [mutate(rng, lc + lf + (a1 if i % 2 else a2) + rf + rc, 5e-4, 2.5e-4, 2.5e-4) for i in range(n_reads)]
+        reads.append(reads[0][: 250 + 250 + len(a2) // 2])  # a read that ends inside the repeat
+        loci.append(dict(left_flank=lf, right_flank=rf, tr=a1, motifs=motifs, reads=reads))
+    return loci
+
+
+def test_cfg3_pathogenic_motif_sets(oracle, mods):
+    # BASELINE configs[2]: the 56 motif sets of the reference's pathogenic catalog (tests/golden/pathogenic_motif_sets.json, from
+    # repeats/pathogenic_repeats.hg38.bed) with one expanded allele each: multi-motif HMMs up to 170 states, alleles past the
+    # LDS-staged sizes of the HMM and genotyper kernels, reads longer than the dedicated WFA kernel takes
+    import json, os
+    locus, _ = mods
+    sets = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pathogenic_motif_sets.json")))["loci"]
+    assert len(sets) == 56
+    rng = np.random.default_rng(56)
+    loci = _cfg3_loci(rng, sets, 500, 3000, 8)
+    b = locus.pack(loci)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+    res = locus.analyze_batch(loci[:4])
+    assert all(len(r.genotype) == 2 for r in res)
+
+
+def test_cfg3_alleles_to_10kb(oracle, mods):
+    # the upper end of cfg3: 10 kb alleles, RFC1's ten-motif set (170 HMM states) and two single-motif loci
+    import json, os
+    locus, _ = mods
+    sets = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pathogenic_motif_sets.json")))["loci"]
+    pick = [s for s in sets if s["id"] in ("RFC1", "HTT", "CNBP")]
+    rng = np.random.default_rng(10)
+    loci = _cfg3_loci(rng, pick, 9000, 10000, 6)
+    b = locus.pack(loci)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+        assert int(out.allele_len.max()) > 8500, mode
