@@ -81,8 +81,10 @@ int trgt_hip_set_workspace_limit(trgt_hip_ctx* ctx, uint64_t bytes);
 #define TRGT_K_FLANK_SCAN 0   /* exact flank search            */
 #define TRGT_K_WFA 1          /* wavefront alignment kernel: trgt_wfa_batch / consensus alignments */
 #define TRGT_K_HMM 2          /* Viterbi + traceback + decode   */
-#define TRGT_K_WFA_FLANK 3    /* wavefront alignment kernel: flank fallback inside trgt_find_spans_batch */
-#define TRGT_K_COUNT 4
+#define TRGT_K_WFA_FLANK 3    /* wavefront alignment kernel: flank fallback inside trgt_find_spans_batch -- the launch over the
+                                 reads too short to span their locus (the expensive alignments), or the only launch */
+#define TRGT_K_WFA_FLANK_REST 4 /* ... the launch(es) over the remaining fallback alignments */
+#define TRGT_K_COUNT 5
 int trgt_hip_timing_enable(trgt_hip_ctx* ctx, int on);
 int trgt_hip_timing_reset(trgt_hip_ctx* ctx);
 /* accumulated device time (ms), number of launches, and DP work items (wavefront offsets / Viterbi cells) */

@@ -36,7 +36,7 @@ namespace trgt {
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
                       const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
-                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len);
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len, uint32_t heavy_tlen_max);
 
 namespace {
 
@@ -279,7 +279,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
-  int64_t stat_flank_jobs = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
+  int64_t stat_flank_jobs = 0, stat_flank_heavy = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
   auto init_outputs = [&]() {
     for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
     for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
@@ -309,9 +309,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   std::vector<uint64_t> piece_off(2 * (size_t)nl);
   std::vector<uint32_t> read_locus((size_t)nr), heavy_len((size_t)nl);
   uint64_t flank_total = 0, read_total = 0, tr_total = 0, allele_total = 0;
-  uint32_t max_read_len = 0;
+  uint32_t max_read_len = 0, heavy_tlen_max = 0;
   {
-    struct alignas(64) Acc { uint64_t flank = 0, read = 0, tr = 0, allele = 0; uint32_t max_len = 0; };  // one cache line per worker
+    struct alignas(64) Acc { uint64_t flank = 0, read = 0, tr = 0, allele = 0; uint32_t max_len = 0, heavy = 0; };  // one cache line per worker
     std::vector<Acc> acc((size_t)pool->size());
     std::atomic<int64_t> short_flank{-1};
     pool->parallel_for(nl, 256, [&](int64_t l, int t) {
@@ -327,14 +327,14 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       heavy_len[(size_t)l] = heavy_read_len(ml, F);
       Acc& a = acc[(size_t)t];
       a.flank = std::max<uint64_t>(a.flank, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
-      a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml);
+      a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml); a.heavy = std::max(a.heavy, heavy_len[(size_t)l]);
       a.tr = std::max<uint64_t>(a.tr, in->tr_off[l] + in->tr_len[l]);
       a.allele = std::max<uint64_t>(a.allele, std::max(out->allele_off[2 * l], out->allele_off[2 * l + 1]) + out->allele_cap[l]);
     });
     if (short_flank >= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: locus %lld flank shorter than flank_len", (long long)short_flank.load());
     for (const Acc& a : acc) {
       flank_total = std::max(flank_total, a.flank); read_total = std::max(read_total, a.read); max_read_len = std::max(max_read_len, a.max_len);
-      tr_total = std::max(tr_total, a.tr); allele_total = std::max(allele_total, a.allele);
+      tr_total = std::max(tr_total, a.tr); allele_total = std::max(allele_total, a.allele); heavy_tlen_max = std::max(heavy_tlen_max, a.heavy);
     }
   }
   c->dbg_ns[0] = now_ns() - t0;  // set-up: thread pool, model thread, piece / read-locus tables
@@ -393,15 +393,15 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   hipEvent_t evA = nullptr;
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
   TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
-  *(uint64_t*)h_cells = 0;
+  ((uint64_t*)h_cells)[0] = ((uint64_t*)h_cells)[1] = 0;
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
-                              (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy)))
+                              (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_ss, d_ss, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_se, d_se, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_hl, d_hl, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_hr, d_hr, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
-  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
   if (dev_gt) {
     gt::GtArgs ga;
     ga.reads = d_reads; ga.read_off = d_roff; ga.read_len = d_rlen; ga.locus_read_begin = g.lrb;
@@ -594,10 +594,17 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   std::memcpy(out->span_end, h_se, (size_t)nr * 4);
   {
     std::vector<int64_t> part((size_t)pool->size() * 8, 0);
-    pool->parallel_for(nr, 8192, [&](int64_t r, int t) { part[(size_t)t * 8] += (((const uint8_t*)h_hl)[r] != 1) + (((const uint8_t*)h_hr)[r] != 1); });
-    for (int t = 0; t < pool->size(); ++t) stat_flank_jobs += part[(size_t)t * 8];
+    pool->parallel_for(nr, 8192, [&](int64_t r, int t) {
+      const int64_t n = (((const uint8_t*)h_hl)[r] != 1) + (((const uint8_t*)h_hr)[r] != 1);
+      part[(size_t)t * 8] += n;
+      if (in->read_len[r] < heavy_len[read_locus[(size_t)r]]) part[(size_t)t * 8 + 1] += n;  // alignments of the first (dominant) launch
+    });
+    for (int t = 0; t < pool->size(); ++t) { stat_flank_jobs += part[(size_t)t * 8]; stat_flank_heavy += part[(size_t)t * 8 + 1]; }
   }
-  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)*(uint64_t*)h_cells;
+  if (c->timing) {  // [0] all flank alignments, [1] those of the first (dominant) launch
+    c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)((uint64_t*)h_cells)[1];
+    c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(((uint64_t*)h_cells)[0] - ((uint64_t*)h_cells)[1]);
+  }
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
     const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];  // the alleles come back packed: a second, exact-size copy
@@ -788,8 +795,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
-    for (int i = 0; i < 6; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
-    s[15] = stat_ed_jobs;
+    for (int i = 0; i < 5; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
+    s[14] = stat_flank_heavy; s[15] = stat_ed_jobs;
   }
   return TRGT_OK;
 }

@@ -203,7 +203,7 @@ __global__ void span_combine_kernel(const CombineArgs a) {
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
                       const uint32_t* d_read_locus, uint32_t max_read_len, int32_t* d_span_start, int32_t* d_span_end,
-                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len) {
+                      uint8_t* d_lf_hit, uint8_t* d_rf_hit, const uint32_t* d_heavy_len, uint32_t heavy_tlen_max) {
   const uint64_t n_jobs = 2ull * (uint64_t)n_reads;
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
@@ -251,12 +251,27 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   L.threads = getenv("TRGT_FLANK_THREADS") ? atoi(getenv("TRGT_FLANK_THREADS")) : 256;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
+  // Two launches.  The front of the list (reads too short to span their locus: 95 % of the wavefront offsets) holds short texts
+  // only, so its launch is planned for heavy_tlen_max: a smaller LDS ring per alignment and one more resident workgroup per CU
+  // (occupancy is what this latency-bound kernel lives on: 16.9 -> 15.1 ms from 4 to 5 per CU).  The rest follows at the full size.
+  const bool split = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < short_max && !getenv("TRGT_WFA_ONE_LAUNCH");
+  if (split) {
+    WfaLaunch LH = L;
+    LH.n_jobs2_dev = nullptr; LH.jobs_cap = 0;
+    LH.max_tlen = heavy_tlen_max; LH.max_sum = (int64_t)p.flank_len + heavy_tlen_max;
+    if ((rc = wfa_launch(c, wp, LH))) return rc;
+    // offsets of the first launch, kept next to the running total (cells[1]): the roofline of the dominant launch counts its own
+    TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
+    L.n_jobs_dev = (const uint32_t*)d_count + 3;  // always 0: this launch takes the back part of the list only
+    L.keep_cells = true; L.timer_slot = TRGT_K_WFA_FLANK_REST;
+  }
   if ((rc = wfa_launch(c, wp, L))) return rc;
+  if (!split) TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
   if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
     WfaLaunch L2 = L;
     L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
-    L2.keep_cells = true;
+    L2.keep_cells = true; L2.timer_slot = TRGT_K_WFA_FLANK_REST;
     if ((rc = wfa_launch(c, wp, L2))) return rc;
   }
   CombineArgs ca;
@@ -292,7 +307,7 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
   std::vector<uint64_t> piece_off(2 * (size_t)n_loci);
   std::vector<uint32_t> read_locus((size_t)n_reads), heavy_len((size_t)n_loci);
   uint64_t flank_total = 0, read_total = 0;
-  uint32_t max_read_len = 0;
+  uint32_t max_read_len = 0, heavy_tlen_max = 0;
   for (int64_t l = 0; l < n_loci; ++l) {
     if ((int64_t)lf_len[l] < p->flank_len || (int64_t)rf_len[l] < p->flank_len)
       return fail(c, TRGT_ERR_INVALID, "trgt_find_spans_batch: locus %lld flank shorter than flank_len", (long long)l);
@@ -302,6 +317,7 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
     uint32_t ml = 0;
     for (uint64_t r = locus_read_begin[l]; r < locus_read_begin[l + 1]; ++r) { read_locus[r] = (uint32_t)l; ml = std::max(ml, read_len[r]); }
     heavy_len[(size_t)l] = heavy_read_len(ml, p->flank_len);
+    heavy_tlen_max = std::max(heavy_tlen_max, heavy_len[(size_t)l]);
   }
   for (int64_t r = 0; r < n_reads; ++r) {
     read_total = std::max<uint64_t>(read_total, read_off[r] + read_len[r]);
@@ -324,12 +340,12 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
       (rc = o_l.init(c, S_FS_HIT0, lf_hit, (size_t)n_reads)) || (rc = o_r.init(c, S_FS_HIT1, rf_hit, (size_t)n_reads)))
     return rc;
   if ((rc = find_spans_device(c, *p, n_loci, n_reads, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, o_s.dev,
-                              o_e.dev, o_l.dev, o_r.dev, d_heavy)))
+                              o_e.dev, o_l.dev, o_r.dev, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
   if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
-  unsigned long long cells = 0;
-  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long cells[2] = {0, 0};  // total, first launch
+  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->timing) c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells;
+  if (c->timing) { c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells[1]; c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(cells[0] - cells[1]); }
   return TRGT_OK;
 }

@@ -514,6 +514,10 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     // (the byte copies of the two sequences are staged in the ring area, which is idle until level 0 is written)
     if (ring_bytes + win_bytes <= 96 * 1024 && seq_need <= ring_bytes) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds = (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
   }
+  // TRGT's flank-location configuration has an instantiation of its own (wfa_fast.hpp, SPEC)
+  const bool fast_spec = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tbf < 0 && a.kp.tef < 0 &&
+                         !getenv("TRGT_WFA_NO_SPEC");
+  void (*const fast_fn)(const KArgs) = fast_spec ? wfa_fast_kernel<true> : wfa_fast_kernel<false>;
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
   int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));
@@ -522,7 +526,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     // waiting for dispatch would do no work anyway, and while they wait the dispatcher keeps kernels of other streams (the
     // gather / HMM kernels of an earlier chunk) from starting.
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wfa_fast_kernel, threads, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fast_fn, threads, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
     int64_t per_cu = occ;
     if (const char* e = getenv("TRGT_WFA_GRID_PER_CU")) per_cu = atoi(e);
     if (getenv("TRGT_WFA_DEBUG")) fprintf(stderr, "[wfa] fast kernel lds=%zu occupancy=%d per_cu=%lld threads=%d\n", lds, occ, (long long)per_cu, threads);
@@ -531,8 +535,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   const dim3 grid((unsigned)grid_blocks), block((unsigned)threads);
   if (a.fast_wcap > 0) {
     // every job of this batch qualifies for the dedicated LDS-resident kernel (wfa_fast.hpp)
-    if (lds > 48 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)wfa_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wfa_fast_kernel, grid, block, lds, c->stream, a);
+    if (lds > 48 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)fast_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (fast_spec) hipLaunchKernelGGL(wfa_fast_kernel<true>, grid, block, lds, c->stream, a);
+    else hipLaunchKernelGGL(wfa_fast_kernel<false>, grid, block, lds, c->stream, a);
   } else
   switch (p.metric) {
     case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;

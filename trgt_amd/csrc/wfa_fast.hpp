@@ -112,6 +112,11 @@ struct FastEnd { int status, score, k, off; unsigned long long cells; };
 
 // P4, T4: LDS 4-byte sliding windows of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  A16: history arena,
 // gd: history descriptors (both HBM, uniform pointers).  All threads (blockDim.x a multiple of 64).
+// SPEC: the configuration TRGT's flank location always runs -- gap-affine (x, o, e) = (2, 5, 1), ends-free with the whole text
+// free at both ends and the pattern not at all (span_locater.rs:17, genotype.rs:66-80) -- as compile-time constants: the ring
+// geometry, the source-level selects and the termination test fold away, and with them a third of the scalar registers
+// (the general instantiation spills SGPRs to VGPR lanes in the per-level prologue).
+template <bool SPEC>
 __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJob& J, const uint32_t* P4, const uint32_t* T4, uint16_t* ring,
                                                      int wcap, g_u16* A16, uint32_t* gd) {
   FastShared& fs = g_fsh;
@@ -119,13 +124,14 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   const int wave = rfl(tid >> 6), nW = nT >> 6;
   const int plen = J.plen, tlen = J.tlen, koff = plen + 2;  // one pad cell each side: kb-1 / kb+1 reads never leave the slot
   const int ak_b = tlen - plen + koff;
-  const int x = pen.x, oe = pen.o1 + pen.e1, e = pen.e1, scope = pen.scope;
+  const int x = SPEC ? 2 : pen.x, oe = SPEC ? 6 : pen.o1 + pen.e1, e = SPEC ? 1 : pen.e1, scope = SPEC ? 7 : pen.scope;
   const int RM = max(x, oe) + 1, RI = e + 1;
   uint16_t* const Mr = ring;
   uint16_t* const Ir = ring + RM * wcap;
   uint16_t* const Dr = Ir + RI * wcap;
   const uint32_t cap = J.cap;
-  const int n_slots = J.n_slots, span = J.span, pef = J.pef, tef = J.tef, pbf = J.pbf, tbf = J.tbf;
+  const int n_slots = J.n_slots, span = SPEC ? 1 : J.span, pef = SPEC ? 0 : J.pef, tef = SPEC ? tlen : J.tef, pbf = SPEC ? 0 : J.pbf,
+            tbf = SPEC ? tlen : J.tbf;
   const uint32_t PDN = (uint32_t)(koff + 1) | ((uint32_t)(koff - 1) << 16);  // the canonical null wavefront (lo = 1, hi = -1)
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A16 - HIST_BIAS), 0, -1, 0x00020000);
   // which sources are "the level just finished" (taken from registers) rather than an older one (taken from the LDS ring)
@@ -501,6 +507,7 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
 // acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring (first used to stage the sequence bytes) | windows.
+template <bool SPEC>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
   FastShared& fs = g_fsh;
@@ -564,7 +571,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       J.n_slots = (int)a.uni_slots; J.cap = a.arena_uni_cap;
     }
     PROF_MARK(1);
-    const FastEnd E = wf_run_lds_affine(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
+    const FastEnd E = wf_run_lds_affine<SPEC>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
 #ifdef TRGT_WFA_PROF
     const unsigned long long pf_t2 = pf_t;
 #endif
