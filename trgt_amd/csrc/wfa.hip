@@ -516,7 +516,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   // TRGT's flank-location configuration has an instantiation of its own (wfa_fast.hpp, SPEC)
   const bool fast_spec = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tbf < 0 && a.kp.tef < 0 &&
-                         !getenv("TRGT_WFA_NO_SPEC");
+                         threads == 256 && !getenv("TRGT_WFA_NO_SPEC");
   void (*const fast_fn)(const KArgs) = fast_spec ? wfa_fast_kernel<true> : wfa_fast_kernel<false>;
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs

@@ -120,7 +120,7 @@ template <bool SPEC>
 __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJob& J, const uint32_t* P4, const uint32_t* T4, uint16_t* ring,
                                                      int wcap, g_u16* A16, uint32_t* gd) {
   FastShared& fs = g_fsh;
-  const int tid = threadIdx.x, nT = blockDim.x, lane = tid & 63;
+  const int tid = threadIdx.x, nT = SPEC ? 256 : (int)blockDim.x, lane = tid & 63;  // SPEC is launched with 256 threads only
   const int wave = rfl(tid >> 6), nW = nT >> 6;
   const int plen = J.plen, tlen = J.tlen, koff = plen + 2;  // one pad cell each side: kb-1 / kb+1 reads never leave the slot
   const int ak_b = tlen - plen + koff;
@@ -506,7 +506,7 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
-// acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring (first used to stage the sequence bytes) | windows.
+// acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring | pattern windows | text windows.
 template <bool SPEC>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
@@ -526,7 +526,6 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   uint32_t* const rle_tmp = reinterpret_cast<uint32_t*>(wsb + a.off_rle_tmp);
   uint32_t* const rle_out = reinterpret_cast<uint32_t*>(wsb + a.off_rle_out);
   uint32_t* const run_start = reinterpret_cast<uint32_t*>(wsb + a.off_run_start);
-  uint8_t* const lds_seq = lds_dyn;  // byte copies live in the ring area: it is idle until level 0 is written
   uint16_t* const ring = reinterpret_cast<uint16_t*>(lds_dyn);
   uint32_t* const P4 = reinterpret_cast<uint32_t*>(lds_dyn + a.fast_ring_bytes);
   const uint32_t n_front = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
@@ -545,22 +544,21 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* const P = a.pat_base + job.pat_off;
     const uint8_t* const Tx = a.txt_base + job.txt_off;
-    const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
-    uint32_t* const T4 = P4 + plen + 1;
-    // byte copies, then the 4-byte sliding windows built from them
-    for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
-    for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
-    __syncthreads();
-    for (int i = tid; i <= plen; i += T) {
-      uint32_t wv = 0;
-      for (int b = 0; b < 4; ++b) if (i + b < plen) wv |= (uint32_t)lds_seq[i + b] << (8 * b);
-      P4[i] = wv;
-    }
-    for (int i = tid; i <= tlen; i += T) {
-      uint32_t wv = 0;
-      for (int b = 0; b < 4; ++b) if (i + b < tlen) wv |= (uint32_t)lds_seq[pl_pad + i + b] << (8 * b);
-      T4[i] = wv;
-    }
+    uint32_t* const T4 = P4 + plen + 4;  // (three entries of slack behind each window array: the unguarded tail writes below)
+    // 4-byte sliding windows straight from global memory: a thread turns two (unaligned) dwords into the windows of four positions
+    auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W) {
+      for (int i0 = 4 * tid; i0 <= len; i0 += 4 * T) {
+        uint32_t d0 = 0, d1 = 0;
+        if (i0 + 8 <= len) { __builtin_memcpy(&d0, src + i0, 4); __builtin_memcpy(&d1, src + i0 + 4, 4); }
+        else
+          for (int b = 0; b < 8; ++b)
+            if (i0 + b < len) { if (b < 4) d0 |= (uint32_t)src[i0 + b] << (8 * b); else d1 |= (uint32_t)src[i0 + b] << (8 * (b - 4)); }
+        W[i0] = d0; W[i0 + 1] = __builtin_amdgcn_alignbyte(d1, d0, 1); W[i0 + 2] = __builtin_amdgcn_alignbyte(d1, d0, 2);
+        W[i0 + 3] = __builtin_amdgcn_alignbyte(d1, d0, 3);
+      }
+    };
+    stage(P, plen, P4);
+    stage(Tx, tlen, T4);
     FastJob J;
     {
       const int sp = a.kp.span;
