@@ -81,6 +81,7 @@ inline bool is_device_ptr(const void* p) {
 enum Slot {
   S_HMM_SEQ = 0, S_HMM_DESC, S_HMM_MODEL, S_HMM_JOBS, S_HMM_BP, S_HMM_PATH, S_HMM_SPANS, S_HMM_NSP, S_HMM_CNT, S_HMM_PUR,
   S_HMM_EDIT, S_HMM_MAXD, S_HMM_PLEN, S_HMM_VISITS, S_HMM_MOTIFS,
+  S_HMM_B_BASE, S_HMM_B_LAST = S_HMM_B_BASE + (S_HMM_MOTIFS - S_HMM_SEQ),  // second set of the HMM slots: two batches in flight
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
@@ -91,7 +92,7 @@ enum Slot {
   S_COUNT
 };
 // pinned host buffer slots
-enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_SEG0, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
+enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_HMM_SEQ_B, P_SEG0, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
                P_GT_RANK, P_GT_NSPAN, P_GT_TOFF, P_GT_PACKED, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {

@@ -536,6 +536,8 @@ extern "C" uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_
 // hmm_collect (result copies).  One batch per ctx may be pending: the device buffers are the ctx's pool slots.
 struct trgt::HmmPending {
   int64_t n_jobs = 0;
+  int set = 0; hipStream_t stream = nullptr;  // scratch-buffer set and stream of this batch
+  std::vector<uint64_t> cnt_off; std::vector<uint32_t> cnt_n; uint32_t* cnt_user = nullptr; uint64_t cnt_total = 0;  // motif counts go back job by job
   bool spans_on_host = false;
   std::vector<uint64_t> tight_off;
   std::vector<HmmJobDev> jobs;   // upload sources stay alive until the batch is collected
@@ -564,8 +566,9 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
                       const uint8_t* seq_blob, const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path,
                       const uint64_t* path_off, uint32_t* path_len, int32_t* spans3, const uint64_t* span_off,
                       uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
-                      int32_t* edit_dist, int32_t* max_dist, HmmPending** out_pending) {
+                      int32_t* edit_dist, int32_t* max_dist, HmmPending** out_pending, int buffer_set) {
   *out_pending = nullptr;
+  const int so = buffer_set ? (int)S_HMM_B_BASE - (int)S_HMM_SEQ : 0;  // slot offset of the buffer set
   if (!c) return TRGT_ERR_INVALID;
   if (n_sets < 0 || n_jobs < 0 || (n_jobs > 0 && (!motif_blob || !motif_off || !set_motif_begin || !job_set || !seq_off ||
                                                     !seq_len || (spans3 && !span_off) || !n_spans || !motif_counts ||
@@ -575,7 +578,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   if (n_jobs == 0) return TRGT_OK;
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
   std::unique_ptr<HmmPending> P(new HmmPending());
-  P->n_jobs = n_jobs; P->spans3 = spans3; P->span_off = span_off;
+  P->n_jobs = n_jobs; P->spans3 = spans3; P->span_off = span_off; P->set = buffer_set; P->stream = c->stream;
   // ---- models (host libm ln tables): built here unless the caller prepared them ahead of time (trgt_locus_batch does,
   //      concurrently with the flank-location stage)
   HmmModels& local_models = P->local_models;
@@ -606,6 +609,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
     if (spans3) span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
     count_total = std::max<uint64_t>(count_total, count_off[j] + (sd.n_blocks - 1));
+    P->cnt_off.push_back(count_off[j]); P->cnt_n.push_back(sd.n_blocks - 1);
     if (path) path_total = std::max<uint64_t>(path_total, path_off[j] + jd.path_cap);
     cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
   }
@@ -622,7 +626,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     uint64_t tight = 0;
     for (int64_t j = 0; j < n_jobs; ++j) tight += seq_len[j];
     void *h_tight = nullptr, *d_tight = nullptr;
-    if ((rc = pin_get(c, P_HMM_SEQ, (size_t)tight + 16, &h_tight)) || (rc = dev_get(c, S_HMM_SEQ, (size_t)tight + 16, &d_tight))) return rc;
+    if ((rc = pin_get(c, buffer_set ? P_HMM_SEQ_B : P_HMM_SEQ, (size_t)tight + 16, &h_tight)) || (rc = dev_get(c, S_HMM_SEQ + so, (size_t)tight + 16, &d_tight))) return rc;
     std::vector<uint64_t> toff((size_t)n_jobs);
     uint64_t o = 0;
     for (int64_t j = 0; j < n_jobs; ++j) { toff[(size_t)j] = o; std::memcpy((uint8_t*)h_tight + o, seq_blob + seq_off[j], seq_len[j]); o += seq_len[j]; }
@@ -638,9 +642,9 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, sets.data(), sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream));
     TRGT_HIP_TRY(c, hipMemcpyAsync(d_model, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
   }
-  if ((rc = dev_get(c, S_HMM_JOBS, jobs.size() * sizeof(HmmJobDev), &d_jobs))) return rc;
-  if ((rc = dev_get(c, S_HMM_BP, (size_t)bp_total, &d_bp))) return rc;
-  if ((rc = dev_get(c, S_HMM_VISITS, (size_t)visit_total * 4, &d_visits))) return rc;
+  if ((rc = dev_get(c, S_HMM_JOBS + so, jobs.size() * sizeof(HmmJobDev), &d_jobs))) return rc;
+  if ((rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp))) return rc;
+  if ((rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits))) return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
   // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the
@@ -657,18 +661,21 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     for (auto& jd : jobs) jd.span_off = tight_off[jd.job_index];
     TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   }
-  if ((rc = o_path.init(c, S_HMM_PATH, path, (size_t)path_total))) return rc;
-  if ((rc = o_plen.init(c, S_HMM_PLEN, path_len, (size_t)n_jobs))) return rc;
+  if ((rc = o_path.init(c, S_HMM_PATH + so, path, (size_t)path_total))) return rc;
+  if ((rc = o_plen.init(c, S_HMM_PLEN + so, path_len, (size_t)n_jobs))) return rc;
   if (spans_on_host) {
     void* d = nullptr;
-    if ((rc = dev_get(c, S_HMM_SPANS, (size_t)tight_total * 12, &d))) return rc;
+    if ((rc = dev_get(c, S_HMM_SPANS + so, (size_t)tight_total * 12, &d))) return rc;
     o_spans.user = spans3; o_spans.dev = (int32_t*)d; o_spans.count = 0; o_spans.staged = false;  // copied back packed, below
-  } else if ((rc = o_spans.init(c, S_HMM_SPANS, spans3, (size_t)span_total * 3))) return rc;
-  if ((rc = o_nsp.init(c, S_HMM_NSP, n_spans, (size_t)n_jobs))) return rc;
-  if ((rc = o_cnt.init(c, S_HMM_CNT, motif_counts, (size_t)count_total))) return rc;
-  if ((rc = o_pur.init(c, S_HMM_PUR, purity, (size_t)n_jobs))) return rc;
-  if ((rc = o_edit.init(c, S_HMM_EDIT, edit_dist, (size_t)n_jobs))) return rc;
-  if ((rc = o_maxd.init(c, S_HMM_MAXD, max_dist, (size_t)n_jobs))) return rc;
+  } else if ((rc = o_spans.init(c, S_HMM_SPANS + so, spans3, (size_t)span_total * 3))) return rc;
+  if ((rc = o_nsp.init(c, S_HMM_NSP + so, n_spans, (size_t)n_jobs))) return rc;
+  if ((rc = o_cnt.init(c, S_HMM_CNT + so, motif_counts, (size_t)count_total))) return rc;
+  if (o_cnt.staged) {  // host array shared with other batches: only the ranges of this batch's jobs may be written back (hmm_collect)
+    P->cnt_user = motif_counts; P->cnt_total = count_total; o_cnt.staged = false;
+  }
+  if ((rc = o_pur.init(c, S_HMM_PUR + so, purity, (size_t)n_jobs))) return rc;
+  if ((rc = o_edit.init(c, S_HMM_EDIT + so, edit_dist, (size_t)n_jobs))) return rc;
+  if ((rc = o_maxd.init(c, S_HMM_MAXD + so, max_dist, (size_t)n_jobs))) return rc;
   // ---- one launch per workgroup-size class
   size_t i = 0;
   while (i < jobs.size()) {
@@ -708,6 +715,9 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   if (!pend) return TRGT_OK;  // an empty batch
   std::unique_ptr<HmmPending> P(pend);
+  const int so = P->set ? (int)S_HMM_B_BASE - (int)S_HMM_SEQ : 0;
+  struct StreamSwap { trgt_hip_ctx* c; hipStream_t saved; ~StreamSwap() { c->stream = saved; } } stream_swap{c, c->stream};
+  c->stream = P->stream;
   const int64_t n_jobs = P->n_jobs;
   const bool spans_on_host = P->spans_on_host;
   std::vector<uint64_t>& tight_off = P->tight_off;
@@ -722,9 +732,9 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
     uint64_t ptotal = 0;
     for (int64_t j = 0; j < n_jobs; ++j) { poff[(size_t)j] = ptotal; ptotal += h_nsp[(size_t)j]; }
     void *d_poff = nullptr, *d_toff = nullptr, *d_packed = nullptr;
-    if ((rc = dev_get(c, S_HMM_MOTIFS, (size_t)n_jobs * 16, &d_poff))) return rc;
+    if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16, &d_poff))) return rc;
     d_toff = (uint8_t*)d_poff + (size_t)n_jobs * 8;
-    if ((rc = dev_get(c, S_HMM_BP, (size_t)ptotal * 12 + 16, &d_packed))) return rc;  // the back-pointer workspace is free again
+    if ((rc = dev_get(c, S_HMM_BP + so, (size_t)ptotal * 12 + 16, &d_packed))) return rc;  // the back-pointer workspace is free again
     TRGT_HIP_TRY(c, hipMemcpyAsync(d_poff, poff.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
     TRGT_HIP_TRY(c, hipMemcpyAsync(d_toff, tight_off.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)o_spans.dev,
@@ -736,10 +746,18 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
     for (int64_t j = 0; j < n_jobs; ++j)
       std::memcpy(spans3 + 3 * span_off[j], h_packed.data() + 3 * poff[(size_t)j], (size_t)h_nsp[(size_t)j] * 12);
   }
+  std::vector<uint32_t> h_cnt;
+  if (P->cnt_user && P->cnt_total) {
+    h_cnt.resize((size_t)P->cnt_total);
+    TRGT_HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), o_cnt.dev, (size_t)P->cnt_total * 4, hipMemcpyDeviceToHost, c->stream));
+  }
   if ((rc = o_path.finish(c)) || (rc = o_plen.finish(c)) || (rc = o_spans.finish(c)) || (rc = o_nsp.finish(c)) ||
       (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
     return rc;
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!h_cnt.empty())
+    for (size_t j = 0; j < P->cnt_off.size(); ++j)
+      std::memcpy(P->cnt_user + P->cnt_off[j], h_cnt.data() + P->cnt_off[j], (size_t)P->cnt_n[j] * 4);
   return TRGT_OK;
 }
 

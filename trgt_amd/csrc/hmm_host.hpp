@@ -33,14 +33,15 @@ int hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, co
                    int32_t* spans3, const uint64_t* span_off, uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off,
                    double* purity, int32_t* edit_dist, int32_t* max_dist);
 
-// Asynchronous form: hmm_enqueue uploads and launches on the ctx stream without waiting for the kernels; hmm_collect waits and
-// copies the results out (and frees the pending state).  *pending stays null for an empty batch.
+// Asynchronous form: hmm_enqueue uploads and launches on the ctx stream without waiting for the kernels; hmm_collect waits (on the
+// stream the batch was enqueued on) and copies the results out (and frees the pending state).  *pending stays null for an empty
+// batch.  buffer_set 0 / 1: which set of device / pinned scratch buffers to use -- two batches may be in flight on two streams.
 struct HmmPending;
 int hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
                 const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set, const uint8_t* seq_blob,
                 const uint64_t* seq_off, const uint32_t* seq_len, uint16_t* path, const uint64_t* path_off, uint32_t* path_len,
                 int32_t* spans3, const uint64_t* span_off, uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off,
-                double* purity, int32_t* edit_dist, int32_t* max_dist, HmmPending** pending);
+                double* purity, int32_t* edit_dist, int32_t* max_dist, HmmPending** pending, int buffer_set = 0);
 int hmm_collect(trgt_hip_ctx* c, HmmPending* pending);
 void hmm_pending_free(HmmPending* pending);
 

@@ -278,6 +278,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   threads = std::min(threads, 32);  // a few microseconds of work per locus: more threads only add wake-up cost
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
+  const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+#define TL(name) do { if (tl_on) fprintf(stderr, "[tl] %-28s %7.2f ms\n", name, (double)(now_ns() - t0) / 1e6); } while (0)
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_flank_heavy = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
   auto init_outputs = [&]() {
@@ -302,8 +304,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     models.d_sets = d_sets; models.d_blob = d_blob;
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
-  HmmPending* hmm_pending = nullptr;
-  struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending};
+  HmmPending *hmm_pending = nullptr, *hmm_pending2 = nullptr;
+  struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending}, pend_guard2{hmm_pending2};
+  std::vector<uint32_t> js2, sl2, ns2; std::vector<uint64_t> so2, spo2, co2; std::vector<double> pu2; std::vector<int64_t> slot2;  // stage C, host-path loci
 
   // ---------------- stage A: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
   std::vector<uint64_t> piece_off(2 * (size_t)nl);
@@ -436,6 +439,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     const int64_t tw = now_ns();
     TRGT_HIP_TRY(c, hipEventSynchronize(evA));
     tA = now_ns() - tw;
+  TL("evA");
   }
   int64_t th_begin = now_ns();
   // ---------------- loci for the host path: all of them without the device genotyper, else the ones it handed back
@@ -560,6 +564,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)seg_bytes, hipMemcpyDeviceToHost, c->stream2));
     }
   }
+  TL("R selected, gather enqueued");
   // ---------------- stage C for the device-genotyped loci starts now, on alleles that already sit in HBM; it is collected after
   // the host path of the others
   std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
@@ -577,6 +582,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
       }
     }
+    TL("hmm1 job lists");
     if (!job_set.empty()) {
       nsp.resize(job_set.size()); pur.resize(job_set.size());
       if (model_thread.joinable()) model_thread.join();
@@ -586,6 +592,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
                        out->motif_counts, count_off.data(), pur.data(), nullptr, nullptr, &hmm_pending);
       if (rc) return rc;
       tC += now_ns() - tc0;
+      TL("hmm1 enqueued");
       stat_hmm_jobs += (int64_t)job_set.size();
     }
   }
@@ -624,6 +631,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
   }
   tHost += now_ns() - th_begin;
+  TL("published+stream2 synced");
 
   // ---------------- host path for the loci in R, second part (second stream for its GPU work: consensus alignments)
   if (nR > 0) {
@@ -653,6 +661,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       genotype_size_front(in->ploidy[R[(size_t)li]] == 1 ? 1 : 2, li, t, w, sc);
     });
     c->dbg_ns[6] = now_ns() - tf0;
+  TL("front");
     tHost += now_ns() - th0;
     // ---- stage B: consensus alignments (BiWFA, affine 2,5,1, default heuristic) for the loci that need them
     std::swap(c->stream, c->stream2);
@@ -692,6 +701,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       stat_ed_jobs = cb.n_ed;
     }
     tB = now_ns() - tb0;
+  TL("stageB");
     // ---- host: repair_consensus, classification, reference allele first, output assembly
     th0 = now_ns();
     {
@@ -757,40 +767,49 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     });
     if (bad) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: allele_cap too small");
     c->dbg_ns[7] = now_ns() - th0;
+  TL("back");
     tHost += now_ns() - th0;
+    // ---- stage C for the host-path loci (label_with_hmm for every allele): enqueued here, on the second stream and the second set
+    // of HMM buffers, next to the batch of the device-genotyped loci that is still running
+    const int64_t tc0 = now_ns();
+    for (int64_t li = 0; li < nR; ++li) {
+      const int64_t l = R[(size_t)li];
+      for (int a = 0; a < out->n_alleles[l]; ++a) {
+        js2.push_back((uint32_t)l); so2.push_back(out->allele_off[2 * l + a]); sl2.push_back(out->allele_len[2 * l + a]);
+        spo2.push_back(out->span_off[2 * l + a]); co2.push_back(out->count_off[2 * l + a]); slot2.push_back(2 * l + a);
+      }
+    }
+    if (!js2.empty()) {
+      ns2.resize(js2.size()); pu2.resize(js2.size());
+      if (model_thread.joinable()) model_thread.join();
+      rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)js2.size(), js2.data(),
+                       out->allele_blob, so2.data(), sl2.data(), nullptr, nullptr, nullptr, out->spans3, spo2.data(), ns2.data(),
+                       out->motif_counts, co2.data(), pu2.data(), nullptr, nullptr, &hmm_pending2, hmm_pending ? 1 : 0);
+      if (rc) return rc;
+      stat_hmm_jobs += (int64_t)js2.size();
+    }
+    tC += now_ns() - tc0;
   }
   // ---------------- stage C results of the device-genotyped loci
+  TL("hmm2 enqueued");
   if (hmm_pending) {
     const int64_t tc0 = now_ns();
     HmmPending* pend = hmm_pending; hmm_pending = nullptr;
     rc = hmm_collect(c, pend);
     if (rc) return rc;
+    TL("hmm1 collected");
     for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
     tC += now_ns() - tc0;
   }
-  // ---------------- stage C for the host-path loci: label_with_hmm for every allele
-  if (nR > 0) {
+  if (hmm_pending2) {
     const int64_t tc0 = now_ns();
-    std::vector<uint32_t> js, sl, ns2; std::vector<uint64_t> so, spo, co; std::vector<double> pu; std::vector<int64_t> sl2;
-    for (int64_t li = 0; li < nR; ++li) {
-      const int64_t l = R[(size_t)li];
-      for (int a = 0; a < out->n_alleles[l]; ++a) {
-        js.push_back((uint32_t)l); so.push_back(out->allele_off[2 * l + a]); sl.push_back(out->allele_len[2 * l + a]);
-        spo.push_back(out->span_off[2 * l + a]); co.push_back(out->count_off[2 * l + a]); sl2.push_back(2 * l + a);
-      }
-    }
-    if (!js.empty()) {
-      ns2.resize(js.size()); pu.resize(js.size());
-      if (model_thread.joinable()) model_thread.join();
-      rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)js.size(), js.data(),
-                          out->allele_blob, so.data(), sl.data(), nullptr, nullptr, nullptr, out->spans3, spo.data(), ns2.data(),
-                          out->motif_counts, co.data(), pu.data(), nullptr, nullptr);
-      if (rc) return rc;
-      for (size_t j = 0; j < sl2.size(); ++j) { out->n_spans[sl2[j]] = ns2[j]; out->purity[sl2[j]] = pu[j]; }
-      stat_hmm_jobs += (int64_t)js.size();
-    }
+    HmmPending* pend = hmm_pending2; hmm_pending2 = nullptr;
+    rc = hmm_collect(c, pend);
+    if (rc) return rc;
+    for (size_t j = 0; j < slot2.size(); ++j) { out->n_spans[slot2[j]] = ns2[j]; out->purity[slot2[j]] = pu2[j]; }
     tC += now_ns() - tc0;
   }
+  TL("all collected");
   if (out->stats) {
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
