@@ -507,7 +507,9 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
 // acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring | pattern windows | text windows.
-template <bool SPEC>
+// TAG only names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments), so
+// that a kernel trace tells the two launches of trgt_find_spans_batch apart.
+template <bool SPEC, int TAG>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
   FastShared& fs = g_fsh;
