@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <thread>
 
 #include "hmm_host.hpp"
@@ -565,10 +566,20 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
   }
   TL("R selected, gather enqueued");
-  // ---------------- stage C for the device-genotyped loci starts now, on alleles that already sit in HBM; it is collected after
-  // the host path of the others
+  // ---------------- the alleles of the device-genotyped loci come back packed: a second, exact-size copy (second stream)
+  if (dev_gt) {
+    const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];
+    if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
+    if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream2));
+  }
+  // ---------------- stage C for the device-genotyped loci (on alleles that already sit in HBM; collected at the end) and the
+  // publishing of spans and device-genotyper results: host work of ~1.2 ms that needs the GPU only to start the HMM batch.  It runs
+  // while the consensus alignments of the host-path loci are on the GPU (wfa_batch_impl calls it between launch and wait), or
+  // right here when there are none.
   std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
   std::vector<uint32_t> nsp; std::vector<double> pur;
+  bool published = false;
+  auto hmm1_enqueue = [&]() -> int {
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
     const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
@@ -596,9 +607,29 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       stat_hmm_jobs += (int64_t)job_set.size();
     }
   }
-  // ---------------- publish spans and the device genotyper's results (the GPU is busy with the HMM batch meanwhile)
-  std::memcpy(out->span_start, h_ss, (size_t)nr * 4);
-  std::memcpy(out->span_end, h_se, (size_t)nr * 4);
+  return TRGT_OK;
+  };
+  if ((rc = hmm1_enqueue())) return rc;
+  if (dev_gt || (n_seg > 0 && reads_on_device)) TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));  // gathered segments, packed alleles
+  tHost += now_ns() - th_begin;
+  TL("stream2 synced");
+  // ---------------- publish spans and the device genotyper's results: host-only work, done while the consensus alignments of the
+  // host-path loci are on the GPU (wfa_batch_impl calls it between launch and wait), or at the end when there are none
+  auto publish = [&]() -> int {
+  published = true;
+  pool->parallel_for(8, 1, [&](int64_t part8, int) {  // ~6 MB of result arrays: spread the copies over a few threads
+    auto piece = [&](void* dst, const void* src, size_t bytes, int64_t k, int64_t n) {
+      const size_t b = bytes * (size_t)k / (size_t)n, e = bytes * (size_t)(k + 1) / (size_t)n;
+      std::memcpy((uint8_t*)dst + b, (const uint8_t*)src + b, e - b);
+    };
+    piece(out->span_start, h_ss, (size_t)nr * 4, part8, 8);
+    piece(out->span_end, h_se, (size_t)nr * 4, part8, 8);
+    if (dev_gt) {
+      piece(out->classification, gh.cls, (size_t)nr * 4, part8, 8); piece(out->read_rank, gh.rank, (size_t)nr * 4, part8, 8);
+      piece(out->n_alleles, gh.nal, (size_t)nl * 4, part8, 8); piece(out->allele_len, gh.alen, 2 * (size_t)nl * 4, part8, 8);
+      piece(out->ci, gh.ci, 4 * (size_t)nl * 4, part8, 8); piece(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4, part8, 8);
+    }
+  });
   {
     std::vector<int64_t> part((size_t)pool->size() * 8, 0);
     pool->parallel_for(nr, 8192, [&](int64_t r, int t) {
@@ -614,24 +645,16 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   }
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
-    const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];  // the alleles come back packed: a second, exact-size copy
-    if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
-    if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream2));
-    std::memcpy(out->n_alleles, gh.nal, (size_t)nl * 4); std::memcpy(out->allele_len, gh.alen, 2 * (size_t)nl * 4);
-    std::memcpy(out->ci, gh.ci, 4 * (size_t)nl * 4); std::memcpy(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4);
-    std::memcpy(out->classification, gh.cls, (size_t)nr * 4); std::memcpy(out->read_rank, gh.rank, (size_t)nr * 4);
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));  // gathered segments of R and the packed alleles are here
     const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
     pool->parallel_for(nl, 256, [&](int64_t l, int) {
       if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
       for (int a = 0; a < out->n_alleles[l]; ++a)
         std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
     });
-  } else if (n_seg > 0 && reads_on_device) {
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
   }
-  tHost += now_ns() - th_begin;
-  TL("published+stream2 synced");
+  TL("published");
+  return TRGT_OK;
+  };
 
   // ---------------- host path for the loci in R, second part (second stream for its GPU work: consensus alignments)
   if (nR > 0) {
@@ -684,12 +707,14 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         }
       }
     PackedCigars pcig;
+    if (jrefs.empty() && !published && (rc = publish())) return rc;
     if (!jrefs.empty()) {
       trgt_wfa_params wp;
       trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
       wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+      const std::function<int()> overlap = [&]() -> int { return publish(); };  // host-only work next to the alignment kernel
       rc = wfa_batch_impl(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pcig);
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pcig, &overlap);
       if (rc) return rc;
       stat_cons_jobs = (int64_t)jrefs.size();
     }
@@ -790,6 +815,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
     tC += now_ns() - tc0;
   }
+  if (!published && (rc = publish())) return rc;
   // ---------------- stage C results of the device-genotyped loci
   TL("hmm2 enqueued");
   if (hmm_pending) {

@@ -594,7 +594,7 @@ __global__ void cigar_pack_kernel(const uint32_t* __restrict__ cigar, const JobD
 int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
                    const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
                    int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
-                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed) {
+                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed, const std::function<int()>* while_running) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: null argument");
@@ -649,7 +649,10 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
       (rc = o_cigar.finish(c)) || (rc = o_clen.finish(c)) || (rc = o_ops.finish(c)) || (rc = o_olen.finish(c)))
     return rc;
   unsigned long long cells = 0;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
+  void* const cells_dev = c->last_wfa_cells_dev;  // (the callback may launch alignments of its own)
+  hipStream_t const my_stream = c->stream;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, cells_dev, 8, hipMemcpyDeviceToHost, my_stream));
+  if (while_running && *while_running) { const int wrc = (*while_running)(); if (wrc) { (void)hipStreamSynchronize(my_stream); return wrc; } }
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
   if (packed) {

@@ -1,5 +1,6 @@
 // trgt_amd/csrc/wfa_host.hpp -- job record and host-side launch descriptor of the WFA kernel (no device code).
 #pragma once
+#include <functional>
 #include <vector>
 #include "common.hpp"
 
@@ -43,6 +44,7 @@ struct PackedCigars { std::vector<uint32_t> data; std::vector<uint64_t> off; };
 int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
                    const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
                    int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
-                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed);
+                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed,
+                   const std::function<int()>* while_running = nullptr);  // host work to do between the launch and the wait
 
 }  // namespace trgt
