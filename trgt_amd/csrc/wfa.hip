@@ -551,7 +551,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   t.stop(0);
 #ifdef TRGT_WFA_PROF
   if (a.fast_wcap > 0) {
-    unsigned long long h[32], lv[8], z[32] = {0};
+    unsigned long long h[32], lv[32], z[32] = {0};
     TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
     TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(wfa::g_wfa_prof), sizeof h));
     TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_prof), z, sizeof h));
@@ -565,6 +565,11 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
             (long long)L.n_jobs_host, (long long)grid_blocks, threads, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot,
             100 * h[4] / tot, 100 * h[5] / tot, h[6] ? (double)h[7] / h[6] : 0.0, h[16], h[16] ? (double)h[17] / h[16] : 0.0,
             h[2] ? 100.0 * h[18] / h[2] : 0.0, tot / 1e6 / (double)grid_blocks, 100 * lv[0] / lt, 100 * lv[1] / lt, 100 * lv[2] / lt, 100 * lv[3] / lt);
+    for (int w = 1; w < 4; ++w) {  // the other waves' view of the level loop
+      const unsigned long long* q = lv + 8 * w;
+      const double t = (double)(q[0] + q[1] + q[2] + q[3]) + 1e-9;
+      fprintf(stderr, "[wfa prof]   wave %d: barrier %.1f%% prologue %.1f%% strips %.1f%% record %.1f%%\n", w, 100 * q[0] / t, 100 * q[1] / t, 100 * q[2] / t, 100 * q[3] / t);
+    }
   }
 #endif
   c->last_wfa_cells_dev = d_cells;

@@ -32,12 +32,12 @@ typedef __attribute__((address_space(1))) uint16_t g_u16;
 // Developer-only build (make PROF=1): thread 0 of every workgroup splits its shader-clock time over the phases of a job
 // (g_wfa_prof) and over the phases of a score level (g_wfa_lvprof).
 __device__ unsigned long long g_wfa_prof[32];
-__device__ unsigned long long g_wfa_lvprof[8];
+__device__ unsigned long long g_wfa_lvprof[32];  // [wave][8]: lane 0 of every wave
 #define PROF_DECL unsigned long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_MARK(i) do { const unsigned long long n_ = clock64(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
 #define LV_DECL unsigned long long lv_t = clock64(), lv_acc[5] = {0, 0, 0, 0, 0}
 #define LV_MARK(i) do { const unsigned long long n_ = clock64(); lv_acc[i] += n_ - lv_t; lv_t = n_; } while (0)
-#define LV_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_wfa_lvprof[i_], lv_acc[i_]); } while (0)
+#define LV_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_wfa_lvprof[(threadIdx.x >> 6) * 8 + i_], lv_acc[i_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
@@ -308,6 +308,11 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     };
     // wave w takes the 128-diagonal strips nW-1-w, 2nW-1-w, ...: the ragged last strip then falls on the last wave, not on wave 0,
     // which also carries thread 0's publishing work.  Strips start on even diagonals.
+    // (Per wave, make PROF=1: strip work is 33 / 42 / 58 / 69 % of the level time on waves 0..3 -- wave 3 owns the first strip, an end
+    //  strip on the two-pass path, and in a level of 4n+1 strips the last one too.  Contiguous blocks of strips per wave, dealing the
+    //  strips by cost, or moving only that last strip all balance the waves (barrier wait 9-31 % instead of 5-36 %) and were all
+    //  SLOWER, 7.33 -> 7.75 / 8.47 / 7.83 ms: the strip work itself grows by ~11 % -- adjacent strips processed at the same time
+    //  write adjacent history segments, and any other loop shape also costs the compiler's schedule of this body.)
     for (int kb0 = (lo & ~1) + (nW - 1 - wave) * 128; kb0 <= hi; kb0 += 2 * nT) {
       if (kb0 >= in_lo && kb0 + 127 <= in_hi) {
         // ---- interior strip: a lane owns the diagonals kbA = kb0 + 2*lane and kbA + 1; recurrences on packed 16-bit pairs,
