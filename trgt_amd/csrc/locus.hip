@@ -617,6 +617,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   // host-path loci are on the GPU (wfa_batch_impl calls it between launch and wait), or at the end when there are none
   auto publish = [&]() -> int {
   published = true;
+  TL("publish begins");
   pool->parallel_for(8, 1, [&](int64_t part8, int) {  // ~6 MB of result arrays: spread the copies over a few threads
     auto piece = [&](void* dst, const void* src, size_t bytes, int64_t k, int64_t n) {
       const size_t b = bytes * (size_t)k / (size_t)n, e = bytes * (size_t)(k + 1) / (size_t)n;
@@ -630,6 +631,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       piece(out->ci, gh.ci, 4 * (size_t)nl * 4, part8, 8); piece(out->num_spanning, gh.nsp, 2 * (size_t)nl * 4, part8, 8);
     }
   });
+  TL("publish: arrays copied");
   {
     std::vector<int64_t> part((size_t)pool->size() * 8, 0);
     pool->parallel_for(nr, 8192, [&](int64_t r, int t) {

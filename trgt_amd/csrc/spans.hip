@@ -87,9 +87,11 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
   }
 }
 
-// One wavefront per READ, both flank pieces at once (flank_len >= 4).  A round covers 1024 read bytes: every lane loads 20
-// consecutive bytes (16 + 4 of overlap), forms its 16 candidate 4-byte windows with byte-align shifts and compares each with
-// the heads of the two pieces; candidates are then verified in increasing position, cooperatively (lane i compares dword i of
+// One wavefront per READ, both flank pieces at once (flank_len >= 4).  A round covers 1024 read bytes: every lane loads 24
+// consecutive bytes (16 + 8 of overlap), forms its 16 candidate windows with byte-align shifts and compares each with the first
+// EIGHT bytes of the two pieces (four bases match by chance once in 256 positions: four false candidates per piece and read, each a
+// dependent round trip to verify -- most of this kernel's time; eight bases: one in 65536); candidates are then verified in
+// increasing position, cooperatively (lane i compares dword i of
 // the piece), so the first full match is the leftmost occurrence, exactly windows().position() (span_locater.rs:10-12).
 // A workgroup walks SCAN_READS_PER_WG reads (one per wave at a time) and collects its fallback jobs in LDS; one global atomic
 // per workgroup reserves their slots in the job list (a per-job atomic on a single counter was most of this kernel's time).
@@ -111,24 +113,27 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
   if (n >= F) {
     const int last = n - F;  // last candidate start
     const uint32_t head[2] = {load_u32(piece[0]), load_u32(piece[1])};
+    const bool h8 = F >= 8;
+    const uint32_t head2[2] = {h8 ? load_u32(piece[0] + 4) : 0u, h8 ? load_u32(piece[1] + 4) : 0u};
     const int nd = F >> 2;   // full dwords of a piece
     for (int base = 0; base <= last && (found[0] < 0 || found[1] < 0); base += 1024) {
       const int off = base + 16 * lane;
-      uint32_t w[5] = {0, 0, 0, 0, 0};
-      if (off + 20 <= n) {
-        uint4 q;
-        __builtin_memcpy(&q, read + off, 16);
-        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; w[4] = load_u32(read + off + 16);
+      uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+      if (off + 24 <= n) {
+        uint4 q; uint2 q2;
+        __builtin_memcpy(&q, read + off, 16); __builtin_memcpy(&q2, read + off + 16, 8);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; w[4] = q2.x; w[5] = q2.y;
       } else if (off < n) {
-        for (int b = 0; b < 20 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
+        for (int b = 0; b < 24 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
       }
       uint32_t m[2] = {0, 0};  // bit s: candidate start off + s matches the head of piece 0 / 1
 #pragma unroll
       for (int s16 = 0; s16 < 16; ++s16) {
         const uint32_t win = (s16 & 3) == 0 ? w[s16 >> 2] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 1], w[s16 >> 2], s16 & 3);
+        const uint32_t win2 = (s16 & 3) == 0 ? w[(s16 >> 2) + 1] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 2], w[(s16 >> 2) + 1], s16 & 3);
         const bool valid = off + s16 <= last;
-        m[0] |= (uint32_t)(valid && win == head[0]) << s16;
-        m[1] |= (uint32_t)(valid && win == head[1]) << s16;
+        m[0] |= (uint32_t)(valid && win == head[0] && (!h8 || win2 == head2[0])) << s16;
+        m[1] |= (uint32_t)(valid && win == head[1] && (!h8 || win2 == head2[1])) << s16;
       }
 #pragma unroll
       for (int side = 0; side < 2; ++side) {

@@ -6,6 +6,7 @@
 // machinery; this file holds the back-trace, the BiWFA driver (breakpoint search + recursion as
 // an explicit stack), the per-job epilogue and the host-side planner.
 #include <algorithm>
+#include <chrono>
 
 #include "wfa_engine.hpp"
 
@@ -607,6 +608,9 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: cigar/ops need their offset and length arrays");
   if (packed) { packed->data.clear(); packed->off.assign((size_t)n_jobs + 1, 0); }
   if (n_jobs == 0) return TRGT_OK;
+  const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+  const auto tl0 = std::chrono::steady_clock::now();
+#define WTL(name) do { if (tl_on) fprintf(stderr, "[tl]   wfa_batch %-18s +%6.2f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count()); } while (0)
   if (n_jobs > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: too many jobs");
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
   std::vector<JobDev> jobs((size_t)n_jobs);
@@ -626,7 +630,9 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   if (L.max_sum > (1 << 27)) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: sequences too long");
   int rc;
   const uint8_t* d_seq = nullptr;
+  WTL("jobs built");
   if ((rc = dev_in(c, S_WFA_SEQ, seqs, (size_t)seq_total, &d_seq))) return rc;
+  WTL("sequences uploaded");
   void* d_jobs = nullptr;
   if ((rc = dev_get(c, S_WFA_JOBS, jobs.size() * sizeof(JobDev), &d_jobs))) return rc;
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), hipMemcpyHostToDevice, c->stream));
@@ -649,7 +655,11 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   L.pat_base = d_seq; L.txt_base = d_seq;
   L.status = o_status.dev; L.score = o_score.dev; L.n_match = o_nm.dev; L.span4 = o_span.dev; L.cigar = o_cigar.dev;
   L.cigar_len = o_clen.dev; L.ops = o_ops.dev; L.ops_len = o_olen.dev;
+  WTL("buffers ready");
   if ((rc = wfa_launch(c, *p, L))) return rc;
+  WTL("launched");
+  // host work of the caller goes here: the copies below end in pageable memory, i.e. they block until the kernel is done
+  if (while_running && *while_running) { const int wrc = (*while_running)(); if (wrc) { (void)hipStreamSynchronize(c->stream); return wrc; } }
   if ((rc = o_status.finish(c)) || (rc = o_score.finish(c)) || (rc = o_nm.finish(c)) || (rc = o_span.finish(c)) ||
       (rc = o_cigar.finish(c)) || (rc = o_clen.finish(c)) || (rc = o_ops.finish(c)) || (rc = o_olen.finish(c)))
     return rc;
@@ -657,7 +667,6 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   void* const cells_dev = c->last_wfa_cells_dev;  // (the callback may launch alignments of its own)
   hipStream_t const my_stream = c->stream;
   TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, cells_dev, 8, hipMemcpyDeviceToHost, my_stream));
-  if (while_running && *while_running) { const int wrc = (*while_running)(); if (wrc) { (void)hipStreamSynchronize(my_stream); return wrc; } }
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
   if (packed) {
