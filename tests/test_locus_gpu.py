@@ -341,3 +341,23 @@ def test_cfg3_alleles_to_10kb(oracle, mods):
     for mode, out in _run_both(locus, b):
         _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
         assert int(out.allele_len.max()) > 8500, mode
+
+
+def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
+    # the planner's choices must not show in the results: one launch instead of two for the flank alignments, the general
+    # instantiation of the dedicated kernel instead of the compile-time flank configuration, the host genotyper
+    import torch
+    locus, synth = mods
+    b = synth.generate(96, first_locus=12000)
+    rd, fd = torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda()
+    base = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
+    _compare(oracle, locus, b, base, locus.Params(), range(0, 96, 4))
+    for env in ("TRGT_WFA_ONE_LAUNCH", "TRGT_WFA_NO_SPEC", "TRGT_HOST_GENOTYPER"):
+        monkeypatch.setenv(env, "1")
+        out = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
+        monkeypatch.delenv(env)
+        for f in ("span_start", "span_end", "n_alleles", "allele_len", "ci", "num_spanning", "classification", "read_rank", "n_spans"):
+            assert np.array_equal(getattr(out, f), getattr(base, f)), (env, f)
+        assert np.array_equal(out.purity.view(np.uint64), base.purity.view(np.uint64)), env
+        for l in range(96):
+            assert locus.locus_result(b, out, l).vcf_fields() == locus.locus_result(b, base, l).vcf_fields(), (env, l)
