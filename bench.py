@@ -198,7 +198,7 @@ def main():
             "work_per_step": {"flank_wfa_jobs": int(stats[0]), "flank_wfa_jobs_first_launch": int(stats[14]), "consensus_jobs": int(stats[1]), "spanning_reads": int(stats[2]),
                               "hmm_jobs": int(stats[3])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(batch)
             nthr = min(os.cpu_count() or 1, 32)
             if nthr > 1:
