@@ -1,0 +1,100 @@
+"""Host-side steps either side of the GPU path: catalog + reference + BAM -> clipped reads
+(trgt_amd/reads.py, mirror of tr.rs:186-196, 262-361 and clip_region.rs) and LocusResult -> VCF record (trgt_amd/vcf.py, mirror of
+write_vcf.rs:95-397).  Inputs are the reference's own example data set (tests/golden/example/ = example/{reference.fasta,
+repeat.bed, sample.bam}); the expected record is the one the reference documents for it (docs/tutorial.md:43-46)."""
+import json
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+EX = os.path.join(GOLD, "example")
+# docs/tutorial.md:45 (`bcftools view --no-header sample.vcf.gz | head -n 1`), tab-separated
+TUTORIAL_RECORD = "\t".join([
+    "chrA", "10001", ".", "C" + "CAG" * 20, "C" + "CAG" * 11, ".", ".", "TRID=TR1;END=10061;MOTIFS=CAG;STRUC=<TR>",
+    "GT:AL:ALLR:SD:MC:MS:AP:AM", "1/1:33,33:30-39,33-33:15,14:11,11:0(0-33),0(0-33):1.000000,1.000000:.,."])
+
+
+def _example():
+    from trgt_amd import reads
+    genome = reads.read_fasta(os.path.join(EX, "reference.fasta"))
+    loci = reads.read_catalog(os.path.join(EX, "repeat.bed"), genome)
+    records = reads.read_bam(os.path.join(EX, "sample.bam"))
+    return reads, loci, records
+
+
+def test_bam_ingestion_reproduces_the_committed_fixture():
+    reads, loci, records = _example()
+    assert len(loci) == 1 and loci[0].id == "TR1" and (loci[0].contig, loci[0].start, loci[0].end) == ("chrA", 10001, 10061)
+    fx = json.load(open(os.path.join(GOLD, "example_e1_reads.json")))["loci"][0]
+    L = reads.locus_inputs(loci[0], records)
+    assert L["left_flank"].decode() == fx["left_flank"] and L["right_flank"].decode() == fx["right_flank"] and L["tr"].decode() == fx["tr"]
+    assert [r.decode() for r in L["reads"]] == fx["reads"]
+    assert all(q is not None and q >= 0.98 for q in L["read_qual"])
+
+
+def test_clip_cigar_cases():
+    from trgt_amd.reads import clip_cigar
+    M, I, D, S = 0, 1, 2, 4
+    # read [100, 160) on the reference, 5 soft-clipped bases in front
+    ops = [(S, 5), (M, 20), (I, 3), (M, 10), (D, 4), (M, 26)]
+    assert clip_cigar(100, ops, (0, 1000)) == (100, 0, ops)                     # region covers everything: soft clip kept
+    assert clip_cigar(100, ops, (110, 125)) == (110, 15, [(M, 10), (I, 3), (M, 5)])
+    assert clip_cigar(100, ops, (131, 140)) == (131, 38, [(D, 3), (M, 6)])      # starts inside the deletion
+    assert clip_cigar(100, ops, (160, 170)) is None and clip_cigar(100, ops, (0, 100)) is None
+
+
+def test_set_gt_and_record_shapes():
+    from trgt_amd import reads, vcf
+    from trgt_amd.hmm import Annotation, Span
+    from trgt_amd.locus import Allele, LocusResult
+    loc = reads.Locus("X", "chr1", 101, 110, b"ACGTT", b"CAGCAGCAG", b"GGGGG", ["CAG"], "(CAG)n")
+    ann = lambda n: Annotation([Span(0, 0, 3 * n)] if n else None, [n], 1.0 if n else float("nan"))
+    al = lambda n: Allele(b"CAG" * n, ann(n), (3 * n, 3 * n), 5)
+    rec = lambda g: vcf.vcf_record(loc, LocusResult(g, [], [], [])).split("\t")
+    r = rec([al(3), al(3)])                       # homozygous reference
+    assert r[3] == "TCAGCAGCAG" and r[4] == "." and r[9].startswith("0/0:9,9:")
+    r = rec([al(3), al(5)])                       # reference first
+    assert r[4] == "T" + "CAG" * 5 and r[9].startswith("0/1:9,15:9-9,15-15:5,5:3,5:0(0-9),0(0-15):1.000000,1.000000:.,.")
+    r = rec([al(4), al(4)])                       # homozygous alternative: one ALT, 1/1
+    assert r[4] == "T" + "CAG" * 4 and r[9].startswith("1/1:")
+    r = rec([al(2), al(5)])                       # two alternatives
+    assert r[4] == "T" + "CAG" * 2 + ",T" + "CAG" * 5 and r[9].startswith("1/2:")
+    r = rec([al(0), al(3)])                       # empty allele: MS '.', AP '.'
+    assert r[4] == "T" and r[9] == "1/0:0,9:0-0,9-9:5,5:0,3:.,0(0-9):.,1.000000:.,."
+    r = rec([al(4)])                              # haploid
+    assert r[9].startswith("1:12:12-12:5:4:")
+    r = rec([])                                   # LocusResult::empty
+    assert r[3] == "TCAGCAGCAG" and r[4] == "." and r[9] == ".:.:.:.:.:.:.:."
+    assert r[:3] == ["chr1", "101", "."] and r[7] == "TRID=X;END=110;MOTIFS=CAG;STRUC=(CAG)n" and r[8] == "GT:AL:ALLR:SD:MC:MS:AP:AM"
+
+
+def test_oracle_result_renders_as_the_tutorial_record(oracle):
+    from trgt_amd import vcf
+    from trgt_amd.hmm import Annotation, Span
+    from trgt_amd.locus import Allele, LocusResult
+    reads, loci, records = _example()
+    L = reads.locus_inputs(loci[0], records)
+    r = oracle.locus_analyze(L["left_flank"], L["right_flank"], L["tr"], L["motifs"], L["reads"])
+    geno = []
+    for a in range(r["n_alleles"]):
+        ms = r["MS"].split(",")[a]
+        labels = None if ms == "." else [Span(int(x.split("(")[0]), int(x.split("(")[1].split("-")[0]), int(x.split("-")[1][:-1])) for x in ms.split("_")]
+        counts = [int(v) for v in r["MC"].split(",")[a].split("_")]
+        ap = r["AP"].split(",")[a]
+        geno.append(Allele(r["alleles"][a].encode(), Annotation(labels, counts, float("nan") if ap == "." else float(ap)),
+                           (int(r["gt_ci"][a][0]), int(r["gt_ci"][a][1])), int(r["num_spanning"][a])))
+    assert vcf.vcf_record(loci[0], LocusResult(geno, [], [], [])) == TUTORIAL_RECORD
+
+
+@pytest.mark.gpu
+def test_example_bam_to_vcf_record_on_the_gpu():
+    # BASELINE.json configs[0] end to end: example/ catalog + reference + BAM -> clipped reads -> trgt_locus_batch -> VCF record
+    from trgt_amd import locus, vcf
+    reads, loci, records = _example()
+    res = locus.analyze_batch([reads.locus_inputs(l, records) for l in loci])
+    assert [vcf.vcf_record(l, r) for l, r in zip(loci, res)] == [TUTORIAL_RECORD]
+    # the cluster genotyper sees the same two alleles on this clean locus
+    res = locus.analyze_batch([reads.locus_inputs(l, records) | {"genotyper": "cluster"} for l in loci])
+    rec = vcf.vcf_record(loci[0], res[0]).split("\t")
+    assert rec[4] == "C" + "CAG" * 11 and rec[9].startswith("1/1:33,33:")
