@@ -171,6 +171,7 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
 
 // --------------------------------------------------------------- kernel
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
+constexpr int HMM_LDS_PER_STATE = 16 + 16 + 8 + 2 + 1 + 1;  // two score columns, lp[2], inst[4], block, flags, bp column
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
   // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
@@ -236,11 +237,13 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       &tb_ref = tb[6], &tb_next = tb[7], &tb_vb1 = tb[8];
   double* sc0 = reinterpret_cast<double*>(lds + 64);
   double* sc1 = sc0 + S;
-  uint16_t* l_inst = reinterpret_cast<uint16_t*>(sc1 + S);           // [4][S]
+  double* l_lp = sc1 + S;                                             // [2][S] ln transition probabilities of predecessors 0 and 1
+  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_lp + 2 * S);       // [4][S]
   int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
   uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
-  uint32_t* l_blocks = reinterpret_cast<uint32_t*>(lds + 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15));  // [4][nb]
-  uint8_t* l_stage = lds + 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15);
+  uint8_t* l_bpcol = l_flags + S;                                     // [S] back-pointers of states evaluated by another lane
+  uint32_t* l_blocks = reinterpret_cast<uint32_t*>(lds + 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15));  // [4][nb]
+  uint8_t* l_stage = lds + 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15);
 
   const double* g_inlp = reinterpret_cast<const double*>(model + set.off_inlp);
   const double* g_em = reinterpret_cast<const double*>(model + set.off_em);
@@ -262,7 +265,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   }
   const uint8_t* const motif_bytes = STAGE ? l_mot : g_motifs;
   for (int i = tid; i < 4 * S; i += nthr) l_inst[i] = g_inst[i];
-  for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; }
+  for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
 
   // ---- my state's tables in registers
@@ -271,6 +274,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int n_in = model[set.off_nin + st];
   const int level = model[set.off_level + st];
   const int n_levels = (int)set.n_levels;
+  (void)n_levels;  // only the level-by-level variant (TRGT_HMM_LEVELWISE) walks the levels
   double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
   const double em0 = g_em[0 * S + st], em1 = g_em[1 * S + st], em2 = g_em[2 * S + st], em3 = g_em[3 * S + st], em4 = g_em[4 * S + st];
   const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
@@ -279,6 +283,13 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
   hmm_sync(sync_n);
+  // roles in the evaluation of the silent states of a column (see the fill loop)
+  const int my_blk = act ? (int)l_block[st] : -1;
+  const bool role_end = act && my_blk >= 0 && st == (int)l_blocks[1 * nb + my_blk];
+  const bool role_start = act && my_blk >= 0 && st == (int)l_blocks[0 * nb + my_blk];
+  const int blk_n = role_end && my_blk != nb - 1 ? (int)l_blocks[2 * nb + my_blk] : 0;            // motif length (0: the skip block)
+  const int blk_m0 = role_end ? (int)l_blocks[0 * nb + my_blk] + 1 : 0, blk_d0 = blk_m0 + 2 * blk_n;  // first match / deletion state
+  const bool role_other = act && level > 0 && !role_end && !role_start && n_in != 0xFF;             // deletion states, run start
 
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
@@ -305,6 +316,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       cur[st] = best;
     }
     hmm_sync(sync_n);
+#ifdef TRGT_HMM_LEVELWISE
     for (int lev = 1; lev <= n_levels; ++lev) {
       if (act && level == lev) {
         if (n_in == 0xFF) {  // run-end state: predecessors are the block end states, in block order
@@ -324,6 +336,54 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       }
       hmm_sync(sync_n);
     }
+#else
+    // Silent states of the column in three passes instead of one per topological level (motif length + 3 of them, each an LDS
+    // round trip and a fence with one or two busy lanes).  The dependency chain of a motif block -- d0 <- d1 <- ... <- block end --
+    // is walked by ONE lane (the block-end state's) with the chain value in a register; then the run-end lane takes the maximum
+    // over the block ends and evaluates the run start behind it; then every block start.  Same sums, same predecessor order, same
+    // strict '>' as level by level (any topological order gives identical values, hmm_model.rs:206-240).
+    if (role_end) {
+      double chain = NINF;
+      for (int k = 0; k + 1 < blk_n; ++k) {  // deletion states d0 + k: predecessors {m0 + k, d0 + k - 1}
+        const int sd = blk_d0 + k;
+        double bd = NINF; int pd = 0xFF;
+        const double v0 = (cur[blk_m0 + k] + l_lp[sd]) + 0.0;
+        if (v0 > bd) { bd = v0; pd = 0; }
+        if (k > 0) { const double v1 = (chain + l_lp[S + sd]) + 0.0; if (v1 > bd) { bd = v1; pd = 1; } }
+        cur[sd] = bd; l_bpcol[sd] = (uint8_t)pd; chain = bd;
+      }
+      // the block end itself: {m_last, i_last, d_last} (or {skip} / {m, i}); d_last is the chain value just computed
+      const double s0 = cur[q0], s1 = cur[q1], s2 = (n_in > 2) ? chain : 0.0;
+      const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0, v2 = (s2 + lp2) + 0.0;
+      if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+      if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+      if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+      cur[st] = best;
+    }
+    hmm_sync(sync_n);
+    if (act && n_in == 0xFF) {  // run end: block ends in block order; then the run start {start state, run end}
+      for (int b = 0; b < nb; ++b) {
+        const double v = (cur[l_blocks[1 * nb + b]] + lp0) + 0.0;
+        if (v > best) { best = v; bpi = b; }
+      }
+      cur[st] = best;
+      double br = NINF; int pr = 0xFF;
+      const double v0 = (cur[0] + l_lp[1]) + 0.0, v1 = (best + l_lp[S + 1]) + 0.0;
+      if (v0 > br) { br = v0; pr = 0; }
+      if (v1 > br) { br = v1; pr = 1; }
+      cur[1] = br; l_bpcol[1] = (uint8_t)pr;
+    }
+    hmm_sync(sync_n);
+    if (role_start) {  // block start: {run start, own block end}
+      const double s0 = cur[q0], s1 = cur[q1];
+      const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0;
+      if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+      if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+      cur[st] = best;
+    }
+    hmm_sync(sync_n);
+    if (role_other) bpi = l_bpcol[st];  // deletion states and the run start were evaluated by another lane
+#endif
     if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
     double* t = prev; prev = cur; cur = t;
   }
@@ -456,7 +516,7 @@ __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const 
 }
 
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb, uint32_t stage_qcap) {
-  size_t o = 64 + (((size_t)(16 + 8 + 2 + 1) * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
+  size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
   if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * ((size_t)stage_qcap + 3) + 4 * (size_t)nb;
