@@ -170,8 +170,17 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
 }
 
 // --------------------------------------------------------------- kernel
+#ifdef TRGT_HMM_PROF
+// developer build (make HMMPROF=1): lane 0 of every job splits its shader-clock time over the phases of the kernel
+__device__ unsigned long long g_hmm_prof[8];
+#define HP_DECL unsigned long long hp_t = clock64()
+#define HP_MARK(i) do { const unsigned long long n_ = clock64(); if (tid == 0) atomicAdd(&g_hmm_prof[i], n_ - hp_t); hp_t = n_; } while (0)
+#else
+#define HP_DECL
+#define HP_MARK(i)
+#endif
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
-constexpr int HMM_LDS_PER_STATE = 16 + 16 + 8 + 2 + 1 + 1;  // two score columns, lp[2], inst[4], block, flags, bp column
+constexpr int HMM_LDS_PER_STATE = 16 + 16 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], info, inst[4], block, flags, bp column
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
   // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
@@ -212,6 +221,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
   const uint32_t jidx = SUB == 32 ? blockIdx.x * 2u + (uint32_t)grp : blockIdx.x;
   if (jidx >= n_launch_jobs) return;
+  HP_DECL;
   unsigned char* const lds = lds_all + (size_t)grp * lds_per_job;
   const HmmJobDev job = jobs[jidx];
   const HmmSetDev set = sets[job.set];
@@ -238,7 +248,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* sc0 = reinterpret_cast<double*>(lds + 64);
   double* sc1 = sc0 + S;
   double* l_lp = sc1 + S;                                             // [2][S] ln transition probabilities of predecessors 0 and 1
-  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_lp + 2 * S);       // [4][S]
+  uint32_t* l_info = reinterpret_cast<uint32_t*>(l_lp + 2 * S);       // [S] what the traceback needs to know about a state, in one word
+  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_info + S);         // [4][S]
   int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
   uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
   uint8_t* l_bpcol = l_flags + S;                                     // [S] back-pointers of states evaluated by another lane
@@ -283,6 +294,24 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
   hmm_sync(sync_n);
+  // traceback word of my state: kind (0 outside any block, 1 block start, 2 block end, 3 skip state, 4 match, 5 insertion,
+  // 6 deletion) | emits << 3 | block << 8 | expected motif base << 16 (match states)
+  if (act) {
+    const int blk = (int)l_block[st];
+    uint32_t kind = 0, expected = 0;
+    if (blk >= 0) {
+      const int bstart = (int)l_blocks[0 * nb + blk], bend = (int)l_blocks[1 * nb + blk];
+      if (st == bstart) kind = 1;
+      else if (st == bend) kind = 2;
+      else if (blk == nb - 1) kind = 3;
+      else {
+        const int mlen = (int)l_blocks[2 * nb + blk], off = st - bstart - 1, k = off / mlen;
+        kind = 4u + (uint32_t)k;
+        if (k == 0) expected = motif_bytes[l_blocks[3 * nb + blk] + off];
+      }
+    }
+    l_info[st] = kind | ((uint32_t)(l_flags[st] & 1) << 3) | ((uint32_t)(blk & 0xFF) << 8) | (expected << 16);
+  }
   // roles in the evaluation of the silent states of a column (see the fill loop)
   const int my_blk = act ? (int)l_block[st] : -1;
   const bool role_end = act && my_blk >= 0 && st == (int)l_blocks[1 * nb + my_blk];
@@ -291,6 +320,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int blk_m0 = role_end ? (int)l_blocks[0 * nb + my_blk] + 1 : 0, blk_d0 = blk_m0 + 2 * blk_n;  // first match / deletion state
   const bool role_other = act && level > 0 && !role_end && !role_start && n_in != 0xFF;             // deletion states, run start
 
+  HP_MARK(0);
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
   double* cur = sc1;
@@ -387,6 +417,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
     double* t = prev; prev = cur; cur = t;
   }
+  HP_MARK(1);
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
   }
@@ -413,34 +444,29 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       while (state != 0 && idx >= c0) {
         if (pbuf && np < pcap) pbuf[pcap - 1 - np] = (uint16_t)state;
         ++np;
-        const int blk = l_block[state];
-        if (blk >= 0) {
-          const int bstart = (int)l_blocks[0 * nb + blk], bend = (int)l_blocks[1 * nb + blk];
-          if (state == bstart) {  // MotifStart + implied leading deletions (events.rs:42-48)
-            const int dels = nxt - state - 1;
-            edit += dels; ref += dels;
-            visits[3 * nv + 0] = (uint32_t)blk; visits[3 * nv + 1] = (uint32_t)idx; visits[3 * nv + 2] = (uint32_t)vb1;
-            ++nv;
-          } else if (state == bend) {
-            vb1 = idx;  // bases of this visit are query[.. idx)
-          } else if (blk == nb - 1) {  // Skip
-            ++edit; ++ref;
-          } else {
-            const int mlen = (int)l_blocks[2 * nb + blk];
-            const int off = state - bstart - 1;
-            const int kind = off / mlen;
-            if (kind == 0) {  // match state: Match iff query base == motif base or motif base is N (events.rs:66-73)
-              const int expected = motif_bytes[l_blocks[3 * nb + blk] + off];
-              const int base = "#ATCG"[hmm_code(seq, idx, L)];
-              ++ref;
-              if (!(base == expected || expected == 'N')) ++edit;
-            } else if (kind == 1) { ++edit; }            // Ins
-            else { ++edit; ++ref; }                      // Del
-          }
-        }
+        // one word describes the state, and nothing but the predecessor lookup depends on the back-pointer: two LDS round trips
+        // per step (it was seven, and an integer division)
+        const uint32_t inf = l_info[state];
         const int b = l_stage[(size_t)(idx - c0) * Spad + state];
+        const int qbase = "#ATCG"[hmm_code(seq, idx, L)];
+        const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
+        if (kind == 1) {  // MotifStart + implied leading deletions (events.rs:42-48)
+          const int dels = nxt - state - 1;
+          edit += dels; ref += dels;
+          visits[3 * nv + 0] = (uint32_t)blk; visits[3 * nv + 1] = (uint32_t)idx; visits[3 * nv + 2] = (uint32_t)vb1;
+          ++nv;
+        } else if (kind == 2) {
+          vb1 = idx;  // bases of this visit are query[.. idx)
+        } else if (kind == 3) {  // Skip
+          ++edit; ++ref;
+        } else if (kind == 4) {  // match state: Match iff query base == motif base or motif base is N (events.rs:66-73)
+          const int expected = (int)((inf >> 16) & 0xFFu);
+          ++ref;
+          if (!(qbase == expected || expected == 'N')) ++edit;
+        } else if (kind == 5) { ++edit; }       // Ins
+        else if (kind == 6) { ++edit; ++ref; }  // Del
         const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[b * S + state];
-        if (l_flags[state] & 1) --idx;
+        if (inf & 8u) --idx;
         nxt = state;
         state = prv;
       }
@@ -450,6 +476,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     hmm_sync(sync_n);
   }
   const int np = tb_npath;
+  HP_MARK(2);
   // ---- state path: shift the reversed tail to the front (forward order)
   if (pbuf) {
     const int n = min(np, pcap), shift = pcap - n;
@@ -502,6 +529,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     hmm_sync(sync_n);
     for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   }
+  HP_MARK(3);
 }
 
 // Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
@@ -815,6 +843,16 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
       (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
     return rc;
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef TRGT_HMM_PROF
+  {
+    unsigned long long h[8], z[8] = {0};
+    TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hmm_prof), sizeof h));
+    TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_hmm_prof), z, sizeof h));
+    const double t = (double)(h[0] + h[1] + h[2] + h[3]) + 1e-9;
+    fprintf(stderr, "[hmm prof] jobs=%lld | setup %.1f%% fill %.1f%% traceback %.1f%% path+decode %.1f%% | kcycles/job %.1f\n", (long long)n_jobs,
+            100 * h[0] / t, 100 * h[1] / t, 100 * h[2] / t, 100 * h[3] / t, t / 1e3 / (double)n_jobs);
+  }
+#endif
   if (!h_cnt.empty())
     for (size_t j = 0; j < P->cnt_off.size(); ++j)
       std::memcpy(P->cnt_user + P->cnt_off[j], h_cnt.data() + P->cnt_off[j], (size_t)P->cnt_n[j] * 4);
