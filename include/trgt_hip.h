@@ -221,7 +221,8 @@ int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_l
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {
   uint64_t seed;           /* 20250509 */
-  int32_t config;          /* 2 / 4 = single-motif STR loci (cfg2, cfg4), 5 = compound / N-motif loci for the cluster genotyper */
+  int32_t config;          /* 2 = single-motif STR loci (cfg2), 4 = genome-wide catalog stand-in (70 % STR, 20 % 2-5 motifs,
+                              10 % VNTR motifs of 7-60 bp), 5 = compound / N-motif loci for the cluster genotyper */
   int32_t reads_per_locus; /* 30 */
   int32_t context_len;     /* 500 */
   int32_t flank_len;       /* 250 */

@@ -361,3 +361,15 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
         assert np.array_equal(out.purity.view(np.uint64), base.purity.view(np.uint64)), env
         for l in range(96):
             assert locus.locus_result(b, out, l).vcf_fields() == locus.locus_result(b, base, l).vcf_fields(), (env, l)
+
+
+def test_cfg4_catalog_mix_matches_oracle(oracle, mods):
+    # BASELINE configs[3] stand-in: 70 % single STR loci, 20 % loci with 2-5 motifs, 10 % VNTR loci with one
+    # motif of 7-60 bp and alleles up to 600 bp -- HMMs from 10 to ~190 states in one batch, size genotyper
+    locus, synth = mods
+    b = synth.generate(120, first_locus=2024, config=4)
+    nm = np.diff(b["set_motif_begin"])
+    mlen = np.diff(b["motif_off"])
+    assert (nm > 1).any() and (mlen >= 20).any() and (nm == 1).sum() > 60
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(120))

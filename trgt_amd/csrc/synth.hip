@@ -1,7 +1,8 @@
 // trgt_amd/csrc/synth.hip -- deterministic synthetic locus batches (host code only).
 //
-// Implements the workload of SURVEY.md Appendix E for BASELINE.json configs[1]/[3] ("10k synthetic
-// single-motif STR loci, motif 3-6 bp, allele <= 200 bp, 30x HiFi"): per-locus splitmix64 stream,
+// Implements the workloads of SURVEY.md Appendix E: BASELINE.json configs[1] ("10k synthetic single-motif STR loci,
+// motif 3-6 bp, allele <= 200 bp, 30x HiFi", config 2), the genome-wide catalog mix of configs[3] (config 4) and the
+// compound / N-motif loci of configs[4] (config 5): per-locus splitmix64 stream,
 // draw order motif -> copy numbers -> flanks -> reads, HiFi-like error channel, +-1 unit stutter and
 // 10 % truncated reads (which must end up with span = None).  Reads are "already clipped" to
 // 2*flank_len of context (what clip_reads leaves, src/trgt/workflows/tr.rs:33-34).
@@ -71,19 +72,19 @@ std::string channel(Rng& g, const std::string& in, const trgt_synth_params& p) {
 // cfg5: 2-10 motifs of length 2-12, at least one containing N, alleles <= max_allele_bp (300) built as
 // consecutive runs of every motif (N positions filled uniformly per copy), Genotyper::Cluster.  Same draw order as cfg2:
 // motifs, copy numbers, flanks, reads.
-void gen_locus_compound(const trgt_synth_params& p, int64_t idx, LocusData& L) {
-  Rng g(p.seed ^ ((uint64_t)(idx + 1) * 0x9E3779B97F4A7C15ull));
-  const int nm = g.range(2, 10);
+struct CompoundShape { int nm_lo, nm_hi, len_lo, len_hi; bool with_n; uint8_t genotyper; int max_bp; };
+void gen_locus_compound(const trgt_synth_params& p, int64_t idx, LocusData& L, Rng& g, const CompoundShape& sh) {
+  const int nm = g.range(sh.nm_lo, sh.nm_hi);
   L.motifs.resize((size_t)nm);
   for (auto& m : L.motifs) {
-    const int n = g.range(2, 12);
+    const int n = g.range(sh.len_lo, sh.len_hi);
     do { m.assign((size_t)n, 'A'); for (int i = 0; i < n; ++i) m[(size_t)i] = g.base(); } while (n > 1 && is_power_of_shorter_unit(m));
   }
-  { std::string& m = L.motifs[g.below((uint32_t)nm)]; m[g.below((uint32_t)m.size())] = 'N'; }
-  L.genotyper = 1;
+  if (sh.with_n) { std::string& m = L.motifs[g.below((uint32_t)nm)]; m[g.below((uint32_t)m.size())] = 'N'; }
+  L.genotyper = sh.genotyper;
   std::vector<int> copies[2];
   for (int m = 0; m < nm; ++m) {
-    const int cap = std::max(1, (p.max_allele_bp / nm) / (int)L.motifs[(size_t)m].size());
+    const int cap = std::max(1, (sh.max_bp / nm) / (int)L.motifs[(size_t)m].size());
     const int c1 = g.range(1, cap);
     const double r = g.real();
     int delta = 0;
@@ -132,8 +133,15 @@ void gen_locus_compound(const trgt_synth_params& p, int64_t idx, LocusData& L) {
 }
 
 void gen_locus(const trgt_synth_params& p, int64_t idx, LocusData& L) {
-  if (p.config == 5) { gen_locus_compound(p, idx, L); return; }
   Rng g(p.seed ^ ((uint64_t)(idx + 1) * 0x9E3779B97F4A7C15ull));
+  if (p.config == 5) { gen_locus_compound(p, idx, L, g, CompoundShape{2, 10, 2, 12, true, 1, p.max_allele_bp}); return; }
+  if (p.config == 4) {
+    // genome-wide catalog stand-in (SURVEY.md Appendix E, cfg4 note): 70 % single STR loci as in cfg2, 20 % loci with 2-5 motifs
+    // of 2-12 bp, 10 % VNTR loci with one motif of 7-60 bp and alleles up to 600 bp.  Size genotyper throughout.
+    const double r = g.real();
+    if (r >= 0.90) { gen_locus_compound(p, idx, L, g, CompoundShape{1, 1, 7, 60, false, 0, 600}); return; }
+    if (r >= 0.70) { gen_locus_compound(p, idx, L, g, CompoundShape{2, 5, 2, 12, false, 0, std::max(p.max_allele_bp, 240)}); return; }
+  }
   // motif
   const int n = g.range(3, 6);
   do {
