@@ -149,6 +149,8 @@ inline int central_read(int n, const std::vector<int>& group, const std::vector<
   return group[best];
 }
 
+inline int64_t now_ns_cluster() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct ClusterBatch {
   trgt_hip_ctx* c;
   HostPool* pool;
@@ -227,11 +229,15 @@ struct ClusterBatch {
 
   int run() {
     if (loci.empty()) return TRGT_OK;
+    const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+    const int64_t tl0 = now_ns_cluster();
+#define CTL(name) do { if (tl_on) fprintf(stderr, "[tl]   cluster %-22s +%7.2f ms\n", name, (double)(now_ns_cluster() - tl0) / 1e6); } while (0)
     // the batch blob: all segments once
     for (auto& L : loci) {
       L.blob_off = blob.size(); L.seg_off.resize((size_t)L.n);
       for (int i = 0; i < L.n; ++i) { L.seg_off[(size_t)i] = blob.size() - L.blob_off; blob.insert(blob.end(), L.trs[i].p, L.trs[i].p + L.trs[i].n); }
     }
+    CTL("blob built");
     // ---- get_dist_matrix for every locus
     ed_clear();
     for (auto& L : loci) L.dists.assign((size_t)L.n * (size_t)(L.n - 1) / 2, 0.0);
@@ -241,8 +247,10 @@ struct ClusterBatch {
         for (int j = i + 1; j < L.n; ++j, ++d)
           ed_add(L.blob_off + L.seg_off[(size_t)i], L.trs[i].n, L.blob_off + L.seg_off[(size_t)j], L.trs[j].n, d);
     }
+    CTL("ed jobs built");
     int rc = ed_run();
     if (rc) return rc;
+    CTL("ed batch done");
     // ---- groups
     pool->parallel_for((int64_t)loci.size(), 4, [&](int64_t k, int) {
       ClusterLocus& L = loci[(size_t)k];
@@ -258,9 +266,11 @@ struct ClusterBatch {
       L.n_groups = 2;
       L.group[0].swap(groups[groups.size() - 1]); L.group[1].swap(groups[groups.size() - 2]);
     });
+    CTL("groups");
     std::vector<std::pair<int, int>> todo;
     for (size_t k = 0; k < loci.size(); ++k) for (int g = 0; g < loci[k].n_groups; ++g) todo.push_back({(int)k, g});
     if ((rc = consensus_round(todo))) return rc;
+    CTL("consensus round 1");
     // ---- small_group_is_outlier (:89-98) -> redo as the homozygous split
     todo.clear();
     for (size_t k = 0; k < loci.size(); ++k) {
@@ -275,6 +285,7 @@ struct ClusterBatch {
       }
     }
     if ((rc = consensus_round(todo))) return rc;
+    CTL("consensus round 2");
     // ---- classification; outlier reads (dropped by cluster()) go to the closer consensus (:117-142)
     ed_clear();
     std::vector<std::array<double, 2>> odist;
@@ -312,6 +323,7 @@ struct ClusterBatch {
         loci[(size_t)oref[o].first].cls[(size_t)oref[o].second] = (int8_t)(d1 < d2 ? 0 : (d2 < d1 ? 1 : 0));
       }
     }
+    CTL("outliers");
     // ---- Gt / allele order
     for (auto& L : loci) {
       if (L.n_groups == 1) {
