@@ -10,8 +10,9 @@ rd = torch.from_numpy(b["read_blob"]).cuda(); fd = torch.from_numpy(b["flank_blo
 out = locus.BatchOutputs(b); ctx = _lib.Context(0)
 params = locus.Params(host_threads=os.cpu_count())
 ts = []
-for i in range(14):
+for i in range(int(os.environ.get('N_STEPS', '14'))):
     if i == 2 and timing: ctx.timing_enable(True); ctx.timing_reset()
+    if i == 8 and timing and len(sys.argv) > 2: ctx.timing_reset()
     torch.cuda.synchronize(); t0 = time.perf_counter(); locus.run_batch(b, params, ctx, out, flank_dev=fd, reads_dev=rd); torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 print("timing" if timing else "plain", " ".join("%.1f" % t for t in ts))

@@ -32,7 +32,7 @@ struct trgt_hip_ctx {
   int64_t k_cells[TRGT_K_COUNT] = {0, 0, 0, 0};
   struct Pending { int k; hipEvent_t a, b; };
   std::vector<Pending> pending;
-  std::vector<hipEvent_t> event_pool;  // recycled: creating events inside a timed region costs milliseconds now and then
+  std::vector<hipEvent_t> retired_events;  // resolved timing events: neither destroyed nor re-recorded while calls are being timed (see resolve_timing)
   void* last_wfa_cells_dev = nullptr;
   int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host-side phase timers of the last call (diagnostics)
   // trgt_locus_batch pipelines chunks of loci: stage A of chunk k+1 runs on `stream` while the host glue of chunk k and its
@@ -170,13 +170,7 @@ struct DevOut {
 struct KTimer {
   trgt_hip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr; bool on;
   KTimer(trgt_hip_ctx* c_, int k_) : c(c_), k(k_), on(c_->timing) {
-    if (on) { a = take(); b = take(); (void)hipEventRecord(a, c->stream); }
-  }
-  hipEvent_t take() {
-    hipEvent_t e = nullptr;
-    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
-    else (void)hipEventCreate(&e);
-    return e;
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
   }
   void stop(int64_t cells) {
     if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({k, a, b}); c->k_launches[k] += 1; c->k_cells[k] += cells; }
@@ -187,9 +181,12 @@ inline void resolve_timing(trgt_hip_ctx* c) {
     float ms = 0;
     (void)hipEventSynchronize(p.b);
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->k_ms[p.k] += ms;
-    c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    // destroying (or re-recording) events here makes one of the next few calls 3-7 ms slower now and then (measured, ROCm 7.2): they
+    // are parked and destroyed with the ctx, or in bulk once there are very many
+    c->retired_events.push_back(p.a); c->retired_events.push_back(p.b);
   }
   c->pending.clear();
+  if (c->retired_events.size() > (1u << 18)) { for (hipEvent_t e : c->retired_events) (void)hipEventDestroy(e); c->retired_events.clear(); }
 }
 
 }  // namespace trgt

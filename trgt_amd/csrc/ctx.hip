@@ -51,7 +51,7 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   for (auto& b : c->pool)
     if (b.p) (void)hipFree(b.p);
   trgt::resolve_timing(c);
-  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->retired_events) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -82,10 +82,6 @@ int trgt_hip_set_workspace_limit(trgt_hip_ctx* c, uint64_t bytes) {
 int trgt_hip_timing_enable(trgt_hip_ctx* c, int on) {
   if (!c) return TRGT_ERR_INVALID;
   c->timing = on != 0;
-  if (c->timing && c->event_pool.size() < 256) {  // enough for a few calls between two timing_get / timing_reset
-    (void)hipSetDevice(c->device);
-    while (c->event_pool.size() < 256) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; c->event_pool.push_back(e); }
-  }
   return TRGT_OK;
 }
 int trgt_hip_timing_reset(trgt_hip_ctx* c) {
