@@ -314,8 +314,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   std::vector<uint32_t> read_locus((size_t)nr), heavy_len((size_t)nl);
   uint64_t flank_total = 0, read_total = 0, tr_total = 0, allele_total = 0;
   uint32_t max_read_len = 0, heavy_tlen_max = 0;
+  uint64_t max_locus_reads = 0;
   {
-    struct alignas(64) Acc { uint64_t flank = 0, read = 0, tr = 0, allele = 0; uint32_t max_len = 0, heavy = 0; };  // one cache line per worker
+    struct alignas(64) Acc { uint64_t flank = 0, read = 0, tr = 0, allele = 0, reads = 0; uint32_t max_len = 0, heavy = 0; };  // one cache line per worker
     std::vector<Acc> acc((size_t)pool->size());
     std::atomic<int64_t> short_flank{-1};
     pool->parallel_for(nl, 256, [&](int64_t l, int t) {
@@ -332,6 +333,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       Acc& a = acc[(size_t)t];
       a.flank = std::max<uint64_t>(a.flank, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
       a.read = std::max(a.read, rt); a.max_len = std::max(a.max_len, ml); a.heavy = std::max(a.heavy, heavy_len[(size_t)l]);
+      a.reads = std::max<uint64_t>(a.reads, in->locus_read_begin[l + 1] - in->locus_read_begin[l]);
       a.tr = std::max<uint64_t>(a.tr, in->tr_off[l] + in->tr_len[l]);
       a.allele = std::max<uint64_t>(a.allele, std::max(out->allele_off[2 * l], out->allele_off[2 * l + 1]) + out->allele_cap[l]);
     });
@@ -339,6 +341,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     for (const Acc& a : acc) {
       flank_total = std::max(flank_total, a.flank); read_total = std::max(read_total, a.read); max_read_len = std::max(max_read_len, a.max_len);
       tr_total = std::max(tr_total, a.tr); allele_total = std::max(allele_total, a.allele); heavy_tlen_max = std::max(heavy_tlen_max, a.heavy);
+      max_locus_reads = std::max(max_locus_reads, a.reads);
     }
   }
   c->dbg_ns[0] = now_ns() - t0;  // set-up: thread pool, model thread, piece / read-locus tables
@@ -415,7 +418,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     ga.need_host = (uint8_t*)g.need; ga.n_alleles = (int32_t*)g.nal; ga.allele_blob = (uint8_t*)g.blob; ga.allele_len = (uint32_t*)g.alen;
     ga.ci = (int32_t*)g.ci; ga.num_spanning = (int32_t*)g.nsp; ga.classification = (int32_t*)g.cls; ga.read_rank = (int32_t*)g.rank;
     ga.n_spanning_reads = (uint32_t*)g.nspan;
-    hipLaunchKernelGGL(gt::locus_genotype_kernel, dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
+    if (max_locus_reads <= 64) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
+    else hipLaunchKernelGGL((gt::locus_genotype_kernel<gt::GT_MAX_READS, gt::GT_SEG_LDS>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     TRGT_HIP_TRY(c, hipGetLastError());
     hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
