@@ -539,33 +539,40 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   const uint32_t n_jobs = n_front + (a.n_jobs2_dev ? *a.n_jobs2_dev : 0u);
   unsigned long long cells_acc = 0;
   PROF_DECL;
-  for (uint32_t jb = 0; jb < a.jobs_per_block; ++jb) {
+  // 4-byte sliding windows straight from global memory: a thread turns two (unaligned) dwords into the windows of four positions
+  auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W, int t, int nt) {
+    for (int i0 = 4 * t; i0 <= len; i0 += 4 * nt) {
+      uint32_t d0 = 0, d1 = 0;
+      if (i0 + 8 <= len) { __builtin_memcpy(&d0, src + i0, 4); __builtin_memcpy(&d1, src + i0 + 4, 4); }
+      else
+        for (int b = 0; b < 8; ++b)
+          if (i0 + b < len) { if (b < 4) d0 |= (uint32_t)src[i0 + b] << (8 * b); else d1 |= (uint32_t)src[i0 + b] << (8 * (b - 4)); }
+      W[i0] = d0; W[i0 + 1] = __builtin_amdgcn_alignbyte(d1, d0, 1); W[i0 + 2] = __builtin_amdgcn_alignbyte(d1, d0, 2);
+      W[i0 + 3] = __builtin_amdgcn_alignbyte(d1, d0, 3);
+    }
+  };
+  auto job_at = [&](uint32_t j) { return a.jobs[j < n_front ? j : a.jobs_cap - 1u - (j - n_front)]; };
+  // Jobs are claimed one ahead: the index of the next job is fetched while the current one runs, so that the waves that idle during
+  // the back-trace of a light alignment (one wave's work) can already build the windows of the next one.
+  __syncthreads();
+  if (tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+  __syncthreads();
+  uint32_t j = rfl((uint32_t)fs.job);
+  bool staged = false;  // windows of job j already built (by waves 1.. during the previous back-trace)
+  while (j < n_jobs) {
     PROF_MARK(5);
-    __syncthreads();
-    if (tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
-    __syncthreads();
-    const uint32_t j = rfl((uint32_t)fs.job);
-    if (j >= n_jobs) break;
     PROF_MARK(0);
-    const JobDev job = a.jobs[j < n_front ? j : a.jobs_cap - 1u - (j - n_front)];
+    const JobDev job = job_at(j);
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* const P = a.pat_base + job.pat_off;
     const uint8_t* const Tx = a.txt_base + job.txt_off;
-    uint32_t* const T4 = P4 + plen + 4;  // (three entries of slack behind each window array: the unguarded tail writes below)
-    // 4-byte sliding windows straight from global memory: a thread turns two (unaligned) dwords into the windows of four positions
-    auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W) {
-      for (int i0 = 4 * tid; i0 <= len; i0 += 4 * T) {
-        uint32_t d0 = 0, d1 = 0;
-        if (i0 + 8 <= len) { __builtin_memcpy(&d0, src + i0, 4); __builtin_memcpy(&d1, src + i0 + 4, 4); }
-        else
-          for (int b = 0; b < 8; ++b)
-            if (i0 + b < len) { if (b < 4) d0 |= (uint32_t)src[i0 + b] << (8 * b); else d1 |= (uint32_t)src[i0 + b] << (8 * (b - 4)); }
-        W[i0] = d0; W[i0 + 1] = __builtin_amdgcn_alignbyte(d1, d0, 1); W[i0 + 2] = __builtin_amdgcn_alignbyte(d1, d0, 2);
-        W[i0 + 3] = __builtin_amdgcn_alignbyte(d1, d0, 3);
-      }
-    };
-    stage(P, plen, P4);
-    stage(Tx, tlen, T4);
+    uint32_t* const T4 = P4 + plen + 4;  // (three entries of slack behind each window array: the unguarded tail writes of stage())
+    if (!staged) { stage(P, plen, P4, tid, T); stage(Tx, tlen, T4, tid, T); }
+    staged = false;
+    // the next job: claimed before the level loop in the launch over the light alignments (its latency hides behind the loop, the
+    // job is a few microseconds of work), behind the loop in the launch over the expensive ones (a workgroup sitting on a claimed
+    // 400-microsecond job while others run dry lengthened that launch by 6 %)
+    if (TAG == 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
     FastJob J;
     {
       const int sp = a.kp.span;
@@ -588,6 +595,8 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     }
 #endif
     cells_acc += E.cells;
+    if (TAG != 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    uint32_t j_next = TAG == 1 ? rfl((uint32_t)fs.job) : 0u;  // TAG != 1: read behind the next barrier
     const bool ok = E.status == ST_END_REACHED;
     int nrun = 0;
     // The run list of the back-trace (reversed) lives in the idle ring area of LDS, behind the staged descriptors, with the run
@@ -603,9 +612,16 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       lruns = reinterpret_cast<uint32_t*>(lds_dyn + run_base);
       lcap = (a.fast_ring_bytes - run_base) / 8u;  // runs [0, lcap), run starts [lcap, 2 lcap)
       __syncthreads();  // every wave has left the level loop (ring idle), thread 0's descriptor stores are done
+      if (TAG != 1) j_next = rfl((uint32_t)fs.job);
       int nt = 0;
       if (in_ring) {
         if (tid < 64) nt = wf_backtrace_fast_affine<4>(pen, plen, tlen, E, reinterpret_cast<const uint32_t*>(fs.fdesc), A16g, rle_tmp, a.rle_cap, lruns, lcap);
+        else if (j_next < n_jobs) {  // meanwhile: the windows of the next job (the back-trace touches neither them nor the sequences)
+          const JobDev nj = job_at(j_next);
+          stage(a.pat_base + nj.pat_off, (int)nj.pat_len, P4, tid - 64, T - 64);
+          stage(a.txt_base + nj.txt_off, (int)nj.txt_len, P4 + nj.pat_len + 4, tid - 64, T - 64);
+        }
+        staged = j_next < n_jobs && T > 64;
       } else if (fits) {
         uint32_t* ld = reinterpret_cast<uint32_t*>(ring);
         for (int i = tid; i < (E.score + 1) * FD_LDS_STRIDE; i += T) {
@@ -627,6 +643,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     uint32_t* const lstart = lruns + lcap;
     auto run_at = [&](int r) -> uint32_t { return lds_runs ? lruns[nrun - 1 - r] : rle_out[r]; };  // forward order
     __syncthreads();
+    if (TAG != 1) j_next = rfl((uint32_t)fs.job);
     PROF_MARK(4);
     // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations (as in wfa_kernel)
     if (tid == 0) {
@@ -661,6 +678,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
         a.ops[job.ops_off + p] = code == 7u ? 'M' : code == 8u ? 'X' : code == 1u ? 'I' : 'D';
       }
     }
+    j = j_next;
   }
   if (tid == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
 #ifdef TRGT_WFA_PROF
