@@ -18,6 +18,7 @@
 // across the states of a column) and re-read in LDS-staged chunks by the traceback,
 // which also classifies events (purity) and collects motif visits on the fly.
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <limits>
 #include <thread>
@@ -266,8 +267,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   uint8_t* l_seq = l_stage + (HMM_STAGE_BYTES > Spad ? HMM_STAGE_BYTES : Spad);
   uint8_t* l_mot = l_seq + ((stage_qcap + 2 + 15) & ~15u);
   const int mot_bytes = (S - 7 - n_motifs) / 3;
-  uint32_t* l_vis = reinterpret_cast<uint32_t*>(l_mot + ((mot_bytes + 15) & ~15));
-  uint32_t* l_cnt = l_vis + 3 * (stage_qcap + 3);
+  // motif visits (block, first base, one past the last base): 16-bit in LDS (staged alleles are at most HMM_STAGE_QLEN long)
+  uint16_t* l_vis = reinterpret_cast<uint16_t*>(l_mot + ((mot_bytes + 15) & ~15));
+  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_vis + ((3 * (stage_qcap + 3) + 1) & ~1u));
   if (STAGE) {
     const uint8_t* gs = seq_blob + job.seq_off;
     for (int i = tid; i < qlen; i += nthr) l_seq[i] = gs[i];
@@ -427,7 +429,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
   const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
-  uint32_t* visits = STAGE ? l_vis : visit_ws + job.visit_off;
+  typedef typename std::conditional<STAGE, uint16_t, uint32_t>::type vis_t;
+  vis_t* visits = STAGE ? reinterpret_cast<vis_t*>(l_vis) : reinterpret_cast<vis_t*>(visit_ws + job.visit_off);
   const int pcap = (int)job.path_cap;
   while (true) {
     if (tb_done) break;
@@ -453,7 +456,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         if (kind == 1) {  // MotifStart + implied leading deletions (events.rs:42-48)
           const int dels = nxt - state - 1;
           edit += dels; ref += dels;
-          visits[3 * nv + 0] = (uint32_t)blk; visits[3 * nv + 1] = (uint32_t)idx; visits[3 * nv + 2] = (uint32_t)vb1;
+          visits[3 * nv + 0] = (vis_t)blk; visits[3 * nv + 1] = (vis_t)idx; visits[3 * nv + 2] = (vis_t)vb1;
           ++nv;
         } else if (kind == 2) {
           vb1 = idx;  // bases of this visit are query[.. idx)
@@ -547,7 +550,7 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb, uint32_t stage_qcap) {
   size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
-  if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * ((size_t)stage_qcap + 3) + 4 * (size_t)nb;
+  if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 2 * ((3 * ((size_t)stage_qcap + 3) + 1) & ~(size_t)1) + 4 * (size_t)nb;
   return o + 64;
 }
 
