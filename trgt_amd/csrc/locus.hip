@@ -613,7 +613,19 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   }
   return TRGT_OK;
   };
-  if ((rc = hmm1_enqueue())) return rc;
+  // (enqueued from the callback below when there are consensus alignments: its ~0.7 ms of host work then runs next to that kernel
+  //  instead of in front of the host path that leads to it)
+  bool hmm1_done = false;
+  auto hmm1_once = [&]() -> int {  // on the first stream, whichever stream is current
+    if (hmm1_done) return TRGT_OK;
+    hmm1_done = true;
+    const bool swapped = c->stream == upload_stream;
+    if (swapped) std::swap(c->stream, c->stream2);
+    const int r = hmm1_enqueue();
+    if (swapped) std::swap(c->stream, c->stream2);
+    return r;
+  };
+  if (nR == 0 && (rc = hmm1_once())) return rc;
   if (dev_gt || (n_seg > 0 && reads_on_device)) TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));  // gathered segments, packed alleles
   tHost += now_ns() - th_begin;
   TL("stream2 synced");
@@ -713,12 +725,15 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         }
       }
     PackedCigars pcig;
-    if (jrefs.empty() && !published && (rc = publish())) return rc;
+    if (jrefs.empty() && ((rc = hmm1_once()) || (!published && (rc = publish())))) return rc;
     if (!jrefs.empty()) {
       trgt_wfa_params wp;
       trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
       wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
-      const std::function<int()> overlap = [&]() -> int { return publish(); };  // host-only work next to the alignment kernel
+      const std::function<int()> overlap = [&]() -> int {  // next to the alignment kernel: start the HMM batch, publish results
+        const int r = hmm1_once();
+        return r ? r : publish();
+      };
       rc = wfa_batch_impl(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pcig, &overlap);
       if (rc) return rc;
@@ -821,6 +836,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
     tC += now_ns() - tc0;
   }
+  if ((rc = hmm1_once())) return rc;
   if (!published && (rc = publish())) return rc;
   // ---------------- stage C results of the device-genotyped loci
   TL("hmm2 enqueued");
