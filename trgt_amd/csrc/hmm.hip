@@ -736,7 +736,6 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   if ((rc = dev_get(c, S_HMM_JOBS + so, jobs.size() * sizeof(HmmJobDev), &d_jobs))) return rc;
   if ((rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp))) return rc;
   if ((rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits))) return rc;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
   // Spans: when the caller's buffer is host memory the kernel writes a tight per-job layout on the device and only the
   // spans actually produced are copied back (packed); a device buffer is written in the caller's layout directly.
@@ -750,7 +749,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     tight_off.resize((size_t)n_jobs);
     for (int64_t j = 0; j < n_jobs; ++j) { tight_off[(size_t)j] = tight_total; tight_total += (uint64_t)seq_len[j] + 1; }
     for (auto& jd : jobs) jd.span_off = tight_off[jd.job_index];
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
+  }
+  {  // the job list goes up once, from pinned memory (a pageable source makes the "async" copy a blocking staged one)
+    void* h_jobs = nullptr;
+    if ((rc = pin_get(c, buffer_set ? P_HMM_JOBS_B : P_HMM_JOBS, jobs.size() * sizeof(HmmJobDev), &h_jobs))) return rc;
+    std::memcpy(h_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
   }
   if ((rc = o_path.init(c, S_HMM_PATH + so, path, (size_t)path_total))) return rc;
   if ((rc = o_plen.init(c, S_HMM_PLEN + so, path_len, (size_t)n_jobs))) return rc;
