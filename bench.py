@@ -134,10 +134,13 @@ def main():
     ctx.timing_reset()
     fence()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(args.steps):
         step()
+        marks.append(time.perf_counter())  # (a call is synchronous: no extra synchronisation is added inside the timed region)
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))
     ctx.timing_enable(False)
     dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
 
@@ -176,6 +179,7 @@ def main():
         res = {
             "metric": "loci/s", "value": round(world * args.loci * args.steps / dt, 1), "unit": "loci/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+            "ms_per_step_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16+u8 (WFA), f64 (HMM)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic single-motif STR loci per GPU (motif 3-6 bp, allele <= 200 bp), "
