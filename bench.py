@@ -53,33 +53,18 @@ def cpu_baseline(batch, seconds_budget=15.0, max_loci=4000):
                 sample="first %d loci of the same synthetic batch, oracle/liboracle.so (C++ restatement), 1 thread, %.1f s" % (done, dt))
 
 
-def cpu_baseline_mt(batch, threads, max_loci=8000):
-    """The same oracle over a static locus partition on `threads` host threads (ctypes drops the GIL inside the C call).
-    Reported next to the single-thread figure; it is still the C++ restatement, not the reference binary."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline_mt(batch, threads):
+    """The same oracle on `threads` native host threads (orc_locus_analyze_many, dynamic chunks of loci: the reference runs one
+    rayon task per locus).  Reported next to the single-thread figure; it is still the C++ restatement, not the reference binary."""
     from oracle import binding as orc
     orc.lib()
-    n = min(int(batch["n_loci"]), max_loci)
-
-    def run(lo, hi):
-        for l in range(lo, hi):
-            a0, a1 = int(batch["locus_read_begin"][l]), int(batch["locus_read_begin"][l + 1])
-            reads = [bytes(batch["read_blob"][int(batch["read_off"][r]):int(batch["read_off"][r]) + int(batch["read_len"][r])])
-                     for r in range(a0, a1)]
-            lf = bytes(batch["flank_blob"][int(batch["lf_off"][l]):int(batch["lf_off"][l]) + int(batch["lf_len"][l])])
-            rf = bytes(batch["flank_blob"][int(batch["rf_off"][l]):int(batch["rf_off"][l]) + int(batch["rf_len"][l])])
-            tr = bytes(batch["tr_blob"][int(batch["tr_off"][l]):int(batch["tr_off"][l]) + int(batch["tr_len"][l])])
-            m0, m1 = int(batch["set_motif_begin"][l]), int(batch["set_motif_begin"][l + 1])
-            motifs = [bytes(batch["motif_blob"][int(batch["motif_off"][m]):int(batch["motif_off"][m + 1])]) for m in range(m0, m1)]
-            orc.locus_analyze(lf, rf, tr, motifs, reads)
-        return hi - lo
-
+    n = int(batch["n_loci"])
+    orc.locus_analyze_many(batch, 0, min(n, 4 * threads), threads)  # thread start-up, page faults
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        done = sum(ex.map(lambda t: run(n * t // threads, n * (t + 1) // threads), range(threads)))
+    done, _ = orc.locus_analyze_many(batch, 0, n, threads)
     dt = time.perf_counter() - t0
     return dict(value=round(done / dt, 2), unit="loci/s", cores=threads, kind="port",
-                sample="first %d loci of the same synthetic batch, oracle/liboracle.so, %d threads over a static locus partition (Python driver: the GIL outside the C call bounds the scaling), %.1f s" % (done, threads, dt))
+                sample="all %d loci of the same synthetic batch, oracle/liboracle.so, %d native threads pulling chunks of loci from a shared counter, %.1f s" % (done, threads, dt))
 
 
 def main():
@@ -132,6 +117,9 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.timing_reset()
+    import gc
+    gc.collect()
+    gc.disable()  # a generation-2 collection of the driver script's own objects showed up as a 30-40 ms pause in one call out of ~400
     fence()
     t0 = time.perf_counter()
     marks = [t0]
@@ -140,6 +128,7 @@ def main():
         marks.append(time.perf_counter())  # (a call is synchronous: no extra synchronisation is added inside the timed region)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     step_ms = sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))
     ctx.timing_enable(False)
     dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
@@ -204,7 +193,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(batch)
-            nthr = min(os.cpu_count() or 1, 32)
+            nthr = min(os.cpu_count() or 1, 128)
             if nthr > 1:
                 res["cpu_baseline_all_cores"] = cpu_baseline_mt(batch, nthr)
         print(json.dumps(res))

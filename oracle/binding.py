@@ -285,6 +285,20 @@ def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250,
                            n_purity=int(stats[6])))
 
 
+def locus_analyze_many(batch, first, n, threads, flank_len=250, min_flank_id_frac=0.7, max_depth=250, scoring=(2, 5, 1)):
+    """analyze_tr for loci [first, first + n) of a packed batch (trgt_amd.locus.pack / synth.generate layout) on `threads` native
+    threads.  Returns (loci analysed, alleles called)."""
+    p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], 2, 0, 0.98)
+    al = C.c_int64()
+    f = lib().orc_locus_analyze_many
+    f.restype = C.c_int64
+    done = f(C.byref(p), C.c_int64(first), C.c_int64(n), _p(batch["flank_blob"]), _p(batch["lf_off"]), _p(batch["lf_len"]), _p(batch["rf_off"]),
+             _p(batch["rf_len"]), _p(batch["tr_blob"]), _p(batch["tr_off"]), _p(batch["tr_len"]), _p(batch["motif_blob"]), _p(batch["motif_off"]),
+             _p(batch["set_motif_begin"]), _p(batch["locus_read_begin"]), _p(batch["read_blob"]), _p(batch["read_off"]), _p(batch["read_len"]),
+             int(threads), C.byref(al))
+    return int(done), int(al.value)
+
+
 def ward_linkage(dists, n):
     """kodama-style linkage(.., Method::Ward) on a condensed matrix.  Returns (steps[n-1,3] = cluster1, cluster2, size;
     dissimilarity[n-1]; the matrix as the call leaves it)."""

@@ -27,7 +27,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 
 namespace orc {
 
@@ -624,6 +626,53 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
   std::memcpy(ms, sms.c_str(), sms.size() + 1);
   std::memcpy(ap, sap.c_str(), sap.size() + 1);
   return finish();
+}
+
+
+// analyze_tr for loci [first, first + n) of a batch in the trgt_locus_batch_in layout, on n_threads std::threads pulling chunks of 8 loci
+// from a shared counter (the reference runs one rayon task per locus, genotype.rs:179-187).  Only counts what it did: returns the number of loci
+// analysed, *alleles_out receives the number of alleles called (a checksum that keeps the work alive).  cpu_baseline helper.
+int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+                               const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
+                               const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
+                               const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                               const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out) {
+  if (n_threads < 1) n_threads = 1;
+  std::vector<int64_t> alleles((size_t)n_threads * 8, 0), done((size_t)n_threads * 8, 0);
+  std::atomic<int64_t> next{0};
+  auto work = [&](int t) {
+    std::vector<int32_t> ss, se, kept, cls;
+    std::vector<char> a0, a1, mc(65536), ms(65536), ap(65536);
+    for (;;) {
+      const int64_t c0 = next.fetch_add(8);  // dynamic chunks of 8 loci
+      if (c0 >= n) break;
+    for (int64_t l = first + c0; l < first + std::min(n, c0 + 8); ++l) {
+      const uint64_t r0 = locus_read_begin[l], r1 = locus_read_begin[l + 1];
+      const int64_t nr = (int64_t)(r1 - r0);
+      uint32_t cap = 8;
+      for (uint64_t r = r0; r < r1; ++r) cap = std::max(cap, read_len[r] + 8);
+      ss.assign((size_t)nr + 1, 0); se.assign((size_t)nr + 1, 0); kept.assign((size_t)nr + 1, 0); cls.assign((size_t)nr + 1, 0);
+      a0.assign(cap, 0); a1.assign(cap, 0);
+      const uint32_t m0 = set_motif_begin[l], m1 = set_motif_begin[l + 1];
+      std::vector<uint32_t> mo(m1 - m0 + 1);
+      for (uint32_t m = m0; m <= m1; ++m) mo[m - m0] = motif_off[m] - motif_off[m0];
+      int32_t n_alleles = 0, n_sp = 0, gt_size[2], gt_ci[4], by_hap[2];
+      int64_t stats[8];
+      orc_locus_analyze(p, flank_blob + lf_off[l], (int)lf_len[l], flank_blob + rf_off[l], (int)rf_len[l], tr_blob + tr_off[l], (int)tr_len[l],
+                        motif_blob + motif_off[m0], mo.data(), (int)(m1 - m0), nr, read_blob, read_off + r0, read_len + r0, ss.data(), se.data(),
+                        &n_alleles, a0.data(), a1.data(), (int)cap, gt_size, gt_ci, &n_sp, kept.data(), cls.data(), by_hap, mc.data(), ms.data(),
+                        ap.data(), 65536, stats, nullptr);
+      alleles[(size_t)t * 8] += n_alleles; done[(size_t)t * 8] += 1;
+    }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+  for (auto& x : th) x.join();
+  int64_t total = 0, al = 0;
+  for (int t = 0; t < n_threads; ++t) { total += done[(size_t)t * 8]; al += alleles[(size_t)t * 8]; }
+  if (alleles_out) *alleles_out = al;
+  return total;
 }
 
 }  // extern "C"

@@ -157,6 +157,14 @@ int orc_locus_analyze(const orc_locus_params* p,
                       int64_t* stats /* [8]: wfa_cells, viterbi_cells, n_wfa_flank, n_wfa_cons, bytes_io, n_wfa_ed, n_purity */,
                       const double* read_qual);
 
+/* orc_locus_analyze over loci [first, first + n) of a batch in the trgt_locus_batch_in layout, on n_threads threads (static
+ * partition).  Returns the number of loci analysed; cpu_baseline helper of bench.py. */
+int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+                               const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
+                               const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
+                               const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                               const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out);
+
 /* Ward linkage as kodama 0.3.0's linkage(.., Method::Ward) performs it (PARITY UNPINNED, see locus.cpp): dists is
  * the condensed matrix, overwritten as kodama overwrites it.  Returns the number of steps (n-1). */
 int orc_ward_linkage(double* dists, int n, int32_t* steps3 /* cluster1, cluster2, size */, double* dissimilarity);
