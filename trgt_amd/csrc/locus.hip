@@ -276,7 +276,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
   if (2 * nr > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: too many reads in one call");
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-  threads = std::min(threads, 32);  // a few microseconds of work per locus: more threads only add wake-up cost
+  // a few microseconds of work per locus: more threads only add wake-up cost.  With the reads in HBM the device genotyper leaves the
+  // host little to do (4 threads measure the same as 32, and large pools produce the occasional late wake-up)
+  threads = std::min(threads, is_device_ptr(in->read_blob) && !getenv("TRGT_HOST_GENOTYPER") ? 8 : 32);
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
