@@ -94,7 +94,8 @@ def main():
     from trgt_amd import _lib, locus, shard, synth
 
     # ---- synthetic shard of this rank (untimed)
-    host_threads = args.host_threads or max(1, (os.cpu_count() or 8) // max(1, world))
+    # host threads for the glue between the GPU stages; the library uses at most 8 of them when the reads are resident in HBM
+    host_threads = min(8, args.host_threads or max(1, (os.cpu_count() or 8) // max(1, world)))
     batch = synth.generate(args.loci, first_locus=rank * args.loci, config=2)
     reads_dev = torch.from_numpy(batch["read_blob"]).cuda()
     flank_dev = torch.from_numpy(batch["flank_blob"]).cuda()
