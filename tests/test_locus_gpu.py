@@ -14,11 +14,18 @@ def mods():
 
 
 def _run_both(locus, b, params=None):
-    """trgt_locus_batch with the reads on the host (host glue path) and resident in HBM (device genotyper + host path for the
-    loci it hands back); both must give the oracle's results."""
+    """trgt_locus_batch three ways -- host glue for every locus (TRGT_HOST_GENOTYPER), reads on the host with the device genotyper
+    working on the uploaded copy, reads resident in HBM -- all must give the oracle's results."""
+    import os
     import torch
     params = params or locus.Params()
-    yield "host", locus.run_batch(b, params)
+    os.environ["TRGT_HOST_GENOTYPER"] = "1"
+    try:
+        out = locus.run_batch(b, params)
+    finally:
+        del os.environ["TRGT_HOST_GENOTYPER"]
+    yield "host glue", out
+    yield "host reads", locus.run_batch(b, params)
     reads_dev = torch.from_numpy(b["read_blob"]).cuda()
     flank_dev = torch.from_numpy(b["flank_blob"]).cuda()
     yield "device", locus.run_batch(b, params, flank_dev=flank_dev, reads_dev=reads_dev)

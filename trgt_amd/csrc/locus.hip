@@ -276,9 +276,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
   if (2 * nr > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: too many reads in one call");
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-  // a few microseconds of work per locus: more threads only add wake-up cost.  With the reads in HBM the device genotyper leaves the
+  // a few microseconds of work per locus: more threads only add wake-up cost.  The device genotyper leaves the
   // host little to do (4 threads measure the same as 32, and large pools produce the occasional late wake-up)
-  threads = std::min(threads, is_device_ptr(in->read_blob) && !getenv("TRGT_HOST_GENOTYPER") ? 8 : 32);
+  threads = std::min(threads, !getenv("TRGT_HOST_GENOTYPER") && p->min_read_qual >= 0.9 ? 8 : 32);
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
@@ -350,7 +350,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const bool reads_on_device = is_device_ptr(in->read_blob);
   // filter_impure_trs (tr.rs:37-50) sits between get_spanning_reads and the genotyper: with it on, every locus takes the host path
   const bool impure_filter = p->min_read_qual < 0.9;
-  const bool dev_gt = reads_on_device && !getenv("TRGT_HOST_GENOTYPER") && !impure_filter;
+  // (host reads are uploaded for the flank scan anyway: the device genotyper then works on that copy just as well)
+  const bool dev_gt = !getenv("TRGT_HOST_GENOTYPER") && !impure_filter;
   auto is_cluster = [&](int64_t l) { return in->genotyper && in->genotyper[l] == 1; };
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
