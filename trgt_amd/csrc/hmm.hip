@@ -707,7 +707,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
   // class 0: at most 32 states (two alleles per wave); else the number of waves per allele; odd = allele too long for LDS staging
   auto job_class = [&](const HmmJobDev& j) { const uint32_t S_ = sets[j.set].S; return 2u * (S_ <= 32 ? 0u : (S_ + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
-  std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
+  {  // (usually one class: skip the sort then)
+    bool mixed = false;
+    const uint32_t c0 = job_class(jobs[0]);
+    for (const auto& jd : jobs) if (job_class(jd) != c0) { mixed = true; break; }
+    if (mixed) std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
+  }
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
   int rc;
