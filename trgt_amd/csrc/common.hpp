@@ -92,7 +92,7 @@ enum Slot {
   S_COUNT
 };
 // pinned host buffer slots
-enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_HMM_SEQ_B, P_HMM_JOBS, P_HMM_JOBS_B, P_SEG0, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
+enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_HMM_SEQ_B, P_HMM_JOBS, P_HMM_JOBS_B, P_SEG0, P_SEG_META, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
                P_GT_RANK, P_GT_NSPAN, P_GT_TOFF, P_GT_PACKED, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {

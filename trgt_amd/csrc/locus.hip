@@ -366,12 +366,27 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
       (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen)) ||
       (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc)) ||
       (rc = dev_in(c, S_FS_HEAVY, heavy_len.data(), (size_t)nl, &d_heavy)) ||
-      (rc = dev_get(c, S_LOCUS_4, (size_t)nr * 4, &d_ss)) || (rc = dev_get(c, S_LOCUS_5, (size_t)nr * 4, &d_se)) ||
-      (rc = dev_get(c, S_FS_HIT0, (size_t)nr, &d_hl)) || (rc = dev_get(c, S_FS_HIT1, (size_t)nr, &d_hr)) ||
-      (rc = pin_get(c, P_SPAN_S, (size_t)nr * 4, &h_ss)) || (rc = pin_get(c, P_SPAN_E, (size_t)nr * 4, &h_se)) ||
-      (rc = pin_get(c, P_HIT_L, (size_t)nr, &h_hl)) || (rc = pin_get(c, P_HIT_R, (size_t)nr, &h_hr)) ||
       (rc = pin_get(c, P_CELLS, 64, &h_cells)))
     return rc;
+  // Everything stage A hands back to the host lives in ONE device slab mirrored by ONE pinned slab, so that it comes back in a single
+  // copy: fourteen separate hipMemcpyAsync D2H cost the host 0.3 ms of completion handling right after the event wait.
+  struct Slab {
+    size_t total = 0;
+    size_t add(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
+  } slab;
+  const size_t o_ss = slab.add((size_t)nr * 4), o_se = slab.add((size_t)nr * 4), o_hl = slab.add((size_t)nr), o_hr = slab.add((size_t)nr);
+  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0;
+  if (dev_gt) {
+    o_need = slab.add((size_t)nl); o_nal = slab.add((size_t)nl * 4); o_alen = slab.add(2 * (size_t)nl * 4); o_ci = slab.add(4 * (size_t)nl * 4);
+    o_nsp = slab.add(2 * (size_t)nl * 4); o_cls = slab.add((size_t)nr * 4); o_rank = slab.add((size_t)nr * 4); o_nspan = slab.add((size_t)nl * 4);
+    o_toff = slab.add((2 * (size_t)nl + 1) * 8);
+  }
+  void *d_slab = nullptr, *h_slab = nullptr;
+  if ((rc = dev_get(c, S_LOCUS_4, slab.total, &d_slab)) || (rc = pin_get(c, P_SPAN_S, slab.total, &h_slab))) return rc;
+  auto dsl = [&](size_t o) { return (void*)((uint8_t*)d_slab + o); };
+  auto hsl = [&](size_t o) { return (void*)((uint8_t*)h_slab + o); };
+  d_ss = dsl(o_ss); d_se = dsl(o_se); d_hl = dsl(o_hl); d_hr = dsl(o_hr);
+  h_ss = hsl(o_ss); h_se = hsl(o_se); h_hl = hsl(o_hl); h_hr = hsl(o_hr);
   // device genotyper: inputs it needs beyond stage A's, and its outputs (device + pinned mirrors)
   struct GtDev {
     const uint64_t* lrb = nullptr; const uint8_t* ploidy = nullptr; const uint8_t* tr = nullptr; const uint64_t* tr_off = nullptr;
@@ -385,18 +400,12 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         (rc = dev_in(c, S_GT_TR, in->tr_blob, (size_t)tr_total, &g.tr)) || (rc = dev_in(c, S_GT_TROFF, in->tr_off, (size_t)nl, &g.tr_off)) ||
         (rc = dev_in(c, S_GT_TRLEN, in->tr_len, (size_t)nl, &g.tr_len)) || (rc = dev_in(c, S_GT_ALOFF, out->allele_off, 2 * (size_t)nl, &g.al_off)) ||
         (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap)) ||
-        (rc = dev_get(c, S_GT_NEED, (size_t)nl, &g.need)) || (rc = dev_get(c, S_GT_NAL, (size_t)nl * 4, &g.nal)) ||
-        (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_ALEN, 2 * (size_t)nl * 4, &g.alen)) ||
-        (rc = dev_get(c, S_GT_CI, 4 * (size_t)nl * 4, &g.ci)) || (rc = dev_get(c, S_GT_NSP, 2 * (size_t)nl * 4, &g.nsp)) ||
-        (rc = dev_get(c, S_GT_CLS, (size_t)nr * 4, &g.cls)) || (rc = dev_get(c, S_GT_RANK, (size_t)nr * 4, &g.rank)) ||
-        (rc = dev_get(c, S_GT_NSPAN, (size_t)nl * 4, &g.nspan)) || (rc = dev_get(c, S_GT_TOFF, (2 * (size_t)nl + 1) * 8, &g.toff)) ||
-        (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)) ||
-        (rc = pin_get(c, P_GT_NEED, (size_t)nl, &gh.need)) || (rc = pin_get(c, P_GT_NAL, (size_t)nl * 4, &gh.nal)) ||
-        (rc = pin_get(c, P_GT_ALEN, 2 * (size_t)nl * 4, &gh.alen)) || (rc = pin_get(c, P_GT_CI, 4 * (size_t)nl * 4, &gh.ci)) ||
-        (rc = pin_get(c, P_GT_NSP, 2 * (size_t)nl * 4, &gh.nsp)) || (rc = pin_get(c, P_GT_CLS, (size_t)nr * 4, &gh.cls)) ||
-        (rc = pin_get(c, P_GT_RANK, (size_t)nr * 4, &gh.rank)) || (rc = pin_get(c, P_GT_NSPAN, (size_t)nl * 4, &gh.nspan)) ||
-        (rc = pin_get(c, P_GT_TOFF, (2 * (size_t)nl + 1) * 8, &gh.toff)))
+        (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)))
       return rc;
+    g.need = dsl(o_need); g.nal = dsl(o_nal); g.alen = dsl(o_alen); g.ci = dsl(o_ci); g.nsp = dsl(o_nsp); g.cls = dsl(o_cls); g.rank = dsl(o_rank);
+    g.nspan = dsl(o_nspan); g.toff = dsl(o_toff);
+    gh.need = hsl(o_need); gh.nal = hsl(o_nal); gh.alen = hsl(o_alen); gh.ci = hsl(o_ci); gh.nsp = hsl(o_nsp); gh.cls = hsl(o_cls); gh.rank = hsl(o_rank);
+    gh.nspan = hsl(o_nspan); gh.toff = hsl(o_toff);
   }
   c->dbg_ns[1] = now_ns() - t0;  // + uploads of the offset tables, buffer (re)allocation
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
@@ -407,10 +416,6 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(h_ss, d_ss, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(h_se, d_se, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(h_hl, d_hl, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(h_hr, d_hr, (size_t)nr, hipMemcpyDeviceToHost, c->stream));
   if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
   if (dev_gt) {
     gt::GtArgs ga;
@@ -428,16 +433,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
     TRGT_HIP_TRY(c, hipGetLastError());
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.need, g.need, (size_t)nl, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nal, g.nal, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.alen, g.alen, 2 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.ci, g.ci, 4 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nsp, g.nsp, 2 * (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.cls, g.cls, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.rank, g.rank, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.nspan, g.nspan, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(gh.toff, g.toff, (2 * (size_t)nl + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   }
+  TRGT_HIP_TRY(c, hipMemcpyAsync(h_slab, d_slab, slab.total, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipEventRecord(evA, c->stream));
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
   init_outputs();  // host-only work: done while the GPU is already busy
@@ -462,6 +459,26 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const int32_t* const sp_s = (const int32_t*)h_ss; const int32_t* const sp_e = (const int32_t*)h_se;  // spans (pinned copies)
   // host path, first part: spanning reads of the loci in R and the gather of their repeat segments (second stream), enqueued
   // before anything else so that it does not have to share the GPU with the HMM batch below
+  TL("R listed");
+  // job lists of stage C for the device-genotyped loci: host-only work, done first because HIP calls made in the ~0.3 ms after the
+  // event wait returns block until the runtime has retired stage A's commands
+  std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
+  std::vector<uint32_t> nsp; std::vector<double> pur;
+  if (dev_gt) {
+    const uint8_t* need = (const uint8_t*)gh.need;
+    const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
+    job_set.reserve(2 * (size_t)nl); seq_off.reserve(2 * (size_t)nl); seq_len.reserve(2 * (size_t)nl); span_off.reserve(2 * (size_t)nl);
+    count_off.reserve(2 * (size_t)nl); slot.reserve(2 * (size_t)nl);
+    for (int64_t l = 0; l < nl; ++l) {
+      if (need[l]) continue;
+      stat_spanning += ((const uint32_t*)gh.nspan)[l];
+      for (int a = 0; a < nal[l]; ++a) {
+        job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(alen[2 * l + a]);
+        span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
+      }
+    }
+    TL("hmm1 job lists");
+  }
   std::vector<LocusWork> work((size_t)nR);
   struct K { uint32_t read, s, e; };
   std::vector<uint64_t> sel_begin((size_t)nR + 1, 0);
@@ -544,6 +561,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
         n_sel[(size_t)li] = m;
       });
     }
+    TL("R pass 1");
     // pass 2: flat segment arrays (LocusResult.reads order within each locus)
     for (int64_t li = 0; li < nR; ++li) { work[(size_t)li].seg_begin = n_seg; n_seg += n_sel[(size_t)li]; work[(size_t)li].seg_end = n_seg; }
     seg_src.resize((size_t)n_seg); seg_dst.resize((size_t)n_seg); seg_len.resize((size_t)n_seg); seg_read.resize((size_t)n_seg); seg_ptr.resize((size_t)n_seg);
@@ -557,18 +575,24 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     for (uint64_t s = 0; s < n_seg; ++s) { seg_dst[s] = seg_bytes; seg_bytes += seg_len[s]; }
     stat_spanning += (int64_t)n_seg;
     c->dbg_ns[4] = now_ns() - th0;
+    TL("R pass 2");
     if (n_seg > 0 && reads_on_device) {
-      void *d_src, *d_dst, *d_len, *d_out;
-      if ((rc = dev_get(c, S_LOCUS_0, (size_t)n_seg * 8, &d_src)) || (rc = dev_get(c, S_LOCUS_1, (size_t)n_seg * 8, &d_dst)) ||
-          (rc = dev_get(c, S_LOCUS_2, (size_t)n_seg * 4, &d_len)) || (rc = dev_get(c, S_LOCUS_3, (size_t)seg_bytes + 1, &d_out)) ||
-          (rc = pin_get(c, P_SEG0, (size_t)seg_bytes + 1, &h_seg)))
+      // source offsets, destination offsets and lengths: the gather kernel reads them straight from pinned host memory (20 B per
+      // segment over PCIe).  A hipMemcpyAsync of them took 0.37 ms on the host however small it was.
+      void *d_out, *h_meta;
+      const size_t meta_bytes = (size_t)n_seg * 20;
+      if ((rc = dev_get(c, S_LOCUS_3, (size_t)seg_bytes + 1, &d_out)) ||
+          (rc = pin_get(c, P_SEG0, (size_t)seg_bytes + 1, &h_seg)) || (rc = pin_get(c, P_SEG_META, meta_bytes, &h_meta)))
         return rc;
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, seg_src.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, c->stream2));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, seg_dst.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, c->stream2));
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_len, seg_len.data(), (size_t)n_seg * 4, hipMemcpyHostToDevice, c->stream2));
+      std::memcpy(h_meta, seg_src.data(), (size_t)n_seg * 8);
+      std::memcpy((uint8_t*)h_meta + (size_t)n_seg * 8, seg_dst.data(), (size_t)n_seg * 8);
+      std::memcpy((uint8_t*)h_meta + (size_t)n_seg * 16, seg_len.data(), (size_t)n_seg * 4);
+      TL("R meta staged");
+      void* const d_src = h_meta; void* const d_dst = (uint8_t*)h_meta + (size_t)n_seg * 8; void* const d_len = (uint8_t*)h_meta + (size_t)n_seg * 16;
       GatherArgs ga{d_reads, (const uint64_t*)d_src, (const uint64_t*)d_dst, (const uint32_t*)d_len, (uint64_t)n_seg, (uint8_t*)d_out};
       hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream2, ga);
       TRGT_HIP_TRY(c, hipGetLastError());
+      TL("R gather launched");
       TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)seg_bytes, hipMemcpyDeviceToHost, c->stream2));
     }
   }
@@ -583,24 +607,9 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   // publishing of spans and device-genotyper results: host work of ~1.2 ms that needs the GPU only to start the HMM batch.  It runs
   // while the consensus alignments of the host-path loci are on the GPU (wfa_batch_impl calls it between launch and wait), or
   // right here when there are none.
-  std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
-  std::vector<uint32_t> nsp; std::vector<double> pur;
   bool published = false;
   auto hmm1_enqueue = [&]() -> int {
   if (dev_gt) {
-    const uint8_t* need = (const uint8_t*)gh.need;
-    const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
-    job_set.reserve(2 * (size_t)nl); seq_off.reserve(2 * (size_t)nl); seq_len.reserve(2 * (size_t)nl); span_off.reserve(2 * (size_t)nl);
-    count_off.reserve(2 * (size_t)nl); slot.reserve(2 * (size_t)nl);
-    for (int64_t l = 0; l < nl; ++l) {
-      if (need[l]) continue;
-      stat_spanning += ((const uint32_t*)gh.nspan)[l];
-      for (int a = 0; a < nal[l]; ++a) {
-        job_set.push_back((uint32_t)l); seq_off.push_back(out->allele_off[2 * l + a]); seq_len.push_back(alen[2 * l + a]);
-        span_off.push_back(out->span_off[2 * l + a]); count_off.push_back(out->count_off[2 * l + a]); slot.push_back(2 * l + a);
-      }
-    }
-    TL("hmm1 job lists");
     if (!job_set.empty()) {
       nsp.resize(job_set.size()); pur.resize(job_set.size());
       if (model_thread.joinable()) model_thread.join();
