@@ -299,6 +299,24 @@ def locus_analyze_many(batch, first, n, threads, flank_len=250, min_flank_id_fra
     return int(done), int(al.value)
 
 
+def locus_records(batch, first, n, threads, stride=16384, flank_len=250, min_flank_id_frac=0.7, max_depth=250, scoring=(2, 5, 1),
+                  min_read_qual=0.98):
+    """analyze_tr for loci [first, first + n) of a packed batch; one text record per locus (see oracle.h) for whole-catalog
+    comparisons against trgt_locus_batch (tests/tools/parity_sweep.py, trgt_amd-independent)."""
+    p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], 2, 0, min_read_qual)
+    blob = C.create_string_buffer(int(n) * int(stride))
+    f = lib().orc_locus_analyze_records
+    f.restype = C.c_int64
+    gt = batch.get("genotyper")
+    done = f(C.byref(p), C.c_int64(first), C.c_int64(n), _p(batch["flank_blob"]), _p(batch["lf_off"]), _p(batch["lf_len"]), _p(batch["rf_off"]),
+             _p(batch["rf_len"]), _p(batch["tr_blob"]), _p(batch["tr_off"]), _p(batch["tr_len"]), _p(batch["motif_blob"]), _p(batch["motif_off"]),
+             _p(batch["set_motif_begin"]), _p(batch["locus_read_begin"]), _p(batch["read_blob"]), _p(batch["read_off"]), _p(batch["read_len"]),
+             int(threads), _p(gt) if gt is not None else None, _p(batch["ploidy"]), blob, C.c_uint64(stride))
+    assert done == n, (done, n)
+    raw = blob.raw
+    return [raw[i * stride:raw.index(b"\0", i * stride)].decode() for i in range(int(n))]
+
+
 def ward_linkage(dists, n):
     """kodama-style linkage(.., Method::Ward) on a condensed matrix.  Returns (steps[n-1,3] = cluster1, cluster2, size;
     dissimilarity[n-1]; the matrix as the call leaves it)."""

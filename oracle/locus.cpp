@@ -632,11 +632,15 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
 // analyze_tr for loci [first, first + n) of a batch in the trgt_locus_batch_in layout, on n_threads std::threads pulling chunks of 8 loci
 // from a shared counter (the reference runs one rayon task per locus, genotype.rs:179-187).  Only counts what it did: returns the number of loci
 // analysed, *alleles_out receives the number of alleles called (a checksum that keeps the work alive).  cpu_baseline helper.
-int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+// One text record per locus (NUL-terminated, `rec_stride` bytes apart) for whole-catalog parity sweeps (tests/tools/parity_sweep.py):
+//   S:<span_start>,<span_end>;...|A:<allele>,<allele>|K:<kept read indices>|C:<classification>|ALLR:..|SD:..|MC:..|MS:..|AP:..
+// `genotyper` (one byte per locus, may be NULL) selects size (0) / cluster (1) like Locus::genotyper.
+static int64_t analyze_many_impl(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
                                const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
                                const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
                                const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
-                               const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out) {
+                               const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out,
+                               const uint8_t* genotyper, const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride) {
   if (n_threads < 1) n_threads = 1;
   std::vector<int64_t> alleles((size_t)n_threads * 8, 0), done((size_t)n_threads * 8, 0);
   std::atomic<int64_t> next{0};
@@ -658,11 +662,33 @@ int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t
       for (uint32_t m = m0; m <= m1; ++m) mo[m - m0] = motif_off[m] - motif_off[m0];
       int32_t n_alleles = 0, n_sp = 0, gt_size[2], gt_ci[4], by_hap[2];
       int64_t stats[8];
-      orc_locus_analyze(p, flank_blob + lf_off[l], (int)lf_len[l], flank_blob + rf_off[l], (int)rf_len[l], tr_blob + tr_off[l], (int)tr_len[l],
+      orc_locus_params pl = *p;
+      if (genotyper) pl.genotyper = genotyper[l];
+      if (ploidy) pl.ploidy = ploidy[l];
+      orc_locus_analyze(&pl, flank_blob + lf_off[l], (int)lf_len[l], flank_blob + rf_off[l], (int)rf_len[l], tr_blob + tr_off[l], (int)tr_len[l],
                         motif_blob + motif_off[m0], mo.data(), (int)(m1 - m0), nr, read_blob, read_off + r0, read_len + r0, ss.data(), se.data(),
                         &n_alleles, a0.data(), a1.data(), (int)cap, gt_size, gt_ci, &n_sp, kept.data(), cls.data(), by_hap, mc.data(), ms.data(),
                         ap.data(), 65536, stats, nullptr);
       alleles[(size_t)t * 8] += n_alleles; done[(size_t)t * 8] += 1;
+      if (rec_blob) {
+        std::string r = "S:";
+        for (int64_t i = 0; i < nr; ++i) { r += std::to_string(ss[(size_t)i]); r += ','; r += std::to_string(se[(size_t)i]); r += ';'; }
+        r += "|A:";
+        if (n_alleles > 0) r += a0.data();
+        if (n_alleles > 1) { r += ','; r += a1.data(); }
+        r += "|K:";
+        for (int32_t i = 0; i < n_sp; ++i) { r += std::to_string(kept[(size_t)i]); r += ','; }
+        r += "|C:";
+        for (int32_t i = 0; i < n_sp; ++i) { r += std::to_string(cls[(size_t)i]); r += ','; }
+        r += "|ALLR:";
+        for (int32_t a = 0; a < n_alleles; ++a) { r += std::to_string(gt_ci[2 * a]); r += '-'; r += std::to_string(gt_ci[2 * a + 1]); r += ','; }
+        r += "|SD:";
+        for (int32_t a = 0; a < n_alleles; ++a) { r += std::to_string(by_hap[a]); r += ','; }
+        if (n_alleles > 0) { r += "|MC:"; r += mc.data(); r += "|MS:"; r += ms.data(); r += "|AP:"; r += ap.data(); }
+        char* dst = rec_blob + (uint64_t)(l - first) * rec_stride;
+        if (r.size() + 1 > rec_stride) r = "OVERFLOW";
+        std::memcpy(dst, r.c_str(), r.size() + 1);
+      }
     }
     }
   };
@@ -673,6 +699,25 @@ int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t
   for (int t = 0; t < n_threads; ++t) { total += done[(size_t)t * 8]; al += alleles[(size_t)t * 8]; }
   if (alleles_out) *alleles_out = al;
   return total;
+}
+
+int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+                               const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
+                               const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
+                               const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                               const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out) {
+  return analyze_many_impl(p, first, n, flank_blob, lf_off, lf_len, rf_off, rf_len, tr_blob, tr_off, tr_len, motif_blob, motif_off, set_motif_begin,
+                           locus_read_begin, read_blob, read_off, read_len, n_threads, alleles_out, nullptr, nullptr, nullptr, 0);
+}
+
+int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+                                  const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
+                                  const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
+                                  const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                                  const uint64_t* read_off, const uint32_t* read_len, int n_threads, const uint8_t* genotyper,
+                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride) {
+  return analyze_many_impl(p, first, n, flank_blob, lf_off, lf_len, rf_off, rf_len, tr_blob, tr_off, tr_len, motif_blob, motif_off, set_motif_begin,
+                           locus_read_begin, read_blob, read_off, read_len, n_threads, nullptr, genotyper, ploidy, rec_blob, rec_stride);
 }
 
 }  // extern "C"

@@ -165,6 +165,16 @@ int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t
                                const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
                                const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out);
 
+/* The same walk, writing one text record per locus (NUL-terminated, rec_stride bytes apart; "OVERFLOW" if it does not fit):
+ *   S:<span_start>,<span_end>;..|A:<alleles>|K:<kept reads>|C:<classification>|ALLR:..|SD:..|MC:..|MS:..|AP:..
+ * genotyper / ploidy: one byte per locus, NULL = the values in *p.  Whole-catalog parity sweeps (tests/tools/parity_sweep.py). */
+int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
+                                  const uint32_t* lf_len, const uint64_t* rf_off, const uint32_t* rf_len, const uint8_t* tr_blob,
+                                  const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
+                                  const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
+                                  const uint64_t* read_off, const uint32_t* read_len, int n_threads, const uint8_t* genotyper,
+                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride);
+
 /* Ward linkage as kodama 0.3.0's linkage(.., Method::Ward) performs it (PARITY UNPINNED, see locus.cpp): dists is
  * the condensed matrix, overwritten as kodama overwrites it.  Returns the number of steps (n-1). */
 int orc_ward_linkage(double* dists, int n, int32_t* steps3 /* cluster1, cluster2, size */, double* dissimilarity);

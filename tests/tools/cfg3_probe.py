@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer helper: cfg3-like batch (long pathogenic-like alleles) through trgt_locus_batch: time per call and a parity spot check."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from trgt_amd import locus, synth
 from oracle import binding as orc

@@ -2,7 +2,7 @@
 """developer helper: cfg5 batch (compound / N motifs, cluster genotyper) through trgt_locus_batch: time per call, stage split,
 kernel times, and the oracle's single-thread rate on the first loci."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from trgt_amd import locus, synth, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -20,7 +20,7 @@ for i in range(4):
           {k: round(ctx.timing_get(i_)[0], 2) for k, i_ in (("scan", 0), ("wfa", 1), ("hmm", 2), ("wfa_flank", 3))})
 if len(sys.argv) > 3:
     from oracle import binding as orc
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     t0 = time.perf_counter()
     m = int(sys.argv[3])
     lrb = b["locus_read_begin"]

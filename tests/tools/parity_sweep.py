@@ -1,0 +1,71 @@
+"""Whole-catalog parity sweep: every locus of a synthetic catalog through trgt_locus_batch (reads resident in HBM) and through the
+CPU oracle (all host cores), compared field by field as text records -- spans of every read, allele sequences, kept reads and their
+classification, ALLR, SD, MC, MS, AP.  A developer tool (minutes of host time for 10^5..10^6 loci), not part of the test suite:
+the suite holds the full-size batch to a seeded sample plus size-independent properties (tests/test_full_size_gpu.py).
+
+    python tests/tests/tools/parity_sweep.py <config> <n_loci> [first_locus] [chunk]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from trgt_amd import locus, synth, _lib
+from oracle import binding as oracle
+
+
+def gpu_records(b, out):
+    nl = int(b["n_loci"])
+    lrb = b["locus_read_begin"]
+    recs = []
+    for l in range(nl):
+        a0, a1 = int(lrb[l]), int(lrb[l + 1])
+        r = locus.locus_result(b, out, l)
+        s = "S:" + "".join("%d,%d;" % (int(x), int(y)) for x, y in zip(out.span_start[a0:a1], out.span_end[a0:a1]))
+        s += "|A:" + ",".join(a.seq.decode() for a in r.genotype)
+        s += "|K:" + "".join("%d," % i for i in r.reads)
+        s += "|C:" + "".join("%d," % c for c in r.classification)
+        s += "|ALLR:" + "".join("%d-%d," % a.ci for a in r.genotype)
+        s += "|SD:" + "".join("%d," % a.num_spanning for a in r.genotype)
+        if r.genotype:
+            f = r.vcf_fields()
+            s += "|MC:" + f["MC"] + "|MS:" + f["MS"] + "|AP:" + f["AP"]
+        recs.append(s)
+    return recs
+
+
+def main():
+    config, n_total = int(sys.argv[1]), int(sys.argv[2])
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
+    threads = min(os.cpu_count() or 1, 128)
+    ctx = _lib.Context(0)
+    bad = n_done = n_alleles = 0
+    t_gpu = t_cpu = 0.0
+    for c0 in range(first, first + n_total, chunk):
+        n = min(chunk, first + n_total - c0)
+        b = synth.generate(n, first_locus=c0, config=config)
+        rd, fd = torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda()
+        t0 = time.perf_counter()
+        out = locus.run_batch(b, locus.Params(), ctx, flank_dev=fd, reads_dev=rd)
+        t_gpu += time.perf_counter() - t0
+        got = gpu_records(b, out)
+        t0 = time.perf_counter()
+        ref = oracle.locus_records(b, 0, n, threads)
+        t_cpu += time.perf_counter() - t0
+        for l, (g, r) in enumerate(zip(got, ref)):
+            if g != r:
+                bad += 1
+                if bad <= 5:
+                    print("MISMATCH locus %d\n  gpu    %s\n  oracle %s" % (c0 + l, g[:600], r[:600]))
+        n_done += n
+        n_alleles += int(out.n_alleles.sum())
+        print("[sweep] config %d loci %d..%d: %d mismatches so far (gpu %.2f s, oracle %.1f s on %d threads)" % (config, first, c0 + n, bad, t_gpu, t_cpu, threads), flush=True)
+    print("RESULT config=%d loci=%d alleles=%d mismatches=%d" % (config, n_done, n_alleles, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
