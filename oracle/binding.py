@@ -308,10 +308,13 @@ def locus_records(batch, first, n, threads, stride=16384, flank_len=250, min_fla
     f = lib().orc_locus_analyze_records
     f.restype = C.c_int64
     gt = batch.get("genotyper")
+    rq = batch.get("read_qual")
+    rq = None if rq is None else np.ascontiguousarray(rq, np.float64)
     done = f(C.byref(p), C.c_int64(first), C.c_int64(n), _p(batch["flank_blob"]), _p(batch["lf_off"]), _p(batch["lf_len"]), _p(batch["rf_off"]),
              _p(batch["rf_len"]), _p(batch["tr_blob"]), _p(batch["tr_off"]), _p(batch["tr_len"]), _p(batch["motif_blob"]), _p(batch["motif_off"]),
              _p(batch["set_motif_begin"]), _p(batch["locus_read_begin"]), _p(batch["read_blob"]), _p(batch["read_off"]), _p(batch["read_len"]),
-             int(threads), _p(gt) if gt is not None else None, _p(batch["ploidy"]), blob, C.c_uint64(stride))
+             int(threads), _p(gt) if gt is not None else None, _p(batch["ploidy"]), blob, C.c_uint64(stride),
+             _p(rq) if rq is not None else None)
     assert done == n, (done, n)
     raw = blob.raw
     return [raw[i * stride:raw.index(b"\0", i * stride)].decode() for i in range(int(n))]

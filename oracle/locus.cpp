@@ -640,7 +640,7 @@ static int64_t analyze_many_impl(const orc_locus_params* p, int64_t first, int64
                                const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
                                const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
                                const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out,
-                               const uint8_t* genotyper, const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride) {
+                               const uint8_t* genotyper, const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride, const double* read_qual) {
   if (n_threads < 1) n_threads = 1;
   std::vector<int64_t> alleles((size_t)n_threads * 8, 0), done((size_t)n_threads * 8, 0);
   std::atomic<int64_t> next{0};
@@ -668,7 +668,7 @@ static int64_t analyze_many_impl(const orc_locus_params* p, int64_t first, int64
       orc_locus_analyze(&pl, flank_blob + lf_off[l], (int)lf_len[l], flank_blob + rf_off[l], (int)rf_len[l], tr_blob + tr_off[l], (int)tr_len[l],
                         motif_blob + motif_off[m0], mo.data(), (int)(m1 - m0), nr, read_blob, read_off + r0, read_len + r0, ss.data(), se.data(),
                         &n_alleles, a0.data(), a1.data(), (int)cap, gt_size, gt_ci, &n_sp, kept.data(), cls.data(), by_hap, mc.data(), ms.data(),
-                        ap.data(), 65536, stats, nullptr);
+                        ap.data(), 65536, stats, read_qual ? read_qual + r0 : nullptr);
       alleles[(size_t)t * 8] += n_alleles; done[(size_t)t * 8] += 1;
       if (rec_blob) {
         std::string r = "S:";
@@ -707,7 +707,7 @@ int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t
                                const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
                                const uint64_t* read_off, const uint32_t* read_len, int n_threads, int64_t* alleles_out) {
   return analyze_many_impl(p, first, n, flank_blob, lf_off, lf_len, rf_off, rf_len, tr_blob, tr_off, tr_len, motif_blob, motif_off, set_motif_begin,
-                           locus_read_begin, read_blob, read_off, read_len, n_threads, alleles_out, nullptr, nullptr, nullptr, 0);
+                           locus_read_begin, read_blob, read_off, read_len, n_threads, alleles_out, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,
@@ -715,9 +715,9 @@ int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int6
                                   const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
                                   const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
                                   const uint64_t* read_off, const uint32_t* read_len, int n_threads, const uint8_t* genotyper,
-                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride) {
+                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride, const double* read_qual) {
   return analyze_many_impl(p, first, n, flank_blob, lf_off, lf_len, rf_off, rf_len, tr_blob, tr_off, tr_len, motif_blob, motif_off, set_motif_begin,
-                           locus_read_begin, read_blob, read_off, read_len, n_threads, nullptr, genotyper, ploidy, rec_blob, rec_stride);
+                           locus_read_begin, read_blob, read_off, read_len, n_threads, nullptr, genotyper, ploidy, rec_blob, rec_stride, read_qual);
 }
 
 }  // extern "C"

@@ -173,7 +173,8 @@ int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int6
                                   const uint64_t* tr_off, const uint32_t* tr_len, const uint8_t* motif_blob, const uint32_t* motif_off,
                                   const uint32_t* set_motif_begin, const uint64_t* locus_read_begin, const uint8_t* read_blob,
                                   const uint64_t* read_off, const uint32_t* read_len, int n_threads, const uint8_t* genotyper,
-                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride);
+                                  const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride,
+                                  const double* read_qual /* one per read of the batch (NaN = no rq tag), or NULL */);
 
 /* Ward linkage as kodama 0.3.0's linkage(.., Method::Ward) performs it (PARITY UNPINNED, see locus.cpp): dists is
  * the condensed matrix, overwritten as kodama overwrites it.  Returns the number of steps (n-1). */

@@ -37,9 +37,26 @@ def gpu_records(b, out):
 
 
 def main():
-    config, n_total = int(sys.argv[1]), int(sys.argv[2])
-    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
+    argv = list(sys.argv[1:])
+    host_reads = "--host-reads" in argv
+    host_glue = "--host-glue" in argv
+    argv = [a for a in argv if a not in ("--host-reads", "--host-glue")]
+    rq_min, depth = None, None
+    if "--rq" in argv:
+        i = argv.index("--rq"); rq_min = float(argv[i + 1]); del argv[i:i + 2]
+    if "--depth" in argv:
+        i = argv.index("--depth"); depth = int(argv[i + 1]); del argv[i:i + 2]
+    config, n_total = int(argv[0]), int(argv[1])
+    first = int(argv[2]) if len(argv) > 2 else 0
+    chunk = int(argv[3]) if len(argv) > 3 else 10000
+    if host_glue:
+        os.environ["TRGT_HOST_GENOTYPER"] = "1"
+    params = locus.Params()
+    okw = {}
+    if rq_min is not None:
+        params.min_read_qual = rq_min; okw["min_read_qual"] = rq_min
+    if depth is not None:
+        params.max_depth = depth; okw["max_depth"] = depth
     threads = min(os.cpu_count() or 1, 128)
     ctx = _lib.Context(0)
     bad = n_done = n_alleles = 0
@@ -47,13 +64,18 @@ def main():
     for c0 in range(first, first + n_total, chunk):
         n = min(chunk, first + n_total - c0)
         b = synth.generate(n, first_locus=c0, config=config)
-        rd, fd = torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda()
+        if rq_min is not None:  # rq tags: mostly high, some below the threshold, some missing
+            rng = np.random.default_rng(c0 + 17)
+            q = np.where(rng.random(int(b["n_reads"])) < 0.7, 0.99, 0.80 + 0.2 * rng.random(int(b["n_reads"])))
+            q[rng.random(int(b["n_reads"])) < 0.05] = np.nan
+            b["read_qual"] = np.ascontiguousarray(q, np.float64)
+        rd, fd = (None, None) if host_reads else (torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda())
         t0 = time.perf_counter()
-        out = locus.run_batch(b, locus.Params(), ctx, flank_dev=fd, reads_dev=rd)
+        out = locus.run_batch(b, params, ctx, flank_dev=fd, reads_dev=rd)
         t_gpu += time.perf_counter() - t0
         got = gpu_records(b, out)
         t0 = time.perf_counter()
-        ref = oracle.locus_records(b, 0, n, threads)
+        ref = oracle.locus_records(b, 0, n, threads, **okw)
         t_cpu += time.perf_counter() - t0
         for l, (g, r) in enumerate(zip(got, ref)):
             if g != r:
@@ -63,7 +85,8 @@ def main():
         n_done += n
         n_alleles += int(out.n_alleles.sum())
         print("[sweep] config %d loci %d..%d: %d mismatches so far (gpu %.2f s, oracle %.1f s on %d threads)" % (config, first, c0 + n, bad, t_gpu, t_cpu, threads), flush=True)
-    print("RESULT config=%d loci=%d alleles=%d mismatches=%d" % (config, n_done, n_alleles, bad))
+    print("RESULT config=%d loci=%d alleles=%d mismatches=%d%s%s%s%s" % (config, n_done, n_alleles, bad, " host-reads" if host_reads else "",
+          " host-glue" if host_glue else "", " min_read_qual=%g" % rq_min if rq_min is not None else "", " max_depth=%d" % depth if depth is not None else ""))
     return 1 if bad else 0
 
 
