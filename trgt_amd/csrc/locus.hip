@@ -347,6 +347,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     }
   }
   c->dbg_ns[0] = now_ns() - t0;  // set-up: thread pool, model thread, piece / read-locus tables
+  TL("set-up");
   const bool reads_on_device = is_device_ptr(in->read_blob);
   // filter_impure_trs (tr.rs:37-50) sits between get_spanning_reads and the genotyper: with it on, every locus takes the host path
   const bool impure_filter = p->min_read_qual < 0.9;
@@ -408,6 +409,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     gh.nspan = hsl(o_nspan); gh.toff = hsl(o_toff);
   }
   c->dbg_ns[1] = now_ns() - t0;  // + uploads of the offset tables, buffer (re)allocation
+  TL("tables uploaded, buffers ready");
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
   hipEvent_t evA = nullptr;
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
@@ -437,6 +439,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   TRGT_HIP_TRY(c, hipMemcpyAsync(h_slab, d_slab, slab.total, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipEventRecord(evA, c->stream));
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
+  TL("stage A enqueued");
   init_outputs();  // host-only work: done while the GPU is already busy
 
   // ---------------- wait for the GPU, publish spans
