@@ -593,7 +593,7 @@ struct Bi {
 WfaResult wfa_align(const orc_wfa_params& p, const uint8_t* pattern, int plen, const uint8_t* text, int tlen) {
   WfaResult r;
   if (p.memory_mode == 3) {  // MemoryUltraLow -> BiWFA (wavefront_bialign)
-    Bi b{p, pattern, text};
+    Bi b{p, pattern, text, std::string(), WF_COMPLETED, INT32_MIN, 0};
     if (p.scope == 0) b.score_only(plen, tlen);
     else {
       const bool min_length = std::max(plen, tlen) <= p.bialign_min_length;
