@@ -352,17 +352,20 @@ def test_cfg3_alleles_to_10kb(oracle, mods):
 
 def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     # the planner's choices must not show in the results: one launch instead of two for the flank alignments, the general
-    # instantiation of the dedicated kernel instead of the compile-time flank configuration, the host genotyper
+    # instantiation of the dedicated kernel instead of the compile-time flank configuration, the host genotyper, other numbers of
+    # waves per alignment
     import torch
     locus, synth = mods
     b = synth.generate(96, first_locus=12000)
     rd, fd = torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda()
     base = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
     _compare(oracle, locus, b, base, locus.Params(), range(0, 96, 4))
-    for env in ("TRGT_WFA_ONE_LAUNCH", "TRGT_WFA_NO_SPEC", "TRGT_HOST_GENOTYPER"):
-        monkeypatch.setenv(env, "1")
+    for env, val in (("TRGT_WFA_ONE_LAUNCH", "1"), ("TRGT_WFA_NO_SPEC", "1"), ("TRGT_HOST_GENOTYPER", "1"), ("TRGT_HEAVY_THREADS", "256"),
+                     ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192")):
+        monkeypatch.setenv(env, val)
         out = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
         monkeypatch.delenv(env)
+        env = env + "=" + val
         for f in ("span_start", "span_end", "n_alleles", "allele_len", "ci", "num_spanning", "classification", "read_rank", "n_spans"):
             assert np.array_equal(getattr(out, f), getattr(base, f)), (env, f)
         assert np.array_equal(out.purity.view(np.uint64), base.purity.view(np.uint64)), env

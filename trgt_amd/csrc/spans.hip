@@ -264,6 +264,9 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     WfaLaunch LH = L;
     LH.n_jobs2_dev = nullptr; LH.jobs_cap = 0;
     LH.max_tlen = heavy_tlen_max; LH.max_sum = (int64_t)p.flank_len + heavy_tlen_max;
+    // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
+    // wave and level), and a wave without a strip still pays the per-level prologue and barrier (7.39 -> 7.21 ms)
+    LH.threads = getenv("TRGT_HEAVY_THREADS") ? atoi(getenv("TRGT_HEAVY_THREADS")) : (L.threads == 256 ? 192 : L.threads);
     if ((rc = wfa_launch(c, wp, LH))) return rc;
     // offsets of the first launch, kept next to the running total (cells[1]): the roofline of the dominant launch counts its own
     TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));

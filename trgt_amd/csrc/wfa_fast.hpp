@@ -116,11 +116,11 @@ struct FastEnd { int status, score, k, off; unsigned long long cells; };
 // free at both ends and the pattern not at all (span_locater.rs:17, genotype.rs:66-80) -- as compile-time constants: the ring
 // geometry, the source-level selects and the termination test fold away, and with them a third of the scalar registers
 // (the general instantiation spills SGPRs to VGPR lanes in the per-level prologue).
-template <bool SPEC>
+template <int SPEC>  // 0: general; else the compile-time thread count of TRGT's flank configuration (256 or 192)
 __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJob& J, const uint32_t* P4, const uint32_t* T4, uint16_t* ring,
                                                      int wcap, g_u16* A16, uint32_t* gd) {
   FastShared& fs = g_fsh;
-  const int tid = threadIdx.x, nT = SPEC ? 256 : (int)blockDim.x, lane = tid & 63;  // SPEC is launched with 256 threads only
+  const int tid = threadIdx.x, nT = SPEC ? SPEC : (int)blockDim.x, lane = tid & 63;  // SPEC is launched with SPEC threads only
   const int wave = rfl(tid >> 6), nW = nT >> 6;
   const int plen = J.plen, tlen = J.tlen, koff = plen + 2;  // one pad cell each side: kb-1 / kb+1 reads never leave the slot
   const int ak_b = tlen - plen + koff;
@@ -514,7 +514,7 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 // acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring | pattern windows | text windows.
 // TAG only names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments), so
 // that a kernel trace tells the two launches of trgt_find_spans_batch apart.
-template <bool SPEC, int TAG>
+template <int SPEC, int TAG>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
   FastShared& fs = g_fsh;
