@@ -1,0 +1,139 @@
+"""Seeded windows of the flank fallback alignments (trgt_amd/csrc/spans.hip: piece_window, flank_window_kernel, window_check_kernel):
+an implementation shortcut that must never show in the results.  Hand-made reads aim at its edges -- penalties right at the bound the
+argument covers (11 for TRGT's penalties), every segment but one spoiled, flanks at the very ends of a read, flanks that occur twice,
+periodic flanks (seeds on many diagonals), a better copy of the flank outside the seeded window -- and every read is compared with
+the oracle's find_tr_spans / analyze_tr."""
+import numpy as np
+import pytest
+
+from helpers import rand_dna
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(rng, seq, positions):
+    b = bytearray(seq)
+    for p in positions:
+        b[p] = int(rng.choice([c for c in b"ACGT" if c != b[p]]))
+    return bytes(b)
+
+
+def _locus(rng, reads_fn, n_reads=12, periodic=None):
+    if periodic:
+        unit = rand_dna(rng, periodic)
+        lf = (unit * (250 // periodic + 1))[:250]
+        rf = rand_dna(rng, 250)
+    else:
+        lf, rf = rand_dna(rng, 250), rand_dna(rng, 250)
+    tr = b"CAG" * 20
+    reads = []
+    for i in range(n_reads):
+        reads.append(reads_fn(rng, i, lf, rf, tr))
+    # two plain long reads keep the locus' longest read (and with it the short-read cut-off) where the others are "light"
+    # (1220 bases: just below the length from which reads take the generic kernel, which has no windows)
+    reads.append(rand_dna(rng, 330) + lf + tr + rf + rand_dna(rng, 330))
+    reads.append(rand_dna(rng, 320) + lf + tr + rf + rand_dna(rng, 325))
+    assert max(len(r) for r in reads) <= 1230 and min(len(r) for r in reads[:n_reads]) >= 925, sorted(len(r) for r in reads)
+    return dict(left_flank=lf, right_flank=rf, tr=tr, motifs=[b"CAG"], ploidy=2, reads=reads)
+
+
+def _check(oracle, loci):
+    import torch
+    from trgt_amd import locus
+    from test_locus_gpu import _compare
+    b = locus.pack(loci)
+    p = locus.Params()
+    outs = [("host reads", locus.run_batch(b, p)),
+            ("device", locus.run_batch(b, p, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda()))]
+    for name, out in outs:
+        _compare(oracle, locus, b, out, p, range(len(loci)))
+    return b, outs[1][1]
+
+
+def test_penalties_around_the_bound(oracle):
+    rng = np.random.default_rng(2025)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        # i mismatches in the left flank (penalty 2 i: 0..22), spread so that they hit different segments first
+        pos = [(41 * j + 7 * (j // 6)) % 250 for j in range(i)]
+        l = _sub(rng, lf, pos)
+        # right flank: a deletion of i + 1 bases (penalty 5 + i + 1) plus, for odd i, one mismatch
+        r = rf[:100] + rf[100 + i + 1:]
+        if i % 2:
+            r = _sub(rng, r, [30])
+        return rand_dna(rng, 300) + l + tr + r + rand_dna(rng, 320)
+
+    _check(oracle, [_locus(rng, reads_fn, n_reads=12) for _ in range(6)])
+
+
+def test_insertions_and_all_but_one_segment_spoiled(oracle):
+    rng = np.random.default_rng(7)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        q = 250 // 6
+        keep = i % 6                                     # the one segment left intact
+        l = _sub(rng, lf, [s * q + 3 + i for s in range(6) if s != keep])          # five mismatches: penalty 10
+        ins = rand_dna(rng, 1 + i % 7)                   # insertion of 1..7 bases: penalty 6..12
+        r = rf[:125] + ins + rf[125:]
+        return rand_dna(rng, 250 + 5 * i) + l + tr + r + rand_dna(rng, 300)
+
+    _check(oracle, [_locus(rng, reads_fn, n_reads=14) for _ in range(5)])
+
+
+def test_flanks_at_the_ends_of_the_read(oracle):
+    rng = np.random.default_rng(11)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        l = _sub(rng, lf, [17, 200][:1 + i % 2])
+        r = _sub(rng, rf, [5, 90, 249][:1 + i % 3])
+        left = rand_dna(rng, [0, 1, 3, 17, 40, 41, 42, 60][i % 8])        # window clipped at the start of the read
+        right = rand_dna(rng, [0, 2, 16, 17, 18, 39, 45, 70][(i // 2) % 8])  # ... and at its end
+        return left + l + tr * 9 + r + right           # (long repeat: the read stays above the short-read cut-off)
+
+    _check(oracle, [_locus(rng, reads_fn, n_reads=16) for _ in range(4)])
+
+
+def test_flank_twice_and_better_copy_elsewhere(oracle):
+    rng = np.random.default_rng(13)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        l1 = _sub(rng, lf, [20, 140])                    # penalty 4 ...
+        l2 = _sub(rng, lf, [60])                         # ... and a better copy (penalty 2) further to the right / left
+        gap = rand_dna(rng, [5, 30, 90, 200][i % 4])
+        first, second = (l1, l2) if i % 2 else (l2, l1)
+        r = _sub(rng, rf, [77])
+        dup_r = rand_dna(rng, 40) + _sub(rng, rf, [10, 11, 12]) if i % 4 == 0 else b""   # a worse copy of the right flank behind it
+        return rand_dna(rng, 45) + first + gap + second + tr + r + dup_r + rand_dna(rng, 45)
+
+    _check(oracle, [_locus(rng, reads_fn, n_reads=12) for _ in range(5)])
+
+
+@pytest.mark.parametrize("period", [1, 2, 3, 5, 8, 13, 41, 42, 83])
+def test_periodic_flanks_seed_many_diagonals(oracle, period):
+    rng = np.random.default_rng(100 + period)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        l = _sub(rng, lf, [9 + 3 * i, 120][:1 + i % 2])
+        if i % 4 == 3:
+            l = l[:60] + l[60 + period:]                 # one period deleted: many equally good placements
+        r = _sub(rng, rf, [50])
+        return rand_dna(rng, 290) + l + tr + r + rand_dna(rng, 310)
+
+    _check(oracle, [_locus(rng, reads_fn, n_reads=10, periodic=period) for _ in range(3)])
+
+
+def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
+    # the debug line of find_spans_device reports how many alignments ran on a window and how many of those were redone
+    rng = np.random.default_rng(5)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        l = _sub(rng, lf, [10 + 37 * j for j in range(i % 8)])     # 0..7 mismatches: penalties 0..14
+        return rand_dna(rng, 300) + l + tr + _sub(rng, rf, [100]) + rand_dna(rng, 300)
+
+    monkeypatch.setenv("TRGT_WFA_DEBUG", "1")
+    _check(oracle, [_locus(rng, reads_fn, n_reads=16) for _ in range(4)])
+    err = capfd.readouterr().err
+    line = [l for l in err.splitlines() if l.startswith("[spans]")][-1]
+    nums = [int(t) for t in line.replace(",", " ").replace("(", " ").replace(")", " ").split() if t.isdigit()]
+    windowed, redone = nums[3], nums[-1]
+    assert windowed > 50 and redone >= 4, line

@@ -7,12 +7,14 @@
 // when count_matches() >= flank_len * min_flank_id_frac; the two flank hits are combined into the
 // repeat span (:52-66).
 //
-// Three launches on the ctx stream, no host round trip in between:
+// Launches on the ctx stream, no host round trip in between:
 //   1. flank_scan_wide_kernel  one wavefront per read, both pieces at once: 1024 read bytes per round, 16 candidate
-//                          windows per lane from one 20-byte load, 4-byte filter, cooperative verify in increasing
+//                          windows per lane from one 24-byte load, 8-byte filter, cooperative verify in increasing
 //                          position -> leftmost hit.  Misses are appended to a device-side job list (atomic counter).
 //                          (flank_scan_kernel, one wavefront per (read, side), remains for flank_len < 4.)
-//   2. wfa_kernel          (wfa.hip) persistent workgroups drain that list.
+//   2. wfa_fast_kernel     (wfa_fast.hpp) persistent workgroups drain that list: first the alignments of the reads too short to
+//                          span their locus; then (flank_window_kernel, window_check_kernel) the other alignments on a seeded
+//                          window of the read where one can be proven sufficient; then the rest against the whole read.
 //   3. span_combine_kernel per read: threshold test and (lf.end, rf.start) combination.
 #include <algorithm>
 
@@ -84,6 +86,122 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
       jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
       (lng ? a.wfa_jobs_long : a.wfa_jobs)[slot] = jd;
     }
+  }
+}
+
+// ---- Seeded windows for the fallback alignments (an implementation shortcut with identical results, checked after the fact) ----
+// The ends-free alignment of a flank piece against a whole read keeps every diagonal of the read alive at every score level,
+// although the alignment it ends up with sits on a handful of diagonals.  When the optimal penalty s* is small this is provable
+// up front.  Cut the piece into win_m segments of win_q bases.  With the conditions checked by window_plan() every mismatch or gap
+// spoils at most as many segments as its penalty / x, so an alignment of penalty <= S0 = x * win_m - 1 leaves at least one segment
+// matched exactly and gap-free: an exact occurrence of that segment at read position t pins the alignment to the diagonal
+// k = t - (segment offset), and its path strays from k by at most G = (S0 - o) / e diagonals (its total gap length).  A wavefront
+// cell (s, k) depends only on cells (s', k') with |k' - k| <= (s - s') / e.  So the alignment of the piece against the read window
+// [kmin - G - C, kmax + G + C + F), C = S0 / e, kmin / kmax over ALL exact segment occurrences in the read, computes every cell the
+// full run's termination test and back-trace would read -- bit for bit -- PROVIDED its penalty turns out <= S0 (window_check_kernel;
+// otherwise, or when the occurrences are spread too widely or there are none, the whole read is aligned as before).  Offsets of a
+// windowed run never exceed those of the full run (fewer sources under the max), so it cannot end early either.
+// One wavefront; every lane returns the same kmin / kmax (kmin > kmax: no occurrence).
+constexpr int WIN_SEGMENTS = 6;
+// An "occurrence" is a match of the first TWELVE bases of a segment (all from registers: no memory round trip per candidate).  That
+// is a superset of the exact occurrences, which is all the argument needs -- a chance match (4^-12 per position) can only widen
+// the window or make the spread test fail.
+__device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, int n, const uint8_t* __restrict__ piece, int q, int lane,
+                                             int& kmin_out, int& kmax_out) {
+  int kmin = 0x7FFFFFFF, kmax = -0x7FFFFFFF;
+  uint64_t h[WIN_SEGMENTS]; uint32_t h3[WIN_SEGMENTS];
+#pragma unroll
+  for (int i = 0; i < WIN_SEGMENTS; ++i) {  // (all loads in flight together)
+    const uint8_t* __restrict__ seg = piece + i * q;
+    h[i] = (uint64_t)load_u32(seg + 4) << 32 | load_u32(seg);
+    h3[i] = load_u32(seg + 8);
+  }
+  const int last = n - 12;  // last start of a twelve-base match
+  for (int base = 0; base <= last; base += 1024) {
+    const int off = base + 16 * lane;
+    uint32_t w[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (off + 28 <= n) {
+      uint4 v; uint2 v2; uint32_t v3;
+      __builtin_memcpy(&v, read + off, 16); __builtin_memcpy(&v2, read + off + 16, 8); __builtin_memcpy(&v3, read + off + 24, 4);
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; w[4] = v2.x; w[5] = v2.y; w[6] = v3;
+    } else if (off < n) {
+      for (int b = 0; b < 28 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
+    }
+    uint64_t win[16]; uint32_t win3[16];  // the twelve bytes at candidate start off + s16
+#pragma unroll
+    for (int s16 = 0; s16 < 16; ++s16) {
+      const int d = s16 >> 2, sh = s16 & 3;
+      const uint32_t lo = sh == 0 ? w[d] : __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
+      const uint32_t hi = sh == 0 ? w[d + 1] : __builtin_amdgcn_alignbyte(w[d + 2], w[d + 1], sh);
+      win3[s16] = sh == 0 ? w[d + 2] : __builtin_amdgcn_alignbyte(w[d + 3], w[d + 2], sh);
+      win[s16] = (uint64_t)hi << 32 | lo;
+    }
+#pragma unroll
+    for (int i = 0; i < WIN_SEGMENTS; ++i) {
+      bool any = false;
+#pragma unroll
+      for (int s16 = 0; s16 < 16; ++s16) any |= win[s16] == h[i];
+      if (__ballot(any) == 0ull) continue;  // (uniform; taken but for the round that holds an occurrence of this segment)
+#pragma unroll
+      for (int s16 = 0; s16 < 16; ++s16) {
+        if (win[s16] == h[i] && win3[s16] == h3[i] && off + s16 <= last) {
+          const int k = off + s16 - i * q;
+          kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+  }
+  kmin_out = kmin; kmax_out = kmax;
+}
+
+// One wavefront per fallback alignment of the light list (the back of wfa_jobs): jobs that get a window go to win_jobs (count[4],
+// JobDev::pad = first text base of the window), the others to rest_jobs (count[5]).  A workgroup takes WIN_JOBS_PER_WG jobs and
+// reserves its output slots with one atomic per list.
+struct WindowArgs {
+  const uint8_t* flank_blob; const uint8_t* read_blob;
+  const JobDev* wfa_jobs; uint32_t jobs_cap; uint32_t* count;
+  JobDev* win_jobs; JobDev* rest_jobs;
+  int32_t flank_len, q, margin, spread;
+};
+constexpr int WIN_JOBS_PER_WG = 64;
+__global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
+  __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
+  __shared__ uint32_t l_nw, l_nr, l_bw, l_br;
+  const uint32_t n_light = a.count[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t c0 = blockIdx.x * WIN_JOBS_PER_WG; c0 < n_light; c0 += gridDim.x * WIN_JOBS_PER_WG) {
+    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; }
+    __syncthreads();
+    const uint32_t c1 = c0 + WIN_JOBS_PER_WG < n_light ? c0 + WIN_JOBS_PER_WG : n_light;
+    for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
+      JobDev jd = a.wfa_jobs[a.jobs_cap - 1u - i];
+      const int n = (int)jd.txt_len, F = a.flank_len;
+      int kmin = 1, kmax = 0;
+      if (n >= 12) piece_window(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
+      int w0 = 0, wl = 0;
+      if (kmin <= kmax && kmax - kmin <= a.spread) {
+        const int lo = kmin - a.margin, hi = kmax + a.margin + F;
+        w0 = lo > 0 ? lo : 0;
+        wl = (hi < n ? hi : n) - w0;
+        if (wl + 32 >= n) wl = 0;  // nothing to gain
+      }
+      if (lane == 0) {
+        if (wl > 0) { jd.txt_off += (uint64_t)w0; jd.txt_len = (uint32_t)wl; jd.pad = (uint32_t)w0; l_out[atomicAdd(&l_nw, 1u)] = jd; }
+        else l_out[WIN_JOBS_PER_WG - 1 - atomicAdd(&l_nr, 1u)] = jd;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + 4, l_nw);
+    if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + 5, l_nr);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
+    for (uint32_t i = threadIdx.x; i < l_nr; i += blockDim.x) a.rest_jobs[l_br + i] = l_out[WIN_JOBS_PER_WG - 1 - i];
+    __syncthreads();
   }
 }
 
@@ -179,6 +297,28 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
   for (uint32_t i = threadIdx.x; i < l_n2; i += blockDim.x) a.wfa_jobs[a.jobs_cap - 1u - (l_base2 + i)] = l_jobs[2 * SCAN_READS_PER_WG - 1 - i];
 }
 
+// After the windowed launch: a windowed alignment whose penalty is within the bound of piece_window's argument IS the alignment of
+// the whole read, shifted by the window start; any other goes to the back of the job list and is aligned against the whole read.
+struct WinCheckArgs {
+  const JobDev* win_jobs; const uint32_t* n_win; const int32_t* score; uint32_t* span4; int32_t* n_match; int32_t s0;
+  JobDev* wfa_jobs; uint32_t* wfa_count; uint32_t jobs_cap; const uint64_t* read_off; const uint32_t* read_len;
+};
+__global__ void window_check_kernel(const WinCheckArgs a) {
+  const uint32_t n = *a.n_win;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    JobDev jd = a.win_jobs[i];
+    const uint32_t j = jd.out_index;
+    const int32_t sc = a.score[j];  // -penalty, INT32_MIN when the alignment did not complete
+    if (sc != INT32_MIN && -sc <= a.s0 && a.n_match[j] > 0) {
+      a.span4[4 * (uint64_t)j + 2] += jd.pad; a.span4[4 * (uint64_t)j + 3] += jd.pad;
+    } else {
+      a.n_match[j] = -1;
+      jd.txt_off = a.read_off[j >> 1]; jd.txt_len = a.read_len[j >> 1]; jd.pad = 0;
+      a.wfa_jobs[atomicAdd(a.wfa_count + 5, 1u)] = jd;  // (wfa_jobs: the rest list here)
+    }
+  }
+}
+
 struct CombineArgs {
   uint64_t n_reads; int32_t flank_len; double threshold;
   const int32_t* pos; const int32_t* n_match; const uint32_t* span4;
@@ -213,10 +353,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
   if ((rc = dev_get(c, S_FS_POS, n_jobs * 4, &d_pos)) || (rc = dev_get(c, S_FS_WFAJOBS, n_jobs * sizeof(JobDev), &d_wjobs)) ||
-      (rc = dev_get(c, S_FS_COUNT, 16, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
+      (rc = dev_get(c, S_FS_COUNT, 32, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
       (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 16, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 32, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_nmatch, 0xFF, n_jobs * 4, c->stream));
   ScanArgs sa;
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
@@ -231,6 +371,26 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void* d_wjobs_long = nullptr;
   if (has_long && (rc = dev_get(c, S_FS_WFAJOBS_LONG, n_jobs * sizeof(JobDev), &d_wjobs_long))) return rc;
   sa.wfa_jobs_long = (JobDev*)d_wjobs_long; sa.long_tlen = has_long ? long_tlen : 0xFFFFFFFFu;
+  // Seeded windows (piece_window): WIN_SEGMENTS segments; the conditions make a mismatch the cheapest way to spoil a segment
+  // (a gap inside one segment costs o + e, a deletion across t segments o + ((t - 2) q + 2) e >= t x), so that S0 = WIN_SEGMENTS x - 1.
+  int32_t win_s0 = 0, win_q = 0, win_margin = 0, win_spread = 0; uint32_t win_tlen = 0;
+  void *d_winjobs = nullptr, *d_restjobs = nullptr, *d_score = nullptr;
+  {
+    const int m = WIN_SEGMENTS, q = p.flank_len / m, x = p.mism, o = p.gapo, e = p.gape;
+    const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < (has_long ? long_tlen : max_read_len) && !getenv("TRGT_WFA_ONE_LAUNCH");
+    const bool ok = two_launches && !getenv("TRGT_WFA_NO_WINDOW") && q >= 12 && x >= 1 && e >= 1 && o >= 0 &&
+                    q * e >= x && o + 2 * e >= 2 * x && o + e >= x;
+    if (ok) {
+      win_s0 = x * m - 1;
+      const int G = win_s0 >= o + e ? (win_s0 - o) / e : 0, C = win_s0 / e;
+      win_q = q; win_margin = G + C; win_spread = 2 * G;
+      win_tlen = (uint32_t)(p.flank_len + 2 * win_margin + win_spread);
+      if (win_tlen + 64 >= max_read_len) win_q = 0;  // reads hardly longer than a window
+    }
+    if (win_q > 0 && ((rc = dev_get(c, S_FS_WINJOBS, n_jobs * sizeof(JobDev), &d_winjobs)) || (rc = dev_get(c, S_FS_RESTJOBS, n_jobs * sizeof(JobDev), &d_restjobs)) ||
+                      (rc = dev_get(c, S_FS_SCORE, n_jobs * 4, &d_score))))
+      return rc;
+  }
   {
     KTimer t(c, TRGT_K_FLANK_SCAN);
     if (p.flank_len >= 4) hipLaunchKernelGGL(flank_scan_wide_kernel, dim3((unsigned)((n_reads + SCAN_READS_PER_WG - 1) / SCAN_READS_PER_WG)), dim3(256), 0, c->stream, sa);
@@ -272,6 +432,32 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
     L.n_jobs_dev = (const uint32_t*)d_count + 3;  // always 0: this launch takes the back part of the list only
     L.keep_cells = true; L.timer_slot = TRGT_K_WFA_FLANK_REST;
+    if (win_q > 0) {  // the alignments with a seeded window: short texts, more of them per CU; then sort out which of them stand
+      WindowArgs wa;
+      wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
+      wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread;
+      {
+        KTimer t(c, TRGT_K_FLANK_SCAN);
+        hipLaunchKernelGGL(flank_window_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG)))),
+                           dim3(256), 0, c->stream, wa);
+        TRGT_HIP_TRY(c, hipGetLastError());
+        t.stop(0);
+      }
+      WfaLaunch LW = L;
+      LW.jobs_dev = (const JobDev*)d_winjobs; LW.n_jobs_dev = (const uint32_t*)d_count + 4; LW.n_jobs2_dev = nullptr; LW.jobs_cap = 0;
+      LW.max_tlen = win_tlen; LW.max_sum = (int64_t)p.flank_len + win_tlen;
+      LW.score = (int32_t*)d_score; LW.kernel_tag = 2;
+      LW.threads = getenv("TRGT_WIN_THREADS") ? atoi(getenv("TRGT_WIN_THREADS")) : (L.threads == 256 ? 192 : L.threads);
+      if ((rc = wfa_launch(c, wp, LW))) return rc;
+      WinCheckArgs wc;
+      wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + 4; wc.score = (const int32_t*)d_score;
+      wc.span4 = (uint32_t*)d_span4; wc.n_match = (int32_t*)d_nmatch; wc.s0 = win_s0;
+      wc.wfa_jobs = (JobDev*)d_restjobs; wc.wfa_count = (uint32_t*)d_count; wc.jobs_cap = (uint32_t)n_jobs;
+      wc.read_off = d_read_off; wc.read_len = d_read_len;
+      hipLaunchKernelGGL(window_check_kernel, dim3(256), dim3(256), 0, c->stream, wc);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      L.jobs_dev = (const JobDev*)d_restjobs; L.n_jobs_dev = (const uint32_t*)d_count + 5; L.n_jobs2_dev = nullptr; L.jobs_cap = 0;
+    }
   }
   if ((rc = wfa_launch(c, wp, L))) return rc;
   if (!split) TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
@@ -289,6 +475,13 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   ca.span_start = d_span_start; ca.span_end = d_span_end; ca.lf_hit = d_lf_hit; ca.rf_hit = d_rf_hit;
   hipLaunchKernelGGL(span_combine_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, ca);
   TRGT_HIP_TRY(c, hipGetLastError());
+  if (getenv("TRGT_WFA_DEBUG")) {  // (synchronises: developer output only)
+    uint32_t h[8];
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand)\n",
+            h[0], h[1], h[2], h[4], h[5], h[2] - h[4], h[5] - (h[2] - h[4]));
+  }
   (void)n_loci;
   return TRGT_OK;
 }

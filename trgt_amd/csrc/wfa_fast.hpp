@@ -512,7 +512,8 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
 // acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring | pattern windows | text windows.
-// TAG only names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments), so
+// TAG only names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments, 2: the
+// launch over the flank alignments with a seeded window), so
 // that a kernel trace tells the two launches of trgt_find_spans_batch apart.
 template <int SPEC, int TAG>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
@@ -572,7 +573,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     // the next job: claimed before the level loop in the launch over the light alignments (its latency hides behind the loop, the
     // job is a few microseconds of work), behind the loop in the launch over the expensive ones (a workgroup sitting on a claimed
     // 400-microsecond job while others run dry lengthened that launch by 6 %)
-    if (TAG == 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    if (TAG >= 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
     FastJob J;
     {
       const int sp = a.kp.span;
@@ -595,8 +596,8 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     }
 #endif
     cells_acc += E.cells;
-    if (TAG != 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
-    uint32_t j_next = TAG == 1 ? rfl((uint32_t)fs.job) : 0u;  // TAG != 1: read behind the next barrier
+    if (TAG == 0 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    uint32_t j_next = TAG >= 1 ? rfl((uint32_t)fs.job) : 0u;  // TAG == 0: read behind the next barrier
     const bool ok = E.status == ST_END_REACHED;
     int nrun = 0;
     // The run list of the back-trace (reversed) lives in the idle ring area of LDS, behind the staged descriptors, with the run
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       lruns = reinterpret_cast<uint32_t*>(lds_dyn + run_base);
       lcap = (a.fast_ring_bytes - run_base) / 8u;  // runs [0, lcap), run starts [lcap, 2 lcap)
       __syncthreads();  // every wave has left the level loop (ring idle), thread 0's descriptor stores are done
-      if (TAG != 1) j_next = rfl((uint32_t)fs.job);
+      if (TAG == 0) j_next = rfl((uint32_t)fs.job);
       int nt = 0;
       if (in_ring) {
         if (tid < 64) nt = wf_backtrace_fast_affine<4>(pen, plen, tlen, E, reinterpret_cast<const uint32_t*>(fs.fdesc), A16g, rle_tmp, a.rle_cap, lruns, lcap);
@@ -643,7 +644,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     uint32_t* const lstart = lruns + lcap;
     auto run_at = [&](int r) -> uint32_t { return lds_runs ? lruns[nrun - 1 - r] : rle_out[r]; };  // forward order
     __syncthreads();
-    if (TAG != 1) j_next = rfl((uint32_t)fs.job);
+    if (TAG == 0) j_next = rfl((uint32_t)fs.job);
     PROF_MARK(4);
     // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations (as in wfa_kernel)
     if (tid == 0) {

@@ -28,6 +28,7 @@ struct WfaLaunch {  // everything device-resident
   int64_t max_plen = 0, max_tlen = 0, max_sum = 0;
   int threads = 0;
   int timer_slot = TRGT_K_WFA;
+  int kernel_tag = -1;  // instantiation of the dedicated kernel to launch (-1: 1 for timer_slot == TRGT_K_WFA_FLANK_REST, else 0); names the launch in a trace
   bool keep_cells = false;  // do not reset the wavefront-offset counter (a second launch of the same logical batch)
   int buffer_set = 0;  // 0 / 1: which workspace / counter buffers of the ctx to use (two launches may be in flight on two streams)
   int32_t* status = nullptr; int32_t* score = nullptr; int32_t* n_match = nullptr; uint32_t* span4 = nullptr;
