@@ -127,7 +127,7 @@ def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
     rng = np.random.default_rng(5)
 
     def reads_fn(rng, i, lf, rf, tr):
-        l = _sub(rng, lf, [10 + 37 * j for j in range(i % 8)])     # 0..7 mismatches: penalties 0..14
+        l = _sub(rng, lf, [10 + 23 * j for j in range(i % 10)])    # 0..9 mismatches: penalties 0..18 (the argument covers up to 15)
         return rand_dna(rng, 300) + l + tr + _sub(rng, rf, [100]) + rand_dna(rng, 300)
 
     monkeypatch.setenv("TRGT_WFA_DEBUG", "1")

@@ -102,10 +102,12 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
 // otherwise, or when the occurrences are spread too widely or there are none, the whole read is aligned as before).  Offsets of a
 // windowed run never exceed those of the full run (fewer sources under the max), so it cannot end early either.
 // One wavefront; every lane returns the same kmin / kmax (kmin > kmax: no occurrence).
-constexpr int WIN_SEGMENTS = 6;
+constexpr int WIN_SEGMENTS_DEFAULT = 8;  // (4, 6 and 8 are instantiated; TRGT_WIN_SEGMENTS picks another one.  Measured on the 10k-locus
+                                         // batch, search + alignments: 4 -> 3.19 ms, 6 -> 3.00, 8 -> 2.90, 10 -> 2.97, 12 -> 3.02)
 // An "occurrence" is a match of the first TWELVE bases of a segment (all from registers: no memory round trip per candidate).  That
 // is a superset of the exact occurrences, which is all the argument needs -- a chance match (4^-12 per position) can only widen
 // the window or make the spread test fail.
+template <int WIN_SEGMENTS>
 __device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, int n, const uint8_t* __restrict__ piece, int q, int lane,
                                              int& kmin_out, int& kmax_out) {
   int kmin = 0x7FFFFFFF, kmax = -0x7FFFFFFF;
@@ -166,9 +168,10 @@ struct WindowArgs {
   const uint8_t* flank_blob; const uint8_t* read_blob;
   const JobDev* wfa_jobs; uint32_t jobs_cap; uint32_t* count;
   JobDev* win_jobs; JobDev* rest_jobs;
-  int32_t flank_len, q, margin, spread;
+  int32_t flank_len, q, margin, spread, tbf;
 };
 constexpr int WIN_JOBS_PER_WG = 64;
+template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
   __shared__ uint32_t l_nw, l_nr, l_bw, l_br;
@@ -182,13 +185,14 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       JobDev jd = a.wfa_jobs[a.jobs_cap - 1u - i];
       const int n = (int)jd.txt_len, F = a.flank_len;
       int kmin = 1, kmax = 0;
-      if (n >= 12) piece_window(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
+      if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
       int w0 = 0, wl = 0;
       if (kmin <= kmax && kmax - kmin <= a.spread) {
-        const int lo = kmin - a.margin, hi = kmax + a.margin + F;
+        // diagonals [kmin - margin, kmax + margin] start the alignment (text_begin_free = 2 margin + spread of the windowed launch, counted
+        // from the window start) and run through at most flank_len more bases of the read
+        const int lo = kmin - a.margin;
         w0 = lo > 0 ? lo : 0;
-        wl = (hi < n ? hi : n) - w0;
-        if (wl + 32 >= n) wl = 0;  // nothing to gain
+        wl = n - w0 < a.tbf + F ? n - w0 : a.tbf + F;
       }
       if (lane == 0) {
         if (wl > 0) { jd.txt_off += (uint64_t)w0; jd.txt_len = (uint32_t)wl; jd.pad = (uint32_t)w0; l_out[atomicAdd(&l_nw, 1u)] = jd; }
@@ -371,12 +375,15 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void* d_wjobs_long = nullptr;
   if (has_long && (rc = dev_get(c, S_FS_WFAJOBS_LONG, n_jobs * sizeof(JobDev), &d_wjobs_long))) return rc;
   sa.wfa_jobs_long = (JobDev*)d_wjobs_long; sa.long_tlen = has_long ? long_tlen : 0xFFFFFFFFu;
-  // Seeded windows (piece_window): WIN_SEGMENTS segments; the conditions make a mismatch the cheapest way to spoil a segment
-  // (a gap inside one segment costs o + e, a deletion across t segments o + ((t - 2) q + 2) e >= t x), so that S0 = WIN_SEGMENTS x - 1.
-  int32_t win_s0 = 0, win_q = 0, win_margin = 0, win_spread = 0; uint32_t win_tlen = 0;
+  // Seeded windows (piece_window): eight segments by default; the conditions make a mismatch the cheapest way to spoil a segment
+  // (a gap inside one segment costs o + e, a deletion across t segments o + ((t - 2) q + 2) e >= t x), so that S0 = (segments) x - 1.
+  int32_t win_s0 = 0, win_q = 0, win_margin = 0, win_spread = 0, win_m = WIN_SEGMENTS_DEFAULT; uint32_t win_tlen = 0;
   void *d_winjobs = nullptr, *d_restjobs = nullptr, *d_score = nullptr;
   {
-    const int m = WIN_SEGMENTS, q = p.flank_len / m, x = p.mism, o = p.gapo, e = p.gape;
+    int m = getenv("TRGT_WIN_SEGMENTS") ? atoi(getenv("TRGT_WIN_SEGMENTS")) : WIN_SEGMENTS_DEFAULT;
+    if (m != 4 && m != 6 && m != 8) m = WIN_SEGMENTS_DEFAULT;
+    win_m = m;
+    const int q = p.flank_len / m, x = p.mism, o = p.gapo, e = p.gape;
     const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < (has_long ? long_tlen : max_read_len) && !getenv("TRGT_WFA_ONE_LAUNCH");
     const bool ok = two_launches && !getenv("TRGT_WFA_NO_WINDOW") && q >= 12 && x >= 1 && e >= 1 && o >= 0 &&
                     q * e >= x && o + 2 * e >= 2 * x && o + e >= x;
@@ -435,20 +442,26 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     if (win_q > 0) {  // the alignments with a seeded window: short texts, more of them per CU; then sort out which of them stand
       WindowArgs wa;
       wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
-      wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread;
+      wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
       {
         KTimer t(c, TRGT_K_FLANK_SCAN);
-        hipLaunchKernelGGL(flank_window_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG)))),
-                           dim3(256), 0, c->stream, wa);
+        const dim3 wgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG))));
+        if (win_m == 4) hipLaunchKernelGGL(flank_window_kernel<4>, wgrid, dim3(256), 0, c->stream, wa);
+        else if (win_m == 6) hipLaunchKernelGGL(flank_window_kernel<6>, wgrid, dim3(256), 0, c->stream, wa);
+        else hipLaunchKernelGGL(flank_window_kernel<8>, wgrid, dim3(256), 0, c->stream, wa);
         TRGT_HIP_TRY(c, hipGetLastError());
         t.stop(0);
       }
       WfaLaunch LW = L;
       LW.jobs_dev = (const JobDev*)d_winjobs; LW.n_jobs_dev = (const uint32_t*)d_count + 4; LW.n_jobs2_dev = nullptr; LW.jobs_cap = 0;
       LW.max_tlen = win_tlen; LW.max_sum = (int64_t)p.flank_len + win_tlen;
-      LW.score = (int32_t*)d_score; LW.kernel_tag = 2;
-      LW.threads = getenv("TRGT_WIN_THREADS") ? atoi(getenv("TRGT_WIN_THREADS")) : (L.threads == 256 ? 192 : L.threads);
-      if ((rc = wfa_launch(c, wp, LW))) return rc;
+      LW.score = (int32_t*)d_score; LW.kernel_tag = 2; LW.max_score = win_s0;
+      // only the diagonals that can matter start the alignment: a wavefront of 2 margin + spread + 1 diagonals instead of one per base
+      // of the window, i.e. one strip of one wave per level
+      LW.threads = getenv("TRGT_WIN_THREADS") ? atoi(getenv("TRGT_WIN_THREADS")) : 64;
+      trgt_wfa_params wpw = wp;
+      wpw.text_begin_free = 2 * win_margin + win_spread;
+      if ((rc = wfa_launch(c, wpw, LW))) return rc;
       WinCheckArgs wc;
       wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + 4; wc.score = (const int32_t*)d_score;
       wc.span4 = (uint32_t*)d_span4; wc.n_match = (int32_t*)d_nmatch; wc.s0 = win_s0;

@@ -458,6 +458,8 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     score_bound = std::min<int64_t>(score_bound, std::max<int64_t>(small, 4 * (int64_t)p.bialign_min_score + 64));
   }
   score_bound = std::min<int64_t>(score_bound, 1 << 20);
+  const bool capped = L.max_score > 0 && p.span == 1 && p.pattern_begin_free == 0 && p.text_begin_free >= 0;
+  if (capped) score_bound = std::min<int64_t>(score_bound, L.max_score + 1);
   const uint64_t per_level = (uint64_t)pen.ncomp * (uint64_t)std::min<int64_t>(msum + 3, 2 * score_bound + 3 + (p.span ? msum : 0));
   uint64_t arena_ints = std::min<uint64_t>((uint64_t)(score_bound + 1) * per_level + 64, (1ull << 30) / 4);  // <= 1 GiB per workgroup
   const uint64_t ring_stride = (uint64_t)msum + 4;
@@ -505,24 +507,29 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   a.lds_seq_cap = (uint32_t)((std::min<uint64_t>(seq_need, 32 * 1024) + 15) & ~15ull);
   if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
   size_t lds = a.lds_seq_cap;
-  a.fast_wcap = 0; a.fast_ring_bytes = 0;
+  a.fast_wcap = 0; a.fast_ring_bytes = 0; a.fast_koff = 0;
   a.fast_dbg = getenv("TRGT_DBG_SKIP_BT") ? 1 : 0;
   if (p.metric == 3 && p.heuristic == 0 && !a.kp.biwfa && a.lds_seq_cap > 0 && mt + score_bound < 65000 && threads % 64 == 0 && threads <= 256) {
     // LDS fast path (wfa_fast.hpp): ring of the live wavefronts as 16-bit offsets
-    const uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
+    uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
+    if (capped) {  // levels 0 .. max_score + 1: diagonals -(max_score + 1) .. text_begin_free + max_score + 1
+      a.fast_koff = (uint32_t)(L.max_score + 4);
+      wcap = std::min<uint64_t>(wcap, ((uint64_t)a.fast_koff + (uint64_t)p.text_begin_free + (uint64_t)L.max_score + 12 + 7) & ~7ull);
+    }
     const uint64_t ring_bytes = (uint64_t)(std::max(pen.x, pen.o1 + pen.e1) + 1 + 2 * (pen.e1 + 1)) * wcap * 2;
     const uint64_t win_bytes = 4ull * (uint64_t)(mp + mt + 8);
     // (the byte copies of the two sequences are staged in the ring area, which is idle until level 0 is written)
-    if (ring_bytes + win_bytes <= 96 * 1024 && seq_need <= ring_bytes) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds = (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
+    if (ring_bytes + win_bytes <= 96 * 1024 && (seq_need <= ring_bytes || capped)) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds = (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
   }
   // TRGT's flank-location configuration has an instantiation of its own (wfa_fast.hpp, SPEC)
-  const bool fast_spec = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tbf < 0 && a.kp.tef < 0 &&
-                         (threads == 256 || threads == 192) && !getenv("TRGT_WFA_NO_SPEC");
+  const bool fast_spec = a.fast_koff == 0 && pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tbf < 0 && a.kp.tef < 0 &&
+                         (threads == 256 || threads == 192 || ((threads == 128 || threads == 64) && L.kernel_tag == 2)) && !getenv("TRGT_WFA_NO_SPEC");
   const int tag = L.kernel_tag >= 0 ? L.kernel_tag : (L.timer_slot == TRGT_K_WFA_FLANK_REST ? 1 : 0);
   void (*const spec_fn[2][3])(const KArgs) = {{wfa_fast_kernel<256, 0>, wfa_fast_kernel<256, 1>, wfa_fast_kernel<256, 2>},
                                               {wfa_fast_kernel<192, 0>, wfa_fast_kernel<192, 1>, wfa_fast_kernel<192, 2>}};
   void (*const gen_fn[3])(const KArgs) = {wfa_fast_kernel<0, 0>, wfa_fast_kernel<0, 1>, wfa_fast_kernel<0, 2>};
-  void (*const fast_fn)(const KArgs) = fast_spec ? spec_fn[threads == 192 ? 1 : 0][tag] : gen_fn[tag];
+  void (*const fast_fn)(const KArgs) = !fast_spec ? gen_fn[tag] : threads == 128 ? wfa_fast_kernel<128, 2> : threads == 64 ? wfa_fast_kernel<64, 2>
+                                                                            : spec_fn[threads == 192 ? 1 : 0][tag];
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
   int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));

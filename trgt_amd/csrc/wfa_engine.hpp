@@ -48,7 +48,7 @@ struct KArgs {
   unsigned int* slot_flags; uint32_t n_slots_ws, jobs_per_block;  // workspace slots are acquired per resident workgroup
   uint8_t* ws; uint64_t ws_per_block;
   uint64_t off_gdesc, off_arena_u, off_arena_f, off_arena_r, off_rle_tmp, off_rle_out, off_run_start;
-  uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg;
+  uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg, fast_koff /* bias of the diagonal index in the ring; 0 = pattern length + 2 */;
   int32_t* status; int32_t* score; int32_t* n_match; uint32_t* span4; uint32_t* cigar; uint32_t* cigar_len; uint8_t* ops; uint32_t* ops_len;
   unsigned long long* cells_out;
 };

@@ -103,11 +103,11 @@ struct FastShared {
   uint32_t flaw[RING];  // ... and their lo_alloc | width << 16: a back-trace of fewer than RING levels needs nothing from HBM but offsets
   uint4 wred[2][16];    // per-wave trim records, double-buffered
   FastTerm fterm[3];
-  int job, slot, rle_n, total_ops;
+  int job, slot, rle_n, total_ops, chunk_end;
 };
 __shared__ FastShared g_fsh;
 
-struct FastJob { int plen, tlen, span, pbf, pef, tbf, tef, n_slots; uint32_t cap; };  // all wave-uniform
+struct FastJob { int plen, tlen, span, pbf, pef, tbf, tef, n_slots, koff; uint32_t cap; };  // all wave-uniform
 struct FastEnd { int status, score, k, off; unsigned long long cells; };
 
 // P4, T4: LDS 4-byte sliding windows of pattern / text.  ring: (RM + 2*RI) * wcap uint16 in LDS.  A16: history arena,
@@ -122,7 +122,8 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   FastShared& fs = g_fsh;
   const int tid = threadIdx.x, nT = SPEC ? SPEC : (int)blockDim.x, lane = tid & 63;  // SPEC is launched with SPEC threads only
   const int wave = rfl(tid >> 6), nW = nT >> 6;
-  const int plen = J.plen, tlen = J.tlen, koff = plen + 2;  // one pad cell each side: kb-1 / kb+1 reads never leave the slot
+  const int plen = J.plen, tlen = J.tlen, koff = SPEC ? plen + 2 : J.koff;  // plen + 2 (one pad cell each side: kb-1 / kb+1 reads never leave
+                                                                              // the slot) unless the launch bounds the penalty (KArgs::fast_koff)
   const int ak_b = tlen - plen + koff;
   const int x = SPEC ? 2 : pen.x, oe = SPEC ? 6 : pen.o1 + pen.e1, e = SPEC ? 1 : pen.e1, scope = SPEC ? 7 : pen.scope;
   const int RM = max(x, oe) + 1, RI = e + 1;
@@ -419,9 +420,8 @@ __device__ __forceinline__ long long bt_value(const BtLoc& l, uint32_t enc, int 
 
 template <int STRIDE>
 __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen, int tlen, const FastEnd& E, const uint32_t* ld,
-                                                        const uint16_t* __restrict__ A16, uint32_t* tmp, uint32_t cap, uint32_t* lruns, uint32_t lcap) {
+                                                        const uint16_t* __restrict__ A16, uint32_t* tmp, uint32_t cap, uint32_t* lruns, uint32_t lcap, int koff) {
   const int lane = threadIdx.x & 63;
-  const int koff = plen + 2;
   const int x = pen.x, oe = pen.o1 + pen.e1, e = pen.e1;
   int mt = CM, s = E.score, k = E.k, off = E.off;
   int h = off, v = off - k, nt = 0;
@@ -555,8 +555,18 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   auto job_at = [&](uint32_t j) { return a.jobs[j < n_front ? j : a.jobs_cap - 1u - (j - n_front)]; };
   // Jobs are claimed one ahead: the index of the next job is fetched while the current one runs, so that the waves that idle during
   // the back-trace of a light alignment (one wave's work) can already build the windows of the next one.
+  // (the launch over the windowed alignments takes four jobs per atomic -- 4: 1.22 ms, 8: 1.25, 16: 1.33, 32: 1.43 for the two light launches
+  //  together: 128 k three-microsecond jobs on one counter came out at 12.7 ns
+  //  apiece whatever the kernel did in between -- the rate of same-address atomics, not of alignments)
+  constexpr int CLAIM = TAG == 2 ? 4 : 1;
+  auto claim = [&]() {  // thread 0
+    if (CLAIM == 1) { fs.job = (int)atomicAdd(a.counter, 1u); return; }
+    int nx = fs.job + 1;
+    if (nx >= fs.chunk_end) { nx = (int)atomicAdd(a.counter, (unsigned)CLAIM); fs.chunk_end = nx + CLAIM; }
+    fs.job = nx;
+  };
   __syncthreads();
-  if (tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+  if (tid == 0) { fs.job = -1; fs.chunk_end = 0; claim(); }
   __syncthreads();
   uint32_t j = rfl((uint32_t)fs.job);
   bool staged = false;  // windows of job j already built (by waves 1.. during the previous back-trace)
@@ -573,15 +583,16 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     // the next job: claimed before the level loop in the launch over the light alignments (its latency hides behind the loop, the
     // job is a few microseconds of work), behind the loop in the launch over the expensive ones (a workgroup sitting on a claimed
     // 400-microsecond job while others run dry lengthened that launch by 6 %)
-    if (TAG >= 1 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    if (TAG >= 1 && tid == 0) claim();
     FastJob J;
     {
       const int sp = a.kp.span;
-      auto fr = [](int v, int len) { return v < 0 ? len : v; };
+      auto fr = [](int v, int len) { return v < 0 || v > len ? len : v; };  // (a free length beyond the sequence means all of it)
       J.plen = plen; J.tlen = tlen; J.span = sp;
       J.pbf = sp ? fr(a.kp.pbf, plen) : 0; J.pef = sp ? fr(a.kp.pef, plen) : 0;
       J.tbf = sp ? fr(a.kp.tbf, tlen) : 0; J.tef = sp ? fr(a.kp.tef, tlen) : 0;
       J.n_slots = (int)a.uni_slots; J.cap = a.arena_uni_cap;
+      J.koff = a.fast_koff ? (int)a.fast_koff : plen + 2;
     }
     PROF_MARK(1);
     const FastEnd E = wf_run_lds_affine<SPEC>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
@@ -596,7 +607,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     }
 #endif
     cells_acc += E.cells;
-    if (TAG == 0 && tid == 0) fs.job = (int)atomicAdd(a.counter, 1u);
+    if (TAG == 0 && tid == 0) claim();
     uint32_t j_next = TAG >= 1 ? rfl((uint32_t)fs.job) : 0u;  // TAG == 0: read behind the next barrier
     const bool ok = E.status == ST_END_REACHED;
     int nrun = 0;
@@ -616,7 +627,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       if (TAG == 0) j_next = rfl((uint32_t)fs.job);
       int nt = 0;
       if (in_ring) {
-        if (tid < 64) nt = wf_backtrace_fast_affine<4>(pen, plen, tlen, E, reinterpret_cast<const uint32_t*>(fs.fdesc), A16g, rle_tmp, a.rle_cap, lruns, lcap);
+        if (tid < 64) nt = wf_backtrace_fast_affine<4>(pen, plen, tlen, E, reinterpret_cast<const uint32_t*>(fs.fdesc), A16g, rle_tmp, a.rle_cap, lruns, lcap, J.koff);
         else if (j_next < n_jobs) {  // meanwhile: the windows of the next job (the back-trace touches neither them nor the sequences)
           const JobDev nj = job_at(j_next);
           stage(a.pat_base + nj.pat_off, (int)nj.pat_len, P4, tid - 64, T - 64);
@@ -630,9 +641,9 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
           ld[i] = gd[(size_t)lvl * FD_STRIDE + c5];
         }
         __syncthreads();
-        if (tid < 64) nt = wf_backtrace_fast_affine<FD_LDS_STRIDE>(pen, plen, tlen, E, ld, A16g, rle_tmp, a.rle_cap, lruns, lcap);
+        if (tid < 64) nt = wf_backtrace_fast_affine<FD_LDS_STRIDE>(pen, plen, tlen, E, ld, A16g, rle_tmp, a.rle_cap, lruns, lcap, J.koff);
       } else if (tid < 64) {
-        nt = wf_backtrace_fast_affine<FD_STRIDE>(pen, plen, tlen, E, gd, A16g, rle_tmp, a.rle_cap, lruns, lcap);
+        nt = wf_backtrace_fast_affine<FD_STRIDE>(pen, plen, tlen, E, gd, A16g, rle_tmp, a.rle_cap, lruns, lcap, J.koff);
       }
       if (tid == 0) fs.rle_n = nt;
       __syncthreads();

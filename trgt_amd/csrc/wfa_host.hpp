@@ -28,6 +28,9 @@ struct WfaLaunch {  // everything device-resident
   int64_t max_plen = 0, max_tlen = 0, max_sum = 0;
   int threads = 0;
   int timer_slot = TRGT_K_WFA;
+  int max_score = 0;    // > 0: alignments whose penalty exceeds it are given up (status OOM, score INT32_MIN): with pattern_begin_free = 0 and a
+                        // fixed text_begin_free the wavefronts then stay within [-max_score, text_begin_free + max_score] and the LDS ring of the
+                        // dedicated kernel is sized (and indexed) for that range instead of the whole text
   int kernel_tag = -1;  // instantiation of the dedicated kernel to launch (-1: 1 for timer_slot == TRGT_K_WFA_FLANK_REST, else 0); names the launch in a trace
   bool keep_cells = false;  // do not reset the wavefront-offset counter (a second launch of the same logical batch)
   int buffer_set = 0;  // 0 / 1: which workspace / counter buffers of the ctx to use (two launches may be in flight on two streams)
