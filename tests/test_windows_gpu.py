@@ -137,3 +137,16 @@ def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
     nums = [int(t) for t in line.replace(",", " ").replace("(", " ").replace(")", " ").split() if t.isdigit()]
     windowed, redone = nums[3], nums[-1]
     assert windowed > 50 and redone >= 4, line
+
+
+@pytest.mark.parametrize("scoring,flank_len", [((1, 2, 1), 250), ((4, 6, 2), 250), ((2, 5, 1), 150), ((2, 5, 1), 100), ((3, 1, 1), 250), ((1, 0, 1), 200)])
+def test_other_penalties_and_flank_lengths(oracle, scoring, flank_len):
+    # the bound, the margins and whether windows are used at all follow from the penalties and the flank length (window_plan in
+    # find_spans_device): synthetic loci under other settings, every locus against the oracle
+    import torch
+    from trgt_amd import locus, synth
+    from test_locus_gpu import _compare
+    b = synth.generate(48, first_locus=4242 + flank_len)
+    p = locus.Params(aln_scoring=scoring, search_flank_len=flank_len)
+    out = locus.run_batch(b, p, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda())
+    _compare(oracle, locus, b, out, p, range(48))

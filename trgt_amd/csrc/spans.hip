@@ -492,8 +492,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     uint32_t h[8];
     TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand)\n",
-            h[0], h[1], h[2], h[4], h[5], h[2] - h[4], h[5] - (h[2] - h[4]));
+    if (win_q > 0)
+      fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand)\n",
+              h[0], h[1], h[2], h[4], h[5], h[2] - h[4], h[5] - (h[2] - h[4]));
+    else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[0], h[1], h[2]);
   }
   (void)n_loci;
   return TRGT_OK;
