@@ -270,9 +270,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // motif visits (block, first base, one past the last base): 16-bit in LDS (staged alleles are at most HMM_STAGE_QLEN long)
   uint16_t* l_vis = reinterpret_cast<uint16_t*>(l_mot + ((mot_bytes + 15) & ~15));
   uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_vis + ((3 * (stage_qcap + 3) + 1) & ~1u));
-  if (STAGE) {
+  if (STAGE) {  // the symbol codes of '#' + allele + '#' (hmm_code), one byte per column
     const uint8_t* gs = seq_blob + job.seq_off;
-    for (int i = tid; i < qlen; i += nthr) l_seq[i] = gs[i];
+    for (int i = tid; i < L; i += nthr) l_seq[i] = (uint8_t)hmm_code(gs, i, L);
     for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
     for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
   }
@@ -294,6 +294,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
+  auto code_at = [&](int i) -> int { return STAGE ? (int)l_seq[i] : hmm_code(seq, i, L); };
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
   hmm_sync(sync_n);
   // traceback word of my state: kind (0 outside any block, 1 block start, 2 block end, 3 skip state, 4 match, 5 insertion,
@@ -326,10 +327,10 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
   double* cur = sc1;
-  int sym_next = hmm_code(seq, 0, L);
+  int sym_next = code_at(0);
   for (int i = 0; i < L; ++i) {
     const int sym = sym_next;
-    if (i + 1 < L) sym_next = hmm_code(seq, i + 1, L);
+    if (i + 1 < L) sym_next = code_at(i + 1);
     double best = NINF;
     int bpi = 0xFF;
     if (act && level == 0) {
@@ -369,6 +370,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       hmm_sync(sync_n);
     }
 #else
+    // (Silent states emit nothing: the reference adds an emission term of 0.0 to their sums, which changes no value -- scores are sums of
+    //  logarithms of probabilities, never -0.0 -- and is left out here.)
     // Silent states of the column in three passes instead of one per topological level (motif length + 3 of them, each an LDS
     // round trip and a fence with one or two busy lanes).  The dependency chain of a motif block -- d0 <- d1 <- ... <- block end --
     // is walked by ONE lane (the block-end state's) with the chain value in a register; then the run-end lane takes the maximum
@@ -379,14 +382,14 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       for (int k = 0; k + 1 < blk_n; ++k) {  // deletion states d0 + k: predecessors {m0 + k, d0 + k - 1}
         const int sd = blk_d0 + k;
         double bd = NINF; int pd = 0xFF;
-        const double v0 = (cur[blk_m0 + k] + l_lp[sd]) + 0.0;
+        const double v0 = (cur[blk_m0 + k] + l_lp[sd]);
         if (v0 > bd) { bd = v0; pd = 0; }
-        if (k > 0) { const double v1 = (chain + l_lp[S + sd]) + 0.0; if (v1 > bd) { bd = v1; pd = 1; } }
+        if (k > 0) { const double v1 = (chain + l_lp[S + sd]); if (v1 > bd) { bd = v1; pd = 1; } }
         cur[sd] = bd; l_bpcol[sd] = (uint8_t)pd; chain = bd;
       }
       // the block end itself: {m_last, i_last, d_last} (or {skip} / {m, i}); d_last is the chain value just computed
       const double s0 = cur[q0], s1 = cur[q1], s2 = (n_in > 2) ? chain : 0.0;
-      const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0, v2 = (s2 + lp2) + 0.0;
+      const double v0 = (s0 + lp0), v1 = (s1 + lp1), v2 = (s2 + lp2);
       if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
       if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
       if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
@@ -395,12 +398,12 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     hmm_sync(sync_n);
     if (act && n_in == 0xFF) {  // run end: block ends in block order; then the run start {start state, run end}
       for (int b = 0; b < nb; ++b) {
-        const double v = (cur[l_blocks[1 * nb + b]] + lp0) + 0.0;
+        const double v = (cur[l_blocks[1 * nb + b]] + lp0);
         if (v > best) { best = v; bpi = b; }
       }
       cur[st] = best;
       double br = NINF; int pr = 0xFF;
-      const double v0 = (cur[0] + l_lp[1]) + 0.0, v1 = (best + l_lp[S + 1]) + 0.0;
+      const double v0 = (cur[0] + l_lp[1]), v1 = (best + l_lp[S + 1]);
       if (v0 > br) { br = v0; pr = 0; }
       if (v1 > br) { br = v1; pr = 1; }
       cur[1] = br; l_bpcol[1] = (uint8_t)pr;
@@ -408,7 +411,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     hmm_sync(sync_n);
     if (role_start) {  // block start: {run start, own block end}
       const double s0 = cur[q0], s1 = cur[q1];
-      const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0;
+      const double v0 = (s0 + lp0), v1 = (s1 + lp1);
       if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
       if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
       cur[st] = best;
@@ -451,7 +454,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         // per step (it was seven, and an integer division)
         const uint32_t inf = l_info[state];
         const int b = l_stage[(size_t)(idx - c0) * Spad + state];
-        const int qbase = "#ATCG"[hmm_code(seq, idx, L)];
+        const int qbase = "#ATCG"[code_at(idx)];
         const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
         if (kind == 1) {  // MotifStart + implied leading deletions (events.rs:42-48)
           const int dels = nxt - state - 1;
@@ -511,7 +514,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         else {
           const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
           for (int j = 0; j < mlen; ++j) {
-            const int obs = "#ATCG"[hmm_code(seq, b0 + j + 1, L)];
+            const int obs = "#ATCG"[code_at(b0 + j + 1)];
             if (mot[j] != 'N' && obs != mot[j]) keep = false;
           }
         }
