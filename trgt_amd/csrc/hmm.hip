@@ -181,7 +181,7 @@ __device__ unsigned long long g_hmm_prof[8];
 #define HP_MARK(i)
 #endif
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
-constexpr int HMM_LDS_PER_STATE = 16 + 16 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], info, inst[4], block, flags, bp column
+constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4], block, flags, bp column
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
   // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
@@ -249,7 +249,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* sc0 = reinterpret_cast<double*>(lds + 64);
   double* sc1 = sc0 + S;
   double* l_lp = sc1 + S;                                             // [2][S] ln transition probabilities of predecessors 0 and 1
-  uint32_t* l_info = reinterpret_cast<uint32_t*>(l_lp + 2 * S);       // [S] what the traceback needs to know about a state, in one word
+  double* l_em = l_lp + 2 * S;                                        // [5][S] ln emission probabilities by symbol code: one LDS read per column instead of a select tree
+  uint32_t* l_info = reinterpret_cast<uint32_t*>(l_em + 5 * S);       // [S] what the traceback needs to know about a state, in one word
   uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_info + S);         // [4][S]
   int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
   uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
@@ -279,6 +280,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const uint8_t* const motif_bytes = STAGE ? l_mot : g_motifs;
   for (int i = tid; i < 4 * S; i += nthr) l_inst[i] = g_inst[i];
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
+  for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
 
   // ---- my state's tables in registers
@@ -289,7 +291,6 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int n_levels = (int)set.n_levels;
   (void)n_levels;  // only the level-by-level variant (TRGT_HMM_LEVELWISE) walks the levels
   double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
-  const double em0 = g_em[0 * S + st], em1 = g_em[1 * S + st], em2 = g_em[2 * S + st], em3 = g_em[3 * S + st], em4 = g_em[4 * S + st];
   const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
   // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
@@ -334,7 +335,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     double best = NINF;
     int bpi = 0xFF;
     if (act && level == 0) {
-      const double em = sym == 0 ? em0 : sym == 1 ? em1 : sym == 2 ? em2 : sym == 3 ? em3 : em4;
+      const double em = l_em[sym * S + st];
       if (i == 0) {
         if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
       } else {
