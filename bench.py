@@ -136,7 +136,8 @@ def main():
 
     if rank == 0:
         # wfa_flank: the launch over the alignments of reads too short to span their locus (95 % of the wavefront offsets);
-        # wfa_flank_rest: the launch over the other flank alignments
+        # wfa_flank_rest: the launches over the other flank alignments (on seeded windows, then the few that need the whole read);
+        # flank_scan: the exact-match scan and the segment search for the windows
         names = {_lib_k: n for n, _lib_k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4))}
         kt = {names[k]: ctx.timing_get(k) for k in names}
         dom = max(kt, key=lambda k: kt[k][0])
