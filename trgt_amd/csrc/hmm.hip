@@ -190,6 +190,9 @@ __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, 
   return b == 'A' ? 1 : b == 'T' ? 2 : b == 'C' ? 3 : b == 'G' ? 4 : ((i - 1) & 3) + 1;
 }
 
+// "#ATCG"[code] without a memory access (a string constant is a global load: a round trip per trace-back step)
+__device__ __forceinline__ int hmm_code_char(int code) { return (int)((0x4743544123ull >> (8 * code)) & 0xFFull); }
+
 // Workgroup synchronisation of the Viterbi kernel.  Most motif sets need at most 64 states, i.e. a single wavefront: its lanes run in
 // lockstep and the LDS unit serves one wave's accesses in order, so a compiler-level fence is all that is needed -- whereas
 // __syncthreads() also waits for every global store in flight (the back-pointer column written at the end of each step), a
@@ -455,23 +458,21 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         // per step (it was seven, and an integer division)
         const uint32_t inf = l_info[state];
         const int b = l_stage[(size_t)(idx - c0) * Spad + state];
-        const int qbase = "#ATCG"[code_at(idx)];
+        const int qbase = hmm_code_char(code_at(idx));
         const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
-        if (kind == 1) {  // MotifStart + implied leading deletions (events.rs:42-48)
-          const int dels = nxt - state - 1;
-          edit += dels; ref += dels;
+        // events of this state (events.rs:17-86), branch-free but for the visit record: MotifStart (1) adds the implied leading
+        // deletions, MotifEnd (2) opens a visit, Skip (3) / Mismatch / Ins (5) / Del (6) are edits, Skip / Match-state / Del consume
+        // a reference base
+        const int expected = (int)((inf >> 16) & 0xFFu);
+        const int dels = kind == 1 ? nxt - state - 1 : 0;
+        const int mism = kind == 4 && !(qbase == expected || expected == 'N');  // events.rs:66-73
+        edit += dels + (kind == 3) + mism + (kind == 5) + (kind == 6);
+        ref += dels + (kind == 3) + (kind == 4) + (kind == 6);
+        if (kind == 1) {
           visits[3 * nv + 0] = (vis_t)blk; visits[3 * nv + 1] = (vis_t)idx; visits[3 * nv + 2] = (vis_t)vb1;
           ++nv;
-        } else if (kind == 2) {
-          vb1 = idx;  // bases of this visit are query[.. idx)
-        } else if (kind == 3) {  // Skip
-          ++edit; ++ref;
-        } else if (kind == 4) {  // match state: Match iff query base == motif base or motif base is N (events.rs:66-73)
-          const int expected = (int)((inf >> 16) & 0xFFu);
-          ++ref;
-          if (!(qbase == expected || expected == 'N')) ++edit;
-        } else if (kind == 5) { ++edit; }       // Ins
-        else if (kind == 6) { ++edit; ++ref; }  // Del
+        }
+        vb1 = kind == 2 ? idx : vb1;  // bases of this visit are query[.. idx)
         const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[b * S + state];
         if (inf & 8u) --idx;
         nxt = state;
@@ -515,7 +516,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         else {
           const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
           for (int j = 0; j < mlen; ++j) {
-            const int obs = "#ATCG"[code_at(b0 + j + 1)];
+            const int obs = hmm_code_char(code_at(b0 + j + 1));
             if (mot[j] != 'N' && obs != mot[j]) keep = false;
           }
         }
