@@ -254,7 +254,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* l_lp = sc1 + S;                                             // [2][S] ln transition probabilities of predecessors 0 and 1
   double* l_em = l_lp + 2 * S;                                        // [5][S] ln emission probabilities by symbol code: one LDS read per column instead of a select tree
   uint32_t* l_info = reinterpret_cast<uint32_t*>(l_em + 5 * S);       // [S] what the traceback needs to know about a state, in one word
-  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_info + S);         // [4][S]
+  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_info + S);         // [S][4] (predecessor b of state s at 4 s + b: no multiply in the trace-back)
   int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
   uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
   uint8_t* l_bpcol = l_flags + S;                                     // [S] back-pointers of states evaluated by another lane
@@ -281,7 +281,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
   }
   const uint8_t* const motif_bytes = STAGE ? l_mot : g_motifs;
-  for (int i = tid; i < 4 * S; i += nthr) l_inst[i] = g_inst[i];
+  for (int i = tid; i < 4 * S; i += nthr) l_inst[4 * (i % S) + i / S] = g_inst[i];
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
   for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
@@ -451,13 +451,14 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     hmm_sync(sync_n);
     if (tid == 0) {
       int state = tb_state, idx = tb_idx, np = tb_npath, nv = tb_nvisit, edit = tb_edit, ref = tb_ref, nxt = tb_next, vb1 = tb_vb1;
+      int row = (idx - c0) * Spad;  // offset of column idx in the staged chunk
       while (state != 0 && idx >= c0) {
         if (pbuf && np < pcap) pbuf[pcap - 1 - np] = (uint16_t)state;
         ++np;
         // one word describes the state, and nothing but the predecessor lookup depends on the back-pointer: two LDS round trips
         // per step (it was seven, and an integer division)
         const uint32_t inf = l_info[state];
-        const int b = l_stage[(size_t)(idx - c0) * Spad + state];
+        const int b = l_stage[row + state];
         const int qbase = hmm_code_char(code_at(idx));
         const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
         // events of this state (events.rs:17-86), branch-free but for the visit record: MotifStart (1) adds the implied leading
@@ -473,8 +474,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           ++nv;
         }
         vb1 = kind == 2 ? idx : vb1;  // bases of this visit are query[.. idx)
-        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[b * S + state];
-        if (inf & 8u) --idx;
+        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[4 * state + b];
+        if (inf & 8u) { --idx; row -= Spad; }
         nxt = state;
         state = prv;
       }
