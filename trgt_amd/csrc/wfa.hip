@@ -522,13 +522,14 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     if (ring_bytes + win_bytes <= 96 * 1024 && (seq_need <= ring_bytes || capped)) { a.fast_wcap = (uint32_t)wcap; a.fast_ring_bytes = (uint32_t)((ring_bytes + 15) & ~15ull); lds = (size_t)a.fast_ring_bytes + (size_t)win_bytes; }
   }
   // TRGT's flank-location configuration has an instantiation of its own (wfa_fast.hpp, SPEC)
-  const bool fast_spec = a.fast_koff == 0 && pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tbf < 0 && a.kp.tef < 0 &&
-                         (threads == 256 || threads == 192) && !getenv("TRGT_WFA_NO_SPEC");
   const int tag = L.kernel_tag >= 0 ? L.kernel_tag : (L.timer_slot == TRGT_K_WFA_FLANK_REST ? 1 : 0);
+  const bool flank_pen = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tef < 0 && !getenv("TRGT_WFA_NO_SPEC");
+  const bool fast_spec = flank_pen && a.fast_koff == 0 && a.kp.tbf < 0 && (threads == 256 || threads == 192);
+  const bool win_spec = flank_pen && a.fast_koff != 0 && tag == 2 && threads == 64;  // the windowed launch of trgt_find_spans_batch
   void (*const spec_fn[2][3])(const KArgs) = {{wfa_fast_kernel<256, 0>, wfa_fast_kernel<256, 1>, wfa_fast_kernel<256, 2>},
                                               {wfa_fast_kernel<192, 0>, wfa_fast_kernel<192, 1>, wfa_fast_kernel<192, 2>}};
   void (*const gen_fn[3])(const KArgs) = {wfa_fast_kernel<0, 0>, wfa_fast_kernel<0, 1>, wfa_fast_kernel<0, 2>};
-  void (*const fast_fn)(const KArgs) = fast_spec ? spec_fn[threads == 192 ? 1 : 0][tag] : gen_fn[tag];
+  void (*const fast_fn)(const KArgs) = win_spec ? wfa_fast_kernel<64, 2> : fast_spec ? spec_fn[threads == 192 ? 1 : 0][tag] : gen_fn[tag];
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
   int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));

@@ -116,13 +116,14 @@ struct FastEnd { int status, score, k, off; unsigned long long cells; };
 // free at both ends and the pattern not at all (span_locater.rs:17, genotype.rs:66-80) -- as compile-time constants: the ring
 // geometry, the source-level selects and the termination test fold away, and with them a third of the scalar registers
 // (the general instantiation spills SGPRs to VGPR lanes in the per-level prologue).
-template <int SPEC>  // 0: general; else the compile-time thread count of TRGT's flank configuration (256 or 192)
+template <int SPEC, bool WIN = false>  // SPEC 0: general; else the compile-time thread count of TRGT's flank configuration (256, 192, 64).
+                                       // WIN: the windowed launch -- the same constants but text_begin_free and the ring bias from the job
 __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJob& J, const uint32_t* P4, const uint32_t* T4, uint16_t* ring,
                                                      int wcap, g_u16* A16, uint32_t* gd) {
   FastShared& fs = g_fsh;
   const int tid = threadIdx.x, nT = SPEC ? SPEC : (int)blockDim.x, lane = tid & 63;  // SPEC is launched with SPEC threads only
   const int wave = rfl(tid >> 6), nW = nT >> 6;
-  const int plen = J.plen, tlen = J.tlen, koff = SPEC ? plen + 2 : J.koff;  // plen + 2 (one pad cell each side: kb-1 / kb+1 reads never leave
+  const int plen = J.plen, tlen = J.tlen, koff = SPEC && !WIN ? plen + 2 : J.koff;  // plen + 2 (one pad cell each side: kb-1 / kb+1 reads never leave
                                                                               // the slot) unless the launch bounds the penalty (KArgs::fast_koff)
   const int ak_b = tlen - plen + koff;
   const int x = SPEC ? 2 : pen.x, oe = SPEC ? 6 : pen.o1 + pen.e1, e = SPEC ? 1 : pen.e1, scope = SPEC ? 7 : pen.scope;
@@ -132,7 +133,7 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
   uint16_t* const Dr = Ir + RI * wcap;
   const uint32_t cap = J.cap;
   const int n_slots = J.n_slots, span = SPEC ? 1 : J.span, pef = SPEC ? 0 : J.pef, tef = SPEC ? tlen : J.tef, pbf = SPEC ? 0 : J.pbf,
-            tbf = SPEC ? tlen : J.tbf;
+            tbf = SPEC && !WIN ? tlen : J.tbf;
   const uint32_t PDN = (uint32_t)(koff + 1) | ((uint32_t)(koff - 1) << 16);  // the canonical null wavefront (lo = 1, hi = -1)
   const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)(A16 - HIST_BIAS), 0, -1, 0x00020000);
   // which sources are "the level just finished" (taken from registers) rather than an older one (taken from the LDS ring)
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       J.koff = a.fast_koff ? (int)a.fast_koff : plen + 2;
     }
     PROF_MARK(1);
-    const FastEnd E = wf_run_lds_affine<SPEC>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
+    const FastEnd E = wf_run_lds_affine<SPEC, TAG == 2>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
 #ifdef TRGT_WFA_PROF
     const unsigned long long pf_t2 = pf_t;
 #endif
