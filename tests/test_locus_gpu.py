@@ -353,7 +353,7 @@ def test_cfg3_alleles_to_10kb(oracle, mods):
 def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     # the planner's choices must not show in the results: one launch instead of two for the flank alignments, the general
     # instantiation of the dedicated kernel instead of the compile-time flank configuration, the host genotyper, other numbers of
-    # waves per alignment
+    # waves per alignment, no seeded windows / other numbers of segments for them
     import torch
     locus, synth = mods
     b = synth.generate(96, first_locus=12000)
@@ -361,7 +361,8 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     base = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
     _compare(oracle, locus, b, base, locus.Params(), range(0, 96, 4))
     for env, val in (("TRGT_WFA_ONE_LAUNCH", "1"), ("TRGT_WFA_NO_SPEC", "1"), ("TRGT_HOST_GENOTYPER", "1"), ("TRGT_HEAVY_THREADS", "256"),
-                     ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192")):
+                     ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192"), ("TRGT_WFA_NO_WINDOW", "1"), ("TRGT_WIN_SEGMENTS", "4"),
+                     ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128")):
         monkeypatch.setenv(env, val)
         out = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
         monkeypatch.delenv(env)
