@@ -3,7 +3,7 @@ with a random number of substitutions (0-12), insertions and deletions of random
 distances, periodic flanks, flanks clipped by the ends of the read.  Every locus goes through trgt_locus_batch (reads in HBM) and
 through the oracle; records are compared as in parity_sweep.py.
 
-    python tests/tools/window_fuzz.py [loci_per_round=3000] [rounds=6] [seed=1]
+    python tests/tools/window_fuzz.py [loci_per_round=3000] [rounds=6] [seed=1] [x,o,e]
 """
 import os
 import sys
@@ -73,6 +73,7 @@ def main():
     n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    scoring = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 5, 1)
     threads = min(os.cpu_count() or 1, 128)
     ctx = _lib.Context(0)
     bad = total = 0
@@ -80,9 +81,9 @@ def main():
     for r in range(rounds):
         rng = np.random.default_rng(seed * 1000 + r)
         b = locus.pack([make_locus(rng) for _ in range(n_loci)])
-        out = locus.run_batch(b, locus.Params(), ctx, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda())
+        out = locus.run_batch(b, locus.Params(aln_scoring=scoring), ctx, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda())
         got = gpu_records(b, out)
-        ref = oracle.locus_records(b, 0, n_loci, threads)
+        ref = oracle.locus_records(b, 0, n_loci, threads, scoring=scoring)
         nb = sum(g != x for g, x in zip(got, ref))
         if nb:
             l = next(i for i in range(n_loci) if got[i] != ref[i])
@@ -90,7 +91,7 @@ def main():
         bad += nb
         total += n_loci
         print("[window fuzz] round %d: %d loci, %d mismatches" % (r, n_loci, nb), flush=True)
-    print("RESULT window fuzz: loci=%d mismatches=%d seed=%d" % (total, bad, seed))
+    print("RESULT window fuzz: loci=%d mismatches=%d seed=%d scoring=%s" % (total, bad, seed, scoring))
     return 1 if bad else 0
 
 
