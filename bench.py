@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 
 
-def cpu_baseline(batch, seconds_budget=15.0, max_loci=4000):
+def cpu_baseline(batch, seconds_budget=20.0, max_loci=8000):
     """The CPU oracle (port of the reference algorithms, single thread) timed on a bounded sample of the same batch."""
     from oracle import binding as orc
     orc.lib()
