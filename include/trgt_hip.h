@@ -78,7 +78,7 @@ int trgt_hip_set_stream(trgt_hip_ctx* ctx, void* hip_stream);
 int trgt_hip_set_workspace_limit(trgt_hip_ctx* ctx, uint64_t bytes);
 
 /* ---- kernel timing (HIP events on the ctx stream, for bench.py's roofline) ---- */
-#define TRGT_K_FLANK_SCAN 0   /* exact flank search            */
+#define TRGT_K_FLANK_SCAN 0   /* exact flank search (+ the segment search for the seeded windows of the fallback alignments) */
 #define TRGT_K_WFA 1          /* wavefront alignment kernel: trgt_wfa_batch / consensus alignments */
 #define TRGT_K_HMM 2          /* Viterbi + traceback + decode   */
 #define TRGT_K_WFA_FLANK 3    /* wavefront alignment kernel: flank fallback inside trgt_find_spans_batch -- the launch over the
