@@ -142,18 +142,29 @@ class BatchOutputs:
             "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off", "purity", "stats")])
 
 
+_CIN_KEYS = ("lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off", "set_motif_begin", "ploidy",
+             "locus_read_begin", "read_off", "read_len", "genotyper", "read_qual")
+
+
 def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, reads_dev=None):
     """trgt_locus_batch on a packed batch.  Returns the (reusable) BatchOutputs."""
     ctx = ctx or _lib.context()
     out = outputs or BatchOutputs(batch)
     p = _lib.ptr
-    cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
-        flank_dev if flank_dev is not None else batch["flank_blob"], batch["lf_off"], batch["lf_len"], batch["rf_off"],
-        batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
-        batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
-        reads_dev if reads_dev is not None else batch["read_blob"], batch["read_off"], batch["read_len"])],
-        p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
-        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
+    flank, reads = flank_dev if flank_dev is not None else batch["flank_blob"], reads_dev if reads_dev is not None else batch["read_blob"]
+    key = (p(flank).value, p(reads).value) + tuple(id(batch.get(k)) for k in _CIN_KEYS)
+    cached = batch.get("_cin")  # the input struct of a batch is rebuilt only when the blobs move (20 pointer conversions per call otherwise); keyed by the identity of every array
+    if cached is None or cached[0] != key:
+        cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
+            flank, batch["lf_off"], batch["lf_len"], batch["rf_off"],
+            batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
+            batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
+            reads, batch["read_off"], batch["read_len"])],
+            p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
+            p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
+        cached = (key, cin)
+        batch["_cin"] = cached
+    cin = cached[1]
     lp = _lib.LocusParams(params.search_flank_len, params.min_flank_id_frac, params.max_depth, params.aln_scoring[0],
                           params.aln_scoring[1], params.aln_scoring[2], params.host_threads, params.min_read_qual)
     ctx.check(_lib.lib().trgt_locus_batch(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out)))
