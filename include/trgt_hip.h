@@ -84,7 +84,9 @@ int trgt_hip_set_workspace_limit(trgt_hip_ctx* ctx, uint64_t bytes);
 #define TRGT_K_WFA_FLANK 3    /* wavefront alignment kernel: flank fallback inside trgt_find_spans_batch -- the launch over the
                                  reads too short to span their locus (the expensive alignments), or the only launch */
 #define TRGT_K_WFA_FLANK_REST 4 /* ... the launch(es) over the remaining fallback alignments */
-#define TRGT_K_COUNT 5
+#define TRGT_K_WFA_FILTER 5   /* register-resident pre-filter of those expensive alignments (penalty + match bound, no back-trace);
+                                 TRGT_K_WFA_FLANK then covers only the alignments the filter keeps */
+#define TRGT_K_COUNT 6
 int trgt_hip_timing_enable(trgt_hip_ctx* ctx, int on);
 int trgt_hip_timing_reset(trgt_hip_ctx* ctx);
 /* accumulated device time (ms), number of launches, and DP work items (wavefront offsets / Viterbi cells) */
@@ -144,6 +146,20 @@ int trgt_find_spans_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t 
                           const uint64_t* locus_read_begin,
                           const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len,
                           int32_t* span_start, int32_t* span_end, uint8_t* lf_hit, uint8_t* rf_hit);
+
+/* Pre-filter of the fallback alignments of find_spans (span_locater.rs:14-22), as trgt_find_spans_batch runs it in front of the
+ * back-tracing kernel.  Job j = align_ends_free(pattern j, 0, 0, text j, |text|, |text|) with gap-affine (mism, gapo, gape),
+ * which must be (2, 5, 1) (--aln-scoring default; anything else: TRGT_ERR_UNSUPPORTED).  Outputs (each may be NULL):
+ *   score[j]        the optimal alignment score (-penalty), exactly WFA2-lib's; INT32_MIN if the job was not judged
+ *   match_bound[j]  an upper bound on count_matches() of the alignment the reference's back-trace returns (-1: not judged)
+ *   keep[j]         1 iff match_bound >= min_matches, or the job was not judged (pattern longer than 254, text shorter than the
+ *                   pattern or longer than the kernel's diagonals, sequence bytes 0x01 / 0x02 / 0xFF): only kept jobs need the
+ *                   back-trace -- for the others count_matches() < min_matches is certain
+ *   offsets_computed  (one value) wavefront offsets computed, equal to WFA2-lib's count for the judged jobs */
+int trgt_flank_filter_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t n_jobs,
+                            const uint8_t* seqs, const uint64_t* pat_off, const uint32_t* pat_len,
+                            const uint64_t* txt_off, const uint32_t* txt_len, int32_t min_matches,
+                            int32_t* score, int32_t* match_bound, uint8_t* keep, int64_t* offsets_computed);
 
 /* ------------------------------------------------------------------ HMM */
 /* n_sets motif sets (one per locus): set s owns motifs [set_motif_begin[s], set_motif_begin[s+1]);

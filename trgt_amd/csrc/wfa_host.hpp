@@ -42,6 +42,30 @@ struct WfaLaunch {  // everything device-resident
 // accumulated in device memory at ctx->last_wfa_cells_dev.
 int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L);
 
+// ---- register-resident pre-filter of the flank fallback alignments (wfa_reg.hip) ----
+struct FilterArgs {  // by-value kernel argument
+  const JobDev* jobs; const uint32_t* n_jobs_dev; uint32_t n_jobs;
+  const uint8_t* pat_base; const uint8_t* txt_base;
+  unsigned int* counter;
+  int32_t min_matches;                      // an alignment is kept iff its match bound >= min_matches (or it could not be judged)
+  JobDev* keep_jobs; uint32_t* keep_count;  // kept alignments, appended (NULL: none wanted)
+  int32_t* score; int32_t* bound; uint8_t* keep;  // optional, indexed by JobDev::out_index
+  unsigned long long* cells_out;
+};
+struct FilterLaunch {
+  const JobDev* jobs_dev = nullptr; int64_t n_jobs_host = 0; const uint32_t* n_jobs_dev = nullptr;
+  const uint8_t* pat_base = nullptr; const uint8_t* txt_base = nullptr;
+  int64_t max_plen = 0, max_tlen = 0;
+  int32_t min_matches = 0;
+  JobDev* keep_jobs = nullptr; uint32_t* keep_count = nullptr;
+  int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;
+  int timer_slot = TRGT_K_WFA_FILTER;
+};
+// Longest text the filter can judge for this pattern length (0: the filter does not apply); longer texts are kept unseen.
+int flank_filter_max_tlen(int flank_len);
+// Enqueue the filter on the ctx stream (asynchronous); offsets computed are accumulated at ctx->last_filter_cells_dev.
+int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L);
+
 // Run-length CIGARs of a whole batch in one dense array: job j = data[off[j] .. off[j + 1]) (len << 4 | code, as cigar_get_CIGAR).
 struct PackedCigars { std::vector<uint32_t> data; std::vector<uint64_t> off; };
 // trgt_wfa_batch with an optional dense CIGAR result (packed != nullptr replaces cigar / cigar_off / cigar_len).

@@ -360,3 +360,34 @@ class WFAligner:
             out.append("%d%s" % (j - i, ops[i]))
             i = j
         return "".join(out)
+
+
+def flank_filter_batch(patterns, texts, min_matches, scoring=(2, 5, 1), ctx=None):
+    """trgt_flank_filter_batch: the pre-filter trgt_find_spans_batch runs in front of the back-tracing kernel
+    (span_locater.rs:14-22).  Per job: the exact optimal score of align_ends_free(pattern, 0, 0, text, |text|, |text|),
+    an upper bound on count_matches() of the reference's alignment, keep = bound >= min_matches (or "not judged").
+    Returns dict(score, bound, keep, offsets)."""
+    ctx = ctx or _lib.context()
+    n = len(patterns)
+    pats = [bytes(x) for x in patterns]
+    txts = [bytes(x) for x in texts]
+    plen = np.array([len(x) for x in pats], np.uint32)
+    tlen = np.array([len(x) for x in txts], np.uint32)
+    blob = b"".join(pats) + b"".join(txts)
+    pat_off = np.zeros(n, np.uint64)
+    pat_off[1:] = np.cumsum(plen[:-1], dtype=np.uint64)
+    txt_off = np.zeros(n, np.uint64)
+    txt_off[1:] = np.cumsum(tlen[:-1], dtype=np.uint64)
+    txt_off += np.uint64(int(plen.sum()))
+    seqs = np.frombuffer(blob, np.uint8).copy() if blob else np.zeros(1, np.uint8)
+    sp = _lib.SpanParams()
+    sp.flank_len, sp.min_flank_id_frac = 0, 0.0
+    sp.mism, sp.gapo, sp.gape = scoring
+    score = np.zeros(n, np.int32)
+    bound = np.zeros(n, np.int32)
+    keep = np.zeros(n, np.uint8)
+    offsets = C.c_int64(0)
+    q = _lib.ptr
+    ctx.check(_lib.lib().trgt_flank_filter_batch(ctx.handle, C.byref(sp), n, q(seqs), q(pat_off), q(plen), q(txt_off), q(tlen),
+                                                 int(min_matches), q(score), q(bound), q(keep), C.byref(offsets)))
+    return dict(score=score, bound=bound, keep=keep, offsets=offsets.value)
