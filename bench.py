@@ -138,7 +138,7 @@ def main():
         # wfa_flank: the launch over the alignments of reads too short to span their locus (95 % of the wavefront offsets);
         # wfa_flank_rest: the launches over the other flank alignments (on seeded windows, then the few that need the whole read);
         # flank_scan: the exact-match scan and the segment search for the windows
-        names = {_lib_k: n for n, _lib_k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4))}
+        names = {_lib_k: n for n, _lib_k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4), ("wfa_filter", 5))}
         kt = {names[k]: ctx.timing_get(k) for k in names}
         dom = max(kt, key=lambda k: kt[k][0])
         ms, launches, cells = kt[dom]
@@ -150,13 +150,18 @@ def main():
             mean_read = float(batch["read_len"].mean())
             bytes_per_launch = 2.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)
             survey_bytes_per_launch = 4.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)  # SURVEY 8(d) prices an offset at 4 B
+        elif dom == "wfa_filter":   # history-free: sequences in, a verdict out; SURVEY 8(d) prices the DP state it keeps in registers at 4 B / offset
+            jobs = int(stats[14])
+            mean_read = float(batch["read_len"].mean())
+            bytes_per_launch = jobs * (250 + mean_read + 20)
+            survey_bytes_per_launch = 4.0 * cells / max(launches, 1) + bytes_per_launch
         elif dom == "hmm_viterbi":  # 1 B per back-pointer cell + allele in + annotation out
             bytes_per_launch = 1.0 * cells / max(launches, 1) + float(out.allele_len.sum()) * 2
         elif dom == "flank_scan":   # every read byte once + 4 B per (read, side)
             bytes_per_launch = float(batch["read_len"].sum()) + 8.0 * n_reads
         else:
             bytes_per_launch = 4.0 * cells / max(launches, 1)
-        if dom != "wfa_flank":
+        if dom not in ("wfa_flank", "wfa_filter"):
             survey_bytes_per_launch = bytes_per_launch
         traffic = None  # measured HBM bytes per launch of the same kernel / workload, when a PMC profile is committed
         try:
@@ -191,7 +196,7 @@ def main():
                                    "hmm_host_visible": round(stats[6] / 1e6, 2), "host_glue": round(stats[7] / 1e6, 2),
                                    "total": round(stats[8] / 1e6, 2)},
             "work_per_step": {"flank_wfa_jobs": int(stats[0]), "flank_wfa_jobs_first_launch": int(stats[14]), "consensus_jobs": int(stats[1]), "spanning_reads": int(stats[2]),
-                              "hmm_jobs": int(stats[3])},
+                              "hmm_jobs": int(stats[3]), "filter_kept": int(stats[16]), "filter_offsets": int(stats[17])},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(batch)

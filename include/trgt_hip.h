@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 2
+#define TRGT_HIP_ABI_VERSION 3
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -228,7 +228,7 @@ typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x 
   int32_t* spans3; const uint64_t* span_off; uint32_t* n_spans;   /* span_off[2l+a], capacity allele_cap[l]+1 */
   uint32_t* motif_counts; const uint64_t* count_off;              /* count_off[2l+a] */
   double* purity;                           /* [2 per locus] */
-  int64_t* stats;                           /* optional [16]: see DESIGN.md */
+  int64_t* stats;                           /* optional [24]: see DESIGN.md */
 } trgt_locus_batch_out;
 
 int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,

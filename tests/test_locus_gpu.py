@@ -16,14 +16,14 @@ def mods():
 def _run_both(locus, b, params=None):
     """trgt_locus_batch three ways -- host glue for every locus (TRGT_HOST_GENOTYPER), reads on the host with the device genotyper
     working on the uploaded copy, reads resident in HBM -- all must give the oracle's results."""
-    import os
     import torch
+    from trgt_amd import _lib
     params = params or locus.Params()
-    os.environ["TRGT_HOST_GENOTYPER"] = "1"
+    hctx = _lib.context_with_env(TRGT_HOST_GENOTYPER=1)  # (planner knobs are read when a context is created)
     try:
-        out = locus.run_batch(b, params)
+        out = locus.run_batch(b, params, ctx=hctx)
     finally:
-        del os.environ["TRGT_HOST_GENOTYPER"]
+        hctx.close()
     yield "host glue", out
     yield "host reads", locus.run_batch(b, params)
     reads_dev = torch.from_numpy(b["read_blob"]).cuda()
@@ -362,10 +362,13 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     _compare(oracle, locus, b, base, locus.Params(), range(0, 96, 4))
     for env, val in (("TRGT_WFA_ONE_LAUNCH", "1"), ("TRGT_WFA_NO_SPEC", "1"), ("TRGT_HOST_GENOTYPER", "1"), ("TRGT_HEAVY_THREADS", "256"),
                      ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192"), ("TRGT_WFA_NO_WINDOW", "1"), ("TRGT_WIN_SEGMENTS", "4"),
-                     ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128")):
-        monkeypatch.setenv(env, val)
-        out = locus.run_batch(b, flank_dev=fd, reads_dev=rd)
-        monkeypatch.delenv(env)
+                     ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128"), ("TRGT_WFA_NO_FILTER", "1"), ("TRGT_FILTER_PER_CU", "3")):
+        from trgt_amd import _lib
+        vctx = _lib.context_with_env(**{env: val})
+        try:
+            out = locus.run_batch(b, flank_dev=fd, reads_dev=rd, ctx=vctx)
+        finally:
+            vctx.close()
         env = env + "=" + val
         for f in ("span_start", "span_end", "n_alleles", "allele_len", "ci", "num_spanning", "classification", "read_rank", "n_spans"):
             assert np.array_equal(getattr(out, f), getattr(base, f)), (env, f)

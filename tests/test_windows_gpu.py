@@ -37,14 +37,14 @@ def _locus(rng, reads_fn, n_reads=12, periodic=None):
     return dict(left_flank=lf, right_flank=rf, tr=tr, motifs=[b"CAG"], ploidy=2, reads=reads)
 
 
-def _check(oracle, loci):
+def _check(oracle, loci, ctx=None):
     import torch
     from trgt_amd import locus
     from test_locus_gpu import _compare
     b = locus.pack(loci)
     p = locus.Params()
-    outs = [("host reads", locus.run_batch(b, p)),
-            ("device", locus.run_batch(b, p, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda()))]
+    outs = [("host reads", locus.run_batch(b, p, ctx=ctx)),
+            ("device", locus.run_batch(b, p, ctx=ctx, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda()))]
     for name, out in outs:
         _compare(oracle, locus, b, out, p, range(len(loci)))
     return b, outs[1][1]
@@ -130,8 +130,12 @@ def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
         l = _sub(rng, lf, [10 + 23 * j for j in range(i % 10)])    # 0..9 mismatches: penalties 0..18 (the argument covers up to 15)
         return rand_dna(rng, 300) + l + tr + _sub(rng, rf, [100]) + rand_dna(rng, 300)
 
-    monkeypatch.setenv("TRGT_WFA_DEBUG", "1")
-    _check(oracle, [_locus(rng, reads_fn, n_reads=16) for _ in range(4)])
+    from trgt_amd import _lib
+    dctx = _lib.context_with_env(TRGT_WFA_DEBUG=1)  # (planner knobs are read when a context is created)
+    try:
+        _check(oracle, [_locus(rng, reads_fn, n_reads=16) for _ in range(4)], ctx=dctx)
+    finally:
+        dctx.close()
     err = capfd.readouterr().err
     line = [l for l in err.splitlines() if l.startswith("[spans]")][-1]
     nums = [int(t) for t in line.replace(",", " ").replace("(", " ").replace(")", " ").split() if t.isdigit()]

@@ -75,9 +75,8 @@ def main():
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     scoring = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 5, 1)
     threads = min(os.cpu_count() or 1, 128)
-    ctx = _lib.Context(0)
+    ctx = _lib.context_with_env(TRGT_WFA_DEBUG=1)
     bad = total = 0
-    os.environ["TRGT_WFA_DEBUG"] = "1"
     for r in range(rounds):
         rng = np.random.default_rng(seed * 1000 + r)
         b = locus.pack([make_locus(rng) for _ in range(n_loci)])

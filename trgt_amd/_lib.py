@@ -174,6 +174,22 @@ class Context:
             pass
 
 
+def context_with_env(device=0, **env):
+    """A NEW context created while the given TRGT_* planner knobs are set in the environment: the library reads them once, in
+    trgt_hip_create (none of them changes a result; the parity tests use them to pin every planner path)."""
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        return Context(device)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def context(device=0):
     """Process-wide context per device."""
     if device not in _CTX:

@@ -15,7 +15,28 @@
 
 #include "../../include/trgt_hip.h"
 
+// Planner knobs: none of them changes a result.  They are read from the environment ONCE, when the context is created
+// (trgt_hip_create), so that the parity tests can pin every planner path against the oracle; a release build carries no switch
+// that skips work (TRGT_DBG_SKIP_BT exists only under `make DEV=1`).
+struct trgt_knobs {
+  int flank_threads = 256;   // TRGT_FLANK_THREADS: threads per flank alignment of the back-tracing kernel
+  int heavy_threads = 0;     // TRGT_HEAVY_THREADS: ... of its launch over the expensive alignments (0: 192 when flank_threads == 256)
+  int win_threads = 64;      // TRGT_WIN_THREADS: ... of the windowed launch
+  int win_segments = 8;      // TRGT_WIN_SEGMENTS: 4 / 6 / 8 segments for the window search
+  int grid_per_cu = 0;       // TRGT_WFA_GRID_PER_CU: persistent workgroups per CU of the dedicated kernel (0: occupancy query)
+  int filter_per_cu = 0;     // TRGT_FILTER_PER_CU: persistent waves per CU of the pre-filter (0: occupancy query)
+  bool one_launch = false;   // TRGT_WFA_ONE_LAUNCH: all flank alignments in one launch
+  bool no_spec = false;      // TRGT_WFA_NO_SPEC: general instantiation of the dedicated kernel
+  bool no_window = false;    // TRGT_WFA_NO_WINDOW: no seeded windows
+  bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
+  bool host_genotyper = false;  // TRGT_HOST_GENOTYPER: host glue for every locus
+  bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
+  bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
+  bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
+};
+
 struct trgt_hip_ctx {
+  trgt_knobs knobs;
   int device = -1;
   hipStream_t stream = nullptr;
   bool own_stream = false;

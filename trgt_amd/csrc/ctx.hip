@@ -29,6 +29,20 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
     return TRGT_ERR_NO_DEVICE;
   }
   trgt_hip_ctx* c = new trgt_hip_ctx();
+  {
+    trgt_knobs& k = c->knobs;
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    auto flag = [](const char* name) { const char* e = getenv(name); return e != nullptr && *e != 0 && std::strcmp(e, "0") != 0; };
+    k.flank_threads = num("TRGT_FLANK_THREADS", k.flank_threads); k.heavy_threads = num("TRGT_HEAVY_THREADS", 0);
+    k.win_threads = num("TRGT_WIN_THREADS", k.win_threads); k.win_segments = num("TRGT_WIN_SEGMENTS", k.win_segments);
+    k.grid_per_cu = num("TRGT_WFA_GRID_PER_CU", 0); k.filter_per_cu = num("TRGT_FILTER_PER_CU", 0);
+    k.one_launch = flag("TRGT_WFA_ONE_LAUNCH"); k.no_spec = flag("TRGT_WFA_NO_SPEC"); k.no_window = flag("TRGT_WFA_NO_WINDOW");
+    k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.debug = flag("TRGT_WFA_DEBUG");
+    k.timeline = flag("TRGT_TIMELINE");
+#ifdef TRGT_DEV_BUILD
+    k.skip_bt = flag("TRGT_DBG_SKIP_BT");
+#endif
+  }
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

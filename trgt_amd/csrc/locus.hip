@@ -278,10 +278,10 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
   // a few microseconds of work per locus: more threads only add wake-up cost.  The device genotyper leaves the
   // host little to do (4 threads measure the same as 32, and large pools produce the occasional late wake-up)
-  threads = std::min(threads, !getenv("TRGT_HOST_GENOTYPER") && p->min_read_qual >= 0.9 ? 8 : 32);
+  threads = std::min(threads, !c->knobs.host_genotyper && p->min_read_qual >= 0.9 ? 8 : 32);
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
-  const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+  const bool tl_on = c->knobs.timeline;
 #define TL(name) do { if (tl_on) fprintf(stderr, "[tl] %-28s %7.2f ms\n", name, (double)(now_ns() - t0) / 1e6); } while (0)
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_flank_heavy = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
@@ -352,7 +352,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   // filter_impure_trs (tr.rs:37-50) sits between get_spanning_reads and the genotyper: with it on, every locus takes the host path
   const bool impure_filter = p->min_read_qual < 0.9;
   // (host reads are uploaded for the flank scan anyway: the device genotyper then works on that copy just as well)
-  const bool dev_gt = !getenv("TRGT_HOST_GENOTYPER") && !impure_filter;
+  const bool dev_gt = !c->knobs.host_genotyper && !impure_filter;
   auto is_cluster = [&](int64_t l) { return in->genotyper && in->genotyper[l] == 1; };
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
@@ -419,6 +419,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
   if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
+  ((uint64_t*)h_cells)[2] = ((uint64_t*)h_cells)[3] = 0;  // pre-filter: offsets computed, alignments kept
+  if (c->last_filter_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync((uint64_t*)h_cells + 2, c->last_filter_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
   if (dev_gt) {
     gt::GtArgs ga;
     ga.reads = d_reads; ga.read_off = d_roff; ga.read_len = d_rlen; ga.locus_read_begin = g.lrb;
@@ -675,6 +677,7 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   if (c->timing) {  // [0] all flank alignments, [1] those of the first (dominant) launch
     c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)((uint64_t*)h_cells)[1];
     c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(((uint64_t*)h_cells)[0] - ((uint64_t*)h_cells)[1]);
+    c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)((uint64_t*)h_cells)[2];
   }
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
@@ -879,6 +882,8 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
     for (int i = 0; i < 5; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
     s[14] = stat_flank_heavy; s[15] = stat_ed_jobs;
+    s[16] = (int64_t)((uint64_t*)h_cells)[3]; s[17] = (int64_t)((uint64_t*)h_cells)[2];  // pre-filter: alignments kept, offsets computed
+    for (int i = 18; i < 24; ++i) s[i] = 0;
   }
   return TRGT_OK;
 }

@@ -229,7 +229,7 @@ struct ClusterBatch {
 
   int run() {
     if (loci.empty()) return TRGT_OK;
-    const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+    const bool tl_on = c->knobs.timeline;
     const int64_t tl0 = now_ns_cluster();
 #define CTL(name) do { if (tl_on) fprintf(stderr, "[tl]   cluster %-22s +%7.2f ms\n", name, (double)(now_ns_cluster() - tl0) / 1e6); } while (0)
     // the batch blob: all segments once

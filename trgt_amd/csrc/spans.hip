@@ -17,6 +17,7 @@
 //                          window of the read where one can be proven sufficient; then the rest against the whole read.
 //   3. span_combine_kernel per read: threshold test and (lf.end, rf.start) combination.
 #include <algorithm>
+#include <cmath>
 
 #include "wfa_host.hpp"
 
@@ -380,12 +381,12 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   int32_t win_s0 = 0, win_q = 0, win_margin = 0, win_spread = 0, win_m = WIN_SEGMENTS_DEFAULT; uint32_t win_tlen = 0;
   void *d_winjobs = nullptr, *d_restjobs = nullptr, *d_score = nullptr;
   {
-    int m = getenv("TRGT_WIN_SEGMENTS") ? atoi(getenv("TRGT_WIN_SEGMENTS")) : WIN_SEGMENTS_DEFAULT;
+    int m = c->knobs.win_segments;
     if (m != 4 && m != 6 && m != 8) m = WIN_SEGMENTS_DEFAULT;
     win_m = m;
     const int q = p.flank_len / m, x = p.mism, o = p.gapo, e = p.gape;
-    const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < (has_long ? long_tlen : max_read_len) && !getenv("TRGT_WFA_ONE_LAUNCH");
-    const bool ok = two_launches && !getenv("TRGT_WFA_NO_WINDOW") && q >= 12 && x >= 1 && e >= 1 && o >= 0 &&
+    const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < (has_long ? long_tlen : max_read_len) && !c->knobs.one_launch;
+    const bool ok = two_launches && !c->knobs.no_window && q >= 12 && x >= 1 && e >= 1 && o >= 0 &&
                     q * e >= x && o + 2 * e >= 2 * x && o + e >= x;
     if (ok) {
       win_s0 = x * m - 1;
@@ -420,20 +421,41 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   L.pat_base = d_flank; L.txt_base = d_reads;
   const uint32_t short_max = has_long ? long_tlen : max_read_len;
   L.max_plen = p.flank_len; L.max_tlen = short_max; L.max_sum = (int64_t)p.flank_len + short_max;
-  L.threads = getenv("TRGT_FLANK_THREADS") ? atoi(getenv("TRGT_FLANK_THREADS")) : 256;
+  L.threads = c->knobs.flank_threads;
   L.timer_slot = TRGT_K_WFA_FLANK;
   L.n_match = (int32_t*)d_nmatch; L.span4 = (uint32_t*)d_span4;
   // Two launches.  The front of the list (reads too short to span their locus: 95 % of the wavefront offsets) holds short texts
   // only, so its launch is planned for heavy_tlen_max: a smaller LDS ring per alignment and one more resident workgroup per CU
   // (occupancy is what this latency-bound kernel lives on: 16.9 -> 15.1 ms from 4 to 5 per CU).  The rest follows at the full size.
-  const bool split = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < short_max && !getenv("TRGT_WFA_ONE_LAUNCH");
+  const bool split = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < short_max && !c->knobs.one_launch;
+  c->last_filter_cells_dev = nullptr;
   if (split) {
     WfaLaunch LH = L;
     LH.n_jobs2_dev = nullptr; LH.jobs_cap = 0;
     LH.max_tlen = heavy_tlen_max; LH.max_sum = (int64_t)p.flank_len + heavy_tlen_max;
+    // The expensive alignments first meet the register-resident pre-filter (wfa_reg.hip): exact penalty and an upper bound on
+    // count_matches() without history or back-trace; only those whose bound reaches the threshold (a quarter of the jobs, 5 % of
+    // the wavefront offsets on the bench workload) are aligned again by the back-tracing kernel.  span_locater.rs:18-22 does
+    // nothing with the others but drop them.
+    const double thr = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;
+    int64_t min_matches = thr > 0 ? (int64_t)std::ceil(thr) : 0;
+    while (min_matches > 0 && (double)(min_matches - 1) >= thr) --min_matches;
+    while ((double)min_matches < thr) ++min_matches;
+    const bool use_filter = p.mism == 2 && p.gapo == 5 && p.gape == 1 && (int64_t)heavy_tlen_max <= flank_filter_max_tlen(p.flank_len) &&
+                            heavy_tlen_max >= (uint32_t)p.flank_len && min_matches <= 254 && !c->knobs.no_filter;
+    if (use_filter) {
+      void* d_keepjobs = nullptr;
+      if ((rc = dev_get(c, S_FS_KEEPJOBS, n_jobs * sizeof(JobDev), &d_keepjobs))) return rc;
+      FilterLaunch FL;
+      FL.jobs_dev = (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs; FL.n_jobs_dev = (const uint32_t*)d_count;
+      FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = heavy_tlen_max;
+      FL.min_matches = (int32_t)min_matches; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
+      if ((rc = flank_filter_launch(c, FL))) return rc;
+      LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + 6;
+    }
     // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
     // wave and level), and a wave without a strip still pays the per-level prologue and barrier (7.39 -> 7.21 ms)
-    LH.threads = getenv("TRGT_HEAVY_THREADS") ? atoi(getenv("TRGT_HEAVY_THREADS")) : (L.threads == 256 ? 192 : L.threads);
+    LH.threads = c->knobs.heavy_threads > 0 ? c->knobs.heavy_threads : (L.threads == 256 ? 192 : L.threads);
     if ((rc = wfa_launch(c, wp, LH))) return rc;
     // offsets of the first launch, kept next to the running total (cells[1]): the roofline of the dominant launch counts its own
     TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
@@ -458,7 +480,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       LW.score = (int32_t*)d_score; LW.kernel_tag = 2; LW.max_score = win_s0;
       // only the diagonals that can matter start the alignment: a wavefront of 2 margin + spread + 1 diagonals instead of one per base
       // of the window, i.e. one strip of one wave per level
-      LW.threads = getenv("TRGT_WIN_THREADS") ? atoi(getenv("TRGT_WIN_THREADS")) : 64;
+      LW.threads = c->knobs.win_threads;
       trgt_wfa_params wpw = wp;
       wpw.text_begin_free = 2 * win_margin + win_spread;
       if ((rc = wfa_launch(c, wpw, LW))) return rc;
@@ -488,7 +510,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   ca.span_start = d_span_start; ca.span_end = d_span_end; ca.lf_hit = d_lf_hit; ca.rf_hit = d_rf_hit;
   hipLaunchKernelGGL(span_combine_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, ca);
   TRGT_HIP_TRY(c, hipGetLastError());
-  if (getenv("TRGT_WFA_DEBUG")) {  // (synchronises: developer output only)
+  if (c->knobs.debug) {  // (synchronises: developer output only)
     uint32_t h[8];
     TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
@@ -559,9 +581,13 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
                               o_e.dev, o_l.dev, o_r.dev, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
   if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
-  unsigned long long cells[2] = {0, 0};  // total, first launch
+  unsigned long long cells[2] = {0, 0}, fcells[2] = {0, 0};  // total, first launch; pre-filter: offsets, alignments kept
   if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_filter_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(fcells, c->last_filter_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->timing) { c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells[1]; c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(cells[0] - cells[1]); }
+  if (c->timing) {
+    c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells[1]; c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(cells[0] - cells[1]);
+    c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)fcells[0];
+  }
   return TRGT_OK;
 }

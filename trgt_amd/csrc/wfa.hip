@@ -508,7 +508,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
   size_t lds = a.lds_seq_cap;
   a.fast_wcap = 0; a.fast_ring_bytes = 0; a.fast_koff = 0;
-  a.fast_dbg = getenv("TRGT_DBG_SKIP_BT") ? 1 : 0;
+  a.fast_dbg = c->knobs.skip_bt ? 1 : 0;
   if (p.metric == 3 && p.heuristic == 0 && !a.kp.biwfa && a.lds_seq_cap > 0 && mt + score_bound < 65000 && threads % 64 == 0 && threads <= 256) {
     // LDS fast path (wfa_fast.hpp): ring of the live wavefronts as 16-bit offsets
     uint64_t wcap = ((uint64_t)msum + 8 + 7) & ~7ull;
@@ -523,7 +523,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   // TRGT's flank-location configuration has an instantiation of its own (wfa_fast.hpp, SPEC)
   const int tag = L.kernel_tag >= 0 ? L.kernel_tag : (L.timer_slot == TRGT_K_WFA_FLANK_REST ? 1 : 0);
-  const bool flank_pen = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tef < 0 && !getenv("TRGT_WFA_NO_SPEC");
+  const bool flank_pen = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tef < 0 && !c->knobs.no_spec;
   const bool fast_spec = flank_pen && a.fast_koff == 0 && a.kp.tbf < 0 && (threads == 256 || threads == 192);
   const bool win_spec = flank_pen && a.fast_koff != 0 && tag == 2 && threads == 64;  // the windowed launch of trgt_find_spans_batch
   void (*const spec_fn[2][3])(const KArgs) = {{wfa_fast_kernel<256, 0>, wfa_fast_kernel<256, 1>, wfa_fast_kernel<256, 2>},
@@ -540,8 +540,8 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fast_fn, threads, lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
     int64_t per_cu = occ;
-    if (const char* e = getenv("TRGT_WFA_GRID_PER_CU")) per_cu = atoi(e);
-    if (getenv("TRGT_WFA_DEBUG")) fprintf(stderr, "[wfa] fast kernel lds=%zu occupancy=%d per_cu=%lld threads=%d\n", lds, occ, (long long)per_cu, threads);
+    if (c->knobs.grid_per_cu > 0) per_cu = c->knobs.grid_per_cu;
+    if (c->knobs.debug) fprintf(stderr, "[wfa] fast kernel lds=%zu occupancy=%d per_cu=%lld threads=%d\n", lds, occ, (long long)per_cu, threads);
     grid_blocks = std::min<int64_t>(grid_blocks, (int64_t)c->num_cus * per_cu);
   }
   const dim3 grid((unsigned)grid_blocks), block((unsigned)threads);
@@ -617,7 +617,7 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: cigar/ops need their offset and length arrays");
   if (packed) { packed->data.clear(); packed->off.assign((size_t)n_jobs + 1, 0); }
   if (n_jobs == 0) return TRGT_OK;
-  const bool tl_on = getenv("TRGT_TIMELINE") != nullptr;
+  const bool tl_on = c->knobs.timeline;
   const auto tl0 = std::chrono::steady_clock::now();
 #define WTL(name) do { if (tl_on) fprintf(stderr, "[tl]   wfa_batch %-18s +%6.2f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count()); } while (0)
   if (n_jobs > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_wfa_batch: too many jobs");

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
   const int lane = (int)threadIdx.x;
   const uint32_t* const twl = Tw + lane * 2 * B;  // + (v + 1) + C_p: the window of diagonal kb = C_p + lane * 2B at offset v + k
   const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
-  unsigned long long cells_acc = 0;
+  unsigned long long cells_acc = 0, kept_acc = 0;
 
   // 4-byte sliding windows of `len` bytes at src into W[base + i] (i = 0 .. n_win - 1), bytes beyond the sequence = pad
   auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W, int n_win, uint32_t pad, uint32_t& dirty) {
@@ -380,9 +380,11 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
       if (a.bound) a.bound[o] = bound_out;
       if (a.keep) a.keep[o] = (uint8_t)keep;
       if (keep && a.keep_jobs) a.keep_jobs[atomicAdd(a.keep_count, 1u)] = job;
+      kept_acc += (unsigned long long)keep;
     }
   }
   if (lane == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
+  if (lane == 0 && a.cells_out && kept_acc) atomicAdd(a.cells_out + 1, kept_acc);  // [1]: alignments kept
 }
 
 }  // namespace wfa
@@ -413,9 +415,9 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
   int occ = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 8; }
-  if (const char* e = getenv("TRGT_FILTER_PER_CU")) occ = std::max(1, atoi(e));
+  if (c->knobs.filter_per_cu > 0) occ = c->knobs.filter_per_cu;
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * occ, L.n_jobs_host));
-  if (getenv("TRGT_WFA_DEBUG")) fprintf(stderr, "[filter] diagonals %lld occupancy %d grid %lld\n", (long long)diag, occ, (long long)grid);
+  if (c->knobs.debug) fprintf(stderr, "[filter] diagonals %lld occupancy %d grid %lld\n", (long long)diag, occ, (long long)grid);
   KTimer t(c, L.timer_slot);
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
   TRGT_HIP_TRY(c, hipGetLastError());

@@ -135,7 +135,7 @@ class BatchOutputs:
         self.ci = np.zeros(4 * nl, np.int32)
         self.num_spanning = np.zeros(2 * nl, np.int32)
         self.classification, self.read_rank = np.zeros(nr, np.int32), np.zeros(nr, np.int32)
-        self.stats = np.zeros(16, np.int64)
+        self.stats = np.zeros(24, np.int64)
         p = _lib.ptr
         self.c_out = _lib.LocusBatchOut(*[p(getattr(self, n)).value for n in (
             "span_start", "span_end", "n_alleles", "allele_blob", "allele_off", "allele_cap", "allele_len", "ci", "num_spanning",
@@ -152,9 +152,12 @@ def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, re
     out = outputs or BatchOutputs(batch)
     p = _lib.ptr
     flank, reads = flank_dev if flank_dev is not None else batch["flank_blob"], reads_dev if reads_dev is not None else batch["read_blob"]
-    key = (p(flank).value, p(reads).value) + tuple(id(batch.get(k)) for k in _CIN_KEYS)
-    cached = batch.get("_cin")  # the input struct of a batch is rebuilt only when the blobs move (20 pointer conversions per call otherwise); keyed by the identity of every array
-    if cached is None or cached[0] != key:
+    # The input struct of a batch is rebuilt only when one of its arrays is replaced (20 pointer conversions per call otherwise).
+    # The cache entry HOLDS the arrays it was built from and compares them by identity: an id() alone could be reused by a new
+    # array allocated at a freed one's address, and the struct would then carry a dangling pointer.
+    key = (int(batch["n_loci"]), flank, reads) + tuple(batch.get(k) for k in _CIN_KEYS)
+    cached = batch.get("_cin")
+    if cached is None or len(cached[0]) != len(key) or cached[0][0] != key[0] or any(a is not b for a, b in zip(cached[0][1:], key[1:])):
         cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
             flank, batch["lf_off"], batch["lf_len"], batch["rf_off"],
             batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
