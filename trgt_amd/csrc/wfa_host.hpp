@@ -59,6 +59,7 @@ struct FilterLaunch {
   int32_t min_matches = 0;
   JobDev* keep_jobs = nullptr; uint32_t* keep_count = nullptr;
   int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;
+  bool count_offsets = false;  // also count the wavefront offsets (a little slower: one more scalar walk per level)
   int timer_slot = TRGT_K_WFA_FILTER;
 };
 // Longest text the filter can judge for this pattern length (0: the filter does not apply); longer texts are kept unseen.

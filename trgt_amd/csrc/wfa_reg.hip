@@ -24,7 +24,7 @@
 // Where the wavefronts live.  One 64-lane wave owns one alignment; the live wavefronts -- M of the last six levels, I and D of
 // the last one -- sit in VGPRs as packed pairs of 16-bit cells: lane l of strip t owns the 2*B consecutive diagonals
 // kb = t*128*B + l*2*B + 2*j + {0, 1} (kb = k + plen).  Neighbouring diagonals are the other half of the same register, the
-// neighbouring register, or -- at the two ends of a lane's block -- the neighbouring lane (one DPP wave shift per strip, source
+// neighbouring register, or -- at the two ends of a lane's block -- the neighbouring lane (one DPP wave shift per level, source
 // and direction).  No LDS for the wavefronts, no barrier, no per-wave redundancy; LDS only holds the two sequences as 4-byte
 // sliding windows (one aligned dword covers four bases: extension = xor + v_ffbl), padded with sentinels so that the ends of
 // the sequences and NULL cells need no test at all (a NULL cell reads the all-ones window and extends by nothing).
@@ -71,7 +71,9 @@ __device__ __forceinline__ uint32_t ffbl_or_m1(uint32_t v) {  // v_ffbl_b32: -1 
   return r;
 }
 __device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
+// A copy the optimiser must take element by element: without it the rotation of the wavefront ring is recognised as a block copy,
+// the rows become ten-wide vector values, and every branch that touches ONE element copies the whole row.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 // lane i <- own[i - 1]; lane 0 <- below[63]
 __device__ __forceinline__ uint32_t shr_from(uint32_t own, uint32_t below) {
   const int t = __builtin_amdgcn_update_dpp(0, (int)below, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
@@ -96,18 +98,22 @@ __device__ __forceinline__ uint32_t dirty_dword(uint32_t x) {
 
 }  // namespace
 
+// NS strips of 128 * B diagonals; lane l of strip t owns the 2 * B consecutive diagonals kb = t * 128 * B + l * 2 * B + 2 * j + {0, 1},
+// j = 0 .. B - 1 (kb = k + plen): B packed registers per strip and component.  A strip's cells follow the diagonal order lane by
+// lane, so "the last in-bounds cell" is a few ballots over ONE strip, the out-of-bounds test of M is needed only in the strips
+// that reach above tlen - plen, and strips outside the level's limits are skipped.
 template <int NS, int B>
-__global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
-  constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA;
+__global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
+  constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA, LW = 2 * B;
   __shared__ uint32_t lds[PWN + TWN];
   uint32_t* const Pw = lds;
   uint32_t* const Tw = lds + PWN;
   const int lane = (int)threadIdx.x;
-  const uint32_t* const twl = Tw + lane * 2 * B;  // + (v + 1) + C_p: the window of diagonal kb = C_p + lane * 2B at offset v + k
+  const uint32_t* const twl = Tw + lane * LW;  // + (v + 1) + C_p: the window of diagonal kb = C_p + lane * LW at offset v + k
   const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
   unsigned long long cells_acc = 0, kept_acc = 0;
 
-  // 4-byte sliding windows of `len` bytes at src into W[base + i] (i = 0 .. n_win - 1), bytes beyond the sequence = pad
+  // 4-byte sliding windows of `len` bytes at src into W[i] (i = 0 .. n_win - 1), bytes beyond the sequence = pad
   auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W, int n_win, uint32_t pad, uint32_t& dirty) {
     for (int i0 = 4 * lane; i0 < n_win; i0 += 256) {
       uint32_t d0 = pad, d1 = pad;
@@ -141,30 +147,61 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
     const bool fits = plen >= 1 && plen <= 254 && tlen >= plen && tlen + plen + 1 <= D;
     uint32_t dirty = 0;
     if (fits) {
-      // ---- the two sequences as sliding windows
-      __builtin_amdgcn_s_barrier();  // (one wave: orders the LDS reads of the previous job before these writes)
+      // ---- the two sequences as sliding windows (one wave: its LDS operations execute in order, no barrier needed)
       if (lane == 0) Pw[0] = NULL_WIN;
       stage(a.pat_base + job.pat_off, plen, Pw + 1, PWN - 1, PAT_PAD, dirty);
       for (int i = lane; i < plen + 1; i += 64) Tw[i] = TXT_PAD;  // text positions < 0: only NULL cells look there
       stage(a.txt_base + job.txt_off, tlen, Tw + plen + 1, TWN - (plen + 1), TXT_PAD, dirty);
-      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     const bool is_dirty = __builtin_amdgcn_ballot_w64(dirty != 0u) != 0ull;
     if (!fits || is_dirty) keep = 1;
     else {
-      // extension of both cells of a packed pair; C = the pair's compile-time diagonal offset inside the lane's window pointer
-      auto extend_pair = [&](uint32_t key, int C) -> uint32_t {
-        uint32_t va = (key >> 8) & 0xFFu, vb = key >> 24;
-        uint32_t na = min(ffbl_or_m1(Pw[va] ^ twl[va + C]) >> 3, 4u);
-        uint32_t nb = min(ffbl_or_m1(Pw[vb] ^ twl[vb + C + 1]) >> 3, 4u);
-        uint32_t ta = na, tb = nb;
-        bool ca = na == 4u, cb = nb == 4u;
-        while (__builtin_amdgcn_ballot_w64(ca || cb)) {
-          if (ca) { na = min(ffbl_or_m1(Pw[va + ta] ^ twl[va + ta + C]) >> 3, 4u); ta += na; ca = na == 4u; }
-          if (cb) { nb = min(ffbl_or_m1(Pw[vb + tb] ^ twl[vb + tb + C + 1]) >> 3, 4u); tb += nb; cb = nb == 4u; }
+      // one step of the extension of both cells of a packed pair: the number of matching bases (0 .. 4) inside the next window,
+      // n_a | n_b << 16.  A NULL cell (v + 1 = 0) reads the all-ones pattern window: no match, it stays NULL.
+      auto window_step = [&](uint32_t key, int C) -> uint32_t {
+        const uint32_t va = (key >> 8) & 0xFFu, vb = key >> 24;
+        const uint32_t na = min(ffbl_or_m1(Pw[va] ^ twl[va + C]) >> 3, 4u);
+        const uint32_t nb = min(ffbl_or_m1(Pw[vb] ^ twl[vb + C + 1]) >> 3, 4u);
+        return na | (nb << 16);
+      };
+      // Extension of the level in Mx: first window of every cell straight-line (all LDS reads in flight together), then, pair by
+      // pair, the cells that matched a whole window go on (a few per level: random bases agree on four in a row once in 256).
+      // Returns the packed maximum over the level (termination test).
+      auto extend_level = [&](uint32_t (&Mx)[NP]) -> uint32_t {
+        static_assert(NP <= 14, "the continuation flags of a level share one register");
+        uint32_t cflag = 0;  // bit 2 + (NP - 1 - p): the A cell of pair p matched a whole window, bit 18 + (NP - 1 - p): its B cell
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+#pragma unroll
+          for (int jj = 0; jj < B; ++jj) {
+            const int p = t * B + jj;
+            const uint32_t n = window_step(Mx[p], t * SW + 2 * jj);
+            Mx[p] += n * 0x0101u;
+            cflag = (cflag << 1) | (n & 0x00040004u);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one strip's LDS reads in flight at a time: all of them together cost a third of the register file
         }
-        return key + (ta | (tb << 16)) * 0x0101u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          uint32_t c = (cflag >> (NP - 1 - p)) & 0x00040004u;
+          if (__builtin_amdgcn_ballot_w64(c != 0u)) {
+            uint32_t m = Mx[p];  // (the loop carries a scalar copy: an array element updated inside it would drag the array along)
+            do {
+              if (c != 0u) {
+                const uint32_t n2 = window_step(m, (p / B) * SW + 2 * (p % B));
+                const uint32_t add = ((c & 0xFFFFu) ? n2 & 0xFFFFu : 0u) | ((c >> 16) ? n2 & 0xFFFF0000u : 0u);
+                m += add * 0x0101u;
+                c = add & 0x00040004u;
+              }
+            } while (__builtin_amdgcn_ballot_w64(c != 0u));
+            Mx[p] = m;
+          }
+        }
+        uint32_t t = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) t = rpk_max(t, Mx[p]);
+        return t;
       };
       uint32_t Mr[6][NP], Ir[NP], Dr[NP];
 #pragma unroll
@@ -177,19 +214,16 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
       int mlo[6], mhi[6], ilo = 1, ihi = -1, dlo = 1, dhi = -1;
 #pragma unroll
       for (int d = 0; d < 6; ++d) { mlo[d] = 1; mhi[d] = -1; }
-      const int lane_kb = lane * 2 * B;
+      const int lane_kb0 = lane * LW;
       const int term_v = plen + 1;
+      const int lane_bnd0 = tlen + 1 + plen - lane_kb0;  // v + 1 <= lane_bnd - C  <=>  offset <= tlen on diagonal kb = C + lane_kb
       // ---- level 0: M[0][k] = k for k in [0, tlen] (v = 0), then extended
-      uint32_t tmax = 0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int C = (p / B) * SW + 2 * (p % B);
-        const int kbA = C + lane_kb;
-        uint32_t key = ((unsigned)(kbA - plen) <= (unsigned)tlen ? 0x0100u : 0u) | ((unsigned)(kbA + 1 - plen) <= (unsigned)tlen ? 0x01000000u : 0u);
-        key = extend_pair(key, C);
-        Mr[0][p] = key;
-        tmax = rpk_max(tmax, key);
+        const int kbA = (p / B) * SW + 2 * (p % B) + lane_kb0;
+        Mr[0][p] = ((unsigned)(kbA - plen) <= (unsigned)tlen ? 0x0100u : 0u) | ((unsigned)(kbA + 1 - plen) <= (unsigned)tlen ? 0x01000000u : 0u);
       }
+      uint32_t tmax = extend_level(Mr[0]);
       mlo[0] = 0; mhi[0] = tlen;
       unsigned long long cells = (unsigned long long)tlen + 1ull;
       int s = 0, num_null = 0;
@@ -201,62 +235,66 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
         ++s;
         if (s > SMAX) { bail = true; break; }
         const bool n_mm = mlo[1] > mhi[1], n_mo = mlo[5] > mhi[5], n_ie = ilo > ihi, n_de = dlo > dhi;
-        uint32_t Mn[NP], In[NP], Dn[NP];
+        // (per-lane constants go through opaque() once per level: hoisted out of the loop, their per-pair variants -- bounds, diagonal
+        //  numbers -- would sit in two dozen registers for the whole alignment)
+        const int lane_bnd = (int)opaque((uint32_t)lane_bnd0), lane_kb = (int)opaque((uint32_t)lane_kb0);
+        uint32_t (&Mn)[NP] = Mr[5];  // the new level replaces M[s - 6] in place (its last use is the first pass below)
         int nmlo = 1, nmhi = -1, nilo = 1, nihi = -1, ndlo = 1, ndhi = -1;
-        tmax = 0;
         if (n_mm && n_mo && n_ie && n_de) {
-          ++num_null;
-          if (num_null > 7) { bail = true; break; }  // (cannot happen with a free text; the exact kernel decides)
+          if (++num_null > 7) { bail = true; break; }  // (cannot happen with a free text; the exact kernel decides)
 #pragma unroll
-          for (int p = 0; p < NP; ++p) { Mn[p] = 0u; In[p] = 0u; Dn[p] = 0u; }
+          for (int p = 0; p < NP; ++p) Mn[p] = 0u;  // (I and D are NULL already: their sources were)
+          tmax = 0;
         } else {
           num_null = 0;
           // wavefront_compute_limits_input (null wavefronts take part with lo = 1, hi = -1, as in the library)
           const int lo = min(min(mlo[1], mlo[5] - 1), min(ilo + 1, dlo - 1));
           const int hi = max(max(mhi[1], mhi[5] + 1), max(ihi + 1, dhi - 1));
           cells += 3ull * (unsigned long long)max(0, hi - lo + 1);
-          const int lob = lo + plen, hib = hi + plen;  // biased
-          const int lane_bnd = tlen + 1 + plen - lane_kb;  // v + 1 <= lane_bnd - C  <=>  offset <= tlen on diagonal kb = C + lane_kb
+          // ---- the recurrences.  ins[k] = max(Mo, Ie)[k - 1] and del[k] = (max(Mo, De) + 1)[k + 1]: ONE diagonal shift per
+          //      component, taken after the maximum.  In place: first I <- max(Mo, I), D <- max(Mo, D) + 1, then the shifts
+          //      (I from the top strip down, D from the bottom up, so that the neighbour's unshifted value is still there).
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const uint32_t mo = Mr[5][p];
+            Ir[p] = rpk_max(mo, Ir[p]);
+            Dr[p] = inc_v_nz(rpk_max(mo, Dr[p]));
+          }
+#pragma unroll
+          for (int t = NS - 1; t >= 0; --t) {
+            // lane i <- lane i - 1's last pair; lane 0 <- the last pair of lane 63 of the strip below
+            const uint32_t edge = shr_from(Ir[t * B + B - 1], t > 0 ? Ir[(t - 1) * B + B - 1] : 0u);
+#pragma unroll
+            for (int jj = B - 1; jj >= 0; --jj) Ir[t * B + jj] = __builtin_amdgcn_alignbit(Ir[t * B + jj], jj ? Ir[t * B + jj - 1] : edge, 16);
+          }
 #pragma unroll
           for (int t = 0; t < NS; ++t) {
-            const int k0 = t * SW, k1 = k0 + SW - 1;
-            if (k1 < lob || k0 > hib) {  // (uniform) nothing of this strip is inside the limits: every source is NULL there
+            const uint32_t edge = shl_from(Dr[t * B], t < NS - 1 ? Dr[(t + 1) * B] : 0u);
 #pragma unroll
-              for (int jj = 0; jj < B; ++jj) { Mn[t * B + jj] = 0u; In[t * B + jj] = 0u; Dn[t * B + jj] = 0u; }
-              continue;
-            }
-            const uint32_t mo_pe = shr_from(Mr[5][t * B + B - 1], t > 0 ? Mr[5][(t - 1) * B + B - 1] : 0u);
-            const uint32_t ie_pe = shr_from(Ir[t * B + B - 1], t > 0 ? Ir[(t - 1) * B + B - 1] : 0u);
-            const uint32_t mo_ne = shl_from(Mr[5][t * B], t < NS - 1 ? Mr[5][(t + 1) * B] : 0u);
-            const uint32_t de_ne = shl_from(Dr[t * B], t < NS - 1 ? Dr[(t + 1) * B] : 0u);
-            const bool top = k1 > tlen;  // (uniform) diagonals k > tlen - plen: an offset can pass the end of the text
+            for (int jj = 0; jj < B; ++jj) Dr[t * B + jj] = __builtin_amdgcn_alignbit(jj < B - 1 ? Dr[t * B + jj + 1] : edge, Dr[t * B + jj], 16);
+          }
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const bool top = t * SW + SW - 1 > tlen;  // (uniform) diagonals k > tlen - plen: an offset can pass the end of the text
 #pragma unroll
             for (int jj = 0; jj < B; ++jj) {
-              const int p = t * B + jj, C = t * SW + 2 * jj;
-              const uint32_t mo_c = Mr[5][p], mo_p = jj ? Mr[5][p - 1] : mo_pe, mo_n = jj < B - 1 ? Mr[5][p + 1] : mo_ne;
-              const uint32_t ie_c = Ir[p], ie_p = jj ? Ir[p - 1] : ie_pe;
-              const uint32_t de_c = Dr[p], de_n = jj < B - 1 ? Dr[p + 1] : de_ne;
-              const uint32_t ins = rpk_max(__builtin_amdgcn_alignbit(mo_c, mo_p, 16), __builtin_amdgcn_alignbit(ie_c, ie_p, 16));
-              const uint32_t del = inc_v_nz(rpk_max(__builtin_amdgcn_alignbit(mo_n, mo_c, 16), __builtin_amdgcn_alignbit(de_n, de_c, 16)));
-              const uint32_t mis = inc_v_nz(Mr[1][p]);
-              uint32_t mxp = rpk_max(del, rpk_max(mis, ins));
+              const int p = t * B + jj;
+              uint32_t mxp = rpk_max(Dr[p], rpk_max(inc_v_nz(Mr[1][p]), Ir[p]));
               if (top) {  // "adjust offset out of boundaries": offset > tlen -> NULL
-                const int bA = lane_bnd - C;
+                const int bA = lane_bnd - (t * SW + 2 * jj);
                 const bool okA = (int)((mxp >> 8) & 0xFFu) <= bA, okB = (int)(mxp >> 24) <= bA - 1;
                 mxp = (okA ? mxp & 0xFFFFu : 0u) | (okB ? mxp & 0xFFFF0000u : 0u);
               }
-              const uint32_t mq = extend_pair(mxp, C);
-              Mn[p] = mq; In[p] = ins; Dn[p] = del;
-              tmax = rpk_max(tmax, mq);
+              Mn[p] = mxp;
             }
           }
+          tmax = extend_level(Mn);
           // ---- wavefront_compute_trim_ends, restated: D is always in bounds; I and M are, below k = tlen - plen (+ 1)
           constexpr int INF = 1 << 20;
           const int so_lo = n_mo ? INF : mlo[5], so_hi = n_mo ? -INF : mhi[5];
           const bool has_d = !n_mo || !n_de, has_i = !n_mo || !n_ie;
           if (has_d) { ndlo = min(so_lo, n_de ? INF : dlo) - 1; ndhi = max(so_hi, n_de ? -INF : dhi) - 1; }
-          int ic_lo = INF, ic_hi = -INF;  // non-NULL I cells
-          // first / last cell of a component for which pred holds, inside biased [kb_lo, kb_hi]; -1: none
+          // last / first cell of a component for which pred holds, looking at the strips from biased kb_hi downwards / kb_lo upwards
           auto find_last = [&](const uint32_t (&R)[NP], int kb_lo, int kb_hi, auto pred) -> int {
             int best = -1;
 #pragma unroll
@@ -267,8 +305,8 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
                   bool va, vb;
                   pred(R[t * B + jj], t * SW + 2 * jj, va, vb);
                   const unsigned long long mA = __builtin_amdgcn_ballot_w64(va), mB = __builtin_amdgcn_ballot_w64(vb);
-                  if (mA) best = max(best, (63 - (int)__builtin_clzll(mA)) * 2 * B + t * SW + 2 * jj);
-                  if (mB) best = max(best, (63 - (int)__builtin_clzll(mB)) * 2 * B + t * SW + 2 * jj + 1);
+                  if (mA) best = max(best, (63 - (int)__builtin_clzll(mA)) * LW + t * SW + 2 * jj);
+                  if (mB) best = max(best, (63 - (int)__builtin_clzll(mB)) * LW + t * SW + 2 * jj + 1);
                 }
               }
             }
@@ -284,8 +322,8 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
                   bool va, vb;
                   pred(R[t * B + jj], t * SW + 2 * jj, va, vb);
                   const unsigned long long mA = __builtin_amdgcn_ballot_w64(va), mB = __builtin_amdgcn_ballot_w64(vb);
-                  if (mA) best = min(best, (int)__builtin_ctzll(mA) * 2 * B + t * SW + 2 * jj);
-                  if (mB) best = min(best, (int)__builtin_ctzll(mB) * 2 * B + t * SW + 2 * jj + 1);
+                  if (mA) best = min(best, (int)__builtin_ctzll(mA) * LW + t * SW + 2 * jj);
+                  if (mB) best = min(best, (int)__builtin_ctzll(mB) * LW + t * SW + 2 * jj + 1);
                 }
               }
             }
@@ -296,15 +334,16 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
             const int bA = lane_bnd - C, ea = (int)((x >> 8) & 0xFFu), eb = (int)(x >> 24);
             va = ea != 0 && ea <= bA; vb = eb != 0 && eb <= bA - 1;
           };
+          int ic_lo = INF, ic_hi = -INF;  // non-NULL I cells
           if (has_i) {
             ic_lo = min(so_lo, n_ie ? INF : ilo) + 1; ic_hi = max(so_hi, n_ie ? -INF : ihi) + 1;
             nilo = ic_lo; nihi = ic_hi;
             if (ic_hi > tlen - plen + 1) {
-              const int f = find_last(In, ic_lo + plen, ic_hi + plen, i_valid);
+              const int f = find_last(Ir, ic_lo + plen, ic_hi + plen, i_valid);
               if (f < 0) { nilo = 1; nihi = -1; }
               else {
                 nihi = f - plen;
-                if (ic_lo > tlen - plen + 1) nilo = find_first(In, ic_lo + plen, ic_hi + plen, i_valid) - plen;
+                if (ic_lo > tlen - plen + 1) nilo = find_first(Ir, ic_lo + plen, ic_hi + plen, i_valid) - plen;
               }
               if (nilo > nihi || nilo != ic_lo || nihi != ic_hi) {
                 // the cells the reference trims away are not NULL: zero them (NULL == outside the trimmed range, for every register)
@@ -316,7 +355,7 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
                     for (int jj = 0; jj < B; ++jj) {
                       const int kbA = t * SW + 2 * jj + lane_kb;
                       const bool kA = kbA >= zlo && kbA <= zhi, kB = kbA + 1 >= zlo && kbA + 1 <= zhi;
-                      In[t * B + jj] &= (kA ? 0xFFFFu : 0u) | (kB ? 0xFFFF0000u : 0u);
+                      Ir[t * B + jj] &= (kA ? 0xFFFFu : 0u) | (kB ? 0xFFFF0000u : 0u);
                     }
                   }
                 }
@@ -338,16 +377,17 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
             }
           }
         }
-        // ---- rotate
+        // ---- rotate: the new level (in the slot of M[s - 6]) becomes M[s - 1].  Element by element through opaque(): see there.
 #pragma unroll
-        for (int d = 5; d >= 1; --d) {
-          mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1];
+        for (int p = 0; p < NP; ++p) {
+          const uint32_t newest = opaque(Mr[5][p]);
 #pragma unroll
-          for (int p = 0; p < NP; ++p) Mr[d][p] = Mr[d - 1][p];
+          for (int d = 5; d >= 1; --d) Mr[d][p] = opaque(Mr[d - 1][p]);
+          Mr[0][p] = newest;
         }
-        mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) { Mr[0][p] = Mn[p]; Ir[p] = In[p]; Dr[p] = Dn[p]; }
+        for (int d = 5; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
+        mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
       }
       cells_acc += cells;
       if (bail || !done) keep = 1;
@@ -361,11 +401,11 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
           const unsigned long long mA = __builtin_amdgcn_ballot_w64(((x >> 8) & 0xFFu) == (uint32_t)term_v);
           const unsigned long long mB = __builtin_amdgcn_ballot_w64((x >> 24) == (uint32_t)term_v);
           if (mA) {
-            const int l = (int)__builtin_ctzll(mA), kb = l * 2 * B + C;
+            const int l = (int)__builtin_ctzll(mA), kb = l * LW + C;
             if (kb < best) { best = kb; best_reg = (uint32_t)__builtin_amdgcn_readlane((int)x, l) & 0xFFFFu; }
           }
           if (mB) {
-            const int l = (int)__builtin_ctzll(mB), kb = l * 2 * B + C + 1;
+            const int l = (int)__builtin_ctzll(mB), kb = l * LW + C + 1;
             if (kb < best) { best = kb; best_reg = (uint32_t)__builtin_amdgcn_readlane((int)x, l) >> 16; }
           }
         }
@@ -390,7 +430,7 @@ __global__ void __launch_bounds__(64) wfa_filter_kernel(const FilterArgs a) {
 }  // namespace wfa
 
 int flank_filter_max_tlen(int flank_len) {
-  const int64_t t = 6 * 256 - (int64_t)flank_len - 1;  // the largest instantiation: 1536 diagonals
+  const int64_t t = 12 * 128 - (int64_t)flank_len - 1;  // the largest instantiation: 1536 diagonals
   return flank_len >= 1 && flank_len <= 254 ? (int)std::max<int64_t>(t, 0) : 0;
 }
 
@@ -413,8 +453,18 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   // instantiation by the number of diagonals the longest text of the launch needs (jobs that do not fit are kept unseen)
   const int64_t diag = L.max_plen + L.max_tlen + 1;
   void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 8; }
+  // One-wave workgroups: resident waves per CU from the kernel's own register and LDS footprint (the occupancy query answers
+  // per SIMD for 64-thread blocks; measured: it said 3 where 12 waves fit a CU)
+  int occ = 8;
+  {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void*)fn) == hipSuccess) {
+      const int alloc = std::max(8, (fa.numRegs + 7) / 8 * 8);
+      const int per_simd = std::max(1, std::min(8, 512 / alloc));
+      const int by_lds = fa.sharedSizeBytes > 0 ? (int)((160u * 1024u) / (unsigned)fa.sharedSizeBytes) : 32;
+      occ = std::max(1, std::min(std::min(4 * per_simd, by_lds), 32));
+    } else (void)hipGetLastError();
+  }
   if (c->knobs.filter_per_cu > 0) occ = c->knobs.filter_per_cu;
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * occ, L.n_jobs_host));
   if (c->knobs.debug) fprintf(stderr, "[filter] diagonals %lld occupancy %d grid %lld\n", (long long)diag, occ, (long long)grid);
@@ -468,6 +518,7 @@ extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* 
       (rc = o_keep.init(c, S_FLT_KEEP, keep, (size_t)n_jobs)))
     return rc;
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.pat_base = d_seq; L.txt_base = d_seq;
+  L.count_offsets = offsets_computed != nullptr || c->timing;
   L.min_matches = min_matches; L.score = o_score.dev; L.bound = o_bound.dev; L.keep = o_keep.dev;
   if ((rc = flank_filter_launch(c, L))) return rc;
   if ((rc = o_score.finish(c)) || (rc = o_bound.finish(c)) || (rc = o_keep.finish(c))) return rc;
