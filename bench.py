@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- loci/s of the TRGT hot path on MI355X (BASELINE.json metric), one process per GPU.
 
-A "step" = one full pass of trgt_locus_batch over one batch of synthetic loci (BASELINE.json configs[1]:
-10k single-motif STR loci, motif 3-6 bp, allele <= 200 bp, 30x HiFi) per GPU:
-flank location (exact scan + ends-free WFA fallback) -> host length genotyping -> consensus BiWFA where
-needed -> motif-HMM labelling (MS/MC/AP).  Read and flank bytes are resident in HBM before the timed
-region; only the per-read offsets / spans / alleles cross PCIe inside it.
+A "step" = one full pass of trgt_locus_batch over one batch of synthetic loci per GPU: flank location (exact scan, register-
+resident pre-filter + back-tracing ends-free WFA for the misses) -> length / cluster genotyping -> consensus BiWFA where
+needed -> motif-HMM labelling (MS / MC / AP).
 
-  python bench.py [--gpus 1] [--steps 3] [--warmup 1] [--loci 10000]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+  python bench.py [--gpus 1] [--steps 100] [--warmup 3] [--config 2|3|4|5] [--loci N]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
-Loci shard embarrassingly: rank r generates and processes loci [r*L, (r+1)*L) (weak scaling, no
-collective on the data path); value = loci of all ranks * steps / max-over-ranks time.
+--config picks the BASELINE.json workload: 2 = configs[1] (10k single-motif STR loci, the configuration the metric is quoted on),
+3 = configs[2] (70 loci of the pathogenic catalog, alleles to 10 kb), 4 = configs[3] catalog mix (10k loci per GPU per step),
+5 = configs[4] (compound / N motifs through the cluster genotyper).
+
+`value` is measured with read and flank bytes resident in HBM before the timed region (only offsets / spans / alleles cross PCIe
+inside it); `value_streaming` is the same batches with the reads starting in pinned HOST memory, uploaded inside every call.
+Loci shard embarrassingly: rank r generates and processes loci [r*L, (r+1)*L) (weak scaling, no collective on the data path);
+value = loci of all ranks * steps / max-over-ranks time.  At N > 1 every rank also recomputes its right neighbour's shard
+(untimed) and the digests must agree: N-GPU output == 1-GPU output, byte for byte.
 """
 import argparse
 import json
@@ -25,32 +30,69 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable, measured below too)
+VALU_LANES_PER_CU = 64   # 4 SIMDs x 16 lanes: one wave64 VALU instruction occupies a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles)
+CLOCK_GHZ = 2.4
+
+DEFAULT_LOCI = {2: 10000, 3: 70, 4: 10000, 5: 2000}
+WORKLOAD = {
+    2: "BASELINE configs[1]: %d synthetic single-motif STR loci per GPU (motif 3-6 bp, allele <= 200 bp), 30 reads/locus HiFi-like, 10%% truncated reads (SURVEY.md Appendix E), seed 20250509",
+    3: "BASELINE configs[2]: %d loci per GPU over the 56 motif sets of the pathogenic catalog, one allele of 10-40 units and one expanded allele log-uniform in 500 bp .. 10 kb, 30 reads/locus, 10%% truncated (trgt_amd.synth.generate_cfg3)",
+    4: "BASELINE configs[3] per-GPU shard: %d loci of the genome-wide catalog mix (70%% STR, 20%% 2-5 motifs, 10%% VNTR motifs of 7-60 bp), 30 reads/locus, 10%% truncated",
+    5: "BASELINE configs[4]: %d compound / N-motif loci per GPU through the cluster genotyper, 30 reads/locus, 10%% truncated",
+}
 
 
-def cpu_baseline(batch, seconds_budget=20.0, max_loci=8000):
-    """The CPU oracle (port of the reference algorithms, single thread) timed on a bounded sample of the same batch."""
+def make_batch(config, n, first):
+    from trgt_amd import synth
+    if config == 3:
+        return synth.generate_cfg3(n, first_locus=first)
+    return synth.generate(n, first_locus=first, config=config)
+
+
+def locus_inputs(batch, l):
+    a0, a1 = int(batch["locus_read_begin"][l]), int(batch["locus_read_begin"][l + 1])
+    reads = [bytes(batch["read_blob"][int(batch["read_off"][r]):int(batch["read_off"][r]) + int(batch["read_len"][r])]) for r in range(a0, a1)]
+    lf = bytes(batch["flank_blob"][int(batch["lf_off"][l]):int(batch["lf_off"][l]) + int(batch["lf_len"][l])])
+    rf = bytes(batch["flank_blob"][int(batch["rf_off"][l]):int(batch["rf_off"][l]) + int(batch["rf_len"][l])])
+    tr = bytes(batch["tr_blob"][int(batch["tr_off"][l]):int(batch["tr_off"][l]) + int(batch["tr_len"][l])])
+    m0, m1 = int(batch["set_motif_begin"][l]), int(batch["set_motif_begin"][l + 1])
+    motifs = [bytes(batch["motif_blob"][int(batch["motif_off"][m]):int(batch["motif_off"][m + 1])]) for m in range(m0, m1)]
+    return lf, rf, tr, motifs, reads, (a0, a1)
+
+
+def cpu_baseline(batch, out, config, seconds_budget=20.0, max_loci=8000):
+    """The CPU oracle (port of the reference algorithms, single thread) timed on a bounded sample of the same batch; what it
+    computed is then compared with what the GPU path returned for the same loci (outside the timed region)."""
     from oracle import binding as orc
+    from trgt_amd import locus
     orc.lib()
     n = min(int(batch["n_loci"]), max_loci)
-    t0 = time.perf_counter()
-    done = 0
+    genotyper = batch.get("genotyper")
+    refs = []
+    t_cpu = 0.0
     for l in range(n):
-        a0, a1 = int(batch["locus_read_begin"][l]), int(batch["locus_read_begin"][l + 1])
-        reads = [bytes(batch["read_blob"][int(batch["read_off"][r]):int(batch["read_off"][r]) + int(batch["read_len"][r])])
-                 for r in range(a0, a1)]
-        lf = bytes(batch["flank_blob"][int(batch["lf_off"][l]):int(batch["lf_off"][l]) + int(batch["lf_len"][l])])
-        rf = bytes(batch["flank_blob"][int(batch["rf_off"][l]):int(batch["rf_off"][l]) + int(batch["rf_len"][l])])
-        tr = bytes(batch["tr_blob"][int(batch["tr_off"][l]):int(batch["tr_off"][l]) + int(batch["tr_len"][l])])
-        m0, m1 = int(batch["set_motif_begin"][l]), int(batch["set_motif_begin"][l + 1])
-        motifs = [bytes(batch["motif_blob"][int(batch["motif_off"][m]):int(batch["motif_off"][m + 1])]) for m in range(m0, m1)]
-        orc.locus_analyze(lf, rf, tr, motifs, reads)
-        done += 1
-        if time.perf_counter() - t0 > seconds_budget:
+        lf, rf, tr, motifs, reads, _ = locus_inputs(batch, l)
+        kw = {"genotyper": 1} if genotyper is not None and int(genotyper[l]) == 1 else {}
+        kw["ploidy"] = int(batch["ploidy"][l])
+        t0 = time.perf_counter()
+        refs.append(orc.locus_analyze(lf, rf, tr, motifs, reads, **kw))
+        t_cpu += time.perf_counter() - t0
+        if t_cpu > seconds_budget:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=round(done / dt, 2), unit="loci/s", cores=1, kind="port",
-                sample="first %d loci of the same synthetic batch, oracle/liboracle.so (C++ restatement), 1 thread, %.1f s" % (done, dt))
+    done = len(refs)
+    mismatches = 0
+    for l, ref in enumerate(refs):
+        a0, a1 = int(batch["locus_read_begin"][l]), int(batch["locus_read_begin"][l + 1])
+        got = locus.locus_result(batch, out, l)
+        f = got.vcf_fields()
+        ok = (np.array_equal(out.span_start[a0:a1], ref["span_start"]) and np.array_equal(out.span_end[a0:a1], ref["span_end"]) and
+              [a.seq.decode() for a in got.genotype] == ref["alleles"] and all(f[k] == ref[k] for k in ("AL", "ALLR", "SD", "MC", "MS", "AP")))
+        mismatches += 0 if ok else 1
+    return (dict(value=round(done / t_cpu, 2), unit="loci/s", cores=1, kind="port",
+                 sample="first %d loci of the same synthetic batch, oracle/liboracle.so (C++ restatement of the reference algorithms), 1 thread, %.1f s" % (done, t_cpu)),
+            dict(parity_checked_loci=done, mismatches=mismatches,
+                 compared="per-read spans, allele sequences, AL / ALLR / SD / MC / MS / AP of the last timed step vs the oracle"))
 
 
 def cpu_baseline_mt(batch, threads):
@@ -67,15 +109,35 @@ def cpu_baseline_mt(batch, threads):
                 sample="all %d loci of the same synthetic batch, oracle/liboracle.so, %d native threads pulling chunks of loci from a shared counter, %.1f s" % (done, threads, dt))
 
 
+def copy_peak_gbs(torch, nbytes=1 << 30, reps=8):
+    """Measured device-copy bandwidth (read + write bytes per second of a large d2d copy): the achievable HBM figure on this box."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    del a, b
+    return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--loci", type=int, default=10000, help="loci per GPU per step")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--loci", type=int, default=0, help="loci per GPU per step (default: by config)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true")
     args = ap.parse_args()
+    n_loci = args.loci or DEFAULT_LOCI[args.config]
 
     import torch
     import torch.distributed as dist
@@ -91,12 +153,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from trgt_amd import _lib, locus, shard, synth
+    from trgt_amd import _lib, locus, shard
 
     # ---- synthetic shard of this rank (untimed)
     # host threads for the glue between the GPU stages; the library uses at most 8 of them when the reads are resident in HBM
     host_threads = min(8, args.host_threads or max(1, (os.cpu_count() or 8) // max(1, world)))
-    batch = synth.generate(args.loci, first_locus=rank * args.loci, config=2)
+    batch = make_batch(args.config, n_loci, rank * n_loci)
     reads_dev = torch.from_numpy(batch["read_blob"]).cuda()
     flank_dev = torch.from_numpy(batch["flank_blob"]).cuda()
     ctx = _lib.Context(local_rank)
@@ -131,77 +193,135 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     step_ms = sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))
+    names = {k: n for n, k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4), ("wfa_filter", 5))}
+    kt = {names[k]: ctx.timing_get(k) for k in names}
     ctx.timing_enable(False)
     dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
 
+    # ---- the same batches with the reads starting in pinned host memory (uploaded inside every call); untimed kernels
+    dt_stream = None
+    if not args.no_streaming:
+        reads_pin = torch.from_numpy(batch["read_blob"]).pin_memory()
+        out_s = locus.BatchOutputs(batch)
+
+        def step_stream():
+            locus.run_batch(batch, params, ctx, out_s, flank_dev=flank_dev, reads_dev=reads_pin)
+
+        n_s = max(3, min(args.steps, 30))
+        step_stream()
+        step_stream()
+        gc.collect()
+        gc.disable()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_s):
+            step_stream()
+        fence()
+        dt_stream = (time.perf_counter() - t0) / n_s
+        gc.enable()
+        dt_stream = shard.max_over_ranks(dt_stream, dist if world > 1 else None, device="cuda")
+        if shard.result_digest(out_s, n_loci) != shard.result_digest(out, n_loci):
+            raise SystemExit("bench.py: host-resident reads gave different results than HBM-resident reads")
+
+    # ---- N > 1: every rank recomputes its right neighbour's shard; the digests must agree (N-GPU output == 1-GPU output)
+    digest_check = None
+    if world > 1:
+        mine = shard.result_digest(out, n_loci)
+        nb = (rank + 1) % world
+        nbatch = make_batch(args.config, n_loci, nb * n_loci)
+        nout = locus.run_batch(nbatch, params, ctx, flank_dev=torch.from_numpy(nbatch["flank_blob"]).cuda(), reads_dev=torch.from_numpy(nbatch["read_blob"]).cuda())
+        theirs = shard.result_digest(nout, n_loci)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, theirs))
+        bad = [r for r in range(world) if gathered[r][1] != gathered[(r + 1) % world][0]]
+        if bad:
+            raise SystemExit("bench.py: shard digests differ between GPUs (ranks %s recomputed their neighbour's shard differently)" % bad)
+        digest_check = {"ranks": world, "shards_recomputed_on_another_gpu": world, "digest_mismatches": 0}
+
     if rank == 0:
-        # wfa_flank: the launch over the alignments of reads too short to span their locus (95 % of the wavefront offsets);
-        # wfa_flank_rest: the launches over the other flank alignments (on seeded windows, then the few that need the whole read);
-        # flank_scan: the exact-match scan and the segment search for the windows
-        names = {_lib_k: n for n, _lib_k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4), ("wfa_filter", 5))}
-        kt = {names[k]: ctx.timing_get(k) for k in names}
+        # wfa_filter: register-resident pre-filter over the alignments of reads too short to span their locus (>90 % of the wavefront
+        # offsets); wfa_flank: the back-tracing kernel over the alignments the filter keeps; wfa_flank_rest: the other flank alignments
+        # (on seeded windows, then the few that need the whole read); flank_scan: exact-match scan + segment search for the windows
         dom = max(kt, key=lambda k: kt[k][0])
         ms, launches, cells = kt[dom]
         stats = out.stats
         n_reads = int(batch["n_reads"])
-        # ALGORITHMIC bytes per launch of the dominant kernel (DESIGN.md "Roofline model"):
-        if dom == "wfa_flank":      # 2 B per wavefront offset (16-bit history) written once + pattern/text in + (n_match, span) out per job
-            jobs = int(stats[14]) if int(kt["wfa_flank_rest"][1]) else int(stats[0])  # alignments of this launch
-            mean_read = float(batch["read_len"].mean())
-            bytes_per_launch = 2.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)
-            survey_bytes_per_launch = 4.0 * cells / max(launches, 1) + jobs * (250 + mean_read + 20)  # SURVEY 8(d) prices an offset at 4 B
-        elif dom == "wfa_filter":   # history-free: sequences in, a verdict out; SURVEY 8(d) prices the DP state it keeps in registers at 4 B / offset
+        mean_read = float(batch["read_len"].mean())
+        launches = max(launches, 1)
+        cells_l = cells / launches
+        # ALGORITHMIC bytes per launch of the dominant kernel (DESIGN.md "Roofline model", SURVEY.md 8(d): B_io + B_dp)
+        if dom == "wfa_filter":     # B_dp = 4 B per wavefront offset; the kernel keeps that state in registers: B_io is all it moves
             jobs = int(stats[14])
-            mean_read = float(batch["read_len"].mean())
-            bytes_per_launch = jobs * (250 + mean_read + 20)
-            survey_bytes_per_launch = 4.0 * cells / max(launches, 1) + bytes_per_launch
+            io_bytes = jobs * (250 + mean_read + 12)
+            dp_bytes = 4.0 * cells_l
+        elif dom == "wfa_flank":    # 2 B per offset of history actually written + sequences in + (n_match, span) out
+            jobs = int(stats[16]) or int(stats[14]) or int(stats[0])
+            io_bytes = jobs * (250 + mean_read + 20)
+            dp_bytes = 4.0 * cells_l
         elif dom == "hmm_viterbi":  # 1 B per back-pointer cell + allele in + annotation out
-            bytes_per_launch = 1.0 * cells / max(launches, 1) + float(out.allele_len.sum()) * 2
+            io_bytes = float(out.allele_len.sum()) * 2
+            dp_bytes = 1.0 * cells_l
         elif dom == "flank_scan":   # every read byte once + 4 B per (read, side)
-            bytes_per_launch = float(batch["read_len"].sum()) + 8.0 * n_reads
+            io_bytes = float(batch["read_len"].sum()) + 8.0 * n_reads
+            dp_bytes = 0.0
         else:
-            bytes_per_launch = 4.0 * cells / max(launches, 1)
-        if dom not in ("wfa_flank", "wfa_filter"):
-            survey_bytes_per_launch = bytes_per_launch
+            io_bytes = 0.0
+            dp_bytes = 4.0 * cells_l
+        bytes_per_launch = io_bytes + dp_bytes
         traffic = None  # measured HBM bytes per launch of the same kernel / workload, when a PMC profile is committed
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("loci_per_gpu") == args.loci and dom in tj["kernels"]:
+            if tj.get("loci_per_gpu") == n_loci and tj.get("config", 2) == args.config and dom in tj["kernels"]:
                 traffic = int(tj["kernels"][dom]["bytes_per_launch"])
         except (OSError, ValueError, KeyError):
             pass
-        avg_ms = ms / max(launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        avg_ms = ms / launches
+        gbs = lambda b: b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = gbs(bytes_per_launch)
+        copy_peak = copy_peak_gbs(torch)
+        num_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        valu_peak = num_cus * VALU_LANES_PER_CU * CLOCK_GHZ * 1e9   # 32-bit integer lane-operations per second
+        cells_per_s = cells / max(ms, 1e-9) * 1e3
         res = {
-            "metric": "loci/s", "value": round(world * args.loci * args.steps / dt, 1), "unit": "loci/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+            "metric": "loci/s", "value": round(world * n_loci * args.steps / dt, 1), "unit": "loci/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "ms_per_step_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16+u8 (WFA), f64 (HMM)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+u8 packed (WFA pre-filter), u16 (WFA back-trace), f64 (HMM)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic single-motif STR loci per GPU (motif 3-6 bp, allele <= 200 bp), "
-                                   "30 reads/locus HiFi-like, 10%% truncated reads (SURVEY.md Appendix E), seed 20250509" % args.loci,
-                       "loci_per_gpu": args.loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
+            "value_is": "HBM-resident: read and flank bytes are in HBM before the timed region; see value_streaming for reads that start in pinned host memory",
+            "value_streaming": round(world * n_loci / dt_stream, 1) if dt_stream else None,
+            "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
+                       "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
                        "host_threads_per_rank": host_threads},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_wavefront_offset": 2,
-                         "frac_at_survey_4B_per_offset": round(survey_bytes_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_ms > 0 else 0.0,
-                         "dp_cells_per_launch": int(cells / max(launches, 1)),
-                         "dp_cells_per_s": round(cells / max(ms, 1e-9) * 1e3, 1)},
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "algorithmic_bytes_model": "SURVEY.md 8(d): B_io + B_dp, B_dp = 4 B per wavefront offset W (1 B per Viterbi cell); W counted on the device, equal to the oracle's count",
+                         "frac_io_only": round(gbs(io_bytes) / HBM_PEAK_GBS, 7), "io_bytes_per_launch": int(io_bytes),
+                         "peak_measured_copy": round(copy_peak, 1), "frac_of_measured_copy": round(achieved / copy_peak, 5) if copy_peak > 0 else None,
+                         "note": "the pre-filter keeps the wavefront state (B_dp) in registers: frac prices it as if it were streamed, frac_io_only is what actually moves",
+                         "dp_cells_per_launch": int(cells_l), "dp_cells_per_s": round(cells_per_s, 1)},
+            # the informative bound for this integer DP: DP offsets per second against the VALU issue peak
+            "issue_roofline": {"kernel": dom, "dp_offsets_per_s": round(cells_per_s, 1), "valu_lane_ops_peak_per_s": valu_peak,
+                               "offsets_per_lane_op_at_peak": round(cells_per_s / valu_peak, 5),
+                               "note": "peak = CUs x 64 lanes x 2.4 GHz; lane-operations per offset and VALU utilisation from the committed SQ counters (profiles/, DESIGN.md)"},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kt.items()},
             # host-visible wall time of the last step: blocked on stage A + device genotyper; consensus alignments of the loci
             # handed back to the host path; HMM enqueue / collect (its kernel overlaps the host path); host glue; whole call
             "stage_ms_last_step": {"wait_flank_location_and_genotyper": round(stats[4] / 1e6, 2), "consensus": round(stats[5] / 1e6, 2),
                                    "hmm_host_visible": round(stats[6] / 1e6, 2), "host_glue": round(stats[7] / 1e6, 2),
                                    "total": round(stats[8] / 1e6, 2)},
-            "work_per_step": {"flank_wfa_jobs": int(stats[0]), "flank_wfa_jobs_first_launch": int(stats[14]), "consensus_jobs": int(stats[1]), "spanning_reads": int(stats[2]),
-                              "hmm_jobs": int(stats[3]), "filter_kept": int(stats[16]), "filter_offsets": int(stats[17])},
+            "work_per_step": {"flank_wfa_jobs": int(stats[0]), "flank_wfa_jobs_expensive": int(stats[14]), "filter_kept": int(stats[16]),
+                              "filter_offsets": int(stats[17]), "consensus_jobs": int(stats[1]), "edit_distance_jobs": int(stats[15]),
+                              "spanning_reads": int(stats[2]), "hmm_jobs": int(stats[3])},
         }
+        if digest_check:
+            res["multi_gpu_digest_check"] = digest_check
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(batch)
+            res["cpu_baseline"], res["parity"] = cpu_baseline(batch, out, args.config)
             nthr = min(os.cpu_count() or 1, 128)
-            if nthr > 1:
+            if nthr > 1 and args.config in (2, 4):
                 res["cpu_baseline_all_cores"] = cpu_baseline_mt(batch, nthr)
         print(json.dumps(res))
     if world > 1:

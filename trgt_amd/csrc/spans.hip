@@ -441,14 +441,16 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     int64_t min_matches = thr > 0 ? (int64_t)std::ceil(thr) : 0;
     while (min_matches > 0 && (double)(min_matches - 1) >= thr) --min_matches;
     while ((double)min_matches < thr) ++min_matches;
-    const bool use_filter = p.mism == 2 && p.gapo == 5 && p.gape == 1 && (int64_t)heavy_tlen_max <= flank_filter_max_tlen(p.flank_len) &&
+    // (texts beyond the filter's diagonals are kept unseen, job by job: a batch with a few long reads still filters the others)
+    const int64_t flt_tlen = flank_filter_max_tlen(p.flank_len);
+    const bool use_filter = p.mism == 2 && p.gapo == 5 && p.gape == 1 && flt_tlen >= 2 * (int64_t)p.flank_len &&
                             heavy_tlen_max >= (uint32_t)p.flank_len && min_matches <= 254 && !c->knobs.no_filter;
     if (use_filter) {
       void* d_keepjobs = nullptr;
       if ((rc = dev_get(c, S_FS_KEEPJOBS, n_jobs * sizeof(JobDev), &d_keepjobs))) return rc;
       FilterLaunch FL;
       FL.jobs_dev = (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs; FL.n_jobs_dev = (const uint32_t*)d_count;
-      FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = heavy_tlen_max;
+      FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
       FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
       if ((rc = flank_filter_launch(c, FL))) return rc;
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + 6;

@@ -44,3 +44,76 @@ def generate(n_loci, first_locus=0, config=2, threads=0, **overrides):
         out[name] = arr.view(dt).copy() if n else np.zeros(0, dt)
     _lib.lib().trgt_synth_free(h)
     return out
+
+
+# ---- BASELINE configs[2]: the pathogenic catalog with expanded alleles (HMM stress) -------------------------------------------
+# The 56 motif sets of the reference's pathogenic catalog (repeats/pathogenic_repeats.hg38.bed: ID, MOTIFS, STRUC; kept as data in
+# trgt_amd/data/pathogenic_motif_sets.json) with, per locus, one allele of 10-40 motif units and one expanded allele whose length
+# is log-uniform in [500, max_allele_bp]; 30 reads per locus with the error model of SURVEY.md Appendix E.  Host-side numpy (70
+# loci): the generator of the other configs (trgt_synth_generate, host C++) only knows single synthetic motif sets.
+def _mutate_np(rng, seq, sub, dele, ins):
+    a = np.frombuffer(seq, np.uint8).copy()
+    n = len(a)
+    if n == 0:
+        return seq
+    r = rng.random(n)
+    s = r < sub
+    if s.any():
+        bases = np.frombuffer(b"ACGT", np.uint8)
+        code = np.zeros(256, np.int64)
+        code[bases] = np.arange(4)
+        a[s] = bases[(code[a[s]] + rng.integers(1, 4, size=int(s.sum()))) % 4]  # another base
+    keep = ~((r >= sub) & (r < sub + dele))
+    a = a[keep]
+    q = rng.random(len(a)) < ins
+    if q.any():
+        pos = np.nonzero(q)[0] + 1
+        a = np.insert(a, pos, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=len(pos))])
+    return a.tobytes()
+
+
+def generate_cfg3(n_loci=70, first_locus=0, seed=20250509, max_allele_bp=10000, reads_per_locus=30, flank_len=250, context_len=250,
+                  truncate_rate=0.10):
+    """Returns the same dict of ABI arrays as generate() (through locus.pack) for loci [first_locus, first_locus + n_loci)."""
+    import json
+    import os
+
+    from . import locus as _locus
+    sets = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "pathogenic_motif_sets.json")))["loci"]
+    bases = np.frombuffer(b"ACGT", np.uint8)
+    loci = []
+    for li in range(first_locus, first_locus + n_loci):
+        rng = np.random.default_rng([seed, 3, li])
+        s = sets[li % len(sets)]
+        motifs = [m.encode() for m in s["motifs"]]
+
+        def fill(m):
+            return bytes(b if b != ord("N") else int(bases[rng.integers(0, 4)]) for b in m)
+
+        def allele(total):
+            out = bytearray()
+            per = max(1, total // len(motifs))
+            for m in motifs:
+                run = bytearray()
+                while len(run) < per:
+                    u = bytearray(fill(m))
+                    if rng.random() < 0.01:
+                        u[int(rng.integers(0, len(u)))] = int(bases[rng.integers(0, 4)])
+                    run += u
+                out += run
+            return bytes(out)
+
+        mean_len = sum(len(m) for m in motifs) / len(motifs)
+        a_short = allele(int(int(rng.integers(10, 41)) * mean_len))
+        a_long = allele(int(np.exp(rng.uniform(np.log(500.0), np.log(float(max_allele_bp))))))
+        rnd = lambda n: bases[rng.integers(0, 4, size=n)].tobytes()
+        lf, rf, lc, rc = rnd(flank_len), rnd(flank_len), rnd(context_len), rnd(context_len)
+        reads = []
+        for i in range(reads_per_locus):
+            r = _mutate_np(rng, lc + lf + (a_short if i % 2 else a_long) + rf + rc, 5e-4, 2.5e-4, 2.5e-4)
+            if rng.random() < truncate_rate:  # a read that ends (or starts) inside the locus
+                cut = int(rng.integers(context_len + flank_len // 2, max(context_len + flank_len // 2 + 1, len(r) - context_len)))
+                r = r[:cut] if rng.random() < 0.5 else r[len(r) - cut:]
+            reads.append(r)
+        loci.append(dict(left_flank=lf, right_flank=rf, tr=a_short, motifs=motifs, reads=reads, ploidy=2))
+    return _locus.pack(loci)
