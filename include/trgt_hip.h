@@ -234,6 +234,19 @@ typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x 
 int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,
                      trgt_locus_batch_out* out);
 
+/* Pipelined form (the consumer side of the reference's per-locus channel, src/commands/genotype.rs:140-187): the upload of batch
+ * k + 1 runs next to the kernels of batch k.
+ *   trgt_locus_batch_submit  starts copying the read and flank bytes of the batch to HBM on the context's copy stream (one of two
+ *                            staging sets) and returns at once with a ticket;
+ *   trgt_locus_batch_wait    analyses that batch exactly as trgt_locus_batch does and returns when `out` is complete.
+ * Tickets are waited for in submission order; at most two may be outstanding.  `in`, `out` and everything they point to must stay
+ * valid and unchanged until the wait returns.  The copy is asynchronous when the blobs are in pinned host memory (hipHostMalloc /
+ * hipHostRegister); from pageable memory it still works, the submit then blocks for the copy.  Blobs already in HBM are used in
+ * place.  Usage: submit(b0); for k: { submit(b[k+1]); wait(b[k]); }  */
+int trgt_locus_batch_submit(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,
+                            trgt_locus_batch_out* out, int64_t* ticket);
+int trgt_locus_batch_wait(trgt_hip_ctx* ctx, int64_t ticket);
+
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {
   uint64_t seed;           /* 20250509 */

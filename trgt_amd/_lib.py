@@ -71,7 +71,7 @@ EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity",
-    "trgt_locus_batch", "trgt_locus_default_params", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
+    "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
         L.trgt_flank_filter_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 5 + [C.c_int32] + [_VP] * 4
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
         L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
+        L.trgt_locus_batch_submit.argtypes = [_VP, _VP, _VP, _VP, C.POINTER(C.c_int64)]
+        L.trgt_locus_batch_wait.argtypes = [_VP, C.c_int64]
         L.trgt_locus_default_params.argtypes = [_VP]
         L.trgt_locus_default_params.restype = None
         L.trgt_synth_generate.argtypes = [_VP, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.POINTER(SynthBatch))]

@@ -58,6 +58,8 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
+  for (auto& st : c->staged) if (st.ready) (void)hipEventDestroy(st.ready);
   delete static_cast<trgt::HostPool*>(c->host_pool);
   for (auto& b : c->pinned)
     if (b.p) (void)hipHostFree(b.p);

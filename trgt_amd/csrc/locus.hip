@@ -258,7 +258,10 @@ extern "C" void trgt_locus_default_params(trgt_locus_params* p) {  // cli.rs:271
   p->min_read_qual = 0.98;
 }
 
-extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+// staged_reads / staged_flank: device copies of in->read_blob / in->flank_blob made ahead of time by trgt_locus_batch_submit (the
+// caller's pointers stay what the host glue reads); `ready`: the event behind those copies.
+static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out,
+                           const uint8_t* staged_reads, const uint8_t* staged_flank, hipEvent_t ready) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || !in || !out) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null argument");
   const int64_t nl = in->n_loci;
@@ -294,18 +297,11 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   // The motif-HMM tables depend only on the catalog: build them on a host thread while the GPU locates flanks.
   // They are uploaded from the same thread (second stream), so stage C finds them in HBM.
+  // (the thread touches nothing of the context: its result and error live in `models`; the upload happens on this thread, below,
+  //  once stage A is on the GPU)
   HmmModels models;
-  const hipStream_t upload_stream = c->stream2;
-  std::thread model_thread([&, upload_stream]() {
-    if (hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models)) return;
-    void *d_sets = nullptr, *d_blob = nullptr;
-    if (hipSetDevice(c->device) != hipSuccess) return;
-    if (dev_get(c, S_HMM_DESC, models.sets.size() * sizeof(HmmSetDev), &d_sets) || dev_get(c, S_HMM_MODEL, models.blob.size(), &d_blob)) return;
-    if (hipMemcpyAsync(d_sets, models.sets.data(), models.sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, upload_stream) != hipSuccess ||
-        hipMemcpyAsync(d_blob, models.blob.data(), models.blob.size(), hipMemcpyHostToDevice, upload_stream) != hipSuccess ||
-        hipStreamSynchronize(upload_stream) != hipSuccess) { (void)hipGetLastError(); return; }
-    models.d_sets = d_sets; models.d_blob = d_blob;
-  });
+  const hipStream_t upload_stream = c->stream2;  // (the "second stream" of this call, whichever of the two is current later on)
+  std::thread model_thread([&]() { (void)hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
   HmmPending *hmm_pending = nullptr, *hmm_pending2 = nullptr;
   struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending}, pend_guard2{hmm_pending2};
@@ -360,9 +356,12 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   const uint32_t *d_rlen = nullptr, *d_rloc = nullptr, *d_heavy = nullptr;
   void *d_ss = nullptr, *d_se = nullptr, *d_hl = nullptr, *d_hr = nullptr;
   void *h_ss = nullptr, *h_se = nullptr, *h_hl = nullptr, *h_hr = nullptr, *h_cells = nullptr;
-  if ((rc = dev_in(c, S_FS_FLANK, in->flank_blob, (size_t)flank_total, &d_flank)) ||
-      (rc = dev_in(c, S_FS_READS, in->read_blob, (size_t)read_total, &d_reads)) ||
-      (rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
+  if (ready) TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
+  if (staged_flank) d_flank = staged_flank;
+  else if ((rc = dev_in(c, S_FS_FLANK, in->flank_blob, (size_t)flank_total, &d_flank))) return rc;
+  if (staged_reads) d_reads = staged_reads;
+  else if ((rc = dev_in(c, S_FS_READS, in->read_blob, (size_t)read_total, &d_reads))) return rc;
+  if ((rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
       (rc = dev_in(c, S_FS_LIST, in->read_off, (size_t)nr, &d_roff)) ||
       (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen)) ||
       (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc)) ||
@@ -443,6 +442,16 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
   TL("stage A enqueued");
   init_outputs();  // host-only work: done while the GPU is already busy
+  // the motif-HMM tables: built meanwhile on the model thread, uploaded from here on the second stream (stage C finds them in HBM)
+  if (model_thread.joinable()) model_thread.join();
+  if (models.rc == 0 && !models.sets.empty()) {
+    void *d_sets = nullptr, *d_blob = nullptr;
+    if ((rc = dev_get(c, S_HMM_DESC, models.sets.size() * sizeof(HmmSetDev), &d_sets)) || (rc = dev_get(c, S_HMM_MODEL, models.blob.size(), &d_blob))) return rc;
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, models.sets.data(), models.sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream2));
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_blob, models.blob.data(), models.blob.size(), hipMemcpyHostToDevice, c->stream2));
+    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    models.d_sets = d_sets; models.d_blob = d_blob;
+  }
 
   // ---------------- wait for the GPU, publish spans
   {
@@ -887,3 +896,72 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   }
   return TRGT_OK;
 }
+
+// ---- C ABI: exceptions never cross it (std::bad_alloc from the host-side vectors becomes TRGT_ERR_NOMEM) ----
+#define TRGT_ABI_GUARD(ctx, call)                                                                  \
+  try { return (call); }                                                                           \
+  catch (const std::bad_alloc&) { return trgt::fail((ctx), TRGT_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception& e) { return trgt::fail((ctx), TRGT_ERR_INVALID, "unexpected exception: %s", e.what()); }
+
+extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out) {
+  TRGT_ABI_GUARD(c, locus_batch_run(c, p, in, out, nullptr, nullptr, nullptr));
+}
+
+static int locus_submit(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out, int64_t* ticket) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (!p || !in || !out || !ticket) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_submit: null argument");
+  if (in->n_loci < 0 || (in->n_loci > 0 && (!in->flank_blob || !in->read_blob || !in->lf_off || !in->lf_len || !in->rf_off || !in->rf_len ||
+                                            !in->locus_read_begin || !in->read_off || !in->read_len)))
+    return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_submit: null field");
+  int slot = -1;
+  for (int i = 0; i < 2; ++i) if (!c->staged[i].in_use) { slot = i; break; }
+  if (slot < 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_submit: two batches are outstanding already (wait for the older one first)");
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  trgt_hip_ctx::Staged& st = c->staged[slot];
+  st.params = *p; st.in = in; st.out = out; st.d_reads = nullptr; st.d_flank = nullptr;
+  const int64_t nl = in->n_loci;
+  const int64_t nr = nl > 0 ? (int64_t)in->locus_read_begin[nl] : 0;
+  if (nl > 0 && nr > 0) {
+    if (!c->stream_copy) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    if (!st.ready) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
+    uint64_t flank_total = 0, read_total = 0;
+    for (int64_t l = 0; l < nl; ++l) flank_total = std::max<uint64_t>(flank_total, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
+    for (int64_t r = 0; r < nr; ++r) read_total = std::max<uint64_t>(read_total, in->read_off[r] + in->read_len[r]);
+    int rc;
+    if (!is_device_ptr(in->read_blob)) {
+      void* d = nullptr;
+      if ((rc = dev_get(c, slot ? S_PF_READS1 : S_PF_READS0, (size_t)read_total, &d))) return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d, in->read_blob, (size_t)read_total, hipMemcpyHostToDevice, c->stream_copy));
+      st.d_reads = (const uint8_t*)d;
+    }
+    if (!is_device_ptr(in->flank_blob)) {
+      void* d = nullptr;
+      if ((rc = dev_get(c, slot ? S_PF_FLANK1 : S_PF_FLANK0, (size_t)flank_total, &d))) return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(d, in->flank_blob, (size_t)flank_total, hipMemcpyHostToDevice, c->stream_copy));
+      st.d_flank = (const uint8_t*)d;
+    }
+    TRGT_HIP_TRY(c, hipEventRecord(st.ready, c->stream_copy));
+  }
+  st.in_use = true; st.ticket = c->next_ticket++;
+  *ticket = st.ticket;
+  return TRGT_OK;
+}
+
+static int locus_wait(trgt_hip_ctx* c, int64_t ticket) {
+  if (!c) return TRGT_ERR_INVALID;
+  int slot = -1;
+  for (int i = 0; i < 2; ++i) if (c->staged[i].in_use && c->staged[i].ticket == ticket) slot = i;
+  if (slot < 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_wait: unknown ticket %lld", (long long)ticket);
+  for (int i = 0; i < 2; ++i)
+    if (c->staged[i].in_use && c->staged[i].ticket < ticket) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_wait: ticket %lld was submitted earlier and must be waited for first", (long long)c->staged[i].ticket);
+  trgt_hip_ctx::Staged& st = c->staged[slot];
+  const bool staged_any = st.d_reads || st.d_flank;
+  const int rc = locus_batch_run(c, &st.params, st.in, st.out, st.d_reads, st.d_flank, staged_any ? st.ready : nullptr);
+  st.in_use = false;
+  return rc;
+}
+
+extern "C" int trgt_locus_batch_submit(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out, int64_t* ticket) {
+  TRGT_ABI_GUARD(c, locus_submit(c, p, in, out, ticket));
+}
+extern "C" int trgt_locus_batch_wait(trgt_hip_ctx* c, int64_t ticket) { TRGT_ABI_GUARD(c, locus_wait(c, ticket)); }

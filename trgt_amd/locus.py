@@ -146,12 +146,8 @@ _CIN_KEYS = ("lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_le
              "locus_read_begin", "read_off", "read_len", "genotyper", "read_qual")
 
 
-def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, reads_dev=None):
-    """trgt_locus_batch on a packed batch.  Returns the (reusable) BatchOutputs."""
-    ctx = ctx or _lib.context()
-    out = outputs or BatchOutputs(batch)
+def _batch_in(batch, flank, reads):
     p = _lib.ptr
-    flank, reads = flank_dev if flank_dev is not None else batch["flank_blob"], reads_dev if reads_dev is not None else batch["read_blob"]
     # The input struct of a batch is rebuilt only when one of its arrays is replaced (20 pointer conversions per call otherwise).
     # The cache entry HOLDS the arrays it was built from and compares them by identity: an id() alone could be reused by a new
     # array allocated at a freed one's address, and the struct would then carry a dangling pointer.
@@ -167,11 +163,56 @@ def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, re
             p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
         cached = (key, cin)
         batch["_cin"] = cached
-    cin = cached[1]
-    lp = _lib.LocusParams(params.search_flank_len, params.min_flank_id_frac, params.max_depth, params.aln_scoring[0],
-                          params.aln_scoring[1], params.aln_scoring[2], params.host_threads, params.min_read_qual)
+    return cached[1]
+
+
+def _locus_params(params):
+    return _lib.LocusParams(params.search_flank_len, params.min_flank_id_frac, params.max_depth, params.aln_scoring[0],
+                            params.aln_scoring[1], params.aln_scoring[2], params.host_threads, params.min_read_qual)
+
+
+def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, reads_dev=None):
+    """trgt_locus_batch on a packed batch.  Returns the (reusable) BatchOutputs."""
+    ctx = ctx or _lib.context()
+    out = outputs or BatchOutputs(batch)
+    flank, reads = flank_dev if flank_dev is not None else batch["flank_blob"], reads_dev if reads_dev is not None else batch["read_blob"]
+    cin = _batch_in(batch, flank, reads)
+    lp = _locus_params(params)
     ctx.check(_lib.lib().trgt_locus_batch(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out)))
     return out
+
+
+class Ticket:
+    """A batch handed to trgt_locus_batch_submit: keeps everything the library still points at alive until wait()."""
+
+    def __init__(self, ctx, batch, out, cin, lp, blobs, ticket):
+        self.ctx, self.batch, self.outputs, self._cin, self._lp, self._blobs, self.id = ctx, batch, out, cin, lp, blobs, ticket
+
+    def wait(self):
+        """trgt_locus_batch_wait: analyses the batch (its reads were uploading meanwhile) and returns the BatchOutputs."""
+        self.ctx.check(_lib.lib().trgt_locus_batch_wait(self.ctx.handle, self.id))
+        return self.outputs
+
+
+def submit_batch(batch, params=Params(), ctx=None, outputs=None, flank=None, reads=None):
+    """trgt_locus_batch_submit: start uploading the batch's read / flank bytes (pass pinned torch tensors or numpy arrays in
+    `reads` / `flank` for an asynchronous copy) and return a Ticket; ticket.wait() runs the analysis.  At most two tickets may be
+    outstanding per context, waited for in order: submit(b0); loop { submit(b[k+1]); wait(b[k]) } overlaps upload and compute."""
+    ctx = ctx or _lib.context()
+    out = outputs or BatchOutputs(batch)
+    fl, rd = flank if flank is not None else batch["flank_blob"], reads if reads is not None else batch["read_blob"]
+    # (a struct of its own: the cached one of run_batch may be rebuilt while this batch is in flight)
+    p = _lib.ptr
+    cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
+        fl, batch["lf_off"], batch["lf_len"], batch["rf_off"], batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"],
+        batch["motif_blob"], batch["motif_off"], batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
+        rd, batch["read_off"], batch["read_len"])],
+        p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
+        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
+    lp = _locus_params(params)
+    t = C.c_int64(0)
+    ctx.check(_lib.lib().trgt_locus_batch_submit(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out), C.byref(t)))
+    return Ticket(ctx, batch, out, cin, lp, (fl, rd), t.value)
 
 
 def locus_result(batch, out, l):
