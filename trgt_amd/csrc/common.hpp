@@ -71,6 +71,8 @@ struct trgt_hip_ctx {
     bool in_use = false; int64_t ticket = 0;
     trgt_locus_params params; const trgt_locus_batch_in* in = nullptr; trgt_locus_batch_out* out = nullptr;
     const uint8_t* d_reads = nullptr; const uint8_t* d_flank = nullptr;  // staged copies (nullptr: the caller's pointer is used as it is)
+    uint64_t read_bytes = 0, flank_bytes = 0;
+    bool copy_pending = false;  // the copy is issued from inside the wait of the batch before (see issue_pending_uploads)
     hipEvent_t ready = nullptr;
   } staged[2];
   int64_t next_ticket = 1;
