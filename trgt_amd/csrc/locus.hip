@@ -458,6 +458,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
   TL("stage A enqueued");
   init_outputs();  // host-only work: done while the GPU is already busy
+  const int64_t tw_a = now_ns();  // from here on the host waits for stage A (the table upload below sits behind it in the copy queue)
   // the motif-HMM tables: built meanwhile on the model thread, uploaded from here on the second stream (stage C finds them in HBM)
   if (model_thread.joinable()) model_thread.join();
   if (models.rc == 0 && !models.sets.empty()) {
@@ -471,9 +472,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
 
   // ---------------- wait for the GPU, publish spans
   {
-    const int64_t tw = now_ns();
     TRGT_HIP_TRY(c, hipEventSynchronize(evA));
-    tA = now_ns() - tw;
+    tA = now_ns() - tw_a;
   TL("evA");
   }
   int64_t th_begin = now_ns();
