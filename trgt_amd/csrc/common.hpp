@@ -76,6 +76,10 @@ struct trgt_hip_ctx {
     hipEvent_t ready = nullptr;
   } staged[2];
   int64_t next_ticket = 1;
+  // side streams for the launches of one HMM batch (one per workgroup-size class: they run next to each other, not one behind the
+  // other's tail), with the events that fork them off the batch's stream and join them back
+  hipStream_t hmm_side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t hmm_fork = nullptr, hmm_join[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace trgt {
@@ -202,12 +206,12 @@ struct DevOut {
 
 // ---- kernel timing: events on the ctx stream, resolved lazily ---------------------------------
 struct KTimer {
-  trgt_hip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr; bool on;
-  KTimer(trgt_hip_ctx* c_, int k_) : c(c_), k(k_), on(c_->timing) {
-    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+  trgt_hip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t s;
+  KTimer(trgt_hip_ctx* c_, int k_, hipStream_t stream = nullptr) : c(c_), k(k_), on(c_->timing), s(stream ? stream : c_->stream) {
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
   }
   void stop(int64_t cells) {
-    if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({k, a, b}); c->k_launches[k] += 1; c->k_cells[k] += cells; }
+    if (on) { (void)hipEventRecord(b, s); c->pending.push_back({k, a, b}); c->k_launches[k] += 1; c->k_cells[k] += cells; }
   }
 };
 inline void resolve_timing(trgt_hip_ctx* c) {

@@ -60,6 +60,11 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
   for (auto& st : c->staged) if (st.ready) (void)hipEventDestroy(st.ready);
+  for (int i = 0; i < 3; ++i) {
+    if (c->hmm_side[i]) { (void)hipStreamSynchronize(c->hmm_side[i]); (void)hipStreamDestroy(c->hmm_side[i]); }
+    if (c->hmm_join[i]) (void)hipEventDestroy(c->hmm_join[i]);
+  }
+  if (c->hmm_fork) (void)hipEventDestroy(c->hmm_fork);
   delete static_cast<trgt::HostPool*>(c->host_pool);
   for (auto& b : c->pinned)
     if (b.p) (void)hipHostFree(b.p);

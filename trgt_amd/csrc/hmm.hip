@@ -197,8 +197,16 @@ __device__ __forceinline__ int hmm_code_char(int code) { return (int)((0x4743544
 // lockstep and the LDS unit serves one wave's accesses in order, so a compiler-level fence is all that is needed -- whereas
 // __syncthreads() also waits for every global store in flight (the back-pointer column written at the end of each step), a
 // memory round trip per step.
+// Several waves: an LDS-only barrier.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier, and the vmcnt(0) makes every
+// one of the four barriers of a column wait for the back-pointer stores of the column before (a round trip to L2 each, most of a
+// column's time for the 170- to 190-state models); those bytes are read again only by the trace-back, behind hmm_sync_mem().
 __device__ __forceinline__ void hmm_sync(int nthr) {
   if (nthr == 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// ... and the full one: global stores of the whole workgroup are visible afterwards
+__device__ __forceinline__ void hmm_sync_mem(int nthr) {
+  if (nthr == 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   else __syncthreads();
 }
 
@@ -206,6 +214,7 @@ __device__ __forceinline__ void hmm_sync(int nthr) {
 // The fill reads one base per column and the traceback / decode of thread 0 is a chain of dependent loads: served from HBM each
 // of them costs a memory round trip, which was most of this kernel's time.
 constexpr int HMM_STAGE_QLEN = 2048;
+constexpr int HMM_CODE_WINDOW = 512;  // columns of symbol codes kept in LDS by the kernel for longer alleles
 // SUB: lanes per allele.  64 (or more: one thread per state, several waves for large motif sets) is the general case; SUB = 32
 // packs TWO alleles into one wave when the model has at most 32 states (a single STR motif of up to 8 bases): the kernel is bound
 // by instruction issue and most passes of a column keep only one or two lanes busy, so halving the waves nearly halves its time.
@@ -298,9 +307,15 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
   const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
-  auto code_at = [&](int i) -> int { return STAGE ? (int)l_seq[i] : hmm_code(seq, i, L); };
+  // Symbol code of column i.  STAGE: the whole allele sits in LDS.  Otherwise (alleles beyond HMM_STAGE_QLEN) the fill and the
+  // trace-back keep a WINDOW of codes in LDS (l_seq, HMM_CODE_WINDOW columns from win0 on) and only the decode reads global memory:
+  // a load per column put a memory round trip -- and, the loads and the back-pointer stores sharing one in-order counter, the store
+  // of the column before -- into every step of a 10-kb allele.
+  int win0 = 0;
+  auto code_at = [&](int i) -> int { return STAGE ? (int)l_seq[i] : (int)l_seq[i - win0]; };
+  auto code_global = [&](int i) -> int { return STAGE ? (int)l_seq[i] : hmm_code(seq, i, L); };
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
-  hmm_sync(sync_n);
+  hmm_sync_mem(sync_n);  // (also orders the zeroing of the motif counts above before thread 0 counts into them)
   // traceback word of my state: kind (0 outside any block, 1 block start, 2 block end, 3 skip state, 4 match, 5 insertion,
   // 6 deletion) | emits << 3 | block << 8 | expected motif base << 16 (match states)
   if (act) {
@@ -331,10 +346,16 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
   double* cur = sc1;
-  int sym_next = code_at(0);
+  int sym_next = STAGE ? code_at(0) : 0;
   for (int i = 0; i < L; ++i) {
-    const int sym = sym_next;
-    if (i + 1 < L) sym_next = code_at(i + 1);
+    if (!STAGE && (i % HMM_CODE_WINDOW) == 0) {  // next window of symbol codes
+      hmm_sync(sync_n);
+      win0 = i;
+      for (int k = tid; k < HMM_CODE_WINDOW && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
+      hmm_sync(sync_n);
+    }
+    const int sym = STAGE ? sym_next : code_at(i);
+    if (STAGE && i + 1 < L) sym_next = code_at(i + 1);
     double best = NINF;
     int bpi = 0xFF;
     if (act && level == 0) {
@@ -430,7 +451,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
   }
-  hmm_sync(sync_n);
+  hmm_sync_mem(sync_n);  // the back-pointer columns written by all waves are read back from here on
 
   // ---- traceback (hmm_model.rs:125-142) fused with get_events/calc_purity (events.rs:17-86, purity.rs:6-41)
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
@@ -447,6 +468,10 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       uint4* dst = reinterpret_cast<uint4*>(l_stage);
       const int n16 = (c1 - c0) * Spad / 16;
       for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
+      if (!STAGE) {  // ... and the symbol codes of the same columns
+        win0 = c0;
+        for (int k = tid; k < c1 - c0; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, c0 + k, L);
+      }
     }
     hmm_sync(sync_n);
     if (tid == 0) {
@@ -489,13 +514,14 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // ---- state path: shift the reversed tail to the front (forward order)
   if (pbuf) {
     const int n = min(np, pcap), shift = pcap - n;
+    hmm_sync_mem(sync_n);  // (the path was written by thread 0)
     for (int base = 0; base < n; base += nthr) {
       const int f = base + tid;
       uint16_t v = 0;
       if (f < n) v = pbuf[shift + f];
-      hmm_sync(sync_n);
+      hmm_sync_mem(sync_n);
       if (f < n) pbuf[f] = v;
-      hmm_sync(sync_n);
+      hmm_sync_mem(sync_n);
     }
   }
   // ---- decode (thread 0): purity, remove_imperfect_motifs(.., 6), label_motifs, skip filter, counts, collapse
@@ -517,7 +543,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         else {
           const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
           for (int j = 0; j < mlen; ++j) {
-            const int obs = hmm_code_char(code_at(b0 + j + 1));
+            const int obs = hmm_code_char(code_global(b0 + j + 1));
             if (mot[j] != 'N' && obs != mot[j]) keep = false;
           }
         }
@@ -557,6 +583,7 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb, uint32_t stage_qcap) {
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
   if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 2 * ((3 * ((size_t)stage_qcap + 3) + 1) & ~(size_t)1) + 4 * (size_t)nb;
+  else o += HMM_CODE_WINDOW + 16;  // the window of symbol codes (l_seq) of the kernel without staging
   return o + 64;
 }
 
@@ -718,6 +745,19 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const uint32_t c0 = job_class(jobs[0]);
     for (const auto& jd : jobs) if (job_class(jd) != c0) { mixed = true; break; }
     if (mixed) std::stable_sort(jobs.begin(), jobs.end(), [&](const HmmJobDev& a, const HmmJobDev& b) { return job_class(a) < job_class(b); });
+    // Inside a class the longest alleles go first: workgroups start in list order, and a launch ends with its last allele -- a 10-kb
+    // allele started behind a thousand short ones is pure tail.  (Classes of many alleles of similar length -- the single STR motif
+    // of a whole-genome catalog -- are left alone: sorting twenty thousand jobs costs more than it saves.)
+    size_t b0 = 0;
+    while (b0 < jobs.size()) {
+      size_t b1 = b0; uint32_t mx = 0; uint64_t sum = 0;
+      const uint32_t jc = job_class(jobs[b0]);
+      while (b1 < jobs.size() && job_class(jobs[b1]) == jc) { mx = std::max(mx, jobs[b1].seq_len); sum += jobs[b1].seq_len; ++b1; }
+      const size_t n = b1 - b0;
+      if (n > 1 && (n <= 4096 || (uint64_t)mx * n > 4 * sum))
+        std::stable_sort(jobs.begin() + (ptrdiff_t)b0, jobs.begin() + (ptrdiff_t)b1, [](const HmmJobDev& a, const HmmJobDev& b) { return a.seq_len > b.seq_len; });
+      b0 = b1;
+    }
   }
   // ---- device buffers
   const uint8_t* d_seq = nullptr;
@@ -782,8 +822,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   if ((rc = o_pur.init(c, S_HMM_PUR + so, purity, (size_t)n_jobs))) return rc;
   if ((rc = o_edit.init(c, S_HMM_EDIT + so, edit_dist, (size_t)n_jobs))) return rc;
   if ((rc = o_maxd.init(c, S_HMM_MAXD + so, max_dist, (size_t)n_jobs))) return rc;
-  // ---- one launch per workgroup-size class
+  // ---- one launch per workgroup-size class; the first on the batch's stream, the others on side streams forked off it, so that
+  //      the classes run next to each other (a class is bounded by its longest allele: one behind the other they add up their tails)
   size_t i = 0;
+  int n_class = 0;
+  bool forked = false;
+  unsigned side_used = 0;
   while (i < jobs.size()) {
     const uint32_t jc = job_class(jobs[i]), cls = jc >> 1;
     const bool stage = (jc & 1u) == 0;
@@ -800,11 +844,23 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const void* kfn = half ? (stage ? (const void*)hmm_viterbi_kernel<true, 32> : (const void*)hmm_viterbi_kernel<false, 32>)
                            : (stage ? (const void*)hmm_viterbi_kernel<true, 64> : (const void*)hmm_viterbi_kernel<false, 64>);
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    KTimer t(c, TRGT_K_HMM);
+    hipStream_t ls = c->stream;
+    if (n_class > 0) {
+      const int sidx = (n_class - 1) % 3;
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->hmm_side[sidx], hipStreamNonBlocking));
+      if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
+      if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
+      if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }  // behind the uploads (and the first launch)
+      ls = c->hmm_side[sidx];
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork, 0));
+      side_used |= 1u << sidx;
+    }
+    ++n_class;
+    KTimer t(c, TRGT_K_HMM, ls);
     const uint32_t nj = (uint32_t)(e - i);
     const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * cls);
 #define TRGT_HMM_LAUNCH(ST, SB)                                                                                                     \
-    hipLaunchKernelGGL((hmm_viterbi_kernel<ST, SB>), grid, block, lds, c->stream, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<ST, SB>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev,    \
                        o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, qcap, nj, (uint32_t)lds_job)
     if (half) { if (stage) TRGT_HMM_LAUNCH(true, 32); else TRGT_HMM_LAUNCH(false, 32); }
@@ -814,6 +870,11 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     t.stop(i == 0 ? cells : 0);
     i = e;
   }
+  for (int sidx = 0; sidx < 3; ++sidx)
+    if (side_used & (1u << sidx)) {
+      TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
+    }
   *out_pending = P.release();
   return TRGT_OK;
 }

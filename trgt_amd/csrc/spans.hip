@@ -385,7 +385,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     if (m != 4 && m != 6 && m != 8) m = WIN_SEGMENTS_DEFAULT;
     win_m = m;
     const int q = p.flank_len / m, x = p.mism, o = p.gapo, e = p.gape;
-    const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < (has_long ? long_tlen : max_read_len) && !c->knobs.one_launch;
+    const bool two_launches = d_heavy_len && heavy_tlen_max > 0 && !c->knobs.one_launch;
     const bool ok = two_launches && !c->knobs.no_window && q >= 12 && x >= 1 && e >= 1 && o >= 0 &&
                     q * e >= x && o + 2 * e >= 2 * x && o + e >= x;
     if (ok) {
@@ -427,7 +427,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   // Two launches.  The front of the list (reads too short to span their locus: 95 % of the wavefront offsets) holds short texts
   // only, so its launch is planned for heavy_tlen_max: a smaller LDS ring per alignment and one more resident workgroup per CU
   // (occupancy is what this latency-bound kernel lives on: 16.9 -> 15.1 ms from 4 to 5 per CU).  The rest follows at the full size.
-  const bool split = d_heavy_len && heavy_tlen_max > 0 && heavy_tlen_max < short_max && !c->knobs.one_launch;
+  // (a catalog with a few long-read loci has heavy_tlen_max beyond the dedicated kernel's texts: those reads are on the long list
+  //  anyway, the launch over the expensive alignments is planned for what is left)
+  const bool split = d_heavy_len && heavy_tlen_max > 0 && !c->knobs.one_launch;
+  heavy_tlen_max = std::min(heavy_tlen_max, short_max);
   c->last_filter_cells_dev = nullptr;
   if (split) {
     WfaLaunch LH = L;
