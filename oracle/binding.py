@@ -335,3 +335,17 @@ def cluster_groups(dists, n):
     g = np.zeros(n, np.int32)
     k = lib().orc_cluster_groups(_p(d), int(n), _p(g))
     return k, g, d
+
+
+def genotype_sizes(ploidy, sizes, counts):
+    """haploid::genotype / diploid::genotype on a length histogram -> [(size, (ci_lo, ci_hi)), ...]"""
+    s, c = np.ascontiguousarray(sizes, np.int32), np.ascontiguousarray(counts, np.int32)
+    gt = np.zeros(6, np.int32)
+    n = lib().orc_genotype_sizes(int(ploidy), _p(s), _p(c), len(s), _p(gt))
+    return [(int(gt[3 * a]), (int(gt[3 * a + 1]), int(gt[3 * a + 2]))) for a in range(n)]
+
+
+def hmm_base_match_ems(ems_probs, state):
+    """get_base_match on Hmm::new(len(ems_probs)) with set_ems(state, probs) for every state; returns a 1-char string."""
+    e = np.ascontiguousarray(ems_probs, np.float64).reshape(-1, 5)
+    return chr(lib().orc_hmm_base_match_ems(len(e), _p(e), int(state)))

@@ -494,6 +494,13 @@ int orc_hmm_base_match(const uint8_t* mb, const uint32_t* mo, int nm, int state)
   return hmm_base_match(h, state);
 }
 
+// get_base_match on a hand-made model: Hmm::new(n_states) + set_ems(state, probs) for every state (events.rs:138-145 builds one)
+int orc_hmm_base_match_ems(int n_states, const double* ems_probs /* 5 per state */, int state) {
+  Hmm h(n_states);
+  for (int s = 0; s < n_states; ++s) h.set_ems(s, {ems_probs[5 * s], ems_probs[5 * s + 1], ems_probs[5 * s + 2], ems_probs[5 * s + 3], ems_probs[5 * s + 4]});
+  return hmm_base_match(h, state);
+}
+
 void orc_replace_invalid_bases(uint8_t* seq, int len, const char* allowed) {
   std::string r = replace_invalid_bases(std::string((const char*)seq, len), allowed);
   std::memcpy(seq, r.data(), len);

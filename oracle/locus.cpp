@@ -481,6 +481,14 @@ int orc_find_spans(const uint8_t* piece, int piece_len, int64_t n_reads, const u
 }
 
 // kodama-style Ward linkage on a condensed matrix (mutated in place); steps4 = n-1 x (cluster1, cluster2, size), diss = n-1 doubles
+// haploid::genotype / diploid::genotype on a length histogram (haploid.rs:3-15, diploid.rs:5-49); gt3 = (size, ci_lo, ci_hi) per allele
+int orc_genotype_sizes(int ploidy, const int32_t* sizes, const int32_t* counts, int n, int32_t* gt3) {
+  std::vector<int> s(sizes, sizes + n), c(counts, counts + n);
+  const std::vector<TrSize> gt = ploidy == 1 ? haploid_genotype(s, c) : diploid_genotype(s, c);
+  for (size_t a = 0; a < gt.size(); ++a) { gt3[3 * a] = gt[a].size; gt3[3 * a + 1] = gt[a].ci_lo; gt3[3 * a + 2] = gt[a].ci_hi; }
+  return (int)gt.size();
+}
+
 int orc_ward_linkage(double* dists, int n, int32_t* steps3, double* diss) {
   std::vector<double> d(dists, dists + (size_t)n * (size_t)(n - 1) / 2);
   std::vector<WardStep> st = ward_linkage(d, n);

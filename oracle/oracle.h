@@ -54,6 +54,8 @@ double orc_hmm_purity(const uint8_t* motif_blob, const uint32_t* motif_off, int 
                       int32_t* edit_dist, int32_t* max_dist);
 /* get_base_match (events.rs:88-117) */
 int orc_hmm_base_match(const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs, int state);
+/* get_base_match on a hand-made model (Hmm::new + set_ems with probabilities, hmm_model.rs:28-52; events.rs:138-145) */
+int orc_hmm_base_match_ems(int n_states, const double* ems_probs /* 5 per state */, int state);
 /* replace_invalid_bases (utils.rs:29-42); allowed is a NUL-terminated string */
 void orc_replace_invalid_bases(uint8_t* seq, int len, const char* allowed);
 
@@ -175,6 +177,10 @@ int64_t orc_locus_analyze_records(const orc_locus_params* p, int64_t first, int6
                                   const uint64_t* read_off, const uint32_t* read_len, int n_threads, const uint8_t* genotyper,
                                   const uint8_t* ploidy, char* rec_blob, uint64_t rec_stride,
                                   const double* read_qual /* one per read of the batch (NaN = no rq tag), or NULL */);
+
+/* haploid::genotype / diploid::genotype on a histogram of repeat lengths (haploid.rs:3-15, diploid.rs:5-49): gt3 receives
+ * (size, ci_lo, ci_hi) per allele; returns the number of alleles (1 or 2). */
+int orc_genotype_sizes(int ploidy, const int32_t* sizes, const int32_t* counts, int n, int32_t* gt3);
 
 /* Ward linkage as kodama 0.3.0's linkage(.., Method::Ward) performs it (PARITY UNPINNED, see locus.cpp): dists is
  * the condensed matrix, overwritten as kodama overwrites it.  Returns the number of steps (n-1). */

@@ -239,3 +239,70 @@ def test_dedicated_affine_kernel_penalties_and_shapes(oracle, W, pen, span):
         got = al.align_ends_free_batch(pats, 3, 5, txts, 40, 7)
         op = oracle.wfa_params(metric="affine", x=x, o1=o, e1=e, span="endsfree", pbf=3, pef=5, tbf=40, tef=7, heuristic="none")
     _check_batch(oracle, got, op, pats, txts)
+
+
+def _plain_affine_global(a, b, x, o, e):
+    """Gotoh: the exact global gap-affine penalty, independent of any wavefront code."""
+    INF = 1 << 28
+    n, m = len(a), len(b)
+    M = [0] + [INF] * m
+    I = [INF] * (m + 1)   # gap in a (text base consumed)
+    D = [INF] * (m + 1)
+    for j in range(1, m + 1):
+        I[j] = o + e * j
+        M[j] = I[j]
+    for i in range(1, n + 1):
+        pM, pI, pD = M, I, D
+        M, I, D = [INF] * (m + 1), [INF] * (m + 1), [INF] * (m + 1)
+        D[0] = o + e * i
+        M[0] = D[0]
+        for j in range(1, m + 1):
+            D[j] = min(pM[j] + o + e, pD[j] + e)
+            I[j] = min(M[j - 1] + o + e, I[j - 1] + e)
+            M[j] = min(pM[j - 1] + (0 if a[i - 1] == b[j - 1] else x), I[j], D[j])
+    return M[m]
+
+
+def test_biwfa_cigars_are_valid_and_optimal_without_the_oracle(W):
+    """BiWFA tie-breaks are unpinned by the reference, so this test leaves the oracle out: whatever CIGAR the GPU returns
+    for a completed end-to-end BiWFA alignment must (i) spell the text out of the pattern, (ii) cost what the aligner reports, and
+    (iii) with Heuristic::None cost exactly the global gap-affine optimum computed by plain dynamic programming."""
+    rng = np.random.default_rng(2718)
+    pats, txts = [], []
+    for i in range(90):
+        motif = [rand_dna(rng, int(rng.integers(2, 7)))]
+        backbone = repeat_allele(rng, motif, int(rng.integers(10, 330)), err=0.0)
+        read = mutate(rng, backbone, 0.02, 0.015, 0.015)
+        if i % 4 == 0:
+            k = len(motif[0]) * int(rng.integers(1, 5))
+            read = read[:len(read) // 3] + (motif[0] * 5)[:k] + read[len(read) // 3:] if i % 8 else read[k:]
+        pats.append(backbone)
+        txts.append(read)
+    x, o, e = 2, 5, 1
+    for heuristic in (W.Heuristic.none(), None):
+        b = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(x, o, e)
+        al = (b.with_heuristic(heuristic) if heuristic is not None else b).build()
+        got = al.align_end_to_end_batch(pats, txts)
+        for j, (p, t) in enumerate(zip(pats, txts)):
+            if int(got["status"][j]) != 0:
+                assert heuristic is None, "exact BiWFA must complete"
+                continue
+            ops = bytes(got["ops"][int(got["cigar_off"][j]):int(got["cigar_off"][j]) + int(got["ops_len"][j])]).decode()
+            pi = ti = 0
+            cost, prev = 0, ""
+            for c in ops:
+                if c in "MX":
+                    assert (p[pi] == t[ti]) == (c == "M"), (j, pi, ti)
+                    cost += x if c == "X" else 0
+                    pi += 1; ti += 1
+                elif c == "I":
+                    cost += e + (o if prev != "I" else 0); ti += 1
+                else:
+                    assert c == "D"
+                    cost += e + (o if prev != "D" else 0); pi += 1
+                prev = c
+            assert pi == len(p) and ti == len(t), (j, "the CIGAR does not span both sequences")
+            if max(len(p), len(t)) > 100:  # (shorter pairs take the unidirectional base case, which never sets cigar.score)
+                assert int(got["score"][j]) == -cost, (j, int(got["score"][j]), cost)
+            if heuristic is not None:
+                assert cost == _plain_affine_global(p, t, x, o, e), (j, cost)

@@ -168,8 +168,6 @@ class WFAligner:
         self.ctx = ctx
         self._last = None  # result of the most recent single alignment (the aligner "owns" its CIGAR, :386-389)
         self._span = "end2end"
-        if pen.match_ != 0:
-            raise NotImplementedError("non-zero match scores are never used on TRGT's paths (wfaligner.rs:292-294)")
 
     @staticmethod
     def builder(alignment_scope, memory_model):
@@ -191,6 +189,8 @@ class WFAligner:
                                "Affine2p": "GapAffine2p"}[self.pen.kind]]
 
     def _params(self, span, pbf=0, pef=0, tbf=0, tef=0):
+        if self.pen.match_ != 0:  # the builder and the accessors take them (wfaligner.rs:1510-1521); no kernel aligns with them
+            raise NotImplementedError("non-zero match scores are never used on TRGT's paths (wfaligner.rs:292-294)")
         p = _lib.WfaParams()
         _lib.lib().trgt_wfa_default_params(C.byref(p))
         p.metric = int(self.metric)
