@@ -29,6 +29,7 @@ struct trgt_knobs {
   bool no_spec = false;      // TRGT_WFA_NO_SPEC: general instantiation of the dedicated kernel
   bool no_window = false;    // TRGT_WFA_NO_WINDOW: no seeded windows
   bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
+  bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them
   bool host_genotyper = false;  // TRGT_HOST_GENOTYPER: host glue for every locus
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
@@ -78,6 +79,7 @@ struct trgt_hip_ctx {
   int64_t next_ticket = 1;
   // side streams for the launches of one HMM batch (one per workgroup-size class: they run next to each other, not one behind the
   // other's tail), with the events that fork them off the batch's stream and join them back
+  hipEvent_t ev_scan = nullptr, ev_heavy = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
   hipStream_t hmm_side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t hmm_fork = nullptr, hmm_join[3] = {nullptr, nullptr, nullptr};
 };

@@ -349,6 +349,8 @@ __global__ void span_combine_kernel(const CombineArgs a) {
   if (a.rf_hit) a.rf_hit[r] = (uint8_t)hit[1];
 }
 
+__global__ void cells_merge_kernel(unsigned long long* total2, const unsigned long long* heavy) { total2[1] = heavy[0]; total2[0] += heavy[0]; }
+
 // Device-side part shared with trgt_locus_batch: everything already resident, results left on the device.
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
@@ -432,6 +434,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   const bool split = d_heavy_len && heavy_tlen_max > 0 && !c->knobs.one_launch;
   heavy_tlen_max = std::min(heavy_tlen_max, short_max);
   c->last_filter_cells_dev = nullptr;
+  bool heavy_join = false;         // the expensive alignments run on the second stream: wait for it before the spans are combined
+  void* heavy_cells_dev = nullptr; // ... and their offset counter lives in workspace set 1
   if (split) {
     WfaLaunch LH = L;
     LH.n_jobs2_dev = nullptr; LH.jobs_cap = 0;
@@ -448,6 +452,21 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     const int64_t flt_tlen = flank_filter_max_tlen(p.flank_len);
     const bool use_filter = p.mism == 2 && p.gapo == 5 && p.gape == 1 && flt_tlen >= 2 * (int64_t)p.flank_len &&
                             heavy_tlen_max >= (uint32_t)p.flank_len && min_matches <= 254 && !c->knobs.no_filter;
+    // Two streams: the expensive alignments (pre-filter, then the back-tracing kernel over what it keeps) run on the second stream
+    // NEXT TO the other fallback alignments (segment search, windowed launch, whole-read launch) instead of in front of them.  The
+    // filter is bound by VALU issue at three waves per SIMD, the light launches by latency and by their job-claim atomics: they
+    // fill each other's gaps (measured: see DESIGN.md).  Workspace set 1 for the back-tracing launch of that stream.
+    const bool two_streams = use_filter && !c->knobs.one_stream;
+    void* cells_heavy = nullptr;
+    if (two_streams) {
+      if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      if (!c->ev_scan) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming));
+      if (!c->ev_heavy) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
+      TRGT_HIP_TRY(c, hipEventRecord(c->ev_scan, c->stream));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_scan, 0));
+      std::swap(c->stream, c->stream2);
+    }
+    struct StreamBack { trgt_hip_ctx* c; bool on; ~StreamBack() { if (on) std::swap(c->stream, c->stream2); } } stream_back{c, two_streams};
     if (use_filter) {
       void* d_keepjobs = nullptr;
       if ((rc = dev_get(c, S_FS_KEEPJOBS, n_jobs * sizeof(JobDev), &d_keepjobs))) return rc;
@@ -461,11 +480,21 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
     // wave and level), and a wave without a strip still pays the per-level prologue and barrier (7.39 -> 7.21 ms)
     LH.threads = c->knobs.heavy_threads > 0 ? c->knobs.heavy_threads : (L.threads == 256 ? 192 : L.threads);
+    if (two_streams) LH.buffer_set = 1;
     if ((rc = wfa_launch(c, wp, LH))) return rc;
-    // offsets of the first launch, kept next to the running total (cells[1]): the roofline of the dominant launch counts its own
-    TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
+    cells_heavy = c->last_wfa_cells_dev;
+    if (two_streams) {
+      TRGT_HIP_TRY(c, hipEventRecord(c->ev_heavy, c->stream));
+      std::swap(c->stream, c->stream2);
+      stream_back.on = false;
+      heavy_join = true;
+    } else {
+      // offsets of the first launch, kept next to the running total (cells[1]): the roofline of the dominant launch counts its own
+      TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    heavy_cells_dev = cells_heavy;
     L.n_jobs_dev = (const uint32_t*)d_count + 3;  // always 0: this launch takes the back part of the list only
-    L.keep_cells = true; L.timer_slot = TRGT_K_WFA_FLANK_REST;
+    L.keep_cells = !two_streams; L.timer_slot = TRGT_K_WFA_FLANK_REST;  // (two streams: the first launch of THIS stream resets the counter of set 0)
     if (win_q > 0) {  // the alignments with a seeded window: short texts, more of them per CU; then sort out which of them stand
       WindowArgs wa;
       wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
@@ -489,6 +518,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       trgt_wfa_params wpw = wp;
       wpw.text_begin_free = 2 * win_margin + win_spread;
       if ((rc = wfa_launch(c, wpw, LW))) return rc;
+      L.keep_cells = true;
       WinCheckArgs wc;
       wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + 4; wc.score = (const int32_t*)d_score;
       wc.span4 = (uint32_t*)d_span4; wc.n_match = (int32_t*)d_nmatch; wc.s0 = win_s0;
@@ -507,6 +537,12 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
     L2.keep_cells = true; L2.timer_slot = TRGT_K_WFA_FLANK_REST;
     if ((rc = wfa_launch(c, wp, L2))) return rc;
+  }
+  if (heavy_join) {
+    TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
+    // one counter pair again: [0] all flank alignments, [1] those of the launch over the expensive ones
+    hipLaunchKernelGGL(cells_merge_kernel, dim3(1), dim3(1), 0, c->stream, (unsigned long long*)c->last_wfa_cells_dev, (const unsigned long long*)heavy_cells_dev);
+    TRGT_HIP_TRY(c, hipGetLastError());
   }
   CombineArgs ca;
   ca.n_reads = (uint64_t)n_reads; ca.flank_len = p.flank_len;
