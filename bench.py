@@ -136,9 +136,11 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=1, help="contexts per GPU (trgt_amd.driver.ChunkDriver): > 1 overlaps the host-bound tail of one step with the flank location of the next")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_amd.driver.ChunkDriver): > 1 overlaps the host-bound tail of one step with the flank location of the next; 0 = by config (2 for configs 3 and 5, whose tails are long and host-bound, else 1)")
     args = ap.parse_args()
     n_loci = args.loci or DEFAULT_LOCI[args.config]
+    if args.contexts <= 0:
+        args.contexts = {3: 2, 5: 2}.get(args.config, 1)  # measured on MI355X: 1.9x / 1.5x for configs 3 / 5, a loss for 2 / 4
 
     import torch
     import torch.distributed as dist

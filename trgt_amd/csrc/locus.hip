@@ -273,6 +273,8 @@ static int issue_pending_uploads(trgt_hip_ctx* c) {
   return TRGT_OK;
 }
 
+static std::mutex g_stage_a_mutex[16];
+
 // staged_reads / staged_flank: device copies of in->read_blob / in->flank_blob made ahead of time by trgt_locus_batch_submit (the
 // caller's pointers stay what the host glue reads); `ready`: the event behind those copies.
 static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out,
@@ -430,6 +432,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
   TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
   ((uint64_t*)h_cells)[0] = ((uint64_t*)h_cells)[1] = 0;
+  // Stage A of one call at a time per device.  Several contexts on one GPU (one host thread each, trgt_amd/driver.py) then form a
+  // pipeline: while one call is in its host-bound tail (consensus repair, HMM collection) the next one's flank location has the
+  // GPU to itself -- two stage A's at once only fight over the CUs their persistent kernels were sized to fill.
+  std::unique_lock<std::mutex> stage_a_token(g_stage_a_mutex[(size_t)c->device % 16]);
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
@@ -473,6 +479,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // ---------------- wait for the GPU, publish spans
   {
     TRGT_HIP_TRY(c, hipEventSynchronize(evA));
+    stage_a_token.unlock();
     tA = now_ns() - tw_a;
   TL("evA");
   }
