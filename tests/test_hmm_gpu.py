@@ -117,6 +117,21 @@ def test_long_allele_10kb(oracle, hmm):
     _same(oracle, hmm, sets, jobs)
 
 
+def test_visit_list_overflow_and_length_buckets(oracle, hmm):
+    # one-base motifs make one motif visit per base: more than the kernel keeps in LDS (the rest go through its global
+    # workspace); alleles of 0..2500 bases of several models land in every length bucket / launch class of one batch
+    rng = np.random.default_rng(17)
+    sets = [[b"A"], [b"A", b"C"], [b"CAG"], [b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"]]
+    jobs = []
+    for n in (1, 63, 64, 65, 150, 192, 193, 400, 640, 641, 1200, 2048, 2049, 2500):
+        jobs.append((0, b"A" * n))
+        jobs.append((1, bytes(rng.choice(np.frombuffer(b"AACCCA", np.uint8), n).tobytes())))
+        jobs.append((2, repeat_allele(rng, sets[2], n, err=0.02)))
+    for n in (100, 300, 900):
+        jobs.append((3, repeat_allele(rng, sets[3], n, err=0.02)))
+    _same(oracle, hmm, sets, jobs)
+
+
 def test_device_resident_inputs(oracle, hmm):
     import torch
     rng = np.random.default_rng(5)

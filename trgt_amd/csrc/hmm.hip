@@ -144,11 +144,50 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
         if (ready) { lev[s] = mx + 1; changed = true; }
       }
     }
-    for (uint32_t s = 0; s < S; ++s) { level[s] = (uint8_t)lev[s]; n_levels = std::max<uint32_t>(n_levels, (uint32_t)lev[s]); }
+    for (uint32_t s = 0; s < S; ++s) { level[s] = (uint8_t)std::min(lev[s], 255); n_levels = std::max<uint32_t>(n_levels, (uint32_t)lev[s]); }  // (the kernel only asks level > 0)
   }
   // serialise
+  // The chain of deletion states of a motif block ends in the block end (d0 .. d0 + n - 2, me = d0 + n - 1: consecutive states, each
+  // with the one before it as its LAST predecessor): the kernel walks it across LANES, and a chain that runs over a wave boundary
+  // costs it another round.  Models of several waves therefore get a lane -> state table that keeps every chain inside one wave
+  // (first fit, longest chain first; the other states fill the lanes left over; a chain longer than a wave starts a wave of its own).
+  uint32_t chain_rounds = 1, n_lanes = 0;
+  std::vector<uint16_t> perm;
+  if (S > 64) {
+    struct Chain { uint32_t first, len; };
+    std::vector<Chain> chains;
+    std::vector<uint8_t> in_chain(S, 0);
+    for (uint32_t b = 0; b + 1 < nb; ++b) {
+      const uint32_t n = blocks[2 * nb + b], me = blocks[1 * nb + b];
+      if (n > 1) { chains.push_back({me - (n - 1), n}); for (uint32_t s = me - (n - 1); s <= me; ++s) in_chain[s] = 1; }
+    }
+    std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.len > b.len; });
+    std::vector<uint32_t> fill;  // lanes used per wave
+    auto place = [&](uint32_t lane, uint32_t st) { if (perm.size() <= lane) perm.resize(((size_t)lane / 64 + 1) * 64, 0xFFFF); perm[lane] = (uint16_t)st; };
+    for (const Chain& ch : chains) {
+      uint32_t w = 0;
+      if (ch.len > 64) { w = (uint32_t)fill.size(); }  // whole waves of its own
+      else { while (w < fill.size() && fill[w] + ch.len > 64) ++w; }
+      const uint32_t waves = (ch.len + 63) / 64;
+      if (w + waves > fill.size()) fill.resize(w + waves, 0);
+      const uint32_t lane0 = 64 * w + fill[w];
+      for (uint32_t k = 0; k < ch.len; ++k) place(lane0 + k, ch.first + k);
+      for (uint32_t k = 0; k < waves; ++k) fill[w + k] = k + 1 < waves ? 64 : std::max(fill[w + k], (lane0 + ch.len) - 64 * (w + k));
+      chain_rounds = std::max(chain_rounds, (lane0 + ch.len - 1) / 64 - lane0 / 64 + 1);
+    }
+    uint32_t w = 0;
+    for (uint32_t st = 0; st < S; ++st) {
+      if (in_chain[st]) continue;
+      while (w < fill.size() && fill[w] >= 64) ++w;
+      if (w == fill.size()) fill.push_back(0);
+      place(64 * w + fill[w], st);
+      ++fill[w];
+    }
+    n_lanes = (uint32_t)perm.size();
+  }
+  (void)n_levels;
+  d.S = S; d.n_blocks = nb; d.chain_rounds = chain_rounds; d.max_mlen = max_mlen; d.n_lanes = n_lanes;
   uint64_t o = 0;  // offsets relative to this set's blob; the caller rebases them
-  d.S = S; d.n_blocks = nb; d.n_levels = n_levels; d.max_mlen = max_mlen;
   d.off_inlp = o; o += 8ull * 4 * S;
   d.off_em = o; o += 8ull * 5 * S;
   d.off_inst = o; o += 2ull * 4 * S;
@@ -157,7 +196,8 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
   d.off_nin = o; o += S;
   d.off_level = o; o += S;
   d.off_flags = o; o += S;
-  d.off_motifs = o; o += mbytes.size();
+  d.off_motifs = o; o += mbytes.size(); o = align_up(o, 2);
+  d.off_perm = o; o += 2ull * perm.size();
   blob.resize(align_up(o, 16), 0);
   std::memcpy(&blob[d.off_inlp], inlp.data(), 8ull * 4 * S);
   std::memcpy(&blob[d.off_em], em.data(), 8ull * 5 * S);
@@ -168,17 +208,24 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
   std::memcpy(&blob[d.off_level], level.data(), S);
   std::memcpy(&blob[d.off_flags], flags.data(), S);
   if (!mbytes.empty()) std::memcpy(&blob[d.off_motifs], mbytes.data(), mbytes.size());
+  if (!perm.empty()) std::memcpy(&blob[d.off_perm], perm.data(), 2ull * perm.size());
 }
 
 // --------------------------------------------------------------- kernel
 #ifdef TRGT_HMM_PROF
 // developer build (make HMMPROF=1): lane 0 of every job splits its shader-clock time over the phases of the kernel
-__device__ unsigned long long g_hmm_prof[8];
+__device__ unsigned long long g_hmm_prof[16];
 #define HP_DECL unsigned long long hp_t = clock64()
 #define HP_MARK(i) do { const unsigned long long n_ = clock64(); if (tid == 0) atomicAdd(&g_hmm_prof[i], n_ - hp_t); hp_t = n_; } while (0)
+#define HP_FILL_DECL unsigned long long hf_t = clock64(), hf_acc[6] = {0, 0, 0, 0, 0, 0}
+#define HP_FILL(i) do { const unsigned long long n_ = clock64(); hf_acc[i] += n_ - hf_t; hf_t = n_; } while (0)
+#define HP_FILL_END do { if (tid == 0) for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_hmm_prof[8 + q_], hf_acc[q_]); } while (0)
 #else
 #define HP_DECL
 #define HP_MARK(i)
+#define HP_FILL_DECL
+#define HP_FILL(i)
+#define HP_FILL_END
 #endif
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
 constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4], block, flags, bp column
@@ -210,23 +257,34 @@ __device__ __forceinline__ void hmm_sync_mem(int nthr) {
   else __syncthreads();
 }
 
-// STAGE: the allele, the motif bytes, the motif-visit list and the motif counts live in LDS (alleles up to HMM_STAGE_QLEN bases).
-// The fill reads one base per column and the traceback / decode of thread 0 is a chain of dependent loads: served from HBM each
-// of them costs a memory round trip, which was most of this kernel's time.
-constexpr int HMM_STAGE_QLEN = 2048;
-constexpr int HMM_CODE_WINDOW = 512;  // columns of symbol codes kept in LDS by the kernel for longer alleles
+// LDS of a job does not depend on the length of its allele (it bounds the waves per SIMD of a kernel that is bound by instruction
+// issue and dependent LDS round trips): the fill and the trace-back see the allele through a WINDOW of symbol codes, the trace-back
+// keeps the first HMM_VIS_LDS motif visits in LDS and the rest in the job's global workspace (read back in staged chunks), the
+// check of the motif copies (remove_imperfect_motifs) happens in the trace-back, where the window holds their bases.
+constexpr int HMM_CODE_WINDOW = 256;  // columns of symbol codes kept in LDS (+ HMM_CODE_PAD behind them)
+constexpr int HMM_CODE_PAD = 16;      // the column after the window (fill), the bases of a motif copy that starts at its end (trace-back)
+constexpr int HMM_VIS_LDS = 64;       // motif visits kept in LDS (block | dropped << 15, first base, one past the last base)
 // SUB: lanes per allele.  64 (or more: one thread per state, several waves for large motif sets) is the general case; SUB = 32
 // packs TWO alleles into one wave when the model has at most 32 states (a single STR motif of up to 8 bases): the kernel is bound
 // by instruction issue and most passes of a column keep only one or two lanes busy, so halving the waves nearly halves its time.
 // The two halves run the same code on their own LDS regions; their control flow may diverge (different allele lengths).
-template <bool STAGE, int SUB>
+// the value of the lane before (lane 0: its own)
+__device__ __forceinline__ double wave_shr1_f64(double x) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const int lo = (int)(u & 0xFFFFFFFFull), hi = (int)(u >> 32);
+  const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+  const int shi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
+}
+
+template <int SUB>
 __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets,
                                    const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
                                    uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws,
                                    uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
                                    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
                                    uint32_t* __restrict__ counts, double* __restrict__ purity,
-                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, uint32_t stage_qcap,
+                                   int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out,
                                    uint32_t n_launch_jobs, uint32_t lds_per_job) {
   extern __shared__ __align__(16) unsigned char lds_all[];
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
@@ -276,44 +334,37 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
   const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
   const uint8_t* g_motifs = model + set.off_motifs;
-  // staged copies (STAGE): sequence | motif bytes | visits | counts, behind the back-pointer staging window
+  // behind the back-pointer staging window: window of symbol codes | motif bytes | motif visits | motif counts
   uint8_t* l_seq = l_stage + (HMM_STAGE_BYTES > Spad ? HMM_STAGE_BYTES : Spad);
-  uint8_t* l_mot = l_seq + ((stage_qcap + 2 + 15) & ~15u);
+  uint8_t* l_mot = l_seq + HMM_CODE_WINDOW + HMM_CODE_PAD;
   const int mot_bytes = (S - 7 - n_motifs) / 3;
-  // motif visits (block, first base, one past the last base): 16-bit in LDS (staged alleles are at most HMM_STAGE_QLEN long)
-  uint16_t* l_vis = reinterpret_cast<uint16_t*>(l_mot + ((mot_bytes + 15) & ~15));
-  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(l_vis + ((3 * (stage_qcap + 3) + 1) & ~1u));
-  if (STAGE) {  // the symbol codes of '#' + allele + '#' (hmm_code), one byte per column
-    const uint8_t* gs = seq_blob + job.seq_off;
-    for (int i = tid; i < L; i += nthr) l_seq[i] = (uint8_t)hmm_code(gs, i, L);
-    for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
-    for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
-  }
-  const uint8_t* const motif_bytes = STAGE ? l_mot : g_motifs;
+  uint32_t* l_vis = reinterpret_cast<uint32_t*>(l_mot + ((mot_bytes + 15) & ~15));
+  uint32_t* l_cnt = l_vis + 3 * HMM_VIS_LDS;
+  for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
+  for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
+  const uint8_t* const motif_bytes = l_mot;
   for (int i = tid; i < 4 * S; i += nthr) l_inst[4 * (i % S) + i / S] = g_inst[i];
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
   for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
 
   // ---- my state's tables in registers
-  const bool act = tid < S;
-  const int st = act ? tid : 0;
+  // (models of several waves: the lane -> state table of build_set, which keeps every deletion chain inside one wave)
+  const int st_lane = set.n_lanes ? (int)reinterpret_cast<const uint16_t*>(model + set.off_perm)[tid] : tid;
+  const bool act = st_lane < S;
+  const int st = act ? st_lane : 0;
   const int n_in = model[set.off_nin + st];
   const int level = model[set.off_level + st];
-  const int n_levels = (int)set.n_levels;
-  (void)n_levels;  // only the level-by-level variant (TRGT_HMM_LEVELWISE) walks the levels
   double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
   const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
   // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
-  const uint8_t* __restrict__ seq = STAGE ? l_seq : seq_blob + job.seq_off;
-  // Symbol code of column i.  STAGE: the whole allele sits in LDS.  Otherwise (alleles beyond HMM_STAGE_QLEN) the fill and the
-  // trace-back keep a WINDOW of codes in LDS (l_seq, HMM_CODE_WINDOW columns from win0 on) and only the decode reads global memory:
-  // a load per column put a memory round trip -- and, the loads and the back-pointer stores sharing one in-order counter, the store
-  // of the column before -- into every step of a 10-kb allele.
+  const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
+  // Symbol code of column i ('#' + allele + '#', hmm_code): from the window l_seq, columns [win0, win0 + HMM_CODE_WINDOW + pad).  A
+  // load per column from global memory put a memory round trip -- and, the loads and the back-pointer stores sharing one in-order
+  // counter, the store of the column before -- into every step.
   int win0 = 0;
-  auto code_at = [&](int i) -> int { return STAGE ? (int)l_seq[i] : (int)l_seq[i - win0]; };
-  auto code_global = [&](int i) -> int { return STAGE ? (int)l_seq[i] : hmm_code(seq, i, L); };
+  auto code_at = [&](int i) -> int { return (int)l_seq[i - win0]; };
   uint8_t* __restrict__ bp = bp_ws + job.bp_off;
   hmm_sync_mem(sync_n);  // (also orders the zeroing of the motif counts above before thread 0 counts into them)
   // traceback word of my state: kind (0 outside any block, 1 block start, 2 block end, 3 skip state, 4 match, 5 insertion,
@@ -338,24 +389,41 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int my_blk = act ? (int)l_block[st] : -1;
   const bool role_end = act && my_blk >= 0 && st == (int)l_blocks[1 * nb + my_blk];
   const bool role_start = act && my_blk >= 0 && st == (int)l_blocks[0 * nb + my_blk];
-  const int blk_n = role_end && my_blk != nb - 1 ? (int)l_blocks[2 * nb + my_blk] : 0;            // motif length (0: the skip block)
-  const int blk_m0 = role_end ? (int)l_blocks[0 * nb + my_blk] + 1 : 0, blk_d0 = blk_m0 + 2 * blk_n;  // first match / deletion state
-  const bool role_other = act && level > 0 && !role_end && !role_start && n_in != 0xFF;             // deletion states, run start
+  const bool role_del = act && level > 0 && !role_end && !role_start && n_in != 0xFF && my_blk >= 0;  // deletion states
+  const bool role_chain = role_del || role_end;
+  // a chain state's LAST predecessor is the state before it (deletion state k: {match k, deletion k - 1}; block end: {last match,
+  // last insertion, last deletion}) -- the lane before it, or the last lane of the wave before
+  const bool chain_prev = role_del ? n_in > 1 : role_end ? n_in > 2 : false;
+  const bool chain_xwave = chain_prev && (threadIdx.x & 63u) == 0;
+  // (every lane runs the chain steps: -inf as the transition term of the lanes that take nothing from their neighbour -- and of the
+  //  first lane of a wave, which takes its predecessor from LDS before the steps -- makes their candidate lose every comparison)
+  const double lp_chain = role_del ? lp1 : lp2, lp_step = chain_prev && !chain_xwave ? lp_chain : NINF;
+  const int chain_steps = min(63, max((int)set.max_mlen, SUB == 32 ? __shfl_xor((int)set.max_mlen, 32) : 0) - 1);
+  const int chain_rounds = (int)set.chain_rounds;
 
   HP_MARK(0);
+  // the run-end state's predecessors (the block ends, in block order): the first BE_REG of them by index in registers
+  const double lp_rs0 = l_lp[1], lp_rs1 = l_lp[S + 1];  // transition terms of the run start (state 1), evaluated by the run-end lane
+  constexpr int BE_REG = 8;
+  int be[BE_REG];
+#pragma unroll
+  for (int b = 0; b < BE_REG; ++b) be[b] = (int)l_blocks[1 * nb + (b < nb ? b : 0)];
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
   double* prev = sc0;
   double* cur = sc1;
-  int sym_next = STAGE ? code_at(0) : 0;
+  HP_FILL_DECL;
+  int sym_next = 0;
   for (int i = 0; i < L; ++i) {
-    if (!STAGE && (i % HMM_CODE_WINDOW) == 0) {  // next window of symbol codes
+    if ((i % HMM_CODE_WINDOW) == 0) {  // next window of symbol codes (one column more than the window: the look-ahead below)
       hmm_sync(sync_n);
       win0 = i;
-      for (int k = tid; k < HMM_CODE_WINDOW && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
+      for (int k = tid; k < HMM_CODE_WINDOW + 1 && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
       hmm_sync(sync_n);
+      sym_next = code_at(i);
     }
-    const int sym = STAGE ? sym_next : code_at(i);
-    if (STAGE && i + 1 < L) sym_next = code_at(i + 1);
+    const int sym = sym_next;
+    if (i + 1 < L) sym_next = code_at(i + 1);  // (fetched a column ahead: its LDS round trip is off this column's critical path)
+    HP_FILL(0);
     double best = NINF;
     int bpi = 0xFF;
     if (act && level == 0) {
@@ -374,66 +442,72 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       cur[st] = best;
     }
     hmm_sync(sync_n);
-#ifdef TRGT_HMM_LEVELWISE
-    for (int lev = 1; lev <= n_levels; ++lev) {
-      if (act && level == lev) {
-        if (n_in == 0xFF) {  // run-end state: predecessors are the block end states, in block order
-          for (int b = 0; b < nb; ++b) {
-            const double v = (cur[l_blocks[1 * nb + b]] + lp0) + 0.0;
-            if (v > best) { best = v; bpi = b; }
-          }
-        } else {
-          const double s0 = cur[q0], s1 = cur[q1], s2 = cur[q2], s3 = cur[q3];
-          const double v0 = (s0 + lp0) + 0.0, v1 = (s1 + lp1) + 0.0, v2 = (s2 + lp2) + 0.0, v3 = (s3 + lp3) + 0.0;
-          if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
-          if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
-          if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
-          if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
-        }
-        cur[st] = best;
-      }
-      hmm_sync(sync_n);
-    }
-#else
+    HP_FILL(1);
     // (Silent states emit nothing: the reference adds an emission term of 0.0 to their sums, which changes no value -- scores are sums of
     //  logarithms of probabilities, never -0.0 -- and is left out here.)
-    // Silent states of the column in three passes instead of one per topological level (motif length + 3 of them, each an LDS
-    // round trip and a fence with one or two busy lanes).  The dependency chain of a motif block -- d0 <- d1 <- ... <- block end --
-    // is walked by ONE lane (the block-end state's) with the chain value in a register; then the run-end lane takes the maximum
-    // over the block ends and evaluates the run start behind it; then every block start.  Same sums, same predecessor order, same
-    // strict '>' as level by level (any topological order gives identical values, hmm_model.rs:206-240).
-    if (role_end) {
-      double chain = NINF;
-      for (int k = 0; k + 1 < blk_n; ++k) {  // deletion states d0 + k: predecessors {m0 + k, d0 + k - 1}
-        const int sd = blk_d0 + k;
-        double bd = NINF; int pd = 0xFF;
-        const double v0 = (cur[blk_m0 + k] + l_lp[sd]);
-        if (v0 > bd) { bd = v0; pd = 0; }
-        if (k > 0) { const double v1 = (chain + l_lp[S + sd]); if (v1 > bd) { bd = v1; pd = 1; } }
-        cur[sd] = bd; l_bpcol[sd] = (uint8_t)pd; chain = bd;
-      }
-      // the block end itself: {m_last, i_last, d_last} (or {skip} / {m, i}); d_last is the chain value just computed
-      const double s0 = cur[q0], s1 = cur[q1], s2 = (n_in > 2) ? chain : 0.0;
-      const double v0 = (s0 + lp0), v1 = (s1 + lp1), v2 = (s2 + lp2);
+    // Silent states of the column in three passes instead of one per topological level (motif length + 3 of them).  First the chains
+    // d0 <- d1 <- ... <- block end of all motif blocks at once: a chain state is max(what its other predecessors give, the state before
+    // it + lp) with ties to the former, and the state before it is the LANE before it -- every lane takes its neighbour's value
+    // (DPP wave_shr:1: no LDS round trip), and after k steps the k-th state of a chain has its final value (steps beyond that
+    // recompute it from the same inputs).  A chain that runs over a wave boundary takes another round: the first lane of a wave reads
+    // the state before it from LDS.  Then the run-end lane takes the maximum over the block ends and evaluates the run start behind
+    // it; then every block start.  Same sums, same predecessor order, same strict '>' as level by level (any topological order gives
+    // identical values, hmm_model.rs:206-240).
+    if (role_chain) {
+      const double s0 = cur[q0], s1 = cur[q1];
+      const double v0 = (s0 + lp0), v1 = (s1 + lp1);
       if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
-      if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
-      if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
-      cur[st] = best;
+      if (role_end && n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+    }
+    {
+      const double own = best;  // what the predecessors other than the chain's give
+      int own_bp = bpi;
+      double val = best, cand = NINF;
+      for (int r = 0; r < chain_rounds; ++r) {
+        if (chain_xwave) {  // the state before sits in the wave before: final after the round before (round 0: a throw-away value)
+          cand = (cur[st - 1] + lp_chain);
+          best = cand > own ? cand : own;
+          bpi = cand > own ? (role_del ? 1 : 2) : own_bp;
+          val = best;
+        }
+#pragma unroll 4
+        for (int t = 0; t < chain_steps; ++t) {
+          cand = (wave_shr1_f64(val) + lp_step);
+          val = cand > best ? cand : best;
+        }
+        if (role_chain) cur[st] = val;
+        if (r + 1 < chain_rounds) hmm_sync(sync_n);
+      }
+      if (cand > best) bpi = role_del ? 1 : 2;  // (never for the lanes whose transition term is -inf)
+      best = val;
     }
     hmm_sync(sync_n);
+    HP_FILL(2);
     if (act && n_in == 0xFF) {  // run end: block ends in block order; then the run start {start state, run end}
-      for (int b = 0; b < nb; ++b) {
+      const double start_now = cur[0];  // (the start state of this column, for the run start below: fetched with the block ends)
+      {
+        double e[BE_REG];
+#pragma unroll
+        for (int b = 0; b < BE_REG; ++b) e[b] = cur[be[b]];  // (their indices sit in registers: one round trip for all of them)
+#pragma unroll
+        for (int b = 0; b < BE_REG; ++b) {
+          const double v = (e[b] + lp0);
+          if (b < nb && v > best) { best = v; bpi = b; }
+        }
+      }
+      for (int b = BE_REG; b < nb; ++b) {
         const double v = (cur[l_blocks[1 * nb + b]] + lp0);
         if (v > best) { best = v; bpi = b; }
       }
       cur[st] = best;
       double br = NINF; int pr = 0xFF;
-      const double v0 = (cur[0] + l_lp[1]), v1 = (best + l_lp[S + 1]);
+      const double v0 = (start_now + lp_rs0), v1 = (best + lp_rs1);
       if (v0 > br) { br = v0; pr = 0; }
       if (v1 > br) { br = v1; pr = 1; }
       cur[1] = br; l_bpcol[1] = (uint8_t)pr;
     }
     hmm_sync(sync_n);
+    HP_FILL(3);
     if (role_start) {  // block start: {run start, own block end}
       const double s0 = cur[q0], s1 = cur[q1];
       const double v0 = (s0 + lp0), v1 = (s1 + lp1);
@@ -442,11 +516,13 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       cur[st] = best;
     }
     hmm_sync(sync_n);
-    if (role_other) bpi = l_bpcol[st];  // deletion states and the run start were evaluated by another lane
-#endif
+    HP_FILL(4);
+    if (act && st == 1) bpi = l_bpcol[1];  // the run start was evaluated by the run-end lane
     if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
     double* t = prev; prev = cur; cur = t;
+    HP_FILL(5);
   }
+  HP_FILL_END;
   HP_MARK(1);
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
@@ -457,8 +533,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
   const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
-  typedef typename std::conditional<STAGE, uint16_t, uint32_t>::type vis_t;
-  vis_t* visits = STAGE ? reinterpret_cast<vis_t*>(l_vis) : reinterpret_cast<vis_t*>(visit_ws + job.visit_off);
+  uint32_t* const g_vis = visit_ws + job.visit_off;  // visits HMM_VIS_LDS, HMM_VIS_LDS + 1, ... at their own index
   const int pcap = (int)job.path_cap;
   while (true) {
     if (tb_done) break;
@@ -468,10 +543,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       uint4* dst = reinterpret_cast<uint4*>(l_stage);
       const int n16 = (c1 - c0) * Spad / 16;
       for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
-      if (!STAGE) {  // ... and the symbol codes of the same columns
-        win0 = c0;
-        for (int k = tid; k < c1 - c0; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, c0 + k, L);
-      }
+      // ... and the symbol codes of the same columns, plus those a motif copy starting in the last of them reaches into
+      win0 = c0;
+      for (int k = tid; k < c1 - c0 + HMM_CODE_PAD && c0 + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, c0 + k, L);
     }
     hmm_sync(sync_n);
     if (tid == 0) {
@@ -494,8 +568,23 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         const int mism = kind == 4 && !(qbase == expected || expected == 'N');  // events.rs:66-73
         edit += dels + (kind == 3) + mism + (kind == 5) + (kind == 6);
         ref += dels + (kind == 3) + (kind == 4) + (kind == 6);
-        if (kind == 1) {
-          visits[3 * nv + 0] = (vis_t)blk; visits[3 * nv + 1] = (vis_t)idx; visits[3 * nv + 2] = (vis_t)vb1;
+        if (kind == 1) {  // a motif visit: bases query[idx .. vb1)
+          // remove_imperfect_motifs(.., 6) (operations.rs:45-57): only copies of STR motifs can be dropped -- short ones, and ones
+          // whose bases differ from the motif (its bases are columns idx + 1 .. idx + mlen: in the window)
+          uint32_t drop = 0;
+          const int mlen = (int)l_blocks[2 * nb + blk];
+          if (blk != nb - 1 && mlen <= 6) {
+            if (vb1 - idx < mlen) drop = 1;
+            else {
+              const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
+              for (int j = 0; j < mlen; ++j) {
+                const int obs = hmm_code_char(code_at(idx + j + 1));
+                if (mot[j] != 'N' && obs != mot[j]) drop = 1;
+              }
+            }
+          }
+          uint32_t* vrec = nv < HMM_VIS_LDS ? l_vis + 3 * nv : g_vis + 3 * (size_t)nv;
+          vrec[0] = (uint32_t)blk | (drop << 15); vrec[1] = (uint32_t)idx; vrec[2] = (uint32_t)vb1;
           ++nv;
         }
         vb1 = kind == 2 ? idx : vb1;  // bases of this visit are query[.. idx)
@@ -524,46 +613,48 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       hmm_sync_mem(sync_n);
     }
   }
-  // ---- decode (thread 0): purity, remove_imperfect_motifs(.., 6), label_motifs, skip filter, counts, collapse
+  // ---- decode (thread 0): purity, label_motifs over the kept copies, skip filter, counts, collapse.  Visits were recorded back to
+  //      front: the last ones recorded (the first of the allele) sit in global memory and come through LDS in chunks.
+  int ns = 0, cum = 0, last_motif = -1, last_end = -1;
+  int32_t* const sp = spans3 + 3 * job.span_off;
+  auto take_visit = [&](const uint32_t* vrec) {
+    const int blk = (int)(vrec[0] & 0x7FFFu), b0 = (int)vrec[1], b1 = (int)vrec[2];
+    const bool keep = (vrec[0] >> 15) == 0;
+    const int cnt = b1 - b0;
+    const int start = cum, end = cum + cnt;
+    cum = end;
+    const int motif = keep ? blk : nb - 1;
+    if (motif < n_motifs) {
+      l_cnt[motif] += 1;
+      if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
+      else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
+      last_end = end;
+    }
+  };
   if (tid == 0) {
     if (path_len) path_len[job.job_index] = (uint32_t)np;
     const int edit = tb_edit, mx = max(tb_ref, qlen);
     purity[job.job_index] = ((double)mx - (double)edit) / (double)mx;
     if (edit_out) edit_out[job.job_index] = edit;
     if (maxd_out) maxd_out[job.job_index] = mx;
-    int32_t* sp = spans3 + 3 * job.span_off;
-    int ns = 0, cum = 0, last_motif = -1, last_end = -1;
-    for (int v = tb_nvisit - 1; v >= 0; --v) {
-      const int blk = (int)visits[3 * v + 0], b0 = (int)visits[3 * v + 1], b1 = (int)visits[3 * v + 2];
-      const int cnt = b1 - b0;
-      bool keep = true;
-      const int mlen = (int)l_blocks[2 * nb + blk];
-      if (blk != nb - 1 && mlen <= 6) {  // only STR motif copies can be removed (operations.rs:45-57)
-        if (cnt < mlen) keep = false;
-        else {
-          const uint8_t* mot = motif_bytes + l_blocks[3 * nb + blk];
-          for (int j = 0; j < mlen; ++j) {
-            const int obs = hmm_code_char(code_global(b0 + j + 1));
-            if (mot[j] != 'N' && obs != mot[j]) keep = false;
-          }
-        }
-      }
-      const int start = cum, end = cum + cnt;
-      cum = end;
-      const int motif = keep ? blk : nb - 1;
-      if (motif < n_motifs) {
-        if (STAGE) l_cnt[motif] += 1; else counts[job.count_off + motif] += 1;
-        if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
-        else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
-        last_end = end;
-      }
-    }
+  }
+  int v = tb_nvisit - 1;
+  constexpr int VIS_CHUNK = HMM_STAGE_BYTES / 12;
+  uint32_t* const l_vchunk = reinterpret_cast<uint32_t*>(l_stage);  // (the staging window of the back-pointers is free now)
+  while (v >= HMM_VIS_LDS) {
+    const int n = min(v - HMM_VIS_LDS + 1, VIS_CHUNK), v0 = v - n + 1;
+    hmm_sync_mem(sync_n);  // (the visits were written by thread 0; the chunk before has been consumed)
+    for (int k = tid; k < 3 * n; k += nthr) l_vchunk[k] = g_vis[3 * (size_t)v0 + k];
+    hmm_sync(sync_n);
+    if (tid == 0) for (int k = n - 1; k >= 0; --k) take_visit(l_vchunk + 3 * k);
+    v -= n;
+  }
+  if (tid == 0) {
+    for (; v >= 0; --v) take_visit(l_vis + 3 * v);
     n_spans[job.job_index] = (uint32_t)ns;
   }
-  if (STAGE) {
-    hmm_sync(sync_n);
-    for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
-  }
+  hmm_sync(sync_n);
+  for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   HP_MARK(3);
 }
 
@@ -578,12 +669,11 @@ __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const 
   for (uint32_t i = 0; i < 3 * n_spans[j]; ++i) dst[i] = src[i];
 }
 
-static size_t hmm_lds_bytes(uint32_t S, uint32_t nb, uint32_t stage_qcap) {
+static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
-  if (stage_qcap) o += (((size_t)stage_qcap + 2 + 15) & ~(size_t)15) + (((size_t)S / 3 + 15) & ~(size_t)15) + 2 * ((3 * ((size_t)stage_qcap + 3) + 1) & ~(size_t)1) + 4 * (size_t)nb;
-  else o += HMM_CODE_WINDOW + 16;  // the window of symbol codes (l_seq) of the kernel without staging
+  o += HMM_CODE_WINDOW + HMM_CODE_PAD + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * (size_t)HMM_VIS_LDS + 4 * (size_t)nb;
   return o + 64;
 }
 
@@ -639,7 +729,7 @@ int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* 
       std::memcpy(blob.data() + pos, blobs[s].data(), blobs[s].size());
       HmmSetDev& d = sets[s];
       d.off_inlp += pos; d.off_em += pos; d.off_inst += pos; d.off_block += pos; d.off_nin += pos; d.off_level += pos;
-      d.off_flags += pos; d.off_blocks += pos; d.off_motifs += pos;
+      d.off_flags += pos; d.off_blocks += pos; d.off_motifs += pos; d.off_perm += pos;
       pos += blobs[s].size();
       std::vector<uint8_t>().swap(blobs[s]);
     }
@@ -738,8 +828,8 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     cells += (int64_t)sd.S * ((int64_t)seq_len[j] + 2);
   }
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
-  // class 0: at most 32 states (two alleles per wave); else the number of waves per allele; odd = allele too long for LDS staging
-  auto job_class = [&](const HmmJobDev& j) { const uint32_t S_ = sets[j.set].S; return 2u * (S_ <= 32 ? 0u : (S_ + 63) / 64) + (j.seq_len > (uint32_t)HMM_STAGE_QLEN ? 1u : 0u); };
+  // class 0: at most 32 states (two alleles per wave); else the number of waves per allele
+  auto job_class = [&](const HmmJobDev& j) { const HmmSetDev& sd_ = sets[j.set]; return sd_.S <= 32 ? 0u : (std::max(sd_.S, sd_.n_lanes) + 63) / 64; };
   {  // (usually one class: skip the sort then)
     bool mixed = false;
     const uint32_t c0 = job_class(jobs[0]);
@@ -829,20 +919,17 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   bool forked = false;
   unsigned side_used = 0;
   while (i < jobs.size()) {
-    const uint32_t jc = job_class(jobs[i]), cls = jc >> 1;
-    const bool stage = (jc & 1u) == 0;
+    const uint32_t jc = job_class(jobs[i]), cls = jc;
     size_t e = i;
     uint32_t maxS = 0, maxnb = 0, maxq = 0;
     while (e < jobs.size() && job_class(jobs[e]) == jc) {
       maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); maxq = std::max(maxq, jobs[e].seq_len); ++e;
     }
-    const uint32_t qcap = stage ? maxq : 0;
     const bool half = cls == 0;  // two alleles per wave
-    const size_t lds_job = (hmm_lds_bytes(maxS, maxnb, qcap) + 15) & ~(size_t)15;
+    const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
     if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
-    const void* kfn = half ? (stage ? (const void*)hmm_viterbi_kernel<true, 32> : (const void*)hmm_viterbi_kernel<false, 32>)
-                           : (stage ? (const void*)hmm_viterbi_kernel<true, 64> : (const void*)hmm_viterbi_kernel<false, 64>);
+    const void* kfn = half ? (const void*)hmm_viterbi_kernel<32> : (const void*)hmm_viterbi_kernel<64>;
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t ls = c->stream;
     if (n_class > 0) {
@@ -859,12 +946,11 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     KTimer t(c, TRGT_K_HMM, ls);
     const uint32_t nj = (uint32_t)(e - i);
     const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * cls);
-#define TRGT_HMM_LAUNCH(ST, SB)                                                                                                     \
-    hipLaunchKernelGGL((hmm_viterbi_kernel<ST, SB>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, \
-                       (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev,    \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, qcap, nj, (uint32_t)lds_job)
-    if (half) { if (stage) TRGT_HMM_LAUNCH(true, 32); else TRGT_HMM_LAUNCH(false, 32); }
-    else { if (stage) TRGT_HMM_LAUNCH(true, 64); else TRGT_HMM_LAUNCH(false, 64); }
+#define TRGT_HMM_LAUNCH(SB)                                                                                                      \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<SB>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
+                       (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job)
+    if (half) TRGT_HMM_LAUNCH(32); else TRGT_HMM_LAUNCH(64);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(i == 0 ? cells : 0);
@@ -924,12 +1010,15 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
 #ifdef TRGT_HMM_PROF
   {
-    unsigned long long h[8], z[8] = {0};
+    unsigned long long h[16], z[16] = {0};
     TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hmm_prof), sizeof h));
     TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_hmm_prof), z, sizeof h));
     const double t = (double)(h[0] + h[1] + h[2] + h[3]) + 1e-9;
     fprintf(stderr, "[hmm prof] jobs=%lld | setup %.1f%% fill %.1f%% traceback %.1f%% path+decode %.1f%% | kcycles/job %.1f\n", (long long)n_jobs,
             100 * h[0] / t, 100 * h[1] / t, 100 * h[2] / t, 100 * h[3] / t, t / 1e3 / (double)n_jobs);
+    const double f = (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13]) + 1e-9;
+    fprintf(stderr, "[hmm prof]   fill: symbol %.1f%% emitting+sync %.1f%% chains+ends+sync %.1f%% run end+sync %.1f%% block starts+sync %.1f%% store %.1f%%\n",
+            100 * h[8] / f, 100 * h[9] / f, 100 * h[10] / f, 100 * h[11] / f, 100 * h[12] / f, 100 * h[13] / f);
   }
 #endif
   if (!h_cnt.empty())

@@ -8,7 +8,7 @@
 namespace trgt {
 
 struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
-  uint32_t S, n_blocks, n_levels, max_mlen;
+  uint32_t S, n_blocks, chain_rounds, max_mlen;  // chain_rounds: waves the longest deletion chain spans
   uint64_t off_inlp;    // f64 [4][S]   ln transition probabilities, predecessor-list order of the reference
   uint64_t off_em;      // f64 [5][S]   ln emissions over # A T C G
   uint64_t off_inst;    // u16 [4][S]   predecessor states
@@ -18,6 +18,8 @@ struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
   uint64_t off_flags;   // u8  [S]      bit0 any finite emission, bit1 emits a base
   uint64_t off_blocks;  // u32 [4][n_blocks]  start,end,mlen,motif byte offset
   uint64_t off_motifs;  // sanitised motif bytes
+  uint64_t off_perm;    // u16 [n_lanes] lane -> state (0xFFFF: idle lane); only when n_lanes != 0
+  uint32_t n_lanes, pad_;  // lanes of a workgroup when the states are not in lane order (models of more than one wave), else 0
 };
 
 struct HmmModels {
