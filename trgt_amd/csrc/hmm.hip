@@ -558,6 +558,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         // per step (it was seven, and an integer division)
         const uint32_t inf = l_info[state];
         const int b = l_stage[row + state];
+        const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);  // (4-byte aligned: S may be odd)
+        const uint2 pred4 = make_uint2(pin[0], pin[1]);  // all four predecessors: no second round trip behind b
         const int qbase = hmm_code_char(code_at(idx));
         const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
         // events of this state (events.rs:17-86), branch-free but for the visit record: MotifStart (1) adds the implied leading
@@ -588,7 +590,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           ++nv;
         }
         vb1 = kind == 2 ? idx : vb1;  // bases of this visit are query[.. idx)
-        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)l_inst[4 * state + b];
+        const uint32_t pw = (b & 2) ? pred4.y : pred4.x;
+        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)((b & 1) ? pw >> 16 : pw & 0xFFFFu);
         if (inf & 8u) { --idx; row -= Spad; }
         nxt = state;
         state = prv;
