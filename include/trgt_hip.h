@@ -185,6 +185,11 @@ int trgt_hmm_batch(trgt_hip_ctx* ctx, int32_t n_sets, const uint8_t* motif_blob,
                    uint32_t* motif_counts, const uint64_t* count_off,
                    double* purity, int32_t* edit_dist, int32_t* max_dist);
 uint64_t trgt_hmm_path_capacity(uint32_t seq_len, uint32_t max_motif_len);
+/* Self-check of the model builder (not a reference interface).  The tables of build_hmm / define_motif_block (src/hmm/builder.rs:4-173)
+ * are built on the device by every entry point; this call builds them a second time with the host-side builder and returns in
+ * *n_diff the number of bytes in which descriptors and tables differ (0 expected). */
+int trgt_hmm_models_check(trgt_hip_ctx* ctx, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                          const uint32_t* set_motif_begin, int64_t* n_diff);
 
 /* ----------------------------------------------------------------- locus */
 typedef struct trgt_locus_params {

@@ -132,6 +132,21 @@ def test_visit_list_overflow_and_length_buckets(oracle, hmm):
     _same(oracle, hmm, sets, jobs)
 
 
+def test_device_built_models_equal_host_builder(hmm):
+    # the model tables (ln transition / emission terms, predecessor lists, block table, lane table of multi-wave models) are built
+    # by a kernel; the host-side builder restates build_hmm / define_motif_block (builder.rs:4-173) independently: byte-identical
+    rng = np.random.default_rng(23)
+    sets = [[b"A"], [b"N"], [b"CAG", b"CCG"], [b"GCN"], [b"AC"], [b"ACGTACGTACGTACGTACGTAAAA"], [b"AXGT", b"R"],
+            [b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"]]
+    for _ in range(300):
+        sets.append([rand_motif(rng, 1, 12) for _ in range(int(rng.integers(1, 5)))])
+    for n in (20, 59, 60, 64, 65, 70, 130, 200):  # (the kernel takes models of up to 1024 states)
+        sets.append([rand_dna(rng, n)])
+        sets.append([rand_dna(rng, n), rand_dna(rng, 3), rand_dna(rng, n // 2 + 1)])
+    sets.append([rand_dna(rng, 338)])
+    assert hmm.models_check(sets) == 0
+
+
 def test_device_resident_inputs(oracle, hmm):
     import torch
     rng = np.random.default_rng(5)

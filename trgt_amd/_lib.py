@@ -70,7 +70,7 @@ class LocusBatchOut(C.Structure):
 EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
-    "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity",
+    "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
     "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
@@ -116,6 +116,7 @@ def lib():
         L.trgt_hmm_path_capacity.restype = C.c_uint64
         L.trgt_hmm_path_capacity.argtypes = [C.c_uint32, C.c_uint32]
         L.trgt_hmm_batch.argtypes = [_VP, C.c_int32, _VP, _VP, _VP, C.c_int64] + [_VP] * 15
+        L.trgt_hmm_models_check.argtypes = [_VP, C.c_int32, _VP, _VP, _VP, _VP]
         L.trgt_wfa_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 15
         L.trgt_flank_filter_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 5 + [C.c_int32] + [_VP] * 4
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13

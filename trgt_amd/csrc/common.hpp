@@ -31,6 +31,7 @@ struct trgt_knobs {
   bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
   bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them
   bool host_genotyper = false;  // TRGT_HOST_GENOTYPER: host glue for every locus
+  bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
@@ -68,6 +69,7 @@ struct trgt_hip_ctx {
   // trgt_locus_batch_submit / _wait: two staging sets for the read and flank bytes of batches whose upload runs on `stream_copy`
   // next to the kernels of the batch before
   hipStream_t stream_copy = nullptr;
+  hipEvent_t ev_upload = nullptr;  // behind the small uploads of a call that go through stream_copy (HMM models, candidate job table)
   struct Staged {
     bool in_use = false; int64_t ticket = 0;
     trgt_locus_params params; const trgt_locus_batch_in* in = nullptr; trgt_locus_batch_out* out = nullptr;
@@ -129,11 +131,12 @@ enum Slot {
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED,
+  S_HMM_BUILD,  // inputs of the device-side model builder (one slab)
   S_COUNT
 };
 // pinned host buffer slots
 enum PinSlot { P_SPAN_S = 0, P_SPAN_E, P_HIT_L, P_HIT_R, P_CELLS, P_HMM_SEQ, P_HMM_SEQ_B, P_HMM_JOBS, P_HMM_JOBS_B, P_SEG0, P_SEG_META, P_GT_NEED, P_GT_NAL, P_GT_ALEN, P_GT_CI, P_GT_NSP, P_GT_CLS,
-               P_GT_RANK, P_GT_NSPAN, P_GT_TOFF, P_GT_PACKED, P_COUNT };
+               P_GT_RANK, P_GT_NSPAN, P_GT_TOFF, P_GT_PACKED, P_HMM_BUILD, P_COUNT };
 
 inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   if ((int)c->pool.size() < S_COUNT) c->pool.resize(S_COUNT);

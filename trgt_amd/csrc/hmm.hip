@@ -42,18 +42,89 @@ struct HmmJobDev {
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// Everything about a motif set's model that follows from the motif LENGTHS: number of states, block table (start state, end state,
+// motif length, offset of the motif's bytes), the lane -> state table of models of more than one wave, and where the tables sit in the
+// set's blob (offsets relative to it).  Shared by the host builder (build_set) and the device builder (hmm_model_build_kernel).
+static uint64_t layout_set(const uint32_t* mlen, uint32_t n_motifs, HmmSetDev& d, std::vector<uint32_t>& blocks, std::vector<uint16_t>& perm) {
+  uint32_t S = 7, max_mlen = 0, mbytes = 0;
+  for (uint32_t i = 0; i < n_motifs; ++i) { S += 3 * mlen[i] + 1; max_mlen = std::max(max_mlen, mlen[i]); }
+  const uint32_t nb = n_motifs + 1;
+  blocks.assign(4 * (size_t)nb, 0);
+  uint32_t ms = 2;
+  for (uint32_t mi = 0; mi < n_motifs; ++mi) {
+    const uint32_t n = mlen[mi], me = ms + 3 * n;
+    blocks[0 * nb + mi] = ms; blocks[1 * nb + mi] = me; blocks[2 * nb + mi] = n; blocks[3 * nb + mi] = mbytes;
+    mbytes += n;
+    ms = me + 1;
+  }
+  blocks[0 * nb + nb - 1] = ms; blocks[1 * nb + nb - 1] = ms + 2; blocks[2 * nb + nb - 1] = 0; blocks[3 * nb + nb - 1] = mbytes;  // skip block (builder.rs:41-53)
+  // The chain of deletion states of a motif block ends in the block end (d0 .. d0 + n - 2, me = d0 + n - 1: consecutive states, each
+  // with the one before it as its LAST predecessor): the kernel walks it across LANES, and a chain that runs over a wave boundary
+  // costs it another round.  Models of several waves therefore get a lane -> state table that keeps every chain inside one wave
+  // (first fit, longest chain first; the other states fill the lanes left over; a chain longer than a wave starts a wave of its own).
+  uint32_t chain_rounds = 1, n_lanes = 0;
+  perm.clear();
+  if (S > 64) {
+    struct Chain { uint32_t first, len; };
+    std::vector<Chain> chains;
+    std::vector<uint8_t> in_chain(S, 0);
+    for (uint32_t b = 0; b + 1 < nb; ++b) {
+      const uint32_t n = blocks[2 * nb + b], me = blocks[1 * nb + b];
+      if (n > 1) { chains.push_back({me - (n - 1), n}); for (uint32_t s = me - (n - 1); s <= me; ++s) in_chain[s] = 1; }
+    }
+    std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.len > b.len; });
+    std::vector<uint32_t> fill;  // lanes used per wave
+    auto place = [&](uint32_t lane, uint32_t st) { if (perm.size() <= lane) perm.resize(((size_t)lane / 64 + 1) * 64, 0xFFFF); perm[lane] = (uint16_t)st; };
+    for (const Chain& ch : chains) {
+      uint32_t w = 0;
+      if (ch.len > 64) { w = (uint32_t)fill.size(); }  // whole waves of its own
+      else { while (w < fill.size() && fill[w] + ch.len > 64) ++w; }
+      const uint32_t waves = (ch.len + 63) / 64;
+      if (w + waves > fill.size()) fill.resize(w + waves, 0);
+      const uint32_t lane0 = 64 * w + fill[w];
+      for (uint32_t k = 0; k < ch.len; ++k) place(lane0 + k, ch.first + k);
+      for (uint32_t k = 0; k < waves; ++k) fill[w + k] = k + 1 < waves ? 64 : std::max(fill[w + k], (lane0 + ch.len) - 64 * (w + k));
+      chain_rounds = std::max(chain_rounds, (lane0 + ch.len - 1) / 64 - lane0 / 64 + 1);
+    }
+    uint32_t w = 0;
+    for (uint32_t st = 0; st < S; ++st) {
+      if (in_chain[st]) continue;
+      while (w < fill.size() && fill[w] >= 64) ++w;
+      if (w == fill.size()) fill.push_back(0);
+      place(64 * w + fill[w], st);
+      ++fill[w];
+    }
+    n_lanes = (uint32_t)perm.size();
+  }
+  d.S = S; d.n_blocks = nb; d.chain_rounds = chain_rounds; d.max_mlen = max_mlen; d.n_lanes = n_lanes; d.pad_ = 0;
+  uint64_t o = 0;  // offsets relative to this set's blob; the caller rebases them
+  d.off_inlp = o; o += 8ull * 4 * S;
+  d.off_em = o; o += 8ull * 5 * S;
+  d.off_inst = o; o += 2ull * 4 * S;
+  d.off_block = o; o += 2ull * S; o = align_up(o, 4);
+  d.off_blocks = o; o += 4ull * 4 * nb;
+  d.off_nin = o; o += S;
+  d.off_level = o; o += S;
+  d.off_flags = o; o += S;
+  d.off_motifs = o; o += mbytes; o = align_up(o, 2);
+  d.off_perm = o; o += 2ull * perm.size();
+  return align_up(o, 16);
+}
+
 // build_hmm restated as flat tables (builder.rs:4-173); predecessor ORDER is part of the contract
-// because the first strict maximum wins in calc_viterbi_score (hmm_model.rs:79-88).
+// because the first strict maximum wins in calc_viterbi_score (hmm_model.rs:79-88).  (Host version: the product builds the tables
+// on the device, hmm_model_build_kernel below; this one is what trgt_hmm_models_check compares it with, byte for byte.)
 static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_t>& blob, HmmSetDev& d) {
-  uint32_t S = 7, max_mlen = 0;
-  for (auto& m : motifs) { S += 3 * (uint32_t)m.size() + 1; max_mlen = std::max<uint32_t>(max_mlen, (uint32_t)m.size()); }
-  const uint32_t nb = (uint32_t)motifs.size() + 1;
+  std::vector<uint32_t> mlens, blocks;
+  std::vector<uint16_t> perm;
+  for (auto& m : motifs) mlens.push_back((uint32_t)m.size());
+  const uint64_t bytes = layout_set(mlens.data(), (uint32_t)mlens.size(), d, blocks, perm);
+  const uint32_t S = d.S, nb = d.n_blocks;
   const double NINF = -std::numeric_limits<double>::infinity();
   std::vector<double> inlp(4 * (size_t)S, NINF), em(5 * (size_t)S, NINF);
   std::vector<uint16_t> inst(4 * (size_t)S, 0);
   std::vector<int16_t> block(S, -1);
   std::vector<uint8_t> nin(S, 0), level(S, 0), flags(S, 0);
-  std::vector<uint32_t> blocks(4 * (size_t)nb, 0);
   std::string mbytes;
   auto set_ems = [&](uint32_t st, const double (&p)[5]) { for (int i = 0; i < 5; ++i) em[(size_t)i * S + st] = std::log(p[i]); };
   auto set_trans = [&](uint32_t st, std::initializer_list<uint32_t> ins, std::initializer_list<double> ps) {
@@ -104,7 +175,6 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
     if (n > 1) set_trans(me, {m0 + n - 1, i0 + n - 1, d0 + n - 2}, {match_prob, 1.0 - ins_to_ins, 1.0});
     else set_trans(me, {m0 + n - 1, i0 + n - 1}, {match_prob, 1.0 - ins_to_ins});
     for (uint32_t s = ms; s <= me; ++s) block[s] = (int16_t)mi;
-    blocks[0 * nb + mi] = ms; blocks[1 * nb + mi] = me; blocks[2 * nb + mi] = n; blocks[3 * nb + mi] = (uint32_t)mbytes.size();
     mbytes += motif;
     ms = me + 1;
   }
@@ -117,88 +187,20 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
   set_ems(me_skip, SILENT);
   set_trans(me_skip, {skip}, {1.0 - 0.5});
   for (uint32_t s = ms; s <= me_skip; ++s) block[s] = (int16_t)(nb - 1);
-  blocks[0 * nb + nb - 1] = ms; blocks[1 * nb + nb - 1] = me_skip; blocks[2 * nb + nb - 1] = 0; blocks[3 * nb + nb - 1] = (uint32_t)mbytes.size();
   // run end: predecessors are the block ends in block order, each ln(me_to_re) (builder.rs:55-57)
   set_ems(re, SILENT);
   nin[re] = 0xFF;
   inlp[re] = std::log(me_to_re);
-  // flags + silent evaluation levels (any topological order gives identical values; hmm_model.rs:206-240)
+  // flags; silent states are evaluated after the emitting ones of a column (level 1; any topological order of the silent states
+  // gives identical values, hmm_model.rs:206-240 -- the kernel's passes are one)
   for (uint32_t s = 0; s < S; ++s) {
     bool any = false, base = false;
     for (int i = 0; i < 5; ++i) if (std::isfinite(em[(size_t)i * S + s])) { any = true; if (i) base = true; }
     flags[s] = (any ? 1 : 0) | (base ? 2 : 0);
-  }
-  uint32_t n_levels = 0;
-  {
-    std::vector<int> lev(S, -1);
-    for (uint32_t s = 0; s < S; ++s) if (flags[s] & 1) lev[s] = 0;
-    bool changed = true;
-    while (changed) {
-      changed = false;
-      for (uint32_t s = 0; s < S; ++s) {
-        if (lev[s] >= 0) continue;
-        int mx = 0; bool ready = true;
-        auto see = [&](uint32_t p) { if (flags[p] & 1) return; if (lev[p] < 0) ready = false; else mx = std::max(mx, lev[p]); };
-        if (nin[s] == 0xFF) for (uint32_t b = 0; b < nb; ++b) see(blocks[1 * nb + b]);
-        else for (int j = 0; j < nin[s]; ++j) see(inst[(size_t)j * S + s]);
-        if (ready) { lev[s] = mx + 1; changed = true; }
-      }
-    }
-    for (uint32_t s = 0; s < S; ++s) { level[s] = (uint8_t)std::min(lev[s], 255); n_levels = std::max<uint32_t>(n_levels, (uint32_t)lev[s]); }  // (the kernel only asks level > 0)
+    level[s] = any ? 0 : 1;
   }
   // serialise
-  // The chain of deletion states of a motif block ends in the block end (d0 .. d0 + n - 2, me = d0 + n - 1: consecutive states, each
-  // with the one before it as its LAST predecessor): the kernel walks it across LANES, and a chain that runs over a wave boundary
-  // costs it another round.  Models of several waves therefore get a lane -> state table that keeps every chain inside one wave
-  // (first fit, longest chain first; the other states fill the lanes left over; a chain longer than a wave starts a wave of its own).
-  uint32_t chain_rounds = 1, n_lanes = 0;
-  std::vector<uint16_t> perm;
-  if (S > 64) {
-    struct Chain { uint32_t first, len; };
-    std::vector<Chain> chains;
-    std::vector<uint8_t> in_chain(S, 0);
-    for (uint32_t b = 0; b + 1 < nb; ++b) {
-      const uint32_t n = blocks[2 * nb + b], me = blocks[1 * nb + b];
-      if (n > 1) { chains.push_back({me - (n - 1), n}); for (uint32_t s = me - (n - 1); s <= me; ++s) in_chain[s] = 1; }
-    }
-    std::stable_sort(chains.begin(), chains.end(), [](const Chain& a, const Chain& b) { return a.len > b.len; });
-    std::vector<uint32_t> fill;  // lanes used per wave
-    auto place = [&](uint32_t lane, uint32_t st) { if (perm.size() <= lane) perm.resize(((size_t)lane / 64 + 1) * 64, 0xFFFF); perm[lane] = (uint16_t)st; };
-    for (const Chain& ch : chains) {
-      uint32_t w = 0;
-      if (ch.len > 64) { w = (uint32_t)fill.size(); }  // whole waves of its own
-      else { while (w < fill.size() && fill[w] + ch.len > 64) ++w; }
-      const uint32_t waves = (ch.len + 63) / 64;
-      if (w + waves > fill.size()) fill.resize(w + waves, 0);
-      const uint32_t lane0 = 64 * w + fill[w];
-      for (uint32_t k = 0; k < ch.len; ++k) place(lane0 + k, ch.first + k);
-      for (uint32_t k = 0; k < waves; ++k) fill[w + k] = k + 1 < waves ? 64 : std::max(fill[w + k], (lane0 + ch.len) - 64 * (w + k));
-      chain_rounds = std::max(chain_rounds, (lane0 + ch.len - 1) / 64 - lane0 / 64 + 1);
-    }
-    uint32_t w = 0;
-    for (uint32_t st = 0; st < S; ++st) {
-      if (in_chain[st]) continue;
-      while (w < fill.size() && fill[w] >= 64) ++w;
-      if (w == fill.size()) fill.push_back(0);
-      place(64 * w + fill[w], st);
-      ++fill[w];
-    }
-    n_lanes = (uint32_t)perm.size();
-  }
-  (void)n_levels;
-  d.S = S; d.n_blocks = nb; d.chain_rounds = chain_rounds; d.max_mlen = max_mlen; d.n_lanes = n_lanes;
-  uint64_t o = 0;  // offsets relative to this set's blob; the caller rebases them
-  d.off_inlp = o; o += 8ull * 4 * S;
-  d.off_em = o; o += 8ull * 5 * S;
-  d.off_inst = o; o += 2ull * 4 * S;
-  d.off_block = o; o += 2ull * S; o = align_up(o, 4);
-  d.off_blocks = o; o += 4ull * 4 * nb;
-  d.off_nin = o; o += S;
-  d.off_level = o; o += S;
-  d.off_flags = o; o += S;
-  d.off_motifs = o; o += mbytes.size(); o = align_up(o, 2);
-  d.off_perm = o; o += 2ull * perm.size();
-  blob.resize(align_up(o, 16), 0);
+  blob.assign((size_t)bytes, 0);
   std::memcpy(&blob[d.off_inlp], inlp.data(), 8ull * 4 * S);
   std::memcpy(&blob[d.off_em], em.data(), 8ull * 5 * S);
   std::memcpy(&blob[d.off_inst], inst.data(), 2ull * 4 * S);
@@ -209,6 +211,122 @@ static void build_set(const std::vector<std::string>& motifs, std::vector<uint8_
   std::memcpy(&blob[d.off_flags], flags.data(), S);
   if (!mbytes.empty()) std::memcpy(&blob[d.off_motifs], mbytes.data(), mbytes.size());
   if (!perm.empty()) std::memcpy(&blob[d.off_perm], perm.data(), 2ull * perm.size());
+}
+
+// ---- the same tables built on the device: one workgroup per motif set.  The natural logarithms are the HOST's (the reference's are
+// Rust f64::ln = the platform libm, and the scores are sums of them: bit-exact parity needs the very same values): the handful of
+// constants comes in by value, ln(seed(n) * (n - k)) from a table with one row per distinct motif length of the batch.
+struct HmmBuildConsts {
+  double ln_match, ln_1m_ins, ln_del2m, ln_ins2ins, ln_m2indel, ln_1m_del2m, ln_one, ln_1m_me2re, ln_me2re, ln_end, ln_skip_self, ln_skip_out,
+         em_hit, em_miss, em_n, em_uni;
+};
+static HmmBuildConsts hmm_build_consts() {
+  const double match_prob = 0.90, ins_to_ins = 0.25, match_to_indel = (1.00 - match_prob) / 2.00, del_to_match = 0.50, me_to_re = 0.50;
+  HmmBuildConsts k;
+  k.ln_match = std::log(match_prob); k.ln_1m_ins = std::log(1.0 - ins_to_ins); k.ln_del2m = std::log(del_to_match); k.ln_ins2ins = std::log(ins_to_ins);
+  k.ln_m2indel = std::log(match_to_indel); k.ln_1m_del2m = std::log(1.0 - del_to_match); k.ln_one = std::log(1.00); k.ln_1m_me2re = std::log(1.0 - me_to_re);
+  k.ln_me2re = std::log(me_to_re); k.ln_end = std::log(0.10); k.ln_skip_self = std::log(0.5); k.ln_skip_out = std::log(1.0 - 0.5);
+  k.em_hit = std::log(0.90); k.em_miss = std::log(0.03); k.em_n = std::log(0.25); k.em_uni = std::log(0.25);
+  return k;
+}
+struct HmmBuildArgs {
+  const HmmSetDev* sets; uint8_t* blob;
+  const uint8_t* motif_bytes;       // sanitised motifs of all sets, back to back
+  const uint32_t* motif_off;        // [n_motifs_total + 1] into motif_bytes
+  const uint32_t* set_motif_begin;  // [n_sets + 1]
+  const uint32_t* seed_row;         // [n_motifs_total] first entry of the motif's row of seed_tab (entry k: ln(seed(n) * (n - k)))
+  const double* seed_tab;
+  const uint16_t* perm_all; const uint64_t* perm_src;  // lane -> state tables of the sets that have one, [n_sets] offsets into perm_all
+  HmmBuildConsts k;
+};
+__global__ void __launch_bounds__(64) hmm_model_build_kernel(const HmmBuildArgs a) {
+  const int s = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const HmmSetDev d = a.sets[s];
+  const int S = (int)d.S, nb = (int)d.n_blocks;
+  const uint32_t mb = a.set_motif_begin[s];
+  uint8_t* const blob = a.blob;
+  double* inlp = reinterpret_cast<double*>(blob + d.off_inlp);
+  double* em = reinterpret_cast<double*>(blob + d.off_em);
+  uint16_t* inst = reinterpret_cast<uint16_t*>(blob + d.off_inst);
+  int16_t* block = reinterpret_cast<int16_t*>(blob + d.off_block);
+  uint32_t* blocks = reinterpret_cast<uint32_t*>(blob + d.off_blocks);
+  uint8_t *nin = blob + d.off_nin, *level = blob + d.off_level, *flags = blob + d.off_flags, *mot = blob + d.off_motifs;
+  __shared__ uint32_t b_start[256];  // first state of every block (n_blocks <= 254)
+  if (tid == 0) {
+    uint32_t ms = 2, mbytes = 0;
+    for (int mi = 0; mi + 1 < nb; ++mi) {
+      const uint32_t n = a.motif_off[mb + mi + 1] - a.motif_off[mb + mi], me = ms + 3 * n;
+      blocks[0 * nb + mi] = ms; blocks[1 * nb + mi] = me; blocks[2 * nb + mi] = n; blocks[3 * nb + mi] = mbytes;
+      b_start[mi] = ms;
+      mbytes += n; ms = me + 1;
+    }
+    blocks[0 * nb + nb - 1] = ms; blocks[1 * nb + nb - 1] = ms + 2; blocks[2 * nb + nb - 1] = 0; blocks[3 * nb + nb - 1] = mbytes;
+    b_start[nb - 1] = ms;
+  }
+  __syncthreads();
+  const double NINF = -__builtin_huge_val();
+  const HmmBuildConsts& k = a.k;
+  for (int st = tid; st < S; st += 64) {
+    double lp[4] = {NINF, NINF, NINF, NINF}, e[5] = {NINF, NINF, NINF, NINF, NINF};
+    uint32_t in[4] = {0, 0, 0, 0};
+    int n_in = 0, blk = -1;
+    if (st == 0) { e[0] = k.ln_one; }                                                   // start: emits '#'
+    else if (st == S - 1) { e[0] = k.ln_one; n_in = 1; in[0] = (uint32_t)S - 2; lp[0] = k.ln_end; }   // end <- run end
+    else if (st == 1) { n_in = 2; in[0] = 0; in[1] = (uint32_t)S - 2; lp[0] = k.ln_one; lp[1] = k.ln_one; }  // run start <- {start, run end}
+    else if (st == S - 2) { n_in = 0xFF; lp[0] = k.ln_me2re; }                          // run end <- the block ends
+    else {
+      int lo = 0, hi = nb - 1;  // the block of the state
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b_start[mid] <= (uint32_t)st) lo = mid; else hi = mid - 1; }
+      blk = lo;
+      const uint32_t ms = b_start[blk];
+      if (blk == nb - 1) {  // skip block
+        const uint32_t skip = ms + 1, me = ms + 2;
+        if ((uint32_t)st == ms) { n_in = 2; in[0] = 1; in[1] = me; lp[0] = k.ln_one; lp[1] = k.ln_1m_me2re; }
+        else if ((uint32_t)st == skip) { e[1] = e[2] = e[3] = e[4] = k.em_uni; n_in = 2; in[0] = ms; in[1] = skip; lp[0] = k.ln_one; lp[1] = k.ln_skip_self; }
+        else { n_in = 1; in[0] = skip; lp[0] = k.ln_skip_out; }
+      } else {
+        const uint32_t mo = a.motif_off[mb + blk], n = a.motif_off[mb + blk + 1] - mo;
+        const uint32_t me = ms + 3 * n, m0 = ms + 1, i0 = m0 + n, d0 = i0 + n;
+        const double* seed = a.seed_tab + a.seed_row[mb + blk];
+        if ((uint32_t)st == ms) { n_in = 2; in[0] = 1; in[1] = me; lp[0] = k.ln_one; lp[1] = k.ln_1m_me2re; }
+        else if ((uint32_t)st == me) {
+          if (n > 1) { n_in = 3; in[0] = m0 + n - 1; in[1] = i0 + n - 1; in[2] = d0 + n - 2; lp[0] = k.ln_match; lp[1] = k.ln_1m_ins; lp[2] = k.ln_one; }
+          else { n_in = 2; in[0] = m0 + n - 1; in[1] = i0 + n - 1; lp[0] = k.ln_match; lp[1] = k.ln_1m_ins; }
+        } else if ((uint32_t)st < i0) {  // match state
+          const uint32_t kk = (uint32_t)st - m0;
+          const uint8_t c = a.motif_bytes[mo + kk];
+          if (c == 'A' || c == 'T' || c == 'C' || c == 'G') { e[1] = e[2] = e[3] = e[4] = k.em_miss; e[c == 'A' ? 1 : c == 'T' ? 2 : c == 'C' ? 3 : 4] = k.em_hit; }
+          else e[1] = e[2] = e[3] = e[4] = k.em_n;
+          if (kk == 0) { n_in = 1; in[0] = ms; lp[0] = k.ln_match; }
+          else if (kk == 1) { n_in = 3; in[0] = m0; in[1] = ms; in[2] = i0; lp[0] = k.ln_match; lp[1] = seed[1]; lp[2] = k.ln_1m_ins; }
+          else { n_in = 4; in[0] = m0 + kk - 1; in[1] = ms; in[2] = i0 + kk - 1; in[3] = d0 + kk - 2; lp[0] = k.ln_match; lp[1] = seed[kk]; lp[2] = k.ln_1m_ins; lp[3] = k.ln_del2m; }
+        } else if ((uint32_t)st < d0) {  // insertion state
+          const uint32_t kk = (uint32_t)st - i0;
+          e[1] = e[2] = e[3] = e[4] = k.em_uni;
+          n_in = 2; in[0] = i0 + kk; in[1] = m0 + kk; lp[0] = k.ln_ins2ins; lp[1] = k.ln_m2indel;
+        } else {  // deletion state
+          const uint32_t kk = (uint32_t)st - d0;
+          if (kk == 0) { n_in = 1; in[0] = m0; lp[0] = k.ln_m2indel; }
+          else { n_in = 2; in[0] = m0 + kk; in[1] = d0 + kk - 1; lp[0] = k.ln_m2indel; lp[1] = k.ln_1m_del2m; }
+        }
+      }
+    }
+    bool any = false, base = false;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { em[(size_t)i * S + st] = e[i]; if (e[i] > NINF) { any = true; if (i) base = true; } }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { inlp[(size_t)j * S + st] = lp[j]; inst[(size_t)j * S + st] = (uint16_t)in[j]; }
+    block[st] = (int16_t)blk; nin[st] = (uint8_t)n_in; flags[st] = (uint8_t)((any ? 1 : 0) | (base ? 2 : 0)); level[st] = any ? 0 : 1;
+  }
+  {  // motif bytes, lane table, padding
+    const uint32_t m_lo = a.motif_off[mb], m_hi = a.motif_off[mb + nb - 1];
+    for (uint32_t i = (uint32_t)tid; i < m_hi - m_lo; i += 64) mot[i] = a.motif_bytes[m_lo + i];
+    if (d.n_lanes) {
+      uint16_t* perm = reinterpret_cast<uint16_t*>(blob + d.off_perm);
+      const uint16_t* src = a.perm_all + a.perm_src[s];
+      for (uint32_t i = (uint32_t)tid; i < d.n_lanes; i += 64) perm[i] = src[i];
+    }
+  }
 }
 
 // --------------------------------------------------------------- kernel
@@ -285,8 +403,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
                                    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
                                    uint32_t* __restrict__ counts, double* __restrict__ purity,
                                    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out,
-                                   uint32_t n_launch_jobs, uint32_t lds_per_job) {
+                                   uint32_t n_launch_jobs, uint32_t lds_per_job, const uint32_t* __restrict__ n_jobs_dev) {
   extern __shared__ __align__(16) unsigned char lds_all[];
+  if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
   const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
@@ -661,6 +780,46 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   HP_MARK(3);
 }
 
+// Job list of a launch class resolved on the device: candidate (locus, allele) slots with everything the host knows ahead of the
+// genotyper (motif set, where the allele will be, output places, workspace for its longest possible sequence) become jobs once the
+// genotyper has written how many alleles a locus has and how long they are -- no host round trip between the genotyper and this
+// kernel's launch.  One workgroup; candidates keep their order (the host derives the same list from the same results later).
+struct HmmResolveArgs {
+  const HmmJobDev* cand; uint32_t n;
+  const uint8_t* skip_locus; const int32_t* n_alleles; const uint32_t* allele_len;  // genotyper results (device), by locus / slot
+  HmmJobDev* jobs; uint32_t* n_jobs; uint32_t* n_spans; double* purity;
+};
+__global__ void __launch_bounds__(1024) hmm_resolve_kernel(const HmmResolveArgs a) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t base_s;
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < a.n; i0 += 1024) {
+    const uint32_t i = i0 + (uint32_t)tid;
+    HmmJobDev jd;
+    bool on = false;
+    if (i < a.n) {
+      jd = a.cand[i];
+      const uint32_t slot = jd.job_index, l = slot >> 1, al = slot & 1u;
+      on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
+      if (on) jd.seq_len = a.allele_len[slot];
+      else { a.n_spans[slot] = 0; a.purity[slot] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
+    }
+    const unsigned long long m = __ballot(on);
+    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    if (on) a.jobs[off + before] = jd;
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base_s += t; }
+    __syncthreads();
+  }
+  if (tid == 0) *a.n_jobs = base_s;
+}
+
 // Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
 __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const uint64_t* __restrict__ job_span_off,
                                       const uint32_t* __restrict__ n_spans, const uint64_t* __restrict__ packed_off,
@@ -740,6 +899,99 @@ int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* 
   return 0;
 }
 
+
+// All motif-set models of a batch, built ON THE DEVICE (hmm_model_build_kernel): the host lays the sets out (sizes, offsets, lane
+// tables: a few microseconds per thousand sets), uploads the motifs and the logarithm table (kilobytes) and launches one workgroup per
+// set -- instead of building ~2 KB of tables per set on host threads and uploading them (6 ms + 22 MB for a 10k-locus batch: it had
+// become the critical path of stage C).  Uploads and the kernel go to `up` (a stream with nothing in front of it); `done` is recorded
+// behind them.  out.sets / out.d_sets / out.d_blob are valid on return (the device side once `done` has fired).
+int hmm_models_on_device(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin,
+                         HmmModels& out, hipStream_t up, hipEvent_t done) {
+  out.rc = 0; out.blob.clear(); out.d_sets = out.d_blob = nullptr;
+  std::vector<HmmSetDev>& sets = out.sets;
+  sets.assign((size_t)n_sets, HmmSetDev());
+  if (n_sets <= 0) return TRGT_OK;
+  const uint32_t m_total = set_motif_begin[n_sets];
+  const uint32_t byte0 = motif_off[0], bytes_total = motif_off[m_total] - byte0;
+  // layout: per set
+  std::vector<uint16_t> perm_all, perm;
+  std::vector<uint64_t> perm_src((size_t)n_sets, 0);
+  std::vector<uint32_t> mlens, blocks, seed_row((size_t)m_total, 0);
+  std::vector<double> seed_tab;
+  std::vector<int64_t> row_of_len;  // motif length -> first entry of its row (-1: none yet)
+  uint64_t pos = 0;
+  char msg[160];
+  for (int s = 0; s < n_sets; ++s) {
+    const uint32_t m0 = set_motif_begin[s], m1 = set_motif_begin[s + 1];
+    if (m1 <= m0) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has no motif", s); out.err = msg; return out.rc = TRGT_ERR_INVALID; }
+    if (m1 - m0 + 1 > 254) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has too many motifs", s); out.err = msg; return out.rc = TRGT_ERR_UNSUPPORTED; }
+    mlens.clear();
+    for (uint32_t m = m0; m < m1; ++m) {
+      const uint32_t n = motif_off[m + 1] - motif_off[m];
+      if (n == 0) { snprintf(msg, sizeof msg, "trgt_hmm_batch: empty motif in set %d", s); out.err = msg; return out.rc = TRGT_ERR_INVALID; }
+      mlens.push_back(n);
+      if (row_of_len.size() <= n) row_of_len.resize((size_t)n + 1, -1);
+      if (row_of_len[n] < 0) {  // ln(seed * (n - k)), k = 1 .. n - 1 (builder.rs:80-173), entry 0 unused
+        row_of_len[n] = (int64_t)seed_tab.size();
+        const double seed = 2.00 * (1.00 - 0.90) / (double)((size_t)n * (size_t)(n - 1));
+        seed_tab.push_back(0.0);
+        for (uint32_t k = 1; k < n; ++k) seed_tab.push_back(std::log(seed * (double)(n - k)));
+      }
+      seed_row[m] = (uint32_t)row_of_len[n];
+    }
+    HmmSetDev& d = sets[(size_t)s];
+    const uint64_t bytes = layout_set(mlens.data(), (uint32_t)mlens.size(), d, blocks, perm);
+    if (d.S > 1024) { snprintf(msg, sizeof msg, "trgt_hmm_batch: set %d has %u HMM states (kernel limit 1024)", s, d.S); out.err = msg; return out.rc = TRGT_ERR_UNSUPPORTED; }
+    d.off_inlp += pos; d.off_em += pos; d.off_inst += pos; d.off_block += pos; d.off_nin += pos; d.off_level += pos;
+    d.off_flags += pos; d.off_blocks += pos; d.off_motifs += pos; d.off_perm += pos;
+    pos += bytes;
+    if (!perm.empty()) { perm_src[(size_t)s] = perm_all.size(); perm_all.insert(perm_all.end(), perm.begin(), perm.end()); }
+  }
+  out.blob_bytes = pos;
+  // one pinned slab -> one device slab: sets | motif_off (rebased) | set_motif_begin | seed_row | perm_src | seed_tab | perm_all | motif bytes
+  struct Lay { size_t total = 0; size_t add(size_t b) { const size_t o = total; total += (b + 15) & ~(size_t)15; return o; } } lay;
+  const size_t o_sets = lay.add(sizeof(HmmSetDev) * (size_t)n_sets), o_moff = lay.add(4 * ((size_t)m_total + 1)), o_smb = lay.add(4 * ((size_t)n_sets + 1)),
+               o_srow = lay.add(4 * (size_t)m_total), o_psrc = lay.add(8 * (size_t)n_sets), o_stab = lay.add(8 * seed_tab.size()),
+               o_perm = lay.add(2 * perm_all.size()), o_mot = lay.add(bytes_total);
+  void *h = nullptr, *dv = nullptr, *d_blob = nullptr, *d_sets = nullptr;
+  int rc;
+  if ((rc = pin_get(c, P_HMM_BUILD, lay.total, &h)) || (rc = dev_get(c, S_HMM_BUILD, lay.total, &dv)) ||
+      (rc = dev_get(c, S_HMM_MODEL, (size_t)pos + 16, &d_blob)) || (rc = dev_get(c, S_HMM_DESC, sizeof(HmmSetDev) * (size_t)n_sets, &d_sets)))
+    return out.rc = rc;
+  uint8_t* hb = (uint8_t*)h;
+  std::memcpy(hb + o_sets, sets.data(), sizeof(HmmSetDev) * (size_t)n_sets);
+  { uint32_t* q = (uint32_t*)(hb + o_moff); for (uint32_t m = 0; m <= m_total; ++m) q[m] = motif_off[m] - byte0; }
+  std::memcpy(hb + o_smb, set_motif_begin, 4 * ((size_t)n_sets + 1));
+  std::memcpy(hb + o_srow, seed_row.data(), 4 * (size_t)m_total);
+  std::memcpy(hb + o_psrc, perm_src.data(), 8 * (size_t)n_sets);
+  std::memcpy(hb + o_stab, seed_tab.data(), 8 * seed_tab.size());
+  if (!perm_all.empty()) std::memcpy(hb + o_perm, perm_all.data(), 2 * perm_all.size());
+  {  // replace_invalid_bases(m, ATCGN) (utils.rs:29-42), position inside the motif
+    uint8_t* q = hb + o_mot;
+    static const char allowed[] = "ATCGN";
+    for (uint32_t m = 0; m < m_total; ++m) {
+      const uint8_t* src = motif_blob + motif_off[m];
+      const uint32_t n = motif_off[m + 1] - motif_off[m];
+      uint8_t* dst = q + (motif_off[m] - byte0);
+      for (uint32_t i = 0; i < n; ++i) { const uint8_t ch = src[i]; dst[i] = (ch == 'A' || ch == 'T' || ch == 'C' || ch == 'G' || ch == 'N') ? ch : (uint8_t)allowed[i % 5]; }
+    }
+  }
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(dv, h, lay.total, hipMemcpyHostToDevice, up));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, (uint8_t*)dv + o_sets, sizeof(HmmSetDev) * (size_t)n_sets, hipMemcpyDeviceToDevice, up));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_blob, 0, (size_t)pos, up));  // (padding between the tables: the blob compares equal to the host builder's)
+  HmmBuildArgs a;
+  const uint8_t* db = (const uint8_t*)dv;
+  a.sets = (const HmmSetDev*)(db + o_sets); a.blob = (uint8_t*)d_blob; a.motif_bytes = db + o_mot; a.motif_off = (const uint32_t*)(db + o_moff);
+  a.set_motif_begin = (const uint32_t*)(db + o_smb); a.seed_row = (const uint32_t*)(db + o_srow); a.seed_tab = (const double*)(db + o_stab);
+  a.perm_all = (const uint16_t*)(db + o_perm); a.perm_src = (const uint64_t*)(db + o_psrc); a.k = hmm_build_consts();
+  hipLaunchKernelGGL(hmm_model_build_kernel, dim3((unsigned)n_sets), dim3(64), 0, up, a);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  if (done) TRGT_HIP_TRY(c, hipEventRecord(done, up));
+  out.d_sets = d_sets; out.d_blob = d_blob;
+  return TRGT_OK;
+}
+
 }  // namespace trgt
 
 using namespace trgt;
@@ -757,6 +1009,8 @@ struct trgt::HmmPending {
   std::vector<uint64_t> cnt_off; std::vector<uint32_t> cnt_n; uint32_t* cnt_user = nullptr; uint64_t cnt_total = 0;  // motif counts go back job by job
   bool spans_on_host = false;
   std::vector<uint64_t> tight_off;
+  std::vector<uint32_t> slot_nm;  // hmm_enqueue_slots: motifs of every slot's set (the job list is only known once the genotyper is back)
+  std::vector<uint64_t> slot_cnt_off;
   std::vector<HmmJobDev> jobs;   // upload sources stay alive until the batch is collected
   HmmModels local_models;
   int32_t* spans3 = nullptr; const uint64_t* span_off = nullptr;
@@ -801,8 +1055,8 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   HmmModels& local_models = P->local_models;
   const HmmModels* mp = premade;
   if (!mp) {
-    const int mrc = hmm_build_models(n_sets, motif_blob, motif_off, set_motif_begin, local_models);
-    if (mrc) return fail(c, mrc, "%s", local_models.err.c_str());
+    const int mrc = hmm_models_on_device(c, n_sets, motif_blob, motif_off, set_motif_begin, local_models, c->stream, nullptr);
+    if (mrc) return fail(c, mrc, "%s", local_models.err.empty() ? trgt_hip_last_error(c) : local_models.err.c_str());
     mp = &local_models;
   } else if (mp->rc) return fail(c, mp->rc, "%s", mp->err.c_str());
   const std::vector<HmmSetDev>& sets = mp->sets;
@@ -952,7 +1206,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB)                                                                                                      \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)nullptr)
     if (half) TRGT_HMM_LAUNCH(32); else TRGT_HMM_LAUNCH(64);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
@@ -966,6 +1220,170 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     }
   *out_pending = P.release();
   return TRGT_OK;
+}
+
+
+// ---- stage C behind a device-side genotyper: the kernels are enqueued before the host knows which alleles exist (see
+//      hmm_resolve_kernel); hmm_slots_resolved tells the pending batch afterwards, hmm_collect is the same as for a host-built list.
+int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots& in, int32_t* spans3, const uint64_t* span_off,
+                            uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity,
+                            HmmPending** out_pending, int buffer_set) {
+  *out_pending = nullptr;
+  const int so = buffer_set ? (int)S_HMM_B_BASE - (int)S_HMM_SEQ : 0;
+  if (!c) return TRGT_ERR_INVALID;
+  if (!mp || mp->rc) return fail(c, mp ? mp->rc : TRGT_ERR_INVALID, "%s", mp ? mp->err.c_str() : "no models");
+  const int64_t nl = in.n_loci, n_slots = 2 * nl;
+  if (nl <= 0) return TRGT_OK;
+  if (!mp->d_sets || !mp->d_blob) return fail(c, TRGT_ERR_INVALID, "hmm_enqueue_slots: the models must be in device memory");
+  if (!is_device_ptr(in.seq_blob_dev) || (spans3 && is_device_ptr(spans3))) return fail(c, TRGT_ERR_INVALID, "hmm_enqueue_slots: device alleles, host results");
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  const std::vector<HmmSetDev>& sets = mp->sets;
+  std::unique_ptr<HmmPending> P(new HmmPending());
+  P->n_jobs = n_slots; P->spans3 = spans3; P->span_off = span_off; P->set = buffer_set; P->stream = c->stream;
+  auto set_class = [&](const HmmSetDev& sd) { return sd.S <= 32 ? 0u : (std::max(sd.S, sd.n_lanes) + 63) / 64; };
+  // candidates by class (a counting sort: loci keep their order inside a class)
+  uint32_t class_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, class_begin[9];
+  for (int64_t l = 0; l < nl; ++l) {
+    if (in.host_skip && in.host_skip[l]) continue;
+    const uint32_t k = set_class(sets[(size_t)l]);
+    if (k >= 8) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: a model of %u states", sets[(size_t)l].S);
+    class_n[k] += 2;
+  }
+  class_begin[0] = 0;
+  for (int k = 0; k < 8; ++k) class_begin[k + 1] = class_begin[k] + class_n[k];
+  const uint32_t n_cand = class_begin[8];
+  P->slot_nm.assign((size_t)n_slots, 0); P->slot_cnt_off.assign(count_off, count_off + n_slots);
+  P->tight_off.assign(span_off, span_off + n_slots);
+  P->spans_on_host = spans3 != nullptr;
+  uint64_t count_total = 0, span_total = 0;
+  for (int64_t sl = 0; sl < n_slots; ++sl) {
+    const HmmSetDev& sd = sets[(size_t)(sl >> 1)];
+    P->slot_nm[(size_t)sl] = sd.n_blocks - 1;
+    count_total = std::max<uint64_t>(count_total, count_off[sl] + (sd.n_blocks - 1));
+    span_total = std::max<uint64_t>(span_total, span_off[sl] + in.cap[sl >> 1] + 1);
+  }
+  if (n_cand == 0) { P->n_jobs = 0; return TRGT_OK; }
+  void* h_cand = nullptr;
+  int rc;
+  if ((rc = pin_get(c, buffer_set ? P_HMM_JOBS_B : P_HMM_JOBS, (size_t)n_cand * sizeof(HmmJobDev), &h_cand))) return rc;
+  HmmJobDev* cand = (HmmJobDev*)h_cand;
+  uint64_t bp_total = 0, visit_total = 0;
+  {
+    uint32_t at[8];
+    for (int k = 0; k < 8; ++k) at[k] = class_begin[k];
+    for (int64_t l = 0; l < nl; ++l) {
+      if (in.host_skip && in.host_skip[l]) continue;
+      const HmmSetDev& sd = sets[(size_t)l];
+      const uint32_t k = set_class(sd);
+      const uint64_t spad = (sd.S + 15) & ~15u;
+      for (int a = 0; a < 2; ++a) {
+        HmmJobDev& jd = cand[at[k]++];
+        const int64_t sl = 2 * l + a;
+        jd.set = (uint32_t)l; jd.seq_len = 0; jd.job_index = (uint32_t)sl; jd.path_cap = 0;
+        jd.seq_off = in.seq_off[sl]; jd.path_off = 0; jd.span_off = span_off[sl]; jd.count_off = count_off[sl];
+        jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)in.cap[l] + 2), 16);  // room for the longest allele the locus can have
+        jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)in.cap[l] + 2);
+      }
+    }
+  }
+  if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
+  void *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
+  const size_t jobs_bytes = (size_t)n_cand * sizeof(HmmJobDev);
+  if ((rc = dev_get(c, S_HMM_JOBS + so, 2 * jobs_bytes + 64, &d_jobs)) || (rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp)) ||
+      (rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits)))
+    return rc;
+  HmmJobDev* const d_cand = (HmmJobDev*)d_jobs;
+  HmmJobDev* const d_list = d_cand + n_cand;
+  uint32_t* const d_count = (uint32_t*)((uint8_t*)d_jobs + 2 * jobs_bytes);
+  {  // on the copy stream: a copy queued on the batch's stream would sit in the copy engine's queue until the genotyper in front of it
+     // has run, and hold up every copy issued after it (the next batch's reads)
+    hipStream_t us = c->stream_copy ? c->stream_copy : c->stream;
+    TRGT_HIP_TRY(c, hipMemcpyAsync(d_cand, h_cand, jobs_bytes, hipMemcpyHostToDevice, us));
+    if (us != c->stream) {
+      if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+      TRGT_HIP_TRY(c, hipEventRecord(c->ev_upload, us));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+    }
+  }
+  auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
+  if ((rc = o_path.init(c, S_HMM_PATH + so, (uint16_t*)nullptr, 0)) || (rc = o_plen.init(c, S_HMM_PLEN + so, (uint32_t*)nullptr, 0))) return rc;
+  {
+    void* d = nullptr;
+    if ((rc = dev_get(c, S_HMM_SPANS + so, (size_t)span_total * 12 + 16, &d))) return rc;
+    o_spans.user = spans3; o_spans.dev = (int32_t*)d; o_spans.count = 0; o_spans.staged = false;  // copied back packed (hmm_collect)
+  }
+  if ((rc = o_nsp.init(c, S_HMM_NSP + so, n_spans, (size_t)n_slots)) || (rc = o_cnt.init(c, S_HMM_CNT + so, motif_counts, (size_t)count_total)) ||
+      (rc = o_pur.init(c, S_HMM_PUR + so, purity, (size_t)n_slots)) || (rc = o_edit.init(c, S_HMM_EDIT + so, (int32_t*)nullptr, 0)) ||
+      (rc = o_maxd.init(c, S_HMM_MAXD + so, (int32_t*)nullptr, 0)))
+    return rc;
+  if (o_cnt.staged) { P->cnt_user = motif_counts; P->cnt_total = count_total; o_cnt.staged = false; }
+  // slots that are no candidates at all (loci left to the host path) hold "no allele" too
+  TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
+  for (int k = 0; k < 8; ++k) {
+    if (!class_n[k]) continue;
+    HmmResolveArgs ra{d_cand + class_begin[k], class_n[k], in.d_skip, in.d_n_alleles, in.d_allele_len, d_list + class_begin[k], d_count + k, o_nsp.dev, o_pur.dev};
+    hipLaunchKernelGGL(hmm_resolve_kernel, dim3(1), dim3(1024), 0, c->stream, ra);
+  }
+  TRGT_HIP_TRY(c, hipGetLastError());
+  int n_class = 0;
+  bool forked = false;
+  unsigned side_used = 0;
+  for (uint32_t k = 0; k < 8; ++k) {
+    if (!class_n[k]) continue;
+    uint32_t maxS = 0, maxnb = 0;
+    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) { const HmmSetDev& sd = sets[cand[i].set]; maxS = std::max(maxS, sd.S); maxnb = std::max(maxnb, sd.n_blocks); }
+    const bool half = k == 0;
+    const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
+    const size_t lds = half ? 2 * lds_job : lds_job;
+    if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
+    const void* kfn = half ? (const void*)hmm_viterbi_kernel<32> : (const void*)hmm_viterbi_kernel<64>;
+    if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipStream_t ls = c->stream;
+    if (n_class > 0) {
+      const int sidx = (n_class - 1) % 3;
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->hmm_side[sidx], hipStreamNonBlocking));
+      if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
+      if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
+      if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }
+      ls = c->hmm_side[sidx];
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork, 0));
+      side_used |= 1u << sidx;
+    }
+    ++n_class;
+    KTimer t(c, TRGT_K_HMM, ls);
+    const uint32_t nj = class_n[k];
+    const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * k);
+#define TRGT_HMM_LAUNCH(SB)                                                                                                      \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<SB>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
+                       (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)(d_count + k))
+    if (half) TRGT_HMM_LAUNCH(32); else TRGT_HMM_LAUNCH(64);
+#undef TRGT_HMM_LAUNCH
+    TRGT_HIP_TRY(c, hipGetLastError());
+    t.stop(0);
+  }
+  for (int sidx = 0; sidx < 3; ++sidx)
+    if (side_used & (1u << sidx)) {
+      TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
+    }
+  *out_pending = P.release();
+  return TRGT_OK;
+}
+
+int64_t trgt::hmm_slots_resolved(trgt_hip_ctx* c, HmmPending* P, const HmmModels* mp, const uint8_t* skip, const int32_t* n_alleles, const uint32_t* allele_len) {
+  if (!P) return 0;
+  int64_t jobs = 0, cells = 0;
+  P->cnt_off.clear(); P->cnt_n.clear();
+  for (int64_t sl = 0; sl < P->n_jobs; ++sl) {
+    const int64_t l = sl >> 1;
+    if (skip[l] || (int32_t)(sl & 1) >= n_alleles[l]) continue;
+    P->cnt_off.push_back(P->slot_cnt_off[(size_t)sl]); P->cnt_n.push_back(P->slot_nm[(size_t)sl]);
+    cells += (int64_t)mp->sets[(size_t)l].S * ((int64_t)allele_len[sl] + 2);
+    ++jobs;
+  }
+  if (c->timing) c->k_cells[TRGT_K_HMM] += cells;
+  return jobs;
 }
 
 int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
@@ -1027,6 +1445,29 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   if (!h_cnt.empty())
     for (size_t j = 0; j < P->cnt_off.size(); ++j)
       std::memcpy(P->cnt_user + P->cnt_off[j], h_cnt.data() + P->cnt_off[j], (size_t)P->cnt_n[j] * 4);
+  return TRGT_OK;
+}
+
+// Developer / test entry: builds the models of the motif sets both ways -- on the device (what every other entry point uses) and with
+// the host builder -- and counts the bytes in which the set descriptors and the table blobs differ (0 expected).
+extern "C" int trgt_hmm_models_check(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
+                                     const uint32_t* set_motif_begin, int64_t* n_diff) {
+  if (!c || !n_diff) return TRGT_ERR_INVALID;
+  *n_diff = -1;
+  HmmModels dev, host;
+  int rc = hmm_models_on_device(c, n_sets, motif_blob, motif_off, set_motif_begin, dev, c->stream, nullptr);
+  if (rc) return fail(c, rc, "%s", dev.err.empty() ? trgt_hip_last_error(c) : dev.err.c_str());
+  rc = hmm_build_models(n_sets, motif_blob, motif_off, set_motif_begin, host);
+  if (rc) return fail(c, rc, "%s", host.err.c_str());
+  std::vector<uint8_t> got((size_t)dev.blob_bytes);
+  if (dev.blob_bytes) TRGT_HIP_TRY(c, hipMemcpyAsync(got.data(), dev.d_blob, (size_t)dev.blob_bytes, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int64_t diff = dev.blob_bytes > host.blob.size() ? (int64_t)(dev.blob_bytes - host.blob.size()) : (int64_t)(host.blob.size() - dev.blob_bytes);
+  const size_t n = std::min((size_t)dev.blob_bytes, host.blob.size());
+  for (size_t i = 0; i < n; ++i) diff += got[i] != host.blob[i];
+  const uint8_t *a = (const uint8_t*)dev.sets.data(), *b = (const uint8_t*)host.sets.data();
+  for (size_t i = 0; i < sizeof(HmmSetDev) * (size_t)n_sets; ++i) diff += a[i] != b[i];
+  *n_diff = diff;
   return TRGT_OK;
 }
 

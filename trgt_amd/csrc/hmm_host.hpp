@@ -24,9 +24,14 @@ struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
 
 struct HmmModels {
   std::vector<HmmSetDev> sets; std::vector<uint8_t> blob; int rc = 0; std::string err;
-  const void* d_sets = nullptr; const void* d_blob = nullptr;  // optional device copies made ahead of time by the caller
+  const void* d_sets = nullptr; const void* d_blob = nullptr;  // device copies (hmm_models_on_device builds the blob there: `blob` stays empty)
+  uint64_t blob_bytes = 0;
 };
 
+// built on the device; uploads and kernel on `up`, `done` (optional) recorded behind them
+int hmm_models_on_device(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin,
+                         HmmModels& out, hipStream_t up, hipEvent_t done);
+// host builder (what trgt_hmm_models_check compares the device builder with)
 int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin, HmmModels& out);
 
 int hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
@@ -45,6 +50,23 @@ int hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const
                 int32_t* spans3, const uint64_t* span_off, uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off,
                 double* purity, int32_t* edit_dist, int32_t* max_dist, HmmPending** pending, int buffer_set = 0);
 int hmm_collect(trgt_hip_ctx* c, HmmPending* pending);
+// Stage C enqueued BEHIND a device-side genotyper, before the host has its results: two candidate jobs per locus (allele slots 2 l,
+// 2 l + 1), resolved into the job list on the device from the genotyper's outputs.  Results land at the slot's index of the caller's
+// arrays (n_spans, purity: 2 n_loci entries; spans3 / motif_counts by span_off / count_off of the slot).
+struct HmmSlots {
+  int64_t n_loci = 0;
+  const uint8_t* host_skip = nullptr;      // host [n_loci], optional: 1 = the locus never gets a job here (it takes the host path)
+  const uint32_t* cap = nullptr;           // host [n_loci]   longest allele the locus can have (workspace is set aside for it)
+  const uint64_t* seq_off = nullptr;       // host [2 n_loci] where the allele of a slot will be in seq_blob_dev
+  const uint8_t* seq_blob_dev = nullptr;   // device
+  const uint8_t* d_skip = nullptr; const int32_t* d_n_alleles = nullptr; const uint32_t* d_allele_len = nullptr;  // device: genotyper results
+};
+int hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* models, const HmmSlots& slots, int32_t* spans3, const uint64_t* span_off,
+                      uint32_t* n_spans, uint32_t* motif_counts, const uint64_t* count_off, double* purity, HmmPending** pending,
+                      int buffer_set = 0);
+// ... and once the host has the genotyper's results (the same arrays, host copies): which slots were jobs.  Returns their number.
+int64_t hmm_slots_resolved(trgt_hip_ctx* c, HmmPending* pending, const HmmModels* models, const uint8_t* skip, const int32_t* n_alleles,
+                           const uint32_t* allele_len);
 void hmm_pending_free(HmmPending* pending);
 
 }  // namespace trgt

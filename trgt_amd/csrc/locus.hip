@@ -316,10 +316,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // They are uploaded from the same thread (second stream), so stage C finds them in HBM.
   // (the thread touches nothing of the context: its result and error live in `models`; the upload happens on this thread, below,
   //  once stage A is on the GPU)
-  HmmModels models;
+  HmmModels models;  // the motif-HMM tables depend only on the catalog: built on the device, behind stage A's launches (below)
   const hipStream_t upload_stream = c->stream2;  // (the "second stream" of this call, whichever of the two is current later on)
-  std::thread model_thread([&]() { (void)hmm_build_models((int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models); });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } model_joiner{model_thread};
   HmmPending *hmm_pending = nullptr, *hmm_pending2 = nullptr;
   struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending}, pend_guard2{hmm_pending2};
   std::vector<uint32_t> js2, sl2, ns2; std::vector<uint64_t> so2, spo2, co2; std::vector<double> pu2; std::vector<int64_t> slot2;  // stage C, host-path loci
@@ -426,7 +424,6 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   }
   c->dbg_ns[1] = now_ns() - t0;  // + uploads of the offset tables, buffer (re)allocation
   TL("tables uploaded, buffers ready");
-  if ((rc = issue_pending_uploads(c))) return rc;  // the next batch's bytes: behind this call's tables, next to stage A
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;
   hipEvent_t evA = nullptr;
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
@@ -465,16 +462,32 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   TL("stage A enqueued");
   init_outputs();  // host-only work: done while the GPU is already busy
   const int64_t tw_a = now_ns();  // from here on the host waits for stage A (the table upload below sits behind it in the copy queue)
-  // the motif-HMM tables: built meanwhile on the model thread, uploaded from here on the second stream (stage C finds them in HBM)
-  if (model_thread.joinable()) model_thread.join();
-  if (models.rc == 0 && !models.sets.empty()) {
-    void *d_sets = nullptr, *d_blob = nullptr;
-    if ((rc = dev_get(c, S_HMM_DESC, models.sets.size() * sizeof(HmmSetDev), &d_sets)) || (rc = dev_get(c, S_HMM_MODEL, models.blob.size(), &d_blob))) return rc;
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, models.sets.data(), models.sets.size() * sizeof(HmmSetDev), hipMemcpyHostToDevice, c->stream2));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_blob, models.blob.data(), models.blob.size(), hipMemcpyHostToDevice, c->stream2));
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));
-    models.d_sets = d_sets; models.d_blob = d_blob;
+  // the motif-HMM tables: built on the device (one small upload and one kernel on the copy stream, which has nothing in front of it:
+  // the second stream may be busy with the heavy flank alignments for milliseconds, and the copy engine serves the streams' copies in
+  // the order they were issued)
+  if (!c->stream_copy) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+  if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+  if ((rc = hmm_models_on_device(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models, c->stream_copy, c->ev_upload)))
+    return models.err.empty() ? rc : fail(c, rc, "%s", models.err.c_str());
+  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
+  TL("models uploaded");
+  // ---------------- stage C of the device-genotyped loci: enqueued right here, behind the genotyper and before the host has seen
+  // its results -- the job list is resolved on the device (hmm_enqueue_slots), so the HMM kernels start the moment stage A ends
+  // instead of after a host round trip (event wait, job lists, uploads: 0.8 ms of a 10k-locus call, 2.6 ms with mixed model sizes)
+  const bool use_slots = dev_gt && models.rc == 0 && models.d_sets && !is_device_ptr(out->spans3) && !c->knobs.host_hmm_lists;
+  std::vector<uint8_t> slot_skip;
+  if (use_slots) {
+    HmmSlots hs;
+    hs.n_loci = nl; hs.cap = out->allele_cap; hs.seq_off = out->allele_off; hs.seq_blob_dev = (const uint8_t*)g.blob;
+    hs.d_skip = (const uint8_t*)g.need; hs.d_n_alleles = (const int32_t*)g.nal; hs.d_allele_len = (const uint32_t*)g.alen;
+    if (in->genotyper) { slot_skip.assign(in->genotyper, in->genotyper + nl); for (auto& v : slot_skip) v = v == 1; hs.host_skip = slot_skip.data(); }
+    const int64_t tc0 = now_ns();
+    if ((rc = hmm_enqueue_slots(c, &models, hs, out->spans3, out->span_off, out->n_spans, out->motif_counts, out->count_off, out->purity, &hmm_pending))) return rc;
+    tC += now_ns() - tc0;
+    TL("hmm1 enqueued (device-resolved job list)");
   }
+  if ((rc = issue_pending_uploads(c))) return rc;  // the next batch's bytes: behind this call's tables and models, next to stage A
 
   // ---------------- wait for the GPU, publish spans
   {
@@ -501,7 +514,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // event wait returns block until the runtime has retired stage A's commands
   std::vector<uint32_t> job_set, seq_len; std::vector<uint64_t> seq_off, span_off, count_off; std::vector<int64_t> slot;
   std::vector<uint32_t> nsp; std::vector<double> pur;
-  if (dev_gt) {
+  if (dev_gt && use_slots) {
+    for (int64_t l = 0; l < nl; ++l) if (!((const uint8_t*)gh.need)[l]) stat_spanning += ((const uint32_t*)gh.nspan)[l];
+    stat_hmm_jobs += hmm_slots_resolved(c, hmm_pending, &models, (const uint8_t*)gh.need, (const int32_t*)gh.nal, (const uint32_t*)gh.alen);
+  } else if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
     const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
     job_set.reserve(2 * (size_t)nl); seq_off.reserve(2 * (size_t)nl); seq_len.reserve(2 * (size_t)nl); span_off.reserve(2 * (size_t)nl);
@@ -573,7 +589,6 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       if (!pj_set.empty()) {
         pj_nsp.resize(pj_set.size()); pj_pur.resize(pj_set.size());
         std::vector<uint32_t> pj_counts((size_t)cnt_total + 1);
-        if (model_thread.joinable()) model_thread.join();
         rc = hmm_batch_impl(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)pj_set.size(), pj_set.data(),
                             reads_on_device ? d_reads : in->read_blob, pj_off.data(), pj_len.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
                             pj_nsp.data(), pj_counts.data(), pj_cnt_off.data(), pj_pur.data(), nullptr, nullptr);
@@ -646,10 +661,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // right here when there are none.
   bool published = false;
   auto hmm1_enqueue = [&]() -> int {
-  if (dev_gt) {
+  if (dev_gt && !use_slots) {
     if (!job_set.empty()) {
       nsp.resize(job_set.size()); pur.resize(job_set.size());
-      if (model_thread.joinable()) model_thread.join();
       const int64_t tc0 = now_ns();
       rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)job_set.size(), job_set.data(),
                        (const uint8_t*)g.blob, seq_off.data(), seq_len.data(), nullptr, nullptr, nullptr, out->spans3, span_off.data(), nsp.data(),
@@ -877,7 +891,6 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     }
     if (!js2.empty()) {
       ns2.resize(js2.size()); pu2.resize(js2.size());
-      if (model_thread.joinable()) model_thread.join();
       rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)js2.size(), js2.data(),
                        out->allele_blob, so2.data(), sl2.data(), nullptr, nullptr, nullptr, out->spans3, spo2.data(), ns2.data(),
                        out->motif_counts, co2.data(), pu2.data(), nullptr, nullptr, &hmm_pending2, hmm_pending ? 1 : 0);
@@ -896,6 +909,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     rc = hmm_collect(c, pend);
     if (rc) return rc;
     TL("hmm1 collected");
+    if (use_slots) {  // (the whole arrays came back: the slots of the loci that took the host path hold "no allele" until stage C of those)
+      const uint8_t* need = (const uint8_t*)gh.need;
+      for (int64_t l = 0; l < nl; ++l) if (need[l]) { out->n_spans[2 * l] = out->n_spans[2 * l + 1] = 0; out->purity[2 * l] = out->purity[2 * l + 1] = std::nan(""); }
+    }
     for (size_t j = 0; j < slot.size(); ++j) { out->n_spans[slot[j]] = nsp[j]; out->purity[slot[j]] = pur[j]; }
     tC += now_ns() - tc0;
   }

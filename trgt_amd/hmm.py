@@ -97,6 +97,16 @@ def pack_hmm_batch(motif_sets, jobs):
                 n_motifs=nm.astype(np.int64))
 
 
+def models_check(motif_sets, ctx=None):
+    """Bytes in which the device-built model tables differ from the host builder's (0 expected)."""
+    ctx = ctx or _lib.context()
+    b = pack_hmm_batch(motif_sets, [])
+    n = C.c_int64(-1)
+    p = _lib.ptr
+    ctx.check(_lib.lib().trgt_hmm_models_check(ctx.handle, len(motif_sets), p(b["motif_blob"]), p(b["motif_off"]), p(b["set_motif_begin"]), C.byref(n)))
+    return int(n.value)
+
+
 def hmm_batch(batch, ctx=None, want_path=True, seq_blob_dev=None):
     """Run trgt_hmm_batch.  seq_blob_dev: optional torch uint8 tensor already resident in HBM."""
     ctx = ctx or _lib.context()
