@@ -155,10 +155,15 @@ int trgt_find_spans_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t 
  *   keep[j]         1 iff match_bound >= min_matches, or the job was not judged (pattern longer than 254, text shorter than the
  *                   pattern or longer than the kernel's diagonals, sequence bytes 0x01 / 0x02 / 0xFF): only kept jobs need the
  *                   back-trace -- for the others count_matches() < min_matches is certain
- *   offsets_computed  (one value) wavefront offsets computed, equal to WFA2-lib's count for the judged jobs */
+ *   offsets_computed  (one value) wavefront offsets computed, equal to WFA2-lib's count for the judged jobs
+ * early_reject != 0 (what trgt_find_spans_batch uses): an alignment is given up at the first score level (checked every 16th)
+ * at which no cell of its wavefronts can end in min_matches matches any more -- matched so far + pattern bases left < min_matches
+ * for all of them, a number no alignment step raises -- so count_matches() < min_matches is certain whatever the optimal
+ * alignment turns out to be.  Such a job gets keep 0, score INT32_MIN + 1 (not computed), match_bound min_matches - 1, and
+ * offsets_computed counts only the levels that were computed. */
 int trgt_flank_filter_batch(trgt_hip_ctx* ctx, const trgt_span_params* p, int64_t n_jobs,
                             const uint8_t* seqs, const uint64_t* pat_off, const uint32_t* pat_len,
-                            const uint64_t* txt_off, const uint32_t* txt_len, int32_t min_matches,
+                            const uint64_t* txt_off, const uint32_t* txt_len, int32_t min_matches, int32_t early_reject,
                             int32_t* score, int32_t* match_bound, uint8_t* keep, int64_t* offsets_computed);
 
 /* ------------------------------------------------------------------ HMM */

@@ -135,3 +135,31 @@ def test_filter_on_synthetic_batch_decisions(oracle):
     r, ref = _check(oracle, pats, txts)
     exact_keep = sum(1 for o in ref if o["n_match"] >= 175)
     assert int(r["keep"].sum()) <= exact_keep + max(3, len(pats) // 20)   # the bound is tight where it matters
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_early_rejection_never_drops_an_accepted_alignment(oracle, seed):
+    # with early_reject the kernel stops an alignment once no wavefront cell can still reach min_matches: exact rejections (the
+    # reference's count_matches is below the threshold for every one of them), exact scores for all the others, fewer offsets
+    from trgt_amd.wfaligner import flank_filter_batch
+    rng = np.random.default_rng(seed)
+    pats, txts = _flank_jobs(rng, 200)
+    ref = _oracle(oracle, pats, txts)
+    full = flank_filter_batch(pats, txts, 175)
+    for mm in (175, 100, 240, 0):
+        r = flank_filter_batch(pats, txts, mm, early_reject=True)
+        n_early = 0
+        for j, o in enumerate(ref):
+            if int(r["score"][j]) == -2**31 + 1:
+                n_early += 1
+                assert int(r["keep"][j]) == 0 and o["n_match"] < mm, (j, o["n_match"], mm)
+            else:
+                assert int(r["score"][j]) == o["score"] and int(r["bound"][j]) >= o["n_match"]
+                assert int(r["keep"][j]) == (1 if int(r["bound"][j]) >= mm else 0)
+            if o["n_match"] >= mm:
+                assert int(r["keep"][j]) == 1
+        assert r["offsets"] <= full["offsets"]
+        if mm == 175:
+            assert n_early > 0 and r["offsets"] < full["offsets"]
+        if mm == 0:
+            assert n_early == 0 and r["offsets"] == full["offsets"]

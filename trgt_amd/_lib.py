@@ -118,7 +118,7 @@ def lib():
         L.trgt_hmm_batch.argtypes = [_VP, C.c_int32, _VP, _VP, _VP, C.c_int64] + [_VP] * 15
         L.trgt_hmm_models_check.argtypes = [_VP, C.c_int32, _VP, _VP, _VP, _VP]
         L.trgt_wfa_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 15
-        L.trgt_flank_filter_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 5 + [C.c_int32] + [_VP] * 4
+        L.trgt_flank_filter_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 5 + [C.c_int32, C.c_int32] + [_VP] * 4
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
         L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
         L.trgt_locus_batch_submit.argtypes = [_VP, _VP, _VP, _VP, C.POINTER(C.c_int64)]

@@ -473,7 +473,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       FilterLaunch FL;
       FL.jobs_dev = (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs; FL.n_jobs_dev = (const uint32_t*)d_count;
       FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
-      FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
+      FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
       if ((rc = flank_filter_launch(c, FL))) return rc;
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + 6;
     }

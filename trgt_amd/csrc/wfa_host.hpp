@@ -48,6 +48,7 @@ struct FilterArgs {  // by-value kernel argument
   const uint8_t* pat_base; const uint8_t* txt_base;
   unsigned int* counter;
   int32_t min_matches;                      // an alignment is kept iff its match bound >= min_matches (or it could not be judged)
+  int32_t early_reject;                     // stop an alignment as soon as no cell of its wavefronts can reach min_matches any more
   JobDev* keep_jobs; uint32_t* keep_count;  // kept alignments, appended (NULL: none wanted)
   int32_t* score; int32_t* bound; uint8_t* keep;  // optional, indexed by JobDev::out_index
   unsigned long long* cells_out;
@@ -57,6 +58,7 @@ struct FilterLaunch {
   const uint8_t* pat_base = nullptr; const uint8_t* txt_base = nullptr;
   int64_t max_plen = 0, max_tlen = 0;
   int32_t min_matches = 0;
+  bool early_reject = false;  // see FilterArgs (then: score INT32_MIN + 1, bound min_matches - 1 for the alignments stopped early)
   JobDev* keep_jobs = nullptr; uint32_t* keep_count = nullptr;
   int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;
   bool count_offsets = false;  // also count the wavefront offsets (a little slower: one more scalar walk per level)

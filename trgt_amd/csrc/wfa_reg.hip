@@ -57,6 +57,18 @@ __device__ __forceinline__ uint32_t rpk_max(uint32_t a, uint32_t b) {
   x.u = a; y.u = b; r.v = __builtin_elementwise_max(x.v, y.v);
   return r.u;
 }
+__device__ __forceinline__ uint32_t rpk_add_sat(uint32_t a, uint32_t b) {  // v_pk_add_u16 ... clamp
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  union U { uint32_t u; us2 v; } x, y, r;
+  x.u = a; y.u = b; r.v = __builtin_elementwise_add_sat(x.v, y.v);
+  return r.u;
+}
+__device__ __forceinline__ uint32_t rpk_sub(uint32_t a, uint32_t b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  union U { uint32_t u; us2 v; } x, y, r;
+  x.u = a; y.u = b; r.v = x.v - y.v;
+  return r.u;
+}
 __device__ __forceinline__ uint32_t rpk_add(uint32_t a, uint32_t b) {
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   union U { uint32_t u; us2 v; } x, y, r;
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(
       mlo[0] = 0; mhi[0] = tlen;
       unsigned long long cells = (unsigned long long)tlen + 1ull;
       int s = 0, num_null = 0;
-      bool done = false, bail = false;
+      bool done = false, bail = false, early = false;
       for (;;) {
         // ---- termination (wavefront_termination_endsfree with pattern_end_free = 0, text_end_free = tlen): v == plen
         const bool tA = ((tmax >> 8) & 0xFFu) == (uint32_t)term_v, tB = (tmax >> 24) == (uint32_t)term_v;
@@ -388,9 +400,43 @@ __global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(
 #pragma unroll
         for (int d = 5; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
         mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
+        // ---- early rejection (every 16th level).  A cell (v bases of the pattern consumed, at most c of them matched, text position
+        //      h = v + k) can end in an alignment of at most c + min(plen - v, tlen - h) matches -- a match needs a base of both -- and
+        //      no step raises that number: a match raises c, v and h together, a mismatch v and h, a deleted base v, an inserted base h.
+        //      Every alignment that ends beyond this level continues from a cell of the last six M levels or of the current I / D: if
+        //      none of them can still reach min_matches, the optimal alignment -- whichever it is -- has fewer matches than the caller
+        //      asks for, and the remaining levels (the widest ones: the work of a level grows with the score) need not be computed.
+        //      Per 16-bit cell: deficit = (v - c) + max(0, k - (tlen - plen)), 0xFFFF for NULL; at most plen - min_matches to go on.
+        if (a.early_reject && (s & 15) == 0) {
+          uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const bool top = t * SW + SW - 1 > tlen;  // (uniform) diagonals above tlen - plen: the text ends before the pattern does
+#pragma unroll
+            for (int jj = 0; jj < B; ++jj) {
+              const int p = t * B + jj;
+              uint32_t dm = 0xFFFFFFFFu;
+              auto take = [&](uint32_t x) {
+                const uint32_t cnt = x & 0x00FF00FFu, v1 = (x >> 8) & 0x00FF00FFu;
+                dm = rpk_min(dm, rpk_sub(rpk_sub(v1, cnt), 0x00010001u));
+              };
+#pragma unroll
+              for (int d = 0; d < 6; ++d) take(Mr[d][p]);
+              take(Ir[p]); take(Dr[p]);
+              if (top) {
+                const int over = t * SW + 2 * jj + lane_kb - tlen;  // biased diagonal of the low half, minus tlen
+                dm = rpk_add_sat(dm, (uint32_t)min(max(over, 0), 0x7FFF) | ((uint32_t)min(max(over + 1, 0), 0x7FFF) << 16));
+              }
+              dmin = rpk_min(dmin, dm);
+            }
+          }
+          const uint32_t best = min(dmin & 0xFFFFu, dmin >> 16);  // the smallest deficit of this lane's cells
+          if (!__builtin_amdgcn_ballot_w64((int)best <= plen - a.min_matches)) { early = true; break; }
+        }
       }
       cells_acc += cells;
-      if (bail || !done) keep = 1;
+      if (early) { keep = 0; score_out = INT32_MIN + 1; bound_out = a.min_matches - 1; }
+      else if (bail || !done) keep = 1;
       else {
         // the first terminating diagonal (wavefront_extend walks k upwards and stops at the first one)
         int best = 1 << 20; uint32_t best_reg = 0;
@@ -441,7 +487,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   std::memset(&a, 0, sizeof a);
   a.jobs = L.jobs_dev; a.n_jobs_dev = L.n_jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host;
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
-  a.min_matches = L.min_matches;
+  a.min_matches = L.min_matches; a.early_reject = L.early_reject ? 1 : 0;
   a.keep_jobs = L.keep_jobs; a.keep_count = L.keep_count;
   a.score = L.score; a.bound = L.bound; a.keep = L.keep;
   void* d_counter = nullptr; void* d_cells = nullptr;
@@ -482,8 +528,8 @@ using namespace trgt;
 
 extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* p, int64_t n_jobs, const uint8_t* seqs,
                                        const uint64_t* pat_off, const uint32_t* pat_len, const uint64_t* txt_off,
-                                       const uint32_t* txt_len, int32_t min_matches, int32_t* score, int32_t* match_bound,
-                                       uint8_t* keep, int64_t* offsets_computed) {
+                                       const uint32_t* txt_len, int32_t min_matches, int32_t early_reject, int32_t* score,
+                                       int32_t* match_bound, uint8_t* keep, int64_t* offsets_computed) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_flank_filter_batch: null argument");
@@ -519,7 +565,7 @@ extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* 
     return rc;
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.pat_base = d_seq; L.txt_base = d_seq;
   L.count_offsets = offsets_computed != nullptr || c->timing;
-  L.min_matches = min_matches; L.score = o_score.dev; L.bound = o_bound.dev; L.keep = o_keep.dev;
+  L.min_matches = min_matches; L.early_reject = early_reject != 0; L.score = o_score.dev; L.bound = o_bound.dev; L.keep = o_keep.dev;
   if ((rc = flank_filter_launch(c, L))) return rc;
   if ((rc = o_score.finish(c)) || (rc = o_bound.finish(c)) || (rc = o_keep.finish(c))) return rc;
   unsigned long long cells = 0;

@@ -362,10 +362,11 @@ class WFAligner:
         return "".join(out)
 
 
-def flank_filter_batch(patterns, texts, min_matches, scoring=(2, 5, 1), ctx=None):
+def flank_filter_batch(patterns, texts, min_matches, scoring=(2, 5, 1), ctx=None, early_reject=False):
     """trgt_flank_filter_batch: the pre-filter trgt_find_spans_batch runs in front of the back-tracing kernel
     (span_locater.rs:14-22).  Per job: the exact optimal score of align_ends_free(pattern, 0, 0, text, |text|, |text|),
     an upper bound on count_matches() of the reference's alignment, keep = bound >= min_matches (or "not judged").
+    early_reject: give an alignment up once no cell of its wavefronts can reach min_matches (score INT32_MIN + 1 then).
     Returns dict(score, bound, keep, offsets)."""
     ctx = ctx or _lib.context()
     n = len(patterns)
@@ -389,5 +390,5 @@ def flank_filter_batch(patterns, texts, min_matches, scoring=(2, 5, 1), ctx=None
     offsets = C.c_int64(0)
     q = _lib.ptr
     ctx.check(_lib.lib().trgt_flank_filter_batch(ctx.handle, C.byref(sp), n, q(seqs), q(pat_off), q(plen), q(txt_off), q(tlen),
-                                                 int(min_matches), q(score), q(bound), q(keep), C.byref(offsets)))
+                                                 int(min_matches), 1 if early_reject else 0, q(score), q(bound), q(keep), C.byref(offsets)))
     return dict(score=score, bound=bound, keep=keep, offsets=offsets.value)
