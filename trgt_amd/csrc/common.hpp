@@ -133,6 +133,7 @@ enum Slot {
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED,
   S_HMM_BUILD,  // inputs of the device-side model builder (one slab)
+  S_VOTE_GROUPS, S_VOTE_SCRATCH, S_VOTE_OUT, S_VOTE_LEN,  // consensus column voting (consensus_vote.hpp)
   S_COUNT
 };
 // pinned host buffer slots

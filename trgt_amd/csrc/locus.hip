@@ -167,41 +167,58 @@ void genotype_size_front(int ploidy, int64_t locus, int thread, LocusWork& w, Sc
   }
 }
 
-// repair_consensus (consensus.rs:5-111); cigars[m] = run-length CIGAR (len<<4|code) of member m vs the backbone
-std::string repair_consensus(const std::string& backbone, const std::vector<Seg>& seqs, const std::vector<std::vector<uint32_t>>& cigars) {
-  const size_t L = backbone.size(), n = seqs.size();
-  std::vector<std::array<int, 5>> votes(L, std::array<int, 5>{0, 0, 0, 0, 0});
-  std::vector<std::vector<std::string>> inserts(L + 1);
-  for (size_t m = 0; m < n; ++m) {
-    size_t x = 0, y = 0;
-    for (uint32_t e : cigars[m]) {
-      const size_t len = e >> 4; const uint32_t code = e & 0xF;
-      if (code == 7 || code == 8 || code == 0) {
-        for (size_t i = 0; i < len; ++i) {
-          const uint8_t b = seqs[m].p[x + i];
-          const int bi = b == 'A' ? 0 : b == 'T' ? 1 : b == 'C' ? 2 : 3;
-          votes[y + i][bi] += 1;
-        }
-        x += len; y += len;
-      } else if (code == 2) { for (size_t i = 0; i < len; ++i) votes[y + i][4] += 1; y += len; }
-      else if (code == 1) { inserts[y].emplace_back((const char*)seqs[m].p + x, len); x += len; }
-    }
+#include "consensus_vote.hpp"
+
+// make_consensus / repair_consensus (consensus.rs:5-111) for a batch of groups: the members of group g are jobs [first[g], first[g + 1])
+// of ONE alignment batch (BiWFA, gap-affine 2,5,1, default heuristic: THREAD_WFA_CONSENSUS, genotype.rs:82-86), each against the
+// group's backbone (the pattern of its jobs).  The run-length CIGARs stay in HBM; the column voting runs there too
+// (consensus_vote_kernel) and only the consensus sequences come back.  results[g] = repaired sequence of group g.
+int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs, const uint64_t* po, const uint32_t* pl, const uint64_t* to,
+                           const uint32_t* tl, const std::vector<size_t>& first, std::vector<std::string>& results,
+                           const std::function<int()>* while_running = nullptr) {
+  const size_t n_groups = first.empty() ? 0 : first.size() - 1;
+  results.assign(n_groups, std::string());
+  if (n_jobs == 0 || n_groups == 0) { if (while_running && *while_running) return (*while_running)(); return TRGT_OK; }
+  trgt_wfa_params wp;
+  trgt_wfa_default_params(&wp);
+  wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+  WfaOnDevice dev;
+  int rc = wfa_batch_impl(c, &wp, n_jobs, seqs, po, pl, to, tl, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, while_running, &dev);
+  if (rc) return rc;
+  std::vector<vote::Group> groups(n_groups);
+  uint64_t out_total = 0, scratch_words = 0;
+  for (size_t g = 0; g < n_groups; ++g) {
+    vote::Group& G = groups[g];
+    const size_t j0 = first[g], j1 = first[g + 1];
+    G.job_first = (uint32_t)j0; G.n_members = (uint32_t)(j1 - j0);
+    G.bb_len = j1 > j0 ? pl[j0] : 0; G.bb_off = j1 > j0 ? po[j0] : 0;
+    uint64_t member_bytes = 0;
+    for (size_t j = j0; j < j1; ++j) member_bytes += tl[j];
+    // at most one base per backbone position plus the insertions taken, each of which is a piece of some member
+    G.out_cap = (uint32_t)std::min<uint64_t>((uint64_t)G.bb_len + member_bytes + 16, 0xFFFFFFF0ull);
+    G.out_off = out_total; out_total += ((uint64_t)G.out_cap + 15) & ~15ull;
+    G.scratch_off = scratch_words;
+    scratch_words += (G.bb_len + 1 <= (uint32_t)vote::VOTE_LDS_POS + 1 ? 0 : 3 * ((uint64_t)G.bb_len + 1)) + 3 * (uint64_t)G.n_members;
   }
-  std::string out;
-  for (size_t pos = 0; pos < L; ++pos) {
-    int best = 0;
-    for (int i = 1; i < 5; ++i) if (votes[pos][i] >= votes[pos][best]) best = i;  // max_by_key: last maximum
-    if (inserts[pos].size() > n / 2) {
-      auto& ins = inserts[pos];
-      std::sort(ins.begin(), ins.end());
-      const size_t without = n - ins.size();
-      size_t top_count = 0; const std::string* top = nullptr;
-      for (size_t i = 0; i < ins.size();) { size_t j = i; while (j < ins.size() && ins[j] == ins[i]) ++j; if (j - i > top_count) { top_count = j - i; top = &ins[i]; } i = j; }
-      if (top_count > without) out += *top;
-    }
-    if (best != 4) out.push_back("ATCG"[best]);
+  void *d_groups = nullptr, *d_scratch = nullptr, *d_out = nullptr, *d_len = nullptr;
+  if ((rc = dev_get(c, S_VOTE_GROUPS, n_groups * sizeof(vote::Group), &d_groups)) || (rc = dev_get(c, S_VOTE_SCRATCH, (size_t)scratch_words * 4 + 16, &d_scratch)) ||
+      (rc = dev_get(c, S_VOTE_OUT, (size_t)out_total + 16, &d_out)) || (rc = dev_get(c, S_VOTE_LEN, n_groups * 4, &d_len)))
+    return rc;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_groups, groups.data(), n_groups * sizeof(vote::Group), hipMemcpyHostToDevice, c->stream));
+  vote::VoteArgs va{(const vote::Group*)d_groups, (uint32_t)n_groups, dev.seqs, dev.jobs, dev.cigar, dev.cigar_len, (uint32_t*)d_scratch, (uint8_t*)d_out, (uint32_t*)d_len};
+  hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)n_groups), dim3(vote::VOTE_THREADS), 0, c->stream, va);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  std::vector<uint32_t> lens(n_groups);
+  std::vector<uint8_t> bytes((size_t)out_total);
+  TRGT_HIP_TRY(c, hipMemcpyAsync(lens.data(), d_len, n_groups * 4, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(bytes.data(), d_out, (size_t)out_total, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (size_t g = 0; g < n_groups; ++g) {
+    if (lens[g] == 0xFFFFFFFFu) return fail(c, TRGT_ERR_UNSUPPORTED, "consensus: repaired sequence of group %zu longer than %u bases", g, groups[g].out_cap);
+    results[g].assign((const char*)bytes.data() + groups[g].out_off, lens[g]);
   }
-  return out;
+  return TRGT_OK;
 }
 
 #include "locus_cluster.hpp"
@@ -788,19 +805,21 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
           jrefs.push_back({&rep, (int)m});
         }
       }
-    PackedCigars pcig;
+    std::vector<size_t> rep_first{0};  // jobs of one repair are contiguous
+    std::vector<Repair*> rep_of;
+    for (size_t j = 0; j < jrefs.size(); ++j)
+      if (jrefs[j].member == 0) { if (j) rep_first.push_back(j); rep_of.push_back(jrefs[j].rep); }
+    if (!jrefs.empty()) rep_first.push_back(jrefs.size());
     if (jrefs.empty() && ((rc = hmm1_once()) || (!published && (rc = publish())))) return rc;
     if (!jrefs.empty()) {
-      trgt_wfa_params wp;
-      trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
-      wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
       const std::function<int()> overlap = [&]() -> int {  // next to the alignment kernel: start the HMM batch, publish results
         const int r = hmm1_once();
         return r ? r : publish();
       };
-      rc = wfa_batch_impl(c, &wp, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pcig, &overlap);
+      std::vector<std::string> repaired;
+      rc = consensus_repair_batch(c, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), rep_first, repaired, &overlap);
       if (rc) return rc;
+      for (size_t g = 0; g < rep_of.size(); ++g) rep_of[g]->result.swap(repaired[g]);
       stat_cons_jobs = (int64_t)jrefs.size();
     }
     // ---- Genotyper::Cluster loci: distance matrix, Ward linkage, consensus rounds, outlier assignment (locus_cluster.hpp)
@@ -814,17 +833,6 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   TL("stageB");
     // ---- host: repair_consensus, classification, reference allele first, output assembly
     th0 = now_ns();
-    {
-      size_t j = 0;
-      while (j < jrefs.size()) {  // jobs of one repair are contiguous
-        Repair* rep = jrefs[j].rep;
-        std::vector<std::vector<uint32_t>> cg;
-        for (size_t m = 0; m < rep->members.size(); ++m, ++j)
-          cg.emplace_back(pcig.data.begin() + (ptrdiff_t)pcig.off[j], pcig.data.begin() + (ptrdiff_t)pcig.off[j + 1]);  // failed alignment -> empty CIGAR
-        const Seg bb = work[(size_t)rep->locus].pick[rep->allele];
-        rep->result = repair_consensus(std::string((const char*)bb.p, bb.n), rep->members, cg);
-      }
-    }
     std::vector<int8_t> seg_cls((size_t)n_seg, 0);
     std::atomic<int> bad{0};
     pool->parallel_for(nR, 64, [&](int64_t li, int) {

@@ -200,30 +200,18 @@ struct ClusterBatch {
       }
       first[t + 1] = po.size();
     }
-    trgt_wfa_params wp;
-    trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
-    wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
-    PackedCigars pc;
-    const int rc = wfa_batch_impl(c, &wp, (int64_t)po.size(), blob.data(), po.data(), pl.data(), to.data(), tl.data(), nullptr, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &pc);
+    std::vector<std::string> repaired;
+    const int rc = consensus_repair_batch(c, (int64_t)po.size(), blob.data(), po.data(), pl.data(), to.data(), tl.data(), first, repaired);
     if (rc) return rc;
     n_cons += (int64_t)po.size();
-    pool->parallel_for((int64_t)todo.size(), 4, [&](int64_t t, int) {
-      ClusterLocus& L = loci[(size_t)todo[(size_t)t].first];
-      const int gi = todo[(size_t)t].second;
-      const std::vector<int>& g = L.group[gi];
-      std::vector<Seg> seqs; std::vector<std::vector<uint32_t>> cg;
+    for (size_t t = 0; t < todo.size(); ++t) {
+      ClusterLocus& L = loci[(size_t)todo[t].first];
+      const int gi = todo[t].second;
       uint32_t lo = 0xFFFFFFFFu, hi = 0;
-      for (size_t m = 0; m < g.size(); ++m) {
-        const size_t j = first[(size_t)t] + m;
-        seqs.push_back(L.trs[g[m]]);
-        cg.emplace_back(pc.data.begin() + (ptrdiff_t)pc.off[j], pc.data.begin() + (ptrdiff_t)pc.off[j + 1]);
-        lo = std::min(lo, L.trs[g[m]].n); hi = std::max(hi, L.trs[g[m]].n);  // get_ci (:229-233)
-      }
-      const Seg bb = L.trs[backbone[(size_t)t]];
-      L.allele[gi] = repair_consensus(std::string((const char*)bb.p, bb.n), seqs, cg);
+      for (int m : L.group[gi]) { lo = std::min(lo, L.trs[m].n); hi = std::max(hi, L.trs[m].n); }  // get_ci (:229-233)
+      L.allele[gi].swap(repaired[t]);
       L.ci[2 * gi] = lo; L.ci[2 * gi + 1] = hi;
-    });
+    }
     return TRGT_OK;
   }
 

@@ -609,7 +609,8 @@ __global__ void cigar_pack_kernel(const uint32_t* __restrict__ cigar, const JobD
 int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
                    const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
                    int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
-                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed, const std::function<int()>* while_running) {
+                   const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed, const std::function<int()>* while_running,
+                   WfaOnDevice* on_device) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_wfa_batch: null argument");
@@ -629,7 +630,7 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
     JobDev& jd = jobs[(size_t)j];
     jd.pat_off = pat_off[j]; jd.txt_off = txt_off[j]; jd.pat_len = pat_len[j]; jd.txt_len = txt_len[j]; jd.out_index = (uint32_t)j;
     jd.cigar_off = cigar ? cigar_off[j] : 0; jd.ops_off = ops ? ops_off[j] : 0;
-    if (packed) { jd.cigar_off = cigar_total; cigar_total += (uint64_t)pat_len[j] + txt_len[j] + 1; }
+    if (packed || on_device) { jd.cigar_off = cigar_total; cigar_total += (uint64_t)pat_len[j] + txt_len[j] + 1; }
     L.max_plen = std::max<int64_t>(L.max_plen, pat_len[j]); L.max_tlen = std::max<int64_t>(L.max_tlen, txt_len[j]);
     L.max_sum = std::max<int64_t>(L.max_sum, (int64_t)pat_len[j] + txt_len[j]);
     seq_total = std::max<uint64_t>(seq_total, std::max(pat_off[j] + pat_len[j], txt_off[j] + txt_len[j]));
@@ -647,18 +648,23 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), hipMemcpyHostToDevice, c->stream));
   DevOut<int32_t> o_status, o_score, o_nm; DevOut<uint32_t> o_span, o_cigar, o_clen, o_olen; DevOut<uint8_t> o_ops;
   std::vector<uint32_t> h_clen;
-  if (packed) {  // device-only CIGAR slots; the lengths come back first
+  if (packed || on_device) {  // device-only CIGAR slots; the lengths come back first (packed) or not at all (on_device)
     void* d = nullptr;
     if ((rc = dev_get(c, S_WFA_CIGAR, (size_t)cigar_total * 4, &d))) return rc;
     o_cigar.dev = (uint32_t*)d;
-    h_clen.resize((size_t)n_jobs);
-    cigar_len = h_clen.data();
+    if (packed) { h_clen.resize((size_t)n_jobs); cigar_len = h_clen.data(); }
   }
   if ((rc = o_status.init(c, S_WFA_STATUS, status, (size_t)n_jobs)) || (rc = o_score.init(c, S_WFA_SCORE, score, (size_t)n_jobs)) ||
       (rc = o_nm.init(c, S_WFA_NMATCH, n_match, (size_t)n_jobs)) || (rc = o_span.init(c, S_WFA_SPAN, span4, (size_t)n_jobs * 4)) ||
-      (!packed && (rc = o_cigar.init(c, S_WFA_CIGAR, cigar, (size_t)cigar_total))) || (rc = o_clen.init(c, S_WFA_CLEN, cigar_len, (size_t)n_jobs)) ||
+      (!packed && !on_device && (rc = o_cigar.init(c, S_WFA_CIGAR, cigar, (size_t)cigar_total))) || (rc = o_clen.init(c, S_WFA_CLEN, cigar_len, (size_t)n_jobs)) ||
       (rc = o_ops.init(c, S_WFA_OPS, ops, (size_t)ops_total)) || (rc = o_olen.init(c, S_WFA_OLEN, ops_len, (size_t)n_jobs)))
     return rc;
+  if (on_device && !o_clen.dev) {  // (no host destination: a device-only array)
+    void* d = nullptr;
+    if ((rc = dev_get(c, S_WFA_CLEN, (size_t)n_jobs * 4, &d))) return rc;
+    o_clen.dev = (uint32_t*)d;
+  }
+  if (on_device) { on_device->jobs = (const JobDev*)d_jobs; on_device->cigar = o_cigar.dev; on_device->cigar_len = o_clen.dev; on_device->seqs = d_seq; }
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.n_jobs_dev = nullptr;
   L.buffer_set = 1;  // trgt_locus_batch runs consensus alignments next to a flank-location launch (set 0) of a later chunk
   L.pat_base = d_seq; L.txt_base = d_seq;

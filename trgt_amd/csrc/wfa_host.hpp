@@ -71,11 +71,15 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L);
 
 // Run-length CIGARs of a whole batch in one dense array: job j = data[off[j] .. off[j + 1]) (len << 4 | code, as cigar_get_CIGAR).
 struct PackedCigars { std::vector<uint32_t> data; std::vector<uint64_t> off; };
+// ... or left in HBM for a kernel of the caller (the consensus column voting): job list, CIGAR slots (job j at cigar[jobs[j].cigar_off ..],
+// cigar_len[jobs[j].out_index] entries) and the sequence blob, valid until the next alignment batch of the context
+struct WfaOnDevice { const JobDev* jobs = nullptr; const uint32_t* cigar = nullptr; const uint32_t* cigar_len = nullptr; const uint8_t* seqs = nullptr; };
 // trgt_wfa_batch with an optional dense CIGAR result (packed != nullptr replaces cigar / cigar_off / cigar_len).
 int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, const uint8_t* seqs, const uint64_t* pat_off,
                    const uint32_t* pat_len, const uint64_t* txt_off, const uint32_t* txt_len, int32_t* status, int32_t* score,
                    int32_t* n_match, uint32_t* span4, uint32_t* cigar, const uint64_t* cigar_off, uint32_t* cigar_len, uint8_t* ops,
                    const uint64_t* ops_off, uint32_t* ops_len, PackedCigars* packed,
-                   const std::function<int()>* while_running = nullptr);  // host work to do between the launch and the wait
+                   const std::function<int()>* while_running = nullptr,  // host work to do between the launch and the wait
+                   WfaOnDevice* on_device = nullptr);  // != nullptr: run-length CIGARs are produced but stay on the device
 
 }  // namespace trgt
