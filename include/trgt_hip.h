@@ -257,6 +257,54 @@ int trgt_locus_batch_submit(trgt_hip_ctx* ctx, const trgt_locus_params* p, const
                             trgt_locus_batch_out* out, int64_t* ticket);
 int trgt_locus_batch_wait(trgt_hip_ctx* ctx, int64_t ticket);
 
+/* ------------------------------------------------------------ read ingestion (the step in front of trgt_locus_batch)
+ * Repeat catalog + indexed FASTA + indexed BAM -> the arrays of trgt_locus_batch_in, i.e. what analyze_tr does before get_spanning_reads:
+ *   Locus::new / get_tr_and_flanks (src/trgt/locus.rs:31-98, 168-190), extract_reads (src/trgt/workflows/tr.rs:268-361: region
+ *   +- flank_len, secondary / supplementary records dropped, rq < min_read_qual dropped and counted, at most 3 * max_depth reads kept
+ *   -- beyond that a reservoir driven by StdRng::seed_from_u64(42)), HiFiRead::from_hts_rec (src/trgt/reads/read.rs:98-141: bases, base
+ *   qualities, rq / HP tags, 5mC calls of the MM / ML tags per CpG, mismatch offsets of snp.rs:51-79) and clip_reads (tr.rs:186-196 ->
+ *   clip_region.rs:19-184, radius 2 * flank_len).  Host code (zlib + the .bai / .fai indexes), loci read by a pool of threads. */
+typedef struct trgt_ingest trgt_ingest;
+typedef struct trgt_ingest_params {
+  int32_t flank_len;       /* 250  --flank-len: flanks of the Locus and the search flank of extract_reads */
+  int32_t max_depth;       /* 250  reads kept per locus: 3 * max_depth */
+  double min_read_qual;    /* 0.98 */
+  int32_t threads;         /* 0 = up to 16 */
+  int32_t genotyper;       /* 0 size, 1 cluster: copied into trgt_ingest_batch::genotyper for every locus */
+  int32_t default_ploidy;  /* 2 (the karyotype logic of locus.rs:216-240 stays with the caller: overwrite ploidy[] for X / Y loci) */
+} trgt_ingest_params;
+typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
+  int64_t n_loci, n_reads, n_motifs;
+  uint64_t flank_bytes, tr_bytes, motif_bytes, read_bytes;
+  /* -- the fields of trgt_locus_batch_in, same names and meaning */
+  const uint8_t* flank_blob; const uint64_t* lf_off; const uint32_t* lf_len; const uint64_t* rf_off; const uint32_t* rf_len;
+  const uint8_t* tr_blob; const uint64_t* tr_off; const uint32_t* tr_len;
+  const uint8_t* motif_blob; const uint32_t* motif_off; const uint32_t* set_motif_begin;
+  const uint8_t* ploidy; const uint8_t* genotyper; const uint64_t* locus_read_begin;
+  const uint8_t* read_blob; const uint64_t* read_off; const uint32_t* read_len; const double* read_qual;  /* NaN = no rq tag */
+  /* -- per locus: catalog fields and counters */
+  const char* contig_blob; const uint64_t* contig_off; const char* id_blob; const uint64_t* id_off;      /* [n_loci + 1] offsets */
+  const char* struc_blob; const uint64_t* struc_off; const int64_t* region_start; const int64_t* region_end;
+  const int32_t* n_quality_filtered; const int64_t* n_reads_seen;   /* dropped for rq; reads that passed the filters (> kept: reservoir) */
+  /* -- per clipped read: the rest of HiFiRead, for the writers and genotype_flank */
+  const uint8_t* qual_blob;                       /* base qualities, same offsets as read_blob */
+  const char* name_blob; const uint64_t* name_off;  /* [n_reads + 1] */
+  const uint8_t* is_reverse; const uint8_t* mapq; const int16_t* hp_tag;   /* hp_tag -1 = None */
+  const int32_t* start_offset; const int32_t* end_offset;                  /* alignment start - region start, alignment end - region end */
+  const int32_t* mismatch_offsets; const uint64_t* mismatch_off;           /* [n_reads + 1] */
+  const uint8_t* meth; const uint64_t* meth_off; const uint8_t* has_meth;  /* [n_reads + 1]; has_meth 0 = None */
+  const uint32_t* cigar; const uint64_t* cigar_off; const int64_t* cigar_ref_pos;  /* clipped CIGAR (len << 4 | op), [n_reads + 1] */
+  void* owner;
+} trgt_ingest_batch;
+void trgt_ingest_default_params(trgt_ingest_params* p);
+int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out);  /* needs <bam>.bai and <fasta>.fai */
+void trgt_ingest_close(trgt_ingest* h);
+const char* trgt_ingest_last_error(const trgt_ingest* h);
+/* loci [first_locus, first_locus + max_loci) of the catalog (max_loci < 0: to the end) */
+int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus,
+                                   int64_t max_loci, trgt_ingest_batch** out);
+void trgt_ingest_free(trgt_ingest_batch* b);
+
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {
   uint64_t seed;           /* 20250509 */

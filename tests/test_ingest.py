@@ -1,0 +1,190 @@
+"""Native read ingestion (trgt_amd/csrc/ingest.hip: BGZF / BAI / FAI, extract_reads, HiFiRead::from_hts_rec, extract_snps_offset,
+clip_to_region) against (a) the Python mirror trgt_amd/reads.py on the reference's example data set and (b) independent restatements
+of the per-read rules on synthetic BAM files written by tests/bamtools.py.  No GPU involved."""
+import os
+
+import numpy as np
+import pytest
+
+from bamtools import write_bam, write_fasta
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+EX = os.path.join(GOLD, "example")
+
+
+def _reads_of(b, l):
+    a, e = int(b["locus_read_begin"][l]), int(b["locus_read_begin"][l + 1])
+    return [bytes(b["read_blob"][int(b["read_off"][r]):int(b["read_off"][r]) + int(b["read_len"][r])]) for r in range(a, e)], range(a, e)
+
+
+def test_example_data_set_matches_the_python_mirror():
+    from trgt_amd import ingest, reads
+    b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
+    genome = reads.read_fasta(os.path.join(EX, "reference.fasta"))
+    loci = reads.read_catalog(os.path.join(EX, "repeat.bed"), genome)
+    records = reads.read_bam(os.path.join(EX, "sample.bam"))
+    assert b["n_loci"] == len(loci) == 1 and b["id"] == [loci[0].id] and b["contig"] == [loci[0].contig]
+    L = reads.locus_inputs(loci[0], records)
+    got, _ = _reads_of(b, 0)
+    assert got == L["reads"] and len(got) == 33
+    assert np.array_equal(b["read_qual"], np.array(L["read_qual"], np.float64))
+    assert bytes(b["flank_blob"][int(b["lf_off"][0]):int(b["lf_off"][0]) + 250]) == L["left_flank"]
+    assert bytes(b["flank_blob"][int(b["rf_off"][0]):int(b["rf_off"][0]) + 250]) == L["right_flank"]
+    assert bytes(b["tr_blob"][:int(b["tr_len"][0])]) == L["tr"]
+    assert bytes(b["motif_blob"]) == b"CAG" and b["struc"] == [loci[0].struc]
+    assert int(b["n_reads_seen"][0]) == 33 and int(b["n_quality_filtered"][0]) == 0 and not b["has_meth"].any() and (b["hp_tag"] == -1).all()
+
+
+def _comp(s):
+    return s.translate(str.maketrans("ACGT", "TGCA"))[::-1]
+
+
+def _synthetic(tmp_path, deep=0):
+    rng = np.random.default_rng(5)
+    genome = "".join(rng.choice(list("ACGT"), 6000))
+    fa = str(tmp_path / "g.fa")
+    write_fasta(fa, [("chr1", genome), ("chr2", genome[::-1])])
+    bed = str(tmp_path / "cat.bed")
+    open(bed, "w").write("chr1\t2000\t2060\tID=L1;MOTIFS=CAG,CCG;STRUC=(CAG)n(CCG)n\n\nchr1\t4000\t4030\tID=L2;MOTIFS=A;STRUC=(A)n\n")
+    recs = []
+
+    def add(name, pos, cigar, flag=0, rq=0.999, hp=None, mm=None, ml=None, tid=0):
+        qlen = sum(n for c, n in cigar if c in "MIS=X")
+        seq = "".join(rng.choice(list("ACGT"), qlen))
+        if mm == "auto":  # a 5mC call on every second CpG (original strand), probabilities 10, 20, ...
+            orig = _comp(seq) if flag & 16 else seq
+            cs = [i for i, ch in enumerate(orig) if ch == "C"]
+            cpg = [k for k, i in enumerate(cs) if orig[i:i + 2] == "CG"][::2]
+            deltas, last = [], -1
+            for k in cpg:
+                deltas.append(k - last - 1)
+                last = k
+            mm, ml = "C+m?," + ",".join(map(str, deltas)) + ";" if deltas else "C+m?;", [(10 * (i + 1)) % 256 for i in range(len(deltas))]
+        tags = {}
+        if rq is not None:
+            tags["rq"] = ("f", rq)
+        if hp is not None:
+            tags["HP"] = ("C", hp)
+        if mm is not None:
+            tags["MM"] = ("Z", mm)
+            tags["ML"] = ("BC", ml)
+        recs.append(dict(name=name, tid=tid, pos=pos, cigar=cigar, seq=seq, flag=flag, tags=tags, qual=[int(x) for x in rng.integers(2, 60, qlen)]))
+
+    add("spans_all", 1400, [("S", 7), ("=", 500), ("X", 2), ("=", 98), ("I", 5), ("=", 60), ("D", 3), ("X", 1), ("=", 400), ("S", 4)], hp=1, mm="auto")
+    add("rev_meth", 1450, [("=", 300), ("X", 1), ("=", 249), ("X", 3), ("=", 700)], flag=16, hp=2, mm="auto")
+    add("starts_inside", 2030, [("M", 600)])
+    add("ends_inside", 1300, [("M", 720)], rq=None)
+    add("low_rq", 1500, [("M", 900)], rq=0.5)
+    add("secondary", 1500, [("M", 900)], flag=256)
+    add("supplementary", 1500, [("M", 900)], flag=2048)
+    add("far_left", 100, [("M", 1000)])
+    add("touches_region_end", 2309, [("M", 50)])
+    add("just_outside", 2310, [("M", 50)])
+    add("other_contig", 1500, [("M", 900)], tid=1)
+    add("locus2", 3700, [("=", 290), ("X", 1), ("=", 9), ("D", 30), ("=", 400)], hp=1)
+    for i in range(deep):
+        add("deep%04d" % i, 3800 + (i % 50), [("M", 500)])
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    bam = str(tmp_path / "s.bam")
+    write_bam(bam, [("chr1", 6000), ("chr2", 6000)], recs)
+    return bam, fa, bed, recs, genome
+
+
+def _expected_snps(rec, start, end):
+    out, ref = [], rec["pos"]
+    for c, n in rec["cigar"]:
+        if c == "X" and not (start <= ref <= end):
+            d = ref - start if ref < start else ref - end
+            out += [d + i for i in range(n)]
+            ref += n
+        elif c in "MX=DN":
+            ref += n
+    return out
+
+
+def _expected_meth(rec):
+    """get_meth (read.rs:55-96) restated from the MM / ML definition: per CpG of the stored sequence"""
+    tags = rec["tags"]
+    if "MM" not in tags:
+        return None
+    seq, rev = rec["seq"], bool(rec["flag"] & 16)
+    orig = _comp(seq) if rev else seq
+    deltas = [int(x) for x in tags["MM"][1].split(";")[0].split(",")[1:]]
+    cs = [i for i, ch in enumerate(orig) if ch == "C"]
+    calls, k = {}, -1
+    for d, q in zip(deltas, tags["ML"][1]):
+        k += d + 1
+        calls[cs[k]] = q
+    cpgs_orig = [i for i in range(len(orig) - 1) if orig[i:i + 2] == "CG"]
+    vals = [calls.get(i, 0) for i in cpgs_orig]
+    if not any(i in calls for i in cpgs_orig):
+        return None
+    return vals  # get_meth reverses the reverse-strand list back into ORIGINAL order: vals is already in original order
+
+
+def test_synthetic_bam_records(tmp_path):
+    from trgt_amd import ingest, reads
+    bam, fa, bed, recs, genome = _synthetic(tmp_path)
+    b = ingest.Reader(bam, fa).batch(bed, threads=2)
+    assert b["n_loci"] == 2 and b["id"] == ["L1", "L2"] and list(b["set_motif_begin"]) == [0, 2, 3]
+    assert bytes(b["tr_blob"][:60]).decode() == genome[2000:2060] and bytes(b["flank_blob"][:250]).decode() == genome[1750:2000]
+    by_name = {r["name"]: r for r in recs}
+    got, idx = _reads_of(b, 0)
+    names = [b["read_name"][r] for r in idx]
+    # region +- flank_len = [1750, 2310): file order, secondary / supplementary dropped, the low-quality one counted
+    assert names == ["ends_inside", "spans_all", "rev_meth", "starts_inside", "touches_region_end"]
+    assert int(b["n_quality_filtered"][0]) == 1 and int(b["n_reads_seen"][0]) == 5
+    for r, name, bases in zip(idx, names, got):
+        rec = by_name[name]
+        mirror = reads.BamRecord(name, "chr1", rec["pos"], rec["flag"], [("MIDNSHP=X".index(c), n) for c, n in rec["cigar"]], rec["seq"], None)
+        assert bases == reads.clip_to_region(mirror, (2000 - 500, 2060 + 500)), name
+        q0 = rec["seq"].find(bases.decode()) if bases else 0
+        assert bytes(b["qual_blob"][int(b["read_off"][r]):int(b["read_off"][r]) + len(bases)]) == bytes(rec["qual"][q0:q0 + len(bases)]), name
+        ref_end = rec["pos"] + sum(n for c, n in rec["cigar"] if c in "MDN=X")
+        assert int(b["start_offset"][r]) == rec["pos"] - 2000 and int(b["end_offset"][r]) == ref_end - 2060
+        assert list(b["mismatch_offsets"][int(b["mismatch_off"][r]):int(b["mismatch_off"][r + 1])]) == _expected_snps(rec, 2000, 2060), name
+        assert int(b["hp_tag"][r]) == (rec["tags"]["HP"][1] if "HP" in rec["tags"] else -1)
+        assert bool(b["is_reverse"][r]) == bool(rec["flag"] & 16)
+        rq = rec["tags"]["rq"][1] if "rq" in rec["tags"] else None
+        assert (np.isnan(b["read_qual"][r]) if rq is None else b["read_qual"][r] == np.float32(rq))
+        exp = _expected_meth(rec)
+        if exp is None:
+            assert not b["has_meth"][r]
+        else:  # clip: the CpGs whose C lies inside the clipped bases (stored orientation)
+            seq = rec["seq"]
+            stored = exp[::-1] if rec["flag"] & 16 else exp   # get_meth's list is in original-strand order ...
+            stored = stored[::-1] if rec["flag"] & 16 else stored  # ... which clip_to_region walks against the STORED bases as is
+            cpg = [i for i in range(len(seq) - 1) if seq[i:i + 2] == "CG"]
+            keep = [v for i, v in zip(cpg, stored) if q0 <= i < q0 + len(bases)]
+            assert b["has_meth"][r] and list(b["meth"][int(b["meth_off"][r]):int(b["meth_off"][r + 1])]) == keep, name
+    got2, idx2 = _reads_of(b, 1)
+    assert [b["read_name"][r] for r in idx2] == ["locus2"] and int(b["hp_tag"][idx2[0]]) == 1
+    r2 = idx2[0]
+    assert list(b["mismatch_offsets"][int(b["mismatch_off"][r2]):int(b["mismatch_off"][r2 + 1])]) == _expected_snps(by_name["locus2"], 4000, 4030)
+
+
+def test_reservoir_caps_deep_loci(tmp_path):
+    from trgt_amd import ingest
+    bam, fa, bed, recs, _ = _synthetic(tmp_path, deep=400)
+    rd = ingest.Reader(bam, fa)
+    b = rd.batch(bed, max_depth=40, threads=1)
+    _, idx = _reads_of(b, 1)
+    assert int(b["n_reads_seen"][1]) == 401 and len(idx) == 120  # 3 * max_depth kept of the reads that passed the filters
+    names = [b["read_name"][r] for r in idx]
+    assert len(set(names)) == 120 and any(n > "deep0119" for n in names if n.startswith("deep"))  # later reads replaced earlier ones
+    again = rd.batch(bed, max_depth=40, threads=4)
+    assert [again["read_name"][r] for r in _reads_of(again, 1)[1]] == names  # a fixed seed: the same sample every time
+
+
+def test_errors_are_reported(tmp_path):
+    from trgt_amd import _lib, ingest
+    with pytest.raises(_lib.TrgtHipError):
+        ingest.Reader(str(tmp_path / "missing.bam"), os.path.join(EX, "reference.fasta"))
+    rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
+    bad = str(tmp_path / "bad.bed")
+    open(bad, "w").write("chrA\t10001\t10061\tID=TR1;MOTIFS=CAG\n")
+    with pytest.raises(_lib.TrgtHipError, match="STRUC field missing"):
+        rd.batch(bad)
+    open(bad, "w").write("chrA\t100\t161\tID=TR1;MOTIFS=CAG;STRUC=(CAG)n\n")
+    with pytest.raises(_lib.TrgtHipError, match="BED line 1"):
+        rd.batch(bad)

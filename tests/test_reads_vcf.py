@@ -98,3 +98,14 @@ def test_example_bam_to_vcf_record_on_the_gpu():
     res = locus.analyze_batch([reads.locus_inputs(l, records) | {"genotyper": "cluster"} for l in loci])
     rec = vcf.vcf_record(loci[0], res[0]).split("\t")
     assert rec[4] == "C" + "CAG" * 11 and rec[9].startswith("1/1:33,33:")
+
+
+@pytest.mark.gpu
+def test_example_bam_through_the_native_ingestion_on_the_gpu():
+    # the same end-to-end case with the native reader (trgt_amd/csrc/ingest.hip) in front: BAM + .bai, FASTA + .fai, catalog ->
+    # trgt_ingest_batch arrays -> trgt_locus_batch -> VCF record of the tutorial
+    from trgt_amd import ingest, locus, vcf
+    reads, loci, _ = _example()
+    b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
+    out = locus.run_batch(b)
+    assert [vcf.vcf_record(l, locus.locus_result(b, out, i)) for i, l in enumerate(loci)] == [TUTORIAL_RECORD]

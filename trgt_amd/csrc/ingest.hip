@@ -1,0 +1,713 @@
+// trgt_amd/csrc/ingest.hip -- read ingestion in front of the GPU path, host C++ (no device code):
+//   repeat catalog + indexed FASTA -> Locus                     src/trgt/locus.rs:13-23, 168-215
+//   indexed BAM -> the reads of a locus                          src/trgt/workflows/tr.rs:268-361 (extract_reads)
+//   HiFiRead::from_hts_rec                                       src/trgt/reads/read.rs:55-141 (bases, quals, rq / HP tags, MM / ML)
+//   extract_snps_offset                                          src/trgt/reads/snp.rs:51-79
+//   HiFiRead::clip_to_region, clip_reads                         src/trgt/reads/clip_region.rs:19-184, tr.rs:186-196
+// and the assembly of the result as the arrays of trgt_locus_batch_in, so that a BAM goes straight into trgt_locus_batch.
+// The reference does the file work through htslib; here BGZF blocks are inflated with zlib, regions are looked up in the .bai
+// (bins + linear index) and in the .fai, and the loci of a batch are read by a pool of threads, each with its own file handle.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/trgt_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- BGZF
+struct Bgzf {
+  int fd = -1;
+  std::vector<uint8_t> raw, block;
+  uint64_t block_coff = ~0ull;  // compressed offset of the block held in `block`
+  uint32_t block_csize = 0;     // its size in the file
+  size_t pos = 0;               // read position inside `block`
+  std::string err;
+  ~Bgzf() { if (fd >= 0) ::close(fd); }
+  bool open(const char* path) { fd = ::open(path, O_RDONLY); if (fd < 0) { err = std::string("cannot open ") + path; return false; } return true; }
+  bool load(uint64_t coff) {
+    uint8_t h[18];
+    const ssize_t got = ::pread(fd, h, 18, (off_t)coff);
+    if (got == 0) { block.clear(); block_coff = coff; block_csize = 0; pos = 0; return true; }  // end of file
+    if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    // the BC subfield is the first one in every file bgzip / htslib / pbmm2 writes; look it up properly all the same
+    std::vector<uint8_t> extra(xlen);
+    if (::pread(fd, extra.data(), xlen, (off_t)coff + 12) != (ssize_t)xlen) { err = "truncated BGZF header"; return false; }
+    uint32_t bsize = 0; bool found = false;
+    for (uint32_t i = 0; i + 4 <= xlen;) {
+      const uint32_t slen = extra[i + 2] | (extra[i + 3] << 8);
+      if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) { bsize = extra[i + 4] | (extra[i + 5] << 8); found = true; break; }
+      i += 4 + slen;
+    }
+    if (!found) { err = "BGZF block without BC field"; return false; }
+    const uint32_t total = bsize + 1, hdr = 12 + xlen;
+    if (total < hdr + 8) { err = "bad BGZF block size"; return false; }
+    raw.resize(total);
+    if (::pread(fd, raw.data(), total, (off_t)coff) != (ssize_t)total) { err = "truncated BGZF block"; return false; }
+    const uint32_t isize = raw[total - 4] | (raw[total - 3] << 8) | (raw[total - 2] << 16) | ((uint32_t)raw[total - 1] << 24);
+    block.resize(isize);
+    if (isize) {
+      z_stream zs;
+      std::memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+      zs.next_in = raw.data() + hdr; zs.avail_in = total - hdr - 8;
+      zs.next_out = block.data(); zs.avail_out = isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "corrupt BGZF block"; return false; }
+    }
+    block_coff = coff; block_csize = total; pos = 0;
+    return true;
+  }
+  bool seek(uint64_t voff) {
+    const uint64_t coff = voff >> 16;
+    if (coff != block_coff && !load(coff)) return false;
+    pos = (size_t)(voff & 0xFFFF);
+    return pos <= block.size();
+  }
+  uint64_t tell() const { return pos < block.size() || block_csize == 0 ? (block_coff << 16) | pos : ((block_coff + block_csize) << 16); }
+  // n bytes; returns 1 ok, 0 clean end of file before the first byte, -1 error
+  int read(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst;
+    size_t done = 0;
+    while (done < n) {
+      if (pos >= block.size()) {
+        if (block_csize == 0 && block_coff != ~0ull) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
+        if (!load(block_coff + block_csize)) return -1;
+        if (block.empty() && block_csize == 0) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
+        continue;
+      }
+      const size_t k = std::min(n - done, block.size() - pos);
+      std::memcpy(d + done, block.data() + pos, k);
+      done += k; pos += k;
+    }
+    return 1;
+  }
+};
+
+inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+// ---------------------------------------------------------------------------------------------- BAI
+struct BaiRef {
+  std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+  std::vector<uint64_t> linear;
+};
+struct Bai {
+  std::vector<BaiRef> refs;
+  bool load(const std::string& path, std::string& err) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { err = "cannot open " + path; return false; }
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (d.size() < 8 || std::memcmp(d.data(), "BAI\1", 4) != 0) { err = "not a BAI index: " + path; return false; }
+    size_t p = 4;
+    auto need = [&](size_t n) { return p + n <= d.size(); };
+    const uint32_t n_ref = le32(&d[p]); p += 4;
+    refs.resize(n_ref);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+      if (!need(4)) { err = "truncated BAI"; return false; }
+      const uint32_t n_bin = le32(&d[p]); p += 4;
+      for (uint32_t b = 0; b < n_bin; ++b) {
+        if (!need(8)) { err = "truncated BAI"; return false; }
+        const uint32_t bin = le32(&d[p]), n_chunk = le32(&d[p + 4]); p += 8;
+        if (!need(16ull * n_chunk)) { err = "truncated BAI"; return false; }
+        auto& v = refs[r].bins[bin];
+        for (uint32_t c = 0; c < n_chunk; ++c) { v.emplace_back(le64(&d[p]), le64(&d[p + 8])); p += 16; }
+      }
+      if (!need(4)) { err = "truncated BAI"; return false; }
+      const uint32_t n_intv = le32(&d[p]); p += 4;
+      if (!need(8ull * n_intv)) { err = "truncated BAI"; return false; }
+      refs[r].linear.resize(n_intv);
+      for (uint32_t i = 0; i < n_intv; ++i) { refs[r].linear[i] = le64(&d[p]); p += 8; }
+    }
+    return true;
+  }
+  // chunks that may hold records overlapping [beg, end) of reference tid, sorted and merged (SAM spec 5.3: reg2bins)
+  std::vector<std::pair<uint64_t, uint64_t>> query(int tid, int64_t beg, int64_t end) const {
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    if (tid < 0 || (size_t)tid >= refs.size() || end <= beg) return out;
+    const BaiRef& R = refs[(size_t)tid];
+    if (beg < 0) beg = 0;
+    const int64_t e = std::min<int64_t>(end, 1ll << 29) - 1;
+    if (beg > e) return out;
+    const size_t li = (size_t)(beg >> 14);
+    const uint64_t min_off = R.linear.empty() ? 0 : R.linear[std::min(li, R.linear.size() - 1)];
+    auto add = [&](uint32_t bin) {
+      auto it = R.bins.find(bin);
+      if (it == R.bins.end()) return;
+      for (auto& ch : it->second) if (ch.second > min_off) out.push_back(ch);
+    };
+    add(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (e >> 26); ++k) add((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (e >> 23); ++k) add((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (e >> 20); ++k) add((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (e >> 17); ++k) add((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (e >> 14); ++k) add((uint32_t)k);
+    std::sort(out.begin(), out.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto& ch : out) {
+      if (!merged.empty() && ch.first <= merged.back().second) merged.back().second = std::max(merged.back().second, ch.second);
+      else merged.push_back(ch);
+    }
+    return merged;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- FASTA + .fai
+struct FaiEntry { int64_t len = 0, offset = 0, line_bases = 0, line_width = 0; };
+struct Fasta {
+  int fd = -1;
+  std::map<std::string, FaiEntry> idx;
+  ~Fasta() { if (fd >= 0) ::close(fd); }
+  bool open(const std::string& path, std::string& err) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "cannot open " + path; return false; }
+    std::ifstream f(path + ".fai");
+    if (!f) { err = "cannot open " + path + ".fai"; return false; }
+    std::string line;
+    while (std::getline(f, line)) {
+      std::istringstream ss(line);
+      std::string name; FaiEntry e;
+      if (ss >> name >> e.len >> e.offset >> e.line_bases >> e.line_width) idx[name] = e;
+    }
+    return true;
+  }
+  // bases [beg, end) of a contig, upper-cased (locus.rs:168-190: fetch_seq_string + to_uppercase)
+  bool fetch(const std::string& contig, int64_t beg, int64_t end, std::string& out, std::string& err) const {
+    auto it = idx.find(contig);
+    if (it == idx.end()) { err = "contig " + contig + " is not in the genome"; return false; }
+    const FaiEntry& e = it->second;
+    if (beg < 0 || end > e.len || beg > end || e.line_bases <= 0) { err = "Error fetching sequence for region " + contig + ":" + std::to_string(beg) + "-" + std::to_string(end); return false; }
+    out.clear();
+    if (beg == end) return true;
+    const int64_t o0 = e.offset + beg / e.line_bases * e.line_width + beg % e.line_bases;
+    const int64_t o1 = e.offset + (end - 1) / e.line_bases * e.line_width + (end - 1) % e.line_bases + 1;
+    std::string rawb((size_t)(o1 - o0), '\0');
+    if (::pread(fd, &rawb[0], rawb.size(), (off_t)o0) != (ssize_t)rawb.size()) { err = "short read from the genome"; return false; }
+    out.reserve((size_t)(end - beg));
+    for (char ch : rawb) if (ch != '\n' && ch != '\r') out.push_back((char)std::toupper((unsigned char)ch));
+    if ((int64_t)out.size() != end - beg) { err = "genome index does not match the FASTA"; return false; }
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- records
+constexpr int OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_EQ = 7, OP_X = 8;
+inline int64_t ref_len(uint32_t op) { const int c = (int)(op & 0xF); return (c == OP_M || c == OP_D || c == OP_N || c == OP_EQ || c == OP_X) ? (int64_t)(op >> 4) : 0; }
+inline int64_t qry_len(uint32_t op) { const int c = (int)(op & 0xF); return (c == OP_M || c == OP_I || c == OP_S || c == OP_EQ || c == OP_X) ? (int64_t)(op >> 4) : 0; }
+
+struct Read {  // HiFiRead (read.rs:10-36)
+  std::string id;
+  bool is_reverse = false, has_meth = false, has_cigar = false;
+  std::string bases; std::vector<uint8_t> quals, meth;
+  double rq = std::numeric_limits<double>::quiet_NaN();
+  std::vector<int32_t> mismatch_offsets;
+  int32_t start_offset = 0, end_offset = 0;
+  int64_t ref_pos = 0; std::vector<uint32_t> cigar;  // BAM encoding: len << 4 | op
+  int hp = -1; uint8_t mapq = 0;
+};
+
+struct RawRec { std::vector<uint8_t> d; int32_t ref_id, pos, l_seq; uint32_t l_rn, n_cig, flag; uint8_t mapq; size_t o_cig, o_seq, o_qual, o_aux; };
+
+bool parse_rec(RawRec& r) {
+  const uint8_t* d = r.d.data();
+  if (r.d.size() < 32) return false;
+  r.ref_id = (int32_t)le32(d); r.pos = (int32_t)le32(d + 4); r.l_rn = d[8]; r.mapq = d[9];
+  r.n_cig = d[12] | (d[13] << 8); r.flag = d[14] | (d[15] << 8); r.l_seq = (int32_t)le32(d + 16);
+  r.o_cig = 32 + r.l_rn; r.o_seq = r.o_cig + 4ull * r.n_cig; r.o_qual = r.o_seq + ((size_t)r.l_seq + 1) / 2; r.o_aux = r.o_qual + (size_t)r.l_seq;
+  return r.o_aux <= r.d.size();
+}
+int64_t rec_ref_end(const RawRec& r) {
+  int64_t e = r.pos;
+  for (uint32_t i = 0; i < r.n_cig; ++i) e += ref_len(le32(r.d.data() + r.o_cig + 4 * i));
+  return e;
+}
+// aux field of a record: pointer to its type byte, or null
+const uint8_t* find_aux(const RawRec& r, const char* tag) {
+  const uint8_t* p = r.d.data() + r.o_aux; const uint8_t* e = r.d.data() + r.d.size();
+  auto size_of = [](uint8_t t) -> int { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
+  while (p + 3 <= e) {
+    const uint8_t ty = p[2];
+    if (p[0] == (uint8_t)tag[0] && p[1] == (uint8_t)tag[1]) return p + 2;
+    p += 3;
+    if (const int s = size_of(ty)) p += s;
+    else if (ty == 'Z' || ty == 'H') { while (p < e && *p) ++p; ++p; }
+    else if (ty == 'B') { if (p + 5 > e) return nullptr; const int s2 = size_of(p[0]); const uint32_t n = le32(p + 1); p += 5 + (size_t)s2 * n; }
+    else return nullptr;
+  }
+  return nullptr;
+}
+bool aux_int(const uint8_t* a, int64_t& v) {
+  if (!a) return false;
+  switch (a[0]) {
+    case 'c': v = (int8_t)a[1]; return true;
+    case 'C': v = a[1]; return true;
+    case 's': v = (int16_t)(a[1] | (a[2] << 8)); return true;
+    case 'S': v = a[1] | (a[2] << 8); return true;
+    case 'i': v = (int32_t)le32(a + 1); return true;
+    case 'I': v = le32(a + 1); return true;
+    default: return false;
+  }
+}
+
+// 5mC calls of a record as (position in the stored sequence, probability), in stored order: the "C+m" entries of the MM tag with the
+// ML values that belong to them (SAM tags spec 1.7: skip counts over the canonical base of the ORIGINAL strand; a reverse-strand
+// record stores the reverse complement, so its C's are G's counted from the end).  rust-htslib's basemods_iter reports them in the
+// same order; get_meth (read.rs:55-96) keeps those that sit on a CpG.
+bool basemods_5mc(const RawRec& r, const std::string& bases, bool reverse, std::vector<std::pair<uint32_t, uint8_t>>& out) {
+  out.clear();
+  const uint8_t* mm = find_aux(r, "MM"); if (!mm) mm = find_aux(r, "Mm");
+  const uint8_t* ml = find_aux(r, "ML"); if (!ml) ml = find_aux(r, "Ml");
+  if (!mm || mm[0] != 'Z' || !ml || ml[0] != 'B' || (ml[1] != 'C' && ml[1] != 'c')) return false;
+  const uint32_t n_ml = le32(ml + 2);
+  const uint8_t* mlv = ml + 6;
+  const char* s = (const char*)mm + 1;
+  uint32_t ml_at = 0;
+  const size_t n = bases.size();
+  while (*s) {
+    // one entry: base strand codes [.?] {,delta} ;
+    const char base = *s; if (!base) break;
+    const char strand = s[1];
+    const char* q = s + 2;
+    std::string codes;
+    while (*q && *q != ',' && *q != ';' && *q != '.' && *q != '?') codes.push_back(*q++);
+    if (*q == '.' || *q == '?') ++q;
+    std::vector<uint32_t> deltas;
+    while (*q == ',') { ++q; uint32_t v = 0; while (*q >= '0' && *q <= '9') v = v * 10 + (uint32_t)(*q++ - '0'); deltas.push_back(v); }
+    if (*q == ';') ++q;
+    s = q;
+    const size_t n_codes = std::max<size_t>(1, codes.size());  // "C+mh": the ML values of a position are interleaved per code
+    const size_t m_idx = codes.find('m');
+    if (base == 'C' && strand == '+' && m_idx != std::string::npos) {
+      const char want = reverse ? 'G' : 'C';
+      size_t i = 0; bool ok = true;  // index in original-strand order
+      std::vector<std::pair<uint32_t, uint8_t>> found;
+      for (size_t k = 0; k < deltas.size() && ok; ++k) {
+        uint32_t skip = deltas[k];
+        for (;; ++i) {
+          if (i >= n) { ok = false; break; }
+          const size_t at = reverse ? n - 1 - i : i;
+          if (bases[at] == want) { if (skip == 0) break; --skip; }
+        }
+        if (!ok) break;
+        const size_t at = reverse ? n - 1 - i : i;
+        const uint32_t mi = ml_at + (uint32_t)(k * n_codes + m_idx);
+        if (mi < n_ml) found.emplace_back((uint32_t)at, mlv[mi]);
+        ++i;
+      }
+      if (reverse) std::reverse(found.begin(), found.end());
+      out.insert(out.end(), found.begin(), found.end());
+    }
+    ml_at += (uint32_t)(deltas.size() * n_codes);
+  }
+  return true;
+}
+
+// HiFiRead::from_hts_rec (read.rs:98-141)
+void make_read(const RawRec& r, int64_t region_start, int64_t region_end, Read& out) {
+  static const char code[] = "=ACMGRSVTWYHKDBN";
+  const uint8_t* d = r.d.data();
+  out.id.assign((const char*)d + 32, r.l_rn ? r.l_rn - 1 : 0);
+  out.is_reverse = (r.flag & 0x10) != 0;
+  out.bases.resize((size_t)r.l_seq);
+  for (int32_t i = 0; i < r.l_seq; ++i) out.bases[(size_t)i] = code[(d[r.o_seq + (size_t)(i >> 1)] >> ((i & 1) ? 0 : 4)) & 0xF];
+  out.quals.assign(d + r.o_qual, d + r.o_qual + r.l_seq);
+  out.mapq = r.mapq;
+  { int64_t v; out.hp = aux_int(find_aux(r, "HP"), v) ? (int)(uint8_t)v : -1; }
+  { const uint8_t* a = find_aux(r, "rq"); float f; if (a && a[0] == 'f') { std::memcpy(&f, a + 1, 4); out.rq = (double)f; } }
+  {  // get_meth (read.rs:55-96): one value per CpG of the stored sequence (0 where no call sits on it), None without any call
+    std::vector<std::pair<uint32_t, uint8_t>> mods;
+    out.has_meth = false; out.meth.clear();
+    if (basemods_5mc(r, out.bases, out.is_reverse, mods)) {
+      std::vector<size_t> cpg;
+      for (size_t i = 0; i + 1 < out.bases.size(); ++i) if (out.bases[i] == 'C' && out.bases[i + 1] == 'G') cpg.push_back(i + (out.is_reverse ? 1 : 0));
+      std::vector<uint8_t> ans(cpg.size(), 0);
+      size_t ind = 0;
+      for (auto& m : mods) {
+        while (ind < cpg.size() && cpg[ind] < m.first) ++ind;
+        if (ind < cpg.size() && m.first == cpg[ind]) { ans[ind] = m.second; ++ind; }
+      }
+      if (ind != 0) { if (out.is_reverse) std::reverse(ans.begin(), ans.end()); out.meth.swap(ans); out.has_meth = true; }
+    }
+  }
+  out.has_cigar = !(r.flag & 0x4);
+  out.ref_pos = r.pos;
+  out.cigar.resize(out.has_cigar ? r.n_cig : 0);
+  for (size_t i = 0; i < out.cigar.size(); ++i) out.cigar[i] = le32(d + r.o_cig + 4 * i);
+  out.start_offset = (int32_t)((int64_t)r.pos - region_start);
+  out.end_offset = (int32_t)(rec_ref_end(r) - region_end);
+  // extract_snps_offset (snp.rs:51-79): X runs that start outside [start, end] of the region, relative to the nearer end
+  out.mismatch_offsets.clear();
+  if (out.has_cigar) {
+    uint32_t start_ref = (uint32_t)r.pos;
+    for (uint32_t op : out.cigar) {
+      const int c = (int)(op & 0xF); const uint32_t n = op >> 4;
+      const bool inside = (int64_t)start_ref >= region_start && (int64_t)start_ref <= region_end;
+      if (c == OP_X && !inside) {
+        const int32_t diff = (int64_t)start_ref < region_start ? (int32_t)start_ref - (int32_t)region_start : (int32_t)start_ref - (int32_t)region_end;
+        for (uint32_t i = 0; i < n; ++i) out.mismatch_offsets.push_back(diff + (int32_t)i);
+        start_ref += n;
+      } else if (c == OP_M || c == OP_X || c == OP_EQ || c == OP_D || c == OP_N) start_ref += n;
+    }
+  }
+}
+
+// clip_cigar + HiFiRead::clip_to_region (clip_region.rs:19-184); false = no overlap (or no alignment)
+bool clip_to_region(const Read& in, int64_t rs, int64_t re, Read& out) {
+  if (!in.has_cigar) return false;
+  int64_t read_end = in.ref_pos;
+  for (uint32_t op : in.cigar) read_end += ref_len(op);
+  if (read_end <= rs || re <= in.ref_pos) return false;
+  int64_t ref_pos = in.ref_pos, query_pos = 0;
+  size_t i = 0;
+  std::vector<uint32_t> ops;
+  while (i < in.cigar.size() && ref_pos + ref_len(in.cigar[i]) <= rs) { ref_pos += ref_len(in.cigar[i]); query_pos += qry_len(in.cigar[i]); ++i; }
+  int64_t c_ref = ref_pos, c_qry = query_pos;
+  if (ref_pos < rs) {  // the operation that straddles the start of the region is split (only reference-consuming ones can)
+    const uint32_t op = in.cigar[i];
+    const int64_t outside = rs - ref_pos;
+    const int64_t keep = ref_pos + ref_len(op) <= re ? ref_len(op) - outside : re - rs;
+    const uint32_t part = ((uint32_t)keep << 4) | (op & 0xF);
+    ops.push_back(part);
+    c_ref += outside;
+    if (qry_len(part) != 0) c_qry += outside;
+    ref_pos += ref_len(op); query_pos += qry_len(op); ++i;
+  }
+  while (i < in.cigar.size() && ref_pos + ref_len(in.cigar[i]) <= re) { ops.push_back(in.cigar[i]); ref_pos += ref_len(in.cigar[i]); query_pos += qry_len(in.cigar[i]); ++i; }
+  if (i < in.cigar.size() && ref_pos < re) ops.push_back(((uint32_t)(re - ref_pos) << 4) | (in.cigar[i] & 0xF));
+  out = Read();
+  out.id = in.id; out.is_reverse = in.is_reverse; out.rq = in.rq; out.mismatch_offsets = in.mismatch_offsets;
+  out.start_offset = in.start_offset; out.end_offset = in.end_offset; out.hp = in.hp; out.mapq = in.mapq;
+  int64_t q = c_qry;
+  for (uint32_t op : ops) {
+    const int64_t n = qry_len(op);
+    if (q + n > (int64_t)in.bases.size()) return false;  // (a CIGAR longer than its sequence: not a record htslib would hand out)
+    out.bases.append(in.bases, (size_t)q, (size_t)n);
+    out.quals.insert(out.quals.end(), in.quals.begin() + q, in.quals.begin() + q + n);
+    q += n;
+  }
+  const int64_t q_end = q;
+  if (in.has_meth) {  // the calls of the CpGs whose C lies inside the clipped part
+    size_t mi = 0;
+    out.has_meth = true;
+    for (size_t idx = 0; idx + 1 < in.bases.size(); ++idx)
+      if (in.bases[idx] == 'C' && in.bases[idx + 1] == 'G') {
+        if (mi >= in.meth.size()) break;
+        if ((int64_t)idx >= c_qry && (int64_t)idx < q_end) out.meth.push_back(in.meth[mi]);
+        ++mi;
+      }
+  }
+  out.has_cigar = true; out.ref_pos = c_ref; out.cigar.swap(ops);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------- StdRng::seed_from_u64(42).random_range
+// The reservoir of extract_reads (tr.rs:311-335) draws from rand 0.9's StdRng = ChaCha12 seeded through rand_core's seed_from_u64
+// (a PCG32 stream fills the 32-byte key).  rand is not vendored in the reference tree: the stream below restates its published
+// algorithms (ChaCha block function, 64-word buffer read in order, Canon's widening-multiply range sampling for 32-bit and 64-bit
+// ranges) -- parity UNPINNED (no fixture in the reference reaches this path).
+struct StdRng {
+  uint32_t key[8]; uint64_t counter = 0; uint32_t buf[64]; int at = 64;
+  explicit StdRng(uint64_t state) {
+    const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+    for (int i = 0; i < 8; ++i) {
+      state = state * MUL + INC;
+      const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+      key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+  }
+  static inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+  void refill() {
+    for (int b = 0; b < 4; ++b) {
+      uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                        (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+      uint32_t x[16];
+      std::memcpy(x, s, sizeof x);
+      auto qr = [&](int a, int bb, int c, int d) {
+        x[a] += x[bb]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[bb] = rotl(x[bb] ^ x[c], 12);
+        x[a] += x[bb]; x[d] = rotl(x[d] ^ x[a], 8); x[c] += x[d]; x[bb] = rotl(x[bb] ^ x[c], 7);
+      };
+      for (int r = 0; r < 6; ++r) { qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15); qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14); }
+      for (int i = 0; i < 16; ++i) buf[16 * b + i] = x[i] + s[i];
+      ++counter;
+    }
+    at = 0;
+  }
+  uint32_t next_u32() { if (at >= 64) refill(); return buf[at++]; }
+  uint64_t next_u64() {
+    if (at < 63) { const uint64_t lo = buf[at], hi = buf[at + 1]; at += 2; return (hi << 32) | lo; }
+    if (at >= 64) { refill(); const uint64_t lo = buf[0], hi = buf[1]; at = 2; return (hi << 32) | lo; }
+    const uint64_t lo = buf[63]; refill(); const uint64_t hi = buf[0]; at = 1; return (hi << 32) | lo;
+  }
+  uint64_t range(uint64_t n) {  // 0 .. n (exclusive), n >= 1
+    if (n <= 0xFFFFFFFFull) {
+      const uint32_t r = (uint32_t)n;
+      uint64_t m = (uint64_t)next_u32() * r;
+      uint32_t hi = (uint32_t)(m >> 32); const uint32_t lo = (uint32_t)m;
+      if (lo > (uint32_t)(0u - r)) { const uint32_t hi2 = (uint32_t)(((uint64_t)next_u32() * r) >> 32); if ((uint64_t)lo + hi2 > 0xFFFFFFFFull) ++hi; }
+      return hi;
+    }
+    const unsigned __int128 m = (unsigned __int128)next_u64() * n;
+    uint64_t hi = (uint64_t)(m >> 64); const uint64_t lo = (uint64_t)m;
+    if (lo > 0ull - n) { const uint64_t hi2 = (uint64_t)(((unsigned __int128)next_u64() * n) >> 64); if (lo + hi2 < lo) ++hi; }
+    return hi;
+  }
+};
+
+}  // namespace
+
+// ============================================================================================== C ABI
+struct trgt_ingest {
+  std::string bam_path, fasta_path, err;
+  std::vector<std::string> ref_names;
+  std::map<std::string, int> ref_id;
+  uint64_t first_record_voff = 0;
+  Bai bai;
+  Fasta fasta;
+};
+
+struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
+  std::string flank, tr, motifs, reads, quals, names, contigs, ids, strucs;
+  std::vector<uint64_t> lf_off, rf_off, tr_off, lrb, read_off, name_off, moff, snp_off;
+  std::vector<uint32_t> lf_len, rf_len, tr_len, motif_off, set_begin, read_len;
+  std::vector<uint8_t> ploidy, genotyper, is_reverse, mapq, meth, has_meth;
+  std::vector<int16_t> hp;
+  std::vector<int32_t> start_offset, end_offset, snp, n_filtered;
+  std::vector<int64_t> n_seen, region_start, region_end;
+  std::vector<double> rq;
+  std::vector<uint64_t> contig_off, id_off, struc_off, cig_off;
+  std::vector<uint32_t> cig;
+  std::vector<int64_t> cig_ref_pos;
+  trgt_ingest_batch pub;
+};
+
+extern "C" {
+
+const char* trgt_ingest_last_error(const trgt_ingest* h) { return h ? h->err.c_str() : "null handle"; }
+
+int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out) {
+  if (!bam_path || !fasta_path || !out) return TRGT_ERR_INVALID;
+  std::unique_ptr<trgt_ingest> h(new trgt_ingest());
+  *out = nullptr;
+  h->bam_path = bam_path; h->fasta_path = fasta_path;
+  auto bad = [&](const std::string& m) { h->err = m; *out = h.release(); return TRGT_ERR_INVALID; };  // (the handle carries the message)
+  Bgzf z;
+  if (!z.open(bam_path) || !z.load(0)) return bad(z.err.empty() ? "cannot read the BAM" : z.err);
+  uint8_t b[8];
+  if (z.read(b, 8) != 1 || std::memcmp(b, "BAM\1", 4) != 0) return bad("not a BAM file");
+  const uint32_t l_text = le32(b + 4);
+  std::vector<uint8_t> text(l_text);
+  if (l_text && z.read(text.data(), l_text) != 1) return bad("truncated BAM header");
+  if (z.read(b, 4) != 1) return bad("truncated BAM header");
+  const uint32_t n_ref = le32(b);
+  for (uint32_t r = 0; r < n_ref; ++r) {
+    if (z.read(b, 4) != 1) return bad("truncated BAM header");
+    const uint32_t l_name = le32(b);
+    std::string name(l_name, '\0');
+    if (l_name && z.read(&name[0], l_name) != 1) return bad("truncated BAM header");
+    if (z.read(b, 4) != 1) return bad("truncated BAM header");
+    if (!name.empty() && name.back() == '\0') name.pop_back();
+    h->ref_id[name] = (int)r;
+    h->ref_names.push_back(name);
+  }
+  h->first_record_voff = z.tell();
+  std::string e;
+  if (!h->bai.load(std::string(bam_path) + ".bai", e)) return bad(e);
+  if (!h->fasta.open(fasta_path, e)) return bad(e);
+  *out = h.release();
+  return TRGT_OK;
+}
+
+void trgt_ingest_close(trgt_ingest* h) { delete h; }
+
+void trgt_ingest_default_params(trgt_ingest_params* p) {
+  if (!p) return;
+  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2;
+}
+
+void trgt_ingest_free(trgt_ingest_batch* b) {
+  if (!b) return;
+  delete reinterpret_cast<BatchStore*>(b->owner);
+}
+
+// one line of the repeat catalog (BED: contig, start, end, ID=..;MOTIFS=..;STRUC=..), locus.rs:31-98
+static bool parse_bed_line(const std::string& line, std::string& contig, int64_t& start, int64_t& end, std::string& id, std::vector<std::string>& motifs,
+                           std::string& struc, std::string& err) {
+  std::vector<std::string> f;
+  { std::istringstream ss(line); std::string t; while (ss >> t) f.push_back(t); }
+  if (f.size() != 4) { err = "Expected 4 fields in the format 'chrom start end info', found " + std::to_string(f.size()) + ": " + line; return false; }
+  contig = f[0];
+  try { start = std::stoll(f[1]); end = std::stoll(f[2]); } catch (...) { err = "Invalid region: " + line; return false; }
+  std::map<std::string, std::string> fields;
+  { std::istringstream ss(f[3]); std::string kv;
+    while (std::getline(ss, kv, ';')) {
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) { err = "Field must be in 'name=value' format: '" + kv + "'"; return false; }
+      if (!fields.emplace(kv.substr(0, eq), kv.substr(eq + 1)).second) { err = "Duplicate field name: '" + kv.substr(0, eq) + "'"; return false; }
+    } }
+  for (const char* key : {"ID", "MOTIFS", "STRUC"}) if (!fields.count(key)) { err = std::string(key) + " field missing"; return false; }
+  id = fields["ID"]; struc = fields["STRUC"];
+  motifs.clear();
+  { std::istringstream ss(fields["MOTIFS"]); std::string m; while (std::getline(ss, m, ',')) motifs.push_back(m); }
+  return true;
+}
+
+int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus, int64_t max_loci,
+                                   trgt_ingest_batch** out) {
+  if (!h || !p || !bed_path || !out) return TRGT_ERR_INVALID;
+  *out = nullptr;
+  auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
+  if (p->flank_len <= 0 || p->max_depth <= 0) return bad("trgt_ingest: flank_len and max_depth must be positive");
+  std::ifstream bed(bed_path);
+  if (!bed) return bad(std::string("cannot open ") + bed_path);
+  struct L { std::string contig, id, struc; int64_t start, end; std::vector<std::string> motifs; std::string lf, tr, rf; std::vector<Read> reads; int32_t n_filt = 0; int64_t n_seen = 0; std::string err; };
+  std::vector<L> loci;
+  {
+    std::string line; int64_t idx = 0, line_no = 0;
+    while (std::getline(bed, line)) {
+      ++line_no;
+      if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+      if (idx++ < first_locus) continue;
+      if (max_loci >= 0 && (int64_t)loci.size() >= max_loci) break;
+      L l; std::string e;
+      if (!parse_bed_line(line, l.contig, l.start, l.end, l.id, l.motifs, l.struc, e)) return bad("Error at BED line " + std::to_string(line_no) + ": " + e);
+      // get_tr_and_flanks (locus.rs:168-190)
+      if (l.start < p->flank_len) return bad("Error at BED line " + std::to_string(line_no) + ": flank of " + l.id + " leaves the contig");
+      if (!h->fasta.fetch(l.contig, l.start - p->flank_len, l.start, l.lf, e) || !h->fasta.fetch(l.contig, l.start, l.end, l.tr, e) ||
+          !h->fasta.fetch(l.contig, l.end, l.end + p->flank_len, l.rf, e))
+        return bad("Error at BED line " + std::to_string(line_no) + ": " + e);
+      loci.push_back(std::move(l));
+    }
+  }
+  const int64_t nl = (int64_t)loci.size();
+  // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
+  int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, nl));
+  std::atomic<int64_t> next{0};
+  auto work = [&]() {
+    Bgzf z;
+    if (!z.open(h->bam_path.c_str())) { for (auto& l : loci) if (l.err.empty()) { l.err = z.err; break; } return; }
+    RawRec rec;
+    for (;;) {
+      const int64_t li = next.fetch_add(1);
+      if (li >= nl) break;
+      L& l = loci[(size_t)li];
+      auto it = h->ref_id.find(l.contig);
+      if (it == h->ref_id.end()) continue;  // "Fetch error" is a warning in the reference: the locus gets no reads
+      const int tid = it->second;
+      const int64_t beg = std::max<int64_t>(0, l.start - p->flank_len), end = l.end + p->flank_len;
+      const int64_t reservoir = 3ll * p->max_depth;
+      std::unique_ptr<StdRng> rng;
+      int64_t n_reads = 0;
+      bool stop = false;
+      for (auto& ch : h->bai.query(tid, beg, end)) {
+        if (stop) break;
+        if (!z.seek(ch.first)) { l.err = z.err; break; }
+        while (z.tell() < ch.second) {
+          uint8_t b4[4];
+          const int g = z.read(b4, 4);
+          if (g == 0) break;
+          if (g < 0) { l.err = z.err; stop = true; break; }
+          rec.d.resize(le32(b4));
+          if (z.read(rec.d.data(), rec.d.size()) != 1 || !parse_rec(rec)) { l.err = z.err.empty() ? "corrupt BAM record" : z.err; stop = true; break; }
+          if (rec.ref_id != tid || rec.pos >= end) { stop = true; break; }  // sorted: nothing further overlaps
+          int64_t rend = rec_ref_end(rec);
+          if (rend == rec.pos) rend = rec.pos + 1;
+          if (rend <= beg) continue;
+          if (rec.flag & (0x800 | 0x100)) continue;  // supplementary / secondary
+          { const uint8_t* a = find_aux(rec, "rq"); float f = 1.0f; if (a && a[0] == 'f') std::memcpy(&f, a + 1, 4);
+            if ((a && a[0] == 'f' ? (double)f : 1.0) < p->min_read_qual) { ++l.n_filt; continue; } }
+          if (n_reads < reservoir) { l.reads.emplace_back(); make_read(rec, l.start, l.end, l.reads.back()); }
+          else {  // the reservoir is full: every further read replaces a random one with probability reservoir / (n + 1)
+            if (!rng) rng.reset(new StdRng(42));
+            const uint64_t j = rng->range((uint64_t)n_reads);
+            if ((int64_t)j < reservoir) make_read(rec, l.start, l.end, l.reads[(size_t)j]);
+          }
+          ++n_reads;
+        }
+      }
+      l.n_seen = n_reads;
+      // clip_reads (tr.rs:186-196): radius 2 * flank_len
+      const int64_t rs = l.start - 2ll * p->flank_len, re = l.end + 2ll * p->flank_len;
+      std::vector<Read> clipped;
+      for (auto& r : l.reads) { Read c; if (clip_to_region(r, rs, re, c)) clipped.push_back(std::move(c)); }
+      l.reads.swap(clipped);
+    }
+  };
+  if (nthr <= 1) work();
+  else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
+  for (auto& l : loci) if (!l.err.empty()) return bad(l.id + ": " + l.err);
+  // ---- the arrays of trgt_locus_batch_in (+ what the writers need per read)
+  std::unique_ptr<BatchStore> S(new BatchStore());
+  S->lrb.push_back(0); S->motif_off.push_back(0); S->set_begin.push_back(0); S->name_off.push_back(0); S->moff.push_back(0); S->snp_off.push_back(0);
+  S->contig_off.push_back(0); S->id_off.push_back(0); S->struc_off.push_back(0); S->cig_off.push_back(0);
+  for (auto& l : loci) {
+    S->lf_off.push_back(S->flank.size()); S->lf_len.push_back((uint32_t)l.lf.size()); S->flank += l.lf;
+    S->rf_off.push_back(S->flank.size()); S->rf_len.push_back((uint32_t)l.rf.size()); S->flank += l.rf;
+    S->tr_off.push_back(S->tr.size()); S->tr_len.push_back((uint32_t)l.tr.size()); S->tr += l.tr;
+    for (auto& m : l.motifs) { S->motifs += m; S->motif_off.push_back((uint32_t)S->motifs.size()); }
+    S->set_begin.push_back((uint32_t)S->motif_off.size() - 1);
+    S->ploidy.push_back((uint8_t)p->default_ploidy); S->genotyper.push_back((uint8_t)p->genotyper);
+    S->contigs += l.contig; S->contig_off.push_back(S->contigs.size()); S->ids += l.id; S->id_off.push_back(S->ids.size());
+    S->strucs += l.struc; S->struc_off.push_back(S->strucs.size());
+    S->region_start.push_back(l.start); S->region_end.push_back(l.end); S->n_filtered.push_back(l.n_filt); S->n_seen.push_back(l.n_seen);
+    for (auto& r : l.reads) {
+      S->read_off.push_back(S->reads.size()); S->read_len.push_back((uint32_t)r.bases.size()); S->reads += r.bases;
+      S->quals.append((const char*)r.quals.data(), r.quals.size());
+      S->names += r.id; S->name_off.push_back(S->names.size());
+      S->rq.push_back(r.rq); S->is_reverse.push_back(r.is_reverse ? 1 : 0); S->mapq.push_back(r.mapq); S->hp.push_back((int16_t)r.hp);
+      S->start_offset.push_back(r.start_offset); S->end_offset.push_back(r.end_offset);
+      S->snp.insert(S->snp.end(), r.mismatch_offsets.begin(), r.mismatch_offsets.end()); S->snp_off.push_back(S->snp.size());
+      if (r.has_meth) S->meth.insert(S->meth.end(), r.meth.begin(), r.meth.end());
+      S->moff.push_back(r.has_meth ? S->meth.size() : (S->moff.back() | (1ull << 63)));  // (bit 63: this read has no methylation profile)
+      S->cig.insert(S->cig.end(), r.cigar.begin(), r.cigar.end()); S->cig_off.push_back(S->cig.size()); S->cig_ref_pos.push_back(r.ref_pos);
+    }
+    S->lrb.push_back(S->read_off.size());
+  }
+  // (the meth offsets carry a flag bit: strip it into a clean CSR + a flag array)
+  S->has_meth.assign(S->read_off.size(), 1);
+  { uint64_t last = 0; for (size_t r = 0; r < S->read_off.size(); ++r) { uint64_t v = S->moff[r + 1]; if (v >> 63) { S->has_meth[r] = 0; v = last; } S->moff[r + 1] = v; last = v; } }
+  trgt_ingest_batch& B = S->pub;
+  std::memset(&B, 0, sizeof B);
+  auto u8 = [](const std::string& s) { return (const uint8_t*)s.data(); };
+  if (S->flank.empty()) S->flank.push_back('\0');
+  if (S->tr.empty()) S->tr.push_back('\0');
+  if (S->reads.empty()) S->reads.push_back('\0');
+  B.n_loci = nl; B.n_reads = (int64_t)S->read_off.size(); B.n_motifs = (int64_t)S->motif_off.size() - 1;
+  B.flank_bytes = S->flank.size(); B.tr_bytes = S->tr.size(); B.motif_bytes = S->motifs.size(); B.read_bytes = S->reads.size();
+  B.flank_blob = u8(S->flank); B.lf_off = S->lf_off.data(); B.lf_len = S->lf_len.data(); B.rf_off = S->rf_off.data(); B.rf_len = S->rf_len.data();
+  B.tr_blob = u8(S->tr); B.tr_off = S->tr_off.data(); B.tr_len = S->tr_len.data();
+  B.motif_blob = u8(S->motifs); B.motif_off = S->motif_off.data(); B.set_motif_begin = S->set_begin.data();
+  B.ploidy = S->ploidy.data(); B.genotyper = S->genotyper.data(); B.locus_read_begin = S->lrb.data();
+  B.read_blob = u8(S->reads); B.read_off = S->read_off.data(); B.read_len = S->read_len.data(); B.read_qual = S->rq.data();
+  B.qual_blob = u8(S->quals); B.name_blob = S->names.data(); B.name_off = S->name_off.data();
+  B.is_reverse = S->is_reverse.data(); B.mapq = S->mapq.data(); B.hp_tag = S->hp.data(); B.has_meth = S->has_meth.data();
+  B.start_offset = S->start_offset.data(); B.end_offset = S->end_offset.data();
+  B.mismatch_offsets = S->snp.data(); B.mismatch_off = S->snp_off.data();
+  B.meth = S->meth.data(); B.meth_off = S->moff.data();
+  B.n_quality_filtered = S->n_filtered.data(); B.n_reads_seen = S->n_seen.data();
+  B.contig_blob = S->contigs.data(); B.contig_off = S->contig_off.data(); B.id_blob = S->ids.data(); B.id_off = S->id_off.data();
+  B.struc_blob = S->strucs.data(); B.struc_off = S->struc_off.data(); B.region_start = S->region_start.data(); B.region_end = S->region_end.data();
+  B.cigar = S->cig.data(); B.cigar_off = S->cig_off.data(); B.cigar_ref_pos = S->cig_ref_pos.data();
+  B.owner = S.release();
+  *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
+  return TRGT_OK;
+}
+
+}  // extern "C"

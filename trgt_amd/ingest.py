@@ -1,0 +1,125 @@
+"""Native read ingestion (trgt_amd/csrc/ingest.hip through the C ABI): repeat catalog + indexed FASTA + indexed BAM -> the arrays of
+trgt_locus_batch_in, i.e. analyze_tr up to clip_reads (src/trgt/workflows/tr.rs:24-35, 186-196, 268-361; locus.rs:31-98, 168-190;
+reads/read.rs:55-141; reads/snp.rs:51-79; reads/clip_region.rs:19-184).  trgt_amd/reads.py is the Python mirror of the same steps."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class IngestParams(C.Structure):
+    _fields_ = [("flank_len", C.c_int32), ("max_depth", C.c_int32), ("min_read_qual", C.c_double), ("threads", C.c_int32),
+                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32)]
+
+
+_P8, _P16, _P32, _P64, _PD, _PC = (C.POINTER(t) for t in (C.c_uint8, C.c_int16, C.c_uint32, C.c_uint64, C.c_double, C.c_char))
+_PI32, _PI64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+
+class IngestBatch(C.Structure):
+    _fields_ = [("n_loci", C.c_int64), ("n_reads", C.c_int64), ("n_motifs", C.c_int64),
+                ("flank_bytes", C.c_uint64), ("tr_bytes", C.c_uint64), ("motif_bytes", C.c_uint64), ("read_bytes", C.c_uint64),
+                ("flank_blob", _P8), ("lf_off", _P64), ("lf_len", _P32), ("rf_off", _P64), ("rf_len", _P32),
+                ("tr_blob", _P8), ("tr_off", _P64), ("tr_len", _P32),
+                ("motif_blob", _P8), ("motif_off", _P32), ("set_motif_begin", _P32),
+                ("ploidy", _P8), ("genotyper", _P8), ("locus_read_begin", _P64),
+                ("read_blob", _P8), ("read_off", _P64), ("read_len", _P32), ("read_qual", _PD),
+                ("contig_blob", _PC), ("contig_off", _P64), ("id_blob", _PC), ("id_off", _P64),
+                ("struc_blob", _PC), ("struc_off", _P64), ("region_start", _PI64), ("region_end", _PI64),
+                ("n_quality_filtered", _PI32), ("n_reads_seen", _PI64),
+                ("qual_blob", _P8), ("name_blob", _PC), ("name_off", _P64),
+                ("is_reverse", _P8), ("mapq", _P8), ("hp_tag", _P16),
+                ("start_offset", _PI32), ("end_offset", _PI32),
+                ("mismatch_offsets", _PI32), ("mismatch_off", _P64),
+                ("meth", _P8), ("meth_off", _P64), ("has_meth", _P8),
+                ("cigar", _P32), ("cigar_off", _P64), ("cigar_ref_pos", _PI64),
+                ("owner", C.c_void_p)]
+
+
+def _arr(ptr, n, dtype):
+    if n <= 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).view(dtype).copy()
+
+
+def _strings(blob, off, n):
+    o = _arr(off, n + 1, np.uint64)
+    raw = C.string_at(blob, int(o[-1])) if n and int(o[-1]) else b""
+    return [raw[int(o[i]):int(o[i + 1])].decode() for i in range(n)]
+
+
+class Reader:
+    """An indexed BAM (<bam>.bai) and an indexed FASTA (<fasta>.fai)."""
+
+    def __init__(self, bam_path, fasta_path):
+        L = _lib.lib()
+        L.trgt_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.trgt_ingest_close.argtypes = [C.c_void_p]
+        L.trgt_ingest_close.restype = None
+        L.trgt_ingest_last_error.argtypes = [C.c_void_p]
+        L.trgt_ingest_last_error.restype = C.c_char_p
+        L.trgt_ingest_default_params.argtypes = [C.POINTER(IngestParams)]
+        L.trgt_ingest_default_params.restype = None
+        L.trgt_ingest_batch_from_catalog.argtypes = [C.c_void_p, C.POINTER(IngestParams), C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.POINTER(IngestBatch))]
+        L.trgt_ingest_free.argtypes = [C.POINTER(IngestBatch)]
+        L.trgt_ingest_free.restype = None
+        self._L = L
+        self.handle = C.c_void_p()
+        rc = L.trgt_ingest_open(str(bam_path).encode(), str(fasta_path).encode(), C.byref(self.handle))
+        if rc != 0:
+            msg = L.trgt_ingest_last_error(self.handle).decode() if self.handle else "trgt_ingest_open failed"
+            if self.handle:
+                L.trgt_ingest_close(self.handle)
+                self.handle = C.c_void_p()
+            raise _lib.TrgtHipError("trgt_ingest_open: %s" % msg)
+
+    def close(self):
+        if self.handle:
+            self._L.trgt_ingest_close(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def batch(self, bed_path, first_locus=0, max_loci=-1, **params):
+        """Loci [first_locus, first_locus + max_loci) of the catalog as the dict of ABI arrays trgt_amd.locus.run_batch takes (the keys
+        of synth.generate) plus the catalog fields and the per-read HiFiRead fields the writers need."""
+        p = IngestParams()
+        self._L.trgt_ingest_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        h = C.POINTER(IngestBatch)()
+        rc = self._L.trgt_ingest_batch_from_catalog(self.handle, C.byref(p), str(bed_path).encode(), first_locus, max_loci, C.byref(h))
+        if rc != 0:
+            raise _lib.TrgtHipError("trgt_ingest: %s" % self._L.trgt_ingest_last_error(self.handle).decode())
+        b = h.contents
+        nl, nr, nm = int(b.n_loci), int(b.n_reads), int(b.n_motifs)
+        u8, u32, u64 = np.uint8, np.uint32, np.uint64
+        out = dict(n_loci=nl, n_reads=nr, n_motifs=nm,
+                   flank_blob=_arr(b.flank_blob, b.flank_bytes, u8), lf_off=_arr(b.lf_off, nl, u64), lf_len=_arr(b.lf_len, nl, u32),
+                   rf_off=_arr(b.rf_off, nl, u64), rf_len=_arr(b.rf_len, nl, u32),
+                   tr_blob=_arr(b.tr_blob, b.tr_bytes, u8), tr_off=_arr(b.tr_off, nl, u64), tr_len=_arr(b.tr_len, nl, u32),
+                   motif_blob=_arr(b.motif_blob, b.motif_bytes, u8), motif_off=_arr(b.motif_off, nm + 1, u32),
+                   set_motif_begin=_arr(b.set_motif_begin, nl + 1, u32), ploidy=_arr(b.ploidy, nl, u8), genotyper=_arr(b.genotyper, nl, u8),
+                   locus_read_begin=_arr(b.locus_read_begin, nl + 1, u64),
+                   read_blob=_arr(b.read_blob, b.read_bytes, u8), read_off=_arr(b.read_off, nr, u64), read_len=_arr(b.read_len, nr, u32),
+                   read_qual=_arr(b.read_qual, nr, np.float64),
+                   contig=_strings(b.contig_blob, b.contig_off, nl), id=_strings(b.id_blob, b.id_off, nl), struc=_strings(b.struc_blob, b.struc_off, nl),
+                   region_start=_arr(b.region_start, nl, np.int64), region_end=_arr(b.region_end, nl, np.int64),
+                   n_quality_filtered=_arr(b.n_quality_filtered, nl, np.int32), n_reads_seen=_arr(b.n_reads_seen, nl, np.int64),
+                   qual_blob=_arr(b.qual_blob, int(_arr(b.read_len, nr, u32).sum()) if nr else 0, u8), read_name=_strings(b.name_blob, b.name_off, nr),
+                   is_reverse=_arr(b.is_reverse, nr, u8), mapq=_arr(b.mapq, nr, u8), hp_tag=_arr(b.hp_tag, nr, np.int16),
+                   start_offset=_arr(b.start_offset, nr, np.int32), end_offset=_arr(b.end_offset, nr, np.int32),
+                   mismatch_off=_arr(b.mismatch_off, nr + 1, u64), meth_off=_arr(b.meth_off, nr + 1, u64), has_meth=_arr(b.has_meth, nr, u8),
+                   cigar_off=_arr(b.cigar_off, nr + 1, u64), cigar_ref_pos=_arr(b.cigar_ref_pos, nr, np.int64))
+        out["mismatch_offsets"] = _arr(b.mismatch_offsets, int(out["mismatch_off"][-1]) if nr else 0, np.int32)
+        out["meth"] = _arr(b.meth, int(out["meth_off"][-1]) if nr else 0, u8)
+        out["cigar"] = _arr(b.cigar, int(out["cigar_off"][-1]) if nr else 0, u32)
+        if len(out["read_blob"]) == 0:
+            out["read_blob"] = np.zeros(1, u8)
+        self._L.trgt_ingest_free(h)
+        return out
