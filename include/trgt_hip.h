@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 3
+#define TRGT_HIP_ABI_VERSION 4
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -223,6 +223,14 @@ typedef struct trgt_locus_batch_in {   /* Locus (locus.rs:13-23) x n_loci, reads
   const uint8_t* genotyper;            /* optional, per locus: 0 Genotyper::Size, 1 Genotyper::Cluster (locus.rs:25-29); NULL = all Size */
   const double* read_qual;             /* optional, per read: HiFiRead::read_qual, NaN = None; NULL = None for every read.
                                           Only looked at when min_read_qual < 0.9. */
+  /* optional, per read: what genotype_flank::genotype reads (src/trgt/genotype/genotype_flank.rs:9-290).  A locus with two alleles at
+   * most 10 bases apart is genotyped again from the haplotype tags or from heterozygous SNVs of the flanks (tr.rs:69-75) when hp_tag or
+   * mismatch_offsets is given; with both NULL the step cannot change anything (no tags, no mismatches: it returns None) and is skipped. */
+  const int16_t* hp_tag;               /* HiFiRead::hp_tag, -1 = None */
+  const int32_t* start_offset;         /* alignment start - region start; NULL = 0 */
+  const int32_t* end_offset;           /* alignment end - region end; NULL = 0 */
+  const int32_t* mismatch_offsets;     /* HiFiRead::mismatch_offsets (snp.rs:51-79), ascending per read */
+  const uint64_t* mismatch_off;        /* [n_reads + 1] into mismatch_offsets */
 } trgt_locus_batch_in;
 
 typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x n_loci; all HOST, caller-allocated */

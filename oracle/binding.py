@@ -247,7 +247,8 @@ def find_spans(piece, reads, mism=2, gapo=5, gape=1, threshold=175.0):
 
 
 def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250, min_flank_id_frac=0.7, max_depth=250,
-                  scoring=(2, 5, 1), ploidy=2, genotyper=0, min_read_qual=0.98, read_qual=None):
+                  scoring=(2, 5, 1), ploidy=2, genotyper=0, min_read_qual=0.98, read_qual=None, meta=None):
+    """meta: dict(hp_tag, start_offset, end_offset, mismatch_offsets (list of lists)) per input read -> genotype_flank runs (tr.rs:69-75)"""
     p = LocusParams(flank_len, min_flank_id_frac, max_depth, scoring[0], scoring[1], scoring[2], ploidy, genotyper, min_read_qual)
     rq = None if read_qual is None else np.ascontiguousarray(read_qual, np.float64)
     mb, mo = motif_blob(motifs)
@@ -267,10 +268,12 @@ def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250,
     scap = 64 * 1024
     mc, ms, ap = C.create_string_buffer(scap), C.create_string_buffer(scap), C.create_string_buffer(scap)
     stats = np.zeros(8, np.int64)
-    rc = lib().orc_locus_analyze(C.byref(p), _p(lf), len(lf), _p(rf), len(rf), _p(tr), len(tr), _p(mb), _p(mo), len(motifs),
-                                 C.c_int64(n), _p(blob), _p(off), _p(lens), _p(ss), _p(se), C.byref(n_alleles), a0, a1, cap,
-                                 _p(gt_size), _p(gt_ci), C.byref(n_sp), _p(kept), _p(cls), _p(by_hap), mc, ms, ap, scap,
-                                 _p(stats), _p(rq) if rq is not None else None)
+    keep = []
+    cm = _read_meta(meta.get("hp_tag"), meta["start_offset"], meta["end_offset"], meta["mismatch_offsets"], keep) if meta is not None else None
+    rc = lib().orc_locus_analyze_meta(C.byref(p), _p(lf), len(lf), _p(rf), len(rf), _p(tr), len(tr), _p(mb), _p(mo), len(motifs),
+                                      C.c_int64(n), _p(blob), _p(off), _p(lens), _p(ss), _p(se), C.byref(n_alleles), a0, a1, cap,
+                                      _p(gt_size), _p(gt_ci), C.byref(n_sp), _p(kept), _p(cls), _p(by_hap), mc, ms, ap, scap,
+                                      _p(stats), _p(rq) if rq is not None else None, C.byref(cm) if cm is not None else None)
     assert rc == 0, rc
     na, k = n_alleles.value, n_sp.value
     alleles = [a0.value.decode(), a1.value.decode()][:na]
@@ -283,6 +286,44 @@ def locus_analyze(left_flank, right_flank, ref_tr, motifs, reads, flank_len=250,
                 stats=dict(wfa_cells=int(stats[0]), viterbi_cells=int(stats[1]), n_wfa_flank=int(stats[2]),
                            n_wfa_cons=int(stats[3]), bytes_io=int(stats[4]), n_wfa_ed=int(stats[5]),
                            n_purity=int(stats[6])))
+
+
+class ReadMeta(C.Structure):
+    _fields_ = [("hp_tag", C.c_void_p), ("start_offset", C.c_void_p), ("end_offset", C.c_void_p), ("mismatch_offsets", C.c_void_p),
+                ("mismatch_off", C.c_void_p)]
+
+
+def _read_meta(hp_tag, start_offset, end_offset, mismatch_lists, keep):
+    """orc_read_meta from per-read Python values; `keep` collects the arrays that must outlive the call"""
+    n = len(mismatch_lists)
+    hp = np.array([-1 if v is None else v for v in (hp_tag if hp_tag is not None else [None] * n)], np.int16)
+    so, eo = np.ascontiguousarray(start_offset, np.int32), np.ascontiguousarray(end_offset, np.int32)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(m) for m in mismatch_lists])
+    mm = np.array([v for m in mismatch_lists for v in m] + [0], np.int32)
+    keep += [hp, so, eo, off, mm]
+    return ReadMeta(hp.ctypes.data, so.ctypes.data, eo.ctypes.data, mm.ctypes.data, off.ctypes.data)
+
+
+def genotype_flank(trs, hp_tag, start_offset, end_offset, mismatch_lists):
+    """genotype_flank::genotype (genotype_flank.rs:9-42) -> None or dict(gt=[(size, (lo, hi))], alleles, assignment)"""
+    n = len(trs)
+    keep = []
+    meta = _read_meta(hp_tag, start_offset, end_offset, mismatch_lists, keep)
+    blob = _u8(b"".join(trs))
+    lens = np.array([len(t) for t in trs], np.uint32)
+    off = np.zeros(max(n, 1), np.uint64)
+    if n > 1:
+        off[1:] = np.cumsum(lens[:-1])
+    cap = int(sum(len(t) for t in trs)) + 64
+    a0, a1 = C.create_string_buffer(cap), C.create_string_buffer(cap)
+    sizes, ci, asg = np.zeros(2, np.int32), np.zeros(4, np.int32), np.zeros(max(n, 1), np.int32)
+    rc = lib().orc_genotype_flank(n, _p(blob), _p(off), _p(lens), C.byref(meta), _p(sizes), _p(ci), a0, a1, cap, _p(asg))
+    assert rc >= 0, rc
+    if rc == 0:
+        return None
+    return dict(gt=[(int(sizes[a]), (int(ci[2 * a]), int(ci[2 * a + 1]))) for a in range(2)], alleles=[a0.value.decode(), a1.value.decode()],
+                assignment=[int(v) for v in asg[:n]])
 
 
 def locus_analyze_many(batch, first, n, threads, flank_len=250, min_flank_id_frac=0.7, max_depth=250, scoring=(2, 5, 1)):

@@ -18,9 +18,10 @@
 //                                   the in-place mutation of the distance matrix (read back by central_read,
 //                                   genotype_cluster.rs:27-29,74,82-83) follows the NN-chain update order.
 //   MC / MS / AP / AL / ALLR / SD   src/trgt/writers/write_vcf.rs:286-377
-// genotype_flank::genotype (tr.rs:70-75) returns None for such reads (no HP
-// tags -> get_trs_with_hp None; no mismatch offsets -> one candidate genotype,
-// genotype_flank.rs:70-95), so it is inert here and not restated.
+//   genotype_flank::genotype        src/trgt/genotype/genotype_flank.rs:9-290 (tr.rs:69-75), pinned by its two inline tests
+//                                   (tests/golden/caller_kats.json F1 / F2).  Runs when the caller passes the per-read fields it
+//                                   reads (orc_locus_analyze_meta); for reads without HP tags and mismatch offsets it returns None
+//                                   (get_trs_with_hp needs 70 % tagged reads, a single candidate genotype is "homozygous").
 #include "oracle_internal.h"
 
 #include <cassert>
@@ -246,6 +247,119 @@ static SizeGt genotype_size(int ploidy, const std::vector<std::string>& seqs, in
   }
   out.alleles = alleles;
   return out;
+}
+
+
+// ---- genotype_flank::genotype (src/trgt/genotype/genotype_flank.rs:9-290): re-genotyping of a locus with two alleles of similar
+// length from the haplotype tags of the reads or, failing that, from heterozygous SNVs in the flanks.
+struct FlankRead { int hp; int start_off, end_off; const int32_t* mm; size_t n_mm; };  // hp < 0: no HP tag
+struct FlankGt { std::vector<TrSize> gt; std::vector<std::string> alleles; std::vector<int> assignment; };
+typedef std::vector<int8_t> Profile;  // -1 None, 0 Some(false), 1 Some(true): Option<bool>'s derived order
+
+static double ln_sum_exp(double a, double b) { const double m = std::max(a, b); return m + std::log(std::exp(a - m) + std::exp(b - m)); }
+
+static bool flank_groups_hp(const std::vector<FlankRead>& reads, std::vector<int> groups[2], std::vector<int>& assignment) {  // :43-76
+  int tie = 1; size_t unassigned = 0;
+  for (size_t i = 0; i < reads.size(); ++i) {
+    if (reads[i].hp == 1) { assignment.push_back(0); groups[0].push_back((int)i); }
+    else if (reads[i].hp == 2) { assignment.push_back(1); groups[1].push_back((int)i); }
+    else { tie = (tie + 1) % 2; assignment.push_back(tie); groups[tie].push_back((int)i); ++unassigned; }
+  }
+  const double prop = (double)(reads.size() - unassigned) / (double)reads.size();
+  return !groups[0].empty() && !groups[1].empty() && prop >= 0.7;
+}
+
+static bool flank_groups_snv(const std::vector<FlankRead>& reads, std::vector<int> groups[2], std::vector<int>& assignment) {  // :78-138
+  const size_t n = reads.size();
+  if (n == 0) return false;
+  // get_analysis_region (:206-226)
+  const size_t skip = (size_t)std::round((double)n * (1.0 - 0.85));
+  std::vector<int> so, eo;
+  for (auto& r : reads) { so.push_back(r.start_off); eo.push_back(r.end_off); }
+  std::sort(so.begin(), so.end()); std::sort(eo.begin(), eo.end());
+  if (skip >= n) return false;  // (nth on too short an iterator: unwrap of None -- cannot happen, round(0.15 n) < n)
+  const int reg0 = so[n - 1 - skip], reg1 = eo[skip];
+  // call_snvs (:271-286)
+  std::map<int, size_t> counts;
+  for (auto& r : reads) for (size_t i = 0; i < r.n_mm; ++i) if (reg0 <= r.mm[i] && r.mm[i] <= reg1) counts[r.mm[i]] += 1;
+  std::vector<int> snvs;
+  for (auto& kv : counts) if ((double)kv.second / (double)n >= 0.20) snvs.push_back(kv.first);
+  // get_profiles (:250-269)
+  std::vector<Profile> prof(n);
+  for (size_t i = 0; i < n; ++i)
+    for (int snv : snvs) {
+      if (snv < reads[i].start_off || snv > reads[i].end_off) prof[i].push_back(-1);
+      else prof[i].push_back(std::binary_search(reads[i].mm, reads[i].mm + reads[i].n_mm, snv) ? 1 : 0);
+    }
+  // get_candidate_gts (:228-248)
+  std::vector<Profile> haps;
+  for (auto& p : prof) if (std::all_of(p.begin(), p.end(), [](int8_t v) { return v >= 0; })) haps.push_back(p);
+  std::sort(haps.begin(), haps.end());
+  if ((double)haps.size() / (double)n < 0.40) return false;
+  haps.erase(std::unique(haps.begin(), haps.end()), haps.end());
+  std::vector<std::pair<Profile, Profile>> cands;
+  for (size_t i = 0; i < haps.size(); ++i) for (size_t j = i; j < haps.size(); ++j) cands.push_back({haps[i], haps[j]});
+  if (cands.size() <= 1) return false;
+  auto eval = [&](const Profile& p, const Profile& h) { double s = 0.0; for (size_t k = 0; k < p.size() && k < h.size(); ++k) if (p[k] >= 0) s += p[k] == h[k] ? std::log(0.9) : std::log(1.0 - 0.9); return s; };
+  size_t top = 0; double top_ll = 0.0;
+  for (size_t c = 0; c < cands.size(); ++c) {
+    double ll = 0.0;
+    for (auto& p : prof) ll += ln_sum_exp(eval(p, cands[c].first), eval(p, cands[c].second)) - std::log(2.0);
+    if (c == 0 || ll >= top_ll) { top = c; top_ll = ll; }  // Iterator::max_by: the last maximum
+  }
+  if (cands[top].first == cands[top].second) return false;
+  auto dist = [](const Profile& p, const Profile& h) { size_t d = 0; for (size_t k = 0; k < p.size() && k < h.size(); ++k) d += p[k] >= 0 && p[k] == h[k]; return d; };
+  int tie = 1;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t d1 = dist(prof[i], cands[top].first), d2 = dist(prof[i], cands[top].second);
+    if (d1 < d2) { assignment.push_back(0); groups[0].push_back((int)i); }
+    else if (d1 > d2) { assignment.push_back(1); groups[1].push_back((int)i); }
+    else { tie = (tie + 1) % 2; assignment.push_back(tie); groups[0].push_back((int)i); groups[1].push_back((int)i); }
+  }
+  return true;
+}
+
+static bool genotype_flank(const std::vector<FlankRead>& reads, const std::vector<std::string>& trs, FlankGt& out, int64_t* cells, int64_t* n_aln) {
+  std::vector<int> groups[2]; std::vector<int> assignment;
+  if (reads.empty()) return false;
+  if (!flank_groups_hp(reads, groups, assignment)) {
+    groups[0].clear(); groups[1].clear(); assignment.clear();
+    if (trs.empty() || !flank_groups_snv(reads, groups, assignment)) return false;
+  }
+  out = FlankGt();
+  for (int g = 0; g < 2; ++g) {
+    std::vector<std::string> seqs;
+    for (int i : groups[g]) seqs.push_back(trs[(size_t)i]);
+    if (seqs.empty()) return false;  // median of nothing: simple_consensus returns None
+    // simple_consensus (:147-170): utils::median is an f32 -- (a + b) as f32 / 2.0 for an even count -- truncated to usize
+    std::vector<int> lens;
+    for (auto& q : seqs) lens.push_back((int)q.size());
+    std::sort(lens.begin(), lens.end());
+    const float med = lens.size() % 2 ? (float)lens[lens.size() / 2] : (float)(lens[lens.size() / 2 - 1] + lens[lens.size() / 2]) / 2.0f;
+    const size_t median_len = (size_t)med;
+    std::map<std::string, size_t> cnt;
+    for (auto& q : seqs) cnt[q] += 1;
+    size_t top = 0;
+    for (auto& kv : cnt) top = std::max(top, kv.second);
+    const std::string* best = nullptr; size_t best_delta = 0;
+    for (auto& kv : cnt) {
+      if (kv.second != top) continue;
+      const size_t d = kv.first.size() > median_len ? kv.first.size() - median_len : median_len - kv.first.size();
+      if (!best || d < best_delta) { best = &kv.first; best_delta = d; }  // min_by_key: the first minimum
+    }
+    const double freq = (double)top / (double)seqs.size();
+    std::string allele = *best;
+    if (freq < 0.5) { auto al = align_all(*best, seqs, cells, n_aln); allele = repair_consensus(*best, seqs, al); }
+    const int lo = lens.front(), hi = lens.back();
+    out.gt.push_back(TrSize{(int)allele.size(), lo, hi});
+    out.alleles.push_back(allele);
+  }
+  out.assignment = assignment;
+  if (out.alleles[0].size() > out.alleles[1].size()) {  // smaller allele first
+    std::swap(out.gt[0], out.gt[1]); std::swap(out.alleles[0], out.alleles[1]);
+    for (int& a : out.assignment) a = (a + 1) % 2;
+  }
+  return true;
 }
 
 // ---- kodama 0.3.0 linkage(dists, n, Method::Ward), restated --------------------------------------------------------
@@ -506,6 +620,29 @@ int orc_cluster_groups(double* dists, int n, int32_t* group_of) {
   return (int)groups.size();
 }
 
+int orc_genotype_flank(int n, const uint8_t* tr_blob, const uint64_t* tr_off, const uint32_t* tr_len, const orc_read_meta* meta,
+                       int32_t* sizes, int32_t* ci, char* allele0, char* allele1, int allele_cap, int32_t* assignment) {
+  std::vector<FlankRead> fr; std::vector<std::string> trs;
+  for (int i = 0; i < n; ++i) {
+    FlankRead r;
+    r.hp = meta && meta->hp_tag ? (int)meta->hp_tag[i] : -1;
+    r.start_off = meta && meta->start_offset ? meta->start_offset[i] : 0; r.end_off = meta && meta->end_offset ? meta->end_offset[i] : 0;
+    r.mm = meta && meta->mismatch_offsets && meta->mismatch_off ? meta->mismatch_offsets + meta->mismatch_off[i] : nullptr;
+    r.n_mm = r.mm ? (size_t)(meta->mismatch_off[i + 1] - meta->mismatch_off[i]) : 0;
+    fr.push_back(r);
+    trs.emplace_back((const char*)tr_blob + tr_off[i], (size_t)tr_len[i]);
+  }
+  FlankGt fg; int64_t cells = 0, n_aln = 0;
+  if (!genotype_flank(fr, trs, fg, &cells, &n_aln)) return 0;
+  for (int a = 0; a < 2; ++a) {
+    sizes[a] = fg.gt[a].size; ci[2 * a] = fg.gt[a].ci_lo; ci[2 * a + 1] = fg.gt[a].ci_hi;
+    if ((int)fg.alleles[a].size() + 1 > allele_cap) return -1;
+    std::memcpy(a == 0 ? allele0 : allele1, fg.alleles[a].c_str(), fg.alleles[a].size() + 1);
+  }
+  for (int i = 0; i < n; ++i) assignment[i] = fg.assignment[(size_t)i];
+  return 1;
+}
+
 int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
                       const uint8_t* ref_tr, int ref_tr_len,
                       const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs, int64_t n_reads,
@@ -513,6 +650,18 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
                       int32_t* span_end, int32_t* n_alleles, char* allele0, char* allele1, int allele_cap, int32_t* gt_size,
                       int32_t* gt_ci, int32_t* n_spanning, int32_t* kept_read, int32_t* classification, int32_t* num_spanning_by_hap,
                       char* mc, char* ms, char* ap, int str_cap, int64_t* stats, const double* read_qual) {
+  return orc_locus_analyze_meta(p, left_flank, lf_len, right_flank, rf_len, ref_tr, ref_tr_len, motif_blob, motif_off, n_motifs, n_reads, read_blob, read_off,
+                                read_len, span_start, span_end, n_alleles, allele0, allele1, allele_cap, gt_size, gt_ci, n_spanning, kept_read, classification,
+                                num_spanning_by_hap, mc, ms, ap, str_cap, stats, read_qual, nullptr);
+}
+
+int orc_locus_analyze_meta(const orc_locus_params* p, const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
+                           const uint8_t* ref_tr, int ref_tr_len,
+                           const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs, int64_t n_reads,
+                           const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len, int32_t* span_start,
+                           int32_t* span_end, int32_t* n_alleles, char* allele0, char* allele1, int allele_cap, int32_t* gt_size,
+                           int32_t* gt_ci, int32_t* n_spanning, int32_t* kept_read, int32_t* classification, int32_t* num_spanning_by_hap,
+                           char* mc, char* ms, char* ap, int str_cap, int64_t* stats, const double* read_qual, const orc_read_meta* meta) {
   const int F = p->flank_len;
   int64_t wfa_cells = 0, vit_cells = 0, n_flank_wfa = 0, n_cons = 0, bytes_io = 0, n_ed = 0, n_purity = 0;
   *n_alleles = 0; *n_spanning = 0;
@@ -595,6 +744,20 @@ int orc_locus_analyze(const orc_locus_params* p, const uint8_t* left_flank, int 
     ClusterGt cg = genotype_cluster(p->ploidy, trs, &wfa_cells, &n_cons, &n_ed);
     g.gt = cg.gt; g.alleles = cg.alleles; g.classification = cg.classification;
   } else g = genotype_size(p->ploidy, trs, &wfa_cells, &n_cons);
+  // flank re-genotyping, only if the alleles have similar length (tr.rs:69-75)
+  if (meta && g.gt.size() == 2 && std::abs(g.gt[0].size - g.gt[1].size) <= 10) {
+    std::vector<FlankRead> fr;
+    for (auto& x : kept) {
+      FlankRead r;
+      r.hp = meta->hp_tag ? (int)meta->hp_tag[x.read] : -1;
+      r.start_off = meta->start_offset ? meta->start_offset[x.read] : 0; r.end_off = meta->end_offset ? meta->end_offset[x.read] : 0;
+      r.mm = meta->mismatch_offsets && meta->mismatch_off ? meta->mismatch_offsets + meta->mismatch_off[x.read] : nullptr;
+      r.n_mm = r.mm ? (size_t)(meta->mismatch_off[x.read + 1] - meta->mismatch_off[x.read]) : 0;
+      fr.push_back(r);
+    }
+    FlankGt fg;
+    if (genotype_flank(fr, trs, fg, &wfa_cells, &n_cons)) { g.gt = fg.gt; g.alleles = fg.alleles; g.classification = fg.assignment; }
+  }
   // label_with_hmm
   std::vector<Annotation> ann;
   for (auto& a : g.alleles) { ann.push_back(annotate_allele(hmm, motifs, a, nullptr, &vit_cells)); bytes_io += (int64_t)a.size(); }

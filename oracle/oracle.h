@@ -159,6 +159,29 @@ int orc_locus_analyze(const orc_locus_params* p,
                       int64_t* stats /* [8]: wfa_cells, viterbi_cells, n_wfa_flank, n_wfa_cons, bytes_io, n_wfa_ed, n_purity */,
                       const double* read_qual);
 
+/* ... with the per-read fields genotype_flank::genotype reads (HiFiRead::hp_tag, start_offset, end_offset, mismatch_offsets; reads/read.rs,
+ * genotype_flank.rs:9-290): the locus is re-genotyped from them when its two alleles differ by at most 10 bases (tr.rs:69-75).
+ * Arrays per INPUT read; any of them may be NULL (no HP tags / offsets 0 / no mismatches); meta NULL = orc_locus_analyze. */
+typedef struct orc_read_meta {
+  const int16_t* hp_tag;            /* -1 = None */
+  const int32_t* start_offset; const int32_t* end_offset;
+  const int32_t* mismatch_offsets; const uint64_t* mismatch_off;  /* CSR, [n_reads + 1] */
+} orc_read_meta;
+int orc_locus_analyze_meta(const orc_locus_params* p,
+                           const uint8_t* left_flank, int lf_len, const uint8_t* right_flank, int rf_len,
+                           const uint8_t* ref_tr, int ref_tr_len,
+                           const uint8_t* motif_blob, const uint32_t* motif_off, int n_motifs,
+                           int64_t n_reads, const uint8_t* read_blob, const uint64_t* read_off, const uint32_t* read_len,
+                           int32_t* span_start, int32_t* span_end, int32_t* n_alleles, char* allele0, char* allele1, int allele_cap,
+                           int32_t* gt_size, int32_t* gt_ci, int32_t* n_spanning, int32_t* kept_read, int32_t* classification,
+                           int32_t* num_spanning_by_hap, char* mc, char* ms, char* ap, int str_cap, int64_t* stats,
+                           const double* read_qual, const orc_read_meta* meta);
+
+/* flank re-genotyping alone (genotype_flank.rs:9-42) on n reads given by their repeat sequences and metadata: returns 1 and the
+ * genotype (sizes[2], ci[4], alleles, assignment[n]) or 0 for None */
+int orc_genotype_flank(int n, const uint8_t* tr_blob, const uint64_t* tr_off, const uint32_t* tr_len, const orc_read_meta* meta,
+                       int32_t* sizes, int32_t* ci, char* allele0, char* allele1, int allele_cap, int32_t* assignment);
+
 /* orc_locus_analyze over loci [first, first + n) of a batch in the trgt_locus_batch_in layout, on n_threads threads (static
  * partition).  Returns the number of loci analysed; cpu_baseline helper of bench.py. */
 int64_t orc_locus_analyze_many(const orc_locus_params* p, int64_t first, int64_t n, const uint8_t* flank_blob, const uint64_t* lf_off,

@@ -84,6 +84,24 @@ def main():
     assert len(heur) == 7, heur
     kats["wrapper_accessors"] = dict(src="src/wfaligner.rs:%d" % (wf[:wf.index("fn test_set_heuristic")].count("\n") + 1), penalties=pen,
                                      set_heuristic=heur)
+    # F1 / F2 genotype_flank.rs:343-390: reads given as encodings ('=' flank base, 'X' mismatching flank base, ACGT = the repeat; a
+    # read is the repeat bases, its mismatch offsets are the X positions relative to the start (left) / end (right) of the repeat,
+    # start_offset = -(bases before the repeat), end_offset = bases after it, no HP tag), expected Some((gt, alleles, assignment)) / None
+    gf = rs("src/trgt/genotype/genotype_flank.rs")
+    tests = gf[gf.index("mod tests"):]
+    flank = []
+    for m in re.finditer(r"fn (if_\w+)\(\) \{(.*?)\n    \}", tests, re.S):
+        name, body = m.group(1), m.group(2)
+        enc = re.findall(r'"([=XACGT]+)"', body[:body.index("let tr_seqs")])
+        exp = None
+        if "assert_eq!(result, None)" not in body:
+            gt = [dict(size=int(a), ci=[int(b), int(c)]) for a, b, c in re.findall(r"size: (\d+),\s*ci: \((\d+), (\d+)\)", body)]
+            alleles = re.findall(r'"([ACGT]+)"\.to_string\(\)', body)
+            assignment = ints(re.search(r"let assignment = vec!\[(.*?)\]", body).group(1))
+            exp = dict(gt=gt, alleles=alleles, assignment=assignment)
+        flank.append(dict(id=name, src="src/trgt/genotype/genotype_flank.rs:%d" % (gf[:gf.index("fn " + name)].count("\n") + 1), reads=enc, expected=exp))
+    assert [f["id"] for f in flank] == ["if_het_snvs_then_genotype", "if_hom_snvs_then_none"] and len(flank[0]["reads"]) == 6 and len(flank[1]["reads"]) == 4, flank
+    kats["genotype_flank"] = flank
     json.dump(kats, open(os.path.join(HERE, "caller_kats.json"), "w"), indent=1)
     print({k: (len(v) if isinstance(v, list) else {a: (len(b) if isinstance(b, list) else b) for a, b in v.items()}) for k, v in kats.items()})
 

@@ -70,3 +70,35 @@ def test_wrapper_accessor_kats():
     for h in KATS["wrapper_accessors"]["set_heuristic"]:
         a.set_heuristic(ctor[h["kind"]](*h["args"]))
         assert a.get_heuristics().kind == h["kind"] and list(a.get_heuristics().args) == h["args"]
+
+
+def decode_flank_read(enc):
+    """the read encoding of genotype_flank.rs:297-337 (see tests/golden/make_caller_kats.py): (repeat bases, mismatch offsets, start, end)"""
+    idx = [i for i, c in enumerate(enc) if c in "ACGT"]
+    s, e = idx[0], idx[-1] + 1
+    mm = [(i - s) if i < s else (i - e) for i, c in enumerate(enc) if c == "X"]
+    return enc[s:e].encode(), mm, -s, len(enc) - e
+
+
+def test_genotype_flank_kats(oracle):
+    for kat in KATS["genotype_flank"]:
+        rd = [decode_flank_read(e) for e in kat["reads"]]
+        got = oracle.genotype_flank([r[0] for r in rd], None, [r[2] for r in rd], [r[3] for r in rd], [r[1] for r in rd])
+        exp = kat["expected"]
+        if exp is None:
+            assert got is None, kat["id"]
+        else:
+            assert got == dict(gt=[(g["size"], tuple(g["ci"])) for g in exp["gt"]], alleles=exp["alleles"], assignment=exp["assignment"]), kat["id"]
+
+
+def test_genotype_flank_with_haplotype_tags(oracle):
+    # get_trs_with_hp (genotype_flank.rs:43-76): >= 70 % of the reads tagged, both haplotypes seen; untagged reads alternate
+    trs = [b"CAGCAGCAG", b"CAGCAGCAG", b"CAGCAGCAGCAG", b"CAGCAGCAGCAG", b"CAGCAGCAGCAG", b"CAGCAG", b"CAGCAGCAGCAGCAG"]
+    hp = [2, 2, 1, 1, 1, None, None]
+    z = [0] * len(trs)
+    got = oracle.genotype_flank(trs, hp, z, z, [[] for _ in trs])
+    # haplotype 1 -> allele index 0 = {12, 12, 12} + untagged #1 (tie-breaker 0), haplotype 2 -> {9, 9} + untagged #2; smaller first
+    assert got["alleles"] == ["CAGCAGCAG", "CAGCAGCAGCAG"] and got["assignment"] == [0, 0, 1, 1, 1, 1, 0]
+    assert got["gt"] == [(9, (9, 15)), (12, (6, 12))]
+    assert oracle.genotype_flank(trs, [1, 1, None, None, None, None, 2], z, z, [[] for _ in trs]) is None  # 3 of 7 tagged
+    assert oracle.genotype_flank(trs[:3], [1, 1, 1], z[:3], z[:3], [[], [], []]) is None                    # one haplotype only

@@ -57,7 +57,8 @@ _VP = C.c_void_p
 class LocusBatchIn(C.Structure):
     _fields_ = [("n_loci", C.c_int64)] + [(n, _VP) for n in (
         "flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off",
-        "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len", "genotyper", "read_qual")]
+        "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len", "genotyper", "read_qual",
+        "hp_tag", "start_offset", "end_offset", "mismatch_offsets", "mismatch_off")]
 
 
 class LocusBatchOut(C.Structure):
@@ -71,7 +72,8 @@ EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
-    "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
+    "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params",
+    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 

@@ -167,6 +167,114 @@ void genotype_size_front(int ploidy, int64_t locus, int thread, LocusWork& w, Sc
   }
 }
 
+// ---- genotype_flank::genotype (src/trgt/genotype/genotype_flank.rs:9-290; tr.rs:69-75): a locus with two alleles at most 10 bases apart
+// is genotyped again from the reads' haplotype tags or, without them, from heterozygous SNVs of the flanks.  Host work on the per-read
+// fields of trgt_locus_batch_in (hp_tag, start_offset, end_offset, mismatch offsets); a locus whose reads carry neither tags nor
+// mismatches leaves here in a few comparisons.  Reads are the kept spanning reads in LocusResult.reads order, given by their index
+// into the batch's read arrays.
+struct FlankMeta { const int16_t* hp; const int32_t* so; const int32_t* eo; const int32_t* mm; const uint64_t* mm_off; };
+struct FlankSplit { std::vector<uint32_t> group[2]; std::vector<int8_t> assignment; };  // positions in the read list
+
+bool flank_split(const FlankMeta& M, const uint32_t* reads, size_t n, FlankSplit& out) {
+  out.group[0].clear(); out.group[1].clear(); out.assignment.clear();
+  if (n == 0) return false;
+  // get_trs_with_hp (:43-76): tagged reads go to their haplotype, the others alternate; needs 70 % tagged and both haplotypes
+  if (M.hp) {
+    size_t untagged = 0; int tie = 1;
+    for (size_t i = 0; i < n; ++i) {
+      const int h = M.hp[reads[i]];
+      int a;
+      if (h == 1) a = 0; else if (h == 2) a = 1; else { tie = (tie + 1) % 2; a = tie; ++untagged; }
+      out.assignment.push_back((int8_t)a); out.group[a].push_back((uint32_t)i);
+    }
+    if (!out.group[0].empty() && !out.group[1].empty() && (double)(n - untagged) / (double)n >= 0.7) return true;
+    out.group[0].clear(); out.group[1].clear(); out.assignment.clear();
+  }
+  // get_trs_with_clustering (:78-138)
+  auto mm_begin = [&](size_t i) { return M.mm && M.mm_off ? M.mm + M.mm_off[reads[i]] : nullptr; };
+  auto mm_count = [&](size_t i) { return M.mm && M.mm_off ? (size_t)(M.mm_off[reads[i] + 1] - M.mm_off[reads[i]]) : (size_t)0; };
+  auto s_off = [&](size_t i) { return M.so ? M.so[reads[i]] : 0; };
+  auto e_off = [&](size_t i) { return M.eo ? M.eo[reads[i]] : 0; };
+  size_t any_mm = 0;
+  for (size_t i = 0; i < n; ++i) any_mm += mm_count(i);
+  if (any_mm == 0) return false;  // no SNV can be called: every profile is empty, one candidate genotype, "homozygous"
+  const size_t skip = (size_t)std::round((double)n * (1.0 - 0.85));  // get_analysis_region (:206-226)
+  if (skip >= n) return false;
+  std::vector<int32_t> so(n), eo(n);
+  for (size_t i = 0; i < n; ++i) { so[i] = s_off(i); eo[i] = e_off(i); }
+  std::sort(so.begin(), so.end()); std::sort(eo.begin(), eo.end());
+  const int32_t reg0 = so[n - 1 - skip], reg1 = eo[skip];
+  std::vector<int32_t> seen;  // call_snvs (:271-286): offsets inside the region carried by at least 20 % of the reads
+  for (size_t i = 0; i < n; ++i) { const int32_t* m = mm_begin(i); for (size_t k = 0; k < mm_count(i); ++k) if (reg0 <= m[k] && m[k] <= reg1) seen.push_back(m[k]); }
+  std::sort(seen.begin(), seen.end());
+  std::vector<int32_t> snvs;
+  for (size_t a = 0; a < seen.size();) { size_t b = a; while (b < seen.size() && seen[b] == seen[a]) ++b; if ((double)(b - a) / (double)n >= 0.20) snvs.push_back(seen[a]); a = b; }
+  const size_t ns = snvs.size();
+  // profiles (:250-269), one row of ns cells per read: 0 None, 1 Some(false), 2 Some(true) (the derived order of Option<bool>)
+  std::vector<uint8_t> prof(n * ns);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t* m = mm_begin(i); const size_t nm = mm_count(i);
+    for (size_t k = 0; k < ns; ++k) prof[i * ns + k] = (snvs[k] < s_off(i) || snvs[k] > e_off(i)) ? 0 : (std::binary_search(m, m + nm, snvs[k]) ? 2 : 1);
+  }
+  auto row = [&](size_t i) { return prof.data() + i * ns; };
+  // candidate genotypes (:228-248): pairs (i <= j) of the distinct fully observed profiles, needs 40 % of the reads fully observed
+  std::vector<size_t> full;
+  for (size_t i = 0; i < n; ++i) { bool all = true; for (size_t k = 0; k < ns; ++k) all = all && row(i)[k] != 0; if (all) full.push_back(i); }
+  if ((double)full.size() / (double)n < 0.40) return false;
+  std::sort(full.begin(), full.end(), [&](size_t a, size_t b) { return std::lexicographical_compare(row(a), row(a) + ns, row(b), row(b) + ns); });
+  full.erase(std::unique(full.begin(), full.end(), [&](size_t a, size_t b) { return std::equal(row(a), row(a) + ns, row(b)); }), full.end());
+  const size_t nh = full.size();
+  if (nh * (nh + 1) / 2 <= 1) return false;
+  const double ln_match = std::log(0.9), ln_mis = std::log(1.0 - 0.9), ln2 = std::log(2.0);
+  auto eval = [&](size_t i, size_t h) { double t = 0.0; for (size_t k = 0; k < ns; ++k) if (row(i)[k]) t += row(i)[k] == row(h)[k] ? ln_match : ln_mis; return t; };
+  size_t top1 = 0, top2 = 0; double top_ll = 0.0; bool first = true;
+  for (size_t a = 0; a < nh; ++a)
+    for (size_t b = a; b < nh; ++b) {
+      double ll = 0.0;
+      for (size_t i = 0; i < n; ++i) {
+        const double t1 = eval(i, full[a]), t2 = eval(i, full[b]), mx = std::max(t1, t2);
+        ll += (mx + std::log(std::exp(t1 - mx) + std::exp(t2 - mx))) - ln2;
+      }
+      if (first || ll >= top_ll) { first = false; top1 = full[a]; top2 = full[b]; top_ll = ll; }  // max_by: the last maximum
+    }
+  if (std::equal(row(top1), row(top1) + ns, row(top2))) return false;
+  auto agree = [&](size_t i, size_t h) { size_t d = 0; for (size_t k = 0; k < ns; ++k) d += row(i)[k] && row(i)[k] == row(h)[k]; return d; };
+  int tie = 1;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t d1 = agree(i, top1), d2 = agree(i, top2);
+    if (d1 < d2) { out.assignment.push_back(0); out.group[0].push_back((uint32_t)i); }
+    else if (d1 > d2) { out.assignment.push_back(1); out.group[1].push_back((uint32_t)i); }
+    else { tie = (tie + 1) % 2; out.assignment.push_back((int8_t)tie); out.group[0].push_back((uint32_t)i); out.group[1].push_back((uint32_t)i); }
+  }
+  return true;
+}
+
+// simple_consensus (:147-170) over the segments of a group: the most frequent sequence (among equals: length closest to the f32 median of
+// the lengths, truncated; among those the smallest sequence) and its relative frequency; false for an empty group
+bool flank_simple_consensus(const std::vector<Seg>& seqs, Seg& best, double& freq) {
+  if (seqs.empty()) return false;
+  std::vector<int32_t> lens;
+  for (auto& q : seqs) lens.push_back((int32_t)q.n);
+  std::sort(lens.begin(), lens.end());
+  const float med = lens.size() % 2 ? (float)lens[lens.size() / 2] : (float)(lens[lens.size() / 2 - 1] + lens[lens.size() / 2]) / 2.0f;
+  const size_t median_len = (size_t)med;
+  std::vector<Seg> sorted = seqs;
+  std::sort(sorted.begin(), sorted.end(), [](const Seg& a, const Seg& b) { return cmp_seg(a, b) < 0; });
+  size_t top = 0;
+  for (size_t i = 0; i < sorted.size();) { size_t j = i; while (j < sorted.size() && eq_seg(sorted[j], sorted[i])) ++j; top = std::max(top, j - i); i = j; }
+  bool have = false; size_t best_delta = 0;
+  for (size_t i = 0; i < sorted.size();) {
+    size_t j = i; while (j < sorted.size() && eq_seg(sorted[j], sorted[i])) ++j;
+    if (j - i == top) {
+      const size_t d = sorted[i].n > median_len ? sorted[i].n - median_len : median_len - sorted[i].n;
+      if (!have || d < best_delta) { have = true; best = sorted[i]; best_delta = d; }  // min_by_key: the first minimum, in sequence order
+    }
+    i = j;
+  }
+  freq = (double)top / (double)seqs.size();
+  return true;
+}
+
 #include "consensus_vote.hpp"
 
 // make_consensus / repair_consensus (consensus.rs:5-111) for a batch of groups: the members of group g are jobs [first[g], first[g + 1])
@@ -382,6 +490,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // (host reads are uploaded for the flank scan anyway: the device genotyper then works on that copy just as well)
   const bool dev_gt = !c->knobs.host_genotyper && !impure_filter;
   auto is_cluster = [&](int64_t l) { return in->genotyper && in->genotyper[l] == 1; };
+  // genotype_flank (tr.rs:69-75) can only change a genotype when reads carry haplotype tags or mismatch offsets
+  const bool flank_on = in->hp_tag != nullptr || (in->mismatch_offsets != nullptr && in->mismatch_off != nullptr);
+  const FlankMeta flank_meta{in->hp_tag, in->start_offset, in->end_offset, in->mismatch_offsets, in->mismatch_off};
   int rc;
   const uint8_t *d_flank = nullptr, *d_reads = nullptr;
   const uint64_t *d_piece = nullptr, *d_roff = nullptr;
@@ -519,6 +630,19 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (dev_gt) {
     uint8_t* need = (uint8_t*)gh.need;
     if (in->genotyper) for (int64_t l = 0; l < nl; ++l) if (in->genotyper[l] == 1) need[l] = 1;  // Genotyper::Cluster: host-driven rounds
+    if (flank_on) {
+      // device-genotyped loci whose two alleles are at most 10 bases apart and whose reads DO split by haplotype tag or flank SNVs
+      // take the host path, where the genotype is replaced (genotype_flank below); the split only needs the per-read fields
+      const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen; const int32_t* rank = (const int32_t*)gh.rank;
+      pool->parallel_for(nl, 64, [&](int64_t l, int) {
+        if (need[l] || nal[l] != 2 || adiff(alen[2 * l], alen[2 * l + 1]) > 10) return;
+        const uint64_t r0 = in->locus_read_begin[l], r1 = in->locus_read_begin[l + 1];
+        std::vector<uint32_t> order;
+        for (uint64_t r = r0; r < r1; ++r) if (rank[r] >= 0) { if ((size_t)rank[r] >= order.size()) order.resize((size_t)rank[r] + 1, 0); order[(size_t)rank[r]] = (uint32_t)r; }
+        FlankSplit sp;
+        if (flank_split(flank_meta, order.data(), order.size(), sp)) need[l] = 1;
+      });
+    }
     for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
   }
   else { R.resize((size_t)nl); for (int64_t l = 0; l < nl; ++l) R[(size_t)l] = l; }
@@ -833,6 +957,64 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   TL("stageB");
     // ---- host: repair_consensus, classification, reference allele first, output assembly
     th0 = now_ns();
+    // ---- genotype_flank::genotype (genotype_flank.rs:9-42) for the loci whose two alleles are at most 10 bases apart (tr.rs:69-75)
+    struct FlankRes { bool on = false; std::string repaired[2]; Seg al[2]; uint32_t ci[4] = {0, 0, 0, 0}; std::vector<int8_t> assignment; int rep_group[2] = {-1, -1}; };
+    std::vector<FlankRes> fres((size_t)(flank_on ? nR : 0));
+    if (flank_on) {
+      struct FlankRepair { int64_t li; int a; Seg backbone; std::vector<Seg> members; };
+      std::vector<std::vector<FlankRepair>> freps((size_t)pool->size());
+      pool->parallel_for(nR, 16, [&](int64_t li, int t) {
+        LocusWork& w = work[(size_t)li];
+        if (w.seg_begin == w.seg_end) return;
+        int n_gt; uint32_t s0, s1;  // Gt sizes: the length genotyper's sizes, the cluster genotyper's allele lengths
+        if (w.cluster >= 0) { const ClusterLocus& L = cl_loci[(size_t)w.cluster]; n_gt = L.n_gt; s0 = (uint32_t)L.allele[0].size(); s1 = (uint32_t)L.allele[1].size(); }
+        else { n_gt = w.n_gt; s0 = w.size[0]; s1 = w.size[1]; }
+        if (n_gt != 2 || adiff(s0, s1) > 10) return;
+        std::vector<uint32_t> rd;
+        for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) rd.push_back(seg_read[s]);
+        FlankSplit sp;
+        if (!flank_split(flank_meta, rd.data(), rd.size(), sp)) return;
+        FlankRes fr;
+        for (int g = 0; g < 2; ++g) {
+          std::vector<Seg> seqs;
+          uint32_t lo = 0xFFFFFFFFu, hi = 0;
+          for (uint32_t i : sp.group[g]) { const uint64_t s = w.seg_begin + i; seqs.push_back(Seg{seg_ptr[s], seg_len[s]}); lo = std::min(lo, seg_len[s]); hi = std::max(hi, seg_len[s]); }
+          Seg best; double freq;
+          if (!flank_simple_consensus(seqs, best, freq)) return;  // an empty group: None
+          fr.al[g] = best; fr.ci[2 * g] = lo; fr.ci[2 * g + 1] = hi;
+          if (freq < 0.5) { fr.rep_group[g] = (int)freps[(size_t)t].size(); freps[(size_t)t].push_back(FlankRepair{li, g, best, std::move(seqs)}); }
+        }
+        fr.on = true; fr.assignment = std::move(sp.assignment);
+        fres[(size_t)li] = std::move(fr);
+      });
+      // groups without a majority sequence: align(backbone, members) + repair_consensus, one more batch on the device
+      std::vector<uint8_t> fb; std::vector<uint64_t> fpo, fto; std::vector<uint32_t> fpl, ftl; std::vector<size_t> ffirst{0};
+      std::vector<std::pair<int64_t, int>> fwho;
+      for (auto& v : freps)
+        for (auto& q : v) {
+          const uint64_t bo = fb.size();
+          fb.insert(fb.end(), q.backbone.p, q.backbone.p + q.backbone.n);
+          for (auto& m : q.members) { fpo.push_back(bo); fpl.push_back(q.backbone.n); fto.push_back(fb.size()); ftl.push_back(m.n); fb.insert(fb.end(), m.p, m.p + m.n); }
+          ffirst.push_back(fpo.size()); fwho.push_back({q.li, q.a});
+        }
+      if (!fwho.empty()) {
+        std::vector<std::string> repaired;
+        if ((rc = consensus_repair_batch(c, (int64_t)fpo.size(), fb.data(), fpo.data(), fpl.data(), fto.data(), ftl.data(), ffirst, repaired))) return rc;
+        stat_cons_jobs += (int64_t)fpo.size();
+        for (size_t g = 0; g < fwho.size(); ++g) {
+          FlankRes& fr = fres[(size_t)fwho[g].first];
+          fr.repaired[fwho[g].second].swap(repaired[g]);
+        }
+      }
+      for (auto& fr : fres) {
+        if (!fr.on) continue;
+        for (int g = 0; g < 2; ++g) if (fr.rep_group[g] >= 0) fr.al[g] = Seg{(const uint8_t*)fr.repaired[g].data(), (uint32_t)fr.repaired[g].size()};
+        if (fr.al[0].n > fr.al[1].n) {  // smaller allele first (:33-38)
+          std::swap(fr.al[0], fr.al[1]); std::swap(fr.ci[0], fr.ci[2]); std::swap(fr.ci[1], fr.ci[3]);
+          for (auto& a : fr.assignment) a = (int8_t)((a + 1) % 2);
+        }
+      }
+    }
     std::vector<int8_t> seg_cls((size_t)n_seg, 0);
     std::atomic<int> bad{0};
     pool->parallel_for(nR, 64, [&](int64_t li, int) {
@@ -863,6 +1045,13 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
           }
           seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
         }
+      }
+      if (flank_on && fres[(size_t)li].on) {  // the flank genotype replaces alleles, intervals and the read assignment
+        const FlankRes& fr = fres[(size_t)li];
+        w.n_gt = 2; al[0] = fr.al[0]; al[1] = fr.al[1];
+        for (int k = 0; k < 4; ++k) w.ci[k] = fr.ci[k];
+        by_hap[0] = by_hap[1] = 0;
+        for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) { const int cc = fr.assignment[(size_t)(s - w.seg_begin)]; seg_cls[s] = (int8_t)cc; by_hap[cc] += 1; }
       }
       int order[2] = {0, 1};
       const Seg ref{in->tr_blob + in->tr_off[l], in->tr_len[l]};

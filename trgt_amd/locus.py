@@ -53,7 +53,8 @@ class LocusResult:  # locus_result.rs:16-22
 
 
 def pack(loci):
-    """loci: list of dict(left_flank, right_flank, tr, motifs, ploidy, reads[, genotyper ("size" | "cluster"), read_qual]).
+    """loci: list of dict(left_flank, right_flank, tr, motifs, ploidy, reads[, genotyper ("size" | "cluster"), read_qual, and -- what
+    genotype_flank reads -- hp_tag (None / 1 / 2 per read), start_offset, end_offset, mismatch_offsets (a list per read)]).
     Returns the ABI arrays (host)."""
     flank, tr, motifs, reads = bytearray(), bytearray(), bytearray(), bytearray()
     lf_off, lf_len, rf_off, rf_len, tr_off, tr_len, motif_off, set_begin, ploidy, lrb, read_off, read_len = ([] for _ in range(12))
@@ -61,7 +62,17 @@ def pack(loci):
     set_begin.append(0)
     lrb.append(0)
     genotyper, read_qual = [], []
+    has_meta = any(L.get("hp_tag") is not None or L.get("mismatch_offsets") is not None for L in loci)
+    hp, so, eo, mm, mm_off = [], [], [], [], [0]
     for L in loci:
+        if has_meta:
+            n = len(L["reads"])
+            hp += [-1 if v is None else int(v) for v in (L.get("hp_tag") if L.get("hp_tag") is not None else [None] * n)]
+            so += list(L.get("start_offset") if L.get("start_offset") is not None else [0] * n)
+            eo += list(L.get("end_offset") if L.get("end_offset") is not None else [0] * n)
+            for lst in (L.get("mismatch_offsets") if L.get("mismatch_offsets") is not None else [[]] * n):
+                mm += list(lst)
+                mm_off.append(len(mm))
         genotyper.append(1 if L.get("genotyper", "size") in (1, "cluster") else 0)
         rq = L.get("read_qual")
         read_qual += [float("nan") if q is None else float(q) for q in (rq if rq is not None else [None] * len(L["reads"]))]
@@ -83,7 +94,9 @@ def pack(loci):
                 motif_off=np.array(motif_off, np.uint32), set_motif_begin=np.array(set_begin, np.uint32),
                 ploidy=np.array(ploidy, np.uint8), locus_read_begin=np.array(lrb, np.uint64), read_blob=u8(reads),
                 read_off=np.array(read_off, np.uint64), read_len=np.array(read_len, np.uint32),
-                genotyper=np.array(genotyper, np.uint8), read_qual=np.array(read_qual, np.float64))
+                genotyper=np.array(genotyper, np.uint8), read_qual=np.array(read_qual, np.float64),
+                **(dict(hp_tag=np.array(hp, np.int16), start_offset=np.array(so, np.int32), end_offset=np.array(eo, np.int32),
+                        mismatch_offsets=np.array(mm + [0], np.int32), mismatch_off=np.array(mm_off, np.uint64)) if has_meta else {}))
 
 
 def find_tr_spans_batch(batch, params=Params(), ctx=None, flank_dev=None, reads_dev=None):
@@ -143,7 +156,7 @@ class BatchOutputs:
 
 
 _CIN_KEYS = ("lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off", "set_motif_begin", "ploidy",
-             "locus_read_begin", "read_off", "read_len", "genotyper", "read_qual")
+             "locus_read_begin", "read_off", "read_len", "genotyper", "read_qual", "hp_tag", "start_offset", "end_offset", "mismatch_offsets", "mismatch_off")
 
 
 def _batch_in(batch, flank, reads):
@@ -159,8 +172,8 @@ def _batch_in(batch, flank, reads):
             batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"], batch["motif_blob"], batch["motif_off"],
             batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
             reads, batch["read_off"], batch["read_len"])],
-            p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
-            p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
+            *[p(batch.get(k)).value if batch.get(k) is not None else None for k in ("genotyper", "read_qual", "hp_tag", "start_offset", "end_offset",
+                                                                                     "mismatch_offsets", "mismatch_off")])
         cached = (key, cin)
         batch["_cin"] = cached
     return cached[1]
