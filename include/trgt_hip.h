@@ -247,6 +247,9 @@ typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x 
   uint32_t* motif_counts; const uint64_t* count_off;              /* count_off[2l+a] */
   double* purity;                           /* [2 per locus] */
   int64_t* stats;                           /* optional [24]: see DESIGN.md */
+  /* optional (NULL = not wanted): what get_meth / assign_read (tr.rs:196-262) need beyond the fields above */
+  int32_t* gt_size;                         /* [2 per locus] TrSize::size of the genotype, output order (the allele length unless it was repaired) */
+  uint8_t* flipped;                         /* per locus: 1 = "reference allele first" swapped the two alleles (tr.rs:95-101) */
 } trgt_locus_batch_out;
 
 int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,
@@ -312,6 +315,33 @@ const char* trgt_ingest_last_error(const trgt_ingest* h);
 int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus,
                                    int64_t max_loci, trgt_ingest_batch** out);
 void trgt_ingest_free(trgt_ingest_batch* b);
+
+/* the header of the BAM behind a reader: its text and its reference sequences (what the writers take over) */
+const char* trgt_ingest_header_text(const trgt_ingest* h);
+int32_t trgt_ingest_n_contigs(const trgt_ingest* h);
+const char* trgt_ingest_contig_name(const trgt_ingest* h, int32_t i);
+uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i);
+
+/* ------------------------------------------------------------ writers (the step behind trgt_locus_batch)
+ * VcfWriter (src/trgt/writers/write_vcf.rs:19-397): header lines, one record per locus -- REF / ALT with the padding base, GT by
+ * set_gt, AL / ALLR / SD / MC / MS / AP and AM (get_meth / assign_read / get_tr_meth, src/trgt/workflows/tr.rs:196-262, 363-398) -- as text,
+ * BGZF-compressed when the path ends in ".gz".  BamWriter (src/trgt/writers/write_bam.rs:33-144): the spanning reads of every locus clipped
+ * to output_flank_len bases around the repeat (HiFiRead::clip_bases, src/trgt/reads/clip_bases.rs:9-120) with the tags TR, rq, MC, MO, HP, SO,
+ * EO, AL, FL, in a BAM whose header is the input's plus a @PG record.  bam_path NULL: no BAM. */
+typedef struct trgt_writer trgt_writer;
+typedef struct trgt_writer_params {
+  int32_t output_flank_len;   /* 50   min(--flank-len, --output-flank-len) (genotype.rs:129) */
+  const char* sample_name;    /* VCF sample column */
+  const char* program;        /* "trgt": ##<program>Version= / ##<program>Command= / @PG ID, PN */
+  const char* version;
+  const char* command_line;
+} trgt_writer_params;
+void trgt_writer_default_params(trgt_writer_params* p);
+int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);
+/* the loci of one ingested batch with the results trgt_locus_batch filled for it (gt_size / flipped wanted for an exact AM) */
+int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* out);
+int trgt_writer_close(trgt_writer* w);   /* flushes, writes the BGZF end-of-file blocks, frees the handle */
+const char* trgt_writer_last_error(const trgt_writer* w);
 
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {

@@ -118,3 +118,57 @@ def write_fasta(path, contigs, width=60):
         off += len(body)
     open(path, "w").write(fa)
     open(path + ".fai", "w").write(fai)
+
+
+def read_bam_records(path):
+    """All records of a BAM with their aux tags: dicts (name, tid, pos, mapq, flag, cigar [(op char, len)], seq, qual, tags {tag: value})."""
+    import gzip
+    data = gzip.open(path, "rb").read()
+    assert data[:4] == b"BAM\1"
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    text = data[8:8 + l_text].decode()
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", data, p)[0]
+        refs.append((data[p + 4:p + 4 + ln - 1].decode(), struct.unpack_from("<i", data, p + 4 + ln)[0]))
+        p += 8 + ln
+    size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+    fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}
+    out = []
+    while p < len(data):
+        bs = struct.unpack_from("<i", data, p)[0]
+        rec = data[p + 4:p + 4 + bs]
+        p += 4 + bs
+        tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+        q = 32
+        name = rec[q:q + l_rn - 1].decode()
+        q += l_rn
+        cigar = [("MIDNSHP=X"[v & 0xF], v >> 4) for v in struct.unpack_from("<%dI" % n_cig, rec, q)]
+        q += 4 * n_cig
+        packed = rec[q:q + (l_seq + 1) // 2]
+        q += (l_seq + 1) // 2
+        seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 0xF] for i in range(l_seq))
+        qual = list(rec[q:q + l_seq])
+        q += l_seq
+        tags = {}
+        while q < len(rec):
+            tag, ty = rec[q:q + 2].decode(), chr(rec[q + 2])
+            q += 3
+            if ty in size:
+                tags[tag] = (ty, struct.unpack_from("<" + fmt.get(ty, "c"), rec, q)[0])
+                q += size[ty]
+            elif ty == "Z":
+                e = rec.index(b"\0", q)
+                tags[tag] = (ty, rec[q:e].decode())
+                q = e + 1
+            elif ty == "B":
+                sub, n = chr(rec[q]), struct.unpack_from("<I", rec, q + 1)[0]
+                tags[tag] = ("B" + sub, list(struct.unpack_from("<%d%s" % (n, fmt[sub]), rec, q + 5)))
+                q += 5 + n * size[sub]
+            else:
+                raise ValueError(ty)
+        out.append(dict(name=name, tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=cigar, seq=seq, qual=qual, tags=tags, mtid=mtid, mpos=mpos))
+    return text, refs, out

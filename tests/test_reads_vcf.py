@@ -109,3 +109,32 @@ def test_example_bam_through_the_native_ingestion_on_the_gpu():
     b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
     out = locus.run_batch(b)
     assert [vcf.vcf_record(l, locus.locus_result(b, out, i)) for i, l in enumerate(loci)] == [TUTORIAL_RECORD]
+
+
+@pytest.mark.gpu
+def test_native_writers_on_the_example(tmp_path):
+    # catalog + reference + BAM -> native ingestion -> trgt_locus_batch -> native VCF and spanning-reads BAM (write_vcf.rs, write_bam.rs)
+    import gzip
+    from trgt_amd import ingest, locus, writers
+    from trgt_amd import reads as pyreads
+    rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
+    b = rd.batch(os.path.join(EX, "repeat.bed"), keep_native=True)
+    out = locus.run_batch(b)
+    for vcf_name in ("out.vcf", "out.vcf.gz"):
+        w = writers.Writer(rd, tmp_path / vcf_name, tmp_path / "out.spanning.bam", sample_name="sample", command_line="trgt genotype --test")
+        w.write(b, out)
+        w.close()
+        text = (gzip.open if vcf_name.endswith(".gz") else open)(tmp_path / vcf_name, "rt").read().splitlines()
+        assert text[0] == "##fileformat=VCFv4.2" and '##FORMAT=<ID=AM,Number=.,Type=Float,Description="Mean methylation level per allele">' in text
+        assert "##contig=<ID=chrA,length=11061>" in text and "##trgtVersion=3.0.0" in text and "##trgtCommand=trgt genotype --test" in text
+        assert text[-2] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample" and text[-1] == TUTORIAL_RECORD
+    # the spanning reads: every kept read, clipped to 50 bases of flank on either side of its repeat, tagged as write_bam.rs:72-144 does
+    recs = pyreads.read_bam(str(tmp_path / "out.spanning.bam"))
+    res = locus.locus_result(b, out, 0)
+    assert len(recs) == len(res.reads) == 29
+    for k, (rec, ri) in enumerate(zip(recs, res.reads)):
+        s, e = int(out.span_start[ri]), int(out.span_end[ri])
+        full = bytes(b["read_blob"][int(b["read_off"][ri]):int(b["read_off"][ri]) + int(b["read_len"][ri])]).decode()
+        assert rec.name == b["read_name"][ri] and rec.seq == full[s - 50:e + 50] and rec.contig == "chrA"
+        assert sum(n for c, n in rec.cigar if c in pyreads.QRY_CONSUMING) == len(rec.seq)
+        assert abs(rec.rq - b["read_qual"][ri]) < 1e-7

@@ -65,7 +65,7 @@ class LocusBatchOut(C.Structure):
     _fields_ = [(n, _VP) for n in (
         "span_start", "span_end", "n_alleles", "allele_blob", "allele_off", "allele_cap", "allele_len", "ci",
         "num_spanning", "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off",
-        "purity", "stats")]
+        "purity", "stats", "gt_size", "flipped")]
 
 
 EXPORTS = [
@@ -73,7 +73,9 @@ EXPORTS = [
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
     "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params",
-    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
+    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free",
+    "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
+    "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 

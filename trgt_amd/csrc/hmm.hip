@@ -589,7 +589,6 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           bpi = cand > own ? (role_del ? 1 : 2) : own_bp;
           val = best;
         }
-#pragma unroll 4
         for (int t = 0; t < chain_steps; ++t) {
           cand = (wave_shr1_f64(val) + lp_step);
           val = cand > best ? cand : best;

@@ -474,8 +474,9 @@ struct StdRng {
 
 // ============================================================================================== C ABI
 struct trgt_ingest {
-  std::string bam_path, fasta_path, err;
+  std::string bam_path, fasta_path, err, header_text;
   std::vector<std::string> ref_names;
+  std::vector<uint32_t> ref_len;
   std::map<std::string, int> ref_id;
   uint64_t first_record_voff = 0;
   Bai bai;
@@ -501,6 +502,12 @@ extern "C" {
 
 const char* trgt_ingest_last_error(const trgt_ingest* h) { return h ? h->err.c_str() : "null handle"; }
 
+// (for the writers, trgt_amd/csrc/writers.hip: the template header and the contigs of the BAM)
+const char* trgt_ingest_header_text(const trgt_ingest* h) { return h ? h->header_text.c_str() : ""; }
+int32_t trgt_ingest_n_contigs(const trgt_ingest* h) { return h ? (int32_t)h->ref_names.size() : 0; }
+const char* trgt_ingest_contig_name(const trgt_ingest* h, int32_t i) { return h && i >= 0 && (size_t)i < h->ref_names.size() ? h->ref_names[(size_t)i].c_str() : ""; }
+uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i) { return h && i >= 0 && (size_t)i < h->ref_len.size() ? h->ref_len[(size_t)i] : 0; }
+
 int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out) {
   if (!bam_path || !fasta_path || !out) return TRGT_ERR_INVALID;
   std::unique_ptr<trgt_ingest> h(new trgt_ingest());
@@ -514,6 +521,8 @@ int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest**
   const uint32_t l_text = le32(b + 4);
   std::vector<uint8_t> text(l_text);
   if (l_text && z.read(text.data(), l_text) != 1) return bad("truncated BAM header");
+  h->header_text.assign(text.begin(), text.end());
+  while (!h->header_text.empty() && h->header_text.back() == '\0') h->header_text.pop_back();
   if (z.read(b, 4) != 1) return bad("truncated BAM header");
   const uint32_t n_ref = le32(b);
   for (uint32_t r = 0; r < n_ref; ++r) {
@@ -522,6 +531,7 @@ int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest**
     std::string name(l_name, '\0');
     if (l_name && z.read(&name[0], l_name) != 1) return bad("truncated BAM header");
     if (z.read(b, 4) != 1) return bad("truncated BAM header");
+    h->ref_len.push_back(le32(b));
     if (!name.empty() && name.back() == '\0') name.pop_back();
     h->ref_id[name] = (int)r;
     h->ref_names.push_back(name);

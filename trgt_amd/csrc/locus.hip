@@ -431,7 +431,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_flank_heavy = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
   auto init_outputs = [&]() {
-    for (int64_t l = 0; l < nl; ++l) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0; }
+    for (int64_t l = 0; l < nl; ++l) {
+      out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; out->num_spanning[2 * l] = out->num_spanning[2 * l + 1] = 0;
+      if (out->gt_size) out->gt_size[2 * l] = out->gt_size[2 * l + 1] = 0;
+      if (out->flipped) out->flipped[l] = 0;
+    }
     for (int64_t r = 0; r < nr; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; out->span_start[r] = out->span_end[r] = -1; }
     for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
   };
@@ -518,11 +522,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     size_t add(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
   } slab;
   const size_t o_ss = slab.add((size_t)nr * 4), o_se = slab.add((size_t)nr * 4), o_hl = slab.add((size_t)nr), o_hr = slab.add((size_t)nr);
-  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0;
+  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0;
   if (dev_gt) {
     o_need = slab.add((size_t)nl); o_nal = slab.add((size_t)nl * 4); o_alen = slab.add(2 * (size_t)nl * 4); o_ci = slab.add(4 * (size_t)nl * 4);
     o_nsp = slab.add(2 * (size_t)nl * 4); o_cls = slab.add((size_t)nr * 4); o_rank = slab.add((size_t)nr * 4); o_nspan = slab.add((size_t)nl * 4);
-    o_toff = slab.add((2 * (size_t)nl + 1) * 8);
+    o_toff = slab.add((2 * (size_t)nl + 1) * 8); o_flip = slab.add((size_t)nl);
   }
   void *d_slab = nullptr, *h_slab = nullptr;
   if ((rc = dev_get(c, S_LOCUS_4, slab.total, &d_slab)) || (rc = pin_get(c, P_SPAN_S, slab.total, &h_slab))) return rc;
@@ -575,7 +579,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     ga.n_loci = nl; ga.flank_len = F; ga.max_depth = p->max_depth;
     ga.need_host = (uint8_t*)g.need; ga.n_alleles = (int32_t*)g.nal; ga.allele_blob = (uint8_t*)g.blob; ga.allele_len = (uint32_t*)g.alen;
     ga.ci = (int32_t*)g.ci; ga.num_spanning = (int32_t*)g.nsp; ga.classification = (int32_t*)g.cls; ga.read_rank = (int32_t*)g.rank;
-    ga.n_spanning_reads = (uint32_t*)g.nspan;
+    ga.n_spanning_reads = (uint32_t*)g.nspan; ga.flipped = (uint8_t*)dsl(o_flip);
     if (max_locus_reads <= 64) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     else hipLaunchKernelGGL((gt::locus_genotype_kernel<gt::GT_MAX_READS, gt::GT_SEG_LDS>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     TRGT_HIP_TRY(c, hipGetLastError());
@@ -869,7 +873,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
     const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
+    const uint8_t* dev_flip = (const uint8_t*)hsl(o_flip);
     pool->parallel_for(nl, 256, [&](int64_t l, int) {
+      if (out->flipped) out->flipped[l] = need[l] ? 0 : dev_flip[l];
+      // (alleles the device genotyper settles have majority support: their length is the genotype's size)
+      if (out->gt_size) { out->gt_size[2 * l] = need[l] ? 0 : (int32_t)out->allele_len[2 * l]; out->gt_size[2 * l + 1] = need[l] ? 0 : (int32_t)out->allele_len[2 * l + 1]; }
       if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
       for (int a = 0; a < out->n_alleles[l]; ++a)
         std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
@@ -1046,9 +1054,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
           seg_cls[s] = (int8_t)cc; by_hap[cc] += 1;
         }
       }
+      // TrSize::size of the genotype: the length genotyper's sizes; the cluster genotyper's and the flank genotype's are allele lengths
+      uint32_t gsz[2] = {w.cluster >= 0 ? al[0].n : w.size[0], w.cluster >= 0 ? (w.n_gt > 1 ? al[1].n : 0u) : w.size[1]};
       if (flank_on && fres[(size_t)li].on) {  // the flank genotype replaces alleles, intervals and the read assignment
         const FlankRes& fr = fres[(size_t)li];
-        w.n_gt = 2; al[0] = fr.al[0]; al[1] = fr.al[1];
+        w.n_gt = 2; al[0] = fr.al[0]; al[1] = fr.al[1]; gsz[0] = al[0].n; gsz[1] = al[1].n;
         for (int k = 0; k < 4; ++k) w.ci[k] = fr.ci[k];
         by_hap[0] = by_hap[1] = 0;
         for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) { const int cc = fr.assignment[(size_t)(s - w.seg_begin)]; seg_cls[s] = (int8_t)cc; by_hap[cc] += 1; }
@@ -1065,7 +1075,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
         out->allele_len[2 * l + oi] = al[a].n;
         out->ci[4 * l + 2 * oi] = (int32_t)w.ci[2 * a]; out->ci[4 * l + 2 * oi + 1] = (int32_t)w.ci[2 * a + 1];
         out->num_spanning[2 * l + oi] = by_hap[a];
+        if (out->gt_size) out->gt_size[2 * l + oi] = (int32_t)gsz[a];
       }
+      if (out->flipped) out->flipped[l] = flip ? 1 : 0;
       for (uint64_t r = in->locus_read_begin[l]; r < in->locus_read_begin[l + 1]; ++r) { out->classification[r] = -1; out->read_rank[r] = -1; }
       for (uint64_t s = w.seg_begin; s < w.seg_end; ++s) {
         out->classification[seg_read[s]] = flip ? 1 - seg_cls[s] : seg_cls[s];

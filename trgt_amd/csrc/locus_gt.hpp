@@ -27,6 +27,7 @@ struct GtArgs {
   int64_t n_loci; int32_t flank_len, max_depth;
   uint8_t* need_host; int32_t* n_alleles; uint8_t* allele_blob; uint32_t* allele_len; int32_t* ci; int32_t* num_spanning;
   int32_t* classification; int32_t* read_rank; uint32_t* n_spanning_reads;
+  uint8_t* flipped;  // per locus: the two alleles were swapped to put the reference allele first
 };
 
 template <int MAXR, int SEG>
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {
   const int F = a.flank_len;
   if (lane == 0) {
     sh.n = 0; sh.bail = 0; sh.res_n_gt = 0;
-    a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0;
+    a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0; a.flipped[l] = 0;
     a.allele_len[2 * l] = a.allele_len[2 * l + 1] = 0; a.num_spanning[2 * l] = a.num_spanning[2 * l + 1] = 0;
   }
   if (a.ploidy[l] == 0 || nr == 0 || nr > MAXR) {  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31); oversized -> host
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {
     a.classification[r0 + sh.s_read[i]] = sh.res_flip ? 1 - sh.cls[i] : sh.cls[i];
     a.read_rank[r0 + sh.s_read[i]] = i;
   }
-  if (lane == 0) { a.n_alleles[l] = n_gt; a.n_spanning_reads[l] = (uint32_t)n; }
+  if (lane == 0) { a.n_alleles[l] = n_gt; a.n_spanning_reads[l] = (uint32_t)n; a.flipped[l] = (uint8_t)sh.res_flip; }
 }
 
 }  // namespace gt

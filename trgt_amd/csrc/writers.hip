@@ -1,0 +1,337 @@
+// trgt_amd/csrc/writers.hip -- the step behind the GPU path, host C++ (no device code):
+//   VcfWriter::new / write / set_gt / encode_*            src/trgt/writers/write_vcf.rs:19-397
+//   BamWriter::create_header / write                      src/trgt/writers/write_bam.rs:33-144
+//   HiFiRead::clip_bases                                  src/trgt/reads/clip_bases.rs:9-120
+//   get_meth / assign_read / get_tr_meth                  src/trgt/workflows/tr.rs:196-262, 363-398 (the AM field)
+// Input: a batch of the native ingestion (trgt_ingest_batch: catalog fields, clipped reads with their HiFiRead fields) and the result
+// arrays trgt_locus_batch filled for it.  The reference writes through htslib; here VCF lines are formatted directly (BGZF-compressed when
+// the path ends in .gz -- the reference's bcf::Writer compresses) and BAM records are encoded and BGZF-compressed with zlib.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/trgt_hip.h"
+
+extern "C" {
+const char* trgt_ingest_header_text(const trgt_ingest* h);
+int32_t trgt_ingest_n_contigs(const trgt_ingest* h);
+const char* trgt_ingest_contig_name(const trgt_ingest* h, int32_t i);
+uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i);
+}
+
+namespace {
+
+struct BgzfOut {  // a file, plain or as a series of BGZF blocks
+  FILE* f = nullptr; bool bgzf = false; std::vector<uint8_t> buf;
+  bool open(const char* path, bool compress) { f = std::fopen(path, "wb"); bgzf = compress; return f != nullptr; }
+  bool block(const uint8_t* d, size_t n) {
+    uint8_t out[0x10000 + 64];
+    z_stream zs; std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t*>(d); zs.avail_in = (uInt)n; zs.next_out = out + 18; zs.avail_out = sizeof(out) - 18 - 8;
+    const int rc = deflate(&zs, Z_FINISH);
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    const size_t clen = zs.total_out, total = 18 + clen + 8;
+    static const uint8_t head[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    std::memcpy(out, head, 16);
+    out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, nullptr, 0), d, (uInt)n);
+    for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+    return std::fwrite(out, 1, total, f) == total;
+  }
+  bool write(const void* d, size_t n) {
+    if (!bgzf) return std::fwrite(d, 1, n, f) == n;
+    const uint8_t* p = (const uint8_t*)d;
+    buf.insert(buf.end(), p, p + n);
+    size_t o = 0;
+    while (buf.size() - o >= 0xFF00) { if (!block(buf.data() + o, 0xFF00)) return false; o += 0xFF00; }
+    if (o) buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)o);
+    return true;
+  }
+  bool close() {
+    bool ok = true;
+    if (f) {
+      if (bgzf) { if (!buf.empty()) ok = block(buf.data(), buf.size()); buf.clear(); ok = block(nullptr, 0) && ok; }  // + the empty EOF block
+      ok = std::fclose(f) == 0 && ok; f = nullptr;
+    }
+    return ok;
+  }
+};
+
+inline void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+inline void put16(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+inline bool ends_with(const std::string& s, const char* suf) { const size_t n = std::strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+inline uint32_t qlen_of(uint32_t op) { const uint32_t c = op & 0xF; return (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) ? op >> 4 : 0; }
+inline uint32_t rlen_of(uint32_t op) { const uint32_t c = op & 0xF; return (c == 0 || c == 2 || c == 3 || c == 7 || c == 8) ? op >> 4 : 0; }
+inline int reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+
+}  // namespace
+
+struct trgt_writer {
+  std::string err, sample;
+  BgzfOut vcf, bam;
+  bool has_bam = false;
+  int32_t flank_len = 50;
+  std::vector<std::string> contigs;
+};
+
+extern "C" {
+
+const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_str() : "null handle"; }
+
+void trgt_writer_default_params(trgt_writer_params* p) {
+  if (!p) return;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = "";
+}
+
+int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
+  if (!src || !p || !vcf_path || !out) return TRGT_ERR_INVALID;
+  std::unique_ptr<trgt_writer> w(new trgt_writer());
+  *out = nullptr;
+  auto bad = [&](const std::string& m) { w->err = m; *out = w.release(); return TRGT_ERR_INVALID; };
+  w->flank_len = p->output_flank_len;
+  const std::string prog = p->program ? p->program : "trgt", ver = p->version ? p->version : "", cl = p->command_line ? p->command_line : "";
+  w->sample = p->sample_name ? p->sample_name : "sample";
+  for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i) w->contigs.push_back(trgt_ingest_contig_name(src, i));
+  if (!w->vcf.open(vcf_path, ends_with(vcf_path, ".gz"))) return bad(std::string("Invalid VCF output path: ") + vcf_path);
+  {  // VcfWriter::new (write_vcf.rs:49-92); the first two lines are what htslib puts into every new header
+    std::string h = "##fileformat=VCFv4.2\n##FILTER=<ID=PASS,Description=\"All filters passed\">\n";
+    h += "##INFO=<ID=TRID,Number=1,Type=String,Description=\"Tandem repeat ID\">\n"
+         "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the variant described in this record\">\n"
+         "##INFO=<ID=MOTIFS,Number=.,Type=String,Description=\"Motifs that the tandem repeat is composed of\">\n"
+         "##INFO=<ID=STRUC,Number=1,Type=String,Description=\"Structure of the region\">\n"
+         "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+         "##FORMAT=<ID=AL,Number=.,Type=Integer,Description=\"Length of each allele\">\n"
+         "##FORMAT=<ID=ALLR,Number=.,Type=String,Description=\"Length range per allele\">\n"
+         "##FORMAT=<ID=SD,Number=.,Type=Integer,Description=\"Number of spanning reads supporting per allele\">\n"
+         "##FORMAT=<ID=MC,Number=.,Type=String,Description=\"Motif counts per allele\">\n"
+         "##FORMAT=<ID=MS,Number=.,Type=String,Description=\"Motif spans per allele\">\n"
+         "##FORMAT=<ID=AP,Number=.,Type=Float,Description=\"Allele purity per allele\">\n"
+         "##FORMAT=<ID=AM,Number=.,Type=Float,Description=\"Mean methylation level per allele\">\n";
+    for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i)
+      h += "##contig=<ID=" + w->contigs[(size_t)i] + ",length=" + std::to_string(trgt_ingest_contig_length(src, i)) + ">\n";
+    h += "##" + prog + "Version=" + ver + "\n##" + prog + "Command=" + cl + "\n";
+    h += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + w->sample + "\n";
+    if (!w->vcf.write(h.data(), h.size())) return bad("cannot write the VCF header");
+  }
+  if (bam_path) {
+    if (!w->bam.open(bam_path, true)) return bad(std::string("cannot open ") + bam_path);
+    w->has_bam = true;
+    std::string text = trgt_ingest_header_text(src);  // BamWriter::create_header (write_bam.rs:52-65): the template + a @PG record
+    if (!text.empty() && text.back() != '\n') text += "\n";
+    text += "@PG\tID:" + prog + "\tPN:" + prog + "\tCL:" + cl + "\tVN:" + ver + "\n";
+    std::vector<uint8_t> h = {'B', 'A', 'M', 1};
+    put32(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end());
+    put32(h, (uint32_t)w->contigs.size());
+    for (size_t i = 0; i < w->contigs.size(); ++i) {
+      put32(h, (uint32_t)w->contigs[i].size() + 1); h.insert(h.end(), w->contigs[i].begin(), w->contigs[i].end()); h.push_back(0);
+      put32(h, trgt_ingest_contig_length(src, (int32_t)i));
+    }
+    if (!w->bam.write(h.data(), h.size())) return bad("cannot write the BAM header");
+  }
+  *out = w.release();
+  return TRGT_OK;
+}
+
+int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* o) {
+  if (!w || !b || !o) return TRGT_ERR_INVALID;
+  auto bad = [&](const std::string& m) { w->err = m; return TRGT_ERR_INVALID; };
+  if (!o->n_alleles || !o->allele_blob || !o->allele_off || !o->allele_len || !o->ci || !o->num_spanning || !o->classification || !o->read_rank ||
+      !o->span_start || !o->span_end || !o->spans3 || !o->span_off || !o->n_spans || !o->motif_counts || !o->count_off || !o->purity)
+    return bad("trgt_writer_write: incomplete result arrays");
+  std::string line;
+  std::vector<uint8_t> rec;
+  char num[64];
+  for (int64_t l = 0; l < b->n_loci; ++l) {
+    const std::string contig(b->contig_blob + b->contig_off[l], b->contig_off[l + 1] - b->contig_off[l]);
+    const std::string id(b->id_blob + b->id_off[l], b->id_off[l + 1] - b->id_off[l]);
+    const std::string struc(b->struc_blob + b->struc_off[l], b->struc_off[l + 1] - b->struc_off[l]);
+    const std::string tr((const char*)b->tr_blob + b->tr_off[l], b->tr_len[l]);
+    if (b->lf_len[l] == 0) return bad("Empty flanks are not allowed");
+    const char pad = (char)b->flank_blob[b->lf_off[l] + b->lf_len[l] - 1];
+    const int n_al = o->n_alleles[l];
+    const uint32_t m0 = b->set_motif_begin[l], m1 = b->set_motif_begin[l + 1];
+    // the kept spanning reads in LocusResult.reads order
+    const uint64_t r0 = b->locus_read_begin[l], r1 = b->locus_read_begin[l + 1];
+    std::vector<uint64_t> kept;
+    for (uint64_t r = r0; r < r1; ++r) if (o->read_rank[r] >= 0) { if ((size_t)o->read_rank[r] >= kept.size()) kept.resize((size_t)o->read_rank[r] + 1, r0); kept[(size_t)o->read_rank[r]] = r; }
+    // ---- VCF record (write_vcf.rs:95-260)
+    line.clear();
+    line += contig; line += '\t'; line += std::to_string(b->region_start[l] > 0 ? b->region_start[l] : 1); line += "\t.\t";  // POS = saturating_sub(start, 1) + 1
+    std::string info = "TRID=" + id + ";END=" + std::to_string(b->region_end[l]) + ";MOTIFS=";
+    for (uint32_t m = m0; m < m1; ++m) { if (m > m0) info += ","; info.append((const char*)b->motif_blob + b->motif_off[m], b->motif_off[m + 1] - b->motif_off[m]); }
+    info += ";STRUC=" + struc;
+    if (n_al == 0) {  // add_missing_allele_info
+      line += pad; line += tr; line += "\t.\t.\t.\t"; line += info; line += "\tGT:AL:ALLR:SD:MC:MS:AP:AM\t.:.:.:.:.:.:.:.\n";
+    } else {
+      std::string al[2];
+      for (int a = 0; a < n_al; ++a) al[a].assign((const char*)o->allele_blob + o->allele_off[2 * l + a], o->allele_len[2 * l + a]);
+      std::vector<const std::string*> seqs{&tr};  // set_gt (:219-260)
+      std::string gt;
+      for (int a = 0; a < n_al; ++a) {
+        int idx;
+        if (al[a] == tr) idx = 0;
+        else if (seqs.size() == 1) { idx = 1; seqs.push_back(&al[a]); }
+        else if (al[0] == al[1]) idx = 1;
+        else { idx = 2; seqs.push_back(&al[a]); }
+        if (a) gt += "/";
+        gt += std::to_string(idx);
+      }
+      line += pad; line += *seqs[0]; line += '\t';
+      if (seqs.size() == 1) line += ".";
+      for (size_t s = 1; s < seqs.size(); ++s) { if (s > 1) line += ","; line += pad; line += *seqs[s]; }
+      line += "\t.\t.\t"; line += info; line += "\tGT:AL:ALLR:SD:MC:MS:AP:AM\t"; line += gt;
+      std::string f_al, f_allr, f_sd, f_mc, f_ms, f_ap, f_am;
+      // get_meth (tr.rs:196-229) in the genotype's own order (before "reference allele first")
+      const bool flipped = o->flipped && o->flipped[l] && n_al == 2;
+      double meth_sum[2] = {0, 0}; size_t meth_n[2] = {0, 0};
+      if (b->has_meth && b->meth && b->meth_off) {
+        auto pre = [&](int a) { return flipped ? 1 - a : a; };  // allele of the original order -> output slot
+        const size_t sz[2] = {(size_t)(o->gt_size ? o->gt_size[2 * l + pre(0)] : (int32_t)o->allele_len[2 * l + pre(0)]),
+                              n_al == 2 ? (size_t)(o->gt_size ? o->gt_size[2 * l + pre(1)] : (int32_t)o->allele_len[2 * l + pre(1)]) : 0};
+        for (uint64_t r : kept) {
+          if (!b->has_meth[r] || b->meth_off[r + 1] == b->meth_off[r]) continue;
+          const size_t s0 = (size_t)o->span_start[r], s1 = (size_t)o->span_end[r];
+          const uint8_t* bases = b->read_blob + b->read_off[r]; const size_t n = b->read_len[r];
+          const uint8_t* me = b->meth + b->meth_off[r]; const size_t nme = (size_t)(b->meth_off[r + 1] - b->meth_off[r]);
+          double total = 0.0; size_t cpg = 0, ci = 0; bool malformed = false;
+          for (size_t pos = 0; pos + 1 < n; ++pos)
+            if (bases[pos] == 'C' && bases[pos + 1] == 'G') {
+              if (s0 <= pos && pos < s1) { if (ci >= nme) { malformed = true; break; } ++cpg; total += (double)me[ci] / 255.0; }
+              ++ci;
+            }
+          if (malformed) return bad("Read " + std::string(b->name_blob + b->name_off[r], b->name_off[r + 1] - b->name_off[r]) + " has malformed methylation profile");
+          if (!cpg) continue;
+          const double level = total / (double)cpg;
+          const size_t len = s1 - s0;
+          if (n_al == 1) { meth_sum[0] += level; ++meth_n[0]; continue; }  // assign_read (:238-262)
+          const auto adiff = [](size_t x, size_t y) { return x > y ? x - y : y - x; };
+          const bool sp1 = (size_t)o->ci[4 * l + 2 * pre(0)] <= len && len <= (size_t)o->ci[4 * l + 2 * pre(0) + 1];
+          const bool sp2 = (size_t)o->ci[4 * l + 2 * pre(1)] <= len && len <= (size_t)o->ci[4 * l + 2 * pre(1) + 1];
+          const size_t d1 = adiff(len, sz[0]), d2 = adiff(len, sz[1]);
+          if (d1 < d2 && sp1) { meth_sum[0] += level; ++meth_n[0]; }
+          else if (d2 < d1 && sp2) { meth_sum[1] += level; ++meth_n[1]; }
+          else if (sz[0] == sz[1] && sp1) { meth_sum[0] += level; ++meth_n[0]; meth_sum[1] += level; ++meth_n[1]; }
+        }
+      }
+      for (int a = 0; a < n_al; ++a) {
+        const char* sep = a ? "," : "";
+        f_al += sep; f_al += std::to_string(o->allele_len[2 * l + a]);
+        f_allr += sep; f_allr += std::to_string(o->ci[4 * l + 2 * a]) + "-" + std::to_string(o->ci[4 * l + 2 * a + 1]);
+        f_sd += sep; f_sd += std::to_string(o->num_spanning[2 * l + a]);
+        f_mc += sep;
+        for (uint32_t m = 0; m < m1 - m0; ++m) { if (m) f_mc += "_"; f_mc += std::to_string(o->motif_counts[o->count_off[2 * l + a] + m]); }
+        f_ms += sep;
+        const uint32_t ns = o->n_spans[2 * l + a];
+        if (ns == 0) f_ms += ".";
+        for (uint32_t k = 0; k < ns; ++k) {
+          const int32_t* sp = o->spans3 + 3 * (o->span_off[2 * l + a] + k);
+          if (k) f_ms += "_";
+          f_ms += std::to_string(sp[0]) + "(" + std::to_string(sp[1]) + "-" + std::to_string(sp[2]) + ")";
+        }
+        f_ap += sep;
+        if (std::isnan(o->purity[2 * l + a])) f_ap += "."; else { std::snprintf(num, sizeof num, "%.6f", o->purity[2 * l + a]); f_ap += num; }
+        f_am += sep;
+        const int src = flipped ? 1 - a : a;  // the allele's slot in the original order
+        if (meth_n[src]) { std::snprintf(num, sizeof num, "%.2f", meth_sum[src] / (double)meth_n[src]); f_am += num; } else f_am += ".";
+      }
+      line += ":" + f_al + ":" + f_allr + ":" + f_sd + ":" + f_mc + ":" + f_ms + ":" + f_ap + ":" + f_am + "\n";
+    }
+    if (!w->vcf.write(line.data(), line.size())) return bad("cannot write the VCF");
+    // ---- spanning reads (write_bam.rs:72-144)
+    if (!w->has_bam) continue;
+    int tid = -1;
+    for (size_t i = 0; i < w->contigs.size(); ++i) if (w->contigs[i] == contig) { tid = (int)i; break; }
+    if (tid < 0) return bad("contig " + contig + " is not in the BAM header");
+    const size_t F = (size_t)w->flank_len;
+    for (uint64_t r : kept) {
+      const size_t s0 = (size_t)o->span_start[r], s1 = (size_t)o->span_end[r], n = b->read_len[r];
+      if (s0 < F || n < s1 + F) continue;  // "unexpectedly short flanks"
+      const size_t left = s0 - F, right = n - s1 - F;
+      if (left + right >= n) continue;     // clip_bases: None
+      const uint8_t* bases = b->read_blob + b->read_off[r] + left; const uint8_t* quals = b->qual_blob + b->read_off[r] + left;
+      const size_t len = n - left - right;
+      // clip_cigar (clip_bases.rs:59-118)
+      std::vector<uint32_t> ops; int64_t ref_pos = b->cigar_ref_pos[r];
+      {
+        const uint32_t* cg = b->cigar + b->cigar_off[r]; const size_t nc = (size_t)(b->cigar_off[r + 1] - b->cigar_off[r]);
+        size_t qsum = 0; for (size_t i = 0; i < nc; ++i) qsum += qlen_of(cg[i]);
+        if (qsum < left + right) return bad("CIGAR shorter than the read");
+        size_t keep = qsum - left - right, left_len = left, i = 0;
+        uint32_t cur = nc ? cg[0] : 0; bool have = nc > 0;
+        while (left_len != 0 && have) {
+          const size_t q = qlen_of(cur);
+          if (q > left_len) { const uint32_t rest = (uint32_t)(q - left_len); if (rlen_of(cur)) ref_pos += (int64_t)left_len; cur = (rest << 4) | (cur & 0xF); left_len = 0; }
+          else { left_len -= q; ref_pos += rlen_of(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
+        }
+        while (have && keep != 0) {
+          const size_t q = qlen_of(cur);
+          if (q > keep) { ops.push_back(((uint32_t)keep << 4) | (cur & 0xF)); keep = 0; }
+          else { keep -= q; ops.push_back(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
+        }
+      }
+      std::vector<uint8_t> meth; bool has_meth = false;
+      if (b->has_meth && b->has_meth[r]) {
+        has_meth = true;
+        const uint8_t* all = b->read_blob + b->read_off[r]; const uint8_t* me = b->meth + b->meth_off[r]; const size_t nme = (size_t)(b->meth_off[r + 1] - b->meth_off[r]);
+        size_t ci = 0;
+        for (size_t idx = 0; idx + 1 < n; ++idx) if (all[idx] == 'C' && all[idx + 1] == 'G') { if (ci < nme && left <= idx && idx < n - right) meth.push_back(me[ci]); ++ci; }
+      }
+      const std::string name(b->name_blob + b->name_off[r], b->name_off[r + 1] - b->name_off[r]);
+      int64_t ref_end = ref_pos; for (uint32_t op : ops) ref_end += rlen_of(op);
+      rec.clear();
+      put32(rec, 0);  // block_size, patched below
+      put32(rec, (uint32_t)tid); put32(rec, (uint32_t)ref_pos);
+      rec.push_back((uint8_t)(name.size() + 1)); rec.push_back(b->mapq[r]);
+      put16(rec, (uint32_t)reg2bin(ref_pos, ref_end > ref_pos ? ref_end : ref_pos + 1)); put16(rec, (uint32_t)ops.size());
+      put16(rec, b->is_reverse[r] ? 0x10u : 0u); put32(rec, (uint32_t)len);
+      put32(rec, 0xFFFFFFFFu); put32(rec, 0xFFFFFFFFu); put32(rec, 0);  // mate: none
+      rec.insert(rec.end(), name.begin(), name.end()); rec.push_back(0);
+      for (uint32_t op : ops) put32(rec, op);
+      { static const int8_t code[256] = {0};
+        (void)code;
+        auto nib = [](uint8_t c) -> uint8_t { switch (c) { case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7;
+                                                           case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14; default: return 15; } };
+        for (size_t i = 0; i < len; i += 2) rec.push_back((uint8_t)((nib(bases[i]) << 4) | (i + 1 < len ? nib(bases[i + 1]) : 0))); }
+      rec.insert(rec.end(), quals, quals + len);
+      auto tag = [&](const char* t, char ty) { rec.push_back((uint8_t)t[0]); rec.push_back((uint8_t)t[1]); rec.push_back((uint8_t)ty); };
+      tag("TR", 'Z'); rec.insert(rec.end(), id.begin(), id.end()); rec.push_back(0);
+      { tag("rq", 'f'); const float f = std::isnan(b->read_qual[r]) ? -1.0f : (float)b->read_qual[r]; uint32_t u; std::memcpy(&u, &f, 4); put32(rec, u); }
+      if (has_meth) { tag("MC", 'B'); rec.push_back('C'); put32(rec, (uint32_t)meth.size()); rec.insert(rec.end(), meth.begin(), meth.end()); }
+      { tag("MO", 'B'); rec.push_back('i'); const uint64_t a0 = b->mismatch_off[r], a1 = b->mismatch_off[r + 1]; put32(rec, (uint32_t)(a1 - a0)); for (uint64_t k = a0; k < a1; ++k) put32(rec, (uint32_t)b->mismatch_offsets[k]); }
+      if (b->hp_tag[r] >= 0) { tag("HP", 'C'); rec.push_back((uint8_t)b->hp_tag[r]); }
+      tag("SO", 'i'); put32(rec, (uint32_t)b->start_offset[r]);
+      tag("EO", 'i'); put32(rec, (uint32_t)b->end_offset[r]);
+      tag("AL", 'i'); put32(rec, (uint32_t)o->classification[r]);
+      tag("FL", 'B'); rec.push_back('I'); put32(rec, 2); put32(rec, (uint32_t)F); put32(rec, (uint32_t)F);
+      const uint32_t bs = (uint32_t)rec.size() - 4;
+      for (int i = 0; i < 4; ++i) rec[(size_t)i] = (uint8_t)(bs >> (8 * i));
+      if (!w->bam.write(rec.data(), rec.size())) return bad("cannot write the BAM");
+    }
+  }
+  return TRGT_OK;
+}
+
+int trgt_writer_close(trgt_writer* w) {
+  if (!w) return TRGT_OK;
+  const bool ok1 = w->vcf.close(), ok2 = !w->has_bam || w->bam.close();
+  delete w;
+  return ok1 && ok2 ? TRGT_OK : TRGT_ERR_INVALID;
+}
+
+}  // extern "C"

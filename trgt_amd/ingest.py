@@ -49,6 +49,21 @@ def _strings(blob, off, n):
     return [raw[int(o[i]):int(o[i + 1])].decode() for i in range(n)]
 
 
+class NativeBatch:
+    """Owner of a trgt_ingest_batch (freed with the object)."""
+
+    def __init__(self, L, handle):
+        self._L, self.handle = L, handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._L.trgt_ingest_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class Reader:
     """An indexed BAM (<bam>.bai) and an indexed FASTA (<fasta>.fai)."""
 
@@ -85,7 +100,7 @@ class Reader:
         except Exception:
             pass
 
-    def batch(self, bed_path, first_locus=0, max_loci=-1, **params):
+    def batch(self, bed_path, first_locus=0, max_loci=-1, keep_native=False, **params):
         """Loci [first_locus, first_locus + max_loci) of the catalog as the dict of ABI arrays trgt_amd.locus.run_batch takes (the keys
         of synth.generate) plus the catalog fields and the per-read HiFiRead fields the writers need."""
         p = IngestParams()
@@ -121,5 +136,8 @@ class Reader:
         out["cigar"] = _arr(b.cigar, int(out["cigar_off"][-1]) if nr else 0, u32)
         if len(out["read_blob"]) == 0:
             out["read_blob"] = np.zeros(1, u8)
-        self._L.trgt_ingest_free(h)
+        if keep_native:  # the writers (trgt_amd/writers.py) take the native batch itself
+            out["_native"] = NativeBatch(self._L, h)
+        else:
+            self._L.trgt_ingest_free(h)
         return out

@@ -149,10 +149,11 @@ class BatchOutputs:
         self.num_spanning = np.zeros(2 * nl, np.int32)
         self.classification, self.read_rank = np.zeros(nr, np.int32), np.zeros(nr, np.int32)
         self.stats = np.zeros(24, np.int64)
+        self.gt_size, self.flipped = np.zeros(2 * nl, np.int32), np.zeros(nl, np.uint8)
         p = _lib.ptr
         self.c_out = _lib.LocusBatchOut(*[p(getattr(self, n)).value for n in (
             "span_start", "span_end", "n_alleles", "allele_blob", "allele_off", "allele_cap", "allele_len", "ci", "num_spanning",
-            "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off", "purity", "stats")])
+            "classification", "read_rank", "spans3", "span_off", "n_spans", "motif_counts", "count_off", "purity", "stats", "gt_size", "flipped")])
 
 
 _CIN_KEYS = ("lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off", "set_motif_begin", "ploidy",

@@ -1,0 +1,53 @@
+"""Native writers (trgt_amd/csrc/writers.hip through the C ABI): the VCF of VcfWriter (src/trgt/writers/write_vcf.rs:19-397, incl. the AM
+field of get_meth, tr.rs:196-262, 363-398) and the spanning-reads BAM of BamWriter (src/trgt/writers/write_bam.rs:33-144) for batches that
+came through the native ingestion (trgt_amd/ingest.py) and trgt_locus_batch.  trgt_amd/vcf.py is the Python mirror of one VCF record."""
+import ctypes as C
+
+from . import _lib
+from .ingest import IngestBatch
+
+
+class WriterParams(C.Structure):
+    _fields_ = [("output_flank_len", C.c_int32), ("sample_name", C.c_char_p), ("program", C.c_char_p), ("version", C.c_char_p),
+                ("command_line", C.c_char_p)]
+
+
+class Writer:
+    def __init__(self, reader, vcf_path, bam_path=None, output_flank_len=50, sample_name="sample", program="trgt", version="3.0.0",
+                 command_line=""):
+        L = _lib.lib()
+        L.trgt_writer_open.argtypes = [C.c_void_p, C.POINTER(WriterParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.trgt_writer_write.argtypes = [C.c_void_p, C.POINTER(IngestBatch), C.c_void_p]
+        L.trgt_writer_close.argtypes = [C.c_void_p]
+        L.trgt_writer_last_error.argtypes = [C.c_void_p]
+        L.trgt_writer_last_error.restype = C.c_char_p
+        self._L = L
+        self._keep = [s.encode() for s in (sample_name, program, version, command_line)]
+        p = WriterParams(output_flank_len, *self._keep)
+        self.handle = C.c_void_p()
+        rc = L.trgt_writer_open(reader.handle, C.byref(p), str(vcf_path).encode(), str(bam_path).encode() if bam_path else None, C.byref(self.handle))
+        if rc != 0:
+            msg = L.trgt_writer_last_error(self.handle).decode() if self.handle else "trgt_writer_open failed"
+            if self.handle:
+                L.trgt_writer_close(self.handle)
+                self.handle = C.c_void_p()
+            raise _lib.TrgtHipError("trgt_writer_open: %s" % msg)
+
+    def write(self, batch, outputs):
+        """batch: a dict of ingest.Reader.batch(..., keep_native=True); outputs: the locus.BatchOutputs trgt_locus_batch filled for it"""
+        rc = self._L.trgt_writer_write(self.handle, batch["_native"].handle, C.addressof(outputs.c_out))
+        if rc != 0:
+            raise _lib.TrgtHipError("trgt_writer_write: %s" % self._L.trgt_writer_last_error(self.handle).decode())
+
+    def close(self):
+        if self.handle:
+            rc = self._L.trgt_writer_close(self.handle)
+            self.handle = C.c_void_p()
+            if rc != 0:
+                raise _lib.TrgtHipError("trgt_writer_close failed")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
