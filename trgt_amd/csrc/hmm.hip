@@ -519,6 +519,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const double lp_chain = role_del ? lp1 : lp2, lp_step = chain_prev && !chain_xwave ? lp_chain : NINF;
   const int chain_steps = min(63, max((int)set.max_mlen, SUB == 32 ? __shfl_xor((int)set.max_mlen, 32) : 0) - 1);
   const int chain_rounds = (int)set.chain_rounds;
+  // (waves of a multi-wave model that hold no chain state skip the steps: they only cost issue slots of their SIMD)
+  const bool wave_chain = __ballot(lp_step > NINF) != 0ull;
 
   HP_MARK(0);
   // the run-end state's predecessors (the block ends, in block order): the first BE_REG of them by index in registers
@@ -589,7 +591,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           bpi = cand > own ? (role_del ? 1 : 2) : own_bp;
           val = best;
         }
-        for (int t = 0; t < chain_steps; ++t) {
+        for (int t = 0; wave_chain && t < chain_steps; ++t) {
           cand = (wave_shr1_f64(val) + lp_step);
           val = cand > best ? cand : best;
         }
