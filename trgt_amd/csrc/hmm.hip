@@ -784,41 +784,42 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
 // Job list of a launch class resolved on the device: candidate (locus, allele) slots with everything the host knows ahead of the
 // genotyper (motif set, where the allele will be, output places, workspace for its longest possible sequence) become jobs once the
 // genotyper has written how many alleles a locus has and how long they are -- no host round trip between the genotyper and this
-// kernel's launch.  One workgroup; candidates keep their order (the host derives the same list from the same results later).
+// kernel's launch.  One workgroup per launch class (results land at the slot's index: the host needs no job order).
 struct HmmResolveArgs {
   const HmmJobDev* cand; uint32_t n;
   const uint8_t* skip_locus; const int32_t* n_alleles; const uint32_t* allele_len;  // genotyper results (device), by locus / slot
   HmmJobDev* jobs; uint32_t* n_jobs; uint32_t* n_spans; double* purity;
+  uint32_t len_shift;  // alleles are binned by length >> len_shift (64 bins, the last one open)
 };
+// ... longest alleles first (bins of similar length, descending): workgroups start in list order and a launch ends with its last
+// allele -- a long allele started behind thousands of short ones is pure tail.  Three sweeps over the candidates: count per bin,
+// exclusive scan over the bins from the longest down, scatter (the order inside a bin is whatever the atomics make it; results do
+// not depend on the job order).
 __global__ void __launch_bounds__(1024) hmm_resolve_kernel(const HmmResolveArgs a) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t base_s;
-  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) base_s = 0;
+  __shared__ uint32_t hist[64], cursor[64];
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
   __syncthreads();
-  for (uint32_t i0 = 0; i0 < a.n; i0 += 1024) {
-    const uint32_t i = i0 + (uint32_t)tid;
+  auto probe = [&](uint32_t i, HmmJobDev& jd) -> bool {
+    jd = a.cand[i];
+    const uint32_t slot = jd.job_index, l = slot >> 1, al = slot & 1u;
+    const bool on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
+    if (on) jd.seq_len = a.allele_len[slot];
+    return on;
+  };
+  auto bin_of = [&](uint32_t len) { const uint32_t b = len >> a.len_shift; return 63u - (b < 63u ? b : 63u); };  // bin 0 = the longest
+  for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
     HmmJobDev jd;
-    bool on = false;
-    if (i < a.n) {
-      jd = a.cand[i];
-      const uint32_t slot = jd.job_index, l = slot >> 1, al = slot & 1u;
-      on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
-      if (on) jd.seq_len = a.allele_len[slot];
-      else { a.n_spans[slot] = 0; a.purity[slot] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
-    }
-    const unsigned long long m = __ballot(on);
-    const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t off = base_s;
-    for (int k = 0; k < w; ++k) off += wsum[k];
-    if (on) a.jobs[off + before] = jd;
-    __syncthreads();
-    if (tid == 0) { uint32_t t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base_s += t; }
-    __syncthreads();
+    if (probe(i, jd)) atomicAdd(&hist[bin_of(jd.seq_len)], 1u);
+    else { a.n_spans[jd.job_index] = 0; a.purity[jd.job_index] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
   }
-  if (tid == 0) *a.n_jobs = base_s;
+  __syncthreads();
+  if (tid == 0) { uint32_t run = 0; for (int b = 0; b < 64; ++b) { cursor[b] = run; run += hist[b]; } *a.n_jobs = run; }
+  __syncthreads();
+  for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
+    HmmJobDev jd;
+    if (probe(i, jd)) a.jobs[atomicAdd(&cursor[bin_of(jd.seq_len)], 1u)] = jd;
+  }
 }
 
 // Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
@@ -1318,11 +1319,14 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       (rc = o_maxd.init(c, S_HMM_MAXD + so, (int32_t*)nullptr, 0)))
     return rc;
   if (o_cnt.staged) { P->cnt_user = motif_counts; P->cnt_total = count_total; o_cnt.staged = false; }
+  uint32_t max_cap = 1, len_shift = 0;
+  for (int64_t l = 0; l < nl; ++l) max_cap = std::max(max_cap, in.cap[l]);
+  while ((max_cap >> len_shift) >= 64) ++len_shift;
   // slots that are no candidates at all (loci left to the host path) hold "no allele" too
   TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
   for (int k = 0; k < 8; ++k) {
     if (!class_n[k]) continue;
-    HmmResolveArgs ra{d_cand + class_begin[k], class_n[k], in.d_skip, in.d_n_alleles, in.d_allele_len, d_list + class_begin[k], d_count + k, o_nsp.dev, o_pur.dev};
+    HmmResolveArgs ra{d_cand + class_begin[k], class_n[k], in.d_skip, in.d_n_alleles, in.d_allele_len, d_list + class_begin[k], d_count + k, o_nsp.dev, o_pur.dev, len_shift};
     hipLaunchKernelGGL(hmm_resolve_kernel, dim3(1), dim3(1024), 0, c->stream, ra);
   }
   TRGT_HIP_TRY(c, hipGetLastError());
