@@ -136,11 +136,11 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_amd.driver.ChunkDriver): > 1 overlaps the host-bound tail of one step with the flank location of the next; 0 = by config (2 for configs 3 and 5, whose tails are long and host-bound, else 1)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_amd.driver.ChunkDriver): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large); 1 = the blocking call only")
     args = ap.parse_args()
     n_loci = args.loci or DEFAULT_LOCI[args.config]
     if args.contexts <= 0:
-        args.contexts = {3: 2, 5: 2}.get(args.config, 1)  # measured on MI355X: 1.9x / 1.5x for configs 3 / 5, a loss for 2 / 4
+        args.contexts = {3: 3}.get(args.config, 4)  # measured on MI355X: 1.1x / 1.7x / 1.4x / 1.4x for configs 2 / 3 / 4 / 5; value_single_context is printed next to it
 
     import torch
     import torch.distributed as dist
@@ -186,36 +186,49 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # a generation-2 collection of the driver script's own objects showed up as a 30-40 ms pause in one call out of ~400
+    # ---- K steps on ONE context (the blocking call, batch after batch) ...
+    fence()
+    t0 = time.perf_counter()
+    marks = [t0]
+    for _ in range(args.steps):
+        step()
+        marks.append(time.perf_counter())  # (a call is synchronous: no extra synchronisation is added inside the timed region)
+    fence()
+    dt_single = time.perf_counter() - t0
+    names = {k: n for n, k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4), ("wfa_filter", 5))}
+    kt = {names[k]: ctx.timing_get(k) for k in names}
+    ctx.timing_enable(False)
+    dt = dt_single
+    # ---- ... and through `contexts` worker threads, one context each, all on this rank's GPU, draining a queue of the same K steps:
+    #      a call's host-bound tail (results back, the few loci of the host path, HMM collection) and the kernels of its last stage
+    #      overlap the flank location of the next calls.  This is `value`; the per-kernel times below are then those of this region,
+    #      summed over the contexts.
     drv = None
-    if args.contexts > 1:  # K steps through a queue drained by `contexts` worker threads, one context each, all on this rank's GPU
+    if args.contexts > 1:
         from trgt_amd.driver import ChunkDriver
         drv = ChunkDriver(devices=[local_rank] * args.contexts, params=params)
         outs_w = [locus.BatchOutputs(batch) for _ in range(args.contexts)]
         wk = lambda w: dict(outputs=outs_w[w], flank_dev=flank_dev, reads_dev=reads_dev)
         drv.run([batch] * (2 * args.contexts), worker_kwargs=wk)  # set-up of every context (buffer pools, code objects)
-    fence()
-    t0 = time.perf_counter()
-    marks = [t0]
-    if drv is not None:
+        for c in drv.contexts:
+            c.timing_enable(True)
+        drv.run([batch] * (3 * args.contexts), worker_kwargs=wk)  # (the one-off cost of the first timing events, see above)
+        for c in drv.contexts:
+            c.timing_reset()
+        fence()
+        t0 = time.perf_counter()
         drv.run([batch] * args.steps, worker_kwargs=wk)
-        marks.append(time.perf_counter())
-    else:
-        for _ in range(args.steps):
-            step()
-            marks.append(time.perf_counter())  # (a call is synchronous: no extra synchronisation is added inside the timed region)
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if drv is not None:
+        fence()
+        dt = time.perf_counter() - t0
+        kt = {names[k]: tuple(sum(c.timing_get(k)[i] for c in drv.contexts) for i in range(3)) for k in names}
         for o in outs_w:
             if shard.result_digest(o, n_loci) != shard.result_digest(out, n_loci):
                 raise SystemExit("bench.py: a worker context returned different results")
         drv.close()
+    gc.enable()
     step_ms = sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))
-    names = {k: n for n, k in (("flank_scan", 0), ("wfa_consensus", 1), ("hmm_viterbi", 2), ("wfa_flank", 3), ("wfa_flank_rest", 4), ("wfa_filter", 5))}
-    kt = {names[k]: ctx.timing_get(k) for k in names}
-    ctx.timing_enable(False)
     dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
+    dt_single = shard.max_over_ranks(dt_single, dist if world > 1 else None, device="cuda")
 
     # ---- the same batches with the reads starting in pinned host memory, through the pipelined entry points: the upload of batch
     #      k + 1 (trgt_locus_batch_submit, copy stream) runs next to the kernels of batch k (trgt_locus_batch_wait)
@@ -316,11 +329,12 @@ def main():
         res = {
             "metric": "loci/s", "value": round(world * n_loci * args.steps / dt, 1), "unit": "loci/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "ms_per_step_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
+            "ms_per_step_single_context_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+u8 packed (WFA pre-filter), u16 (WFA back-trace), f64 (HMM)",
             "data": "synthetic",
             "value_is": "HBM-resident: read and flank bytes are in HBM before the timed region; value_streaming: every batch's reads start in pinned host memory and are uploaded by trgt_locus_batch_submit next to the compute of the batch before (trgt_locus_batch_wait)",
             "value_streaming": round(world * n_loci / dt_stream, 1) if dt_stream else None,
+            "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
                        "host_threads_per_rank": host_threads, "contexts_per_gpu": args.contexts},
