@@ -85,7 +85,7 @@ __device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__
 }
 
 template <int MAXR, int SEG>
-__global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {
+__global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  // exactly one wave per locus: the lane-0 sections and the ballots rely on it
   __shared__ GtShared<MAXR, SEG> sh;
   const int64_t l = blockIdx.x;
   if (l >= a.n_loci) return;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {
   }
   if (n > 0 && !sh.bail) {
     // ---- unique lengths / counts ascending (sorted(lens) of genotype_size_front; after a downsample the list is not sorted)
-    {
+    if (lane == 0) {  // (one lane builds the histogram: read-modify-writes of LDS by 64 lanes at once only work by lockstep)
       int u = 0;
       for (int i = 0; i < n; ++i) {
         const uint32_t v = sh.s_len[i];
@@ -260,9 +260,13 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {
           if (c == 0) { eq = mid; break; }
           if (c < 0) hi = mid; else lo = mid + 1;
         }
-        if (eq >= 0) { sh.u_cnt[eq] += 1; continue; }
-        for (int q = nu; q > lo; --q) { sh.u_rep[q] = sh.u_rep[q - 1]; sh.u_cnt[q] = sh.u_cnt[q - 1]; }
-        sh.u_rep[lo] = (uint16_t)i; sh.u_cnt[lo] = 1; ++nu;
+        // (the list is written by lane 0 only; the comparisons of the next round read it back in program order: one wave, one LDS queue)
+        if (eq >= 0) { if (lane == 0) sh.u_cnt[eq] += 1; continue; }
+        if (lane == 0) {
+          for (int q = nu; q > lo; --q) { sh.u_rep[q] = sh.u_rep[q - 1]; sh.u_cnt[q] = sh.u_cnt[q - 1]; }
+          sh.u_rep[lo] = (uint16_t)i; sh.u_cnt[lo] = 1;
+        }
+        ++nu;
       }
       auto ulen_of = [&](int q) { return sh.s_len[sh.u_rep[q]]; };
       auto closest = [&](uint32_t target) { uint32_t c = ulen_of(0); for (int q = 0; q < nu; ++q) if (adiff_u(c, target) > adiff_u(ulen_of(q), target)) c = ulen_of(q); return c; };
