@@ -32,6 +32,7 @@ struct trgt_knobs {
   bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them
   bool host_genotyper = false;  // TRGT_HOST_GENOTYPER: host glue for every locus
   bool no_early = false;        // TRGT_WFA_NO_EARLY: the flank pre-filter runs every alignment to its end
+  bool stage_lock = false;      // TRGT_STAGE_LOCK: only one context per device in its flank-location stage at a time
   bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr

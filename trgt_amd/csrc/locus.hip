@@ -561,10 +561,13 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
   TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
   ((uint64_t*)h_cells)[0] = ((uint64_t*)h_cells)[1] = 0;
-  // Stage A of one call at a time per device.  Several contexts on one GPU (one host thread each, trgt_amd/driver.py) then form a
-  // pipeline: while one call is in its host-bound tail (consensus repair, HMM collection) the next one's flank location has the
-  // GPU to itself -- two stage A's at once only fight over the CUs their persistent kernels were sized to fill.
-  std::unique_lock<std::mutex> stage_a_token(g_stage_a_mutex[(size_t)c->device % 16]);
+  // Several contexts on one GPU (one host thread each, trgt_amd/driver.py) form a pipeline: while one call is in its tail (results
+  // back, the loci of the host path, HMM) the next ones' flank location has the GPU.  TRGT_STAGE_LOCK=1 lets only one call per device
+  // be in stage A at a time -- that was worth 2x while the tails were host-bound (first half of round 2); since the stage-C job list
+  // and the model tables are made on the device, letting the stages overlap freely is 14 % faster on the 10k-locus batch (1.50 -> 1.71 M
+  // loci/s with four contexts) and neutral on the others.
+  std::unique_lock<std::mutex> stage_a_token(g_stage_a_mutex[(size_t)c->device % 16], std::defer_lock);
+  if (c->knobs.stage_lock) stage_a_token.lock();
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
@@ -624,7 +627,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // ---------------- wait for the GPU, publish spans
   {
     TRGT_HIP_TRY(c, hipEventSynchronize(evA));
-    stage_a_token.unlock();
+    if (stage_a_token.owns_lock()) stage_a_token.unlock();
     tA = now_ns() - tw_a;
   TL("evA");
   }
