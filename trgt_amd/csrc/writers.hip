@@ -303,9 +303,7 @@ int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_loc
       put32(rec, 0xFFFFFFFFu); put32(rec, 0xFFFFFFFFu); put32(rec, 0);  // mate: none
       rec.insert(rec.end(), name.begin(), name.end()); rec.push_back(0);
       for (uint32_t op : ops) put32(rec, op);
-      { static const int8_t code[256] = {0};
-        (void)code;
-        auto nib = [](uint8_t c) -> uint8_t { switch (c) { case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7;
+      { auto nib = [](uint8_t c) -> uint8_t { switch (c) { case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7;
                                                            case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14; default: return 15; } };
         for (size_t i = 0; i < len; i += 2) rec.push_back((uint8_t)((nib(bases[i]) << 4) | (i + 1 < len ? nib(bases[i + 1]) : 0))); }
       rec.insert(rec.end(), quals, quals + len);
