@@ -66,6 +66,7 @@ struct trgt_hip_ctx {
   hipStream_t stream2 = nullptr;
   struct PinBuf { void* p = nullptr; size_t cap = 0; };
   std::vector<PinBuf> pinned;
+  std::vector<PinBuf> h2d_stage;  // pinned staging of the small uploads, one per device slot (h2d_small)
   void* host_pool = nullptr;  // trgt::HostPool*, created on first use
   int host_pool_threads = 0;
   // trgt_locus_batch_submit / _wait: two staging sets for the read and flank bytes of batches whose upload runs on `stream_copy`
@@ -179,6 +180,48 @@ inline int pin_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   return TRGT_OK;
 }
 
+// Small host -> device uploads (offset tables, job lists, model inputs: KB to a few MB) go through a KERNEL that reads pinned host
+// memory, not through hipMemcpyAsync: the copy engine serves the host-to-device copies of ALL streams and contexts in issue order, and
+// a table queued behind another call's 360-MB read upload waits milliseconds for it (several contexts per GPU, or the pipelined
+// submit / wait entry points, then run at 70 % of the link rate).  Bulk data (the read and flank blobs) stays on the copy engine.
+constexpr size_t H2D_KERNEL_MAX = 8u << 20;
+static __global__ void h2d_copy_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t bytes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+    const size_t n16 = bytes >> 4;
+    for (size_t k = i; k < n16; k += n) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+    for (size_t k = (n16 << 4) + i; k < bytes; k += n) dst[k] = src[k];
+  } else for (size_t k = i; k < bytes; k += n) dst[k] = src[k];
+}
+inline bool is_pinned_host_ptr(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+// dst (device) <- src (host) on `stream`.  stage_slot >= 0: src may be pageable, it is copied into that slot's pinned staging first (the
+// caller may then reuse src at once); < 0: src is pinned and stays untouched until the stream has passed the copy.
+inline int h2d_small(trgt_hip_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t stream, int stage_slot) {
+  if (bytes == 0) return TRGT_OK;
+  if (bytes > H2D_KERNEL_MAX) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
+  const void* from = src;
+  if (stage_slot >= 0 && !is_pinned_host_ptr(src)) {
+    if ((int)c->h2d_stage.size() < S_COUNT) c->h2d_stage.resize(S_COUNT);
+    auto& b = c->h2d_stage[(size_t)stage_slot];
+    if (b.cap < bytes) {
+      if (b.p) { TRGT_HIP_TRY(c, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+      const size_t want = bytes + bytes / 4 + 4096;
+      if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return fail(c, TRGT_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", want); }
+      b.cap = want;
+    }
+    std::memcpy(b.p, src, bytes);
+    from = b.p;
+  }
+  const unsigned blocks = (unsigned)std::min<size_t>(256, (bytes / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(h2d_copy_kernel, dim3(blocks), dim3(256), 0, stream, (uint8_t*)dst, (const uint8_t*)from, bytes);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  return TRGT_OK;
+}
+
 // Input that may live on the host or on the device.  dev() returns a device pointer valid until the next
 // use of the same slot (uploading on the ctx stream when the caller's pointer is a host pointer).
 template <typename T>
@@ -187,7 +230,7 @@ inline int dev_in(trgt_hip_ctx* c, int slot, const T* p, size_t count, const T**
   void* d = nullptr;
   int rc = dev_get(c, slot, count * sizeof(T), &d);
   if (rc) return rc;
-  if (count) TRGT_HIP_TRY(c, hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  if (count && (rc = h2d_small(c, d, p, count * sizeof(T), c->stream, slot))) return rc;
   *out = (const T*)d;
   return TRGT_OK;
 }

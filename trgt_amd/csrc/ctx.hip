@@ -69,6 +69,7 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
   if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
   delete static_cast<trgt::HostPool*>(c->host_pool);
+  for (auto& b : c->h2d_stage) if (b.p) (void)hipHostFree(b.p);
   for (auto& b : c->pinned)
     if (b.p) (void)hipHostFree(b.p);
   trgt::resolve_timing(c);

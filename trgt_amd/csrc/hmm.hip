@@ -979,7 +979,7 @@ int hmm_models_on_device(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_b
     }
   }
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(dv, h, lay.total, hipMemcpyHostToDevice, up));
+  if ((rc = h2d_small(c, dv, h, lay.total, up, -1))) return out.rc = rc;  // (pinned source; a kernel copy: not queued behind bulk uploads)
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, (uint8_t*)dv + o_sets, sizeof(HmmSetDev) * (size_t)n_sets, hipMemcpyDeviceToDevice, up));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_blob, 0, (size_t)pos, up));  // (padding between the tables: the blob compares equal to the host builder's)
   HmmBuildArgs a;
@@ -1122,7 +1122,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     uint64_t o = 0;
     for (int64_t j = 0; j < n_jobs; ++j) { toff[(size_t)j] = o; std::memcpy((uint8_t*)h_tight + o, seq_blob + seq_off[j], seq_len[j]); o += seq_len[j]; }
     for (auto& jd : jobs) jd.seq_off = toff[jd.job_index];
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_tight, h_tight, (size_t)tight, hipMemcpyHostToDevice, c->stream));
+    if ((rc = h2d_small(c, d_tight, h_tight, (size_t)tight, c->stream, -1))) return rc;
     d_seq = (const uint8_t*)d_tight;
   }
   void *d_sets = nullptr, *d_model = nullptr, *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
@@ -1154,7 +1154,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     void* h_jobs = nullptr;
     if ((rc = pin_get(c, buffer_set ? P_HMM_JOBS_B : P_HMM_JOBS, jobs.size() * sizeof(HmmJobDev), &h_jobs))) return rc;
     std::memcpy(h_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, jobs.size() * sizeof(HmmJobDev), hipMemcpyHostToDevice, c->stream));
+    if ((rc = h2d_small(c, d_jobs, h_jobs, jobs.size() * sizeof(HmmJobDev), c->stream, -1))) return rc;
   }
   if ((rc = o_path.init(c, S_HMM_PATH + so, path, (size_t)path_total))) return rc;
   if ((rc = o_plen.init(c, S_HMM_PLEN + so, path_len, (size_t)n_jobs))) return rc;
@@ -1300,7 +1300,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   {  // on the copy stream: a copy queued on the batch's stream would sit in the copy engine's queue until the genotyper in front of it
      // has run, and hold up every copy issued after it (the next batch's reads)
     hipStream_t us = c->stream_copy ? c->stream_copy : c->stream;
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_cand, h_cand, jobs_bytes, hipMemcpyHostToDevice, us));
+    if ((rc = h2d_small(c, d_cand, h_cand, jobs_bytes, us, -1))) return rc;
     if (us != c->stream) {
       if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
       TRGT_HIP_TRY(c, hipEventRecord(c->ev_upload, us));
@@ -1414,8 +1414,11 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
     if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16, &d_poff))) return rc;
     d_toff = (uint8_t*)d_poff + (size_t)n_jobs * 8;
     if ((rc = dev_get(c, S_HMM_BP + so, (size_t)ptotal * 12 + 16, &d_packed))) return rc;  // the back-pointer workspace is free again
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_poff, poff.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpyAsync(d_toff, tight_off.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
+    {  // (both tables through one staging buffer of the slot: poff | toff)
+      std::vector<uint64_t> both((size_t)n_jobs * 2);
+      std::memcpy(both.data(), poff.data(), (size_t)n_jobs * 8); std::memcpy(both.data() + n_jobs, tight_off.data(), (size_t)n_jobs * 8);
+      if ((rc = h2d_small(c, d_poff, both.data(), (size_t)n_jobs * 16, c->stream, S_HMM_MOTIFS + so))) return rc;
+    }
     hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)o_spans.dev,
                        (const uint64_t*)d_toff, (const uint32_t*)o_nsp.dev, (const uint64_t*)d_poff, (int32_t*)d_packed, (uint64_t)n_jobs);
     TRGT_HIP_TRY(c, hipGetLastError());

@@ -313,7 +313,7 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
   if ((rc = dev_get(c, S_VOTE_GROUPS, n_groups * sizeof(vote::Group), &d_groups)) || (rc = dev_get(c, S_VOTE_SCRATCH, (size_t)scratch_words * 4 + 16, &d_scratch)) ||
       (rc = dev_get(c, S_VOTE_OUT, (size_t)out_total + 16, &d_out)) || (rc = dev_get(c, S_VOTE_LEN, n_groups * 4, &d_len)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_groups, groups.data(), n_groups * sizeof(vote::Group), hipMemcpyHostToDevice, c->stream));
+  if ((rc = h2d_small(c, d_groups, groups.data(), n_groups * sizeof(vote::Group), c->stream, S_VOTE_GROUPS))) return rc;
   vote::VoteArgs va{(const vote::Group*)d_groups, (uint32_t)n_groups, dev.seqs, dev.jobs, dev.cigar, dev.cigar_len, (uint32_t*)d_scratch, (uint8_t*)d_out, (uint32_t*)d_len};
   hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)n_groups), dim3(vote::VOTE_THREADS), 0, c->stream, va);
   TRGT_HIP_TRY(c, hipGetLastError());

@@ -645,7 +645,7 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   WTL("sequences uploaded");
   void* d_jobs = nullptr;
   if ((rc = dev_get(c, S_WFA_JOBS, jobs.size() * sizeof(JobDev), &d_jobs))) return rc;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), hipMemcpyHostToDevice, c->stream));
+  if ((rc = h2d_small(c, d_jobs, jobs.data(), jobs.size() * sizeof(JobDev), c->stream, S_WFA_JOBS))) return rc;
   DevOut<int32_t> o_status, o_score, o_nm; DevOut<uint32_t> o_span, o_cigar, o_clen, o_olen; DevOut<uint8_t> o_ops;
   std::vector<uint32_t> h_clen;
   if (packed || on_device) {  // device-only CIGAR slots; the lengths come back first (packed) or not at all (on_device)
@@ -692,7 +692,7 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
     if (total) {
       void *d_poff = nullptr, *d_packed = nullptr;
       if ((rc = dev_get(c, S_WFA_POFF, (size_t)n_jobs * 8, &d_poff)) || (rc = dev_get(c, S_WFA_PACKED, (size_t)total * 4, &d_packed))) return rc;
-      TRGT_HIP_TRY(c, hipMemcpyAsync(d_poff, packed->off.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, c->stream));
+      if ((rc = h2d_small(c, d_poff, packed->off.data(), (size_t)n_jobs * 8, c->stream, S_WFA_POFF))) return rc;
       hipLaunchKernelGGL(cigar_pack_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, (const uint32_t*)o_cigar.dev,
                          (const JobDev*)d_jobs, (const uint32_t*)o_clen.dev, (const uint64_t*)d_poff, (uint32_t*)d_packed, (uint64_t)n_jobs);
       TRGT_HIP_TRY(c, hipGetLastError());
