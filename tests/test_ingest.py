@@ -188,3 +188,28 @@ def test_errors_are_reported(tmp_path):
     open(bad, "w").write("chrA\t100\t161\tID=TR1;MOTIFS=CAG;STRUC=(CAG)n\n")
     with pytest.raises(_lib.TrgtHipError, match="BED line 1"):
         rd.batch(bad)
+
+
+def test_truncated_and_corrupt_files_give_errors_not_crashes(tmp_path):
+    import shutil
+    from trgt_amd import _lib, ingest
+    fa = os.path.join(EX, "reference.fasta")
+    data = open(os.path.join(EX, "sample.bam"), "rb").read()
+    outcomes = []
+    for tag, blob in [("cut90", data[:int(len(data) * 0.9)]), ("cut50", data[:len(data) // 2]), ("cut1", data[:len(data) // 100]),
+                      ("flip", data[:60000] + bytes(b ^ 0x5A for b in data[60000:60200]) + data[60200:])]:
+        bam = str(tmp_path / (tag + ".bam"))
+        open(bam, "wb").write(blob)
+        shutil.copy(os.path.join(EX, "sample.bam.bai"), bam + ".bai")
+        try:
+            b = ingest.Reader(bam, fa).batch(os.path.join(EX, "repeat.bed"))
+            outcomes.append((tag, int(b["n_reads"])))
+        except _lib.TrgtHipError as e:
+            outcomes.append((tag, str(e)))
+    assert all(isinstance(v, str) or 0 <= v <= 33 for _, v in outcomes), outcomes
+    assert any(isinstance(v, str) for _, v in outcomes), outcomes  # at least the badly damaged files are reported
+    bam = str(tmp_path / "badidx.bam")
+    shutil.copy(os.path.join(EX, "sample.bam"), bam)
+    open(bam + ".bai", "wb").write(b"BAI\1" + b"\xff" * 40)
+    with pytest.raises(_lib.TrgtHipError):
+        ingest.Reader(bam, fa)

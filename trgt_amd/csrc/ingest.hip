@@ -21,6 +21,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <new>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -119,6 +120,7 @@ struct Bai {
     size_t p = 4;
     auto need = [&](size_t n) { return p + n <= d.size(); };
     const uint32_t n_ref = le32(&d[p]); p += 4;
+    if ((uint64_t)n_ref * 8 > d.size()) { err = "corrupt BAI"; return false; }  // (every reference has at least two counters)
     refs.resize(n_ref);
     for (uint32_t r = 0; r < n_ref; ++r) {
       if (!need(4)) { err = "truncated BAI"; return false; }
@@ -508,7 +510,7 @@ int32_t trgt_ingest_n_contigs(const trgt_ingest* h) { return h ? (int32_t)h->ref
 const char* trgt_ingest_contig_name(const trgt_ingest* h, int32_t i) { return h && i >= 0 && (size_t)i < h->ref_names.size() ? h->ref_names[(size_t)i].c_str() : ""; }
 uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i) { return h && i >= 0 && (size_t)i < h->ref_len.size() ? h->ref_len[(size_t)i] : 0; }
 
-int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out) {
+static int ingest_open_impl(const char* bam_path, const char* fasta_path, trgt_ingest** out) {
   if (!bam_path || !fasta_path || !out) return TRGT_ERR_INVALID;
   std::unique_ptr<trgt_ingest> h(new trgt_ingest());
   *out = nullptr;
@@ -519,15 +521,18 @@ int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest**
   uint8_t b[8];
   if (z.read(b, 8) != 1 || std::memcmp(b, "BAM\1", 4) != 0) return bad("not a BAM file");
   const uint32_t l_text = le32(b + 4);
+  if (l_text > (1u << 30)) return bad("corrupt BAM header");
   std::vector<uint8_t> text(l_text);
   if (l_text && z.read(text.data(), l_text) != 1) return bad("truncated BAM header");
   h->header_text.assign(text.begin(), text.end());
   while (!h->header_text.empty() && h->header_text.back() == '\0') h->header_text.pop_back();
   if (z.read(b, 4) != 1) return bad("truncated BAM header");
   const uint32_t n_ref = le32(b);
+  if (n_ref > (1u << 24)) return bad("corrupt BAM header");
   for (uint32_t r = 0; r < n_ref; ++r) {
     if (z.read(b, 4) != 1) return bad("truncated BAM header");
     const uint32_t l_name = le32(b);
+    if (l_name > 65536) return bad("corrupt BAM header");
     std::string name(l_name, '\0');
     if (l_name && z.read(&name[0], l_name) != 1) return bad("truncated BAM header");
     if (z.read(b, 4) != 1) return bad("truncated BAM header");
@@ -578,8 +583,8 @@ static bool parse_bed_line(const std::string& line, std::string& contig, int64_t
   return true;
 }
 
-int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus, int64_t max_loci,
-                                   trgt_ingest_batch** out) {
+static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus, int64_t max_loci,
+                             trgt_ingest_batch** out) {
   if (!h || !p || !bed_path || !out) return TRGT_ERR_INVALID;
   *out = nullptr;
   auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
@@ -610,7 +615,7 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
   int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, nl));
   std::atomic<int64_t> next{0};
-  auto work = [&]() {
+  auto work_body = [&]() {
     Bgzf z;
     if (!z.open(h->bam_path.c_str())) { for (auto& l : loci) if (l.err.empty()) { l.err = z.err; break; } return; }
     RawRec rec;
@@ -634,7 +639,7 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
           const int g = z.read(b4, 4);
           if (g == 0) break;
           if (g < 0) { l.err = z.err; stop = true; break; }
-          rec.d.resize(le32(b4));
+          { const uint32_t bs = le32(b4); if (bs < 32 || bs > (1u << 29)) { l.err = "corrupt BAM record"; stop = true; break; } rec.d.resize(bs); }
           if (z.read(rec.d.data(), rec.d.size()) != 1 || !parse_rec(rec)) { l.err = z.err.empty() ? "corrupt BAM record" : z.err; stop = true; break; }
           if (rec.ref_id != tid || rec.pos >= end) { stop = true; break; }  // sorted: nothing further overlaps
           int64_t rend = rec_ref_end(rec);
@@ -659,6 +664,10 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
       for (auto& r : l.reads) { Read c; if (clip_to_region(r, rs, re, c)) clipped.push_back(std::move(c)); }
       l.reads.swap(clipped);
     }
+  };
+  std::atomic<int> worker_failed{0};
+  auto work = [&]() {  // (an exception must not leave a thread, nor cross the C ABI)
+    try { work_body(); } catch (const std::exception& e) { worker_failed = 1; for (auto& l : loci) if (l.err.empty()) { l.err = std::string("reading the BAM: ") + e.what(); break; } }
   };
   if (nthr <= 1) work();
   else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
@@ -718,6 +727,20 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
   B.owner = S.release();
   *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
   return TRGT_OK;
+}
+
+// exceptions (std::bad_alloc on a corrupt size field, ...) never cross the C ABI
+int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out) {
+  try { return ingest_open_impl(bam_path, fasta_path, out); }
+  catch (const std::exception& e) {
+    if (out) { trgt_ingest* h = new (std::nothrow) trgt_ingest(); if (h) h->err = std::string("trgt_ingest_open: ") + e.what(); *out = h; }
+    return TRGT_ERR_NOMEM;
+  }
+}
+int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus, int64_t max_loci,
+                                   trgt_ingest_batch** out) {
+  try { return ingest_batch_impl(h, p, bed_path, first_locus, max_loci, out); }
+  catch (const std::exception& e) { if (h) h->err = std::string("trgt_ingest_batch_from_catalog: ") + e.what(); return TRGT_ERR_NOMEM; }
 }
 
 }  // extern "C"

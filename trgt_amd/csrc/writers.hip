@@ -99,7 +99,7 @@ void trgt_writer_default_params(trgt_writer_params* p) {
   p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = "";
 }
 
-int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
+static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
   if (!src || !p || !vcf_path || !out) return TRGT_ERR_INVALID;
   std::unique_ptr<trgt_writer> w(new trgt_writer());
   *out = nullptr;
@@ -148,7 +148,7 @@ int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const 
   return TRGT_OK;
 }
 
-int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* o) {
+static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* o) {
   if (!w || !b || !o) return TRGT_ERR_INVALID;
   auto bad = [&](const std::string& m) { w->err = m; return TRGT_ERR_INVALID; };
   if (!o->n_alleles || !o->allele_blob || !o->allele_off || !o->allele_len || !o->ci || !o->num_spanning || !o->classification || !o->read_rank ||
@@ -323,6 +323,13 @@ int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_loc
     }
   }
   return TRGT_OK;
+}
+
+int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
+  try { return writer_open_impl(src, p, vcf_path, bam_path, out); } catch (const std::exception&) { return TRGT_ERR_NOMEM; }  // (exceptions never cross the C ABI)
+}
+int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* o) {
+  try { return writer_write_impl(w, b, o); } catch (const std::exception& e) { if (w) w->err = std::string("trgt_writer_write: ") + e.what(); return TRGT_ERR_NOMEM; }
 }
 
 int trgt_writer_close(trgt_writer* w) {
