@@ -795,30 +795,34 @@ struct HmmResolveArgs {
 // allele -- a long allele started behind thousands of short ones is pure tail.  Three sweeps over the candidates: count per bin,
 // exclusive scan over the bins from the longest down, scatter (the order inside a bin is whatever the atomics make it; results do
 // not depend on the job order).
+constexpr uint32_t HMM_RESOLVE_LDS = 24576;  // candidates whose (active, length) verdict is kept in LDS between the sweeps (96 KB)
 __global__ void __launch_bounds__(1024) hmm_resolve_kernel(const HmmResolveArgs a) {
   __shared__ uint32_t hist[64], cursor[64];
+  __shared__ uint32_t verdict[HMM_RESOLVE_LDS];  // length + 1 of an active candidate, 0 otherwise
   const int tid = (int)threadIdx.x;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
-  auto probe = [&](uint32_t i, HmmJobDev& jd) -> bool {
-    jd = a.cand[i];
-    const uint32_t slot = jd.job_index, l = slot >> 1, al = slot & 1u;
+  auto probe = [&](uint32_t i) -> uint32_t {  // length + 1 if candidate i is a job, else 0
+    const uint32_t slot = a.cand[i].job_index, l = slot >> 1, al = slot & 1u;
     const bool on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
-    if (on) jd.seq_len = a.allele_len[slot];
-    return on;
+    if (!on) { a.n_spans[slot] = 0; a.purity[slot] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
+    return on ? a.allele_len[slot] + 1u : 0u;
   };
   auto bin_of = [&](uint32_t len) { const uint32_t b = len >> a.len_shift; return 63u - (b < 63u ? b : 63u); };  // bin 0 = the longest
   for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
-    HmmJobDev jd;
-    if (probe(i, jd)) atomicAdd(&hist[bin_of(jd.seq_len)], 1u);
-    else { a.n_spans[jd.job_index] = 0; a.purity[jd.job_index] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
+    const uint32_t v = probe(i);
+    if (i < HMM_RESOLVE_LDS) verdict[i] = v;
+    if (v) atomicAdd(&hist[bin_of(v - 1u)], 1u);
   }
   __syncthreads();
   if (tid == 0) { uint32_t run = 0; for (int b = 0; b < 64; ++b) { cursor[b] = run; run += hist[b]; } *a.n_jobs = run; }
   __syncthreads();
   for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
-    HmmJobDev jd;
-    if (probe(i, jd)) a.jobs[atomicAdd(&cursor[bin_of(jd.seq_len)], 1u)] = jd;
+    const uint32_t v = i < HMM_RESOLVE_LDS ? verdict[i] : probe(i);
+    if (!v) continue;
+    HmmJobDev jd = a.cand[i];
+    jd.seq_len = v - 1u;
+    a.jobs[atomicAdd(&cursor[bin_of(v - 1u)], 1u)] = jd;
   }
 }
 
