@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_amd.driver.ChunkDriver): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large); 1 = the blocking call only")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large); 1 = the blocking call only")
     args = ap.parse_args()
     n_loci = args.loci or DEFAULT_LOCI[args.config]
     if args.contexts <= 0:
@@ -203,28 +203,32 @@ def main():
     #      a call's host-bound tail (results back, the few loci of the host path, HMM collection) and the kernels of its last stage
     #      overlap the flank location of the next calls.  This is `value`; the per-kernel times below are then those of this region,
     #      summed over the contexts.
-    drv = None
+    # ---- ... and through `contexts` contexts on this rank's GPU behind one queue (trgt_hip_pool / trgt_locus_batch_many: one worker
+    #      thread per context inside the library), draining the same K steps: a call's tail (results back, the few loci of the host
+    #      path, HMM collection) and the kernels of its last stage overlap the flank location of the next calls.  This is `value`; the
+    #      per-kernel times below are then those of this region, summed over the contexts.
+    pool, kt_pool = None, None
     if args.contexts > 1:
-        from trgt_amd.driver import ChunkDriver
-        drv = ChunkDriver(devices=[local_rank] * args.contexts, params=params)
+        pool = _lib.Pool([local_rank] * args.contexts)
         outs_w = [locus.BatchOutputs(batch) for _ in range(args.contexts)]
-        wk = lambda w: dict(outputs=outs_w[w], flank_dev=flank_dev, reads_dev=reads_dev)
-        drv.run([batch] * (2 * args.contexts), worker_kwargs=wk)  # set-up of every context (buffer pools, code objects)
-        for c in drv.contexts:
+        many = lambda n: locus.run_many(pool, [batch] * n, params, outs_w, flank_dev=flank_dev, reads_dev=reads_dev, out_per_context=True)
+        many(2 * args.contexts)  # set-up of every context (buffer pools, code objects)
+        for c in pool.contexts:
             c.timing_enable(True)
-        drv.run([batch] * (3 * args.contexts), worker_kwargs=wk)  # (the one-off cost of the first timing events, see above)
-        for c in drv.contexts:
+        many(3 * args.contexts)  # (the one-off cost of the first timing events, see above)
+        for c in pool.contexts:
             c.timing_reset()
         fence()
         t0 = time.perf_counter()
-        drv.run([batch] * args.steps, worker_kwargs=wk)
+        _, ran = many(args.steps)
         fence()
         dt = time.perf_counter() - t0
-        kt = {names[k]: tuple(sum(c.timing_get(k)[i] for c in drv.contexts) for i in range(3)) for k in names}
-        for o in outs_w:
-            if shard.result_digest(o, n_loci) != shard.result_digest(out, n_loci):
-                raise SystemExit("bench.py: a worker context returned different results")
-        drv.close()
+        kt_pool = {names[k]: tuple(sum(c.timing_get(k)[i] for c in pool.contexts) for i in range(3)) for k in names}
+        for w in set(ran):
+            if shard.result_digest(outs_w[w], n_loci) != shard.result_digest(out, n_loci):
+                raise SystemExit("bench.py: a pool context returned different results")
+        for c in pool.contexts:
+            c.timing_enable(False)
     gc.enable()
     step_ms = sorted(1e3 * (b - a) for a, b in zip(marks, marks[1:]))
     dt = shard.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
@@ -259,25 +263,23 @@ def main():
             if shard.result_digest(o, n_loci) != shard.result_digest(out, n_loci):
                 raise SystemExit("bench.py: host-resident reads gave different results than HBM-resident reads")
         dt_stream_single = dt_stream
-        if args.contexts > 1:  # ... and with `contexts` workers, each running the blocking call on reads in pinned host memory (its own
-            from trgt_amd.driver import ChunkDriver  # upload, then its kernels): the upload of one call runs next to the kernels of the others
-            sdrv = ChunkDriver(devices=[local_rank] * args.contexts, params=params)
-            pins_w = [pins[w % 2] if w < 2 else torch.from_numpy(batch["read_blob"]).pin_memory() for w in range(args.contexts)]
+        if pool is not None:  # ... and through the pool, every context running the blocking call on reads in pinned host memory (its
+            # own upload, then its kernels): the upload of one call runs next to the kernels of the others.  (One pinned copy: the
+            # contexts only read it.)
             outs_sw = [locus.BatchOutputs(batch) for _ in range(args.contexts)]
-            swk = lambda w: dict(outputs=outs_sw[w], flank_dev=flank_dev, reads_dev=pins_w[w])
-            sdrv.run([batch] * (3 * args.contexts), worker_kwargs=swk)
+            smany = lambda n: locus.run_many(pool, [batch] * n, params, outs_sw, flank_dev=flank_dev, reads_dev=pins[0], out_per_context=True)
+            smany(3 * args.contexts)
             gc.collect()
             gc.disable()
             fence()
             t0 = time.perf_counter()
-            sdrv.run([batch] * n_s, worker_kwargs=swk)
+            _, sran = smany(n_s)
             fence()
             dt_stream = shard.max_over_ranks((time.perf_counter() - t0) / n_s, dist if world > 1 else None, device="cuda")
             gc.enable()
-            for o in outs_sw:
-                if shard.result_digest(o, n_loci) != shard.result_digest(out, n_loci):
+            for w in set(sran):
+                if shard.result_digest(outs_sw[w], n_loci) != shard.result_digest(out, n_loci):
                     raise SystemExit("bench.py: host-resident reads gave different results than HBM-resident reads")
-            sdrv.close()
 
     # ---- N > 1: every rank recomputes its right neighbour's shard; the digests must agree (N-GPU output == 1-GPU output)
     digest_check = None
@@ -294,6 +296,8 @@ def main():
             raise SystemExit("bench.py: shard digests differ between GPUs (ranks %s recomputed their neighbour's shard differently)" % bad)
         digest_check = {"ranks": world, "shards_recomputed_on_another_gpu": world, "digest_mismatches": 0}
 
+    if pool is not None:
+        pool.close()
     if rank == 0:
         # wfa_filter: register-resident pre-filter over the alignments of reads too short to span their locus (>90 % of the wavefront
         # offsets); wfa_flank: the back-tracing kernel over the alignments the filter keeps; wfa_flank_rest: the other flank alignments
@@ -361,7 +365,7 @@ def main():
                        "host_threads_per_rank": host_threads, "contexts_per_gpu": args.contexts},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
+                         "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "algorithmic_bytes_model": "SURVEY.md 8(d): B_io + B_dp, B_dp = 4 B per wavefront offset W (1 B per Viterbi cell); W = offsets the kernel computed, counted on the device (the pre-filter stops an alignment that cannot reach the match threshold: W is below WFA2-lib's count, see dp_cells_reference_per_launch)",
                          "dp_cells_reference_per_launch": ref_cells_l,
@@ -374,7 +378,11 @@ def main():
             "issue_roofline": {"kernel": dom, "dp_offsets_per_s": round(cells_per_s, 1), "valu_lane_ops_peak_per_s": valu_peak,
                                "offsets_per_lane_op_at_peak": round(cells_per_s / valu_peak, 5),
                                "note": "peak = CUs x 64 lanes x 2.4 GHz; lane-operations per offset and VALU utilisation from the committed SQ counters (profiles/, DESIGN.md)"},
+            # per-kernel HIP-event times: of the single-context loop (a kernel's own duration inside its call: what the roofline block
+            # uses) and of the region `value` is measured on, summed over the contexts (there a kernel's events also bracket the time it
+            # shares the CUs with the other contexts' kernels)
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kt.items()},
+            "kernels_ms_per_step_value_region": {k: round(v[0] / args.steps, 3) for k, v in kt_pool.items()} if kt_pool else None,
             # host-visible wall time of the last step: blocked on stage A + device genotyper; consensus alignments of the loci
             # handed back to the host path; HMM enqueue / collect (its kernel overlaps the host path); host glue; whole call
             "stage_ms_last_step": {"wait_flank_location_and_genotyper": round(stats[4] / 1e6, 2), "consensus": round(stats[5] / 1e6, 2),

@@ -268,6 +268,23 @@ int trgt_locus_batch_submit(trgt_hip_ctx* ctx, const trgt_locus_params* p, const
                             trgt_locus_batch_out* out, int64_t* ticket);
 int trgt_locus_batch_wait(trgt_hip_ctx* ctx, int64_t ticket);
 
+/* ---- several contexts, one queue of batches (the consumer side of the reference's locus channel, src/commands/genotype.rs:140-187, one level
+ * up: a context is single-threaded and a call is synchronous, so K contexts keep K batches in flight -- the tail of one call overlaps the
+ * flank location of the next ones).  devices[i] = HIP ordinal of context i; ordinals may repeat (several contexts per GPU: 4 measure
+ * 1.3x one context on the 10k-locus STR batch) and differ (one process driving several GPUs).  trgt_locus_batch_many hands the batches
+ * to one worker thread per context through a shared counter (dynamic: a batch of long alleles does not hold the others up) and returns
+ * when all are done; the first error of any batch is returned (message: trgt_hip_pool_last_error), batches not yet started are
+ * skipped then.  out[i] belongs to batch i -- or, with out_per_context != 0, out has one entry per CONTEXT and every batch a context
+ * runs overwrites that context's entry (throughput measurements).  ran_on (optional, per batch): the context that took it. */
+typedef struct trgt_hip_pool trgt_hip_pool;
+int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, trgt_hip_pool** out);
+void trgt_hip_pool_destroy(trgt_hip_pool* pool);
+int32_t trgt_hip_pool_size(const trgt_hip_pool* pool);
+trgt_hip_ctx* trgt_hip_pool_context(trgt_hip_pool* pool, int32_t i);   /* e.g. for trgt_hip_timing_* */
+const char* trgt_hip_pool_last_error(const trgt_hip_pool* pool);
+int trgt_locus_batch_many(trgt_hip_pool* pool, const trgt_locus_params* p, int64_t n_batches, const trgt_locus_batch_in* const* in,
+                          trgt_locus_batch_out* const* out, int32_t out_per_context, int32_t* ran_on);
+
 /* ------------------------------------------------------------ read ingestion (the step in front of trgt_locus_batch)
  * Repeat catalog + indexed FASTA + indexed BAM -> the arrays of trgt_locus_batch_in, i.e. what analyze_tr does before get_spanning_reads:
  *   Locus::new / get_tr_and_flanks (src/trgt/locus.rs:31-98, 168-190), extract_reads (src/trgt/workflows/tr.rs:268-361: region

@@ -37,3 +37,35 @@ def test_contexts_on_one_gpu_equal_one_context(oracle, config, n, chunk, k, lock
         assert np.array_equal(g.n_alleles, whole.n_alleles[off:off + nl]) and np.array_equal(g.ci, whole.ci[4 * off:4 * (off + nl)])
         assert np.array_equal(g.purity.view(np.uint64), whole.purity[2 * off:2 * (off + nl)].view(np.uint64))
         off += nl
+
+
+def test_native_pool_equals_one_context(oracle):
+    # trgt_hip_pool / trgt_locus_batch_many: the same queue of batches inside the library (worker threads in C++), per-batch outputs
+    import torch
+    from trgt_amd import _lib, locus, shard, synth
+    from trgt_amd.driver import split_batch
+    b = synth.generate(1500, first_locus=47000, config=2)
+    chunks = split_batch(b, 200)
+    rd, fd = torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda()
+    one = _lib.Context(0)
+    ref = [locus.run_batch(c, ctx=one, flank_dev=fd, reads_dev=rd) for c in chunks]
+    one.close()
+    pool = _lib.Pool([0, 0, 0])
+    try:
+        for rep in range(2):
+            got, ran = locus.run_many(pool, chunks, flank_dev=fd, reads_dev=rd)
+            assert len(set(ran)) >= 2 and all(0 <= w < 3 for w in ran)
+            for c, g, r in zip(chunks, got, ref):
+                assert shard.result_digest(g, c["n_loci"]) == shard.result_digest(r, c["n_loci"])
+        # per-context outputs: the last batch every context ran is what its entry holds
+        outs, ran = locus.run_many(pool, [chunks[0]] * 7, flank_dev=fd, reads_dev=rd, out_per_context=True)
+        for w in set(ran):
+            assert shard.result_digest(outs[w], chunks[0]["n_loci"]) == shard.result_digest(ref[0], chunks[0]["n_loci"])
+        # an error in one batch is reported with its index
+        bad = dict(chunks[1])
+        bad["lf_len"] = bad["lf_len"].copy()
+        bad["lf_len"][3] = 10  # shorter than flank_len
+        with pytest.raises(_lib.TrgtHipError, match="batch"):
+            locus.run_many(pool, [chunks[0], bad, chunks[2]], flank_dev=fd, reads_dev=rd)
+    finally:
+        pool.close()

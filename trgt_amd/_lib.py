@@ -73,6 +73,7 @@ EXPORTS = [
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
     "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params",
+    "trgt_hip_pool_create", "trgt_hip_pool_destroy", "trgt_hip_pool_size", "trgt_hip_pool_context", "trgt_hip_pool_last_error", "trgt_locus_batch_many",
     "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free",
     "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
     "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
@@ -173,6 +174,58 @@ class Context:
         if self.handle:
             lib().trgt_hip_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """trgt_hip_pool: several contexts (devices[i] = ordinal of context i, ordinals may repeat) behind one queue of batches."""
+
+    def __init__(self, devices):
+        L = lib()
+        L.trgt_hip_pool_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+        L.trgt_hip_pool_destroy.argtypes = [C.c_void_p]
+        L.trgt_hip_pool_destroy.restype = None
+        L.trgt_hip_pool_context.argtypes = [C.c_void_p, C.c_int32]
+        L.trgt_hip_pool_context.restype = C.c_void_p
+        L.trgt_hip_pool_last_error.argtypes = [C.c_void_p]
+        L.trgt_hip_pool_last_error.restype = C.c_char_p
+        L.trgt_locus_batch_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        dev = (C.c_int32 * len(devices))(*devices)
+        self.handle = C.c_void_p()
+        rc = L.trgt_hip_pool_create(dev, len(devices), C.byref(self.handle))
+        if rc != 0:
+            raise TrgtHipError("trgt_hip_pool_create failed: %d %s" % (rc, L.trgt_hip_last_error(None).decode()))
+        self.n = len(devices)
+        # the pool owns its contexts: views that never destroy them
+        self.contexts = []
+        for i in range(self.n):
+            c = Context.__new__(Context)
+            c.handle = C.c_void_p(L.trgt_hip_pool_context(self.handle, i))
+            c.device = devices[i]
+            c.close = lambda: None
+            self.contexts.append(c)
+
+    def run_many(self, params_struct, cins, couts, out_per_context=False):
+        """cins / couts: lists of LocusBatchIn / LocusBatchOut structures (couts: one per batch, or one per context)"""
+        n = len(cins)
+        pin = (C.c_void_p * n)(*[C.addressof(x) for x in cins])
+        pout = (C.c_void_p * len(couts))(*[C.addressof(x) for x in couts])
+        ran = (C.c_int32 * max(n, 1))()
+        rc = lib().trgt_locus_batch_many(self.handle, C.byref(params_struct), n, pin, pout, 1 if out_per_context else 0, ran)
+        if rc != 0:
+            raise TrgtHipError("trgt_locus_batch_many error %d: %s" % (rc, lib().trgt_hip_pool_last_error(self.handle).decode()))
+        return list(ran[:n])
+
+    def close(self):
+        if self.handle:
+            lib().trgt_hip_pool_destroy(self.handle)
+            self.handle = C.c_void_p()
+            self.contexts = []
 
     def __del__(self):
         try:

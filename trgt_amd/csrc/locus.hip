@@ -1222,3 +1222,61 @@ extern "C" int trgt_locus_batch_submit(trgt_hip_ctx* c, const trgt_locus_params*
   TRGT_ABI_GUARD(c, locus_submit(c, p, in, out, ticket));
 }
 extern "C" int trgt_locus_batch_wait(trgt_hip_ctx* c, int64_t ticket) { TRGT_ABI_GUARD(c, locus_wait(c, ticket)); }
+
+
+// ---- several contexts, one queue of batches ------------------------------------------------------------------------------
+struct trgt_hip_pool {
+  std::vector<trgt_hip_ctx*> ctx;
+  std::string err;
+};
+
+extern "C" int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, trgt_hip_pool** out) {
+  if (!devices || n_contexts < 1 || !out) return TRGT_ERR_INVALID;
+  *out = nullptr;
+  try {
+    std::unique_ptr<trgt_hip_pool> P(new trgt_hip_pool());
+    for (int32_t i = 0; i < n_contexts; ++i) {
+      trgt_hip_ctx* c = nullptr;
+      const int rc = trgt_hip_create(devices[i], &c);
+      if (rc) { for (auto* q : P->ctx) trgt_hip_destroy(q); return rc; }
+      P->ctx.push_back(c);
+    }
+    *out = P.release();
+    return TRGT_OK;
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
+}
+extern "C" void trgt_hip_pool_destroy(trgt_hip_pool* P) { if (!P) return; for (auto* c : P->ctx) trgt_hip_destroy(c); delete P; }
+extern "C" int32_t trgt_hip_pool_size(const trgt_hip_pool* P) { return P ? (int32_t)P->ctx.size() : 0; }
+extern "C" trgt_hip_ctx* trgt_hip_pool_context(trgt_hip_pool* P, int32_t i) { return P && i >= 0 && (size_t)i < P->ctx.size() ? P->ctx[(size_t)i] : nullptr; }
+extern "C" const char* trgt_hip_pool_last_error(const trgt_hip_pool* P) { return P ? P->err.c_str() : "null pool"; }
+
+extern "C" int trgt_locus_batch_many(trgt_hip_pool* P, const trgt_locus_params* p, int64_t n_batches, const trgt_locus_batch_in* const* in,
+                                     trgt_locus_batch_out* const* out, int32_t out_per_context, int32_t* ran_on) {
+  if (!P || !p || n_batches < 0 || (n_batches > 0 && (!in || !out))) return TRGT_ERR_INVALID;
+  try {
+    std::atomic<int64_t> next{0};
+    std::atomic<int> first_rc{0};
+    std::mutex err_mutex;
+    auto worker = [&](size_t w) {
+      trgt_hip_ctx* c = P->ctx[w];
+      for (;;) {
+        if (first_rc.load()) return;
+        const int64_t i = next.fetch_add(1);
+        if (i >= n_batches) return;
+        const int rc = trgt_locus_batch(c, p, in[i], out_per_context ? out[w] : out[i]);  // (catches its own exceptions)
+        if (ran_on) ran_on[i] = (int32_t)w;
+        if (rc) {
+          std::lock_guard<std::mutex> g(err_mutex);
+          if (!first_rc.load()) { first_rc = rc; P->err = "batch " + std::to_string((long long)i) + " on context " + std::to_string(w) + ": " + trgt_hip_last_error(c); }
+          return;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for (auto& x : t) if (x.joinable()) x.join(); } } join_all{th};
+    for (size_t w = 1; w < P->ctx.size(); ++w) th.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    return first_rc.load();
+  } catch (const std::exception& e) { P->err = std::string("trgt_locus_batch_many: ") + e.what(); return TRGT_ERR_NOMEM; }
+}

@@ -196,6 +196,21 @@ def run_batch(batch, params=Params(), ctx=None, outputs=None, flank_dev=None, re
     return out
 
 
+def run_many(pool, batches, params=Params(), outputs=None, flank_dev=None, reads_dev=None, out_per_context=False):
+    """trgt_locus_batch_many: the batches (packed dicts) through the contexts of a _lib.Pool, one worker thread per context inside the
+    library.  outputs: one BatchOutputs per batch, or -- out_per_context -- one per context (every batch a context runs overwrites its
+    entry: throughput measurements).  flank_dev / reads_dev: HBM copies shared by all batches (same device).  Returns (outputs, ran_on)."""
+    if outputs is None:
+        outputs = [BatchOutputs(batches[i if not out_per_context else 0]) for i in range(pool.n if out_per_context else len(batches))]
+    cins = []
+    for b in batches:
+        flank, reads = flank_dev if flank_dev is not None else b["flank_blob"], reads_dev if reads_dev is not None else b["read_blob"]
+        cins.append(_batch_in(b, flank, reads))
+    lp = _locus_params(params)
+    ran = pool.run_many(lp, cins, [o.c_out for o in outputs], out_per_context)
+    return outputs, ran
+
+
 class Ticket:
     """A batch handed to trgt_locus_batch_submit: keeps everything the library still points at alive until wait()."""
 
