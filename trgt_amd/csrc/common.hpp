@@ -44,6 +44,7 @@ struct trgt_hip_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int stream_priority = 0;  // of every stream the context creates (0: the default)
   std::string err;
   uint64_t ws_limit = 32ull << 30;
   int num_cus = 256;
@@ -67,6 +68,11 @@ struct trgt_hip_ctx {
   struct PinBuf { void* p = nullptr; size_t cap = 0; };
   std::vector<PinBuf> pinned;
   std::vector<PinBuf> h2d_stage;  // pinned staging of the small uploads, one per device slot (h2d_small)
+  // downloads into pageable memory go through pinned chunks and reach their destination when the stream is waited for (trgt::d2h)
+  struct D2hChunk { void* p = nullptr; size_t cap = 0, used = 0; };
+  struct D2hPending { void* dst; const void* staged; size_t bytes; hipStream_t stream; };
+  std::vector<D2hChunk> d2h_chunks;
+  std::vector<D2hPending> d2h_pending;
   void* host_pool = nullptr;  // trgt::HostPool*, created on first use
   int host_pool_threads = 0;
   // trgt_locus_batch_submit / _wait: two staging sets for the read and flank bytes of batches whose upload runs on `stream_copy`
@@ -113,6 +119,35 @@ inline int fail(trgt_hip_ctx* c, int code, const char* fmt, ...) {
       return trgt::fail((ctx), TRGT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                         __FILE__, __LINE__);                                                          \
   } while (0)
+
+// Waiting for a stream or an event: the runtime's own wait by default; TRGT_POLL_WAIT=1 polls the completion state instead (spins
+// for the first 2 ms, then every 20 us), which was written while hunting the stalls that turned out to be malloc's (see ctx.hip) and
+// measures the same since.
+inline bool poll_wait_knob() { static const bool on = [] { const char* e = getenv("TRGT_POLL_WAIT"); return e && *e && std::strcmp(e, "0") != 0; }(); return on; }
+template <class Query>
+inline hipError_t poll_until_ready(Query q) {
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned it = 0;; ++it) {
+    const hipError_t e = q();
+    if (e != hipErrorNotReady) {
+      if (it) (void)hipGetLastError();  // (the "not ready" answers of this thread must not surface in a later hipGetLastError())
+      return e;
+    }
+    if ((it & 63) == 63) {
+      timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+      if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 2000000ll) { const timespec nap{0, 20000}; nanosleep(&nap, nullptr); }
+    }
+    __builtin_ia32_pause();
+  }
+}
+inline hipError_t stream_wait(hipStream_t s) {
+  if (!poll_wait_knob()) return hipStreamSynchronize(s);
+  return poll_until_ready([s] { return hipStreamQuery(s); });
+}
+inline hipError_t event_wait(hipEvent_t ev) {
+  if (!poll_wait_knob()) return hipEventSynchronize(ev);
+  return poll_until_ready([ev] { return hipEventQuery(ev); });
+}
 
 inline bool is_device_ptr(const void* p) {
   if (p == nullptr) return false;
@@ -198,11 +233,57 @@ inline bool is_pinned_host_ptr(const void* p) {
   if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return at.type == hipMemoryTypeHost;
 }
+// dst (host) <- src (device) on `stream`.  A download into pageable memory is a synchronous call in the HIP runtime (it returns when
+// the stream has reached it); so pageable destinations are served from pinned chunks: the copy lands there and is moved to dst by
+// the stream_wait(c, stream) that follows, and the host is free until then.  dst must stay valid until that wait.
+inline int d2h(trgt_hip_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return TRGT_OK;
+  if (is_pinned_host_ptr(dst)) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); return TRGT_OK; }
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  trgt_hip_ctx::D2hChunk* ch = nullptr;
+  for (auto& k : c->d2h_chunks) if (k.cap - k.used >= need) { ch = &k; break; }
+  if (!ch) {
+    trgt_hip_ctx::D2hChunk k;
+    k.cap = std::max<size_t>(need, (size_t)4 << 20);
+    if (hipHostMalloc(&k.p, k.cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(c, TRGT_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", k.cap); }
+    c->d2h_chunks.push_back(k);
+    ch = &c->d2h_chunks.back();
+  }
+  void* staged = (uint8_t*)ch->p + ch->used;
+  ch->used += need;
+  TRGT_HIP_TRY(c, hipMemcpyAsync(staged, src, bytes, hipMemcpyDeviceToHost, stream));
+  c->d2h_pending.push_back({dst, staged, bytes, stream});
+  return TRGT_OK;
+}
+// waits for `stream`, then delivers the downloads d2h() staged on it
+inline hipError_t stream_wait(trgt_hip_ctx* c, hipStream_t stream) {
+  const hipError_t e = stream_wait(stream);
+  if (c->d2h_pending.empty()) return e;
+  size_t kept = 0;
+  for (auto& q : c->d2h_pending) {
+    if (q.stream == stream) { if (e == hipSuccess) std::memcpy(q.dst, q.staged, q.bytes); }
+    else c->d2h_pending[kept++] = q;
+  }
+  c->d2h_pending.resize(kept);
+  if (kept == 0) {  // nothing in flight: the chunks are free again (one chunk of the total size replaces several)
+    size_t total = 0;
+    for (auto& k : c->d2h_chunks) { total += k.used; k.used = 0; }
+    if (c->d2h_chunks.size() > 1) {
+      for (auto& k : c->d2h_chunks) (void)hipHostFree(k.p);
+      c->d2h_chunks.clear();
+      trgt_hip_ctx::D2hChunk k; k.cap = total + total / 4 + 4096;
+      if (hipHostMalloc(&k.p, k.cap, hipHostMallocDefault) == hipSuccess) c->d2h_chunks.push_back(k); else (void)hipGetLastError();
+    }
+  }
+  return e;
+}
+
 // dst (device) <- src (host) on `stream`.  stage_slot >= 0: src may be pageable, it is copied into that slot's pinned staging first (the
 // caller may then reuse src at once); < 0: src is pinned and stays untouched until the stream has passed the copy.
 inline int h2d_small(trgt_hip_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t stream, int stage_slot) {
   if (bytes == 0) return TRGT_OK;
-  if (bytes > H2D_KERNEL_MAX) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
+  static const size_t kmax = [] { const char* e = getenv("TRGT_H2D_KERNEL_MAX"); return e && *e ? (size_t)atoll(e) : H2D_KERNEL_MAX; }();
+  if (bytes > kmax) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
   const void* from = src;
   if (stage_slot >= 0 && !is_pinned_host_ptr(src)) {
     if ((int)c->h2d_stage.size() < S_COUNT) c->h2d_stage.resize(S_COUNT);
@@ -250,7 +331,7 @@ struct DevOut {
     return TRGT_OK;
   }
   int finish(trgt_hip_ctx* c) {
-    if (staged && count) TRGT_HIP_TRY(c, hipMemcpyAsync(user, dev, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (staged && count) return d2h(c, user, dev, count * sizeof(T), c->stream);
     return TRGT_OK;
   }
 };
@@ -265,10 +346,14 @@ struct KTimer {
     if (on) { (void)hipEventRecord(b, s); c->pending.push_back({k, a, b}); c->k_launches[k] += 1; c->k_cells[k] += cells; }
   }
 };
+// streams of a context (ctx.hip)
+hipError_t make_stream(trgt_hip_ctx* c, hipStream_t* s);
+void ctx_next_stream_priority(int p);
+
 inline void resolve_timing(trgt_hip_ctx* c) {
   for (auto& p : c->pending) {
     float ms = 0;
-    (void)hipEventSynchronize(p.b);
+    (void)trgt::event_wait(p.b);
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->k_ms[p.k] += ms;
     // destroying (or re-recording) events here makes one of the next few calls 3-7 ms slower now and then (measured, ROCm 7.2): they
     // are parked and destroyed with the ctx, or in bulk once there are very many

@@ -1197,7 +1197,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     hipStream_t ls = c->stream;
     if (n_class > 0) {
       const int sidx = (n_class - 1) % 3;
-      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->hmm_side[sidx], hipStreamNonBlocking));
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
       if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
       if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }  // behind the uploads (and the first launch)
@@ -1350,7 +1350,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     hipStream_t ls = c->stream;
     if (n_class > 0) {
       const int sidx = (n_class - 1) % 3;
-      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->hmm_side[sidx], hipStreamNonBlocking));
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
       if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
       if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }
@@ -1407,10 +1407,14 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   int32_t* spans3 = P->spans3; const uint64_t* span_off = P->span_off;
   auto &o_path = P->o_path; auto &o_plen = P->o_plen, &o_nsp = P->o_nsp, &o_cnt = P->o_cnt; auto &o_spans = P->o_spans, &o_edit = P->o_edit, &o_maxd = P->o_maxd; auto& o_pur = P->o_pur;
   int rc;
+  const bool tl_on = c->knobs.timeline;
+  const auto tl0 = std::chrono::steady_clock::now();
+  auto HTL = [&](const char* name, double mb) { if (tl_on) fprintf(stderr, "[tl]   hmm collect %-22s +%6.2f ms  (%.2f MB)\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count(), mb); };
   if (spans_on_host) {
     std::vector<uint32_t> h_nsp((size_t)n_jobs);
-    TRGT_HIP_TRY(c, hipMemcpyAsync(h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { const int d2h_rc = trgt::d2h(c, h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, c->stream); if (d2h_rc) return d2h_rc; }
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+    HTL("span counts on host", (double)n_jobs * 4 / 1e6);
     std::vector<uint64_t> poff((size_t)n_jobs);
     uint64_t ptotal = 0;
     for (int64_t j = 0; j < n_jobs; ++j) { poff[(size_t)j] = ptotal; ptotal += h_nsp[(size_t)j]; }
@@ -1427,20 +1431,24 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
                        (const uint64_t*)d_toff, (const uint32_t*)o_nsp.dev, (const uint64_t*)d_poff, (int32_t*)d_packed, (uint64_t)n_jobs);
     TRGT_HIP_TRY(c, hipGetLastError());
     std::vector<int32_t> h_packed((size_t)ptotal * 3 + 1);
-    TRGT_HIP_TRY(c, hipMemcpyAsync(h_packed.data(), d_packed, (size_t)ptotal * 12, hipMemcpyDeviceToHost, c->stream));
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { const int d2h_rc = trgt::d2h(c, h_packed.data(), d_packed, (size_t)ptotal * 12, c->stream); if (d2h_rc) return d2h_rc; }
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+    HTL("packed spans on host", (double)ptotal * 12 / 1e6);
     for (int64_t j = 0; j < n_jobs; ++j)
       std::memcpy(spans3 + 3 * span_off[j], h_packed.data() + 3 * poff[(size_t)j], (size_t)h_nsp[(size_t)j] * 12);
   }
   std::vector<uint32_t> h_cnt;
   if (P->cnt_user && P->cnt_total) {
     h_cnt.resize((size_t)P->cnt_total);
-    TRGT_HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), o_cnt.dev, (size_t)P->cnt_total * 4, hipMemcpyDeviceToHost, c->stream));
+    { const int d2h_rc = trgt::d2h(c, h_cnt.data(), o_cnt.dev, (size_t)P->cnt_total * 4, c->stream); if (d2h_rc) return d2h_rc; }
   }
   if ((rc = o_path.finish(c)) || (rc = o_plen.finish(c)) || (rc = o_spans.finish(c)) || (rc = o_nsp.finish(c)) ||
       (rc = o_cnt.finish(c)) || (rc = o_pur.finish(c)) || (rc = o_edit.finish(c)) || (rc = o_maxd.finish(c)))
     return rc;
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HTL("copies enqueued", (double)((o_path.staged ? o_path.count * 2 : 0) + (o_plen.staged ? o_plen.count * 4 : 0) + (o_spans.staged ? o_spans.count * 4 : 0) + (o_nsp.staged ? o_nsp.count * 4 : 0) +
+                                  (o_cnt.staged ? o_cnt.count * 4 : 0) + (o_pur.staged ? o_pur.count * 8 : 0) + (o_edit.staged ? o_edit.count * 4 : 0) + (o_maxd.staged ? o_maxd.count * 4 : 0)) / 1e6);
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+  HTL("synced", 0.0);
 #ifdef TRGT_HMM_PROF
   {
     unsigned long long h[16], z[16] = {0};
@@ -1472,8 +1480,8 @@ extern "C" int trgt_hmm_models_check(trgt_hip_ctx* c, int32_t n_sets, const uint
   rc = hmm_build_models(n_sets, motif_blob, motif_off, set_motif_begin, host);
   if (rc) return fail(c, rc, "%s", host.err.c_str());
   std::vector<uint8_t> got((size_t)dev.blob_bytes);
-  if (dev.blob_bytes) TRGT_HIP_TRY(c, hipMemcpyAsync(got.data(), dev.d_blob, (size_t)dev.blob_bytes, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (dev.blob_bytes) { const int d2h_rc = trgt::d2h(c, got.data(), dev.d_blob, (size_t)dev.blob_bytes, c->stream); if (d2h_rc) return d2h_rc; }
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
   int64_t diff = dev.blob_bytes > host.blob.size() ? (int64_t)(dev.blob_bytes - host.blob.size()) : (int64_t)(host.blob.size() - dev.blob_bytes);
   const size_t n = std::min((size_t)dev.blob_bytes, host.blob.size());
   for (size_t i = 0; i < n; ++i) diff += got[i] != host.blob[i];

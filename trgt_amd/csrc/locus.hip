@@ -319,9 +319,9 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
   TRGT_HIP_TRY(c, hipGetLastError());
   std::vector<uint32_t> lens(n_groups);
   std::vector<uint8_t> bytes((size_t)out_total);
-  TRGT_HIP_TRY(c, hipMemcpyAsync(lens.data(), d_len, n_groups * 4, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipMemcpyAsync(bytes.data(), d_out, (size_t)out_total, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { const int d2h_rc = trgt::d2h(c, lens.data(), d_len, n_groups * 4, c->stream); if (d2h_rc) return d2h_rc; }
+  { const int d2h_rc = trgt::d2h(c, bytes.data(), d_out, (size_t)out_total, c->stream); if (d2h_rc) return d2h_rc; }
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
   for (size_t g = 0; g < n_groups; ++g) {
     if (lens[g] == 0xFFFFFFFFu) return fail(c, TRGT_ERR_UNSUPPORTED, "consensus: repaired sequence of group %zu longer than %u bases", g, groups[g].out_cap);
     results[g].assign((const char*)bytes.data() + groups[g].out_off, lens[g]);
@@ -440,7 +440,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     for (int64_t s = 0; s < 2 * nl; ++s) { out->n_spans[s] = 0; out->purity[s] = std::nan(""); }
   };
   if (nr == 0) { init_outputs(); return TRGT_OK; }
-  if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  if (!c->stream2) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream2));
   // The motif-HMM tables depend only on the catalog: build them on a host thread while the GPU locates flanks.
   // They are uploaded from the same thread (second stream), so stage C finds them in HBM.
   // (the thread touches nothing of the context: its result and error live in `models`; the upload happens on this thread, below,
@@ -571,9 +571,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
-  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(h_cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_wfa_cells_dev) { const int d2h_rc = trgt::d2h(c, h_cells, c->last_wfa_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
   ((uint64_t*)h_cells)[2] = ((uint64_t*)h_cells)[3] = 0;  // pre-filter: offsets computed, alignments kept
-  if (c->last_filter_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync((uint64_t*)h_cells + 2, c->last_filter_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
+  if (c->last_filter_cells_dev) { const int d2h_rc = trgt::d2h(c, (uint64_t*)h_cells + 2, c->last_filter_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
   if (dev_gt) {
     gt::GtArgs ga;
     ga.reads = d_reads; ga.read_off = d_roff; ga.read_len = d_rlen; ga.locus_read_begin = g.lrb;
@@ -591,7 +591,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
     TRGT_HIP_TRY(c, hipGetLastError());
   }
-  TRGT_HIP_TRY(c, hipMemcpyAsync(h_slab, d_slab, slab.total, hipMemcpyDeviceToHost, c->stream));
+  { const int d2h_rc = trgt::d2h(c, h_slab, d_slab, slab.total, c->stream); if (d2h_rc) return d2h_rc; }
   TRGT_HIP_TRY(c, hipEventRecord(evA, c->stream));
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
   TL("stage A enqueued");
@@ -600,7 +600,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // the motif-HMM tables: built on the device (one small upload and one kernel on the copy stream, which has nothing in front of it:
   // the second stream may be busy with the heavy flank alignments for milliseconds, and the copy engine serves the streams' copies in
   // the order they were issued)
-  if (!c->stream_copy) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+  if (!c->stream_copy) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream_copy));
   if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
   if ((rc = hmm_models_on_device(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models, c->stream_copy, c->ev_upload)))
     return models.err.empty() ? rc : fail(c, rc, "%s", models.err.c_str());
@@ -626,7 +626,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
 
   // ---------------- wait for the GPU, publish spans
   {
-    TRGT_HIP_TRY(c, hipEventSynchronize(evA));
+    TRGT_HIP_TRY(c, trgt::event_wait(evA));
     if (stage_a_token.owns_lock()) stage_a_token.unlock();
     tA = now_ns() - tw_a;
   TL("evA");
@@ -793,7 +793,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, c->stream2, ga);
       TRGT_HIP_TRY(c, hipGetLastError());
       TL("R gather launched");
-      TRGT_HIP_TRY(c, hipMemcpyAsync(h_seg, d_out, (size_t)seg_bytes, hipMemcpyDeviceToHost, c->stream2));
+      { const int d2h_rc = trgt::d2h(c, h_seg, d_out, (size_t)seg_bytes, c->stream2); if (d2h_rc) return d2h_rc; }
     }
   }
   TL("R selected, gather enqueued");
@@ -801,7 +801,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (dev_gt) {
     const uint64_t packed_total = ((const uint64_t*)gh.toff)[2 * nl];
     if ((rc = pin_get(c, P_GT_PACKED, (size_t)packed_total + 16, &gh.packed))) return rc;
-    if (packed_total) TRGT_HIP_TRY(c, hipMemcpyAsync(gh.packed, g.packed, (size_t)packed_total, hipMemcpyDeviceToHost, c->stream2));
+    if (packed_total) { const int d2h_rc = trgt::d2h(c, gh.packed, g.packed, (size_t)packed_total, c->stream2); if (d2h_rc) return d2h_rc; }
   }
   // ---------------- stage C for the device-genotyped loci (on alleles that already sit in HBM; collected at the end) and the
   // publishing of spans and device-genotyper results: host work of ~1.2 ms that needs the GPU only to start the HMM batch.  It runs
@@ -837,7 +837,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     return r;
   };
   if (nR == 0 && (rc = hmm1_once())) return rc;
-  if (dev_gt || (n_seg > 0 && reads_on_device)) TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream2));  // gathered segments, packed alleles
+  if (dev_gt || (n_seg > 0 && reads_on_device)) TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream2));  // gathered segments, packed alleles
   tHost += now_ns() - th_begin;
   TL("stream2 synced");
   // ---------------- publish spans and the device genotyper's results: host-only work, done while the consensus alignments of the
@@ -1137,6 +1137,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     tC += now_ns() - tc0;
   }
   TL("all collected");
+  if (c->timing) { resolve_timing(c); TL("timing events resolved"); }  // (all of the call's events have fired: reading them now keeps the list short)
   if (out->stats) {
     int64_t* s = out->stats;
     s[0] = stat_flank_jobs; s[1] = stat_cons_jobs; s[2] = stat_spanning; s[3] = stat_hmm_jobs;
@@ -1174,7 +1175,7 @@ static int locus_submit(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_
   const int64_t nl = in->n_loci;
   const int64_t nr = nl > 0 ? (int64_t)in->locus_read_begin[nl] : 0;
   if (nl > 0 && nr > 0) {
-    if (!c->stream_copy) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    if (!c->stream_copy) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream_copy));
     if (!st.ready) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
     uint64_t flank_total = 0, read_total = 0;
     for (int64_t l = 0; l < nl; ++l) flank_total = std::max<uint64_t>(flank_total, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
@@ -1235,9 +1236,17 @@ extern "C" int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, 
   *out = nullptr;
   try {
     std::unique_ptr<trgt_hip_pool> P(new trgt_hip_pool());
+    const char* pe = getenv("TRGT_POOL_PRIORITIES");
+    const bool priorities = !(pe && *pe == '0');
     for (int32_t i = 0; i < n_contexts; ++i) {
       trgt_hip_ctx* c = nullptr;
+      if (priorities && n_contexts > 1) {  // contexts of a pool: different stream priorities, see make_stream (ctx.hip)
+        int lo = 0, hi = 0;  // (lo = least urgent, numerically larger)
+        if (hipSetDevice(devices[i]) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi) trgt::ctx_next_stream_priority(hi + (int)(i % (lo - hi + 1)));
+        else (void)hipGetLastError();
+      }
       const int rc = trgt_hip_create(devices[i], &c);
+      trgt::ctx_next_stream_priority(0);
       if (rc) { for (auto* q : P->ctx) trgt_hip_destroy(q); return rc; }
       P->ctx.push_back(c);
     }
@@ -1257,13 +1266,17 @@ extern "C" int trgt_locus_batch_many(trgt_hip_pool* P, const trgt_locus_params* 
     std::atomic<int64_t> next{0};
     std::atomic<int> first_rc{0};
     std::mutex err_mutex;
+    const bool trace = getenv("TRGT_POOL_TRACE") != nullptr;  // (one line per batch on stderr: context, batch, start and end in ms)
+    const int64_t t_many0 = now_ns();
     auto worker = [&](size_t w) {
       trgt_hip_ctx* c = P->ctx[w];
       for (;;) {
         if (first_rc.load()) return;
         const int64_t i = next.fetch_add(1);
         if (i >= n_batches) return;
+        const int64_t tb0 = trace ? now_ns() : 0;
         const int rc = trgt_locus_batch(c, p, in[i], out_per_context ? out[w] : out[i]);  // (catches its own exceptions)
+        if (trace) fprintf(stderr, "[pool] %zu %lld %.3f %.3f\n", w, (long long)i, (double)(tb0 - t_many0) / 1e6, (double)(now_ns() - t_many0) / 1e6);
         if (ran_on) ran_on[i] = (int32_t)w;
         if (rc) {
           std::lock_guard<std::mutex> g(err_mutex);

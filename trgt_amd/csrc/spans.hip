@@ -459,7 +459,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     const bool two_streams = use_filter && !c->knobs.one_stream;
     void* cells_heavy = nullptr;
     if (two_streams) {
-      if (!c->stream2) TRGT_HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      if (!c->stream2) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream2));
       if (!c->ev_scan) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scan, hipEventDisableTiming));
       if (!c->ev_heavy) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
       TRGT_HIP_TRY(c, hipEventRecord(c->ev_scan, c->stream));
@@ -553,7 +553,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   TRGT_HIP_TRY(c, hipGetLastError());
   if (c->knobs.debug) {  // (synchronises: developer output only)
     uint32_t h[8];
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
     if (win_q > 0)
       fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand)\n",
@@ -623,9 +623,9 @@ extern "C" int trgt_find_spans_batch(trgt_hip_ctx* c, const trgt_span_params* p,
     return rc;
   if ((rc = o_s.finish(c)) || (rc = o_e.finish(c)) || (rc = o_l.finish(c)) || (rc = o_r.finish(c))) return rc;
   unsigned long long cells[2] = {0, 0}, fcells[2] = {0, 0};  // total, first launch; pre-filter: offsets, alignments kept
-  if (c->last_wfa_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(cells, c->last_wfa_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
-  if (c->last_filter_cells_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(fcells, c->last_filter_cells_dev, 16, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->last_wfa_cells_dev) { const int d2h_rc = trgt::d2h(c, cells, c->last_wfa_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
+  if (c->last_filter_cells_dev) { const int d2h_rc = trgt::d2h(c, fcells, c->last_filter_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
   if (c->timing) {
     c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)cells[1]; c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(cells[0] - cells[1]);
     c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)fcells[0];

@@ -562,7 +562,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
 #ifdef TRGT_WFA_PROF
   if (a.fast_wcap > 0) {
     unsigned long long h[32], lv[32], z[32] = {0};
-    TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(wfa::g_wfa_prof), sizeof h));
     TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_prof), z, sizeof h));
     TRGT_HIP_TRY(c, hipMemcpyFromSymbol(lv, HIP_SYMBOL(wfa::g_wfa_lvprof), sizeof lv));
@@ -674,15 +674,15 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
   if ((rc = wfa_launch(c, *p, L))) return rc;
   WTL("launched");
   // host work of the caller goes here: the copies below end in pageable memory, i.e. they block until the kernel is done
-  if (while_running && *while_running) { const int wrc = (*while_running)(); if (wrc) { (void)hipStreamSynchronize(c->stream); return wrc; } }
+  if (while_running && *while_running) { const int wrc = (*while_running)(); if (wrc) { (void)trgt::stream_wait(c, c->stream); return wrc; } }
   if ((rc = o_status.finish(c)) || (rc = o_score.finish(c)) || (rc = o_nm.finish(c)) || (rc = o_span.finish(c)) ||
       (rc = o_cigar.finish(c)) || (rc = o_clen.finish(c)) || (rc = o_ops.finish(c)) || (rc = o_olen.finish(c)))
     return rc;
   unsigned long long cells = 0;
   void* const cells_dev = c->last_wfa_cells_dev;  // (the callback may launch alignments of its own)
   hipStream_t const my_stream = c->stream;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, cells_dev, 8, hipMemcpyDeviceToHost, my_stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { const int d2h_rc = trgt::d2h(c, &cells, cells_dev, 8, my_stream); if (d2h_rc) return d2h_rc; }
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
   if (c->timing) c->k_cells[TRGT_K_WFA] += (int64_t)cells;
   if (packed) {
     uint64_t total = 0;
@@ -696,8 +696,8 @@ int wfa_batch_impl(trgt_hip_ctx* c, const trgt_wfa_params* p, int64_t n_jobs, co
       hipLaunchKernelGGL(cigar_pack_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream, (const uint32_t*)o_cigar.dev,
                          (const JobDev*)d_jobs, (const uint32_t*)o_clen.dev, (const uint64_t*)d_poff, (uint32_t*)d_packed, (uint64_t)n_jobs);
       TRGT_HIP_TRY(c, hipGetLastError());
-      TRGT_HIP_TRY(c, hipMemcpyAsync(packed->data.data(), d_packed, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
-      TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      { const int d2h_rc = trgt::d2h(c, packed->data.data(), d_packed, (size_t)total * 4, c->stream); if (d2h_rc) return d2h_rc; }
+      TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     }
   }
   return TRGT_OK;

@@ -569,8 +569,8 @@ extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* 
   if ((rc = flank_filter_launch(c, L))) return rc;
   if ((rc = o_score.finish(c)) || (rc = o_bound.finish(c)) || (rc = o_keep.finish(c))) return rc;
   unsigned long long cells = 0;
-  TRGT_HIP_TRY(c, hipMemcpyAsync(&cells, c->last_filter_cells_dev, 8, hipMemcpyDeviceToHost, c->stream));
-  TRGT_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { const int d2h_rc = trgt::d2h(c, &cells, c->last_filter_cells_dev, 8, c->stream); if (d2h_rc) return d2h_rc; }
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
   if (offsets_computed) *offsets_computed = (int64_t)cells;
   if (c->timing) c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)cells;
   return TRGT_OK;
