@@ -13,6 +13,12 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python bench.py --config $
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt
 tail -1 $O/bench.json > $O/${TAG}_bench.json
 head -14 $O/${TAG}_kernel_stats.txt
+# the same workload through one context only (no pool, no streaming leg): the launches of this trace are the uncontended ones the
+# roofline block of bench.py is computed from (its single-context loop), so the per-kernel averages of the two must agree
+rocprofv3 --kernel-trace --stats -d $O/kt1 -o bench1 -- python bench.py --config $CFG --steps 20 --warmup 2 --contexts 1 --no-streaming --no-cpu-baseline > $O/bench1.json 2> $O/bench1.err
+python tools/rocprof_summary.py $(find $O/kt1 -name "*.db" | head -1) > $O/${TAG}_kernel_stats_one_context.txt
+tail -1 $O/bench1.json > $O/${TAG}_bench_one_context.json
+head -8 $O/${TAG}_kernel_stats_one_context.txt
 if [ "$PMC" = "1" ]; then
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM"; do
