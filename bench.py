@@ -244,7 +244,7 @@ def main():
 
     # ---- the same batches with the reads starting in pinned host memory, through the pipelined entry points: the upload of batch
     #      k + 1 (trgt_locus_batch_submit, copy stream) runs next to the kernels of batch k (trgt_locus_batch_wait)
-    dt_stream = dt_stream_single = None
+    dt_stream = dt_stream_single = dt_stream4 = dt_stream4_single = None
     if not args.no_streaming:
         pins = [torch.from_numpy(batch["read_blob"]).pin_memory() for _ in range(2)]
         outs_s = [locus.BatchOutputs(batch) for _ in range(2)]
@@ -288,6 +288,44 @@ def main():
             for w in set(sran):
                 if shard.result_digest(outs_sw[w], n_loci) != shard.result_digest(out, n_loci):
                     raise SystemExit("bench.py: host-resident reads gave different results than HBM-resident reads")
+
+        # ... and with the reads as BAM 4-bit codes (TRGT_READS_BAM4: what a BAM record holds; half the bytes cross the link, one kernel
+        #     expands them in HBM), pinned as well
+        pk = locus.pack_bam4(batch, pinned=True)
+
+        def stream_loop4(n):
+            t = locus.submit_batch(pk, params, ctx, outs_s[0], flank=flank_dev)
+            for k in range(n):
+                nxt = locus.submit_batch(pk, params, ctx, outs_s[(k + 1) % 2], flank=flank_dev) if k + 1 < n else None
+                t.wait()
+                t = nxt
+
+        stream_loop4(3)
+        gc.collect()
+        gc.disable()
+        fence()
+        t0 = time.perf_counter()
+        stream_loop4(n_s)
+        fence()
+        dt_stream4 = dt_stream4_single = shard.max_over_ranks((time.perf_counter() - t0) / n_s, dist if world > 1 else None, device="cuda")
+        gc.enable()
+        for o in outs_s:
+            if shard.result_digest(o, n_loci) != shard.result_digest(out, n_loci):
+                raise SystemExit("bench.py: 4-bit reads gave different results than ASCII reads")
+        if pool is not None:
+            smany4 = lambda n: locus.run_many(pool, [pk] * n, params, outs_sw, flank_dev=flank_dev, out_per_context=True)
+            smany4(3 * args.contexts)
+            gc.collect()
+            gc.disable()
+            fence()
+            t0 = time.perf_counter()
+            _, sran = smany4(n_s)
+            fence()
+            dt_stream4 = shard.max_over_ranks((time.perf_counter() - t0) / n_s, dist if world > 1 else None, device="cuda")
+            gc.enable()
+            for w in set(sran):
+                if shard.result_digest(outs_sw[w], n_loci) != shard.result_digest(out, n_loci):
+                    raise SystemExit("bench.py: 4-bit reads gave different results than ASCII reads")
 
     # ---- N > 1: every rank recomputes its right neighbour's shard; the digests must agree (N-GPU output == 1-GPU output)
     digest_check = None
@@ -364,9 +402,11 @@ def main():
             "ms_per_step_single_context_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+u8 packed (WFA pre-filter), u16 (WFA back-trace), f64 (HMM)",
             "data": "synthetic",
-            "value_is": "HBM-resident: read and flank bytes are in HBM before the timed region; value_streaming: every batch's reads start in pinned host memory and cross PCIe inside the timed region -- through the same worker contexts, each uploading its batch and then computing on it (single context: uploaded by trgt_locus_batch_submit next to the compute of the batch before, trgt_locus_batch_wait)",
+            "value_is": "HBM-resident: read and flank bytes are in HBM before the timed region; value_streaming: every batch's reads start in pinned host memory and cross PCIe inside the timed region -- through the same worker contexts, each uploading its batch and then computing on it (single context: uploaded by trgt_locus_batch_submit next to the compute of the batch before, trgt_locus_batch_wait); value_streaming_bam4: the same with the reads as BAM 4-bit codes (TRGT_READS_BAM4), expanded in HBM",
             "value_streaming": round(world * n_loci / dt_stream, 1) if dt_stream else None,
             "value_streaming_single_context": round(world * n_loci / dt_stream_single, 1) if dt_stream else None,
+            "value_streaming_bam4": round(world * n_loci / dt_stream4, 1) if dt_stream4 else None,
+            "value_streaming_bam4_single_context": round(world * n_loci / dt_stream4_single, 1) if dt_stream4 else None,
             "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,

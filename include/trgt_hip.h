@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 4
+#define TRGT_HIP_ABI_VERSION 5
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -231,7 +231,15 @@ typedef struct trgt_locus_batch_in {   /* Locus (locus.rs:13-23) x n_loci, reads
   const int32_t* end_offset;           /* alignment end - region end; NULL = 0 */
   const int32_t* mismatch_offsets;     /* HiFiRead::mismatch_offsets (snp.rs:51-79), ascending per read */
   const uint64_t* mismatch_off;        /* [n_reads + 1] into mismatch_offsets */
+  /* How read_blob holds the bases.  0: one base per byte (ASCII, what HiFiRead::bases is, reads.rs).  1 (TRGT_READS_BAM4): the BAM
+   * record's own 4-bit codes, two bases per byte, first base in the high nibble ("=ACMGRSVTWYHKDBN", SAM spec 4.2.3; rust-htslib
+   * hands them out as record.seq().encoded): read_off[r] is the BYTE offset of read r's first pair, every read starts on a byte
+   * boundary, read_len[r] stays the number of bases.  The library expands the codes to the same ASCII bytes in HBM (one kernel, 0.5 B
+   * read + 1 B written per base) -- half the bytes cross PCIe, the results are identical.  Host or device, like encoding 0. */
+  int32_t read_encoding;
 } trgt_locus_batch_in;
+#define TRGT_READS_ASCII 0
+#define TRGT_READS_BAM4 1
 
 typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x n_loci; all HOST, caller-allocated */
   int32_t* span_start; int32_t* span_end;   /* per input read (find_tr_spans), -1 = None */
@@ -254,6 +262,13 @@ typedef struct trgt_locus_batch_out {  /* LocusResult (locus_result.rs:16-22) x 
 
 int trgt_locus_batch(trgt_hip_ctx* ctx, const trgt_locus_params* p, const trgt_locus_batch_in* in,
                      trgt_locus_batch_out* out);
+
+/* Host helper for callers that hold ASCII reads and want TRGT_READS_BAM4 (a BAM reader has the codes already: trgt_ingest_params.
+ * keep_bam4): packs read r (ascii + read_off[r], read_len[r] bases) to packed + packed_off[r], where packed_off[r] is written as the
+ * running sum of ceil(read_len / 2).  Letters outside "=ACMGRSVTWYHKDBN" become N, as in htslib.  packed needs
+ * sum(ceil(read_len[r] / 2)) bytes; returns that sum, or a negative TRGT_ERR_* code. */
+int64_t trgt_reads_pack_bam4(const uint8_t* ascii, int64_t n_reads, const uint64_t* read_off, const uint32_t* read_len,
+                             uint8_t* packed, uint64_t* packed_off);
 
 /* Pipelined form (the consumer side of the reference's per-locus channel, src/commands/genotype.rs:140-187): the upload of batch
  * k + 1 runs next to the kernels of batch k.
@@ -300,6 +315,7 @@ typedef struct trgt_ingest_params {
   int32_t threads;         /* 0 = up to 16 */
   int32_t genotyper;       /* 0 size, 1 cluster: copied into trgt_ingest_batch::genotyper for every locus */
   int32_t default_ploidy;  /* 2 (the karyotype logic of locus.rs:216-240 stays with the caller: overwrite ploidy[] for X / Y loci) */
+  int32_t keep_bam4;       /* 0; 1 = also fill read_bam4 / read_bam4_off: the clipped reads as 4-bit codes for TRGT_READS_BAM4 */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;
@@ -322,6 +338,9 @@ typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch
   const int32_t* mismatch_offsets; const uint64_t* mismatch_off;           /* [n_reads + 1] */
   const uint8_t* meth; const uint64_t* meth_off; const uint8_t* has_meth;  /* [n_reads + 1]; has_meth 0 = None */
   const uint32_t* cigar; const uint64_t* cigar_off; const int64_t* cigar_ref_pos;  /* clipped CIGAR (len << 4 | op), [n_reads + 1] */
+  /* -- with trgt_ingest_params.keep_bam4: the reads once more as BAM 4-bit codes (trgt_locus_batch_in: read_blob = read_bam4, read_off =
+   *    read_bam4_off, read_encoding = TRGT_READS_BAM4; read_len is shared).  NULL otherwise. */
+  const uint8_t* read_bam4; const uint64_t* read_bam4_off; uint64_t read_bam4_bytes;
   void* owner;
 } trgt_ingest_batch;
 void trgt_ingest_default_params(trgt_ingest_params* p);

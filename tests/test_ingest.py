@@ -213,3 +213,26 @@ def test_truncated_and_corrupt_files_give_errors_not_crashes(tmp_path):
     open(bam + ".bai", "wb").write(b"BAI\1" + b"\xff" * 40)
     with pytest.raises(_lib.TrgtHipError):
         ingest.Reader(bam, fa)
+
+
+def test_keep_bam4_holds_the_same_bases_as_the_ascii_reads():
+    # trgt_ingest_params.keep_bam4: the clipped reads once more as BAM 4-bit codes (TRGT_READS_BAM4), byte-aligned per read
+    from trgt_amd import ingest
+    rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
+    b = rd.batch(os.path.join(EX, "repeat.bed"), keep_bam4=1)
+    plain = rd.batch(os.path.join(EX, "repeat.bed"))
+    assert "read_bam4" not in plain
+    letters = "=ACMGRSVTWYHKDBN"
+    nr = int(b["n_reads"])
+    assert nr > 0 and np.array_equal(b["read_blob"], plain["read_blob"])
+    o = 0
+    for r in range(nr):
+        n, off = int(b["read_len"][r]), int(b["read_bam4_off"][r])
+        assert off == o
+        packed = b["read_bam4"][off:off + (n + 1) // 2]
+        dec = "".join(letters[x >> 4] + letters[x & 15] for x in packed)[:n]
+        assert dec == bytes(b["read_blob"][int(b["read_off"][r]):int(b["read_off"][r]) + n]).decode()
+        o += (n + 1) // 2
+    v = ingest.bam4_view(b)
+    assert v["read_encoding"] == 1 and v["read_blob"] is b["read_bam4"] and v["read_len"] is b["read_len"]
+    rd.close()

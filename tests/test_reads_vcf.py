@@ -5,6 +5,7 @@ repeat.bed, sample.bam}); the expected record is the one the reference documents
 import json
 import os
 
+import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -109,6 +110,21 @@ def test_example_bam_through_the_native_ingestion_on_the_gpu():
     b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
     out = locus.run_batch(b)
     assert [vcf.vcf_record(l, locus.locus_result(b, out, i)) for i, l in enumerate(loci)] == [TUTORIAL_RECORD]
+
+
+@pytest.mark.gpu
+def test_native_ingestion_with_4bit_reads_gives_the_same_call():
+    # the reads of the BAM handed to the GPU as the 4-bit codes the records hold (keep_bam4 -> TRGT_READS_BAM4): same results, same record
+    from trgt_amd import ingest, locus
+    rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
+    b = rd.batch(os.path.join(EX, "repeat.bed"), keep_bam4=1)
+    ref = locus.run_batch(b)
+    out = locus.run_batch(ingest.bam4_view(b))
+    for f in ("span_start", "span_end", "n_alleles", "allele_len", "allele_blob", "ci", "num_spanning", "classification", "read_rank", "spans3", "motif_counts"):
+        assert np.array_equal(getattr(out, f), getattr(ref, f)), f
+    assert np.array_equal(out.purity.view(np.uint64), ref.purity.view(np.uint64))
+    assert locus.locus_result(b, out, 0).vcf_fields() == locus.locus_result(b, ref, 0).vcf_fields()
+    rd.close()
 
 
 @pytest.mark.gpu

@@ -58,7 +58,7 @@ class LocusBatchIn(C.Structure):
     _fields_ = [("n_loci", C.c_int64)] + [(n, _VP) for n in (
         "flank_blob", "lf_off", "lf_len", "rf_off", "rf_len", "tr_blob", "tr_off", "tr_len", "motif_blob", "motif_off",
         "set_motif_begin", "ploidy", "locus_read_begin", "read_blob", "read_off", "read_len", "genotyper", "read_qual",
-        "hp_tag", "start_offset", "end_offset", "mismatch_offsets", "mismatch_off")]
+        "hp_tag", "start_offset", "end_offset", "mismatch_offsets", "mismatch_off")] + [("read_encoding", C.c_int32)]
 
 
 class LocusBatchOut(C.Structure):
@@ -72,7 +72,7 @@ EXPORTS = [
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
-    "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params",
+    "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_reads_pack_bam4",
     "trgt_hip_pool_create", "trgt_hip_pool_destroy", "trgt_hip_pool_size", "trgt_hip_pool_context", "trgt_hip_pool_last_error", "trgt_locus_batch_many",
     "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free",
     "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
@@ -126,6 +126,8 @@ def lib():
         L.trgt_flank_filter_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 5 + [C.c_int32, C.c_int32] + [_VP] * 4
         L.trgt_find_spans_batch.argtypes = [_VP, _VP, C.c_int64] + [_VP] * 13
         L.trgt_locus_batch.argtypes = [_VP, _VP, _VP, _VP]
+        L.trgt_reads_pack_bam4.argtypes = [_VP, C.c_int64, _VP, _VP, _VP, _VP]
+        L.trgt_reads_pack_bam4.restype = C.c_int64
         L.trgt_locus_batch_submit.argtypes = [_VP, _VP, _VP, _VP, C.POINTER(C.c_int64)]
         L.trgt_locus_batch_wait.argtypes = [_VP, C.c_int64]
         L.trgt_locus_default_params.argtypes = [_VP]

@@ -497,6 +497,8 @@ struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
   std::vector<uint64_t> contig_off, id_off, struc_off, cig_off;
   std::vector<uint32_t> cig;
   std::vector<int64_t> cig_ref_pos;
+  std::vector<uint8_t> bam4;
+  std::vector<uint64_t> bam4_off;
   trgt_ingest_batch pub;
 };
 
@@ -553,7 +555,7 @@ void trgt_ingest_close(trgt_ingest* h) { delete h; }
 
 void trgt_ingest_default_params(trgt_ingest_params* p) {
   if (!p) return;
-  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2;
+  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0;
 }
 
 void trgt_ingest_free(trgt_ingest_batch* b) {
@@ -724,6 +726,15 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   B.contig_blob = S->contigs.data(); B.contig_off = S->contig_off.data(); B.id_blob = S->ids.data(); B.id_off = S->id_off.data();
   B.struc_blob = S->strucs.data(); B.struc_off = S->struc_off.data(); B.region_start = S->region_start.data(); B.region_end = S->region_end.data();
   B.cigar = S->cig.data(); B.cigar_off = S->cig_off.data(); B.cigar_ref_pos = S->cig_ref_pos.data();
+  if (p->keep_bam4) {  // the reads once more, two bases per byte (half the bytes to move to the GPU)
+    uint64_t total = 0;
+    for (uint32_t n : S->read_len) total += ((uint64_t)n + 1) / 2;
+    S->bam4.assign((size_t)total + 1, 0);
+    S->bam4_off.assign(S->read_off.size() + 1, 0);
+    const int64_t got = trgt_reads_pack_bam4(u8(S->reads), (int64_t)S->read_off.size(), S->read_off.data(), S->read_len.data(), S->bam4.data(), S->bam4_off.data());
+    if (got != (int64_t)total) return bad("trgt_ingest: packing the reads failed");
+    B.read_bam4 = S->bam4.data(); B.read_bam4_off = S->bam4_off.data(); B.read_bam4_bytes = total;
+  }
   B.owner = S.release();
   *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
   return TRGT_OK;

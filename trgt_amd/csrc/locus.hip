@@ -400,6 +400,34 @@ static int issue_pending_uploads(trgt_hip_ctx* c) {
 
 static std::mutex g_stage_a_mutex[16];
 
+// TRGT_READS_BAM4 -> ASCII: byte i of the packed blob becomes bytes 2i, 2i+1 of the expanded one (so a read that starts at packed byte
+// o starts at expanded byte 2o).  A thread turns 16 packed bytes into 32: one 16-byte load, two 16-byte stores.
+__device__ __forceinline__ uint32_t bam4_pair_to_ascii(uint32_t b) {  // one packed byte -> two ASCII bytes (first base in the low byte)
+  const uint64_t lo = 0x565352474d43413dull /* "=ACMGRSV" */, hi = 0x4e42444b48595754ull /* "TWYHKDBN" */;
+  const uint32_t a = b >> 4, z = b & 15u;
+  const uint32_t ca = (uint32_t)(((a & 8u) ? hi : lo) >> (8 * (a & 7u))) & 0xFFu, cz = (uint32_t)(((z & 8u) ? hi : lo) >> (8 * (z & 7u))) & 0xFFu;
+  return ca | (cz << 8);
+}
+__global__ void __launch_bounds__(256) expand_bam4_kernel(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, uint64_t n_bytes) {
+  const uint64_t n16 = n_bytes / 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = ((const uint4*)packed)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[2 * k] = bam4_pair_to_ascii(w[k] & 0xFFu) | (bam4_pair_to_ascii((w[k] >> 8) & 0xFFu) << 16);
+      o[2 * k + 1] = bam4_pair_to_ascii((w[k] >> 16) & 0xFFu) | (bam4_pair_to_ascii(w[k] >> 24) << 16);
+    }
+    ((uint4*)out)[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+    ((uint4*)out)[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+  }
+  if (blockIdx.x == 0) {  // the tail of fewer than 16 bytes
+    const uint64_t i = n16 * 16 + threadIdx.x;
+    if (i < n_bytes) { const uint32_t t = bam4_pair_to_ascii(packed[i]); out[2 * i] = (uint8_t)t; out[2 * i + 1] = (uint8_t)(t >> 8); }
+  }
+}
+
 // staged_reads / staged_flank: device copies of in->read_blob / in->flank_blob made ahead of time by trgt_locus_batch_submit (the
 // caller's pointers stay what the host glue reads); `ready`: the event behind those copies.
 static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out,
@@ -420,6 +448,33 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (F <= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: flank_len must be positive");
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
   if (2 * nr > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: too many reads in one call");
+  // reads handed over as BAM 4-bit codes: expanded in HBM, and from here on the batch is one with its reads on the device (the host
+  // glue of the later stages fetches the few read segments it needs from there, as it does for a caller's device blob)
+  trgt_locus_batch_in in_expanded;
+  std::vector<uint64_t> expanded_off;
+  if (in->read_encoding != TRGT_READS_ASCII && in->read_encoding != TRGT_READS_BAM4) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: read_encoding %d", in->read_encoding);
+  if (in->read_encoding == TRGT_READS_BAM4 && nr > 0) {
+    uint64_t packed_total = 0;
+    expanded_off.resize((size_t)nr);
+    for (int64_t r = 0; r < nr; ++r) {
+      packed_total = std::max<uint64_t>(packed_total, in->read_off[r] + ((uint64_t)in->read_len[r] + 1) / 2);
+      expanded_off[(size_t)r] = 2 * in->read_off[r];
+    }
+    const uint8_t* d_packed = nullptr;
+    void* d_exp = nullptr;
+    int erc;
+    if (ready) TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
+    if (staged_reads) d_packed = staged_reads;
+    else if ((erc = dev_in(c, S_READS_PACKED, in->read_blob, (size_t)packed_total, &d_packed))) return erc;
+    if ((erc = dev_get(c, S_READS_EXPANDED, 2 * (size_t)packed_total + 64, &d_exp))) return erc;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus * 16, packed_total / (16 * 256) + 1);
+    hipLaunchKernelGGL(expand_bam4_kernel, dim3(blocks), dim3(256), 0, c->stream, d_packed, (uint8_t*)d_exp, packed_total);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    in_expanded = *in;
+    in_expanded.read_blob = (const uint8_t*)d_exp; in_expanded.read_off = expanded_off.data(); in_expanded.read_encoding = TRGT_READS_ASCII;
+    in = &in_expanded;
+    staged_reads = nullptr;
+  }
   int threads = p->host_threads > 0 ? p->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
   // a few microseconds of work per locus: more threads only add wake-up cost.  The device genotyper leaves the
   // host little to do (4 threads measure the same as 32, and large pools produce the occasional late wake-up)
@@ -1160,6 +1215,26 @@ extern "C" int trgt_locus_batch(trgt_hip_ctx* c, const trgt_locus_params* p, con
   TRGT_ABI_GUARD(c, locus_batch_run(c, p, in, out, nullptr, nullptr, nullptr));
 }
 
+extern "C" int64_t trgt_reads_pack_bam4(const uint8_t* ascii, int64_t n_reads, const uint64_t* read_off, const uint32_t* read_len,
+                                        uint8_t* packed, uint64_t* packed_off) {
+  if (n_reads < 0 || (n_reads > 0 && (!ascii || !read_off || !read_len || !packed || !packed_off))) return TRGT_ERR_INVALID;
+  uint8_t code[256];
+  std::memset(code, 15, sizeof code);  // N
+  const char* letters = "=ACMGRSVTWYHKDBN";
+  for (int k = 0; k < 16; ++k) { code[(uint8_t)letters[k]] = (uint8_t)k; code[(uint8_t)std::tolower(letters[k])] = (uint8_t)k; }
+  uint64_t o = 0;
+  for (int64_t r = 0; r < n_reads; ++r) {
+    const uint8_t* s = ascii + read_off[r];
+    const uint32_t n = read_len[r];
+    packed_off[r] = o;
+    uint8_t* d = packed + o;
+    for (uint32_t i = 0; i + 1 < n; i += 2) d[i / 2] = (uint8_t)((code[s[i]] << 4) | code[s[i + 1]]);
+    if (n & 1) d[n / 2] = (uint8_t)(code[s[n - 1]] << 4);
+    o += ((uint64_t)n + 1) / 2;
+  }
+  return (int64_t)o;
+}
+
 static int locus_submit(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_locus_batch_in* in, trgt_locus_batch_out* out, int64_t* ticket) {
   if (!c) return TRGT_ERR_INVALID;
   if (!p || !in || !out || !ticket) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch_submit: null argument");
@@ -1179,7 +1254,8 @@ static int locus_submit(trgt_hip_ctx* c, const trgt_locus_params* p, const trgt_
     if (!st.ready) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
     uint64_t flank_total = 0, read_total = 0;
     for (int64_t l = 0; l < nl; ++l) flank_total = std::max<uint64_t>(flank_total, std::max(in->lf_off[l] + in->lf_len[l], in->rf_off[l] + in->rf_len[l]));
-    for (int64_t r = 0; r < nr; ++r) read_total = std::max<uint64_t>(read_total, in->read_off[r] + in->read_len[r]);
+    const bool bam4 = in->read_encoding == TRGT_READS_BAM4;  // two bases per byte
+    for (int64_t r = 0; r < nr; ++r) read_total = std::max<uint64_t>(read_total, in->read_off[r] + (bam4 ? ((uint64_t)in->read_len[r] + 1) / 2 : (uint64_t)in->read_len[r]));
     int rc;
     st.read_bytes = read_total; st.flank_bytes = flank_total;
     if (!is_device_ptr(in->read_blob)) {
@@ -1270,19 +1346,33 @@ extern "C" int trgt_locus_batch_many(trgt_hip_pool* P, const trgt_locus_params* 
     const int64_t t_many0 = now_ns();
     auto worker = [&](size_t w) {
       trgt_hip_ctx* c = P->ctx[w];
+      auto failed = [&](int rc, int64_t i) {
+        std::lock_guard<std::mutex> g(err_mutex);
+        if (!first_rc.load()) { first_rc = rc; P->err = "batch " + std::to_string((long long)i) + " on context " + std::to_string(w) + ": " + trgt_hip_last_error(c); }
+      };
+      // one batch ahead: the next batch is submitted (its host-resident reads start crossing the link on the copy stream) before
+      // the current one is analysed -- trgt_locus_batch_submit / _wait per context; for blobs already in HBM this is the blocking call
+      auto take = [&](int64_t* i, int64_t* ticket) -> bool {  // false: nothing left (or an error somewhere)
+        if (first_rc.load()) return false;
+        *i = next.fetch_add(1);
+        if (*i >= n_batches) return false;
+        const int rc = trgt_locus_batch_submit(c, p, in[*i], out_per_context ? out[w] : out[*i], ticket);
+        if (rc) { failed(rc, *i); return false; }
+        return true;
+      };
+      int64_t cur = -1, cur_ticket = 0;
+      if (!take(&cur, &cur_ticket)) return;
       for (;;) {
-        if (first_rc.load()) return;
-        const int64_t i = next.fetch_add(1);
-        if (i >= n_batches) return;
+        int64_t nxt = -1, nxt_ticket = 0;
+        const bool more = take(&nxt, &nxt_ticket);
         const int64_t tb0 = trace ? now_ns() : 0;
-        const int rc = trgt_locus_batch(c, p, in[i], out_per_context ? out[w] : out[i]);  // (catches its own exceptions)
-        if (trace) fprintf(stderr, "[pool] %zu %lld %.3f %.3f\n", w, (long long)i, (double)(tb0 - t_many0) / 1e6, (double)(now_ns() - t_many0) / 1e6);
-        if (ran_on) ran_on[i] = (int32_t)w;
-        if (rc) {
-          std::lock_guard<std::mutex> g(err_mutex);
-          if (!first_rc.load()) { first_rc = rc; P->err = "batch " + std::to_string((long long)i) + " on context " + std::to_string(w) + ": " + trgt_hip_last_error(c); }
-          return;
-        }
+        const int rc = trgt_locus_batch_wait(c, cur_ticket);
+        if (trace) fprintf(stderr, "[pool] %zu %lld %.3f %.3f\n", w, (long long)cur, (double)(tb0 - t_many0) / 1e6, (double)(now_ns() - t_many0) / 1e6);
+        if (ran_on) ran_on[cur] = (int32_t)w;
+        if (rc) failed(rc, cur);
+        if (!more) return;  // (a submit that failed left nothing outstanding)
+        if (rc) { (void)trgt_locus_batch_wait(c, nxt_ticket); return; }  // (drain the submitted batch: the caller's buffers must be free when we return)
+        cur = nxt; cur_ticket = nxt_ticket;
       }
     };
     std::vector<std::thread> th;

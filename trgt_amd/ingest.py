@@ -10,7 +10,7 @@ from . import _lib
 
 class IngestParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("max_depth", C.c_int32), ("min_read_qual", C.c_double), ("threads", C.c_int32),
-                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32)]
+                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32)]
 
 
 _P8, _P16, _P32, _P64, _PD, _PC = (C.POINTER(t) for t in (C.c_uint8, C.c_int16, C.c_uint32, C.c_uint64, C.c_double, C.c_char))
@@ -34,6 +34,7 @@ class IngestBatch(C.Structure):
                 ("mismatch_offsets", _PI32), ("mismatch_off", _P64),
                 ("meth", _P8), ("meth_off", _P64), ("has_meth", _P8),
                 ("cigar", _P32), ("cigar_off", _P64), ("cigar_ref_pos", _PI64),
+                ("read_bam4", _P8), ("read_bam4_off", _P64), ("read_bam4_bytes", C.c_uint64),
                 ("owner", C.c_void_p)]
 
 
@@ -136,8 +137,19 @@ class Reader:
         out["cigar"] = _arr(b.cigar, int(out["cigar_off"][-1]) if nr else 0, u32)
         if len(out["read_blob"]) == 0:
             out["read_blob"] = np.zeros(1, u8)
+        if b.read_bam4:  # keep_bam4=1: the reads once more as 4-bit codes; bam4_view(batch) is the batch that hands those to the GPU
+            out["read_bam4"] = _arr(b.read_bam4, max(int(b.read_bam4_bytes), 1), u8)
+            out["read_bam4_off"] = _arr(b.read_bam4_off, max(nr, 1), u64)
         if keep_native:  # the writers (trgt_amd/writers.py) take the native batch itself
             out["_native"] = NativeBatch(self._L, h)
         else:
             self._L.trgt_ingest_free(h)
         return out
+
+
+def bam4_view(batch):
+    """The batch of Reader.batch(..., keep_bam4=1) with its 4-bit reads in the place of the ASCII ones (read_encoding = TRGT_READS_BAM4):
+    what trgt_amd.locus.run_batch / submit_batch / run_many upload then is half the size."""
+    b = {k: v for k, v in batch.items() if k not in ("_cin", "read_bam4", "read_bam4_off")}
+    b["read_blob"], b["read_off"], b["read_encoding"] = batch["read_bam4"], batch["read_bam4_off"], 1
+    return b

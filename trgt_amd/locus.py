@@ -165,7 +165,7 @@ def _batch_in(batch, flank, reads):
     # The input struct of a batch is rebuilt only when one of its arrays is replaced (20 pointer conversions per call otherwise).
     # The cache entry HOLDS the arrays it was built from and compares them by identity: an id() alone could be reused by a new
     # array allocated at a freed one's address, and the struct would then carry a dangling pointer.
-    key = (int(batch["n_loci"]), flank, reads) + tuple(batch.get(k) for k in _CIN_KEYS)
+    key = (int(batch["n_loci"]), flank, reads) + tuple(batch.get(k) for k in _CIN_KEYS) + (int(batch.get("read_encoding", 0)),)
     cached = batch.get("_cin")
     if cached is None or len(cached[0]) != len(key) or cached[0][0] != key[0] or any(a is not b for a, b in zip(cached[0][1:], key[1:])):
         cin = _lib.LocusBatchIn(int(batch["n_loci"]), *[p(v).value for v in (
@@ -174,10 +174,35 @@ def _batch_in(batch, flank, reads):
             batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
             reads, batch["read_off"], batch["read_len"])],
             *[p(batch.get(k)).value if batch.get(k) is not None else None for k in ("genotyper", "read_qual", "hp_tag", "start_offset", "end_offset",
-                                                                                     "mismatch_offsets", "mismatch_off")])
+                                                                                     "mismatch_offsets", "mismatch_off")],
+            int(batch.get("read_encoding", 0)))
         cached = (key, cin)
         batch["_cin"] = cached
     return cached[1]
+
+
+def pack_bam4(batch, pinned=False):
+    """The batch with its reads as BAM 4-bit codes (TRGT_READS_BAM4, include/trgt_hip.h): a shallow copy whose read_blob / read_off are the
+    packed ones (trgt_reads_pack_bam4) and read_encoding = 1.  pinned: the packed blob in pinned host memory (a torch tensor kept in the
+    dict).  read_len and everything else are shared with the original."""
+    nr = int(batch["locus_read_begin"][int(batch["n_loci"])])
+    total = int(((batch["read_len"][:nr].astype(np.uint64) + 1) // 2).sum())
+    if pinned:
+        import torch
+        t = torch.empty(max(total, 1), dtype=torch.uint8).pin_memory()
+        packed = t.numpy()
+    else:
+        t, packed = None, np.zeros(max(total, 1), np.uint8)
+    off = np.zeros(max(nr, 1), np.uint64)
+    blob = np.ascontiguousarray(batch["read_blob"])
+    got = _lib.lib().trgt_reads_pack_bam4(_lib.ptr(blob), nr, _lib.ptr(batch["read_off"]), _lib.ptr(batch["read_len"]), _lib.ptr(packed), _lib.ptr(off))
+    if got != total:
+        raise RuntimeError(f"trgt_reads_pack_bam4 returned {got}, expected {total}")
+    b = {k: v for k, v in batch.items() if k != "_cin"}
+    b["read_blob"], b["read_off"], b["read_encoding"] = packed, off, 1
+    if t is not None:
+        b["_read_blob_pinned"] = t
+    return b
 
 
 def _locus_params(params):
@@ -237,7 +262,8 @@ def submit_batch(batch, params=Params(), ctx=None, outputs=None, flank=None, rea
         batch["motif_blob"], batch["motif_off"], batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
         rd, batch["read_off"], batch["read_len"])],
         p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
-        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None)
+        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None,
+        read_encoding=int(batch.get("read_encoding", 0)))
     lp = _locus_params(params)
     t = C.c_int64(0)
     ctx.check(_lib.lib().trgt_locus_batch_submit(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out), C.byref(t)))
