@@ -3,7 +3,7 @@ CPU oracle (all host cores), compared field by field as text records -- spans of
 classification, ALLR, SD, MC, MS, AP.  A developer tool (minutes of host time for 10^5..10^6 loci), not part of the test suite:
 the suite holds the full-size batch to a seeded sample plus size-independent properties (tests/test_full_size_gpu.py).
 
-    python tests/tests/tools/parity_sweep.py <config> <n_loci> [first_locus] [chunk]
+    python tests/tools/parity_sweep.py <config> <n_loci> [first_locus] [chunk] [--host-reads | --bam4] [--host-glue] [--rq Q] [--depth D]
 """
 import os
 import sys
@@ -40,7 +40,8 @@ def main():
     argv = list(sys.argv[1:])
     host_reads = "--host-reads" in argv
     host_glue = "--host-glue" in argv
-    argv = [a for a in argv if a not in ("--host-reads", "--host-glue")]
+    bam4 = "--bam4" in argv  # reads handed over as BAM 4-bit codes (TRGT_READS_BAM4), from host memory
+    argv = [a for a in argv if a not in ("--host-reads", "--host-glue", "--bam4")]
     rq_min, depth = None, None
     if "--rq" in argv:
         i = argv.index("--rq"); rq_min = float(argv[i + 1]); del argv[i:i + 2]
@@ -69,9 +70,10 @@ def main():
             q = np.where(rng.random(int(b["n_reads"])) < 0.7, 0.99, 0.80 + 0.2 * rng.random(int(b["n_reads"])))
             q[rng.random(int(b["n_reads"])) < 0.05] = np.nan
             b["read_qual"] = np.ascontiguousarray(q, np.float64)
-        rd, fd = (None, None) if host_reads else (torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda())
+        rd, fd = (None, None) if host_reads or bam4 else (torch.from_numpy(b["read_blob"]).cuda(), torch.from_numpy(b["flank_blob"]).cuda())
+        gb = locus.pack_bam4(b) if bam4 else b
         t0 = time.perf_counter()
-        out = locus.run_batch(b, params, ctx, flank_dev=fd, reads_dev=rd)
+        out = locus.run_batch(gb, params, ctx, flank_dev=fd, reads_dev=rd)
         t_gpu += time.perf_counter() - t0
         got = gpu_records(b, out)
         t0 = time.perf_counter()
@@ -85,7 +87,7 @@ def main():
         n_done += n
         n_alleles += int(out.n_alleles.sum())
         print("[sweep] config %d loci %d..%d: %d mismatches so far (gpu %.2f s, oracle %.1f s on %d threads)" % (config, first, c0 + n, bad, t_gpu, t_cpu, threads), flush=True)
-    print("RESULT config=%d loci=%d alleles=%d mismatches=%d%s%s%s%s" % (config, n_done, n_alleles, bad, " host-reads" if host_reads else "",
+    print("RESULT config=%d loci=%d alleles=%d mismatches=%d%s%s%s%s%s" % (config, n_done, n_alleles, bad, " bam4" if bam4 else "", " host-reads" if host_reads else "",
           " host-glue" if host_glue else "", " min_read_qual=%g" % rq_min if rq_min is not None else "", " max_depth=%d" % depth if depth is not None else ""))
     return 1 if bad else 0
 
