@@ -91,8 +91,9 @@ struct trgt_hip_ctx {
   // side streams for the launches of one HMM batch (one per workgroup-size class: they run next to each other, not one behind the
   // other's tail), with the events that fork them off the batch's stream and join them back
   hipEvent_t ev_scan = nullptr, ev_heavy = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
-  hipStream_t hmm_side[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t hmm_fork = nullptr, hmm_join[3] = {nullptr, nullptr, nullptr};
+  // side streams of the HMM launches: [0..2] of buffer set 0, [3..5] of buffer set 1 (the second batch of a call runs next to the first)
+  hipStream_t hmm_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t hmm_fork[2] = {nullptr, nullptr}, hmm_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace trgt {

@@ -96,11 +96,11 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
   if (c->stream_copy) { (void)trgt::stream_wait(c, c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
   for (auto& st : c->staged) if (st.ready) (void)hipEventDestroy(st.ready);
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 6; ++i) {
     if (c->hmm_side[i]) { (void)trgt::stream_wait(c, c->hmm_side[i]); (void)hipStreamDestroy(c->hmm_side[i]); }
     if (c->hmm_join[i]) (void)hipEventDestroy(c->hmm_join[i]);
   }
-  if (c->hmm_fork) (void)hipEventDestroy(c->hmm_fork);
+  for (int i = 0; i < 2; ++i) if (c->hmm_fork[i]) (void)hipEventDestroy(c->hmm_fork[i]);
   if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
   if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
   delete static_cast<trgt::HostPool*>(c->host_pool);

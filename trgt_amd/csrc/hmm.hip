@@ -1177,9 +1177,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   if ((rc = o_maxd.init(c, S_HMM_MAXD + so, max_dist, (size_t)n_jobs))) return rc;
   // ---- one launch per workgroup-size class; the first on the batch's stream, the others on side streams forked off it, so that
   //      the classes run next to each other (a class is bounded by its longest allele: one behind the other they add up their tails)
+  // the fork event sits behind the uploads and IN FRONT of the first launch: recorded behind it (as it was until the cfg3 trace showed
+  // it), every other class waited for the first class to finish -- 17.6 + 15.2 ms instead of 17.6 for the 10-kb alleles of cfg3
+  if (!c->hmm_fork[buffer_set ? 1 : 0]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork[buffer_set ? 1 : 0], hipEventDisableTiming));
+  TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork[buffer_set ? 1 : 0], c->stream));
   size_t i = 0;
   int n_class = 0;
-  bool forked = false;
   unsigned side_used = 0;
   while (i < jobs.size()) {
     const uint32_t jc = job_class(jobs[i]), cls = jc;
@@ -1196,13 +1199,11 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t ls = c->stream;
     if (n_class > 0) {
-      const int sidx = (n_class - 1) % 3;
+      const int sidx = (n_class - 1) % 3 + (buffer_set ? 3 : 0);
       if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
-      if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
-      if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }  // behind the uploads (and the first launch)
       ls = c->hmm_side[sidx];
-      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork, 0));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork[buffer_set ? 1 : 0], 0));
       side_used |= 1u << sidx;
     }
     ++n_class;
@@ -1219,7 +1220,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     t.stop(i == 0 ? cells : 0);
     i = e;
   }
-  for (int sidx = 0; sidx < 3; ++sidx)
+  for (int sidx = 0; sidx < 6; ++sidx)
     if (side_used & (1u << sidx)) {
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
@@ -1334,8 +1335,9 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     hipLaunchKernelGGL(hmm_resolve_kernel, dim3(1), dim3(1024), 0, c->stream, ra);
   }
   TRGT_HIP_TRY(c, hipGetLastError());
+  if (!c->hmm_fork[buffer_set ? 1 : 0]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork[buffer_set ? 1 : 0], hipEventDisableTiming));
+  TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork[buffer_set ? 1 : 0], c->stream));  // (behind the resolve kernel, in front of the first launch)
   int n_class = 0;
-  bool forked = false;
   unsigned side_used = 0;
   for (uint32_t k = 0; k < 8; ++k) {
     if (!class_n[k]) continue;
@@ -1349,13 +1351,11 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t ls = c->stream;
     if (n_class > 0) {
-      const int sidx = (n_class - 1) % 3;
+      const int sidx = (n_class - 1) % 3 + (buffer_set ? 3 : 0);
       if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
-      if (!c->hmm_fork) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork, hipEventDisableTiming));
-      if (!forked) { TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork, c->stream)); forked = true; }
       ls = c->hmm_side[sidx];
-      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork, 0));
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork[buffer_set ? 1 : 0], 0));
       side_used |= 1u << sidx;
     }
     ++n_class;
@@ -1371,7 +1371,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(0);
   }
-  for (int sidx = 0; sidx < 3; ++sidx)
+  for (int sidx = 0; sidx < 6; ++sidx)
     if (side_used & (1u << sidx)) {
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));

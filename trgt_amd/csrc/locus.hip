@@ -1158,6 +1158,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     }
     if (!js2.empty()) {
       ns2.resize(js2.size()); pu2.resize(js2.size());
+      // next to the batch of the device-genotyped loci, if there is one: the call's second stream and the second set of side streams
+      // (the two batches are independent; queued on the same streams the second one waited for the first -- config 3: 65 -> 5x ms per call)
+      struct StreamSwap { trgt_hip_ctx* c; hipStream_t saved; ~StreamSwap() { c->stream = saved; } } hmm2_stream{c, c->stream};
+      if (hmm_pending) c->stream = c->stream2;
       rc = hmm_enqueue(c, &models, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, (int64_t)js2.size(), js2.data(),
                        out->allele_blob, so2.data(), sl2.data(), nullptr, nullptr, nullptr, out->spans3, spo2.data(), ns2.data(),
                        out->motif_counts, co2.data(), pu2.data(), nullptr, nullptr, &hmm_pending2, hmm_pending ? 1 : 0);
