@@ -64,7 +64,7 @@ def main():
     t_gpu = t_cpu = 0.0
     for c0 in range(first, first + n_total, chunk):
         n = min(chunk, first + n_total - c0)
-        b = synth.generate(n, first_locus=c0, config=config)
+        b = synth.generate_cfg3(n, first_locus=c0) if config == 3 else synth.generate(n, first_locus=c0, config=config)
         if rq_min is not None:  # rq tags: mostly high, some below the threshold, some missing
             rng = np.random.default_rng(c0 + 17)
             q = np.where(rng.random(int(b["n_reads"])) < 0.7, 0.99, 0.80 + 0.2 * rng.random(int(b["n_reads"])))

@@ -35,6 +35,7 @@ struct trgt_knobs {
   bool stage_lock = false;      // TRGT_STAGE_LOCK: only one context per device in its flank-location stage at a time
   bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
+  bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
 };
@@ -166,7 +167,7 @@ enum Slot {
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
-  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY,
+  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED,

@@ -351,6 +351,83 @@ __global__ void span_combine_kernel(const CombineArgs a) {
 
 __global__ void cells_merge_kernel(unsigned long long* total2, const unsigned long long* heavy) { total2[1] = heavy[0]; total2[0] += heavy[0]; }
 
+// ---- reads beyond the dedicated kernels' texts (alleles of kilobases): the pre-filter judges them WINDOW BY WINDOW.
+// An optimal ends-free alignment of a flank piece costs at most o + plen e (the piece deleted as a whole), so it inserts at most that
+// many bases and covers at most span_max = 2 plen + o text bases: with windows of wl bases every `step` = wl - span_max bases (and one
+// flush with the end of the read) every alignment the whole read admits lies inside a window, with the same penalty and the same
+// matches.  If the filter rejects every window -- no alignment of the window that can still be optimal has min_matches matches -- then
+// no alignment of the read has, whichever of the co-optimal ones WFA2-lib would return: the job is dropped as the filter drops a
+// short one.  A job with a window that is kept (or could not be judged) goes to the exact kernel with its whole read, as before.
+struct LongWinArgs {
+  const JobDev* jobs; const uint32_t* n_jobs;  // the long list and its length
+  uint32_t* first;                             // [n + 1] first window of job j (exclusive prefix sum of the window counts)
+  JobDev* sub; uint32_t* parent; uint8_t* sub_keep; uint32_t* n_sub; uint32_t cap;
+  uint8_t* job_keep;                           // per long job: 1 = to the exact kernel
+  JobDev* kept; uint32_t* n_kept;
+  int32_t wl, step;
+};
+__device__ __forceinline__ uint32_t long_windows_of(uint32_t tlen, int wl, int step) {
+  return tlen <= (uint32_t)wl ? 1u : (tlen - (uint32_t)wl + (uint32_t)step - 1u) / (uint32_t)step + 1u;
+}
+// one workgroup: window counts -> offsets; jobs whose windows do not fit the list any more are kept unseen
+__global__ void __launch_bounds__(1024) long_offsets_kernel(const LongWinArgs a) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
+  const uint32_t n = *a.n_jobs;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t j = base + threadIdx.x;
+    const uint32_t nw = j < n ? long_windows_of(a.jobs[j].txt_len, a.wl, a.step) : 0u;
+    part[threadIdx.x] = nw;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive scan
+      const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const uint32_t off = carry + part[threadIdx.x] - nw;
+    if (j < n) {
+      const bool fits = off + nw <= a.cap;
+      a.first[j] = fits ? off : 0xFFFFFFFFu;
+      a.job_keep[j] = fits ? 0 : 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *a.n_sub = carry < a.cap ? carry : a.cap; *a.n_kept = 0; }
+  // (a job in the middle that does not fit leaves a hole of unwritten windows only if a later, smaller one fits again: the offsets are
+  //  monotone, so "fits" is a prefix property and the list [0, n_sub) is dense)
+}
+__global__ void long_windows_kernel(const LongWinArgs a) {
+  const uint32_t n = *a.n_jobs;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t off = a.first[j];
+    if (off == 0xFFFFFFFFu) continue;
+    const JobDev job = a.jobs[j];
+    const uint32_t tlen = job.txt_len, nw = long_windows_of(tlen, a.wl, a.step);
+    for (uint32_t w = 0; w < nw; ++w) {
+      uint32_t start = w * (uint32_t)a.step;
+      if (tlen > (uint32_t)a.wl && start + (uint32_t)a.wl > tlen) start = tlen - (uint32_t)a.wl;  // the last window: flush with the end
+      JobDev sj = job;
+      sj.txt_off = job.txt_off + start; sj.txt_len = tlen > (uint32_t)a.wl ? (uint32_t)a.wl : tlen; sj.out_index = off + w;
+      a.sub[off + w] = sj; a.parent[off + w] = j;
+    }
+  }
+}
+__global__ void long_verdict_kernel(const LongWinArgs a) {  // a kept window keeps its job
+  const uint32_t n = *a.n_sub;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+    if (a.sub_keep[s]) a.job_keep[a.parent[s]] = 1;
+}
+__global__ void long_kept_kernel(const LongWinArgs a) {
+  const uint32_t n = *a.n_jobs;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    if (a.job_keep[j]) a.kept[atomicAdd(a.n_kept, 1u)] = a.jobs[j];
+}
+
 // Device-side part shared with trgt_locus_batch: everything already resident, results left on the device.
 int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci, int64_t n_reads, const uint8_t* d_flank,
                       const uint64_t* d_piece_off, const uint8_t* d_reads, const uint64_t* d_read_off, const uint32_t* d_read_len,
@@ -536,6 +613,42 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
     L2.keep_cells = true; L2.timer_slot = TRGT_K_WFA_FLANK_REST;
+    // the pre-filter over windows of the long reads (see LongWinArgs): what it rejects never reaches the exact kernel
+    {
+      const double thr = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;
+      int64_t min_matches = thr > 0 ? (int64_t)std::ceil(thr) : 0;
+      while (min_matches > 0 && (double)(min_matches - 1) >= thr) --min_matches;
+      while ((double)min_matches < thr) ++min_matches;
+      const int64_t wl = flank_filter_max_tlen(p.flank_len);
+      const int64_t span_max = 2 * (int64_t)p.flank_len + p.gapo + 8, step = wl - span_max;
+      if (p.mism == 2 && p.gapo == 5 && p.gape == 1 && min_matches >= 1 && min_matches <= 254 && step >= 256 && !c->knobs.no_filter && !c->knobs.no_long_filter) {
+        const uint64_t w_max = (uint64_t)((int64_t)max_read_len > wl ? ((int64_t)max_read_len - wl + step - 1) / step + 1 : 1);
+        const uint64_t cap = std::min<uint64_t>((uint64_t)n_jobs * w_max, 1ull << 21);
+        void *d_first = nullptr, *d_sub = nullptr, *d_parent = nullptr, *d_subkeep = nullptr, *d_jobkeep = nullptr, *d_kept = nullptr, *d_lwc = nullptr;
+        if ((rc = dev_get(c, S_LW_FIRST, (n_jobs + 1) * 4, &d_first)) || (rc = dev_get(c, S_LW_SUB, cap * sizeof(JobDev), &d_sub)) ||
+            (rc = dev_get(c, S_LW_PARENT, cap * 4, &d_parent)) || (rc = dev_get(c, S_LW_SUBKEEP, cap, &d_subkeep)) ||
+            (rc = dev_get(c, S_LW_JOBKEEP, n_jobs, &d_jobkeep)) || (rc = dev_get(c, S_LW_KEPT, n_jobs * sizeof(JobDev), &d_kept)) ||
+            (rc = dev_get(c, S_LW_COUNT, 16, &d_lwc)))
+          return rc;
+        LongWinArgs lw;
+        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + 1; lw.first = (uint32_t*)d_first;
+        lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
+        lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
+        const dim3 g((unsigned)c->num_cus * 2), b(256);
+        hipLaunchKernelGGL(long_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, lw);
+        hipLaunchKernelGGL(long_windows_kernel, g, b, 0, c->stream, lw);
+        TRGT_HIP_TRY(c, hipGetLastError());
+        FilterLaunch FW;
+        FW.jobs_dev = (const JobDev*)d_sub; FW.n_jobs_host = (int64_t)cap; FW.n_jobs_dev = (const uint32_t*)d_lwc;
+        FW.pat_base = d_flank; FW.txt_base = d_reads; FW.max_plen = p.flank_len; FW.max_tlen = wl;
+        FW.min_matches = (int32_t)min_matches; FW.early_reject = !c->knobs.no_early; FW.keep = (uint8_t*)d_subkeep; FW.set = 1;
+        if ((rc = flank_filter_launch(c, FW))) return rc;
+        hipLaunchKernelGGL(long_verdict_kernel, g, b, 0, c->stream, lw);
+        hipLaunchKernelGGL(long_kept_kernel, g, b, 0, c->stream, lw);
+        TRGT_HIP_TRY(c, hipGetLastError());
+        L2.jobs_dev = (const JobDev*)d_kept; L2.n_jobs_dev = (const uint32_t*)d_lwc + 1;
+      }
+    }
     if ((rc = wfa_launch(c, wp, L2))) return rc;
   }
   if (heavy_join) {

@@ -63,6 +63,7 @@ struct FilterLaunch {
   int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;
   bool count_offsets = false;  // also count the wavefront offsets (a little slower: one more scalar walk per level)
   int timer_slot = TRGT_K_WFA_FILTER;
+  int set = 0;  // 1: a second launch that may run next to the first (own job counter and offset counter; ctx->last_filter_cells_dev stays the first's)
 };
 // Longest text the filter can judge for this pattern length (0: the filter does not apply); longer texts are kept unseen.
 int flank_filter_max_tlen(int flank_len);

@@ -492,7 +492,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   a.score = L.score; a.bound = L.bound; a.keep = L.keep;
   void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
-  if ((rc = dev_get(c, S_FLT_COUNTER, 16, &d_counter)) || (rc = dev_get(c, S_FLT_CELLS, 16, &d_cells))) return rc;
+  if ((rc = dev_get(c, L.set ? S_FLT_COUNTER_B : S_FLT_COUNTER, 16, &d_counter)) || (rc = dev_get(c, L.set ? S_FLT_CELLS_B : S_FLT_CELLS, 16, &d_cells))) return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
@@ -518,7 +518,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
-  c->last_filter_cells_dev = d_cells;
+  if (!L.set) c->last_filter_cells_dev = d_cells;
   return TRGT_OK;
 }
 
