@@ -360,7 +360,6 @@ __global__ void cells_merge_kernel(unsigned long long* total2, const unsigned lo
 // short one.  A job with a window that is kept (or could not be judged) goes to the exact kernel with its whole read, as before.
 struct LongWinArgs {
   const JobDev* jobs; const uint32_t* n_jobs;  // the long list and its length
-  uint32_t* first;                             // [n + 1] first window of job j (exclusive prefix sum of the window counts)
   JobDev* sub; uint32_t* parent; uint8_t* sub_keep; uint32_t* n_sub; uint32_t cap;
   uint8_t* job_keep;                           // per long job: 1 = to the exact kernel
   JobDev* kept; uint32_t* n_kept;
@@ -369,47 +368,19 @@ struct LongWinArgs {
 __device__ __forceinline__ uint32_t long_windows_of(uint32_t tlen, int wl, int step) {
   return tlen <= (uint32_t)wl ? 1u : (tlen - (uint32_t)wl + (uint32_t)step - 1u) / (uint32_t)step + 1u;
 }
-// one workgroup: window counts -> offsets; jobs whose windows do not fit the list any more are kept unseen
-__global__ void __launch_bounds__(1024) long_offsets_kernel(const LongWinArgs a) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t carry;
-  const uint32_t n = *a.n_jobs;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n; base += 1024) {
-    const uint32_t j = base + threadIdx.x;
-    const uint32_t nw = j < n ? long_windows_of(a.jobs[j].txt_len, a.wl, a.step) : 0u;
-    part[threadIdx.x] = nw;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive scan
-      const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-      __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
-    }
-    const uint32_t off = carry + part[threadIdx.x] - nw;
-    if (j < n) {
-      const bool fits = off + nw <= a.cap;
-      a.first[j] = fits ? off : 0xFFFFFFFFu;
-      a.job_keep[j] = fits ? 0 : 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += part[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { *a.n_sub = carry < a.cap ? carry : a.cap; *a.n_kept = 0; }
-  // (a job in the middle that does not fit leaves a hole of unwritten windows only if a later, smaller one fits again: the offsets are
-  //  monotone, so "fits" is a prefix property and the list [0, n_sub) is dense)
-}
+// The windows of a job take a range of the list reserved with one atomic (their order in the list does not matter).  A job whose range
+// passes the end of the list is kept unseen; the part of its range that is inside the list is filled with copies of its first window,
+// so that the list [0, min(n_sub, cap)) holds valid jobs only.
 __global__ void long_windows_kernel(const LongWinArgs a) {
   const uint32_t n = *a.n_jobs;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const uint32_t off = a.first[j];
-    if (off == 0xFFFFFFFFu) continue;
     const JobDev job = a.jobs[j];
     const uint32_t tlen = job.txt_len, nw = long_windows_of(tlen, a.wl, a.step);
-    for (uint32_t w = 0; w < nw; ++w) {
-      uint32_t start = w * (uint32_t)a.step;
+    const uint32_t off = atomicAdd(a.n_sub, nw);
+    const bool fits = off <= a.cap && nw <= a.cap - off;
+    a.job_keep[j] = fits ? 0 : 1;
+    for (uint32_t w = 0; w < nw && off + w < a.cap; ++w) {
+      uint32_t start = fits ? w * (uint32_t)a.step : 0u;
       if (tlen > (uint32_t)a.wl && start + (uint32_t)a.wl > tlen) start = tlen - (uint32_t)a.wl;  // the last window: flush with the end
       JobDev sj = job;
       sj.txt_off = job.txt_off + start; sj.txt_len = tlen > (uint32_t)a.wl ? (uint32_t)a.wl : tlen; sj.out_index = off + w;
@@ -418,7 +389,7 @@ __global__ void long_windows_kernel(const LongWinArgs a) {
   }
 }
 __global__ void long_verdict_kernel(const LongWinArgs a) {  // a kept window keeps its job
-  const uint32_t n = *a.n_sub;
+  const uint32_t n = min(*a.n_sub, a.cap);
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
     if (a.sub_keep[s]) a.job_keep[a.parent[s]] = 1;
 }
@@ -621,21 +592,26 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       while ((double)min_matches < thr) ++min_matches;
       const int64_t wl = flank_filter_max_tlen(p.flank_len);
       const int64_t span_max = 2 * (int64_t)p.flank_len + p.gapo + 8, step = wl - span_max;
-      if (p.mism == 2 && p.gapo == 5 && p.gape == 1 && min_matches >= 1 && min_matches <= 254 && step >= 256 && !c->knobs.no_filter && !c->knobs.no_long_filter) {
+      // It pays where the exact kernel is the generic one (wavefronts in HBM): texts beyond what the LDS kernel of wfa_launch takes
+      // (ring of 11 levels x 2 B + 4 B of windows per diagonal in 96 KB: about 3 500 bases for 250-base pieces).  Reads just above the
+      // dedicated launches' length (cfg4: up to 1 300 bases) go to that LDS kernel, and the extra filter launch cost 5 % there.
+      const int64_t lds_kernel_tlen = (96 * 1024) / (2 * ring_slots + 4) - p.flank_len - 32;
+      if (p.mism == 2 && p.gapo == 5 && p.gape == 1 && min_matches >= 1 && min_matches <= 254 && step >= 256 && (int64_t)max_read_len > lds_kernel_tlen &&
+          !c->knobs.no_filter && !c->knobs.no_long_filter) {
         const uint64_t w_max = (uint64_t)((int64_t)max_read_len > wl ? ((int64_t)max_read_len - wl + step - 1) / step + 1 : 1);
         const uint64_t cap = std::min<uint64_t>((uint64_t)n_jobs * w_max, 1ull << 21);
-        void *d_first = nullptr, *d_sub = nullptr, *d_parent = nullptr, *d_subkeep = nullptr, *d_jobkeep = nullptr, *d_kept = nullptr, *d_lwc = nullptr;
-        if ((rc = dev_get(c, S_LW_FIRST, (n_jobs + 1) * 4, &d_first)) || (rc = dev_get(c, S_LW_SUB, cap * sizeof(JobDev), &d_sub)) ||
+        void *d_sub = nullptr, *d_parent = nullptr, *d_subkeep = nullptr, *d_jobkeep = nullptr, *d_kept = nullptr, *d_lwc = nullptr;
+        if ((rc = dev_get(c, S_LW_SUB, cap * sizeof(JobDev), &d_sub)) ||
             (rc = dev_get(c, S_LW_PARENT, cap * 4, &d_parent)) || (rc = dev_get(c, S_LW_SUBKEEP, cap, &d_subkeep)) ||
             (rc = dev_get(c, S_LW_JOBKEEP, n_jobs, &d_jobkeep)) || (rc = dev_get(c, S_LW_KEPT, n_jobs * sizeof(JobDev), &d_kept)) ||
             (rc = dev_get(c, S_LW_COUNT, 16, &d_lwc)))
           return rc;
         LongWinArgs lw;
-        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + 1; lw.first = (uint32_t*)d_first;
+        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + 1; 
         lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
         lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
         const dim3 g((unsigned)c->num_cus * 2), b(256);
-        hipLaunchKernelGGL(long_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, lw);
+        TRGT_HIP_TRY(c, hipMemsetAsync(d_lwc, 0, 16, c->stream));
         hipLaunchKernelGGL(long_windows_kernel, g, b, 0, c->stream, lw);
         TRGT_HIP_TRY(c, hipGetLastError());
         FilterLaunch FW;

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(
   uint32_t* const Tw = lds + PWN;
   const int lane = (int)threadIdx.x;
   const uint32_t* const twl = Tw + lane * LW;  // + (v + 1) + C_p: the window of diagonal kb = C_p + lane * LW at offset v + k
-  const uint32_t n_jobs = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
+  const uint32_t n_jobs = a.n_jobs_dev ? min(*a.n_jobs_dev, a.n_jobs) : a.n_jobs;  // (never past the list the host sized)
   unsigned long long cells_acc = 0, kept_acc = 0;
 
   // 4-byte sliding windows of `len` bytes at src into W[i] (i = 0 .. n_win - 1), bytes beyond the sequence = pad
