@@ -459,6 +459,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int mot_bytes = (S - 7 - n_motifs) / 3;
   uint32_t* l_vis = reinterpret_cast<uint32_t*>(l_mot + ((mot_bytes + 15) & ~15));
   uint32_t* l_cnt = l_vis + 3 * HMM_VIS_LDS;
+  uint32_t* l_rec = l_cnt + ((nb + 1) & ~1);  // [HMM_REC_MAX][2] (state, column) of the steps of a trace-back round
   for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
   for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
   const uint8_t* const motif_bytes = l_mot;
@@ -651,10 +652,21 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
 
   // ---- traceback (hmm_model.rs:125-142) fused with get_events/calc_purity (events.rs:17-86, purity.rs:6-41)
   //      and motif-visit collection (operations.rs:26-40); back-pointer columns are staged through LDS.
+  //      Thread 0 only CHASES the back-pointers (state, column -> predecessor: two LDS round trips and a dozen instructions per step)
+  //      and notes the states it passes, HMM_REC at a time; what each step means -- its events, its part of the edit count, the motif
+  //      visit it closes -- is then worked out for all noted steps at once, one lane per step.  (Everything in one loop on one lane was
+  //      90 instructions per step: 750 cycles, a third of the kernel.)  What a step needs from its neighbours is little: the state
+  //      walked just before it (the implied leading deletions of a block start) and the column of the last block end before it (the
+  //      bases of the visit a block start closes): a lane shift and a ballot.
   const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
   uint32_t* const g_vis = visit_ws + job.visit_off;  // visits HMM_VIS_LDS, HMM_VIS_LDS + 1, ... at their own index
   const int pcap = (int)job.path_cap;
+  constexpr int HMM_REC = SUB == 32 ? 32 : 64;  // steps per round: the lanes of the job's first wave
+  int &tb_nrec = tb[9], &tb_more = tb[10];      // steps noted in this round; 1: the chunk has more, 0: it is exhausted, 2: the walk is over
+  const int hwlane = (int)(threadIdx.x & 63u);
+  const unsigned long long gmask = SUB == 32 ? (0xFFFFFFFFull << (hwlane & 32)) : ~0ull;  // the lanes of my job in this wave
+  const unsigned long long below = gmask & ((1ull << hwlane) - 1ull);
   while (true) {
     if (tb_done) break;
     const int c1 = tb_idx + 1, c0 = max(0, c1 - cols_per_chunk);
@@ -668,29 +680,50 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       for (int k = tid; k < c1 - c0 + HMM_CODE_PAD && c0 + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, c0 + k, L);
     }
     hmm_sync(sync_n);
-    if (tid == 0) {
-      int state = tb_state, idx = tb_idx, np = tb_npath, nv = tb_nvisit, edit = tb_edit, ref = tb_ref, nxt = tb_next, vb1 = tb_vb1;
-      int row = (idx - c0) * Spad;  // offset of column idx in the staged chunk
-      while (state != 0 && idx >= c0) {
-        if (pbuf && np < pcap) pbuf[pcap - 1 - np] = (uint16_t)state;
-        ++np;
-        // one word describes the state, and nothing but the predecessor lookup depends on the back-pointer: two LDS round trips
-        // per step (it was seven, and an integer division)
-        const uint32_t inf = l_info[state];
-        const int b = l_stage[row + state];
-        const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);  // (4-byte aligned: S may be odd)
-        const uint2 pred4 = make_uint2(pin[0], pin[1]);  // all four predecessors: no second round trip behind b
-        const int qbase = hmm_code_char(code_at(idx));
-        const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu);
-        // events of this state (events.rs:17-86), branch-free but for the visit record: MotifStart (1) adds the implied leading
-        // deletions, MotifEnd (2) opens a visit, Skip (3) / Mismatch / Ins (5) / Del (6) are edits, Skip / Match-state / Del consume
-        // a reference base
-        const int expected = (int)((inf >> 16) & 0xFFu);
+    for (;;) {
+      if (tid == 0) {  // ---- the chase
+        int state = tb_state, idx = tb_idx, n = 0;
+        int row = (idx - c0) * Spad;  // offset of column idx in the staged chunk
+        while (state != 0 && idx >= c0 && n < HMM_REC) {
+          l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
+          const uint32_t inf = l_info[state];
+          const int b = l_stage[row + state];
+          const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);  // (4-byte aligned: S may be odd)
+          const uint2 pred4 = make_uint2(pin[0], pin[1]);  // all four predecessors: no second round trip behind b
+          const uint32_t pw = (b & 2) ? pred4.y : pred4.x;
+          const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)((b & 1) ? pw >> 16 : pw & 0xFFFFu);
+          if (inf & 8u) { --idx; row -= Spad; }
+          state = prv;
+        }
+        tb_state = state; tb_idx = idx; tb_nrec = n;
+        tb_more = state == 0 ? 2 : (idx >= c0 ? 1 : 0);
+      }
+      hmm_sync(sync_n);
+      const int more = tb_more;  // (read before the next barrier: thread 0 writes it again right behind that one)
+      if (tid < HMM_REC) {  // ---- what the noted steps mean (events.rs:17-86, purity.rs:6-41, operations.rs:26-57), one lane per step
+        const int n = tb_nrec, np0 = tb_npath, nv0 = tb_nvisit, nxt0 = tb_next, vb0 = tb_vb1;
+        const bool valid = tid < n;
+        const int state = valid ? (int)l_rec[2 * tid] : 0, idx = valid ? (int)l_rec[2 * tid + 1] : 0;
+        const uint32_t inf = valid ? l_info[state] : 0u;
+        const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu), expected = (int)((inf >> 16) & 0xFFu);
+        if (valid && pbuf && np0 + tid < pcap) pbuf[pcap - 1 - (np0 + tid)] = (uint16_t)state;
+        // the state walked just before this one (the step before: the lane before)
+        const int up = __shfl_up(state, 1);
+        const int nxt = tid == 0 ? nxt0 : up;
+        // MotifStart (1) adds the implied leading deletions, Skip (3) / Mismatch / Ins (5) / Del (6) are edits, Skip / Match-state /
+        // Del consume a reference base
+        const int qbase = valid ? hmm_code_char(code_at(idx)) : 0;
         const int dels = kind == 1 ? nxt - state - 1 : 0;
         const int mism = kind == 4 && !(qbase == expected || expected == 'N');  // events.rs:66-73
-        edit += dels + (kind == 3) + mism + (kind == 5) + (kind == 6);
-        ref += dels + (kind == 3) + (kind == 4) + (kind == 6);
-        if (kind == 1) {  // a motif visit: bases query[idx .. vb1)
+        int edit = valid ? dels + (kind == 3) + mism + (kind == 5) + (kind == 6) : 0;
+        int ref = valid ? dels + (kind == 3) + (kind == 4) + (kind == 6) : 0;
+        // the last block end (2) walked before this step: the bases of the visit a block start (1) closes are query[idx .. vb1)
+        const unsigned long long ends = __ballot(valid && kind == 2) & gmask, starts = __ballot(valid && kind == 1) & gmask;
+        const unsigned long long ends_below = ends & below;
+        const int src_end = ends_below ? 63 - (int)__builtin_clzll(ends_below) : hwlane;
+        const int idx_end = __shfl(idx, src_end);
+        const int vb1 = ends_below ? idx_end : vb0;
+        if (valid && kind == 1) {  // a motif visit
           // remove_imperfect_motifs(.., 6) (operations.rs:45-57): only copies of STR motifs can be dropped -- short ones, and ones
           // whose bases differ from the motif (its bases are columns idx + 1 .. idx + mlen: in the window)
           uint32_t drop = 0;
@@ -705,21 +738,27 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
               }
             }
           }
+          const int nv = nv0 + (int)__builtin_popcountll(starts & below);
           uint32_t* vrec = nv < HMM_VIS_LDS ? l_vis + 3 * nv : g_vis + 3 * (size_t)nv;
           vrec[0] = (uint32_t)blk | (drop << 15); vrec[1] = (uint32_t)idx; vrec[2] = (uint32_t)vb1;
-          ++nv;
         }
-        vb1 = kind == 2 ? idx : vb1;  // bases of this visit are query[.. idx)
-        const uint32_t pw = (b & 2) ? pred4.y : pred4.x;
-        const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)((b & 1) ? pw >> 16 : pw & 0xFFFFu);
-        if (inf & 8u) { --idx; row -= Spad; }
-        nxt = state;
-        state = prv;
+        // sums over the round (butterfly inside the job's lanes)
+#pragma unroll
+        for (int o = HMM_REC / 2; o >= 1; o >>= 1) { edit += __shfl_xor(edit, o); ref += __shfl_xor(ref, o); }
+        const int src_last_end = ends ? 63 - (int)__builtin_clzll(ends) : hwlane;
+        const int idx_last_end = __shfl(idx, src_last_end);
+        const int last_state = __shfl(state, (hwlane & ~(HMM_REC - 1)) + max(n - 1, 0));
+        if (tid == 0) {
+          int np = np0 + n;
+          if (more == 2) { if (pbuf && np < pcap) pbuf[pcap - 1 - np] = 0; ++np; tb_done = 1; }
+          tb_npath = np; tb_nvisit = nv0 + (int)__builtin_popcountll(starts); tb_edit += edit; tb_ref += ref;
+          if (n > 0) tb_next = last_state;
+          if (ends) tb_vb1 = idx_last_end;
+        }
       }
-      if (state == 0) { if (pbuf && np < pcap) pbuf[pcap - 1 - np] = 0; ++np; tb_done = 1; }
-      tb_state = state; tb_idx = idx; tb_npath = np; tb_nvisit = nv; tb_edit = edit; tb_ref = ref; tb_next = nxt; tb_vb1 = vb1;
+      hmm_sync(sync_n);
+      if (more != 1) break;
     }
-    hmm_sync(sync_n);
   }
   const int np = tb_npath;
   HP_MARK(2);
@@ -842,6 +881,7 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   const size_t spad = (S + 15) & ~15u;
   if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
   o += HMM_CODE_WINDOW + HMM_CODE_PAD + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * (size_t)HMM_VIS_LDS + 4 * (size_t)nb;
+  o += 8 + 8 * 64;  // the steps of a trace-back round (l_rec)
   return o + 64;
 }
 
