@@ -463,7 +463,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   for (int i = tid; i < mot_bytes; i += nthr) l_mot[i] = g_motifs[i];
   for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
   const uint8_t* const motif_bytes = l_mot;
-  for (int i = tid; i < 4 * S; i += nthr) l_inst[4 * (i % S) + i / S] = g_inst[i];
+  // (bit 15 of a predecessor entry: that state emits a base -- the trace-back then knows it on arrival, without a look-up of its own)
+  for (int i = tid; i < 4 * S; i += nthr) { const uint16_t pr = g_inst[i]; l_inst[4 * (i % S) + i / S] = (uint16_t)(pr | ((pr < S ? (uint16_t)(model[set.off_flags + pr] & 1) : (uint16_t)0) << 15)); }
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
   for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
@@ -684,16 +685,18 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (tid == 0) {  // ---- the chase
         int state = tb_state, idx = tb_idx, n = 0;
         int row = (idx - c0) * Spad;  // offset of column idx in the staged chunk
+        int emits = (int)((l_info[state] >> 3) & 1u);
         while (state != 0 && idx >= c0 && n < HMM_REC) {
           l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
-          const uint32_t inf = l_info[state];
           const int b = l_stage[row + state];
           const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);  // (4-byte aligned: S may be odd)
           const uint2 pred4 = make_uint2(pin[0], pin[1]);  // all four predecessors: no second round trip behind b
           const uint32_t pw = (b & 2) ? pred4.y : pred4.x;
-          const int prv = (state == S - 2) ? (int)l_blocks[1 * nb + b] : (int)((b & 1) ? pw >> 16 : pw & 0xFFFFu);
-          if (inf & 8u) { --idx; row -= Spad; }
-          state = prv;
+          uint32_t pe = (b & 1) ? pw >> 16 : pw & 0xFFFFu;  // predecessor | its "emits" bit << 15
+          if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + b]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15); }  // the run end: from a block end
+          if (emits) { --idx; row -= Spad; }
+          emits = (int)(pe >> 15);
+          state = (int)(pe & 0x7FFFu);
         }
         tb_state = state; tb_idx = idx; tb_nrec = n;
         tb_more = state == 0 ? 2 : (idx >= c0 ? 1 : 0);
