@@ -607,16 +607,22 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     HP_FILL(2);
     if (act && n_in == 0xFF) {  // run end: block ends in block order; then the run start {start state, run end}
       const double start_now = cur[0];  // (the start state of this column, for the run start below: fetched with the block ends)
-      {
-        double e[BE_REG];
+      // (their indices sit in registers: one round trip for all of them; a model of one or two motifs -- two or three blocks, nearly every
+      //  locus of a genome-wide catalog -- fetches and compares only what it has: 8 fetches and compares per column were 200 of its 2 400 cycles)
+      auto block_ends = [&](auto n_const) {
+        constexpr int N = decltype(n_const)::value;
+        double e[N];
 #pragma unroll
-        for (int b = 0; b < BE_REG; ++b) e[b] = cur[be[b]];  // (their indices sit in registers: one round trip for all of them)
+        for (int b = 0; b < N; ++b) e[b] = cur[be[b]];
 #pragma unroll
-        for (int b = 0; b < BE_REG; ++b) {
+        for (int b = 0; b < N; ++b) {
           const double v = (e[b] + lp0);
           if (b < nb && v > best) { best = v; bpi = b; }
         }
-      }
+      };
+      if (nb <= 2) block_ends(std::integral_constant<int, 2>());
+      else if (nb <= 4) block_ends(std::integral_constant<int, 4>());
+      else block_ends(std::integral_constant<int, BE_REG>());
       for (int b = BE_REG; b < nb; ++b) {
         const double v = (cur[l_blocks[1 * nb + b]] + lp0);
         if (v > best) { best = v; bpi = b; }
