@@ -68,7 +68,10 @@ extern "C" {
 typedef struct trgt_hip_ctx trgt_hip_ctx;
 
 int trgt_hip_abi_version(void);
-/* device: HIP ordinal (>= 0).  There is no CPU device. */
+/* device: HIP ordinal (>= 0).  There is no CPU device.
+ * Process-wide side effect: the first context of a process calls mallopt() -- mmap threshold 32 MB, no heap trimming -- because every
+ * munmap (what free() of a large block ends in) delays the next GPU submission of the process by 10-30 ms on this stack (DESIGN.md
+ * section 5, INTEGRATION.md "Host allocator").  TRGT_MALLOC_TUNE=0 in the environment leaves malloc alone. */
 int trgt_hip_create(int device, trgt_hip_ctx** out);
 void trgt_hip_destroy(trgt_hip_ctx* ctx);
 const char* trgt_hip_last_error(const trgt_hip_ctx* ctx); /* ctx may be NULL: last create() error */
