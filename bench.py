@@ -136,11 +136,14 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large); 1 = the blocking call only")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large; 6 for config 5); 1 = the blocking call only")
     args = ap.parse_args()
     n_loci = args.loci or DEFAULT_LOCI[args.config]
     if args.contexts <= 0:
-        args.contexts = {3: 3}.get(args.config, 4)  # measured on MI355X: 1.1x / 1.7x / 1.4x / 1.4x for configs 2 / 3 / 4 / 5; value_single_context is printed next to it
+        # measured on MI355X (tools/contexts_sweep.sh): config 2 is flat from 4 contexts on (1.87 M loci/s with 4, 5, 6 and 8); config 5,
+        # whose calls wait on the host between their GPU stages, still gains (210 / 235 / 245 k with 4 / 6 / 8; 10 do not fit the HBM any more);
+        # configs 3 and 4 are limited by their workspaces (tens of GB per context).  value_single_context is printed next to value
+        args.contexts = {3: 3, 5: 6}.get(args.config, 4)
 
     import torch
     import torch.distributed as dist
