@@ -136,14 +136,21 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 3 for config 3, whose workspaces are large; 6 for config 5); 1 = the blocking call only")
+    ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per context in GB (trgt_hip_set_workspace_limit; 0 = by config: the library's 32 GB, 8 GB for config 3)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 6 for configs 3 and 5); 1 = the blocking call only")
     args = ap.parse_args()
     n_loci = args.loci or DEFAULT_LOCI[args.config]
     if args.contexts <= 0:
         # measured on MI355X (tools/contexts_sweep.sh): config 2 is flat from 4 contexts on (1.87 M loci/s with 4, 5, 6 and 8); config 5,
         # whose calls wait on the host between their GPU stages, still gains (210 / 235 / 245 k with 4 / 6 / 8; 10 do not fit the HBM any more);
-        # configs 3 and 4 are limited by their workspaces (tens of GB per context).  value_single_context is printed next to value
-        args.contexts = {3: 3, 5: 6}.get(args.config, 4)
+        # config 4 is limited by its workspaces (tens of GB per context), config 3 runs six contexts with a smaller workspace limit (below).
+        # value_single_context is printed next to value
+        args.contexts = {3: 6, 5: 6}.get(args.config, 4)
+    if args.ws_limit_gb <= 0 and args.config == 3:
+        # the generic alignment kernel sizes its HBM arena by this limit; since the long reads meet the pre-filter window by window it has
+        # little left to do, and six contexts of 12 GB do more than three of 32 (8.2 against 6.4 k loci/s; 16 GB the same, 8 GB 7.6 k)
+        args.ws_limit_gb = 12.0
+    ws_limit = int(args.ws_limit_gb * (1 << 30))
 
     import torch
     import torch.distributed as dist
@@ -213,6 +220,9 @@ def main():
     pool, kt_pool = None, None
     if args.contexts > 1:
         pool = _lib.Pool([local_rank] * args.contexts)
+        if ws_limit:
+            for pc in pool.contexts:
+                pc.check(_lib.lib().trgt_hip_set_workspace_limit(pc.handle, ws_limit))
         outs_w = [locus.BatchOutputs(batch) for _ in range(args.contexts)]
         many = lambda n: locus.run_many(pool, [batch] * n, params, outs_w, flank_dev=flank_dev, reads_dev=reads_dev, out_per_context=True)
         # set-up of every context (buffer pools, code objects, first touch of its workspaces): at least 3 batches per context and 0.6 s
@@ -413,7 +423,7 @@ def main():
             "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
-                       "host_threads_per_rank": host_threads, "contexts_per_gpu": args.contexts},
+                       "host_threads_per_rank": host_threads, "contexts_per_gpu": args.contexts, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",
