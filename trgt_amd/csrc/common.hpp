@@ -186,6 +186,7 @@ inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
   if (b.cap < bytes) {
     if (b.p) { TRGT_HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
+    if (c->knobs.debug && want > ((size_t)256 << 20)) fprintf(stderr, "[mem] slot %d: %.2f GB\n", slot, (double)want / (double)(1ull << 30));
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
       (void)hipGetLastError();

@@ -1330,6 +1330,18 @@ extern "C" int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, 
       if (rc) { for (auto* q : P->ctx) trgt_hip_destroy(q); return rc; }
       P->ctx.push_back(c);
     }
+    // contexts that share a device share its memory: the workspace limit of each (32 GB by default, what the alignment and HMM launches
+    // size their arenas by) is lowered to its share of 70 % of what is free now -- ten contexts on one GPU then plan 19 GB each instead
+    // of failing in the middle of a batch.  (trgt_hip_set_workspace_limit on trgt_hip_pool_context(i) overrides it.)
+    for (size_t i = 0; i < P->ctx.size(); ++i) {
+      int64_t same = 0;
+      for (auto* q : P->ctx) same += q->device == P->ctx[i]->device;
+      size_t free_b = 0, total_b = 0;
+      if (hipSetDevice(P->ctx[i]->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && same > 0) {
+        const uint64_t share = (uint64_t)((double)free_b * 0.7 / (double)same);
+        P->ctx[i]->ws_limit = std::max<uint64_t>(4ull << 30, std::min<uint64_t>(P->ctx[i]->ws_limit, share));
+      } else (void)hipGetLastError();
+    }
     *out = P.release();
     return TRGT_OK;
   } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
