@@ -247,6 +247,14 @@ __device__ __noinline__ bool bi_base(const KArgs& a, const BlockWs& ws, const ui
 }
 
 // ------------------------------------------------------------------ kernel
+#ifdef TRGT_WFA_PROF
+__device__ unsigned long long g_wfa_gprof[8];  // generic kernel, thread 0: claim + staging, breakpoint searches, base alignments, epilogue, jobs
+#define GP_DECL unsigned long long gp_t = clock64()
+#define GP_MARK(i) do { const unsigned long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_wfa_gprof[i], n_ - gp_t); gp_t = n_; } while (0)
+#else
+#define GP_DECL
+#define GP_MARK(i)
+#endif
 template <int METRIC>
 __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_seq[];
@@ -276,8 +284,10 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
   const uint32_t n_front = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
   const uint32_t n_jobs = n_front + (a.n_jobs2_dev ? *a.n_jobs2_dev : 0u);
   unsigned long long cells_acc = 0;
+  GP_DECL;
   for (uint32_t jb = 0; jb < a.jobs_per_block; ++jb) {
     __syncthreads();
+    GP_MARK(3);
     if (tid == 0) sh.job = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
     const uint32_t j = (uint32_t)sh.job;
@@ -295,6 +305,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     }
     if (tid == 0) { sh.status = TRGT_WF_COMPLETED; sh.score = INT32_MIN; sh.rle_n = 0; sh.sp = 0; sh.cells = 0; sh.top_bp = 0; }
     __syncthreads();
+    GP_MARK(0);
     if (!kp.biwfa) {
       // ---- unidirectional (wavefront_unialign): MemoryHigh / Med / Low
       if (tid == 0) {
@@ -343,9 +354,11 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
         __syncthreads();
         if (seg.tl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 2u, seg.pl); continue; }
         if (seg.pl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 1u, seg.tl); continue; }
-        if (seg.rem <= kp.bi_min_score) { bi_base<METRIC>(a, ws, P, Tx, seg, true); continue; }
+        GP_MARK(3);
+        if (seg.rem <= kp.bi_min_score) { bi_base<METRIC>(a, ws, P, Tx, seg, true); GP_MARK(2); continue; }
         const int st = bi_find_breakpoint<METRIC>(a, ws, P, Tx, seg);
-        if (st == ST_END_REACHED) { bi_base<METRIC>(a, ws, P, Tx, seg, true); continue; }
+        GP_MARK(1);
+        if (st == ST_END_REACHED) { bi_base<METRIC>(a, ws, P, Tx, seg, true); GP_MARK(2); continue; }
         if (st != ST_OK) { if (tid == 0) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE; continue; }
         if (tid == 0) {
           const Breakpoint bp = sh.bp;
@@ -361,6 +374,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
       }
     }
     __syncthreads();
+    GP_MARK(3);
     // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations
     const int ok = sh.status == TRGT_WF_COMPLETED;
     const int nrun = ok ? sh.rle_n : 0;
@@ -560,6 +574,15 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
 #ifdef TRGT_WFA_PROF
+  if (a.fast_wcap == 0) {
+    unsigned long long h[8], z[8] = {0};
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(wfa::g_wfa_gprof), sizeof h));
+    TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_gprof), z, sizeof h));
+    const double tot = (double)(h[0] + h[1] + h[2] + h[3]) + 1e-9;
+    fprintf(stderr, "[wfa gprof] jobs=%lld grid=%lld thr=%d | claim+stage %.1f%% breakpoint %.1f%% base %.1f%% other %.1f%% | Mcycles total %.1f\n",
+            (long long)L.n_jobs_host, (long long)grid_blocks, threads, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, tot / 1e6);
+  }
   if (a.fast_wcap > 0) {
     unsigned long long h[32], lv[32], z[32] = {0};
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
