@@ -391,7 +391,16 @@ static int issue_pending_uploads(trgt_hip_ctx* c) {
   for (auto& st : c->staged) {
     if (!st.in_use || !st.copy_pending) continue;
     st.copy_pending = false;
-    if (st.d_reads) TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_reads), st.in->read_blob, (size_t)st.read_bytes, hipMemcpyHostToDevice, c->stream_copy));
+    if (st.d_reads) {
+      // in pieces: one copy command of hundreds of MB holds the engine until it is through, and the small copies of the other contexts
+      // of a pool queue behind it (TRGT_UPLOAD_CHUNK_MB, default 32; 0 = one command)
+      static const size_t piece = [] { const char* e = getenv("TRGT_UPLOAD_CHUNK_MB"); const long v = e && *e ? atol(e) : 32; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
+      const size_t total = (size_t)st.read_bytes;
+      for (size_t o = 0; o < total; o += piece ? piece : total) {
+        const size_t n = piece ? std::min(piece, total - o) : total;
+        TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_reads) + o, st.in->read_blob + o, n, hipMemcpyHostToDevice, c->stream_copy));
+      }
+    }
     if (st.d_flank) TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_flank), st.in->flank_blob, (size_t)st.flank_bytes, hipMemcpyHostToDevice, c->stream_copy));
     TRGT_HIP_TRY(c, hipEventRecord(st.ready, c->stream_copy));
   }
