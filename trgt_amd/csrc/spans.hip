@@ -250,13 +250,26 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
         for (int b = 0; b < 24 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
       }
       uint32_t m[2] = {0, 0};  // bit s: candidate start off + s matches the head of piece 0 / 1
+      // (eight head bytes as one 64-bit compare per position and piece; the positions beyond the last candidate start are masked once
+      //  per round, not tested per position: this kernel is bound by instruction issue)
+      const uint64_t h64[2] = {(uint64_t)head[0] | ((uint64_t)head2[0] << 32), (uint64_t)head[1] | ((uint64_t)head2[1] << 32)};
 #pragma unroll
       for (int s16 = 0; s16 < 16; ++s16) {
         const uint32_t win = (s16 & 3) == 0 ? w[s16 >> 2] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 1], w[s16 >> 2], s16 & 3);
-        const uint32_t win2 = (s16 & 3) == 0 ? w[(s16 >> 2) + 1] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 2], w[(s16 >> 2) + 1], s16 & 3);
-        const bool valid = off + s16 <= last;
-        m[0] |= (uint32_t)(valid && win == head[0] && (!h8 || win2 == head2[0])) << s16;
-        m[1] |= (uint32_t)(valid && win == head[1] && (!h8 || win2 == head2[1])) << s16;
+        if (h8) {
+          const uint32_t win2 = (s16 & 3) == 0 ? w[(s16 >> 2) + 1] : __builtin_amdgcn_alignbyte(w[(s16 >> 2) + 2], w[(s16 >> 2) + 1], s16 & 3);
+          const uint64_t w64 = (uint64_t)win | ((uint64_t)win2 << 32);
+          m[0] |= (uint32_t)(w64 == h64[0]) << s16;
+          m[1] |= (uint32_t)(w64 == h64[1]) << s16;
+        } else {
+          m[0] |= (uint32_t)(win == head[0]) << s16;
+          m[1] |= (uint32_t)(win == head[1]) << s16;
+        }
+      }
+      {
+        const int room = last - off;  // candidate starts off .. off + room are inside the read
+        const uint32_t vmask = room >= 15 ? 0xFFFFu : room < 0 ? 0u : (1u << (room + 1)) - 1u;
+        m[0] &= vmask; m[1] &= vmask;
       }
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
