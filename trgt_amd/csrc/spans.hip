@@ -246,7 +246,10 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
         uint4 q; uint2 q2;
         __builtin_memcpy(&q, read + off, 16); __builtin_memcpy(&q2, read + off + 16, 8);
         w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; w[4] = q2.x; w[5] = q2.y;
-      } else if (off < n) {
+      } else if (off <= last) {
+        // (a lane whose 24 bytes cross the end of the read AND that still holds a candidate start: only with pieces shorter than 24
+        //  bases.  With TRGT's 250 the lanes at the end of a read start beyond the last candidate, their bytes are never looked at --
+        //  and this byte loop, which the whole wave walks when one lane enters it, was a third of the kernel's instructions)
         for (int b = 0; b < 24 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
       }
       uint32_t m[2] = {0, 0};  // bit s: candidate start off + s matches the head of piece 0 / 1
