@@ -128,7 +128,22 @@ __device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, i
       __builtin_memcpy(&v, read + off, 16); __builtin_memcpy(&v2, read + off + 16, 8); __builtin_memcpy(&v3, read + off + 24, 4);
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; w[4] = v2.x; w[5] = v2.y; w[6] = v3;
     } else if (off < n) {
-      for (int b = 0; b < 28 && off + b < n; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
+      // the lane that crosses the end of the read (the whole wave walks this branch with it): whole dwords while they fit, then the last
+      // one to three bytes out of the dword that ENDS with the read -- seven independent loads and a shift (byte by byte it was 28
+      // dependent iterations, a fifth of the kernel's instructions)
+      const int rem = n - off, full = rem >> 2, tail = rem & 3;
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (k < full) w[k] = load_u32(read + off + 4 * k);
+      if (tail && full < 7) {
+        const uint32_t t = n >= 4 ? load_u32(read + n - 4) >> (8 * (4 - tail)) : 0u;  // bytes n - tail .. n - 1, zero above
+        if (n >= 4) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) if (k == full) w[k] = t;
+        } else {
+          for (int b = 4 * full; b < rem; ++b) w[b >> 2] |= (uint32_t)read[off + b] << (8 * (b & 3));
+        }
+      }
     }
     uint64_t win[16]; uint32_t win3[16];  // the twelve bytes at candidate start off + s16
 #pragma unroll
