@@ -546,7 +546,14 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
     for (int i0 = 4 * t; i0 <= len; i0 += 4 * nt) {
       uint32_t d0 = 0, d1 = 0;
       if (i0 + 8 <= len) { __builtin_memcpy(&d0, src + i0, 4); __builtin_memcpy(&d1, src + i0 + 4, 4); }
-      else
+      else if (len >= 4) {
+        // the last positions (the whole wave walks this branch with the one or two threads that take it): a whole dword if it fits, then
+        // the one to three bytes left out of the dword that ENDS with the sequence -- two loads and a shift, not eight byte loads
+        const int rem = len - i0, tail = rem & 3;
+        uint32_t t = 0;
+        if (tail) { __builtin_memcpy(&t, src + len - 4, 4); t >>= 8 * (4 - tail); }  // bytes len - tail .. len - 1, zero above
+        if (rem >= 4) { __builtin_memcpy(&d0, src + i0, 4); d1 = t; } else d0 = t;
+      } else
         for (int b = 0; b < 8; ++b)
           if (i0 + b < len) { if (b < 4) d0 |= (uint32_t)src[i0 + b] << (8 * b); else d1 |= (uint32_t)src[i0 + b] << (8 * (b - 4)); }
       W[i0] = d0; W[i0 + 1] = __builtin_amdgcn_alignbyte(d1, d0, 1); W[i0 + 2] = __builtin_amdgcn_alignbyte(d1, d0, 2);
