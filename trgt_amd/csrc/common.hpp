@@ -46,6 +46,7 @@ struct trgt_hip_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int stream_priority = 0;  // of every stream the context creates (0: the default)
+  bool in_pool = false;     // created by trgt_hip_pool_create
   std::string err;
   uint64_t ws_limit = 32ull << 30;
   int num_cus = 256;
@@ -351,7 +352,9 @@ struct KTimer {
 };
 // streams of a context (ctx.hip)
 hipError_t make_stream(trgt_hip_ctx* c, hipStream_t* s);
+hipError_t make_side_stream(trgt_hip_ctx* c, hipStream_t* s);
 void ctx_next_stream_priority(int p);
+void ctx_next_in_pool(bool on);
 
 inline void resolve_timing(trgt_hip_ctx* c) {
   for (auto& p : c->pending) {

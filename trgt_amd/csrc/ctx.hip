@@ -31,9 +31,26 @@ namespace trgt {
 // share fewer queues, and when their kernels meet on the GPU the more urgent one finishes first instead of all of them finishing
 // together (config 2: 1.74 -> 1.82 M loci/s with four contexts, config 4: 0.88 -> 0.92 M).
 static thread_local int g_next_stream_priority = 0;
+static thread_local bool g_next_in_pool = false;
 void ctx_next_stream_priority(int p) { g_next_stream_priority = p; }
+void ctx_next_in_pool(bool on) { g_next_in_pool = on; }
 hipError_t make_stream(trgt_hip_ctx* c, hipStream_t* s) {
   return c->stream_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, c->stream_priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+// The side streams of the HMM launches take a priority of their own: the runtime maps the streams of a process onto a few hardware
+// queues PER PRIORITY, round robin in creation order, and streams on one queue run one after the other.  With one priority for all
+// nine streams of a context a side stream lands on the queue of the main stream -- and the two longest HMM launches of a config-3
+// call, made to run next to each other, ran one behind the other (44 ms per call in a fresh context, 30 ms in one whose streams
+// happened to fall differently).
+hipError_t make_side_stream(trgt_hip_ctx* c, hipStream_t* s) {
+  // (the contexts of a pool already sit on different priorities, context by context, and measured better with all streams of a context
+  //  on its own: 8.3 against 7.1 k loci/s on config 3, 1.11 against 1.05 M on config 4)
+  if (c->in_pool) return make_stream(c, s);
+  int lo = 0, hi = 0;  // (lo = least urgent, numerically larger)
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo <= hi) { (void)hipGetLastError(); return make_stream(c, s); }
+  const int base = c->stream_priority;  // 0 = default
+  const int side = base != hi ? hi : hi + 1;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, side);
 }
 }  // namespace trgt
 
@@ -80,6 +97,7 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
   c->stream_priority = trgt::g_next_stream_priority;
+  c->in_pool = trgt::g_next_in_pool;
   e = trgt::make_stream(c, &c->stream);
   if (e != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return TRGT_ERR_HIP; }
   c->own_stream = true;

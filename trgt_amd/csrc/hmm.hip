@@ -1249,7 +1249,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     hipStream_t ls = c->stream;
     if (n_class > 0) {
       const int sidx = (n_class - 1) % 3 + (buffer_set ? 3 : 0);
-      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_side_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
       ls = c->hmm_side[sidx];
       TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork[buffer_set ? 1 : 0], 0));
@@ -1401,7 +1401,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     hipStream_t ls = c->stream;
     if (n_class > 0) {
       const int sidx = (n_class - 1) % 3 + (buffer_set ? 3 : 0);
-      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->hmm_side[sidx]));
+      if (!c->hmm_side[sidx]) TRGT_HIP_TRY(c, trgt::make_side_stream(c, &c->hmm_side[sidx]));
       if (!c->hmm_join[sidx]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_join[sidx], hipEventDisableTiming));
       ls = c->hmm_side[sidx];
       TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_fork[buffer_set ? 1 : 0], 0));

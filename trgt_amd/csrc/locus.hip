@@ -1334,8 +1334,9 @@ extern "C" int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, 
         if (hipSetDevice(devices[i]) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi) trgt::ctx_next_stream_priority(hi + (int)(i % (lo - hi + 1)));
         else (void)hipGetLastError();
       }
+      trgt::ctx_next_in_pool(n_contexts > 1);
       const int rc = trgt_hip_create(devices[i], &c);
-      trgt::ctx_next_stream_priority(0);
+      trgt::ctx_next_stream_priority(0); trgt::ctx_next_in_pool(false);
       if (rc) { for (auto* q : P->ctx) trgt_hip_destroy(q); return rc; }
       P->ctx.push_back(c);
     }
