@@ -160,11 +160,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the TRGT hot path")
+    # (TRGT_BENCH_ONE_GPU=1: every rank on GPU 0 with the gloo backend -- the N > 1 code path on a one-GPU box, for testing only)
+    one_gpu_test = os.environ.get("TRGT_BENCH_ONE_GPU") == "1"
+    if one_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from trgt_amd import _lib, locus, shard
 
