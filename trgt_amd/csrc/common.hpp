@@ -35,6 +35,7 @@ struct trgt_knobs {
   bool stage_lock = false;      // TRGT_STAGE_LOCK: only one context per device in its flank-location stage at a time
   bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
+  bool filter_one_launch = false;  // TRGT_FILTER_ONE_LAUNCH: the pre-filter in one launch whatever the text lengths
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong

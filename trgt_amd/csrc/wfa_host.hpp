@@ -51,6 +51,7 @@ struct FilterArgs {  // by-value kernel argument
   int32_t early_reject;                     // stop an alignment as soon as no cell of its wavefronts can reach min_matches any more
   JobDev* keep_jobs; uint32_t* keep_count;  // kept alignments, appended (NULL: none wanted)
   int32_t* score; int32_t* bound; uint8_t* keep;  // optional, indexed by JobDev::out_index
+  int32_t diag_lo, diag_hi;                 // this launch takes the jobs with diag_lo < plen + tlen + 1 <= diag_hi (the others belong to another launch over the same list)
   unsigned long long* cells_out;
 };
 struct FilterLaunch {

@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(
     if (j >= n_jobs) break;
     const JobDev job = a.jobs[j];
     const int plen = rfl_i((int)job.pat_len), tlen = rfl_i((int)job.txt_len);
+    if (plen + tlen + 1 <= a.diag_lo || plen + tlen + 1 > a.diag_hi) continue;  // another launch's job
     int keep = 0, score_out = INT32_MIN, bound_out = -1;
     const bool fits = plen >= 1 && plen <= 254 && tlen >= plen && tlen + plen + 1 <= D;
     uint32_t dirty = 0;
@@ -496,9 +497,15 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
+  a.diag_lo = INT32_MIN; a.diag_hi = INT32_MAX;
   // instantiation by the number of diagonals the longest text of the launch needs (jobs that do not fit are kept unseen)
   const int64_t diag = L.max_plen + L.max_tlen + 1;
-  void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
+  // (nine strips of 128 diagonals for texts that need up to 1152: 8 % faster there than the five strips of 256, which carry 128 dead ones)
+  void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 9 * 128 ? wfa_filter_kernel<9, 1> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
+  if (const char* force = getenv("TRGT_FILTER_FORCE")) {  // developer probe (tools/filter_inst_probe.py): one instantiation for the whole launch
+    const int f = atoi(force);
+    fn = f == 71 ? wfa_filter_kernel<7, 1> : f == 91 ? wfa_filter_kernel<9, 1> : f == 42 ? wfa_filter_kernel<4, 2> : f == 52 ? wfa_filter_kernel<5, 2> : fn;
+  }
   // One-wave workgroups: resident waves per CU from the kernel's own register and LDS footprint (the occupancy query answers
   // per SIMD for 64-thread blocks; measured: it said 3 where 12 waves fit a CU)
   int occ = 8;
@@ -515,7 +522,20 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * occ, L.n_jobs_host));
   if (c->knobs.debug) fprintf(stderr, "[filter] diagonals %lld occupancy %d grid %lld\n", (long long)diag, occ, (long long)grid);
   KTimer t(c, L.timer_slot);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
+  // Two launches over the same list when the longest text needs more than four strips: most texts are shorter than the longest (on
+  // the 10k-locus batch 80 % of the expensive alignments fit 1024 diagonals, the rest needs up to 1280), and a job in the four-strip
+  // instantiation runs a fifth fewer instructions per level than in the five-strip one.  (Skipping the dead strips inside one kernel
+  // was slower: DESIGN.md 5.)  The long ones first; each launch claims the whole list with a counter of its own and passes over the
+  // other's jobs.
+  const bool split = diag > 4 * 256 && L.n_jobs_host >= 1024 && !c->knobs.filter_one_launch && !getenv("TRGT_FILTER_FORCE");
+  if (split) {
+    FilterArgs b = a;
+    b.diag_lo = 4 * 256;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, b);
+    FilterArgs s4 = a;
+    s4.diag_hi = 4 * 256; s4.counter = a.counter + 1;
+    hipLaunchKernelGGL((wfa_filter_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, c->stream, s4);
+  } else hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
   if (!L.set) c->last_filter_cells_dev = d_cells;
