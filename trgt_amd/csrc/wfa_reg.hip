@@ -508,19 +508,20 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   }
   // One-wave workgroups: resident waves per CU from the kernel's own register and LDS footprint (the occupancy query answers
   // per SIMD for 64-thread blocks; measured: it said 3 where 12 waves fit a CU)
-  int occ = 8;
-  {
+  auto grid_for = [&](void (*f)(const FilterArgs)) -> int64_t {
+    int occ = 8;
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void*)fn) == hipSuccess) {
+    if (hipFuncGetAttributes(&fa, (const void*)f) == hipSuccess) {
       const int alloc = std::max(8, (fa.numRegs + 7) / 8 * 8);
       const int per_simd = std::max(1, std::min(8, 512 / alloc));
       const int by_lds = fa.sharedSizeBytes > 0 ? (int)((160u * 1024u) / (unsigned)fa.sharedSizeBytes) : 32;
       occ = std::max(1, std::min(std::min(4 * per_simd, by_lds), 32));
     } else (void)hipGetLastError();
-  }
-  if (c->knobs.filter_per_cu > 0) occ = c->knobs.filter_per_cu;
-  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * occ, L.n_jobs_host));
-  if (c->knobs.debug) fprintf(stderr, "[filter] diagonals %lld occupancy %d grid %lld\n", (long long)diag, occ, (long long)grid);
+    if (c->knobs.filter_per_cu > 0) occ = c->knobs.filter_per_cu;
+    if (c->knobs.debug) fprintf(stderr, "[filter] diagonals %lld occupancy %d\n", (long long)diag, occ);
+    return std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * occ, L.n_jobs_host));
+  };
+  const int64_t grid = grid_for(fn);
   KTimer t(c, L.timer_slot);
   // Two launches over the same list when the longest text needs more than four strips: most texts are shorter than the longest (on
   // the 10k-locus batch 80 % of the expensive alignments fit 1024 diagonals, the rest needs up to 1280), and a job in the four-strip
@@ -529,12 +530,14 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   // other's jobs.
   const bool split = diag > 4 * 256 && L.n_jobs_host >= 1024 && !c->knobs.filter_one_launch && !getenv("TRGT_FILTER_FORCE");
   if (split) {
+    // (a ladder of four instantiations -- 1536 / 1280 / 1152 / 1024 diagonals -- was no better than these two on the catalog mix:
+    //  every launch has a tail)
     FilterArgs b = a;
     b.diag_lo = 4 * 256;
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, b);
     FilterArgs s4 = a;
     s4.diag_hi = 4 * 256; s4.counter = a.counter + 1;
-    hipLaunchKernelGGL((wfa_filter_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, c->stream, s4);
+    hipLaunchKernelGGL((wfa_filter_kernel<4, 2>), dim3((unsigned)grid_for(wfa_filter_kernel<4, 2>)), dim3(64), 0, c->stream, s4);
   } else hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
