@@ -145,26 +145,32 @@ __device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, i
         }
       }
     }
-    uint64_t win[16]; uint32_t win3[16];  // the twelve bytes at candidate start off + s16
+    // The first FOUR bytes at every candidate start decide whether a segment is looked at more closely in this round (a 32-bit
+    // compare per position and segment; the other eight bytes are formed only then).  This kernel is bound by instruction issue:
+    // twelve bytes at every position and 64-bit compares were 48 byte-aligns and 128 double-width compares per round.
+    uint32_t lo[16];
 #pragma unroll
     for (int s16 = 0; s16 < 16; ++s16) {
       const int d = s16 >> 2, sh = s16 & 3;
-      const uint32_t lo = sh == 0 ? w[d] : __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
-      const uint32_t hi = sh == 0 ? w[d + 1] : __builtin_amdgcn_alignbyte(w[d + 2], w[d + 1], sh);
-      win3[s16] = sh == 0 ? w[d + 2] : __builtin_amdgcn_alignbyte(w[d + 3], w[d + 2], sh);
-      win[s16] = (uint64_t)hi << 32 | lo;
+      lo[s16] = sh == 0 ? w[d] : __builtin_amdgcn_alignbyte(w[d + 1], w[d], sh);
     }
 #pragma unroll
     for (int i = 0; i < WIN_SEGMENTS; ++i) {
+      const uint32_t h_lo = (uint32_t)h[i], h_hi = (uint32_t)(h[i] >> 32);
       bool any = false;
 #pragma unroll
-      for (int s16 = 0; s16 < 16; ++s16) any |= win[s16] == h[i];
-      if (__ballot(any) == 0ull) continue;  // (uniform; taken but for the round that holds an occurrence of this segment)
+      for (int s16 = 0; s16 < 16; ++s16) any |= lo[s16] == h_lo;
+      if (__ballot(any) == 0ull) continue;  // (uniform; taken but for the round that holds an occurrence of this segment, or four of its bases by chance)
 #pragma unroll
       for (int s16 = 0; s16 < 16; ++s16) {
-        if (win[s16] == h[i] && win3[s16] == h3[i] && off + s16 <= last) {
-          const int k = off + s16 - i * q;
-          kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+        if (lo[s16] == h_lo) {
+          const int d = s16 >> 2, sh = s16 & 3;
+          const uint32_t hi = sh == 0 ? w[d + 1] : __builtin_amdgcn_alignbyte(w[d + 2], w[d + 1], sh);
+          const uint32_t w3 = sh == 0 ? w[d + 2] : __builtin_amdgcn_alignbyte(w[d + 3], w[d + 2], sh);
+          if (hi == h_hi && w3 == h3[i] && off + s16 <= last) {
+            const int k = off + s16 - i * q;
+            kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax;
+          }
         }
       }
     }
