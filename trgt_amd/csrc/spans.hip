@@ -308,8 +308,7 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
           const int p = base + 16 * lq + sq;
           bool ok = true;  // lane i verifies dwords i, i + 64, ... and the last lane the tail bytes
           for (int i = lane; i < nd; i += 64) ok = ok && load_u32(read + p + 4 * i) == load_u32(piece[side] + 4 * i);
-          if (lane == 63)
-            for (int i = nd * 4; i < F; ++i) ok = ok && read[p + i] == piece[side][i];
+          if (lane == 63 && (F & 3)) ok = ok && load_u32(read + p + F - 4) == load_u32(piece[side] + F - 4);  // the last one to three bytes: the dword that ends the piece (F >= 4)
           if (__ballot(!ok) == 0ull) { found[side] = p; break; }
           if (lane == lq) mm &= mm - 1u;  // drop this candidate
         }
