@@ -115,7 +115,7 @@ __device__ __forceinline__ uint32_t dirty_dword(uint32_t x) {
 // lane, so "the last in-bounds cell" is a few ballots over ONE strip, the out-of-bounds test of M is needed only in the strips
 // that reach above tlen - plen, and strips outside the level's limits are skipped.
 template <int NS, int B>
-__global__ void __launch_bounds__(64, (NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
+__global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
   constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA, LW = 2 * B;
   __shared__ uint32_t lds[PWN + TWN];
   uint32_t* const Pw = lds;
