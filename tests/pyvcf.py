@@ -5,7 +5,7 @@ src/trgt/writers/write_vcf.rs:95-397.  The record is rendered as `bcftools view 
 is how the reference documents its expected output (docs/tutorial.md:43-46).  AM (methylation) is "." per allele: methylation tags
 are not carried through this path.
 """
-from .hmm import encode_ap, encode_mc, encode_ms
+from trgt_amd.hmm import encode_ap, encode_mc, encode_ms
 
 
 def set_gt(locus_tr: bytes, genotype):
@@ -26,7 +26,7 @@ def set_gt(locus_tr: bytes, genotype):
 
 
 def vcf_record(locus, result, sample_meth=None):
-    """locus: trgt_amd.reads.Locus; result: trgt_amd.locus.LocusResult.  Returns the record as one tab-separated line."""
+    """locus: pyreads.Locus; result: trgt_amd.locus.LocusResult.  Returns the record as one tab-separated line."""
     pad = locus.left_flank[-1:]
     info = "TRID=%s;END=%d;MOTIFS=%s;STRUC=%s" % (locus.id, locus.end, ",".join(locus.motifs), locus.struc)
     fmt = "GT:AL:ALLR:SD:MC:MS:AP:AM"

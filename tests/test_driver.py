@@ -51,3 +51,32 @@ def test_split_batch_chunks_cover_the_batch(oracle):
     for c in chunks:
         parts += oracle.locus_records(c, 0, c["n_loci"], 2)
     assert parts == whole
+
+
+def test_split_batch_keeps_read_metadata_and_encoding():
+    """chunks must carry hp_tag / start_offset / end_offset / mismatch offsets (rebased) and read_encoding."""
+    from trgt_amd.driver import split_batch
+    from trgt_amd import locus
+    rng = np.random.default_rng(3)
+    loci = []
+    for l in range(7):
+        n = 3 + l
+        loci.append(dict(left_flank=b"A" * 250, right_flank=b"C" * 250, tr=b"CAGCAG", motifs=[b"CAG"], ploidy=2,
+                         reads=[b"ACGT" * (5 + i) for i in range(n)], hp_tag=[None, 1, 2][l % 3:] + [1] * (n - 3 + l % 3),
+                         start_offset=[-10 * i for i in range(n)], end_offset=[7 * i for i in range(n)],
+                         mismatch_offsets=[sorted(int(v) for v in rng.integers(-50, 50, size=i % 4)) for i in range(n)]))
+    b = locus.pack(loci)
+    b["read_encoding"] = 1  # (only the propagation is checked here: no library call)
+    chunks = split_batch(b, 3)
+    assert [c["n_loci"] for c in chunks] == [3, 3, 1]
+    r = 0
+    for c in chunks:
+        assert c["read_encoding"] == 1
+        for i in range(c["n_reads"]):
+            assert c["hp_tag"][i] == b["hp_tag"][r] and c["start_offset"][i] == b["start_offset"][r] and c["end_offset"][i] == b["end_offset"][r]
+            got = c["mismatch_offsets"][int(c["mismatch_off"][i]):int(c["mismatch_off"][i + 1])]
+            want = b["mismatch_offsets"][int(b["mismatch_off"][r]):int(b["mismatch_off"][r + 1])]
+            assert list(got) == list(want)
+            r += 1
+        assert int(c["mismatch_off"][0]) == 0 and len(c["mismatch_offsets"]) == int(c["mismatch_off"][-1]) + 1
+    assert r == b["n_reads"]

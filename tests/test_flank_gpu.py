@@ -114,3 +114,32 @@ def test_random_loci_with_read_metadata(oracle):
                                   snv=bool(rng.integers(0, 2)), err=float(rng.choice([0.002, 0.01, 0.03])),
                                   genotyper="cluster" if rng.random() < 0.2 else "size"))
     _check(oracle, loci)
+
+
+def test_split_and_submitted_batches_keep_the_flank_genotype(oracle):
+    """split_batch chunks and trgt_locus_batch_submit / _wait must apply genotype_flank like the blocking call on the whole
+    batch (the per-read fields travel with the chunk / the ticket); chunks of a 4-bit batch keep their encoding."""
+    from trgt_amd import locus
+    from trgt_amd.driver import split_batch
+    rng = np.random.default_rng(8)
+    loci = [_phased_locus(rng, b"CAG", 20, 22, hp_frac=1.0), _phased_locus(rng, b"CAG", 20, 22, hp_frac=0.0, snv=True),
+            _phased_locus(rng, b"GGC", 10, 12, hp_frac=0.9), _phased_locus(rng, b"AT", 25, 27, hp_frac=0.0, snv=True),
+            _phased_locus(rng, b"CCG", 18, 19, hp_frac=0.8, snv=True, err=0.03)]
+    b = locus.pack(loci)
+    whole = locus.run_batch(b)
+    recs = lambda bb, out: [(locus.locus_result(bb, out, l).genotype, locus.locus_result(bb, out, l).classification) for l in range(int(bb["n_loci"]))]
+    want = recs(b, whole)
+    plain = dict(b)
+    for k in ("hp_tag", "start_offset", "end_offset", "mismatch_offsets", "mismatch_off", "_cin"):
+        plain.pop(k, None)
+    assert recs(plain, locus.run_batch(plain)) != want  # the metadata does change these genotypes
+    got = []
+    for c in split_batch(b, 2):
+        got += recs(c, locus.run_batch(c))
+    assert got == want
+    assert recs(b, locus.submit_batch(b).wait()) == want
+    pk = locus.pack_bam4(b)
+    got4 = []
+    for c in split_batch(pk, 2):
+        got4 += recs(c, locus.run_batch(c))
+    assert got4 == want

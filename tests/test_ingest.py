@@ -1,5 +1,5 @@
 """Native read ingestion (trgt_amd/csrc/ingest.hip: BGZF / BAI / FAI, extract_reads, HiFiRead::from_hts_rec, extract_snps_offset,
-clip_to_region) against (a) the Python mirror trgt_amd/reads.py on the reference's example data set and (b) independent restatements
+clip_to_region) against (a) the Python mirror tests/pyreads.py on the reference's example data set and (b) independent restatements
 of the per-read rules on synthetic BAM files written by tests/bamtools.py.  No GPU involved."""
 import os
 
@@ -18,7 +18,8 @@ def _reads_of(b, l):
 
 
 def test_example_data_set_matches_the_python_mirror():
-    from trgt_amd import ingest, reads
+    from trgt_amd import ingest
+    import pyreads as reads
     b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
     genome = reads.read_fasta(os.path.join(EX, "reference.fasta"))
     loci = reads.read_catalog(os.path.join(EX, "repeat.bed"), genome)
@@ -123,7 +124,8 @@ def _expected_meth(rec):
 
 
 def test_synthetic_bam_records(tmp_path):
-    from trgt_amd import ingest, reads
+    from trgt_amd import ingest
+    import pyreads as reads
     bam, fa, bed, recs, genome = _synthetic(tmp_path)
     b = ingest.Reader(bam, fa).batch(bed, threads=2)
     assert b["n_loci"] == 2 and b["id"] == ["L1", "L2"] and list(b["set_motif_begin"]) == [0, 2, 3]

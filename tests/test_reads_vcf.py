@@ -1,5 +1,5 @@
 """Host-side steps either side of the GPU path: catalog + reference + BAM -> clipped reads
-(trgt_amd/reads.py, mirror of tr.rs:186-196, 262-361 and clip_region.rs) and LocusResult -> VCF record (trgt_amd/vcf.py, mirror of
+(tests/pyreads.py, mirror of tr.rs:186-196, 262-361 and clip_region.rs) and LocusResult -> VCF record (tests/pyvcf.py, mirror of
 write_vcf.rs:95-397).  Inputs are the reference's own example data set (tests/golden/example/ = example/{reference.fasta,
 repeat.bed, sample.bam}); the expected record is the one the reference documents for it (docs/tutorial.md:43-46)."""
 import json
@@ -17,7 +17,7 @@ TUTORIAL_RECORD = "\t".join([
 
 
 def _example():
-    from trgt_amd import reads
+    import pyreads as reads
     genome = reads.read_fasta(os.path.join(EX, "reference.fasta"))
     loci = reads.read_catalog(os.path.join(EX, "repeat.bed"), genome)
     records = reads.read_bam(os.path.join(EX, "sample.bam"))
@@ -35,7 +35,7 @@ def test_bam_ingestion_reproduces_the_committed_fixture():
 
 
 def test_clip_cigar_cases():
-    from trgt_amd.reads import clip_cigar
+    from pyreads import clip_cigar
     M, I, D, S = 0, 1, 2, 4
     # read [100, 160) on the reference, 5 soft-clipped bases in front
     ops = [(S, 5), (M, 20), (I, 3), (M, 10), (D, 4), (M, 26)]
@@ -46,7 +46,8 @@ def test_clip_cigar_cases():
 
 
 def test_set_gt_and_record_shapes():
-    from trgt_amd import reads, vcf
+    import pyreads as reads
+    import pyvcf as vcf
     from trgt_amd.hmm import Annotation, Span
     from trgt_amd.locus import Allele, LocusResult
     loc = reads.Locus("X", "chr1", 101, 110, b"ACGTT", b"CAGCAGCAG", b"GGGGG", ["CAG"], "(CAG)n")
@@ -71,7 +72,7 @@ def test_set_gt_and_record_shapes():
 
 
 def test_oracle_result_renders_as_the_tutorial_record(oracle):
-    from trgt_amd import vcf
+    import pyvcf as vcf
     from trgt_amd.hmm import Annotation, Span
     from trgt_amd.locus import Allele, LocusResult
     reads, loci, records = _example()
@@ -91,7 +92,8 @@ def test_oracle_result_renders_as_the_tutorial_record(oracle):
 @pytest.mark.gpu
 def test_example_bam_to_vcf_record_on_the_gpu():
     # BASELINE.json configs[0] end to end: example/ catalog + reference + BAM -> clipped reads -> trgt_locus_batch -> VCF record
-    from trgt_amd import locus, vcf
+    from trgt_amd import locus
+    import pyvcf as vcf
     reads, loci, records = _example()
     res = locus.analyze_batch([reads.locus_inputs(l, records) for l in loci])
     assert [vcf.vcf_record(l, r) for l, r in zip(loci, res)] == [TUTORIAL_RECORD]
@@ -105,7 +107,8 @@ def test_example_bam_to_vcf_record_on_the_gpu():
 def test_example_bam_through_the_native_ingestion_on_the_gpu():
     # the same end-to-end case with the native reader (trgt_amd/csrc/ingest.hip) in front: BAM + .bai, FASTA + .fai, catalog ->
     # trgt_ingest_batch arrays -> trgt_locus_batch -> VCF record of the tutorial
-    from trgt_amd import ingest, locus, vcf
+    from trgt_amd import ingest, locus
+    import pyvcf as vcf
     reads, loci, _ = _example()
     b = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta")).batch(os.path.join(EX, "repeat.bed"))
     out = locus.run_batch(b)
@@ -132,7 +135,7 @@ def test_native_writers_on_the_example(tmp_path):
     # catalog + reference + BAM -> native ingestion -> trgt_locus_batch -> native VCF and spanning-reads BAM (write_vcf.rs, write_bam.rs)
     import gzip
     from trgt_amd import ingest, locus, writers
-    from trgt_amd import reads as pyreads
+    import pyreads
     rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
     b = rd.batch(os.path.join(EX, "repeat.bed"), keep_native=True)
     out = locus.run_batch(b)

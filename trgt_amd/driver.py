@@ -99,5 +99,17 @@ def split_batch(batch, chunk_loci):
             c["genotyper"] = np.ascontiguousarray(batch["genotyper"][a:b])
         if batch.get("read_qual") is not None and len(batch["read_qual"]):
             c["read_qual"] = np.ascontiguousarray(batch["read_qual"][r0:r1])
+        # the per-read fields genotype_flank reads (tr.rs:69-75): without them a chunk would skip the flank re-genotyping
+        for k in ("hp_tag", "start_offset", "end_offset"):
+            if batch.get(k) is not None:
+                c[k] = np.ascontiguousarray(batch[k][r0:r1])
+        if batch.get("mismatch_off") is not None and batch.get("mismatch_offsets") is not None:
+            mo = batch["mismatch_off"]
+            m0o, m1o = int(mo[r0]), int(mo[r1])
+            c["mismatch_off"] = np.ascontiguousarray(mo[r0:r1 + 1] - np.uint64(m0o))
+            c["mismatch_offsets"] = np.ascontiguousarray(np.concatenate([batch["mismatch_offsets"][m0o:m1o], np.zeros(1, np.int32)]).astype(np.int32))
+        # (4-bit reads: the chunk's read_off still points into the parent's PACKED blob)
+        if batch.get("read_encoding"):
+            c["read_encoding"] = int(batch["read_encoding"])
         out.append(c)
     return out

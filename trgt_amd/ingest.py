@@ -1,6 +1,6 @@
 """Native read ingestion (trgt_amd/csrc/ingest.hip through the C ABI): repeat catalog + indexed FASTA + indexed BAM -> the arrays of
 trgt_locus_batch_in, i.e. analyze_tr up to clip_reads (src/trgt/workflows/tr.rs:24-35, 186-196, 268-361; locus.rs:31-98, 168-190;
-reads/read.rs:55-141; reads/snp.rs:51-79; reads/clip_region.rs:19-184).  trgt_amd/reads.py is the Python mirror of the same steps."""
+reads/read.rs:55-141; reads/snp.rs:51-79; reads/clip_region.rs:19-184).  tests/pyreads.py is the Python mirror of the same steps."""
 import ctypes as C
 
 import numpy as np

@@ -261,13 +261,14 @@ def submit_batch(batch, params=Params(), ctx=None, outputs=None, flank=None, rea
         fl, batch["lf_off"], batch["lf_len"], batch["rf_off"], batch["rf_len"], batch["tr_blob"], batch["tr_off"], batch["tr_len"],
         batch["motif_blob"], batch["motif_off"], batch["set_motif_begin"], batch["ploidy"], batch["locus_read_begin"],
         rd, batch["read_off"], batch["read_len"])],
-        p(batch.get("genotyper")).value if batch.get("genotyper") is not None else None,
-        p(batch.get("read_qual")).value if batch.get("read_qual") is not None else None,
-        read_encoding=int(batch.get("read_encoding", 0)))
+        *[p(batch.get(k)).value if batch.get(k) is not None else None for k in ("genotyper", "read_qual", "hp_tag", "start_offset", "end_offset",
+                                                                                 "mismatch_offsets", "mismatch_off")],
+        int(batch.get("read_encoding", 0)))
+    # (the same optional-field list as _batch_in: without hp_tag / offsets the library would skip genotype_flank, tr.rs:69-75)
     lp = _locus_params(params)
     t = C.c_int64(0)
     ctx.check(_lib.lib().trgt_locus_batch_submit(ctx.handle, C.byref(lp), C.byref(cin), C.byref(out.c_out), C.byref(t)))
-    return Ticket(ctx, batch, out, cin, lp, (fl, rd), t.value)
+    return Ticket(ctx, batch, out, cin, lp, (fl, rd) + tuple(batch.get(k) for k in _CIN_KEYS), t.value)
 
 
 def locus_result(batch, out, l):

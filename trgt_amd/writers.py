@@ -1,6 +1,6 @@
 """Native writers (trgt_amd/csrc/writers.hip through the C ABI): the VCF of VcfWriter (src/trgt/writers/write_vcf.rs:19-397, incl. the AM
 field of get_meth, tr.rs:196-262, 363-398) and the spanning-reads BAM of BamWriter (src/trgt/writers/write_bam.rs:33-144) for batches that
-came through the native ingestion (trgt_amd/ingest.py) and trgt_locus_batch.  trgt_amd/vcf.py is the Python mirror of one VCF record."""
+came through the native ingestion (trgt_amd/ingest.py) and trgt_locus_batch.  tests/pyvcf.py is the Python mirror of one VCF record."""
 import ctypes as C
 
 from . import _lib
