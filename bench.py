@@ -126,32 +126,25 @@ def copy_peak_gbs(torch, nbytes=1 << 30, reps=8):
     return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE workload; 0 (default) = config 2 (the one the metric is quoted on) followed, at N = 1, by short legs of configs 3, 4 and 5 reported under \"configs\" in the same JSON line")
     ap.add_argument("--loci", type=int, default=0, help="loci per GPU per step (default: by config)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="with --config 0: config 2 only")
+    ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of each of the config 3 / 4 / 5 legs")
     ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per context in GB (trgt_hip_set_workspace_limit; 0 = by config: the library's 32 GB, 8 GB for config 3)")
     ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 6 for configs 3 and 5); 1 = the blocking call only")
-    args = ap.parse_args()
-    n_loci = args.loci or DEFAULT_LOCI[args.config]
-    if args.contexts <= 0:
-        # measured on MI355X (tools/contexts_sweep.sh): config 2 is flat from 4 contexts on (1.87 M loci/s with 4, 5, 6 and 8); config 5,
-        # whose calls wait on the host between their GPU stages, still gains (210 / 235 / 245 k with 4 / 6 / 8; 10 do not fit the HBM any more);
-        # config 4 is limited by its workspaces (tens of GB per context), config 3 runs six contexts with a smaller workspace limit (below).
-        # value_single_context is printed next to value
-        args.contexts = {3: 6, 5: 6}.get(args.config, 4)
-    if args.ws_limit_gb <= 0 and args.config == 3:
-        # the generic alignment kernel sizes its HBM arena by this limit; since the long reads meet the pre-filter window by window it has
-        # little left to do, and six contexts of 12 GB do more than three of 32 (8.2 against 6.4 k loci/s; 16 GB the same, 8 GB 7.6 k)
-        args.ws_limit_gb = 12.0
-    ws_limit = int(args.ws_limit_gb * (1 << 30))
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     import torch
     import torch.distributed as dist
 
@@ -172,12 +165,52 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    env = dict(torch=torch, dist=dist, rank=rank, local_rank=local_rank, world=world)
+    legs = args.config == 0 and not args.no_legs and world == 1
+    first = argparse.Namespace(**vars(args))
+    first.config = args.config or 2
+    res = run_one(first, env)
+    if legs:
+        # BASELINE configs[2..4] under the same clock: short legs (HBM-resident value through the pool + the one-context loop the
+        # roofline block is measured in + the parity sample), each reported in full under "configs"
+        res["configs"] = {}
+        for cfg in (3, 4, 5):
+            a = argparse.Namespace(**vars(args))
+            a.config, a.steps, a.warmup, a.no_streaming, a.loci, a.contexts, a.ws_limit_gb = cfg, args.leg_steps, min(args.warmup, 2), True, 0, 0, 0.0
+            t0 = time.perf_counter()
+            r = run_one(a, env, cpu_seconds=6.0, all_cores=False)
+            r["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+            res["configs"][str(cfg)] = r
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_one(args, env, cpu_seconds=20.0, all_cores=True):
+    """One BASELINE config measured on this rank's GPU; returns the result dict on rank 0 (None elsewhere)."""
+    torch, dist, rank, local_rank, world = env["torch"], env["dist"], env["rank"], env["local_rank"], env["world"]
+    n_loci = args.loci or DEFAULT_LOCI[args.config]
+    if args.contexts <= 0:
+        # measured on MI355X (DESIGN.md 5; tools/contexts_sweep.sh): config 2 is flat from 4 contexts on (1.87 M loci/s with 4, 5, 6 and 8); config 5,
+        # whose calls wait on the host between their GPU stages, still gains (210 / 235 / 245 k with 4 / 6 / 8; 10 do not fit the HBM any more);
+        # config 4 is limited by its workspaces (tens of GB per context), config 3 runs six contexts with a smaller workspace limit (below).
+        # value_single_context is printed next to value
+        args.contexts = {3: 6, 5: 6}.get(args.config, 4)
+    if args.ws_limit_gb <= 0 and args.config == 3:
+        # the generic alignment kernel sizes its HBM arena by this limit; since the long reads meet the pre-filter window by window it has
+        # little left to do, and six contexts of 12 GB do more than three of 32 (8.2 against 6.4 k loci/s; 16 GB the same, 8 GB 7.6 k)
+        args.ws_limit_gb = 12.0
+    ws_limit = int(args.ws_limit_gb * (1 << 30))
 
     from trgt_amd import _lib, locus, shard
 
     # ---- synthetic shard of this rank (untimed)
     # host threads for the glue between the GPU stages; the library uses at most 8 of them when the reads are resident in HBM
-    host_threads = min(8, args.host_threads or max(1, (os.cpu_count() or 8) // max(1, world)))
+    # (ranks x contexts per GPU x host threads per context never exceeds the host's cores: the first real 8-GPU run must not oversubscribe)
+    cores = os.cpu_count() or 8
+    host_threads = min(8, args.host_threads or max(1, cores // max(1, world * args.contexts)))
     batch = make_batch(args.config, n_loci, rank * n_loci)
     reads_dev = torch.from_numpy(batch["read_blob"]).cuda()
     flank_dev = torch.from_numpy(batch["flank_blob"]).cuda()
@@ -376,6 +409,7 @@ def main():
 
     if pool is not None:
         pool.close()
+    res = None
     if rank == 0:
         # wfa_filter: register-resident pre-filter over the alignments of reads too short to span their locus (>90 % of the wavefront
         # offsets); wfa_flank: the back-tracing kernel over the alignments the filter keeps; wfa_flank_rest: the other flank alignments
@@ -424,6 +458,7 @@ def main():
             rout = locus.BatchOutputs(batch)
             locus.run_batch(batch, params, rctx, rout, flank_dev=flank_dev, reads_dev=reads_dev)
             ref_cells_l = int(rout.stats[17])
+            rctx.close()
         copy_peak = copy_peak_gbs(torch)
         num_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         valu_peak = num_cus * VALU_LANES_PER_CU * CLOCK_GHZ * 1e9   # 32-bit integer lane-operations per second
@@ -442,7 +477,8 @@ def main():
             "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3), "ms_per_step_single_context_with_timing_events": round(1e3 * dt_single_instrumented / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
-                       "host_threads_per_rank": host_threads, "contexts_per_gpu": args.contexts, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
+                       "host_threads_per_context": host_threads, "contexts_per_gpu": args.contexts, "host_cores": cores,
+                       "host_threads_all_ranks": host_threads * args.contexts * world, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",
@@ -476,14 +512,14 @@ def main():
         if digest_check:
             res["multi_gpu_digest_check"] = digest_check
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            res["cpu_baseline"], res["parity"] = cpu_baseline(batch, out, args.config)
+            res["cpu_baseline"], res["parity"] = cpu_baseline(batch, out, args.config, seconds_budget=cpu_seconds)
             nthr = min(os.cpu_count() or 1, 128)
-            if nthr > 1 and args.config in (2, 4):
+            if all_cores and nthr > 1 and args.config in (2, 4):
                 res["cpu_baseline_all_cores"] = cpu_baseline_mt(batch, nthr)
-        print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.close()
+    del reads_dev, flank_dev
+    torch.cuda.empty_cache()
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":

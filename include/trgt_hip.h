@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 5
+#define TRGT_HIP_ABI_VERSION 6
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -344,13 +344,17 @@ typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch
   /* -- with trgt_ingest_params.keep_bam4: the reads once more as BAM 4-bit codes (trgt_locus_batch_in: read_blob = read_bam4, read_off =
    *    read_bam4_off, read_encoding = TRGT_READS_BAM4; read_len is shared).  NULL otherwise. */
   const uint8_t* read_bam4; const uint64_t* read_bam4_off; uint64_t read_bam4_bytes;
+  /* -- catalog lines that gave no locus: one "Error at BED line N: ..." message each (locus.rs:93-137 reports them and goes on) */
+  int64_t n_skipped; const char* skipped_blob; const uint64_t* skipped_off;   /* [n_skipped + 1] offsets into skipped_blob */
   void* owner;
 } trgt_ingest_batch;
 void trgt_ingest_default_params(trgt_ingest_params* p);
 int trgt_ingest_open(const char* bam_path, const char* fasta_path, trgt_ingest** out);  /* needs <bam>.bai and <fasta>.fai */
 void trgt_ingest_close(trgt_ingest* h);
 const char* trgt_ingest_last_error(const trgt_ingest* h);
-/* loci [first_locus, first_locus + max_loci) of the catalog (max_loci < 0: to the end) */
+/* catalog LINES [first_locus, first_locus + max_loci) (max_loci < 0: to the end); a line that gives no Locus -- wrong field count
+ * (blank lines too), bad coordinates, flanks leaving the contig, unknown contig -- is skipped and reported in skipped_blob, as
+ * stream_loci_into_channel does (src/trgt/locus.rs:93-137) */
 int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus,
                                    int64_t max_loci, trgt_ingest_batch** out);
 void trgt_ingest_free(trgt_ingest_batch* b);
@@ -381,6 +385,37 @@ int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const 
 int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* out);
 int trgt_writer_close(trgt_writer* w);   /* flushes, writes the BGZF end-of-file blocks, frees the handle */
 const char* trgt_writer_last_error(const trgt_writer* w);
+
+/* ------------------------------------------------- per-read helpers of the ingestion / writer steps, exported on their own
+ * (host code; the functions trgt_ingest_* and trgt_writer_* use internally -- a host that keeps its own BAM reader can call them, and the
+ * reference's unit tests for them run through these entry points: tests/test_read_helper_kats.py).  CIGAR operations are BAM words
+ * (len << 4 | op, op: 0 M, 1 I, 2 D, 3 N, 4 S, 5 H, 6 P, 7 =, 8 X).  Every function returns the number of elements it produced, -1 for
+ * "None" in the reference's sense, or a TRGT_ERR_* code (<= -2 ... see the values above) when an output capacity is too small. */
+/* CigarOpExt::get_ref_len / get_query_len (src/trgt/reads/cigar.rs:8-31) and Cigar::query_len (:41-45) */
+int64_t trgt_cigar_ref_len(uint32_t op);
+int64_t trgt_cigar_query_len(uint32_t op);
+int64_t trgt_cigar_total_query_len(const uint32_t* cigar, int64_t n_ops);
+/* extract_snps_offset (src/trgt/reads/snp.rs:51-79): offsets of the X runs outside [region_start, region_end] */
+int64_t trgt_read_mismatch_offsets(const uint32_t* cigar, int64_t n_ops, int64_t ref_pos, int64_t region_start, int64_t region_end,
+                                   int32_t* out, int64_t cap);
+/* get_meth (src/trgt/reads/read.rs:55-96) from the MM text and ML bytes of a record: one value per CpG of `bases`; -1 = None */
+int64_t trgt_read_meth(const uint8_t* bases, int64_t n_bases, const char* mm, const uint8_t* ml, int64_t n_ml, int32_t is_reverse,
+                       uint8_t* out, int64_t cap);
+/* HiFiRead::clip_to_region (src/trgt/reads/clip_region.rs:19-184): bases / quals / per-CpG meth (n_meth < 0: None) / CIGAR of the part of
+ * the read aligned inside [region_start, region_end).  Returns the clipped number of bases, -1 = None (no overlap); out_meth_n gets
+ * the number of meth values kept (-1 = None), out_ref_pos / out_cigar / out_n_ops the clipped alignment.  Output capacities: n_bases
+ * bases and quals, n_meth meth values, n_ops + 1 operations. */
+int64_t trgt_read_clip_to_region(const uint8_t* bases, const uint8_t* quals, int64_t n_bases, const uint8_t* meth, int64_t n_meth,
+                                 const uint32_t* cigar, int64_t n_ops, int64_t ref_pos, int64_t region_start, int64_t region_end,
+                                 uint8_t* out_bases, uint8_t* out_quals, uint8_t* out_meth, int64_t* out_meth_n,
+                                 uint32_t* out_cigar, int64_t* out_n_ops, int64_t* out_ref_pos);
+/* HiFiRead::clip_bases (src/trgt/reads/clip_bases.rs:9-120): the read without its first left_len and last right_len bases; same outputs */
+int64_t trgt_read_clip_bases(const uint8_t* bases, const uint8_t* quals, int64_t n_bases, const uint8_t* meth, int64_t n_meth,
+                             const uint32_t* cigar, int64_t n_ops, int64_t ref_pos, int64_t left_len, int64_t right_len,
+                             uint8_t* out_bases, uint8_t* out_quals, uint8_t* out_meth, int64_t* out_meth_n,
+                             uint32_t* out_cigar, int64_t* out_n_ops, int64_t* out_ref_pos);
+/* utils::math::median (src/utils/math.rs:73-98): f32 median of i32 values as simple_consensus uses it (genotype_flank.rs:147); 0 = None */
+int32_t trgt_median_i32(const int32_t* data, int64_t n, float* out);
 
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {

@@ -190,6 +190,7 @@ struct Fasta {
     }
     return true;
   }
+  int64_t length(const std::string& contig) const { auto it = idx.find(contig); return it == idx.end() ? -1 : it->second.len; }
   // bases [beg, end) of a contig, upper-cased (locus.rs:168-190: fetch_seq_string + to_uppercase)
   bool fetch(const std::string& contig, int64_t beg, int64_t end, std::string& out, std::string& err) const {
     auto it = idx.find(contig);
@@ -272,23 +273,31 @@ bool aux_int(const uint8_t* a, int64_t& v) {
 // ML values that belong to them (SAM tags spec 1.7: skip counts over the canonical base of the ORIGINAL strand; a reverse-strand
 // record stores the reverse complement, so its C's are G's counted from the end).  rust-htslib's basemods_iter reports them in the
 // same order; get_meth (read.rs:55-96) keeps those that sit on a CpG.
+bool basemods_5mc_tags(const char* mm_text, const uint8_t* mlv, uint32_t n_ml, const std::string& bases, bool reverse, std::vector<std::pair<uint32_t, uint8_t>>& out);
 bool basemods_5mc(const RawRec& r, const std::string& bases, bool reverse, std::vector<std::pair<uint32_t, uint8_t>>& out) {
   out.clear();
   const uint8_t* mm = find_aux(r, "MM"); if (!mm) mm = find_aux(r, "Mm");
   const uint8_t* ml = find_aux(r, "ML"); if (!ml) ml = find_aux(r, "Ml");
   if (!mm || mm[0] != 'Z' || !ml || ml[0] != 'B' || (ml[1] != 'C' && ml[1] != 'c')) return false;
-  const uint32_t n_ml = le32(ml + 2);
-  const uint8_t* mlv = ml + 6;
-  const char* s = (const char*)mm + 1;
+  return basemods_5mc_tags((const char*)mm + 1, ml + 6, le32(ml + 2), bases, reverse, out);
+}
+// (false: a tag htslib's bam_parse_basemod refuses -- get_meth then returns None, read.rs:189-195 test_basemods_error)
+bool basemods_5mc_tags(const char* mm_text, const uint8_t* mlv, uint32_t n_ml, const std::string& bases, bool reverse, std::vector<std::pair<uint32_t, uint8_t>>& out) {
+  out.clear();
+  const char* s = mm_text;
   uint32_t ml_at = 0;
   const size_t n = bases.size();
   while (*s) {
     // one entry: base strand codes [.?] {,delta} ;
     const char base = *s; if (!base) break;
     const char strand = s[1];
+    if (!std::strchr("ACGTUN", base) || (strand != '+' && strand != '-')) return false;  // "no": not a base-modification string (htslib refuses it)
     const char* q = s + 2;
     std::string codes;
     while (*q && *q != ',' && *q != ';' && *q != '.' && *q != '?') codes.push_back(*q++);
+    if (codes.empty()) return false;
+    // a numeric ChEBI code ("C+76792") is ONE modification, not one per digit
+    if (codes.find_first_not_of("0123456789") == std::string::npos) codes = "#";
     if (*q == '.' || *q == '?') ++q;
     std::vector<uint32_t> deltas;
     while (*q == ',') { ++q; uint32_t v = 0; while (*q >= '0' && *q <= '9') v = v * 10 + (uint32_t)(*q++ - '0'); deltas.push_back(v); }
@@ -321,6 +330,36 @@ bool basemods_5mc(const RawRec& r, const std::string& bases, bool reverse, std::
   return true;
 }
 
+// get_meth (read.rs:55-96): one value per CpG of the stored sequence (0 where no call sits on it); false = None (no call on any CpG)
+bool meth_per_cpg(const std::string& bases, bool reverse, const std::vector<std::pair<uint32_t, uint8_t>>& mods, std::vector<uint8_t>& meth) {
+  std::vector<size_t> cpg;
+  for (size_t i = 0; i + 1 < bases.size(); ++i) if (bases[i] == 'C' && bases[i + 1] == 'G') cpg.push_back(i + (reverse ? 1 : 0));
+  std::vector<uint8_t> ans(cpg.size(), 0);
+  size_t ind = 0;
+  for (auto& m : mods) {
+    while (ind < cpg.size() && cpg[ind] < m.first) ++ind;
+    if (ind < cpg.size() && m.first == cpg[ind]) { ans[ind] = m.second; ++ind; }
+  }
+  if (ind == 0) return false;
+  if (reverse) std::reverse(ans.begin(), ans.end());
+  meth.swap(ans);
+  return true;
+}
+// extract_snps_offset (snp.rs:51-79): X runs that start outside [start, end] of the region, relative to the nearer end
+void snps_offset(const uint32_t* cigar, size_t n_ops, int64_t pos, int64_t region_start, int64_t region_end, std::vector<int32_t>& out) {
+  uint32_t start_ref = (uint32_t)pos;
+  for (size_t k = 0; k < n_ops; ++k) {
+    const uint32_t op = cigar[k];
+    const int c = (int)(op & 0xF); const uint32_t n = op >> 4;
+    const bool inside = (int64_t)start_ref >= region_start && (int64_t)start_ref <= region_end;
+    if (c == OP_X && !inside) {
+      const int32_t diff = (int64_t)start_ref < region_start ? (int32_t)start_ref - (int32_t)region_start : (int32_t)start_ref - (int32_t)region_end;
+      for (uint32_t i = 0; i < n; ++i) out.push_back(diff + (int32_t)i);
+      start_ref += n;
+    } else if (c == OP_M || c == OP_X || c == OP_EQ || c == OP_D || c == OP_N) start_ref += n;
+  }
+}
+
 // HiFiRead::from_hts_rec (read.rs:98-141)
 void make_read(const RawRec& r, int64_t region_start, int64_t region_end, Read& out) {
   static const char code[] = "=ACMGRSVTWYHKDBN";
@@ -331,22 +370,12 @@ void make_read(const RawRec& r, int64_t region_start, int64_t region_end, Read& 
   for (int32_t i = 0; i < r.l_seq; ++i) out.bases[(size_t)i] = code[(d[r.o_seq + (size_t)(i >> 1)] >> ((i & 1) ? 0 : 4)) & 0xF];
   out.quals.assign(d + r.o_qual, d + r.o_qual + r.l_seq);
   out.mapq = r.mapq;
-  { int64_t v; out.hp = aux_int(find_aux(r, "HP"), v) ? (int)(uint8_t)v : -1; }
+  { const uint8_t* a = find_aux(r, "HP"); out.hp = a && a[0] == 'C' ? (int)a[1] : -1; }  // get_hp_tag (read.rs:167-172): Aux::U8 only
   { const uint8_t* a = find_aux(r, "rq"); float f; if (a && a[0] == 'f') { std::memcpy(&f, a + 1, 4); out.rq = (double)f; } }
-  {  // get_meth (read.rs:55-96): one value per CpG of the stored sequence (0 where no call sits on it), None without any call
+  {  // get_meth (read.rs:55-96)
     std::vector<std::pair<uint32_t, uint8_t>> mods;
     out.has_meth = false; out.meth.clear();
-    if (basemods_5mc(r, out.bases, out.is_reverse, mods)) {
-      std::vector<size_t> cpg;
-      for (size_t i = 0; i + 1 < out.bases.size(); ++i) if (out.bases[i] == 'C' && out.bases[i + 1] == 'G') cpg.push_back(i + (out.is_reverse ? 1 : 0));
-      std::vector<uint8_t> ans(cpg.size(), 0);
-      size_t ind = 0;
-      for (auto& m : mods) {
-        while (ind < cpg.size() && cpg[ind] < m.first) ++ind;
-        if (ind < cpg.size() && m.first == cpg[ind]) { ans[ind] = m.second; ++ind; }
-      }
-      if (ind != 0) { if (out.is_reverse) std::reverse(ans.begin(), ans.end()); out.meth.swap(ans); out.has_meth = true; }
-    }
+    if (basemods_5mc(r, out.bases, out.is_reverse, mods)) out.has_meth = meth_per_cpg(out.bases, out.is_reverse, mods, out.meth);
   }
   out.has_cigar = !(r.flag & 0x4);
   out.ref_pos = r.pos;
@@ -354,20 +383,8 @@ void make_read(const RawRec& r, int64_t region_start, int64_t region_end, Read& 
   for (size_t i = 0; i < out.cigar.size(); ++i) out.cigar[i] = le32(d + r.o_cig + 4 * i);
   out.start_offset = (int32_t)((int64_t)r.pos - region_start);
   out.end_offset = (int32_t)(rec_ref_end(r) - region_end);
-  // extract_snps_offset (snp.rs:51-79): X runs that start outside [start, end] of the region, relative to the nearer end
   out.mismatch_offsets.clear();
-  if (out.has_cigar) {
-    uint32_t start_ref = (uint32_t)r.pos;
-    for (uint32_t op : out.cigar) {
-      const int c = (int)(op & 0xF); const uint32_t n = op >> 4;
-      const bool inside = (int64_t)start_ref >= region_start && (int64_t)start_ref <= region_end;
-      if (c == OP_X && !inside) {
-        const int32_t diff = (int64_t)start_ref < region_start ? (int32_t)start_ref - (int32_t)region_start : (int32_t)start_ref - (int32_t)region_end;
-        for (uint32_t i = 0; i < n; ++i) out.mismatch_offsets.push_back(diff + (int32_t)i);
-        start_ref += n;
-      } else if (c == OP_M || c == OP_X || c == OP_EQ || c == OP_D || c == OP_N) start_ref += n;
-    }
-  }
+  if (out.has_cigar) snps_offset(out.cigar.data(), out.cigar.size(), r.pos, region_start, region_end, out.mismatch_offsets);
 }
 
 // clip_cigar + HiFiRead::clip_to_region (clip_region.rs:19-184); false = no overlap (or no alignment)
@@ -499,6 +516,7 @@ struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
   std::vector<int64_t> cig_ref_pos;
   std::vector<uint8_t> bam4;
   std::vector<uint64_t> bam4_off;
+  std::string skipped; std::vector<uint64_t> skipped_off;
   trgt_ingest_batch pub;
 };
 
@@ -570,7 +588,19 @@ static bool parse_bed_line(const std::string& line, std::string& contig, int64_t
   { std::istringstream ss(line); std::string t; while (ss >> t) f.push_back(t); }
   if (f.size() != 4) { err = "Expected 4 fields in the format 'chrom start end info', found " + std::to_string(f.size()) + ": " + line; return false; }
   contig = f[0];
-  try { start = std::stoll(f[1]); end = std::stoll(f[2]); } catch (...) { err = "Invalid region: " + line; return false; }
+  // GenomicRegion::from_string (utils/region.rs:23-35): "contig:start-end" split at ':' and '-' must give three elements, the
+  // coordinates parse as u32 (digits with an optional '+', no sign, no trailing text: "12abc" and "-3" are refused), start < end
+  auto u32_of = [](const std::string& t, int64_t& v) {
+    size_t i = !t.empty() && t[0] == '+' ? 1 : 0;
+    if (i >= t.size()) return false;
+    uint64_t x = 0;
+    for (; i < t.size(); ++i) { if (t[i] < '0' || t[i] > '9') return false; x = x * 10 + (uint64_t)(t[i] - '0'); if (x > 0xFFFFFFFFull) return false; }
+    v = (int64_t)x; return true;
+  };
+  const std::string enc = f[0] + ":" + f[1] + "-" + f[2];
+  if (f[0].find_first_of(":-") != std::string::npos || f[1].find_first_of(":-") != std::string::npos || f[2].find_first_of(":-") != std::string::npos ||
+      !u32_of(f[1], start) || !u32_of(f[2], end)) { err = "Invalid region encoding: " + enc; return false; }
+  if (start >= end) { err = "Invalid region: start " + std::to_string(start) + " >= end " + std::to_string(end); return false; }
   std::map<std::string, std::string> fields;
   { std::istringstream ss(f[3]); std::string kv;
     while (std::getline(ss, kv, ';')) {
@@ -595,20 +625,29 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   if (!bed) return bad(std::string("cannot open ") + bed_path);
   struct L { std::string contig, id, struc; int64_t start, end; std::vector<std::string> motifs; std::string lf, tr, rf; std::vector<Read> reads; int32_t n_filt = 0; int64_t n_seen = 0; std::string err; };
   std::vector<L> loci;
+  std::vector<std::string> skipped;  // one message per catalog line that gave no locus
   {
-    std::string line; int64_t idx = 0, line_no = 0;
+    // stream_loci_into_channel (locus.rs:93-137): a line that does not give a Locus is reported ("Error at BED line N: ...") and the
+    // next line is read; blank lines are lines like any other ("Expected 4 fields ..., found 0").  first_locus / max_loci count
+    // catalog LINES.
+    std::string line; int64_t line_no = 0;
     while (std::getline(bed, line)) {
       ++line_no;
-      if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
-      if (idx++ < first_locus) continue;
-      if (max_loci >= 0 && (int64_t)loci.size() >= max_loci) break;
+      if (line_no - 1 < first_locus) continue;
+      if (max_loci >= 0 && line_no - 1 >= first_locus + max_loci) break;
+      if (!line.empty() && line.back() == '\r') line.pop_back();
       L l; std::string e;
-      if (!parse_bed_line(line, l.contig, l.start, l.end, l.id, l.motifs, l.struc, e)) return bad("Error at BED line " + std::to_string(line_no) + ": " + e);
+      auto skip = [&](const std::string& m) { skipped.push_back("Error at BED line " + std::to_string(line_no) + ": " + m); };
+      if (!parse_bed_line(line, l.contig, l.start, l.end, l.id, l.motifs, l.struc, e)) { skip(e); continue; }
+      // check_region_bounds (locus.rs:220-257)
+      const int64_t chrom_len = h->fasta.length(l.contig);
+      if (chrom_len < 0) { skip("FASTA reference does not contain chromosome '" + l.contig + "' in BED file"); continue; }
+      if (l.start < (int64_t)p->flank_len + 1) { skip("Region start '" + std::to_string(l.start) + "' with flank length '" + std::to_string(p->flank_len) + "' underflows for chromosome '" + l.contig + "'."); continue; }
+      if (l.end + p->flank_len > 0xFFFFFFFFll) { skip("Region end '" + std::to_string(l.end) + "' with flank length '" + std::to_string(p->flank_len) + "' overflows for chromosome '" + l.contig + "'."); continue; }
+      if (l.end + p->flank_len > chrom_len) { skip("Region end '" + std::to_string(l.end + p->flank_len) + "' with flank length '" + std::to_string(p->flank_len) + "' exceeds chromosome '" + l.contig + "' bounds (0.." + std::to_string(chrom_len) + ")."); continue; }
       // get_tr_and_flanks (locus.rs:168-190)
-      if (l.start < p->flank_len) return bad("Error at BED line " + std::to_string(line_no) + ": flank of " + l.id + " leaves the contig");
       if (!h->fasta.fetch(l.contig, l.start - p->flank_len, l.start, l.lf, e) || !h->fasta.fetch(l.contig, l.start, l.end, l.tr, e) ||
-          !h->fasta.fetch(l.contig, l.end, l.end + p->flank_len, l.rf, e))
-        return bad("Error at BED line " + std::to_string(line_no) + ": " + e);
+          !h->fasta.fetch(l.contig, l.end, l.end + p->flank_len, l.rf, e)) { skip(e); continue; }
       loci.push_back(std::move(l));
     }
   }
@@ -726,6 +765,9 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   B.contig_blob = S->contigs.data(); B.contig_off = S->contig_off.data(); B.id_blob = S->ids.data(); B.id_off = S->id_off.data();
   B.struc_blob = S->strucs.data(); B.struc_off = S->struc_off.data(); B.region_start = S->region_start.data(); B.region_end = S->region_end.data();
   B.cigar = S->cig.data(); B.cigar_off = S->cig_off.data(); B.cigar_ref_pos = S->cig_ref_pos.data();
+  S->skipped_off.push_back(0);
+  for (auto& m : skipped) { S->skipped += m; S->skipped_off.push_back(S->skipped.size()); }
+  B.n_skipped = (int64_t)skipped.size(); B.skipped_blob = S->skipped.data(); B.skipped_off = S->skipped_off.data();
   if (p->keep_bam4) {  // the reads once more, two bases per byte (half the bytes to move to the GPU)
     uint64_t total = 0;
     for (uint32_t n : S->read_len) total += ((uint64_t)n + 1) / 2;
@@ -752,6 +794,54 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
                                    trgt_ingest_batch** out) {
   try { return ingest_batch_impl(h, p, bed_path, first_locus, max_loci, out); }
   catch (const std::exception& e) { if (h) h->err = std::string("trgt_ingest_batch_from_catalog: ") + e.what(); return TRGT_ERR_NOMEM; }
+}
+
+// ---- the per-read helpers on their own (include/trgt_hip.h: "per-read helpers"): thin wrappers over the functions above
+int64_t trgt_cigar_ref_len(uint32_t op) { return ref_len(op); }
+int64_t trgt_cigar_query_len(uint32_t op) { return qry_len(op); }
+int64_t trgt_cigar_total_query_len(const uint32_t* cigar, int64_t n_ops) {
+  if (n_ops < 0 || (n_ops > 0 && !cigar)) return TRGT_ERR_INVALID;
+  int64_t t = 0; for (int64_t i = 0; i < n_ops; ++i) t += qry_len(cigar[i]); return t;
+}
+int64_t trgt_read_mismatch_offsets(const uint32_t* cigar, int64_t n_ops, int64_t ref_pos, int64_t region_start, int64_t region_end, int32_t* out, int64_t cap) {
+  if (n_ops < 0 || (n_ops > 0 && !cigar) || cap < 0 || (cap > 0 && !out)) return TRGT_ERR_INVALID;
+  try {
+    std::vector<int32_t> v;
+    snps_offset(cigar, (size_t)n_ops, ref_pos, region_start, region_end, v);
+    if ((int64_t)v.size() > cap) return TRGT_ERR_INVALID;
+    std::copy(v.begin(), v.end(), out);
+    return (int64_t)v.size();
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
+}
+int64_t trgt_read_meth(const uint8_t* bases, int64_t n_bases, const char* mm, const uint8_t* ml, int64_t n_ml, int32_t is_reverse, uint8_t* out, int64_t cap) {
+  if (n_bases < 0 || (n_bases > 0 && !bases) || !mm || n_ml < 0 || (n_ml > 0 && !ml) || cap < 0 || (cap > 0 && !out)) return TRGT_ERR_INVALID;
+  try {
+    const std::string b((const char*)bases, (size_t)n_bases);
+    std::vector<std::pair<uint32_t, uint8_t>> mods; std::vector<uint8_t> meth;
+    if (!basemods_5mc_tags(mm, ml, (uint32_t)n_ml, b, is_reverse != 0, mods) || !meth_per_cpg(b, is_reverse != 0, mods, meth)) return -1;
+    if ((int64_t)meth.size() > cap) return TRGT_ERR_INVALID;
+    std::copy(meth.begin(), meth.end(), out);
+    return (int64_t)meth.size();
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
+}
+int64_t trgt_read_clip_to_region(const uint8_t* bases, const uint8_t* quals, int64_t n_bases, const uint8_t* meth, int64_t n_meth, const uint32_t* cigar,
+                                 int64_t n_ops, int64_t ref_pos, int64_t region_start, int64_t region_end, uint8_t* out_bases, uint8_t* out_quals,
+                                 uint8_t* out_meth, int64_t* out_meth_n, uint32_t* out_cigar, int64_t* out_n_ops, int64_t* out_ref_pos) {
+  if (n_bases < 0 || (n_bases > 0 && (!bases || !quals || !out_bases || !out_quals)) || n_ops < 0 || (n_ops > 0 && !cigar) || !out_cigar || !out_n_ops ||
+      !out_ref_pos || !out_meth_n || (n_meth > 0 && (!meth || !out_meth)))
+    return TRGT_ERR_INVALID;
+  try {
+    Read in, c;
+    in.bases.assign((const char*)bases, (size_t)n_bases); in.quals.assign(quals, quals + n_bases);
+    in.has_meth = n_meth >= 0; if (n_meth > 0) in.meth.assign(meth, meth + n_meth);
+    in.has_cigar = true; in.ref_pos = ref_pos; in.cigar.assign(cigar, cigar + n_ops);
+    if (!clip_to_region(in, region_start, region_end, c)) return -1;
+    std::copy(c.bases.begin(), c.bases.end(), out_bases); std::copy(c.quals.begin(), c.quals.end(), out_quals);
+    *out_meth_n = c.has_meth ? (int64_t)c.meth.size() : -1;
+    if (c.has_meth) std::copy(c.meth.begin(), c.meth.end(), out_meth);
+    std::copy(c.cigar.begin(), c.cigar.end(), out_cigar); *out_n_ops = (int64_t)c.cigar.size(); *out_ref_pos = c.ref_pos;
+    return (int64_t)c.bases.size();
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
 }
 
 }  // extern "C"
