@@ -378,6 +378,10 @@ typedef struct trgt_writer_params {
   const char* program;        /* "trgt": ##<program>Version= / ##<program>Command= / @PG ID, PN */
   const char* version;
   const char* command_line;
+  int32_t keep_unmapped_flag; /* 0 (default): aligned reads are written with flag 0 / 0x10.  1: flag 0x4 stays set on every record, which is
+                                 what write_bam.rs:96-111 produces if rust-htslib 0.46's Record::new() initialises a record as unmapped (its
+                                 published source does: set_unmapped(), tid / pos / mtid / mpos = -1) and nothing clears it on the mapped branch --
+                                 rust-htslib is un-vendored, no reference-produced BAM is on disk: parity of this bit is UNPINNED, hence the switch */
 } trgt_writer_params;
 void trgt_writer_default_params(trgt_writer_params* p);
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);

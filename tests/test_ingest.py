@@ -184,12 +184,13 @@ def test_errors_are_reported(tmp_path):
         ingest.Reader(str(tmp_path / "missing.bam"), os.path.join(EX, "reference.fasta"))
     rd = ingest.Reader(os.path.join(EX, "sample.bam"), os.path.join(EX, "reference.fasta"))
     bad = str(tmp_path / "bad.bed")
-    open(bad, "w").write("chrA\t10001\t10061\tID=TR1;MOTIFS=CAG\n")
-    with pytest.raises(_lib.TrgtHipError, match="STRUC field missing"):
-        rd.batch(bad)
-    open(bad, "w").write("chrA\t100\t161\tID=TR1;MOTIFS=CAG;STRUC=(CAG)n\n")
-    with pytest.raises(_lib.TrgtHipError, match="BED line 1"):
-        rd.batch(bad)
+    # a catalog line that gives no locus is reported and skipped, as stream_loci_into_channel does (locus.rs:93-137): the good line survives
+    open(bad, "w").write("chrA\t10001\t10061\tID=TR1;MOTIFS=CAG\nchrA\t100\t161\tID=TR1;MOTIFS=CAG;STRUC=(CAG)n\nchrA\t10001\t10061\tID=TR1;MOTIFS=CAG;STRUC=(CAG)n\n")
+    b = rd.batch(bad)
+    assert b["n_loci"] == 1 and b["id"] == ["TR1"] and len(b["skipped"]) == 2
+    assert b["skipped"][0] == "Error at BED line 1: STRUC field missing" and b["skipped"][1].startswith("Error at BED line 2: Region start '100' with flank length '250' underflows")
+    with pytest.raises(_lib.TrgtHipError):
+        rd.batch(str(tmp_path / "missing.bed"))
 
 
 def test_truncated_and_corrupt_files_give_errors_not_crashes(tmp_path):

@@ -134,3 +134,10 @@ def test_vcf_and_spanning_bam_from_handmade_results(tmp_path):
         me = list(b["meth"][int(b["meth_off"][r]):int(b["meth_off"][r + 1])])
         cpg = [i for i in range(n - 1) if bases[i:i + 2] == "CG"]
         assert t["MC"] == ("BC", [m for i, m in zip(cpg, me) if left <= i < n - right])
+    # keep_unmapped_flag = 1: the records as rust-htslib 0.46's Record::new() would leave them if nothing clears 0x4 (UNPINNED, see the header)
+    w = writers.Writer(rd, tmp_path / "u.vcf", tmp_path / "u.bam", output_flank_len=40, sample_name="S1", command_line="cmd", keep_unmapped_flag=1)
+    w.write(b, out)
+    w.close()
+    _, _, got_u = read_bam_records(str(tmp_path / "u.bam"))
+    assert [(g["name"], g["flag"]) for g in got_u] == [(g["name"], g["flag"] | 4) for g in got]
+    assert [{k: v for k, v in g.items() if k != "flag"} for g in got_u] == [{k: v for k, v in g.items() if k != "flag"} for g in got]

@@ -76,7 +76,9 @@ EXPORTS = [
     "trgt_hip_pool_create", "trgt_hip_pool_destroy", "trgt_hip_pool_size", "trgt_hip_pool_context", "trgt_hip_pool_last_error", "trgt_locus_batch_many",
     "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free",
     "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
-    "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
+    "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error",
+    "trgt_cigar_ref_len", "trgt_cigar_query_len", "trgt_cigar_total_query_len", "trgt_read_mismatch_offsets", "trgt_read_meth", "trgt_read_clip_to_region",
+    "trgt_read_clip_bases", "trgt_median_i32", "trgt_synth_default_params", "trgt_synth_generate", "trgt_synth_free",
 ]
 
 

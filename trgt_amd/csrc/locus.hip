@@ -249,14 +249,20 @@ bool flank_split(const FlankMeta& M, const uint32_t* reads, size_t n, FlankSplit
   return true;
 }
 
+// utils::math::median (src/utils/math.rs:73-98): the middle value, or -- even sizes -- (a + b) as i32, then f32 / 2.0 (quickselect in the
+// reference; any selection gives the same values).  data is reordered; empty input has no median (the callers never pass one).
+float median_f32(std::vector<int32_t>& lens) {
+  std::sort(lens.begin(), lens.end());
+  return lens.size() % 2 ? (float)lens[lens.size() / 2] : (float)(lens[lens.size() / 2 - 1] + lens[lens.size() / 2]) / 2.0f;
+}
+
 // simple_consensus (:147-170) over the segments of a group: the most frequent sequence (among equals: length closest to the f32 median of
 // the lengths, truncated; among those the smallest sequence) and its relative frequency; false for an empty group
 bool flank_simple_consensus(const std::vector<Seg>& seqs, Seg& best, double& freq) {
   if (seqs.empty()) return false;
   std::vector<int32_t> lens;
   for (auto& q : seqs) lens.push_back((int32_t)q.n);
-  std::sort(lens.begin(), lens.end());
-  const float med = lens.size() % 2 ? (float)lens[lens.size() / 2] : (float)(lens[lens.size() / 2 - 1] + lens[lens.size() / 2]) / 2.0f;
+  const float med = median_f32(lens);
   const size_t median_len = (size_t)med;
   std::vector<Seg> sorted = seqs;
   std::sort(sorted.begin(), sorted.end(), [](const Seg& a, const Seg& b) { return cmp_seg(a, b) < 0; });
@@ -300,6 +306,8 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
     vote::Group& G = groups[g];
     const size_t j0 = first[g], j1 = first[g + 1];
     G.job_first = (uint32_t)j0; G.n_members = (uint32_t)(j1 - j0);
+    // (the votes are 16-bit counters packed in pairs: a larger group would carry from one counter into its neighbour)
+    if (j1 - j0 > 65535) return fail(c, TRGT_ERR_UNSUPPORTED, "consensus: group %zu has %zu members (at most 65535: 3 * max_depth reads per locus)", g, j1 - j0);
     G.bb_len = j1 > j0 ? pl[j0] : 0; G.bb_off = j1 > j0 ? po[j0] : 0;
     uint64_t member_bytes = 0;
     for (size_t j = j0; j < j1; ++j) member_bytes += tl[j];
@@ -375,6 +383,12 @@ __global__ void allele_pack_kernel(const uint8_t* __restrict__ blob, const uint6
 }  // namespace trgt
 
 using namespace trgt;
+
+extern "C" int32_t trgt_median_i32(const int32_t* data, int64_t n, float* out) {  // include/trgt_hip.h: "per-read helpers"
+  if (n < 0 || (n > 0 && !data) || !out) return TRGT_ERR_INVALID;
+  if (n == 0) return 0;
+  try { std::vector<int32_t> v(data, data + n); *out = median_f32(v); return 1; } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
+}
 
 extern "C" void trgt_locus_default_params(trgt_locus_params* p) {  // cli.rs:271-344
   if (!p) return;

@@ -70,6 +70,31 @@ inline void put16(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)x)
 inline bool ends_with(const std::string& s, const char* suf) { const size_t n = std::strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 inline uint32_t qlen_of(uint32_t op) { const uint32_t c = op & 0xF; return (c == 0 || c == 1 || c == 4 || c == 7 || c == 8) ? op >> 4 : 0; }
 inline uint32_t rlen_of(uint32_t op) { const uint32_t c = op & 0xF; return (c == 0 || c == 2 || c == 3 || c == 7 || c == 8) ? op >> 4 : 0; }
+// clip_cigar of HiFiRead::clip_bases (clip_bases.rs:59-118): the operations left after dropping left / right query bases; ref_pos moves
+// past the reference bases the dropped prefix consumed.  false: the CIGAR covers fewer query bases than are clipped.
+bool clip_bases_cigar(const uint32_t* cg, size_t nc, size_t left, size_t right, std::vector<uint32_t>& ops, int64_t& ref_pos) {
+  size_t qsum = 0; for (size_t i = 0; i < nc; ++i) qsum += qlen_of(cg[i]);
+  if (qsum < left + right) return false;
+  size_t keep = qsum - left - right, left_len = left, i = 0;
+  uint32_t cur = nc ? cg[0] : 0; bool have = nc > 0;
+  while (left_len != 0 && have) {
+    const size_t q = qlen_of(cur);
+    if (q > left_len) { const uint32_t rest = (uint32_t)(q - left_len); if (rlen_of(cur)) ref_pos += (int64_t)left_len; cur = (rest << 4) | (cur & 0xF); left_len = 0; }
+    else { left_len -= q; ref_pos += rlen_of(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
+  }
+  while (have && keep != 0) {
+    const size_t q = qlen_of(cur);
+    if (q > keep) { ops.push_back(((uint32_t)keep << 4) | (cur & 0xF)); keep = 0; }
+    else { keep -= q; ops.push_back(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
+  }
+  return true;
+}
+// the per-CpG methylation values of the CpGs whose C stays inside [left, n - right) (clip_bases.rs:34-52)
+void clip_bases_meth(const uint8_t* all, size_t n, const uint8_t* me, size_t nme, size_t left, size_t right, std::vector<uint8_t>& meth) {
+  size_t ci = 0;
+  for (size_t idx = 0; idx + 1 < n; ++idx) if (all[idx] == 'C' && all[idx + 1] == 'G') { if (ci < nme && left <= idx && idx < n - right) meth.push_back(me[ci]); ++ci; }
+}
+
 inline int reg2bin(int64_t beg, int64_t end) {
   --end;
   if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
@@ -85,7 +110,7 @@ inline int reg2bin(int64_t beg, int64_t end) {
 struct trgt_writer {
   std::string err, sample;
   BgzfOut vcf, bam;
-  bool has_bam = false;
+  bool has_bam = false, keep_unmapped = false;
   int32_t flank_len = 50;
   std::vector<std::string> contigs;
 };
@@ -96,7 +121,7 @@ const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_s
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = "";
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 0;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
@@ -104,7 +129,7 @@ static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p,
   std::unique_ptr<trgt_writer> w(new trgt_writer());
   *out = nullptr;
   auto bad = [&](const std::string& m) { w->err = m; *out = w.release(); return TRGT_ERR_INVALID; };
-  w->flank_len = p->output_flank_len;
+  w->flank_len = p->output_flank_len; w->keep_unmapped = p->keep_unmapped_flag != 0;
   const std::string prog = p->program ? p->program : "trgt", ver = p->version ? p->version : "", cl = p->command_line ? p->command_line : "";
   w->sample = p->sample_name ? p->sample_name : "sample";
   for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i) w->contigs.push_back(trgt_ingest_contig_name(src, i));
@@ -266,31 +291,13 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
       if (left + right >= n) continue;     // clip_bases: None
       const uint8_t* bases = b->read_blob + b->read_off[r] + left; const uint8_t* quals = b->qual_blob + b->read_off[r] + left;
       const size_t len = n - left - right;
-      // clip_cigar (clip_bases.rs:59-118)
       std::vector<uint32_t> ops; int64_t ref_pos = b->cigar_ref_pos[r];
-      {
-        const uint32_t* cg = b->cigar + b->cigar_off[r]; const size_t nc = (size_t)(b->cigar_off[r + 1] - b->cigar_off[r]);
-        size_t qsum = 0; for (size_t i = 0; i < nc; ++i) qsum += qlen_of(cg[i]);
-        if (qsum < left + right) return bad("CIGAR shorter than the read");
-        size_t keep = qsum - left - right, left_len = left, i = 0;
-        uint32_t cur = nc ? cg[0] : 0; bool have = nc > 0;
-        while (left_len != 0 && have) {
-          const size_t q = qlen_of(cur);
-          if (q > left_len) { const uint32_t rest = (uint32_t)(q - left_len); if (rlen_of(cur)) ref_pos += (int64_t)left_len; cur = (rest << 4) | (cur & 0xF); left_len = 0; }
-          else { left_len -= q; ref_pos += rlen_of(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
-        }
-        while (have && keep != 0) {
-          const size_t q = qlen_of(cur);
-          if (q > keep) { ops.push_back(((uint32_t)keep << 4) | (cur & 0xF)); keep = 0; }
-          else { keep -= q; ops.push_back(cur); ++i; have = i < nc; if (have) cur = cg[i]; }
-        }
-      }
+      if (!clip_bases_cigar(b->cigar + b->cigar_off[r], (size_t)(b->cigar_off[r + 1] - b->cigar_off[r]), left, right, ops, ref_pos)) return bad("CIGAR shorter than the read");
+      if (ops.size() > 65535) return bad("more than 65535 CIGAR operations in a clipped read (the BAM record would need a CG tag)");
       std::vector<uint8_t> meth; bool has_meth = false;
       if (b->has_meth && b->has_meth[r]) {
         has_meth = true;
-        const uint8_t* all = b->read_blob + b->read_off[r]; const uint8_t* me = b->meth + b->meth_off[r]; const size_t nme = (size_t)(b->meth_off[r + 1] - b->meth_off[r]);
-        size_t ci = 0;
-        for (size_t idx = 0; idx + 1 < n; ++idx) if (all[idx] == 'C' && all[idx + 1] == 'G') { if (ci < nme && left <= idx && idx < n - right) meth.push_back(me[ci]); ++ci; }
+        clip_bases_meth(b->read_blob + b->read_off[r], n, b->meth + b->meth_off[r], (size_t)(b->meth_off[r + 1] - b->meth_off[r]), left, right, meth);
       }
       const std::string name(b->name_blob + b->name_off[r], b->name_off[r + 1] - b->name_off[r]);
       int64_t ref_end = ref_pos; for (uint32_t op : ops) ref_end += rlen_of(op);
@@ -299,7 +306,7 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
       put32(rec, (uint32_t)tid); put32(rec, (uint32_t)ref_pos);
       rec.push_back((uint8_t)(name.size() + 1)); rec.push_back(b->mapq[r]);
       put16(rec, (uint32_t)reg2bin(ref_pos, ref_end > ref_pos ? ref_end : ref_pos + 1)); put16(rec, (uint32_t)ops.size());
-      put16(rec, b->is_reverse[r] ? 0x10u : 0u); put32(rec, (uint32_t)len);
+      put16(rec, (b->is_reverse[r] ? 0x10u : 0u) | (w->keep_unmapped ? 0x4u : 0u)); put32(rec, (uint32_t)len);
       put32(rec, 0xFFFFFFFFu); put32(rec, 0xFFFFFFFFu); put32(rec, 0);  // mate: none
       rec.insert(rec.end(), name.begin(), name.end()); rec.push_back(0);
       for (uint32_t op : ops) put32(rec, op);
@@ -323,6 +330,26 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
     }
   }
   return TRGT_OK;
+}
+
+// HiFiRead::clip_bases on its own (include/trgt_hip.h: "per-read helpers")
+int64_t trgt_read_clip_bases(const uint8_t* bases, const uint8_t* quals, int64_t n_bases, const uint8_t* meth, int64_t n_meth, const uint32_t* cigar,
+                             int64_t n_ops, int64_t ref_pos, int64_t left_len, int64_t right_len, uint8_t* out_bases, uint8_t* out_quals,
+                             uint8_t* out_meth, int64_t* out_meth_n, uint32_t* out_cigar, int64_t* out_n_ops, int64_t* out_ref_pos) {
+  if (n_bases < 0 || (n_bases > 0 && (!bases || !quals || !out_bases || !out_quals)) || n_ops < 0 || (n_ops > 0 && !cigar) || !out_cigar || !out_n_ops ||
+      !out_ref_pos || !out_meth_n || (n_meth > 0 && (!meth || !out_meth)) || left_len < 0 || right_len < 0)
+    return TRGT_ERR_INVALID;
+  try {
+    if (left_len + right_len >= n_bases) return -1;  // clip_bases.rs:10-12
+    const size_t left = (size_t)left_len, right = (size_t)right_len, n = (size_t)n_bases, len = n - left - right;
+    std::vector<uint32_t> ops; int64_t rp = ref_pos;
+    if (!clip_bases_cigar(cigar, (size_t)n_ops, left, right, ops, rp)) return TRGT_ERR_INVALID;
+    std::memcpy(out_bases, bases + left, len); std::memcpy(out_quals, quals + left, len);
+    *out_meth_n = -1;
+    if (n_meth >= 0) { std::vector<uint8_t> m; clip_bases_meth(bases, n, meth, (size_t)n_meth, left, right, m); std::copy(m.begin(), m.end(), out_meth); *out_meth_n = (int64_t)m.size(); }
+    std::copy(ops.begin(), ops.end(), out_cigar); *out_n_ops = (int64_t)ops.size(); *out_ref_pos = rp;
+    return (int64_t)len;
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
 }
 
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {

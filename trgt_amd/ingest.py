@@ -35,6 +35,7 @@ class IngestBatch(C.Structure):
                 ("meth", _P8), ("meth_off", _P64), ("has_meth", _P8),
                 ("cigar", _P32), ("cigar_off", _P64), ("cigar_ref_pos", _PI64),
                 ("read_bam4", _P8), ("read_bam4_off", _P64), ("read_bam4_bytes", C.c_uint64),
+                ("n_skipped", C.c_int64), ("skipped_blob", _PC), ("skipped_off", _P64),
                 ("owner", C.c_void_p)]
 
 
@@ -140,6 +141,7 @@ class Reader:
         if b.read_bam4:  # keep_bam4=1: the reads once more as 4-bit codes; bam4_view(batch) is the batch that hands those to the GPU
             out["read_bam4"] = _arr(b.read_bam4, max(int(b.read_bam4_bytes), 1), u8)
             out["read_bam4_off"] = _arr(b.read_bam4_off, max(nr, 1), u64)
+        out["skipped"] = _strings(b.skipped_blob, b.skipped_off, int(b.n_skipped))  # "Error at BED line N: ..." per catalog line without a locus
         if keep_native:  # the writers (trgt_amd/writers.py) take the native batch itself
             out["_native"] = NativeBatch(self._L, h)
         else:
