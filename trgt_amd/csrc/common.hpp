@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -317,6 +318,89 @@ inline int dev_in(trgt_hip_ctx* c, int slot, const T* p, size_t count, const T**
   int rc = dev_get(c, slot, count * sizeof(T), &d);
   if (rc) return rc;
   if (count && (rc = h2d_small(c, d, p, count * sizeof(T), c->stream, slot))) return rc;
+  *out = (const T*)d;
+  return TRGT_OK;
+}
+
+// Several small uploads / fills as ONE dispatch (every dispatch of a call costs 5-30 us of queue time, and a dozen offset tables in front
+// of stage A were 0.35 ms of its critical path): segments are collected with add() / add_fill() and flush() launches one kernel over
+// all of them (blockIdx.y = segment).  Host sources that are not pinned are staged in the slot's pinned buffer first (stage()).
+struct MultiSeg { void* dst; const void* src; size_t bytes; uint32_t fill; };  // src == nullptr: fill with the byte `fill`
+constexpr int MULTI_SEG_MAX = 20;
+struct MultiSegs { MultiSeg s[MULTI_SEG_MAX]; int n; };
+static __global__ void __launch_bounds__(256) multi_copy_kernel(const MultiSegs m) {
+  const MultiSeg g = m.s[blockIdx.y];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+  uint8_t* __restrict__ dst = (uint8_t*)g.dst;
+  if (g.src == nullptr) {
+    const uint32_t f4 = g.fill * 0x01010101u;
+    if (((uintptr_t)dst & 15u) == 0) {
+      const size_t n16 = g.bytes >> 4;
+      for (size_t k = i; k < n16; k += n) reinterpret_cast<uint4*>(dst)[k] = make_uint4(f4, f4, f4, f4);
+      for (size_t k = (n16 << 4) + i; k < g.bytes; k += n) dst[k] = (uint8_t)g.fill;
+    } else for (size_t k = i; k < g.bytes; k += n) dst[k] = (uint8_t)g.fill;
+    return;
+  }
+  const uint8_t* __restrict__ src = (const uint8_t*)g.src;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+    const size_t n16 = g.bytes >> 4;
+    for (size_t k = i; k < n16; k += n) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+    for (size_t k = (n16 << 4) + i; k < g.bytes; k += n) dst[k] = src[k];
+  } else for (size_t k = i; k < g.bytes; k += n) dst[k] = src[k];
+}
+struct UploadBatch {
+  trgt_hip_ctx* c; hipStream_t stream; MultiSegs m;
+  struct Staging { void* pinned; const void* src; size_t bytes; };
+  std::vector<Staging> staging;  // host memcpys still to do (run_staging: the caller may spread them over its threads)
+  UploadBatch(trgt_hip_ctx* c_, hipStream_t s) : c(c_), stream(s) { m.n = 0; }
+  int flush() {
+    run_staging();
+    if (m.n == 0) return TRGT_OK;
+    size_t most = 0;
+    for (int i = 0; i < m.n; ++i) most = std::max(most, m.s[i].bytes);
+    const unsigned bx = (unsigned)std::min<size_t>(128, most / (16 * 256) + 1);
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, (unsigned)m.n), dim3(256), 0, stream, m);
+    m.n = 0;
+    TRGT_HIP_TRY(c, hipGetLastError());
+    return TRGT_OK;
+  }
+  void run_staging() { for (auto& g : staging) std::memcpy(g.pinned, g.src, g.bytes); staging.clear(); }
+  int add_fill(void* dst, size_t bytes, uint8_t value) {
+    if (bytes == 0) return TRGT_OK;
+    if (m.n == MULTI_SEG_MAX) { const int rc = flush(); if (rc) return rc; }
+    m.s[m.n++] = MultiSeg{dst, nullptr, bytes, value};
+    return TRGT_OK;
+  }
+  // src: host memory (pinned, or pageable with stage_slot >= 0: copied into that slot's pinned staging by run_staging / flush)
+  int add(void* dst, const void* src, size_t bytes, int stage_slot) {
+    if (bytes == 0) return TRGT_OK;
+    if (bytes > H2D_KERNEL_MAX) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
+    const void* from = src;
+    if (stage_slot >= 0 && !is_pinned_host_ptr(src)) {
+      if ((int)c->h2d_stage.size() < S_COUNT) c->h2d_stage.resize(S_COUNT);
+      auto& b = c->h2d_stage[(size_t)stage_slot];
+      if (b.cap < bytes) {
+        if (b.p) { TRGT_HIP_TRY(c, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return fail(c, TRGT_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", want); }
+        b.cap = want;
+      }
+      staging.push_back({b.p, src, bytes});
+      from = b.p;
+    }
+    if (m.n == MULTI_SEG_MAX) { const int rc = flush(); if (rc) return rc; }
+    m.s[m.n++] = MultiSeg{dst, from, bytes, 0};
+    return TRGT_OK;
+  }
+};
+// dev_in whose upload joins a batch (valid once the batch is flushed)
+template <typename T>
+inline int dev_in(trgt_hip_ctx* c, int slot, const T* p, size_t count, const T** out, UploadBatch* ub) {
+  if (is_device_ptr(p)) { *out = p; return TRGT_OK; }
+  void* d = nullptr;
+  int rc = dev_get(c, slot, count * sizeof(T), &d);
+  if (rc) return rc;
+  if (count && (rc = ub->add(d, p, count * sizeof(T), slot))) return rc;
   *out = (const T*)d;
   return TRGT_OK;
 }

@@ -885,6 +885,21 @@ __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const 
   for (uint32_t i = 0; i < 3 * n_spans[j]; ++i) dst[i] = src[i];
 }
 
+// exclusive prefix of the span counts (one workgroup): where every job's spans go in the packed array; off[n] = their total
+__global__ void __launch_bounds__(1024) hmm_span_prefix_kernel(const uint32_t* __restrict__ n_spans, uint64_t* __restrict__ off, uint64_t n) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint64_t per = (n + 1023) / 1024, b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+  uint64_t sum = 0;
+  for (uint64_t i = b; i < e; ++i) sum += n_spans[i];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) { uint64_t run = 0; for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; } off[n] = run; }
+  __syncthreads();
+  uint64_t run = part[t];
+  for (uint64_t i = b; i < e; ++i) { off[i] = run; run += n_spans[i]; }
+}
+
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
@@ -1063,6 +1078,8 @@ struct trgt::HmmPending {
   int set = 0; hipStream_t stream = nullptr;  // scratch-buffer set and stream of this batch
   std::vector<uint64_t> cnt_off; std::vector<uint32_t> cnt_n; uint32_t* cnt_user = nullptr; uint64_t cnt_total = 0;  // motif counts go back job by job
   bool spans_on_host = false;
+  // the packed copy of the spans is made behind the kernels at enqueue time (pack_behind_kernels): collect only copies
+  const int32_t* d_packed = nullptr; const uint64_t* d_poff = nullptr; uint64_t packed_cap_bytes = 0;
   std::vector<uint64_t> tight_off;
   std::vector<uint32_t> slot_nm;  // hmm_enqueue_slots: motifs of every slot's set (the job list is only known once the genotyper is back)
   std::vector<uint64_t> slot_cnt_off;
@@ -1073,6 +1090,26 @@ struct trgt::HmmPending {
 };
 
 void trgt::hmm_pending_free(HmmPending* p) { delete p; }
+
+// Behind the kernels of a batch whose spans go to host memory: prefix of the span counts + compaction of the per-job span lists into
+// the back-pointer workspace (free once the kernels are through; at least 16 B per (base, state-row) >= 12 B per possible span).
+// hmm_collect then copies counts, total and the first HMM_PACKED_FIRST bytes of the packed spans in ONE go -- the host used to wait for
+// the counts, build the offsets, upload them, launch the compaction and wait again (0.5 ms of a 10k-locus call's tail).
+constexpr size_t HMM_PACKED_FIRST = 1u << 20;
+static int pack_behind_kernels(trgt_hip_ctx* c, trgt::HmmPending* P, const uint64_t* tight_off_host, int64_t n_jobs, void* d_bp, uint64_t bp_bytes,
+                               const int32_t* d_spans, const uint32_t* d_nsp, int so) {
+  void* d_tabs = nullptr;
+  int rc;
+  if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16 + 16, &d_tabs))) return rc;
+  uint64_t* d_poff = (uint64_t*)d_tabs; uint64_t* d_toff = d_poff + (n_jobs + 1);
+  if ((rc = h2d_small(c, d_toff, tight_off_host, (size_t)n_jobs * 8, c->stream, S_HMM_MOTIFS + so))) return rc;
+  hipLaunchKernelGGL(hmm_span_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, d_nsp, d_poff, (uint64_t)n_jobs);
+  hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, d_spans, (const uint64_t*)d_toff, d_nsp,
+                     (const uint64_t*)d_poff, (int32_t*)d_bp, (uint64_t)n_jobs);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  P->d_packed = (const int32_t*)d_bp; P->d_poff = d_poff; P->packed_cap_bytes = bp_bytes;
+  return TRGT_OK;
+}
 
 int trgt::hmm_batch_impl(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off,
                          const uint32_t* set_motif_begin, int64_t n_jobs, const uint32_t* job_set,
@@ -1274,6 +1311,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
     }
+  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), tight_off.data(), n_jobs, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();
   return TRGT_OK;
 }
@@ -1425,6 +1463,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
     }
+  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), P->tight_off.data(), n_slots, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();
   return TRGT_OK;
 }
@@ -1447,7 +1486,6 @@ int64_t trgt::hmm_slots_resolved(trgt_hip_ctx* c, HmmPending* P, const HmmModels
 int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   if (!pend) return TRGT_OK;  // an empty batch
   std::unique_ptr<HmmPending> P(pend);
-  const int so = P->set ? (int)S_HMM_B_BASE - (int)S_HMM_SEQ : 0;
   struct StreamSwap { trgt_hip_ctx* c; hipStream_t saved; ~StreamSwap() { c->stream = saved; } } stream_swap{c, c->stream};
   c->stream = P->stream;
   const int64_t n_jobs = P->n_jobs;
@@ -1460,31 +1498,29 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
   const auto tl0 = std::chrono::steady_clock::now();
   auto HTL = [&](const char* name, double mb) { if (tl_on) fprintf(stderr, "[tl]   hmm collect %-22s +%6.2f ms  (%.2f MB)\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count(), mb); };
   if (spans_on_host) {
+    // counts, total and the head of the packed spans in one round trip (the compaction ran behind the kernels: pack_behind_kernels)
     std::vector<uint32_t> h_nsp((size_t)n_jobs);
-    { const int d2h_rc = trgt::d2h(c, h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, c->stream); if (d2h_rc) return d2h_rc; }
-    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
-    HTL("span counts on host", (double)n_jobs * 4 / 1e6);
-    std::vector<uint64_t> poff((size_t)n_jobs);
     uint64_t ptotal = 0;
-    for (int64_t j = 0; j < n_jobs; ++j) { poff[(size_t)j] = ptotal; ptotal += h_nsp[(size_t)j]; }
-    void *d_poff = nullptr, *d_toff = nullptr, *d_packed = nullptr;
-    if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16, &d_poff))) return rc;
-    d_toff = (uint8_t*)d_poff + (size_t)n_jobs * 8;
-    if ((rc = dev_get(c, S_HMM_BP + so, (size_t)ptotal * 12 + 16, &d_packed))) return rc;  // the back-pointer workspace is free again
-    {  // (both tables through one staging buffer of the slot: poff | toff)
-      std::vector<uint64_t> both((size_t)n_jobs * 2);
-      std::memcpy(both.data(), poff.data(), (size_t)n_jobs * 8); std::memcpy(both.data() + n_jobs, tight_off.data(), (size_t)n_jobs * 8);
-      if ((rc = h2d_small(c, d_poff, both.data(), (size_t)n_jobs * 16, c->stream, S_HMM_MOTIFS + so))) return rc;
-    }
-    hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)o_spans.dev,
-                       (const uint64_t*)d_toff, (const uint32_t*)o_nsp.dev, (const uint64_t*)d_poff, (int32_t*)d_packed, (uint64_t)n_jobs);
-    TRGT_HIP_TRY(c, hipGetLastError());
-    std::vector<int32_t> h_packed((size_t)ptotal * 3 + 1);
-    { const int d2h_rc = trgt::d2h(c, h_packed.data(), d_packed, (size_t)ptotal * 12, c->stream); if (d2h_rc) return d2h_rc; }
+    const size_t first = (size_t)std::min<uint64_t>(HMM_PACKED_FIRST, P->packed_cap_bytes);
+    std::vector<int32_t> h_packed(first / 4 + 4);
+    { const int d2h_rc = trgt::d2h(c, h_nsp.data(), o_nsp.dev, (size_t)n_jobs * 4, c->stream); if (d2h_rc) return d2h_rc; }
+    { const int d2h_rc = trgt::d2h(c, &ptotal, P->d_poff + n_jobs, 8, c->stream); if (d2h_rc) return d2h_rc; }
+    { const int d2h_rc = trgt::d2h(c, h_packed.data(), P->d_packed, first, c->stream); if (d2h_rc) return d2h_rc; }
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
-    HTL("packed spans on host", (double)ptotal * 12 / 1e6);
-    for (int64_t j = 0; j < n_jobs; ++j)
-      std::memcpy(spans3 + 3 * span_off[j], h_packed.data() + 3 * poff[(size_t)j], (size_t)h_nsp[(size_t)j] * 12);
+    HTL("counts + packed spans on host", (double)((size_t)n_jobs * 4 + first) / 1e6);
+    if (ptotal * 12 > P->packed_cap_bytes) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: %llu spans do not fit the packing workspace", (unsigned long long)ptotal);
+    if (ptotal * 12 > first) {  // the rest (many spans: long alleles of interrupted repeats)
+      h_packed.resize((size_t)ptotal * 3 + 4);
+      { const int d2h_rc = trgt::d2h(c, (uint8_t*)h_packed.data() + first, (const uint8_t*)P->d_packed + first, (size_t)ptotal * 12 - first, c->stream); if (d2h_rc) return d2h_rc; }
+      TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+      HTL("rest of the packed spans", (double)(ptotal * 12 - first) / 1e6);
+    }
+    uint64_t at = 0;
+    for (int64_t j = 0; j < n_jobs; ++j) {
+      std::memcpy(spans3 + 3 * span_off[j], h_packed.data() + 3 * at, (size_t)h_nsp[(size_t)j] * 12);
+      at += h_nsp[(size_t)j];
+    }
+    (void)tight_off; (void)rc;
   }
   std::vector<uint32_t> h_cnt;
   if (P->cnt_user && P->cnt_total) {

@@ -401,7 +401,25 @@ extern "C" void trgt_locus_default_params(trgt_locus_params* p) {  // cli.rs:271
 // drain through one queue in issue order, so a 360 MB upload issued BEFORE a call's own small uploads (offset tables, job lists)
 // holds each of them up until it is through, and nothing overlaps (copy || call = copy + call).  Issued right BEHIND the call's
 // tables it runs next to stage A, which uploads nothing, and is through before the later stages upload their job lists.
+// All contexts of a process send their bulk uploads to a device through ONE stream (TRGT_SHARED_UPLOAD_STREAM=0: each through its own copy
+// stream).  Every stream with copies in flight may get a copy engine of its own; four engines pulling at once keep the link's read queue
+// four times as deep, and everything latency-bound that reads host memory -- queue packets, kernel arguments, the small tables kernels
+// fetch from pinned memory -- waits behind it (measured: see DESIGN.md).
+static std::mutex g_upload_mutex[16];
+static hipStream_t g_upload_stream[16];
+static hipStream_t bulk_upload_stream(trgt_hip_ctx* c) {
+  static const bool shared = [] { const char* e = getenv("TRGT_SHARED_UPLOAD_STREAM"); return !(e && *e == '0'); }();
+  if (!shared) return c->stream_copy;
+  const size_t d = (size_t)c->device % 16;
+  if (!g_upload_stream[d] && hipStreamCreateWithFlags(&g_upload_stream[d], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream_copy; }
+  return g_upload_stream[d];
+}
 static int issue_pending_uploads(trgt_hip_ctx* c) {
+  bool any = false;
+  for (auto& st : c->staged) any = any || (st.in_use && st.copy_pending);
+  if (!any) return TRGT_OK;
+  std::lock_guard<std::mutex> upload_lock(g_upload_mutex[(size_t)c->device % 16]);  // (one batch's pieces stay together in the queue)
+  const hipStream_t up = bulk_upload_stream(c);
   for (auto& st : c->staged) {
     if (!st.in_use || !st.copy_pending) continue;
     st.copy_pending = false;
@@ -410,13 +428,22 @@ static int issue_pending_uploads(trgt_hip_ctx* c) {
       // of a pool queue behind it (TRGT_UPLOAD_CHUNK_MB, default 32; 0 = one command)
       static const size_t piece = [] { const char* e = getenv("TRGT_UPLOAD_CHUNK_MB"); const long v = e && *e ? atol(e) : 32; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
       const size_t total = (size_t)st.read_bytes;
+      // TRGT_UPLOAD_KERNEL=<workgroups>: the read bytes are pulled by a copy KERNEL of that many workgroups instead of the copy engine
+      // (pinned sources only).  The engine keeps the link's read queue full, and every dispatch of every context -- its queue packet and
+      // its arguments are fetched from host memory -- waits behind that queue; a kernel with a bounded number of loads in flight leaves
+      // the queue short.  0 = the copy engine.
+      static const int kernel_wgs = [] { const char* e = getenv("TRGT_UPLOAD_KERNEL"); return e && *e ? atoi(e) : 0; }();
+      if (kernel_wgs > 0 && is_pinned_host_ptr(st.in->read_blob)) {
+        hipLaunchKernelGGL(h2d_copy_kernel, dim3((unsigned)kernel_wgs), dim3(256), 0, up, const_cast<uint8_t*>(st.d_reads), st.in->read_blob, total);
+        TRGT_HIP_TRY(c, hipGetLastError());
+      } else
       for (size_t o = 0; o < total; o += piece ? piece : total) {
         const size_t n = piece ? std::min(piece, total - o) : total;
-        TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_reads) + o, st.in->read_blob + o, n, hipMemcpyHostToDevice, c->stream_copy));
+        TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_reads) + o, st.in->read_blob + o, n, hipMemcpyHostToDevice, up));
       }
     }
-    if (st.d_flank) TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_flank), st.in->flank_blob, (size_t)st.flank_bytes, hipMemcpyHostToDevice, c->stream_copy));
-    TRGT_HIP_TRY(c, hipEventRecord(st.ready, c->stream_copy));
+    if (st.d_flank) TRGT_HIP_TRY(c, hipMemcpyAsync(const_cast<uint8_t*>(st.d_flank), st.in->flank_blob, (size_t)st.flank_bytes, hipMemcpyHostToDevice, up));
+    TRGT_HIP_TRY(c, hipEventRecord(st.ready, up));
   }
   return TRGT_OK;
 }
@@ -505,7 +532,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
   const bool tl_on = c->knobs.timeline;
-#define TL(name) do { if (tl_on) fprintf(stderr, "[tl] %-28s %7.2f ms\n", name, (double)(now_ns() - t0) / 1e6); } while (0)
+#define TL(name) do { if (tl_on) fprintf(stderr, "[tl] %-28s %7.2f ms  ctx=%p\n", name, (double)(now_ns() - t0) / 1e6, (void*)c); } while (0)
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
   int64_t stat_flank_jobs = 0, stat_flank_heavy = 0, stat_cons_jobs = 0, stat_spanning = 0, stat_hmm_jobs = 0, stat_ed_jobs = 0;
   auto init_outputs = [&]() {
@@ -586,11 +613,13 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   else if ((rc = dev_in(c, S_FS_FLANK, in->flank_blob, (size_t)flank_total, &d_flank))) return rc;
   if (staged_reads) d_reads = staged_reads;
   else if ((rc = dev_in(c, S_FS_READS, in->read_blob, (size_t)read_total, &d_reads))) return rc;
-  if ((rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece)) ||
-      (rc = dev_in(c, S_FS_LIST, in->read_off, (size_t)nr, &d_roff)) ||
-      (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen)) ||
-      (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc)) ||
-      (rc = dev_in(c, S_FS_HEAVY, heavy_len.data(), (size_t)nl, &d_heavy)) ||
+  // the offset tables of stage A and of the device genotyper go up as ONE dispatch (a dozen separate ones were 0.35 ms in front of the scan)
+  UploadBatch ub(c, c->stream);
+  if ((rc = dev_in(c, S_FS_JOBS, piece_off.data(), piece_off.size(), &d_piece, &ub)) ||
+      (rc = dev_in(c, S_FS_LIST, in->read_off, (size_t)nr, &d_roff, &ub)) ||
+      (rc = dev_in(c, S_FS_OUT0, in->read_len, (size_t)nr, &d_rlen, &ub)) ||
+      (rc = dev_in(c, S_FS_OUT1, read_locus.data(), (size_t)nr, &d_rloc, &ub)) ||
+      (rc = dev_in(c, S_FS_HEAVY, heavy_len.data(), (size_t)nl, &d_heavy, &ub)) ||
       (rc = pin_get(c, P_CELLS, 64, &h_cells)))
     return rc;
   // Everything stage A hands back to the host lives in ONE device slab mirrored by ONE pinned slab, so that it comes back in a single
@@ -621,10 +650,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   } g;
   struct GtHost { void *need = nullptr, *nal = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr, *toff = nullptr, *packed = nullptr; } gh;
   if (dev_gt) {
-    if ((rc = dev_in(c, S_GT_LRB, in->locus_read_begin, (size_t)nl + 1, &g.lrb)) || (rc = dev_in(c, S_GT_PLOIDY, in->ploidy, (size_t)nl, &g.ploidy)) ||
-        (rc = dev_in(c, S_GT_TR, in->tr_blob, (size_t)tr_total, &g.tr)) || (rc = dev_in(c, S_GT_TROFF, in->tr_off, (size_t)nl, &g.tr_off)) ||
-        (rc = dev_in(c, S_GT_TRLEN, in->tr_len, (size_t)nl, &g.tr_len)) || (rc = dev_in(c, S_GT_ALOFF, out->allele_off, 2 * (size_t)nl, &g.al_off)) ||
-        (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap)) ||
+    if ((rc = dev_in(c, S_GT_LRB, in->locus_read_begin, (size_t)nl + 1, &g.lrb, &ub)) || (rc = dev_in(c, S_GT_PLOIDY, in->ploidy, (size_t)nl, &g.ploidy, &ub)) ||
+        (rc = dev_in(c, S_GT_TR, in->tr_blob, (size_t)tr_total, &g.tr, &ub)) || (rc = dev_in(c, S_GT_TROFF, in->tr_off, (size_t)nl, &g.tr_off, &ub)) ||
+        (rc = dev_in(c, S_GT_TRLEN, in->tr_len, (size_t)nl, &g.tr_len, &ub)) || (rc = dev_in(c, S_GT_ALOFF, out->allele_off, 2 * (size_t)nl, &g.al_off, &ub)) ||
+        (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap, &ub)) ||
         (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)))
       return rc;
     g.need = dsl(o_need); g.nal = dsl(o_nal); g.alen = dsl(o_alen); g.ci = dsl(o_ci); g.nsp = dsl(o_nsp); g.cls = dsl(o_cls); g.rank = dsl(o_rank);
@@ -632,6 +661,15 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     gh.need = hsl(o_need); gh.nal = hsl(o_nal); gh.alen = hsl(o_alen); gh.ci = hsl(o_ci); gh.nsp = hsl(o_nsp); gh.cls = hsl(o_cls); gh.rank = hsl(o_rank);
     gh.nspan = hsl(o_nspan); gh.toff = hsl(o_toff);
   }
+  if (!ub.staging.empty()) {  // the host copies into pinned staging, spread over the pool's threads
+    auto& st = ub.staging;
+    constexpr size_t PIECE = 256 << 10;
+    std::vector<std::array<size_t, 3>> parts;  // staging index, offset, bytes
+    for (size_t i = 0; i < st.size(); ++i) for (size_t o = 0; o < st[i].bytes; o += PIECE) parts.push_back({i, o, std::min(PIECE, st[i].bytes - o)});
+    pool->parallel_for((int64_t)parts.size(), 1, [&](int64_t k, int) { const auto& q = parts[(size_t)k]; std::memcpy((uint8_t*)st[q[0]].pinned + q[1], (const uint8_t*)st[q[0]].src + q[1], q[2]); });
+    st.clear();
+  }
+  if ((rc = ub.flush())) return rc;
   c->dbg_ns[1] = now_ns() - t0;  // + uploads of the offset tables, buffer (re)allocation
   TL("tables uploaded, buffers ready");
   trgt_span_params sp; sp.flank_len = F; sp.min_flank_id_frac = p->min_flank_id_frac; sp.mism = p->mism; sp.gapo = p->gapo; sp.gape = p->gape;

@@ -30,6 +30,7 @@ struct ScanArgs {
   uint64_t n_jobs;             // 2 * n_reads
   int32_t flank_len;
   int32_t* pos;                // [n_jobs] leftmost exact start or -1
+  int32_t* n_match;            // [n_jobs] initialised to -1 here (the alignment kernels fill in the jobs they run)
   JobDev* wfa_jobs; uint32_t* wfa_count;  // fallback alignments: two-ended job list.  Reads shorter than heavy_len[locus] cannot hold
                                           // both flanks: their alignments run to high scores and cost 10-100x the others, so they
                                           // are appended from the front (wfa_count[0]) and drained first; the rest from the back
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
     }
   }
   if (lane == 0) {
-    a.pos[j] = found;
+    a.pos[j] = found; a.n_match[j] = -1;
     if (found < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
       const bool lng = (uint32_t)n > a.long_tlen;
       const uint32_t slot = atomicAdd(a.wfa_count + (lng ? 1 : 0), 1u);
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
   if (lane == 0) {
     for (int side = 0; side < 2; ++side) {
       const uint64_t j = 2 * r + side;
-      a.pos[j] = found[side];
+      a.pos[j] = found[side]; a.n_match[j] = -1;
       if (found[side] < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
         JobDev jd;
         jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
@@ -448,10 +449,9 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
     return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 32, c->stream));
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_nmatch, 0xFF, n_jobs * 4, c->stream));
   ScanArgs sa;
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
-  sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos;
+  sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos; sa.n_match = (int32_t*)d_nmatch;
   sa.wfa_jobs = (JobDev*)d_wjobs; sa.wfa_count = (uint32_t*)d_count;
   sa.heavy_len = d_heavy_len; sa.jobs_cap = (uint32_t)n_jobs;
   // reads up to long_tlen keep the dedicated kernel at 4 workgroups per CU (LDS: ring + windows <= ~39 KB per alignment)
