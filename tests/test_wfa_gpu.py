@@ -306,3 +306,34 @@ def test_biwfa_cigars_are_valid_and_optimal_without_the_oracle(W):
                 assert int(got["score"][j]) == -cost, (j, int(got["score"][j]), cost)
             if heuristic is not None:
                 assert cost == _plain_affine_global(p, t, x, o, e), (j, cost)
+
+
+@pytest.mark.parametrize("kb", [3, 7, 18])
+def test_lds_arena_variant_of_the_biwfa_kernel_gives_the_same_results(W, kb):
+    """TRGT_WFA_LDS=1: BiWFA batches of one wave per alignment first meet the LDS-arena variant of the kernel (wavefronts, descriptor
+    rings and run-length buffers in LDS); what does not fit its budget -- here made small enough that much does not -- is redone by the
+    HBM-arena variant.  Same engine code on the same inputs: status, score and CIGAR must not depend on where an alignment ran."""
+    from trgt_amd import _lib
+    rng = np.random.default_rng(77 + kb)
+    pats, txts = [], []
+    for i in range(400):
+        n = int(rng.integers(1, 420)) if i % 9 else int(rng.integers(500, 1100))
+        a = rand_dna(rng, n) if i % 5 else repeat_allele(rng, [b"CAG", b"CCG"], n, err=0.0)
+        b = mutate(rng, a, *[(0.002, 0.001, 0.001), (0.02, 0.01, 0.01), (0.08, 0.04, 0.04)][i % 3])
+        if i % 17 == 0:
+            b = rand_dna(rng, int(rng.integers(1, 300)))  # unrelated: high scores, wide wavefronts
+        pats.append(bytes(a)); txts.append(bytes(b) or b"A")
+    lds = _lib.context_with_env(TRGT_WFA_LDS=1, TRGT_WFA_LDS_KB=kb, TRGT_WFA_LDS_SEQ=640)
+    try:
+        for build in (lambda c: W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(2, 5, 1).build(ctx=c),
+                      lambda c: W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(2, 5, 1).with_heuristic(W.Heuristic.none()).build(ctx=c),
+                      lambda c: W.WFAligner.builder(W.AlignmentScope.Score, W.MemoryModel.MemoryUltraLow).edit().build(ctx=c)):
+            want = build(None).align_end_to_end_batch(pats, txts, want_ops=False)
+            got = build(lds).align_end_to_end_batch(pats, txts, want_ops=False)
+            assert np.array_equal(got["status"], want["status"]) and np.array_equal(got["score"], want["score"])
+            assert np.array_equal(got["cigar_len"], want["cigar_len"]) and np.array_equal(got["n_match"], want["n_match"])
+            for j in range(len(pats)):
+                o, n = int(got["cigar_off"][j]), int(got["cigar_len"][j])
+                assert np.array_equal(got["cigar"][o:o + n], want["cigar"][int(want["cigar_off"][j]):int(want["cigar_off"][j]) + n]), j
+    finally:
+        lds.close()

@@ -27,7 +27,7 @@ struct Group {  // one backbone and its members = jobs [job_first, job_first + n
   uint64_t scratch_off;  // in 32-bit words: 3 (bb_len + 1) vote words (when they do not fit LDS) | 3 n_members words of insert records
 };
 struct VoteArgs {
-  const Group* groups; uint32_t n_groups;
+  const Group* groups; uint32_t n_groups; const uint32_t* n_groups_dev;  // n_groups_dev != nullptr: the count is read there (the grid is an upper bound)
   const uint8_t* seqs; const trgt::JobDev* jobs; const uint32_t* cigar; const uint32_t* cigar_len;
   uint32_t* scratch; uint8_t* out; uint32_t* out_len;  // out_len: 0xFFFFFFFF when the result does not fit out_cap
 };
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(VOTE_THREADS) consensus_vote_kernel(const Vote
   __shared__ uint32_t l_scan[VOTE_THREADS / 64 + 1];
   __shared__ uint32_t l_carry, l_top_member, l_top_count, l_k;
   const uint32_t g = blockIdx.x;
-  if (g >= a.n_groups) return;
+  if (g >= (a.n_groups_dev ? *a.n_groups_dev : a.n_groups)) return;
   const Group grp = a.groups[g];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t L = grp.bb_len, n = grp.n_members;

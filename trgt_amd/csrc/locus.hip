@@ -23,6 +23,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <functional>
 #include <thread>
@@ -282,6 +283,9 @@ bool flank_simple_consensus(const std::vector<Seg>& seqs, Seg& best, double& fre
 }
 
 #include "consensus_vote.hpp"
+static_assert(sizeof(vote::Group) == sizeof(gt::RGroup) && offsetof(vote::Group, bb_off) == offsetof(gt::RGroup, bb_off) &&
+              offsetof(vote::Group, out_off) == offsetof(gt::RGroup, out_off) && offsetof(vote::Group, scratch_off) == offsetof(gt::RGroup, scratch_off) &&
+              offsetof(vote::Group, out_cap) == offsetof(gt::RGroup, out_cap), "gt::RGroup mirrors vote::Group");
 
 // make_consensus / repair_consensus (consensus.rs:5-111) for a batch of groups: the members of group g are jobs [first[g], first[g + 1])
 // of ONE alignment batch (BiWFA, gap-affine 2,5,1, default heuristic: THREAD_WFA_CONSENSUS, genotype.rs:82-86), each against the
@@ -322,7 +326,7 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
       (rc = dev_get(c, S_VOTE_OUT, (size_t)out_total + 16, &d_out)) || (rc = dev_get(c, S_VOTE_LEN, n_groups * 4, &d_len)))
     return rc;
   if ((rc = h2d_small(c, d_groups, groups.data(), n_groups * sizeof(vote::Group), c->stream, S_VOTE_GROUPS))) return rc;
-  vote::VoteArgs va{(const vote::Group*)d_groups, (uint32_t)n_groups, dev.seqs, dev.jobs, dev.cigar, dev.cigar_len, (uint32_t*)d_scratch, (uint8_t*)d_out, (uint32_t*)d_len};
+  vote::VoteArgs va{(const vote::Group*)d_groups, (uint32_t)n_groups, nullptr, dev.seqs, dev.jobs, dev.cigar, dev.cigar_len, (uint32_t*)d_scratch, (uint8_t*)d_out, (uint32_t*)d_len};
   hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)n_groups), dim3(vote::VOTE_THREADS), 0, c->stream, va);
   TRGT_HIP_TRY(c, hipGetLastError());
   std::vector<uint32_t> lens(n_groups);
@@ -338,6 +342,35 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
 }
 
 #include "locus_cluster.hpp"
+
+// developer aid (TRGT_REPAIR_CHECK=1): the job list the genotyper wrote for the device-side repair, checked before the alignment kernel reads it
+__global__ void repair_check_kernel(const gt::RepairBufs rp, uint64_t read_bytes) {
+  const uint32_t nj = rp.counts[gt::RC_JOBS], ng = rp.counts[gt::RC_GROUPS];
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += gridDim.x * blockDim.x) {
+    const JobDev jd = rp.jobs[j];
+    const bool bad = jd.pat_len > rp.max_seg || jd.txt_len > rp.max_seg || jd.pat_off + jd.pat_len > read_bytes || jd.txt_off + jd.txt_len > read_bytes ||
+                     jd.cigar_off + jd.pat_len + jd.txt_len + 1 > rp.cap_cigar || jd.out_index != j;
+    if (bad) { atomicAdd(rp.counts + 10, 1u); rp.counts[11] = j; rp.counts[12] = jd.pat_len; rp.counts[13] = jd.txt_len; rp.counts[14] = jd.out_index; rp.counts[15] = (uint32_t)jd.cigar_off; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (nj > rp.cap_jobs || ng > rp.cap_groups)) atomicAdd(rp.counts + 10, 1000000u);
+}
+
+static uint32_t* g_trace_dump = nullptr;
+static uint32_t* repair_trace_buf() {
+  if (!getenv("TRGT_REPAIR_TRACE")) return nullptr;
+  if (!g_trace_dump) (void)hipHostMalloc((void**)&g_trace_dump, 4096, hipHostMallocDefault);
+  return g_trace_dump;
+}
+// developer aid (TRGT_REPAIR_TRACE=1): the repair counters and the first jobs as the GPU sees them right behind the genotyper, written to
+// pinned host memory (readable after a later device fault)
+__global__ void repair_trace_kernel(const gt::RepairBufs rp, uint32_t* host) {
+  if (threadIdx.x < gt::RC_WORDS) host[threadIdx.x] = __hip_atomic_load(rp.counts + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 8) { const JobDev jd = rp.jobs[threadIdx.x]; uint32_t* h = host + 16 + 8 * threadIdx.x;
+    h[0] = (uint32_t)jd.pat_off; h[1] = jd.pat_len; h[2] = (uint32_t)jd.txt_off; h[3] = jd.txt_len; h[4] = (uint32_t)jd.cigar_off; h[5] = jd.out_index; h[6] = (uint32_t)(jd.pat_off >> 32); h[7] = (uint32_t)(jd.txt_off >> 32); }
+  __threadfence_system();
+}
+// counters that kernels bump with atomics are zeroed the same way (device-scope atomic stores), not with hipMemsetAsync: see DESIGN.md
+__global__ void zero_words_kernel(uint32_t* p, uint32_t n) { for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicExch(p + i, 0u); }
 
 struct GatherArgs { const uint8_t* reads; const uint64_t* src_off; const uint64_t* dst_off; const uint32_t* len; uint64_t n; uint8_t* out; };
 __global__ void gather_segments_kernel(const GatherArgs a) {  // one wavefront per segment
@@ -629,11 +662,12 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     size_t add(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
   } slab;
   const size_t o_ss = slab.add((size_t)nr * 4), o_se = slab.add((size_t)nr * 4), o_hl = slab.add((size_t)nr), o_hr = slab.add((size_t)nr);
-  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0;
+  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0, o_gsz = 0, o_rpc = 0;
   if (dev_gt) {
     o_need = slab.add((size_t)nl); o_nal = slab.add((size_t)nl * 4); o_alen = slab.add(2 * (size_t)nl * 4); o_ci = slab.add(4 * (size_t)nl * 4);
     o_nsp = slab.add(2 * (size_t)nl * 4); o_cls = slab.add((size_t)nr * 4); o_rank = slab.add((size_t)nr * 4); o_nspan = slab.add((size_t)nl * 4);
     o_toff = slab.add((2 * (size_t)nl + 1) * 8); o_flip = slab.add((size_t)nl);
+    o_gsz = slab.add(2 * (size_t)nl * 4); o_rpc = slab.add(gt::RC_WORDS * 4);
   }
   void *d_slab = nullptr, *h_slab = nullptr;
   if ((rc = dev_get(c, S_LOCUS_4, slab.total, &d_slab)) || (rc = pin_get(c, P_SPAN_S, slab.total, &h_slab))) return rc;
@@ -699,9 +733,79 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     ga.need_host = (uint8_t*)g.need; ga.n_alleles = (int32_t*)g.nal; ga.allele_blob = (uint8_t*)g.blob; ga.allele_len = (uint32_t*)g.alen;
     ga.ci = (int32_t*)g.ci; ga.num_spanning = (int32_t*)g.nsp; ga.classification = (int32_t*)g.cls; ga.read_rank = (int32_t*)g.rank;
     ga.n_spanning_reads = (uint32_t*)g.nspan; ga.flipped = (uint8_t*)dsl(o_flip);
-    if (max_locus_reads <= 64) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
+    ga.gt_size = (int32_t*)dsl(o_gsz);
+    // ---- stage B on the device for the loci whose pick lacks majority support (locus_gt.hpp): job list, vote groups and the
+    //      record of the decisions are written by the genotyper; the alignment kernel, the column voting and the finishing kernel
+    //      follow on the same stream, and the host first hears of these loci when they are done.  TRGT_HOST_REPAIR=1: the host path.
+    gt::RepairBufs& rp = ga.rp;
+    std::memset(&rp, 0, sizeof rp);
+    void *d_vout = nullptr, *d_vlen = nullptr, *d_vscr = nullptr, *d_rcig = nullptr, *d_rclen = nullptr;
+    const bool dev_repair = !c->knobs.host_repair;
+    if (dev_repair) {
+      { void* d_cnt = nullptr; if ((rc = dev_get(c, S_RP_COUNTS, 256, &d_cnt))) return rc; rp.counts = (uint32_t*)d_cnt; }
+      rp.cap_groups = (uint32_t)std::min<int64_t>(2 * nl, 0x7FFFFFFF); rp.cap_jobs = (uint32_t)nr;
+      rp.max_seg = (uint32_t)std::max(16, c->knobs.repair_max_seg); rp.vote_lds_pos = (uint32_t)vote::VOTE_LDS_POS;
+      // room for the typical batch (a few per cent of the loci, segments of a few hundred bases); a locus that finds none takes the host path
+      rp.cap_cigar = std::min<uint64_t>((uint64_t)nr * (2ull * rp.max_seg + 1), 32ull << 20);       // words
+      rp.cap_out = std::min<uint64_t>((uint64_t)nr * (rp.max_seg + 16ull) + 64, 256ull << 20);      // bytes
+      rp.cap_scratch = std::min<uint64_t>(3ull * (uint64_t)nr + 3ull * (uint64_t)rp.cap_groups * (rp.max_seg + 1ull) + 64, 32ull << 20);  // words
+      void *d_g = nullptr, *d_j = nullptr, *d_l = nullptr, *d_p = nullptr;
+      if ((rc = dev_get(c, S_RP_GROUPS, (size_t)rp.cap_groups * sizeof(gt::RGroup), &d_g)) || (rc = dev_get(c, S_RP_JOBS, (size_t)rp.cap_jobs * sizeof(JobDev), &d_j)) ||
+          (rc = dev_get(c, S_RP_LOCI, (size_t)nl * 4, &d_l)) || (rc = dev_get(c, S_RP_PEND, (size_t)nl * sizeof(gt::RepairPend), &d_p)) ||
+          (rc = dev_get(c, S_RP_CIGAR, (size_t)rp.cap_cigar * 4, &d_rcig)) || (rc = dev_get(c, S_RP_CLEN, (size_t)rp.cap_jobs * 4, &d_rclen)) ||
+          (rc = dev_get(c, S_RP_VOUT, (size_t)rp.cap_out + 16, &d_vout)) || (rc = dev_get(c, S_RP_VLEN, (size_t)rp.cap_groups * 4, &d_vlen)) ||
+          (rc = dev_get(c, S_RP_VSCR, (size_t)rp.cap_scratch * 4 + 16, &d_vscr)))
+        return rc;
+      rp.groups = (gt::RGroup*)d_g; rp.jobs = (JobDev*)d_j; rp.loci = (uint32_t*)d_l; rp.pend = (gt::RepairPend*)d_p;
+      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, rp.counts, (uint32_t)gt::RC_WORDS);
+    }
+    const bool small_gt = max_locus_reads <= 64;
+    if (small_gt) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     else hipLaunchKernelGGL((gt::locus_genotype_kernel<gt::GT_MAX_READS, gt::GT_SEG_LDS>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     TRGT_HIP_TRY(c, hipGetLastError());
+    if (dev_repair) {
+      trgt_wfa_params wp;
+      trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86): BiWFA, gap-affine 2,5,1, default heuristic
+      wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+      WfaLaunch LR;
+      // (n_jobs_host bounds the workgroups and their workspaces, not the jobs: the count is read on the device)
+      LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, 2048); LR.n_jobs_dev = rp.counts + gt::RC_JOBS;
+      LR.pat_base = d_reads; LR.txt_base = d_reads;
+      LR.max_plen = rp.max_seg; LR.max_tlen = rp.max_seg; LR.max_sum = 2 * (int64_t)rp.max_seg;
+      LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2;
+      auto dbg_sync = [&](const char* what) -> int {  // TRGT_WFA_DEBUG: which kernel of the chain a device fault belongs to
+        if (!c->knobs.debug) return TRGT_OK;
+        const hipError_t e = trgt::stream_wait(c, c->stream);
+        uint32_t h[gt::RC_WORDS]; std::memset(h, 0, sizeof h);
+        if (e == hipSuccess) (void)hipMemcpy(h, rp.counts, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[repair] %s: %s (groups %u jobs %u loci %u failed %u cigar words %llu)\n", what, hipGetErrorString(e), h[gt::RC_GROUPS], h[gt::RC_JOBS], h[gt::RC_LOCI], h[gt::RC_FAILED],
+                (unsigned long long)h[gt::RC_CIGAR] | ((unsigned long long)h[gt::RC_CIGAR + 1] << 32));
+        return e == hipSuccess ? TRGT_OK : fail(c, TRGT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+      };
+      if ((rc = dbg_sync("genotyper"))) return rc;
+      if (uint32_t* trace_host = repair_trace_buf()) { std::memset(trace_host, 0, 4096); hipLaunchKernelGGL(repair_trace_kernel, dim3(1), dim3(64), 0, c->stream, rp, trace_host); }
+      static const bool repair_check = getenv("TRGT_REPAIR_CHECK") != nullptr;
+      if (repair_check) {
+        hipLaunchKernelGGL(repair_check_kernel, dim3(64), dim3(256), 0, c->stream, rp, (uint64_t)read_total);
+        uint32_t h[gt::RC_WORDS];
+        (void)trgt::stream_wait(c, c->stream);
+        (void)hipMemcpy(h, rp.counts, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[repair check] jobs %u groups %u loci %u bad %u (last bad job %u: plen %u tlen %u out_index %u cigar_off %u) caps: jobs %u cigar %llu max_seg %u read bytes %llu\n", h[1], h[0], h[2], h[10], h[11], h[12], h[13],
+                h[14], h[15], rp.cap_jobs, (unsigned long long)rp.cap_cigar, rp.max_seg, (unsigned long long)read_total);
+      }
+      if ((rc = wfa_launch(c, wp, LR))) return rc;
+      if ((rc = dbg_sync("consensus alignments"))) return rc;
+      vote::VoteArgs va{(const vote::Group*)rp.groups, 0u, rp.counts + gt::RC_GROUPS, d_reads, rp.jobs, (const uint32_t*)d_rcig, (const uint32_t*)d_rclen,
+                        (uint32_t*)d_vscr, (uint8_t*)d_vout, (uint32_t*)d_vlen};
+      hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)rp.cap_groups), dim3(vote::VOTE_THREADS), 0, c->stream, va);
+      const gt::FinishArgs fa{(const uint8_t*)d_vout, (const uint32_t*)d_vlen};
+      const dim3 fgrid((unsigned)nl);
+      if (small_gt) hipLaunchKernelGGL((gt::repair_finish_kernel<64>), fgrid, dim3(64), 0, c->stream, ga, fa);
+      else hipLaunchKernelGGL((gt::repair_finish_kernel<gt::GT_MAX_READS>), fgrid, dim3(64), 0, c->stream, ga, fa);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      if ((rc = dbg_sync("vote + finish"))) return rc;
+      TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_rpc), rp.counts, gt::RC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
+    } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_rpc), 0, gt::RC_WORDS * 4, c->stream));
     hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
@@ -742,7 +846,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
 
   // ---------------- wait for the GPU, publish spans
   {
-    TRGT_HIP_TRY(c, trgt::event_wait(evA));
+    { const hipError_t ea = trgt::event_wait(evA);
+      if (g_trace_dump && getenv("TRGT_REPAIR_TRACE")) { const uint32_t* h = g_trace_dump; fprintf(stderr, "[repair trace] evA %s counts:", hipGetErrorString(ea)); for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", h[i]);
+        fprintf(stderr, "\n"); }
+      if (ea != hipSuccess) return trgt::fail(c, TRGT_ERR_HIP, "trgt::event_wait(evA) failed: %s", hipGetErrorString(ea)); }
     if (stage_a_token.owns_lock()) stage_a_token.unlock();
     tA = now_ns() - tw_a;
   TL("evA");
@@ -767,6 +874,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       });
     }
     for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
+    stat_cons_jobs += (int64_t)((const uint32_t*)hsl(o_rpc))[gt::RC_JOBS];  // consensus alignments of the device-side repair
   }
   else { R.resize((size_t)nl); for (int64_t l = 0; l < nl; ++l) R[(size_t)l] = l; }
   const int64_t nR = (int64_t)R.size();
@@ -993,10 +1101,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     const uint8_t* need = (const uint8_t*)gh.need;
     const uint64_t* toff = (const uint64_t*)gh.toff; const uint8_t* packed = (const uint8_t*)gh.packed;
     const uint8_t* dev_flip = (const uint8_t*)hsl(o_flip);
+    const int32_t* dev_gsz = (const int32_t*)hsl(o_gsz);
     pool->parallel_for(nl, 256, [&](int64_t l, int) {
       if (out->flipped) out->flipped[l] = need[l] ? 0 : dev_flip[l];
       // (alleles the device genotyper settles have majority support: their length is the genotype's size)
-      if (out->gt_size) { out->gt_size[2 * l] = need[l] ? 0 : (int32_t)out->allele_len[2 * l]; out->gt_size[2 * l + 1] = need[l] ? 0 : (int32_t)out->allele_len[2 * l + 1]; }
+      if (out->gt_size) { out->gt_size[2 * l] = need[l] ? 0 : dev_gsz[2 * l]; out->gt_size[2 * l + 1] = need[l] ? 0 : dev_gsz[2 * l + 1]; }
       if (need[l]) { out->n_alleles[l] = 0; out->allele_len[2 * l] = out->allele_len[2 * l + 1] = 0; return; }
       for (int a = 0; a < out->n_alleles[l]; ++a)
         std::memcpy(out->allele_blob + out->allele_off[2 * l + a], packed + toff[2 * l + a], out->allele_len[2 * l + a]);
@@ -1071,7 +1180,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       rc = consensus_repair_batch(c, (int64_t)jrefs.size(), cblob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), rep_first, repaired, &overlap);
       if (rc) return rc;
       for (size_t g = 0; g < rep_of.size(); ++g) rep_of[g]->result.swap(repaired[g]);
-      stat_cons_jobs = (int64_t)jrefs.size();
+      stat_cons_jobs += (int64_t)jrefs.size();
     }
     // ---- Genotyper::Cluster loci: distance matrix, Ward linkage, consensus rounds, outlier assignment (locus_cluster.hpp)
     if (!cl_loci.empty()) {

@@ -10,6 +10,7 @@
 // operation for operation like the host version in locus.hip, which the oracle pins.
 #pragma once
 #include "common.hpp"
+#include "wfa_host.hpp"
 
 namespace trgt {
 namespace gt {
@@ -18,6 +19,27 @@ namespace gt {
 // per locus, i.e. 14 instead of 5 loci in flight per CU for a kernel that is all latency (0.53 -> 0.3 ms on the 10k-locus batch).
 constexpr int GT_MAX_READS = 256;      // reads of a locus (and therefore kept spanning reads) handled by the large instantiation
 constexpr int GT_SEG_LDS = 16 * 1024;  // bytes of repeat segments staged per locus (large instantiation)
+
+// ---- consensus repair on the device (genotype_size.rs:32-37 -> utils::align -> repair_consensus, consensus.rs:5-111): a locus whose pick
+// lacks majority support no longer goes back to the host.  The genotyper writes the consensus alignments it needs (backbone = the pick,
+// texts = the unique sequences of the allele's group, all of them segments of the read blob) into a job list, one vote group per allele
+// and a record of what it had decided; behind it run the alignment kernel over that list, the column voting and repair_finish_kernel,
+// which classifies the reads against the repaired alleles and writes the locus out.  Space is handed out with atomic counters; a locus
+// that finds no room (or is out of the envelope: a segment longer than max_seg) takes the host path as before.
+struct RGroup {  // = vote::Group (consensus_vote.hpp; the layouts are asserted equal in locus.hip)
+  uint32_t job_first, n_members, bb_len, out_cap;
+  uint64_t bb_off, out_off, scratch_off;
+};
+struct RepairPend {  // what the genotyper had decided for a locus that waits for its repaired alleles
+  int32_t n_gt, n_pick; uint32_t size[2]; int32_t civ[4]; int32_t rep[2] /* rank of the pick */; int32_t grp[2] /* vote group, -1: the pick stands */;
+};
+enum { RC_GROUPS = 0, RC_JOBS = 1, RC_LOCI = 2, RC_FAILED = 3, RC_CIGAR = 4 /* u64 */, RC_OUT = 6 /* u64 */, RC_SCRATCH = 8 /* u64 */, RC_WORDS = 16 };
+struct RepairBufs {
+  uint32_t* counts;  // [RC_WORDS]; nullptr: no device-side repair (every such locus takes the host path)
+  RGroup* groups; JobDev* jobs; uint32_t* loci; RepairPend* pend;
+  uint32_t cap_groups, cap_jobs, max_seg, vote_lds_pos;
+  uint64_t cap_cigar, cap_out, cap_scratch;
+};
 
 struct GtArgs {
   const uint8_t* reads; const uint64_t* read_off; const uint32_t* read_len; const uint64_t* locus_read_begin;
@@ -28,6 +50,8 @@ struct GtArgs {
   uint8_t* need_host; int32_t* n_alleles; uint8_t* allele_blob; uint32_t* allele_len; int32_t* ci; int32_t* num_spanning;
   int32_t* classification; int32_t* read_rank; uint32_t* n_spanning_reads;
   uint8_t* flipped;  // per locus: the two alleles were swapped to put the reference allele first
+  int32_t* gt_size;  // [2 n_loci] TrSize::size of the genotype behind every allele (optional)
+  RepairBufs rp;
 };
 
 template <int MAXR, int SEG>
@@ -42,6 +66,8 @@ struct GtShared {
   int n, n_sizes, bail;
   // decisions of lane 0, written out by the whole wave
   int res_n_gt, res_flip, res_rep[2], res_ci[4], res_hap[2];
+  // device-side repair: reservations of lane 0
+  int rp_ok; uint32_t rp_g0, rp_j0; unsigned long long rp_c0, rp_o0, rp_s0;
   uint32_t ref_off;                                    // the reference repeat staged behind the segments
   alignas(16) uint8_t bytes[SEG];
 };
@@ -84,34 +110,17 @@ __device__ __forceinline__ void copy16(uint8_t* dst, const uint8_t* __restrict__
   for (uint32_t b = full * 16 + (uint32_t)sub; b < n; b += 16) dst[b] = src[b];
 }
 
-template <int MAXR, int SEG>
-__global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  // exactly one wave per locus: the lane-0 sections and the ballots rely on it
-  __shared__ GtShared<MAXR, SEG> sh;
-  const int64_t l = blockIdx.x;
-  if (l >= a.n_loci) return;
-  const int lane = threadIdx.x;
-  const uint64_t r0 = a.locus_read_begin[l], r1 = a.locus_read_begin[l + 1];
-  const int nr = (int)(r1 - r0);
+// get_spanning_reads (tr.rs:111-184) for one locus by one wave: filter, stable sort by span length, uniform downsample.  On return
+// sh.n kept reads sit in sh.s_read / s_start / s_len in LocusResult.reads order (sh.r_off: blob offsets of all reads of the locus).
+template <int MAXR, class SH>
+__device__ __forceinline__ void gt_front(SH& sh, const GtArgs& a, uint64_t r0, int nr, int lane) {
   const int F = a.flank_len;
-  if (lane == 0) {
-    sh.n = 0; sh.bail = 0; sh.res_n_gt = 0;
-    a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0; a.flipped[l] = 0;
-    a.allele_len[2 * l] = a.allele_len[2 * l + 1] = 0; a.num_spanning[2 * l] = a.num_spanning[2 * l + 1] = 0;
-  }
-  if (a.ploidy[l] == 0 || nr == 0 || nr > MAXR) {  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31); oversized -> host
-    for (int i = lane; i < nr; i += 64) { a.classification[r0 + i] = -1; a.read_rank[r0 + i] = -1; }
-    if (lane == 0 && nr > MAXR && a.ploidy[l] != 0) a.need_host[l] = 1;
-    return;
-  }
-  // ---- everything the decisions need is fetched from HBM by all lanes, once
   for (int i = lane; i < nr; i += 64) {
     const int32_t s = a.span_start[r0 + i], e = a.span_end[r0 + i];
     const bool keep = s >= 0 && s >= F && (int64_t)a.read_len[r0 + i] - e >= F;  // filter of get_spanning_reads (tr.rs:139-145)
     sh.r_s[i] = keep ? (uint32_t)s : 0xFFFFFFFFu; sh.r_len[i] = keep ? (uint32_t)(e - s) : 0u;
     sh.r_off[i] = a.read_off[r0 + i];
   }
-  const uint32_t refn = a.tr_len[l];
-  const uint64_t refo = a.tr_off[l];
   __syncthreads();
   if (lane == 0) {  // in read order
     int n = 0;
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
     sh.n = n;
   }
   __syncthreads();
-  int n = sh.n;
+  const int n = sh.n;
   if (n > 0) {
     // ---- stable sort by span length (:157): rank = #{shorter} + #{equal and earlier}; every lane owns elements lane, lane+64, ...
     {
@@ -156,6 +165,36 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
         }
         sh.n = a.max_depth;
       }
+    }
+    __syncthreads();
+  }
+}
+
+template <int MAXR, int SEG>
+__global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  // exactly one wave per locus: the lane-0 sections and the ballots rely on it
+  __shared__ GtShared<MAXR, SEG> sh;
+  const int64_t l = blockIdx.x;
+  if (l >= a.n_loci) return;
+  const int lane = threadIdx.x;
+  const uint64_t r0 = a.locus_read_begin[l], r1 = a.locus_read_begin[l + 1];
+  const int nr = (int)(r1 - r0);
+  if (lane == 0) {
+    sh.n = 0; sh.bail = 0; sh.res_n_gt = 0;
+    if (a.gt_size) a.gt_size[2 * l] = a.gt_size[2 * l + 1] = 0;
+    a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0; a.flipped[l] = 0;
+    a.allele_len[2 * l] = a.allele_len[2 * l + 1] = 0; a.num_spanning[2 * l] = a.num_spanning[2 * l + 1] = 0;
+  }
+  if (a.ploidy[l] == 0 || nr == 0 || nr > MAXR) {  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31); oversized -> host
+    for (int i = lane; i < nr; i += 64) { a.classification[r0 + i] = -1; a.read_rank[r0 + i] = -1; }
+    if (lane == 0 && nr > MAXR && a.ploidy[l] != 0) a.need_host[l] = 1;
+    return;
+  }
+  gt_front<MAXR>(sh, a, r0, nr, lane);
+  const uint32_t refn = a.tr_len[l];
+  const uint64_t refo = a.tr_off[l];
+  int n = sh.n;
+  if (n > 0) {
+    if (lane == 0) {
       // ---- LDS layout of the repeat segments (4-aligned) and of the reference repeat behind them
       uint32_t o = 0;
       const int nn = sh.n;
@@ -274,20 +313,110 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
       int pick[2] = {most_frequent(closest(size[0])), -1};
       int n_pick = 1;
       if (n_gt != 1 && size[0] != size[1]) { pick[1] = most_frequent(closest(size[1])); n_pick = 2; }
-      bool majority = true;
+      bool majority = true, lacks[2] = {false, false};
+      auto in_group = [&](int q, int al) {
+        if (n_gt == 1) return true;
+        const uint32_t d1 = adiff_u(ulen_of(q), size[0]), d2 = adiff_u(ulen_of(q), size[1]);
+        return al == 0 ? d1 <= d2 : d2 < d1;
+      };
       for (int al = 0; al < n_pick; ++al) {  // split(): majority support of the pick inside its group, else stage B is needed
         uint64_t coverage = 0, ref_count = 0;
         for (int q = 0; q < nu; ++q) {
-          bool in;
-          if (n_gt == 1) in = true;
-          else { const uint32_t d1 = adiff_u(ulen_of(q), size[0]), d2 = adiff_u(ulen_of(q), size[1]); in = al == 0 ? d1 <= d2 : d2 < d1; }
-          if (!in) continue;
+          if (!in_group(q, al)) continue;
           coverage += sh.u_cnt[q];
           if (q == pick[al]) ref_count = sh.u_cnt[q];
         }
-        if (!(2 * ref_count >= coverage)) majority = false;
+        if (!(2 * ref_count >= coverage)) { majority = false; lacks[al] = true; }
       }
-      if (!majority) sh.bail = 1;
+      if (!majority) {
+        // ---- stage B on the device: one vote group per allele without majority support, one alignment job per unique sequence of
+        //      its group against the pick (the members of make_consensus, genotype_size.rs:32-37), all segments of the read blob
+        const RepairBufs& rp = a.rp;
+        bool can = rp.counts != nullptr;
+        uint32_t nm[2] = {0, 0}; unsigned long long mbytes[2] = {0, 0}, cig[2] = {0, 0};
+        if (can)
+          for (int al = 0; al < n_pick; ++al) {
+            if (!lacks[al]) continue;
+            const uint32_t bb = ulen_of(pick[al]);
+            if (bb > rp.max_seg) can = false;
+            for (int q = 0; q < nu; ++q) {
+              if (!in_group(q, al)) continue;
+              const uint32_t ln = ulen_of(q);
+              if (ln > rp.max_seg) can = false;
+              nm[al] += 1; mbytes[al] += ln; cig[al] += (unsigned long long)bb + ln + 1;
+            }
+          }
+        unsigned long long out_need[2] = {0, 0}, scr_need[2] = {0, 0};
+        uint32_t out_cap[2] = {0, 0};
+        if (can) {
+          for (int al = 0; al < n_pick; ++al) {
+            if (!lacks[al]) continue;
+            const uint32_t bb = ulen_of(pick[al]);
+            // at most one base per backbone position plus the insertions taken, each of which is a piece of some member
+            out_cap[al] = (uint32_t)(bb + mbytes[al] + 16);
+            out_need[al] = ((unsigned long long)out_cap[al] + 15ull) & ~15ull;
+            scr_need[al] = (bb + 1 <= rp.vote_lds_pos + 1 ? 0ull : 3ull * ((unsigned long long)bb + 1)) + 3ull * nm[al];
+          }
+          if (lane == 0) {  // cigar words, result bytes and vote scratch first: a failed reservation must not leave holes in the job list
+            const unsigned long long cn = cig[0] + cig[1], on = out_need[0] + out_need[1], sn = scr_need[0] + scr_need[1];
+            int ok = 1;
+            unsigned long long c0 = 0, o0 = 0, s0 = 0;
+            c0 = atomicAdd(reinterpret_cast<unsigned long long*>(rp.counts + RC_CIGAR), cn);
+            if (c0 + cn > rp.cap_cigar) ok = 0;
+            if (ok) { o0 = atomicAdd(reinterpret_cast<unsigned long long*>(rp.counts + RC_OUT), on); if (o0 + on > rp.cap_out) ok = 0; }
+            if (ok) { s0 = atomicAdd(reinterpret_cast<unsigned long long*>(rp.counts + RC_SCRATCH), sn); if (s0 + sn > rp.cap_scratch) ok = 0; }
+            if (ok) {
+              sh.rp_j0 = atomicAdd(rp.counts + RC_JOBS, nm[0] + nm[1]);
+              sh.rp_g0 = atomicAdd(rp.counts + RC_GROUPS, (uint32_t)lacks[0] + (uint32_t)lacks[1]);
+              rp.loci[atomicAdd(rp.counts + RC_LOCI, 1u)] = (uint32_t)l;
+              if (sh.rp_j0 + nm[0] + nm[1] > rp.cap_jobs || sh.rp_g0 + 2 > rp.cap_groups) ok = 0;  // (cannot happen: the caps are the read and locus counts)
+            } else atomicAdd(rp.counts + RC_FAILED, 1u);
+            sh.rp_ok = ok; sh.rp_c0 = c0; sh.rp_o0 = o0; sh.rp_s0 = s0;
+          }
+          __syncthreads();
+          can = sh.rp_ok != 0;
+        }
+        if (!can) sh.bail = 1;
+        else {
+          uint32_t g = sh.rp_g0, j = sh.rp_j0;
+          unsigned long long co = sh.rp_c0, oo = sh.rp_o0, so = sh.rp_s0;
+          RepairPend pd;
+          pd.n_gt = n_gt; pd.n_pick = n_pick; pd.size[0] = size[0]; pd.size[1] = size[1];
+          for (int k = 0; k < 4; ++k) pd.civ[k] = (int32_t)civ[k];
+          pd.rep[0] = pd.rep[1] = -1; pd.grp[0] = pd.grp[1] = -1;
+          for (int al = 0; al < n_pick; ++al) {
+            const int rep = sh.u_rep[pick[al]];
+            pd.rep[al] = rep;
+            if (!lacks[al]) continue;
+            const unsigned long long bb_off = sh.r_off[sh.s_read[rep]] + sh.s_start[rep];
+            const uint32_t bb = sh.s_len[rep];
+            if (lane == 0) {
+              RGroup G;
+              G.job_first = j; G.n_members = nm[al]; G.bb_len = bb; G.out_cap = out_cap[al];
+              G.bb_off = bb_off; G.out_off = oo; G.scratch_off = so;
+              rp.groups[g] = G;
+            }
+            pd.grp[al] = (int32_t)g;
+            uint32_t k = 0;
+            for (int q = 0; q < nu; ++q) {
+              if (!in_group(q, al)) continue;
+              const int rq = sh.u_rep[q];
+              if ((int)(k & 63u) == lane) {
+                JobDev jd;
+                jd.pat_off = bb_off; jd.pat_len = bb;
+                jd.txt_off = sh.r_off[sh.s_read[rq]] + sh.s_start[rq]; jd.txt_len = sh.s_len[rq];
+                jd.cigar_off = co; jd.ops_off = 0; jd.out_index = j + k; jd.pad = 0;
+                rp.jobs[j + k] = jd;
+              }
+              co += (unsigned long long)bb + sh.s_len[rq] + 1;
+              ++k;
+            }
+            j += nm[al]; oo += out_need[al]; so += scr_need[al]; ++g;
+          }
+          if (lane == 0) rp.pend[l] = pd;
+          sh.bail = 2;  // the locus waits for repair_finish_kernel
+        }
+      }
       else {
         // ---- classification (genotype_size.rs:42-61), reference allele first (tr.rs:95-101)
         int rep[2]; uint32_t aln[2];
@@ -320,7 +449,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
   // ---- outputs, by the whole wave
   const bool done = n > 0 && !sh.bail;
   for (int i = lane; i < nr; i += 64) { a.classification[r0 + i] = -1; a.read_rank[r0 + i] = -1; }
-  if (n > 0 && sh.bail) { if (lane == 0) a.need_host[l] = 1; return; }
+  if (n > 0 && sh.bail) { if (lane == 0) a.need_host[l] = (uint8_t)(sh.bail == 2 ? 2 : 1); return; }
   if (!done) return;
   __syncthreads();  // the -1 defaults above are ordered before the entries of the kept reads (same wave, same addresses)
   const int n_gt = sh.res_n_gt;
@@ -334,6 +463,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
       a.allele_len[2 * l + oi] = len;
       a.ci[4 * l + 2 * oi] = sh.res_ci[2 * oi]; a.ci[4 * l + 2 * oi + 1] = sh.res_ci[2 * oi + 1];
       a.num_spanning[2 * l + oi] = sh.res_hap[oi];
+      if (a.gt_size) a.gt_size[2 * l + oi] = (int32_t)len;  // (a pick with majority support has the genotype's size)
     }
   }
   for (int i = lane; i < n; i += 64) {
@@ -341,6 +471,90 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
     a.read_rank[r0 + sh.s_read[i]] = i;
   }
   if (lane == 0) { a.n_alleles[l] = n_gt; a.n_spanning_reads[l] = (uint32_t)n; a.flipped[l] = (uint8_t)sh.res_flip; }
+}
+
+// ---- behind the consensus alignments and the column voting of the loci that waited for a repair: the rest of genotype_size::genotype
+// (classification of the reads against the repaired alleles, genotype_size.rs:42-61), reference allele first (tr.rs:95-101), outputs.
+// One wave per waiting locus (list in rp.loci).  A locus whose repaired allele does not fit (vote overflow, allele_cap) goes to the
+// host path after all (need_host = 1); the others leave with need_host = 0.
+struct FinishArgs { const uint8_t* vote_out; const uint32_t* vote_len; };
+template <int MAXR>
+struct FinShared {
+  uint32_t r_s[MAXR], r_len[MAXR]; uint64_t r_off[MAXR];
+  uint32_t s_read[MAXR], s_start[MAXR], s_len[MAXR];
+  int8_t cls[MAXR];
+  int n;
+};
+// equality of two byte strings in global memory, by the whole wave (uniform arguments, uniform result)
+__device__ __forceinline__ bool wave_equal(const uint8_t* __restrict__ p, uint32_t n, const uint8_t* __restrict__ q, uint32_t m) {
+  if (n != m) return false;
+  bool diff = false;
+  for (uint32_t i = threadIdx.x & 63; i < n; i += 64) diff = diff || p[i] != q[i];
+  return __ballot(diff) == 0ull;
+}
+template <int MAXR>
+__global__ void __launch_bounds__(64) repair_finish_kernel(const GtArgs a, const FinishArgs f) {
+  __shared__ FinShared<MAXR> sh;
+  const RepairBufs& rp = a.rp;
+  if (blockIdx.x >= rp.counts[RC_LOCI]) return;
+  const int64_t l = rp.loci[blockIdx.x];
+  const int lane = threadIdx.x;
+  const uint64_t r0 = a.locus_read_begin[l];
+  const int nr = (int)(a.locus_read_begin[l + 1] - r0);
+  if (lane == 0) sh.n = 0;
+  gt_front<MAXR>(sh, a, r0, nr, lane);
+  const int n = sh.n;
+  const RepairPend pd = rp.pend[l];
+  const int ploidy = a.ploidy[l] == 1 ? 1 : 2;
+  // the alleles: the repaired sequence of a group, or the pick that had majority support
+  const uint8_t* ap[2] = {nullptr, nullptr}; uint32_t aln[2] = {0, 0};
+  bool fail = n == 0;
+  for (int al = 0; al < pd.n_pick && !fail; ++al) {
+    if (pd.grp[al] >= 0) {
+      const uint32_t len = f.vote_len[pd.grp[al]];
+      if (len == 0xFFFFFFFFu) { fail = true; break; }
+      ap[al] = f.vote_out + rp.groups[pd.grp[al]].out_off; aln[al] = len;
+    } else {
+      const int rep = pd.rep[al];
+      ap[al] = a.reads + sh.r_off[sh.s_read[rep]] + sh.s_start[rep]; aln[al] = sh.s_len[rep];
+    }
+  }
+  int n_al = pd.n_pick;
+  if (!fail && ploidy == 2 && n_al == 1) { ap[1] = ap[0]; aln[1] = aln[0]; n_al = 2; }
+  int by_hap[2] = {0, 0}, order[2] = {0, 1}, flip = 0;
+  if (!fail) {
+    int tie = 1;  // (every lane walks the reads: uniform, and the list is short)
+    for (int i = 0; i < n; ++i) {
+      int cc = 0;
+      if (n_al == 2) {
+        const uint32_t d1 = adiff_u(sh.s_len[i], aln[0]), d2 = adiff_u(sh.s_len[i], aln[1]);
+        if (d1 < d2) cc = 0; else if (d1 > d2) cc = 1; else { tie = (tie + 1) % 2; cc = tie; }
+      }
+      if (lane == 0) sh.cls[i] = (int8_t)cc;
+      by_hap[cc] += 1;
+    }
+    const uint8_t* ref = a.tr_blob + a.tr_off[l]; const uint32_t refn = a.tr_len[l];
+    if (pd.n_gt != 1 && !wave_equal(ap[0], aln[0], ref, refn) && wave_equal(ap[1], aln[1], ref, refn)) { order[0] = 1; order[1] = 0; flip = 1; }
+    for (int oi = 0; oi < pd.n_gt; ++oi) if (aln[order[oi]] > a.allele_cap[l]) fail = true;  // the host path reports the error
+  }
+  __syncthreads();
+  if (fail) { if (lane == 0) a.need_host[l] = 1; return; }
+  for (int oi = 0; oi < pd.n_gt; ++oi) {
+    const int al = order[oi];
+    uint8_t* dst = a.allele_blob + a.allele_off[2 * l + oi];
+    for (uint32_t b = lane; b < aln[al]; b += 64) dst[b] = ap[al][b];
+    if (lane == 0) {
+      a.allele_len[2 * l + oi] = aln[al];
+      a.ci[4 * l + 2 * oi] = pd.civ[2 * al]; a.ci[4 * l + 2 * oi + 1] = pd.civ[2 * al + 1];
+      a.num_spanning[2 * l + oi] = by_hap[al];
+      if (a.gt_size) a.gt_size[2 * l + oi] = (int32_t)pd.size[al];
+    }
+  }
+  for (int i = lane; i < n; i += 64) {
+    a.classification[r0 + sh.s_read[i]] = flip ? 1 - sh.cls[i] : sh.cls[i];
+    a.read_rank[r0 + sh.s_read[i]] = i;
+  }
+  if (lane == 0) { a.n_alleles[l] = pd.n_gt; a.n_spanning_reads[l] = (uint32_t)n; a.flipped[l] = (uint8_t)flip; a.need_host[l] = 0; }
 }
 
 }  // namespace gt

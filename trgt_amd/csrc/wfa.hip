@@ -19,16 +19,19 @@ struct RleOut { uint32_t* buf; uint32_t cap; };
 __device__ __forceinline__ uint32_t op_code(char op) { return op == 'M' ? 7u : op == 'X' ? 8u : op == 'I' ? 1u : 2u; }
 
 
+template <bool LA>
 __device__ __forceinline__ long long bt_cand(const Inst& I, int c, int s, int k, int add, int type) {
   if (s < 0 || s >= I.n_slots) return (long long)OFF_NULL;
   const WfDesc d = I.gdesc[(size_t)s * 5 + c];
   if (d.base == NOBASE || k < d.lo || k > d.hi) return (long long)OFF_NULL;
-  return (((long long)(I.arena[d.base + (uint32_t)(k - d.lo_alloc)] + add)) << 4) | type;  // BACKTRACE_TYPE_BITS_SET
+  return (((long long)(arena_of<LA>(I)[d.base + (uint32_t)(k - d.lo_alloc)] + add)) << 4) | type;  // BACKTRACE_TYPE_BITS_SET
 }
 
 // wavefront_backtrace_{linear,affine}: candidates encoded (offset << 4 | type), maximum wins.
 // Emits the operations in reverse order, run-length encoded, into tmp[0..*ntmp).
-__device__ __noinline__ void wf_backtrace(const Inst& I, const Pen& pen, uint32_t* tmp, int& ntmp, uint32_t cap) {
+template <bool LA>
+__device__ __noinline__ void wf_backtrace(const Inst& I, uint32_t* tmp, int& ntmp, uint32_t cap) {
+  const Pen& pen = KP.pen;
   const int plen = I.plen, tlen = I.tlen, metric = pen.metric;
   const int x = pen.x, o1 = pen.o1, e1 = pen.e1, o2 = pen.o2, e2 = pen.e2;
   const bool lin = metric <= M_LINEAR;
@@ -42,16 +45,16 @@ __device__ __noinline__ void wf_backtrace(const Inst& I, const Pen& pen, uint32_
   while (v > 0 && h > 0 && s > 0) {
     long long best = (long long)OFF_NULL;
     if (lin) {
-      if (metric != M_INDEL) best = max(best, bt_cand(I, CM, s - x, k, +1, 9));
-      best = max(best, bt_cand(I, CM, s - o1, k - 1, +1, 1));
-      best = max(best, bt_cand(I, CM, s - o1, k + 1, 0, 5));
+      if (metric != M_INDEL) best = max(best, bt_cand<LA>(I, CM, s - x, k, +1, 9));
+      best = max(best, bt_cand<LA>(I, CM, s - o1, k - 1, +1, 1));
+      best = max(best, bt_cand<LA>(I, CM, s - o1, k + 1, 0, 5));
     } else {
-      if (mt == CM) best = max(best, bt_cand(I, CM, s - x, k, +1, 9));
-      if (mt == CM || mt == CD1) { best = max(best, bt_cand(I, CD1, s - e1, k + 1, 0, 6)); best = max(best, bt_cand(I, CM, s - o1 - e1, k + 1, 0, 5)); }
-      if (mt == CM || mt == CI1) { best = max(best, bt_cand(I, CI1, s - e1, k - 1, +1, 2)); best = max(best, bt_cand(I, CM, s - o1 - e1, k - 1, +1, 1)); }
+      if (mt == CM) best = max(best, bt_cand<LA>(I, CM, s - x, k, +1, 9));
+      if (mt == CM || mt == CD1) { best = max(best, bt_cand<LA>(I, CD1, s - e1, k + 1, 0, 6)); best = max(best, bt_cand<LA>(I, CM, s - o1 - e1, k + 1, 0, 5)); }
+      if (mt == CM || mt == CI1) { best = max(best, bt_cand<LA>(I, CI1, s - e1, k - 1, +1, 2)); best = max(best, bt_cand<LA>(I, CM, s - o1 - e1, k - 1, +1, 1)); }
       if (metric == M_AFFINE2P) {
-        if (mt == CM || mt == CD2) { best = max(best, bt_cand(I, CD2, s - e2, k + 1, 0, 8)); best = max(best, bt_cand(I, CM, s - o2 - e2, k + 1, 0, 7)); }
-        if (mt == CM || mt == CI2) { best = max(best, bt_cand(I, CI2, s - e2, k - 1, +1, 4)); best = max(best, bt_cand(I, CM, s - o2 - e2, k - 1, +1, 3)); }
+        if (mt == CM || mt == CD2) { best = max(best, bt_cand<LA>(I, CD2, s - e2, k + 1, 0, 8)); best = max(best, bt_cand<LA>(I, CM, s - o2 - e2, k + 1, 0, 7)); }
+        if (mt == CM || mt == CI2) { best = max(best, bt_cand<LA>(I, CI2, s - e2, k - 1, +1, 4)); best = max(best, bt_cand<LA>(I, CM, s - o2 - e2, k - 1, +1, 3)); }
       }
     }
     if (best < 0) break;
@@ -90,10 +93,12 @@ __device__ __forceinline__ void rle_append_reversed(uint32_t* out, int& n, uint3
 
 // ------------------------------------------------------------------ BiWFA
 // wavefront_bialign_breakpoint_{indel2indel,m2m}.  All threads.
+template <bool LA>
 __device__ __noinline__ void bp_check(int i0, int i1, bool fwd, int s0, int s1, const WfDesc& w0, const WfDesc& w1, int comp,
                          int gap_open) {
   const Inst& A0 = sh.inst[i0];
   const Inst& A1 = sh.inst[i1];
+  const int32_t* const R0 = arena_of<LA>(A0); const int32_t* const R1 = arena_of<LA>(A1);
   const int plen = A0.plen, tlen = A0.tlen, tid = threadIdx.x, T = blockDim.x;
   const int lo0 = w0.lo, hi0 = w0.hi, lo1 = (tlen - plen) - w1.hi, hi1 = (tlen - plen) - w1.lo;
   if (hi1 < lo0 || hi0 < lo1) return;
@@ -107,7 +112,7 @@ __device__ __noinline__ void bp_check(int i0, int i1, bool fwd, int s0, int s1, 
     bool ok = false;
     if (k0 <= min_hi) {
       const int k1 = (tlen - plen) - k0;
-      const int32_t h0 = A0.arena[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = A1.arena[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
+      const int32_t h0 = R0[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = R1[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
       if (h0 + h1 >= tlen) {
         const int hh = fwd ? h0 : h1, kk = fwd ? k0 : k1;
         ok = !((hh - kk) > plen || hh > tlen);
@@ -118,7 +123,7 @@ __device__ __noinline__ void bp_check(int i0, int i1, bool fwd, int s0, int s1, 
   __syncthreads();
   if (tid == 0 && sh.red.bp_k != INT32_MAX) {
     const int k0 = sh.red.bp_k, k1 = (tlen - plen) - k0;
-    const int32_t h0 = A0.arena[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = A1.arena[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
+    const int32_t h0 = R0[w0.base + (uint32_t)(k0 - w0.lo_alloc)], h1 = R1[w1.base + (uint32_t)(k1 - w1.lo_alloc)];
     Breakpoint& bp = sh.bp;
     if (fwd) { bp.score_f = s0; bp.score_r = s1; bp.k_f = k0; bp.off_f = h0; }
     else { bp.score_f = s1; bp.score_r = s0; bp.k_f = k1; bp.off_f = h1; }
@@ -128,7 +133,9 @@ __device__ __noinline__ void bp_check(int i0, int i1, bool fwd, int s0, int s1, 
 }
 
 // wavefront_bialign_overlap.  All threads.
-__device__ __noinline__ void bi_overlap(const Pen& pen, int i0, int i1, int s0, int s1, bool fwd) {
+template <bool LA>
+__device__ __noinline__ void bi_overlap(int i0, int i1, int s0, int s1, bool fwd) {
+  const Pen& pen = KP.pen;
   const WfDesc m0 = fetch_raw(i0, CM, s0);
   if (m0.base == NOBASE) return;
   WfDesc d10 = null_desc(), i10 = null_desc(), d20 = null_desc(), i20 = null_desc();
@@ -139,19 +146,19 @@ __device__ __noinline__ void bi_overlap(const Pen& pen, int i0, int i1, int s0, 
     if (si < 0) break;
     if (pen.metric == M_AFFINE2P && s0 + si - pen.o2 < sh.bp.score) {
       const WfDesc d21 = fetch_raw(i1, CD2, si);
-      if (d20.base != NOBASE && d21.base != NOBASE) bp_check(i0, i1, fwd, s0, si, d20, d21, CD2, pen.o2);
+      if (d20.base != NOBASE && d21.base != NOBASE) bp_check<LA>(i0, i1, fwd, s0, si, d20, d21, CD2, pen.o2);
       const WfDesc i21 = fetch_raw(i1, CI2, si);
-      if (i20.base != NOBASE && i21.base != NOBASE) bp_check(i0, i1, fwd, s0, si, i20, i21, CI2, pen.o2);
+      if (i20.base != NOBASE && i21.base != NOBASE) bp_check<LA>(i0, i1, fwd, s0, si, i20, i21, CI2, pen.o2);
     }
     if (pen.metric >= M_AFFINE && s0 + si - pen.o1 < sh.bp.score) {
       const WfDesc d11 = fetch_raw(i1, CD1, si);
-      if (d10.base != NOBASE && d11.base != NOBASE) bp_check(i0, i1, fwd, s0, si, d10, d11, CD1, pen.o1);
+      if (d10.base != NOBASE && d11.base != NOBASE) bp_check<LA>(i0, i1, fwd, s0, si, d10, d11, CD1, pen.o1);
       const WfDesc i11 = fetch_raw(i1, CI1, si);
-      if (i10.base != NOBASE && i11.base != NOBASE) bp_check(i0, i1, fwd, s0, si, i10, i11, CI1, pen.o1);
+      if (i10.base != NOBASE && i11.base != NOBASE) bp_check<LA>(i0, i1, fwd, s0, si, i10, i11, CI1, pen.o1);
     }
     if (s0 + si >= sh.bp.score) continue;
     const WfDesc m1 = fetch_raw(i1, CM, si);
-    if (m1.base != NOBASE) bp_check(i0, i1, fwd, s0, si, m0, m1, CM, 0);
+    if (m1.base != NOBASE) bp_check<LA>(i0, i1, fwd, s0, si, m0, m1, CM, 0);
   }
 }
 
@@ -159,49 +166,68 @@ struct BlockWs {  // carved from the workgroup's HBM workspace
   WfDesc* gdesc; int32_t* arena_u; int32_t* arena_f; int32_t* arena_r; uint32_t* rle_tmp; uint32_t* rle_out; uint32_t* run_start;
 };
 
-__device__ __forceinline__ void setup_inst(int ii, const KArgs& a, const BlockWs& ws, const uint8_t* P, int pl,
-                                           const uint8_t* T, int tl, int rev, int span, int pbf, int pef, int tbf, int tef,
+// P / T: sequences of the (sub-)alignment; p_lds / t_lds: their byte offsets in the dynamic LDS (LDS-arena variant)
+template <bool LA>
+__device__ __forceinline__ void setup_inst(int ii, const BlockWs& ws, const uint8_t* P, uint32_t p_lds, int pl,
+                                           const uint8_t* T, uint32_t t_lds, int tl, int rev, int span, int pbf, int pef, int tbf, int tef,
                                            int cb, int ce) {
   Inst& I = sh.inst[ii];
-  I.pp = P; I.tp = T; I.plen = pl; I.tlen = tl; I.rev = rev;
+  const KArgs& a = sh.args;
+  I.pp = P; I.tp = T; I.pp_lds = p_lds; I.tp_lds = t_lds; I.plen = pl; I.tlen = tl; I.rev = rev;
   I.span = span; I.pbf = pbf; I.pef = pef; I.tbf = tbf; I.tef = tef; I.cb = cb; I.ce = ce;
   I.modular = ii != I_UNI;
-  I.gdesc = ws.gdesc; I.n_slots = ii == I_UNI ? (int)a.uni_slots : INT32_MAX;
-  I.arena = ii == I_UNI ? ws.arena_u : (ii == I_FWD ? ws.arena_f : ws.arena_r);
-  I.arena_cap = a.arena_uni_cap; I.stride = a.ring_stride; I.bump = 0;
+  I.bump = 0;
+  if constexpr (LA) {
+    // One LDS region serves the two phases of an alignment, which never overlap: the forward / reverse rings of the breakpoint search
+    // (half of it each: stride = what fits scope x ncomp wavefronts), or the descriptor history + the bump arena of a base alignment.
+    const uint32_t half = (a.la_region_bytes / 2) & ~15u;
+    const uint32_t per_dir = (uint32_t)(a.kp.pen.scope * a.kp.pen.ncomp);
+    if (ii == I_UNI) {
+      const uint32_t gd_bytes = a.la_gdesc_slots * 5u * (uint32_t)sizeof(WfDesc);
+      I.gdesc = reinterpret_cast<WfDesc*>(lds_dyn + a.la_region); I.n_slots = (int)a.la_gdesc_slots;
+      I.arena_lds = a.la_region + gd_bytes; I.arena_cap = (a.la_region_bytes - gd_bytes) / 4; I.stride = 0; I.arena = nullptr;
+    } else {
+      I.gdesc = nullptr; I.n_slots = INT32_MAX;
+      I.arena_lds = a.la_region + (ii == I_FWD ? 0u : half); I.arena_cap = 0; I.stride = half / 4 / per_dir; I.arena = nullptr;
+    }
+  } else {
+    I.gdesc = ws.gdesc; I.n_slots = ii == I_UNI ? (int)a.uni_slots : INT32_MAX;
+    I.arena = ii == I_UNI ? ws.arena_u : (ii == I_FWD ? ws.arena_f : ws.arena_r);
+    I.arena_cap = a.arena_uni_cap; I.stride = a.ring_stride; I.arena_lds = 0;
+  }
 }
 
 // wavefront_bialign_find_breakpoint.  All threads.
-template <int METRIC>
-__device__ __noinline__ int bi_find_breakpoint(const KArgs& a, const BlockWs& ws, const uint8_t* P, const uint8_t* T, const Seg seg) {
-  const KParams& kp = a.kp;
+template <int METRIC, bool LA>
+__device__ __noinline__ int bi_find_breakpoint(const BlockWs& ws, const uint8_t* P, uint32_t p_lds, const uint8_t* T, uint32_t t_lds, const Seg seg) {
+  const KParams& kp = KP;
   __syncthreads();
   if (threadIdx.x == 0) {
-    setup_inst(I_FWD, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, CM);
-    setup_inst(I_REV, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 1, 0, 0, 0, 0, 0, seg.ce, CM);
+    setup_inst<LA>(I_FWD, ws, P + seg.pb, p_lds + (uint32_t)seg.pb, seg.pl, T + seg.tb, t_lds + (uint32_t)seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, CM);
+    setup_inst<LA>(I_REV, ws, P + seg.pb, p_lds + (uint32_t)seg.pb, seg.pl, T + seg.tb, t_lds + (uint32_t)seg.tb, seg.tl, 1, 0, 0, 0, 0, 0, seg.ce, CM);
     sh.bp.score = INT32_MAX;
   }
   __syncthreads();
   const int max_antidiagonal = seg.pl + seg.tl - 1;
   int sf = 0, sr = 0, fak = 0, rak = 0, mak = 0;
-  wf_init(I_FWD, kp);
+  wf_init<LA>(I_FWD);
   if (sh.inst[I_FWD].status == ST_OOM) return ST_OOM;
-  wf_extend_only(I_FWD, 0, true);
-  if (wf_post_extend(I_FWD, 0, kp, true, &fak)) return sh.inst[I_FWD].status;
-  wf_init(I_REV, kp);
+  wf_extend_only<LA>(I_FWD, 0, true);
+  if (wf_post_extend<LA>(I_FWD, 0, true, &fak)) return sh.inst[I_FWD].status;
+  wf_init<LA>(I_REV);
   if (sh.inst[I_REV].status == ST_OOM) return ST_OOM;
-  wf_extend_only(I_REV, 0, true);
-  if (wf_post_extend(I_REV, 0, kp, true, &rak)) return sh.inst[I_REV].status;
+  wf_extend_only<LA>(I_REV, 0, true);
+  if (wf_post_extend<LA>(I_REV, 0, true, &rak)) return sh.inst[I_REV].status;
   bool last_forward = false;
   while (true) {
     if (fak + rak >= max_antidiagonal) break;
     ++sf;
-    if (wf_step<METRIC>(I_FWD, sf, kp, true, &mak)) return sh.inst[I_FWD].status;
+    if (wf_step<METRIC, LA>(I_FWD, sf, true, &mak)) return sh.inst[I_FWD].status;
     if (fak < mak) fak = mak;
     last_forward = true;
     if (fak + rak >= max_antidiagonal) break;
     ++sr;
-    if (wf_step<METRIC>(I_REV, sr, kp, true, &mak)) return sh.inst[I_REV].status;
+    if (wf_step<METRIC, LA>(I_REV, sr, true, &mak)) return sh.inst[I_REV].status;
     if (rak < mak) rak = mak;
     last_forward = false;
   }
@@ -211,15 +237,15 @@ __device__ __noinline__ int bi_find_breakpoint(const KArgs& a, const BlockWs& ws
     if (last_forward) {
       const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
       if (sf + min_sr - gap_opening >= sh.bp.score) break;
-      bi_overlap(kp.pen, I_FWD, I_REV, sf, sr, true);
+      bi_overlap<LA>(I_FWD, I_REV, sf, sr, true);
       ++sr;
-      if (wf_step<METRIC>(I_REV, sr, kp, false, nullptr)) return sh.inst[I_REV].status;  // only a dead front ends phase 2
+      if (wf_step<METRIC, LA>(I_REV, sr, false, nullptr)) return sh.inst[I_REV].status;  // only a dead front ends phase 2
     }
     const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
     if (min_sf + sr - gap_opening >= sh.bp.score) break;
-    bi_overlap(kp.pen, I_REV, I_FWD, sr, sf, false);
+    bi_overlap<LA>(I_REV, I_FWD, sr, sf, false);
     ++sf;
-    if (wf_step<METRIC>(I_FWD, sf, kp, false, nullptr)) return sh.inst[I_FWD].status;
+    if (wf_step<METRIC, LA>(I_FWD, sf, false, nullptr)) return sh.inst[I_FWD].status;
     last_forward = true;
   }
   return ST_OK;
@@ -228,18 +254,19 @@ __device__ __noinline__ int bi_find_breakpoint(const KArgs& a, const BlockWs& ws
 __device__ __forceinline__ int classic_score(int metric, int s) { return metric <= M_EDIT ? s : -s; }
 
 // wavefront_bialign_base.  All threads.  Returns false on failure (sh.status set).
-template <int METRIC>
-__device__ __noinline__ bool bi_base(const KArgs& a, const BlockWs& ws, const uint8_t* P, const uint8_t* T, const Seg seg, bool want_cigar) {
+template <int METRIC, bool LA>
+__device__ __noinline__ bool bi_base(const BlockWs& ws, const uint8_t* P, uint32_t p_lds, const uint8_t* T, uint32_t t_lds, const Seg seg, bool want_cigar, uint32_t rle_cap) {
   __syncthreads();
-  if (threadIdx.x == 0) setup_inst(I_UNI, a, ws, P + seg.pb, seg.pl, T + seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, seg.ce);
+  if (threadIdx.x == 0) setup_inst<LA>(I_UNI, ws, P + seg.pb, p_lds + (uint32_t)seg.pb, seg.pl, T + seg.tb, t_lds + (uint32_t)seg.tb, seg.tl, 0, 0, 0, 0, 0, 0, seg.cb, seg.ce);
   __syncthreads();
-  const int st = wf_run<METRIC>(I_UNI, a.kp);
+  const int st = wf_run<METRIC, LA>(I_UNI);
   if (threadIdx.x == 0) {
     if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
     else if (want_cigar) {
       int nt = 0;
-      wf_backtrace(sh.inst[I_UNI], a.kp.pen, ws.rle_tmp, nt, a.rle_cap);
-      rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
+      wf_backtrace<LA>(sh.inst[I_UNI], ws.rle_tmp, nt, rle_cap);
+      rle_append_reversed(ws.rle_out, sh.rle_n, rle_cap, ws.rle_tmp, nt);
+      if (LA && ((uint32_t)nt >= rle_cap || (uint32_t)sh.rle_n >= rle_cap)) sh.status = TRGT_WF_OOM;
     }
   }
   __syncthreads();
@@ -255,23 +282,34 @@ __device__ unsigned long long g_wfa_gprof[8];  // generic kernel, thread 0: clai
 #define GP_DECL
 #define GP_MARK(i)
 #endif
-template <int METRIC>
+// LA = false: wavefronts in the workgroup's HBM workspace (any size).  LA = true (the LDS-arena variant, one wave per alignment):
+// sequences, run-length buffers and wavefronts of the current alignment live in the dynamic LDS; an alignment that does not fit -- a
+// wavefront wider than the ring stride, a base alignment whose history outgrows the arena or its descriptor slots, more runs than
+// the buffers hold, sequences beyond the staging area -- is appended to the retry list and redone by the HBM variant (launched right
+// behind over that list): the same code on the same inputs, so the results do not depend on where an alignment ran.
+template <int METRIC, bool LA>
 __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
-  extern __shared__ unsigned char lds_seq[];
   const int tid = threadIdx.x, T = blockDim.x;
-  const KParams& kp = a.kp;
-  // The HBM workspace belongs to a *slot* acquired for the lifetime of the workgroup (not to blockIdx), which keeps the
-  // door open for grids larger than the slot count; today the grid equals the slot count and workgroups are persistent.
-  if (tid == 0) {
-    uint32_t i = (blockIdx.x * 2654435761u) % a.n_slots_ws;
-    while (atomicCAS(&a.slot_flags[i], 0u, 1u) != 0u) i = i + 1 == a.n_slots_ws ? 0 : i + 1;
-    sh.top_bp = (int)i;
+  {  // the argument block into LDS (what the engine functions read) and the place of the descriptor rings in the dynamic LDS
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&a); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.args);
+    for (uint32_t i = tid; i < sizeof(KArgs) / 4; i += T) dst[i] = src[i];
+    if (tid == 0) { sh.ring_off = a.ring_off; sh.ring_mask = a.ring_mask; }
   }
   __syncthreads();
-  const uint32_t ws_slot = (uint32_t)sh.top_bp;
-  __syncthreads();
+  const KParams& kp = KP;
+  // The HBM workspace belongs to a *slot* acquired for the lifetime of the workgroup (not to blockIdx), which keeps the
+  // door open for grids larger than the slot count; today the grid equals the slot count and workgroups are persistent.
+  uint32_t ws_slot = 0;
   BlockWs ws;
-  {
+  if constexpr (!LA) {
+    if (tid == 0) {
+      uint32_t i = (blockIdx.x * 2654435761u) % a.n_slots_ws;
+      while (atomicCAS(&a.slot_flags[i], 0u, 1u) != 0u) i = i + 1 == a.n_slots_ws ? 0 : i + 1;
+      sh.top_bp = (int)i;
+    }
+    __syncthreads();
+    ws_slot = (uint32_t)sh.top_bp;
+    __syncthreads();
     uint8_t* base = a.ws + (size_t)ws_slot * a.ws_per_block;
     ws.gdesc = reinterpret_cast<WfDesc*>(base + a.off_gdesc);
     ws.arena_u = reinterpret_cast<int32_t*>(base + a.off_arena_u);
@@ -280,7 +318,12 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     ws.rle_tmp = reinterpret_cast<uint32_t*>(base + a.off_rle_tmp);
     ws.rle_out = reinterpret_cast<uint32_t*>(base + a.off_rle_out);
     ws.run_start = reinterpret_cast<uint32_t*>(base + a.off_run_start);
+  } else {
+    ws.gdesc = nullptr; ws.arena_u = ws.arena_f = ws.arena_r = nullptr; ws.run_start = nullptr;
+    ws.rle_tmp = reinterpret_cast<uint32_t*>(lds_dyn + a.la_rle_tmp);
+    ws.rle_out = reinterpret_cast<uint32_t*>(lds_dyn + a.la_rle_out);
   }
+  const uint32_t rle_cap = LA ? a.la_rle_cap : a.rle_cap;
   const uint32_t n_front = a.n_jobs_dev ? *a.n_jobs_dev : a.n_jobs;
   const uint32_t n_jobs = n_front + (a.n_jobs2_dev ? *a.n_jobs2_dev : 0u);
   unsigned long long cells_acc = 0;
@@ -298,11 +341,17 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     const uint8_t* Tx = a.txt_base + job.txt_off;
     // stage the two sequences in LDS when they fit (extension = byte compares against LDS)
     const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
-    if (pl_pad + (uint32_t)tlen <= a.lds_seq_cap) {
-      for (int i = tid; i < plen; i += T) lds_seq[i] = P[i];
-      for (int i = tid; i < tlen; i += T) lds_seq[pl_pad + i] = Tx[i];
-      P = lds_seq; Tx = lds_seq + pl_pad;
+    const bool staged = pl_pad + (uint32_t)tlen <= a.lds_seq_cap;
+    if (LA && !staged) {  // too long for this variant: to the HBM one
+      if (tid == 0) a.retry_jobs[atomicAdd(a.retry_count, 1u)] = job;
+      continue;
     }
+    if (staged) {
+      for (int i = tid; i < plen; i += T) lds_dyn[i] = P[i];
+      for (int i = tid; i < tlen; i += T) lds_dyn[pl_pad + i] = Tx[i];
+      P = lds_dyn; Tx = lds_dyn + pl_pad;
+    }
+    const uint32_t p_lds = 0, t_lds = pl_pad;
     if (tid == 0) { sh.status = TRGT_WF_COMPLETED; sh.score = INT32_MIN; sh.rle_n = 0; sh.sp = 0; sh.cells = 0; sh.top_bp = 0; }
     __syncthreads();
     GP_MARK(0);
@@ -311,28 +360,29 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
       if (tid == 0) {
         const int sp = kp.span;
         auto fr = [](int v, int len) { return v < 0 ? len : v; };
-        setup_inst(I_UNI, a, ws, P, plen, Tx, tlen, 0, sp, sp ? fr(kp.pbf, plen) : 0, sp ? fr(kp.pef, plen) : 0,
-                   sp ? fr(kp.tbf, tlen) : 0, sp ? fr(kp.tef, tlen) : 0, CM, CM);
+        setup_inst<LA>(I_UNI, ws, P, p_lds, plen, Tx, t_lds, tlen, 0, sp, sp ? fr(kp.pbf, plen) : 0, sp ? fr(kp.pef, plen) : 0,
+                       sp ? fr(kp.tbf, tlen) : 0, sp ? fr(kp.tef, tlen) : 0, CM, CM);
       }
       __syncthreads();
-      const int st = wf_run<METRIC>(I_UNI, kp);
+      const int st = wf_run<METRIC, LA>(I_UNI);
       if (tid == 0) {
         if (st != ST_END_REACHED) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
         else {
           sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
           if (kp.scope_alignment) {
             int nt = 0;
-            wf_backtrace(sh.inst[I_UNI], kp.pen, ws.rle_tmp, nt, a.rle_cap);
-            rle_append_reversed(ws.rle_out, sh.rle_n, a.rle_cap, ws.rle_tmp, nt);
+            wf_backtrace<LA>(sh.inst[I_UNI], ws.rle_tmp, nt, rle_cap);
+            rle_append_reversed(ws.rle_out, sh.rle_n, rle_cap, ws.rle_tmp, nt);
+            if (LA && ((uint32_t)nt >= rle_cap || (uint32_t)sh.rle_n >= rle_cap)) sh.status = TRGT_WF_OOM;
           }
         }
       }
     } else if (!kp.scope_alignment) {
       // ---- BiWFA score only (wavefront_bialign_compute_score)
       Seg seg; seg.pb = 0; seg.pl = plen; seg.tb = 0; seg.tl = tlen; seg.cb = CM; seg.ce = CM; seg.rem = INT32_MAX; seg.top = 1;
-      const int st = bi_find_breakpoint<METRIC>(a, ws, P, Tx, seg);
+      const int st = bi_find_breakpoint<METRIC, LA>(ws, P, p_lds, Tx, t_lds, seg);
       if (st == ST_END_REACHED) {
-        if (bi_base<METRIC>(a, ws, P, Tx, seg, false) && tid == 0) sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
+        if (bi_base<METRIC, LA>(ws, P, p_lds, Tx, t_lds, seg, false, rle_cap) && tid == 0) sh.score = classic_score(METRIC, sh.inst[I_UNI].end_score);
       } else if (tid == 0) {
         if (st != ST_OK) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE;
         else sh.score = classic_score(METRIC, sh.bp.score);
@@ -352,19 +402,19 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
         __syncthreads();
         if (tid == 0) sh.sp -= 1;
         __syncthreads();
-        if (seg.tl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 2u, seg.pl); continue; }
-        if (seg.pl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, a.rle_cap, 1u, seg.tl); continue; }
+        if (seg.tl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, rle_cap, 2u, seg.pl); continue; }
+        if (seg.pl == 0) { if (tid == 0) rle_push(ws.rle_out, sh.rle_n, rle_cap, 1u, seg.tl); continue; }
         GP_MARK(3);
-        if (seg.rem <= kp.bi_min_score) { bi_base<METRIC>(a, ws, P, Tx, seg, true); GP_MARK(2); continue; }
-        const int st = bi_find_breakpoint<METRIC>(a, ws, P, Tx, seg);
+        if (seg.rem <= kp.bi_min_score) { bi_base<METRIC, LA>(ws, P, p_lds, Tx, t_lds, seg, true, rle_cap); GP_MARK(2); continue; }
+        const int st = bi_find_breakpoint<METRIC, LA>(ws, P, p_lds, Tx, t_lds, seg);
         GP_MARK(1);
-        if (st == ST_END_REACHED) { bi_base<METRIC>(a, ws, P, Tx, seg, true); GP_MARK(2); continue; }
+        if (st == ST_END_REACHED) { bi_base<METRIC, LA>(ws, P, p_lds, Tx, t_lds, seg, true, rle_cap); GP_MARK(2); continue; }
         if (st != ST_OK) { if (tid == 0) sh.status = st == ST_OOM ? TRGT_WF_OOM : TRGT_WF_UNATTAINABLE; continue; }
         if (tid == 0) {
           const Breakpoint bp = sh.bp;
           const int bh = bp.off_f, bv = bp.off_f - bp.k_f;
           if (seg.top) { sh.top_bp = 1; sh.score = classic_score(METRIC, bp.score); }
-          if (sh.sp + 2 > 64) sh.status = TRGT_WF_OOM;
+          if (sh.sp + 2 > BI_STACK) sh.status = TRGT_WF_OOM;
           else {
             Seg r; r.pb = seg.pb + bv; r.pl = seg.pl - bv; r.tb = seg.tb + bh; r.tl = seg.tl - bh; r.cb = bp.comp; r.ce = seg.ce; r.rem = bp.score_r; r.top = 0;
             Seg l; l.pb = seg.pb; l.pl = bv; l.tb = seg.tb; l.tl = bh; l.cb = seg.cb; l.ce = bp.comp; l.rem = bp.score_f; l.top = 0;
@@ -372,9 +422,14 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
           }
         }
       }
+      if (LA && tid == 0 && (uint32_t)sh.rle_n >= rle_cap) sh.status = TRGT_WF_OOM;
     }
     __syncthreads();
     GP_MARK(3);
+    if (LA && sh.status == TRGT_WF_OOM) {  // did not fit the LDS budget somewhere: the HBM variant redoes it from scratch
+      if (tid == 0) a.retry_jobs[atomicAdd(a.retry_count, 1u)] = job;  // (its offsets are counted where it completes)
+      continue;
+    }
     // ---- per-job epilogue: status, score, count_matches, alignment span, CIGAR, expanded operations
     const int ok = sh.status == TRGT_WF_COMPLETED;
     const int nrun = ok ? sh.rle_n : 0;
@@ -386,7 +441,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
       bool started = false;
       for (int r = 0; r < nrun; ++r) {
         const uint32_t e = ws.rle_out[r], len = e >> 4, code = e & 0xF;
-        ws.run_start[r] = total;
+        if (!LA) ws.run_start[r] = total;
         total += len;
         if (code == 1u) ti += len;
         else if (code == 2u) pi += len;
@@ -402,7 +457,7 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     }
     __syncthreads();
     if (a.cigar) for (int r = tid; r < nrun; r += T) a.cigar[job.cigar_off + r] = ws.rle_out[r];
-    if (a.ops && nrun > 0) {
+    if (!LA && a.ops && nrun > 0) {
       const uint32_t total = (uint32_t)sh.top_bp;
       for (uint32_t p = tid; p < total; p += T) {
         int lo = 0, hi = nrun - 1;  // last run whose start <= p
@@ -413,8 +468,10 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     }
   }
   if (tid == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
-  __syncthreads();
-  if (tid == 0) { __threadfence(); atomicExch(&a.slot_flags[ws_slot], 0u); }
+  if constexpr (!LA) {
+    __syncthreads();
+    if (tid == 0) { __threadfence(); atomicExch(&a.slot_flags[ws_slot], 0u); }
+  }
 }
 
 }  // namespace wfa
@@ -505,9 +562,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
-  if ((rc = dev_get(c, L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
-  if ((rc = dev_get(c, L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
-  if ((rc = dev_get(c, L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 16, &d_cells))) return rc;
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 16, &d_cells))) return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
   if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
@@ -517,6 +574,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
   a.status = L.status; a.score = L.score; a.n_match = L.n_match; a.span4 = L.span4; a.cigar = L.cigar; a.cigar_len = L.cigar_len;
   a.ops = L.ops; a.ops_len = L.ops_len;
+  a.retry_jobs = nullptr; a.retry_count = nullptr;
   const uint64_t seq_need = ((uint64_t)mp + 15) / 16 * 16 + (uint64_t)mt + 16;
   a.lds_seq_cap = (uint32_t)((std::min<uint64_t>(seq_need, 32 * 1024) + 15) & ~15ull);
   if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
@@ -559,20 +617,65 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     grid_blocks = std::min<int64_t>(grid_blocks, (int64_t)c->num_cus * per_cu);
   }
   const dim3 grid((unsigned)grid_blocks), block((unsigned)threads);
+  if (a.fast_wcap == 0) {  // the generic kernel keeps the descriptor rings of its three instances behind the staged sequences
+    a.ring_mask = RING - 1; a.ring_off = (a.lds_seq_cap + 15u) & ~15u;
+    lds = (size_t)a.ring_off + 3 * RING * 5 * sizeof(WfDesc);
+    if (lds > 48 * 1024)
+      for (const void* fn : {(const void*)wfa_kernel<0, false>, (const void*)wfa_kernel<1, false>, (const void*)wfa_kernel<2, false>, (const void*)wfa_kernel<3, false>, (const void*)wfa_kernel<4, false>})
+        TRGT_HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  // ---- BiWFA batches of one wave per alignment (consensus alignments, edit distances): first the LDS-arena variant over the whole list,
+  //      then the HBM variant over what did not fit (its job list and count are written by the first launch)
+  const bool la_ok = a.kp.biwfa && p.span == 0 && threads == 64 && !L.ops && (p.metric == 1 || p.metric == 3) && !c->knobs.no_lds_wfa &&
+                     a.fast_wcap == 0 && !L.n_jobs2_dev;
+  if (la_ok) {
+    void* d_retry = nullptr;
+    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)L.n_jobs_host * sizeof(JobDev), &d_retry))) return rc;
+    KArgs la = a;
+    // dynamic LDS of a workgroup: sequences | two run-length buffers | descriptor rings (as many levels as the score scope needs) | the
+    // region of the wavefronts.  Defaults sized for 12 workgroups per CU (one wave each; the registers allow no more): this kernel is all
+    // latency, and the alignments that do not fit are few and go to the HBM variant.
+    const uint32_t seq_cap = (uint32_t)std::max(256, c->knobs.lds_wfa_seq), rle_cap = 96, region = (uint32_t)std::max(2, c->knobs.lds_wfa_kb) * 1024u;
+    uint32_t ring_levels = 2;
+    while ((int)ring_levels < pen.scope) ring_levels *= 2;
+    la.lds_seq_cap = seq_cap; la.la_rle_cap = rle_cap; la.la_rle_tmp = seq_cap; la.la_rle_out = seq_cap + 4 * rle_cap;
+    la.ring_off = seq_cap + 8 * rle_cap; la.ring_mask = ring_levels - 1;
+    la.la_region = la.ring_off + 3 * ring_levels * 5 * (uint32_t)sizeof(WfDesc); la.la_region_bytes = region;
+    la.la_gdesc_slots = std::min<uint32_t>(40, (region / 3) / (5 * (uint32_t)sizeof(WfDesc)));
+    la.retry_jobs = (JobDev*)d_retry; la.retry_count = (unsigned int*)d_counter + 1;
+    const size_t la_lds = (size_t)la.la_region + region;
+    void (*const la_fn)(const KArgs) = p.metric == 1 ? wfa_kernel<1, true> : wfa_kernel<3, true>;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, la_fn, 64, la_lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
+    const int64_t la_grid = std::max<int64_t>(1, std::min<int64_t>(L.n_jobs_host, (int64_t)c->num_cus * occ));
+    if (c->knobs.debug) fprintf(stderr, "[wfa] LDS-arena variant: lds=%zu (+ static) occupancy=%d grid=%lld ring levels %u gdesc slots %u\n", la_lds, occ, (long long)la_grid, ring_levels, la.la_gdesc_slots);
+    hipLaunchKernelGGL(la_fn, dim3((unsigned)la_grid), dim3(64), la_lds, c->stream, la);
+    TRGT_HIP_TRY(c, hipGetLastError());
+    a.jobs = (const JobDev*)d_retry; a.n_jobs_dev = (const uint32_t*)d_counter + 1; a.n_jobs2_dev = nullptr; a.jobs_cap = 0;
+    a.counter = (unsigned int*)d_counter + 2;
+  }
   if (a.fast_wcap > 0) {
     // every job of this batch qualifies for the dedicated LDS-resident kernel (wfa_fast.hpp)
     if (lds > 48 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)fast_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fast_fn, grid, block, lds, c->stream, a);
   } else
   switch (p.metric) {
-    case 0: hipLaunchKernelGGL(wfa_kernel<0>, grid, block, lds, c->stream, a); break;
-    case 1: hipLaunchKernelGGL(wfa_kernel<1>, grid, block, lds, c->stream, a); break;
-    case 2: hipLaunchKernelGGL(wfa_kernel<2>, grid, block, lds, c->stream, a); break;
-    case 3: hipLaunchKernelGGL(wfa_kernel<3>, grid, block, lds, c->stream, a); break;
-    default: hipLaunchKernelGGL(wfa_kernel<4>, grid, block, lds, c->stream, a); break;
+    case 0: hipLaunchKernelGGL((wfa_kernel<0, false>), grid, block, lds, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((wfa_kernel<1, false>), grid, block, lds, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((wfa_kernel<2, false>), grid, block, lds, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((wfa_kernel<3, false>), grid, block, lds, c->stream, a); break;
+    default: hipLaunchKernelGGL((wfa_kernel<4, false>), grid, block, lds, c->stream, a); break;
   }
-  TRGT_HIP_TRY(c, hipGetLastError());
+  { const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "alignment kernel launch failed: %s (buffer set %d, at most %lld jobs, metric %d, %s, lds %zu, grid %lld x %d)", hipGetErrorString(le),
+                                      L.buffer_set, (long long)L.n_jobs_host, p.metric, a.fast_wcap ? "dedicated kernel" : "generic kernel", lds, (long long)grid_blocks, threads); }
   t.stop(0);
+  if (la_ok && c->knobs.debug) {  // (synchronises: developer output only)
+    unsigned int h[4] = {0, 0, 0, 0};
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpy(h, d_counter, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[wfa] LDS-arena variant: metric %d, %lld jobs at most, %u went on to the HBM variant\n", p.metric, (long long)L.n_jobs_host, h[1]);
+  }
 #ifdef TRGT_WFA_PROF
   if (a.fast_wcap == 0) {
     unsigned long long h[8], z[8] = {0};

@@ -51,6 +51,10 @@ struct KArgs {
   uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg, fast_koff /* bias of the diagonal index in the ring; 0 = pattern length + 2 */;
   int32_t* status; int32_t* score; int32_t* n_match; uint32_t* span4; uint32_t* cigar; uint32_t* cigar_len; uint8_t* ops; uint32_t* ops_len;
   unsigned long long* cells_out;
+  // LDS-arena variant: byte offsets inside the dynamic LDS and capacities; jobs it cannot hold go to the retry list (the HBM variant)
+  uint32_t la_rle_tmp, la_rle_out, la_rle_cap, la_region, la_region_bytes, la_gdesc_slots, la_seq_max;
+  JobDev* retry_jobs; unsigned int* retry_count;
+  uint32_t ring_off, ring_mask;  // descriptor rings in the dynamic LDS (behind the sequences): ring_mask + 1 levels (a power of two >= the score scope)
 };
 
 struct Inst {  // one unidirectional aligner (forward / reverse / base)
@@ -61,6 +65,7 @@ struct Inst {  // one unidirectional aligner (forward / reverse / base)
   WfDesc* gdesc; int n_slots;           // global descriptor history (full-history instance only)
   int32_t* arena; uint32_t arena_cap, bump, stride;
   int num_null_steps, steps_wait, status, end_score, end_k, end_off, cur;
+  uint32_t arena_lds, pp_lds, tp_lds;   // LDS-arena variant (LA): byte offsets of the arena / the two sequences in the dynamic LDS
 };
 
 struct Red {
@@ -73,19 +78,38 @@ struct Red {
 struct Breakpoint { int score, score_f, score_r, k_f, off_f, comp; };
 struct Seg { int pb, pl, tb, tl, cb, ce, rem, top; };
 
+constexpr int BI_STACK = 48;  // explicit recursion stack of the BiWFA driver (two entries per level of the split tree)
 struct Shared {
   Inst inst[3];
-  WfDesc ring[3][RING * 5];
   Red red;
   Breakpoint bp;
-  Seg stack[64];
+  Seg stack[BI_STACK];
   int sp, job, status, score, top_bp, rle_n, rle_tmp_n;
   unsigned long long cells;
+  // the kernel argument, copied once per workgroup: the engine functions read it here (a reference to the kernel argument itself handed to
+  // a non-inlined function forces a private copy of all of it, and every field read becomes a scratch load)
+  KArgs args;
+  uint32_t ring_off, ring_mask;  // descriptor rings of the three instances in the dynamic LDS: [3][ring_mask + 1][5] WfDesc at lds_dyn + ring_off
 };
 
 // Workgroup state lives in one file-scope LDS object so that the (non-inlined) engine functions address it as LDS.
 __shared__ Shared g_sh;
 #define sh g_sh
+
+// Dynamic LDS of wfa_kernel: [pattern | text] staged per job, and -- LDS-arena variant (template parameter LA of everything below that
+// touches wavefront offsets) -- the run-length buffers and the wavefront arenas of the current alignment.  With LA the arena and the
+// sequences are addressed as offsets into this array, so that the compiler emits LDS instructions (a pointer kept in the Inst record
+// would make every access a flat one); without it they are the HBM workspace pointers of the Inst record.
+extern __shared__ unsigned char lds_dyn[];
+__device__ __forceinline__ WfDesc& ring_at(int ii, int s, int c) {
+  return reinterpret_cast<WfDesc*>(lds_dyn + sh.ring_off)[((uint32_t)ii * (sh.ring_mask + 1u) + ((uint32_t)s & sh.ring_mask)) * 5u + (uint32_t)c];
+}
+#define KP (sh.args.kp)
+template <bool LA> __device__ __forceinline__ int32_t* arena_of(const Inst& I) {
+  if constexpr (LA) return reinterpret_cast<int32_t*>(lds_dyn + I.arena_lds); else return I.arena;
+}
+template <bool LA> __device__ __forceinline__ const uint8_t* pat_of(const Inst& I) { if constexpr (LA) return lds_dyn + I.pp_lds; else return I.pp; }
+template <bool LA> __device__ __forceinline__ const uint8_t* txt_of(const Inst& I) { if constexpr (LA) return lds_dyn + I.tp_lds; else return I.tp; }
 
 // run-length CIGAR building block (len << 4 | code), merging equal neighbours
 __device__ __forceinline__ void rle_push(uint32_t* buf, int& n, uint32_t cap, uint32_t code, int len) {
@@ -101,14 +125,14 @@ __device__ __forceinline__ WfDesc null_desc() { WfDesc d; d.lo = 1; d.hi = -1; d
 // wavefront_compute_get_*wavefront: NULL pointer or ->null are replaced by the canonical null wavefront
 __device__ __forceinline__ WfDesc fetch(int ii, int c, int s) {
   if (s < 0) return null_desc();
-  WfDesc d = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+  WfDesc d = ring_at(ii, s, c);
   if (d.base == NOBASE || d.lo > d.hi) return null_desc();
   return d;
 }
 // raw pointer semantics (may be ->null); valid for s within the last RING levels
 __device__ __forceinline__ WfDesc fetch_raw(int ii, int c, int s) {
   if (s < 0) return null_desc();
-  return sh.ring[ii][(s & (RING - 1)) * 5 + c];
+  return ring_at(ii, s, c);
 }
 __device__ __forceinline__ int32_t wf_get(const int32_t* __restrict__ arena, const WfDesc& d, int k) {
   return (k >= d.lo && k <= d.hi) ? arena[d.base + (uint32_t)(k - d.lo_alloc)] : OFF_NULL;
@@ -153,10 +177,11 @@ __device__ __forceinline__ void red_reset(Red& r) {
 }
 
 // Extend one M cell (wavefront_extend_matches_packed_*), update termination / antidiagonal reductions.
+template <bool LA>
 __device__ __forceinline__ int32_t extend_cell(const Inst& I, Red& red, int k, int32_t off, bool want_ak, int ak) {
   int v = off - k, h = off;
   const int plen = I.plen, tlen = I.tlen, rev = I.rev;
-  const uint8_t* pp = I.pp; const uint8_t* tp = I.tp;
+  const uint8_t* pp = pat_of<LA>(I); const uint8_t* tp = txt_of<LA>(I);
   while (v < plen && h < tlen && seq_at(pp, plen, rev, v) == seq_at(tp, tlen, rev, h)) { ++v; ++h; }
   off = h;
   if (I.span == 1) {  // wavefront_termination_endsfree
@@ -170,7 +195,7 @@ __device__ __forceinline__ int32_t extend_cell(const Inst& I, Red& red, int k, i
 
 // thread 0: publish a finished descriptor (LDS mirror + global history)
 __device__ __forceinline__ void put_desc(int ii, int c, int s, const WfDesc& d) {
-  sh.ring[ii][(s & (RING - 1)) * 5 + c] = d;
+  ring_at(ii, s, c) = d;
   Inst& I = sh.inst[ii];
   if (!I.modular && s < I.n_slots) I.gdesc[(size_t)s * 5 + c] = d;
 }
@@ -190,8 +215,11 @@ __device__ __forceinline__ uint32_t wf_alloc(Inst& I, Red& red, int s, int ci, i
 
 // ------------------------------------------------------------------------------------------------
 // wavefront_unialign_init: wavefront zero (+ heuristic clear).  All threads.
-__device__ __noinline__ void wf_init(int ii, const KParams& kp) {
+template <bool LA>
+__device__ __noinline__ void wf_init(int ii) {
+  const KParams& kp = KP;
   Inst& I = sh.inst[ii];
+  int32_t* const AR = arena_of<LA>(I);
   const int tid = threadIdx.x, T = blockDim.x;
   __syncthreads();
   if (tid == 0) {
@@ -204,7 +232,7 @@ __device__ __noinline__ void wf_init(int ii, const KParams& kp) {
       d.lo = d.hi = d.lo_alloc = 0;
       static const int slot_of[5] = {0, 1, 3, 2, 4};  // component -> allocation slot (M, I1, D1, I2, D2)
       d.base = wf_alloc(I, sh.red, 0, slot_of[I.cb], ncomp, kp.pen.scope, 1);
-      if (!sh.red.oom) { I.arena[d.base] = 0; put_desc(ii, I.cb, 0, d); }
+      if (!sh.red.oom) { AR[d.base] = 0; put_desc(ii, I.cb, 0, d); }
       sh.cells += 1;
     } else {
       d.lo = d.lo_alloc = -I.pbf; d.hi = I.tbf;
@@ -216,15 +244,17 @@ __device__ __noinline__ void wf_init(int ii, const KParams& kp) {
   __syncthreads();
   if (sh.red.oom) { if (tid == 0) I.status = ST_OOM; __syncthreads(); return; }
   if (I.span == 1) {
-    const WfDesc d = sh.ring[ii][CM];
-    for (int k = d.lo + tid; k <= d.hi; k += T) I.arena[d.base + (uint32_t)(k - d.lo_alloc)] = k > 0 ? k : 0;
+    const WfDesc d = ring_at(ii, 0, CM);
+    for (int k = d.lo + tid; k <= d.hi; k += T) AR[d.base + (uint32_t)(k - d.lo_alloc)] = k > 0 ? k : 0;
   }
   __syncthreads();
 }
 
 // Extension of an existing M wavefront (score 0).  All threads.
+template <bool LA>
 __device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
   Inst& I = sh.inst[ii];
+  int32_t* const AR = arena_of<LA>(I);
   const int tid = threadIdx.x, T = blockDim.x;
   const WfDesc d = fetch_raw(ii, CM, s);
   if (tid == 0) red_reset(sh.red);
@@ -232,14 +262,14 @@ __device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
   if (d.base != NOBASE) {
     const int ak = I.tlen - I.plen;
     for (int k = d.lo + tid; k <= d.hi; k += T) {
-      int32_t off = I.arena[d.base + (uint32_t)(k - d.lo_alloc)];
+      int32_t off = AR[d.base + (uint32_t)(k - d.lo_alloc)];
       if (off < 0) continue;
-      off = extend_cell(I, sh.red, k, off, want_ak, ak);
-      I.arena[d.base + (uint32_t)(k - d.lo_alloc)] = off;
+      off = extend_cell<LA>(I, sh.red, k, off, want_ak, ak);
+      AR[d.base + (uint32_t)(k - d.lo_alloc)] = off;
     }
     if (I.ce != CM && tid == 0) {  // end component other than M at score 0: its single cell
       const WfDesc e = fetch_raw(ii, I.ce, s);
-      if (e.base != NOBASE && ak >= e.lo && ak <= e.hi) sh.red.end_val = I.arena[e.base + (uint32_t)(ak - e.lo_alloc)];
+      if (e.base != NOBASE && ak >= e.lo && ak <= e.hi) sh.red.end_val = AR[e.base + (uint32_t)(ak - e.lo_alloc)];
     }
   }
   __syncthreads();
@@ -249,8 +279,9 @@ __device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
 // wavefront_compute_{edit,linear,affine,affine2p} fused with the extension of the new M wavefront.
 // All threads.  On return the descriptors of score s are published and the reductions hold the
 // termination / antidiagonal data of M[s].
-template <int METRIC>
-__device__ __noinline__ void wf_compute_extend(int ii, int s, const KParams& kp, bool want_ak) {
+template <int METRIC, bool LA>
+__device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
+  const KParams& kp = KP;
   Inst& I = sh.inst[ii];
   Red& red = sh.red;
   const Pen& pen = kp.pen;
@@ -301,23 +332,23 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, const KParams& kp,
     red_reset(red);
     for (int c = 0; c < 5; ++c) put_desc(ii, c, s, null_desc());
     WfDesc d; d.lo = d.lo_alloc = lo; d.hi = hi;
-    d.base = wf_alloc(I, red, s, 0, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CM] = d;
+    d.base = wf_alloc(I, red, s, 0, NCOMP, pen.scope, width); ring_at(ii, s, CM) = d;
     if (NCOMP >= 3) {
-      d.base = wf_alloc(I, red, s, 1, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CI1] = d;
-      d.base = wf_alloc(I, red, s, 2, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CD1] = d;
+      d.base = wf_alloc(I, red, s, 1, NCOMP, pen.scope, width); ring_at(ii, s, CI1) = d;
+      d.base = wf_alloc(I, red, s, 2, NCOMP, pen.scope, width); ring_at(ii, s, CD1) = d;
     }
     if (NCOMP == 5) {
-      d.base = wf_alloc(I, red, s, 3, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CI2] = d;
-      d.base = wf_alloc(I, red, s, 4, NCOMP, pen.scope, width); sh.ring[ii][(s & (RING - 1)) * 5 + CD2] = d;
+      d.base = wf_alloc(I, red, s, 3, NCOMP, pen.scope, width); ring_at(ii, s, CI2) = d;
+      d.base = wf_alloc(I, red, s, 4, NCOMP, pen.scope, width); ring_at(ii, s, CD2) = d;
     }
     sh.cells += (unsigned long long)(width > 0 ? width : 0) * NCOMP;
   }
   __syncthreads();
   if (red.oom) { if (tid == 0) { I.status = ST_OOM; I.cur = s; } __syncthreads(); return; }
-  const uint32_t bM = sh.ring[ii][(s & (RING - 1)) * 5 + CM].base;
-  const uint32_t bI1 = sh.ring[ii][(s & (RING - 1)) * 5 + CI1].base, bD1 = sh.ring[ii][(s & (RING - 1)) * 5 + CD1].base;
-  const uint32_t bI2 = sh.ring[ii][(s & (RING - 1)) * 5 + CI2].base, bD2 = sh.ring[ii][(s & (RING - 1)) * 5 + CD2].base;
-  int32_t* __restrict__ A = I.arena;
+  const uint32_t bM = ring_at(ii, s, CM).base;
+  const uint32_t bI1 = ring_at(ii, s, CI1).base, bD1 = ring_at(ii, s, CD1).base;
+  const uint32_t bI2 = ring_at(ii, s, CI2).base, bD2 = ring_at(ii, s, CD2).base;
+  int32_t* __restrict__ A = arena_of<LA>(I);
   // ---- strips of T diagonals
   for (int kb = lo; kb <= hi; kb += T) {
     const int k = kb + tid;
@@ -349,7 +380,7 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, const KParams& kp,
         if (METRIC == M_AFFINE2P) { A[bI2 + idx] = ins2; A[bD2 + idx] = del2; }
       }
       if (!in_bounds(mx, k, plen, tlen)) mx = OFF_NULL;  // "adjust offset out of boundaries"
-      if (mx >= 0) mx = extend_cell(I, red, k, mx, want_ak, ak);
+      if (mx >= 0) mx = extend_cell<LA>(I, red, k, mx, want_ak, ak);
       A[bM + idx] = mx;
       if (NCOMP >= 3 && k == ak && I.ce != CM)
         red.end_val = I.ce == CI1 ? ins1 : I.ce == CD1 ? del1 : I.ce == CI2 ? ins2 : del2;
@@ -368,7 +399,7 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, const KParams& kp,
   __syncthreads();
   if (tid == 0) {
     auto fin = [&](int c, bool exists) {
-      WfDesc d = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+      WfDesc d = ring_at(ii, s, c);
       if (!exists) d = null_desc();
       else if (red.lo[c] == INT32_MAX) { d.hi = d.lo - 1; }  // nothing in bounds: ->null (lo > hi)
       else { d.lo = red.lo[c]; d.hi = red.hi[c]; }
@@ -392,7 +423,9 @@ __device__ __forceinline__ int wf_dist(const Inst& I, int32_t off, int k) {
 }
 
 // wavefront_heuristic_cufoff (wfadaptive).  All threads.
-__device__ __noinline__ void wf_heuristic_cutoff(int ii, int s, const KParams& kp) {
+template <bool LA>
+__device__ __noinline__ void wf_heuristic_cutoff(int ii, int s) {
+  const KParams& kp = KP;
   Inst& I = sh.inst[ii];
   Red& red = sh.red;
   const int tid = threadIdx.x, T = blockDim.x;
@@ -403,7 +436,7 @@ __device__ __noinline__ void wf_heuristic_cutoff(int ii, int s, const KParams& k
   __syncthreads();
   const bool run = I.steps_wait <= 0 && (m.hi - m.lo + 1) >= kp.h_min_len;
   if (run) {
-    const int32_t* __restrict__ A = I.arena;
+    const int32_t* __restrict__ A = arena_of<LA>(I);
     for (int kb = m.lo; kb <= m.hi; kb += T) {
       const int k = kb + tid;
       int d = INT32_MAX;
@@ -440,7 +473,7 @@ __device__ __noinline__ void wf_heuristic_cutoff(int ii, int s, const KParams& k
     put_desc(ii, CM, s, d);
     if (kp.pen.metric > M_LINEAR) {  // wavefront_heuristic_equate
       auto equate = [&](int c) {
-        WfDesc e = sh.ring[ii][(s & (RING - 1)) * 5 + c];
+        WfDesc e = ring_at(ii, s, c);
         if (e.base == NOBASE) return;
         if (d.lo > e.lo) e.lo = d.lo;
         if (d.hi < e.hi) e.hi = d.hi;
@@ -454,7 +487,9 @@ __device__ __noinline__ void wf_heuristic_cutoff(int ii, int s, const KParams& k
 }
 
 // Post-extension part of wavefront_extend_{end2end,end2end_max,endsfree}.  All threads; returns 1 when done.
-__device__ __noinline__ int wf_post_extend(int ii, int s, const KParams& kp, bool act_on_end, int* max_ak) {
+template <bool LA>
+__device__ __noinline__ int wf_post_extend(int ii, int s, bool act_on_end, int* max_ak) {
+  const KParams& kp = KP;
   Inst& I = sh.inst[ii];
   Red& red = sh.red;
   const int tid = threadIdx.x;
@@ -493,27 +528,27 @@ __device__ __noinline__ int wf_post_extend(int ii, int s, const KParams& kp, boo
   __syncthreads();
   const int f = red.flag;
   const int mak = red.max_ak;
-  if (f & 2) wf_heuristic_cutoff(ii, s, kp);
+  if (f & 2) wf_heuristic_cutoff<LA>(ii, s);
   if (max_ak) *max_ak = (f & 1) ? 0 : mak;
   return f & 1;
 }
 
 // One score step: compute + extend + post.  All threads.
-template <int METRIC>
-__device__ __forceinline__ int wf_step(int ii, int s, const KParams& kp, bool act_on_end, int* max_ak) {
-  wf_compute_extend<METRIC>(ii, s, kp, max_ak != nullptr);
-  return wf_post_extend(ii, s, kp, act_on_end, max_ak);
+template <int METRIC, bool LA>
+__device__ __forceinline__ int wf_step(int ii, int s, bool act_on_end, int* max_ak) {
+  wf_compute_extend<METRIC, LA>(ii, s, max_ak != nullptr);
+  return wf_post_extend<LA>(ii, s, act_on_end, max_ak);
 }
 
 // wavefront_unialign.  All threads; returns status.
-template <int METRIC>
-__device__ int wf_run(int ii, const KParams& kp) {
-  wf_init(ii, kp);
+template <int METRIC, bool LA>
+__device__ int wf_run(int ii) {
+  wf_init<LA>(ii);
   if (sh.inst[ii].status == ST_OOM) return ST_OOM;
-  wf_extend_only(ii, 0, false);
-  if (wf_post_extend(ii, 0, kp, true, nullptr)) return sh.inst[ii].status;
+  wf_extend_only<LA>(ii, 0, false);
+  if (wf_post_extend<LA>(ii, 0, true, nullptr)) return sh.inst[ii].status;
   for (int s = 1;; ++s)
-    if (wf_step<METRIC>(ii, s, kp, true, nullptr)) return sh.inst[ii].status;
+    if (wf_step<METRIC, LA>(ii, s, true, nullptr)) return sh.inst[ii].status;
 }
 
 }  // namespace wfa
