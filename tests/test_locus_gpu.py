@@ -25,6 +25,25 @@ def _run_both(locus, b, params=None):
     finally:
         hctx.close()
     yield "host glue", out
+    rctx = _lib.context_with_env(TRGT_HOST_REPAIR=1)  # loci whose pick lacks majority support go back to the host (no device-side repair)
+    try:
+        out = locus.run_batch(b, params, ctx=rctx)
+        assert int(out.stats[18]) == 0
+    finally:
+        rctx.close()
+    yield "host repair", out
+    sctx = _lib.context_with_env(TRGT_REPAIR_MAX_SEG=60)  # device-side repair for short segments only: both paths in one call
+    try:
+        out = locus.run_batch(b, params, ctx=sctx)
+    finally:
+        sctx.close()
+    yield "mixed repair", out
+    pctx = _lib.context_with_env(TRGT_SPLIT_HMM=1)  # the HMM of the settled loci next to the device-side repair, a second batch behind it
+    try:
+        out = locus.run_batch(b, params, ctx=pctx)
+    finally:
+        pctx.close()
+    yield "split hmm", out
     yield "host reads", locus.run_batch(b, params)
     reads_dev = torch.from_numpy(b["read_blob"]).cuda()
     flank_dev = torch.from_numpy(b["flank_blob"]).cuda()
@@ -101,6 +120,8 @@ def test_locus_batch_noisy_reads_trigger_consensus_repair(oracle, mods):
     for mode, out in _run_both(locus, b):
         n_repair = _compare(oracle, locus, b, out, locus.Params(), range(60))
         assert n_repair > 5 and int(out.stats[1]) > 0, mode
+        if mode in ("host reads", "device"):  # the consensus repair ran on the device (locus_gt.hpp), nothing found no room
+            assert int(out.stats[18]) > 5 and int(out.stats[19]) == 0 and int(out.stats[20]) == int(out.stats[1]), (mode, out.stats[18:21])
 
 
 def test_locus_batch_device_resident_reads_and_downsampling(oracle, mods):

@@ -43,6 +43,8 @@ struct trgt_knobs {
   int lds_wfa_kb = 7;        // TRGT_WFA_LDS_KB: LDS of the LDS-arena variant for the wavefronts of one alignment
   int lds_wfa_seq = 768;     // TRGT_WFA_LDS_SEQ: ... for its two sequences (padded pattern + text)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
+  bool split_hmm = false;    // TRGT_SPLIT_HMM: the HMM of the loci the genotyper settles next to the device-side repair of the others, a second batch behind it
+  int repair_blocks = 2048;  // TRGT_REPAIR_BLOCKS: workgroups (and workspaces) of the alignment kernel of the device-side repair
   int repair_max_seg = 256;  // TRGT_REPAIR_MAX_SEG: longest repeat segment the device-side repair takes (its alignment workspace is planned for it)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
@@ -100,6 +102,8 @@ struct trgt_hip_ctx {
   int64_t next_ticket = 1;
   // side streams for the launches of one HMM batch (one per workgroup-size class: they run next to each other, not one behind the
   // other's tail), with the events that fork them off the batch's stream and join them back
+  hipStream_t stream_hmm = nullptr;  // the first device-resolved HMM batch of a call, when the device-side repair runs next to it
+  hipEvent_t ev_gt = nullptr, ev_rp = nullptr;  // fork / join of the device-side consensus repair (second stream) next to the first HMM batch
   hipEvent_t ev_scan = nullptr, ev_heavy = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
   // side streams of the HMM launches: [0..2] of buffer set 0, [3..5] of buffer set 1 (the second batch of a call runs next to the first)
   hipStream_t hmm_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -179,7 +183,7 @@ enum Slot {
   S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
-  S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED,
+  S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED, S_GT_GENO,
   S_HMM_BUILD,  // inputs of the device-side model builder (one slab)
   S_VOTE_GROUPS, S_VOTE_SCRATCH, S_VOTE_OUT, S_VOTE_LEN,  // consensus column voting (consensus_vote.hpp)
   S_RP_GROUPS, S_RP_JOBS, S_RP_LOCI, S_RP_PEND, S_RP_CIGAR, S_RP_CLEN, S_RP_VOUT, S_RP_VLEN, S_RP_VSCR, S_RP_COUNTS,  // device-side consensus repair (locus_gt.hpp)

@@ -90,7 +90,7 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
     k.one_launch = flag("TRGT_WFA_ONE_LAUNCH"); k.no_spec = flag("TRGT_WFA_NO_SPEC"); k.no_window = flag("TRGT_WFA_NO_WINDOW");
     k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.one_stream = flag("TRGT_FLANK_ONE_STREAM"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.host_hmm_lists = flag("TRGT_HOST_HMM_LISTS"); k.no_early = flag("TRGT_WFA_NO_EARLY"); k.stage_lock = flag("TRGT_STAGE_LOCK"); k.no_long_filter = flag("TRGT_NO_LONG_FILTER"); k.filter_one_launch = flag("TRGT_FILTER_ONE_LAUNCH"); k.debug = flag("TRGT_WFA_DEBUG");
     k.timeline = flag("TRGT_TIMELINE");
-    k.host_repair = flag("TRGT_HOST_REPAIR"); k.repair_max_seg = num("TRGT_REPAIR_MAX_SEG", k.repair_max_seg);
+    k.host_repair = flag("TRGT_HOST_REPAIR"); k.repair_max_seg = num("TRGT_REPAIR_MAX_SEG", k.repair_max_seg); k.split_hmm = flag("TRGT_SPLIT_HMM"); k.repair_blocks = num("TRGT_REPAIR_BLOCKS", k.repair_blocks);
     k.no_lds_wfa = !flag("TRGT_WFA_LDS"); k.lds_wfa_kb = num("TRGT_WFA_LDS_KB", k.lds_wfa_kb); k.lds_wfa_seq = num("TRGT_WFA_LDS_SEQ", k.lds_wfa_seq);
 #ifdef TRGT_DEV_BUILD
     k.skip_bt = flag("TRGT_DBG_SKIP_BT");
@@ -123,6 +123,9 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
   for (int i = 0; i < 2; ++i) if (c->hmm_fork[i]) (void)hipEventDestroy(c->hmm_fork[i]);
   if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
   if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
+  if (c->stream_hmm) (void)hipStreamDestroy(c->stream_hmm);
+  if (c->ev_gt) (void)hipEventDestroy(c->ev_gt);
+  if (c->ev_rp) (void)hipEventDestroy(c->ev_rp);
   delete static_cast<trgt::HostPool*>(c->host_pool);
   for (auto& b : c->h2d_stage) if (b.p) (void)hipHostFree(b.p);
   for (auto& k : c->d2h_chunks) if (k.p) (void)hipHostFree(k.p);

@@ -585,8 +585,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   //  once stage A is on the GPU)
   HmmModels models;  // the motif-HMM tables depend only on the catalog: built on the device, behind stage A's launches (below)
   const hipStream_t upload_stream = c->stream2;  // (the "second stream" of this call, whichever of the two is current later on)
-  HmmPending *hmm_pending = nullptr, *hmm_pending2 = nullptr;
-  struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending}, pend_guard2{hmm_pending2};
+  HmmPending *hmm_pending = nullptr, *hmm_pending2 = nullptr, *hmm_pendingB = nullptr;
+  struct PendGuard { HmmPending*& p; ~PendGuard() { if (p) hmm_pending_free(p); } } pend_guard{hmm_pending}, pend_guard2{hmm_pending2}, pend_guardB{hmm_pendingB};
   std::vector<uint32_t> js2, sl2, ns2; std::vector<uint64_t> so2, spo2, co2; std::vector<double> pu2; std::vector<int64_t> slot2;  // stage C, host-path loci
 
   // ---------------- stage A: flank location on the GPU (span_locater.rs:32-68), enqueued without host waits
@@ -662,12 +662,12 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     size_t add(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
   } slab;
   const size_t o_ss = slab.add((size_t)nr * 4), o_se = slab.add((size_t)nr * 4), o_hl = slab.add((size_t)nr), o_hr = slab.add((size_t)nr);
-  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0, o_gsz = 0, o_rpc = 0;
+  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0, o_gsz = 0, o_rpc = 0, o_skipb = 0;
   if (dev_gt) {
     o_need = slab.add((size_t)nl); o_nal = slab.add((size_t)nl * 4); o_alen = slab.add(2 * (size_t)nl * 4); o_ci = slab.add(4 * (size_t)nl * 4);
     o_nsp = slab.add(2 * (size_t)nl * 4); o_cls = slab.add((size_t)nr * 4); o_rank = slab.add((size_t)nr * 4); o_nspan = slab.add((size_t)nl * 4);
     o_toff = slab.add((2 * (size_t)nl + 1) * 8); o_flip = slab.add((size_t)nl);
-    o_gsz = slab.add(2 * (size_t)nl * 4); o_rpc = slab.add(gt::RC_WORDS * 4);
+    o_gsz = slab.add(2 * (size_t)nl * 4); o_rpc = slab.add(gt::RC_WORDS * 4); o_skipb = slab.add((size_t)nl);
   }
   void *d_slab = nullptr, *h_slab = nullptr;
   if ((rc = dev_get(c, S_LOCUS_4, slab.total, &d_slab)) || (rc = pin_get(c, P_SPAN_S, slab.total, &h_slab))) return rc;
@@ -678,7 +678,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // device genotyper: inputs it needs beyond stage A's, and its outputs (device + pinned mirrors)
   struct GtDev {
     const uint64_t* lrb = nullptr; const uint8_t* ploidy = nullptr; const uint8_t* tr = nullptr; const uint64_t* tr_off = nullptr;
-    const uint32_t* tr_len = nullptr; const uint64_t* al_off = nullptr; const uint32_t* al_cap = nullptr;
+    const uint32_t* tr_len = nullptr; const uint64_t* al_off = nullptr; const uint32_t* al_cap = nullptr; const uint8_t* geno = nullptr;
     void *need = nullptr, *nal = nullptr, *blob = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr,
          *toff = nullptr, *packed = nullptr;
   } g;
@@ -687,7 +687,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     if ((rc = dev_in(c, S_GT_LRB, in->locus_read_begin, (size_t)nl + 1, &g.lrb, &ub)) || (rc = dev_in(c, S_GT_PLOIDY, in->ploidy, (size_t)nl, &g.ploidy, &ub)) ||
         (rc = dev_in(c, S_GT_TR, in->tr_blob, (size_t)tr_total, &g.tr, &ub)) || (rc = dev_in(c, S_GT_TROFF, in->tr_off, (size_t)nl, &g.tr_off, &ub)) ||
         (rc = dev_in(c, S_GT_TRLEN, in->tr_len, (size_t)nl, &g.tr_len, &ub)) || (rc = dev_in(c, S_GT_ALOFF, out->allele_off, 2 * (size_t)nl, &g.al_off, &ub)) ||
-        (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap, &ub)) ||
+        (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap, &ub)) || (in->genotyper && (rc = dev_in(c, S_GT_GENO, in->genotyper, (size_t)nl, &g.geno, &ub))) ||
         (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)))
       return rc;
     g.need = dsl(o_need); g.nal = dsl(o_nal); g.alen = dsl(o_alen); g.ci = dsl(o_ci); g.nsp = dsl(o_nsp); g.cls = dsl(o_cls); g.rank = dsl(o_rank);
@@ -724,6 +724,29 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (c->last_wfa_cells_dev) { const int d2h_rc = trgt::d2h(c, h_cells, c->last_wfa_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
   ((uint64_t*)h_cells)[2] = ((uint64_t*)h_cells)[3] = 0;  // pre-filter: offsets computed, alignments kept
   if (c->last_filter_cells_dev) { const int d2h_rc = trgt::d2h(c, (uint64_t*)h_cells + 2, c->last_filter_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
+  // the motif-HMM tables: built on the device (one small upload and one kernel on the copy stream, which has nothing in front of it:
+  // the second stream may be busy with the heavy flank alignments for milliseconds, and the copy engine serves the streams' copies in
+  // the order they were issued)
+  if (!c->stream_copy) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream_copy));
+  if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+  if ((rc = hmm_models_on_device(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models, c->stream_copy, c->ev_upload)))
+    return models.err.empty() ? rc : fail(c, rc, "%s", models.err.c_str());
+  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
+  TL("models uploaded");
+  // ---------------- stage C of the device-genotyped loci is enqueued behind the genotyper and before the host has seen its results: the
+  // job list is resolved on the device (hmm_enqueue_slots), so the HMM kernels start the moment the genotyper ends instead of after a
+  // host round trip (event wait, job lists, uploads: 0.8 ms of a 10k-locus call, 2.6 ms with mixed model sizes).  Two batches: the loci
+  // the genotyper settles (on the call's stream, next to the consensus repair of the others on the second stream), then the repaired ones.
+  const bool use_slots = dev_gt && models.rc == 0 && models.d_sets && !is_device_ptr(out->spans3) && !c->knobs.host_hmm_lists;
+  std::vector<uint8_t> slot_skip;
+  HmmSlots hs;
+  std::vector<uint32_t> nsB; std::vector<double> puB;  // n_spans / purity of the second batch (merged into the outputs slot by slot)
+  if (use_slots) {
+    hs.n_loci = nl; hs.cap = out->allele_cap; hs.seq_off = out->allele_off; hs.seq_blob_dev = (const uint8_t*)g.blob;
+    hs.d_n_alleles = (const int32_t*)g.nal; hs.d_allele_len = (const uint32_t*)g.alen;
+    if (in->genotyper) { slot_skip.assign(in->genotyper, in->genotyper + nl); for (auto& v : slot_skip) v = v == 1; hs.host_skip = slot_skip.data(); }
+  }
   if (dev_gt) {
     gt::GtArgs ga;
     ga.reads = d_reads; ga.read_off = d_roff; ga.read_len = d_rlen; ga.locus_read_begin = g.lrb;
@@ -733,7 +756,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     ga.need_host = (uint8_t*)g.need; ga.n_alleles = (int32_t*)g.nal; ga.allele_blob = (uint8_t*)g.blob; ga.allele_len = (uint32_t*)g.alen;
     ga.ci = (int32_t*)g.ci; ga.num_spanning = (int32_t*)g.nsp; ga.classification = (int32_t*)g.cls; ga.read_rank = (int32_t*)g.rank;
     ga.n_spanning_reads = (uint32_t*)g.nspan; ga.flipped = (uint8_t*)dsl(o_flip);
-    ga.gt_size = (int32_t*)dsl(o_gsz);
+    ga.gt_size = (int32_t*)dsl(o_gsz); ga.skip_b = (uint8_t*)dsl(o_skipb); ga.genotyper = g.geno;
     // ---- stage B on the device for the loci whose pick lacks majority support (locus_gt.hpp): job list, vote groups and the
     //      record of the decisions are written by the genotyper; the alignment kernel, the column voting and the finishing kernel
     //      follow on the same stream, and the host first hears of these loci when they are done.  TRGT_HOST_REPAIR=1: the host path.
@@ -763,13 +786,43 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     if (small_gt) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     else hipLaunchKernelGGL((gt::locus_genotype_kernel<gt::GT_MAX_READS, gt::GT_SEG_LDS>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     TRGT_HIP_TRY(c, hipGetLastError());
+    // Two ways to order the HMM of the settled loci and the repair of the others: one HMM batch behind the repair (default), or -- split_hmm,
+    // TRGT_SPLIT_HMM=1 -- the HMM of the settled loci on a stream of its own next to the repair and a second batch for the repaired loci.
+    // Measured: the split costs more in extra launches and streams than the overlap gives back, on every config.
+    const bool split = use_slots && dev_repair && c->knobs.split_hmm;
+    ga.finish_clears_need = split ? 0 : 1;  // (read by repair_finish_kernel only)
+    if (use_slots && split) {
+      if (!c->ev_gt) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_gt, hipEventDisableTiming));
+      if (!c->ev_rp) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rp, hipEventDisableTiming));
+      if (!c->stream_hmm) TRGT_HIP_TRY(c, trgt::make_side_stream(c, &c->stream_hmm));
+      TRGT_HIP_TRY(c, hipEventRecord(c->ev_gt, c->stream));
+    }
+    if (use_slots && split) {
+      // the HMM batch of the loci the genotyper settled (need_host == 0), on a stream of its own: the call's stream goes on to the results
+      // the host waits for (they must not queue behind the HMM kernels), the second stream to the device-side repair
+      const hipStream_t main_stream = c->stream;
+      TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream_hmm, c->ev_gt, 0)); TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream_hmm, c->ev_upload, 0)); c->stream = c->stream_hmm;
+      hs.d_skip = (const uint8_t*)g.need;
+      const int64_t tc0 = now_ns();
+      rc = hmm_enqueue_slots(c, &models, hs, out->spans3, out->span_off, out->n_spans, out->motif_counts, out->count_off, out->purity, &hmm_pending);
+      c->stream = main_stream;
+      if (rc) return rc;
+      tC += now_ns() - tc0;
+      TL("hmm1 enqueued (device-resolved job list)");
+    }
     if (dev_repair) {
+      // on the second stream: alignments, voting, finish, and the HMM batch of the repaired loci right behind
+      if (split) {
+        TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_gt, 0));
+        std::swap(c->stream, c->stream2);
+      }
+      struct SwapBackRp { trgt_hip_ctx* c; bool on; ~SwapBackRp() { if (on) std::swap(c->stream, c->stream2); } } swap_back_rp{c, split};
       trgt_wfa_params wp;
       trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86): BiWFA, gap-affine 2,5,1, default heuristic
       wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
       WfaLaunch LR;
       // (n_jobs_host bounds the workgroups and their workspaces, not the jobs: the count is read on the device)
-      LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, 2048); LR.n_jobs_dev = rp.counts + gt::RC_JOBS;
+      LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS;
       LR.pat_base = d_reads; LR.txt_base = d_reads;
       LR.max_plen = rp.max_seg; LR.max_tlen = rp.max_seg; LR.max_sum = 2 * (int64_t)rp.max_seg;
       LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2;
@@ -805,6 +858,16 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       TRGT_HIP_TRY(c, hipGetLastError());
       if ((rc = dbg_sync("vote + finish"))) return rc;
       TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_rpc), rp.counts, gt::RC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
+      if (split) {
+        TRGT_HIP_TRY(c, hipEventRecord(c->ev_rp, c->stream));  // (the results the host waits for do not wait for the second HMM batch)
+        hs.d_skip = (const uint8_t*)dsl(o_skipb);
+        nsB.assign(2 * (size_t)nl, 0); puB.assign(2 * (size_t)nl, 0.0);
+        const int64_t tc0 = now_ns();
+        if ((rc = hmm_enqueue_slots(c, &models, hs, out->spans3, out->span_off, nsB.data(), out->motif_counts, out->count_off, puB.data(), &hmm_pendingB, 1))) return rc;
+        tC += now_ns() - tc0;
+        std::swap(c->stream, c->stream2); swap_back_rp.on = false;
+        TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rp, 0));
+      }
     } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_rpc), 0, gt::RC_WORDS * 4, c->stream));
     hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
@@ -817,26 +880,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   TL("stage A enqueued");
   init_outputs();  // host-only work: done while the GPU is already busy
   const int64_t tw_a = now_ns();  // from here on the host waits for stage A (the table upload below sits behind it in the copy queue)
-  // the motif-HMM tables: built on the device (one small upload and one kernel on the copy stream, which has nothing in front of it:
-  // the second stream may be busy with the heavy flank alignments for milliseconds, and the copy engine serves the streams' copies in
-  // the order they were issued)
-  if (!c->stream_copy) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream_copy));
-  if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
-  if ((rc = hmm_models_on_device(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models, c->stream_copy, c->ev_upload)))
-    return models.err.empty() ? rc : fail(c, rc, "%s", models.err.c_str());
-  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
-  TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
-  TL("models uploaded");
-  // ---------------- stage C of the device-genotyped loci: enqueued right here, behind the genotyper and before the host has seen
-  // its results -- the job list is resolved on the device (hmm_enqueue_slots), so the HMM kernels start the moment stage A ends
-  // instead of after a host round trip (event wait, job lists, uploads: 0.8 ms of a 10k-locus call, 2.6 ms with mixed model sizes)
-  const bool use_slots = dev_gt && models.rc == 0 && models.d_sets && !is_device_ptr(out->spans3) && !c->knobs.host_hmm_lists;
-  std::vector<uint8_t> slot_skip;
-  if (use_slots) {
-    HmmSlots hs;
-    hs.n_loci = nl; hs.cap = out->allele_cap; hs.seq_off = out->allele_off; hs.seq_blob_dev = (const uint8_t*)g.blob;
-    hs.d_skip = (const uint8_t*)g.need; hs.d_n_alleles = (const int32_t*)g.nal; hs.d_allele_len = (const uint32_t*)g.alen;
-    if (in->genotyper) { slot_skip.assign(in->genotyper, in->genotyper + nl); for (auto& v : slot_skip) v = v == 1; hs.host_skip = slot_skip.data(); }
+  if (use_slots && !hmm_pending && !hmm_pendingB) {  // one HMM batch behind the genotyper and the repair (need_host is final by then)
+    hs.d_skip = (const uint8_t*)g.need;
     const int64_t tc0 = now_ns();
     if ((rc = hmm_enqueue_slots(c, &models, hs, out->spans3, out->span_off, out->n_spans, out->motif_counts, out->count_off, out->purity, &hmm_pending))) return rc;
     tC += now_ns() - tc0;
@@ -857,8 +902,12 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   int64_t th_begin = now_ns();
   // ---------------- loci for the host path: all of them without the device genotyper, else the ones it handed back
   std::vector<int64_t> R;
+  std::vector<uint8_t> need_a;  // need_host as the first HMM batch saw it (2 = waiting for the device-side repair: not its job)
   if (dev_gt) {
     uint8_t* need = (uint8_t*)gh.need;
+    const uint8_t* skip_b = (const uint8_t*)hsl(o_skipb);
+    if (hmm_pendingB) need_a.assign(need, need + nl);
+    for (int64_t l = 0; l < nl; ++l) if (need[l] == 2) need[l] = skip_b[l] ? 1 : 0;  // repaired on the device, or back to the host path after all
     if (in->genotyper) for (int64_t l = 0; l < nl; ++l) if (in->genotyper[l] == 1) need[l] = 1;  // Genotyper::Cluster: host-driven rounds
     if (flank_on) {
       // device-genotyped loci whose two alleles are at most 10 bases apart and whose reads DO split by haplotype tag or flank SNVs
@@ -888,7 +937,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   std::vector<uint32_t> nsp; std::vector<double> pur;
   if (dev_gt && use_slots) {
     for (int64_t l = 0; l < nl; ++l) if (!((const uint8_t*)gh.need)[l]) stat_spanning += ((const uint32_t*)gh.nspan)[l];
-    stat_hmm_jobs += hmm_slots_resolved(c, hmm_pending, &models, (const uint8_t*)gh.need, (const int32_t*)gh.nal, (const uint32_t*)gh.alen);
+    stat_hmm_jobs += hmm_slots_resolved(c, hmm_pending, &models, need_a.empty() ? (const uint8_t*)gh.need : need_a.data(), (const int32_t*)gh.nal, (const uint32_t*)gh.alen);
+    if (hmm_pendingB) stat_hmm_jobs += hmm_slots_resolved(c, hmm_pendingB, &models, (const uint8_t*)hsl(o_skipb), (const int32_t*)gh.nal, (const uint32_t*)gh.alen);
   } else if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
     const int32_t* nal = (const int32_t*)gh.nal; const uint32_t* alen = (const uint32_t*)gh.alen;
@@ -1031,6 +1081,29 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // publishing of spans and device-genotyper results: host work of ~1.2 ms that needs the GPU only to start the HMM batch.  It runs
   // while the consensus alignments of the host-path loci are on the GPU (wfa_batch_impl calls it between launch and wait), or
   // right here when there are none.
+  // the two device-resolved HMM batches: the first one's counts / purities arrive as whole arrays ("no allele" in every slot that was not
+  // its job), so it is collected first and the second one's are merged in slot by slot
+  auto collect_ab = [&]() -> int {
+    if (!hmm_pendingB) return TRGT_OK;  // (a single batch is collected where it always was, below)
+    const int64_t tc0 = now_ns();
+    if (hmm_pending) {
+      HmmPending* pend = hmm_pending; hmm_pending = nullptr;
+      if (int r = hmm_collect(c, pend)) return r;
+      const uint8_t* need = (const uint8_t*)gh.need;
+      for (int64_t l = 0; l < nl; ++l) if (need[l]) { out->n_spans[2 * l] = out->n_spans[2 * l + 1] = 0; out->purity[2 * l] = out->purity[2 * l + 1] = std::nan(""); }
+      TL("hmm1 collected");
+    }
+    {
+      HmmPending* pend = hmm_pendingB; hmm_pendingB = nullptr;
+      if (int r = hmm_collect(c, pend)) return r;
+      const uint8_t* skip_b = (const uint8_t*)hsl(o_skipb); const int32_t* nal = (const int32_t*)gh.nal;
+      for (int64_t l = 0; l < nl; ++l)
+        if (!skip_b[l]) for (int a = 0; a < nal[l]; ++a) { out->n_spans[2 * l + a] = nsB[(size_t)(2 * l + a)]; out->purity[2 * l + a] = puB[(size_t)(2 * l + a)]; }
+      TL("hmm1b collected");
+    }
+    tC += now_ns() - tc0;
+    return TRGT_OK;
+  };
   bool published = false;
   auto hmm1_enqueue = [&]() -> int {
   if (dev_gt && !use_slots) {
@@ -1327,6 +1400,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       }
     }
     if (!js2.empty()) {
+      if ((rc = collect_ab())) return rc;  // (the second device-resolved batch holds buffer set 1)
       ns2.resize(js2.size()); pu2.resize(js2.size());
       // next to the batch of the device-genotyped loci, if there is one: the call's second stream and the second set of side streams
       // (the two batches are independent; queued on the same streams the second one waited for the first -- config 3: 65 -> 5x ms per call)
@@ -1344,6 +1418,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (!published && (rc = publish())) return rc;
   // ---------------- stage C results of the device-genotyped loci
   TL("hmm2 enqueued");
+  if ((rc = collect_ab())) return rc;
   if (hmm_pending) {
     const int64_t tc0 = now_ns();
     HmmPending* pend = hmm_pending; hmm_pending = nullptr;
@@ -1375,6 +1450,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     s[14] = stat_flank_heavy; s[15] = stat_ed_jobs;
     s[16] = (int64_t)((uint64_t*)h_cells)[3]; s[17] = (int64_t)((uint64_t*)h_cells)[2];  // pre-filter: alignments kept, offsets computed
     for (int i = 18; i < 24; ++i) s[i] = 0;
+    if (dev_gt) { const uint32_t* rc_ = (const uint32_t*)hsl(o_rpc); s[18] = rc_[gt::RC_LOCI]; s[19] = rc_[gt::RC_FAILED]; s[20] = rc_[gt::RC_JOBS]; }  // device-side consensus repair: loci, loci without room, alignments
   }
   return TRGT_OK;
 }

@@ -51,6 +51,9 @@ struct GtArgs {
   int32_t* classification; int32_t* read_rank; uint32_t* n_spanning_reads;
   uint8_t* flipped;  // per locus: the two alleles were swapped to put the reference allele first
   int32_t* gt_size;  // [2 n_loci] TrSize::size of the genotype behind every allele (optional)
+  const uint8_t* genotyper;  // optional [n_loci]: 1 = Genotyper::Cluster, a locus the host genotypes (need_host = 1 at once)
+  uint8_t* skip_b;   // [n_loci] 0 for the loci repair_finish_kernel completed (their HMM batch runs behind it), else 1
+  int32_t finish_clears_need;  // 1: repair_finish_kernel also sets need_host = 0 (nothing reads it concurrently: one HMM batch behind the repair)
   RepairBufs rp;
 };
 
@@ -181,12 +184,14 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
   if (lane == 0) {
     sh.n = 0; sh.bail = 0; sh.res_n_gt = 0;
     if (a.gt_size) a.gt_size[2 * l] = a.gt_size[2 * l + 1] = 0;
+    if (a.skip_b) a.skip_b[l] = 1;
     a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0; a.flipped[l] = 0;
     a.allele_len[2 * l] = a.allele_len[2 * l + 1] = 0; a.num_spanning[2 * l] = a.num_spanning[2 * l + 1] = 0;
   }
-  if (a.ploidy[l] == 0 || nr == 0 || nr > MAXR) {  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31); oversized -> host
+  const bool cluster = a.genotyper && a.genotyper[l] == 1;
+  if (a.ploidy[l] == 0 || nr == 0 || nr > MAXR || cluster) {  // Ploidy::Zero -> LocusResult::empty (tr.rs:29-31); oversized, cluster genotyper -> host
     for (int i = lane; i < nr; i += 64) { a.classification[r0 + i] = -1; a.read_rank[r0 + i] = -1; }
-    if (lane == 0 && nr > MAXR && a.ploidy[l] != 0) a.need_host[l] = 1;
+    if (lane == 0 && (nr > MAXR || cluster) && a.ploidy[l] != 0 && nr != 0) a.need_host[l] = 1;
     return;
   }
   gt_front<MAXR>(sh, a, r0, nr, lane);
@@ -554,7 +559,8 @@ __global__ void __launch_bounds__(64) repair_finish_kernel(const GtArgs a, const
     a.classification[r0 + sh.s_read[i]] = flip ? 1 - sh.cls[i] : sh.cls[i];
     a.read_rank[r0 + sh.s_read[i]] = i;
   }
-  if (lane == 0) { a.n_alleles[l] = pd.n_gt; a.n_spanning_reads[l] = (uint32_t)n; a.flipped[l] = (uint8_t)flip; a.need_host[l] = 0; }
+  // (need_host stays 2: the HMM batch of the loci settled by the genotyper may be reading it right now; the host turns 2 into skip_b)
+  if (lane == 0) { a.n_alleles[l] = pd.n_gt; a.n_spanning_reads[l] = (uint32_t)n; a.flipped[l] = (uint8_t)flip; a.skip_b[l] = 0; if (a.finish_clears_need) a.need_host[l] = 0; }
 }
 
 }  // namespace gt
