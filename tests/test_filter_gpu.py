@@ -9,18 +9,18 @@ from helpers import mutate, rand_dna
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(oracle, pats, txts):
+def _oracle(oracle, pats, txts, scoring=(2, 5, 1)):
     out = []
     for p, t in zip(pats, txts):
-        pp = oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, span="endsfree", pbf=0, pef=0, tbf=len(t), tef=len(t), heuristic="none")
+        pp = oracle.wfa_params(metric="affine", x=scoring[0], o1=scoring[1], e1=scoring[2], span="endsfree", pbf=0, pef=0, tbf=len(t), tef=len(t), heuristic="none")
         out.append(oracle.wfa_align(pp, p, t))
     return out
 
 
-def _check(oracle, pats, txts, min_matches=175, judged=True):
+def _check(oracle, pats, txts, min_matches=175, judged=True, scoring=(2, 5, 1), early_reject=False):
     from trgt_amd.wfaligner import flank_filter_batch
-    r = flank_filter_batch(pats, txts, min_matches)
-    ref = _oracle(oracle, pats, txts)
+    r = flank_filter_batch(pats, txts, min_matches, scoring=scoring, early_reject=early_reject)
+    ref = _oracle(oracle, pats, txts, scoring)
     cells = 0
     for j, o in enumerate(ref):
         assert o["status"] == 0
@@ -187,3 +187,27 @@ def test_two_launches_by_text_length_and_forced_instantiations(oracle, monkeypat
             else:
                 assert int(r["keep"][j]) == 1, (force, j)
     monkeypatch.delenv("TRGT_FILTER_FORCE")
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_targeted_preset_1_0_1_has_a_filter_too(oracle, seed):
+    """--aln-scoring 1,0,1 (the targeted preset, cli.rs:271-280): X = OE = 1, one ring level updated in place.  Exact score, offset count
+    and a bound that never undercuts count_matches(), on the same job mix and on every instantiation; and what the early rejection drops
+    the reference would not have accepted."""
+    rng = np.random.default_rng(seed)
+    pats, txts = _flank_jobs(rng, 120)
+    r, ref = _check(oracle, pats, txts, scoring=(1, 0, 1))
+    assert 0 < int(r["keep"].sum()) < len(pats)
+    for plen, lo, hi in ((250, 780, 1000), (250, 1040, 1150), (254, 1100, 1160), (200, 200, 700)):
+        p2, t2 = _flank_jobs(rng, 24, lo, hi, plen)
+        _check(oracle, p2, t2, min_matches=int(plen * 0.7), scoring=(1, 0, 1))
+    from trgt_amd.wfaligner import flank_filter_batch
+    e = flank_filter_batch(pats, txts, 175, scoring=(1, 0, 1), early_reject=True)
+    for j, o in enumerate(ref):
+        if o["n_match"] >= 175:
+            assert int(e["keep"][j]) == 1, j
+        if int(e["keep"][j]) and int(e["score"][j]) > -(1 << 30):
+            assert int(e["score"][j]) == o["score"], j
+    assert e["offsets"] <= r["offsets"]
+    with pytest.raises(Exception):
+        flank_filter_batch(pats[:2], txts[:2], 175, scoring=(3, 1, 1))

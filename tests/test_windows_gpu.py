@@ -154,3 +154,6 @@ def test_other_penalties_and_flank_lengths(oracle, scoring, flank_len):
     p = locus.Params(aln_scoring=scoring, search_flank_len=flank_len)
     out = locus.run_batch(b, p, flank_dev=torch.from_numpy(b["flank_blob"]).cuda(), reads_dev=torch.from_numpy(b["read_blob"]).cuda())
     _compare(oracle, locus, b, out, p, range(48))
+    # the pre-filter is engaged for the two presets that have an instantiation (2,5,1 and the targeted 1,0,1): it counts its offsets
+    engaged = int(out.stats[17]) > 0
+    assert engaged == (tuple(scoring) in ((2, 5, 1), (1, 0, 1))), (scoring, int(out.stats[17]))

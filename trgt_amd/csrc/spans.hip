@@ -534,7 +534,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     while ((double)min_matches < thr) ++min_matches;
     // (texts beyond the filter's diagonals are kept unseen, job by job: a batch with a few long reads still filters the others)
     const int64_t flt_tlen = flank_filter_max_tlen(p.flank_len);
-    const bool use_filter = p.mism == 2 && p.gapo == 5 && p.gape == 1 && flt_tlen >= 2 * (int64_t)p.flank_len &&
+    const bool filter_pen = (p.mism == 2 && p.gapo == 5 && p.gape == 1) || (p.mism == 1 && p.gapo == 0 && p.gape == 1);  // wgs / targeted presets (cli.rs:271-280)
+    const bool use_filter = filter_pen && flt_tlen >= 2 * (int64_t)p.flank_len &&
                             heavy_tlen_max >= (uint32_t)p.flank_len && min_matches <= 254 && !c->knobs.no_filter;
     // Two streams: the expensive alignments (pre-filter, then the back-tracing kernel over what it keeps) run on the second stream
     // NEXT TO the other fallback alignments (segment search, windowed launch, whole-read launch) instead of in front of them.  The
@@ -557,7 +558,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       FilterLaunch FL;
       FL.jobs_dev = (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs; FL.n_jobs_dev = (const uint32_t*)d_count;
       FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
-      FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
+      FL.mism = p.mism; FL.gapo = p.gapo; FL.gape = p.gape; FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
       if ((rc = flank_filter_launch(c, FL))) return rc;
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + 6;
     }
@@ -632,7 +633,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       // (ring of 11 levels x 2 B + 4 B of windows per diagonal in 96 KB: about 3 500 bases for 250-base pieces).  Reads just above the
       // dedicated launches' length (cfg4: up to 1 300 bases) go to that LDS kernel, and the extra filter launch cost 5 % there.
       const int64_t lds_kernel_tlen = (96 * 1024) / (2 * ring_slots + 4) - p.flank_len - 32;
-      if (p.mism == 2 && p.gapo == 5 && p.gape == 1 && min_matches >= 1 && min_matches <= 254 && step >= 256 && (int64_t)max_read_len > lds_kernel_tlen &&
+      if (((p.mism == 2 && p.gapo == 5 && p.gape == 1) || (p.mism == 1 && p.gapo == 0 && p.gape == 1)) && min_matches >= 1 && min_matches <= 254 && step >= 256 && (int64_t)max_read_len > lds_kernel_tlen &&
           !c->knobs.no_filter && !c->knobs.no_long_filter) {
         const uint64_t w_max = (uint64_t)((int64_t)max_read_len > wl ? ((int64_t)max_read_len - wl + step - 1) / step + 1 : 1);
         const uint64_t cap = std::min<uint64_t>((uint64_t)n_jobs * w_max, 1ull << 21);
@@ -653,7 +654,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         FilterLaunch FW;
         FW.jobs_dev = (const JobDev*)d_sub; FW.n_jobs_host = (int64_t)cap; FW.n_jobs_dev = (const uint32_t*)d_lwc;
         FW.pat_base = d_flank; FW.txt_base = d_reads; FW.max_plen = p.flank_len; FW.max_tlen = wl;
-        FW.min_matches = (int32_t)min_matches; FW.early_reject = !c->knobs.no_early; FW.keep = (uint8_t*)d_subkeep; FW.set = 1;
+        FW.mism = p.mism; FW.gapo = p.gapo; FW.gape = p.gape; FW.min_matches = (int32_t)min_matches; FW.early_reject = !c->knobs.no_early; FW.keep = (uint8_t*)d_subkeep; FW.set = 1;
         if ((rc = flank_filter_launch(c, FW))) return rc;
         hipLaunchKernelGGL(long_verdict_kernel, g, b, 0, c->stream, lw);
         hipLaunchKernelGGL(long_kept_kernel, g, b, 0, c->stream, lw);

@@ -59,6 +59,7 @@ struct FilterLaunch {
   const uint8_t* pat_base = nullptr; const uint8_t* txt_base = nullptr;
   int64_t max_plen = 0, max_tlen = 0;
   int32_t min_matches = 0;
+  int mism = 2, gapo = 5, gape = 1;  // --aln-scoring: 2,5,1 (wgs) or 1,0,1 (targeted) have an instantiation
   bool early_reject = false;  // see FilterArgs (then: score INT32_MIN + 1, bound min_matches - 1 for the alignments stopped early)
   JobDev* keep_jobs = nullptr; uint32_t* keep_count = nullptr;
   int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;

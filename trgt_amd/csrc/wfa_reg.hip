@@ -114,9 +114,11 @@ __device__ __forceinline__ uint32_t dirty_dword(uint32_t x) {
 // j = 0 .. B - 1 (kb = k + plen): B packed registers per strip and component.  A strip's cells follow the diagonal order lane by
 // lane, so "the last in-bounds cell" is a few ballots over ONE strip, the out-of-bounds test of M is needed only in the strips
 // that reach above tlen - plen, and strips outside the level's limits are skipped.
-template <int NS, int B>
+// X = mismatch penalty, OE = gap_open + gap_extend (gap_extend = 1): M[s - X] and M[s - OE] are the sources of a level, the ring keeps
+// R = max(X, OE) M levels (wgs preset 2,5,1: X = 2, OE = 6; targeted preset 1,0,1 of cli.rs:271-280: X = OE = 1, one level, updated in place).
+template <int NS, int B, int X = 2, int OE = 6>
 __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
-  constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA, LW = 2 * B;
+  constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA, LW = 2 * B, R = X > OE ? X : OE;
   __shared__ uint32_t lds[PWN + TWN];
   uint32_t* const Pw = lds;
   uint32_t* const Tw = lds + PWN;
@@ -233,17 +235,17 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
         for (int p = 0; p < NP; ++p) t = rpk_max(t, Mx[p]);
         return t;
       };
-      uint32_t Mr[6][NP], Ir[NP], Dr[NP];
+      uint32_t Mr[R][NP], Ir[NP], Dr[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int d = 0; d < 6; ++d) Mr[d][p] = 0u;
+        for (int d = 0; d < R; ++d) Mr[d][p] = 0u;
         Ir[p] = 0u; Dr[p] = 0u;
       }
       // trimmed ranges of the live wavefronts in k (not biased); null = (1, -1) as in the library
-      int mlo[6], mhi[6], ilo = 1, ihi = -1, dlo = 1, dhi = -1;
+      int mlo[R], mhi[R], ilo = 1, ihi = -1, dlo = 1, dhi = -1;
 #pragma unroll
-      for (int d = 0; d < 6; ++d) { mlo[d] = 1; mhi[d] = -1; }
+      for (int d = 0; d < R; ++d) { mlo[d] = 1; mhi[d] = -1; }
       const int lane_kb0 = lane * LW;
       const int term_v = plen + 1;
       const int lane_bnd0 = tlen + 1 + plen - lane_kb0;  // v + 1 <= lane_bnd - C  <=>  offset <= tlen on diagonal kb = C + lane_kb
@@ -264,29 +266,30 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
         if (__builtin_amdgcn_ballot_w64(tA || tB)) { done = true; break; }
         ++s;
         if (s > SMAX) { bail = true; break; }
-        const bool n_mm = mlo[1] > mhi[1], n_mo = mlo[5] > mhi[5], n_ie = ilo > ihi, n_de = dlo > dhi;
+        const bool n_mm = mlo[X - 1] > mhi[X - 1], n_mo = mlo[OE - 1] > mhi[OE - 1], n_ie = ilo > ihi, n_de = dlo > dhi;
         // (per-lane constants go through opaque() once per level: hoisted out of the loop, their per-pair variants -- bounds, diagonal
         //  numbers -- would sit in two dozen registers for the whole alignment)
         const int lane_bnd = (int)opaque((uint32_t)lane_bnd0), lane_kb = (int)opaque((uint32_t)lane_kb0);
-        uint32_t (&Mn)[NP] = Mr[5];  // the new level replaces M[s - 6] in place (its last use is the first pass below)
+        uint32_t (&Mn)[NP] = Mr[R - 1];  // the new level replaces M[s - R] in place (its last use: the first pass below for the gap-open
+                                         // source, the read of the same element in the third pass when it is also the mismatch source)
         int nmlo = 1, nmhi = -1, nilo = 1, nihi = -1, ndlo = 1, ndhi = -1;
         if (n_mm && n_mo && n_ie && n_de) {
-          if (++num_null > 7) { bail = true; break; }  // (cannot happen with a free text; the exact kernel decides)
+          if (++num_null > R + 1) { bail = true; break; }  // (cannot happen with a free text; the exact kernel decides)
 #pragma unroll
           for (int p = 0; p < NP; ++p) Mn[p] = 0u;  // (I and D are NULL already: their sources were)
           tmax = 0;
         } else {
           num_null = 0;
           // wavefront_compute_limits_input (null wavefronts take part with lo = 1, hi = -1, as in the library)
-          const int lo = min(min(mlo[1], mlo[5] - 1), min(ilo + 1, dlo - 1));
-          const int hi = max(max(mhi[1], mhi[5] + 1), max(ihi + 1, dhi - 1));
+          const int lo = min(min(mlo[X - 1], mlo[OE - 1] - 1), min(ilo + 1, dlo - 1));
+          const int hi = max(max(mhi[X - 1], mhi[OE - 1] + 1), max(ihi + 1, dhi - 1));
           cells += 3ull * (unsigned long long)max(0, hi - lo + 1);
           // ---- the recurrences.  ins[k] = max(Mo, Ie)[k - 1] and del[k] = (max(Mo, De) + 1)[k + 1]: ONE diagonal shift per
           //      component, taken after the maximum.  In place: first I <- max(Mo, I), D <- max(Mo, D) + 1, then the shifts
           //      (I from the top strip down, D from the bottom up, so that the neighbour's unshifted value is still there).
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
-            const uint32_t mo = Mr[5][p];
+            const uint32_t mo = Mr[OE - 1][p];
             Ir[p] = rpk_max(mo, Ir[p]);
             Dr[p] = inc_v_nz(rpk_max(mo, Dr[p]));
           }
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
             for (int jj = 0; jj < B; ++jj) {
               const int p = t * B + jj;
-              uint32_t mxp = rpk_max(Dr[p], rpk_max(inc_v_nz(Mr[1][p]), Ir[p]));
+              uint32_t mxp = rpk_max(Dr[p], rpk_max(inc_v_nz(Mr[X - 1][p]), Ir[p]));
               if (top) {  // "adjust offset out of boundaries": offset > tlen -> NULL
                 const int bA = lane_bnd - (t * SW + 2 * jj);
                 const bool okA = (int)((mxp >> 8) & 0xFFu) <= bA, okB = (int)(mxp >> 24) <= bA - 1;
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
           tmax = extend_level(Mn);
           // ---- wavefront_compute_trim_ends, restated: D is always in bounds; I and M are, below k = tlen - plen (+ 1)
           constexpr int INF = 1 << 20;
-          const int so_lo = n_mo ? INF : mlo[5], so_hi = n_mo ? -INF : mhi[5];
+          const int so_lo = n_mo ? INF : mlo[OE - 1], so_hi = n_mo ? -INF : mhi[OE - 1];
           const bool has_d = !n_mo || !n_de, has_i = !n_mo || !n_ie;
           if (has_d) { ndlo = min(so_lo, n_de ? INF : dlo) - 1; ndhi = max(so_hi, n_de ? -INF : dhi) - 1; }
           // last / first cell of a component for which pred holds, looking at the strips from biased kb_hi downwards / kb_lo upwards
@@ -393,7 +396,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
             }
           }
           {
-            int mc_lo = n_mm ? INF : mlo[1], mc_hi = n_mm ? -INF : mhi[1];
+            int mc_lo = n_mm ? INF : mlo[X - 1], mc_hi = n_mm ? -INF : mhi[X - 1];
             if (has_i) { mc_lo = min(mc_lo, ic_lo); mc_hi = max(mc_hi, ic_hi); }
             if (has_d) { mc_lo = min(mc_lo, ndlo); mc_hi = max(mc_hi, ndhi); }
             nmlo = mc_lo; nmhi = mc_hi;
@@ -410,13 +413,13 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
         // ---- rotate: the new level (in the slot of M[s - 6]) becomes M[s - 1].  Element by element through opaque(): see there.
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const uint32_t newest = opaque(Mr[5][p]);
+          const uint32_t newest = opaque(Mr[R - 1][p]);
 #pragma unroll
-          for (int d = 5; d >= 1; --d) Mr[d][p] = opaque(Mr[d - 1][p]);
+          for (int d = R - 1; d >= 1; --d) Mr[d][p] = opaque(Mr[d - 1][p]);
           Mr[0][p] = newest;
         }
 #pragma unroll
-        for (int d = 5; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
+        for (int d = R - 1; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
         mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
         // ---- early rejection (every 16th level).  A cell (v bases of the pattern consumed, at most c of them matched, text position
         //      h = v + k) can end in an alignment of at most c + min(plen - v, tlen - h) matches -- a match needs a base of both -- and
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
                 dm = rpk_min(dm, rpk_sub(rpk_sub(v1, cnt), 0x00010001u));
               };
 #pragma unroll
-              for (int d = 0; d < 6; ++d) take(Mr[d][p]);
+              for (int d = 0; d < R; ++d) take(Mr[d][p]);
               take(Ir[p]); take(Dr[p]);
               if (top) {
                 const int over = t * SW + 2 * jj + lane_kb - tlen;  // biased diagonal of the low half, minus tlen
@@ -518,8 +521,12 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   // instantiation by the number of diagonals the longest text of the launch needs (jobs that do not fit are kept unseen)
   const int64_t diag = L.max_plen + L.max_tlen + 1;
   // (nine strips of 128 diagonals for texts that need up to 1152: 8 % faster there than the five strips of 256, which carry 128 dead ones)
+  const bool targeted = L.mism == 1 && L.gapo == 0 && L.gape == 1;  // the other preset: 1,0,1 (cli.rs:271-280)
+  if (!targeted && !(L.mism == 2 && L.gapo == 5 && L.gape == 1)) return fail(c, TRGT_ERR_UNSUPPORTED, "flank filter: no instantiation for penalties %d,%d,%d", L.mism, L.gapo, L.gape);
   void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 9 * 128 ? wfa_filter_kernel<9, 1> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
-  if (const char* force = getenv("TRGT_FILTER_FORCE")) {  // developer probe (tools/filter_inst_probe.py): one instantiation for the whole launch
+  void (*fn4)(const FilterArgs) = wfa_filter_kernel<4, 2>;
+  if (targeted) { fn = diag <= 4 * 256 ? wfa_filter_kernel<4, 2, 1, 1> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2, 1, 1> : wfa_filter_kernel<6, 2, 1, 1>; fn4 = wfa_filter_kernel<4, 2, 1, 1>; }
+  if (const char* force = targeted ? nullptr : getenv("TRGT_FILTER_FORCE")) {  // developer probe (tools/filter_inst_probe.py): one instantiation for the whole launch
     const int f = atoi(force);
     fn = f == 71 ? wfa_filter_kernel<7, 1> : f == 91 ? wfa_filter_kernel<9, 1> : f == 42 ? wfa_filter_kernel<4, 2> : f == 52 ? wfa_filter_kernel<5, 2> : fn;
   }
@@ -554,7 +561,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, b);
     FilterArgs s4 = a;
     s4.diag_hi = 4 * 256; s4.counter = a.counter + 1;
-    hipLaunchKernelGGL((wfa_filter_kernel<4, 2>), dim3((unsigned)grid_for(wfa_filter_kernel<4, 2>)), dim3(64), 0, c->stream, s4);
+    hipLaunchKernelGGL(fn4, dim3((unsigned)grid_for(fn4)), dim3(64), 0, c->stream, s4);
   } else hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
   TRGT_HIP_TRY(c, hipGetLastError());
   t.stop(0);
@@ -573,8 +580,8 @@ extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* 
   if (!c) return TRGT_ERR_INVALID;
   if (!p || n_jobs < 0 || (n_jobs > 0 && (!seqs || !pat_off || !pat_len || !txt_off || !txt_len)))
     return fail(c, TRGT_ERR_INVALID, "trgt_flank_filter_batch: null argument");
-  if (p->mism != 2 || p->gapo != 5 || p->gape != 1)
-    return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_flank_filter_batch: only --aln-scoring 2,5,1 has a filter kernel");
+  if (!(p->mism == 2 && p->gapo == 5 && p->gape == 1) && !(p->mism == 1 && p->gapo == 0 && p->gape == 1))
+    return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_flank_filter_batch: only --aln-scoring 2,5,1 and 1,0,1 have a filter kernel");
   if (offsets_computed) *offsets_computed = 0;
   if (n_jobs == 0) return TRGT_OK;
   if (n_jobs > 0xFFFFFFF0ll) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_flank_filter_batch: too many jobs");
@@ -604,7 +611,7 @@ extern "C" int trgt_flank_filter_batch(trgt_hip_ctx* c, const trgt_span_params* 
       (rc = o_keep.init(c, S_FLT_KEEP, keep, (size_t)n_jobs)))
     return rc;
   L.jobs_dev = (const JobDev*)d_jobs; L.n_jobs_host = n_jobs; L.pat_base = d_seq; L.txt_base = d_seq;
-  L.count_offsets = offsets_computed != nullptr || c->timing;
+  L.count_offsets = offsets_computed != nullptr || c->timing; L.mism = p->mism; L.gapo = p->gapo; L.gape = p->gape;
   L.min_matches = min_matches; L.early_reject = early_reject != 0; L.score = o_score.dev; L.bound = o_bound.dev; L.keep = o_keep.dev;
   if ((rc = flank_filter_launch(c, L))) return rc;
   if ((rc = o_score.finish(c)) || (rc = o_bound.finish(c)) || (rc = o_keep.finish(c))) return rc;
