@@ -137,6 +137,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="with --config 0: config 2 only")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (synthetic BAM -> native ingestion -> GPU -> VCF / spanning BAM) reported under \"e2e\"")
+    ap.add_argument("--e2e-loci", type=int, default=4000)
+    ap.add_argument("--e2e-read-len", type=int, default=6000)
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of each of the config 3 / 4 / 5 legs")
     ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per context in GB (trgt_hip_set_workspace_limit; 0 = by config: the library's 32 GB, 8 GB for config 3)")
     ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 6 for configs 3 and 5); 1 = the blocking call only")
@@ -181,11 +184,119 @@ def main():
             r = run_one(a, env, cpu_seconds=6.0, all_cores=False)
             r["leg_wall_s"] = round(time.perf_counter() - t0, 1)
             res["configs"][str(cfg)] = r
+    if world == 1 and not args.no_e2e and args.config == 0:
+        res["e2e"] = run_e2e(args, env)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_e2e(args, env):
+    """BAM -> VCF on this box: a synthetic coordinate-sorted BAM of full-length reads over cfg2-like loci (trgt_amd/synth_bam.py) through
+    the native ingestion (trgt_ingest_batch_from_catalog: .bai lookup, BGZF inflate, record decoding, clip_to_region; all host cores, 4-bit
+    reads kept), the locus path (reads handed over as host buffers, 4-bit) and the native VCF + spanning-BAM writer (trgt_writer_write).
+    Every stage is timed on its own over the same chunks, then the three run as a pipeline (one thread per stage, chunk queues between
+    them): that wall time is what a user of the whole tool would see.  None of this is `value`."""
+    import queue
+    import shutil
+    import tempfile
+    import threading
+    from trgt_amd import _lib, ingest, locus, synth_bam, writers
+    cores = os.cpu_count() or 8
+    n, chunk = args.e2e_loci, 1000
+    d = tempfile.mkdtemp(prefix="trgt_e2e_")
+    try:
+        t0 = time.perf_counter()
+        ds = synth_bam.write_dataset(d, n_loci=n, read_len=args.e2e_read_len)
+        t_gen = time.perf_counter() - t0
+        rd = ingest.Reader(ds["bam"], ds["fasta"])
+        firsts = list(range(0, n, chunk))
+        ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256
+    ing = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
+        ing(0)  # page cache, thread start-up
+        t0 = time.perf_counter()
+        one = ing(0, 1)
+        t_ing1 = (time.perf_counter() - t0) / max(1, one["n_loci"])
+        t0 = time.perf_counter()
+        batches = [ing(a) for a in firsts]
+        t_ing = time.perf_counter() - t0
+        views = [ingest.bam4_view(b) for b in batches]
+        ctx = _lib.Context(env["local_rank"])
+        params = locus.Params(host_threads=min(8, cores))
+        gpu = lambda v: locus.run_batch(v, params, ctx)
+        for v in views[:2]:
+            gpu(v)
+        t0 = time.perf_counter()
+        outs = [gpu(v) for v in views]
+        t_gpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        w = writers.Writer(rd, os.path.join(d, "out.vcf"), os.path.join(d, "out.spanning.bam"))
+        for b, o in zip(batches, outs):
+            w.write(b, o)
+        w.close()
+        t_wr = time.perf_counter() - t0
+        vcf_records = sum(1 for line in open(os.path.join(d, "out.vcf")) if not line.startswith("#"))
+        # the genotypes against what the data set was made from: allele lengths per locus are {len(allele 0), len(allele 1)} by construction
+        # (checked loosely here -- the parity proper is tests/ -- so that a broken hand-over cannot report a rate)
+        called, at = 0, 0
+        for b, o in zip(views, outs):
+            k = int(b["n_loci"])
+            got = np.sort(o.allele_len[:2 * k].reshape(k, 2).astype(np.int64), axis=1)
+            called += int(((got == np.sort(ds["allele_len"][at:at + k], axis=1)).all(axis=1) & (o.n_alleles[:k] == 2)).sum())
+            at += k
+        del outs, views, batches
+        # ---- pipeline: ingest | GPU | write, chunk queues of depth 2
+        q1, q2, err = queue.Queue(2), queue.Queue(2), []
+
+        def stage_ingest():
+            try:
+                for a in firsts:
+                    q1.put(ing(a))
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+            q1.put(None)
+
+        def stage_gpu():
+            try:
+                while True:
+                    b = q1.get()
+                    if b is None:
+                        break
+                    q2.put((b, gpu(ingest.bam4_view(b))))
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+            q2.put(None)
+
+        w = writers.Writer(rd, os.path.join(d, "out2.vcf"), os.path.join(d, "out2.spanning.bam"))
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=stage_ingest, daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
+        for t in th:
+            t.start()
+        while True:
+            item = q2.get()
+            if item is None:
+                break
+            w.write(*item)
+        w.close()
+        for t in th:
+            t.join()
+        t_pipe = time.perf_counter() - t0
+        if err:
+            raise err[0]
+        same = open(os.path.join(d, "out.vcf")).read() == open(os.path.join(d, "out2.vcf")).read()
+        r = lambda x: round(x, 1)
+        return dict(
+            workload="%d cfg2-like loci (motif 2-6 bp, 5-40 copies per allele), %d reads of ~%d bases per locus, one contig; BAM %.1f MB (%d reads, %.0f MB of records), written by trgt_amd/synth_bam.py in %.1f s"
+                     % (n, 30, args.e2e_read_len, ds["bam_bytes"] / 1e6, ds["n_reads"], ds["bases"] / 1e6, t_gen),
+            chunk_loci=chunk, ingest_threads=ing_threads, host_cores=cores,
+            ingest_loci_per_s=r(n / t_ing), ingest_loci_per_s_one_thread=r(1.0 / t_ing1), ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing),
+            gpu_loci_per_s=r(n / t_gpu), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
+            vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
+            bound="host: BGZF inflate + record decoding (ingestion) and deflate (spanning BAM); the GPU stage is >10x faster than either, see DESIGN.md")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def run_one(args, env, cpu_seconds=20.0, all_cores=True):

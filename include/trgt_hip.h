@@ -315,7 +315,7 @@ typedef struct trgt_ingest_params {
   int32_t flank_len;       /* 250  --flank-len: flanks of the Locus and the search flank of extract_reads */
   int32_t max_depth;       /* 250  reads kept per locus: 3 * max_depth */
   double min_read_qual;    /* 0.98 */
-  int32_t threads;         /* 0 = up to 16 */
+  int32_t threads;         /* 0 = min(32, cores); a worker takes runs of consecutive catalog lines and keeps the last BGZF blocks it inflated */
   int32_t genotyper;       /* 0 size, 1 cluster: copied into trgt_ingest_batch::genotyper for every locus */
   int32_t default_ploidy;  /* 2 (the karyotype logic of locus.rs:216-240 stays with the caller: overwrite ploidy[] for X / Y loci) */
   int32_t keep_bam4;       /* 0; 1 = also fill read_bam4 / read_bam4_off: the clipped reads as 4-bit codes for TRGT_READS_BAM4 */
@@ -382,6 +382,8 @@ typedef struct trgt_writer_params {
                                  what write_bam.rs:96-111 produces if rust-htslib 0.46's Record::new() initialises a record as unmapped (its
                                  published source does: set_unmapped(), tid / pos / mtid / mpos = -1) and nothing clears it on the mapped branch --
                                  rust-htslib is un-vendored, no reference-produced BAM is on disk: parity of this bit is UNPINNED, hence the switch */
+  int32_t threads;            /* 0 = min(32, cores): workers that format the loci of a batch (contiguous ranges, written in locus order) and
+                                 deflate its BGZF blocks; the files do not depend on it */
 } trgt_writer_params;
 void trgt_writer_default_params(trgt_writer_params* p);
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);

@@ -239,3 +239,28 @@ def test_keep_bam4_holds_the_same_bases_as_the_ascii_reads():
     v = ingest.bam4_view(b)
     assert v["read_encoding"] == 1 and v["read_blob"] is b["read_bam4"] and v["read_len"] is b["read_len"]
     rd.close()
+
+
+def test_synthetic_dataset_ingests_the_same_whatever_the_threads(tmp_path):
+    """trgt_amd/synth_bam.py (the end-to-end leg of bench.py): every locus gets its 30 reads, and the batch does not depend on the number
+    of ingestion threads, on the block cache (runs of loci per worker) or on copy=False (views of the native batch)."""
+    from trgt_amd import ingest, synth_bam
+    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=48, read_len=1500)
+    rd = ingest.Reader(ds["bam"], ds["fasta"])
+    a = rd.batch(ds["bed"], threads=1, keep_bam4=1)
+    assert a["n_loci"] == 48 and a["n_reads"] == 48 * 30 and not a["skipped"] and (a["n_reads_seen"] == 30).all()
+    b = rd.batch(ds["bed"], threads=5, keep_bam4=1, keep_native=True, copy=False, read_names=False)
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, b[k]), k
+    assert b["read_name"] is None and a["id"] == b["id"]
+    # the reads carry the alleles the data set was made from: the bases between the flanks of read 0 of locus 0
+    lf = bytes(a["flank_blob"][int(a["lf_off"][0]):int(a["lf_off"][0]) + 250])
+    r0 = bytes(a["read_blob"][int(a["read_off"][0]):int(a["read_off"][0]) + int(a["read_len"][0])])
+    assert r0.count(lf[-40:]) == 1 or lf[-40:] not in r0  # (a substitution may sit in the flank)
+    # the 4-bit copy is the ASCII one packed
+    from trgt_amd import _lib
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    n0 = int(a["read_len"][0])
+    packed = a["read_bam4"][int(a["read_bam4_off"][0]):int(a["read_bam4_off"][0]) + (n0 + 1) // 2]
+    assert [int(x) >> 4 for x in packed[:8]] == [code[chr(c)] for c in r0[0:16:2]]

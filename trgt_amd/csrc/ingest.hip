@@ -24,6 +24,7 @@
 #include <new>
 #include <sstream>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -33,28 +34,49 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------- BGZF
 struct Bgzf {
+  // A few inflated blocks are kept (least recently used one replaced): the .bai sends the query of a locus back to the first record of
+  // the 16 kb window its region starts in, so neighbouring loci of a dense catalog walk over the same blocks, and a worker that takes
+  // a run of consecutive loci inflates each of them once.
+  struct Block { uint64_t coff = ~0ull; uint32_t csize = 0; uint64_t stamp = 0; std::vector<uint8_t> data; };
   int fd = -1;
-  std::vector<uint8_t> raw, block;
-  uint64_t block_coff = ~0ull;  // compressed offset of the block held in `block`
-  uint32_t block_csize = 0;     // its size in the file
-  size_t pos = 0;               // read position inside `block`
+  std::vector<uint8_t> raw;
+  std::vector<Block> cache;
+  size_t cur = 0;               // the block being read
+  uint64_t clock = 0, n_inflated = 0, n_hits = 0;
+  uint64_t block_coff = ~0ull;  // compressed offset of the current block
+  uint32_t block_csize = 0;     // its size in the file (0: end of file)
+  size_t pos = 0;               // read position inside it
+  z_stream zs; bool zs_ready = false;
   std::string err;
-  ~Bgzf() { if (fd >= 0) ::close(fd); }
+  explicit Bgzf(size_t n_cached = 1) : cache(std::max<size_t>(1, n_cached)) { std::memset(&zs, 0, sizeof zs); }
+  Bgzf(const Bgzf&) = delete;
+  Bgzf& operator=(const Bgzf&) = delete;
+  ~Bgzf() { if (fd >= 0) ::close(fd); if (zs_ready) inflateEnd(&zs); }
+  const std::vector<uint8_t>& block() const { return cache[cur].data; }
   bool open(const char* path) { fd = ::open(path, O_RDONLY); if (fd < 0) { err = std::string("cannot open ") + path; return false; } return true; }
   bool load(uint64_t coff) {
+    size_t lru = 0;
+    for (size_t i = 0; i < cache.size(); ++i) {
+      if (cache[i].coff == coff) { cur = i; cache[i].stamp = ++clock; block_coff = coff; block_csize = cache[i].csize; pos = 0; ++n_hits; return true; }
+      if (cache[i].stamp < cache[lru].stamp) lru = i;
+    }
     uint8_t h[18];
     const ssize_t got = ::pread(fd, h, 18, (off_t)coff);
-    if (got == 0) { block.clear(); block_coff = coff; block_csize = 0; pos = 0; return true; }  // end of file
+    Block& B = cache[lru];
+    if (got == 0) { B.data.clear(); B.coff = ~0ull; cur = lru; block_coff = coff; block_csize = 0; pos = 0; return true; }  // end of file (not kept)
     if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
     const uint32_t xlen = h[10] | (h[11] << 8);
     // the BC subfield is the first one in every file bgzip / htslib / pbmm2 writes; look it up properly all the same
-    std::vector<uint8_t> extra(xlen);
-    if (::pread(fd, extra.data(), xlen, (off_t)coff + 12) != (ssize_t)xlen) { err = "truncated BGZF header"; return false; }
     uint32_t bsize = 0; bool found = false;
-    for (uint32_t i = 0; i + 4 <= xlen;) {
-      const uint32_t slen = extra[i + 2] | (extra[i + 3] << 8);
-      if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) { bsize = extra[i + 4] | (extra[i + 5] << 8); found = true; break; }
-      i += 4 + slen;
+    if (xlen == 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0) { bsize = h[16] | (h[17] << 8); found = true; }
+    else {
+      std::vector<uint8_t> extra(xlen);
+      if (::pread(fd, extra.data(), xlen, (off_t)coff + 12) != (ssize_t)xlen) { err = "truncated BGZF header"; return false; }
+      for (uint32_t i = 0; i + 4 <= xlen;) {
+        const uint32_t slen = extra[i + 2] | (extra[i + 3] << 8);
+        if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) { bsize = extra[i + 4] | (extra[i + 5] << 8); found = true; break; }
+        i += 4 + slen;
+      }
     }
     if (!found) { err = "BGZF block without BC field"; return false; }
     const uint32_t total = bsize + 1, hdr = 12 + xlen;
@@ -62,17 +84,18 @@ struct Bgzf {
     raw.resize(total);
     if (::pread(fd, raw.data(), total, (off_t)coff) != (ssize_t)total) { err = "truncated BGZF block"; return false; }
     const uint32_t isize = raw[total - 4] | (raw[total - 3] << 8) | (raw[total - 2] << 16) | ((uint32_t)raw[total - 1] << 24);
-    block.resize(isize);
+    B.coff = ~0ull;  // (not a valid entry while it is being overwritten)
+    B.data.resize(isize);
     if (isize) {
-      z_stream zs;
-      std::memset(&zs, 0, sizeof zs);
-      if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+      if (!zs_ready) { if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; } zs_ready = true; }
+      else if (inflateReset(&zs) != Z_OK) { err = "inflateReset failed"; return false; }
       zs.next_in = raw.data() + hdr; zs.avail_in = total - hdr - 8;
-      zs.next_out = block.data(); zs.avail_out = isize;
+      zs.next_out = B.data.data(); zs.avail_out = isize;
       const int rc = inflate(&zs, Z_FINISH);
-      inflateEnd(&zs);
       if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "corrupt BGZF block"; return false; }
     }
+    ++n_inflated;
+    B.coff = coff; B.csize = total; B.stamp = ++clock; cur = lru;
     block_coff = coff; block_csize = total; pos = 0;
     return true;
   }
@@ -80,22 +103,22 @@ struct Bgzf {
     const uint64_t coff = voff >> 16;
     if (coff != block_coff && !load(coff)) return false;
     pos = (size_t)(voff & 0xFFFF);
-    return pos <= block.size();
+    return pos <= block().size();
   }
-  uint64_t tell() const { return pos < block.size() || block_csize == 0 ? (block_coff << 16) | pos : ((block_coff + block_csize) << 16); }
+  uint64_t tell() const { return pos < block().size() || block_csize == 0 ? (block_coff << 16) | pos : ((block_coff + block_csize) << 16); }
   // n bytes; returns 1 ok, 0 clean end of file before the first byte, -1 error
   int read(void* dst, size_t n) {
     uint8_t* d = (uint8_t*)dst;
     size_t done = 0;
     while (done < n) {
-      if (pos >= block.size()) {
+      if (pos >= block().size()) {
         if (block_csize == 0 && block_coff != ~0ull) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
         if (!load(block_coff + block_csize)) return -1;
-        if (block.empty() && block_csize == 0) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
+        if (block().empty() && block_csize == 0) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
         continue;
       }
-      const size_t k = std::min(n - done, block.size() - pos);
-      std::memcpy(d + done, block.data() + pos, k);
+      const size_t k = std::min(n - done, block().size() - pos);
+      std::memcpy(d + done, block().data() + pos, k);
       done += k; pos += k;
     }
     return 1;
@@ -623,6 +646,9 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   if (p->flank_len <= 0 || p->max_depth <= 0) return bad("trgt_ingest: flank_len and max_depth must be positive");
   std::ifstream bed(bed_path);
   if (!bed) return bad(std::string("cannot open ") + bed_path);
+  const bool trace = std::getenv("TRGT_INGEST_TRACE") != nullptr;  // phase times on stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   struct L { std::string contig, id, struc; int64_t start, end; std::vector<std::string> motifs; std::string lf, tr, rf; std::vector<Read> reads; int32_t n_filt = 0; int64_t n_seen = 0; std::string err; };
   std::vector<L> loci;
   std::vector<std::string> skipped;  // one message per catalog line that gave no locus
@@ -652,17 +678,23 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     }
   }
   const int64_t nl = (int64_t)loci.size();
+  const double t1 = now();
   // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
-  int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // (more than 32 workers lose: tools/ingest_scaling.py)
   nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, nl));
   std::atomic<int64_t> next{0};
+  std::atomic<uint64_t> n_inflated{0}, n_cache_hits{0};
+  // a worker takes a run of consecutive catalog lines (sorted catalogs: neighbours share BGZF blocks, see Bgzf), short enough that
+  // every thread still gets several runs
+  const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, nl / (4ll * nthr)));
   auto work_body = [&]() {
-    Bgzf z;
+    Bgzf z(48);
     if (!z.open(h->bam_path.c_str())) { for (auto& l : loci) if (l.err.empty()) { l.err = z.err; break; } return; }
     RawRec rec;
     for (;;) {
-      const int64_t li = next.fetch_add(1);
-      if (li >= nl) break;
+      const int64_t l0 = next.fetch_add(run);
+      if (l0 >= nl) break;
+     for (int64_t li = l0; li < std::min(nl, l0 + run); ++li) {
       L& l = loci[(size_t)li];
       auto it = h->ref_id.find(l.contig);
       if (it == h->ref_id.end()) continue;  // "Fetch error" is a warning in the reference: the locus gets no reads
@@ -704,7 +736,9 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
       std::vector<Read> clipped;
       for (auto& r : l.reads) { Read c; if (clip_to_region(r, rs, re, c)) clipped.push_back(std::move(c)); }
       l.reads.swap(clipped);
+     }
     }
+    n_inflated += z.n_inflated; n_cache_hits += z.n_hits;
   };
   std::atomic<int> worker_failed{0};
   auto work = [&]() {  // (an exception must not leave a thread, nor cross the C ABI)
@@ -713,11 +747,16 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   if (nthr <= 1) work();
   else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
   for (auto& l : loci) if (!l.err.empty()) return bad(l.id + ": " + l.err);
+  const double t2 = now();
   // ---- the arrays of trgt_locus_batch_in (+ what the writers need per read)
   std::unique_ptr<BatchStore> S(new BatchStore());
-  S->lrb.push_back(0); S->motif_off.push_back(0); S->set_begin.push_back(0); S->name_off.push_back(0); S->moff.push_back(0); S->snp_off.push_back(0);
-  S->contig_off.push_back(0); S->id_off.push_back(0); S->struc_off.push_back(0); S->cig_off.push_back(0);
-  for (auto& l : loci) {
+  S->lrb.push_back(0); S->motif_off.push_back(0); S->set_begin.push_back(0);
+  S->contig_off.push_back(0); S->id_off.push_back(0); S->struc_off.push_back(0);
+  // per locus: the catalog fields, and where its reads go in the per-read arrays (sizes first, then the loci are copied in by the workers)
+  struct At { uint64_t read = 0, bytes = 0, name = 0, snp = 0, meth = 0, cig = 0, bam4 = 0; };
+  std::vector<At> at((size_t)nl + 1);
+  for (int64_t li = 0; li < nl; ++li) {
+    L& l = loci[(size_t)li];
     S->lf_off.push_back(S->flank.size()); S->lf_len.push_back((uint32_t)l.lf.size()); S->flank += l.lf;
     S->rf_off.push_back(S->flank.size()); S->rf_len.push_back((uint32_t)l.rf.size()); S->flank += l.rf;
     S->tr_off.push_back(S->tr.size()); S->tr_len.push_back((uint32_t)l.tr.size()); S->tr += l.tr;
@@ -727,22 +766,62 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     S->contigs += l.contig; S->contig_off.push_back(S->contigs.size()); S->ids += l.id; S->id_off.push_back(S->ids.size());
     S->strucs += l.struc; S->struc_off.push_back(S->strucs.size());
     S->region_start.push_back(l.start); S->region_end.push_back(l.end); S->n_filtered.push_back(l.n_filt); S->n_seen.push_back(l.n_seen);
+    At n = at[(size_t)li];
     for (auto& r : l.reads) {
-      S->read_off.push_back(S->reads.size()); S->read_len.push_back((uint32_t)r.bases.size()); S->reads += r.bases;
-      S->quals.append((const char*)r.quals.data(), r.quals.size());
-      S->names += r.id; S->name_off.push_back(S->names.size());
-      S->rq.push_back(r.rq); S->is_reverse.push_back(r.is_reverse ? 1 : 0); S->mapq.push_back(r.mapq); S->hp.push_back((int16_t)r.hp);
-      S->start_offset.push_back(r.start_offset); S->end_offset.push_back(r.end_offset);
-      S->snp.insert(S->snp.end(), r.mismatch_offsets.begin(), r.mismatch_offsets.end()); S->snp_off.push_back(S->snp.size());
-      if (r.has_meth) S->meth.insert(S->meth.end(), r.meth.begin(), r.meth.end());
-      S->moff.push_back(r.has_meth ? S->meth.size() : (S->moff.back() | (1ull << 63)));  // (bit 63: this read has no methylation profile)
-      S->cig.insert(S->cig.end(), r.cigar.begin(), r.cigar.end()); S->cig_off.push_back(S->cig.size()); S->cig_ref_pos.push_back(r.ref_pos);
+      ++n.read; n.bytes += r.bases.size(); n.name += r.id.size(); n.snp += r.mismatch_offsets.size(); n.meth += r.has_meth ? r.meth.size() : 0;
+      n.cig += r.cigar.size(); n.bam4 += (r.bases.size() + 1) / 2;
     }
-    S->lrb.push_back(S->read_off.size());
+    at[(size_t)li + 1] = n;
+    S->lrb.push_back(n.read);
   }
-  // (the meth offsets carry a flag bit: strip it into a clean CSR + a flag array)
-  S->has_meth.assign(S->read_off.size(), 1);
-  { uint64_t last = 0; for (size_t r = 0; r < S->read_off.size(); ++r) { uint64_t v = S->moff[r + 1]; if (v >> 63) { S->has_meth[r] = 0; v = last; } S->moff[r + 1] = v; last = v; } }
+  const At tot = at[(size_t)nl];
+  const size_t nr = (size_t)tot.read;
+  S->read_off.resize(nr); S->read_len.resize(nr); S->reads.resize((size_t)tot.bytes); S->quals.resize((size_t)tot.bytes);
+  S->names.resize((size_t)tot.name); S->name_off.assign(nr + 1, 0); S->rq.resize(nr); S->is_reverse.resize(nr); S->mapq.resize(nr); S->hp.resize(nr);
+  S->start_offset.resize(nr); S->end_offset.resize(nr); S->snp.resize((size_t)tot.snp); S->snp_off.assign(nr + 1, 0);
+  S->meth.resize((size_t)tot.meth); S->moff.assign(nr + 1, 0); S->has_meth.resize(nr);
+  S->cig.resize((size_t)tot.cig); S->cig_off.assign(nr + 1, 0); S->cig_ref_pos.resize(nr);
+  if (p->keep_bam4) { S->bam4.assign((size_t)tot.bam4 + 1, 0); S->bam4_off.assign(nr + 1, 0); }  // the reads once more, two bases per byte (half the bytes to move to the GPU)
+  std::atomic<int64_t> next_fill{0};
+  std::atomic<int> fill_failed{0};
+  auto fill = [&]() {
+    for (;;) {
+      const int64_t l0 = next_fill.fetch_add(16);
+      if (l0 >= nl) break;
+      for (int64_t li = l0; li < std::min(nl, l0 + 16); ++li) {
+        At n = at[(size_t)li];
+        const size_t r0 = (size_t)n.read;
+        for (auto& r : loci[(size_t)li].reads) {
+          const size_t k = (size_t)n.read;
+          S->read_off[k] = n.bytes; S->read_len[k] = (uint32_t)r.bases.size();
+          std::memcpy(&S->reads[0] + n.bytes, r.bases.data(), r.bases.size());
+          std::memcpy(&S->quals[0] + n.bytes, r.quals.data(), std::min(r.quals.size(), r.bases.size()));
+          std::memcpy(&S->names[0] + n.name, r.id.data(), r.id.size());
+          S->rq[k] = r.rq; S->is_reverse[k] = r.is_reverse ? 1 : 0; S->mapq[k] = r.mapq; S->hp[k] = (int16_t)r.hp;
+          S->start_offset[k] = r.start_offset; S->end_offset[k] = r.end_offset;
+          std::copy(r.mismatch_offsets.begin(), r.mismatch_offsets.end(), S->snp.begin() + (ptrdiff_t)n.snp);
+          S->has_meth[k] = r.has_meth ? 1 : 0;
+          if (r.has_meth) std::copy(r.meth.begin(), r.meth.end(), S->meth.begin() + (ptrdiff_t)n.meth);
+          std::copy(r.cigar.begin(), r.cigar.end(), S->cig.begin() + (ptrdiff_t)n.cig); S->cig_ref_pos[k] = r.ref_pos;
+          ++n.read; n.bytes += r.bases.size(); n.name += r.id.size(); n.snp += r.mismatch_offsets.size(); n.meth += r.has_meth ? r.meth.size() : 0; n.cig += r.cigar.size();
+          S->name_off[k + 1] = n.name; S->snp_off[k + 1] = n.snp; S->moff[k + 1] = n.meth; S->cig_off[k + 1] = n.cig;
+        }
+        if (p->keep_bam4 && n.read > r0) {
+          const uint64_t base = at[(size_t)li].bam4;
+          const int64_t got = trgt_reads_pack_bam4((const uint8_t*)S->reads.data(), (int64_t)(n.read - r0), S->read_off.data() + r0, S->read_len.data() + r0, S->bam4.data() + base, S->bam4_off.data() + r0);
+          if (got != (int64_t)(at[(size_t)li + 1].bam4 - base)) fill_failed = 1;
+          for (size_t k = r0; k < (size_t)n.read; ++k) S->bam4_off[k] += base;
+        }
+        std::vector<Read>().swap(loci[(size_t)li].reads);  // (freed by the worker, not by the caller's thread at the end)
+      }
+    }
+  };
+  {
+    auto guarded = [&]() { try { fill(); } catch (const std::exception&) { fill_failed = 1; } };
+    if (nthr <= 1) guarded();
+    else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(guarded); for (auto& t : th) t.join(); }
+  }
+  if (fill_failed) return bad("trgt_ingest: assembling the batch failed");
   trgt_ingest_batch& B = S->pub;
   std::memset(&B, 0, sizeof B);
   auto u8 = [](const std::string& s) { return (const uint8_t*)s.data(); };
@@ -768,15 +847,8 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   S->skipped_off.push_back(0);
   for (auto& m : skipped) { S->skipped += m; S->skipped_off.push_back(S->skipped.size()); }
   B.n_skipped = (int64_t)skipped.size(); B.skipped_blob = S->skipped.data(); B.skipped_off = S->skipped_off.data();
-  if (p->keep_bam4) {  // the reads once more, two bases per byte (half the bytes to move to the GPU)
-    uint64_t total = 0;
-    for (uint32_t n : S->read_len) total += ((uint64_t)n + 1) / 2;
-    S->bam4.assign((size_t)total + 1, 0);
-    S->bam4_off.assign(S->read_off.size() + 1, 0);
-    const int64_t got = trgt_reads_pack_bam4(u8(S->reads), (int64_t)S->read_off.size(), S->read_off.data(), S->read_len.data(), S->bam4.data(), S->bam4_off.data());
-    if (got != (int64_t)total) return bad("trgt_ingest: packing the reads failed");
-    B.read_bam4 = S->bam4.data(); B.read_bam4_off = S->bam4_off.data(); B.read_bam4_bytes = total;
-  }
+  if (p->keep_bam4) { B.read_bam4 = S->bam4.data(); B.read_bam4_off = S->bam4_off.data(); B.read_bam4_bytes = tot.bam4; }
+  if (trace) std::fprintf(stderr, "[ingest] %lld loci, %d threads (runs of %lld): catalog+genome %.1f ms, reads %.1f ms (%llu blocks inflated, %llu found in the cache), arrays %.1f ms\n", (long long)nl, nthr, (long long)run, t1 - t0, t2 - t1, (unsigned long long)n_inflated.load(), (unsigned long long)n_cache_hits.load(), now() - t2);
   B.owner = S.release();
   *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
   return TRGT_OK;

@@ -9,11 +9,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/trgt_hip.h"
@@ -27,33 +29,50 @@ uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i);
 
 namespace {
 
-struct BgzfOut {  // a file, plain or as a series of BGZF blocks
-  FILE* f = nullptr; bool bgzf = false; std::vector<uint8_t> buf;
+struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF00 bytes of payload, whatever the number of threads)
+  FILE* f = nullptr; bool bgzf = false; std::vector<uint8_t> buf; int threads = 1;
   bool open(const char* path, bool compress) { f = std::fopen(path, "wb"); bgzf = compress; return f != nullptr; }
-  bool block(const uint8_t* d, size_t n) {
-    uint8_t out[0x10000 + 64];
+  static bool deflate_block(const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
+    out.resize(0x10000 + 64);
     z_stream zs; std::memset(&zs, 0, sizeof zs);
     if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    zs.next_in = const_cast<uint8_t*>(d); zs.avail_in = (uInt)n; zs.next_out = out + 18; zs.avail_out = sizeof(out) - 18 - 8;
+    zs.next_in = const_cast<uint8_t*>(d); zs.avail_in = (uInt)n; zs.next_out = out.data() + 18; zs.avail_out = (uInt)out.size() - 18 - 8;
     const int rc = deflate(&zs, Z_FINISH);
     deflateEnd(&zs);
     if (rc != Z_STREAM_END) return false;
     const size_t clen = zs.total_out, total = 18 + clen + 8;
     static const uint8_t head[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
-    std::memcpy(out, head, 16);
+    std::memcpy(out.data(), head, 16);
     out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
     const uint32_t crc = (uint32_t)crc32(crc32(0L, nullptr, 0), d, (uInt)n);
     for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
-    return std::fwrite(out, 1, total, f) == total;
+    out.resize(total);
+    return true;
+  }
+  bool block(const uint8_t* d, size_t n) { std::vector<uint8_t> out; return deflate_block(d, n, out) && std::fwrite(out.data(), 1, out.size(), f) == out.size(); }
+  // the full blocks of buf: deflated by `threads` workers (a block is independent of its neighbours), written in order
+  bool flush_full_blocks() {
+    const size_t nb = buf.size() / 0xFF00;
+    if (!nb) return true;
+    std::vector<std::vector<uint8_t>> outs(nb);
+    std::atomic<size_t> next{0}; std::atomic<int> failed{0};
+    auto work = [&]() {
+      try { for (;;) { const size_t k = next.fetch_add(1); if (k >= nb) break; if (!deflate_block(buf.data() + k * 0xFF00, 0xFF00, outs[k])) failed = 1; } }
+      catch (const std::exception&) { failed = 1; }
+    };
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), nb);
+    if (nt <= 1) work();
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
+    if (failed) return false;
+    for (auto& o : outs) if (std::fwrite(o.data(), 1, o.size(), f) != o.size()) return false;
+    buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)(nb * 0xFF00));
+    return true;
   }
   bool write(const void* d, size_t n) {
     if (!bgzf) return std::fwrite(d, 1, n, f) == n;
     const uint8_t* p = (const uint8_t*)d;
     buf.insert(buf.end(), p, p + n);
-    size_t o = 0;
-    while (buf.size() - o >= 0xFF00) { if (!block(buf.data() + o, 0xFF00)) return false; o += 0xFF00; }
-    if (o) buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)o);
-    return true;
+    return flush_full_blocks();
   }
   bool close() {
     bool ok = true;
@@ -112,6 +131,7 @@ struct trgt_writer {
   BgzfOut vcf, bam;
   bool has_bam = false, keep_unmapped = false;
   int32_t flank_len = 50;
+  int threads = 1;
   std::vector<std::string> contigs;
 };
 
@@ -121,7 +141,7 @@ const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_s
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 0;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 0; p->threads = 0;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
@@ -130,6 +150,8 @@ static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p,
   *out = nullptr;
   auto bad = [&](const std::string& m) { w->err = m; *out = w.release(); return TRGT_ERR_INVALID; };
   w->flank_len = p->output_flank_len; w->keep_unmapped = p->keep_unmapped_flag != 0;
+  w->threads = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  w->vcf.threads = w->bam.threads = w->threads;
   const std::string prog = p->program ? p->program : "trgt", ver = p->version ? p->version : "", cl = p->command_line ? p->command_line : "";
   w->sample = p->sample_name ? p->sample_name : "sample";
   for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i) w->contigs.push_back(trgt_ingest_contig_name(src, i));
@@ -179,10 +201,12 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
   if (!o->n_alleles || !o->allele_blob || !o->allele_off || !o->allele_len || !o->ci || !o->num_spanning || !o->classification || !o->read_rank ||
       !o->span_start || !o->span_end || !o->spans3 || !o->span_off || !o->n_spans || !o->motif_counts || !o->count_off || !o->purity)
     return bad("trgt_writer_write: incomplete result arrays");
-  std::string line;
-  std::vector<uint8_t> rec;
-  char num[64];
-  for (int64_t l = 0; l < b->n_loci; ++l) {
+  // One locus: its VCF line and its spanning-BAM records, appended to the caller's buffers (loci are independent: a batch is formatted
+  // by w->threads workers over contiguous ranges of loci, and the pieces are written in locus order).
+  auto format_locus = [&](int64_t l, std::string& lines, std::vector<uint8_t>& recs, std::vector<uint8_t>& rec, std::string& err) -> bool {
+    auto bad = [&](const std::string& m) { err = m; return false; };
+    std::string line;
+    char num[64];
     const std::string contig(b->contig_blob + b->contig_off[l], b->contig_off[l + 1] - b->contig_off[l]);
     const std::string id(b->id_blob + b->id_off[l], b->id_off[l + 1] - b->id_off[l]);
     const std::string struc(b->struc_blob + b->struc_off[l], b->struc_off[l + 1] - b->struc_off[l]);
@@ -277,9 +301,9 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
       }
       line += ":" + f_al + ":" + f_allr + ":" + f_sd + ":" + f_mc + ":" + f_ms + ":" + f_ap + ":" + f_am + "\n";
     }
-    if (!w->vcf.write(line.data(), line.size())) return bad("cannot write the VCF");
+    lines += line;
     // ---- spanning reads (write_bam.rs:72-144)
-    if (!w->has_bam) continue;
+    if (!w->has_bam) return true;
     int tid = -1;
     for (size_t i = 0; i < w->contigs.size(); ++i) if (w->contigs[i] == contig) { tid = (int)i; break; }
     if (tid < 0) return bad("contig " + contig + " is not in the BAM header");
@@ -326,8 +350,26 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
       tag("FL", 'B'); rec.push_back('I'); put32(rec, 2); put32(rec, (uint32_t)F); put32(rec, (uint32_t)F);
       const uint32_t bs = (uint32_t)rec.size() - 4;
       for (int i = 0; i < 4; ++i) rec[(size_t)i] = (uint8_t)(bs >> (8 * i));
-      if (!w->bam.write(rec.data(), rec.size())) return bad("cannot write the BAM");
+      recs.insert(recs.end(), rec.begin(), rec.end());
     }
+    return true;
+  };
+  const int64_t nl = b->n_loci;
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(w->threads, nl / 16));
+  std::vector<std::string> lines((size_t)nt), errs((size_t)nt);
+  std::vector<std::vector<uint8_t>> recs((size_t)nt);
+  auto work = [&](int t) {
+    try {
+      std::vector<uint8_t> rec;
+      for (int64_t l = nl * t / nt; l < nl * (t + 1) / nt; ++l) if (!format_locus(l, lines[(size_t)t], recs[(size_t)t], rec, errs[(size_t)t])) return;
+    } catch (const std::exception& e) { errs[(size_t)t] = std::string("trgt_writer_write: ") + e.what(); }
+  };
+  if (nt <= 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
+  for (int t = 0; t < nt; ++t) {  // (what precedes the first failing locus is written, as a serial writer would have)
+    if (!lines[(size_t)t].empty() && !w->vcf.write(lines[(size_t)t].data(), lines[(size_t)t].size())) return bad("cannot write the VCF");
+    if (!recs[(size_t)t].empty() && !w->bam.write(recs[(size_t)t].data(), recs[(size_t)t].size())) return bad("cannot write the BAM");
+    if (!errs[(size_t)t].empty()) return bad(errs[(size_t)t]);
   }
   return TRGT_OK;
 }

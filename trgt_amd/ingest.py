@@ -39,10 +39,11 @@ class IngestBatch(C.Structure):
                 ("owner", C.c_void_p)]
 
 
-def _arr(ptr, n, dtype):
+def _arr(ptr, n, dtype, copy=True):
     if n <= 0:
         return np.zeros(0, dtype)
-    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).view(dtype).copy()
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).view(dtype)
+    return a.copy() if copy else a  # (copy=False: a view of the native batch's memory)
 
 
 def _strings(blob, off, n):
@@ -102,9 +103,14 @@ class Reader:
         except Exception:
             pass
 
-    def batch(self, bed_path, first_locus=0, max_loci=-1, keep_native=False, **params):
+    def batch(self, bed_path, first_locus=0, max_loci=-1, keep_native=False, copy=True, read_names=True, **params):
         """Loci [first_locus, first_locus + max_loci) of the catalog as the dict of ABI arrays trgt_amd.locus.run_batch takes (the keys
-        of synth.generate) plus the catalog fields and the per-read HiFiRead fields the writers need."""
+        of synth.generate) plus the catalog fields and the per-read HiFiRead fields the writers need.  copy=False (with keep_native):
+        the arrays are views of the native batch's memory, valid as long as batch["_native"] lives; read_names=False leaves the list of
+        read names out (one Python string per read)."""
+        if not copy and not keep_native:
+            raise ValueError("copy=False needs keep_native=True (the views point into the native batch)")
+        _arr = lambda ptr, n, dtype: globals()["_arr"](ptr, n, dtype, copy)  # noqa: E731
         p = IngestParams()
         self._L.trgt_ingest_default_params(C.byref(p))
         for k, v in params.items():
@@ -128,7 +134,7 @@ class Reader:
                    contig=_strings(b.contig_blob, b.contig_off, nl), id=_strings(b.id_blob, b.id_off, nl), struc=_strings(b.struc_blob, b.struc_off, nl),
                    region_start=_arr(b.region_start, nl, np.int64), region_end=_arr(b.region_end, nl, np.int64),
                    n_quality_filtered=_arr(b.n_quality_filtered, nl, np.int32), n_reads_seen=_arr(b.n_reads_seen, nl, np.int64),
-                   qual_blob=_arr(b.qual_blob, int(_arr(b.read_len, nr, u32).sum()) if nr else 0, u8), read_name=_strings(b.name_blob, b.name_off, nr),
+                   qual_blob=_arr(b.qual_blob, int(_arr(b.read_len, nr, u32).sum()) if nr else 0, u8), read_name=_strings(b.name_blob, b.name_off, nr) if read_names else None,
                    is_reverse=_arr(b.is_reverse, nr, u8), mapq=_arr(b.mapq, nr, u8), hp_tag=_arr(b.hp_tag, nr, np.int16),
                    start_offset=_arr(b.start_offset, nr, np.int32), end_offset=_arr(b.end_offset, nr, np.int32),
                    mismatch_off=_arr(b.mismatch_off, nr + 1, u64), meth_off=_arr(b.meth_off, nr + 1, u64), has_meth=_arr(b.has_meth, nr, u8),
