@@ -214,7 +214,7 @@ def run_e2e(args, env):
         rd = ingest.Reader(ds["bam"], ds["fasta"])
         firsts = list(range(0, n, chunk))
         ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256
-    ing = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
+        ing = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
         ing(0)  # page cache, thread start-up
         t0 = time.perf_counter()
         one = ing(0, 1)
