@@ -52,3 +52,12 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_entry_scripts_compile():
+    """bench.py / __graft_entry__.py only run on the GPU box: a syntax error must not wait for it."""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(root, f), doraise=True)

@@ -139,8 +139,8 @@ def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
     err = capfd.readouterr().err
     line = [l for l in err.splitlines() if l.startswith("[spans]")][-1]
     nums = [int(t) for t in line.replace(",", " ").replace("(", " ").replace(")", " ").split() if t.isdigit()]
-    windowed, redone = nums[3], nums[-1]
-    assert windowed > 50 and redone >= 4, line
+    windowed, redone, shortcut = nums[3], nums[-2], nums[-1]
+    assert windowed > 30 and redone >= 4 and shortcut >= 64, line  # (every right flank and the left flanks with 1-2 mismatches need no alignment)
 
 
 @pytest.mark.parametrize("scoring,flank_len", [((1, 2, 1), 250), ((4, 6, 2), 250), ((2, 5, 1), 150), ((2, 5, 1), 100), ((3, 1, 1), 250), ((1, 0, 1), 200)])
@@ -157,3 +157,44 @@ def test_other_penalties_and_flank_lengths(oracle, scoring, flank_len):
     # the pre-filter is engaged for the two presets that have an instantiation (2,5,1 and the targeted 1,0,1): it counts its offsets
     engaged = int(out.stats[17]) > 0
     assert engaged == (tuple(scoring) in ((2, 5, 1), (1, 0, 1))), (scoring, int(out.stats[17]))
+
+
+def test_substitution_only_shortcut(oracle):
+    """One or two substitutions in a flank, all seeds on one diagonal: the window search settles the alignment itself (stats[21]).  Aimed
+    at its edges: mismatches in the first / last bases and in the two bytes after the last full dword, three mismatches (not covered),
+    a second copy of the flank with more mismatches elsewhere in the read (seeds on two diagonals: not covered), flanks flush with the
+    ends of the read, a mismatch next to a deletion."""
+    rng = np.random.default_rng(99)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        sets = [[0], [249], [248], [247, 249], [0, 1], [124], [30, 200], [3, 100, 220], [60], [10, 11], [246], [125, 126]]
+        l = _sub(rng, lf, sets[i % len(sets)])
+        r = _sub(rng, rf, sets[(i + 5) % len(sets)])
+        head, tail = rand_dna(rng, 300 + i), rand_dna(rng, 310)
+        if i == 4:    # a worse copy of the left flank further left (four mismatches): seeds on two diagonals
+            head = rand_dna(rng, 20) + _sub(rng, lf, [5, 70, 140, 210]) + rand_dna(rng, 40)
+        if i == 6:    # flank flush with the start of the read
+            head = b""
+            tail = rand_dna(rng, 600)
+        if i == 8:    # ... and with its end
+            tail = b""
+            head = rand_dna(rng, 620)
+        if i == 9:    # a substitution and a deletion in the same flank: not substitution-only
+            r = r[:180] + r[181:]
+        return head + l + tr + r + tail
+
+    import torch
+    from trgt_amd import _lib, locus
+    loci = [_locus(rng, reads_fn, n_reads=12) for _ in range(5)]
+    b, out = _check(oracle, loci)
+    assert int(out.stats[21]) >= 5 * 12  # most of the 2 x 12 flank pieces per locus are settled without an alignment
+    import os
+    os.environ["TRGT_NO_HAMMING"] = "1"
+    try:
+        ctx = _lib.Context(0)
+        _, out2 = _check(oracle, loci, ctx=ctx)
+    finally:
+        del os.environ["TRGT_NO_HAMMING"]
+    assert int(out2.stats[21]) == 0
+    for k in ("span_start", "span_end", "allele_len", "classification"):
+        assert np.array_equal(getattr(out, k), getattr(out2, k)), k

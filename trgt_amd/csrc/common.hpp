@@ -29,6 +29,7 @@ struct trgt_knobs {
   bool one_launch = false;   // TRGT_WFA_ONE_LAUNCH: all flank alignments in one launch
   bool no_spec = false;      // TRGT_WFA_NO_SPEC: general instantiation of the dedicated kernel
   bool no_window = false;    // TRGT_WFA_NO_WINDOW: no seeded windows
+  bool no_hamming = false;   // TRGT_NO_HAMMING: no substitution-only shortcut in the window search (every light fallback is aligned)
   bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
   bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them
   bool host_genotyper = false;  // TRGT_HOST_GENOTYPER: host glue for every locus

@@ -710,7 +710,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   hipEvent_t evA = nullptr;
   struct EvGuard { hipEvent_t& e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } ev_guard{evA};
   TRGT_HIP_TRY(c, hipEventCreateWithFlags(&evA, hipEventDisableTiming));
-  ((uint64_t*)h_cells)[0] = ((uint64_t*)h_cells)[1] = 0;
+  ((uint64_t*)h_cells)[0] = ((uint64_t*)h_cells)[1] = ((uint64_t*)h_cells)[2] = 0;
   // Several contexts on one GPU (one host thread each, trgt_amd/driver.py) form a pipeline: while one call is in its tail (results
   // back, the loci of the host path, HMM) the next ones' flank location has the GPU.  TRGT_STAGE_LOCK=1 lets only one call per device
   // be in stage A at a time -- that was worth 2x while the tails were host-bound (first half of round 2); since the stage-C job list
@@ -721,9 +721,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if ((rc = find_spans_device(c, sp, nl, nr, d_flank, d_piece, d_reads, d_roff, d_rlen, d_rloc, max_read_len, (int32_t*)d_ss, (int32_t*)d_se,
                               (uint8_t*)d_hl, (uint8_t*)d_hr, d_heavy, heavy_tlen_max > 0 ? heavy_tlen_max - 1 : 0)))
     return rc;
-  if (c->last_wfa_cells_dev) { const int d2h_rc = trgt::d2h(c, h_cells, c->last_wfa_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
-  ((uint64_t*)h_cells)[2] = ((uint64_t*)h_cells)[3] = 0;  // pre-filter: offsets computed, alignments kept
-  if (c->last_filter_cells_dev) { const int d2h_rc = trgt::d2h(c, (uint64_t*)h_cells + 2, c->last_filter_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
+  if (c->last_wfa_cells_dev) { const int d2h_rc = trgt::d2h(c, h_cells, c->last_wfa_cells_dev, 24, c->stream); if (d2h_rc) return d2h_rc; }
+  ((uint64_t*)h_cells)[4] = ((uint64_t*)h_cells)[5] = 0;  // pre-filter: offsets computed, alignments kept
+  if (c->last_filter_cells_dev) { const int d2h_rc = trgt::d2h(c, (uint64_t*)h_cells + 4, c->last_filter_cells_dev, 16, c->stream); if (d2h_rc) return d2h_rc; }
   // the motif-HMM tables: built on the device (one small upload and one kernel on the copy stream, which has nothing in front of it:
   // the second stream may be busy with the heavy flank alignments for milliseconds, and the copy engine serves the streams' copies in
   // the order they were issued)
@@ -1168,7 +1168,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (c->timing) {  // [0] all flank alignments, [1] those of the first (dominant) launch
     c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)((uint64_t*)h_cells)[1];
     c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(((uint64_t*)h_cells)[0] - ((uint64_t*)h_cells)[1]);
-    c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)((uint64_t*)h_cells)[2];
+    c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)((uint64_t*)h_cells)[4];
   }
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;
@@ -1448,8 +1448,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     s[4] = tA; s[5] = tB; s[6] = tC; s[7] = tHost; s[8] = now_ns() - t0;
     for (int i = 0; i < 5; ++i) s[9 + i] = c->dbg_ns[i + (i >= 3 ? 1 : 0)];
     s[14] = stat_flank_heavy; s[15] = stat_ed_jobs;
-    s[16] = (int64_t)((uint64_t*)h_cells)[3]; s[17] = (int64_t)((uint64_t*)h_cells)[2];  // pre-filter: alignments kept, offsets computed
+    s[16] = (int64_t)((uint64_t*)h_cells)[5]; s[17] = (int64_t)((uint64_t*)h_cells)[4];  // pre-filter: alignments kept, offsets computed
     for (int i = 18; i < 24; ++i) s[i] = 0;
+    s[21] = (int64_t)((uint64_t*)h_cells)[2];  // light fallback alignments settled by the substitution shortcut of the window search
     if (dev_gt) { const uint32_t* rc_ = (const uint32_t*)hsl(o_rpc); s[18] = rc_[gt::RC_LOCI]; s[19] = rc_[gt::RC_FAILED]; s[20] = rc_[gt::RC_JOBS]; }  // device-side consensus repair: loci, loci without room, alignments
   }
   return TRGT_OK;

@@ -192,6 +192,8 @@ struct WindowArgs {
   const JobDev* wfa_jobs; uint32_t jobs_cap; uint32_t* count;
   JobDev* win_jobs; JobDev* rest_jobs;
   int32_t flank_len, q, margin, spread, tbf;
+  int32_t hamming_max;                 // > 0: the substitution-only shortcut below, for up to this many mismatches
+  int32_t* n_match; uint32_t* span4;   // per (read, side): what the alignment kernels would have written for such a job
 };
 constexpr int WIN_JOBS_PER_WG = 64;
 template <int WIN_SEGMENTS>
@@ -209,6 +211,33 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       const int n = (int)jd.txt_len, F = a.flank_len;
       int kmin = 1, kmax = 0;
       if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
+      // ---- The alignment of a piece that differs from the read by one or two substitutions, without aligning.  All seeds on ONE
+      //      diagonal k with the piece inside the read there, d <= hamming_max = min(segments - 1, (o + e - 1) / x) mismatches on it:
+      //      every alignment of penalty <= x d < o + e is gap-free, i.e. a diagonal k' with at most d mismatches; those spoil at most
+      //      d segments, the others occur exactly on k' and their heads are among the seeds, so k' = k.  The optimal alignment is
+      //      therefore unique -- diagonal k, penalty x d -- and what the reference reads off it (span_locater.rs:14-26) is
+      //      count_matches() = F - d and the text span [k, k + F).  (d = 0 cannot happen: the exact scan would have found it.)
+      bool solved = false;
+      if (a.hamming_max > 0 && kmin == kmax && kmin >= 0 && kmin + F <= n) {
+        const uint8_t* __restrict__ t = a.read_blob + jd.txt_off + kmin;
+        const uint8_t* __restrict__ pz = a.flank_blob + jd.pat_off;
+        auto differing_bytes = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_popcount((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u); };
+        uint32_t cnt = 0;
+        for (int i = lane; i < (F >> 2); i += 64) cnt += differing_bytes(load_u32(t + 4 * i) ^ load_u32(pz + 4 * i));
+        if (lane == 63 && (F & 3)) cnt += differing_bytes((load_u32(t + F - 4) ^ load_u32(pz + F - 4)) >> (8 * (4 - (F & 3))));  // the last one to three bytes
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, dd);
+        if (cnt >= 1u && cnt <= (uint32_t)a.hamming_max) {
+          solved = true;
+          if (lane == 0) {
+            const uint64_t j = jd.out_index;
+            a.n_match[j] = F - (int)cnt;
+            a.span4[4 * j] = 0u; a.span4[4 * j + 1] = (uint32_t)F; a.span4[4 * j + 2] = (uint32_t)kmin; a.span4[4 * j + 3] = (uint32_t)(kmin + F);
+            atomicAdd(a.count + 7, 1u);
+          }
+        }
+      }
+      if (solved) continue;
       int w0 = 0, wl = 0;
       if (kmin <= kmax && kmax - kmin <= a.spread) {
         // diagonals [kmin - margin, kmax + margin] start the alignment (text_begin_free = 2 margin + spread of the windowed launch, counted
@@ -365,10 +394,12 @@ struct CombineArgs {
   uint64_t n_reads; int32_t flank_len; double threshold;
   const int32_t* pos; const int32_t* n_match; const uint32_t* span4;
   int32_t* span_start; int32_t* span_end; uint8_t* lf_hit; uint8_t* rf_hit;
+  const uint32_t* count; unsigned long long* cells;  // count[7] (alignments settled by the substitution shortcut) -> cells[2], next to the offset counters
 };
 
 __global__ void span_combine_kernel(const CombineArgs a) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0 && a.cells) a.cells[2] = a.count[7];
   if (r >= a.n_reads) return;
   int s[2], e[2], hit[2];
   for (int side = 0; side < 2; ++side) {
@@ -584,6 +615,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       WindowArgs wa;
       wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
       wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
+      wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism);
+      wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
       {
         KTimer t(c, TRGT_K_FLANK_SCAN);
         const dim3 wgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG))));
@@ -675,6 +708,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   ca.threshold = (double)(uint64_t)p.flank_len * p.min_flank_id_frac;  // span_locater.rs:46
   ca.pos = (const int32_t*)d_pos; ca.n_match = (const int32_t*)d_nmatch; ca.span4 = (const uint32_t*)d_span4;
   ca.span_start = d_span_start; ca.span_end = d_span_end; ca.lf_hit = d_lf_hit; ca.rf_hit = d_rf_hit;
+  ca.count = (const uint32_t*)d_count; ca.cells = (unsigned long long*)c->last_wfa_cells_dev;
   hipLaunchKernelGGL(span_combine_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, ca);
   TRGT_HIP_TRY(c, hipGetLastError());
   if (c->knobs.debug) {  // (synchronises: developer output only)
@@ -682,8 +716,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
     if (win_q > 0)
-      fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand)\n",
-              h[0], h[1], h[2], h[4], h[5], h[2] - h[4], h[5] - (h[2] - h[4]));
+      fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the substitution shortcut %u\n",
+              h[0], h[1], h[2], h[4], h[5], h[2] - h[4] - h[7], h[5] - (h[2] - h[4] - h[7]), h[7]);
     else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[0], h[1], h[2]);
   }
   (void)n_loci;

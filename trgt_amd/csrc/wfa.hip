@@ -564,7 +564,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   int rc;
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
-  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 16, &d_cells))) return rc;
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
   if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
