@@ -199,11 +199,11 @@ constexpr int WIN_JOBS_PER_WG = 64;
 template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
-  __shared__ uint32_t l_nw, l_nr, l_bw, l_br;
+  __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns;
   const uint32_t n_light = a.count[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t c0 = blockIdx.x * WIN_JOBS_PER_WG; c0 < n_light; c0 += gridDim.x * WIN_JOBS_PER_WG) {
-    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; }
+    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; }
     __syncthreads();
     const uint32_t c1 = c0 + WIN_JOBS_PER_WG < n_light ? c0 + WIN_JOBS_PER_WG : n_light;
     for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       int kmin = 1, kmax = 0;
       if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
       // ---- The alignment of a piece that differs from the read by one or two substitutions, without aligning.  All seeds on ONE
-      //      diagonal k with the piece inside the read there, d <= hamming_max = min(segments - 1, (o + e - 1) / x) mismatches on it:
+      //      diagonal k with the piece inside the read there, d <= hamming_max = min(segments - 1, (o + e - 1) / x, 4) mismatches on it:
       //      every alignment of penalty <= x d < o + e is gap-free, i.e. a diagonal k' with at most d mismatches; those spoil at most
       //      d segments, the others occur exactly on k' and their heads are among the seeds, so k' = k.  The optimal alignment is
       //      therefore unique -- diagonal k, penalty x d -- and what the reference reads off it (span_locater.rs:14-26) is
@@ -225,15 +225,18 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
         uint32_t cnt = 0;
         for (int i = lane; i < (F >> 2); i += 64) cnt += differing_bytes(load_u32(t + 4 * i) ^ load_u32(pz + 4 * i));
         if (lane == 63 && (F & 3)) cnt += differing_bytes((load_u32(t + F - 4) ^ load_u32(pz + F - 4)) >> (8 * (4 - (F & 3))));  // the last one to three bytes
-#pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, dd);
+        // (the sum over the lanes from four ballots: a shuffle reduction is six LDS round trips per job, as much as the search itself)
+        const unsigned long long b1 = __ballot(cnt >= 1u);
+        uint32_t total = (uint32_t)__popcll(b1);
+        if (total <= (uint32_t)a.hamming_max) total += (uint32_t)(__popcll(__ballot(cnt >= 2u)) + __popcll(__ballot(cnt >= 3u)) + __popcll(__ballot(cnt >= 4u)) + __popcll(__ballot(cnt >= 5u)));
+        cnt = total;  // (uniform; lanes hold at most one dword and the tail for flanks up to 255 bases, more only beyond -- then cnt >= 5 ends the shortcut)
         if (cnt >= 1u && cnt <= (uint32_t)a.hamming_max) {
           solved = true;
           if (lane == 0) {
             const uint64_t j = jd.out_index;
             a.n_match[j] = F - (int)cnt;
             a.span4[4 * j] = 0u; a.span4[4 * j + 1] = (uint32_t)F; a.span4[4 * j + 2] = (uint32_t)kmin; a.span4[4 * j + 3] = (uint32_t)(kmin + F);
-            atomicAdd(a.count + 7, 1u);
+            atomicAdd(&l_ns, 1u);  // (one global atomic per workgroup below: 60k of them on one address doubled this kernel's time)
           }
         }
       }
@@ -254,6 +257,7 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
     __syncthreads();
     if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + 4, l_nw);
     if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + 5, l_nr);
+    if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + 7, l_ns);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
     for (uint32_t i = threadIdx.x; i < l_nr; i += blockDim.x) a.rest_jobs[l_br + i] = l_out[WIN_JOBS_PER_WG - 1 - i];
@@ -615,7 +619,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       WindowArgs wa;
       wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
       wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
-      wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism);
+      wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism), 4);  // (4: the kernel's count is exact up to there)
       wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
       {
         KTimer t(c, TRGT_K_FLANK_SCAN);
