@@ -29,6 +29,8 @@ struct trgt_knobs {
   bool one_launch = false;   // TRGT_WFA_ONE_LAUNCH: all flank alignments in one launch
   bool no_spec = false;      // TRGT_WFA_NO_SPEC: general instantiation of the dedicated kernel
   bool no_window = false;    // TRGT_WFA_NO_WINDOW: no seeded windows
+  bool early_adaptive = true;   // TRGT_EARLY_ADAPTIVE=0: the pre-filter's early-rejection test every 16th level (else scheduled by the smallest deficit seen)
+  bool no_heavy_window = false;  // TRGT_NO_HEAVY_WINDOW: the expensive fallback alignments go to the pre-filter without the seed search first
   bool no_hamming = false;   // TRGT_NO_HAMMING: no substitution-only shortcut in the window search (every light fallback is aligned)
   bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
   bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them
@@ -105,7 +107,7 @@ struct trgt_hip_ctx {
   // other's tail), with the events that fork them off the batch's stream and join them back
   hipStream_t stream_hmm = nullptr;  // the first device-resolved HMM batch of a call, when the device-side repair runs next to it
   hipEvent_t ev_gt = nullptr, ev_rp = nullptr;  // fork / join of the device-side consensus repair (second stream) next to the first HMM batch
-  hipEvent_t ev_scan = nullptr, ev_heavy = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
+  hipEvent_t ev_scan = nullptr, ev_heavy = nullptr, ev_hwin = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
   // side streams of the HMM launches: [0..2] of buffer set 0, [3..5] of buffer set 1 (the second batch of a call runs next to the first)
   hipStream_t hmm_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t hmm_fork[2] = {nullptr, nullptr}, hmm_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -181,7 +183,7 @@ enum Slot {
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED, S_WFA_RETRY, S_WFA_RETRY_B, S_WFA_WS_C, S_WFA_COUNTER_C, S_WFA_CELLS_C, S_WFA_RETRY_C,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
-  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY,
+  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY, S_FS_NOSEED,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED, S_GT_GENO,

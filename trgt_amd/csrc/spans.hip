@@ -192,6 +192,7 @@ struct WindowArgs {
   const JobDev* wfa_jobs; uint32_t jobs_cap; uint32_t* count;
   JobDev* win_jobs; JobDev* rest_jobs;
   int32_t flank_len, q, margin, spread, tbf;
+  int32_t front;                       // 1: the jobs at the FRONT of wfa_jobs (count[0], the expensive ones); the jobs without a window then go to rest_jobs under count[8]
   int32_t hamming_max;                 // > 0: the substitution-only shortcut below, for up to this many mismatches
   int32_t* n_match; uint32_t* span4;   // per (read, side): what the alignment kernels would have written for such a job
 };
@@ -200,14 +201,17 @@ template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
   __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns;
-  const uint32_t n_light = a.count[2];
+  const uint32_t n_light = a.count[a.front ? 0 : 2];  // (the length of the list this launch walks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t c0 = blockIdx.x * WIN_JOBS_PER_WG; c0 < n_light; c0 += gridDim.x * WIN_JOBS_PER_WG) {
+  // jobs per workgroup and round: 64, fewer when the list is short (a job is a dependent chain of loads: 17 k jobs in rounds of 64 kept
+  // 270 workgroups busy for 0.39 ms; spread over all of them they take a fifth of that)
+  const uint32_t per_wg = min((uint32_t)WIN_JOBS_PER_WG, max(4u, ((n_light + gridDim.x - 1u) / gridDim.x + 3u) & ~3u));
+  for (uint32_t c0 = blockIdx.x * per_wg; c0 < n_light; c0 += gridDim.x * per_wg) {
     if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; }
     __syncthreads();
-    const uint32_t c1 = c0 + WIN_JOBS_PER_WG < n_light ? c0 + WIN_JOBS_PER_WG : n_light;
+    const uint32_t c1 = c0 + per_wg < n_light ? c0 + per_wg : n_light;
     for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
-      JobDev jd = a.wfa_jobs[a.jobs_cap - 1u - i];
+      JobDev jd = a.front ? a.wfa_jobs[i] : a.wfa_jobs[a.jobs_cap - 1u - i];
       const int n = (int)jd.txt_len, F = a.flank_len;
       int kmin = 1, kmax = 0;
       if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
@@ -242,7 +246,10 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       }
       if (solved) continue;
       int w0 = 0, wl = 0;
-      if (kmin <= kmax && kmax - kmin <= a.spread) {
+      // (front list: only a piece that lies inside the read whole.  A read that ends within the piece has seeds too, but its alignment
+      //  deletes the rest of the piece -- far beyond the bound of the window argument: it would fail the check and be aligned against
+      //  the whole read without the pre-filter in front; measured, that put 6 ms of alignments behind a 1.4-ms filter pass)
+      if (kmin <= kmax && kmax - kmin <= a.spread && (!a.front || (kmin >= 0 && kmax + F <= n))) {
         // diagonals [kmin - margin, kmax + margin] start the alignment (text_begin_free = 2 margin + spread of the windowed launch, counted
         // from the window start) and run through at most flank_len more bases of the read
         const int lo = kmin - a.margin;
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + 4, l_nw);
-    if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + 5, l_nr);
+    if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + (a.front ? 8 : 5), l_nr);
     if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + 7, l_ns);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
@@ -480,10 +487,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
   if ((rc = dev_get(c, S_FS_POS, n_jobs * 4, &d_pos)) || (rc = dev_get(c, S_FS_WFAJOBS, n_jobs * sizeof(JobDev), &d_wjobs)) ||
-      (rc = dev_get(c, S_FS_COUNT, 32, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
+      (rc = dev_get(c, S_FS_COUNT, 64, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
       (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 32, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64, c->stream));
   ScanArgs sa;
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
   sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos; sa.n_match = (int32_t*)d_nmatch;
@@ -552,6 +559,22 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   //  anyway, the launch over the expensive alignments is planned for what is left)
   const bool split = d_heavy_len && heavy_tlen_max > 0 && !c->knobs.one_launch;
   heavy_tlen_max = std::min(heavy_tlen_max, short_max);
+  bool heavy_window = false;  // the seed search runs over the expensive list as well (below)
+  auto window_args = [&]() {
+    WindowArgs wa;
+    wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
+    wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
+    wa.front = 0;
+    wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism), 4);  // (4: the kernel's count is exact up to there)
+    wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
+    return wa;
+  };
+  auto launch_window = [&](const WindowArgs& wa) {  // on the current stream
+    const dim3 wgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG))));
+    if (win_m == 4) hipLaunchKernelGGL(flank_window_kernel<4>, wgrid, dim3(256), 0, c->stream, wa);
+    else if (win_m == 6) hipLaunchKernelGGL(flank_window_kernel<6>, wgrid, dim3(256), 0, c->stream, wa);
+    else hipLaunchKernelGGL(flank_window_kernel<8>, wgrid, dim3(256), 0, c->stream, wa);
+  };
   c->last_filter_cells_dev = nullptr;
   bool heavy_join = false;         // the expensive alignments run on the second stream: wait for it before the spans are combined
   void* heavy_cells_dev = nullptr; // ... and their offset counter lives in workspace set 1
@@ -587,11 +610,29 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       std::swap(c->stream, c->stream2);
     }
     struct StreamBack { trgt_hip_ctx* c; bool on; ~StreamBack() { if (on) std::swap(c->stream, c->stream2); } } stream_back{c, two_streams};
+    // The expensive list first meets the seed search too.  "Too short to span the locus" says nothing about the flank the read DOES
+    // hold: a fifth of these alignments have a penalty below 8 (tools/filter_hist.py) -- the pre-filter let them through after a few
+    // levels and the back-tracing kernel aligned them a second time, at the end of this stream's chain.  With seeds they are settled
+    // by the substitution shortcut or join the windowed launch of the other stream; the pre-filter sees the jobs WITHOUT seeds only.
+    heavy_window = use_filter && two_streams && win_q > 0 && !c->knobs.no_heavy_window;
+    void* d_noseed = nullptr;
+    if (heavy_window) {
+      if ((rc = dev_get(c, S_FS_NOSEED, n_jobs * sizeof(JobDev), &d_noseed))) return rc;
+      if (!c->ev_hwin) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_hwin, hipEventDisableTiming));
+      WindowArgs wh = window_args();
+      wh.front = 1; wh.rest_jobs = (JobDev*)d_noseed;
+      KTimer t(c, TRGT_K_FLANK_SCAN);
+      launch_window(wh);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      t.stop(0);
+      TRGT_HIP_TRY(c, hipEventRecord(c->ev_hwin, c->stream));
+    }
     if (use_filter) {
       void* d_keepjobs = nullptr;
       if ((rc = dev_get(c, S_FS_KEEPJOBS, n_jobs * sizeof(JobDev), &d_keepjobs))) return rc;
       FilterLaunch FL;
-      FL.jobs_dev = (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs; FL.n_jobs_dev = (const uint32_t*)d_count;
+      FL.jobs_dev = heavy_window ? (const JobDev*)d_noseed : (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs;
+      FL.n_jobs_dev = heavy_window ? (const uint32_t*)d_count + 8 : (const uint32_t*)d_count;
       FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
       FL.mism = p.mism; FL.gapo = p.gapo; FL.gape = p.gape; FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
       if ((rc = flank_filter_launch(c, FL))) return rc;
@@ -616,20 +657,13 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     L.n_jobs_dev = (const uint32_t*)d_count + 3;  // always 0: this launch takes the back part of the list only
     L.keep_cells = !two_streams; L.timer_slot = TRGT_K_WFA_FLANK_REST;  // (two streams: the first launch of THIS stream resets the counter of set 0)
     if (win_q > 0) {  // the alignments with a seeded window: short texts, more of them per CU; then sort out which of them stand
-      WindowArgs wa;
-      wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
-      wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
-      wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism), 4);  // (4: the kernel's count is exact up to there)
-      wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
       {
         KTimer t(c, TRGT_K_FLANK_SCAN);
-        const dim3 wgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus * 8, (int64_t)((n_jobs + WIN_JOBS_PER_WG - 1) / WIN_JOBS_PER_WG))));
-        if (win_m == 4) hipLaunchKernelGGL(flank_window_kernel<4>, wgrid, dim3(256), 0, c->stream, wa);
-        else if (win_m == 6) hipLaunchKernelGGL(flank_window_kernel<6>, wgrid, dim3(256), 0, c->stream, wa);
-        else hipLaunchKernelGGL(flank_window_kernel<8>, wgrid, dim3(256), 0, c->stream, wa);
+        launch_window(window_args());
         TRGT_HIP_TRY(c, hipGetLastError());
         t.stop(0);
       }
+      if (heavy_window) TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_hwin, 0));  // (the other stream's seed search appends to the same windowed list)
       WfaLaunch LW = L;
       LW.jobs_dev = (const JobDev*)d_winjobs; LW.n_jobs_dev = (const uint32_t*)d_count + 4; LW.n_jobs2_dev = nullptr; LW.jobs_cap = 0;
       LW.max_tlen = win_tlen; LW.max_sum = (int64_t)p.flank_len + win_tlen;
@@ -716,12 +750,13 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   hipLaunchKernelGGL(span_combine_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, ca);
   TRGT_HIP_TRY(c, hipGetLastError());
   if (c->knobs.debug) {  // (synchronises: developer output only)
-    uint32_t h[8];
+    uint32_t h[16];
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
-    TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 32, hipMemcpyDeviceToHost));
+    TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 64, hipMemcpyDeviceToHost));
     if (win_q > 0)
       fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the substitution shortcut %u\n",
               h[0], h[1], h[2], h[4], h[5], h[2] - h[4] - h[7], h[5] - (h[2] - h[4] - h[7]), h[7]);
+    if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[8], h[0]);
     else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[0], h[1], h[2]);
   }
   (void)n_loci;

@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
       mlo[0] = 0; mhi[0] = tlen;
       unsigned long long cells = (unsigned long long)tlen + 1ull;
       int s = 0, num_null = 0;
+      int next_check = 16;  // early rejection: the next level at which it is tried (every 16th, sooner when the best cell is close to the limit)
       bool done = false, bail = false, early = false;
       for (;;) {
         // ---- termination (wavefront_termination_endsfree with pattern_end_free = 0, text_end_free = tlen): v == plen
@@ -421,14 +422,14 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
         for (int d = R - 1; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
         mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
-        // ---- early rejection (every 16th level).  A cell (v bases of the pattern consumed, at most c of them matched, text position
+        // ---- early rejection (at the levels where it can first succeed, see next_check).  A cell (v bases of the pattern consumed, at most c of them matched, text position
         //      h = v + k) can end in an alignment of at most c + min(plen - v, tlen - h) matches -- a match needs a base of both -- and
         //      no step raises that number: a match raises c, v and h together, a mismatch v and h, a deleted base v, an inserted base h.
         //      Every alignment that ends beyond this level continues from a cell of the last six M levels or of the current I / D: if
         //      none of them can still reach min_matches, the optimal alignment -- whichever it is -- has fewer matches than the caller
         //      asks for, and the remaining levels (the widest ones: the work of a level grows with the score) need not be computed.
         //      Per 16-bit cell: deficit = (v - c) + max(0, k - (tlen - plen)), 0xFFFF for NULL; at most plen - min_matches to go on.
-        if (a.early_reject && (s & 15) == 0) {
+        if (a.early_reject && s >= next_check) {
           uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
           for (int t = 0; t < NS; ++t) {
@@ -451,8 +452,17 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
               dmin = rpk_min(dmin, dm);
             }
           }
-          const uint32_t best = min(dmin & 0xFFFFu, dmin >> 16);  // the smallest deficit of this lane's cells
+          uint32_t best = min(dmin & 0xFFFFu, dmin >> 16);  // the smallest deficit of this lane's cells
           if (!__builtin_amdgcn_ballot_w64((int)best <= plen - a.min_matches)) { early = true; break; }
+          // When to look again: in 16 levels, or -- when the smallest deficit m is close to the limit -- after the X (limit - m + 1)
+          // levels the cheapest way of spoiling bases (mismatches, one every X levels) takes to push that cell over it.  (Only the
+          // schedule rests on this estimate; a test is exact whenever it runs.)  A text without the piece is given up at level 52
+          // with TRGT's 2,5,1 and 90 % instead of at level 64.
+          if (a.early_reject == 2) {
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, dd));
+          }
+          next_check = s + (a.early_reject == 2 ? max(2, min(16, X * (plen - a.min_matches - (int)best + 1))) : 16);
         }
       }
       cells_acc += cells;
@@ -508,7 +518,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   std::memset(&a, 0, sizeof a);
   a.jobs = L.jobs_dev; a.n_jobs_dev = L.n_jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host;
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
-  a.min_matches = L.min_matches; a.early_reject = L.early_reject ? 1 : 0;
+  a.min_matches = L.min_matches; a.early_reject = L.early_reject ? (c->knobs.early_adaptive ? 2 : 1) : 0;
   a.keep_jobs = L.keep_jobs; a.keep_count = L.keep_count;
   a.score = L.score; a.bound = L.bound; a.keep = L.keep;
   void* d_counter = nullptr; void* d_cells = nullptr;
