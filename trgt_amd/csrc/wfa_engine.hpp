@@ -182,7 +182,31 @@ __device__ __forceinline__ int32_t extend_cell(const Inst& I, Red& red, int k, i
   int v = off - k, h = off;
   const int plen = I.plen, tlen = I.tlen, rev = I.rev;
   const uint8_t* pp = pat_of<LA>(I); const uint8_t* tp = txt_of<LA>(I);
+  // Eight bases per step while both sequences have them (the alignments of this kernel are of near-identical sequences -- reads of
+  // an allele against its consensus: one lane runs along a diagonal for hundreds of bases while the others wait for it; a byte per
+  // step, each a dependent load, was most of the kernel's time).  Reverse sequences (BiWFA's backward fronts) read the eight bytes
+  // that END at the position and count equal bytes from the top.
+  if constexpr (!LA) {
+    if (!rev) {
+      while (v + 8 <= plen && h + 8 <= tlen) {
+        uint64_t a, b;
+        __builtin_memcpy(&a, pp + v, 8); __builtin_memcpy(&b, tp + h, 8);
+        const uint64_t x = a ^ b;
+        if (x) { const int n = __builtin_ctzll(x) >> 3; v += n; h += n; goto extended; }
+        v += 8; h += 8;
+      }
+    } else {
+      while (v + 8 <= plen && h + 8 <= tlen) {
+        uint64_t a, b;
+        __builtin_memcpy(&a, pp + (plen - v - 8), 8); __builtin_memcpy(&b, tp + (tlen - h - 8), 8);
+        const uint64_t x = a ^ b;
+        if (x) { const int n = __builtin_clzll(x) >> 3; v += n; h += n; goto extended; }
+        v += 8; h += 8;
+      }
+    }
+  }
   while (v < plen && h < tlen && seq_at(pp, plen, rev, v) == seq_at(tp, tlen, rev, h)) { ++v; ++h; }
+extended:
   off = h;
   if (I.span == 1) {  // wavefront_termination_endsfree
     if ((h >= tlen && plen - v <= I.pef) || (v >= plen && tlen - h <= I.tef))
