@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
             for (int dd = 32; dd >= 1; dd >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, dd));
           }
-          next_check = s + (a.early_reject == 2 ? max(2, min(16, X * (plen - a.min_matches - (int)best + 1))) : 16);
+          next_check = s + (a.early_reject == 2 ? max(2, min(16, X * (plen - a.min_matches - rfl_i((int)best) + 1))) : 16);  // (uniform: an SGPR -- as a vector value it was spilled, a scratch load per level)
         }
       }
       cells_acc += cells;
