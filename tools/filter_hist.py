@@ -12,6 +12,7 @@ from trgt_amd import _lib, synth, wfaligner
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 b = synth.generate(n, config=2)
 F = 250
+MINM = int(sys.argv[2]) if len(sys.argv) > 2 else 175  # ceil(250 * 0.7): --min-flank-id-frac default
 pats, txts = [], []
 lrb = b["locus_read_begin"]
 for l in range(n):
@@ -29,8 +30,8 @@ for l in range(n):
                 pats.append(piece)
                 txts.append(rd)
 ctx = _lib.Context(0)
-full = wfaligner.flank_filter_batch(pats, txts, 225, ctx=ctx, early_reject=False)
-early = wfaligner.flank_filter_batch(pats, txts, 225, ctx=ctx, early_reject=True)
+full = wfaligner.flank_filter_batch(pats, txts, MINM, ctx=ctx, early_reject=False)
+early = wfaligner.flank_filter_batch(pats, txts, MINM, ctx=ctx, early_reject=True)
 pen = -full["score"].astype(np.int64)
 tl = np.array([len(t) for t in txts])
 keep = full["keep"].astype(bool)
