@@ -142,18 +142,54 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
 
   // Extension over 4-byte sliding windows: P4[i] = pattern bytes i..i+3 (zero padded), T4 likewise.  One aligned LDS
   // dword per sequence covers four bases; most diagonals stop inside the first window, so the common case is straight-line.
-  auto extend = [&](int k, int32_t off, FastTerm& tm) -> int32_t {
-    int v = off - k, h = off;
-    uint32_t n;
-    do {
-      const uint32_t xw = P4[v] ^ T4[h];
-      n = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - v, tlen - h));
-      v += (int)n; h += (int)n;
-    } while (n == 4u);
-    if (span == 1) {
-      if ((h >= tlen && plen - v <= pef) || (v >= plen && tlen - h <= tef))
-        atomicMin(&tm.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)h);
-    } else if (k + koff == ak_b) tm.end_val = h;
+  // The rest of a run of matches, by the whole wave (uniform control flow; `c`: this lane's cell matched its windows so far and goes on
+  // at (v, h)).  A cell that is still going after two windows is almost surely on the diagonal of the alignment itself -- the piece
+  // matches the read there for dozens or hundreds of bases -- and one lane stepping four bases at a time kept the other 63 waiting
+  // (a quarter of the windowed launch's instructions).  Lane i compares the window 4 i bases further on: 256 bases per round trip; the
+  // first lane whose window does not match whole ends the run, exactly where the one-lane loop would have ended it.
+  auto finish_runs = [&](bool c, int& v, int& h) {
+    unsigned long long m = __ballot(c);
+    while (m) {
+      const int j = (int)__builtin_ctzll(m);
+      m &= m - 1ull;
+      int vj = __builtin_amdgcn_readlane(v, j), hj = __builtin_amdgcn_readlane(h, j);
+      for (;;) {
+        const int pv = vj + 4 * lane, ph = hj + 4 * lane;
+        const int rem = min(plen - pv, tlen - ph);  // (<= 0 beyond either sequence: that lane ends the run with nothing)
+        const uint32_t xw = P4[min(pv, plen)] ^ T4[min(ph, tlen)];
+        const uint32_t n = rem > 0 ? min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)rem) : 0u;
+        const unsigned long long stop = __ballot(n < 4u);
+        if (stop) {
+          const int js = (int)__builtin_ctzll(stop);
+          const int ext = 4 * js + __builtin_amdgcn_readlane((int)n, js);
+          vj += ext; hj += ext;
+          break;
+        }
+        vj += 256; hj += 256;
+      }
+      if (lane == j) { v = vj; h = hj; }
+    }
+  };
+  // extend() for a whole wave in uniform control flow (`on`: this lane has a cell): two windows per lane, then finish_runs
+  auto extend_u = [&](int k, int32_t off, bool on, FastTerm& tm) -> int32_t {
+    int v = on ? off - k : 0, h = on ? off : 0;
+    bool c = on;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (c) {
+        const uint32_t xw = P4[v] ^ T4[h];
+        const uint32_t n = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - v, tlen - h));
+        v += (int)n; h += (int)n;
+        c = n == 4u;
+      }
+    }
+    finish_runs(c, v, h);
+    if (on) {
+      if (span == 1) {
+        if ((h >= tlen && plen - v <= pef) || (v >= plen && tlen - h <= tef))
+          atomicMin(&tm.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)h);
+      } else if (k + koff == ak_b) tm.end_val = h;
+    }
     return h;
   };
 
@@ -182,10 +218,11 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     const uint32_t so0 = 2u * (uint32_t)(HIST_BIAS - (int)lo_c);
     for (int kb0 = (int)lo_c + wave * 64; kb0 <= hi_b; kb0 += nT) {
       const int kb = kb0 + lane;
-      if (kb <= hi_b) {
-        const int k = kb - koff;
-        int32_t off = span ? (k > 0 ? k : 0) : 0;
-        off = extend(k, off, tm);
+      const bool on = kb <= hi_b;
+      const int k = kb - koff;
+      int32_t off = span ? (k > 0 ? k : 0) : 0;
+      off = extend_u(k, off, on, tm);
+      if (on) {
         Mr[kb] = (uint16_t)(off + 1);
         hist_store(hrs, 2u * (uint32_t)kb, so0, (uint32_t)(off + 1));
       }
@@ -288,7 +325,7 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
     LV_MARK(1);
     // One diagonal per lane, every source masked by its range: the strips at the two ends of a wavefront.
     // Encoded domain (enc = offset + 1, 0 = NULL): ins = max(Mo[k-1], Ie[k-1]) + 1, del = max(Mo[k+1], De[k+1]), mis = Mm[k] + 1.
-    auto edge = [&](int kb, bool& okM, bool& okI, bool& okD) {
+    auto edge = [&](int kb, bool& okM, int32_t& off_e, unsigned& ins_e, unsigned& del_e) {
       unsigned a = pMo[kb - 1], b = pIe[kb - 1], c = pMo[kb + 1], d = pDe[kb + 1], m = pMm[kb];
       a = (unsigned)(kb - 1 - lo_mo) < n_mo ? a : 0u;
       b = (unsigned)(kb - 1 - lo_ie) < n_ie ? b : 0u;
@@ -299,9 +336,14 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
       const unsigned ins = mi + (mi != 0u), del = max(c, d), mis = m + (m != 0u);
       unsigned mx = max(del, max(mis, ins));
       const int k = kb - koff;
-      int32_t off = (int32_t)mx - 1;
-      okM = (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
-      if (okM) { off = extend(k, off, tn); mx = (unsigned)off + 1u; } else mx = 0u;
+      off_e = (int32_t)mx - 1;
+      okM = (uint32_t)off_e <= (uint32_t)tlen && (uint32_t)(off_e - k) <= (uint32_t)plen;
+      ins_e = ins; del_e = del;
+    };
+    // ... and, after the extension (taken by the whole wave together: extend_u), what is stored of the cell
+    auto edge_store = [&](int kb, bool okM, int32_t off, unsigned ins, unsigned del, bool& okI, bool& okD) {
+      const int k = kb - koff;
+      const unsigned mx = okM ? (unsigned)off + 1u : 0u;
       qI[kb] = (uint16_t)ins; qD[kb] = (uint16_t)del; qM[kb] = (uint16_t)mx;
       const uint32_t kb2 = 2u * (uint32_t)kb;
       hist_store(hrs, kb2, soI, ins); hist_store(hrs, kb2, soD, del); hist_store(hrs, kb2, soM, mx);  // history: written once
@@ -342,9 +384,11 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
         uint32_t nB = min(min(ffbl_raw(xB) >> 3, 4u), (uint32_t)min(plen - vB, tlen - hB));
         vA += (int)nA; hA += (int)nA; vB += (int)nB; hB += (int)nB;
         bool cA = okMA && nA == 4u, cB = okMB && nB == 4u;
-        while (cA || cB) {  // rare: a run of 4+ matches
+        if (__ballot(cA || cB)) {  // rare: a run of 4+ matches -- one more window per lane, then the wave together (finish_runs)
           if (cA) { const uint32_t xw = P4[vA] ^ T4[hA]; nA = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - vA, tlen - hA)); vA += (int)nA; hA += (int)nA; cA = nA == 4u; }
           if (cB) { const uint32_t xw = P4[vB] ^ T4[hB]; nB = min(min(ffbl_raw(xw) >> 3, 4u), (uint32_t)min(plen - vB, tlen - hB)); vB += (int)nB; hB += (int)nB; cB = nB == 4u; }
+          finish_runs(cA, vA, hA);
+          finish_runs(cB, vB, hB);
         }
         if (span == 1) {  // wavefront_termination_endsfree
           if (okMA && ((hA >= tlen && plen - vA <= pef) || (vA >= plen && tlen - hA <= tef)))
@@ -373,7 +417,11 @@ __device__ __forceinline__ FastEnd wf_run_lds_affine(const Pen& pen, const FastJ
           const int kbs = kb0 + 64 * half, kb = kbs + lane;
           if (kbs > hi) break;
           bool okM = false, okI = false, okD = false;
-          if (kb >= lo && kb <= hi) edge(kb, okM, okI, okD);
+          const bool inr = kb >= lo && kb <= hi;
+          int32_t off_e = 0; unsigned ins_e = 0, del_e = 0;
+          if (inr) edge(kb, okM, off_e, ins_e, del_e);
+          off_e = extend_u(kb - koff, off_e, okM, tn);
+          if (inr) edge_store(kb, okM, off_e, ins_e, del_e, okI, okD);
           note(__ballot(okM), kbs, fM, lM); note(__ballot(okI), kbs, fI, lI); note(__ballot(okD), kbs, fD, lD);
         }
       }
