@@ -139,7 +139,7 @@ def test_windows_are_in_use_and_some_do_not_stand(oracle, capfd, monkeypatch):
     err = capfd.readouterr().err
     line = [l for l in err.splitlines() if l.startswith("[spans]")][-1]
     nums = [int(t) for t in line.replace(",", " ").replace("(", " ").replace(")", " ").split() if t.isdigit()]
-    windowed, redone, shortcut = nums[3], nums[-2], nums[-1]
+    windowed, redone, shortcut = nums[3], nums[-3], nums[-2]  # (the last number: how many of the shortcut's were one-base gaps)
     assert windowed > 30 and redone >= 4 and shortcut >= 64, line  # (every right flank and the left flanks with 1-2 mismatches need no alignment)
 
 
@@ -196,5 +196,65 @@ def test_substitution_only_shortcut(oracle):
     finally:
         del os.environ["TRGT_NO_HAMMING"]
     assert int(out2.stats[21]) == 0
+    for k in ("span_start", "span_end", "allele_len", "classification"):
+        assert np.array_equal(getattr(out, k), getattr(out2, k)), k
+
+
+def test_one_base_gap_shortcut(oracle):
+    """One inserted or deleted base in a flank, seeds on two neighbouring diagonals: settled by the window search without an alignment.
+    Gaps at every kind of position -- near the ends (inside the margins: left to the aligner), in the middle, inside homopolymer and
+    dinucleotide runs (the place of the gap is open, the result is not), next to a substitution (not covered), two gaps (not covered) --
+    and flanks of low complexity, where prefix and suffix match on both diagonals."""
+    rng = np.random.default_rng(4242)
+
+    def with_run(rng, flank, at, unit, n):
+        b = bytearray(flank)
+        run = (unit * (n // len(unit) + 1))[:n]
+        b[at:at + n] = run
+        return bytes(b)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        pos = [1, 5, 12, 14, 20, 31, 62, 100, 125, 180, 214, 216, 218, 230, 247, 249]
+        p = pos[i % len(pos)]
+        l, r = lf, rf
+        if i % 3 == 0:
+            l = l[:p] + rand_dna(rng, 1) + l[p:]          # inserted base (may equal a neighbour: then the place is open)
+        elif i % 3 == 1:
+            l = l[:p] + l[p + 1:]                          # deleted base
+        else:
+            l = l[:p] + l[p + 1:]
+            l = _sub(rng, l, [(p + 40) % 240])             # ... and a substitution: the aligner's job
+        q = pos[(i + 7) % len(pos)]
+        if i % 2:
+            r = r[:q] + r[q:q + 1] + r[q:]                 # a base doubled (an insertion inside a run of at least two)
+        else:
+            r = r[:q] + r[q + 1:]
+        if i == 5:                                         # two gaps in one flank
+            r = rf[:60] + rf[61:150] + b"A" + rf[150:]
+        return rand_dna(rng, 300 + i) + l + tr + r + rand_dna(rng, 310)
+
+    loci = [_locus(rng, reads_fn, n_reads=16) for _ in range(4)]
+    # flanks with long runs: a 40-base homopolymer and a dinucleotide run in the left flank, gaps inside and next to them
+    for unit, at in ((b"A", 90), (b"AC", 120), (b"T", 30)):
+        base = dict(left_flank=rand_dna(rng, 250), right_flank=rand_dna(rng, 250), tr=b"CAG" * 20)
+        lf = with_run(rng, base["left_flank"], at, unit, 40)
+        rf = base["right_flank"]
+        reads = []
+        for i in range(16):
+            p = at - 3 + 3 * i
+            l = lf[:p] + lf[p + 1:] if i % 2 else lf[:p] + lf[p:p + 1] + lf[p:]
+            reads.append(rand_dna(rng, 305) + l + base["tr"] + rf + rand_dna(rng, 300))
+        reads += [rand_dna(rng, 330) + lf + base["tr"] + rf + rand_dna(rng, 330), rand_dna(rng, 320) + lf + base["tr"] + rf + rand_dna(rng, 325)]
+        loci.append(dict(left_flank=lf, right_flank=rf, tr=base["tr"], motifs=[b"CAG"], ploidy=2, reads=reads))
+    import os
+    from trgt_amd import _lib
+    b, out = _check(oracle, loci)
+    os.environ["TRGT_NO_INDEL_SHORTCUT"] = "1"
+    try:
+        ctx = _lib.Context(0)
+        _, out2 = _check(oracle, loci, ctx=ctx)
+    finally:
+        del os.environ["TRGT_NO_INDEL_SHORTCUT"]
+    assert int(out.stats[21]) >= int(out2.stats[21]) + 40  # the gaps outside the margins are settled without an alignment
     for k in ("span_start", "span_end", "allele_len", "classification"):
         assert np.array_equal(getattr(out, k), getattr(out2, k)), k

@@ -31,6 +31,7 @@ struct trgt_knobs {
   bool no_window = false;    // TRGT_WFA_NO_WINDOW: no seeded windows
   bool early_adaptive = true;   // TRGT_EARLY_ADAPTIVE=0: the pre-filter's early-rejection test every 16th level (else scheduled by the smallest deficit seen)
   bool no_heavy_window = false;  // TRGT_NO_HEAVY_WINDOW: the expensive fallback alignments go to the pre-filter without the seed search first
+  bool no_indel_shortcut = false;  // TRGT_NO_INDEL_SHORTCUT: one-base gaps are aligned (the substitution shortcut stays)
   bool no_hamming = false;   // TRGT_NO_HAMMING: no substitution-only shortcut in the window search (every light fallback is aligned)
   bool no_filter = false;    // TRGT_WFA_NO_FILTER: no pre-filter in front of the expensive alignments
   bool one_stream = false;   // TRGT_FLANK_ONE_STREAM: the expensive flank alignments in front of the others instead of next to them

@@ -194,20 +194,21 @@ struct WindowArgs {
   int32_t flank_len, q, margin, spread, tbf;
   int32_t front;                       // 1: the jobs at the FRONT of wfa_jobs (count[0], the expensive ones); the jobs without a window then go to rest_jobs under count[8]
   int32_t hamming_max;                 // > 0: the substitution-only shortcut below, for up to this many mismatches
+  int32_t indel_ok;                    // 1: the one-base-gap shortcut (penalties 2,5,1)
   int32_t* n_match; uint32_t* span4;   // per (read, side): what the alignment kernels would have written for such a job
 };
 constexpr int WIN_JOBS_PER_WG = 64;
 template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
-  __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns;
+  __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns, l_ni;
   const uint32_t n_light = a.count[a.front ? 0 : 2];  // (the length of the list this launch walks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // jobs per workgroup and round: 64, fewer when the list is short (a job is a dependent chain of loads: 17 k jobs in rounds of 64 kept
   // 270 workgroups busy for 0.39 ms; spread over all of them they take a fifth of that)
   const uint32_t per_wg = min((uint32_t)WIN_JOBS_PER_WG, max(4u, ((n_light + gridDim.x - 1u) / gridDim.x + 3u) & ~3u));
   for (uint32_t c0 = blockIdx.x * per_wg; c0 < n_light; c0 += gridDim.x * per_wg) {
-    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; }
+    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; l_ni = 0; }
     __syncthreads();
     const uint32_t c1 = c0 + per_wg < n_light ? c0 + per_wg : n_light;
     for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
@@ -244,6 +245,61 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
           }
         }
       }
+      // ---- ... and of a piece that differs from the read by ONE inserted or deleted base (penalties 2,5,1 only: o + e = 6).  All seeds on
+      //      two neighbouring diagonals, both inside the read.  An alignment of penalty <= 6 is gap-free with <= 3 mismatches, or has one
+      //      gap of one base and no mismatch.  The former leaves five segments exact, so it lies on a seeded diagonal: excluded when both
+      //      have >= 4 mismatches -- and with 2 and 4 excluded as well, the optimal penalty is 6.  The latter leaves seven segments exact;
+      //      the part on either side of the gap that holds a whole segment head lies on a seeded diagonal.  Both parts seeded: prefix on
+      //      one, suffix on the other of the two diagonals -- feasible iff the exact prefix on the first reaches the exact suffix on the
+      //      second (lcp / sfx below), and required to be feasible in ONE order only.  One part without a head (fewer than 12 bases in
+      //      front of the gap, or a suffix that starts beyond the last head): then the other part is exact from within 13 bases of the
+      //      start, or up to the last head, on a seeded diagonal -- excluded by the two margin tests.  So every optimal alignment runs
+      //      along the first diagonal, takes the one-base gap somewhere in the overlap of prefix and suffix (a homopolymer leaves the
+      //      place open, nothing else) and ends on the second: count_matches() and the span are the same for all of them --
+      //      F matches over F + 1 bases for an inserted base, F - 1 over F - 1 for a deleted one (span_locater.rs:14-26).
+      if (!solved && a.indel_ok && kmax - kmin == 1 && kmin >= 0 && kmax + F <= n && F <= 255) {
+        const uint8_t* __restrict__ t = a.read_blob + jd.txt_off + kmin;
+        const uint8_t* __restrict__ pz = a.flank_blob + jd.pat_off;
+        const int nd = F >> 2, rem = F & 3;
+        uint32_t pw = 0, t0 = 0, t1 = 0;  // lane i: bytes 4 i .. 4 i + 3 of the piece and of the read on the two diagonals; lane nd: the last one to three
+        if (lane < nd) { pw = load_u32(pz + 4 * lane); t0 = load_u32(t + 4 * lane); t1 = load_u32(t + 1 + 4 * lane); }
+        else if (lane == nd && rem) { const int sh = 8 * (4 - rem); pw = load_u32(pz + F - 4) >> sh; t0 = load_u32(t + F - 4) >> sh; t1 = load_u32(t + 1 + F - 4) >> sh; }
+        auto byte_flags = [](uint32_t x) -> uint32_t { return (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; };  // bit 8 b + 7: byte b differs
+        const uint32_t m0 = byte_flags(pw ^ t0), m1 = byte_flags(pw ^ t1);
+        const unsigned long long b0 = __ballot(m0 != 0u), b1 = __ballot(m1 != 0u);
+        auto lcp = [&](unsigned long long b, uint32_t m) -> int {  // bases of the piece that match from its start
+          if (!b) return F;
+          const int l = (int)__builtin_ctzll(b);
+          return 4 * l + (__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)m, l)) >> 3);
+        };
+        auto sfx = [&](unsigned long long b, uint32_t m) -> int {  // first base of the piece's exact suffix
+          if (!b) return 0;
+          const int l = 63 - (int)__builtin_clzll(b);
+          return 4 * l + ((31 - __builtin_clz((uint32_t)__builtin_amdgcn_readlane((int)m, l))) >> 3) + 1;
+        };
+        auto at_least_4 = [&](unsigned long long b, uint32_t m) -> bool {  // mismatches on the diagonal
+          const int lanes = __popcll(b);
+          if (lanes >= 4) return true;
+          const uint32_t c = (uint32_t)__builtin_popcount(m);
+          return lanes + __popcll(__ballot(c >= 2u)) + __popcll(__ballot(c >= 3u)) + __popcll(__ballot(c >= 4u)) >= 4;
+        };
+        const int lcp0 = lcp(b0, m0), lcp1 = lcp(b1, m1), sfx0 = sfx(b0, m0), sfx1 = sfx(b1, m1);
+        const int last_head = (WIN_SEGMENTS - 1) * a.q;
+        const bool margins = sfx0 > 13 && sfx1 > 13 && lcp0 < last_head - 1 && lcp1 < last_head - 1;
+        const bool ins_ok = sfx1 <= lcp0;                                  // prefix on kmin, one read base skipped, suffix on kmin + 1
+        const bool del_ok = max(sfx0 - 1, 0) <= min(lcp1, F - 1);          // prefix on kmin + 1, one base of the piece skipped, suffix on kmin
+        if (margins && ins_ok != del_ok && at_least_4(b0, m0) && at_least_4(b1, m1)) {
+          solved = true;
+          if (lane == 0) {
+            const uint64_t j = jd.out_index;
+            const int start = ins_ok ? kmin : kmax, len = ins_ok ? F + 1 : F - 1;
+            a.n_match[j] = ins_ok ? F : F - 1;
+            a.span4[4 * j] = 0u; a.span4[4 * j + 1] = (uint32_t)F; a.span4[4 * j + 2] = (uint32_t)start; a.span4[4 * j + 3] = (uint32_t)(start + len);
+            atomicAdd(&l_ns, 1u);
+            atomicAdd(&l_ni, 1u);
+          }
+        }
+      }
       if (solved) continue;
       int w0 = 0, wl = 0;
       // (front list: only a piece that lies inside the read whole.  A read that ends within the piece has seeds too, but its alignment
@@ -265,6 +321,7 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
     if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + 4, l_nw);
     if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + (a.front ? 8 : 5), l_nr);
     if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + 7, l_ns);
+    if (threadIdx.x == 192 && l_ni) atomicAdd(a.count + 9, l_ni);  // (of those: one-base gaps)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
     for (uint32_t i = threadIdx.x; i < l_nr; i += blockDim.x) a.rest_jobs[l_br + i] = l_out[WIN_JOBS_PER_WG - 1 - i];
@@ -566,6 +623,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
     wa.front = 0;
     wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism), 4);  // (4: the kernel's count is exact up to there)
+    wa.indel_ok = !c->knobs.no_hamming && !c->knobs.no_indel_shortcut && p.mism == 2 && p.gapo == 5 && p.gape == 1 && wa.hamming_max == 2 ? 1 : 0;
     wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
     return wa;
   };
@@ -754,8 +812,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 64, hipMemcpyDeviceToHost));
     if (win_q > 0)
-      fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the substitution shortcut %u\n",
-              h[0], h[1], h[2], h[4], h[5], h[2] - h[4] - h[7], h[5] - (h[2] - h[4] - h[7]), h[7]);
+      fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the shortcuts %u (one-base gaps: %u)\n",
+              h[0], h[1], h[2], h[4], h[5], h[2] - h[4] - h[7], h[5] - (h[2] - h[4] - h[7]), h[7], h[9]);
     if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[8], h[0]);
     else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[0], h[1], h[2]);
   }
