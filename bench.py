@@ -593,7 +593,7 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",
-                         "launch_is": "wfa_filter runs as two kernel launches over one job list when the longest text needs more than 1024 diagonals (wfa_filter_kernel<9,1> or <5,2> / <6,2> for the jobs above 1024, then <4,2>): a 'launch' here is the pair, one pass of the pre-filter over a batch -- in a rocprofv3 kernel summary its time is the sum of the two kernels' averages" if dom == "wfa_filter" else None,
+                         "launch_is": "wfa_filter runs as two kernel launches over one job list when the longest text needs more than 1024 diagonals (wfa_filter_kernel<9,1> or <5,2> / <6,2> for the jobs above 1024, then <4,2>): a 'launch' here is the pair, one pass of the pre-filter over a batch.  Outside a pool the two kernels run NEXT TO each other on two streams (round 3): the pass lasts from the start of the first to the end of the last -- in a rocprofv3 kernel summary of the one-context command that is about the longer kernel's average, not the sum (TRGT_FILTER_SERIAL=1 puts them one after the other again: then the sum)" if dom == "wfa_filter" else None,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "algorithmic_bytes_model": "SURVEY.md 8(d): B_io + B_dp, B_dp = 4 B per wavefront offset W (1 B per Viterbi cell); W = offsets the kernel computed, counted on the device (the pre-filter stops an alignment that cannot reach the match threshold: W is below WFA2-lib's count, see dp_cells_reference_per_launch)",
                          "dp_cells_reference_per_launch": ref_cells_l,

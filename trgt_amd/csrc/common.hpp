@@ -40,6 +40,8 @@ struct trgt_knobs {
   bool stage_lock = false;      // TRGT_STAGE_LOCK: only one context per device in its flank-location stage at a time
   bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
+  bool filter_side = false;        // TRGT_FILTER_SIDE: ... next to each other in the contexts of a pool too
+  bool filter_serial = false;      // TRGT_FILTER_SERIAL: the pre-filter's two launches one after the other on one stream
   bool filter_one_launch = false;  // TRGT_FILTER_ONE_LAUNCH: the pre-filter in one launch whatever the text lengths
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool no_lds_wfa = true;    // TRGT_WFA_LDS=1 turns the LDS-arena variant of the BiWFA kernel on (in front of the HBM-arena one).  Off by default:
@@ -106,6 +108,8 @@ struct trgt_hip_ctx {
   int64_t next_ticket = 1;
   // side streams for the launches of one HMM batch (one per workgroup-size class: they run next to each other, not one behind the
   // other's tail), with the events that fork them off the batch's stream and join them back
+  hipStream_t stream_flt = nullptr;  // the pre-filter's launch over the long texts, next to the one over the others
+  hipEvent_t ev_flt_a = nullptr, ev_flt_b = nullptr;
   hipStream_t stream_hmm = nullptr;  // the first device-resolved HMM batch of a call, when the device-side repair runs next to it
   hipEvent_t ev_gt = nullptr, ev_rp = nullptr;  // fork / join of the device-side consensus repair (second stream) next to the first HMM batch
   hipEvent_t ev_scan = nullptr, ev_heavy = nullptr, ev_hwin = nullptr;  // find_spans_device: fork / join of the stream with the expensive flank alignments
