@@ -339,6 +339,33 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* P = a.pat_base + job.pat_off;
     const uint8_t* Tx = a.txt_base + job.txt_off;
+    // ---- Identical sequences (end-to-end): a read of an allele against the central read / the consensus of its cluster, most of the
+    //      time.  The result needs no alignment: one run of matches, penalty 0 -- what the code below returns for such a pair after a
+    //      forward extension over the whole length, a base alignment and its back-trace (BiWFA: the breakpoint search ends with "end
+    //      reached" at score 0 and hands over to the base alignment, so the top-level score is never set; score-only: 0).  Checked
+    //      eight bytes per thread and step, straight from global memory, before anything is staged.
+    if (kp.span == 0 && plen == tlen && plen > 0 && !LA) {
+      uint64_t diff = 0;
+      int i = 8 * tid;
+      for (; i + 8 <= plen; i += 8 * T) { uint64_t x, y; __builtin_memcpy(&x, P + i, 8); __builtin_memcpy(&y, Tx + i, 8); diff |= x ^ y; }
+      if (i < plen && i + 8 > plen) for (int b = i; b < plen; ++b) diff |= (uint64_t)(P[b] ^ Tx[b]);
+      if (!__syncthreads_or(diff != 0ull)) {
+        if (tid == 0) {
+          const uint32_t o = job.out_index;
+          const bool aln = kp.scope_alignment != 0;
+          if (a.status) a.status[o] = TRGT_WF_COMPLETED;
+          if (a.score) a.score[o] = kp.biwfa && aln ? INT32_MIN : 0;
+          if (a.n_match) a.n_match[o] = aln ? plen : 0;
+          if (a.span4) { a.span4[4 * o + 0] = 0; a.span4[4 * o + 1] = (uint32_t)plen; a.span4[4 * o + 2] = 0; a.span4[4 * o + 3] = (uint32_t)tlen; }
+          if (a.cigar_len) a.cigar_len[o] = aln ? 1u : 0u;
+          if (a.ops_len) a.ops_len[o] = aln ? (uint32_t)plen : 0u;
+          if (aln && a.cigar) a.cigar[job.cigar_off] = ((uint32_t)plen << 4) | 7u;
+          cells_acc += kp.biwfa ? 2ull : 1ull;  // (the level-0 cells of the runs this stands for)
+        }
+        if (kp.scope_alignment && a.ops) for (int p = tid; p < plen; p += T) a.ops[job.ops_off + p] = 'M';
+        continue;
+      }
+    }
     // stage the two sequences in LDS when they fit (extension = byte compares against LDS)
     const uint32_t pl_pad = ((uint32_t)plen + 15u) & ~15u;
     const bool staged = pl_pad + (uint32_t)tlen <= a.lds_seq_cap;
