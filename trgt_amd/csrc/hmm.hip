@@ -857,20 +857,45 @@ __global__ void __launch_bounds__(1024) hmm_resolve_kernel(const HmmResolveArgs 
     return on ? a.allele_len[slot] + 1u : 0u;
   };
   auto bin_of = [&](uint32_t len) { const uint32_t b = len >> a.len_shift; return 63u - (b < 63u ? b : 63u); };  // bin 0 = the longest
-  for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
-    const uint32_t v = probe(i);
-    if (i < HMM_RESOLVE_LDS) verdict[i] = v;
-    if (v) atomicAdd(&hist[bin_of(v - 1u)], 1u);
+  // One LDS atomic per wave and bin, not per candidate: the alleles of an STR catalog fall into two or three bins, and 20 k atomics on
+  // three LDS words were most of this kernel's 0.14 ms (it sits between the genotyper and the HMM on every call's critical path).
+  // Returns, for a lane with a bin, the lane's rank among the wave's lanes of the same bin, their number, and whether it leads them.
+  auto wave_bins = [&](bool on, uint32_t bin, uint32_t& rank, uint32_t& count, uint32_t& leader) {
+    const int lane = tid & 63;
+    unsigned long long todo = __ballot(on);
+    rank = 0; count = 0; leader = 0;
+    while (todo) {
+      const int lead = (int)__builtin_ctzll(todo);
+      const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bin, lead);
+      const unsigned long long same = __ballot(on && bin == bb);
+      if (on && bin == bb) { rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); count = (uint32_t)__popcll(same); leader = (uint32_t)lead; }
+      todo &= ~same;
+    }
+  };
+  const uint32_t n_round = (a.n + 1023u) & ~1023u;  // (whole waves walk the loops: the ballots need every lane)
+  for (uint32_t i = (uint32_t)tid; i < n_round; i += 1024) {
+    const uint32_t v = i < a.n ? probe(i) : 0u;
+    if (i < a.n && i < HMM_RESOLVE_LDS) verdict[i] = v;
+    uint32_t rank, count, leader;
+    const uint32_t bin = v ? bin_of(v - 1u) : 0u;
+    wave_bins(v != 0u, bin, rank, count, leader);
+    if (v && rank == 0u) atomicAdd(&hist[bin], count);
   }
   __syncthreads();
   if (tid == 0) { uint32_t run = 0; for (int b = 0; b < 64; ++b) { cursor[b] = run; run += hist[b]; } *a.n_jobs = run; }
   __syncthreads();
-  for (uint32_t i = (uint32_t)tid; i < a.n; i += 1024) {
-    const uint32_t v = i < HMM_RESOLVE_LDS ? verdict[i] : probe(i);
+  for (uint32_t i = (uint32_t)tid; i < n_round; i += 1024) {
+    const uint32_t v = i < a.n ? (i < HMM_RESOLVE_LDS ? verdict[i] : probe(i)) : 0u;
+    uint32_t rank, count, leader;
+    const uint32_t bin = v ? bin_of(v - 1u) : 0u;
+    wave_bins(v != 0u, bin, rank, count, leader);
+    uint32_t base = 0;
+    if (v && rank == 0u) base = atomicAdd(&cursor[bin], count);
+    base = (uint32_t)__shfl((int)base, (int)leader);  // (the first lane of a bin's group holds its base; lanes without a job read lane 0)
     if (!v) continue;
     HmmJobDev jd = a.cand[i];
     jd.seq_len = v - 1u;
-    a.jobs[atomicAdd(&cursor[bin_of(v - 1u)], 1u)] = jd;
+    a.jobs[base + rank] = jd;
   }
 }
 
