@@ -11,6 +11,8 @@ base = [B[rng.integers(0, 4, L)].tobytes() for _ in range(n)]
 def sub(s):
     b = bytearray(s); p = L // 2; b[p] = ord("A") if b[p] != ord("A") else ord("C"); return bytes(b)
 ctx = _lib.Context(0)
+if len(sys.argv) > 3:  # workspace limit in GB: fewer resident workgroups (ws_limit / workspace per workgroup)
+    ctx.check(_lib.lib().trgt_hip_set_workspace_limit(ctx.handle, int(float(sys.argv[3]) * (1 << 30))))
 al = W.WFAligner.builder(W.AlignmentScope.Alignment, W.MemoryModel.MemoryUltraLow).affine(2, 5, 1).build(ctx)
 for name, txt in (("identical", base), ("one substitution", [sub(s) for s in base]), ("one deleted base", [s[:L // 3] + s[L // 3 + 1:] for s in base])):
     for rep in range(2):

@@ -604,7 +604,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   a.retry_jobs = nullptr; a.retry_count = nullptr;
   const uint64_t seq_need = ((uint64_t)mp + 15) / 16 * 16 + (uint64_t)mt + 16;
   a.lds_seq_cap = (uint32_t)((std::min<uint64_t>(seq_need, 32 * 1024) + 15) & ~15ull);
-  if (seq_need > 32 * 1024) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
+  if (seq_need > 32 * 1024 || c->knobs.wfa_no_stage) a.lds_seq_cap = 0;  // too long: extend straight from global memory (L1/L2 cached)
   size_t lds = a.lds_seq_cap;
   a.fast_wcap = 0; a.fast_ring_bytes = 0; a.fast_koff = 0;
   a.fast_dbg = c->knobs.skip_bt ? 1 : 0;
@@ -712,6 +712,15 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     const double tot = (double)(h[0] + h[1] + h[2] + h[3]) + 1e-9;
     fprintf(stderr, "[wfa gprof] jobs=%lld grid=%lld thr=%d | claim+stage %.1f%% breakpoint %.1f%% base %.1f%% other %.1f%% | Mcycles total %.1f\n",
             (long long)L.n_jobs_host, (long long)grid_blocks, threads, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, tot / 1e6);
+    unsigned long long e[16], ze[16] = {0};
+    TRGT_HIP_TRY(c, hipMemcpyFromSymbol(e, HIP_SYMBOL(wfa::g_wfa_eprof), sizeof e));
+    TRGT_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(wfa::g_wfa_eprof), ze, sizeof e));
+    const double lv = (double)e[10] + 1e-9;
+    fprintf(stderr, "[wfa eprof] levels %llu (%.1f per job) | cycles per level: fetch %.0f alloc %.0f strips %.0f close %.0f post %.0f heuristic %.0f | per job: init %.0f extend_only %.0f\n",
+            e[10], lv / (double)std::max<int64_t>(1, L.n_jobs_host), e[0] / lv, e[1] / lv, e[2] / lv, e[3] / lv, e[4] / lv, e[5] / lv,
+            (double)e[7] / (double)std::max<int64_t>(1, L.n_jobs_host), (double)e[8] / (double)std::max<int64_t>(1, L.n_jobs_host));
+    fprintf(stderr, "[wfa eprof] inside the strips, cycles per level: loads + recurrences %.0f, extension %.0f, termination / antidiagonal atomics %.0f, stores + range reductions %.0f\n",
+            e[11] / lv, e[12] / lv, e[13] / lv, e[14] / lv);
   }
   if (a.fast_wcap > 0) {
     unsigned long long h[32], lv[32], z[32] = {0};

@@ -101,6 +101,19 @@ __shared__ Shared g_sh;
 // sequences are addressed as offsets into this array, so that the compiler emits LDS instructions (a pointer kept in the Inst record
 // would make every access a flat one); without it they are the HBM workspace pointers of the Inst record.
 extern __shared__ unsigned char lds_dyn[];
+#ifdef TRGT_WFA_PROF
+// engine profile (make PROF=1): thread-0 clocks per section of a score level -- [0] fetch of the source descriptors, [1] thread 0's
+// allocation / descriptor block, [2] strips (loads, recurrences, extension, stores, range reductions), [3] closing descriptors,
+// [4] post_extend, [5] heuristic cut-off, [6] bialign overlap, [7] init, [8] extend_only, [9] back-trace, [10] levels counted
+__device__ unsigned long long g_wfa_eprof[16];
+#define EP_DECL unsigned long long ep_t = clock64()
+#define EP_MARK(i) do { const unsigned long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_wfa_eprof[i], n_ - ep_t); ep_t = n_; } while (0)
+#define EP_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_wfa_eprof[i], 1ull); } while (0)
+#else
+#define EP_DECL
+#define EP_MARK(i)
+#define EP_COUNT(i)
+#endif
 __device__ __forceinline__ WfDesc& ring_at(int ii, int s, int c) {
   return reinterpret_cast<WfDesc*>(lds_dyn + sh.ring_off)[((uint32_t)ii * (sh.ring_mask + 1u) + ((uint32_t)s & sh.ring_mask)) * 5u + (uint32_t)c];
 }
@@ -176,45 +189,66 @@ __device__ __forceinline__ void red_reset(Red& r) {
   r.bp_k = INT32_MAX; r.oom = 0;
 }
 
-// Extend one M cell (wavefront_extend_matches_packed_*), update termination / antidiagonal reductions.
+// Extension of the M cells of a wave (wavefront_extend_matches_packed_*), in uniform control flow: `on` = this lane has a cell at
+// offset `off` on diagonal k.  Every lane first compares eight bases of its own (most cells of a wavefront stop inside them); a cell
+// that matched all eight is almost surely on the diagonal of the alignment itself -- these are alignments of near-identical sequences,
+// a read of an allele against its consensus -- and is finished by the whole wave: lane i compares the eight bases 8 i further on, 512
+// bases per memory round trip (a lane stepping along such a diagonal alone took one dependent round trip per eight bases -- ~1 500
+// cycles each, whether the sequences sit in LDS behind a generic pointer or in global memory -- with the other 63 lanes waiting: most
+// of this kernel's time, tools/biwfa_probe.py).  Reverse sequences (BiWFA's backward fronts) read the eight bytes that END at the
+// position and count equal bytes from the top.  Returns the extended offset (h); same result as a base-by-base walk.
 template <bool LA>
-__device__ __forceinline__ int32_t extend_cell(const Inst& I, Red& red, int k, int32_t off, bool want_ak, int ak) {
-  int v = off - k, h = off;
+__device__ __forceinline__ int32_t extend_wave(const Inst& I, int k, int32_t off, bool on) {
   const int plen = I.plen, tlen = I.tlen, rev = I.rev;
   const uint8_t* pp = pat_of<LA>(I); const uint8_t* tp = txt_of<LA>(I);
-  // Eight bases per step while both sequences have them (the alignments of this kernel are of near-identical sequences -- reads of
-  // an allele against its consensus: one lane runs along a diagonal for hundreds of bases while the others wait for it; a byte per
-  // step, each a dependent load, was most of the kernel's time).  Reverse sequences (BiWFA's backward fronts) read the eight bytes
-  // that END at the position and count equal bytes from the top.
-  if constexpr (!LA) {
-    if (!rev) {
-      while (v + 8 <= plen && h + 8 <= tlen) {
-        uint64_t a, b;
-        __builtin_memcpy(&a, pp + v, 8); __builtin_memcpy(&b, tp + h, 8);
-        const uint64_t x = a ^ b;
-        if (x) { const int n = __builtin_ctzll(x) >> 3; v += n; h += n; goto extended; }
-        v += 8; h += 8;
-      }
-    } else {
-      while (v + 8 <= plen && h + 8 <= tlen) {
-        uint64_t a, b;
-        __builtin_memcpy(&a, pp + (plen - v - 8), 8); __builtin_memcpy(&b, tp + (tlen - h - 8), 8);
-        const uint64_t x = a ^ b;
-        if (x) { const int n = __builtin_clzll(x) >> 3; v += n; h += n; goto extended; }
-        v += 8; h += 8;
-      }
+  // bases that match from (v, h) on, looking at eight of them at most (fewer at the end of a sequence)
+  auto chunk = [&](int v, int h) -> int {
+    const int rem = min(plen - v, tlen - h);
+    if (rem >= 8) {
+      uint64_t a, b;
+      if (!rev) { __builtin_memcpy(&a, pp + v, 8); __builtin_memcpy(&b, tp + h, 8); }
+      else { __builtin_memcpy(&a, pp + (plen - v - 8), 8); __builtin_memcpy(&b, tp + (tlen - h - 8), 8); }
+      const uint64_t x = a ^ b;
+      if (!x) return 8;
+      return (!rev ? __builtin_ctzll(x) : __builtin_clzll(x)) >> 3;
     }
+    int n = 0;
+    while (n < rem && seq_at(pp, plen, rev, v + n) == seq_at(tp, tlen, rev, h + n)) ++n;
+    return n;  // (< 8: the run ends here, by a mismatch or with the sequence)
+  };
+  int v = on ? off - k : 0, h = on ? off : 0;
+  bool going = false;
+  if (on) { const int n = chunk(v, h); v += n; h += n; going = n == 8; }
+  unsigned long long m = __ballot(going);
+  const int lane = (int)(threadIdx.x & 63u);
+  while (m) {
+    const int j = (int)__builtin_ctzll(m);
+    m &= m - 1ull;
+    int vj = __builtin_amdgcn_readlane(v, j), hj = __builtin_amdgcn_readlane(h, j);
+    for (;;) {
+      const int n = chunk(vj + 8 * lane, hj + 8 * lane);  // (beyond either sequence: rem <= 0, nothing matches)
+      const unsigned long long stop = __ballot(n < 8);
+      if (stop) {
+        const int js = (int)__builtin_ctzll(stop);
+        const int ext = 8 * js + __builtin_amdgcn_readlane(n, js);
+        vj += ext; hj += ext;
+        break;
+      }
+      vj += 512; hj += 512;
+    }
+    if (lane == j) { v = vj; h = hj; }
   }
-  while (v < plen && h < tlen && seq_at(pp, plen, rev, v) == seq_at(tp, tlen, rev, h)) { ++v; ++h; }
-extended:
-  off = h;
+  return h;
+}
+// ... and what the wavefront's reductions take from an extended cell (termination, end cell, antidiagonal)
+__device__ __forceinline__ void extended_cell(const Inst& I, Red& red, int k, int32_t off, bool want_ak, int ak) {
   if (I.span == 1) {  // wavefront_termination_endsfree
-    if ((h >= tlen && plen - v <= I.pef) || (v >= plen && tlen - h <= I.tef))
+    const int h = off, v = off - k;
+    if ((h >= I.tlen && I.plen - v <= I.pef) || (v >= I.plen && I.tlen - h <= I.tef))
       atomicMin(&red.term_key, ((unsigned long long)(unsigned)(k + KBIAS) << 32) | (unsigned)off);
   }
   if (k == ak && I.ce == CM) red.end_val = off;
   if (want_ak) atomicMax(&red.max_ak, 2 * off - k);
-  return off;
 }
 
 // thread 0: publish a finished descriptor (LDS mirror + global history)
@@ -245,6 +279,7 @@ __device__ __noinline__ void wf_init(int ii) {
   Inst& I = sh.inst[ii];
   int32_t* const AR = arena_of<LA>(I);
   const int tid = threadIdx.x, T = blockDim.x;
+  EP_DECL;
   __syncthreads();
   if (tid == 0) {
     I.num_null_steps = 0; I.status = ST_OK; I.end_score = -1; I.steps_wait = kp.h_steps; I.bump = 0; I.cur = 0;
@@ -272,6 +307,7 @@ __device__ __noinline__ void wf_init(int ii) {
     for (int k = d.lo + tid; k <= d.hi; k += T) AR[d.base + (uint32_t)(k - d.lo_alloc)] = k > 0 ? k : 0;
   }
   __syncthreads();
+  EP_MARK(7);
 }
 
 // Extension of an existing M wavefront (score 0).  All threads.
@@ -281,15 +317,20 @@ __device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
   int32_t* const AR = arena_of<LA>(I);
   const int tid = threadIdx.x, T = blockDim.x;
   const WfDesc d = fetch_raw(ii, CM, s);
+  EP_DECL;
   if (tid == 0) red_reset(sh.red);
   __syncthreads();
   if (d.base != NOBASE) {
     const int ak = I.tlen - I.plen;
-    for (int k = d.lo + tid; k <= d.hi; k += T) {
-      int32_t off = AR[d.base + (uint32_t)(k - d.lo_alloc)];
-      if (off < 0) continue;
-      off = extend_cell<LA>(I, sh.red, k, off, want_ak, ak);
-      AR[d.base + (uint32_t)(k - d.lo_alloc)] = off;
+    for (int kb = d.lo; kb <= d.hi; kb += T) {  // (whole waves: the extension is a wave's joint work)
+      const int k = kb + tid;
+      int32_t off = k <= d.hi ? AR[d.base + (uint32_t)(k - d.lo_alloc)] : OFF_NULL;
+      const bool on = off >= 0;
+      off = extend_wave<LA>(I, k, off, on);
+      if (on) {
+        extended_cell(I, sh.red, k, off, want_ak, ak);
+        AR[d.base + (uint32_t)(k - d.lo_alloc)] = off;
+      }
     }
     if (I.ce != CM && tid == 0) {  // end component other than M at score 0: its single cell
       const WfDesc e = fetch_raw(ii, I.ce, s);
@@ -297,6 +338,7 @@ __device__ __noinline__ void wf_extend_only(int ii, int s, bool want_ak) {
     }
   }
   __syncthreads();
+  EP_MARK(8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,6 +354,8 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int plen = I.plen, tlen = I.tlen, ak = tlen - plen;
   constexpr int NCOMP = METRIC <= M_LINEAR ? 1 : (METRIC == M_AFFINE ? 3 : 5);
+  EP_DECL;
+  EP_COUNT(10);
   // ---- inputs (uniform)
   WfDesc m_mis = null_desc(), m_o1 = null_desc(), m_o2 = null_desc(), i1e = null_desc(), d1e = null_desc(), i2e = null_desc(), d2e = null_desc();
   int lo, hi;
@@ -338,6 +382,7 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
     }
   }
   __syncthreads();  // everyone has read the ring before thread 0 overwrites the slot of score s
+  EP_MARK(0);
   if (all_null) {  // wavefront_compute_allocate_output_null
     if (tid == 0) {
       I.num_null_steps += 1;
@@ -368,6 +413,7 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
     sh.cells += (unsigned long long)(width > 0 ? width : 0) * NCOMP;
   }
   __syncthreads();
+  EP_MARK(1);
   if (red.oom) { if (tid == 0) { I.status = ST_OOM; I.cur = s; } __syncthreads(); return; }
   const uint32_t bM = ring_at(ii, s, CM).base;
   const uint32_t bI1 = ring_at(ii, s, CI1).base, bD1 = ring_at(ii, s, CD1).base;
@@ -404,7 +450,16 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
         if (METRIC == M_AFFINE2P) { A[bI2 + idx] = ins2; A[bD2 + idx] = del2; }
       }
       if (!in_bounds(mx, k, plen, tlen)) mx = OFF_NULL;  // "adjust offset out of boundaries"
-      if (mx >= 0) mx = extend_cell<LA>(I, red, k, mx, want_ak, ak);
+    }
+    EP_MARK(11);
+    {
+      const bool on = act && mx >= 0;
+      const int32_t ext = extend_wave<LA>(I, k, mx, on);
+      EP_MARK(12);
+      if (on) { mx = ext; extended_cell(I, red, k, mx, want_ak, ak); }
+    }
+    EP_MARK(13);
+    if (act) {
       A[bM + idx] = mx;
       if (NCOMP >= 3 && k == ak && I.ce != CM)
         red.end_val = I.ce == CI1 ? ins1 : I.ce == CD1 ? del1 : I.ce == CI2 ? ins2 : del2;
@@ -419,8 +474,10 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
       red_range(act && in_bounds(ins2, k, plen, tlen), k, &red.lo[CI2], &red.hi[CI2]);
       red_range(act && in_bounds(del2, k, plen, tlen), k, &red.lo[CD2], &red.hi[CD2]);
     }
+    EP_MARK(14);
   }
   __syncthreads();
+  EP_MARK(2);
   if (tid == 0) {
     auto fin = [&](int c, bool exists) {
       WfDesc d = ring_at(ii, s, c);
@@ -436,6 +493,7 @@ __device__ __noinline__ void wf_compute_extend(int ii, int s, bool want_ak) {
     I.cur = s;
   }
   __syncthreads();
+  EP_MARK(3);
 }
 
 // wf_distance_end2end / _endsfree for the wfadaptive cut-off
@@ -455,6 +513,7 @@ __device__ __noinline__ void wf_heuristic_cutoff(int ii, int s) {
   const int tid = threadIdx.x, T = blockDim.x;
   const WfDesc m = fetch_raw(ii, CM, s);
   if (m.base == NOBASE || m.lo > m.hi) return;  // uniform
+  EP_DECL;
   __syncthreads();
   if (tid == 0) { I.steps_wait -= 1; red.min_dist = max(I.plen, I.tlen); red.cand_lo = INT32_MAX; red.cand_hi = INT32_MIN; }
   __syncthreads();
@@ -508,6 +567,7 @@ __device__ __noinline__ void wf_heuristic_cutoff(int ii, int s) {
     }
   }
   __syncthreads();
+  EP_MARK(5);
 }
 
 // Post-extension part of wavefront_extend_{end2end,end2end_max,endsfree}.  All threads; returns 1 when done.
@@ -517,6 +577,7 @@ __device__ __noinline__ int wf_post_extend(int ii, int s, bool act_on_end, int* 
   Inst& I = sh.inst[ii];
   Red& red = sh.red;
   const int tid = threadIdx.x;
+  EP_DECL;
   __syncthreads();
   if (tid == 0) {
     int done = 0, cont_heur = 0;
@@ -552,6 +613,7 @@ __device__ __noinline__ int wf_post_extend(int ii, int s, bool act_on_end, int* 
   __syncthreads();
   const int f = red.flag;
   const int mak = red.max_ak;
+  EP_MARK(4);
   if (f & 2) wf_heuristic_cutoff<LA>(ii, s);
   if (max_ak) *max_ak = (f & 1) ? 0 : mak;
   return f & 1;
