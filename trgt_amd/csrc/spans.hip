@@ -23,6 +23,21 @@
 
 namespace trgt {
 
+// The counter block of a find_spans call (16 words in HBM, cleared in front of the scan): list lengths and tallies shared by its kernels.
+enum SpanCount : int {
+  SC_HEAVY = 0,     // expensive fallback alignments: the front of the two-ended job list
+  SC_LONG = 1,      // reads beyond the dedicated kernels' texts (second list)
+  SC_LIGHT = 2,     // the other fallback alignments: the back of the two-ended list
+  SC_ZERO = 3,      // stays 0 (the "front" count of a launch that takes the back of the list only)
+  SC_WIN = 4,       // alignments on a seeded window
+  SC_REST = 5,      // alignments against the whole read (no window, or a window that did not stand)
+  SC_KEEP = 6,      // what the pre-filter keeps for the back-tracing launch
+  SC_SHORTCUT = 7,  // alignments settled by the substitution / one-base-gap shortcuts
+  SC_NOSEED = 8,    // expensive alignments without seeds inside the read: the pre-filter's list
+  SC_GAPS = 9,      // of SC_SHORTCUT: one-base gaps
+  SC_WORDS = 16
+};
+
 struct ScanArgs {
   const uint8_t* flank_blob; const uint8_t* read_blob;
   const uint64_t* piece_off;   // [2 * n_loci] left piece, right piece (offsets into flank_blob)
@@ -82,7 +97,7 @@ __global__ void __launch_bounds__(256) flank_scan_kernel(const ScanArgs a) {
     a.pos[j] = found; a.n_match[j] = -1;
     if (found < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
       const bool lng = (uint32_t)n > a.long_tlen;
-      const uint32_t slot = atomicAdd(a.wfa_count + (lng ? 1 : 0), 1u);
+      const uint32_t slot = atomicAdd(a.wfa_count + (lng ? SC_LONG : SC_HEAVY), 1u);
       JobDev jd;
       jd.pat_off = a.piece_off[2 * (uint64_t)a.read_locus[r] + side]; jd.txt_off = a.read_off[r];
       jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
@@ -202,7 +217,7 @@ template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
   __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns, l_ni;
-  const uint32_t n_light = a.count[a.front ? 0 : 2];  // (the length of the list this launch walks)
+  const uint32_t n_light = a.count[a.front ? SC_HEAVY : SC_LIGHT];  // (the length of the list this launch walks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // jobs per workgroup and round: 64, fewer when the list is short (a job is a dependent chain of loads: 17 k jobs in rounds of 64 kept
   // 270 workgroups busy for 0.39 ms; spread over all of them they take a fifth of that)
@@ -318,10 +333,10 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + 4, l_nw);
-    if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + (a.front ? 8 : 5), l_nr);
-    if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + 7, l_ns);
-    if (threadIdx.x == 192 && l_ni) atomicAdd(a.count + 9, l_ni);  // (of those: one-base gaps)
+    if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + SC_WIN, l_nw);
+    if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + (a.front ? SC_NOSEED : SC_REST), l_nr);
+    if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + SC_SHORTCUT, l_ns);
+    if (threadIdx.x == 192 && l_ni) atomicAdd(a.count + SC_GAPS, l_ni);  // (of those: one-base gaps)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
     for (uint32_t i = threadIdx.x; i < l_nr; i += blockDim.x) a.rest_jobs[l_br + i] = l_out[WIN_JOBS_PER_WG - 1 - i];
@@ -421,7 +436,7 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
         JobDev jd;
         jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
         jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
-        if ((uint32_t)n > a.long_tlen) a.wfa_jobs_long[atomicAdd(a.wfa_count + 1, 1u)] = jd;  // rare: straight to the second list
+        if ((uint32_t)n > a.long_tlen) a.wfa_jobs_long[atomicAdd(a.wfa_count + SC_LONG, 1u)] = jd;  // rare: straight to the second list
         else if (!a.heavy_len || (uint32_t)n < a.heavy_len[a.read_locus[r]]) l_jobs[atomicAdd(&l_n, 1u)] = jd;
         else l_jobs[2 * SCAN_READS_PER_WG - 1 - atomicAdd(&l_n2, 1u)] = jd;
       }
@@ -429,8 +444,8 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
   }
   }  // reads of this workgroup
   __syncthreads();
-  if (threadIdx.x == 0 && l_n) l_base = atomicAdd(a.wfa_count, l_n);
-  if (threadIdx.x == 64 && l_n2) l_base2 = atomicAdd(a.wfa_count + 2, l_n2);
+  if (threadIdx.x == 0 && l_n) l_base = atomicAdd(a.wfa_count + SC_HEAVY, l_n);
+  if (threadIdx.x == 64 && l_n2) l_base2 = atomicAdd(a.wfa_count + SC_LIGHT, l_n2);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < l_n; i += blockDim.x) a.wfa_jobs[l_base + i] = l_jobs[i];
   for (uint32_t i = threadIdx.x; i < l_n2; i += blockDim.x) a.wfa_jobs[a.jobs_cap - 1u - (l_base2 + i)] = l_jobs[2 * SCAN_READS_PER_WG - 1 - i];
@@ -453,7 +468,7 @@ __global__ void window_check_kernel(const WinCheckArgs a) {
     } else {
       a.n_match[j] = -1;
       jd.txt_off = a.read_off[j >> 1]; jd.txt_len = a.read_len[j >> 1]; jd.pad = 0;
-      a.wfa_jobs[atomicAdd(a.wfa_count + 5, 1u)] = jd;  // (wfa_jobs: the rest list here)
+      a.wfa_jobs[atomicAdd(a.wfa_count + SC_REST, 1u)] = jd;  // (wfa_jobs: the rest list here)
     }
   }
 }
@@ -467,7 +482,7 @@ struct CombineArgs {
 
 __global__ void span_combine_kernel(const CombineArgs a) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0 && a.cells) a.cells[2] = a.count[7];
+  if (r == 0 && a.cells) a.cells[2] = a.count[SC_SHORTCUT];
   if (r >= a.n_reads) return;
   int s[2], e[2], hit[2];
   for (int side = 0; side < 2; ++side) {
@@ -544,10 +559,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
   if ((rc = dev_get(c, S_FS_POS, n_jobs * 4, &d_pos)) || (rc = dev_get(c, S_FS_WFAJOBS, n_jobs * sizeof(JobDev), &d_wjobs)) ||
-      (rc = dev_get(c, S_FS_COUNT, 64, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
+      (rc = dev_get(c, S_FS_COUNT, 4 * SC_WORDS, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
       (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 4 * SC_WORDS, c->stream));
   ScanArgs sa;
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
   sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos; sa.n_match = (int32_t*)d_nmatch;
@@ -602,7 +617,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   c->last_wfa_cells_dev = nullptr;
   WfaLaunch L;
   L.jobs_dev = (const JobDev*)d_wjobs; L.n_jobs_host = (int64_t)n_jobs; L.n_jobs_dev = (const uint32_t*)d_count;
-  L.n_jobs2_dev = (const uint32_t*)d_count + 2; L.jobs_cap = (uint32_t)n_jobs;
+  L.n_jobs2_dev = (const uint32_t*)d_count + SC_LIGHT; L.jobs_cap = (uint32_t)n_jobs;
   L.pat_base = d_flank; L.txt_base = d_reads;
   const uint32_t short_max = has_long ? long_tlen : max_read_len;
   L.max_plen = p.flank_len; L.max_tlen = short_max; L.max_sum = (int64_t)p.flank_len + short_max;
@@ -690,11 +705,11 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if ((rc = dev_get(c, S_FS_KEEPJOBS, n_jobs * sizeof(JobDev), &d_keepjobs))) return rc;
       FilterLaunch FL;
       FL.jobs_dev = heavy_window ? (const JobDev*)d_noseed : (const JobDev*)d_wjobs; FL.n_jobs_host = (int64_t)n_jobs;
-      FL.n_jobs_dev = heavy_window ? (const uint32_t*)d_count + 8 : (const uint32_t*)d_count;
+      FL.n_jobs_dev = (const uint32_t*)d_count + (heavy_window ? SC_NOSEED : SC_HEAVY);
       FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
-      FL.mism = p.mism; FL.gapo = p.gapo; FL.gape = p.gape; FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + 6;
+      FL.mism = p.mism; FL.gapo = p.gapo; FL.gape = p.gape; FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + SC_KEEP;
       if ((rc = flank_filter_launch(c, FL))) return rc;
-      LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + 6;
+      LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + SC_KEEP;
     }
     // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
     // wave and level), and a wave without a strip still pays the per-level prologue and barrier (7.39 -> 7.21 ms)
@@ -712,7 +727,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
     }
     heavy_cells_dev = cells_heavy;
-    L.n_jobs_dev = (const uint32_t*)d_count + 3;  // always 0: this launch takes the back part of the list only
+    L.n_jobs_dev = (const uint32_t*)d_count + SC_ZERO;  // always 0: this launch takes the back part of the list only
     L.keep_cells = !two_streams; L.timer_slot = TRGT_K_WFA_FLANK_REST;  // (two streams: the first launch of THIS stream resets the counter of set 0)
     if (win_q > 0) {  // the alignments with a seeded window: short texts, more of them per CU; then sort out which of them stand
       // (the other stream's seed search appends to the same windowed list; this stream's search waits for it rather than running next to
@@ -726,7 +741,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         t.stop(0);
       }
       WfaLaunch LW = L;
-      LW.jobs_dev = (const JobDev*)d_winjobs; LW.n_jobs_dev = (const uint32_t*)d_count + 4; LW.n_jobs2_dev = nullptr; LW.jobs_cap = 0;
+      LW.jobs_dev = (const JobDev*)d_winjobs; LW.n_jobs_dev = (const uint32_t*)d_count + SC_WIN; LW.n_jobs2_dev = nullptr; LW.jobs_cap = 0;
       LW.max_tlen = win_tlen; LW.max_sum = (int64_t)p.flank_len + win_tlen;
       LW.score = (int32_t*)d_score; LW.kernel_tag = 2; LW.max_score = win_s0;
       // only the diagonals that can matter start the alignment: a wavefront of 2 margin + spread + 1 diagonals instead of one per base
@@ -737,20 +752,20 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if ((rc = wfa_launch(c, wpw, LW))) return rc;
       L.keep_cells = true;
       WinCheckArgs wc;
-      wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + 4; wc.score = (const int32_t*)d_score;
+      wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + SC_WIN; wc.score = (const int32_t*)d_score;
       wc.span4 = (uint32_t*)d_span4; wc.n_match = (int32_t*)d_nmatch; wc.s0 = win_s0;
       wc.wfa_jobs = (JobDev*)d_restjobs; wc.wfa_count = (uint32_t*)d_count; wc.jobs_cap = (uint32_t)n_jobs;
       wc.read_off = d_read_off; wc.read_len = d_read_len;
       hipLaunchKernelGGL(window_check_kernel, dim3(256), dim3(256), 0, c->stream, wc);
       TRGT_HIP_TRY(c, hipGetLastError());
-      L.jobs_dev = (const JobDev*)d_restjobs; L.n_jobs_dev = (const uint32_t*)d_count + 5; L.n_jobs2_dev = nullptr; L.jobs_cap = 0;
+      L.jobs_dev = (const JobDev*)d_restjobs; L.n_jobs_dev = (const uint32_t*)d_count + SC_REST; L.n_jobs2_dev = nullptr; L.jobs_cap = 0;
     }
   }
   if ((rc = wfa_launch(c, wp, L))) return rc;
   if (!split) TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
   if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
     WfaLaunch L2 = L;
-    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + 1; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
+    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + SC_LONG; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
     L2.keep_cells = true; L2.timer_slot = TRGT_K_WFA_FLANK_REST;
     // the pre-filter over windows of the long reads (see LongWinArgs): what it rejects never reaches the exact kernel
@@ -776,7 +791,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
             (rc = dev_get(c, S_LW_COUNT, 16, &d_lwc)))
           return rc;
         LongWinArgs lw;
-        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + 1; 
+        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + SC_LONG; 
         lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
         lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
         const dim3 g((unsigned)c->num_cus * 2), b(256);
@@ -816,9 +831,9 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     TRGT_HIP_TRY(c, hipMemcpy(h, d_count, 64, hipMemcpyDeviceToHost));
     if (win_q > 0)
       fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the shortcuts %u (one-base gaps: %u)\n",
-              h[0], h[1], h[2], h[4], h[5], h[2] - h[4] - h[7], h[5] - (h[2] - h[4] - h[7]), h[7], h[9]);
-    if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[8], h[0]);
-    else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[0], h[1], h[2]);
+              h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT], h[SC_WIN], h[SC_REST], h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT], h[SC_REST] - (h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT]), h[SC_SHORTCUT], h[SC_GAPS]);
+    if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[SC_NOSEED], h[SC_HEAVY]);
+    else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT]);
   }
   (void)n_loci;
   return TRGT_OK;

@@ -39,7 +39,7 @@ class IngestBatch(C.Structure):
                 ("owner", C.c_void_p)]
 
 
-def _arr(ptr, n, dtype, copy=True):
+def _array(ptr, n, dtype, copy=True):
     if n <= 0:
         return np.zeros(0, dtype)
     a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(n) * np.dtype(dtype).itemsize,)).view(dtype)
@@ -47,7 +47,7 @@ def _arr(ptr, n, dtype, copy=True):
 
 
 def _strings(blob, off, n):
-    o = _arr(off, n + 1, np.uint64)
+    o = _array(off, n + 1, np.uint64)
     raw = C.string_at(blob, int(o[-1])) if n and int(o[-1]) else b""
     return [raw[int(o[i]):int(o[i + 1])].decode() for i in range(n)]
 
@@ -110,7 +110,8 @@ class Reader:
         read names out (one Python string per read)."""
         if not copy and not keep_native:
             raise ValueError("copy=False needs keep_native=True (the views point into the native batch)")
-        _arr = lambda ptr, n, dtype: globals()["_arr"](ptr, n, dtype, copy)  # noqa: E731
+        def _arr(ptr, n, dtype):  # (copies, or views of the native batch's memory)
+            return _array(ptr, n, dtype, copy)
         p = IngestParams()
         self._L.trgt_ingest_default_params(C.byref(p))
         for k, v in params.items():
