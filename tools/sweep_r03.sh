@@ -18,4 +18,5 @@ echo "== fuzzers" >> $O
 python tests/tools/hmm_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/wfa_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/window_fuzz.py 2>&1 | grep RESULT >> $O
+python tests/tools/shortcut_fuzz.py 4000 $((30*SC)) 1 2>&1 | grep RESULT >> $O
 cat $O
