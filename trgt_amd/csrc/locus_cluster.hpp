@@ -178,7 +178,9 @@ struct ClusterBatch {
     const int rc = trgt_wfa_batch(c, &wp, (int64_t)refs.size(), blob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr,
                                   score.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    for (size_t j = 0; j < refs.size(); ++j) *refs[j].dst = std::sqrt((double)score[j]);  // aligner.score() as f64, then sqrt
+    pool->parallel_for((int64_t)((refs.size() + 4095) / 4096), 1, [&](int64_t blk, int) {  // aligner.score() as f64, then sqrt
+      for (size_t j = (size_t)blk * 4096, e = std::min(refs.size(), j + 4096); j < e; ++j) *refs[j].dst = std::sqrt((double)score[j]);
+    });
     n_ed += (int64_t)refs.size();
     return TRGT_OK;
   }
@@ -221,19 +223,49 @@ struct ClusterBatch {
     const int64_t tl0 = now_ns_cluster();
 #define CTL(name) do { if (tl_on) fprintf(stderr, "[tl]   cluster %-22s +%7.2f ms\n", name, (double)(now_ns_cluster() - tl0) / 1e6); } while (0)
     // the batch blob: all segments once
-    for (auto& L : loci) {
-      L.blob_off = blob.size(); L.seg_off.resize((size_t)L.n);
-      for (int i = 0; i < L.n; ++i) { L.seg_off[(size_t)i] = blob.size() - L.blob_off; blob.insert(blob.end(), L.trs[i].p, L.trs[i].p + L.trs[i].n); }
+    {
+      uint64_t total = 0;
+      for (auto& L : loci) {
+        L.blob_off = total; L.seg_off.resize((size_t)L.n);
+        for (int i = 0; i < L.n; ++i) { L.seg_off[(size_t)i] = total - L.blob_off; total += L.trs[i].n; }
+      }
+      blob.resize((size_t)total);
+      pool->parallel_for((int64_t)loci.size(), 32, [&](int64_t k, int) {
+        const ClusterLocus& L = loci[(size_t)k];
+        for (int i = 0; i < L.n; ++i) std::memcpy(blob.data() + L.blob_off + L.seg_off[(size_t)i], L.trs[i].p, L.trs[i].n);
+      });
     }
     CTL("blob built");
     // ---- get_dist_matrix for every locus
     ed_clear();
-    for (auto& L : loci) L.dists.assign((size_t)L.n * (size_t)(L.n - 1) / 2, 0.0);
-    for (auto& L : loci) {
-      double* d = L.dists.data();
-      for (int i = 0; i < L.n; ++i)
-        for (int j = i + 1; j < L.n; ++j, ++d)
-          ed_add(L.blob_off + L.seg_off[(size_t)i], L.trs[i].n, L.blob_off + L.seg_off[(size_t)j], L.trs[j].n, d);
+    {
+      // the pair list of every locus, written by the host pool into its place in the batch arrays (a 2 000-locus call has 870 k pairs:
+      // one thread pushing them one by one took 2 ms): first the number of alignments per locus -- pairs beyond MAX_OPS take the
+      // length difference (get_dist :238-248) -- then the entries
+      std::vector<uint64_t> first(loci.size() + 1, 0);
+      pool->parallel_for((int64_t)loci.size(), 16, [&](int64_t k, int) {
+        ClusterLocus& L = loci[(size_t)k];
+        L.dists.assign((size_t)L.n * (size_t)(L.n - 1) / 2, 0.0);
+        uint64_t n = 0;
+        for (int i = 0; i < L.n; ++i)
+          for (int j = i + 1; j < L.n; ++j) n += (uint64_t)L.trs[i].n * (uint64_t)L.trs[j].n <= MAX_OPS;
+        first[(size_t)k + 1] = n;
+      });
+      for (size_t k = 0; k < loci.size(); ++k) first[k + 1] += first[k];
+      const size_t total = (size_t)first[loci.size()];
+      poff.resize(total); plen.resize(total); toff.resize(total); tlen.resize(total); refs.resize(total);
+      pool->parallel_for((int64_t)loci.size(), 16, [&](int64_t k, int) {
+        ClusterLocus& L = loci[(size_t)k];
+        double* d = L.dists.data();
+        size_t at = (size_t)first[(size_t)k];
+        for (int i = 0; i < L.n; ++i)
+          for (int j = i + 1; j < L.n; ++j, ++d) {
+            const uint32_t a_len = L.trs[i].n, b_len = L.trs[j].n;
+            if ((uint64_t)a_len * (uint64_t)b_len > MAX_OPS) { *d = std::sqrt((double)(int32_t)(a_len > b_len ? a_len - b_len : b_len - a_len)); continue; }
+            poff[at] = L.blob_off + L.seg_off[(size_t)i]; plen[at] = a_len; toff[at] = L.blob_off + L.seg_off[(size_t)j]; tlen[at] = b_len; refs[at] = EdRef{d};
+            ++at;
+          }
+      });
     }
     CTL("ed jobs built");
     int rc = ed_run();
