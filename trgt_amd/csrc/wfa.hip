@@ -288,7 +288,16 @@ __device__ unsigned long long g_wfa_gprof[8];  // generic kernel, thread 0: clai
 // the buffers hold, sequences beyond the staging area -- is appended to the retry list and redone by the HBM variant (launched right
 // behind over that list): the same code on the same inputs, so the results do not depend on where an alignment ran.
 template <int METRIC, bool LA>
-__global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) {
+__device__ __forceinline__ void wfa_kernel_body(const KArgs& a);
+template <int METRIC, bool LA>
+__global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) { wfa_kernel_body<METRIC, LA>(a); }
+// One wave per alignment (consensus alignments, edit distances: every batch of the locus path but the flank location): the same body
+// compiled for 128 VGPRs, i.e. four waves per SIMD instead of three.  The kernel waits on dependent memory round trips most of the
+// time: resident waves are what its throughput is made of.
+template <int METRIC>
+__global__ void __launch_bounds__(64, 4) wfa_kernel_wave(const KArgs a) { wfa_kernel_body<METRIC, false>(a); }
+template <int METRIC, bool LA>
+__device__ __forceinline__ void wfa_kernel_body(const KArgs& a) {
   const int tid = threadIdx.x, T = blockDim.x;
   {  // the argument block into LDS (what the engine functions read) and the place of the descriptor rings in the dynamic LDS
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&a); uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.args);
@@ -648,7 +657,8 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     a.ring_mask = RING - 1; a.ring_off = (a.lds_seq_cap + 15u) & ~15u;
     lds = (size_t)a.ring_off + 3 * RING * 5 * sizeof(WfDesc);
     if (lds > 48 * 1024)
-      for (const void* fn : {(const void*)wfa_kernel<0, false>, (const void*)wfa_kernel<1, false>, (const void*)wfa_kernel<2, false>, (const void*)wfa_kernel<3, false>, (const void*)wfa_kernel<4, false>})
+      for (const void* fn : {(const void*)wfa_kernel<0, false>, (const void*)wfa_kernel<1, false>, (const void*)wfa_kernel<2, false>, (const void*)wfa_kernel<3, false>, (const void*)wfa_kernel<4, false>,
+                             (const void*)wfa_kernel_wave<1>, (const void*)wfa_kernel_wave<3>})
         TRGT_HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   // ---- BiWFA batches of one wave per alignment (consensus alignments, edit distances): first the LDS-arena variant over the whole list,
@@ -681,6 +691,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     a.jobs = (const JobDev*)d_retry; a.n_jobs_dev = (const uint32_t*)d_counter + 1; a.n_jobs2_dev = nullptr; a.jobs_cap = 0;
     a.counter = (unsigned int*)d_counter + 2;
   }
+  const bool wave_variant = threads == 64 && !c->knobs.wfa_no_wave_variant;  // (edit and gap-affine have one: what the locus path uses)
   if (a.fast_wcap > 0) {
     // every job of this batch qualifies for the dedicated LDS-resident kernel (wfa_fast.hpp)
     if (lds > 48 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)fast_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -688,9 +699,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   } else
   switch (p.metric) {
     case 0: hipLaunchKernelGGL((wfa_kernel<0, false>), grid, block, lds, c->stream, a); break;
-    case 1: hipLaunchKernelGGL((wfa_kernel<1, false>), grid, block, lds, c->stream, a); break;
+    case 1: if (wave_variant) hipLaunchKernelGGL((wfa_kernel_wave<1>), grid, block, lds, c->stream, a); else hipLaunchKernelGGL((wfa_kernel<1, false>), grid, block, lds, c->stream, a); break;
     case 2: hipLaunchKernelGGL((wfa_kernel<2, false>), grid, block, lds, c->stream, a); break;
-    case 3: hipLaunchKernelGGL((wfa_kernel<3, false>), grid, block, lds, c->stream, a); break;
+    case 3: if (wave_variant) hipLaunchKernelGGL((wfa_kernel_wave<3>), grid, block, lds, c->stream, a); else hipLaunchKernelGGL((wfa_kernel<3, false>), grid, block, lds, c->stream, a); break;
     default: hipLaunchKernelGGL((wfa_kernel<4, false>), grid, block, lds, c->stream, a); break;
   }
   { const hipError_t le = hipGetLastError();
