@@ -296,6 +296,8 @@ __global__ void __launch_bounds__(256, 3) wfa_kernel(const KArgs a) { wfa_kernel
 // time: resident waves are what its throughput is made of.
 template <int METRIC>
 __global__ void __launch_bounds__(64, 4) wfa_kernel_wave(const KArgs a) { wfa_kernel_body<METRIC, false>(a); }
+template <int METRIC>
+__global__ void __launch_bounds__(64, 4) wfa_kernel_wave_la(const KArgs a) { wfa_kernel_body<METRIC, true>(a); }
 template <int METRIC, bool LA>
 __device__ __forceinline__ void wfa_kernel_body(const KArgs& a) {
   const int tid = threadIdx.x, T = blockDim.x;
@@ -681,7 +683,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     la.la_gdesc_slots = std::min<uint32_t>(40, (region / 3) / (5 * (uint32_t)sizeof(WfDesc)));
     la.retry_jobs = (JobDev*)d_retry; la.retry_count = (unsigned int*)d_counter + 1;
     const size_t la_lds = (size_t)la.la_region + region;
-    void (*const la_fn)(const KArgs) = p.metric == 1 ? wfa_kernel<1, true> : wfa_kernel<3, true>;
+    void (*const la_fn)(const KArgs) = c->knobs.wfa_no_wave_variant ? (p.metric == 1 ? wfa_kernel<1, true> : wfa_kernel<3, true>) : (p.metric == 1 ? wfa_kernel_wave_la<1> : wfa_kernel_wave_la<3>);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, la_fn, 64, la_lds) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
     const int64_t la_grid = std::max<int64_t>(1, std::min<int64_t>(L.n_jobs_host, (int64_t)c->num_cus * occ));
