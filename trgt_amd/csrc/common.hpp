@@ -40,6 +40,7 @@ struct trgt_knobs {
   bool stage_lock = false;      // TRGT_STAGE_LOCK: only one context per device in its flank-location stage at a time
   bool host_hmm_lists = false;  // TRGT_HOST_HMM_LISTS: stage C job lists built by the host after the genotyper (not resolved on the device)
   bool debug = false;        // TRGT_WFA_DEBUG: launch plans on stderr (synchronises)
+  bool hmm_resolve_one_wg = false;   // TRGT_HMM_RESOLVE_ONE_WG: the stage-C job list by the one-workgroup kernel, class after class
   bool wfa_no_wave_variant = false;  // TRGT_WFA_NO_WAVE_VARIANT: one-wave batches of the generic kernel take the 168-register build (three waves per SIMD)
   bool wfa_no_stage = false;       // TRGT_WFA_NO_STAGE: the generic kernel extends from global memory, sequences are not staged in LDS
   bool filter_side = false;        // TRGT_FILTER_SIDE: ... next to each other in the contexts of a pool too

@@ -899,6 +899,78 @@ __global__ void __launch_bounds__(1024) hmm_resolve_kernel(const HmmResolveArgs 
   }
 }
 
+// The same in two launches of many workgroups, all classes of a call at once (round 3: the one-workgroup kernel above took 0.14 ms per
+// class -- twenty dependent rounds of probes on one CU -- between the genotyper and the HMM of every call).  First launch: verdict per
+// candidate, counts per (class, length bin) through one atomic per wave and key; second launch: every workgroup scans the 8 x 64 counts
+// itself (longest bin first within a class) and reserves the places of its candidates, again one atomic per wave and key.
+struct HmmResolveAllArgs {
+  const HmmJobDev* cand; uint32_t n;        // all candidates, classes back to back
+  uint32_t class_begin[9];                  // class k = candidates [class_begin[k], class_begin[k + 1])
+  const uint8_t* skip_locus; const int32_t* n_alleles; const uint32_t* allele_len;
+  HmmJobDev* jobs; uint32_t* n_jobs;        // job list of class k at jobs + class_begin[k], its length at n_jobs[k]
+  uint32_t* n_spans; double* purity;
+  uint32_t* verdict; uint32_t* hist; uint32_t* taken;  // [n], [512], [512] (hist and taken cleared by the caller)
+  uint32_t len_shift;
+};
+__device__ __forceinline__ void hmm_wave_keys(bool on, uint32_t key, int lane, uint32_t& rank, uint32_t& count, uint32_t& leader) {
+  unsigned long long todo = __ballot(on);
+  rank = 0; count = 0; leader = 0;
+  while (todo) {
+    const int lead = (int)__builtin_ctzll(todo);
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, lead);
+    const unsigned long long same = __ballot(on && key == kk);
+    if (on && key == kk) { rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); count = (uint32_t)__popcll(same); leader = (uint32_t)lead; }
+    todo &= ~same;
+  }
+}
+__device__ __forceinline__ uint32_t hmm_class_of(const HmmResolveAllArgs& a, uint32_t i) {
+  uint32_t k = 0;
+#pragma unroll
+  for (int c = 1; c < 8; ++c) k += i >= a.class_begin[c] ? 1u : 0u;
+  return k;
+}
+__global__ void __launch_bounds__(256) hmm_resolve_count_kernel(const HmmResolveAllArgs a) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63u);
+  uint32_t v = 0, key = 0;
+  if (i < a.n) {
+    const uint32_t slot = a.cand[i].job_index, l = slot >> 1, al = slot & 1u;
+    const bool on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
+    if (!on) { a.n_spans[slot] = 0; a.purity[slot] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
+    v = on ? a.allele_len[slot] + 1u : 0u;
+    a.verdict[i] = v;
+    if (v) { const uint32_t b = (v - 1u) >> a.len_shift; key = hmm_class_of(a, i) * 64u + (63u - (b < 63u ? b : 63u)); }
+  }
+  uint32_t rank, count, leader;
+  hmm_wave_keys(v != 0u, key, lane, rank, count, leader);
+  if (v && rank == 0u) atomicAdd(&a.hist[key], count);
+}
+__global__ void __launch_bounds__(256) hmm_resolve_scatter_kernel(const HmmResolveAllArgs a) {
+  __shared__ uint32_t base[512];
+  for (uint32_t t = threadIdx.x; t < 512; t += 256) base[t] = a.hist[t];
+  __syncthreads();
+  if (threadIdx.x < 8) {  // exclusive scan of a class's bins, bin 0 (the longest alleles) first
+    uint32_t run = 0;
+    for (int b = 0; b < 64; ++b) { const uint32_t h = base[threadIdx.x * 64 + b]; base[threadIdx.x * 64 + b] = run; run += h; }
+    if (blockIdx.x == 0) a.n_jobs[threadIdx.x] = run;
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t v = i < a.n ? a.verdict[i] : 0u;
+  uint32_t key = 0, k = 0;
+  if (v) { k = hmm_class_of(a, i); const uint32_t b = (v - 1u) >> a.len_shift; key = k * 64u + (63u - (b < 63u ? b : 63u)); }
+  uint32_t rank, count, leader;
+  hmm_wave_keys(v != 0u, key, lane, rank, count, leader);
+  uint32_t at = 0;
+  if (v && rank == 0u) at = atomicAdd(&a.taken[key], count);
+  at = (uint32_t)__shfl((int)at, (int)leader);
+  if (!v) return;
+  HmmJobDev jd = a.cand[i];
+  jd.seq_len = v - 1u;
+  a.jobs[a.class_begin[k] + base[key] + at + rank] = jd;
+}
+
 // Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
 __global__ void hmm_pack_spans_kernel(const int32_t* __restrict__ spans3, const uint64_t* __restrict__ job_span_off,
                                       const uint32_t* __restrict__ n_spans, const uint64_t* __restrict__ packed_off,
@@ -1408,7 +1480,8 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
   void *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
   const size_t jobs_bytes = (size_t)n_cand * sizeof(HmmJobDev);
-  if ((rc = dev_get(c, S_HMM_JOBS + so, 2 * jobs_bytes + 64, &d_jobs)) || (rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp)) ||
+  // (S_HMM_JOBS: candidates | job lists | 8 counts | 512 + 512 resolve counters | verdicts)
+  if ((rc = dev_get(c, S_HMM_JOBS + so, 2 * jobs_bytes + 64 + 4096 + 4 * (size_t)n_cand, &d_jobs)) || (rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp)) ||
       (rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits)))
     return rc;
   HmmJobDev* const d_cand = (HmmJobDev*)d_jobs;
@@ -1441,10 +1514,24 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   while ((max_cap >> len_shift) >= 64) ++len_shift;
   // slots that are no candidates at all (loci left to the host path) hold "no allele" too
   TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
-  for (int k = 0; k < 8; ++k) {
-    if (!class_n[k]) continue;
-    HmmResolveArgs ra{d_cand + class_begin[k], class_n[k], in.d_skip, in.d_n_alleles, in.d_allele_len, d_list + class_begin[k], d_count + k, o_nsp.dev, o_pur.dev, len_shift};
-    hipLaunchKernelGGL(hmm_resolve_kernel, dim3(1), dim3(1024), 0, c->stream, ra);
+  if (c->knobs.hmm_resolve_one_wg) {
+    for (int k = 0; k < 8; ++k) {
+      if (!class_n[k]) continue;
+      HmmResolveArgs ra{d_cand + class_begin[k], class_n[k], in.d_skip, in.d_n_alleles, in.d_allele_len, d_list + class_begin[k], d_count + k, o_nsp.dev, o_pur.dev, len_shift};
+      hipLaunchKernelGGL(hmm_resolve_kernel, dim3(1), dim3(1024), 0, c->stream, ra);
+    }
+  } else {
+    HmmResolveAllArgs ra;
+    ra.cand = d_cand; ra.n = (uint32_t)n_cand;
+    for (int k = 0; k < 8; ++k) ra.class_begin[k] = (uint32_t)class_begin[k];
+    ra.class_begin[8] = (uint32_t)n_cand;
+    ra.skip_locus = in.d_skip; ra.n_alleles = in.d_n_alleles; ra.allele_len = in.d_allele_len;
+    ra.jobs = d_list; ra.n_jobs = d_count; ra.n_spans = o_nsp.dev; ra.purity = o_pur.dev;
+    ra.hist = d_count + 16; ra.taken = ra.hist + 512; ra.verdict = ra.taken + 512; ra.len_shift = len_shift;
+    TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64 + 4096, c->stream));
+    const dim3 rg((unsigned)((n_cand + 255) / 256));
+    hipLaunchKernelGGL(hmm_resolve_count_kernel, rg, dim3(256), 0, c->stream, ra);
+    hipLaunchKernelGGL(hmm_resolve_scatter_kernel, rg, dim3(256), 0, c->stream, ra);
   }
   TRGT_HIP_TRY(c, hipGetLastError());
   if (!c->hmm_fork[buffer_set ? 1 : 0]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork[buffer_set ? 1 : 0], hipEventDisableTiming));
