@@ -105,7 +105,7 @@ def cpu_baseline_mt(batch, threads):
     t0 = time.perf_counter()
     done, _ = orc.locus_analyze_many(batch, 0, n, threads)
     dt = time.perf_counter() - t0
-    return dict(value=round(done / dt, 2), unit="loci/s", cores=threads, kind="port",
+    return dict(value=round(done / dt, 2), unit="loci/s", cores=threads, kind="port", cpu_quota=cpu_quota(),  # (threads share the quota when there is one)
                 sample="all %d loci of the same synthetic batch, oracle/liboracle.so, %d native threads pulling chunks of loci from a shared counter, %.1f s" % (done, threads, dt))
 
 
@@ -124,6 +124,25 @@ def copy_peak_gbs(torch, nbytes=1 << 30, reps=8):
     ms = e0.elapsed_time(e1)
     del a, b
     return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
+
+
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's CFS quota (cpu.max: "quota period" or "max") when there is one, else None.  On the
+    MI355X boxes of this pool os.cpu_count() is 256 and the quota 16: every host-side rate of this file (CPU baseline on "all cores",
+    ingestion, writer) is a rate under that quota, and thread counts beyond ~2x the quota only add scheduling."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    return round(int(t[0]) / int(t[1]), 2)
+            else:
+                q = int(t[0])
+                if q > 0:
+                    return round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
 
 
 def parse_args():
@@ -213,7 +232,7 @@ def run_e2e(args, env):
         t_gen = time.perf_counter() - t0
         rd = ingest.Reader(ds["bam"], ds["fasta"])
         firsts = list(range(0, n, chunk))
-        ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256
+        ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256 -- under the box's CFS quota of 16 CPUs (cpu_quota()): 15 x one thread is all the quota gives
         ing = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
         ing(0)  # page cache, thread start-up
         t0 = time.perf_counter()
@@ -290,7 +309,7 @@ def run_e2e(args, env):
         return dict(
             workload="%d cfg2-like loci (motif 2-6 bp, 5-40 copies per allele), %d reads of ~%d bases per locus, one contig; BAM %.1f MB (%d reads, %.0f MB of records), written by trgt_amd/synth_bam.py in %.1f s"
                      % (n, 30, args.e2e_read_len, ds["bam_bytes"] / 1e6, ds["n_reads"], ds["bases"] / 1e6, t_gen),
-            chunk_loci=chunk, ingest_threads=ing_threads, host_cores=cores,
+            chunk_loci=chunk, ingest_threads=ing_threads, host_cores=cores, host_cpu_quota=cpu_quota(),
             ingest_loci_per_s=r(n / t_ing), ingest_loci_per_s_one_thread=r(1.0 / t_ing1), ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing),
             gpu_loci_per_s=r(n / t_gpu), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
@@ -588,7 +607,7 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3), "ms_per_step_single_context_with_timing_events": round(1e3 * dt_single_instrumented / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
-                       "host_threads_per_context": host_threads, "contexts_per_gpu": args.contexts, "host_cores": cores,
+                       "host_threads_per_context": host_threads, "contexts_per_gpu": args.contexts, "host_cores": cores, "host_cpu_quota": cpu_quota(),
                        "host_threads_all_ranks": host_threads * args.contexts * world, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -21,6 +21,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
@@ -523,6 +524,10 @@ struct trgt_ingest {
   uint64_t first_record_voff = 0;
   Bai bai;
   Fasta fasta;
+  // readers of the worker threads, kept between calls: an open file and the last inflated blocks (3 MB each) -- a call that continues
+  // where the last one stopped finds the blocks of the chunk boundary inflated, and no call pays for fresh pages again
+  std::mutex idle_mu;
+  std::vector<std::unique_ptr<Bgzf>> idle_readers;
 };
 
 struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
@@ -688,8 +693,15 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   // every thread still gets several runs
   const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, nl / (4ll * nthr)));
   auto work_body = [&]() {
-    Bgzf z(48);
-    if (!z.open(h->bam_path.c_str())) { for (auto& l : loci) if (l.err.empty()) { l.err = z.err; break; } return; }
+    std::unique_ptr<Bgzf> zp;
+    { std::lock_guard<std::mutex> g(h->idle_mu); if (!h->idle_readers.empty()) { zp = std::move(h->idle_readers.back()); h->idle_readers.pop_back(); } }
+    if (!zp) {
+      zp.reset(new Bgzf(48));
+      if (!zp->open(h->bam_path.c_str())) { for (auto& l : loci) if (l.err.empty()) { l.err = zp->err; break; } return; }
+    }
+    struct Back { trgt_ingest* h; std::unique_ptr<Bgzf>& z; ~Back() { if (z && z->err.empty()) { std::lock_guard<std::mutex> g(h->idle_mu); h->idle_readers.push_back(std::move(z)); } } } back{h, zp};
+    Bgzf& z = *zp;
+    const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits;
     RawRec rec;
     for (;;) {
       const int64_t l0 = next.fetch_add(run);
@@ -738,7 +750,7 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
       l.reads.swap(clipped);
      }
     }
-    n_inflated += z.n_inflated; n_cache_hits += z.n_hits;
+    n_inflated += z.n_inflated - inflated0; n_cache_hits += z.n_hits - hits0;
   };
   std::atomic<int> worker_failed{0};
   auto work = [&]() {  // (an exception must not leave a thread, nor cross the C ABI)
