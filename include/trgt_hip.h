@@ -423,6 +423,11 @@ int64_t trgt_read_clip_bases(const uint8_t* bases, const uint8_t* quals, int64_t
 /* utils::math::median (src/utils/math.rs:73-98): f32 median of i32 values as simple_consensus uses it (genotype_flank.rs:147); 0 = None */
 int32_t trgt_median_i32(const int32_t* data, int64_t n, float* out);
 
+/* One raw DEFLATE stream (a BGZF block's payload) into exactly n_out bytes: mode 0 = the library's decoder (trgt_amd/csrc/inflate_fast.hpp;
+ * 1 = done, 0 = declined -- ingestion then lets zlib decide), mode 1 = zlib.  Exported for tests/test_inflate.py; htslib's bgzf_read_block
+ * is what it stands in for (the reference reads BAM through rust-htslib). */
+int32_t trgt_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t n_out, int32_t mode);
+
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {
   uint64_t seed;           /* 20250509 */

@@ -1,0 +1,118 @@
+"""The library's own DEFLATE decoder (trgt_amd/csrc/inflate_fast.hpp, what ingestion inflates BGZF blocks with) against zlib: every
+block of BAM files, streams of all block types and levels, damaged streams (declined or refused, never a wrong result)."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+def _lib():
+    from trgt_amd import _lib
+    L = _lib.lib()
+    L.trgt_inflate_raw.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]
+    L.trgt_inflate_raw.restype = C.c_int32
+    return L
+
+
+def _fast(L, comp, n_out, mode=0):
+    out = np.full(n_out + 16, 0xA5, np.uint8)
+    rc = L.trgt_inflate_raw(comp, len(comp), out.ctypes.data, n_out, mode)
+    assert (out[n_out:] == 0xA5).all(), "wrote beyond the output"
+    return rc, out[:n_out].tobytes()
+
+
+def _raw(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _corpus():
+    rng = np.random.default_rng(11)
+    dna = b"ACGT"
+    yield b""
+    yield b"A"
+    yield b"A" * 70000
+    yield bytes(rng.integers(0, 256, 50000, dtype=np.uint8))                      # incompressible: stored blocks
+    yield bytes(np.frombuffer(dna, np.uint8)[rng.integers(0, 4, 65000)])          # 2 bits of entropy per byte
+    yield (b"CAG" * 7000 + bytes(np.frombuffer(dna, np.uint8)[rng.integers(0, 4, 3000)])) * 2
+    yield bytes(rng.integers(0, 4, 60000, dtype=np.uint8)) + bytes(rng.integers(0, 256, 5280, dtype=np.uint8))
+    yield bytes((np.arange(65280) % 251).astype(np.uint8))
+    yield bytes(rng.choice(np.array([40] * 17 + list(range(2, 40)), np.uint8), 65280))   # binned qualities
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(300)]
+    yield b" ".join(words[int(i)] for i in rng.integers(0, 300, 9000))[:65280]
+    yield bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 200                  # long matches at distance 300
+
+
+def test_streams_of_every_kind_equal_zlib():
+    L = _lib()
+    n = 0
+    for data in _corpus():
+        for level in (0, 1, 2, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                comp = _raw(data, level, strategy)
+                rc, got = _fast(L, comp, len(data))
+                rcz, gotz = _fast(L, comp, len(data), mode=1)
+                assert rcz == 1 and gotz == data
+                assert rc in (0, 1)
+                if rc == 1:
+                    assert got == data, (len(data), level, strategy)
+                    n += 1
+                else:  # declined: only the exceptions the decoder leaves to zlib (a single distance code, ...)
+                    assert level > 0 and strategy in (zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_DEFAULT_STRATEGY), (len(data), level, strategy)
+    assert n > 200
+
+
+def test_bam_blocks_equal_zlib(tmp_path):
+    from trgt_amd import synth_bam
+    L = _lib()
+    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=12, read_len=3000)
+    paths = [ds["bam"], os.path.join(os.path.dirname(__file__), "golden", "example", "sample.bam")]
+    total = declined = 0
+    for path in paths:
+        if not os.path.exists(path):
+            continue
+        raw = open(path, "rb").read()
+        p = 0
+        while p < len(raw):
+            bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+            comp, isize = raw[p + 18:p + bsize - 8], struct.unpack_from("<I", raw, p + bsize - 4)[0]
+            want = zlib.decompress(comp, -15)
+            assert len(want) == isize
+            rc, got = _fast(L, comp, isize)
+            total += 1
+            declined += rc == 0
+            assert rc == 0 or got == want
+            p += bsize
+    assert total > 20 and declined <= 2  # (the empty end-of-file blocks are fixed-code blocks: taken as well)
+
+
+def test_damaged_streams_are_never_inflated_wrongly():
+    L = _lib()
+    rng = np.random.default_rng(5)
+    data = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20000)]) + b"CAG" * 500
+    comp = bytearray(_raw(data, 6))
+    ok = 0
+    for trial in range(400):
+        bad = bytearray(comp)
+        kind = trial % 4
+        if kind == 0:
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            bad = bad[:int(rng.integers(1, len(bad)))]                 # cut short
+        elif kind == 2:
+            bad += bytes(rng.integers(0, 256, 5, dtype=np.uint8))      # trailing bytes: still a complete stream in front
+        n_out = len(data) + (0 if kind != 3 else int(rng.integers(-3, 4)))  # kind 3: a wrong announced size
+        rc, got = _fast(L, bytes(bad), max(n_out, 0))
+        if rc == 1:
+            ok += 1
+            # whatever it accepts must be what zlib makes of the same bytes, with exactly that size
+            d = zlib.decompressobj(-15)
+            try:
+                ref = d.decompress(bytes(bad))
+            except zlib.error:
+                ref = None
+            assert ref is not None and d.eof and ref == got and len(got) == n_out, (trial, kind)
+    assert ok >= 50  # (the trailing-bytes and unchanged cases)

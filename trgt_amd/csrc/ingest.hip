@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/trgt_hip.h"
+#include "inflate_fast.hpp"
 
 namespace {
 
@@ -43,7 +44,8 @@ struct Bgzf {
   std::vector<uint8_t> raw;
   std::vector<Block> cache;
   size_t cur = 0;               // the block being read
-  uint64_t clock = 0, n_inflated = 0, n_hits = 0;
+  uint64_t clock = 0, n_inflated = 0, n_hits = 0, n_declined = 0;
+  std::unique_ptr<trgt::inflate_fast::Tables> tables;
   uint64_t block_coff = ~0ull;  // compressed offset of the current block
   uint32_t block_csize = 0;     // its size in the file (0: end of file)
   size_t pos = 0;               // read position inside it
@@ -87,7 +89,14 @@ struct Bgzf {
     const uint32_t isize = raw[total - 4] | (raw[total - 3] << 8) | (raw[total - 2] << 16) | ((uint32_t)raw[total - 1] << 24);
     B.coff = ~0ull;  // (not a valid entry while it is being overwritten)
     B.data.resize(isize);
-    if (isize) {
+    bool isize_done = false;
+    static const bool zlib_only = std::getenv("TRGT_ZLIB_INFLATE") != nullptr;  // (the decoder of inflate_fast.hpp is tried first; zlib takes every block it declines)
+    if (isize && !zlib_only) {
+      if (!tables) tables.reset(new trgt::inflate_fast::Tables());
+      if (!trgt::inflate_fast::inflate_block(raw.data() + hdr, total - hdr - 8, B.data.data(), isize, *tables)) ++n_declined;
+      else isize_done = true;
+    }
+    if (isize && !isize_done) {
       if (!zs_ready) { if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; } zs_ready = true; }
       else if (inflateReset(&zs) != Z_OK) { err = "inflateReset failed"; return false; }
       zs.next_in = raw.data() + hdr; zs.avail_in = total - hdr - 8;
@@ -878,6 +887,21 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
                                    trgt_ingest_batch** out) {
   try { return ingest_batch_impl(h, p, bed_path, first_locus, max_loci, out); }
   catch (const std::exception& e) { if (h) h->err = std::string("trgt_ingest_batch_from_catalog: ") + e.what(); return TRGT_ERR_NOMEM; }
+}
+
+// raw DEFLATE of one block by the library's own decoder (mode 0; 1 = inflated, 0 = declined: ingestion then runs zlib) or by zlib (mode 1)
+int32_t trgt_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t n_out, int32_t mode) {
+  if (n_in < 0 || n_out < 0 || (n_in > 0 && !in) || (n_out > 0 && !out)) return TRGT_ERR_INVALID;
+  try {
+    if (mode == 0) { std::unique_ptr<trgt::inflate_fast::Tables> t(new trgt::inflate_fast::Tables()); return trgt::inflate_fast::inflate_block(in, (size_t)n_in, out, (size_t)n_out, *t) ? 1 : 0; }
+    z_stream zs; std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return TRGT_ERR_NOMEM;
+    zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)n_in; zs.next_out = out; zs.avail_out = (uInt)n_out;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0;
+    inflateEnd(&zs);
+    return ok ? 1 : 0;
+  } catch (const std::exception&) { return TRGT_ERR_NOMEM; }
 }
 
 // ---- the per-read helpers on their own (include/trgt_hip.h: "per-read helpers"): thin wrappers over the functions above
