@@ -44,6 +44,10 @@ def _corpus():
     words = [bytes(rng.integers(97, 123, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(300)]
     yield b" ".join(words[int(i)] for i in rng.integers(0, 300, 9000))[:65280]
     yield bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 200                  # long matches at distance 300
+    # symbol frequencies 2^-k: code lengths up to the limit of 15, so that the header lists all 19 code-length codes (19 x 3 bits)
+    skew = np.concatenate([np.full(1 << (17 - k), k, np.uint8) for k in range(18)])
+    for lead in (0, 1, 2, 3, 5, 11, 50):
+        yield bytes(rng.integers(0, 256, lead, dtype=np.uint8)) + bytes(rng.permutation(skew))[:65000]
 
 
 def test_streams_of_every_kind_equal_zlib():

@@ -150,8 +150,11 @@ inline bool inflate_block(const uint8_t* in, size_t n_in, uint8_t* out, size_t n
       buf >>= 14; cnt -= 14;
       if (hlit > 286 || hdist > 30) return false;
       uint8_t plens[19] = {0};
-      refill();  // (<= 57 bits: 19 x 3)
-      for (int i = 0; i < hclen; ++i) { plens[pre_order[i]] = (uint8_t)(buf & 7u); buf >>= 3; cnt -= 3; }
+      refill();
+      for (int i = 0; i < hclen; ++i) {
+        if (i == 12) refill();  // (19 x 3 = 57 bits: one more than a refill guarantees)
+        plens[pre_order[i]] = (uint8_t)(buf & 7u); buf >>= 3; cnt -= 3;
+      }
       if (!build_table(plens, 19, PRE_ROOT, T.pre, PRE_TABLE, pre_sym)) return false;
       uint8_t lens[286 + 30 + 140];
       int i = 0;
