@@ -10,8 +10,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -355,6 +357,9 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
     return true;
   };
   const int64_t nl = b->n_loci;
+  static const bool trace = std::getenv("TRGT_WRITER_TRACE") != nullptr;  // phase times on stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(w->threads, nl / 16));
   std::vector<std::string> lines((size_t)nt), errs((size_t)nt);
   std::vector<std::vector<uint8_t>> recs((size_t)nt);
@@ -366,6 +371,10 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
   };
   if (nt <= 1) work(0);
   else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
+  const double t1 = now();
+  size_t vcf_bytes = 0, bam_bytes = 0;
+  for (int t = 0; t < nt; ++t) { vcf_bytes += lines[(size_t)t].size(); bam_bytes += recs[(size_t)t].size(); }
+  struct Tr { bool on; double t0, t1; int64_t nl; int nt; size_t v, b; decltype(now)& now; ~Tr() { if (on) std::fprintf(stderr, "[writer] %lld loci, %d threads: formatting %.1f ms (%zu B of VCF, %zu B of BAM records), deflate + write %.1f ms\n", (long long)nl, nt, t1 - t0, v, b, now() - t1); } } tr{trace, t0, t1, nl, nt, vcf_bytes, bam_bytes, now};
   for (int t = 0; t < nt; ++t) {  // (what precedes the first failing locus is written, as a serial writer would have)
     if (!lines[(size_t)t].empty() && !w->vcf.write(lines[(size_t)t].data(), lines[(size_t)t].size())) return bad("cannot write the VCF");
     if (!recs[(size_t)t].empty() && !w->bam.write(recs[(size_t)t].data(), recs[(size_t)t].size())) return bad("cannot write the BAM");
