@@ -212,6 +212,17 @@ inline int dev_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
     if (b.p) { TRGT_HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
     if (c->knobs.debug && want > ((size_t)256 << 20)) fprintf(stderr, "[mem] slot %d: %.2f GB\n", slot, (double)want / (double)(1ull << 30));
+    // A large buffer must leave the runtime room for what it allocates itself when a kernel is launched (scratch for the kernels with
+    // spills, queue and signal memory): with a few dozen MB of HBM left, ROCm aborts the whole process from a queue callback
+    // (HSA_STATUS_ERROR_OUT_OF_RESOURCES) instead of failing a call.  So the call fails here, with a message, while that is still possible.
+    if (want >= ((size_t)64 << 20)) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t reserve = (size_t)1 << 30;
+        if (free_b < want || free_b - want < reserve)
+          return fail(c, TRGT_ERR_NOMEM, "%zu bytes of device memory wanted, %zu free: less than 1 GB would be left for the runtime (fewer contexts per GPU, or a smaller trgt_hip_set_workspace_limit)", want, free_b);
+      } else (void)hipGetLastError();
+    }
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
       (void)hipGetLastError();
