@@ -229,7 +229,8 @@ inline bool inflate_block(const uint8_t* in, size_t n_in, uint8_t* out, size_t n
         const uint8_t* src = op - dist;
         uint8_t* dst = op;
         op += len;
-        if (dist >= 8) { do { std::memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < op); }
+        if (dist >= 16) { do { std::memcpy(dst, src, 16); dst += 16; src += 16; } while (dst < op); }  // (up to 15 bytes beyond the match: inside the 320-byte margin)
+        else if (dist >= 8) { do { std::memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < op); }
         else if (dist == 1) std::memset(dst, *src, len);
         else { do { *dst++ = *src++; } while (dst < op); }
         continue;
