@@ -340,7 +340,9 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
     # host threads for the glue between the GPU stages; the library uses at most 8 of them when the reads are resident in HBM
     # (ranks x contexts per GPU x host threads per context never exceeds the host's cores: the first real 8-GPU run must not oversubscribe)
     cores = os.cpu_count() or 8
-    host_threads = min(8, args.host_threads or max(1, cores // max(1, world * args.contexts)))
+    quota = cpu_quota()
+    cores_eff = max(1, min(cores, int(quota))) if quota else cores  # (what the cgroup lets this process use at once: 16 of 256 on the GPU boxes)
+    host_threads = min(8, args.host_threads or max(1, cores_eff // max(1, world * args.contexts)))
     batch = make_batch(args.config, n_loci, rank * n_loci)
     reads_dev = torch.from_numpy(batch["read_blob"]).cuda()
     flank_dev = torch.from_numpy(batch["flank_blob"]).cuda()
