@@ -187,6 +187,15 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # Waiting for the GPU: the library's default (hipEventSynchronize) keeps a CPU per context spinning -- 5.2 CPUs per rank with four
+    # contexts on cfg2.  Where the cgroup grants fewer CPUs than the ranks of this job would spin on (the GPU boxes of this pool: 16),
+    # the waits poll and nap instead (2.2 CPUs per rank at 98 % of the rate; 1.95 without any spinning): set before the library reads it.
+    quota = cpu_quota()
+    if quota and "TRGT_POLL_WAIT" not in os.environ:
+        if world * 5.5 > quota:
+            os.environ["TRGT_POLL_WAIT"] = "1"
+            os.environ.setdefault("TRGT_POLL_SPIN_US", "200" if world * 2.3 <= quota else "0")
+            os.environ.setdefault("TRGT_POLL_NAP_US", "20" if world * 2.3 <= quota else "100")
     env = dict(torch=torch, dist=dist, rank=rank, local_rank=local_rank, world=world)
     legs = args.config == 0 and not args.no_legs and world == 1
     first = argparse.Namespace(**vars(args))
@@ -401,7 +410,7 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
     #      thread per context inside the library), draining the same K steps: a call's tail (results back, the few loci of the host
     #      path, HMM collection) and the kernels of its last stage overlap the flank location of the next calls.  This is `value`; the
     #      per-kernel times below are then those of this region, summed over the contexts.
-    pool, kt_pool = None, None
+    pool, kt_pool, cpus_busy = None, None, None
     if args.contexts > 1:
         pool = _lib.Pool([local_rank] * args.contexts)
         if ws_limit:
@@ -416,10 +425,14 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
         while time.perf_counter() - t_w < 0.6:
             many(2 * args.contexts)
         fence()
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         _, ran = many(args.steps)  # (no timing events in this region: pure throughput)
         fence()
         dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpus_busy = (ru1.ru_utime - ru0.ru_utime + ru1.ru_stime - ru0.ru_stime) / max(dt, 1e-9)  # host CPUs this rank kept busy while `value` was measured
         # per-kernel times of the same region, from a shorter instrumented pass
         for c in pool.contexts:
             c.timing_enable(True)
@@ -610,7 +623,7 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
                        "host_threads_per_context": host_threads, "contexts_per_gpu": args.contexts, "host_cores": cores, "host_cpu_quota": cpu_quota(),
-                       "host_threads_all_ranks": host_threads * args.contexts * world, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
+                       "host_threads_all_ranks": host_threads * args.contexts * world, "gpu_waits": ("poll, spin %s us, nap %s us" % (os.environ.get("TRGT_POLL_SPIN_US", "2000"), os.environ.get("TRGT_POLL_NAP_US", "20"))) if os.environ.get("TRGT_POLL_WAIT", "0") not in ("", "0") else "hipEventSynchronize (spins)", "host_cpus_busy_per_rank": round(cpus_busy, 2) if cpus_busy is not None else None, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",

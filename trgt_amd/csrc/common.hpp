@@ -149,6 +149,11 @@ inline int fail(trgt_hip_ctx* c, int code, const char* fmt, ...) {
 // Waiting for a stream or an event: the runtime's own wait by default; TRGT_POLL_WAIT=1 polls the completion state instead (spins
 // for the first 2 ms, then every 20 us), which was written while hunting the stalls that turned out to be malloc's (see ctx.hip) and
 // measures the same since.
+// TRGT_POLL_SPIN_US: how long a polling wait spins before it starts to nap (default 2000); TRGT_POLL_NAP_US: the nap (default 20).  A host
+// whose cgroup grants fewer CPUs than ranks x contexts want to spin on (bench.py sets these then) gives the waits up sooner.
+inline long poll_knob(const char* name, long dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const long v = std::atol(e); return v >= 0 ? v : dflt; }
+inline long poll_spin_ns() { static const long v = poll_knob("TRGT_POLL_SPIN_US", 2000) * 1000; return v; }
+inline long poll_nap_ns() { static const long v = std::max(1l, poll_knob("TRGT_POLL_NAP_US", 20)) * 1000; return v; }
 inline bool poll_wait_knob() { static const bool on = [] { const char* e = getenv("TRGT_POLL_WAIT"); return e && *e && std::strcmp(e, "0") != 0; }(); return on; }
 template <class Query>
 inline hipError_t poll_until_ready(Query q) {
@@ -161,7 +166,7 @@ inline hipError_t poll_until_ready(Query q) {
     }
     if ((it & 63) == 63) {
       timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
-      if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 2000000ll) { const timespec nap{0, 20000}; nanosleep(&nap, nullptr); }
+      if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > (long long)poll_spin_ns()) { const timespec nap{0, poll_nap_ns()}; nanosleep(&nap, nullptr); }
     }
     __builtin_ia32_pause();
   }
