@@ -61,6 +61,32 @@ def gen_pairs(rng, n, kind):
             if i % 3 == 0:
                 k = len(mot) * int(rng.integers(1, 4))
                 b = np.concatenate([b[:len(b) // 2], np.tile(mot, 3)[:k], b[len(b) // 2:]]) if i % 2 else b[k:]
+        elif kind == "consensus":  # a read of an allele against the central read of its cluster: HiFi errors, a stutter now and then, long alleles too
+            mot = rand_idx(rng, int(rng.integers(2, 9)))
+            L = int(rng.integers(20, 2500 if i % 16 == 0 else 700))
+            a = np.tile(mot, L // len(mot) + 1)[:L]
+            if i % 3 == 0:   # an interruption or two inside the repeat
+                for _ in range(int(rng.integers(1, 3))):
+                    at = int(rng.integers(0, len(a)))
+                    a = np.concatenate([a[:at], rand_idx(rng, int(rng.integers(1, 12))), a[at:]])
+            e = (0.001, 0.0005, 0.0005) if i % 4 else (0.01, 0.006, 0.006)
+            b = mutate_idx(rng, a, *e)
+            if i % 5 == 0:
+                k = len(mot) * int(rng.integers(1, 3))
+                at = int(rng.integers(0, len(b) + 1))
+                b = np.concatenate([b[:at], np.tile(mot, 3)[:k], b[at:]]) if i % 2 else np.concatenate([b[:at], b[at + k:]])
+            if i % 7 == 0:
+                a = mutate_idx(rng, a, *e)
+            if i % 13 == 0:
+                a, b = b, a
+        elif kind == "alleles":    # reads of two alleles of one locus against each other (the distance matrix): lengths apart by up to ~60
+            mot = rand_idx(rng, int(rng.integers(2, 7)))
+            L = int(rng.integers(8, 100))
+            a = np.tile(mot, L // len(mot) + 1)[:L]
+            L2 = max(0, L + int(rng.integers(-60, 61)))
+            b = mutate_idx(rng, np.tile(mot, L2 // len(mot) + 1)[:L2], 0.01, 0.005, 0.005)
+            if i % 9 == 0:
+                b = rand_idx(rng, int(rng.integers(0, 101)))
         elif kind == "short":      # <= 100 bp (edit-distance matrix of the cluster genotyper)
             a = rand_idx(rng, int(rng.integers(0, 101)))
             b = mutate_idx(rng, a, 0.05, 0.03, 0.03) if i % 4 else rand_idx(rng, int(rng.integers(0, 101)))
@@ -81,7 +107,8 @@ def gen_pairs(rng, n, kind):
 
 def compare(got, ref, coff, n):
     bad = []
-    for f in ("status", "score", "n_match", "span4", "cigar_len", "ops_len"):
+    no_ops = got["ops"] is None
+    for f in ("status", "score", "n_match", "span4", "cigar_len") + (() if no_ops else ("ops_len",)):
         g, r = np.asarray(got[f]), np.asarray(ref[f])
         if not np.array_equal(g, r):
             d = np.nonzero((g != r).reshape(n, -1).any(axis=1))[0]
@@ -89,19 +116,19 @@ def compare(got, ref, coff, n):
     if not bad:
         for j in range(n):
             o, cl, ol = int(coff[j]), int(ref["cigar_len"][j]), int(ref["ops_len"][j])
-            if not np.array_equal(got["cigar"][o:o + cl], ref["cigar"][o:o + cl]) or bytes(got["ops"][o:o + ol]) != bytes(ref["ops"][o:o + ol]):
+            if not np.array_equal(got["cigar"][o:o + cl], ref["cigar"][o:o + cl]) or (not no_ops and bytes(got["ops"][o:o + ol]) != bytes(ref["ops"][o:o + ol])):
                 bad.append(("cigar/ops", j, 1))
                 break
     return bad
 
 
-def run_mode(name, al, span, free, op, pats, txts, threads, min_length=None):
+def run_mode(name, al, span, free, op, pats, txts, threads, min_length=None, want_ops=True):
     n = len(pats)
     p = al._params(span, *free)
     if min_length is not None:
         p.bialign_min_length = min_length
     t0 = time.perf_counter()
-    got = al._run_batch(p, pats, txts)
+    got = al._run_batch(p, pats, txts, want_ops)
     tg = time.perf_counter() - t0
     blob = b"".join(pats) + b"".join(txts)
     plen = np.array([len(x) for x in pats], np.uint32)
@@ -133,8 +160,12 @@ def main():
         k += 1
         return np.random.default_rng(seed * 1000 + k)
 
+    only = os.environ.get("WFA_FUZZ_ONLY", "")  # e.g. "no ops": only the modes whose name contains it
+
     def go(name, al, span, free, op, kind, count=n, **kw):
         nonlocal nbad, nmodes, njobs
+        if only and only not in name:
+            return
         pats, txts = gen_pairs(rng(), count, kind)
         if span == "endsfree" and free[0] >= 0 and max(free) > 0:   # fixed free-end lengths must not exceed the sequences
             r = rng()
@@ -180,6 +211,25 @@ def main():
     al = W.WFAligner.builder(A.Score, S.MemoryUltraLow).edit().build()
     go("BiWFA edit score-only (get_dist)", al, "end2end", (0, 0, 0, 0), oracle.wfa_params(metric="edit", scope="score", memory="ultralow", heuristic="default"), "short", 2 * n)
     go("BiWFA edit score-only, longer", al, "end2end", (0, 0, 0, 0), oracle.wfa_params(metric="edit", scope="score", memory="ultralow", heuristic="default"), "str", n // 2)
+    # the same BiWFA configurations WITHOUT expanded operations -- what the locus path asks for, and the form the register-resident kernel
+    # (wfa_lean.hip) takes in front of the generic one -- on pairs shaped like its callers'
+    for ml in (100, 0):
+        for heur in ("default", "none"):
+            b = W.WFAligner.builder(A.Alignment, S.MemoryUltraLow).affine(2, 5, 1)
+            al = b.build() if heur == "default" else hi(b)
+            for kind in ("consensus", "str", "alleles", "generic"):
+                go("BiWFA affine(2,5,1) no ops, %s, heuristic %s, min_length %d" % (kind, heur, ml), al, "end2end", (0, 0, 0, 0),
+                   oracle.wfa_params(metric="affine", x=2, o1=5, e1=1, memory="ultralow", heuristic=heur, min_length=ml), kind, n // 2, min_length=ml, want_ops=False)
+    for heur in ("default", "none"):
+        b = W.WFAligner.builder(A.Score, S.MemoryUltraLow).edit()
+        al = b.build() if heur == "default" else hi(b)
+        for kind in ("short", "alleles", "consensus", "str"):
+            go("BiWFA edit score-only no ops, %s, heuristic %s" % (kind, heur), al, "end2end", (0, 0, 0, 0),
+               oracle.wfa_params(metric="edit", scope="score", memory="ultralow", heuristic=heur), kind, n, want_ops=False)
+        b = W.WFAligner.builder(A.Alignment, S.MemoryUltraLow).edit()
+        al = b.build() if heur == "default" else hi(b)
+        go("BiWFA edit alignment no ops, consensus, heuristic %s" % heur, al, "end2end", (0, 0, 0, 0),
+           oracle.wfa_params(metric="edit", memory="ultralow", heuristic=heur), "consensus", n // 2, want_ops=False)
     print("RESULT wfa fuzz: modes=%d jobs=%d modes_with_mismatch=%d seed=%d" % (nmodes, njobs, nbad, seed))
     return 1 if nbad else 0
 

@@ -47,6 +47,7 @@ struct trgt_knobs {
   bool filter_serial = false;      // TRGT_FILTER_SERIAL: the pre-filter's two launches one after the other on one stream
   bool filter_one_launch = false;  // TRGT_FILTER_ONE_LAUNCH: the pre-filter in one launch whatever the text lengths
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
+  bool no_lean = false;      // TRGT_WFA_NO_LEAN: consensus alignments / edit distances straight to the generic kernel (no register-resident BiWFA kernel in front)
   bool no_lds_wfa = true;    // TRGT_WFA_LDS=1 turns the LDS-arena variant of the BiWFA kernel on (in front of the HBM-arena one).  Off by default:
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency
   int lds_wfa_kb = 7;        // TRGT_WFA_LDS_KB: LDS of the LDS-arena variant for the wavefronts of one alignment

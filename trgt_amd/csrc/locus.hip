@@ -822,7 +822,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
       WfaLaunch LR;
       // (n_jobs_host bounds the workgroups and their workspaces, not the jobs: the count is read on the device)
-      LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS;
+      LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS; LR.jobs_bound = rp.cap_jobs;
       LR.pat_base = d_reads; LR.txt_base = d_reads;
       LR.max_plen = rp.max_seg; LR.max_tlen = rp.max_seg; LR.max_sum = 2 * (int64_t)rp.max_seg;
       LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2;

@@ -601,9 +601,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
-  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks, &d_counter))) return rc;
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks + 32, &d_counter))) return rc;  // job counters | slot flags | 8 statistics words
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks + 32, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
   if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
@@ -665,11 +665,24 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   }
   // ---- BiWFA batches of one wave per alignment (consensus alignments, edit distances): first the LDS-arena variant over the whole list,
   //      then the HBM variant over what did not fit (its job list and count are written by the first launch)
-  const bool la_ok = a.kp.biwfa && p.span == 0 && threads == 64 && !L.ops && (p.metric == 1 || p.metric == 3) && !c->knobs.no_lds_wfa &&
-                     a.fast_wcap == 0 && !L.n_jobs2_dev;
+  // ---- BiWFA batches of one wave per alignment (consensus alignments, edit distances): first the register-resident kernel (wfa_lean.hip) over
+  //      the whole list, then this kernel over what it did not take (job list and count written by the first launch)
+  const int64_t jobs_bound = L.jobs_bound > 0 ? L.jobs_bound : L.n_jobs_host;  // (n_jobs_host may only bound the workgroups: the retry list holds every job)
+  const bool one_wave_biwfa = a.kp.biwfa && p.span == 0 && threads == 64 && !L.ops && a.fast_wcap == 0 && !L.n_jobs2_dev;
+  const bool lean_ok = one_wave_biwfa && !c->knobs.no_lean && (p.metric == 1 || (p.metric == 3 && pen.x == 2 && pen.o1 == 5 && pen.e1 == 1));
+  if (lean_ok) {
+    void* d_retry = nullptr;
+    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)jobs_bound * sizeof(JobDev), &d_retry))) return rc;
+    if ((rc = wfa_lean_launch(c, p, L, (JobDev*)d_retry, (unsigned int*)d_counter + 1, (uint32_t)std::min<int64_t>(jobs_bound, 0xFFFFFFF0ll), (unsigned int*)d_counter + 3,
+                              (unsigned int*)d_counter, (unsigned long long*)d_cells, c->knobs.debug ? (unsigned int*)d_counter + 4 + blocks : nullptr)))
+      return rc;
+    a.jobs = (const JobDev*)d_retry; a.n_jobs_dev = (const uint32_t*)d_counter + 1; a.n_jobs2_dev = nullptr; a.jobs_cap = 0;
+    a.counter = (unsigned int*)d_counter + 2;
+  }
+  const bool la_ok = !lean_ok && one_wave_biwfa && (p.metric == 1 || p.metric == 3) && !c->knobs.no_lds_wfa;
   if (la_ok) {
     void* d_retry = nullptr;
-    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)L.n_jobs_host * sizeof(JobDev), &d_retry))) return rc;
+    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)jobs_bound * sizeof(JobDev), &d_retry))) return rc;
     KArgs la = a;
     // dynamic LDS of a workgroup: sequences | two run-length buffers | descriptor rings (as many levels as the score scope needs) | the
     // region of the wavefronts.  Defaults sized for 12 workgroups per CU (one wave each; the registers allow no more): this kernel is all
@@ -710,6 +723,15 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "alignment kernel launch failed: %s (buffer set %d, at most %lld jobs, metric %d, %s, lds %zu, grid %lld x %d)", hipGetErrorString(le),
                                       L.buffer_set, (long long)L.n_jobs_host, p.metric, a.fast_wcap ? "dedicated kernel" : "generic kernel", lds, (long long)grid_blocks, threads); }
   t.stop(0);
+  if (lean_ok && c->knobs.debug) {  // (synchronises: developer output only)
+    unsigned int h[4] = {0, 0, 0, 0};
+    TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+    TRGT_HIP_TRY(c, hipMemcpy(h, d_counter, 16, hipMemcpyDeviceToHost));
+    unsigned int w[8];
+    TRGT_HIP_TRY(c, hipMemcpy(w, (unsigned int*)d_counter + 4 + blocks, 32, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[wfa] lean kernel: metric %d, %lld jobs at most, %u went on to the generic kernel (%u lost): lengths %u, window %u, range %u, history levels %u, history cells %u, runs %u, stack %u, status %u\n",
+            p.metric, (long long)jobs_bound, h[1], h[3], w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+  }
   if (la_ok && c->knobs.debug) {  // (synchronises: developer output only)
     unsigned int h[4] = {0, 0, 0, 0};
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));

@@ -21,6 +21,7 @@ inline uint32_t heavy_read_len(uint32_t locus_max_read_len, int flank_len) {
 
 struct WfaLaunch {  // everything device-resident
   const JobDev* jobs_dev = nullptr; int64_t n_jobs_host = 0; const uint32_t* n_jobs_dev = nullptr;
+  int64_t jobs_bound = 0;  // with n_jobs_dev: the most jobs the list can hold (0: n_jobs_host is that bound, not just a bound on the workgroups)
   // two-ended list: jobs expected to be expensive are appended from the front (count *n_jobs_dev) and are drained first,
   // the others from the back (jobs_dev[jobs_cap - 1 - k], count *n_jobs2_dev)
   const uint32_t* n_jobs2_dev = nullptr; uint32_t jobs_cap = 0;
@@ -41,6 +42,11 @@ struct WfaLaunch {  // everything device-resident
 // Enqueue the WFA kernel on the ctx stream (asynchronous).  The number of wavefront offsets computed is
 // accumulated in device memory at ctx->last_wfa_cells_dev.
 int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L);
+
+// The register-resident BiWFA kernel for small end-to-end alignments (wfa_lean.hip), launched by wfa_launch in front of the generic
+// kernel: alignments it does not take are appended to retry_jobs / *retry_count (device memory) and redone there from scratch.
+int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L, JobDev* retry_jobs, unsigned int* retry_count, uint32_t retry_cap,
+                    unsigned int* retry_lost, unsigned int* counter, unsigned long long* cells_out, unsigned int* why_hist);
 
 // ---- register-resident pre-filter of the flank fallback alignments (wfa_reg.hip) ----
 struct FilterArgs {  // by-value kernel argument
