@@ -601,9 +601,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
-  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks + 32, &d_counter))) return rc;  // job counters | slot flags | 8 statistics words
+  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks + 96, &d_counter))) return rc;  // job counters | slot flags | 24 words of the lean kernels (statistics, their counters)
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks + 32, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks + 96, c->stream));
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
   if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
@@ -673,8 +673,11 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   if (lean_ok) {
     void* d_retry = nullptr;
     if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)jobs_bound * sizeof(JobDev), &d_retry))) return rc;
-    if ((rc = wfa_lean_launch(c, p, L, (JobDev*)d_retry, (unsigned int*)d_counter + 1, (uint32_t)std::min<int64_t>(jobs_bound, 0xFFFFFFF0ll), (unsigned int*)d_counter + 3,
-                              (unsigned int*)d_counter, (unsigned long long*)d_cells, c->knobs.debug ? (unsigned int*)d_counter + 4 + blocks : nullptr)))
+    void* d_mid = nullptr;
+    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_MID_C : L.buffer_set ? S_WFA_MID_B : S_WFA_MID, (size_t)jobs_bound * sizeof(JobDev), &d_mid))) return rc;
+    unsigned int* const lean_words = (unsigned int*)d_counter + 4 + blocks;  // [0..15] statistics of the two tiers, [16..18] their counters
+    if ((rc = wfa_lean_launch(c, p, L, (JobDev*)d_mid, (JobDev*)d_retry, (unsigned int*)d_counter + 1, (uint32_t)std::min<int64_t>(jobs_bound, 0xFFFFFFF0ll), (unsigned int*)d_counter + 3,
+                              lean_words + 16, (unsigned long long*)d_cells, c->knobs.debug ? lean_words : nullptr)))
       return rc;
     a.jobs = (const JobDev*)d_retry; a.n_jobs_dev = (const uint32_t*)d_counter + 1; a.n_jobs2_dev = nullptr; a.jobs_cap = 0;
     a.counter = (unsigned int*)d_counter + 2;
@@ -727,10 +730,12 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     unsigned int h[4] = {0, 0, 0, 0};
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_counter, 16, hipMemcpyDeviceToHost));
-    unsigned int w[8];
-    TRGT_HIP_TRY(c, hipMemcpy(w, (unsigned int*)d_counter + 4 + blocks, 32, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[wfa] lean kernel: metric %d, %lld jobs at most, %u went on to the generic kernel (%u lost): lengths %u, window %u, range %u, history levels %u, history cells %u, runs %u, stack %u, status %u\n",
-            p.metric, (long long)jobs_bound, h[1], h[3], w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+    unsigned int w[24];
+    TRGT_HIP_TRY(c, hipMemcpy(w, (unsigned int*)d_counter + 4 + blocks, 96, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[wfa] lean kernels: metric %d, %lld jobs at most, %u went on to the second tier, %u to the generic kernel (%u lost)\n", p.metric, (long long)jobs_bound, w[17], h[1], h[3]);
+    for (int t = 0; t < 2; ++t)
+      fprintf(stderr, "[wfa]   tier %d handed on: lengths %u, window %u, range %u, history levels %u, history cells %u, runs %u, stack %u, status %u\n", t + 1,
+              w[8 * t + 0], w[8 * t + 1], w[8 * t + 2], w[8 * t + 3], w[8 * t + 4], w[8 * t + 5], w[8 * t + 6], w[8 * t + 7]);
   }
   if (la_ok && c->knobs.debug) {  // (synchronises: developer output only)
     unsigned int h[4] = {0, 0, 0, 0};

@@ -45,8 +45,8 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L);
 
 // The register-resident BiWFA kernel for small end-to-end alignments (wfa_lean.hip), launched by wfa_launch in front of the generic
 // kernel: alignments it does not take are appended to retry_jobs / *retry_count (device memory) and redone there from scratch.
-int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L, JobDev* retry_jobs, unsigned int* retry_count, uint32_t retry_cap,
-                    unsigned int* retry_lost, unsigned int* counter, unsigned long long* cells_out, unsigned int* why_hist);
+int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L, JobDev* mid_jobs, JobDev* retry_jobs, unsigned int* retry_count, uint32_t retry_cap,
+                    unsigned int* retry_lost, unsigned int* counters, unsigned long long* cells_out, unsigned int* why_hist);
 
 // ---- register-resident pre-filter of the flank fallback alignments (wfa_reg.hip) ----
 struct FilterArgs {  // by-value kernel argument
