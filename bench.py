@@ -126,6 +126,21 @@ def copy_peak_gbs(torch, nbytes=1 << 30, reps=8):
     return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
 
 
+def plan_host(world, contexts, cores, quota, host_threads_arg=0):
+    """Host threads per context and the way the library waits for the GPU, for `world` ranks of `contexts` contexts each on a host with
+    `cores` CPUs of which the cgroup grants `quota` (None: all).  Pure function: tests/test_host_logic.py simulates the 8-rank launch.
+    * threads: ranks x contexts x threads never exceeds what the process group may use (at least one thread per context, at most 8)
+    * waits: hipEventSynchronize keeps ~5.5 CPUs per rank spinning (four contexts on cfg2); where the ranks together would spin on more
+      than the quota the waits poll and nap (TRGT_POLL_WAIT: 2.2 CPUs per rank at 98 % of the rate with 200 us of spinning, 1.95 with none)"""
+    cores_eff = max(1, min(cores, int(quota))) if quota else cores
+    threads = min(8, host_threads_arg or max(1, cores_eff // max(1, world * contexts)))
+    waits = {}
+    if quota and world * 5.5 > quota:
+        light = world * 2.3 <= quota
+        waits = {"TRGT_POLL_WAIT": "1", "TRGT_POLL_SPIN_US": "200" if light else "0", "TRGT_POLL_NAP_US": "20" if light else "100"}
+    return threads, waits
+
+
 def cpu_quota():
     """CPUs this process may use at once: the cgroup's CFS quota (cpu.max: "quota period" or "max") when there is one, else None.  On the
     MI355X boxes of this pool os.cpu_count() is 256 and the quota 16: every host-side rate of this file (CPU baseline on "all cores",
@@ -190,12 +205,9 @@ def main():
     # Waiting for the GPU: the library's default (hipEventSynchronize) keeps a CPU per context spinning -- 5.2 CPUs per rank with four
     # contexts on cfg2.  Where the cgroup grants fewer CPUs than the ranks of this job would spin on (the GPU boxes of this pool: 16),
     # the waits poll and nap instead (2.2 CPUs per rank at 98 % of the rate; 1.95 without any spinning): set before the library reads it.
-    quota = cpu_quota()
-    if quota and "TRGT_POLL_WAIT" not in os.environ:
-        if world * 5.5 > quota:
-            os.environ["TRGT_POLL_WAIT"] = "1"
-            os.environ.setdefault("TRGT_POLL_SPIN_US", "200" if world * 2.3 <= quota else "0")
-            os.environ.setdefault("TRGT_POLL_NAP_US", "20" if world * 2.3 <= quota else "100")
+    if "TRGT_POLL_WAIT" not in os.environ:
+        for k, v in plan_host(world, max(1, args.contexts), os.cpu_count() or 8, cpu_quota())[1].items():
+            os.environ.setdefault(k, v)
     env = dict(torch=torch, dist=dist, rank=rank, local_rank=local_rank, world=world)
     legs = args.config == 0 and not args.no_legs and world == 1
     first = argparse.Namespace(**vars(args))
@@ -350,8 +362,7 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
     # (ranks x contexts per GPU x host threads per context never exceeds the host's cores: the first real 8-GPU run must not oversubscribe)
     cores = os.cpu_count() or 8
     quota = cpu_quota()
-    cores_eff = max(1, min(cores, int(quota))) if quota else cores  # (what the cgroup lets this process use at once: 16 of 256 on the GPU boxes)
-    host_threads = min(8, args.host_threads or max(1, cores_eff // max(1, world * args.contexts)))
+    host_threads = plan_host(world, args.contexts, cores, quota, args.host_threads)[0]  # (the cgroup lets this process use 16 of the 256 CPUs of the GPU boxes)
     batch = make_batch(args.config, n_loci, rank * n_loci)
     reads_dev = torch.from_numpy(batch["read_blob"]).cuda()
     flank_dev = torch.from_numpy(batch["flank_blob"]).cuda()
@@ -586,10 +597,12 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             dp_bytes = 4.0 * cells_l
         bytes_per_launch = io_bytes + dp_bytes
         traffic = None  # measured HBM bytes per launch of the same kernel / workload, when a PMC profile is committed
+        valu_insts = None  # VALU wave-instructions per launch of the same kernel, from the committed SQ counters
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("loci_per_gpu") == n_loci and tj.get("config", 2) == args.config and dom in tj["kernels"]:
                 traffic = int(tj["kernels"][dom]["bytes_per_launch"])
+                valu_insts = tj["kernels"][dom].get("valu_wave_insts_per_launch")
         except (OSError, ValueError, KeyError):
             pass
         avg_ms = ms / launches
@@ -606,6 +619,9 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             rctx.close()
         copy_peak = copy_peak_gbs(torch)
         num_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        # what binds the dominant kernel: VALU issue.  A wave-instruction occupies its SIMD's 16 lanes for 4 cycles; the
+        # pass has num_cus * 4 SIMDs for avg_ms: issue fraction = committed VALU wave-instructions of one launch * 4 / SIMD-cycles of it
+        valu_issue_frac = round(valu_insts * 4.0 / (num_cus * 4 * avg_ms * 1e-3 * CLOCK_GHZ * 1e9), 4) if valu_insts and avg_ms > 0 else None
         valu_peak = num_cus * VALU_LANES_PER_CU * CLOCK_GHZ * 1e9   # 32-bit integer lane-operations per second
         cells_per_s = cells / max(ms, 1e-9) * 1e3
         res = {
@@ -614,18 +630,27 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
             "ms_per_step_single_context_min_median_max": [round(step_ms[0], 2), round(step_ms[len(step_ms) // 2], 2), round(step_ms[-1], 2)],  # rank 0
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+u8 packed (WFA pre-filter), u16 (WFA back-trace), f64 (HMM)",
             "data": "synthetic",
-            "value_is": "HBM-resident: read and flank bytes are in HBM before the timed region; value_streaming: every batch's reads start in pinned host memory and cross PCIe inside the timed region -- through the same worker contexts, each uploading its batch and then computing on it (single context: uploaded by trgt_locus_batch_submit next to the compute of the batch before, trgt_locus_batch_wait); value_streaming_bam4: the same with the reads as BAM 4-bit codes (TRGT_READS_BAM4), expanded in HBM",
+            "value_is": "HBM-resident, the K steps REPLAY ONE BATCH (the contexts of the pool read the same blob: the L2 / MALL see it more than once; nothing in the step is HBM-bound, and no result is kept between steps): read and flank bytes are in HBM before the timed region; value_streaming: every batch's reads start in pinned host memory and cross PCIe inside the timed region -- through the same worker contexts, each uploading its batch and then computing on it (single context: uploaded by trgt_locus_batch_submit next to the compute of the batch before, trgt_locus_batch_wait); value_streaming_bam4: the same with the reads as BAM 4-bit codes (TRGT_READS_BAM4), expanded in HBM",
             "value_streaming": round(world * n_loci / dt_stream, 1) if dt_stream else None,
             "value_streaming_single_context": round(world * n_loci / dt_stream_single, 1) if dt_stream else None,
             "value_streaming_bam4": round(world * n_loci / dt_stream4, 1) if dt_stream4 else None,
             "value_streaming_bam4_single_context": round(world * n_loci / dt_stream4_single, 1) if dt_stream4 else None,
             "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3), "ms_per_step_single_context_with_timing_events": round(1e3 * dt_single_instrumented / args.steps, 3),
             "config": {"workload": WORKLOAD[args.config] % n_loci, "baseline_config": args.config,
+                       # (the figures next to `value` that a reader of the parsed line needs: SURVEY 8(d)'s "first H2D to last D2H" rates and the blocking call)
+                       "value_streaming": round(world * n_loci / dt_stream, 1) if dt_stream else None,
+                       "value_streaming_bam4": round(world * n_loci / dt_stream4, 1) if dt_stream4 else None,
+                       "value_single_context": round(world * n_loci * args.steps / dt_single, 1), "ms_per_step_single_context": round(1e3 * dt_single / args.steps, 3),
+                       "steps_replay_one_batch": True,
                        "loci_per_gpu": n_loci, "reads_per_locus": 30, "parallelism": "loci sharded across %d GPU(s), no collective" % world,
                        "host_threads_per_context": host_threads, "contexts_per_gpu": args.contexts, "host_cores": cores, "host_cpu_quota": cpu_quota(),
                        "host_threads_all_ranks": host_threads * args.contexts * world, "gpu_waits": ("poll, spin %s us, nap %s us" % (os.environ.get("TRGT_POLL_SPIN_US", "2000"), os.environ.get("TRGT_POLL_NAP_US", "20"))) if os.environ.get("TRGT_POLL_WAIT", "0") not in ("", "0") else "hipEventSynchronize (spins)", "host_cpus_busy_per_rank": round(cpus_busy, 2) if cpus_busy is not None else None, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         # the bound that binds, and the fractions that say the HBM pricing is nominal
+                         "bound_measured": "valu-issue" if dom in ("wfa_filter", "wfa_flank", "wfa_flank_rest", "flank_scan") else ("scalar-issue / latency" if dom == "wfa_consensus" else "latency (dependent chain per column)"),
+                         "valu_issue_frac": valu_issue_frac, "valu_wave_insts_per_launch": valu_insts,
+                         "frac_at_reference_work": round(gbs(io_bytes + 4.0 * ref_cells_l) / HBM_PEAK_GBS, 5) if ref_cells_l else None,
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches), "measured_in": "the single-context loop of this run (K steps, HIP events on the kernel's stream)",
                          "launch_is": "wfa_filter runs as two kernel launches over one job list when the longest text needs more than 1024 diagonals (wfa_filter_kernel<9,1> or <5,2> / <6,2> for the jobs above 1024, then <4,2>): a 'launch' here is the pair, one pass of the pre-filter over a batch.  Outside a pool the two kernels run NEXT TO each other on two streams (round 3): the pass lasts from the start of the first to the end of the last -- in a rocprofv3 kernel summary of the one-context command that is about the longer kernel's average, not the sum (TRGT_FILTER_SERIAL=1 puts them one after the other again: then the sum)" if dom == "wfa_filter" else None,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),

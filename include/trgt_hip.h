@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 6
+#define TRGT_HIP_ABI_VERSION 7
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -378,10 +378,11 @@ typedef struct trgt_writer_params {
   const char* program;        /* "trgt": ##<program>Version= / ##<program>Command= / @PG ID, PN */
   const char* version;
   const char* command_line;
-  int32_t keep_unmapped_flag; /* 0 (default): aligned reads are written with flag 0 / 0x10.  1: flag 0x4 stays set on every record, which is
-                                 what write_bam.rs:96-111 produces if rust-htslib 0.46's Record::new() initialises a record as unmapped (its
-                                 published source does: set_unmapped(), tid / pos / mtid / mpos = -1) and nothing clears it on the mapped branch --
-                                 rust-htslib is un-vendored, no reference-produced BAM is on disk: parity of this bit is UNPINNED, hence the switch */
+  int32_t keep_unmapped_flag; /* 1 (default since ABI 7): flag 0x4 stays set on every record (flags 4 / 20) -- what write_bam.rs:96-111 produces with
+                                 rust-htslib 0.46 (Cargo.lock), whose Record::new() initialises a record as unmapped (set_unmapped(), tid / pos /
+                                 mtid / mpos = -1: the mate fields this writer mirrors already) and whose set() / set_pos() / set_mapq() / set_reverse()
+                                 do not clear it; write_bam.rs never calls unset_unmapped().  0: aligned reads are written with flag 0 / 0x10.
+                                 rust-htslib is un-vendored and no reference-produced BAM is on disk: parity of this bit is UNPINNED, hence the switch */
   int32_t threads;            /* 0 = min(32, cores): workers that format the loci of a batch (contiguous ranges, written in locus order) and
                                  deflate its BGZF blocks; the files do not depend on it */
 } trgt_writer_params;

@@ -102,3 +102,32 @@ def test_hmm_mirror_pure_python_parts():
     assert (H.encode_mc(anns), H.encode_ms(anns), H.encode_ap(anns)) == ("11,0", "0(0-33),.", "1.000000,.")
     b = H.pack_hmm_batch([["CAG"], ["A", "GCN"]], [(0, "CAGCAG"), (1, ""), (1, "GCAGCC")])
     assert list(b["seq_len"]) == [6, 0, 6] and list(b["count_off"]) == [0, 1, 3, 5] and list(b["span_off"]) == [0, 7, 8, 15]
+
+
+def test_bench_host_plan_for_eight_ranks_stays_within_the_cpu_quota():
+    """what bench.py plans for the first real 8-GPU run (simulated: WORLD_SIZE = 8 on the pool's hosts -- 256 CPUs, a cgroup
+    quota of 16 -- and on an unrestricted host): ranks x contexts x host threads never exceeds what the process group may use (one thread
+    per context is the floor), and the library's GPU waits only spin where the ranks' spinning fits the quota."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_plan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4, 8):
+        for contexts in (1, 4, 6):
+            for cores, quota in ((256, 16.0), (256, None), (8, None), (64, 48.0)):
+                threads, waits = bench.plan_host(world, contexts, cores, quota)
+                allowed = min(cores, int(quota)) if quota else cores
+                assert 1 <= threads <= 8
+                assert threads * contexts * world <= max(allowed, contexts * world), (world, contexts, cores, quota, threads)
+                spinning_cpus = world * 5.5
+                if quota and spinning_cpus > quota:
+                    assert waits.get("TRGT_POLL_WAIT") == "1", (world, quota)
+                    assert waits["TRGT_POLL_SPIN_US"] in ("0", "200") and (waits["TRGT_POLL_SPIN_US"] == "0") == (world * 2.3 > quota)
+                else:
+                    assert waits == {}
+    # the pool's hosts at N = 8: polling without spinning, one host thread per context
+    threads, waits = bench.plan_host(8, 4, 256, 16.0)
+    assert threads == 1 and waits == {"TRGT_POLL_WAIT": "1", "TRGT_POLL_SPIN_US": "0", "TRGT_POLL_NAP_US": "100"}
+    # an explicit --host-threads is honoured up to the library's cap
+    assert bench.plan_host(1, 4, 256, 16.0, 3)[0] == 3 and bench.plan_host(1, 4, 256, 16.0, 64)[0] == 8

@@ -125,7 +125,7 @@ def test_vcf_and_spanning_bam_from_handmade_results(tmp_path):
         cig = [("MIDNSHP=X"[int(v) & 0xF], int(v) >> 4) for v in b["cigar"][int(b["cigar_off"][r]):int(b["cigar_off"][r + 1])]]
         pos, ops = _clip_cigar_by_bases(int(b["cigar_ref_pos"][r]), cig, left, right)
         assert g["pos"] == pos and g["cigar"] == ops, g["name"]
-        assert g["tid"] == 0 and g["mapq"] == 60 and g["flag"] == (16 if by_name[g["name"]]["flag"] & 16 else 0) and g["mtid"] == -1
+        assert g["tid"] == 0 and g["mapq"] == 60 and g["flag"] == (20 if by_name[g["name"]]["flag"] & 16 else 4) and g["mtid"] == -1
         t = g["tags"]
         assert t["TR"] == ("Z", "L1") and t["AL"] == ("i", cls) and t["FL"] == ("BI", [40, 40])
         assert t["SO"] == ("i", int(b["start_offset"][r])) and t["EO"] == ("i", int(b["end_offset"][r]))
@@ -134,10 +134,10 @@ def test_vcf_and_spanning_bam_from_handmade_results(tmp_path):
         me = list(b["meth"][int(b["meth_off"][r]):int(b["meth_off"][r + 1])])
         cpg = [i for i in range(n - 1) if bases[i:i + 2] == "CG"]
         assert t["MC"] == ("BC", [m for i, m in zip(cpg, me) if left <= i < n - right])
-    # keep_unmapped_flag = 1: the records as rust-htslib 0.46's Record::new() would leave them if nothing clears 0x4 (UNPINNED, see the header)
-    w = writers.Writer(rd, tmp_path / "u.vcf", tmp_path / "u.bam", output_flank_len=40, sample_name="S1", command_line="cmd", keep_unmapped_flag=1)
+    # (the default keeps 0x4, as rust-htslib 0.46's Record::new() leaves it: UNPINNED, see the header) keep_unmapped_flag = 0 clears it
+    w = writers.Writer(rd, tmp_path / "u.vcf", tmp_path / "u.bam", output_flank_len=40, sample_name="S1", command_line="cmd", keep_unmapped_flag=0)
     w.write(b, out)
     w.close()
     _, _, got_u = read_bam_records(str(tmp_path / "u.bam"))
-    assert [(g["name"], g["flag"]) for g in got_u] == [(g["name"], g["flag"] | 4) for g in got]
+    assert [(g["name"], g["flag"]) for g in got_u] == [(g["name"], g["flag"] & ~4) for g in got]
     assert [{k: v for k, v in g.items() if k != "flag"} for g in got_u] == [{k: v for k, v in g.items() if k != "flag"} for g in got]

@@ -300,10 +300,14 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
   trgt_wfa_params wp;
   trgt_wfa_default_params(&wp);
   wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+  const bool tl_on = c->knobs.timeline;
+  const int64_t tl0 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#define RTL(name) do { if (tl_on) fprintf(stderr, "[tl]     repair %-20s +%7.2f ms\n", name, (double)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() - tl0) / 1e6); } while (0)
   WfaOnDevice dev;
   int rc = wfa_batch_impl(c, &wp, n_jobs, seqs, po, pl, to, tl, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                           nullptr, nullptr, while_running, &dev);
   if (rc) return rc;
+  RTL("alignments done");
   std::vector<vote::Group> groups(n_groups);
   uint64_t out_total = 0, scratch_words = 0;
   for (size_t g = 0; g < n_groups; ++g) {
@@ -321,6 +325,7 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
     G.scratch_off = scratch_words;
     scratch_words += (G.bb_len + 1 <= (uint32_t)vote::VOTE_LDS_POS + 1 ? 0 : 3 * ((uint64_t)G.bb_len + 1)) + 3 * (uint64_t)G.n_members;
   }
+  RTL("groups built");
   void *d_groups = nullptr, *d_scratch = nullptr, *d_out = nullptr, *d_len = nullptr;
   if ((rc = dev_get(c, S_VOTE_GROUPS, n_groups * sizeof(vote::Group), &d_groups)) || (rc = dev_get(c, S_VOTE_SCRATCH, (size_t)scratch_words * 4 + 16, &d_scratch)) ||
       (rc = dev_get(c, S_VOTE_OUT, (size_t)out_total + 16, &d_out)) || (rc = dev_get(c, S_VOTE_LEN, n_groups * 4, &d_len)))
@@ -329,11 +334,15 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
   vote::VoteArgs va{(const vote::Group*)d_groups, (uint32_t)n_groups, nullptr, dev.seqs, dev.jobs, dev.cigar, dev.cigar_len, (uint32_t*)d_scratch, (uint8_t*)d_out, (uint32_t*)d_len};
   hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)n_groups), dim3(vote::VOTE_THREADS), 0, c->stream, va);
   TRGT_HIP_TRY(c, hipGetLastError());
+  RTL("vote launched");
   std::vector<uint32_t> lens(n_groups);
   std::vector<uint8_t> bytes((size_t)out_total);
   { const int d2h_rc = trgt::d2h(c, lens.data(), d_len, n_groups * 4, c->stream); if (d2h_rc) return d2h_rc; }
   { const int d2h_rc = trgt::d2h(c, bytes.data(), d_out, (size_t)out_total, c->stream); if (d2h_rc) return d2h_rc; }
+  RTL("d2h enqueued");
   TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+  if (tl_on) fprintf(stderr, "[tl]     repair outputs: %zu groups, %.2f MB of output slots, %.2f MB of scratch\n", n_groups, (double)out_total / 1e6, (double)scratch_words * 4 / 1e6);
+  RTL("synced");
   for (size_t g = 0; g < n_groups; ++g) {
     if (lens[g] == 0xFFFFFFFFu) return fail(c, TRGT_ERR_UNSUPPORTED, "consensus: repaired sequence of group %zu longer than %u bases", g, groups[g].out_cap);
     results[g].assign((const char*)bytes.data() + groups[g].out_off, lens[g]);

@@ -17,7 +17,7 @@
 // one lane permutation (k_reverse = tlen - plen - k_forward is a reversal of the lanes).  LDS holds only what the back-trace of a
 // base alignment needs: 16-bit offsets of the computed range of every level, bump-allocated, and the run-length operations.
 //
-// Semantics are those of oracle/wfa.cpp (the restatement of WFA2-lib that the KATs pin): recurrences,
+// Semantics are those of the generic engine and of the test suite's CPU restatement of WFA2-lib that the KATs pin: recurrences,
 // trimming, the null-step bookkeeping, wfadaptive(10, 50, 1) with its equate step, termination, back-trace priorities, the two
 // phases of the breakpoint search with the extra levels of the second, the bialign_min_length / bialign_min_score base cases and
 // the component hand-over (begin / end in M, I or D) between the halves of a split.  Anything this kernel does not finish with

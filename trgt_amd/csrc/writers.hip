@@ -143,7 +143,7 @@ const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_s
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 0; p->threads = 0;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {

@@ -14,7 +14,7 @@ class WriterParams(C.Structure):
 
 class Writer:
     def __init__(self, reader, vcf_path, bam_path=None, output_flank_len=50, sample_name="sample", program="trgt", version="3.0.0",
-                 command_line="", keep_unmapped_flag=0, threads=0):
+                 command_line="", keep_unmapped_flag=1, threads=0):
         L = _lib.lib()
         L.trgt_writer_open.argtypes = [C.c_void_p, C.POINTER(WriterParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.trgt_writer_write.argtypes = [C.c_void_p, C.POINTER(IngestBatch), C.c_void_p]
