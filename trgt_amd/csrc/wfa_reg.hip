@@ -37,8 +37,13 @@
 // trimmed range" holds for every register.  The number of offsets computed per level therefore equals the reference's
 // (tests/test_filter_gpu.py compares it with the count of the CPU restatement).
 #include <algorithm>
+#include <type_traits>
 
 #include "wfa_host.hpp"
+
+#ifndef TRGT_FLT_W4
+#define TRGT_FLT_W4 4  // waves per SIMD the four-strip instantiation is compiled for
+#endif
 
 namespace trgt {
 namespace wfa {
@@ -117,8 +122,14 @@ __device__ __forceinline__ uint32_t dirty_dword(uint32_t x) {
 // X = mismatch penalty, OE = gap_open + gap_extend (gap_extend = 1): M[s - X] and M[s - OE] are the sources of a level, the ring keeps
 // R = max(X, OE) M levels (wgs preset 2,5,1: X = 2, OE = 6; targeted preset 1,0,1 of cli.rs:271-280: X = OE = 1, one level, updated in place).
 template <int NS, int B, int X = 2, int OE = 6>
-__global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
+__global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 ? 3 : 2)) wfa_filter_kernel(const FilterArgs a) {
   constexpr int NP = NS * B, SW = 128 * B, D = NS * SW, TWN = D + TW_EXTRA, LW = 2 * B, R = X > OE ? X : OE;
+  // The M levels a level reads, s - X and s - OE, are in ITS OWN residue class modulo G = gcd(X, OE) (2,5,1: even levels read even levels,
+  // odd ones odd ones).  So the ring of the last R levels is G rings of R / G: a level rotates only the ring of its class -- two register
+  // moves per pair of cells and level instead of five -- and the level loop is unrolled over the classes, which makes the ring a level
+  // uses a compile-time choice.
+  constexpr int G = (X == OE) ? X : ((X % 2 == 0 && OE % 2 == 0) ? 2 : 1), DEP = R / G, IX = X / G - 1, IO = OE / G - 1;
+  static_assert(R % G == 0 && X % G == 0 && OE % G == 0 && G <= 2, "ring classes");
   __shared__ uint32_t lds[PWN + TWN];
   uint32_t* const Pw = lds;
   uint32_t* const Tw = lds + PWN;
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
     else {
       // one step of the extension of both cells of a packed pair: the number of matching bases (0 .. 4) inside the next window,
       // n_a | n_b << 16.  A NULL cell (v + 1 = 0) reads the all-ones pattern window: no match, it stays NULL.
-      auto window_step = [&](uint32_t key, int C) -> uint32_t {
+      auto window_step = [&](uint32_t key, int C) __attribute__((always_inline)) -> uint32_t {
         const uint32_t va = (key >> 8) & 0xFFu, vb = key >> 24;
         // the four LDS reads of the pair go out together, one wait for all of them
         const uint32_t pa = Pw[va], ta = twl[va + C], pb = Pw[vb], tb = twl[vb + C + 1];
@@ -187,7 +198,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
       // Extension of the level in Mx: first window of every cell straight-line (all LDS reads in flight together), then, pair by
       // pair, the cells that matched a whole window go on (a few per level: random bases agree on four in a row once in 256).
       // Returns the packed maximum over the level (termination test).
-      auto extend_level = [&](uint32_t (&Mx)[NP]) -> uint32_t {
+      auto extend_level = [&](uint32_t (&Mx)[NP]) __attribute__((always_inline)) -> uint32_t {
         static_assert(NP <= 14, "the continuation flags of a level share one register");
         uint32_t cflag = 0;  // bit 2 + (NP - 1 - p): the A cell of pair p matched a whole window, bit 18 + (NP - 1 - p): its B cell
 #pragma unroll
@@ -235,17 +246,21 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
         for (int p = 0; p < NP; ++p) t = rpk_max(t, Mx[p]);
         return t;
       };
-      uint32_t Mr[R][NP], Ir[NP], Dr[NP];
+      uint32_t Mr[G][DEP][NP], Ir[NP], Dr[NP];  // Mr[c][d]: level s - G (d + 1) of class c = s mod G, for the level s being computed
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int d = 0; d < R; ++d) Mr[d][p] = 0u;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int d = 0; d < DEP; ++d) Mr[g][d][p] = 0u;
         Ir[p] = 0u; Dr[p] = 0u;
       }
       // trimmed ranges of the live wavefronts in k (not biased); null = (1, -1) as in the library
-      int mlo[R], mhi[R], ilo = 1, ihi = -1, dlo = 1, dhi = -1;
+      int mlo[G][DEP], mhi[G][DEP], ilo = 1, ihi = -1, dlo = 1, dhi = -1;
 #pragma unroll
-      for (int d = 0; d < R; ++d) { mlo[d] = 1; mhi[d] = -1; }
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int d = 0; d < DEP; ++d) { mlo[g][d] = 1; mhi[g][d] = -1; }
       const int lane_kb0 = lane * LW;
       const int term_v = plen + 1;
       const int lane_bnd0 = tlen + 1 + plen - lane_kb0;  // v + 1 <= lane_bnd - C  <=>  offset <= tlen on diagonal kb = C + lane_kb
@@ -253,44 +268,49 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int kbA = (p / B) * SW + 2 * (p % B) + lane_kb0;
-        Mr[0][p] = ((unsigned)(kbA - plen) <= (unsigned)tlen ? 0x0100u : 0u) | ((unsigned)(kbA + 1 - plen) <= (unsigned)tlen ? 0x01000000u : 0u);
+        Mr[0][0][p] = ((unsigned)(kbA - plen) <= (unsigned)tlen ? 0x0100u : 0u) | ((unsigned)(kbA + 1 - plen) <= (unsigned)tlen ? 0x01000000u : 0u);
       }
-      uint32_t tmax = extend_level(Mr[0]);
-      mlo[0] = 0; mhi[0] = tlen;
+      uint32_t tmax = extend_level(Mr[0][0]);
+      mlo[0][0] = 0; mhi[0][0] = tlen;
       unsigned long long cells = (unsigned long long)tlen + 1ull;
       int s = 0, num_null = 0;
       int next_check = 16;  // early rejection: the next level at which it is tried (every 16th, sooner when the best cell is close to the limit)
       bool done = false, bail = false, early = false;
-      for (;;) {
+      // one level of class RC (= s mod G once s is counted up); false: the alignment is over (done / bail / early say how)
+      auto level = [&](auto rc_) __attribute__((always_inline)) -> bool {
+        constexpr int RC = decltype(rc_)::value;
+        uint32_t (&Ms)[DEP][NP] = Mr[RC];
+        int (&slo)[DEP] = mlo[RC];
+        int (&shi)[DEP] = mhi[RC];
         // ---- termination (wavefront_termination_endsfree with pattern_end_free = 0, text_end_free = tlen): v == plen
         const bool tA = ((tmax >> 8) & 0xFFu) == (uint32_t)term_v, tB = (tmax >> 24) == (uint32_t)term_v;
-        if (__builtin_amdgcn_ballot_w64(tA || tB)) { done = true; break; }
+        if (__builtin_amdgcn_ballot_w64(tA || tB)) { done = true; return false; }
         ++s;
-        if (s > SMAX) { bail = true; break; }
-        const bool n_mm = mlo[X - 1] > mhi[X - 1], n_mo = mlo[OE - 1] > mhi[OE - 1], n_ie = ilo > ihi, n_de = dlo > dhi;
+        if (s > SMAX) { bail = true; return false; }
+        const bool n_mm = slo[IX] > shi[IX], n_mo = slo[IO] > shi[IO], n_ie = ilo > ihi, n_de = dlo > dhi;
         // (per-lane constants go through opaque() once per level: hoisted out of the loop, their per-pair variants -- bounds, diagonal
         //  numbers -- would sit in two dozen registers for the whole alignment)
         const int lane_bnd = (int)opaque((uint32_t)lane_bnd0), lane_kb = (int)opaque((uint32_t)lane_kb0);
-        uint32_t (&Mn)[NP] = Mr[R - 1];  // the new level replaces M[s - R] in place (its last use: the first pass below for the gap-open
+        uint32_t (&Mn)[NP] = Ms[DEP - 1];  // the new level replaces M[s - R] in place (its last use: the first pass below for the gap-open
                                          // source, the read of the same element in the third pass when it is also the mismatch source)
         int nmlo = 1, nmhi = -1, nilo = 1, nihi = -1, ndlo = 1, ndhi = -1;
         if (n_mm && n_mo && n_ie && n_de) {
-          if (++num_null > R + 1) { bail = true; break; }  // (cannot happen with a free text; the exact kernel decides)
+          if (++num_null > R + 1) { bail = true; return false; }  // (cannot happen with a free text; the exact kernel decides)
 #pragma unroll
           for (int p = 0; p < NP; ++p) Mn[p] = 0u;  // (I and D are NULL already: their sources were)
           tmax = 0;
         } else {
           num_null = 0;
           // wavefront_compute_limits_input (null wavefronts take part with lo = 1, hi = -1, as in the library)
-          const int lo = min(min(mlo[X - 1], mlo[OE - 1] - 1), min(ilo + 1, dlo - 1));
-          const int hi = max(max(mhi[X - 1], mhi[OE - 1] + 1), max(ihi + 1, dhi - 1));
+          const int lo = min(min(slo[IX], slo[IO] - 1), min(ilo + 1, dlo - 1));
+          const int hi = max(max(shi[IX], shi[IO] + 1), max(ihi + 1, dhi - 1));
           cells += 3ull * (unsigned long long)max(0, hi - lo + 1);
           // ---- the recurrences.  ins[k] = max(Mo, Ie)[k - 1] and del[k] = (max(Mo, De) + 1)[k + 1]: ONE diagonal shift per
           //      component, taken after the maximum.  In place: first I <- max(Mo, I), D <- max(Mo, D) + 1, then the shifts
           //      (I from the top strip down, D from the bottom up, so that the neighbour's unshifted value is still there).
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
-            const uint32_t mo = Mr[OE - 1][p];
+            const uint32_t mo = Ms[IO][p];
             Ir[p] = rpk_max(mo, Ir[p]);
             Dr[p] = inc_v_nz(rpk_max(mo, Dr[p]));
           }
@@ -313,7 +333,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
             for (int jj = 0; jj < B; ++jj) {
               const int p = t * B + jj;
-              uint32_t mxp = rpk_max(Dr[p], rpk_max(inc_v_nz(Mr[X - 1][p]), Ir[p]));
+              uint32_t mxp = rpk_max(Dr[p], rpk_max(inc_v_nz(Ms[IX][p]), Ir[p]));
               if (top) {  // "adjust offset out of boundaries": offset > tlen -> NULL
                 const int bA = lane_bnd - (t * SW + 2 * jj);
                 const bool okA = (int)((mxp >> 8) & 0xFFu) <= bA, okB = (int)(mxp >> 24) <= bA - 1;
@@ -325,11 +345,11 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
           tmax = extend_level(Mn);
           // ---- wavefront_compute_trim_ends, restated: D is always in bounds; I and M are, below k = tlen - plen (+ 1)
           constexpr int INF = 1 << 20;
-          const int so_lo = n_mo ? INF : mlo[OE - 1], so_hi = n_mo ? -INF : mhi[OE - 1];
+          const int so_lo = n_mo ? INF : slo[IO], so_hi = n_mo ? -INF : shi[IO];
           const bool has_d = !n_mo || !n_de, has_i = !n_mo || !n_ie;
           if (has_d) { ndlo = min(so_lo, n_de ? INF : dlo) - 1; ndhi = max(so_hi, n_de ? -INF : dhi) - 1; }
           // last / first cell of a component for which pred holds, looking at the strips from biased kb_hi downwards / kb_lo upwards
-          auto find_last = [&](const uint32_t (&R)[NP], int kb_lo, int kb_hi, auto pred) -> int {
+          auto find_last = [&](const uint32_t (&R)[NP], int kb_lo, int kb_hi, auto pred) __attribute__((always_inline)) -> int {
             int best = -1;
 #pragma unroll
             for (int t = NS - 1; t >= 0; --t) {
@@ -346,7 +366,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
             }
             return best;
           };
-          auto find_first = [&](const uint32_t (&R)[NP], int kb_lo, int kb_hi, auto pred) -> int {
+          auto find_first = [&](const uint32_t (&R)[NP], int kb_lo, int kb_hi, auto pred) __attribute__((always_inline)) -> int {
             int best = INF;
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
@@ -397,7 +417,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
             }
           }
           {
-            int mc_lo = n_mm ? INF : mlo[X - 1], mc_hi = n_mm ? -INF : mhi[X - 1];
+            int mc_lo = n_mm ? INF : slo[IX], mc_hi = n_mm ? -INF : shi[IX];
             if (has_i) { mc_lo = min(mc_lo, ic_lo); mc_hi = max(mc_hi, ic_hi); }
             if (has_d) { mc_lo = min(mc_lo, ndlo); mc_hi = max(mc_hi, ndhi); }
             nmlo = mc_lo; nmhi = mc_hi;
@@ -411,17 +431,20 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
             }
           }
         }
-        // ---- rotate: the new level (in the slot of M[s - 6]) becomes M[s - 1].  Element by element through opaque(): see there.
+        // ---- rotate the ring of this class: the new level (in the slot of M[s - R]) becomes its newest.  Element by element through
+        //      opaque(): see there.
+        if constexpr (DEP > 1) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const uint32_t newest = opaque(Mr[R - 1][p]);
+          for (int p = 0; p < NP; ++p) {
+            const uint32_t newest = opaque(Ms[DEP - 1][p]);
 #pragma unroll
-          for (int d = R - 1; d >= 1; --d) Mr[d][p] = opaque(Mr[d - 1][p]);
-          Mr[0][p] = newest;
+            for (int d = DEP - 1; d >= 1; --d) Ms[d][p] = opaque(Ms[d - 1][p]);
+            Ms[0][p] = newest;
+          }
+#pragma unroll
+          for (int d = DEP - 1; d >= 1; --d) { slo[d] = slo[d - 1]; shi[d] = shi[d - 1]; }
         }
-#pragma unroll
-        for (int d = R - 1; d >= 1; --d) { mlo[d] = mlo[d - 1]; mhi[d] = mhi[d - 1]; }
-        mlo[0] = nmlo; mhi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
+        slo[0] = nmlo; shi[0] = nmhi; ilo = nilo; ihi = nihi; dlo = ndlo; dhi = ndhi;
         // ---- early rejection (at the levels where it can first succeed, see next_check).  A cell (v bases of the pattern consumed, at most c of them matched, text position
         //      h = v + k) can end in an alignment of at most c + min(plen - v, tlen - h) matches -- a match needs a base of both -- and
         //      no step raises that number: a match raises c, v and h together, a mismatch v and h, a deleted base v, an inserted base h.
@@ -443,7 +466,9 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
                 dm = rpk_min(dm, rpk_sub(rpk_sub(v1, cnt), 0x00010001u));
               };
 #pragma unroll
-              for (int d = 0; d < R; ++d) take(Mr[d][p]);
+              for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int d = 0; d < DEP; ++d) take(Mr[g][d][p]);
               take(Ir[p]); take(Dr[p]);
               if (top) {
                 const int over = t * SW + 2 * jj + lane_kb - tlen;  // biased diagonal of the low half, minus tlen
@@ -453,7 +478,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
             }
           }
           uint32_t best = min(dmin & 0xFFFFu, dmin >> 16);  // the smallest deficit of this lane's cells
-          if (!__builtin_amdgcn_ballot_w64((int)best <= plen - a.min_matches)) { early = true; break; }
+          if (!__builtin_amdgcn_ballot_w64((int)best <= plen - a.min_matches)) { early = true; return false; }
           // When to look again: in 16 levels, or -- when the smallest deficit m is close to the limit -- after the X (limit - m + 1)
           // levels the cheapest way of spoiling bases (mismatches, one every X levels) takes to push that cell over it.  (Only the
           // schedule rests on this estimate; a test is exact whenever it runs.)  A text without the piece is given up at level 52
@@ -464,6 +489,11 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
           }
           next_check = s + (a.early_reject == 2 ? max(2, min(16, X * (plen - a.min_matches - rfl_i((int)best) + 1))) : 16);  // (uniform: an SGPR -- as a vector value it was spilled, a scratch load per level)
         }
+        return true;
+      };
+      for (;;) {  // levels 1, 2, 3, ...: class 1, class 0, class 1, ... (one class when G = 1)
+        if constexpr (G == 2) { if (!level(std::integral_constant<int, 1>())) break; }
+        if (!level(std::integral_constant<int, 0>())) break;
       }
       cells_acc += cells;
       if (early) { keep = 0; score_out = INT32_MIN + 1; bound_out = a.min_matches - 1; }
@@ -474,7 +504,8 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? 4 : NS * B <= 10 ? 3 : 2)) 
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const int C = (p / B) * SW + 2 * (p % B);
-          const uint32_t x = Mr[0][p];
+          // (the newest level: of the class of s)
+          const uint32_t x = (G == 2 && (s & 1)) ? opaque(Mr[G - 1][0][p]) : opaque(Mr[0][0][p]);
           const unsigned long long mA = __builtin_amdgcn_ballot_w64(((x >> 8) & 0xFFu) == (uint32_t)term_v);
           const unsigned long long mB = __builtin_amdgcn_ballot_w64((x >> 24) == (uint32_t)term_v);
           if (mA) {
