@@ -43,6 +43,20 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // "divergent" for the register allocator: ranges and scores in VGPRs, uniform branches through exec masks.)
 #define JOIN() __builtin_amdgcn_wave_barrier()
 
+#ifdef TRGT_LEAN_PROF
+// developer build (make EXTRA=-DTRGT_LEAN_PROF): shader-clock time of the phases of a level, summed over all waves
+// [0] compute [1] extend [2] heuristic [3] swap [4] overlap [5] history [6] back-trace [7] job set-up + epilogue [8] levels
+__device__ unsigned long long g_lean_prof[16];
+__shared__ unsigned long long l_lean_prof[16];  // (per wave; flushed when the wave ends: a global atomic per mark would be what the next memory wait measures)
+#define LP_DECL unsigned long long lp_t = __builtin_readcyclecounter()
+#define LP_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (lane_id() == 0) l_lean_prof[i] += n_ - lp_t; lp_t = n_; } while (0)
+#define LP_COUNT(i) do { if (lane_id() == 0) l_lean_prof[i] += 1ull; } while (0)
+#else
+#define LP_DECL
+#define LP_MARK(i)
+#define LP_COUNT(i)
+#endif
+
 struct Range { int lo, hi; };  // lo > hi: ->null
 __device__ __forceinline__ bool is_null(const Range& r) { return r.lo > r.hi; }
 __device__ __forceinline__ Range canon(const Range& r) { Range o; const bool n = r.lo > r.hi; o.lo = n ? 1 : r.lo; o.hi = n ? -1 : r.hi; return o; }  // wavefront_compute_get_*wavefront: ->null reads as (1, -1)
@@ -76,6 +90,16 @@ template <int NS> __device__ __forceinline__ Wf<NS> from_above(const Wf<NS>& x) 
 // of addresses inside the Front object, which then stays in scratch memory as a whole (1 KB per lane, and every value read back from it
 // counts as divergent).  An empty asm statement makes each candidate a register value first.
 __device__ __forceinline__ int keep(int x) { asm volatile("" : "+v"(x)); return x; }
+template <int NS> __device__ __forceinline__ int below_strip(const Wf<NS>& x, int t) {  // strip t of from_below(x); t a compile-time constant after unrolling
+  int carry = NUL;
+  if (t > 0) carry = __builtin_amdgcn_update_dpp(0, x.v[t > 0 ? t - 1 : 0], 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+  return __builtin_amdgcn_update_dpp(carry, x.v[t], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+template <int NS> __device__ __forceinline__ int above_strip(const Wf<NS>& x, int t) {
+  int carry = NUL;
+  if (t + 1 < NS) carry = __builtin_amdgcn_update_dpp(0, x.v[t + 1 < NS ? t + 1 : t], 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+  return __builtin_amdgcn_update_dpp(carry, x.v[t], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
 // the cell of window position g (uniform), to every lane
 template <int NS> __device__ __forceinline__ int cell_at(const Wf<NS>& x, int g) {
   int src = keep(x.v[0]);
@@ -158,6 +182,14 @@ __device__ __forceinline__ int extend_cells(const Seqs& q, int k, int off, bool 
   bool going = false;
   if (on) { const int n = match8(q, v, h); v += n; h += n; going = n == 8; }
   unsigned long long m = __ballot(going);
+  // Repeats: a diagonal a multiple of the motif length away from the alignment's own matches for tens or hundreds of bases too, and in a
+  // tandem repeat there are dozens of such lanes per level (measured: the one-at-a-time finish below was 90-99 % of a level's time on the
+  // cluster genotyper's and the VNTR batches).  While more than a few cells are still running every lane steps its own cell, eight bases
+  // per round trip; the stragglers -- the alignment's own diagonal, mostly -- are then finished by the whole wave.
+  while (__builtin_popcountll(m) > 3) {
+    if (going) { const int n = match8(q, v, h); v += n; h += n; going = n == 8; }
+    m = __ballot(going);
+  }
   const int lane = lane_id();
   while (m) {
     const int j = (int)__builtin_ctzll(m);
@@ -198,8 +230,13 @@ template <int NS> __device__ __forceinline__ Range trim(Wf<NS>& w, const Range& 
   bool valid[NS];
 #pragma unroll
   for (int t = 0; t < NS; ++t) { const int k = k0 + 64 * t; valid[t] = k >= c.lo && k <= c.hi && in_bounds(w.v[t], k, q.plen, q.tlen); }
-  int first, last;
-  first_last<NS>(valid, first, last);
+  int first = -1, last = -1;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    if (NS > 1 && (q.kbase + 64 * t > c.hi || q.kbase + 64 * t + 63 < c.lo)) continue;  // (uniform: no cell of the level in this strip)
+    const unsigned long long m = __ballot(valid[t]);
+    if (m) { if (first < 0) first = 64 * t + (int)__builtin_ctzll(m); last = 64 * t + 63 - (int)__builtin_clzll(m); }
+  }
   Range r;
   if (first >= 0) { r.lo = q.kbase + first; r.hi = q.kbase + last; }
   else { r.lo = c.lo; r.hi = c.lo - 1; }
@@ -280,13 +317,12 @@ __device__ __forceinline__ bool front_compute(Front<NL, NC, NS>& f, const Seqs& 
     Range prev; prev.lo = f.m_exists ? f.rM[0].lo : 1; prev.hi = f.m_exists ? f.rM[0].hi : -1;
     const Range c{prev.lo - 1, prev.hi + 1};
     if (c.lo <= c.hi && (c.lo < wlo || c.hi > whi)) return false;
-    const Wf<NS> src = f.M[0];
-    const Wf<NS> ins = from_below(src), del = from_above(src);
     Wf<NS> mx;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
+      if (NS > 1 && (q.kbase + 64 * t > c.hi || q.kbase + 64 * t + 63 < c.lo)) { mx.v[t] = NUL; continue; }
       const int k = k0 + 64 * t;
-      int m = max(del.v[t], max(ins.v[t], src.v[t]) + 1);
+      int m = max(above_strip(f.M[0], t), max(below_strip(f.M[0], t), f.M[0].v[t]) + 1);
       if (k < c.lo || k > c.hi || !in_bounds(m, k, q.plen, q.tlen)) m = NUL;
       mx.v[t] = m;
     }
@@ -314,15 +350,15 @@ __device__ __forceinline__ bool front_compute(Front<NL, NC, NS>& f, const Seqs& 
     c.lo = min(c.lo, r_i.lo + 1); c.hi = max(c.hi, r_i.hi + 1);
     c.lo = min(c.lo, r_d.lo - 1); c.hi = max(c.hi, r_d.hi - 1);
     if (c.lo <= c.hi && (c.lo < wlo || c.hi > whi)) return false;
-    const Wf<NS> m_mis = f.M[X - 1];
-    const Wf<NS> ob = from_below(f.M[OE - 1]), ib = from_below(f.I[E - 1]), oa = from_above(f.M[OE - 1]), da = from_above(f.D[E - 1]);
     Wf<NS> mx, ins, del;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
+      // (a strip the level does not reach -- a window of 256 diagonals is mostly wider than the wavefront -- costs three moves)
+      if (NS > 1 && (q.kbase + 64 * t > c.hi || q.kbase + 64 * t + 63 < c.lo)) { mx.v[t] = NUL; ins.v[t] = NUL; del.v[t] = NUL; continue; }
       const int k = k0 + 64 * t;
-      int i = max(ob.v[t], ib.v[t]) + 1;
-      int d = max(oa.v[t], da.v[t]);
-      int m = max(d, max(m_mis.v[t] + 1, i));
+      int i = max(below_strip(f.M[OE - 1], t), below_strip(f.I[E - 1], t)) + 1;
+      int d = max(above_strip(f.M[OE - 1], t), above_strip(f.D[E - 1], t));
+      int m = max(d, max(f.M[X - 1].v[t] + 1, i));
       const bool act = k >= c.lo && k <= c.hi;
       if (!act || !in_bounds(m, k, q.plen, q.tlen)) m = NUL;
       if (!act) { i = NUL; d = NUL; }
@@ -667,7 +703,9 @@ __device__ __forceinline__ int engine(Shared<HC, HL, SC>& S, const uint8_t* P, c
   bool last_forward = false, a_fwd = true, first = true;
   // pc: 0 / 1 the two extensions of level 0; 2 / 3 phase one (forward / reverse step); 5 phase two (the fronts keep alternating)
   int pc = 0;
+  LP_DECL;
   for (;;) {
+    LP_COUNT(8);
     bool compute = !first, act = true, want_ak = mode == 0, swap_first = mode == 0 && !first;
     if (mode == 0) {
       if (pc == 1) compute = false;
@@ -680,11 +718,16 @@ __device__ __forceinline__ int engine(Shared<HC, HL, SC>& S, const uint8_t* P, c
         overlap<METRIC>(A, B, q, A.s, sb, a_fwd, bp);
       }
     }
+    LP_MARK(4);
     if (swap_first) { swap_fronts(A, B); a_fwd = !a_fwd; }
     q.rev = A.rev;
+    LP_MARK(3);
     if (compute && !front_compute<METRIC>(A, q, cells)) { why = WHY_RANGE; return ST_NOFIT; }
+    LP_MARK(0);
     const int done = front_extend<METRIC>(A, q, mode == 0 ? (int)CM : ce, hp, act, want_ak, mak);
+    LP_MARK(1);
     if (mode == 1 && !hist_store(S, A, q, bump, why)) return ST_NOFIT;
+    LP_MARK(5);
     if (done) { end_score = A.end_score; q.rev = 0; return A.status; }
     first = false;
     if (mode == 0) {
@@ -706,6 +749,10 @@ __global__ void __launch_bounds__(64) wfa_lean_kernel(const Args a) {
   constexpr int NL = METRIC == 1 ? 2 : 7, NC = METRIC == 1 ? 1 : 3;
   __shared__ Shared<HC, HL, SC> S;
   const int lane = lane_id();
+#ifdef TRGT_LEAN_PROF
+  if (lane < 16) l_lean_prof[lane] = 0;
+  __syncthreads();
+#endif
   if (lane == 0) {
     Outs& o = S.out;
     o.status = a.status; o.score = a.score; o.n_match = a.n_match; o.span4 = a.span4; o.cigar = a.cigar; o.cigar_len = a.cigar_len; o.ops_len = a.ops_len;
@@ -860,6 +907,10 @@ __global__ void __launch_bounds__(64) wfa_lean_kernel(const Args a) {
     }
   }
   if (lane == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
+#ifdef TRGT_LEAN_PROF
+  __syncthreads();
+  if (lane < 16 && l_lean_prof[lane]) atomicAdd(&g_lean_prof[lane], l_lean_prof[lane]);
+#endif
 }
 
 }  // namespace lean
@@ -908,6 +959,16 @@ int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& 
     le = hipGetLastError();
     if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "lean alignment kernel (second tier) launch failed: %s", hipGetErrorString(le));
   }
+#ifdef TRGT_LEAN_PROF
+  {
+    unsigned long long h[16], z[16] = {0};
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(lean::g_lean_prof), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lean::g_lean_prof), z, sizeof h);
+    const double lv = (double)h[8] + 1e-9;
+    fprintf(stderr, "[lean prof] metric %d levels %llu | cycles per level: compute %.0f extend %.0f swap %.0f overlap %.0f history %.0f\n", p.metric, h[8], h[0] / lv, h[1] / lv, h[3] / lv, h[4] / lv, h[5] / lv);
+  }
+#endif
   return TRGT_OK;
 }
 
