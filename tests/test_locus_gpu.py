@@ -44,6 +44,13 @@ def _run_both(locus, b, params=None):
     finally:
         pctx.close()
     yield "split hmm", out
+    cctx = _lib.context_with_env(TRGT_HOST_CLUSTER=1)  # Genotyper::Cluster loci on host threads (locus_cluster.hpp), not by the device chain
+    try:
+        out = locus.run_batch(b, params, ctx=cctx)
+        assert int(out.stats[22]) == 0
+    finally:
+        cctx.close()
+    yield "host cluster", out
     yield "host reads", locus.run_batch(b, params)
     reads_dev = torch.from_numpy(b["read_blob"]).cuda()
     flank_dev = torch.from_numpy(b["flank_blob"]).cuda()
@@ -230,6 +237,8 @@ def test_cluster_genotyper_cfg5_matches_oracle(oracle, mods):
     for mode, out in _run_both(locus, b):
         _compare(oracle, locus, b, out, locus.Params(), range(48))
         assert int(out.stats[15]) > 0 and int(out.stats[1]) > 48 * 10, mode  # edit-distance and consensus jobs ran on the GPU
+        if mode in ("host reads", "device", "host repair", "mixed repair"):  # ... and the linkage, the groups and the rounds on the device as well
+            assert int(out.stats[22]) == 48 and int(out.stats[23]) == 0, (mode, out.stats[22:24])
     # short alleles: |a|*|b| <= MAX_OPS for every pair, so the whole distance matrix comes from edit-distance alignments
     b = synth.generate(24, first_locus=7000, config=5, max_allele_bp=90)
     for mode, out in _run_both(locus, b):
@@ -266,9 +275,29 @@ def test_cluster_genotyper_shapes(oracle, mods):
     b = locus.pack(loci)
     for mode, out in _run_both(locus, b):
         _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+        if mode in ("host reads", "device"):
+            assert int(out.stats[22]) == len(loci) - 1 and int(out.stats[23]) == 0, (mode, out.stats[22:24])
     res = locus.analyze_batch(loci)
     assert len(res[0].genotype) == 1 and len(res[1].genotype) == 2 and res[1].genotype[0].seq == res[1].genotype[1].seq == b"CAG" * 9
     assert [len(a.seq) for a in res[2].genotype] == [27, 36]
+
+
+def test_cluster_genotyper_deep_loci_and_downsampling(oracle, mods):
+    # more than 64 reads per locus: the large instantiations of the device chain (distance matrix in HBM); more reads than max_depth:
+    # the uniform downsample in front of the pair list; a locus beyond 256 reads takes the host path
+    locus, synth = mods
+    b = synth.generate(6, first_locus=40, config=5, reads_per_locus=100, max_allele_bp=120)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(6))
+        if mode in ("host reads", "device"):
+            assert int(out.stats[22]) == 6, (mode, out.stats[22:24])
+    params = locus.Params(max_depth=40)
+    for mode, out in _run_both(locus, b, params):
+        _compare(oracle, locus, b, out, params, range(6))
+    b = synth.generate(2, first_locus=90, config=5, reads_per_locus=280, max_allele_bp=60)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(2))
+        assert int(out.stats[22]) == 0, mode
 
 
 def test_filter_impure_trs_matches_oracle(oracle, mods):

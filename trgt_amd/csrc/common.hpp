@@ -53,6 +53,7 @@ struct trgt_knobs {
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency
   int lds_wfa_kb = 7;        // TRGT_WFA_LDS_KB: LDS of the LDS-arena variant for the wavefronts of one alignment
   int lds_wfa_seq = 768;     // TRGT_WFA_LDS_SEQ: ... for its two sequences (padded pattern + text)
+  bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
   bool split_hmm = false;    // TRGT_SPLIT_HMM: the HMM of the loci the genotyper settles next to the device-side repair of the others, a second batch behind it
   int repair_blocks = 2048;  // TRGT_REPAIR_BLOCKS: workgroups (and workspaces) of the alignment kernel of the device-side repair
@@ -205,6 +206,8 @@ enum Slot {
   S_HMM_BUILD,  // inputs of the device-side model builder (one slab)
   S_VOTE_GROUPS, S_VOTE_SCRATCH, S_VOTE_OUT, S_VOTE_LEN,  // consensus column voting (consensus_vote.hpp)
   S_RP_GROUPS, S_RP_JOBS, S_RP_LOCI, S_RP_PEND, S_RP_CIGAR, S_RP_CLEN, S_RP_VOUT, S_RP_VLEN, S_RP_VSCR, S_RP_COUNTS,  // device-side consensus repair (locus_gt.hpp)
+  S_CL_LIST, S_CL_MOFF, S_CL_COUNTS, S_CL_REC, S_CL_CLS, S_CL_ESCORE, S_CL_GMAT, S_CL_EDJOBS, S_CL_JOBS, S_CL_GROUPS, S_CL_ED2JOBS, S_CL_ESCORE2, S_CL_CIGAR, S_CL_CLEN,
+  S_CL_VOUT, S_CL_VLEN, S_CL_VSCR,  // device-side cluster genotyper (locus_cluster_dev.hpp)
   S_COUNT
 };
 // pinned host buffer slots

@@ -31,6 +31,7 @@
 #include "hmm_host.hpp"
 #include "host_pool.hpp"
 #include "locus_gt.hpp"
+#include "locus_cluster_dev.hpp"
 #include "wfa_host.hpp"
 
 namespace trgt {
@@ -671,12 +672,12 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     size_t add(size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; }
   } slab;
   const size_t o_ss = slab.add((size_t)nr * 4), o_se = slab.add((size_t)nr * 4), o_hl = slab.add((size_t)nr), o_hr = slab.add((size_t)nr);
-  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0, o_gsz = 0, o_rpc = 0, o_skipb = 0;
+  size_t o_need = 0, o_nal = 0, o_alen = 0, o_ci = 0, o_nsp = 0, o_cls = 0, o_rank = 0, o_nspan = 0, o_toff = 0, o_flip = 0, o_gsz = 0, o_rpc = 0, o_skipb = 0, o_clc = 0;
   if (dev_gt) {
     o_need = slab.add((size_t)nl); o_nal = slab.add((size_t)nl * 4); o_alen = slab.add(2 * (size_t)nl * 4); o_ci = slab.add(4 * (size_t)nl * 4);
     o_nsp = slab.add(2 * (size_t)nl * 4); o_cls = slab.add((size_t)nr * 4); o_rank = slab.add((size_t)nr * 4); o_nspan = slab.add((size_t)nl * 4);
     o_toff = slab.add((2 * (size_t)nl + 1) * 8); o_flip = slab.add((size_t)nl);
-    o_gsz = slab.add(2 * (size_t)nl * 4); o_rpc = slab.add(gt::RC_WORDS * 4); o_skipb = slab.add((size_t)nl);
+    o_gsz = slab.add(2 * (size_t)nl * 4); o_rpc = slab.add(gt::RC_WORDS * 4); o_skipb = slab.add((size_t)nl); o_clc = slab.add(cl::CC_WORDS * 4);
   }
   void *d_slab = nullptr, *h_slab = nullptr;
   if ((rc = dev_get(c, S_LOCUS_4, slab.total, &d_slab)) || (rc = pin_get(c, P_SPAN_S, slab.total, &h_slab))) return rc;
@@ -691,6 +692,9 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     void *need = nullptr, *nal = nullptr, *blob = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr,
          *toff = nullptr, *packed = nullptr;
   } g;
+  std::vector<uint32_t> cl_list; std::vector<uint64_t> cl_moff;
+  uint64_t cl_pairs = 0, cl_reads = 0; uint32_t cl_max_nr = 0;
+  const uint32_t* d_cl_list = nullptr; const uint64_t* d_cl_moff = nullptr;
   struct GtHost { void *need = nullptr, *nal = nullptr, *alen = nullptr, *ci = nullptr, *nsp = nullptr, *cls = nullptr, *rank = nullptr, *nspan = nullptr, *toff = nullptr, *packed = nullptr; } gh;
   if (dev_gt) {
     if ((rc = dev_in(c, S_GT_LRB, in->locus_read_begin, (size_t)nl + 1, &g.lrb, &ub)) || (rc = dev_in(c, S_GT_PLOIDY, in->ploidy, (size_t)nl, &g.ploidy, &ub)) ||
@@ -699,6 +703,20 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
         (rc = dev_in(c, S_GT_ALCAP, out->allele_cap, (size_t)nl, &g.al_cap, &ub)) || (in->genotyper && (rc = dev_in(c, S_GT_GENO, in->genotyper, (size_t)nl, &g.geno, &ub))) ||
         (rc = dev_get(c, S_GT_BLOB, (size_t)allele_total + 16, &g.blob)) || (rc = dev_get(c, S_GT_PACKED, (size_t)allele_total + 16, &g.packed)))
       return rc;
+    // Genotyper::Cluster loci stay on the device too (locus_cluster_dev.hpp) unless TRGT_HOST_CLUSTER / TRGT_SPLIT_HMM say otherwise: the
+    // list of them and the first pair slot of each (condensed distance matrix, sized for all reads of the locus)
+    if (in->genotyper && !c->knobs.host_cluster && !c->knobs.split_hmm) {
+      for (int64_t l = 0; l < nl; ++l) {
+        if (in->genotyper[l] != 1 || in->ploidy[l] == 0) continue;
+        const uint64_t n = in->locus_read_begin[l + 1] - in->locus_read_begin[l];
+        if (n == 0 || n > (uint64_t)gt::GT_MAX_READS) continue;
+        cl_list.push_back((uint32_t)l); cl_moff.push_back(cl_pairs);
+        cl_pairs += n * (n - 1) / 2; cl_reads += n; cl_max_nr = std::max(cl_max_nr, (uint32_t)n);
+      }
+      if (cl_pairs > 0x7FFFFFF0ull) { cl_list.clear(); cl_moff.clear(); }  // (pair slots are 32-bit output indices: the host path takes such a batch)
+      if (!cl_list.empty() && ((rc = dev_in(c, S_CL_LIST, cl_list.data(), cl_list.size(), &d_cl_list, &ub)) || (rc = dev_in(c, S_CL_MOFF, cl_moff.data(), cl_moff.size(), &d_cl_moff, &ub))))
+        return rc;
+    }
     g.need = dsl(o_need); g.nal = dsl(o_nal); g.alen = dsl(o_alen); g.ci = dsl(o_ci); g.nsp = dsl(o_nsp); g.cls = dsl(o_cls); g.rank = dsl(o_rank);
     g.nspan = dsl(o_nspan); g.toff = dsl(o_toff);
     gh.need = hsl(o_need); gh.nal = hsl(o_nal); gh.alen = hsl(o_alen); gh.ci = hsl(o_ci); gh.nsp = hsl(o_nsp); gh.cls = hsl(o_cls); gh.rank = hsl(o_rank);
@@ -754,7 +772,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   if (use_slots) {
     hs.n_loci = nl; hs.cap = out->allele_cap; hs.seq_off = out->allele_off; hs.seq_blob_dev = (const uint8_t*)g.blob;
     hs.d_n_alleles = (const int32_t*)g.nal; hs.d_allele_len = (const uint32_t*)g.alen;
-    if (in->genotyper) { slot_skip.assign(in->genotyper, in->genotyper + nl); for (auto& v : slot_skip) v = v == 1; hs.host_skip = slot_skip.data(); }
+    if (in->genotyper && cl_list.empty()) { slot_skip.assign(in->genotyper, in->genotyper + nl); for (auto& v : slot_skip) v = v == 1; hs.host_skip = slot_skip.data(); }
   }
   if (dev_gt) {
     gt::GtArgs ga;
@@ -878,6 +896,80 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
         TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rp, 0));
       }
     } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_rpc), 0, gt::RC_WORDS * 4, c->stream));
+    if (!cl_list.empty()) {
+      // ---- Genotyper::Cluster on the device (locus_cluster_dev.hpp): pair list -> edit distances -> linkage / groups / backbones ->
+      //      consensus round -> redo or dropped reads -> second round + edit distances -> genotype.  Four alignment launches and two
+      //      votes, most of them over empty lists after the first round; nothing waits for the host.
+      const uint32_t n_cl = (uint32_t)cl_list.size();
+      const uint32_t max_seg = max_read_len > 2u * (uint32_t)F ? max_read_len - 2u * (uint32_t)F : 1u;
+      cl::ClArgs ca;
+      std::memset(&ca, 0, sizeof ca);
+      ca.g = ga; ca.list = d_cl_list; ca.n_list = n_cl; ca.mat_off = d_cl_moff;
+      ca.cap_j = (uint32_t)cl_reads; ca.cap_g = 2 * n_cl; ca.vote_lds_pos = (uint32_t)vote::VOTE_LDS_POS;
+      // arenas for two consensus rounds at worst-case slots per alignment, bounded: a locus that finds no room takes the host path
+      ca.cap_cigar = std::min<uint64_t>(2ull * cl_reads * (2ull * max_seg + 1), 96ull << 20);   // words
+      ca.cap_out = std::min<uint64_t>(2ull * (cl_reads + 2ull * n_cl) * ((uint64_t)max_seg + 16) + 64, 256ull << 20);  // bytes
+      ca.cap_scratch = std::min<uint64_t>(6ull * cl_reads + 12ull * n_cl * ((uint64_t)max_seg + 1) + 64, 32ull << 20);  // words
+      const bool big = cl_max_nr > 64;
+      void *d_cnt = nullptr, *d_rec = nullptr, *d_cls = nullptr, *d_es = nullptr, *d_gm = nullptr, *d_edj = nullptr, *d_j = nullptr, *d_g = nullptr, *d_ed2 = nullptr, *d_es2 = nullptr,
+           *d_cig = nullptr, *d_clen = nullptr, *d_vout = nullptr, *d_vlen = nullptr, *d_vscr = nullptr;
+      if ((rc = dev_get(c, S_CL_COUNTS, 256, &d_cnt)) || (rc = dev_get(c, S_CL_REC, (size_t)n_cl * sizeof(cl::ClRec), &d_rec)) || (rc = dev_get(c, S_CL_CLS, (size_t)nr + 16, &d_cls)) ||
+          (rc = dev_get(c, S_CL_ESCORE, (size_t)cl_pairs * 4 + 16, &d_es)) || (big && (rc = dev_get(c, S_CL_GMAT, (size_t)cl_pairs * 8 + 16, &d_gm))) ||
+          (rc = dev_get(c, S_CL_EDJOBS, (size_t)cl_pairs * sizeof(JobDev) + 16, &d_edj)) || (rc = dev_get(c, S_CL_JOBS, 2 * (size_t)ca.cap_j * sizeof(JobDev), &d_j)) ||
+          (rc = dev_get(c, S_CL_GROUPS, 2 * (size_t)ca.cap_g * sizeof(gt::RGroup), &d_g)) || (rc = dev_get(c, S_CL_ED2JOBS, 2 * (size_t)cl_reads * sizeof(JobDev), &d_ed2)) ||
+          (rc = dev_get(c, S_CL_ESCORE2, 2 * (size_t)nr * 4 + 16, &d_es2)) || (rc = dev_get(c, S_CL_CIGAR, (size_t)ca.cap_cigar * 4, &d_cig)) ||
+          (rc = dev_get(c, S_CL_CLEN, 2 * (size_t)ca.cap_j * 4, &d_clen)) || (rc = dev_get(c, S_CL_VOUT, (size_t)ca.cap_out + 16, &d_vout)) ||
+          (rc = dev_get(c, S_CL_VLEN, 2 * (size_t)ca.cap_g * 4, &d_vlen)) || (rc = dev_get(c, S_CL_VSCR, (size_t)ca.cap_scratch * 4 + 16, &d_vscr)))
+        return rc;
+      ca.counts = (uint32_t*)d_cnt; ca.rec = (cl::ClRec*)d_rec; ca.cls = (int8_t*)d_cls; ca.escore = (int32_t*)d_es; ca.gmat = (double*)d_gm;
+      ca.ed_jobs = (JobDev*)d_edj; ca.jobs = (JobDev*)d_j; ca.groups = (gt::RGroup*)d_g; ca.ed2_jobs = (JobDev*)d_ed2; ca.escore2 = (int32_t*)d_es2;
+      ca.vote_out = (const uint8_t*)d_vout; ca.vote_len = (const uint32_t*)d_vlen;
+      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, ca.counts, (uint32_t)cl::CC_WORDS);
+      const dim3 cgrid(n_cl);
+      if (big) hipLaunchKernelGGL((cl::cluster_front_kernel<gt::GT_MAX_READS>), cgrid, dim3(64), 0, c->stream, ca);
+      else hipLaunchKernelGGL((cl::cluster_front_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      const int64_t wg_bound = (int64_t)std::max(64, 2 * c->knobs.repair_blocks);
+      const int64_t ed_len = (int64_t)std::min<uint64_t>(max_seg, cl::CL_MAX_OPS);
+      trgt_wfa_params wed;
+      trgt_wfa_default_params(&wed);  // THREAD_WFA_ED (genotype.rs:88-92): edit distance, score only, BiWFA, default heuristic
+      wed.metric = 1; wed.span = 0; wed.scope = 0; wed.memory_mode = 3;
+      trgt_wfa_params wco;
+      trgt_wfa_default_params(&wco);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
+      wco.metric = 3; wco.mismatch = 2; wco.gap_open1 = 5; wco.gap_ext1 = 1; wco.span = 0; wco.scope = 1; wco.memory_mode = 3;
+      auto ed_launch = [&](const JobDev* jobs, uint64_t bound, const uint32_t* count, const uint8_t* txt_base, int32_t* score) -> int {
+        WfaLaunch LE;
+        LE.jobs_dev = jobs; LE.n_jobs_host = std::min<int64_t>((int64_t)std::max<uint64_t>(bound, 1), wg_bound); LE.n_jobs_dev = count; LE.jobs_bound = (int64_t)std::max<uint64_t>(bound, 1);
+        LE.pat_base = d_reads; LE.txt_base = txt_base; LE.max_plen = ed_len; LE.max_tlen = ed_len; LE.max_sum = std::min<int64_t>(2 * ed_len, (int64_t)cl::CL_MAX_OPS + 1);
+        LE.score = score; LE.buffer_set = 2; LE.ws_budget = 512ull << 20;
+        return wfa_launch(c, wed, LE);
+      };
+      auto cons_launch = [&](uint32_t first_job, const uint32_t* count, uint32_t first_group, const uint32_t* group_count) -> int {
+        WfaLaunch LC;
+        LC.jobs_dev = ca.jobs + first_job; LC.n_jobs_host = std::min<int64_t>((int64_t)ca.cap_j, wg_bound); LC.n_jobs_dev = count; LC.jobs_bound = (int64_t)ca.cap_j;
+        LC.pat_base = d_reads; LC.txt_base = d_reads; LC.max_plen = max_seg; LC.max_tlen = max_seg; LC.max_sum = 2 * (int64_t)max_seg;
+        LC.cigar = (uint32_t*)d_cig; LC.cigar_len = (uint32_t*)d_clen; LC.buffer_set = 2; LC.ws_budget = 512ull << 20;
+        if (int r = wfa_launch(c, wco, LC)) return r;
+        vote::VoteArgs va{(const vote::Group*)(ca.groups + first_group), 0u, group_count, d_reads, ca.jobs, (const uint32_t*)d_cig, (const uint32_t*)d_clen,
+                          (uint32_t*)d_vscr, (uint8_t*)d_vout, (uint32_t*)d_vlen + first_group};
+        hipLaunchKernelGGL(vote::consensus_vote_kernel, dim3((unsigned)ca.cap_g), dim3(vote::VOTE_THREADS), 0, c->stream, va);
+        return TRGT_OK;
+      };
+      if ((rc = ed_launch(ca.ed_jobs, cl_pairs, ca.counts + cl::CC_ED, d_reads, ca.escore))) return rc;
+      if (big) hipLaunchKernelGGL((cl::cluster_ward_kernel<gt::GT_MAX_READS, false>), cgrid, dim3(64), 0, c->stream, ca);
+      else hipLaunchKernelGGL((cl::cluster_ward_kernel<64, true>), cgrid, dim3(64), 0, c->stream, ca);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      if ((rc = cons_launch(0, ca.counts + cl::CC_J1, 0, ca.counts + cl::CC_G1))) return rc;
+      if (big) hipLaunchKernelGGL((cl::cluster_round2_kernel<gt::GT_MAX_READS>), cgrid, dim3(64), 0, c->stream, ca);
+      else hipLaunchKernelGGL((cl::cluster_round2_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      if ((rc = cons_launch(ca.cap_j, ca.counts + cl::CC_J2, ca.cap_g, ca.counts + cl::CC_G2))) return rc;
+      if ((rc = ed_launch(ca.ed2_jobs, 2 * cl_reads, ca.counts + cl::CC_ED2, (const uint8_t*)d_vout, ca.escore2))) return rc;
+      if (big) hipLaunchKernelGGL((cl::cluster_finish_kernel<gt::GT_MAX_READS>), cgrid, dim3(64), 0, c->stream, ca);
+      else hipLaunchKernelGGL((cl::cluster_finish_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_clc), ca.counts, cl::CC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
+    } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_clc), 0, cl::CC_WORDS * 4, c->stream));
     hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
@@ -917,7 +1009,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     const uint8_t* skip_b = (const uint8_t*)hsl(o_skipb);
     if (hmm_pendingB) need_a.assign(need, need + nl);
     for (int64_t l = 0; l < nl; ++l) if (need[l] == 2) need[l] = skip_b[l] ? 1 : 0;  // repaired on the device, or back to the host path after all
-    if (in->genotyper) for (int64_t l = 0; l < nl; ++l) if (in->genotyper[l] == 1) need[l] = 1;  // Genotyper::Cluster: host-driven rounds
+    if (in->genotyper && cl_list.empty()) for (int64_t l = 0; l < nl; ++l) if (in->genotyper[l] == 1) need[l] = 1;  // Genotyper::Cluster: host-driven rounds (else: genotyped by the device chain, need_host = 0)
     if (flank_on) {
       // device-genotyped loci whose two alleles are at most 10 bases apart and whose reads DO split by haplotype tag or flank SNVs
       // take the host path, where the genotype is replaced (genotype_flank below); the split only needs the per-read fields
@@ -933,6 +1025,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     }
     for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
     stat_cons_jobs += (int64_t)((const uint32_t*)hsl(o_rpc))[gt::RC_JOBS];  // consensus alignments of the device-side repair
+    { const uint32_t* cc = (const uint32_t*)hsl(o_clc);  // ... and of the device-side cluster genotyper, with its edit distances
+      stat_cons_jobs += (int64_t)cc[cl::CC_J1] + (int64_t)cc[cl::CC_J2]; stat_ed_jobs += (int64_t)cc[cl::CC_ED] + (int64_t)cc[cl::CC_ED2]; }
   }
   else { R.resize((size_t)nl); for (int64_t l = 0; l < nl; ++l) R[(size_t)l] = l; }
   const int64_t nR = (int64_t)R.size();
@@ -1269,7 +1363,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       ClusterBatch cb(c, pool, cl_loci);
       if ((rc = cb.run())) return rc;
       stat_cons_jobs += cb.n_cons;
-      stat_ed_jobs = cb.n_ed;
+      stat_ed_jobs += cb.n_ed;
     }
     tB = now_ns() - tb0;
   TL("stageB");
@@ -1460,7 +1554,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     s[16] = (int64_t)((uint64_t*)h_cells)[5]; s[17] = (int64_t)((uint64_t*)h_cells)[4];  // pre-filter: alignments kept, offsets computed
     for (int i = 18; i < 24; ++i) s[i] = 0;
     s[21] = (int64_t)((uint64_t*)h_cells)[2];  // light fallback alignments settled by the substitution shortcut of the window search
-    if (dev_gt) { const uint32_t* rc_ = (const uint32_t*)hsl(o_rpc); s[18] = rc_[gt::RC_LOCI]; s[19] = rc_[gt::RC_FAILED]; s[20] = rc_[gt::RC_JOBS]; }  // device-side consensus repair: loci, loci without room, alignments
+    if (dev_gt) { const uint32_t* rc_ = (const uint32_t*)hsl(o_rpc); s[18] = rc_[gt::RC_LOCI]; s[19] = rc_[gt::RC_FAILED]; s[20] = rc_[gt::RC_JOBS];  // device-side consensus repair: loci, loci without room, alignments
+      const uint32_t* cc = (const uint32_t*)hsl(o_clc); s[22] = cc[cl::CC_DONE]; s[23] = cc[cl::CC_FAILED]; }  // device-side cluster genotyper: loci genotyped, loci handed to the host path
   }
   return TRGT_OK;
 }

@@ -590,6 +590,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   const int threads = L.threads > 0 ? L.threads : (p.span == 1 ? 256 : 64);
   int64_t blocks = std::min<int64_t>(L.n_jobs_host, (int64_t)c->num_cus * (threads >= 512 ? 4 : threads >= 256 ? 8 : 16));
   blocks = std::min<int64_t>(blocks, (int64_t)(c->ws_limit / std::max<uint64_t>(a.ws_per_block, 1)));
+  if (L.ws_budget > 0 && blocks > 1) blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)(L.ws_budget / std::max<uint64_t>(a.ws_per_block, 1))));
   if (blocks < 1) {
     // shrink the per-workgroup arena to what the limit allows; overflowing jobs report TRGT_WF_OOM
     const uint64_t fixed = a.ws_per_block - al(arena_ints * 4);

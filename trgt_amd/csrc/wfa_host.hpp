@@ -34,6 +34,8 @@ struct WfaLaunch {  // everything device-resident
                         // dedicated kernel is sized (and indexed) for that range instead of the whole text
   int kernel_tag = -1;  // instantiation of the dedicated kernel to launch (-1: 1 for timer_slot == TRGT_K_WFA_FLANK_REST, else 0); names the launch in a trace
   bool keep_cells = false;  // do not reset the wavefront-offset counter (a second launch of the same logical batch)
+  uint64_t ws_budget = 0;  // > 0: the generic kernel's workgroups (one workspace each) are limited to this many bytes of workspace -- launches whose jobs
+                           // the register-resident kernels take almost entirely, planned for lengths far above what the jobs have
   int buffer_set = 0;  // 0 / 1 / 2: which workspace / counter buffers of the ctx to use (launches may be in flight on two streams; 2 = the device-side consensus repair, whose buffers must not be re-sized while the flank location is still running on sets 0 / 1)
   int32_t* status = nullptr; int32_t* score = nullptr; int32_t* n_match = nullptr; uint32_t* span4 = nullptr;
   uint32_t* cigar = nullptr; uint32_t* cigar_len = nullptr; uint8_t* ops = nullptr; uint32_t* ops_len = nullptr;
