@@ -57,7 +57,7 @@ struct trgt_knobs {
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
   bool split_hmm = false;    // TRGT_SPLIT_HMM: the HMM of the loci the genotyper settles next to the device-side repair of the others, a second batch behind it
   int repair_blocks = 2048;  // TRGT_REPAIR_BLOCKS: workgroups (and workspaces) of the alignment kernel of the device-side repair
-  int repair_max_seg = 256;  // TRGT_REPAIR_MAX_SEG: longest repeat segment the device-side repair takes (its alignment workspace is planned for it)
+  int repair_max_seg = 1024;  // TRGT_REPAIR_MAX_SEG: longest repeat segment the device-side repair takes (its alignment workspace is planned for it)
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
 };

@@ -852,7 +852,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS; LR.jobs_bound = rp.cap_jobs;
       LR.pat_base = d_reads; LR.txt_base = d_reads;
       LR.max_plen = rp.max_seg; LR.max_tlen = rp.max_seg; LR.max_sum = 2 * (int64_t)rp.max_seg;
-      LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2;
+      LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2; LR.ws_budget = 512ull << 20;
       auto dbg_sync = [&](const char* what) -> int {  // TRGT_WFA_DEBUG: which kernel of the chain a device fault belongs to
         if (!c->knobs.debug) return TRGT_OK;
         const hipError_t e = trgt::stream_wait(c, c->stream);

@@ -66,7 +66,7 @@ struct GtShared {
   uint16_t u_rep[MAXR], u_cnt[MAXR];  // unique sequences (lexicographic order): representative, multiplicity
   uint32_t ulen[MAXR], ucnt[MAXR];    // unique lengths ascending, multiplicities
   int8_t cls[MAXR];
-  int n, n_sizes, bail;
+  int n, n_sizes, bail, fits;
   // decisions of lane 0, written out by the whole wave
   int res_n_gt, res_flip, res_rep[2], res_ci[4], res_hap[2];
   // device-side repair: reservations of lane 0
@@ -97,6 +97,27 @@ __device__ __forceinline__ int cmp_lds(const uint8_t* a, uint32_t na, const uint
       const int f = __ffsll((long long)ne) - 1;
       const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, f), yf = (uint32_t)__builtin_amdgcn_readlane((int)y, f);
       return __builtin_bswap32(xf) < __builtin_bswap32(yf) ? -1 : 1;
+    }
+  }
+  return na < nb ? -1 : (na > nb ? 1 : 0);
+}
+
+// the same order on byte strings anywhere (global memory, any alignment): lane i assembles dword i from four byte loads.  For the
+// loci whose repeat segments do not fit the LDS staging area (long alleles, deep loci): a few per cent of a genome-wide catalog.
+__device__ __forceinline__ int cmp_bytes(const uint8_t* __restrict__ a, uint32_t na, const uint8_t* __restrict__ b, uint32_t nb) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t m = na < nb ? na : nb;
+  for (uint32_t base = 0; base < m; base += 256) {
+    uint32_t x = 0, y = 0;  // big-endian: the first byte is the most significant
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t i = base + 4u * (uint32_t)lane + q;
+      if (i < m) { x |= (uint32_t)a[i] << (24 - 8 * q); y |= (uint32_t)b[i] << (24 - 8 * q); }
+    }
+    const unsigned long long ne = __ballot(x != y);
+    if (ne) {
+      const int f = __ffsll((long long)ne) - 1;
+      const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, f), yf = (uint32_t)__builtin_amdgcn_readlane((int)y, f);
+      return xf < yf ? -1 : 1;
     }
   }
   return na < nb ? -1 : (na > nb ? 1 : 0);
@@ -182,7 +203,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
   const uint64_t r0 = a.locus_read_begin[l], r1 = a.locus_read_begin[l + 1];
   const int nr = (int)(r1 - r0);
   if (lane == 0) {
-    sh.n = 0; sh.bail = 0; sh.res_n_gt = 0;
+    sh.n = 0; sh.bail = 0; sh.fits = 1; sh.res_n_gt = 0;
     if (a.gt_size) a.gt_size[2 * l] = a.gt_size[2 * l + 1] = 0;
     if (a.skip_b) a.skip_b[l] = 1;
     a.need_host[l] = 0; a.n_alleles[l] = 0; a.n_spanning_reads[l] = 0; a.flipped[l] = 0;
@@ -203,19 +224,25 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
       // ---- LDS layout of the repeat segments (4-aligned) and of the reference repeat behind them
       uint32_t o = 0;
       const int nn = sh.n;
-      for (int i = 0; i < nn; ++i) { sh.s_loff[i] = (uint16_t)o; o += (sh.s_len[i] + 3u) & ~3u; if (o > (uint32_t)SEG) { sh.bail = 1; break; } }
+      //      (segments that do not fit are compared where they lie, in the read blob: sh.fits = 0)
+      for (int i = 0; i < nn; ++i) { sh.s_loff[i] = (uint16_t)o; o += (sh.s_len[i] + 3u) & ~3u; if (o > (uint32_t)SEG) { sh.fits = 0; break; } }
       sh.ref_off = o;
-      if (o + ((refn + 3u) & ~3u) > (uint32_t)SEG) sh.bail = 1;
+      if (o + ((refn + 3u) & ~3u) > (uint32_t)SEG) sh.fits = 0;
     }
     __syncthreads();
     n = sh.n;
-    if (!sh.bail) {
+    if (sh.fits) {
       const int grp = lane >> 4, sub = lane & 15;
       for (int i = grp; i < n; i += 4) copy16(sh.bytes + sh.s_loff[i], a.reads + sh.r_off[sh.s_read[i]] + sh.s_start[i], sh.s_len[i], sub);
       if (grp == 0) copy16(sh.bytes + sh.ref_off, a.tr_blob + refo, refn, sub);
     }
     __syncthreads();
   }
+  const bool fits = sh.fits != 0;
+  auto seg_glob = [&](int i) { return a.reads + sh.r_off[sh.s_read[i]] + sh.s_start[i]; };
+  auto cmp_seg = [&](int i, int j) {  // uniform arguments, uniform result
+    return fits ? cmp_lds(sh.bytes + sh.s_loff[i], sh.s_len[i], sh.bytes + sh.s_loff[j], sh.s_len[j]) : cmp_bytes(seg_glob(i), sh.s_len[i], seg_glob(j), sh.s_len[j]);
+  };
   if (n > 0 && !sh.bail) {
     // ---- unique lengths / counts ascending (sorted(lens) of genotype_size_front; after a downsample the list is not sorted)
     if (lane == 0) {  // (one lane builds the histogram: read-modify-writes of LDS by 64 lanes at once only work by lockstep)
@@ -295,12 +322,11 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
       // ---- get_seq_hist: unique sequences in byte-lexicographic order (binary-search insertion into a sorted unique list)
       int nu = 0;
       for (int i = 0; i < n; ++i) {
-        const uint8_t* bi = sh.bytes + sh.s_loff[i]; const uint32_t ni = sh.s_len[i];
         int lo = 0, hi = nu, eq = -1;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
           const int r = sh.u_rep[mid];
-          const int c = cmp_lds(bi, ni, sh.bytes + sh.s_loff[r], sh.s_len[r]);
+          const int c = cmp_seg(i, r);
           if (c == 0) { eq = mid; break; }
           if (c < 0) hi = mid; else lo = mid + 1;
         }
@@ -437,7 +463,9 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
           }
           sh.cls[i] = (int8_t)cc; by_hap[cc] += 1;
         }
-        auto eq_ref = [&](int al) { return cmp_lds(sh.bytes + sh.s_loff[rep[al]], aln[al], sh.bytes + sh.ref_off, refn) == 0; };
+        auto eq_ref = [&](int al) {
+          return fits ? cmp_lds(sh.bytes + sh.s_loff[rep[al]], aln[al], sh.bytes + sh.ref_off, refn) == 0 : cmp_bytes(seg_glob(rep[al]), aln[al], a.tr_blob + refo, refn) == 0;
+        };
         int order[2] = {0, 1}; int flip = 0;
         if (n_gt != 1 && !eq_ref(0) && eq_ref(1)) { order[0] = 1; order[1] = 0; flip = 1; }
         for (int oi = 0; oi < n_gt; ++oi)
@@ -461,7 +489,7 @@ __global__ void __launch_bounds__(64) locus_genotype_kernel(const GtArgs a) {  /
   for (int oi = 0; oi < n_gt; ++oi) {
     const int rep = sh.res_rep[oi];
     const uint32_t len = sh.s_len[rep];
-    const uint8_t* src = sh.bytes + sh.s_loff[rep];
+    const uint8_t* src = fits ? sh.bytes + sh.s_loff[rep] : seg_glob(rep);
     uint8_t* dst = a.allele_blob + a.allele_off[2 * l + oi];
     for (uint32_t b = lane; b < len; b += 64) dst[b] = src[b];
     if (lane == 0) {
