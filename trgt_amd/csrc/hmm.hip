@@ -395,7 +395,19 @@ __device__ __forceinline__ double wave_shr1_f64(double x) {
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
 }
 
-template <int SUB>
+// f64 from another lane of the wave (byte address of the source lane: lane << 2)
+__device__ __forceinline__ double bperm_f64(int addr, double x) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(u & 0xFFFFFFFFull)), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// ONE_WAVE (models of at most 64 states: one state per lane of ONE wave, or two alleles of at most 32 states in its halves): the score
+// columns of the fill live in REGISTERS -- a state's predecessors are fetched from their lanes (ds_bpermute: one LDS-crossbar round per
+// pass, nothing written) instead of through two LDS arrays (a write, a fence and a read per pass), and what the run-end lane worked out
+// alone (the maximum over the block ends, the run start behind it) every lane of the job works out for itself from the same fetched
+// values.  Same sums, same predecessor order, same strict '>'.
+template <int SUB, bool ONE_WAVE>
 __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets,
                                    const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
                                    uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws,
@@ -536,6 +548,107 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* cur = sc1;
   HP_FILL_DECL;
   int sym_next = 0;
+  if constexpr (ONE_WAVE) {
+    const int hw = (int)(threadIdx.x & 63u), lane_base = hw & ~(SUB - 1);
+    const int a_q0 = (lane_base + q0) << 2, a_q1 = (lane_base + q1) << 2, a_q2 = (lane_base + q2) << 2, a_q3 = (lane_base + q3) << 2, a_st0 = lane_base << 2;
+    int a_be[BE_REG];
+#pragma unroll
+    for (int b = 0; b < BE_REG; ++b) a_be[b] = (lane_base + be[b]) << 2;
+    const double lp_re = l_lp[S - 2];  // the run end's transition term (one for all its predecessors' slot 0 ... see below)
+    const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
+    double prev_v = NINF;
+    double em_next = 0.0;
+    for (int i = 0; i < L; ++i) {
+      if ((i % HMM_CODE_WINDOW) == 0) {
+        hmm_sync(sync_n);
+        win0 = i;
+        for (int k = tid; k < HMM_CODE_WINDOW + 1 && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
+        hmm_sync(sync_n);
+        sym_next = code_at(i);
+        em_next = l_em[sym_next * S + st];
+      }
+      const double em = em_next;
+      if (i + 1 < L) { sym_next = code_at(i + 1); em_next = l_em[sym_next * S + st]; }  // (a column ahead: off this column's critical path)
+      HP_FILL(0);
+      double best = NINF;
+      int bpi = 0xFF;
+      {
+        const double s0 = bperm_f64(a_q0, prev_v), s1 = bperm_f64(a_q1, prev_v), s2 = bperm_f64(a_q2, prev_v), s3 = bperm_f64(a_q3, prev_v);
+        if (act && level == 0) {
+          if (i == 0) {
+            if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
+          } else {
+            const double v0 = (s0 + lp0) + em, v1 = (s1 + lp1) + em, v2 = (s2 + lp2) + em, v3 = (s3 + lp3) + em;
+            if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+            if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+            if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+            if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
+          }
+        }
+      }
+      double cur_v = best;  // emitting states: final; silent ones: -inf until their pass
+      HP_FILL(1);
+      {  // the chains d0 <- d1 <- ... <- block end (see the LDS variant below for the argument)
+        const double s0 = bperm_f64(a_q0, cur_v), s1 = bperm_f64(a_q1, cur_v);
+        if (role_chain) {
+          const double v0 = (s0 + lp0), v1 = (s1 + lp1);
+          if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+          if (role_end && n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+        }
+        double val = best, cand = NINF;
+        for (int t = 0; wave_chain && t < chain_steps; ++t) {
+          cand = (wave_shr1_f64(val) + lp_step);
+          val = cand > best ? cand : best;
+        }
+        if (cand > best) bpi = role_del ? 1 : 2;  // (never for the lanes whose transition term is -inf)
+        best = val;
+        if (role_chain) cur_v = val;
+      }
+      HP_FILL(2);
+      {  // run end: the block ends in block order; the run start {start state, run end} behind it -- by every lane, kept by the two
+        const double start_now = bperm_f64(a_st0, cur_v);
+        double re = NINF; int re_bp = 0xFF;
+        auto block_ends = [&](auto n_const) {
+          constexpr int N = decltype(n_const)::value;
+          double e[N];
+#pragma unroll
+          for (int b = 0; b < N; ++b) e[b] = bperm_f64(a_be[b], cur_v);
+#pragma unroll
+          for (int b = 0; b < N; ++b) {
+            const double v = (e[b] + lp_re);
+            if (b < nb && v > re) { re = v; re_bp = b; }
+          }
+        };
+        if (nb <= 2) block_ends(std::integral_constant<int, 2>());
+        else if (nb <= 4) block_ends(std::integral_constant<int, 4>());
+        else block_ends(std::integral_constant<int, BE_REG>());
+        for (int b = BE_REG; b < nb; ++b) {
+          const double v = (bperm_f64((lane_base + (int)l_blocks[1 * nb + b]) << 2, cur_v) + lp_re);
+          if (v > re) { re = v; re_bp = b; }
+        }
+        double br = NINF; int pr = 0xFF;
+        const double v0 = (start_now + lp_rs0), v1 = (re + lp_rs1);
+        if (v0 > br) { br = v0; pr = 0; }
+        if (v1 > br) { br = v1; pr = 1; }
+        if (is_run_end) { cur_v = re; best = re; bpi = re_bp; }
+        if (is_run_start) { cur_v = br; best = br; bpi = pr; }
+      }
+      HP_FILL(3);
+      {  // block starts: {run start, own block end}
+        const double s0 = bperm_f64(a_q0, cur_v), s1 = bperm_f64(a_q1, cur_v);
+        if (role_start) {
+          const double v0 = (s0 + lp0), v1 = (s1 + lp1);
+          if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+          if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+          cur_v = best;
+        }
+      }
+      HP_FILL(4);
+      if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
+      prev_v = cur_v;
+      HP_FILL(5);
+    }
+  } else
   for (int i = 0; i < L; ++i) {
     if ((i % HMM_CODE_WINDOW) == 0) {  // next window of symbol codes (one column more than the window: the look-ahead below)
       hmm_sync(sync_n);
@@ -1378,7 +1491,9 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
     if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
-    const void* kfn = half ? (const void*)hmm_viterbi_kernel<32> : (const void*)hmm_viterbi_kernel<64>;
+    const bool regs = !c->knobs.hmm_lds_fill;  // one-wave classes keep the score columns in registers (TRGT_HMM_LDS_FILL=1: in LDS like the others)
+    const void* kfn = half ? (regs ? (const void*)hmm_viterbi_kernel<32, true> : (const void*)hmm_viterbi_kernel<32, false>)
+                           : (regs && cls == 1 ? (const void*)hmm_viterbi_kernel<64, true> : (const void*)hmm_viterbi_kernel<64, false>);
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t ls = c->stream;
     if (n_class > 0) {
@@ -1393,11 +1508,13 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     KTimer t(c, TRGT_K_HMM, ls);
     const uint32_t nj = (uint32_t)(e - i);
     const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * cls);
-#define TRGT_HMM_LAUNCH(SB)                                                                                                      \
-    hipLaunchKernelGGL((hmm_viterbi_kernel<SB>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
+#define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
                        o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)nullptr)
-    if (half) TRGT_HMM_LAUNCH(32); else TRGT_HMM_LAUNCH(64);
+    if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
+    else if (regs && cls == 1) TRGT_HMM_LAUNCH(64, true);
+    else TRGT_HMM_LAUNCH(64, false);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(i == 0 ? cells : 0);
@@ -1546,7 +1663,9 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
     if (lds > 160 * 1024) return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_hmm_batch: LDS need %zu B", lds);
-    const void* kfn = half ? (const void*)hmm_viterbi_kernel<32> : (const void*)hmm_viterbi_kernel<64>;
+    const bool regs = !c->knobs.hmm_lds_fill;  // one-wave classes keep the score columns in registers (TRGT_HMM_LDS_FILL=1: in LDS like the others)
+    const void* kfn = half ? (regs ? (const void*)hmm_viterbi_kernel<32, true> : (const void*)hmm_viterbi_kernel<32, false>)
+                           : (regs && k == 1 ? (const void*)hmm_viterbi_kernel<64, true> : (const void*)hmm_viterbi_kernel<64, false>);
     if (lds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t ls = c->stream;
     if (n_class > 0) {
@@ -1561,11 +1680,13 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     KTimer t(c, TRGT_K_HMM, ls);
     const uint32_t nj = class_n[k];
     const dim3 grid(half ? (nj + 1) / 2 : nj), block(half ? 64 : 64 * k);
-#define TRGT_HMM_LAUNCH(SB)                                                                                                      \
-    hipLaunchKernelGGL((hmm_viterbi_kernel<SB>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
+#define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
+    hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
                        o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)(d_count + k))
-    if (half) TRGT_HMM_LAUNCH(32); else TRGT_HMM_LAUNCH(64);
+    if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
+    else if (regs && k == 1) TRGT_HMM_LAUNCH(64, true);
+    else TRGT_HMM_LAUNCH(64, false);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(0);
