@@ -53,6 +53,11 @@ struct trgt_knobs {
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency
   int lds_wfa_kb = 7;        // TRGT_WFA_LDS_KB: LDS of the LDS-arena variant for the wavefronts of one alignment
   int lds_wfa_seq = 768;     // TRGT_WFA_LDS_SEQ: ... for its two sequences (padded pattern + text)
+  // tools/unpinned_sensitivity.py: the decisions inside un-vendored dependencies that no reference test pins, flipped one at a time
+  int sens_bialign_min_len = -1;  // TRGT_SENS_BIALIGN_MIN_LEN: bialign_min_length of the consensus alignments / edit distances (default 100; SURVEY A.7 read literally: 0)
+  bool sens_cons_unidir = false;  // TRGT_SENS_CONS_UNIDIR: consensus alignments back-traced unidirectionally (MemoryHigh) instead of by BiWFA
+  bool sens_ward_ties = false;    // TRGT_SENS_WARD_TIES: nearest-neighbour ties of the Ward linkage go to the LAST candidate instead of the first
+  bool sens_lw_order = false;     // TRGT_SENS_LW_ORDER: the Lance-Williams update summed in another order (last bits of the matrix central_read reads)
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
   bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
@@ -86,7 +91,8 @@ struct trgt_hip_ctx {
   std::vector<hipEvent_t> retired_events;  // resolved timing events: neither destroyed nor re-recorded while calls are being timed (see resolve_timing)
   void* last_wfa_cells_dev = nullptr;
   void* last_filter_cells_dev = nullptr;
-  int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host-side phase timers of the last call (diagnostics)
+  int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t tl_t0 = 0;  // TRGT_TIMELINE: start of the call being traced (steady clock, ns)  // host-side phase timers of the last call (diagnostics)
   // trgt_locus_batch pipelines chunks of loci: stage A of chunk k+1 runs on `stream` while the host glue of chunk k and its
   // small transfers / gather kernel use `stream2`; pinned host buffers (slot-indexed like `pool`) make those copies asynchronous
   hipStream_t stream2 = nullptr;
@@ -182,6 +188,13 @@ inline hipError_t stream_wait(hipStream_t s) {
 inline hipError_t event_wait(hipEvent_t ev) {
   if (!poll_wait_knob()) return hipEventSynchronize(ev);
   return poll_until_ready([ev] { return hipEventQuery(ev); });
+}
+
+// TRGT_TIMELINE: a mark of the host-side timeline from inside the enqueue path (ms since the call started)
+inline void tl_mark(const trgt_hip_ctx* c, const char* name) {
+  if (!c->knobs.timeline || !c->tl_t0) return;
+  timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+  fprintf(stderr, "[tl]   . %-26s %7.3f ms\n", name, (double)((int64_t)t.tv_sec * 1000000000ll + t.tv_nsec - c->tl_t0) / 1e6);
 }
 
 inline bool is_device_ptr(const void* p) {

@@ -1570,6 +1570,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     count_total = std::max<uint64_t>(count_total, count_off[sl] + (sd.n_blocks - 1));
     span_total = std::max<uint64_t>(span_total, span_off[sl] + in.cap[sl >> 1] + 1);
   }
+  tl_mark(c, "hmm slots: counted");
   if (n_cand == 0) { P->n_jobs = 0; return TRGT_OK; }
   void* h_cand = nullptr;
   int rc;
@@ -1594,6 +1595,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       }
     }
   }
+  tl_mark(c, "hmm slots: candidates");
   if (bp_total > c->ws_limit) return fail(c, TRGT_ERR_NOMEM, "trgt_hmm_batch: back-pointer workspace %llu B exceeds limit", (unsigned long long)bp_total);
   void *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
   const size_t jobs_bytes = (size_t)n_cand * sizeof(HmmJobDev);
@@ -1651,6 +1653,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     hipLaunchKernelGGL(hmm_resolve_scatter_kernel, rg, dim3(256), 0, c->stream, ra);
   }
   TRGT_HIP_TRY(c, hipGetLastError());
+  tl_mark(c, "hmm slots: resolve launched");
   if (!c->hmm_fork[buffer_set ? 1 : 0]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork[buffer_set ? 1 : 0], hipEventDisableTiming));
   TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork[buffer_set ? 1 : 0], c->stream));  // (behind the resolve kernel, in front of the first launch)
   int n_class = 0;
@@ -1696,6 +1699,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
     }
+  tl_mark(c, "hmm slots: classes launched");
   if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), P->tight_off.data(), n_slots, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();
   return TRGT_OK;

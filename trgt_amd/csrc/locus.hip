@@ -283,6 +283,13 @@ bool flank_simple_consensus(const std::vector<Seg>& seqs, Seg& best, double& fre
   return true;
 }
 
+// Developer switches of tools/unpinned_sensitivity.py: the two readings of WFA2-lib's BiWFA that no reference test pins, applied
+// to the consensus alignments and edit distances of the locus path
+inline void sens_apply(const trgt_hip_ctx* c, trgt_wfa_params& wp) {
+  if (c->knobs.sens_bialign_min_len >= 0) wp.bialign_min_length = c->knobs.sens_bialign_min_len;
+  if (c->knobs.sens_cons_unidir && wp.scope == 1) wp.memory_mode = 0;
+}
+
 #include "consensus_vote.hpp"
 static_assert(sizeof(vote::Group) == sizeof(gt::RGroup) && offsetof(vote::Group, bb_off) == offsetof(gt::RGroup, bb_off) &&
               offsetof(vote::Group, out_off) == offsetof(gt::RGroup, out_off) && offsetof(vote::Group, scratch_off) == offsetof(gt::RGroup, scratch_off) &&
@@ -300,7 +307,7 @@ int consensus_repair_batch(trgt_hip_ctx* c, int64_t n_jobs, const uint8_t* seqs,
   if (n_jobs == 0 || n_groups == 0) { if (while_running && *while_running) return (*while_running)(); return TRGT_OK; }
   trgt_wfa_params wp;
   trgt_wfa_default_params(&wp);
-  wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+  wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3; sens_apply(c, wp);
   const bool tl_on = c->knobs.timeline;
   const int64_t tl0 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 #define RTL(name) do { if (tl_on) fprintf(stderr, "[tl]     repair %-20s +%7.2f ms\n", name, (double)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() - tl0) / 1e6); } while (0)
@@ -574,6 +581,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   threads = std::min(threads, !c->knobs.host_genotyper && p->min_read_qual >= 0.9 ? 8 : 32);
   HostPool* pool = host_pool(c, threads);
   const int64_t t0 = now_ns();
+  c->tl_t0 = t0;
   const bool tl_on = c->knobs.timeline;
 #define TL(name) do { if (tl_on) fprintf(stderr, "[tl] %-28s %7.2f ms  ctx=%p\n", name, (double)(now_ns() - t0) / 1e6, (void*)c); } while (0)
   int64_t tA = 0, tB = 0, tC = 0, tHost = 0;
@@ -756,6 +764,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // the order they were issued)
   if (!c->stream_copy) TRGT_HIP_TRY(c, trgt::make_stream(c, &c->stream_copy));
   if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+  tl_mark(c, "find_spans enqueued");
   if ((rc = hmm_models_on_device(c, (int32_t)nl, in->motif_blob, in->motif_off, in->set_motif_begin, models, c->stream_copy, c->ev_upload)))
     return models.err.empty() ? rc : fail(c, rc, "%s", models.err.c_str());
   TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
@@ -813,6 +822,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     if (small_gt) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     else hipLaunchKernelGGL((gt::locus_genotype_kernel<gt::GT_MAX_READS, gt::GT_SEG_LDS>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
     TRGT_HIP_TRY(c, hipGetLastError());
+    tl_mark(c, "genotyper launched");
     // Two ways to order the HMM of the settled loci and the repair of the others: one HMM batch behind the repair (default), or -- split_hmm,
     // TRGT_SPLIT_HMM=1 -- the HMM of the settled loci on a stream of its own next to the repair and a second batch for the repaired loci.
     // Measured: the split costs more in extra launches and streams than the overlap gives back, on every config.
@@ -846,7 +856,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       struct SwapBackRp { trgt_hip_ctx* c; bool on; ~SwapBackRp() { if (on) std::swap(c->stream, c->stream2); } } swap_back_rp{c, split};
       trgt_wfa_params wp;
       trgt_wfa_default_params(&wp);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86): BiWFA, gap-affine 2,5,1, default heuristic
-      wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3;
+      wp.metric = 3; wp.mismatch = 2; wp.gap_open1 = 5; wp.gap_ext1 = 1; wp.span = 0; wp.scope = 1; wp.memory_mode = 3; sens_apply(c, wp);
       WfaLaunch LR;
       // (n_jobs_host bounds the workgroups and their workspaces, not the jobs: the count is read on the device)
       LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS; LR.jobs_bound = rp.cap_jobs;
@@ -884,6 +894,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       else hipLaunchKernelGGL((gt::repair_finish_kernel<gt::GT_MAX_READS>), fgrid, dim3(64), 0, c->stream, ga, fa);
       TRGT_HIP_TRY(c, hipGetLastError());
       if ((rc = dbg_sync("vote + finish"))) return rc;
+      tl_mark(c, "repair chain enqueued");
       TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_rpc), rp.counts, gt::RC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
       if (split) {
         TRGT_HIP_TRY(c, hipEventRecord(c->ev_rp, c->stream));  // (the results the host waits for do not wait for the second HMM batch)
@@ -905,6 +916,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       cl::ClArgs ca;
       std::memset(&ca, 0, sizeof ca);
       ca.g = ga; ca.list = d_cl_list; ca.n_list = n_cl; ca.mat_off = d_cl_moff;
+      ca.flags = (c->knobs.sens_ward_ties ? 1u : 0u) | (c->knobs.sens_lw_order ? 2u : 0u);
       ca.cap_j = (uint32_t)cl_reads; ca.cap_g = 2 * n_cl; ca.vote_lds_pos = (uint32_t)vote::VOTE_LDS_POS;
       // arenas for two consensus rounds at worst-case slots per alignment, bounded: a locus that finds no room takes the host path
       ca.cap_cigar = std::min<uint64_t>(2ull * cl_reads * (2ull * max_seg + 1), 96ull << 20);   // words
@@ -933,10 +945,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       const int64_t ed_len = (int64_t)std::min<uint64_t>(max_seg, cl::CL_MAX_OPS);
       trgt_wfa_params wed;
       trgt_wfa_default_params(&wed);  // THREAD_WFA_ED (genotype.rs:88-92): edit distance, score only, BiWFA, default heuristic
-      wed.metric = 1; wed.span = 0; wed.scope = 0; wed.memory_mode = 3;
+      wed.metric = 1; wed.span = 0; wed.scope = 0; wed.memory_mode = 3; sens_apply(c, wed);
       trgt_wfa_params wco;
       trgt_wfa_default_params(&wco);  // THREAD_WFA_CONSENSUS (genotype.rs:82-86)
-      wco.metric = 3; wco.mismatch = 2; wco.gap_open1 = 5; wco.gap_ext1 = 1; wco.span = 0; wco.scope = 1; wco.memory_mode = 3;
+      wco.metric = 3; wco.mismatch = 2; wco.gap_open1 = 5; wco.gap_ext1 = 1; wco.span = 0; wco.scope = 1; wco.memory_mode = 3; sens_apply(c, wco);
       auto ed_launch = [&](const JobDev* jobs, uint64_t bound, const uint32_t* count, const uint8_t* txt_base, int32_t* score) -> int {
         WfaLaunch LE;
         LE.jobs_dev = jobs; LE.n_jobs_host = std::min<int64_t>((int64_t)std::max<uint64_t>(bound, 1), wg_bound); LE.n_jobs_dev = count; LE.jobs_bound = (int64_t)std::max<uint64_t>(bound, 1);
@@ -968,6 +980,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       if (big) hipLaunchKernelGGL((cl::cluster_finish_kernel<gt::GT_MAX_READS>), cgrid, dim3(64), 0, c->stream, ca);
       else hipLaunchKernelGGL((cl::cluster_finish_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
       TRGT_HIP_TRY(c, hipGetLastError());
+      tl_mark(c, "cluster chain enqueued");
       TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_clc), ca.counts, cl::CC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
     } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_clc), 0, cl::CC_WORDS * 4, c->stream));
     hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));

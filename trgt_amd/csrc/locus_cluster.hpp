@@ -173,7 +173,7 @@ struct ClusterBatch {
     if (refs.empty()) return TRGT_OK;
     trgt_wfa_params wp;
     trgt_wfa_default_params(&wp);  // THREAD_WFA_ED: Score scope, MemoryUltraLow, edit, default heuristic (genotype.rs:88-92)
-    wp.metric = 1; wp.span = 0; wp.scope = 0; wp.memory_mode = 3;
+    wp.metric = 1; wp.span = 0; wp.scope = 0; wp.memory_mode = 3; sens_apply(c, wp);
     std::vector<int32_t> score(refs.size());
     const int rc = trgt_wfa_batch(c, &wp, (int64_t)refs.size(), blob.data(), poff.data(), plen.data(), toff.data(), tlen.data(), nullptr,
                                   score.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

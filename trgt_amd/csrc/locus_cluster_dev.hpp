@@ -55,6 +55,7 @@ struct ClArgs {
   JobDev* ed2_jobs; int32_t* escore2;     // dropped reads against both alleles: slot 2 * (read of the batch) + allele
   const uint8_t* vote_out; const uint32_t* vote_len;
   uint64_t cap_cigar, cap_out, cap_scratch; uint32_t vote_lds_pos;
+  uint32_t flags;  // tools/unpinned_sensitivity.py: 1 = nearest-neighbour ties to the last candidate, 2 = Lance-Williams summed in another order
 };
 
 template <int MAXR>
@@ -220,15 +221,16 @@ __global__ void __launch_bounds__(64) cluster_ward_kernel(const ClArgs a) {
       __syncthreads();
       const double inf = __builtin_huge_val();
       // smallest D(i, cur) over the active i != cur, and the smallest such i among equals
+      const bool ties_last = (a.flags & 1u) != 0, lw_alt = (a.flags & 2u) != 0;
       auto scan = [&](int cur, double& vmin, int& imin) {
         double bv = inf; int bi = -1;
         for (int t = 0; t < T; ++t) {
           const int i = lane * T + t;
-          if (i < n && i != cur && sh.act[i]) { const double v = D[pair_sym(un, (uint32_t)i, (uint32_t)cur)]; if (v < bv) { bv = v; bi = i; } }
+          if (i < n && i != cur && sh.act[i]) { const double v = D[pair_sym(un, (uint32_t)i, (uint32_t)cur)]; if (v < bv || (ties_last && v == bv)) { bv = v; bi = i; } }
         }
         vmin = wave_min_f64(bv);
         const unsigned long long mask = __ballot(bi >= 0 && bv == vmin);
-        const int src = mask ? __ffsll((long long)mask) - 1 : 0;
+        const int src = mask ? (ties_last ? 63 - (int)__builtin_clzll(mask) : __ffsll((long long)mask) - 1) : 0;
         imin = __shfl(bi, src);
       };
       int chain_len = 0;
@@ -265,7 +267,8 @@ __global__ void __launch_bounds__(64) cluster_ward_kernel(const ClArgs a) {
             const double d_lo = D[pair_sym(un, (uint32_t)x, (uint32_t)lo)];
             double* const ph = D + pair_sym(un, (uint32_t)x, (uint32_t)hi);
             const double d_hi = *ph;
-            *ph = (((sx + s_lo) * d_lo) + ((sx + s_hi) * d_hi) - (sx * best)) / (s_lo + s_hi + sx);
+            *ph = lw_alt ? (((sx + s_lo) * d_lo) - (sx * best) + ((sx + s_hi) * d_hi)) / (sx + (s_lo + s_hi))
+                         : (((sx + s_lo) * d_lo) + ((sx + s_hi) * d_hi) - (sx * best)) / (s_lo + s_hi + sx);
           }
         }
         __syncthreads();

@@ -606,6 +606,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     TRGT_HIP_TRY(c, hipGetLastError());
     t.stop(0);
   }
+  tl_mark(c, "scan launched");
   trgt_wfa_params wp;
   trgt_wfa_default_params(&wp);  // THREAD_WFA_FLANK (genotype.rs:66-80)
   wp.metric = 3; wp.mismatch = p.mism; wp.gap_open1 = p.gapo; wp.gap_ext1 = p.gape;
@@ -709,6 +710,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       FL.pat_base = d_flank; FL.txt_base = d_reads; FL.max_plen = p.flank_len; FL.max_tlen = std::min<int64_t>(heavy_tlen_max, flt_tlen);
       FL.mism = p.mism; FL.gapo = p.gapo; FL.gape = p.gape; FL.count_offsets = c->timing; FL.min_matches = (int32_t)min_matches; FL.early_reject = !c->knobs.no_early; FL.keep_jobs = (JobDev*)d_keepjobs; FL.keep_count = (uint32_t*)d_count + SC_KEEP;
       if ((rc = flank_filter_launch(c, FL))) return rc;
+      tl_mark(c, "filter launched");
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + SC_KEEP;
     }
     // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
@@ -716,6 +718,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     LH.threads = c->knobs.heavy_threads > 0 ? c->knobs.heavy_threads : (L.threads == 256 ? 192 : L.threads);
     if (two_streams) LH.buffer_set = 1;
     if ((rc = wfa_launch(c, wp, LH))) return rc;
+    tl_mark(c, "heavy launch");
     cells_heavy = c->last_wfa_cells_dev;
     if (two_streams) {
       TRGT_HIP_TRY(c, hipEventRecord(c->ev_heavy, c->stream));
@@ -750,6 +753,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       trgt_wfa_params wpw = wp;
       wpw.text_begin_free = 2 * win_margin + win_spread;
       if ((rc = wfa_launch(c, wpw, LW))) return rc;
+      tl_mark(c, "window launch");
       L.keep_cells = true;
       WinCheckArgs wc;
       wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + SC_WIN; wc.score = (const int32_t*)d_score;
@@ -762,6 +766,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     }
   }
   if ((rc = wfa_launch(c, wp, L))) return rc;
+  tl_mark(c, "rest launch");
   if (!split) TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
   if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
     WfaLaunch L2 = L;
