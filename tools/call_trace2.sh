@@ -1,9 +1,9 @@
 #!/bin/bash
-# call_trace2.sh CONFIG [WINDOW_MS] [MIN_MS]: kernel trace of tools/timeline.py CONFIG; kernels (>= 0.15 ms) of the last WINDOW_MS of the run with start, duration, stream, queue
-CFG=${1:-3}; WIN=${2:-70}; MIN=${3:-0.15}
+# call_trace2.sh CONFIG [WINDOW_MS] [MIN_MS] [N_LOCI]: kernel trace of tools/timeline.py CONFIG; kernels (>= 0.15 ms) of the last WINDOW_MS of the run with start, duration, stream, queue
+CFG=${1:-3}; WIN=${2:-70}; MIN=${3:-0.15}; NL=${4:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/calltrace2; rm -rf $O; mkdir -p $O; cd $R
-rocprofv3 --kernel-trace --output-format csv -d $O/k -o k -- python tools/timeline.py $CFG > $O/t.out 2> $O/t.err
+rocprofv3 --kernel-trace --output-format csv -d $O/k -o k -- python tools/timeline.py $CFG $NL > $O/t.out 2> $O/t.err
 grep -E "evA|stageB|hmm2 enq|collected" $O/t.err | tail -5
 python - "$(find $O/k -name '*kernel_trace.csv' | head -1)" $WIN $MIN <<'PY'
 import csv, sys
