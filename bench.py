@@ -254,7 +254,7 @@ def run_e2e(args, env):
         rd = ingest.Reader(ds["bam"], ds["fasta"])
         firsts = list(range(0, n, chunk))
         ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256 -- under the box's CFS quota of 16 CPUs (cpu_quota()): 15 x one thread is all the quota gives
-        ing = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
+        ing = lambda a, th=ing_threads, dev=-1: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1, inflate_device=dev)
         ing(0)  # page cache, thread start-up
         t0 = time.perf_counter()
         one = ing(0, 1)
@@ -262,6 +262,15 @@ def run_e2e(args, env):
         t0 = time.perf_counter()
         batches = [ing(a) for a in firsts]
         t_ing = time.perf_counter() - t0
+        # ... and with the BGZF blocks of a chunk inflated on the GPU in one batch (trgt_ingest_params.inflate_device, inflate_dev.hip): the
+        # workers then only decode records
+        dev = env["local_rank"]
+        ing(0, ing_threads, dev)
+        t0 = time.perf_counter()
+        batches_d = [ing(a, ing_threads, dev) for a in firsts]
+        t_ing_dev = time.perf_counter() - t0
+        same_batches = all(int(x["n_reads"]) == int(y["n_reads"]) and np.array_equal(x["read_blob"], y["read_blob"]) and np.array_equal(x["read_off"], y["read_off"]) for x, y in zip(batches, batches_d))
+        del batches_d
         views = [ingest.bam4_view(b) for b in batches]
         ctx = _lib.Context(env["local_rank"])
         params = locus.Params(host_threads=min(8, cores))
@@ -290,10 +299,10 @@ def run_e2e(args, env):
         # ---- pipeline: ingest | GPU | write, chunk queues of depth 2
         q1, q2, err = queue.Queue(2), queue.Queue(2), []
 
-        def stage_ingest():
+        def stage_ingest(dev_inflate=-1):
             try:
                 for a in firsts:
-                    q1.put(ing(a))
+                    q1.put(ing(a, ing_threads, dev_inflate))
             except Exception as e:  # noqa: BLE001
                 err.append(e)
             q1.put(None)
@@ -309,29 +318,37 @@ def run_e2e(args, env):
                 err.append(e)
             q2.put(None)
 
-        w = writers.Writer(rd, os.path.join(d, "out2.vcf"), os.path.join(d, "out2.spanning.bam"))
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=stage_ingest, daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
-        for t in th:
-            t.start()
-        while True:
-            item = q2.get()
-            if item is None:
-                break
-            w.write(*item)
-        w.close()
-        for t in th:
-            t.join()
-        t_pipe = time.perf_counter() - t0
-        if err:
-            raise err[0]
-        same = open(os.path.join(d, "out.vcf")).read() == open(os.path.join(d, "out2.vcf")).read()
+        def pipeline(tag, dev_inflate, level):
+            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level)
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=stage_ingest, args=(dev_inflate,), daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
+            for t in th:
+                t.start()
+            while True:
+                item = q2.get()
+                if item is None:
+                    break
+                w.write(*item)
+            w.close()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            if err:
+                raise err[0]
+            return dt, open(os.path.join(d, "out.vcf")).read() == open(os.path.join(d, tag + ".vcf")).read()
+
+        t_pipe, same = pipeline("out2", -1, 6)           # as rounds 1-3 measured it: host inflate, htslib's BAM level
+        t_pipe_fast, same_fast = pipeline("out3", -1, 1)  # the spanning BAM at level 1 (trgt_writer_params.bam_compress_level: a larger file with the same records)
+        t_pipe_dev, same_dev = pipeline("out4", dev, 1)   # ... and the BGZF blocks inflated on the GPU
+        same = same and same_dev and same_fast
         r = lambda x: round(x, 1)
         return dict(
             workload="%d cfg2-like loci (motif 2-6 bp, 5-40 copies per allele), %d reads of ~%d bases per locus, one contig; BAM %.1f MB (%d reads, %.0f MB of records), written by trgt_amd/synth_bam.py in %.1f s"
                      % (n, 30, args.e2e_read_len, ds["bam_bytes"] / 1e6, ds["n_reads"], ds["bases"] / 1e6, t_gen),
             chunk_loci=chunk, ingest_threads=ing_threads, host_cores=cores, host_cpu_quota=cpu_quota(),
             ingest_loci_per_s=r(n / t_ing), ingest_loci_per_s_one_thread=r(1.0 / t_ing1), ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing),
+            ingest_loci_per_s_device_inflate=r(n / t_ing_dev), ingest_device_inflate_same_batches=bool(same_batches),
+            pipeline_loci_per_s_bam_level_1=r(n / t_pipe_fast), pipeline_loci_per_s_bam_level_1_device_inflate=r(n / t_pipe_dev),
             gpu_loci_per_s=r(n / t_gpu), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
             bound="host: BGZF inflate + record decoding (ingestion) and deflate (spanning BAM); the GPU stage is >10x faster than either, see DESIGN.md")

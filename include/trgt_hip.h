@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 7
+#define TRGT_HIP_ABI_VERSION 8
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -319,6 +319,9 @@ typedef struct trgt_ingest_params {
   int32_t genotyper;       /* 0 size, 1 cluster: copied into trgt_ingest_batch::genotyper for every locus */
   int32_t default_ploidy;  /* 2 (the karyotype logic of locus.rs:216-240 stays with the caller: overwrite ploidy[] for X / Y loci) */
   int32_t keep_bam4;       /* 0; 1 = also fill read_bam4 / read_bam4_off: the clipped reads as 4-bit codes for TRGT_READS_BAM4 */
+  int32_t inflate_device;  /* ABI 8: -1 (default) = BGZF blocks are inflated by the worker threads as they meet them; >= 0 = the blocks the .bai
+                              names for the loci of the call are read, inflated on that GPU in one batch (trgt_inflate_blocks) and kept for the
+                              workers, which then only decode records; a block the device declines is inflated by the worker that meets it */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;
@@ -385,6 +388,8 @@ typedef struct trgt_writer_params {
                                  rust-htslib is un-vendored and no reference-produced BAM is on disk: parity of this bit is UNPINNED, hence the switch */
   int32_t threads;            /* 0 = min(32, cores): workers that format the loci of a batch (contiguous ranges, written in locus order) and
                                  deflate its BGZF blocks; the files do not depend on it */
+  int32_t bam_compress_level; /* ABI 8: 6 (default: htslib's level for BAM) ... 1 (fast), 0 = stored DEFLATE blocks: the same records in a
+                                 larger file, for pipelines whose spanning BAM is transient; the VCF (.gz) always uses 6 */
 } trgt_writer_params;
 void trgt_writer_default_params(trgt_writer_params* p);
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);
@@ -428,6 +433,15 @@ int32_t trgt_median_i32(const int32_t* data, int64_t n, float* out);
  * 1 = done, 0 = declined -- ingestion then lets zlib decide), mode 1 = zlib.  Exported for tests/test_inflate.py; htslib's bgzf_read_block
  * is what it stands in for (the reference reads BAM through rust-htslib). */
 int32_t trgt_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t n_out, int32_t mode);
+
+/* ABI 8 -- device-side BGZF inflate (trgt_amd/csrc/inflate_dev.hip): n_blocks independent raw DEFLATE streams (the payloads of BGZF
+ * blocks: what htslib's bgzf_read_block inflates one by one for bam::IndexedReader, src/trgt/workflows/tr.rs:268-305), block b from
+ * src + src_off[b] (src_len[b] bytes) into dst + dst_off[b] (exactly dst_len[b] <= 65536 bytes); src / dst host or device memory.
+ * status[b] = 1: inflated; 0: declined (a stream the device decoder does not take, or a damaged one: hand it to zlib, which yields
+ * the data or the error).  One wave per block, Huffman tables and the LZ77 window in LDS.  Synchronous.  trgt_ingest_params.
+ * inflate_device makes the ingestion use it for the blocks of a whole batch of loci at once. */
+int trgt_inflate_blocks(trgt_hip_ctx* ctx, int64_t n_blocks, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len,
+                        uint8_t* dst, const uint64_t* dst_off, const uint32_t* dst_len, uint8_t* status);
 
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {

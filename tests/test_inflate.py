@@ -120,3 +120,96 @@ def test_damaged_streams_are_never_inflated_wrongly():
                 ref = None
             assert ref is not None and d.eof and ref == got and len(got) == n_out, (trial, kind)
     assert ok >= 50  # (the trailing-bytes and unchanged cases)
+
+
+# ---- the device-side decoder (trgt_amd/csrc/inflate_dev.hip, trgt_inflate_blocks): the same vectors through the GPU
+@pytest.mark.gpu
+def test_device_streams_of_every_kind_equal_zlib():
+    from trgt_amd import _lib, ingest
+    ctx = _lib.Context(0)
+    streams, datas = [], []
+    for data in _corpus():
+        data = data[:65536]
+        for level in (0, 1, 2, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                streams.append(_raw(data, level, strategy)); datas.append(data)
+    got, status = ingest.inflate_blocks(ctx, streams, [len(d) for d in datas])
+    n_ok = 0
+    for g, d, st in zip(got, datas, status):
+        assert st in (0, 1)
+        if st == 1:
+            assert g == d
+            n_ok += 1
+    assert n_ok >= len(streams) - 8, (n_ok, len(streams))  # (declined: the few streams with an incomplete code it leaves to zlib)
+
+
+@pytest.mark.gpu
+def test_device_bam_blocks_equal_zlib(tmp_path):
+    from trgt_amd import _lib, ingest, synth_bam
+    ctx = _lib.Context(0)
+    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=40, read_len=3000)
+    paths = [ds["bam"], os.path.join(os.path.dirname(__file__), "golden", "example", "sample.bam")]
+    streams, want = [], []
+    for path in paths:
+        raw = open(path, "rb").read()
+        p = 0
+        while p < len(raw):
+            bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+            comp = raw[p + 18:p + bsize - 8]
+            streams.append(comp); want.append(zlib.decompress(comp, -15))
+            p += bsize
+    got, status = ingest.inflate_blocks(ctx, streams, [len(w) for w in want])
+    assert len(streams) > 40 and int((status == 0).sum()) <= 2
+    for g, w, st in zip(got, want, status):
+        assert st == 0 or g == w
+
+
+@pytest.mark.gpu
+def test_device_damaged_streams_are_never_inflated_wrongly():
+    from trgt_amd import _lib, ingest
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(5)
+    data = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20000)]) + b"CAG" * 500
+    comp = bytearray(_raw(data, 6))
+    streams, sizes, kinds = [], [], []
+    for trial in range(400):
+        bad = bytearray(comp)
+        kind = trial % 4
+        if kind == 0:
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            bad = bad[:int(rng.integers(1, len(bad)))]
+        elif kind == 2:
+            bad += bytes(rng.integers(0, 256, 5, dtype=np.uint8))
+        n_out = len(data) + (0 if kind != 3 else int(rng.integers(-3, 4)))
+        streams.append(bytes(bad)); sizes.append(max(n_out, 0)); kinds.append(kind)
+    got, status = ingest.inflate_blocks(ctx, streams, sizes)
+    ok = 0
+    for g, st, bad, n_out, kind in zip(got, status, streams, sizes, kinds):
+        if st == 1:
+            ok += 1
+            d = zlib.decompressobj(-15)
+            try:
+                ref = d.decompress(bad)
+            except zlib.error:
+                ref = None
+            assert ref is not None and d.eof and ref == g and len(g) == n_out, kind
+    assert ok >= 50
+
+
+@pytest.mark.gpu
+def test_ingestion_with_device_inflate_gives_the_same_batch(tmp_path):
+    from trgt_amd import ingest, synth_bam
+    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=60, read_len=3000)
+    rd = ingest.Reader(ds["bam"], ds["fasta"])
+    a = rd.batch(ds["bed"], keep_bam4=1)
+    b = rd.batch(ds["bed"], keep_bam4=1, inflate_device=0)
+    c = rd.batch(ds["bed"], first_locus=10, max_loci=25, inflate_device=0)   # a second call: staging reused, readers kept
+    a2 = rd.batch(ds["bed"], first_locus=10, max_loci=25)
+    for x, y in ((a, b), (a2, c)):
+        assert x["n_loci"] == y["n_loci"] and x["n_reads"] == y["n_reads"] and x["n_reads"] > 100
+        for k in x:
+            if isinstance(x[k], np.ndarray):
+                assert np.array_equal(x[k], y[k], equal_nan=True) if x[k].dtype.kind == "f" else np.array_equal(x[k], y[k]), k
+            elif isinstance(x[k], list):
+                assert x[k] == y[k], k

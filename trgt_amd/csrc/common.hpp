@@ -222,6 +222,7 @@ enum Slot {
   S_RP_GROUPS, S_RP_JOBS, S_RP_LOCI, S_RP_PEND, S_RP_CIGAR, S_RP_CLEN, S_RP_VOUT, S_RP_VLEN, S_RP_VSCR, S_RP_COUNTS,  // device-side consensus repair (locus_gt.hpp)
   S_CL_LIST, S_CL_MOFF, S_CL_COUNTS, S_CL_REC, S_CL_CLS, S_CL_ESCORE, S_CL_GMAT, S_CL_EDJOBS, S_CL_JOBS, S_CL_GROUPS, S_CL_ED2JOBS, S_CL_ESCORE2, S_CL_CIGAR, S_CL_CLEN,
   S_CL_VOUT, S_CL_VLEN, S_CL_VSCR,  // device-side cluster genotyper (locus_cluster_dev.hpp)
+  S_INF_SRC, S_INF_DESC, S_INF_DST, S_INF_STATUS, S_INF_COUNTER,  // device-side BGZF inflate (inflate_dev.hip)
   S_COUNT
 };
 // pinned host buffer slots

@@ -1,0 +1,332 @@
+// trgt_amd/csrc/inflate_dev.hip -- raw DEFLATE (RFC 1951) of many independent blocks on the device: the BGZF blocks of a BAM.
+//
+// Replaces, for the read ingestion of SURVEY.md 8(f) row 3, what the reference does inside htslib's bgzf_read_block (rust-htslib ->
+// htslib -> zlib inflate; src/trgt/workflows/tr.rs:268-305 reaches it through bam::IndexedReader::fetch / records()): every BGZF block
+// is a DEFLATE stream of its own (at most 64 KB inflated), so a chunk of loci is a few thousand independent streams.
+//
+// One wave per block, blocks claimed from a counter.  The Huffman decoding itself is a serial dependent chain (the position of a code
+// depends on the length of the one before) and runs on lane 0; what parallelises is done by the whole wave at rendezvous points of a
+// uniform loop: loading the next window of compressed bytes into LDS, filling the lookup tables of a dynamic block, copying stored
+// blocks, and flushing finished 16-KB segments of the output.  The last 32 KB of output live in an LDS ring (the LZ77 window: matches
+// are LDS-to-LDS byte copies), so a block needs 40 KB of LDS and four blocks are in flight per CU -- one per SIMD: the decode loop is
+// latency-bound (a table lookup per symbol), and more waves is what hides it.
+// A stream this decoder does not like (bad code lengths, distance too far back, output not exactly the announced size) is DECLINED
+// (status 0): the caller hands that block to zlib, which produces the data or the error message.
+#include "common.hpp"
+#include "inflate_dev.hpp"
+
+namespace trgt {
+namespace infl {
+
+constexpr uint32_t RING = 32768, RING_MASK = RING - 1, SEG = 16384;
+constexpr uint32_t IN_WIN = 3072;        // compressed bytes staged in LDS
+constexpr uint32_t HDR_ROOM = 1024;      // a dynamic block header (<= 19 * 3 + 320 * 14 bits) is parsed without a reload in between
+constexpr int LIT_BITS = 10, DIST_BITS = 8;
+
+enum : uint32_t { EV_NONE = 0, EV_RELOAD = 1, EV_FLUSH = 2, EV_BUILD = 3, EV_COPY = 4, EV_DONE = 5, EV_ERROR = 6 };
+
+struct Shared {
+  uint32_t ev;            // what lane 0 asks the wave for
+  uint32_t win_base;      // source offset of in_win[0]
+  uint32_t op;            // bytes produced so far
+  uint32_t copy_src, copy_dst, copy_len;  // EV_COPY: stored bytes src[copy_src ..) -> out[copy_dst ..)
+  uint32_t nlit, ndist;   // EV_BUILD
+  uint32_t block;         // the claimed block
+  uint16_t lit_tab[1 << LIT_BITS], dist_tab[1 << DIST_BITS];  // symbol << 4 | code length (0: longer than the table's bits)
+  uint16_t lit_cnt[16], dist_cnt[16];     // codes per length (canonical decoding of the long codes, and the checks)
+  uint16_t lit_sym[288], dist_sym[32];    // symbols in code order
+  uint16_t code[320];                     // canonical code of every symbol (table fill)
+  uint8_t lens[320], lens2[320];
+  alignas(16) uint8_t in_win[IN_WIN + 16];
+  alignas(16) uint8_t out[RING];
+};
+
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // RFC 1951 3.2.7
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __builtin_bitreverse32(v) >> (32 - n); }
+
+// canonical decoding bit by bit (codes longer than the table's bits: rare symbols by construction)
+__device__ __forceinline__ int slow_decode(const uint16_t* cnt, const uint16_t* sym, uint64_t bits, int& len_out) {
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; ++len) {
+    code |= (int)(bits & 1); bits >>= 1;
+    const int c = cnt[len];
+    if (code - c < first) { len_out = len; return sym[index + (code - first)]; }
+    index += c; first += c; first <<= 1; code <<= 1;
+  }
+  len_out = 0;
+  return -1;
+}
+
+// code lengths -> counts, symbols in code order, canonical codes; false: over-subscribed or incomplete (a single distance code is
+// allowed to be incomplete, RFC 1951 3.2.7)
+__device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, uint16_t* sym, uint16_t* code, bool dist) {
+  for (int l = 0; l < 16; ++l) cnt[l] = 0;
+  for (int s = 0; s < n; ++s) cnt[lens[s]] += 1;
+  if (cnt[0] == n) return dist;  // no codes at all: fine for distances of an all-literal block
+  int left = 1;
+  for (int l = 1; l <= 15; ++l) { left <<= 1; left -= cnt[l]; if (left < 0) return false; }
+  if (left > 0 && !(dist && n - cnt[0] == 1)) return false;
+  uint16_t offs[16], next[16];
+  offs[1] = 0; next[1] = 0;
+  for (int l = 1; l < 15; ++l) { offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); next[l + 1] = (uint16_t)((next[l] + cnt[l]) << 1); }
+  for (int s = 0; s < n; ++s) {
+    const int l = lens[s];
+    if (l) { sym[offs[l]++] = (uint16_t)s; code[s] = next[l]++; }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                            uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter) {
+  __shared__ Shared sh;
+  const int lane = threadIdx.x;
+  for (;;) {
+    __syncthreads();
+    if (lane == 0) sh.block = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t bi = sh.block;
+    if (bi >= n_blocks) return;
+    const BlockDesc bd = blocks[bi];
+    const uint8_t* __restrict__ in = src + bd.src_off;
+    uint8_t* __restrict__ outp = dst + bd.dst_off;
+    const uint32_t in_len = bd.src_len, out_len = bd.dst_len;
+    // lane 0's decoder state (registers; the other lanes carry copies they never use)
+    uint64_t bitbuf = 0; uint32_t bitcnt = 0, in_pos = 0, op = 0, wb = 0, pending_skip = 0, stored_left = 0;
+    int phase = 0;           // 0: at a block header, 1: inside a Huffman block, 2: inside a stored block
+    bool final_block = false, have_window = false;
+    uint32_t flushed = 0;    // uniform
+    bool ok = out_len <= 65536u;
+    for (;;) {
+      // ---- lane 0 decodes until it needs the wave
+      if (lane == 0) {
+        uint32_t want = ok ? (uint32_t)EV_NONE : (uint32_t)EV_ERROR;
+        auto refill = [&]() {
+          if (bitcnt < 32) {
+            const uint32_t o = in_pos - wb;
+            const uint32_t a = *reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u)), b = *reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u) + 4);
+            const uint32_t w = (uint32_t)((((uint64_t)b << 32) | a) >> (8 * (o & 3u)));
+            bitbuf |= (uint64_t)w << bitcnt; bitcnt += 32; in_pos += 4;
+          }
+        };
+        auto take = [&](uint32_t n) { const uint32_t v = (uint32_t)(bitbuf & ((1ull << n) - 1ull)); bitbuf >>= n; bitcnt -= n; return v; };
+        // the window must hold `room` more bytes (unless it already reaches the end of the input: zeros follow)
+        auto window_low = [&](uint32_t room) { return in_pos + room > wb + IN_WIN && wb + IN_WIN < in_len + 8; };
+        if (!have_window) { have_window = true; if (want == EV_NONE) want = EV_RELOAD; }
+        else if (pending_skip) {  // behind a reload: the consumed bits of the first byte are dropped again
+          const uint32_t byte = sh.in_win[in_pos - wb];
+          bitbuf = (uint64_t)(byte >> pending_skip); bitcnt = 8u - pending_skip; in_pos += 1; pending_skip = 0;
+        }
+        while (want == EV_NONE) {
+          if (in_pos > in_len + 8) { want = EV_ERROR; break; }
+          if (phase == 0) {
+            // ---- block header (a dynamic one is parsed without a reload in between)
+            if (window_low(HDR_ROOM)) { want = EV_RELOAD; break; }
+            refill();
+            final_block = take(1) != 0;
+            const uint32_t type = take(2);
+            if (type == 0) {
+              take(bitcnt & 7u);  // to the byte boundary
+              refill();
+              const uint32_t len = take(16), nlen = take(16);
+              if ((len ^ nlen) != 0xFFFFu) { want = EV_ERROR; break; }
+              in_pos -= bitcnt >> 3; bitbuf = 0; bitcnt = 0;  // first byte of the data
+              if (in_pos + len > in_len || op + len > out_len) { want = EV_ERROR; break; }
+              stored_left = len; phase = 2;
+            } else if (type == 1 || type == 2) {
+              uint32_t nlit, ndist;
+              if (type == 1) {
+                nlit = 288; ndist = 32;
+                for (int s = 0; s < 144; ++s) sh.lens[s] = 8;
+                for (int s = 144; s < 256; ++s) sh.lens[s] = 9;
+                for (int s = 256; s < 280; ++s) sh.lens[s] = 7;
+                for (int s = 280; s < 288; ++s) sh.lens[s] = 8;
+                for (int s = 0; s < 32; ++s) sh.lens[288 + s] = 5;
+              } else {
+                refill();
+                nlit = take(5) + 257; ndist = take(5) + 1; const uint32_t ncode = take(4) + 4;
+                if (nlit > 286 || ndist > 30) { want = EV_ERROR; break; }
+                for (int i = 0; i < 19; ++i) sh.lens[i] = 0;
+                for (uint32_t i = 0; i < ncode; ++i) { refill(); sh.lens[kClOrder[i]] = (uint8_t)take(3); }
+                // the code-length code (19 symbols, at most 7 bits), decoded canonically from counts kept in the distance arrays
+                if (!prepare_codes(sh.lens, 19, sh.dist_cnt, sh.dist_sym, sh.code, false)) { want = EV_ERROR; break; }
+                uint32_t idx = 0; bool bad = false;
+                while (idx < nlit + ndist) {
+                  refill();
+                  int l; const int sym = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, l);
+                  if (sym < 0) { bad = true; break; }
+                  take((uint32_t)l);
+                  if (sym < 16) sh.lens2[idx++] = (uint8_t)sym;
+                  else {
+                    uint32_t rep, val = 0;
+                    if (sym == 16) { if (idx == 0) { bad = true; break; } val = sh.lens2[idx - 1]; rep = 3 + take(2); }
+                    else if (sym == 17) rep = 3 + take(3);
+                    else rep = 11 + take(7);
+                    if (idx + rep > nlit + ndist) { bad = true; break; }
+                    while (rep--) sh.lens2[idx++] = (uint8_t)val;
+                  }
+                }
+                if (bad || sh.lens2[256] == 0) { want = EV_ERROR; break; }
+                for (uint32_t i = 0; i < nlit + ndist; ++i) sh.lens[i] = sh.lens2[i];
+              }
+              if (!prepare_codes(sh.lens, (int)nlit, sh.lit_cnt, sh.lit_sym, sh.code, false) ||
+                  !prepare_codes(sh.lens + nlit, (int)ndist, sh.dist_cnt, sh.dist_sym, sh.code + nlit, true)) { want = EV_ERROR; break; }
+              sh.nlit = nlit; sh.ndist = ndist;
+              phase = 1;
+              want = EV_BUILD;
+            } else { want = EV_ERROR; break; }
+          } else if (phase == 2) {
+            // ---- stored bytes, one piece (up to the next segment boundary) per rendezvous
+            if (stored_left == 0) { phase = 0; if (final_block) want = EV_DONE; continue; }
+            const uint32_t room = SEG - (op & (SEG - 1));
+            const uint32_t piece = stored_left < room ? stored_left : room;
+            sh.copy_src = in_pos; sh.copy_dst = op; sh.copy_len = piece;
+            in_pos += piece; op += piece; stored_left -= piece;
+            want = EV_COPY;
+          } else {
+            // ---- symbols of a Huffman block
+            if (window_low(16)) { want = EV_RELOAD; break; }
+            refill();
+            uint32_t e = sh.lit_tab[bitbuf & ((1u << LIT_BITS) - 1u)];
+            int l = (int)(e & 15u), sym = (int)(e >> 4);
+            if (l == 0) { sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); if (sym < 0) { want = EV_ERROR; break; } }
+            take((uint32_t)l);
+            if (sym < 256) {
+              if (op >= out_len) { want = EV_ERROR; break; }
+              sh.out[op & RING_MASK] = (uint8_t)sym; ++op;
+              if ((op & (SEG - 1)) == 0) want = EV_FLUSH;
+              continue;
+            }
+            if (sym == 256) { phase = 0; if (final_block) want = EV_DONE; continue; }
+            if (sym > 285) { want = EV_ERROR; break; }
+            refill();
+            uint32_t len;
+            if (sym < 265) len = (uint32_t)sym - 254u;
+            else if (sym == 285) len = 258;
+            else { const uint32_t eb = ((uint32_t)sym - 261u) >> 2; len = 3u + ((4u + (((uint32_t)sym - 265u) & 3u)) << eb) + take(eb); }
+            e = sh.dist_tab[bitbuf & ((1u << DIST_BITS) - 1u)];
+            int dl = (int)(e & 15u), ds = (int)(e >> 4);
+            if (dl == 0) { ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); if (ds < 0) { want = EV_ERROR; break; } }
+            take((uint32_t)dl);
+            if (ds > 29) { want = EV_ERROR; break; }
+            refill();
+            uint32_t dist;
+            if (ds < 4) dist = (uint32_t)ds + 1u;
+            else { const uint32_t eb = ((uint32_t)ds >> 1) - 1u; dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + take(eb); }
+            if (dist > op || op + len > out_len) { want = EV_ERROR; break; }
+            const uint32_t before = op;
+            for (uint32_t i = 0; i < len; ++i, ++op) sh.out[op & RING_MASK] = sh.out[(op - dist) & RING_MASK];
+            if ((before ^ op) & SEG) want = EV_FLUSH;
+          }
+        }
+        if (want == EV_RELOAD) {
+          // the window restarts at the byte that holds the next unconsumed bit; its consumed bits are dropped again behind the load
+          const uint32_t whole = bitcnt >> 3, frac = bitcnt & 7u;
+          in_pos = in_pos - whole - (frac ? 1u : 0u);
+          pending_skip = frac ? 8u - frac : 0u;
+          bitbuf = 0; bitcnt = 0;
+          wb = in_pos & ~3u;
+          sh.win_base = wb;
+        }
+        sh.ev = want; sh.op = op;
+      }
+      __syncthreads();
+      const uint32_t ev = sh.ev;
+      if (ev == EV_ERROR) { ok = false; break; }
+      // ---- what the wave does together
+      if (ev == EV_RELOAD) {
+        const uint32_t w0 = sh.win_base;  // (a multiple of 4)
+        for (uint32_t i = 4u * (uint32_t)lane; i < IN_WIN + 16; i += 256) {
+          uint32_t w = 0;
+          const uint32_t p = w0 + i;
+          if (p + 4 <= in_len) __builtin_memcpy(&w, in + p, 4);
+          else for (uint32_t q = 0; q < 4; ++q) if (p + q < in_len) w |= (uint32_t)in[p + q] << (8 * q);
+          *reinterpret_cast<uint32_t*>(sh.in_win + i) = w;
+        }
+      } else if (ev == EV_COPY) {
+        const uint32_t cs = sh.copy_src, cl = sh.copy_len, o = sh.copy_dst;
+        for (uint32_t i = (uint32_t)lane; i < cl; i += 64) sh.out[(o + i) & RING_MASK] = in[cs + i];
+      } else if (ev == EV_BUILD) {
+        const uint32_t nlit = sh.nlit, ndist = sh.ndist;
+        for (uint32_t i = (uint32_t)lane; i < (1u << LIT_BITS); i += 64) sh.lit_tab[i] = 0;
+        for (uint32_t i = (uint32_t)lane; i < (1u << DIST_BITS); i += 64) sh.dist_tab[i] = 0;
+        __syncthreads();
+        for (uint32_t s = (uint32_t)lane; s < nlit + ndist; s += 64) {
+          const uint32_t l = sh.lens[s];
+          if (!l) continue;
+          const bool is_dist = s >= nlit;
+          const uint32_t bits = is_dist ? (uint32_t)DIST_BITS : (uint32_t)LIT_BITS;
+          if (l > bits) continue;
+          uint16_t* tab = is_dist ? sh.dist_tab : sh.lit_tab;
+          const uint16_t entry = (uint16_t)(((is_dist ? s - nlit : s) << 4) | l);
+          for (uint32_t i = rev_bits(sh.code[s], (int)l); i < (1u << bits); i += 1u << l) tab[i] = entry;
+        }
+      }
+      __syncthreads();
+      {  // finished segments of the ring go out; at the end, the tail
+        const uint32_t opn = sh.op;
+        const uint32_t upto = ev == EV_DONE ? opn : (opn & ~(SEG - 1));
+        if (upto > flushed) {
+          for (uint32_t i = flushed + 16u * (uint32_t)lane; i < upto; i += 1024) {
+            if (i + 16 <= upto) { const uint4 v = *reinterpret_cast<const uint4*>(sh.out + (i & RING_MASK)); __builtin_memcpy(outp + i, &v, 16); }
+            else for (uint32_t q = i; q < upto; ++q) outp[q] = sh.out[q & RING_MASK];
+          }
+          flushed = upto;
+        }
+      }
+      if (ev == EV_DONE) break;
+      __syncthreads();
+    }
+    if (lane == 0) status[bi] = (uint8_t)((ok && flushed == out_len) ? 1 : 0);
+  }
+}
+
+}  // namespace infl
+
+// n raw DEFLATE streams src[src_off .. + src_len) -> dst[dst_off .. + dst_len) (host or device memory), status[b] = 1 inflated, 0 declined.
+// Synchronous: returns when dst and status are complete.
+int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64_t src_bytes, const infl::BlockDesc* descs, uint8_t* dst, uint64_t dst_bytes,
+                          uint8_t* status, bool preserve_dst) {
+  if (n <= 0) return TRGT_OK;
+  TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  void *d_src = nullptr, *d_desc = nullptr, *d_dst = nullptr, *d_status = nullptr, *d_counter = nullptr;
+  int rc;
+  const bool src_dev = is_device_ptr(src), dst_dev = is_device_ptr(dst);
+  if ((!src_dev && (rc = dev_get(c, S_INF_SRC, (size_t)src_bytes + 64, &d_src))) || (rc = dev_get(c, S_INF_DESC, (size_t)n * sizeof(infl::BlockDesc), &d_desc)) ||
+      (!dst_dev && (rc = dev_get(c, S_INF_DST, (size_t)dst_bytes + 64, &d_dst))) || (rc = dev_get(c, S_INF_STATUS, (size_t)n + 16, &d_status)) ||
+      (rc = dev_get(c, S_INF_COUNTER, 16, &d_counter)))
+    return rc;
+  if (src_dev) d_src = const_cast<uint8_t*>(src);
+  else TRGT_HIP_TRY(c, hipMemcpyAsync(d_src, src, (size_t)src_bytes, hipMemcpyHostToDevice, c->stream));
+  if (dst_dev) d_dst = dst;
+  else if (preserve_dst) TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, dst, (size_t)dst_bytes, hipMemcpyHostToDevice, c->stream));  // (the bytes between the blocks come back as they were)
+  TRGT_HIP_TRY(c, hipMemcpyAsync(d_desc, descs, (size_t)n * sizeof(infl::BlockDesc), hipMemcpyHostToDevice, c->stream));
+  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
+  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 4);
+  hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
+                     (uint8_t*)d_status, (unsigned int*)d_counter);
+  TRGT_HIP_TRY(c, hipGetLastError());
+  if (!dst_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(dst, d_dst, (size_t)dst_bytes, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, hipMemcpyAsync(status, d_status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
+  return TRGT_OK;
+}
+
+}  // namespace trgt
+
+// include/trgt_hip.h: "device-side BGZF inflate"
+extern "C" int trgt_inflate_blocks(trgt_hip_ctx* c, int64_t n_blocks, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len, uint8_t* dst,
+                                   const uint64_t* dst_off, const uint32_t* dst_len, uint8_t* status) {
+  if (!c) return TRGT_ERR_INVALID;
+  if (n_blocks < 0 || (n_blocks > 0 && (!src || !src_off || !src_len || !dst || !dst_off || !dst_len || !status))) return trgt::fail(c, TRGT_ERR_INVALID, "trgt_inflate_blocks: null argument");
+  try {
+    std::vector<trgt::infl::BlockDesc> d((size_t)n_blocks);
+    uint64_t sb = 0, db = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+      if (dst_len[b] > 65536u) return trgt::fail(c, TRGT_ERR_INVALID, "trgt_inflate_blocks: block %lld inflates to %u bytes (a BGZF block holds at most 65536)", (long long)b, dst_len[b]);
+      d[(size_t)b] = trgt::infl::BlockDesc{src_off[b], dst_off[b], src_len[b], dst_len[b]};
+      sb = std::max<uint64_t>(sb, src_off[b] + src_len[b]); db = std::max<uint64_t>(db, dst_off[b] + dst_len[b]);
+    }
+    return trgt::inflate_blocks_device(c, n_blocks, src, sb, d.data(), dst, db, status, true);
+  } catch (const std::bad_alloc&) { return trgt::fail(c, TRGT_ERR_NOMEM, "out of host memory"); }
+}

@@ -1,0 +1,15 @@
+// trgt_amd/csrc/inflate_dev.hpp -- host interface of the device-side DEFLATE decoder (inflate_dev.hip)
+#pragma once
+#include <cstdint>
+
+struct trgt_hip_ctx;
+
+namespace trgt {
+namespace infl {
+struct BlockDesc { uint64_t src_off, dst_off; uint32_t src_len, dst_len; };  // one raw DEFLATE stream and where its bytes go
+}
+// n streams src[src_off .. + src_len) -> dst[dst_off .. + dst_len) (host or device memory; pinned host memory keeps the copies at link
+// speed), status[b] = 1 inflated, 0 declined.  Synchronous.
+int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64_t src_bytes, const infl::BlockDesc* descs, uint8_t* dst, uint64_t dst_bytes,
+                          uint8_t* status, bool preserve_dst = false);  // preserve_dst: host bytes of dst outside the blocks survive (the whole range is copied back)
+}  // namespace trgt

@@ -29,12 +29,25 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/trgt_hip.h"
+#include "inflate_dev.hpp"
 #include "inflate_fast.hpp"
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------- BGZF
+// The blocks of a whole call inflated in one batch on the device (trgt_ingest_params.inflate_device): read-only while the workers run.
+struct SharedBlocks {
+  struct E { uint64_t coff; uint32_t csize, isize; const uint8_t* data; };
+  std::vector<E> blocks;  // sorted by coff
+  const E* find(uint64_t coff) const {
+    auto it = std::lower_bound(blocks.begin(), blocks.end(), coff, [](const E& e, uint64_t c) { return e.coff < c; });
+    return it != blocks.end() && it->coff == coff ? &*it : nullptr;
+  }
+};
+
 struct Bgzf {
   // A few inflated blocks are kept (least recently used one replaced): the .bai sends the query of a locus back to the first record of
   // the 16 kb window its region starts in, so neighbouring loci of a dense catalog walk over the same blocks, and a worker that takes
@@ -55,18 +68,21 @@ struct Bgzf {
   Bgzf(const Bgzf&) = delete;
   Bgzf& operator=(const Bgzf&) = delete;
   ~Bgzf() { if (fd >= 0) ::close(fd); if (zs_ready) inflateEnd(&zs); }
-  const std::vector<uint8_t>& block() const { return cache[cur].data; }
+  const SharedBlocks* shared = nullptr;  // blocks some one else inflated for this call (looked up behind the reader's own cache)
+  const uint8_t* cur_data = nullptr; size_t cur_size = 0;  // the current block's bytes: an entry of `cache` or of `shared`
+  uint64_t n_shared = 0;
   bool open(const char* path) { fd = ::open(path, O_RDONLY); if (fd < 0) { err = std::string("cannot open ") + path; return false; } return true; }
   bool load(uint64_t coff) {
     size_t lru = 0;
     for (size_t i = 0; i < cache.size(); ++i) {
-      if (cache[i].coff == coff) { cur = i; cache[i].stamp = ++clock; block_coff = coff; block_csize = cache[i].csize; pos = 0; ++n_hits; return true; }
+      if (cache[i].coff == coff) { cur = i; cache[i].stamp = ++clock; block_coff = coff; block_csize = cache[i].csize; pos = 0; ++n_hits; cur_data = cache[i].data.data(); cur_size = cache[i].data.size(); return true; }
       if (cache[i].stamp < cache[lru].stamp) lru = i;
     }
+    if (shared) if (const SharedBlocks::E* e = shared->find(coff)) { cur_data = e->data; cur_size = e->isize; block_coff = coff; block_csize = e->csize; pos = 0; ++n_shared; return true; }
     uint8_t h[18];
     const ssize_t got = ::pread(fd, h, 18, (off_t)coff);
     Block& B = cache[lru];
-    if (got == 0) { B.data.clear(); B.coff = ~0ull; cur = lru; block_coff = coff; block_csize = 0; pos = 0; return true; }  // end of file (not kept)
+    if (got == 0) { B.data.clear(); B.coff = ~0ull; cur = lru; block_coff = coff; block_csize = 0; pos = 0; cur_data = nullptr; cur_size = 0; return true; }  // end of file (not kept)
     if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
     const uint32_t xlen = h[10] | (h[11] << 8);
     // the BC subfield is the first one in every file bgzip / htslib / pbmm2 writes; look it up properly all the same
@@ -106,29 +122,29 @@ struct Bgzf {
     }
     ++n_inflated;
     B.coff = coff; B.csize = total; B.stamp = ++clock; cur = lru;
-    block_coff = coff; block_csize = total; pos = 0;
+    block_coff = coff; block_csize = total; pos = 0; cur_data = B.data.data(); cur_size = B.data.size();
     return true;
   }
   bool seek(uint64_t voff) {
     const uint64_t coff = voff >> 16;
     if (coff != block_coff && !load(coff)) return false;
     pos = (size_t)(voff & 0xFFFF);
-    return pos <= block().size();
+    return pos <= cur_size;
   }
-  uint64_t tell() const { return pos < block().size() || block_csize == 0 ? (block_coff << 16) | pos : ((block_coff + block_csize) << 16); }
+  uint64_t tell() const { return pos < cur_size || block_csize == 0 ? (block_coff << 16) | pos : ((block_coff + block_csize) << 16); }
   // n bytes; returns 1 ok, 0 clean end of file before the first byte, -1 error
   int read(void* dst, size_t n) {
     uint8_t* d = (uint8_t*)dst;
     size_t done = 0;
     while (done < n) {
-      if (pos >= block().size()) {
+      if (pos >= cur_size) {
         if (block_csize == 0 && block_coff != ~0ull) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
         if (!load(block_coff + block_csize)) return -1;
-        if (block().empty() && block_csize == 0) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
+        if (cur_size == 0 && block_csize == 0) { if (done == 0) return 0; err = "unexpected end of BAM"; return -1; }
         continue;
       }
-      const size_t k = std::min(n - done, block().size() - pos);
-      std::memcpy(d + done, block().data() + pos, k);
+      const size_t k = std::min(n - done, cur_size - pos);
+      std::memcpy(d + done, cur_data + pos, k);
       done += k; pos += k;
     }
     return 1;
@@ -537,7 +553,125 @@ struct trgt_ingest {
   // where the last one stopped finds the blocks of the chunk boundary inflated, and no call pays for fresh pages again
   std::mutex idle_mu;
   std::vector<std::unique_ptr<Bgzf>> idle_readers;
+  // trgt_ingest_params.inflate_device: a context on that GPU and pinned staging for the compressed and the inflated blocks of a call
+  std::mutex infl_mu;
+  trgt_hip_ctx* infl_ctx = nullptr; int infl_device = -1;
+  void *pin_src = nullptr, *pin_dst = nullptr; size_t pin_src_cap = 0, pin_dst_cap = 0;
+  ~trgt_ingest() {
+    if (pin_src) (void)hipHostFree(pin_src);
+    if (pin_dst) (void)hipHostFree(pin_dst);
+    if (infl_ctx) trgt_hip_destroy(infl_ctx);
+  }
 };
+
+// The BGZF blocks between the compressed offsets of `ranges` ([first block, last block] pairs from the .bai chunks of the loci of a
+// call): read, inflated on the device in ONE batch (inflate_dev.hip) and left in pinned host memory for the workers.  Blocks the
+// device declines, and blocks beyond what the index names, are inflated by the worker that meets them, as before.
+static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uint64_t, uint64_t>>& ranges, SharedBlocks& sb, double* ms) {
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
+  if (!h->infl_ctx || h->infl_device != device) {
+    if (h->infl_ctx) { trgt_hip_destroy(h->infl_ctx); h->infl_ctx = nullptr; }
+    const int rc = trgt_hip_create(device, &h->infl_ctx);
+    if (rc) { h->infl_ctx = nullptr; return bad("trgt_ingest: inflate_device " + std::to_string(device) + ": no usable gfx950 device"); }
+    h->infl_device = device;
+  }
+  (void)hipSetDevice(device);
+  std::sort(ranges.begin(), ranges.end());
+  std::vector<std::pair<uint64_t, uint64_t>> merged;
+  for (auto& r : ranges) {
+    if (!merged.empty() && r.first <= merged.back().second + 0x10000) merged.back().second = std::max(merged.back().second, r.second);
+    else merged.push_back(r);
+  }
+  const int fd = ::open(h->bam_path.c_str(), O_RDONLY);
+  if (fd < 0) return bad("cannot open " + h->bam_path);
+  struct Fd { int fd; ~Fd() { ::close(fd); } } fdg{fd};
+  struct stat st;
+  if (::fstat(fd, &st) != 0) return bad("cannot stat " + h->bam_path);
+  const uint64_t fsize = (uint64_t)st.st_size;
+  uint64_t src_total = 0;
+  std::vector<uint64_t> src_at(merged.size());
+  for (size_t i = 0; i < merged.size(); ++i) {
+    const uint64_t c0 = merged[i].first, c1 = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
+    src_at[i] = src_total;
+    if (c1 > c0) src_total += ((c1 - c0) + 63) & ~63ull;
+  }
+  auto pin = [&](void*& p, size_t& cap, size_t need) {
+    if (cap >= need) return true;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = need + need / 4 + (1u << 20);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+    cap = want;
+    return true;
+  };
+  if (!pin(h->pin_src, h->pin_src_cap, (size_t)src_total + 64)) return bad("trgt_ingest: no pinned memory for the compressed blocks");
+  uint8_t* const src = (uint8_t*)h->pin_src;
+  // the compressed ranges, read by a few threads (page cache or disk)
+  {
+    std::atomic<size_t> next{0}; std::atomic<int> failed{0};
+    auto rd = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= merged.size()) break;
+        const uint64_t c0 = merged[i].first, c1 = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
+        for (uint64_t o = c0; o < c1;) {
+          const ssize_t g = ::pread(fd, src + src_at[i] + (o - c0), (size_t)std::min<uint64_t>(c1 - o, 8u << 20), (off_t)o);
+          if (g <= 0) { failed = 1; break; }
+          o += (uint64_t)g;
+        }
+      }
+    };
+    const int nt = (int)std::min<size_t>(8, merged.size());
+    if (nt <= 1) rd();
+    else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(rd); for (auto& t : th) t.join(); }
+    if (failed) return bad("trgt_ingest: reading the compressed blocks failed");
+  }
+  const double t_read = now();
+  // block boundaries (every header names its block's size), payloads and inflated sizes
+  std::vector<trgt::infl::BlockDesc> descs;
+  std::vector<SharedBlocks::E> ents;
+  uint64_t dst_total = 0;
+  for (size_t i = 0; i < merged.size(); ++i) {
+    const uint64_t c0 = merged[i].first, cend = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
+    uint64_t coff = c0;
+    while (coff <= merged[i].second && coff + 18 <= cend) {
+      const uint8_t* hp = src + src_at[i] + (coff - c0);
+      if (hp[0] != 31 || hp[1] != 139 || hp[2] != 8 || !(hp[3] & 4)) break;  // (not a block start: the workers will say what is wrong)
+      const uint32_t xlen = hp[10] | (hp[11] << 8);
+      if (coff + 12 + xlen > cend) break;
+      uint32_t bsize = 0; bool found = false;
+      for (uint32_t k = 0; k + 4 <= xlen;) {
+        const uint32_t slen = hp[12 + k + 2] | (hp[12 + k + 3] << 8);
+        if (hp[12 + k] == 'B' && hp[12 + k + 1] == 'C' && slen == 2 && k + 6 <= xlen) { bsize = hp[12 + k + 4] | (hp[12 + k + 5] << 8); found = true; break; }
+        k += 4 + slen;
+      }
+      if (!found) break;
+      const uint32_t total = bsize + 1, hdr = 12 + xlen;
+      if (total < hdr + 8 || coff + total > cend) break;
+      const uint32_t isize = hp[total - 4] | (hp[total - 3] << 8) | (hp[total - 2] << 16) | ((uint32_t)hp[total - 1] << 24);
+      if (isize > 0 && isize <= 0x10000) {
+        descs.push_back(trgt::infl::BlockDesc{src_at[i] + (coff - c0) + hdr, dst_total, total - hdr - 8, isize});
+        ents.push_back(SharedBlocks::E{coff, total, isize, nullptr});
+        dst_total += ((uint64_t)isize + 63) & ~63ull;
+      }
+      coff += total;
+    }
+  }
+  sb.blocks.clear();
+  if (descs.empty()) { if (ms) *ms = now() - t0; return TRGT_OK; }
+  if (!pin(h->pin_dst, h->pin_dst_cap, (size_t)dst_total + 64)) return bad("trgt_ingest: no pinned memory for the inflated blocks");
+  std::vector<uint8_t> status(descs.size(), 0);
+  const double t_walk = now();
+  const int rc = trgt::inflate_blocks_device(h->infl_ctx, (int64_t)descs.size(), src, src_total, descs.data(), (uint8_t*)h->pin_dst, dst_total, status.data());
+  if (rc) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx));
+  for (size_t b = 0; b < ents.size(); ++b)
+    if (status[b] == 1) { ents[b].data = (const uint8_t*)h->pin_dst + descs[b].dst_off; sb.blocks.push_back(ents[b]); }
+  std::sort(sb.blocks.begin(), sb.blocks.end(), [](const SharedBlocks::E& a, const SharedBlocks::E& b) { return a.coff < b.coff; });
+  if (std::getenv("TRGT_INGEST_TRACE")) std::fprintf(stderr, "[ingest]   device inflate: %zu ranges, %.1f MB read in %.1f ms, headers %.1f ms, upload + kernel + download of %.1f MB %.1f ms\n", merged.size(), (double)src_total / 1e6, t_read - t0, t_walk - t_read, (double)dst_total / 1e6, now() - t_walk);
+  if (ms) *ms = now() - t0;
+  return TRGT_OK;
+}
 
 struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
   std::string flank, tr, motifs, reads, quals, names, contigs, ids, strucs;
@@ -610,7 +744,7 @@ void trgt_ingest_close(trgt_ingest* h) { delete h; }
 
 void trgt_ingest_default_params(trgt_ingest_params* p) {
   if (!p) return;
-  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0;
+  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0; p->inflate_device = -1;
 }
 
 void trgt_ingest_free(trgt_ingest_batch* b) {
@@ -693,11 +827,25 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   }
   const int64_t nl = (int64_t)loci.size();
   const double t1 = now();
+  // ---- trgt_ingest_params.inflate_device: the blocks the index names for these loci, inflated on the GPU in one batch
+  SharedBlocks shared_blocks;
+  std::unique_lock<std::mutex> infl_lock(h->infl_mu, std::defer_lock);
+  double t_prefetch = 0.0;
+  if (p->inflate_device >= 0 && nl > 0) {
+    infl_lock.lock();  // (the pinned staging belongs to the handle: one call at a time in this mode)
+    std::vector<std::pair<uint64_t, uint64_t>> ranges;
+    for (auto& l : loci) {
+      auto it = h->ref_id.find(l.contig);
+      if (it == h->ref_id.end()) continue;
+      for (auto& ch : h->bai.query(it->second, std::max<int64_t>(0, l.start - p->flank_len), l.end + p->flank_len)) ranges.emplace_back(ch.first >> 16, ch.second >> 16);
+    }
+    if (!ranges.empty()) { const int prc = prefetch_blocks(h, p->inflate_device, ranges, shared_blocks, &t_prefetch); if (prc) return prc; }
+  }
   // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
   int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // (more than 32 workers lose: tools/ingest_scaling.py)
   nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, nl));
   std::atomic<int64_t> next{0};
-  std::atomic<uint64_t> n_inflated{0}, n_cache_hits{0};
+  std::atomic<uint64_t> n_inflated{0}, n_cache_hits{0}, n_from_device{0};
   // a worker takes a run of consecutive catalog lines (sorted catalogs: neighbours share BGZF blocks, see Bgzf), short enough that
   // every thread still gets several runs
   const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, nl / (4ll * nthr)));
@@ -710,7 +858,9 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     }
     struct Back { trgt_ingest* h; std::unique_ptr<Bgzf>& z; ~Back() { if (z && z->err.empty()) { std::lock_guard<std::mutex> g(h->idle_mu); h->idle_readers.push_back(std::move(z)); } } } back{h, zp};
     Bgzf& z = *zp;
-    const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits;
+    z.shared = shared_blocks.blocks.empty() ? nullptr : &shared_blocks;
+    z.block_coff = ~0ull; z.block_csize = 0; z.cur_data = nullptr; z.cur_size = 0; z.pos = 0;  // (a kept reader may point at a shared block of an earlier call)
+    const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits, shared0 = z.n_shared;
     RawRec rec;
     for (;;) {
       const int64_t l0 = next.fetch_add(run);
@@ -759,7 +909,8 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
       l.reads.swap(clipped);
      }
     }
-    n_inflated += z.n_inflated - inflated0; n_cache_hits += z.n_hits - hits0;
+    n_inflated += z.n_inflated - inflated0; n_cache_hits += z.n_hits - hits0; n_from_device += z.n_shared - shared0;
+    z.shared = nullptr;
   };
   std::atomic<int> worker_failed{0};
   auto work = [&]() {  // (an exception must not leave a thread, nor cross the C ABI)
@@ -869,7 +1020,7 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   for (auto& m : skipped) { S->skipped += m; S->skipped_off.push_back(S->skipped.size()); }
   B.n_skipped = (int64_t)skipped.size(); B.skipped_blob = S->skipped.data(); B.skipped_off = S->skipped_off.data();
   if (p->keep_bam4) { B.read_bam4 = S->bam4.data(); B.read_bam4_off = S->bam4_off.data(); B.read_bam4_bytes = tot.bam4; }
-  if (trace) std::fprintf(stderr, "[ingest] %lld loci, %d threads (runs of %lld): catalog+genome %.1f ms, reads %.1f ms (%llu blocks inflated, %llu found in the cache), arrays %.1f ms\n", (long long)nl, nthr, (long long)run, t1 - t0, t2 - t1, (unsigned long long)n_inflated.load(), (unsigned long long)n_cache_hits.load(), now() - t2);
+  if (trace) std::fprintf(stderr, "[ingest] %lld loci, %d threads (runs of %lld): catalog+genome %.1f ms, reads %.1f ms (%llu blocks inflated by the workers, %llu found in their caches, %llu taken from the device batch of %zu blocks: %.1f ms), arrays %.1f ms\n", (long long)nl, nthr, (long long)run, t1 - t0, t2 - t1, (unsigned long long)n_inflated.load(), (unsigned long long)n_cache_hits.load(), (unsigned long long)n_from_device.load(), shared_blocks.blocks.size(), t_prefetch, now() - t2);
   B.owner = S.release();
   *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
   return TRGT_OK;

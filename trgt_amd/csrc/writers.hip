@@ -32,12 +32,12 @@ uint32_t trgt_ingest_contig_length(const trgt_ingest* h, int32_t i);
 namespace {
 
 struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF00 bytes of payload, whatever the number of threads)
-  FILE* f = nullptr; bool bgzf = false; std::vector<uint8_t> buf; int threads = 1;
+  FILE* f = nullptr; bool bgzf = false; std::vector<uint8_t> buf; int threads = 1; int level = 6;
   bool open(const char* path, bool compress) { f = std::fopen(path, "wb"); bgzf = compress; return f != nullptr; }
-  static bool deflate_block(const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
+  static bool deflate_block(const uint8_t* d, size_t n, std::vector<uint8_t>& out, int level = 6) {
     out.resize(0x10000 + 64);
     z_stream zs; std::memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t*>(d); zs.avail_in = (uInt)n; zs.next_out = out.data() + 18; zs.avail_out = (uInt)out.size() - 18 - 8;
     const int rc = deflate(&zs, Z_FINISH);
     deflateEnd(&zs);
@@ -51,7 +51,7 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     out.resize(total);
     return true;
   }
-  bool block(const uint8_t* d, size_t n) { std::vector<uint8_t> out; return deflate_block(d, n, out) && std::fwrite(out.data(), 1, out.size(), f) == out.size(); }
+  bool block(const uint8_t* d, size_t n) { std::vector<uint8_t> out; return deflate_block(d, n, out, level) && std::fwrite(out.data(), 1, out.size(), f) == out.size(); }
   // the full blocks of buf: deflated by `threads` workers (a block is independent of its neighbours), written in order
   bool flush_full_blocks() {
     const size_t nb = buf.size() / 0xFF00;
@@ -59,7 +59,7 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     std::vector<std::vector<uint8_t>> outs(nb);
     std::atomic<size_t> next{0}; std::atomic<int> failed{0};
     auto work = [&]() {
-      try { for (;;) { const size_t k = next.fetch_add(1); if (k >= nb) break; if (!deflate_block(buf.data() + k * 0xFF00, 0xFF00, outs[k])) failed = 1; } }
+      try { for (;;) { const size_t k = next.fetch_add(1); if (k >= nb) break; if (!deflate_block(buf.data() + k * 0xFF00, 0xFF00, outs[k], level)) failed = 1; } }
       catch (const std::exception&) { failed = 1; }
     };
     const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), nb);
@@ -143,7 +143,7 @@ const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_s
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0; p->bam_compress_level = 6;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
@@ -154,6 +154,7 @@ static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p,
   w->flank_len = p->output_flank_len; w->keep_unmapped = p->keep_unmapped_flag != 0;
   w->threads = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
   w->vcf.threads = w->bam.threads = w->threads;
+  w->bam.level = std::min(9, std::max(0, p->bam_compress_level));
   const std::string prog = p->program ? p->program : "trgt", ver = p->version ? p->version : "", cl = p->command_line ? p->command_line : "";
   w->sample = p->sample_name ? p->sample_name : "sample";
   for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i) w->contigs.push_back(trgt_ingest_contig_name(src, i));

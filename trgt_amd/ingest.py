@@ -10,7 +10,7 @@ from . import _lib
 
 class IngestParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("max_depth", C.c_int32), ("min_read_qual", C.c_double), ("threads", C.c_int32),
-                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32)]
+                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32), ("inflate_device", C.c_int32)]
 
 
 _P8, _P16, _P32, _P64, _PD, _PC = (C.POINTER(t) for t in (C.c_uint8, C.c_int16, C.c_uint32, C.c_uint64, C.c_double, C.c_char))
@@ -154,6 +154,34 @@ class Reader:
         else:
             self._L.trgt_ingest_free(h)
         return out
+
+
+def inflate_blocks(ctx, streams, sizes):
+    """trgt_inflate_blocks: raw DEFLATE streams (BGZF payloads) -> (list of bytes or None for a declined stream, status array).  The
+    device-side stand-in for htslib's bgzf_read_block; sizes[i] is the announced inflated size of streams[i] (at most 65536)."""
+    L = _lib.lib()
+    n = len(streams)
+    src_off = np.zeros(n, np.uint64); src_len = np.zeros(n, np.uint32); dst_off = np.zeros(n, np.uint64); dst_len = np.asarray(sizes, np.uint32)
+    so = do = 0
+    for i, s_ in enumerate(streams):
+        src_off[i], src_len[i], dst_off[i] = so, len(s_), do
+        so += (len(s_) + 15) & ~15
+        do += (int(dst_len[i]) + 63) & ~63
+    src = np.zeros(so + 16, np.uint8)
+    for i, s_ in enumerate(streams):
+        src[int(src_off[i]):int(src_off[i]) + len(s_)] = np.frombuffer(s_, np.uint8)
+    dst = np.full(do + 64, 0xA5, np.uint8)
+    status = np.zeros(n, np.uint8)
+    L.trgt_inflate_blocks.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+    L.trgt_inflate_blocks.restype = C.c_int
+    ctx.check(L.trgt_inflate_blocks(ctx.handle, n, src.ctypes.data, src_off.ctypes.data, src_len.ctypes.data, dst.ctypes.data, dst_off.ctypes.data, dst_len.ctypes.data, status.ctypes.data))
+    out = []
+    for i in range(n):
+        a, k = int(dst_off[i]), int(dst_len[i])
+        pad = dst[a + k:a + ((k + 63) & ~63)]
+        assert (pad == 0xA5).all(), "wrote beyond a block's output"
+        out.append(dst[a:a + k].tobytes() if status[i] == 1 else None)
+    return out, status
 
 
 def bam4_view(batch):
