@@ -5,7 +5,9 @@
 // is a DEFLATE stream of its own (at most 64 KB inflated), so a chunk of loci is a few thousand independent streams.
 //
 // One wave per block, blocks claimed from a counter.  The Huffman decoding itself is a serial dependent chain (the position of a code
-// depends on the length of the one before) and runs on lane 0; what parallelises is done by the whole wave at rendezvous points of a
+// depends on the length of the one before): every lane runs it on the same values, which are kept wave-uniform on purpose (what comes
+// back from LDS goes through v_readfirstlane) so that the decoder's state lives in SGPRs, its arithmetic is scalar and its branches are
+// scalar branches -- no exec-mask bookkeeping around a one-lane loop; what parallelises is done by the whole wave at rendezvous points of a
 // uniform loop: loading the next window of compressed bytes into LDS, filling the lookup tables of a dynamic block, copying stored
 // blocks, and flushing finished 16-KB segments of the output.  The last 32 KB of output live in an LDS ring (the LZ77 window: matches
 // are LDS-to-LDS byte copies), so a block needs 40 KB of LDS and four blocks are in flight per CU -- one per SIMD: the decode loop is
@@ -37,9 +39,12 @@ struct Shared {
   uint16_t lit_sym[288], dist_sym[32];    // symbols in code order
   uint16_t code[320];                     // canonical code of every symbol (table fill)
   uint8_t lens[320], lens2[320];
+  uint16_t offs[16], next[16];            // prepare_codes
   alignas(16) uint8_t in_win[IN_WIN + 16];
   alignas(16) uint8_t out[RING];
 };
+
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // RFC 1951 3.2.7
 
@@ -50,8 +55,8 @@ __device__ __forceinline__ int slow_decode(const uint16_t* cnt, const uint16_t* 
   int code = 0, first = 0, index = 0;
   for (int len = 1; len <= 15; ++len) {
     code |= (int)(bits & 1); bits >>= 1;
-    const int c = cnt[len];
-    if (code - c < first) { len_out = len; return sym[index + (code - first)]; }
+    const int c = (int)RFL(cnt[len]);
+    if (code - c < first) { len_out = len; return (int)RFL(sym[index + (code - first)]); }
     index += c; first += c; first <<= 1; code <<= 1;
   }
   len_out = 0;
@@ -60,19 +65,19 @@ __device__ __forceinline__ int slow_decode(const uint16_t* cnt, const uint16_t* 
 
 // code lengths -> counts, symbols in code order, canonical codes; false: over-subscribed or incomplete (a single distance code is
 // allowed to be incomplete, RFC 1951 3.2.7)
-__device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, uint16_t* sym, uint16_t* code, bool dist) {
+__device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, uint16_t* sym, uint16_t* code, bool dist, uint16_t* offs, uint16_t* next) {
+  // (every lane of the wave runs this on the same values: the read-modify-writes of LDS below happen in lockstep)
   for (int l = 0; l < 16; ++l) cnt[l] = 0;
-  for (int s = 0; s < n; ++s) cnt[lens[s]] += 1;
-  if (cnt[0] == n) return dist;  // no codes at all: fine for distances of an all-literal block
+  for (int s = 0; s < n; ++s) { const uint32_t l = RFL(lens[s]); cnt[l] = (uint16_t)(RFL(cnt[l]) + 1u); }
+  if ((int)RFL(cnt[0]) == n) return dist;  // no codes at all: fine for distances of an all-literal block
   int left = 1;
-  for (int l = 1; l <= 15; ++l) { left <<= 1; left -= cnt[l]; if (left < 0) return false; }
-  if (left > 0 && !(dist && n - cnt[0] == 1)) return false;
-  uint16_t offs[16], next[16];
-  offs[1] = 0; next[1] = 0;
-  for (int l = 1; l < 15; ++l) { offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); next[l + 1] = (uint16_t)((next[l] + cnt[l]) << 1); }
+  for (int l = 1; l <= 15; ++l) { left <<= 1; left -= (int)RFL(cnt[l]); if (left < 0) return false; }
+  if (left > 0 && !(dist && n - (int)RFL(cnt[0]) == 1)) return false;
+  uint32_t o = 0, c = 0;
+  for (int l = 1; l <= 15; ++l) { offs[l] = (uint16_t)o; next[l] = (uint16_t)c; const uint32_t k = RFL(cnt[l]); o += k; c = (c + k) << 1; }
   for (int s = 0; s < n; ++s) {
-    const int l = lens[s];
-    if (l) { sym[offs[l]++] = (uint16_t)s; code[s] = next[l]++; }
+    const uint32_t l = RFL(lens[s]);
+    if (l) { const uint32_t at = RFL(offs[l]), cd = RFL(next[l]); sym[at] = (uint16_t)s; code[s] = (uint16_t)cd; offs[l] = (uint16_t)(at + 1); next[l] = (uint16_t)(cd + 1); }
   }
   return true;
 }
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
     __syncthreads();
     if (lane == 0) sh.block = atomicAdd(counter, 1u);
     __syncthreads();
-    const uint32_t bi = sh.block;
+    const uint32_t bi = RFL(sh.block);
     if (bi >= n_blocks) return;
     const BlockDesc bd = blocks[bi];
     const uint8_t* __restrict__ in = src + bd.src_off;
@@ -98,13 +103,13 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
     uint32_t flushed = 0;    // uniform
     bool ok = out_len <= 65536u;
     for (;;) {
-      // ---- lane 0 decodes until it needs the wave
-      if (lane == 0) {
+      // ---- the decoder runs (on every lane, on uniform values) until it needs the wave
+      {
         uint32_t want = ok ? (uint32_t)EV_NONE : (uint32_t)EV_ERROR;
         auto refill = [&]() {
           if (bitcnt < 32) {
             const uint32_t o = in_pos - wb;
-            const uint32_t a = *reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u)), b = *reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u) + 4);
+            const uint32_t a = RFL(*reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u))), b = RFL(*reinterpret_cast<const uint32_t*>(sh.in_win + (o & ~3u) + 4));
             const uint32_t w = (uint32_t)((((uint64_t)b << 32) | a) >> (8 * (o & 3u)));
             bitbuf |= (uint64_t)w << bitcnt; bitcnt += 32; in_pos += 4;
           }
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
         auto window_low = [&](uint32_t room) { return in_pos + room > wb + IN_WIN && wb + IN_WIN < in_len + 8; };
         if (!have_window) { have_window = true; if (want == EV_NONE) want = EV_RELOAD; }
         else if (pending_skip) {  // behind a reload: the consumed bits of the first byte are dropped again
-          const uint32_t byte = sh.in_win[in_pos - wb];
+          const uint32_t byte = RFL(sh.in_win[in_pos - wb]);
           bitbuf = (uint64_t)(byte >> pending_skip); bitcnt = 8u - pending_skip; in_pos += 1; pending_skip = 0;
         }
         while (want == EV_NONE) {
@@ -147,9 +152,9 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
                 nlit = take(5) + 257; ndist = take(5) + 1; const uint32_t ncode = take(4) + 4;
                 if (nlit > 286 || ndist > 30) { want = EV_ERROR; break; }
                 for (int i = 0; i < 19; ++i) sh.lens[i] = 0;
-                for (uint32_t i = 0; i < ncode; ++i) { refill(); sh.lens[kClOrder[i]] = (uint8_t)take(3); }
+                for (uint32_t i = 0; i < ncode; ++i) { refill(); sh.lens[RFL(kClOrder[i])] = (uint8_t)take(3); }
                 // the code-length code (19 symbols, at most 7 bits), decoded canonically from counts kept in the distance arrays
-                if (!prepare_codes(sh.lens, 19, sh.dist_cnt, sh.dist_sym, sh.code, false)) { want = EV_ERROR; break; }
+                if (!prepare_codes(sh.lens, 19, sh.dist_cnt, sh.dist_sym, sh.code, false, sh.offs, sh.next)) { want = EV_ERROR; break; }
                 uint32_t idx = 0; bool bad = false;
                 while (idx < nlit + ndist) {
                   refill();
@@ -159,18 +164,18 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
                   if (sym < 16) sh.lens2[idx++] = (uint8_t)sym;
                   else {
                     uint32_t rep, val = 0;
-                    if (sym == 16) { if (idx == 0) { bad = true; break; } val = sh.lens2[idx - 1]; rep = 3 + take(2); }
+                    if (sym == 16) { if (idx == 0) { bad = true; break; } val = RFL(sh.lens2[idx - 1]); rep = 3 + take(2); }
                     else if (sym == 17) rep = 3 + take(3);
                     else rep = 11 + take(7);
                     if (idx + rep > nlit + ndist) { bad = true; break; }
                     while (rep--) sh.lens2[idx++] = (uint8_t)val;
                   }
                 }
-                if (bad || sh.lens2[256] == 0) { want = EV_ERROR; break; }
-                for (uint32_t i = 0; i < nlit + ndist; ++i) sh.lens[i] = sh.lens2[i];
+                if (bad || RFL(sh.lens2[256]) == 0) { want = EV_ERROR; break; }
+                for (uint32_t i = 0; i < nlit + ndist; ++i) sh.lens[i] = (uint8_t)RFL(sh.lens2[i]);
               }
-              if (!prepare_codes(sh.lens, (int)nlit, sh.lit_cnt, sh.lit_sym, sh.code, false) ||
-                  !prepare_codes(sh.lens + nlit, (int)ndist, sh.dist_cnt, sh.dist_sym, sh.code + nlit, true)) { want = EV_ERROR; break; }
+              if (!prepare_codes(sh.lens, (int)nlit, sh.lit_cnt, sh.lit_sym, sh.code, false, sh.offs, sh.next) ||
+                  !prepare_codes(sh.lens + nlit, (int)ndist, sh.dist_cnt, sh.dist_sym, sh.code + nlit, true, sh.offs, sh.next)) { want = EV_ERROR; break; }
               sh.nlit = nlit; sh.ndist = ndist;
               phase = 1;
               want = EV_BUILD;
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             // ---- symbols of a Huffman block
             if (window_low(16)) { want = EV_RELOAD; break; }
             refill();
-            uint32_t e = sh.lit_tab[bitbuf & ((1u << LIT_BITS) - 1u)];
+            uint32_t e = RFL(sh.lit_tab[bitbuf & ((1u << LIT_BITS) - 1u)]);
             int l = (int)(e & 15u), sym = (int)(e >> 4);
             if (l == 0) { sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); if (sym < 0) { want = EV_ERROR; break; } }
             take((uint32_t)l);
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             if (sym < 265) len = (uint32_t)sym - 254u;
             else if (sym == 285) len = 258;
             else { const uint32_t eb = ((uint32_t)sym - 261u) >> 2; len = 3u + ((4u + (((uint32_t)sym - 265u) & 3u)) << eb) + take(eb); }
-            e = sh.dist_tab[bitbuf & ((1u << DIST_BITS) - 1u)];
+            e = RFL(sh.dist_tab[bitbuf & ((1u << DIST_BITS) - 1u)]);
             int dl = (int)(e & 15u), ds = (int)(e >> 4);
             if (dl == 0) { ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); if (ds < 0) { want = EV_ERROR; break; } }
             take((uint32_t)dl);
@@ -215,7 +220,20 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             else { const uint32_t eb = ((uint32_t)ds >> 1) - 1u; dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + take(eb); }
             if (dist > op || op + len > out_len) { want = EV_ERROR; break; }
             const uint32_t before = op;
-            for (uint32_t i = 0; i < len; ++i, ++op) sh.out[op & RING_MASK] = sh.out[(op - dist) & RING_MASK];
+            // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
+            // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
+            if (dist >= 64u) {
+              for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (a round only reads what earlier rounds or earlier symbols wrote)
+                const uint32_t k = k0 + (uint32_t)lane;
+                if (k < len) sh.out[(op + k) & RING_MASK] = sh.out[(op + k - dist) & RING_MASK];
+              }
+            } else {
+              for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                if (k < len) sh.out[(op + k) & RING_MASK] = sh.out[(op - dist + k % dist) & RING_MASK];
+              }
+            }
+            op += len;
             if ((before ^ op) & SEG) want = EV_FLUSH;
           }
         }
@@ -231,7 +249,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
         sh.ev = want; sh.op = op;
       }
       __syncthreads();
-      const uint32_t ev = sh.ev;
+      const uint32_t ev = RFL(sh.ev);
       if (ev == EV_ERROR) { ok = false; break; }
       // ---- what the wave does together
       if (ev == EV_RELOAD) {
@@ -278,6 +296,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
       __syncthreads();
     }
     if (lane == 0) status[bi] = (uint8_t)((ok && flushed == out_len) ? 1 : 0);
+    // (lane 0's store: every lane holds the same verdict)
   }
 }
 
