@@ -117,6 +117,42 @@ def test_long_allele_10kb(oracle, hmm):
     _same(oracle, hmm, sets, jobs)
 
 
+def test_long_alleles_parallel_traceback(oracle, hmm):
+    # alleles of 1 536 columns and more are traced back by hmm_traceback_long_kernel (chunk maps on many waves, then every chunk again
+    # from its known entry state): lengths around the threshold and around chunk boundaries (64 columns), one-wave, two-alleles-per-wave
+    # and multi-wave models, one-base motifs (a motif visit per column), with and without state paths -- and the same batch with the
+    # kernel switched off (TRGT_HMM_NO_LONG_TB=1)
+    from trgt_amd import _lib
+    rng = np.random.default_rng(29)
+    sets = [[b"CAG"], [b"A"], [b"GGCCTG", b"CCG"], [b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"],
+            [b"ACGTTGCAAGGCTTAACCGTAC"]]
+    jobs = []
+    for n in (1533, 1534, 1535, 1598, 1599, 1600, 1662, 4000):
+        jobs.append((0, repeat_allele(rng, sets[0], n, err=0.02)))
+    for n in (1534, 2047, 3000):
+        jobs.append((1, b"A" * n))
+        jobs.append((2, repeat_allele(rng, sets[2], n, err=0.03)))
+    for n in (1540, 2600):
+        jobs.append((3, repeat_allele(rng, sets[3], n, err=0.02)))
+        jobs.append((4, repeat_allele(rng, sets[4], n, err=0.02)))
+    jobs.append((0, rand_dna(rng, 2000)))  # nothing of the motif: skip states all the way
+    for want_path in (True, False):
+        _same(oracle, hmm, sets, jobs, want_path=want_path)
+    batch = hmm.pack_hmm_batch(sets, jobs)
+    ctx = _lib.context_with_env(TRGT_HMM_NO_LONG_TB=1)
+    try:
+        a = hmm.hmm_batch(batch, ctx=ctx)
+    finally:
+        ctx.close()
+    b = hmm.hmm_batch(batch)
+    for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["purity"].view(np.uint64), b["purity"].view(np.uint64))
+    for j in range(len(jobs)):  # (behind a job's path the buffer holds what the reversal left there)
+        po, pl = int(batch["path_off"][j]), int(a["path_len"][j])
+        assert np.array_equal(a["path"][po:po + pl], b["path"][po:po + pl]), j
+
+
 def test_visit_list_overflow_and_length_buckets(oracle, hmm):
     # one-base motifs make one motif visit per base: more than the kernel keeps in LDS (the rest go through its global
     # workspace); alleles of 0..2500 bases of several models land in every length bucket / launch class of one batch

@@ -58,6 +58,7 @@ struct trgt_knobs {
   bool sens_cons_unidir = false;  // TRGT_SENS_CONS_UNIDIR: consensus alignments back-traced unidirectionally (MemoryHigh) instead of by BiWFA
   bool sens_ward_ties = false;    // TRGT_SENS_WARD_TIES: nearest-neighbour ties of the Ward linkage go to the LAST candidate instead of the first
   bool sens_lw_order = false;     // TRGT_SENS_LW_ORDER: the Lance-Williams update summed in another order (last bits of the matrix central_read reads)
+  bool hmm_no_long_tb = false;  // TRGT_HMM_NO_LONG_TB: alleles of 1 536 columns and more are traced back by the fill kernel's one lane too (not by hmm_traceback_long_kernel)
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
   bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
@@ -208,7 +209,7 @@ inline bool is_device_ptr(const void* p) {
 // pool slot ids (each call site owns a range so buffers are reused call to call)
 enum Slot {
   S_HMM_SEQ = 0, S_HMM_DESC, S_HMM_MODEL, S_HMM_JOBS, S_HMM_BP, S_HMM_PATH, S_HMM_SPANS, S_HMM_NSP, S_HMM_CNT, S_HMM_PUR,
-  S_HMM_EDIT, S_HMM_MAXD, S_HMM_PLEN, S_HMM_VISITS, S_HMM_MOTIFS,
+  S_HMM_EDIT, S_HMM_MAXD, S_HMM_PLEN, S_HMM_VISITS, S_HMM_LONG, S_HMM_MOTIFS,
   S_HMM_B_BASE, S_HMM_B_LAST = S_HMM_B_BASE + (S_HMM_MOTIFS - S_HMM_SEQ),  // second set of the HMM slots: two batches in flight
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED, S_WFA_RETRY, S_WFA_RETRY_B, S_WFA_WS_C, S_WFA_COUNTER_C, S_WFA_CELLS_C, S_WFA_RETRY_C, S_WFA_MID, S_WFA_MID_B, S_WFA_MID_C,

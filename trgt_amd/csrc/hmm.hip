@@ -38,6 +38,7 @@ namespace trgt {
 struct HmmJobDev {
   uint32_t set, seq_len, job_index, path_cap;
   uint64_t seq_off, bp_off, path_off, span_off, count_off, visit_off;
+  uint64_t map_off;  // words into the visit workspace: chunk maps of the parallel trace-back of long alleles (0: none, the fill kernel traces back itself)
 };
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -345,6 +346,8 @@ __device__ unsigned long long g_hmm_prof[16];
 #define HP_FILL(i)
 #define HP_FILL_END
 #endif
+constexpr int HMM_LONG_MIN = 1536;   // columns from which an allele's trace-back goes to hmm_traceback_long_kernel
+constexpr int HMM_LONG_CHUNK = 64;   // columns per chunk map there
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
 constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4], block, flags, bp column
 
@@ -415,7 +418,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
                                    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans,
                                    uint32_t* __restrict__ counts, double* __restrict__ purity,
                                    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out,
-                                   uint32_t n_launch_jobs, uint32_t lds_per_job, const uint32_t* __restrict__ n_jobs_dev) {
+                                   uint32_t n_launch_jobs, uint32_t lds_per_job, const uint32_t* __restrict__ n_jobs_dev, uint32_t* __restrict__ long_list) {
   extern __shared__ __align__(16) unsigned char lds_all[];
   if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
@@ -765,6 +768,12 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   }
   HP_FILL_END;
   HP_MARK(1);
+  // long alleles are traced back by hmm_traceback_long_kernel (many waves per allele, behind this launch on the same stream)
+  if (long_list && job.map_off && L >= HMM_LONG_MIN) {
+    hmm_sync_mem(sync_n);
+    if (tid == 0) long_list[1 + atomicAdd(long_list, 1u)] = jidx;
+    return;
+  }
   if (tid == 0) {
     tb_state = S - 1; tb_idx = L - 1; tb_done = 0; tb_npath = 0; tb_nvisit = 0; tb_edit = 0; tb_ref = 0; tb_next = -1; tb_vb1 = 0;
   }
@@ -942,6 +951,280 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   HP_MARK(3);
 }
 
+// ---- trace-back of LONG alleles on many waves (DESIGN_HISTORY 7.3: "block-wise composed trace-back").  The chase of the back-pointers
+// is a serial chain of dependent look-ups -- a third of a long allele's time on one lane.  Here the columns are cut into chunks of
+// HMM_LONG_CHUNK; (A) for every chunk and EVERY state it could be entered in, a wave (lane = entry state) walks the chunk and notes where
+// the walk leaves it and what it passed (steps, motif visits, the last block end, the last state); (B) one thread strings the chunks
+// together from the end state -- a look-up per chunk; (C) every chunk is walked again from its now known entry state with the full
+// decoding of the steps (events, purity counts, motif visits: the code of hmm_viterbi_kernel), the waves of the workgroup side by side.
+// Exact by construction: (C) walks the very path the serial chase walks, and what a step needs from the steps before it (the state
+// walked last, the column of the last block end, how many steps / visits came before) is handed over by (B).
+struct HmmChunkMap { uint16_t exit_state, last_state, n_steps, n_starts; int32_t last_end; };  // 12 bytes = 3 words
+struct HmmChunkRec { uint32_t entry, np0, nv0; int32_t vb0, nxt0; uint32_t pad[3]; };          // 8 words
+constexpr int HMM_LONG_THREADS = 1024, HMM_LONG_STG = 2048;
+constexpr int HMM_LONG_MAP_LDS = 48 * 1024;  // chunk maps and records that fit stay in LDS (a 10-kb allele of a 16-state model: 35 KB), else in the job's workspace
+
+__global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
+    const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
+    const uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws, uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
+    int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans, uint32_t* __restrict__ counts, double* __restrict__ purity,
+    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, const uint32_t* __restrict__ long_list) {
+  extern __shared__ __align__(16) unsigned char lds_long[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = HMM_LONG_THREADS / 64;
+  for (uint32_t li = blockIdx.x; li < long_list[0]; li += gridDim.x) {
+    __syncthreads();
+    const HmmJobDev job = jobs[long_list[1 + li]];
+    const HmmSetDev set = sets[job.set];
+    const int S = (int)set.S, nb = (int)set.n_blocks, n_motifs = nb - 1;
+    const int qlen = (int)job.seq_len, L = qlen + 2;
+    const int Spad = (S + 15) & ~15;
+    const int C = HMM_LONG_CHUNK, n_chunks = (L + C - 1) / C;
+    // ---- LDS: totals | tables | per wave: staged back-pointer columns, the steps of a round
+    int* tot = reinterpret_cast<int*>(lds_long);  // [0] edit, [1] ref, [2] np, [3] nv
+    uint16_t* l_inst = reinterpret_cast<uint16_t*>(lds_long + 64);                       // [S][4] predecessor | emits << 15
+    uint32_t* l_info = reinterpret_cast<uint32_t*>(l_inst + 4 * S);                      // [S]
+    uint32_t* l_blocks = l_info + S;                                                     // [4][nb]
+    uint32_t* l_cnt = l_blocks + 4 * nb;                                                 // [nb]
+    uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_cnt + nb);                           // [S]
+    const int mot_bytes = (S - 7 - n_motifs) / 3;
+    uint8_t* l_mot = l_flags + ((S + 3) & ~3);
+    unsigned char* wave_base = lds_long + ((64 + (size_t)8 * S + 4 * S + 16 * nb + 4 * nb + ((S + 3) & ~3) + ((mot_bytes + 15) & ~15) + 15) & ~(size_t)15);
+    uint8_t* l_stage = wave_base + (size_t)wave * (HMM_LONG_STG + 512);
+    uint32_t* const l_map = reinterpret_cast<uint32_t*>(wave_base + (size_t)NW * (HMM_LONG_STG + 512));
+    const bool map_lds = ((size_t)3 * S + 8) * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS;
+    uint32_t* l_rec = reinterpret_cast<uint32_t*>(l_stage + HMM_LONG_STG);               // [64][2]
+    const uint16_t* g_inst = reinterpret_cast<const uint16_t*>(model + set.off_inst);
+    const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
+    const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
+    const uint8_t* g_motifs = model + set.off_motifs;
+    for (int i = tid; i < 4 * S; i += HMM_LONG_THREADS) { const uint16_t pr = g_inst[i]; l_inst[4 * (i % S) + i / S] = (uint16_t)(pr | ((pr < S ? (uint16_t)(model[set.off_flags + pr] & 1) : (uint16_t)0) << 15)); }
+    for (int i = tid; i < S; i += HMM_LONG_THREADS) l_flags[i] = model[set.off_flags + i];
+    for (int i = tid; i < 4 * nb; i += HMM_LONG_THREADS) l_blocks[i] = g_blocks[i];
+    for (int i = tid; i < mot_bytes; i += HMM_LONG_THREADS) l_mot[i] = g_motifs[i];
+    for (int i = tid; i < nb; i += HMM_LONG_THREADS) l_cnt[i] = 0;
+    for (int m = tid; m < n_motifs; m += HMM_LONG_THREADS) counts[job.count_off + m] = 0;
+    if (tid < 4) tot[tid] = 0;
+    __syncthreads();
+    for (int st = tid; st < S; st += HMM_LONG_THREADS) {  // the trace-back word of a state (as in hmm_viterbi_kernel)
+      const int blk = (int)g_block[st];
+      uint32_t kind = 0, expected = 0;
+      if (blk >= 0) {
+        const int bstart = (int)l_blocks[0 * nb + blk], bend = (int)l_blocks[1 * nb + blk];
+        if (st == bstart) kind = 1;
+        else if (st == bend) kind = 2;
+        else if (blk == nb - 1) kind = 3;
+        else {
+          const int mlen = (int)l_blocks[2 * nb + blk], off = st - bstart - 1, k = off / mlen;
+          kind = 4u + (uint32_t)k;
+          if (k == 0) expected = l_mot[l_blocks[3 * nb + blk] + off];
+        }
+      }
+      l_info[st] = kind | ((uint32_t)(l_flags[st] & 1) << 3) | ((uint32_t)(blk & 0xFF) << 8) | (expected << 16);
+    }
+    __syncthreads();
+    const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
+    const uint8_t* __restrict__ bp = bp_ws + job.bp_off;
+    uint32_t* const g_vis = visit_ws + job.visit_off;
+    uint32_t* const g_map = map_lds ? l_map : visit_ws + job.map_off;                 // [n_chunks][S] HmmChunkMap
+    HmmChunkRec* const g_crec = reinterpret_cast<HmmChunkRec*>(g_map + (size_t)3 * S * n_chunks);  // [n_chunks]
+    const int sub_cols = max(1, HMM_LONG_STG / Spad);
+    // one step of the chase: the predecessor of `state` in column `idx` (b: its back-pointer)
+    auto pred_of = [&](int state, int b) -> uint32_t {
+      const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
+      const uint32_t pw = (b & 2) ? pin[1] : pin[0];
+      uint32_t pe = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
+      if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + (b < nb ? b : 0)]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15); }
+      return pe;
+    };
+    // wave-cooperative staging of the back-pointer columns [c0, c1) (16-byte pieces; the rows are Spad = 16 k bytes)
+    auto stage_cols = [&](int c0, int c1) {
+      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * Spad);
+      uint4* dst = reinterpret_cast<uint4*>(l_stage);
+      const int n16 = (c1 - c0) * Spad / 16;
+      for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+    };
+    // ---- (A) chunk maps: every (chunk, block of 64 entry states) is a task of one wave
+    const int passes = (S + 63) / 64;
+    for (int task = wave; task < n_chunks * passes; task += NW) {
+      const int j = task / passes, q = task % passes;
+      const int bot = j * C, top = min(L - 1, bot + C - 1);
+      const int s0 = 64 * q + lane;
+      int state = s0 < S ? s0 : 0, idx = top;
+      int nsteps = 0, nstarts = 0, last_end = -1, last_state = state;
+      const int step_cap = (top - bot + 1) * (int)(set.max_mlen + 8) + S;  // (entry states the path cannot be in may hold arbitrary back-pointers)
+      for (int c1 = top + 1; c1 > bot;) {
+        const int c0 = max(bot, c1 - sub_cols);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stage_cols(c0, c1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        while (__ballot(state != 0 && idx >= c0 && nsteps < step_cap) != 0ull) {
+          if (state != 0 && idx >= c0 && nsteps < step_cap) {
+            const uint32_t inf = l_info[state];
+            const int kind = (int)(inf & 7u);
+            ++nsteps; nstarts += kind == 1; if (kind == 2) last_end = idx; last_state = state;
+            const int b = l_stage[(idx - c0) * Spad + state];
+            const uint32_t pe = pred_of(state, b);
+            if ((inf >> 3) & 1u) --idx;
+            const int nx = (int)(pe & 0x7FFFu);
+            state = nx < S ? nx : 0;
+          }
+        }
+        c1 = c0;
+      }
+      if (s0 < S) {
+        uint32_t* m = g_map + (size_t)3 * ((size_t)j * S + s0);
+        m[0] = (uint32_t)(nsteps >= step_cap ? 0 : state) | ((uint32_t)last_state << 16);
+        m[1] = (uint32_t)(nsteps & 0xFFFF) | ((uint32_t)(nstarts & 0xFFFF) << 16);
+        m[2] = (uint32_t)last_end;
+      }
+    }
+    __syncthreads();  // (+ the maps are in global memory: read back by thread 0 of this workgroup)
+    __threadfence();
+    // ---- (B) the chunks strung together from the end state
+    if (tid == 0) {
+      uint32_t e = (uint32_t)(S - 1), np = 0, nv = 0; int vb = 0, nxt = -1;
+      for (int j = n_chunks - 1; j >= 0; --j) {
+        HmmChunkRec r; r.entry = e; r.np0 = np; r.nv0 = nv; r.vb0 = vb; r.nxt0 = nxt; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        g_crec[j] = r;
+        const uint32_t* m = g_map + (size_t)3 * ((size_t)j * S + e);
+        const uint32_t m0 = map_lds ? m[0] : __builtin_nontemporal_load(m), m1 = map_lds ? m[1] : __builtin_nontemporal_load(m + 1), m2 = map_lds ? m[2] : __builtin_nontemporal_load(m + 2);
+        const uint32_t ns = m1 & 0xFFFFu;
+        np += ns; nv += m1 >> 16;
+        if ((int32_t)m2 >= 0) vb = (int32_t)m2;
+        if (ns) nxt = (int)(m0 >> 16);
+        e = m0 & 0xFFFFu;
+      }
+      tot[2] = (int)np; tot[3] = (int)nv;
+    }
+    __syncthreads();
+    __threadfence();
+    // ---- (C) every chunk again, from its entry state, with the decoding of the steps (the round loop of hmm_viterbi_kernel)
+    uint16_t* pbuf = path ? path + job.path_off : nullptr;
+    const int pcap = (int)job.path_cap;
+    auto code_at = [&](int i) -> int { return hmm_code(seq, i, L); };
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int edit_acc = 0, ref_acc = 0;
+    for (int j = wave; j < n_chunks; j += NW) {
+      const HmmChunkRec cr = g_crec[j];
+      const int bot = j * C, top = min(L - 1, bot + C - 1);
+      int state = (int)cr.entry, idx = top, np_c = (int)cr.np0, nv_c = (int)cr.nv0, vb_c = cr.vb0, nxt_c = cr.nxt0;
+      for (int c1 = top + 1; c1 > bot && state != 0;) {
+        const int c0 = max(bot, c1 - sub_cols);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stage_cols(c0, c1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        while (state != 0 && idx >= c0) {
+          // the chase of up to 64 steps: on wave-uniform values (state and column in SGPRs: scalar arithmetic, scalar branches)
+          int n = 0;
+          while (state != 0 && idx >= c0 && n < 64) {
+            l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
+            const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_info[state]);
+            const int b = __builtin_amdgcn_readfirstlane((int)l_stage[(idx - c0) * Spad + state]);
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)pred_of(state, b));
+            if ((inf >> 3) & 1u) --idx;
+            state = (int)(pe & 0x7FFFu);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          {  // ---- what the noted steps mean, one lane per step (events.rs:17-86, purity.rs:6-41, operations.rs:26-57)
+            const bool valid = lane < n;
+            const int st = valid ? (int)l_rec[2 * lane] : 0, ix = valid ? (int)l_rec[2 * lane + 1] : 0;
+            const uint32_t inf = valid ? l_info[st] : 0u;
+            const int kind = (int)(inf & 7u), blk = (int)((inf >> 8) & 0xFFu), expected = (int)((inf >> 16) & 0xFFu);
+            if (valid && pbuf && np_c + lane < pcap) pbuf[pcap - 1 - (np_c + lane)] = (uint16_t)st;
+            const int up = __shfl_up(st, 1);
+            const int nxt = lane == 0 ? nxt_c : up;
+            const int qbase = valid ? hmm_code_char(code_at(ix)) : 0;
+            const int dels = kind == 1 ? nxt - st - 1 : 0;
+            const int mism = kind == 4 && !(qbase == expected || expected == 'N');
+            int edit = valid ? dels + (kind == 3) + mism + (kind == 5) + (kind == 6) : 0;
+            int ref = valid ? dels + (kind == 3) + (kind == 4) + (kind == 6) : 0;
+            const unsigned long long ends = __ballot(valid && kind == 2), starts = __ballot(valid && kind == 1);
+            const unsigned long long ends_below = ends & below;
+            const int src_end = ends_below ? 63 - (int)__builtin_clzll(ends_below) : lane;
+            const int idx_end = __shfl(ix, src_end);
+            const int vb1 = ends_below ? idx_end : vb_c;
+            if (valid && kind == 1) {
+              uint32_t drop = 0;
+              const int mlen = (int)l_blocks[2 * nb + blk];
+              if (blk != nb - 1 && mlen <= 6) {
+                if (vb1 - ix < mlen) drop = 1;
+                else {
+                  const uint8_t* mot = l_mot + l_blocks[3 * nb + blk];
+                  for (int jj = 0; jj < mlen; ++jj) {
+                    const int obs = hmm_code_char(code_at(ix + jj + 1));
+                    if (mot[jj] != 'N' && obs != mot[jj]) drop = 1;
+                  }
+                }
+              }
+              const int nv = nv_c + (int)__builtin_popcountll(starts & below);
+              uint32_t* vrec = g_vis + 3 * (size_t)nv;
+              vrec[0] = (uint32_t)blk | (drop << 15); vrec[1] = (uint32_t)ix; vrec[2] = (uint32_t)vb1;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { edit += __shfl_xor(edit, o); ref += __shfl_xor(ref, o); }
+            const int src_last_end = ends ? 63 - (int)__builtin_clzll(ends) : lane;
+            const int idx_last_end = __shfl(ix, src_last_end);
+            const int last_state = __shfl(st, max(n - 1, 0));
+            np_c += n; nv_c += (int)__builtin_popcountll(starts); edit_acc += edit; ref_acc += ref;
+            if (n > 0) nxt_c = last_state;
+            if (ends) vb_c = idx_last_end;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        c1 = c0;
+      }
+    }
+    if (lane == 0) { atomicAdd(&tot[0], edit_acc); atomicAdd(&tot[1], ref_acc); }
+    __syncthreads();
+    __threadfence();
+    // ---- the end of the walk (the start state closes the path), then as in hmm_viterbi_kernel: path order, purity, the visits
+    int np = tot[2];
+    if (tid == 0 && pbuf && np < pcap) pbuf[pcap - 1 - np] = 0;
+    ++np;
+    if (pbuf) {
+      const int n = min(np, pcap), shift = pcap - n;
+      __syncthreads();
+      for (int base = 0; base < n; base += HMM_LONG_THREADS) {
+        const int f = base + tid;
+        uint16_t v = 0;
+        if (f < n) v = pbuf[shift + f];
+        __syncthreads();
+        if (f < n) pbuf[f] = v;
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      if (path_len) path_len[job.job_index] = (uint32_t)np;
+      const int edit = tot[0], mx = max(tot[1], qlen);
+      purity[job.job_index] = ((double)mx - (double)edit) / (double)mx;
+      if (edit_out) edit_out[job.job_index] = edit;
+      if (maxd_out) maxd_out[job.job_index] = mx;
+      // label_motifs over the kept copies, skip filter, counts, collapse: the visits were recorded back to front
+      int ns = 0, cum = 0, last_motif = -1, last_end = -1;
+      int32_t* const sp = spans3 + 3 * job.span_off;
+      for (int v = tot[3] - 1; v >= 0; --v) {
+        const uint32_t v0 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v), v1 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v + 1), v2 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v + 2);
+        const int blk = (int)(v0 & 0x7FFFu), b0 = (int)v1, b1 = (int)v2;
+        const bool keep = (v0 >> 15) == 0;
+        const int cnt = b1 - b0;
+        const int start = cum, end = cum + cnt;
+        cum = end;
+        const int motif = keep ? blk : nb - 1;
+        if (motif < n_motifs) {
+          l_cnt[motif] += 1;
+          if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
+          else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
+          last_end = end;
+        }
+      }
+      n_spans[job.job_index] = (uint32_t)ns;
+    }
+    __syncthreads();
+    for (int m = tid; m < n_motifs; m += HMM_LONG_THREADS) counts[job.count_off + m] = l_cnt[m];
+  }
+}
+
 // Job list of a launch class resolved on the device: candidate (locus, allele) slots with everything the host knows ahead of the
 // genotyper (motif set, where the allele will be, output places, workspace for its longest possible sequence) become jobs once the
 // genotyper has written how many alleles a locus has and how long they are -- no host round trip between the genotyper and this
@@ -1110,6 +1393,18 @@ __global__ void __launch_bounds__(1024) hmm_span_prefix_kernel(const uint32_t* _
   for (uint64_t i = b; i < e; ++i) { off[i] = run; run += n_spans[i]; }
 }
 
+
+// ---- host side of the long trace-back: room for the chunk maps of a job that may be long, and the launch behind a class's fill kernel
+static inline uint64_t hmm_map_words(uint32_t S, uint64_t max_len) {
+  const uint64_t L = max_len + 2;
+  if (L < (uint64_t)HMM_LONG_MIN) return 0;
+  const uint64_t n_chunks = (L + HMM_LONG_CHUNK - 1) / HMM_LONG_CHUNK;
+  return n_chunks * (3ull * S + 8ull) + 8;
+}
+static size_t hmm_long_lds_bytes(uint32_t S, uint32_t nb) {
+  size_t o = 64 + (size_t)12 * S + (size_t)20 * nb + ((S + 3) & ~3u) + (((size_t)S / 3 + 15) & ~(size_t)15) + 32;
+  return ((o + 15) & ~(size_t)15) + (size_t)(HMM_LONG_THREADS / 64) * (HMM_LONG_STG + 512) + HMM_LONG_MAP_LDS;
+}
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
   size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
   const size_t spad = (S + 15) & ~15u;
@@ -1379,6 +1674,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const uint64_t spad = (sd.S + 15) & ~15u;
     jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)seq_len[j] + 2), 16);
     jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
+    { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, seq_len[j]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
     if (spans3) span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
     count_total = std::max<uint64_t>(count_total, count_off[j] + (sd.n_blocks - 1));
@@ -1511,12 +1807,28 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)nullptr)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)nullptr, d_long_cls)
+    // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
+    uint32_t* d_long_cls = nullptr;
+    if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)HMM_LONG_MIN) {
+      void* dl = nullptr;
+      if ((rc = dev_get(c, S_HMM_LONG + so, 8 * ((size_t)jobs.size() + 16) * 4, &dl))) return rc;
+      d_long_cls = (uint32_t*)dl + (size_t)n_class * 0 + (i + 8 * (size_t)(n_class - 1));  // [count | job indices] of this class
+      TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+    }
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && cls == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
+    if (d_long_cls) {
+      const size_t llds = hmm_long_lds_bytes(maxS, maxnb);
+      if (llds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_traceback_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+      hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,
+                         (const uint8_t*)d_model, d_seq, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
+                         o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls);
+      TRGT_HIP_TRY(c, hipGetLastError());
+    }
     t.stop(i == 0 ? cells : 0);
     i = e;
   }
@@ -1592,6 +1904,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
         jd.seq_off = in.seq_off[sl]; jd.path_off = 0; jd.span_off = span_off[sl]; jd.count_off = count_off[sl];
         jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)in.cap[l] + 2), 16);  // room for the longest allele the locus can have
         jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)in.cap[l] + 2);
+        { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, in.cap[l]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
       }
     }
   }
@@ -1686,12 +1999,29 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)(d_count + k))
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)(d_count + k), d_long_cls)
+    uint32_t* d_long_cls = nullptr;
+    uint32_t max_cap_cls = 0;
+    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
+    if (!c->knobs.hmm_no_long_tb && (uint64_t)max_cap_cls + 2 >= (uint64_t)HMM_LONG_MIN) {
+      void* dl = nullptr;
+      if ((rc = dev_get(c, S_HMM_LONG + so, ((size_t)n_cand + 8 * 16) * 4, &dl))) return rc;
+      d_long_cls = (uint32_t*)dl + class_begin[k] + 8 * k;  // [count | job indices] of this class
+      TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+    }
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && k == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
 #undef TRGT_HMM_LAUNCH
     TRGT_HIP_TRY(c, hipGetLastError());
+    if (d_long_cls) {
+      const size_t llds = hmm_long_lds_bytes(maxS, maxnb);
+      if (llds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_traceback_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+      hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets,
+                         (const uint8_t*)mp->d_blob, in.seq_blob_dev, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
+                         o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls);
+      TRGT_HIP_TRY(c, hipGetLastError());
+    }
     t.stop(0);
   }
   for (int sidx = 0; sidx < 6; ++sidx)
