@@ -51,6 +51,12 @@ def _run_both(locus, b, params=None):
     finally:
         cctx.close()
     yield "host cluster", out
+    dctx = _lib.context_with_env(TRGT_HMM_NO_DEDUPE=1, TRGT_HMM_NO_LONG_TB=1, TRGT_HMM_LDS_FILL=1)  # every allele labelled by a job of its own, the round-3 HMM paths
+    try:
+        out = locus.run_batch(b, params, ctx=dctx)
+    finally:
+        dctx.close()
+    yield "plain hmm", out
     yield "host reads", locus.run_batch(b, params)
     reads_dev = torch.from_numpy(b["read_blob"]).cuda()
     flank_dev = torch.from_numpy(b["flank_blob"]).cuda()

@@ -58,13 +58,14 @@ struct trgt_knobs {
   bool sens_cons_unidir = false;  // TRGT_SENS_CONS_UNIDIR: consensus alignments back-traced unidirectionally (MemoryHigh) instead of by BiWFA
   bool sens_ward_ties = false;    // TRGT_SENS_WARD_TIES: nearest-neighbour ties of the Ward linkage go to the LAST candidate instead of the first
   bool sens_lw_order = false;     // TRGT_SENS_LW_ORDER: the Lance-Williams update summed in another order (last bits of the matrix central_read reads)
+  bool hmm_no_dedupe = false;   // TRGT_HMM_NO_DEDUPE: the second allele of a homozygous locus is labelled by an HMM job of its own (as the reference does) instead of taking the first one's results
   bool hmm_no_long_tb = false;  // TRGT_HMM_NO_LONG_TB: alleles of 1 536 columns and more are traced back by the fill kernel's one lane too (not by hmm_traceback_long_kernel)
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
   bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
   bool split_hmm = false;    // TRGT_SPLIT_HMM: the HMM of the loci the genotyper settles next to the device-side repair of the others, a second batch behind it
   int repair_blocks = 2048;  // TRGT_REPAIR_BLOCKS: workgroups (and workspaces) of the alignment kernel of the device-side repair
-  int repair_max_seg = 1024;  // TRGT_REPAIR_MAX_SEG: longest repeat segment the device-side repair takes (its alignment workspace is planned for it)
+  int repair_max_seg = 0;     // TRGT_REPAIR_MAX_SEG: longest repeat segment the device-side repair takes; 0 = by the batch: what its longest read can hold, between 1 024 and 16 384 bases
   bool timeline = false;     // TRGT_TIMELINE: host-side timeline of a call on stderr
   bool skip_bt = false;      // TRGT_DBG_SKIP_BT (make DEV=1 only): skip back-traces -- timing experiments, results are wrong
 };

@@ -1307,6 +1307,7 @@ struct HmmResolveAllArgs {
   uint32_t* n_spans; double* purity;
   uint32_t* verdict; uint32_t* hist; uint32_t* taken;  // [n], [512], [512] (hist and taken cleared by the caller)
   uint32_t len_shift;
+  const uint8_t* seq_blob; uint8_t* dup;   // dup [n] (optional): 1 = the second allele of a locus equals the first -- no job, its results are copied (hmm_dup_copy_kernel)
 };
 __device__ __forceinline__ void hmm_wave_keys(bool on, uint32_t key, int lane, uint32_t& rank, uint32_t& count, uint32_t& leader) {
   unsigned long long todo = __ballot(on);
@@ -1334,6 +1335,20 @@ __global__ void __launch_bounds__(256) hmm_resolve_count_kernel(const HmmResolve
     const bool on = !a.skip_locus[l] && (int32_t)al < a.n_alleles[l];
     if (!on) { a.n_spans[slot] = 0; a.purity[slot] = __builtin_nan(""); }  // what the caller's arrays hold for an allele that is not there
     v = on ? a.allele_len[slot] + 1u : 0u;
+    // a homozygous locus labels the same sequence twice in the reference (label_with_hmm per allele, tr.rs:454-492): here the second
+    // allele gets no job when it equals the first byte for byte (the candidates of a locus sit next to each other)
+    if (a.dup) {
+      uint8_t d = 0;
+      if (on && al == 1u && i > 0 && a.cand[i - 1].job_index == slot - 1u && a.allele_len[slot - 1u] == a.allele_len[slot]) {
+        const uint8_t* p = a.seq_blob + a.cand[i - 1].seq_off; const uint8_t* q = a.seq_blob + a.cand[i].seq_off;
+        const uint32_t n = a.allele_len[slot];
+        uint32_t t = 0;
+        while (t < n && p[t] == q[t]) ++t;
+        d = t == n ? 1 : 0;
+      }
+      a.dup[i] = d;
+      if (d) v = 0;
+    }
     a.verdict[i] = v;
     if (v) { const uint32_t b = (v - 1u) >> a.len_shift; key = hmm_class_of(a, i) * 64u + (63u - (b < 63u ? b : 63u)); }
   }
@@ -1365,6 +1380,19 @@ __global__ void __launch_bounds__(256) hmm_resolve_scatter_kernel(const HmmResol
   HmmJobDev jd = a.cand[i];
   jd.seq_len = v - 1u;
   a.jobs[a.class_begin[k] + base[key] + at + rank] = jd;
+}
+
+// Behind the HMM kernels: the results of a locus' first allele copied to its second one where hmm_resolve_count_kernel found them equal
+__global__ void __launch_bounds__(256) hmm_dup_copy_kernel(const HmmJobDev* __restrict__ cand, uint32_t n, const uint8_t* __restrict__ dup, const HmmSetDev* __restrict__ sets,
+                                                           int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans, uint32_t* __restrict__ counts, double* __restrict__ purity) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n || !dup[i]) return;
+  const HmmJobDev a = cand[i - 1], b = cand[i];
+  const uint32_t ns = n_spans[a.job_index];
+  n_spans[b.job_index] = ns; purity[b.job_index] = purity[a.job_index];
+  for (uint32_t k = 0; k < 3 * ns; ++k) spans3[3 * b.span_off + k] = spans3[3 * a.span_off + k];
+  const uint32_t nm = sets[b.set].n_blocks - 1;
+  for (uint32_t k = 0; k < nm; ++k) counts[b.count_off + k] = counts[a.count_off + k];
 }
 
 // Compaction of the per-job span lists (each job owns a worst-case region) into one dense array for the D2H copy.
@@ -1913,7 +1941,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   void *d_jobs = nullptr, *d_bp = nullptr, *d_visits = nullptr;
   const size_t jobs_bytes = (size_t)n_cand * sizeof(HmmJobDev);
   // (S_HMM_JOBS: candidates | job lists | 8 counts | 512 + 512 resolve counters | verdicts)
-  if ((rc = dev_get(c, S_HMM_JOBS + so, 2 * jobs_bytes + 64 + 4096 + 4 * (size_t)n_cand, &d_jobs)) || (rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp)) ||
+  if ((rc = dev_get(c, S_HMM_JOBS + so, 2 * jobs_bytes + 64 + 4096 + 4 * (size_t)n_cand + (size_t)n_cand + 16, &d_jobs)) || (rc = dev_get(c, S_HMM_BP + so, (size_t)bp_total, &d_bp)) ||
       (rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits)))
     return rc;
   HmmJobDev* const d_cand = (HmmJobDev*)d_jobs;
@@ -1946,6 +1974,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   while ((max_cap >> len_shift) >= 64) ++len_shift;
   // slots that are no candidates at all (loci left to the host path) hold "no allele" too
   TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
+  const uint8_t* d_dup = nullptr;
   if (c->knobs.hmm_resolve_one_wg) {
     for (int k = 0; k < 8; ++k) {
       if (!class_n[k]) continue;
@@ -1960,6 +1989,8 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     ra.skip_locus = in.d_skip; ra.n_alleles = in.d_n_alleles; ra.allele_len = in.d_allele_len;
     ra.jobs = d_list; ra.n_jobs = d_count; ra.n_spans = o_nsp.dev; ra.purity = o_pur.dev;
     ra.hist = d_count + 16; ra.taken = ra.hist + 512; ra.verdict = ra.taken + 512; ra.len_shift = len_shift;
+    ra.seq_blob = in.seq_blob_dev; ra.dup = c->knobs.hmm_no_dedupe ? nullptr : reinterpret_cast<uint8_t*>(ra.verdict + n_cand);
+    d_dup = ra.dup;
     TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64 + 4096, c->stream));
     const dim3 rg((unsigned)((n_cand + 255) / 256));
     hipLaunchKernelGGL(hmm_resolve_count_kernel, rg, dim3(256), 0, c->stream, ra);
@@ -2029,6 +2060,11 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
     }
+  if (d_dup) {  // homozygous loci: the second allele's results are the first one's
+    hipLaunchKernelGGL(hmm_dup_copy_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream, (const HmmJobDev*)d_cand, (uint32_t)n_cand, d_dup, (const HmmSetDev*)mp->d_sets,
+                       o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev);
+    TRGT_HIP_TRY(c, hipGetLastError());
+  }
   tl_mark(c, "hmm slots: classes launched");
   if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), P->tight_off.data(), n_slots, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();

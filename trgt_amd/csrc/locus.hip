@@ -803,7 +803,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     if (dev_repair) {
       { void* d_cnt = nullptr; if ((rc = dev_get(c, S_RP_COUNTS, 256, &d_cnt))) return rc; rp.counts = (uint32_t*)d_cnt; }
       rp.cap_groups = (uint32_t)std::min<int64_t>(2 * nl, 0x7FFFFFFF); rp.cap_jobs = (uint32_t)nr;
-      rp.max_seg = (uint32_t)std::max(16, c->knobs.repair_max_seg); rp.vote_lds_pos = (uint32_t)vote::VOTE_LDS_POS;
+      // (segments beyond what the register-resident kernels take go to the generic engine, whose workgroups are bounded by ws_budget: a batch of
+      //  10-kb alleles -- cfg3 -- is repaired on the device too instead of going back to the host: one-context call 22.2 -> 14.4 ms)
+      const uint32_t seg_auto = std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, max_read_len > 2u * (uint32_t)F ? max_read_len - 2u * (uint32_t)F : 0u));
+      rp.max_seg = c->knobs.repair_max_seg > 0 ? (uint32_t)std::max(16, c->knobs.repair_max_seg) : seg_auto; rp.vote_lds_pos = (uint32_t)vote::VOTE_LDS_POS;
       // room for the typical batch (a few per cent of the loci, segments of a few hundred bases); a locus that finds none takes the host path
       rp.cap_cigar = std::min<uint64_t>((uint64_t)nr * (2ull * rp.max_seg + 1), 32ull << 20);       // words
       rp.cap_out = std::min<uint64_t>((uint64_t)nr * (rp.max_seg + 16ull) + 64, 256ull << 20);      // bytes
