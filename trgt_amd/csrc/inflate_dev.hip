@@ -9,9 +9,10 @@
 // back from LDS goes through v_readfirstlane) so that the decoder's state lives in SGPRs, its arithmetic is scalar and its branches are
 // scalar branches -- no exec-mask bookkeeping around a one-lane loop; what parallelises is done by the whole wave at rendezvous points of a
 // uniform loop: loading the next window of compressed bytes into LDS, filling the lookup tables of a dynamic block, copying stored
-// blocks, and flushing finished 16-KB segments of the output.  The last 32 KB of output live in an LDS ring (the LZ77 window: matches
-// are LDS-to-LDS byte copies), so a block needs 40 KB of LDS and four blocks are in flight per CU -- one per SIMD: the decode loop is
-// latency-bound (a table lookup per symbol), and more waves is what hides it.
+// blocks, and flushing finished 4-KB segments of the output.  The last 8 KB of output live in an LDS ring (matches are byte copies by
+// the whole wave: from the ring, or -- the few that reach further back, up to 32 KB -- from the output already flushed to HBM), so a block
+// needs 16 KB of LDS and ten blocks are in flight per CU: the decode loop is latency-bound (a table look-up per symbol), and the
+// number of streams in flight is what sets the rate (32 KB of ring: four per CU, 7.7 GB/s).
 // A stream this decoder does not like (bad code lengths, distance too far back, output not exactly the announced size) is DECLINED
 // (status 0): the caller hands that block to zlib, which produces the data or the error message.
 #include "common.hpp"
@@ -20,7 +21,7 @@
 namespace trgt {
 namespace infl {
 
-constexpr uint32_t RING = 32768, RING_MASK = RING - 1, SEG = 16384;
+constexpr uint32_t RING = 8192, RING_MASK = RING - 1, SEG = 4096;  // the last 8 KB of output in LDS; older bytes are read back from the flushed output
 constexpr uint32_t IN_WIN = 3072;        // compressed bytes staged in LDS
 constexpr uint32_t HDR_ROOM = 1024;      // a dynamic block header (<= 19 * 3 + 320 * 14 bits) is parsed without a reload in between
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
@@ -222,15 +223,16 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             const uint32_t before = op;
             // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
             // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
-            if (dist >= 64u) {
-              for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (a round only reads what earlier rounds or earlier symbols wrote)
-                const uint32_t k = k0 + (uint32_t)lane;
-                if (k < len) sh.out[(op + k) & RING_MASK] = sh.out[(op + k - dist) & RING_MASK];
-              }
-            } else {
-              for (uint32_t k0 = 0; k0 < len; k0 += 64) {
-                const uint32_t k = k0 + (uint32_t)lane;
-                if (k < len) sh.out[(op + k) & RING_MASK] = sh.out[(op - dist + k % dist) & RING_MASK];
+            // A source byte still in the ring (not overwritten before this copy ends: its position + RING >= op + len) comes from LDS;
+            // an older one was flushed (every finished segment goes out before decoding continues) and is read back from the output.
+            for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (dist >= 64: a round only reads what earlier rounds or earlier symbols wrote)
+              const uint32_t k = k0 + (uint32_t)lane;
+              if (k < len) {
+                const uint32_t sp = dist >= 64u ? op + k - dist : op - dist + k % dist;
+                uint8_t v;
+                if (sp + RING >= op + len) v = sh.out[sp & RING_MASK];
+                else v = __hip_atomic_load(outp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh.out[(op + k) & RING_MASK] = v;
               }
             }
             op += len;
@@ -290,6 +292,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             else for (uint32_t q = i; q < upto; ++q) outp[q] = sh.out[q & RING_MASK];
           }
           flushed = upto;
+          __threadfence();  // (far matches read these bytes back)
         }
       }
       if (ev == EV_DONE) break;
@@ -321,7 +324,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   else if (preserve_dst) TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, dst, (size_t)dst_bytes, hipMemcpyHostToDevice, c->stream));  // (the bytes between the blocks come back as they were)
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_desc, descs, (size_t)n * sizeof(infl::BlockDesc), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 4);
+  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 10);
   hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
                      (uint8_t*)d_status, (unsigned int*)d_counter);
   TRGT_HIP_TRY(c, hipGetLastError());

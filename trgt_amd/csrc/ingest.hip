@@ -555,12 +555,13 @@ struct trgt_ingest {
   std::vector<std::unique_ptr<Bgzf>> idle_readers;
   // trgt_ingest_params.inflate_device: a context on that GPU and pinned staging for the compressed and the inflated blocks of a call
   std::mutex infl_mu;
-  trgt_hip_ctx* infl_ctx = nullptr; int infl_device = -1;
+  static constexpr int INFL_CTX = 3;  // contexts (streams, device buffers) the blocks of a call are spread over: the copies of one overlap the kernel of another
+  trgt_hip_ctx* infl_ctx[INFL_CTX] = {nullptr, nullptr, nullptr}; int infl_device = -1;
   void *pin_src = nullptr, *pin_dst = nullptr; size_t pin_src_cap = 0, pin_dst_cap = 0;
   ~trgt_ingest() {
     if (pin_src) (void)hipHostFree(pin_src);
     if (pin_dst) (void)hipHostFree(pin_dst);
-    if (infl_ctx) trgt_hip_destroy(infl_ctx);
+    for (auto* x : infl_ctx) if (x) trgt_hip_destroy(x);
   }
 };
 
@@ -571,10 +572,10 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
-  if (!h->infl_ctx || h->infl_device != device) {
-    if (h->infl_ctx) { trgt_hip_destroy(h->infl_ctx); h->infl_ctx = nullptr; }
-    const int rc = trgt_hip_create(device, &h->infl_ctx);
-    if (rc) { h->infl_ctx = nullptr; return bad("trgt_ingest: inflate_device " + std::to_string(device) + ": no usable gfx950 device"); }
+  if (!h->infl_ctx[0] || h->infl_device != device) {
+    for (auto*& x : h->infl_ctx) { if (x) trgt_hip_destroy(x); x = nullptr; }
+    for (auto*& x : h->infl_ctx)
+      if (trgt_hip_create(device, &x)) { x = nullptr; return bad("trgt_ingest: inflate_device " + std::to_string(device) + ": no usable gfx950 device"); }
     h->infl_device = device;
   }
   (void)hipSetDevice(device);
@@ -663,8 +664,30 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
   if (!pin(h->pin_dst, h->pin_dst_cap, (size_t)dst_total + 64)) return bad("trgt_ingest: no pinned memory for the inflated blocks");
   std::vector<uint8_t> status(descs.size(), 0);
   const double t_walk = now();
-  const int rc = trgt::inflate_blocks_device(h->infl_ctx, (int64_t)descs.size(), src, src_total, descs.data(), (uint8_t*)h->pin_dst, dst_total, status.data());
-  if (rc) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx));
+  {
+    // the blocks in file order, cut into up to INFL_CTX runs of about equal compressed size: a thread and a context each (upload, kernel
+    // and download of one run overlap those of the others)
+    const int G = (int)std::min<size_t>((size_t)trgt_ingest::INFL_CTX, (descs.size() + 255) / 256);
+    std::vector<size_t> cut((size_t)G + 1, 0);
+    for (int g = 1; g < G; ++g) {
+      const uint64_t want = descs[0].src_off + (src_total - descs[0].src_off) * (uint64_t)g / (uint64_t)G;
+      cut[(size_t)g] = (size_t)(std::lower_bound(descs.begin(), descs.end(), want, [](const trgt::infl::BlockDesc& d, uint64_t w) { return d.src_off < w; }) - descs.begin());
+    }
+    cut[(size_t)G] = descs.size();
+    std::vector<int> rcs((size_t)G, 0);
+    auto run = [&](int g) {
+      const size_t b0 = cut[(size_t)g], b1 = cut[(size_t)g + 1];
+      if (b1 <= b0) return;
+      std::vector<trgt::infl::BlockDesc> d(descs.begin() + (ptrdiff_t)b0, descs.begin() + (ptrdiff_t)b1);
+      const uint64_t s0 = d.front().src_off & ~63ull, d0 = d.front().dst_off;
+      const uint64_t s1 = d.back().src_off + d.back().src_len, d1 = d.back().dst_off + d.back().dst_len;
+      for (auto& x : d) { x.src_off -= s0; x.dst_off -= d0; }
+      rcs[(size_t)g] = trgt::inflate_blocks_device(h->infl_ctx[g], (int64_t)d.size(), src + s0, s1 - s0, d.data(), (uint8_t*)h->pin_dst + d0, d1 - d0, status.data() + b0);
+    };
+    if (G <= 1) run(0);
+    else { std::vector<std::thread> th; for (int g = 0; g < G; ++g) th.emplace_back(run, g); for (auto& t : th) t.join(); }
+    for (int g = 0; g < G; ++g) if (rcs[(size_t)g]) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx[g]));
+  }
   for (size_t b = 0; b < ents.size(); ++b)
     if (status[b] == 1) { ents[b].data = (const uint8_t*)h->pin_dst + descs[b].dst_off; sb.blocks.push_back(ents[b]); }
   std::sort(sb.blocks.begin(), sb.blocks.end(), [](const SharedBlocks::E& a, const SharedBlocks::E& b) { return a.coff < b.coff; });
