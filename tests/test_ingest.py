@@ -189,6 +189,12 @@ def test_errors_are_reported(tmp_path):
     b = rd.batch(bad)
     assert b["n_loci"] == 1 and b["id"] == ["TR1"] and len(b["skipped"]) == 2
     assert b["skipped"][0] == "Error at BED line 1: STRUC field missing" and b["skipped"][1].startswith("Error at BED line 2: Region start '100' with flank length '250' underflows")
+    # Locus::new (locus.rs:50-60) checks the region bounds BEFORE it decodes the info field: a line with both problems reports the bounds
+    open(bad, "w").write("chrA\t100\t161\tID=TR1;MOTIFS=CAG\nchrZ\t10001\t10061\tID=TR1;MOTIFS\n")
+    b = rd.batch(bad)
+    assert b["n_loci"] == 0 and len(b["skipped"]) == 2
+    assert b["skipped"][0].startswith("Error at BED line 1: Region start '100' with flank length '250' underflows")
+    assert b["skipped"][1] == "Error at BED line 2: FASTA reference does not contain chromosome 'chrZ' in BED file"
     with pytest.raises(_lib.TrgtHipError):
         rd.batch(str(tmp_path / "missing.bed"))
 

@@ -412,9 +412,11 @@ struct UploadBatch {
   trgt_hip_ctx* c; hipStream_t stream; MultiSegs m;
   struct Staging { void* pinned; const void* src; size_t bytes; };
   std::vector<Staging> staging;  // host memcpys still to do (run_staging: the caller may spread them over its threads)
+  std::vector<int> used_slots;   // staging slots holding a source of this batch
   UploadBatch(trgt_hip_ctx* c_, hipStream_t s) : c(c_), stream(s) { m.n = 0; }
   int flush() {
     run_staging();
+    used_slots.clear();
     if (m.n == 0) return TRGT_OK;
     size_t most = 0;
     for (int i = 0; i < m.n; ++i) most = std::max(most, m.s[i].bytes);
@@ -437,6 +439,9 @@ struct UploadBatch {
     if (bytes > H2D_KERNEL_MAX) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
     const void* from = src;
     if (stage_slot >= 0 && !is_pinned_host_ptr(src)) {
+      // (a slot's pinned staging holds ONE source until the batch is flushed: a second use of the slot flushes first)
+      for (const auto& u : used_slots) if (u == stage_slot) { const int rc = flush(); if (rc) return rc; break; }
+      used_slots.push_back(stage_slot);
       if ((int)c->h2d_stage.size() < S_COUNT) c->h2d_stage.resize(S_COUNT);
       auto& b = c->h2d_stage[(size_t)stage_slot];
       if (b.cap < bytes) {

@@ -776,8 +776,9 @@ void trgt_ingest_free(trgt_ingest_batch* b) {
 }
 
 // one line of the repeat catalog (BED: contig, start, end, ID=..;MOTIFS=..;STRUC=..), locus.rs:31-98
-static bool parse_bed_line(const std::string& line, std::string& contig, int64_t& start, int64_t& end, std::string& id, std::vector<std::string>& motifs,
-                           std::string& struc, std::string& err) {
+// Locus::new (locus.rs:31-60) in its order: the four fields and GenomicRegion::from_string (parse_bed_region), then -- by the caller --
+// check_region_bounds, then decode_fields / get_field (parse_bed_info): a line with a bounds problem AND a bad info field reports the bounds
+static bool parse_bed_region(const std::string& line, std::string& contig, int64_t& start, int64_t& end, std::string& info, std::string& err) {
   std::vector<std::string> f;
   { std::istringstream ss(line); std::string t; while (ss >> t) f.push_back(t); }
   if (f.size() != 4) { err = "Expected 4 fields in the format 'chrom start end info', found " + std::to_string(f.size()) + ": " + line; return false; }
@@ -795,8 +796,12 @@ static bool parse_bed_line(const std::string& line, std::string& contig, int64_t
   if (f[0].find_first_of(":-") != std::string::npos || f[1].find_first_of(":-") != std::string::npos || f[2].find_first_of(":-") != std::string::npos ||
       !u32_of(f[1], start) || !u32_of(f[2], end)) { err = "Invalid region encoding: " + enc; return false; }
   if (start >= end) { err = "Invalid region: start " + std::to_string(start) + " >= end " + std::to_string(end); return false; }
+  info = f[3];
+  return true;
+}
+static bool parse_bed_info(const std::string& info, std::string& id, std::vector<std::string>& motifs, std::string& struc, std::string& err) {
   std::map<std::string, std::string> fields;
-  { std::istringstream ss(f[3]); std::string kv;
+  { std::istringstream ss(info); std::string kv;
     while (std::getline(ss, kv, ';')) {
       const size_t eq = kv.find('=');
       if (eq == std::string::npos || eq == 0 || eq + 1 >= kv.size()) { err = "Field must be in 'name=value' format: '" + kv + "'"; return false; }
@@ -835,13 +840,15 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
       if (!line.empty() && line.back() == '\r') line.pop_back();
       L l; std::string e;
       auto skip = [&](const std::string& m) { skipped.push_back("Error at BED line " + std::to_string(line_no) + ": " + m); };
-      if (!parse_bed_line(line, l.contig, l.start, l.end, l.id, l.motifs, l.struc, e)) { skip(e); continue; }
+      std::string info;
+      if (!parse_bed_region(line, l.contig, l.start, l.end, info, e)) { skip(e); continue; }
       // check_region_bounds (locus.rs:220-257)
       const int64_t chrom_len = h->fasta.length(l.contig);
       if (chrom_len < 0) { skip("FASTA reference does not contain chromosome '" + l.contig + "' in BED file"); continue; }
       if (l.start < (int64_t)p->flank_len + 1) { skip("Region start '" + std::to_string(l.start) + "' with flank length '" + std::to_string(p->flank_len) + "' underflows for chromosome '" + l.contig + "'."); continue; }
       if (l.end + p->flank_len > 0xFFFFFFFFll) { skip("Region end '" + std::to_string(l.end) + "' with flank length '" + std::to_string(p->flank_len) + "' overflows for chromosome '" + l.contig + "'."); continue; }
       if (l.end + p->flank_len > chrom_len) { skip("Region end '" + std::to_string(l.end + p->flank_len) + "' with flank length '" + std::to_string(p->flank_len) + "' exceeds chromosome '" + l.contig + "' bounds (0.." + std::to_string(chrom_len) + ")."); continue; }
+      if (!parse_bed_info(info, l.id, l.motifs, l.struc, e)) { skip(e); continue; }
       // get_tr_and_flanks (locus.rs:168-190)
       if (!h->fasta.fetch(l.contig, l.start - p->flank_len, l.start, l.lf, e) || !h->fasta.fetch(l.contig, l.start, l.end, l.tr, e) ||
           !h->fasta.fetch(l.contig, l.end, l.end + p->flank_len, l.rf, e)) { skip(e); continue; }
