@@ -40,11 +40,15 @@ namespace {
 // ---------------------------------------------------------------------------------------------- BGZF
 // The blocks of a whole call inflated in one batch on the device (trgt_ingest_params.inflate_device): read-only while the workers run.
 struct SharedBlocks {
-  struct E { uint64_t coff; uint32_t csize, isize; const uint8_t* data; };
-  std::vector<E> blocks;  // sorted by coff
+  struct E { uint64_t coff; uint32_t csize, isize; const uint8_t* data; int32_t group; uint8_t ok; };
+  std::vector<E> blocks;  // sorted by coff; immutable once the store is published
+  std::vector<uint8_t> status;                   // per block, written by the device run of its group
+  std::atomic<int> group_ready[4] = {{0}, {0}, {0}, {0}};  // a group's blocks may be used once its run is through (release / acquire)
   const E* find(uint64_t coff) const {
     auto it = std::lower_bound(blocks.begin(), blocks.end(), coff, [](const E& e, uint64_t c) { return e.coff < c; });
-    return it != blocks.end() && it->coff == coff ? &*it : nullptr;
+    if (it == blocks.end() || it->coff != coff) return nullptr;
+    if (!group_ready[it->group].load(std::memory_order_acquire)) return nullptr;  // still on the device: the worker inflates it itself
+    return status[(size_t)(it - blocks.begin())] == 1 ? &*it : nullptr;
   }
 };
 
@@ -68,7 +72,7 @@ struct Bgzf {
   Bgzf(const Bgzf&) = delete;
   Bgzf& operator=(const Bgzf&) = delete;
   ~Bgzf() { if (fd >= 0) ::close(fd); if (zs_ready) inflateEnd(&zs); }
-  const SharedBlocks* shared = nullptr;  // blocks some one else inflated for this call (looked up behind the reader's own cache)
+  const std::atomic<const SharedBlocks*>* shared = nullptr;  // blocks the device inflates for this call (published when their list is known; looked up behind the reader's own cache)
   const uint8_t* cur_data = nullptr; size_t cur_size = 0;  // the current block's bytes: an entry of `cache` or of `shared`
   uint64_t n_shared = 0;
   bool open(const char* path) { fd = ::open(path, O_RDONLY); if (fd < 0) { err = std::string("cannot open ") + path; return false; } return true; }
@@ -78,7 +82,7 @@ struct Bgzf {
       if (cache[i].coff == coff) { cur = i; cache[i].stamp = ++clock; block_coff = coff; block_csize = cache[i].csize; pos = 0; ++n_hits; cur_data = cache[i].data.data(); cur_size = cache[i].data.size(); return true; }
       if (cache[i].stamp < cache[lru].stamp) lru = i;
     }
-    if (shared) if (const SharedBlocks::E* e = shared->find(coff)) { cur_data = e->data; cur_size = e->isize; block_coff = coff; block_csize = e->csize; pos = 0; ++n_shared; return true; }
+    if (const SharedBlocks* sb = shared ? shared->load(std::memory_order_acquire) : nullptr) if (const SharedBlocks::E* e = sb->find(coff)) { cur_data = e->data; cur_size = e->isize; block_coff = coff; block_csize = e->csize; pos = 0; ++n_shared; return true; }
     uint8_t h[18];
     const ssize_t got = ::pread(fd, h, 18, (off_t)coff);
     Block& B = cache[lru];
@@ -568,7 +572,8 @@ struct trgt_ingest {
 // The BGZF blocks between the compressed offsets of `ranges` ([first block, last block] pairs from the .bai chunks of the loci of a
 // call): read, inflated on the device in ONE batch (inflate_dev.hip) and left in pinned host memory for the workers.  Blocks the
 // device declines, and blocks beyond what the index names, are inflated by the worker that meets them, as before.
-static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uint64_t, uint64_t>>& ranges, SharedBlocks& sb, double* ms) {
+static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uint64_t, uint64_t>>& ranges, double share, SharedBlocks& sb,
+                           std::atomic<const SharedBlocks*>& publish, double* ms) {
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
@@ -584,6 +589,27 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
   for (auto& r : ranges) {
     if (!merged.empty() && r.first <= merged.back().second + 0x10000) merged.back().second = std::max(merged.back().second, r.second);
     else merged.push_back(r);
+  }
+  // The device takes the END of the compressed span (the workers walk the loci -- and the file -- from the front and meet it in the
+  // middle): `share` of the bytes, cut at a block start the index names (the first block of a chunk)
+  if (share < 1.0) {
+    uint64_t total = 0;
+    for (auto& m : merged) total += m.second - m.first + 0x10000;
+    uint64_t want = (uint64_t)((double)total * std::max(0.0, share)), acc = 0, cut = ~0ull;
+    for (size_t i = merged.size(); i-- > 0 && cut == ~0ull;) {
+      const uint64_t len = merged[i].second - merged[i].first + 0x10000;
+      if (acc + len < want) { acc += len; continue; }
+      const uint64_t pos = merged[i].second + 0x10000 - (want - acc);  // byte position of the cut inside this range
+      auto it = std::lower_bound(ranges.begin(), ranges.end(), std::make_pair(pos, (uint64_t)0));
+      cut = it != ranges.end() && it->first <= merged[i].second ? it->first : (i + 1 < merged.size() ? merged[i + 1].first : ~0ull);
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> tail;
+    for (auto& m : merged) {
+      if (m.second < cut) continue;
+      tail.emplace_back(std::max(m.first, cut), m.second);
+    }
+    merged.swap(tail);
+    if (merged.empty()) { if (ms) *ms = now() - t0; return TRGT_OK; }
   }
   const int fd = ::open(h->bam_path.c_str(), O_RDONLY);
   if (fd < 0) return bad("cannot open " + h->bam_path);
@@ -608,22 +634,26 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
   };
   if (!pin(h->pin_src, h->pin_src_cap, (size_t)src_total + 64)) return bad("trgt_ingest: no pinned memory for the compressed blocks");
   uint8_t* const src = (uint8_t*)h->pin_src;
-  // the compressed ranges, read by a few threads (page cache or disk)
-  {
+  {  // the compressed ranges, read by a few threads (page cache or disk), in pieces
+    struct Piece { uint64_t off; uint8_t* dst; size_t n; };
+    std::vector<Piece> pieces;
+    for (size_t i = 0; i < merged.size(); ++i) {
+      const uint64_t c0 = merged[i].first, c1 = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
+      for (uint64_t o = c0; o < c1; o += 8u << 20) pieces.push_back({o, src + src_at[i] + (o - c0), (size_t)std::min<uint64_t>(c1 - o, 8u << 20)});
+    }
     std::atomic<size_t> next{0}; std::atomic<int> failed{0};
     auto rd = [&]() {
       for (;;) {
         const size_t i = next.fetch_add(1);
-        if (i >= merged.size()) break;
-        const uint64_t c0 = merged[i].first, c1 = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
-        for (uint64_t o = c0; o < c1;) {
-          const ssize_t g = ::pread(fd, src + src_at[i] + (o - c0), (size_t)std::min<uint64_t>(c1 - o, 8u << 20), (off_t)o);
-          if (g <= 0) { failed = 1; break; }
-          o += (uint64_t)g;
+        if (i >= pieces.size()) break;
+        for (size_t done = 0; done < pieces[i].n;) {
+          const ssize_t g = ::pread(fd, pieces[i].dst + done, pieces[i].n - done, (off_t)(pieces[i].off + done));
+          if (g <= 0) { failed = 1; return; }
+          done += (size_t)g;
         }
       }
     };
-    const int nt = (int)std::min<size_t>(8, merged.size());
+    const int nt = (int)std::min<size_t>(4, pieces.size());
     if (nt <= 1) rd();
     else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(rd); for (auto& t : th) t.join(); }
     if (failed) return bad("trgt_ingest: reading the compressed blocks failed");
@@ -631,8 +661,8 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
   const double t_read = now();
   // block boundaries (every header names its block's size), payloads and inflated sizes
   std::vector<trgt::infl::BlockDesc> descs;
-  std::vector<SharedBlocks::E> ents;
   uint64_t dst_total = 0;
+  sb.blocks.clear();
   for (size_t i = 0; i < merged.size(); ++i) {
     const uint64_t c0 = merged[i].first, cend = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
     uint64_t coff = c0;
@@ -653,45 +683,44 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
       const uint32_t isize = hp[total - 4] | (hp[total - 3] << 8) | (hp[total - 2] << 16) | ((uint32_t)hp[total - 1] << 24);
       if (isize > 0 && isize <= 0x10000) {
         descs.push_back(trgt::infl::BlockDesc{src_at[i] + (coff - c0) + hdr, dst_total, total - hdr - 8, isize});
-        ents.push_back(SharedBlocks::E{coff, total, isize, nullptr});
+        sb.blocks.push_back(SharedBlocks::E{coff, total, isize, nullptr, 0});
         dst_total += ((uint64_t)isize + 63) & ~63ull;
       }
       coff += total;
     }
   }
-  sb.blocks.clear();
   if (descs.empty()) { if (ms) *ms = now() - t0; return TRGT_OK; }
   if (!pin(h->pin_dst, h->pin_dst_cap, (size_t)dst_total + 64)) return bad("trgt_ingest: no pinned memory for the inflated blocks");
-  std::vector<uint8_t> status(descs.size(), 0);
+  // the blocks in file order, cut into up to INFL_CTX runs of about equal compressed size: a thread and a context each (upload, kernel and
+  // download of one run overlap those of the others); the list is published first, a run's blocks become usable when it is through
+  const int G = (int)std::min<size_t>((size_t)trgt_ingest::INFL_CTX, (descs.size() + 255) / 256);
+  std::vector<size_t> cut((size_t)G + 1, 0);
+  for (int g = 1; g < G; ++g) {
+    const uint64_t want = descs[0].src_off + (src_total - descs[0].src_off) * (uint64_t)g / (uint64_t)G;
+    cut[(size_t)g] = (size_t)(std::lower_bound(descs.begin(), descs.end(), want, [](const trgt::infl::BlockDesc& d, uint64_t w) { return d.src_off < w; }) - descs.begin());
+  }
+  cut[(size_t)G] = descs.size();
+  for (int g = 0; g < G; ++g) for (size_t b = cut[(size_t)g]; b < cut[(size_t)g + 1]; ++b) { sb.blocks[b].group = g; sb.blocks[b].data = (const uint8_t*)h->pin_dst + descs[b].dst_off; }
+  sb.status.assign(descs.size(), 0);
+  for (auto& f : sb.group_ready) f.store(0, std::memory_order_relaxed);
+  publish.store(&sb, std::memory_order_release);
   const double t_walk = now();
-  {
-    // the blocks in file order, cut into up to INFL_CTX runs of about equal compressed size: a thread and a context each (upload, kernel
-    // and download of one run overlap those of the others)
-    const int G = (int)std::min<size_t>((size_t)trgt_ingest::INFL_CTX, (descs.size() + 255) / 256);
-    std::vector<size_t> cut((size_t)G + 1, 0);
-    for (int g = 1; g < G; ++g) {
-      const uint64_t want = descs[0].src_off + (src_total - descs[0].src_off) * (uint64_t)g / (uint64_t)G;
-      cut[(size_t)g] = (size_t)(std::lower_bound(descs.begin(), descs.end(), want, [](const trgt::infl::BlockDesc& d, uint64_t w) { return d.src_off < w; }) - descs.begin());
-    }
-    cut[(size_t)G] = descs.size();
-    std::vector<int> rcs((size_t)G, 0);
-    auto run = [&](int g) {
-      const size_t b0 = cut[(size_t)g], b1 = cut[(size_t)g + 1];
-      if (b1 <= b0) return;
+  std::vector<int> rcs((size_t)G, 0);
+  auto run = [&](int g) {
+    const size_t b0 = cut[(size_t)g], b1 = cut[(size_t)g + 1];
+    if (b1 > b0) {
       std::vector<trgt::infl::BlockDesc> d(descs.begin() + (ptrdiff_t)b0, descs.begin() + (ptrdiff_t)b1);
       const uint64_t s0 = d.front().src_off & ~63ull, d0 = d.front().dst_off;
       const uint64_t s1 = d.back().src_off + d.back().src_len, d1 = d.back().dst_off + d.back().dst_len;
       for (auto& x : d) { x.src_off -= s0; x.dst_off -= d0; }
-      rcs[(size_t)g] = trgt::inflate_blocks_device(h->infl_ctx[g], (int64_t)d.size(), src + s0, s1 - s0, d.data(), (uint8_t*)h->pin_dst + d0, d1 - d0, status.data() + b0);
-    };
-    if (G <= 1) run(0);
-    else { std::vector<std::thread> th; for (int g = 0; g < G; ++g) th.emplace_back(run, g); for (auto& t : th) t.join(); }
-    for (int g = 0; g < G; ++g) if (rcs[(size_t)g]) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx[g]));
-  }
-  for (size_t b = 0; b < ents.size(); ++b)
-    if (status[b] == 1) { ents[b].data = (const uint8_t*)h->pin_dst + descs[b].dst_off; sb.blocks.push_back(ents[b]); }
-  std::sort(sb.blocks.begin(), sb.blocks.end(), [](const SharedBlocks::E& a, const SharedBlocks::E& b) { return a.coff < b.coff; });
-  if (std::getenv("TRGT_INGEST_TRACE")) std::fprintf(stderr, "[ingest]   device inflate: %zu ranges, %.1f MB read in %.1f ms, headers %.1f ms, upload + kernel + download of %.1f MB %.1f ms\n", merged.size(), (double)src_total / 1e6, t_read - t0, t_walk - t_read, (double)dst_total / 1e6, now() - t_walk);
+      rcs[(size_t)g] = trgt::inflate_blocks_device(h->infl_ctx[g], (int64_t)d.size(), src + s0, s1 - s0, d.data(), (uint8_t*)h->pin_dst + d0, d1 - d0, sb.status.data() + b0);
+    }
+    if (!rcs[(size_t)g]) sb.group_ready[g].store(1, std::memory_order_release);
+  };
+  if (G <= 1) run(0);
+  else { std::vector<std::thread> th; for (int g = G - 1; g >= 0; --g) th.emplace_back(run, g); for (auto& t : th) t.join(); }
+  for (int g = 0; g < G; ++g) if (rcs[(size_t)g]) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx[g]));
+  if (std::getenv("TRGT_INGEST_TRACE")) std::fprintf(stderr, "[ingest]   device inflate: %zu ranges, %zu blocks, %.1f MB read in %.1f ms, headers %.1f ms, upload + kernel + download of %.1f MB %.1f ms\n", merged.size(), descs.size(), (double)src_total / 1e6, t_read - t0, t_walk - t_read, (double)dst_total / 1e6, now() - t_walk);
   if (ms) *ms = now() - t0;
   return TRGT_OK;
 }
@@ -859,17 +888,29 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   const double t1 = now();
   // ---- trgt_ingest_params.inflate_device: the blocks the index names for these loci, inflated on the GPU in one batch
   SharedBlocks shared_blocks;
+  std::atomic<const SharedBlocks*> shared_pub{nullptr};
   std::unique_lock<std::mutex> infl_lock(h->infl_mu, std::defer_lock);
   double t_prefetch = 0.0;
+  std::thread prefetch_thread;
+  int prefetch_rc = TRGT_OK;
+  struct JoinPrefetch { std::thread& t; ~JoinPrefetch() { if (t.joinable()) t.join(); } } join_prefetch{prefetch_thread};  // (the staging belongs to the handle: never left running)
+  std::vector<std::pair<uint64_t, uint64_t>> infl_ranges;
   if (p->inflate_device >= 0 && nl > 0) {
-    infl_lock.lock();  // (the pinned staging belongs to the handle: one call at a time in this mode)
-    std::vector<std::pair<uint64_t, uint64_t>> ranges;
+    infl_lock.lock();  // (one call at a time in this mode)
     for (auto& l : loci) {
       auto it = h->ref_id.find(l.contig);
       if (it == h->ref_id.end()) continue;
-      for (auto& ch : h->bai.query(it->second, std::max<int64_t>(0, l.start - p->flank_len), l.end + p->flank_len)) ranges.emplace_back(ch.first >> 16, ch.second >> 16);
+      for (auto& ch : h->bai.query(it->second, std::max<int64_t>(0, l.start - p->flank_len), l.end + p->flank_len)) infl_ranges.emplace_back(ch.first >> 16, ch.second >> 16);
     }
-    if (!ranges.empty()) { const int prc = prefetch_blocks(h, p->inflate_device, ranges, shared_blocks, &t_prefetch); if (prc) return prc; }
+    // The device inflates a SHARE of the blocks (from the end of the span, TRGT_INGEST_DEVICE_SHARE per cent, default 40) while the workers
+    // start at once on the rest: a stream inflates at 7 MB/s on the device whatever the decoder does, so the GPU adds to the host
+    // threads rather than replacing them.  100: everything on the device, the workers wait for nothing and inflate what is not ready.
+    static const double share = [] { const char* e = std::getenv("TRGT_INGEST_DEVICE_SHARE"); const double v = e && *e ? std::atof(e) : 40.0; return std::min(100.0, std::max(1.0, v)) / 100.0; }();
+    if (!infl_ranges.empty())
+      prefetch_thread = std::thread([&]() {
+        try { prefetch_rc = prefetch_blocks(h, p->inflate_device, infl_ranges, share, shared_blocks, shared_pub, &t_prefetch); }
+        catch (const std::exception& e) { h->err = std::string("trgt_ingest: device inflate: ") + e.what(); prefetch_rc = TRGT_ERR_NOMEM; }
+      });
   }
   // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
   int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // (more than 32 workers lose: tools/ingest_scaling.py)
@@ -888,7 +929,7 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     }
     struct Back { trgt_ingest* h; std::unique_ptr<Bgzf>& z; ~Back() { if (z && z->err.empty()) { std::lock_guard<std::mutex> g(h->idle_mu); h->idle_readers.push_back(std::move(z)); } } } back{h, zp};
     Bgzf& z = *zp;
-    z.shared = shared_blocks.blocks.empty() ? nullptr : &shared_blocks;
+    z.shared = p->inflate_device >= 0 ? &shared_pub : nullptr;
     z.block_coff = ~0ull; z.block_csize = 0; z.cur_data = nullptr; z.cur_size = 0; z.pos = 0;  // (a kept reader may point at a shared block of an earlier call)
     const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits, shared0 = z.n_shared;
     RawRec rec;
@@ -948,6 +989,8 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   };
   if (nthr <= 1) work();
   else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
+  if (prefetch_thread.joinable()) prefetch_thread.join();
+  if (prefetch_rc) return prefetch_rc;
   for (auto& l : loci) if (!l.err.empty()) return bad(l.id + ": " + l.err);
   const double t2 = now();
   // ---- the arrays of trgt_locus_batch_in (+ what the writers need per read)
