@@ -348,7 +348,10 @@ __device__ unsigned long long g_hmm_prof[16];
 #endif
 constexpr int HMM_LONG_MIN = 1536;   // columns from which an allele's trace-back goes to hmm_traceback_long_kernel
 constexpr int HMM_LONG_CHUNK = 64;   // columns per chunk map there
-constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback
+constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback (one-wave models)
+// ... models of several waves (rows of 80 to 320 bytes) stage 16 columns at a time: 1 KB held five columns of a 192-state model, and every
+// chunk costs a global round trip and two barriers
+__host__ __device__ constexpr int hmm_stage_bytes(int spad) { return spad > 64 ? (16 * spad > HMM_STAGE_BYTES ? 16 * spad : HMM_STAGE_BYTES) : HMM_STAGE_BYTES; }
 constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4], block, flags, bp column
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
@@ -469,7 +472,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
   const uint8_t* g_motifs = model + set.off_motifs;
   // behind the back-pointer staging window: window of symbol codes | motif bytes | motif visits | motif counts
-  uint8_t* l_seq = l_stage + (HMM_STAGE_BYTES > Spad ? HMM_STAGE_BYTES : Spad);
+  uint8_t* l_seq = l_stage + hmm_stage_bytes(Spad);
   uint8_t* l_mot = l_seq + HMM_CODE_WINDOW + HMM_CODE_PAD;
   const int mot_bytes = (S - 7 - n_motifs) / 3;
   uint32_t* l_vis = reinterpret_cast<uint32_t*>(l_mot + ((mot_bytes + 15) & ~15));
@@ -787,7 +790,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   //      90 instructions per step: 750 cycles, a third of the kernel.)  What a step needs from its neighbours is little: the state
   //      walked just before it (the implied leading deletions of a block start) and the column of the last block end before it (the
   //      bases of the visit a block start closes): a lane shift and a ballot.
-  const int cols_per_chunk = max(1, HMM_STAGE_BYTES / Spad);
+  const int cols_per_chunk = max(1, hmm_stage_bytes(Spad) / Spad);
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
   uint32_t* const g_vis = visit_ws + job.visit_off;  // visits HMM_VIS_LDS, HMM_VIS_LDS + 1, ... at their own index
   const int pcap = (int)job.path_cap;
@@ -1434,9 +1437,9 @@ static size_t hmm_long_lds_bytes(uint32_t S, uint32_t nb) {
   return ((o + 15) & ~(size_t)15) + (size_t)(HMM_LONG_THREADS / 64) * (HMM_LONG_STG + 512) + HMM_LONG_MAP_LDS;
 }
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
-  size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + HMM_STAGE_BYTES;
+  size_t o = 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15) + (((size_t)16 * nb + 15) & ~(size_t)15) + (size_t)hmm_stage_bytes((int)((S + 15) & ~15u));
   const size_t spad = (S + 15) & ~15u;
-  if (spad > (size_t)HMM_STAGE_BYTES) o += spad - HMM_STAGE_BYTES;
+  (void)spad;
   o += HMM_CODE_WINDOW + HMM_CODE_PAD + (((size_t)S / 3 + 15) & ~(size_t)15) + 12 * (size_t)HMM_VIS_LDS + 4 * (size_t)nb;
   o += 8 + 8 * 64;  // the steps of a trace-back round (l_rec)
   return o + 64;
