@@ -84,7 +84,7 @@ def test_catalog_coordinates_parse_like_genomic_region(tmp_path):
         start, end = rest.split("-")
         lines.append("%s\t%s\t%s\t%s" % (contig, start, end, info))
         want.append(None if c["ok"] else c["error"])
-    lines += ["", "chrA\t12abc\t20\t" + info, "chrA\t-3\t20\t" + info, "chrA\t100\t200\tID=x;MOTIFS=CAG", "chrA\t250\t260\t" + info, "chrA\t251\t260\t" + info]
+    lines += ["", "chrA\t12abc\t20\t" + info, "chrA\t-3\t20\t" + info, "chrA\t10001\t10061\tID=x;MOTIFS=CAG", "chrA\t250\t260\t" + info, "chrA\t251\t260\t" + info]
     bed = tmp_path / "cat.bed"
     bed.write_text("\n".join(lines) + "\n")
     rd = ingest.Reader(os.path.join(ex, "sample.bam"), os.path.join(ex, "reference.fasta"))
