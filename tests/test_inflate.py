@@ -204,7 +204,11 @@ def test_ingestion_with_device_inflate_gives_the_same_batch(tmp_path):
     rd = ingest.Reader(ds["bam"], ds["fasta"])
     a = rd.batch(ds["bed"], keep_bam4=1)
     b = rd.batch(ds["bed"], keep_bam4=1, inflate_device=0)
-    c = rd.batch(ds["bed"], first_locus=10, max_loci=25, inflate_device=0)   # a second call: staging reused, readers kept
+    os.environ["TRGT_INGEST_DEVICE_SHARE"] = "100"  # every block the index names goes to the device (default: the last 40 % of the span)
+    try:
+        c = rd.batch(ds["bed"], first_locus=10, max_loci=25, inflate_device=0)   # a second call: staging reused, readers kept
+    finally:
+        del os.environ["TRGT_INGEST_DEVICE_SHARE"]
     a2 = rd.batch(ds["bed"], first_locus=10, max_loci=25)
     for x, y in ((a, b), (a2, c)):
         assert x["n_loci"] == y["n_loci"] and x["n_reads"] == y["n_reads"] and x["n_reads"] > 100

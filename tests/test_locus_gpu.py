@@ -13,6 +13,11 @@ def mods():
     return locus, synth
 
 
+def _lib_mod():
+    from trgt_amd import _lib
+    return _lib
+
+
 def _run_both(locus, b, params=None):
     """trgt_locus_batch three ways -- host glue for every locus (TRGT_HOST_GENOTYPER), reads on the host with the device genotyper
     working on the uploaded copy, reads resident in HBM -- all must give the oracle's results."""
@@ -245,6 +250,14 @@ def test_cluster_genotyper_cfg5_matches_oracle(oracle, mods):
         assert int(out.stats[15]) > 0 and int(out.stats[1]) > 48 * 10, mode  # edit-distance and consensus jobs ran on the GPU
         if mode in ("host reads", "device", "host repair", "mixed repair"):  # ... and the linkage, the groups and the rounds on the device as well
             assert int(out.stats[22]) == 48 and int(out.stats[23]) == 0, (mode, out.stats[22:24])
+    # arenas too small for all loci: some are genotyped by the device chain, the others find no room and take the host path in the same call
+    actx = _lib_mod().context_with_env(TRGT_CLUSTER_ARENA_KB=600)
+    try:
+        out = locus.run_batch(b, locus.Params(), ctx=actx)
+    finally:
+        actx.close()
+    _compare(oracle, locus, b, out, locus.Params(), range(48))
+    assert 0 < int(out.stats[22]) < 48 and int(out.stats[23]) > 0, out.stats[22:24]
     # short alleles: |a|*|b| <= MAX_OPS for every pair, so the whole distance matrix comes from edit-distance alignments
     b = synth.generate(24, first_locus=7000, config=5, max_allele_bp=90)
     for mode, out in _run_both(locus, b):

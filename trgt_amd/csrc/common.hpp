@@ -61,6 +61,7 @@ struct trgt_knobs {
   bool hmm_no_dedupe = false;   // TRGT_HMM_NO_DEDUPE: the second allele of a homozygous locus is labelled by an HMM job of its own (as the reference does) instead of taking the first one's results
   bool hmm_no_long_tb = false;  // TRGT_HMM_NO_LONG_TB: alleles of 1 536 columns and more are traced back by the fill kernel's one lane too (not by hmm_traceback_long_kernel)
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
+  int cluster_arena_kb = 0;  // TRGT_CLUSTER_ARENA_KB: developer switch -- the CIGAR / result / scratch arenas of the device-side cluster genotyper capped at this many KB (loci that find no room take the host path: the mixed case of the tests)
   bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
   bool host_repair = false;  // TRGT_HOST_REPAIR: loci whose pick lacks majority support go back to the host (no device-side consensus repair)
   bool split_hmm = false;    // TRGT_SPLIT_HMM: the HMM of the loci the genotyper settles next to the device-side repair of the others, a second batch behind it

@@ -905,7 +905,7 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     // The device inflates a SHARE of the blocks (from the end of the span, TRGT_INGEST_DEVICE_SHARE per cent, default 40) while the workers
     // start at once on the rest: a stream inflates at 7 MB/s on the device whatever the decoder does, so the GPU adds to the host
     // threads rather than replacing them.  100: everything on the device, the workers wait for nothing and inflate what is not ready.
-    static const double share = [] { const char* e = std::getenv("TRGT_INGEST_DEVICE_SHARE"); const double v = e && *e ? std::atof(e) : 40.0; return std::min(100.0, std::max(1.0, v)) / 100.0; }();
+    const double share = [] { const char* e = std::getenv("TRGT_INGEST_DEVICE_SHARE"); const double v = e && *e ? std::atof(e) : 40.0; return std::min(100.0, std::max(1.0, v)) / 100.0; }();  // (read per call)
     if (!infl_ranges.empty())
       prefetch_thread = std::thread([&]() {
         try { prefetch_rc = prefetch_blocks(h, p->inflate_device, infl_ranges, share, shared_blocks, shared_pub, &t_prefetch); }

@@ -925,6 +925,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       ca.cap_cigar = std::min<uint64_t>(2ull * cl_reads * (2ull * max_seg + 1), 96ull << 20);   // words
       ca.cap_out = std::min<uint64_t>(2ull * (cl_reads + 2ull * n_cl) * ((uint64_t)max_seg + 16) + 64, 256ull << 20);  // bytes
       ca.cap_scratch = std::min<uint64_t>(6ull * cl_reads + 12ull * n_cl * ((uint64_t)max_seg + 1) + 64, 32ull << 20);  // words
+      if (c->knobs.cluster_arena_kb > 0) {
+        const uint64_t kb = (uint64_t)c->knobs.cluster_arena_kb;
+        ca.cap_cigar = std::min<uint64_t>(ca.cap_cigar, kb * 256); ca.cap_out = std::min<uint64_t>(ca.cap_out, kb * 1024); ca.cap_scratch = std::min<uint64_t>(ca.cap_scratch, kb * 256);
+      }
       const bool big = cl_max_nr > 64;
       void *d_cnt = nullptr, *d_rec = nullptr, *d_cls = nullptr, *d_es = nullptr, *d_gm = nullptr, *d_edj = nullptr, *d_j = nullptr, *d_g = nullptr, *d_ed2 = nullptr, *d_es2 = nullptr,
            *d_cig = nullptr, *d_clen = nullptr, *d_vout = nullptr, *d_vlen = nullptr, *d_vscr = nullptr;
