@@ -1,20 +1,20 @@
 #!/bin/bash
-# sweep_r04.sh TAG: the whole-catalog parity sweeps of round 4 (fresh locus ranges: 8.0 M and up) + the fuzzers; summary lines into gpurun_out/TAG_parity_sweep.txt
+# sweep_r04.sh TAG: the whole-catalog parity sweeps of round 4 (fresh locus ranges: 9.0 M and up on the last run, 8.0 M on the first) + the fuzzers; summary lines into gpurun_out/TAG_parity_sweep.txt
 TAG=${1:-r04}
 O=gpurun_out/${TAG}_parity_sweep.txt; mkdir -p gpurun_out; : > $O
 run() { echo "# parity_sweep.py $*" >> $O; python tests/tools/parity_sweep.py "$@" 2>&1 | grep -E "RESULT|MISMATCH" | head -20 >> $O; }
-run 2 300000 8000000
-run 4 300000 8000000
-run 5 100000 8000000 2000
-run 3 4000 8000000 70
-run 2 60000 8400000 --bam4
-run 5 20000 8400000 2000 --bam4
-run 4 60000 8500000 --host-reads
-run 5 20000 8500000 2000 --host-reads
-run 4 40000 8600000 --rq 0.85
-run 5 10000 8600000 2000 --depth 20
-TRGT_HOST_CLUSTER=1 python tests/tools/parity_sweep.py 5 10000 8700000 2000 2>&1 | grep -E "RESULT|MISMATCH" | sed 's/^/(TRGT_HOST_CLUSTER=1) /' >> $O
-TRGT_HMM_NO_LONG_TB=1 python tests/tools/parity_sweep.py 3 1000 8700000 70 2>&1 | grep -E "RESULT|MISMATCH" | sed 's/^/(TRGT_HMM_NO_LONG_TB=1) /' >> $O
+run 2 300000 9000000
+run 4 300000 9000000
+run 5 100000 9000000 2000
+run 3 4000 9000000 70
+run 2 60000 9400000 --bam4
+run 5 20000 9400000 2000 --bam4
+run 4 60000 9500000 --host-reads
+run 5 20000 9500000 2000 --host-reads
+run 4 40000 9600000 --rq 0.85
+run 5 10000 9600000 2000 --depth 20
+TRGT_HOST_CLUSTER=1 python tests/tools/parity_sweep.py 5 10000 9700000 2000 2>&1 | grep -E "RESULT|MISMATCH" | sed 's/^/(TRGT_HOST_CLUSTER=1) /' >> $O
+TRGT_HMM_NO_LONG_TB=1 python tests/tools/parity_sweep.py 3 1000 9700000 70 2>&1 | grep -E "RESULT|MISMATCH" | sed 's/^/(TRGT_HMM_NO_LONG_TB=1) /' >> $O
 python tests/tools/hmm_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/wfa_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/window_fuzz.py 2>&1 | grep RESULT >> $O
