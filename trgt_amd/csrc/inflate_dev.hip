@@ -41,7 +41,7 @@ struct Shared {
   uint16_t code[320];                     // canonical code of every symbol (table fill)
   uint8_t lens[320], lens2[320];
   uint16_t offs[16], next[16];            // prepare_codes
-  alignas(16) uint8_t in_win[IN_WIN + 16];
+  alignas(16) uint8_t in_win[IN_WIN + 32];  // (+ what the refills of one symbol may read past a window that already reaches the end of the input)
   alignas(16) uint8_t out[RING];
 };
 
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
       // ---- what the wave does together
       if (ev == EV_RELOAD) {
         const uint32_t w0 = sh.win_base;  // (a multiple of 4)
-        for (uint32_t i = 4u * (uint32_t)lane; i < IN_WIN + 16; i += 256) {
+        for (uint32_t i = 4u * (uint32_t)lane; i < IN_WIN + 32; i += 256) {
           uint32_t w = 0;
           const uint32_t p = w0 + i;
           if (p + 4 <= in_len) __builtin_memcpy(&w, in + p, 4);
