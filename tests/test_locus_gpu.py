@@ -422,7 +422,8 @@ def test_cfg3_alleles_to_10kb(oracle, mods):
 def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     # the planner's choices must not show in the results: one launch instead of two for the flank alignments, the general
     # instantiation of the dedicated kernel instead of the compile-time flank configuration, the host genotyper, other numbers of
-    # waves per alignment, no seeded windows / other numbers of segments for them
+    # waves per alignment, no seeded windows / other numbers of segments for them, no band / other bands for the back-trace of what the
+    # pre-filter keeps
     import torch
     locus, synth = mods
     b = synth.generate(96, first_locus=12000)
@@ -431,7 +432,8 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     _compare(oracle, locus, b, base, locus.Params(), range(0, 96, 4))
     for env, val in (("TRGT_WFA_ONE_LAUNCH", "1"), ("TRGT_WFA_NO_SPEC", "1"), ("TRGT_HOST_GENOTYPER", "1"), ("TRGT_HEAVY_THREADS", "256"),
                      ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192"), ("TRGT_WFA_NO_WINDOW", "1"), ("TRGT_WIN_SEGMENTS", "4"),
-                     ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128"), ("TRGT_WFA_NO_FILTER", "1"), ("TRGT_FILTER_PER_CU", "3")):
+                     ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128"), ("TRGT_WFA_NO_FILTER", "1"), ("TRGT_FILTER_PER_CU", "3"), ("TRGT_HEAVY_BAND", "0"), ("TRGT_HEAVY_BAND", "20"),
+                     ("TRGT_HEAVY_BAND", "256")):
         from trgt_amd import _lib
         vctx = _lib.context_with_env(**{env: val})
         try:

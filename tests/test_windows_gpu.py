@@ -258,3 +258,72 @@ def test_one_base_gap_shortcut(oracle):
     assert int(out.stats[21]) >= int(out2.stats[21]) + 40  # the gaps outside the margins are settled without an alignment
     for k in ("span_start", "span_end", "allele_len", "classification"):
         assert np.array_equal(getattr(out, k), getattr(out2, k)), k
+
+
+def _short_read_locus(rng, reads_fn, n_reads):
+    # as _locus, but the reads under test are at least 300 bases shorter than the locus' longest read: "too short to span the locus",
+    # the list that meets the pre-filter, and what it keeps is back-traced inside a band (heavy_band_kernel / band_check_kernel)
+    lf, rf = rand_dna(rng, 250), rand_dna(rng, 250)
+    tr = b"CAG" * 20
+    reads = [reads_fn(rng, i, lf, rf, tr) for i in range(n_reads)]
+    reads.append(rand_dna(rng, 330) + lf + tr + rf + rand_dna(rng, 330))
+    reads.append(rand_dna(rng, 320) + lf + tr + rf + rand_dna(rng, 325))
+    assert max(len(r) for r in reads[:n_reads]) < 915 and min(len(r) for r in reads[:n_reads]) >= 250, sorted(len(r) for r in reads)
+    return dict(left_flank=lf, right_flank=rf, tr=tr, motifs=[b"CAG"], ploidy=2, reads=reads)
+
+
+def _no_seed(rng, flank, extra=0):
+    # a mismatch inside the first twelve bases of each of the eight segments (no seed anywhere: penalty 16), then `extra` more
+    pos = [31 * s + 2 + (5 * s) % 9 for s in range(8)] + [31 * (j % 8) + 14 + j // 8 * 3 for j in range(extra)]
+    return _sub(rng, flank, pos)
+
+
+@pytest.mark.parametrize("band", [None, "0", "24", "256"])
+def test_kept_alignments_run_inside_their_band(oracle, capfd, band):
+    """What the pre-filter keeps is aligned again with a back-trace, inside the diagonals its penalty and end diagonal allow.  Reads too
+    short to span the locus whose left flank has no seed: penalties from 16 to beyond the default band (96), insertions and deletions
+    (the band must hold the whole path, not just its end), the flank at the very start / end of the read (band clipped by the text), the
+    flank twice at the same penalty (the first end diagonal wins) and reads without it.  Same results as the oracle whatever the band."""
+    rng = np.random.default_rng(4242)
+
+    def reads_fn(rng, i, lf, rf, tr):
+        k = i % 12
+        l = _no_seed(rng, lf, extra=(0, 3, 8, 4, 0, 2, 0, 0, 1, 0, 0, 6)[k])
+        if k == 3:    # a 20-base insertion and a 6-base deletion in the flank: penalty 16 + 8 + 25 + 11
+            l = l[:90] + rand_dna(rng, 20) + l[90:170] + l[176:]
+        elif k == 4:  # three long insertions: beyond the default band
+            l = l[:60] + rand_dna(rng, 30) + l[60:130] + rand_dna(rng, 30) + l[130:200] + rand_dna(rng, 28) + l[200:]
+        elif k == 5:  # two insertions: close to the default band
+            l = l[:80] + rand_dna(rng, 28) + l[80:180] + rand_dna(rng, 30) + l[180:]
+        head = rand_dna(rng, 0 if k == 6 else 3 if k == 7 else int(rng.integers(20, 200)))
+        if k == 8:    # the same damaged flank twice
+            head = head + l + rand_dna(rng, 40)
+        if k == 9:    # no left flank at all
+            l = rand_dna(rng, 250)
+        r = _sub(rng, rf, [100]) if k != 10 else b""  # k == 10: the read ends with the left flank
+        tail = rand_dna(rng, int(rng.integers(5, 60))) if k != 10 else b""
+        mid = tr if k != 10 else b""
+        return (head + l + mid + r + tail)[:900]
+
+    from trgt_amd import _lib
+    env = dict(TRGT_WFA_DEBUG=1)
+    if band is not None:
+        env["TRGT_HEAVY_BAND"] = band
+    dctx = _lib.context_with_env(**env)
+    try:
+        _check(oracle, [_short_read_locus(rng, reads_fn, n_reads=24) for _ in range(5)], ctx=dctx)
+    finally:
+        dctx.close()
+    lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[spans+] kept by the pre-filter")]
+    if band == "0":
+        assert not lines
+        return
+    nums = [int(t) for t in lines[-1].replace(",", " ").replace("(", " ").replace(")", " ").replace(":", " ").split() if t.isdigit()]
+    kept, banded, failed, whole = nums
+    assert failed == 0 and kept == banded + whole and kept >= 60, lines[-1]
+    if band is None:
+        assert banded >= 50 and whole >= 5, lines[-1]   # (the three long insertions: penalty above 96)
+    if band == "24":
+        assert 10 <= banded < kept - 20, lines[-1]
+    if band == "256":
+        assert whole == 0, lines[-1]

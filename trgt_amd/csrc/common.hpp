@@ -21,6 +21,7 @@
 // that skips work (TRGT_DBG_SKIP_BT exists only under `make DEV=1`).
 struct trgt_knobs {
   int flank_threads = 256;   // TRGT_FLANK_THREADS: threads per flank alignment of the back-tracing kernel
+  int heavy_band = 96;       // TRGT_HEAVY_BAND: the back-trace of what the pre-filter keeps runs inside the band its penalty allows when that is at most this (0: off)
   int heavy_threads = 0;     // TRGT_HEAVY_THREADS: ... of its launch over the expensive alignments (0: 192 when flank_threads == 256)
   int win_threads = 64;      // TRGT_WIN_THREADS: ... of the windowed launch
   int win_segments = 8;      // TRGT_WIN_SEGMENTS: 4 / 6 / 8 segments for the window search
@@ -60,6 +61,7 @@ struct trgt_knobs {
   bool sens_lw_order = false;     // TRGT_SENS_LW_ORDER: the Lance-Williams update summed in another order (last bits of the matrix central_read reads)
   bool hmm_no_dedupe = false;   // TRGT_HMM_NO_DEDUPE: the second allele of a homozygous locus is labelled by an HMM job of its own (as the reference does) instead of taking the first one's results
   bool hmm_no_long_tb = false;  // TRGT_HMM_NO_LONG_TB: alleles of 1 536 columns and more are traced back by the fill kernel's one lane too (not by hmm_traceback_long_kernel)
+  bool hmm_four_rounds = false;  // TRGT_HMM_FOUR_ROUNDS: the register fill fetches across lanes once per pass of a column (four rounds) instead of twice per column
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
   int cluster_arena_kb = 0;  // TRGT_CLUSTER_ARENA_KB: developer switch -- the CIGAR / result / scratch arenas of the device-side cluster genotyper capped at this many KB (loci that find no room take the host path: the mixed case of the tests)
   bool host_cluster = false; // TRGT_HOST_CLUSTER: Genotyper::Cluster loci take the host path (linkage, groups and round sequencing on host threads, locus_cluster.hpp)
@@ -216,7 +218,7 @@ enum Slot {
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED, S_WFA_RETRY, S_WFA_RETRY_B, S_WFA_WS_C, S_WFA_COUNTER_C, S_WFA_CELLS_C, S_WFA_RETRY_C, S_WFA_MID, S_WFA_MID_B, S_WFA_MID_C,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
-  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY, S_FS_NOSEED,
+  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY, S_FS_NOSEED, S_FS_BANDJOBS, S_FS_HRESTJOBS, S_FS_BSCORE,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED, S_GT_GENO,

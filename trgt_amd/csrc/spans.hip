@@ -35,6 +35,9 @@ enum SpanCount : int {
   SC_SHORTCUT = 7,  // alignments settled by the substitution / one-base-gap shortcuts
   SC_NOSEED = 8,    // expensive alignments without seeds inside the read: the pre-filter's list
   SC_GAPS = 9,      // of SC_SHORTCUT: one-base gaps
+  SC_BAND = 10,     // of SC_KEEP: back-traced inside the band the pre-filter's penalty and end diagonal allow
+  SC_HREST = 11,    // of SC_KEEP: the others (and the banded ones that did not stand), back-traced over the whole read
+  SC_BANDFAIL = 12, // banded runs that did not come out with the pre-filter's penalty (the argument says: none)
   SC_WORDS = 16
 };
 
@@ -473,6 +476,54 @@ __global__ void window_check_kernel(const WinCheckArgs a) {
   }
 }
 
+// ---- The back-trace of what the pre-filter keeps, confined to a band ----
+// The pre-filter hands over more than a verdict: the optimal penalty s* and the diagonal k_end the run ends on (the first one with
+// the pattern consumed at level s*).  A wavefront cell (s, k) depends only on cells (s', k') with |k' - k| <= (s - s') / e, and the
+// back-trace from (s*, k_end) reads nothing but such cells: everything it touches lies on the diagonals [k_end - s*, k_end + s*],
+// text positions [k_end - s*, k_end + s* + plen).  The alignment of the piece against THAT window, started on those diagonals only,
+// computes these cells bit for bit; its other cells can only be smaller than in the full run (fewer sources under the max), so it can
+// neither end at a lower level nor, at level s*, on a diagonal below k_end.  band_check_kernel compares the penalty anyway and
+// sends what differs to the whole-read launch.  A full run spends its time on the ~tlen + 2 s diagonals of every level; the banded
+// one on 2 s* + 2 s + 1.
+struct BandArgs {
+  const JobDev* keep_jobs; const uint32_t* n_keep; JobDev* band_jobs; JobDev* rest_jobs; uint32_t* count; int32_t s_max;
+  const int32_t* score; uint32_t* span4; int32_t* n_match; const uint64_t* read_off; const uint32_t* read_len;
+};
+__global__ void heavy_band_kernel(const BandArgs a) {
+  const uint32_t n = *a.n_keep;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    JobDev jd = a.keep_jobs[i];
+    const uint32_t pad = jd.pad;
+    const int s = (int)((pad >> 16) & 0x7FFFu), plen = (int)jd.pat_len, tlen = (int)jd.txt_len, k_end = (int)(pad & 0xFFFFu) - plen;
+    const int t0 = max(0, k_end - s), k_hi = min(k_end + s, tlen), t_end = min(tlen, k_end + s + plen);
+    if ((pad >> 31) && s <= a.s_max && k_hi >= t0 && t_end > t0) {
+      jd.txt_off += (uint64_t)t0; jd.txt_len = (uint32_t)(t_end - t0); jd.pad = (uint32_t)t0;
+      jd.ops_off = (uint64_t)(k_hi - t0);  // the free text start of this job (wfa_fast_kernel<64, 3>)
+      jd.cigar_off = (uint64_t)s;          // the penalty it must come out with
+      a.band_jobs[atomicAdd(a.count + SC_BAND, 1u)] = jd;
+    } else {
+      jd.pad = 0;
+      a.rest_jobs[atomicAdd(a.count + SC_HREST, 1u)] = jd;
+    }
+  }
+}
+__global__ void band_check_kernel(const BandArgs a) {
+  const uint32_t n = a.count[SC_BAND];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    JobDev jd = a.band_jobs[i];
+    const uint32_t j = jd.out_index;
+    const int32_t sc = a.score[j];  // -penalty, INT32_MIN when the alignment did not complete
+    if (sc != INT32_MIN && -sc == (int32_t)jd.cigar_off && a.n_match[j] > 0) {
+      a.span4[4 * (uint64_t)j + 2] += jd.pad; a.span4[4 * (uint64_t)j + 3] += jd.pad;
+    } else {
+      a.n_match[j] = -1;
+      jd.txt_off = a.read_off[j >> 1]; jd.txt_len = a.read_len[j >> 1]; jd.pad = 0; jd.ops_off = 0; jd.cigar_off = 0;
+      a.rest_jobs[atomicAdd(a.count + SC_HREST, 1u)] = jd;
+      atomicAdd(a.count + SC_BANDFAIL, 1u);
+    }
+  }
+}
+
 struct CombineArgs {
   uint64_t n_reads; int32_t flank_len; double threshold;
   const int32_t* pos; const int32_t* n_match; const uint32_t* span4;
@@ -633,6 +684,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   const bool split = d_heavy_len && heavy_tlen_max > 0 && !c->knobs.one_launch;
   heavy_tlen_max = std::min(heavy_tlen_max, short_max);
   bool heavy_window = false;  // the seed search runs over the expensive list as well (below)
+  bool heavy_band = false;    // ... and what the pre-filter keeps of it is back-traced inside a band (BandArgs)
   auto window_args = [&]() {
     WindowArgs wa;
     wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
@@ -712,6 +764,31 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if ((rc = flank_filter_launch(c, FL))) return rc;
       tl_mark(c, "filter launched");
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + SC_KEEP;
+      heavy_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt;
+    }
+    if (heavy_band) {  // (see BandArgs) the kept alignments inside their band, one wave each; then whatever is left over the whole read
+      void *d_band = nullptr, *d_hrest = nullptr, *d_bscore = nullptr;
+      if ((rc = dev_get(c, S_FS_BANDJOBS, n_jobs * sizeof(JobDev), &d_band)) || (rc = dev_get(c, S_FS_HRESTJOBS, n_jobs * sizeof(JobDev), &d_hrest)) ||
+          (rc = dev_get(c, S_FS_BSCORE, n_jobs * 4, &d_bscore)))
+        return rc;
+      const int s_max = c->knobs.heavy_band;
+      BandArgs ba;
+      ba.keep_jobs = LH.jobs_dev; ba.n_keep = LH.n_jobs_dev; ba.band_jobs = (JobDev*)d_band; ba.rest_jobs = (JobDev*)d_hrest; ba.count = (uint32_t*)d_count;
+      ba.s_max = s_max; ba.score = (const int32_t*)d_bscore; ba.span4 = (uint32_t*)d_span4; ba.n_match = (int32_t*)d_nmatch;
+      ba.read_off = d_read_off; ba.read_len = d_read_len;
+      hipLaunchKernelGGL(heavy_band_kernel, dim3(64), dim3(256), 0, c->stream, ba);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      WfaLaunch LB = LH;
+      LB.jobs_dev = (const JobDev*)d_band; LB.n_jobs_dev = (const uint32_t*)d_count + SC_BAND;
+      LB.max_tlen = (int64_t)p.flank_len + 2 * s_max; LB.max_sum = (int64_t)p.flank_len + LB.max_tlen;
+      LB.score = (int32_t*)d_bscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = 64;
+      if (two_streams) LB.buffer_set = 1;
+      trgt_wfa_params wpb = wp;
+      wpb.text_begin_free = 2 * s_max;
+      if ((rc = wfa_launch(c, wpb, LB))) return rc;
+      hipLaunchKernelGGL(band_check_kernel, dim3(64), dim3(256), 0, c->stream, ba);
+      TRGT_HIP_TRY(c, hipGetLastError());
+      LH.jobs_dev = (const JobDev*)d_hrest; LH.n_jobs_dev = (const uint32_t*)d_count + SC_HREST; LH.keep_cells = true;
     }
     // three waves per alignment here: the wavefronts of these short texts are narrow (on average less than one 128-diagonal strip per
     // wave and level), and a wave without a strip still pays the per-level prologue and barrier (7.39 -> 7.21 ms)
@@ -837,8 +914,9 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     if (win_q > 0)
       fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u -> windowed %u, whole read %u (that is %u without seeds + %u windows that did not stand), settled by the shortcuts %u (one-base gaps: %u)\n",
               h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT], h[SC_WIN], h[SC_REST], h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT], h[SC_REST] - (h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT]), h[SC_SHORTCUT], h[SC_GAPS]);
+    if (win_q <= 0) fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT]);
     if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[SC_NOSEED], h[SC_HEAVY]);
-    else fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT]);
+    if (heavy_band) fprintf(stderr, "[spans+] kept by the pre-filter: %u -> back-traced inside a band %u (did not stand: %u), over the whole read %u\n", h[SC_KEEP], h[SC_BAND], h[SC_BANDFAIL], h[SC_HREST]);
   }
   (void)n_loci;
   return TRGT_OK;

@@ -561,9 +561,10 @@ __device__ __forceinline__ int wf_backtrace_fast_affine(const Pen& pen, int plen
 // ------------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one alignment at a time per workgroup (job cost varies by 100x), workspace slot
 // acquired per resident workgroup exactly as in wfa_kernel.  LDS (dynamic): ring | pattern windows | text windows.
-// TAG only names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments, 2: the
-// launch over the flank alignments with a seeded window), so
-// that a kernel trace tells the two launches of trgt_find_spans_batch apart.
+// TAG names the instantiation (0: the first / only launch of a batch, 1: the launch over the remaining flank alignments, 2: the
+// launch over the flank alignments with a seeded window, 3: the launch over the band the pre-filter found -- as 2, but one job per
+// claim and the free text start of each job in its JobDev::ops_off), so that a kernel trace tells the launches of
+// trgt_find_spans_batch apart.
 template <int SPEC, int TAG>
 __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
   extern __shared__ unsigned char lds_dyn[];
@@ -649,9 +650,10 @@ __global__ void __launch_bounds__(256, 4) wfa_fast_kernel(const KArgs a) {
       J.tbf = sp ? fr(a.kp.tbf, tlen) : 0; J.tef = sp ? fr(a.kp.tef, tlen) : 0;
       J.n_slots = (int)a.uni_slots; J.cap = a.arena_uni_cap;
       J.koff = a.fast_koff ? (int)a.fast_koff : plen + 2;
+      if (TAG == 3) J.tbf = min(J.tbf, (int)job.ops_off);
     }
     PROF_MARK(1);
-    const FastEnd E = wf_run_lds_affine<SPEC, TAG == 2>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
+    const FastEnd E = wf_run_lds_affine<SPEC, TAG >= 2>(pen, J, P4, T4, ring, (int)a.fast_wcap, (g_u16*)A16g, gd);
 #ifdef TRGT_WFA_PROF
     const unsigned long long pf_t2 = pf_t;
 #endif

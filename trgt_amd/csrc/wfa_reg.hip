@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
     const int plen = rfl_i((int)job.pat_len), tlen = rfl_i((int)job.txt_len);
     if (plen + tlen + 1 <= a.diag_lo || plen + tlen + 1 > a.diag_hi) continue;  // another launch's job
     int keep = 0, score_out = INT32_MIN, bound_out = -1;
+    uint32_t band = 0;  // (kept jobs: bit 31 | penalty << 16 | biased end diagonal when the run completed)
     const bool fits = plen >= 1 && plen <= 254 && tlen >= plen && tlen + plen + 1 <= D;
     uint32_t dirty = 0;
     if (fits) {
@@ -520,6 +521,9 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
         score_out = -s;
         bound_out = (int)(best_reg & 0xFFu);
         keep = bound_out >= a.min_matches ? 1 : 0;
+        // for the back-tracing launch over what is kept: the penalty and the (biased) diagonal the alignment ends on are all it takes
+        // to confine that run to a band (heavy_band_kernel, spans.hip)
+        if (s < 0x8000 && best < 0x10000) band = 0x80000000u | ((uint32_t)s << 16) | (uint32_t)best;
       }
     }
     if (lane == 0) {
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
       if (a.score) a.score[o] = score_out;
       if (a.bound) a.bound[o] = bound_out;
       if (a.keep) a.keep[o] = (uint8_t)keep;
-      if (keep && a.keep_jobs) a.keep_jobs[atomicAdd(a.keep_count, 1u)] = job;
+      if (keep && a.keep_jobs) { JobDev kj = job; kj.pad = band; a.keep_jobs[atomicAdd(a.keep_count, 1u)] = kj; }
       kept_acc += (unsigned long long)keep;
     }
   }
