@@ -153,6 +153,38 @@ def test_long_alleles_parallel_traceback(oracle, hmm):
         assert np.array_equal(a["path"][po:po + pl], b["path"][po:po + pl]), j
 
 
+def test_register_fill_variants_agree(oracle, hmm):
+    # one-wave models fill their columns in registers with two rounds of cross-lane fetches per column (run end, run start and block
+    # starts worked out by every lane from one round); TRGT_HMM_FOUR_ROUNDS=1 takes the loop with one round per pass, TRGT_HMM_LDS_FILL=1
+    # the LDS columns of the larger models.  One-motif models (two alleles per wave), models up to 64 states, motifs of one and two bases
+    # (no deletion states / one), N in motifs and alleles, alleles without the motif, empty alleles -- all three like the oracle.
+    from trgt_amd import _lib
+    rng = np.random.default_rng(911)
+    sets = [[b"CAG"], [b"A"], [b"AC"], [b"GCN"], [b"CAG", b"CCG"], [b"A", b"T", b"CG"], [b"AAGGG", b"AAAAG", b"ACG"], [b"ACGTTGCA"],
+            [b"GGCCTG", b"CCG", b"A"], [b"ACGTACGTACGTACGTAC"]]
+    assert max(hmm.num_states(m) for m in sets) <= 64 and min(hmm.num_states(m) for m in sets) <= 11
+    jobs = []
+    for s, m in enumerate(sets):
+        for n in (0, 1, 2, 7, 40, 150, 333):
+            jobs.append((s, repeat_allele(rng, m, n, err=0.04)))
+        jobs.append((s, rand_dna(rng, 120)))
+        jobs.append((s, b"N" * 9 + repeat_allele(rng, m, 30, err=0.0) + b"NN"))
+    base = _same(oracle, hmm, sets, jobs)
+    batch = hmm.pack_hmm_batch(sets, jobs)
+    for env in (dict(TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_LDS_FILL=1)):
+        ctx = _lib.context_with_env(**env)
+        try:
+            a = hmm.hmm_batch(batch, ctx=ctx)
+        finally:
+            ctx.close()
+        for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
+            assert np.array_equal(a[k], base[k]), (env, k)
+        assert np.array_equal(a["purity"].view(np.uint64), base["purity"].view(np.uint64)), env
+        for j in range(len(jobs)):
+            po, pl = int(batch["path_off"][j]), int(a["path_len"][j])
+            assert np.array_equal(a["path"][po:po + pl], base["path"][po:po + pl]), (env, j)
+
+
 def test_visit_list_overflow_and_length_buckets(oracle, hmm):
     # one-base motifs make one motif visit per base: more than the kernel keeps in LDS (the rest go through its global
     # workspace); alleles of 0..2500 bases of several models land in every length bucket / launch class of one batch

@@ -424,6 +424,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
                                    uint32_t n_launch_jobs, uint32_t lds_per_job, const uint32_t* __restrict__ n_jobs_dev, uint32_t* __restrict__ long_list) {
   extern __shared__ __align__(16) unsigned char lds_all[];
   if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
+  const bool four_rounds = (lds_per_job >> 31) != 0u;  // (TRGT_HMM_FOUR_ROUNDS, see the register fill)
+  lds_per_job &= 0x7FFFFFFFu;
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
   const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
@@ -562,6 +564,137 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     for (int b = 0; b < BE_REG; ++b) a_be[b] = (lane_base + be[b]) << 2;
     const double lp_re = l_lp[S - 2];  // the run end's transition term (one for all its predecessors' slot 0 ... see below)
     const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
+    // Two crossbar rounds per column instead of four.  What the silent states of a column need is final early: the deletion chains
+    // and block ends after the chain pass, and run end / run start / block starts are then plain functions of THOSE -- every lane
+    // works them out for itself from one round of fetches (block ends, start state, its own block's end): the run end as before, the
+    // run start behind it, and the start of its own block {run start, own block end}.  The same round fetches the predecessors of
+    // the NEXT column's emitting states (emitting, deletion and block-end states: final by then); a predecessor that is a block
+    // start or the run end is taken from the lane's own copy.  Same sums, same order, same strict '>'.  The topology this rests on
+    // (builder.rs:4-173) is checked per job: block start = {run start, own block end}; an emitting state's silent predecessors are
+    // deletion states, block ends, its OWN block's start (slot 0 or 1) or the run end (slot 0) -- anything else takes the loop
+    // with one round per pass below.
+    const int my_ms = my_blk >= 0 ? (int)l_blocks[0 * nb + my_blk] : 0, my_me = my_blk >= 0 ? (int)l_blocks[1 * nb + my_blk] : 0;
+    const int a_myend = (lane_base + my_me) << 2;
+    const double ms_lp0 = my_blk >= 0 ? l_lp[my_ms] : NINF, ms_lp1 = my_blk >= 0 ? l_lp[S + my_ms] : NINF;
+    bool bad = false, use_loc0 = false, use_loc1 = false;
+    if (act && my_blk >= 0) bad = model[set.off_nin + my_ms] != 2 || g_inst[0 * S + my_ms] != 1 || g_inst[1 * S + my_ms] != my_me;
+    if (act && level == 0 && n_in != 0xFF) {
+      for (int b = 0; b < n_in && b < 4; ++b) {
+        const int pb = b == 0 ? p0 : b == 1 ? p1 : b == 2 ? p2 : p3;
+        const int pblk = pb < S ? (int)l_block[pb] : -1;
+        const bool p_start = pblk >= 0 && pb == (int)l_blocks[0 * nb + pblk];
+        if (pb == 1) bad = true;                                   // the run start feeds block starts only
+        else if (pb == S - 2) { if (b == 0) use_loc0 = true; else bad = true; }
+        else if (p_start) {
+          if (pblk == my_blk && b == 0) use_loc0 = true;
+          else if (pblk == my_blk && b == 1) use_loc1 = true;
+          else bad = true;
+        }
+      }
+    }
+    const bool two_rounds = __ballot(bad) == 0ull && !four_rounds;
+    if (two_rounds) {
+      // (What a column costs the one wave is issue slots: a ds_bpermute_b32 of a permutation ~32 cycles, 14 when all lanes read one
+      //  lane, an f64 add or compare ~16, tools/micro/bperm_cost.hip.  Tried on top of this loop and dropped, each slower or even:
+      //  block ends by v_readlane, predecessor 0 by a DPP shift, the own block end picked from the block ends, every "first maximum"
+      //  as a tournament with -inf transition terms in the invalid slots -- fewer crossbar passes, more selects.)
+      double em_next = 0.0;
+      const bool loc_is_re = act && use_loc0 && p0 == S - 2;
+      double pe0 = NINF, pe1 = NINF, pe2 = NINF, pe3 = NINF;  // the predecessors' scores of the column before
+      uint8_t* __restrict__ bp_col = bp;
+      for (int i = 0; i < L; ++i) {
+        // (symbol codes two columns ahead, emission terms one: neither LDS round trip is waited for in the column that starts it)
+        if ((i % HMM_CODE_WINDOW) == 0) {
+          hmm_sync(sync_n);
+          win0 = i;
+          for (int k = tid; k < HMM_CODE_WINDOW + 2 && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
+          hmm_sync(sync_n);
+          sym_next = code_at(i);
+          em_next = l_em[sym_next * S + st];
+          sym_next = i + 1 < L ? code_at(i + 1) : 0;
+        }
+        const double em = em_next;
+        em_next = l_em[__umul24((unsigned)sym_next, (unsigned)S) + st];
+        sym_next = i + 2 < L ? code_at(i + 2) : 0;
+        HP_FILL(0);
+        double best = NINF;
+        int bpi = 0xFF;
+        if (act && level == 0) {
+          if (i == 0) {
+            if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
+          } else {
+            const double v0 = (pe0 + lp0) + em, v1 = (pe1 + lp1) + em, v2 = (pe2 + lp2) + em, v3 = (pe3 + lp3) + em;
+            if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+            if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+            if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+            if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
+          }
+        }
+        double cur_v = best;
+        HP_FILL(1);
+        {  // round 1: the chains d0 <- d1 <- ... <- block end take this column's emitting states
+          const double s0 = bperm_f64(a_q0, cur_v), s1 = bperm_f64(a_q1, cur_v);
+          if (role_chain) {
+            const double v0 = (s0 + lp0), v1 = (s1 + lp1);
+            if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+            if (role_end && n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+          }
+          double val = best, cand = NINF;
+          for (int t = 0; wave_chain && t < chain_steps; ++t) {
+            cand = (wave_shr1_f64(val) + lp_step);
+            val = cand > best ? cand : best;
+          }
+          if (cand > best) bpi = role_del ? 1 : 2;
+          best = val;
+          if (role_chain) cur_v = val;
+        }
+        HP_FILL(2);
+        {  // round 2: block ends, start state, own block end -- and the next column's predecessors
+          const double f0 = bperm_f64(a_q0, cur_v), f1 = bperm_f64(a_q1, cur_v), f2 = bperm_f64(a_q2, cur_v), f3 = bperm_f64(a_q3, cur_v);
+          const double start_now = bperm_f64(a_st0, cur_v), myend = bperm_f64(a_myend, cur_v);
+          double re = NINF; int re_bp = 0xFF;
+          auto block_ends = [&](auto n_const) {
+            constexpr int N = decltype(n_const)::value;
+            double e[N];
+#pragma unroll
+            for (int b = 0; b < N; ++b) e[b] = bperm_f64(a_be[b], cur_v);
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+              const double v = (e[b] + lp_re);
+              if (b < nb && v > re) { re = v; re_bp = b; }
+            }
+          };
+          if (nb <= 2) block_ends(std::integral_constant<int, 2>());
+          else if (nb <= 4) block_ends(std::integral_constant<int, 4>());
+          else block_ends(std::integral_constant<int, BE_REG>());
+          for (int b = BE_REG; b < nb; ++b) {
+            const double v = (bperm_f64((lane_base + (int)l_blocks[1 * nb + b]) << 2, cur_v) + lp_re);
+            if (v > re) { re = v; re_bp = b; }
+          }
+          double br = NINF; int pr = 0xFF;
+          {
+            const double v0 = (start_now + lp_rs0), v1 = (re + lp_rs1);
+            if (v0 > br) { br = v0; pr = 0; }
+            if (v1 > br) { br = v1; pr = 1; }
+          }
+          double msv = NINF; int ms_bp = 0xFF;  // the start of my block: {run start, own block end}
+          {
+            const double v0 = (br + ms_lp0), v1 = (myend + ms_lp1);
+            if (v0 > msv) { msv = v0; ms_bp = 0; }
+            if (v1 > msv) { msv = v1; ms_bp = 1; }
+          }
+          if (is_run_end) bpi = re_bp;
+          if (is_run_start) bpi = pr;
+          if (role_start) bpi = ms_bp;
+          const double loc = loc_is_re ? re : msv;
+          pe0 = use_loc0 ? loc : f0; pe1 = use_loc1 ? msv : f1; pe2 = f2; pe3 = f3;
+        }
+        HP_FILL(4);
+        if (act) bp_col[st] = (uint8_t)bpi;  // (a uniform base that moves by a column, the lane's state as the offset: no 64-bit address arithmetic per lane)
+        bp_col += Spad;
+        HP_FILL(5);
+      }
+    } else {
     double prev_v = NINF;
     double em_next = 0.0;
     for (int i = 0; i < L; ++i) {
@@ -653,6 +786,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
       prev_v = cur_v;
       HP_FILL(5);
+    }
     }
   } else
   for (int i = 0; i < L; ++i) {
@@ -1838,7 +1972,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)nullptr, d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u), (const uint32_t*)nullptr, d_long_cls)
     // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
     uint32_t* d_long_cls = nullptr;
     if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)HMM_LONG_MIN) {
@@ -2033,7 +2167,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job, (const uint32_t*)(d_count + k), d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u), (const uint32_t*)(d_count + k), d_long_cls)
     uint32_t* d_long_cls = nullptr;
     uint32_t max_cap_cls = 0;
     for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
@@ -2149,8 +2283,8 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
     fprintf(stderr, "[hmm prof] jobs=%lld | setup %.1f%% fill %.1f%% traceback %.1f%% path+decode %.1f%% | kcycles/job %.1f\n", (long long)n_jobs,
             100 * h[0] / t, 100 * h[1] / t, 100 * h[2] / t, 100 * h[3] / t, t / 1e3 / (double)n_jobs);
     const double f = (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13]) + 1e-9;
-    fprintf(stderr, "[hmm prof]   fill: symbol %.1f%% emitting+sync %.1f%% chains+ends+sync %.1f%% run end+sync %.1f%% block starts+sync %.1f%% store %.1f%%\n",
-            100 * h[8] / f, 100 * h[9] / f, 100 * h[10] / f, 100 * h[11] / f, 100 * h[12] / f, 100 * h[13] / f);
+    fprintf(stderr, "[hmm prof]   fill (%.0f kcycles on the profiled lanes): symbol %.1f%% emitting+sync %.1f%% chains+ends+sync %.1f%% run end+sync %.1f%% block starts+sync %.1f%% store %.1f%%\n",
+            f / 1e3, 100 * h[8] / f, 100 * h[9] / f, 100 * h[10] / f, 100 * h[11] / f, 100 * h[12] / f, 100 * h[13] / f);
   }
 #endif
   if (!h_cnt.empty())
