@@ -107,7 +107,16 @@ def test_many_motifs_multi_wave_workgroup(oracle, hmm):
     sets = [[b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"]]
     assert hmm.num_states(sets[0]) > 128
     jobs = [(0, repeat_allele(rng, sets[0], n, err=0.02)) for n in (5, 60, 333, 1000)]
-    _same(oracle, hmm, sets, jobs)
+    base = _same(oracle, hmm, sets, jobs)
+    from trgt_amd import _lib
+    ctx = _lib.context_with_env(TRGT_HMM_FOUR_ROUNDS=1)  # four barriers per column (the loop the two-barrier fill falls back to)
+    try:
+        a = hmm.hmm_batch(hmm.pack_hmm_batch(sets, jobs), ctx=ctx)
+    finally:
+        ctx.close()
+    for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
+        assert np.array_equal(a[k], base[k]), k
+    assert np.array_equal(a["purity"].view(np.uint64), base["purity"].view(np.uint64))
 
 
 def test_long_allele_10kb(oracle, hmm):
@@ -156,7 +165,7 @@ def test_long_alleles_parallel_traceback(oracle, hmm):
 def test_register_fill_variants_agree(oracle, hmm):
     # one-wave models fill their columns in registers with two rounds of cross-lane fetches per column (run end, run start and block
     # starts worked out by every lane from one round); TRGT_HMM_FOUR_ROUNDS=1 takes the loop with one round per pass, TRGT_HMM_LDS_FILL=1
-    # the LDS columns of the larger models.  One-motif models (two alleles per wave), models up to 64 states, motifs of one and two bases
+    # the LDS columns of the larger models (two barriers per column; with TRGT_HMM_FOUR_ROUNDS=1 four).  One-motif models (two alleles per wave), models up to 64 states, motifs of one and two bases
     # (no deletion states / one), N in motifs and alleles, alleles without the motif, empty alleles -- all three like the oracle.
     from trgt_amd import _lib
     rng = np.random.default_rng(911)
@@ -171,7 +180,7 @@ def test_register_fill_variants_agree(oracle, hmm):
         jobs.append((s, b"N" * 9 + repeat_allele(rng, m, 30, err=0.0) + b"NN"))
     base = _same(oracle, hmm, sets, jobs)
     batch = hmm.pack_hmm_batch(sets, jobs)
-    for env in (dict(TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_LDS_FILL=1)):
+    for env in (dict(TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_LDS_FILL=1), dict(TRGT_HMM_LDS_FILL=1, TRGT_HMM_FOUR_ROUNDS=1)):
         ctx = _lib.context_with_env(**env)
         try:
             a = hmm.hmm_batch(batch, ctx=ctx)

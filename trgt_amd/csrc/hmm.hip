@@ -552,6 +552,34 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
 #pragma unroll
   for (int b = 0; b < BE_REG; ++b) be[b] = (int)l_blocks[1 * nb + (b < nb ? b : 0)];
   // ---- Viterbi fill (generate_mats, hmm_model.rs:99-114)
+  // Two rounds of cross-lane traffic per column instead of four (register fill: crossbar fetches; LDS fill: barriers).  What the silent states of a column need is final early: the deletion chains
+  // and block ends after the chain pass, and run end / run start / block starts are then plain functions of THOSE -- every lane
+  // works them out for itself from one round of fetches (block ends, start state, its own block's end): the run end as before, the
+  // run start behind it, and the start of its own block {run start, own block end}.  The same round fetches the predecessors of
+  // the NEXT column's emitting states (emitting, deletion and block-end states: final by then); a predecessor that is a block
+  // start or the run end is taken from the lane's own copy.  Same sums, same order, same strict '>'.  The topology this rests on
+  // (builder.rs:4-173) is checked per job: block start = {run start, own block end}; an emitting state's silent predecessors are
+  // deletion states, block ends, its OWN block's start (slot 0 or 1) or the run end (slot 0) -- anything else takes the loop
+  // with one round per pass below.
+  const int my_ms = my_blk >= 0 ? (int)l_blocks[0 * nb + my_blk] : 0, my_me = my_blk >= 0 ? (int)l_blocks[1 * nb + my_blk] : 0;
+  const double ms_lp0 = my_blk >= 0 ? l_lp[my_ms] : NINF, ms_lp1 = my_blk >= 0 ? l_lp[S + my_ms] : NINF;
+  bool bad = false, use_loc0 = false, use_loc1 = false;
+  if (act && my_blk >= 0) bad = model[set.off_nin + my_ms] != 2 || g_inst[0 * S + my_ms] != 1 || g_inst[1 * S + my_ms] != my_me;
+  if (act && level == 0 && n_in != 0xFF) {
+    for (int b = 0; b < n_in && b < 4; ++b) {
+      const int pb = b == 0 ? p0 : b == 1 ? p1 : b == 2 ? p2 : p3;
+      const int pblk = pb < S ? (int)l_block[pb] : -1;
+      const bool p_start = pblk >= 0 && pb == (int)l_blocks[0 * nb + pblk];
+      if (pb == 1) bad = true;                                   // the run start feeds block starts only
+      else if (pb == S - 2) { if (b == 0) use_loc0 = true; else bad = true; }
+      else if (p_start) {
+        if (pblk == my_blk && b == 0) use_loc0 = true;
+        else if (pblk == my_blk && b == 1) use_loc1 = true;
+        else bad = true;
+      }
+    }
+  }
+  const bool two_rounds = !(sync_n == 64 ? __ballot(bad) != 0ull : __syncthreads_or(bad ? 1 : 0) != 0) && !four_rounds;
   double* prev = sc0;
   double* cur = sc1;
   HP_FILL_DECL;
@@ -563,36 +591,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
 #pragma unroll
     for (int b = 0; b < BE_REG; ++b) a_be[b] = (lane_base + be[b]) << 2;
     const double lp_re = l_lp[S - 2];  // the run end's transition term (one for all its predecessors' slot 0 ... see below)
-    const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
-    // Two crossbar rounds per column instead of four.  What the silent states of a column need is final early: the deletion chains
-    // and block ends after the chain pass, and run end / run start / block starts are then plain functions of THOSE -- every lane
-    // works them out for itself from one round of fetches (block ends, start state, its own block's end): the run end as before, the
-    // run start behind it, and the start of its own block {run start, own block end}.  The same round fetches the predecessors of
-    // the NEXT column's emitting states (emitting, deletion and block-end states: final by then); a predecessor that is a block
-    // start or the run end is taken from the lane's own copy.  Same sums, same order, same strict '>'.  The topology this rests on
-    // (builder.rs:4-173) is checked per job: block start = {run start, own block end}; an emitting state's silent predecessors are
-    // deletion states, block ends, its OWN block's start (slot 0 or 1) or the run end (slot 0) -- anything else takes the loop
-    // with one round per pass below.
-    const int my_ms = my_blk >= 0 ? (int)l_blocks[0 * nb + my_blk] : 0, my_me = my_blk >= 0 ? (int)l_blocks[1 * nb + my_blk] : 0;
     const int a_myend = (lane_base + my_me) << 2;
-    const double ms_lp0 = my_blk >= 0 ? l_lp[my_ms] : NINF, ms_lp1 = my_blk >= 0 ? l_lp[S + my_ms] : NINF;
-    bool bad = false, use_loc0 = false, use_loc1 = false;
-    if (act && my_blk >= 0) bad = model[set.off_nin + my_ms] != 2 || g_inst[0 * S + my_ms] != 1 || g_inst[1 * S + my_ms] != my_me;
-    if (act && level == 0 && n_in != 0xFF) {
-      for (int b = 0; b < n_in && b < 4; ++b) {
-        const int pb = b == 0 ? p0 : b == 1 ? p1 : b == 2 ? p2 : p3;
-        const int pblk = pb < S ? (int)l_block[pb] : -1;
-        const bool p_start = pblk >= 0 && pb == (int)l_blocks[0 * nb + pblk];
-        if (pb == 1) bad = true;                                   // the run start feeds block starts only
-        else if (pb == S - 2) { if (b == 0) use_loc0 = true; else bad = true; }
-        else if (p_start) {
-          if (pblk == my_blk && b == 0) use_loc0 = true;
-          else if (pblk == my_blk && b == 1) use_loc1 = true;
-          else bad = true;
-        }
-      }
-    }
-    const bool two_rounds = __ballot(bad) == 0ull && !four_rounds;
+    const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
     if (two_rounds) {
       // (What a column costs the one wave is issue slots: a ds_bpermute_b32 of a permutation ~32 cycles, 14 when all lanes read one
       //  lane, an f64 add or compare ~16, tools/micro/bperm_cost.hip.  Tried on top of this loop and dropped, each slower or even:
@@ -787,6 +787,118 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       prev_v = cur_v;
       HP_FILL(5);
     }
+    }
+  } else if (two_rounds) {
+    // The LDS fill with two barriers per column (plus one per extra chain round): emitting states | chains | -- and what used to be
+    // two more passes with a barrier each (run end + run start by one lane, then the block starts) every lane works out for itself
+    // from the block ends, the start state and its own block's end, as in the register fill above.  Run end, run start and block
+    // starts are not written to the score columns any more: the only readers were those passes and the next column's emitting states,
+    // which take them from their own copy.
+    const double lp_re = l_lp[S - 2];
+    const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
+    const bool loc_is_re = act && use_loc0 && p0 == S - 2;
+    double loc = NINF, msv_prev = NINF;  // my copies of the column before: run end or own block start | own block start
+    for (int i = 0; i < L; ++i) {
+      if ((i % HMM_CODE_WINDOW) == 0) {
+        hmm_sync(sync_n);
+        win0 = i;
+        for (int k = tid; k < HMM_CODE_WINDOW + 1 && i + k < L; k += nthr) l_seq[k] = (uint8_t)hmm_code(seq, i + k, L);
+        hmm_sync(sync_n);
+        sym_next = code_at(i);
+      }
+      const int sym = sym_next;
+      if (i + 1 < L) sym_next = code_at(i + 1);
+      HP_FILL(0);
+      double best = NINF;
+      int bpi = 0xFF;
+      if (act && level == 0) {
+        const double em = l_em[sym * S + st];
+        if (i == 0) {
+          if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
+        } else {
+          const double r0 = prev[q0], r1 = prev[q1], s2 = prev[q2], s3 = prev[q3];
+          const double s0 = use_loc0 ? loc : r0, s1 = use_loc1 ? msv_prev : r1;
+          const double v0 = (s0 + lp0) + em, v1 = (s1 + lp1) + em, v2 = (s2 + lp2) + em, v3 = (s3 + lp3) + em;
+          if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+          if (n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+          if (n_in > 2 && v2 > best) { best = v2; bpi = 2; }
+          if (n_in > 3 && v3 > best) { best = v3; bpi = 3; }
+        }
+        cur[st] = best;
+      }
+      hmm_sync(sync_n);
+      HP_FILL(1);
+      if (role_chain) {
+        const double s0 = cur[q0], s1 = cur[q1];
+        const double v0 = (s0 + lp0), v1 = (s1 + lp1);
+        if (n_in > 0 && v0 > best) { best = v0; bpi = 0; }
+        if (role_end && n_in > 1 && v1 > best) { best = v1; bpi = 1; }
+      }
+      {
+        const double own = best;
+        int own_bp = bpi;
+        double val = best, cand = NINF;
+        for (int r = 0; r < chain_rounds; ++r) {
+          if (chain_xwave) {
+            cand = (cur[st - 1] + lp_chain);
+            best = cand > own ? cand : own;
+            bpi = cand > own ? (role_del ? 1 : 2) : own_bp;
+            val = best;
+          }
+          for (int t = 0; wave_chain && t < chain_steps; ++t) {
+            cand = (wave_shr1_f64(val) + lp_step);
+            val = cand > best ? cand : best;
+          }
+          if (role_chain) cur[st] = val;
+          if (r + 1 < chain_rounds) hmm_sync(sync_n);
+        }
+        if (cand > best) bpi = role_del ? 1 : 2;
+        best = val;
+      }
+      hmm_sync(sync_n);
+      HP_FILL(2);
+      {
+        const double start_now = cur[0], myend = cur[my_me];
+        double re = NINF; int re_bp = 0xFF;
+        auto block_ends = [&](auto n_const) {
+          constexpr int N = decltype(n_const)::value;
+          double e[N];
+#pragma unroll
+          for (int b = 0; b < N; ++b) e[b] = cur[be[b]];
+#pragma unroll
+          for (int b = 0; b < N; ++b) {
+            const double v = (e[b] + lp_re);
+            if (b < nb && v > re) { re = v; re_bp = b; }
+          }
+        };
+        if (nb <= 2) block_ends(std::integral_constant<int, 2>());
+        else if (nb <= 4) block_ends(std::integral_constant<int, 4>());
+        else block_ends(std::integral_constant<int, BE_REG>());
+        for (int b = BE_REG; b < nb; ++b) {
+          const double v = (cur[l_blocks[1 * nb + b]] + lp_re);
+          if (v > re) { re = v; re_bp = b; }
+        }
+        double br = NINF; int pr = 0xFF;
+        {
+          const double v0 = (start_now + lp_rs0), v1 = (re + lp_rs1);
+          if (v0 > br) { br = v0; pr = 0; }
+          if (v1 > br) { br = v1; pr = 1; }
+        }
+        double msv = NINF; int ms_bp = 0xFF;  // the start of my block: {run start, own block end}
+        {
+          const double v0 = (br + ms_lp0), v1 = (myend + ms_lp1);
+          if (v0 > msv) { msv = v0; ms_bp = 0; }
+          if (v1 > msv) { msv = v1; ms_bp = 1; }
+        }
+        if (is_run_end) bpi = re_bp;
+        if (is_run_start) bpi = pr;
+        if (role_start) bpi = ms_bp;
+        loc = loc_is_re ? re : msv; msv_prev = msv;
+      }
+      HP_FILL(4);
+      if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
+      double* t = prev; prev = cur; cur = t;
+      HP_FILL(5);
     }
   } else
   for (int i = 0; i < L; ++i) {
