@@ -401,6 +401,13 @@ __device__ __forceinline__ double wave_shr1_f64(double x) {
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
 }
 
+// max of two scores: the value of (a > b ? a : b) -- scores are never NaN or -0.0 -- in ONE v_max_f64 (fmax() comes with a canonicalising
+// v_max_f64 x, x in front of it: 16 more cycles in a loop that runs once per base of the longest motif per column)
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // f64 from another lane of the wave (byte address of the source lane: lane << 2)
 __device__ __forceinline__ double bperm_f64(int addr, double x) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
@@ -539,7 +546,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   // (every lane runs the chain steps: -inf as the transition term of the lanes that take nothing from their neighbour -- and of the
   //  first lane of a wave, which takes its predecessor from LDS before the steps -- makes their candidate lose every comparison)
   const double lp_chain = role_del ? lp1 : lp2, lp_step = chain_prev && !chain_xwave ? lp_chain : NINF;
-  const int chain_steps = min(63, max((int)set.max_mlen, SUB == 32 ? __shfl_xor((int)set.max_mlen, 32) : 0) - 1);
+  const int chain_steps = __builtin_amdgcn_readfirstlane(min(63, max((int)set.max_mlen, SUB == 32 ? __shfl_xor((int)set.max_mlen, 32) : 0) - 1));  // (the same in every lane: a scalar loop count)
   const int chain_rounds = (int)set.chain_rounds;
   // (waves of a multi-wave model that hold no chain state skip the steps: they only cost issue slots of their SIMD)
   const bool wave_chain = __ballot(lp_step > NINF) != 0ull;
@@ -642,7 +649,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           double val = best, cand = NINF;
           for (int t = 0; wave_chain && t < chain_steps; ++t) {
             cand = (wave_shr1_f64(val) + lp_step);
-            val = cand > best ? cand : best;
+            val = max_f64(cand, best);
           }
           if (cand > best) bpi = role_del ? 1 : 2;
           best = val;
@@ -798,6 +805,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     const bool is_run_end = act && n_in == 0xFF, is_run_start = act && st == 1;
     const bool loc_is_re = act && use_loc0 && p0 == S - 2;
     double loc = NINF, msv_prev = NINF;  // my copies of the column before: run end or own block start | own block start
+    uint8_t* __restrict__ bp_col = bp;
     for (int i = 0; i < L; ++i) {
       if ((i % HMM_CODE_WINDOW) == 0) {
         hmm_sync(sync_n);
@@ -847,7 +855,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           }
           for (int t = 0; wave_chain && t < chain_steps; ++t) {
             cand = (wave_shr1_f64(val) + lp_step);
-            val = cand > best ? cand : best;
+            val = max_f64(cand, best);
           }
           if (role_chain) cur[st] = val;
           if (r + 1 < chain_rounds) hmm_sync(sync_n);
@@ -896,7 +904,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         loc = loc_is_re ? re : msv; msv_prev = msv;
       }
       HP_FILL(4);
-      if (act) bp[(size_t)i * Spad + st] = (uint8_t)bpi;
+      if (act) bp_col[st] = (uint8_t)bpi;
+      bp_col += Spad;
       double* t = prev; prev = cur; cur = t;
       HP_FILL(5);
     }
