@@ -603,13 +603,16 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     if (two_rounds) {
       // (What a column costs the one wave is issue slots: a ds_bpermute_b32 of a permutation ~32 cycles, 14 when all lanes read one
       //  lane, an f64 add or compare ~16, tools/micro/bperm_cost.hip.  Tried on top of this loop and dropped, each slower or even:
-      //  block ends by v_readlane, predecessor 0 by a DPP shift, the own block end picked from the block ends, every "first maximum"
-      //  as a tournament with -inf transition terms in the invalid slots -- fewer crossbar passes, more selects.)
+      //  block ends by v_readlane, predecessor 0 by a DPP shift, the own block end picked from the block ends (each also on its own:
+      //  6.0 -> 6.5 / 6.25 ms for a class of a cfg3 call), every "first maximum" as a tournament with -inf transition terms in the
+      //  invalid slots -- fewer crossbar passes, more selects and uniform branches that split the column's one basic block.)
       double em_next = 0.0;
       const bool loc_is_re = act && use_loc0 && p0 == S - 2;
       double pe0 = NINF, pe1 = NINF, pe2 = NINF, pe3 = NINF;  // the predecessors' scores of the column before
       uint8_t* __restrict__ bp_col = bp;
-      for (int i = 0; i < L; ++i) {
+      // (column 0 is a copy of its own: the start state's special case and the run start's first candidate cost no branch per column)
+      auto column = [&](const int i, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         // (symbol codes two columns ahead, emission terms one: neither LDS round trip is waited for in the column that starts it)
         if ((i % HMM_CODE_WINDOW) == 0) {
           hmm_sync(sync_n);
@@ -627,7 +630,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         double best = NINF;
         int bpi = 0xFF;
         if (act && level == 0) {
-          if (i == 0) {
+          if constexpr (FIRST) {
             if (n_in == 0 && em > NINF) { best = em; bpi = 0xFE; }  // the start state (hmm_model.rs:91-94)
           } else {
             const double v0 = (pe0 + lp0) + em, v1 = (pe1 + lp1) + em, v2 = (pe2 + lp2) + em, v3 = (pe3 + lp3) + em;
@@ -658,7 +661,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         HP_FILL(2);
         {  // round 2: block ends, start state, own block end -- and the next column's predecessors
           const double f0 = bperm_f64(a_q0, cur_v), f1 = bperm_f64(a_q1, cur_v), f2 = bperm_f64(a_q2, cur_v), f3 = bperm_f64(a_q3, cur_v);
-          const double start_now = bperm_f64(a_st0, cur_v), myend = bperm_f64(a_myend, cur_v);
+          const double myend = bperm_f64(a_myend, cur_v);
           double re = NINF; int re_bp = 0xFF;
           auto block_ends = [&](auto n_const) {
             constexpr int N = decltype(n_const)::value;
@@ -678,10 +681,16 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
             const double v = (bperm_f64((lane_base + (int)l_blocks[1 * nb + b]) << 2, cur_v) + lp_re);
             if (v > re) { re = v; re_bp = b; }
           }
+          // run start {start state, run end}: the start state has a score in column 0 only (no predecessors, hmm_model.rs:91-94), so
+          // from column 1 on its candidate is -inf + lp = -inf and loses the strict '>': the run start is what the run end gives
           double br = NINF; int pr = 0xFF;
-          {
+          if constexpr (FIRST) {
+            const double start_now = bperm_f64(a_st0, cur_v);
             const double v0 = (start_now + lp_rs0), v1 = (re + lp_rs1);
             if (v0 > br) { br = v0; pr = 0; }
+            if (v1 > br) { br = v1; pr = 1; }
+          } else {
+            const double v1 = (re + lp_rs1);
             if (v1 > br) { br = v1; pr = 1; }
           }
           double msv = NINF; int ms_bp = 0xFF;  // the start of my block: {run start, own block end}
@@ -700,7 +709,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
         if (act) bp_col[st] = (uint8_t)bpi;  // (a uniform base that moves by a column, the lane's state as the offset: no 64-bit address arithmetic per lane)
         bp_col += Spad;
         HP_FILL(5);
-      }
+      };
+      column(0, std::true_type());
+      for (int i = 1; i < L; ++i) column(i, std::false_type());
     } else {
     double prev_v = NINF;
     double em_next = 0.0;
@@ -806,7 +817,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     const bool loc_is_re = act && use_loc0 && p0 == S - 2;
     double loc = NINF, msv_prev = NINF;  // my copies of the column before: run end or own block start | own block start
     uint8_t* __restrict__ bp_col = bp;
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < L; ++i) {  // (column 0 as a copy of its own, as in the register fill, measured slower here: 5.45 -> 5.64 ms)
       if ((i % HMM_CODE_WINDOW) == 0) {
         hmm_sync(sync_n);
         win0 = i;
@@ -866,7 +877,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
       hmm_sync(sync_n);
       HP_FILL(2);
       {
-        const double start_now = cur[0], myend = cur[my_me];
+        const double myend = cur[my_me];
         double re = NINF; int re_bp = 0xFF;
         auto block_ends = [&](auto n_const) {
           constexpr int N = decltype(n_const)::value;
@@ -886,10 +897,14 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
           const double v = (cur[l_blocks[1 * nb + b]] + lp_re);
           if (v > re) { re = v; re_bp = b; }
         }
-        double br = NINF; int pr = 0xFF;
-        {
+        double br = NINF; int pr = 0xFF;  // (the start state has a score in column 0 only: see the register fill)
+        if (i == 0) {
+          const double start_now = cur[0];
           const double v0 = (start_now + lp_rs0), v1 = (re + lp_rs1);
           if (v0 > br) { br = v0; pr = 0; }
+          if (v1 > br) { br = v1; pr = 1; }
+        } else {
+          const double v1 = (re + lp_rs1);
           if (v1 > br) { br = v1; pr = 1; }
         }
         double msv = NINF; int ms_bp = 0xFF;  // the start of my block: {run start, own block end}
