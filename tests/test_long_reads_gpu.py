@@ -1,5 +1,5 @@
 """Reads beyond the dedicated kernels' texts (kilobases: expanded alleles): their flank alignments meet the pre-filter window by window
-(trgt_amd/csrc/spans.hip, LongWinArgs) before the exact kernel.  The shortcut must never show: hand-made long reads -- flanks with errors
+(trgt_amd/csrc/spans.hip, LongWinArgs) before the exact kernel, and what the windows keep is aligned again inside the band they name (heavy_band_kernel).  The shortcuts must never show: hand-made long reads -- flanks with errors
 around the acceptance threshold, flanks near the borders of the filter's windows, flanks split by an insertion, flanks cut by the end of
 the read, reads without a flank, two copies of a flank -- are compared read by read with the oracle's find_tr_spans, and with the same
 library run without the window filter."""
@@ -31,6 +31,16 @@ def _spans_equal(oracle, loci, env_ctx):
     plain = locus.find_tr_spans_batch(b, ctx=env_ctx)
     for x, y, name in zip(got, plain, ("span_start", "span_end", "lf_hit", "rf_hit")):
         assert np.array_equal(x, y), name
+    # what the window filter keeps is back-traced inside the band its windows name (penalty and end diagonal: the smallest over the
+    # windows); without the band, and with bands that take only some of the alignments, the same spans
+    for band in ("0", "12", "256"):
+        bctx = _lib.context_with_env(TRGT_HEAVY_BAND=band)
+        try:
+            other = locus.find_tr_spans_batch(b, ctx=bctx)
+        finally:
+            bctx.close()
+        for x, y, name in zip(got, other, ("span_start", "span_end", "lf_hit", "rf_hit")):
+            assert np.array_equal(x, y), (band, name)
     r = 0
     n_some = 0
     for L in loci:

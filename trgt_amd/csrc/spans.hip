@@ -38,6 +38,8 @@ enum SpanCount : int {
   SC_BAND = 10,     // of SC_KEEP: back-traced inside the band the pre-filter's penalty and end diagonal allow
   SC_HREST = 11,    // of SC_KEEP: the others (and the banded ones that did not stand), back-traced over the whole read
   SC_BANDFAIL = 12, // banded runs that did not come out with the pre-filter's penalty (the argument says: none)
+  SC_LBAND = 13,    // long reads (SC_LONG) whose windows named the penalty and the end diagonal: back-traced inside a band
+  SC_LREST = 14,    // ... the other long reads the window filter keeps: back-traced over the whole read
   SC_WORDS = 16
 };
 
@@ -488,6 +490,7 @@ __global__ void window_check_kernel(const WinCheckArgs a) {
 struct BandArgs {
   const JobDev* keep_jobs; const uint32_t* n_keep; JobDev* band_jobs; JobDev* rest_jobs; uint32_t* count; int32_t s_max;
   const int32_t* score; uint32_t* span4; int32_t* n_match; const uint64_t* read_off; const uint32_t* read_len;
+  int32_t i_band, i_rest;  // which counters of the block (SC_BAND / SC_HREST, or SC_LBAND / SC_LREST for the long reads)
 };
 __global__ void heavy_band_kernel(const BandArgs a) {
   const uint32_t n = *a.n_keep;
@@ -500,15 +503,15 @@ __global__ void heavy_band_kernel(const BandArgs a) {
       jd.txt_off += (uint64_t)t0; jd.txt_len = (uint32_t)(t_end - t0); jd.pad = (uint32_t)t0;
       jd.ops_off = (uint64_t)(k_hi - t0);  // the free text start of this job (wfa_fast_kernel<64, 3>)
       jd.cigar_off = (uint64_t)s;          // the penalty it must come out with
-      a.band_jobs[atomicAdd(a.count + SC_BAND, 1u)] = jd;
+      a.band_jobs[atomicAdd(a.count + a.i_band, 1u)] = jd;
     } else {
       jd.pad = 0;
-      a.rest_jobs[atomicAdd(a.count + SC_HREST, 1u)] = jd;
+      a.rest_jobs[atomicAdd(a.count + a.i_rest, 1u)] = jd;
     }
   }
 }
 __global__ void band_check_kernel(const BandArgs a) {
-  const uint32_t n = a.count[SC_BAND];
+  const uint32_t n = a.count[a.i_band];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     JobDev jd = a.band_jobs[i];
     const uint32_t j = jd.out_index;
@@ -518,7 +521,7 @@ __global__ void band_check_kernel(const BandArgs a) {
     } else {
       a.n_match[j] = -1;
       jd.txt_off = a.read_off[j >> 1]; jd.txt_len = a.read_len[j >> 1]; jd.pad = 0; jd.ops_off = 0; jd.cigar_off = 0;
-      a.rest_jobs[atomicAdd(a.count + SC_HREST, 1u)] = jd;
+      a.rest_jobs[atomicAdd(a.count + a.i_rest, 1u)] = jd;
       atomicAdd(a.count + SC_BANDFAIL, 1u);
     }
   }
@@ -566,6 +569,12 @@ struct LongWinArgs {
   uint8_t* job_keep;                           // per long job: 1 = to the exact kernel
   JobDev* kept; uint32_t* n_kept;
   int32_t wl, step;
+  // The windows also say WHERE the alignment of a kept job is (FilterArgs::band): every alignment the read admits lies inside a window
+  // with the same penalty, so the read's optimal penalty is the smallest one a window reports and its end diagonal the smallest among
+  // those windows (a terminating diagonal of a window's run terminates in the whole read's run too, and the first one of the read is
+  // the first one of the window that holds its alignment).  That holds when every window either completed or was rejected at a level
+  // above that penalty; then the kept job carries penalty and diagonal for the banded back-trace (heavy_band_kernel), else 0.
+  const uint32_t* sub_band; uint32_t* job_best; uint32_t* job_rej;  // per long job: min (penalty << 16 | biased end diagonal in the read) | min level of a rejected window (0: a window was not judged)
 };
 __device__ __forceinline__ uint32_t long_windows_of(uint32_t tlen, int wl, int step) {
   return tlen <= (uint32_t)wl ? 1u : (tlen - (uint32_t)wl + (uint32_t)step - 1u) / (uint32_t)step + 1u;
@@ -581,6 +590,7 @@ __global__ void long_windows_kernel(const LongWinArgs a) {
     const uint32_t off = atomicAdd(a.n_sub, nw);
     const bool fits = off <= a.cap && nw <= a.cap - off;
     a.job_keep[j] = fits ? 0 : 1;
+    if (a.job_best) { a.job_best[j] = 0xFFFFFFFFu; a.job_rej[j] = fits ? 0xFFFFFFFFu : 0u; }
     for (uint32_t w = 0; w < nw && off + w < a.cap; ++w) {
       uint32_t start = fits ? w * (uint32_t)a.step : 0u;
       if (tlen > (uint32_t)a.wl && start + (uint32_t)a.wl > tlen) start = tlen - (uint32_t)a.wl;  // the last window: flush with the end
@@ -592,13 +602,31 @@ __global__ void long_windows_kernel(const LongWinArgs a) {
 }
 __global__ void long_verdict_kernel(const LongWinArgs a) {  // a kept window keeps its job
   const uint32_t n = min(*a.n_sub, a.cap);
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
-    if (a.sub_keep[s]) a.job_keep[a.parent[s]] = 1;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const uint32_t p = a.parent[s];
+    if (a.sub_keep[s]) a.job_keep[p] = 1;
+    if (a.sub_band) {
+      const uint32_t b = a.sub_band[s];
+      if (b >> 31) {
+        const uint64_t kbg = (uint64_t)(b & 0xFFFFu) + (a.sub[s].txt_off - a.jobs[p].txt_off);  // the diagonal counted from the start of the read
+        if (kbg < 0x10000u) atomicMin(a.job_best + p, (b & 0x7FFF0000u) | (uint32_t)kbg);
+        else atomicMin(a.job_rej + p, 0u);
+      } else atomicMin(a.job_rej + p, (b >> 30) ? (b & 0x3FFFFFFFu) : 0u);
+    }
+  }
 }
 __global__ void long_kept_kernel(const LongWinArgs a) {
   const uint32_t n = *a.n_jobs;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    if (a.job_keep[j]) a.kept[atomicAdd(a.n_kept, 1u)] = a.jobs[j];
+    if (a.job_keep[j]) {
+      JobDev jd = a.jobs[j];
+      jd.pad = 0;
+      if (a.job_best) {
+        const uint32_t best = a.job_best[j];
+        if (best != 0xFFFFFFFFu && (best >> 16) < a.job_rej[j]) jd.pad = 0x80000000u | best;
+      }
+      a.kept[atomicAdd(a.n_kept, 1u)] = jd;
+    }
 }
 
 // Device-side part shared with trgt_locus_batch: everything already resident, results left on the device.
@@ -775,7 +803,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       BandArgs ba;
       ba.keep_jobs = LH.jobs_dev; ba.n_keep = LH.n_jobs_dev; ba.band_jobs = (JobDev*)d_band; ba.rest_jobs = (JobDev*)d_hrest; ba.count = (uint32_t*)d_count;
       ba.s_max = s_max; ba.score = (const int32_t*)d_bscore; ba.span4 = (uint32_t*)d_span4; ba.n_match = (int32_t*)d_nmatch;
-      ba.read_off = d_read_off; ba.read_len = d_read_len;
+      ba.read_off = d_read_off; ba.read_len = d_read_len; ba.i_band = SC_BAND; ba.i_rest = SC_HREST;
       hipLaunchKernelGGL(heavy_band_kernel, dim3(64), dim3(256), 0, c->stream, ba);
       TRGT_HIP_TRY(c, hipGetLastError());
       WfaLaunch LB = LH;
@@ -876,6 +904,10 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + SC_LONG; 
         lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
         lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
+        const bool long_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt && max_read_len < 0xF000u;
+        void *d_sband = nullptr, *d_jbest = nullptr, *d_jrej = nullptr;
+        if (long_band && ((rc = dev_get(c, S_LW_SUBBAND, cap * 4, &d_sband)) || (rc = dev_get(c, S_LW_JOBBEST, n_jobs * 4, &d_jbest)) || (rc = dev_get(c, S_LW_JOBREJ, n_jobs * 4, &d_jrej)))) return rc;
+        lw.sub_band = (const uint32_t*)d_sband; lw.job_best = (uint32_t*)d_jbest; lw.job_rej = (uint32_t*)d_jrej;
         const dim3 g((unsigned)c->num_cus * 2), b(256);
         TRGT_HIP_TRY(c, hipMemsetAsync(d_lwc, 0, 16, c->stream));
         hipLaunchKernelGGL(long_windows_kernel, g, b, 0, c->stream, lw);
@@ -883,12 +915,35 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         FilterLaunch FW;
         FW.jobs_dev = (const JobDev*)d_sub; FW.n_jobs_host = (int64_t)cap; FW.n_jobs_dev = (const uint32_t*)d_lwc;
         FW.pat_base = d_flank; FW.txt_base = d_reads; FW.max_plen = p.flank_len; FW.max_tlen = wl;
-        FW.mism = p.mism; FW.gapo = p.gapo; FW.gape = p.gape; FW.min_matches = (int32_t)min_matches; FW.early_reject = !c->knobs.no_early; FW.keep = (uint8_t*)d_subkeep; FW.set = 1;
+        FW.mism = p.mism; FW.gapo = p.gapo; FW.gape = p.gape; FW.min_matches = (int32_t)min_matches; FW.early_reject = !c->knobs.no_early; FW.keep = (uint8_t*)d_subkeep; FW.band = (uint32_t*)d_sband; FW.set = 1;
         if ((rc = flank_filter_launch(c, FW))) return rc;
         hipLaunchKernelGGL(long_verdict_kernel, g, b, 0, c->stream, lw);
         hipLaunchKernelGGL(long_kept_kernel, g, b, 0, c->stream, lw);
         TRGT_HIP_TRY(c, hipGetLastError());
         L2.jobs_dev = (const JobDev*)d_kept; L2.n_jobs_dev = (const uint32_t*)d_lwc + 1;
+        if (long_band) {  // the kept reads whose windows named penalty and end diagonal: inside their band, as the short reads (BandArgs)
+          void *d_lband = nullptr, *d_lrest = nullptr, *d_lscore = nullptr;
+          if ((rc = dev_get(c, S_LW_BANDJOBS, n_jobs * sizeof(JobDev), &d_lband)) || (rc = dev_get(c, S_LW_RESTJOBS, n_jobs * sizeof(JobDev), &d_lrest)) ||
+              (rc = dev_get(c, S_LW_BSCORE, n_jobs * 4, &d_lscore)))
+            return rc;
+          const int s_max = c->knobs.heavy_band;
+          BandArgs ba;
+          ba.keep_jobs = (const JobDev*)d_kept; ba.n_keep = (const uint32_t*)d_lwc + 1; ba.band_jobs = (JobDev*)d_lband; ba.rest_jobs = (JobDev*)d_lrest; ba.count = (uint32_t*)d_count;
+          ba.s_max = s_max; ba.score = (const int32_t*)d_lscore; ba.span4 = (uint32_t*)d_span4; ba.n_match = (int32_t*)d_nmatch;
+          ba.read_off = d_read_off; ba.read_len = d_read_len; ba.i_band = SC_LBAND; ba.i_rest = SC_LREST;
+          hipLaunchKernelGGL(heavy_band_kernel, dim3(64), dim3(256), 0, c->stream, ba);
+          TRGT_HIP_TRY(c, hipGetLastError());
+          WfaLaunch LB = L2;
+          LB.jobs_dev = (const JobDev*)d_lband; LB.n_jobs_dev = (const uint32_t*)d_count + SC_LBAND;
+          LB.max_tlen = (int64_t)p.flank_len + 2 * s_max; LB.max_sum = (int64_t)p.flank_len + LB.max_tlen;
+          LB.score = (int32_t*)d_lscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = 64;
+          trgt_wfa_params wpb = wp;
+          wpb.text_begin_free = 2 * s_max;
+          if ((rc = wfa_launch(c, wpb, LB))) return rc;
+          hipLaunchKernelGGL(band_check_kernel, dim3(64), dim3(256), 0, c->stream, ba);
+          TRGT_HIP_TRY(c, hipGetLastError());
+          L2.jobs_dev = (const JobDev*)d_lrest; L2.n_jobs_dev = (const uint32_t*)d_count + SC_LREST;
+        }
       }
     }
     if ((rc = wfa_launch(c, wp, L2))) return rc;
@@ -916,6 +971,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
               h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT], h[SC_WIN], h[SC_REST], h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT], h[SC_REST] - (h[SC_LIGHT] - h[SC_WIN] - h[SC_SHORTCUT]), h[SC_SHORTCUT], h[SC_GAPS]);
     if (win_q <= 0) fprintf(stderr, "[spans] fallback alignments: first launch %u, long reads %u, light %u (no seeded windows for this configuration)\n", h[SC_HEAVY], h[SC_LONG], h[SC_LIGHT]);
     if (win_q > 0 && heavy_window) fprintf(stderr, "[spans+] (the seed search ran over the first launch's list too: %u of its %u alignments had no seeds and met the pre-filter; the counts of the windowed list and of the shortcut include the others)\n", h[SC_NOSEED], h[SC_HEAVY]);
+    if (has_long) fprintf(stderr, "[spans+] long reads kept by the window filter: back-traced inside a band %u, over the whole read %u\n", h[SC_LBAND], h[SC_LREST]);
     if (heavy_band) fprintf(stderr, "[spans+] kept by the pre-filter: %u -> back-traced inside a band %u (did not stand: %u), over the whole read %u\n", h[SC_KEEP], h[SC_BAND], h[SC_BANDFAIL], h[SC_HREST]);
   }
   (void)n_loci;

@@ -59,6 +59,7 @@ struct FilterArgs {  // by-value kernel argument
   int32_t early_reject;                     // stop an alignment as soon as no cell of its wavefronts can reach min_matches any more
   JobDev* keep_jobs; uint32_t* keep_count;  // kept alignments, appended (NULL: none wanted)
   int32_t* score; int32_t* bound; uint8_t* keep;  // optional, indexed by JobDev::out_index
+  uint32_t* band;                           // optional, by out_index: bit 31 | penalty << 16 | biased end diagonal of a run that completed; bit 30 | level of one rejected early (its penalty is larger); 0: not judged
   int32_t diag_lo, diag_hi;                 // this launch takes the jobs with diag_lo < plen + tlen + 1 <= diag_hi (the others belong to another launch over the same list)
   unsigned long long* cells_out;
 };
@@ -70,7 +71,7 @@ struct FilterLaunch {
   int mism = 2, gapo = 5, gape = 1;  // --aln-scoring: 2,5,1 (wgs) or 1,0,1 (targeted) have an instantiation
   bool early_reject = false;  // see FilterArgs (then: score INT32_MIN + 1, bound min_matches - 1 for the alignments stopped early)
   JobDev* keep_jobs = nullptr; uint32_t* keep_count = nullptr;
-  int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr;
+  int32_t* score = nullptr; int32_t* bound = nullptr; uint8_t* keep = nullptr; uint32_t* band = nullptr;
   bool count_offsets = false;  // also count the wavefront offsets (a little slower: one more scalar walk per level)
   int timer_slot = TRGT_K_WFA_FILTER;
   int set = 0;  // 1: a second launch that may run next to the first (own job counter and offset counter; ctx->last_filter_cells_dev stays the first's)

@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
         if (!level(std::integral_constant<int, 0>())) break;
       }
       cells_acc += cells;
-      if (early) { keep = 0; score_out = INT32_MIN + 1; bound_out = a.min_matches - 1; }
+      if (early) { keep = 0; score_out = INT32_MIN + 1; bound_out = a.min_matches - 1; band = 0x40000000u | (uint32_t)min(s, 0x3FFFFFFF); }  // (no alignment of penalty <= s exists: the run had not ended)
       else if (bail || !done) keep = 1;
       else {
         // the first terminating diagonal (wavefront_extend walks k upwards and stops at the first one)
@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
       if (a.score) a.score[o] = score_out;
       if (a.bound) a.bound[o] = bound_out;
       if (a.keep) a.keep[o] = (uint8_t)keep;
-      if (keep && a.keep_jobs) { JobDev kj = job; kj.pad = band; a.keep_jobs[atomicAdd(a.keep_count, 1u)] = kj; }
+      if (a.band) a.band[o] = band;
+      if (keep && a.keep_jobs) { JobDev kj = job; kj.pad = (band >> 31) ? band : 0u; a.keep_jobs[atomicAdd(a.keep_count, 1u)] = kj; }
       kept_acc += (unsigned long long)keep;
     }
   }
@@ -555,7 +556,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;
   a.min_matches = L.min_matches; a.early_reject = L.early_reject ? (c->knobs.early_adaptive ? 2 : 1) : 0;
   a.keep_jobs = L.keep_jobs; a.keep_count = L.keep_count;
-  a.score = L.score; a.bound = L.bound; a.keep = L.keep;
+  a.score = L.score; a.bound = L.bound; a.keep = L.keep; a.band = L.band;
   void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
   if ((rc = dev_get(c, L.set ? S_FLT_COUNTER_B : S_FLT_COUNTER, 16, &d_counter)) || (rc = dev_get(c, L.set ? S_FLT_CELLS_B : S_FLT_CELLS, 16, &d_cells))) return rc;
