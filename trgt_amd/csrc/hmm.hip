@@ -339,12 +339,16 @@ __device__ unsigned long long g_hmm_prof[16];
 #define HP_FILL_DECL unsigned long long hf_t = clock64(), hf_acc[6] = {0, 0, 0, 0, 0, 0}
 #define HP_FILL(i) do { const unsigned long long n_ = clock64(); hf_acc[i] += n_ - hf_t; hf_t = n_; } while (0)
 #define HP_FILL_END do { if (tid == 0) for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_hmm_prof[8 + q_], hf_acc[q_]); } while (0)
+#define HP_LONG_DECL unsigned long long hl_t = clock64()
+#define HP_LONG(i) do { const unsigned long long n_ = clock64(); if (tid == 0) atomicAdd(&g_hmm_prof[i], n_ - hl_t); hl_t = n_; } while (0)
 #else
 #define HP_DECL
 #define HP_MARK(i)
 #define HP_FILL_DECL
 #define HP_FILL(i)
 #define HP_FILL_END
+#define HP_LONG_DECL
+#define HP_LONG(i)
 #endif
 constexpr int HMM_LONG_MIN = 1536;   // columns from which an allele's trace-back goes to hmm_traceback_long_kernel
 constexpr int HMM_LONG_CHUNK = 64;   // columns per chunk map there
@@ -1303,9 +1307,9 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     HmmChunkRec* const g_crec = reinterpret_cast<HmmChunkRec*>(g_map + (size_t)3 * S * n_chunks);  // [n_chunks]
     const int sub_cols = max(1, HMM_LONG_STG / Spad);
     // one step of the chase: the predecessor of `state` in column `idx` (b: its back-pointer)
-    auto pred_of = [&](int state, int b) -> uint32_t {
-      const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
-      const uint32_t pw = (b & 2) ? pin[1] : pin[0];
+    // (all four predecessor entries of the state are read before its back-pointer is known -- one LDS round trip per step, not two)
+    auto pred_of = [&](int state, int b, uint32_t p01, uint32_t p23) -> uint32_t {
+      const uint32_t pw = (b & 2) ? p23 : p01;
       uint32_t pe = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
       if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + (b < nb ? b : 0)]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15); }
       return pe;
@@ -1317,6 +1321,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
       const int n16 = (c1 - c0) * Spad / 16;
       for (int i = lane; i < n16; i += 64) dst[i] = src[i];
     };
+    HP_LONG_DECL;
     // ---- (A) chunk maps: every (chunk, block of 64 entry states) is a task of one wave
     const int passes = (S + 63) / 64;
     for (int task = wave; task < n_chunks * passes; task += NW) {
@@ -1333,11 +1338,12 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         while (__ballot(state != 0 && idx >= c0 && nsteps < step_cap) != 0ull) {
           if (state != 0 && idx >= c0 && nsteps < step_cap) {
-            const uint32_t inf = l_info[state];
+            const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
+            const uint32_t inf = l_info[state], p01 = pin[0], p23 = pin[1];
+            const int b = l_stage[(idx - c0) * Spad + state];
             const int kind = (int)(inf & 7u);
             ++nsteps; nstarts += kind == 1; if (kind == 2) last_end = idx; last_state = state;
-            const int b = l_stage[(idx - c0) * Spad + state];
-            const uint32_t pe = pred_of(state, b);
+            const uint32_t pe = pred_of(state, b, p01, p23);
             if ((inf >> 3) & 1u) --idx;
             const int nx = (int)(pe & 0x7FFFu);
             state = nx < S ? nx : 0;
@@ -1354,6 +1360,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     }
     __syncthreads();  // (+ the maps are in global memory: read back by thread 0 of this workgroup)
     __threadfence();
+    HP_LONG(4);
     // ---- (B) the chunks strung together from the end state
     if (tid == 0) {
       uint32_t e = (uint32_t)(S - 1), np = 0, nv = 0; int vb = 0, nxt = -1;
@@ -1372,6 +1379,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     }
     __syncthreads();
     __threadfence();
+    HP_LONG(5);
     // ---- (C) every chunk again, from its entry state, with the decoding of the steps (the round loop of hmm_viterbi_kernel)
     uint16_t* pbuf = path ? path + job.path_off : nullptr;
     const int pcap = (int)job.path_cap;
@@ -1390,12 +1398,15 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
         while (state != 0 && idx >= c0) {
           // the chase of up to 64 steps: on wave-uniform values (state and column in SGPRs: scalar arithmetic, scalar branches)
           int n = 0;
+          int emits = __builtin_amdgcn_readfirstlane((int)((l_info[state] >> 3) & 1u));  // (afterwards: bit 15 of the predecessor entry)
           while (state != 0 && idx >= c0 && n < 64) {
             l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
-            const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_info[state]);
+            const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
+            const uint32_t p01 = pin[0], p23 = pin[1];
             const int b = __builtin_amdgcn_readfirstlane((int)l_stage[(idx - c0) * Spad + state]);
-            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)pred_of(state, b));
-            if ((inf >> 3) & 1u) --idx;
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)pred_of(state, b, p01, p23));
+            if (emits) --idx;
+            emits = (int)(pe >> 15);
             state = (int)(pe & 0x7FFFu);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1451,6 +1462,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     if (lane == 0) { atomicAdd(&tot[0], edit_acc); atomicAdd(&tot[1], ref_acc); }
     __syncthreads();
     __threadfence();
+    HP_LONG(6);
     // ---- the end of the walk (the start state closes the path), then as in hmm_viterbi_kernel: path order, purity, the visits
     int np = tot[2];
     if (tid == 0 && pbuf && np < pcap) pbuf[pcap - 1 - np] = 0;
@@ -1473,28 +1485,76 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
       purity[job.job_index] = ((double)mx - (double)edit) / (double)mx;
       if (edit_out) edit_out[job.job_index] = edit;
       if (maxd_out) maxd_out[job.job_index] = mx;
-      // label_motifs over the kept copies, skip filter, counts, collapse: the visits were recorded back to front
-      int ns = 0, cum = 0, last_motif = -1, last_end = -1;
+    }
+    // label_motifs over the kept copies, skip filter, counts, collapse (hmm_model.rs:158-200, operations.rs:6-80, utils.rs:3-27), all threads:
+    // the visits were recorded back to front, one lane takes one visit; base ranges by a prefix sum of the copy lengths, "the kept
+    // visit before me" by a look-back (a span goes on when that one has my motif and ends where I start), span numbers by a prefix
+    // count of the span heads, span ends by an atomic max (they grow along a span).  (One thread walking the list paid three
+    // dependent global loads per visit: 43 % of this kernel on a 10-kb CAG allele.)
+    {
       int32_t* const sp = spans3 + 3 * job.span_off;
-      for (int v = tot[3] - 1; v >= 0; --v) {
-        const uint32_t v0 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v), v1 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v + 1), v2 = __builtin_nontemporal_load(g_vis + 3 * (size_t)v + 2);
-        const int blk = (int)(v0 & 0x7FFFu), b0 = (int)v1, b1 = (int)v2;
-        const bool keep = (v0 >> 15) == 0;
-        const int cnt = b1 - b0;
-        const int start = cum, end = cum + cnt;
-        cum = end;
-        const int motif = keep ? blk : nb - 1;
-        if (motif < n_motifs) {
-          l_cnt[motif] += 1;
-          if (ns > 0 && last_motif == motif && last_end == start) { sp[3 * (ns - 1) + 2] = end; }
-          else { sp[3 * ns + 0] = motif; sp[3 * ns + 1] = start; sp[3 * ns + 2] = end; ++ns; last_motif = motif; }
-          last_end = end;
+      int* const sc_sum = reinterpret_cast<int*>(wave_base);  // [NW] | [NW] | [NW][3]: the staging areas are free now
+      int* const sc_heads = sc_sum + NW;
+      int* const sc_last = sc_heads + NW;
+      const int nvis = tot[3];
+      int carry_cum = 0, carry_ns = 0, carry_motif = -1, carry_end = -1;  // (the same in every thread)
+      const unsigned long long below_m = (1ull << lane) - 1ull;
+      auto scan_add = [&](int x, int* lds_w, int& total) -> int {  // inclusive prefix sum over the workgroup
+        int v = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+        if (lane == 63) lds_w[wave] = v;
+        __syncthreads();
+        int woff = 0, tt = 0;
+        for (int w = 0; w < NW; ++w) { const int t = lds_w[w]; if (w < wave) woff += t; tt += t; }
+        __syncthreads();
+        total = tt;
+        return v + woff;
+      };
+      for (int base = 0; base < nvis; base += HMM_LONG_THREADS) {
+        const int i = base + tid;
+        const bool in = i < nvis;
+        uint32_t v0 = 0, v1 = 0, v2 = 0;
+        if (in) {
+          const uint32_t* vr = g_vis + 3 * (size_t)(nvis - 1 - i);
+          v0 = __builtin_nontemporal_load(vr); v1 = __builtin_nontemporal_load(vr + 1); v2 = __builtin_nontemporal_load(vr + 2);
         }
+        const int blk = (int)(v0 & 0x7FFFu), cnt = in ? (int)v2 - (int)v1 : 0;
+        const int motif = (v0 >> 15) == 0 ? blk : nb - 1;
+        const bool valid = in && motif < n_motifs;
+        int total_cnt = 0;
+        const int end = carry_cum + scan_add(cnt, sc_sum, total_cnt), start = end - cnt;
+        // the kept visit before me: in my wave, else the last one of the nearest wave before that has any, else the chunk before
+        const unsigned long long vm = __ballot(valid);
+        const int last_lane = vm ? 63 - (int)__builtin_clzll(vm) : 0;
+        if (lane == last_lane) { sc_last[3 * wave] = vm ? 1 : 0; sc_last[3 * wave + 1] = motif; sc_last[3 * wave + 2] = end; }
+        __syncthreads();
+        const unsigned long long vb = vm & below_m;
+        const int src = vb ? 63 - (int)__builtin_clzll(vb) : lane;
+        int pm = __shfl(motif, src), pe = __shfl(end, src);
+        if (!vb) {
+          pm = carry_motif; pe = carry_end;
+          for (int w = wave - 1; w >= 0; --w) if (sc_last[3 * w]) { pm = sc_last[3 * w + 1]; pe = sc_last[3 * w + 2]; break; }
+        }
+        int new_motif = carry_motif, new_end = carry_end;
+        for (int w = NW - 1; w >= 0; --w) if (sc_last[3 * w]) { new_motif = sc_last[3 * w + 1]; new_end = sc_last[3 * w + 2]; break; }
+        const bool head = valid && !(pm == motif && pe == start && pm >= 0);
+        int total_heads = 0;
+        const int hincl = scan_add(head ? 1 : 0, sc_heads, total_heads);
+        const int si = carry_ns + hincl - 1;  // my span (a head: the one it opens)
+        if (head) { sp[3 * si + 0] = motif; sp[3 * si + 1] = start; sp[3 * si + 2] = end; }
+        if (valid) atomicAdd(&l_cnt[motif], 1u);
+        __syncthreads();
+        __threadfence();
+        if (valid && !head) atomicMax(&sp[3 * si + 2], end);
+        carry_cum += total_cnt; carry_ns += total_heads; carry_motif = new_motif; carry_end = new_end;
+        __syncthreads();
       }
-      n_spans[job.job_index] = (uint32_t)ns;
+      if (tid == 0) n_spans[job.job_index] = (uint32_t)carry_ns;
     }
     __syncthreads();
     for (int m = tid; m < n_motifs; m += HMM_LONG_THREADS) counts[job.count_off + m] = l_cnt[m];
+    HP_LONG(7);
   }
 }
 
@@ -2419,6 +2479,7 @@ int trgt::hmm_collect(trgt_hip_ctx* c, HmmPending* pend) {
     fprintf(stderr, "[hmm prof] jobs=%lld | setup %.1f%% fill %.1f%% traceback %.1f%% path+decode %.1f%% | kcycles/job %.1f\n", (long long)n_jobs,
             100 * h[0] / t, 100 * h[1] / t, 100 * h[2] / t, 100 * h[3] / t, t / 1e3 / (double)n_jobs);
     const double f = (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13]) + 1e-9;
+    fprintf(stderr, "[hmm prof]   long trace-back (kcycles of thread 0 over all alleles): chunk maps %.0f, stringing %.0f, re-walk %.0f, path order + visits %.0f\n", h[4] / 1e3, h[5] / 1e3, h[6] / 1e3, h[7] / 1e3);
     fprintf(stderr, "[hmm prof]   fill (%.0f kcycles on the profiled lanes): symbol %.1f%% emitting+sync %.1f%% chains+ends+sync %.1f%% run end+sync %.1f%% block starts+sync %.1f%% store %.1f%%\n",
             f / 1e3, 100 * h[8] / f, 100 * h[9] / f, 100 * h[10] / f, 100 * h[11] / f, 100 * h[12] / f, 100 * h[13] / f);
   }
