@@ -33,8 +33,9 @@ def _spans_equal(oracle, loci, env_ctx):
         assert np.array_equal(x, y), name
     # what the window filter keeps is back-traced inside the band its windows name (penalty and end diagonal: the smallest over the
     # windows); without the band, and with bands that take only some of the alignments, the same spans
-    for band in ("0", "12", "256"):
-        bctx = _lib.context_with_env(TRGT_HEAVY_BAND=band)
+    for band in ("0", "12", "256", "no seed search"):
+        # ("no seed search": the long reads' alignments straight to the window filter, without the shortcuts and seeded windows in front)
+        bctx = _lib.context_with_env(TRGT_HEAVY_BAND=band) if band != "no seed search" else _lib.context_with_env(TRGT_NO_LONG_WINDOW=1)
         try:
             other = locus.find_tr_spans_batch(b, ctx=bctx)
         finally:

@@ -47,6 +47,7 @@ struct trgt_knobs {
   bool filter_side = false;        // TRGT_FILTER_SIDE: ... next to each other in the contexts of a pool too
   bool filter_serial = false;      // TRGT_FILTER_SERIAL: the pre-filter's two launches one after the other on one stream
   bool filter_one_launch = false;  // TRGT_FILTER_ONE_LAUNCH: the pre-filter in one launch whatever the text lengths
+  bool no_long_window = false;  // TRGT_NO_LONG_WINDOW: the long reads' alignments skip the seed search (shortcuts, seeded windows)
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool no_lean = false;      // TRGT_WFA_NO_LEAN: consensus alignments / edit distances straight to the generic kernel (no register-resident BiWFA kernel in front)
   bool lean_one_tier = false;  // TRGT_WFA_LEAN_ONE_TIER: no second tier (256 diagonals) between the register-resident kernel and the generic one
@@ -218,7 +219,7 @@ enum Slot {
   S_WFA_SEQ, S_WFA_JOBS, S_WFA_WS, S_WFA_STATUS, S_WFA_SCORE, S_WFA_NMATCH, S_WFA_SPAN, S_WFA_CIGAR, S_WFA_CLEN, S_WFA_OPS,
   S_WFA_OLEN, S_WFA_COUNTER, S_WFA_CELLS, S_WFA_WS_B, S_WFA_COUNTER_B, S_WFA_CELLS_B, S_WFA_POFF, S_WFA_PACKED, S_WFA_RETRY, S_WFA_RETRY_B, S_WFA_WS_C, S_WFA_COUNTER_C, S_WFA_CELLS_C, S_WFA_RETRY_C, S_WFA_MID, S_WFA_MID_B, S_WFA_MID_C,
   S_FS_FLANK, S_FS_READS, S_FS_JOBS, S_FS_POS, S_FS_LIST, S_FS_COUNT, S_FS_OUT0, S_FS_OUT1, S_FS_HIT0, S_FS_HIT1,
-  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY, S_FS_NOSEED, S_FS_BANDJOBS, S_FS_HRESTJOBS, S_FS_BSCORE, S_LW_SUBBAND, S_LW_JOBBEST, S_LW_JOBREJ, S_LW_BANDJOBS, S_LW_RESTJOBS, S_LW_BSCORE,
+  S_FS_WFAJOBS, S_FS_WFAJOBS_LONG, S_FS_KEEPJOBS, S_PF_READS0, S_PF_READS1, S_PF_FLANK0, S_PF_FLANK1, S_READS_PACKED, S_READS_EXPANDED, S_FLT_COUNTER, S_FLT_CELLS, S_FLT_COUNTER_B, S_FLT_CELLS_B, S_LW_FIRST, S_LW_SUB, S_LW_PARENT, S_LW_SUBKEEP, S_LW_JOBKEEP, S_LW_KEPT, S_LW_COUNT, S_FLT_SEQ, S_FLT_JOBS, S_FLT_SCORE, S_FLT_BOUND, S_FLT_KEEP, S_FS_WINJOBS, S_FS_RESTJOBS, S_FS_SCORE, S_FS_SPAN, S_FS_NMATCH, S_FS_HEAVY, S_FS_NOSEED, S_FS_BANDJOBS, S_FS_HRESTJOBS, S_FS_BSCORE, S_FS_LONGNOSEED, S_LW_SUBBAND, S_LW_JOBBEST, S_LW_JOBREJ, S_LW_BANDJOBS, S_LW_RESTJOBS, S_LW_BSCORE,
   S_LOCUS_0, S_LOCUS_1, S_LOCUS_2, S_LOCUS_3, S_LOCUS_4, S_LOCUS_5, S_LOCUS_6, S_LOCUS_7,
   S_GT_LRB, S_GT_PLOIDY, S_GT_TR, S_GT_TROFF, S_GT_TRLEN, S_GT_ALOFF, S_GT_ALCAP, S_GT_NEED, S_GT_NAL, S_GT_BLOB, S_GT_ALEN, S_GT_CI, S_GT_NSP,
   S_GT_CLS, S_GT_RANK, S_GT_NSPAN, S_GT_TOFF, S_GT_PACKED, S_GT_GENO,

@@ -40,6 +40,7 @@ enum SpanCount : int {
   SC_BANDFAIL = 12, // banded runs that did not come out with the pre-filter's penalty (the argument says: none)
   SC_LBAND = 13,    // long reads (SC_LONG) whose windows named the penalty and the end diagonal: back-traced inside a band
   SC_LREST = 14,    // ... the other long reads the window filter keeps: back-traced over the whole read
+  SC_LNOSEED = 15,  // long reads' alignments the seed search could neither settle nor window (or whose window did not stand): the window filter's list
   SC_WORDS = 16
 };
 
@@ -213,6 +214,7 @@ struct WindowArgs {
   JobDev* win_jobs; JobDev* rest_jobs;
   int32_t flank_len, q, margin, spread, tbf;
   int32_t front;                       // 1: the jobs at the FRONT of wfa_jobs (count[0], the expensive ones); the jobs without a window then go to rest_jobs under count[8]
+  const JobDev* long_jobs; JobDev* long_rest;  // not NULL (with front == 0): the long reads' list (count[SC_LONG]) behind the light one; its jobs without a window go to long_rest under count[SC_LNOSEED]
   int32_t hamming_max;                 // > 0: the substitution-only shortcut below, for up to this many mismatches
   int32_t indel_ok;                    // 1: the one-base-gap shortcut (penalties 2,5,1)
   int32_t* n_match; uint32_t* span4;   // per (read, side): what the alignment kernels would have written for such a job
@@ -221,18 +223,22 @@ constexpr int WIN_JOBS_PER_WG = 64;
 template <int WIN_SEGMENTS>
 __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
   __shared__ JobDev l_out[WIN_JOBS_PER_WG];  // windowed jobs from the front, the others from the back
-  __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns, l_ni;
-  const uint32_t n_light = a.count[a.front ? SC_HEAVY : SC_LIGHT];  // (the length of the list this launch walks)
+  __shared__ JobDev l_long[WIN_JOBS_PER_WG]; // long reads' jobs without a window
+  __shared__ uint32_t l_nw, l_nr, l_bw, l_br, l_ns, l_ni, l_nl, l_bl;
+  // (the length of the list this launch walks; with long_jobs the long reads' list behind it -- ONE launch: a second one would wait behind the
+  //  pre-filter's persistent workgroups of the other stream, 1.6 ms for 9 k jobs on the catalog mix)
+  const uint32_t n_first = a.count[a.front ? SC_HEAVY : SC_LIGHT], n_light = n_first + (a.long_jobs ? a.count[SC_LONG] : 0u);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // jobs per workgroup and round: 64, fewer when the list is short (a job is a dependent chain of loads: 17 k jobs in rounds of 64 kept
   // 270 workgroups busy for 0.39 ms; spread over all of them they take a fifth of that)
   const uint32_t per_wg = min((uint32_t)WIN_JOBS_PER_WG, max(4u, ((n_light + gridDim.x - 1u) / gridDim.x + 3u) & ~3u));
   for (uint32_t c0 = blockIdx.x * per_wg; c0 < n_light; c0 += gridDim.x * per_wg) {
-    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; l_ni = 0; }
+    if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; l_ni = 0; l_nl = 0; }
     __syncthreads();
     const uint32_t c1 = c0 + per_wg < n_light ? c0 + per_wg : n_light;
     for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
-      JobDev jd = a.front ? a.wfa_jobs[i] : a.wfa_jobs[a.jobs_cap - 1u - i];
+      const bool is_long = i >= n_first;
+      JobDev jd = is_long ? a.long_jobs[i - n_first] : a.front ? a.wfa_jobs[i] : a.wfa_jobs[a.jobs_cap - 1u - i];
       const int n = (int)jd.txt_len, F = a.flank_len;
       int kmin = 1, kmax = 0;
       if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
@@ -334,17 +340,20 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
       }
       if (lane == 0) {
         if (wl > 0) { jd.txt_off += (uint64_t)w0; jd.txt_len = (uint32_t)wl; jd.pad = (uint32_t)w0; l_out[atomicAdd(&l_nw, 1u)] = jd; }
+        else if (is_long) l_long[atomicAdd(&l_nl, 1u)] = jd;
         else l_out[WIN_JOBS_PER_WG - 1 - atomicAdd(&l_nr, 1u)] = jd;
       }
     }
     __syncthreads();
     if (threadIdx.x == 0 && l_nw) l_bw = atomicAdd(a.count + SC_WIN, l_nw);
     if (threadIdx.x == 64 && l_nr) l_br = atomicAdd(a.count + (a.front ? SC_NOSEED : SC_REST), l_nr);
+    if (threadIdx.x == 65 && l_nl) l_bl = atomicAdd(a.count + SC_LNOSEED, l_nl);
     if (threadIdx.x == 128 && l_ns) atomicAdd(a.count + SC_SHORTCUT, l_ns);
     if (threadIdx.x == 192 && l_ni) atomicAdd(a.count + SC_GAPS, l_ni);  // (of those: one-base gaps)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_nw; i += blockDim.x) a.win_jobs[l_bw + i] = l_out[i];
     for (uint32_t i = threadIdx.x; i < l_nr; i += blockDim.x) a.rest_jobs[l_br + i] = l_out[WIN_JOBS_PER_WG - 1 - i];
+    for (uint32_t i = threadIdx.x; i < l_nl; i += blockDim.x) a.long_rest[l_bl + i] = l_long[i];
     __syncthreads();
   }
 }
@@ -461,6 +470,7 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
 struct WinCheckArgs {
   const JobDev* win_jobs; const uint32_t* n_win; const int32_t* score; uint32_t* span4; int32_t* n_match; int32_t s0;
   JobDev* wfa_jobs; uint32_t* wfa_count; uint32_t jobs_cap; const uint64_t* read_off; const uint32_t* read_len;
+  JobDev* long_rest; uint32_t long_tlen;  // a long read's alignment whose window did not stand: to the long reads' list (NULL: there is none)
 };
 __global__ void window_check_kernel(const WinCheckArgs a) {
   const uint32_t n = *a.n_win;
@@ -473,7 +483,8 @@ __global__ void window_check_kernel(const WinCheckArgs a) {
     } else {
       a.n_match[j] = -1;
       jd.txt_off = a.read_off[j >> 1]; jd.txt_len = a.read_len[j >> 1]; jd.pad = 0;
-      a.wfa_jobs[atomicAdd(a.wfa_count + SC_REST, 1u)] = jd;  // (wfa_jobs: the rest list here)
+      if (a.long_rest && jd.txt_len > a.long_tlen) a.long_rest[atomicAdd(a.wfa_count + SC_LNOSEED, 1u)] = jd;
+      else a.wfa_jobs[atomicAdd(a.wfa_count + SC_REST, 1u)] = jd;  // (wfa_jobs: the rest list here)
     }
   }
 }
@@ -717,7 +728,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     WindowArgs wa;
     wa.flank_blob = d_flank; wa.read_blob = d_reads; wa.wfa_jobs = (const JobDev*)d_wjobs; wa.jobs_cap = (uint32_t)n_jobs; wa.count = (uint32_t*)d_count;
     wa.win_jobs = (JobDev*)d_winjobs; wa.rest_jobs = (JobDev*)d_restjobs; wa.flank_len = p.flank_len; wa.q = win_q; wa.margin = win_margin; wa.spread = win_spread; wa.tbf = 2 * win_margin + win_spread;
-    wa.front = 0;
+    wa.front = 0; wa.long_jobs = nullptr; wa.long_rest = nullptr;
     wa.hamming_max = c->knobs.no_hamming ? 0 : std::min(std::min(win_m - 1, (p.gapo + p.gape - 1) / p.mism), 4);  // (4: the kernel's count is exact up to there)
     wa.indel_ok = !c->knobs.no_hamming && !c->knobs.no_indel_shortcut && p.mism == 2 && p.gapo == 5 && p.gape == 1 && wa.hamming_max == 2 ? 1 : 0;
     wa.n_match = (int32_t*)d_nmatch; wa.span4 = (uint32_t*)d_span4;
@@ -729,6 +740,8 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
     else if (win_m == 6) hipLaunchKernelGGL(flank_window_kernel<6>, wgrid, dim3(256), 0, c->stream, wa);
     else hipLaunchKernelGGL(flank_window_kernel<8>, wgrid, dim3(256), 0, c->stream, wa);
   };
+  void* d_long_noseed = nullptr;                                   // the long reads' list behind the seed search (when that runs over it)
+  const JobDev* long_in = (const JobDev*)d_wjobs_long; int long_in_count = SC_LONG;
   c->last_filter_cells_dev = nullptr;
   bool heavy_join = false;         // the expensive alignments run on the second stream: wait for it before the spans are combined
   void* heavy_cells_dev = nullptr; // ... and their offset counter lives in workspace set 1
@@ -844,7 +857,13 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if (heavy_window) TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_hwin, 0));
       {
         KTimer t(c, TRGT_K_FLANK_SCAN);
-        launch_window(window_args());
+        WindowArgs wl2 = window_args();
+        if (has_long && !c->knobs.no_long_window) {  // the long reads' alignments meet the seed search too: shortcuts and windows do not care how long the read is
+          if ((rc = dev_get(c, S_FS_LONGNOSEED, n_jobs * sizeof(JobDev), &d_long_noseed))) return rc;
+          wl2.long_jobs = (const JobDev*)d_wjobs_long; wl2.long_rest = (JobDev*)d_long_noseed;
+          long_in = (const JobDev*)d_long_noseed; long_in_count = SC_LNOSEED;
+        }
+        launch_window(wl2);
         TRGT_HIP_TRY(c, hipGetLastError());
         t.stop(0);
       }
@@ -864,7 +883,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       wc.win_jobs = (const JobDev*)d_winjobs; wc.n_win = (const uint32_t*)d_count + SC_WIN; wc.score = (const int32_t*)d_score;
       wc.span4 = (uint32_t*)d_span4; wc.n_match = (int32_t*)d_nmatch; wc.s0 = win_s0;
       wc.wfa_jobs = (JobDev*)d_restjobs; wc.wfa_count = (uint32_t*)d_count; wc.jobs_cap = (uint32_t)n_jobs;
-      wc.read_off = d_read_off; wc.read_len = d_read_len;
+      wc.read_off = d_read_off; wc.read_len = d_read_len; wc.long_rest = (JobDev*)d_long_noseed; wc.long_tlen = long_tlen;
       hipLaunchKernelGGL(window_check_kernel, dim3(256), dim3(256), 0, c->stream, wc);
       TRGT_HIP_TRY(c, hipGetLastError());
       L.jobs_dev = (const JobDev*)d_restjobs; L.n_jobs_dev = (const uint32_t*)d_count + SC_REST; L.n_jobs2_dev = nullptr; L.jobs_cap = 0;
@@ -875,7 +894,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   if (!split) TRGT_HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->last_wfa_cells_dev + 8, c->last_wfa_cells_dev, 8, hipMemcpyDeviceToDevice, c->stream));
   if (has_long) {  // the long reads: same parameters, workspace and kernel choice planned for their size
     WfaLaunch L2 = L;
-    L2.jobs_dev = (const JobDev*)d_wjobs_long; L2.n_jobs_dev = (const uint32_t*)d_count + SC_LONG; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
+    L2.jobs_dev = long_in; L2.n_jobs_dev = (const uint32_t*)d_count + long_in_count; L2.n_jobs2_dev = nullptr; L2.jobs_cap = 0;
     L2.max_tlen = max_read_len; L2.max_sum = (int64_t)p.flank_len + max_read_len;
     L2.keep_cells = true; L2.timer_slot = TRGT_K_WFA_FLANK_REST;
     // the pre-filter over windows of the long reads (see LongWinArgs): what it rejects never reaches the exact kernel
@@ -901,7 +920,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
             (rc = dev_get(c, S_LW_COUNT, 16, &d_lwc)))
           return rc;
         LongWinArgs lw;
-        lw.jobs = (const JobDev*)d_wjobs_long; lw.n_jobs = (const uint32_t*)d_count + SC_LONG; 
+        lw.jobs = long_in; lw.n_jobs = (const uint32_t*)d_count + long_in_count; 
         lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
         lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
         const bool long_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt && max_read_len < 0xF000u;
