@@ -148,18 +148,20 @@ def test_long_alleles_parallel_traceback(oracle, hmm):
     for want_path in (True, False):
         _same(oracle, hmm, sets, jobs, want_path=want_path)
     batch = hmm.pack_hmm_batch(sets, jobs)
-    ctx = _lib.context_with_env(TRGT_HMM_NO_LONG_TB=1)
-    try:
-        a = hmm.hmm_batch(batch, ctx=ctx)
-    finally:
-        ctx.close()
     b = hmm.hmm_batch(batch)
-    for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
-        assert np.array_equal(a[k], b[k]), k
-    assert np.array_equal(a["purity"].view(np.uint64), b["purity"].view(np.uint64))
-    for j in range(len(jobs)):  # (behind a job's path the buffer holds what the reversal left there)
-        po, pl = int(batch["path_off"][j]), int(a["path_len"][j])
-        assert np.array_equal(a["path"][po:po + pl], b["path"][po:po + pl]), j
+    # ... switched off; by one workgroup per allele in one launch; by three and by sixteen workgroups per allele (default: four)
+    for env in (dict(TRGT_HMM_NO_LONG_TB=1), dict(TRGT_HMM_LONG_WGS=1), dict(TRGT_HMM_LONG_WGS=3), dict(TRGT_HMM_LONG_WGS=16)):
+        ctx = _lib.context_with_env(**env)
+        try:
+            a = hmm.hmm_batch(batch, ctx=ctx)
+        finally:
+            ctx.close()
+        for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
+            assert np.array_equal(a[k], b[k]), (env, k)
+        assert np.array_equal(a["purity"].view(np.uint64), b["purity"].view(np.uint64)), env
+        for j in range(len(jobs)):  # (behind a job's path the buffer holds what the reversal left there)
+            po, pl = int(batch["path_off"][j]), int(a["path_len"][j])
+            assert np.array_equal(a["path"][po:po + pl], b["path"][po:po + pl]), (env, j)
 
 
 def test_register_fill_variants_agree(oracle, hmm):

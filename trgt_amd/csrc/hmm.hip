@@ -1245,11 +1245,17 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
     const uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws, uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
     int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans, uint32_t* __restrict__ counts, double* __restrict__ purity,
-    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, const uint32_t* __restrict__ long_list) {
+    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, const uint32_t* __restrict__ long_list, const int phase, const int G) {
+  // phase 0: the whole trace-back by one workgroup per allele.  Phases 1 / 2 / 3 are the same code as three launches with G workgroups
+  // per allele in (A) and (C) -- an allele's chunks are independent there, and a class has few long alleles for 256 CUs: 1: (A) with
+  // the maps in the job's workspace; 2: (B) by one workgroup; 3: (C), the totals in the four words in front of the maps, and the
+  // workgroup that finishes last does the rest (path order, purity, visits).
   extern __shared__ __align__(16) unsigned char lds_long[];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = HMM_LONG_THREADS / 64;
-  for (uint32_t li = blockIdx.x; li < long_list[0]; li += gridDim.x) {
+  const int part = (int)(blockIdx.x % (unsigned)G);
+  __shared__ int l_last;
+  for (uint32_t li = blockIdx.x / (unsigned)G; li < long_list[0]; li += gridDim.x / (unsigned)G) {
     __syncthreads();
     const HmmJobDev job = jobs[long_list[1 + li]];
     const HmmSetDev set = sets[job.set];
@@ -1269,7 +1275,8 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     unsigned char* wave_base = lds_long + ((64 + (size_t)8 * S + 4 * S + 16 * nb + 4 * nb + ((S + 3) & ~3) + ((mot_bytes + 15) & ~15) + 15) & ~(size_t)15);
     uint8_t* l_stage = wave_base + (size_t)wave * (HMM_LONG_STG + 512);
     uint32_t* const l_map = reinterpret_cast<uint32_t*>(wave_base + (size_t)NW * (HMM_LONG_STG + 512));
-    const bool map_lds = ((size_t)3 * S + 8) * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS;
+    const bool map_lds = phase == 0 && ((size_t)3 * S + 8) * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS;
+    uint32_t* const hdr = visit_ws + job.map_off - 4;                                    // [0] edit, [1] ref, [2] workgroups done (phase 3)
     uint32_t* l_rec = reinterpret_cast<uint32_t*>(l_stage + HMM_LONG_STG);               // [64][2]
     const uint16_t* g_inst = reinterpret_cast<const uint16_t*>(model + set.off_inst);
     const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
@@ -1324,7 +1331,8 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     HP_LONG_DECL;
     // ---- (A) chunk maps: every (chunk, block of 64 entry states) is a task of one wave
     const int passes = (S + 63) / 64;
-    for (int task = wave; task < n_chunks * passes; task += NW) {
+    if (phase <= 1)
+    for (int task = wave + NW * part; task < n_chunks * passes; task += NW * G) {
       const int j = task / passes, q = task % passes;
       const int bot = j * C, top = min(L - 1, bot + C - 1);
       const int s0 = 64 * q + lane;
@@ -1361,14 +1369,21 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     __syncthreads();  // (+ the maps are in global memory: read back by thread 0 of this workgroup)
     __threadfence();
     HP_LONG(4);
+    if (phase == 1) continue;
     // ---- (B) the chunks strung together from the end state
-    if (tid == 0) {
+    uint32_t* const g_tail = reinterpret_cast<uint32_t*>(g_crec + n_chunks);  // [0] steps, [1] visits of the whole walk (phases 2 -> 3)
+    if (phase == 2 && (size_t)3 * S * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS) {  // the maps through LDS: the chain is a dependent look-up per chunk
+      for (int i = tid; i < 3 * S * n_chunks; i += HMM_LONG_THREADS) l_map[i] = __builtin_nontemporal_load(g_map + i);
+      __syncthreads();
+    }
+    const bool b_lds = map_lds || (phase == 2 && (size_t)3 * S * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS);
+    if (tid == 0 && phase != 3) {
       uint32_t e = (uint32_t)(S - 1), np = 0, nv = 0; int vb = 0, nxt = -1;
       for (int j = n_chunks - 1; j >= 0; --j) {
         HmmChunkRec r; r.entry = e; r.np0 = np; r.nv0 = nv; r.vb0 = vb; r.nxt0 = nxt; r.pad[0] = r.pad[1] = r.pad[2] = 0;
         g_crec[j] = r;
-        const uint32_t* m = g_map + (size_t)3 * ((size_t)j * S + e);
-        const uint32_t m0 = map_lds ? m[0] : __builtin_nontemporal_load(m), m1 = map_lds ? m[1] : __builtin_nontemporal_load(m + 1), m2 = map_lds ? m[2] : __builtin_nontemporal_load(m + 2);
+        const uint32_t* m = (b_lds ? l_map : g_map) + (size_t)3 * ((size_t)j * S + e);
+        const uint32_t m0 = b_lds ? m[0] : __builtin_nontemporal_load(m), m1 = b_lds ? m[1] : __builtin_nontemporal_load(m + 1), m2 = b_lds ? m[2] : __builtin_nontemporal_load(m + 2);
         const uint32_t ns = m1 & 0xFFFFu;
         np += ns; nv += m1 >> 16;
         if ((int32_t)m2 >= 0) vb = (int32_t)m2;
@@ -1376,17 +1391,19 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
         e = m0 & 0xFFFFu;
       }
       tot[2] = (int)np; tot[3] = (int)nv;
+      if (phase == 2) { g_tail[0] = np; g_tail[1] = nv; hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; }
     }
     __syncthreads();
     __threadfence();
     HP_LONG(5);
+    if (phase == 2) continue;
     // ---- (C) every chunk again, from its entry state, with the decoding of the steps (the round loop of hmm_viterbi_kernel)
     uint16_t* pbuf = path ? path + job.path_off : nullptr;
     const int pcap = (int)job.path_cap;
     auto code_at = [&](int i) -> int { return hmm_code(seq, i, L); };
     const unsigned long long below = (1ull << lane) - 1ull;
     int edit_acc = 0, ref_acc = 0;
-    for (int j = wave; j < n_chunks; j += NW) {
+    for (int j = wave + NW * part; j < n_chunks; j += NW * G) {
       const HmmChunkRec cr = g_crec[j];
       const int bot = j * C, top = min(L - 1, bot + C - 1);
       int state = (int)cr.entry, idx = top, np_c = (int)cr.np0, nv_c = (int)cr.nv0, vb_c = cr.vb0, nxt_c = cr.nxt0;
@@ -1463,6 +1480,21 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     __syncthreads();
     __threadfence();
     HP_LONG(6);
+    if (phase == 3) {  // totals of all workgroups of the allele; the one that arrives last goes on
+      if (tid == 0) {
+        atomicAdd(hdr + 0, (uint32_t)tot[0]); atomicAdd(hdr + 1, (uint32_t)tot[1]);
+        __threadfence();
+        l_last = atomicAdd(hdr + 2, 1u) == (uint32_t)(G - 1) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!l_last) continue;
+      __threadfence();
+      if (tid == 0) {
+        tot[0] = (int)__hip_atomic_load(hdr + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot[1] = (int)__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[2] = (int)__builtin_nontemporal_load(g_tail); tot[3] = (int)__builtin_nontemporal_load(g_tail + 1);
+      }
+      __syncthreads();
+    }
     // ---- the end of the walk (the start state closes the path), then as in hmm_viterbi_kernel: path order, purity, the visits
     int np = tot[2];
     if (tid == 0 && pbuf && np < pcap) pbuf[pcap - 1 - np] = 0;
@@ -2185,9 +2217,11 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     if (d_long_cls) {
       const size_t llds = hmm_long_lds_bytes(maxS, maxnb);
       if (llds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_traceback_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-      hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,
-                         (const uint8_t*)d_model, d_seq, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
-                         o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls);
+      const int G = c->knobs.hmm_long_wgs;  // workgroups per long allele (1: one launch, the whole trace-back by one workgroup)
+      for (int ph = G > 1 ? 1 : 0; ph <= (G > 1 ? 3 : 0); ++ph)
+        hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u) * (unsigned)(ph == 1 || ph == 3 ? G : 1)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,
+                           (const uint8_t*)d_model, d_seq, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
+                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph, ph == 1 || ph == 3 ? G : 1);
       TRGT_HIP_TRY(c, hipGetLastError());
     }
     t.stop(i == 0 ? cells : 0);
@@ -2381,9 +2415,11 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     if (d_long_cls) {
       const size_t llds = hmm_long_lds_bytes(maxS, maxnb);
       if (llds > 64 * 1024) TRGT_HIP_TRY(c, hipFuncSetAttribute((const void*)hmm_traceback_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-      hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets,
-                         (const uint8_t*)mp->d_blob, in.seq_blob_dev, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
-                         o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls);
+      const int G = c->knobs.hmm_long_wgs;
+      for (int ph = G > 1 ? 1 : 0; ph <= (G > 1 ? 3 : 0); ++ph)
+        hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u) * (unsigned)(ph == 1 || ph == 3 ? G : 1)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets,
+                           (const uint8_t*)mp->d_blob, in.seq_blob_dev, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
+                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph, ph == 1 || ph == 3 ? G : 1);
       TRGT_HIP_TRY(c, hipGetLastError());
     }
     t.stop(0);
