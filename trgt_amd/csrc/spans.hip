@@ -805,7 +805,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if ((rc = flank_filter_launch(c, FL))) return rc;
       tl_mark(c, "filter launched");
       LH.jobs_dev = (const JobDev*)d_keepjobs; LH.n_jobs_dev = (const uint32_t*)d_count + SC_KEEP;
-      heavy_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt;
+      heavy_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt && !c->knobs.wfa_no_stage;  // (the banded launch exists as the LDS kernel of TRGT's configuration only)
     }
     if (heavy_band) {  // (see BandArgs) the kept alignments inside their band, one wave each; then whatever is left over the whole read
       void *d_band = nullptr, *d_hrest = nullptr, *d_bscore = nullptr;
@@ -923,7 +923,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         lw.jobs = long_in; lw.n_jobs = (const uint32_t*)d_count + long_in_count; 
         lw.sub = (JobDev*)d_sub; lw.parent = (uint32_t*)d_parent; lw.sub_keep = (uint8_t*)d_subkeep; lw.n_sub = (uint32_t*)d_lwc; lw.cap = (uint32_t)cap;
         lw.job_keep = (uint8_t*)d_jobkeep; lw.kept = (JobDev*)d_kept; lw.n_kept = (uint32_t*)d_lwc + 1; lw.wl = (int32_t)wl; lw.step = (int32_t)step;
-        const bool long_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt && max_read_len < 0xF000u;
+        const bool long_band = c->knobs.heavy_band > 0 && p.mism == 2 && p.gapo == 5 && p.gape == 1 && !c->knobs.no_spec && !c->knobs.skip_bt && !c->knobs.wfa_no_stage && max_read_len < 0xF000u;
         void *d_sband = nullptr, *d_jbest = nullptr, *d_jrej = nullptr;
         if (long_band && ((rc = dev_get(c, S_LW_SUBBAND, cap * 4, &d_sband)) || (rc = dev_get(c, S_LW_JOBBEST, n_jobs * 4, &d_jbest)) || (rc = dev_get(c, S_LW_JOBREJ, n_jobs * 4, &d_jrej)))) return rc;
         lw.sub_band = (const uint32_t*)d_sband; lw.job_best = (uint32_t*)d_jbest; lw.job_rej = (uint32_t*)d_jrej;
