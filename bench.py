@@ -176,6 +176,7 @@ def parse_args():
     ap.add_argument("--e2e-read-len", type=int, default=6000)
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of each of the config 3 / 4 / 5 legs")
     ap.add_argument("--ws-limit-gb", type=float, default=0.0, help="workspace limit per context in GB (trgt_hip_set_workspace_limit; 0 = by config: the library's 32 GB, 8 GB for config 3)")
+    ap.add_argument("--detail", default="", help="where the full record goes (default: bench_detail.json next to bench.py, and gpurun_out/ when it exists); stdout carries the compact contract line only")
     ap.add_argument("--contexts", type=int, default=0, help="contexts per GPU (trgt_hip_pool / trgt_locus_batch_many): worker threads, one context each, draining the queue of steps, so that the tail of one step (results back, host-path loci, HMM) overlaps the flank location of the next ones; 0 = by config (4; 6 for configs 3 and 5); 1 = the blocking call only")
     return ap.parse_args()
 
@@ -227,10 +228,101 @@ def main():
     if world == 1 and not args.no_e2e and args.config == 0:
         res["e2e"] = run_e2e(args, env)
     if rank == 0:
-        print(json.dumps(res))
+        # The full record (per-config detail, prose, every side figure) goes to a side file; stdout carries ONE compact contract line
+        # (the single line had grown past what the driver keeps, and the round went unparsed).
+        detail_path = write_detail(res, args.detail)
+        line = compact_line(res, detail_path)
+        print(line)
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 4096   # bytes of the one stdout line (tests/test_bench_line.py)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_at_reference_work", "bound_measured", "valu_issue_frac",
+                 "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "dp_cells_per_launch")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+CONFIG_KEYS = ("workload", "baseline_config", "value_streaming", "value_streaming_bam4", "value_single_context", "ms_per_step_single_context",
+               "contexts_per_gpu", "loci_per_gpu", "reads_per_locus", "parallelism", "host_cpu_quota")
+E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "write_loci_per_s", "pipeline_loci_per_s",
+            "pipeline_loci_per_s_bam_level_1", "pipeline_vcf_identical")
+
+
+def _short(s, n):
+    return s if len(s) <= n else s[:n - 1].rstrip() + "~"
+
+
+def compact_line(res, detail_path=None):
+    """The contract line: the keys the driver reads plus `roofline`, `cpu_baseline`, `parity`, one row per extra config and the
+    end-to-end rates -- numbers and short labels only, guaranteed below LINE_LIMIT bytes (fields are dropped from the least important
+    end if a future addition overshoots).  Pure function of the full record: tests/test_bench_line.py drives it without a GPU."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "data"))
+    out["vs_baseline"] = res.get("vs_baseline")
+    out["dtype"] = "u8/u16 (WFA) + f64 (HMM)"
+    cfg = _pick(res.get("config", {}), CONFIG_KEYS)
+    if "workload" in cfg:
+        cfg["workload"] = _short(cfg["workload"], 200)
+    out["config"] = cfg
+    roof = _pick(res.get("roofline", {}), ROOFLINE_KEYS)
+    out["roofline"] = roof
+    if res.get("cpu_baseline"):
+        cb = _pick(res["cpu_baseline"], CPU_KEYS)
+        cb["sample"] = _short(cb.get("sample", ""), 120)
+        out["cpu_baseline"] = cb
+    if res.get("cpu_baseline_all_cores"):
+        out["cpu_baseline_all_cores"] = _pick(res["cpu_baseline_all_cores"], ("value", "cores", "cpu_quota"))
+    if res.get("parity"):
+        out["parity"] = _pick(res["parity"], ("parity_checked_loci", "mismatches"))
+    if res.get("multi_gpu_digest_check"):
+        out["multi_gpu_digest_check"] = res["multi_gpu_digest_check"]
+    legs = {}
+    for k, r in (res.get("configs") or {}).items():
+        if not r:
+            continue
+        leg = _pick(r, ("value", "ms_per_step"))
+        leg.update(_pick(r.get("config", {}), ("value_single_context", "ms_per_step_single_context", "loci_per_gpu")))
+        leg["roofline"] = _pick(r.get("roofline", {}), ("kernel", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "bound_measured"))
+        leg["cpu_baseline"] = (r.get("cpu_baseline") or {}).get("value")
+        leg["parity"] = _pick(r.get("parity", {}), ("parity_checked_loci", "mismatches"))
+        legs[k] = leg
+    if legs:
+        out["configs"] = legs
+    if res.get("e2e"):
+        out["e2e"] = _pick(res["e2e"], E2E_KEYS)
+    if detail_path:
+        out["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("detail", "e2e", "cpu_baseline_all_cores", "configs"):  # never reached today; the contract keys are never dropped
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(res, path=None):
+    """The whole record, pretty-printed, next to bench.py (bench_detail.json; also under gpurun_out/ when that exists, so that a
+    gpurun call brings it back).  Returns the path written, or None when the directory is read-only."""
+    path = path or os.path.join(ROOT, "bench_detail.json")
+    written = None
+    for p in (path, os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(p)):
+                with open(p, "w") as f:
+                    json.dump(res, f, indent=1)
+                    f.write("\n")
+                written = written or p
+        except OSError:
+            pass
+    return written
 
 
 def run_e2e(args, env):
