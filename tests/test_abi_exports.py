@@ -61,3 +61,11 @@ def test_entry_scripts_compile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in ("bench.py", "__graft_entry__.py"):
         py_compile.compile(os.path.join(root, f), doraise=True)
+
+
+def test_release_library_has_no_result_changing_switch():
+    """the switches that change results (TRGT_SENS_*, TRGT_DBG_SKIP_BT) are compiled in only by `make DEV=1`
+    (libtrgt_hip_dev.so); the library the tests, the bench and a user load must not even contain their names."""
+    blob = open(os.path.join(ROOT, "trgt_amd", "libtrgt_hip.so"), "rb").read()
+    assert b"TRGT_SENS_" not in blob and b"TRGT_DBG_SKIP_BT" not in blob
+    assert b"TRGT_WFA_NO_FILTER" in blob   # (the planner knobs, which change no result, are there)

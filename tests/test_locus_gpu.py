@@ -301,6 +301,28 @@ def test_cluster_genotyper_shapes(oracle, mods):
     assert [len(a.seq) for a in res[2].genotype] == [27, 36]
 
 
+def test_cluster_empty_segment_against_segments_beyond_10kb(oracle, mods):
+    # |a| * |b| <= MAX_OPS holds for an EMPTY repeat segment against one of any length, so the edit-distance launch of the
+    # device chain sees (0, > 10 kb) pairs: its workspace must be planned for them (the rings were sized for 10 kb + 1)
+    locus, _ = mods
+    rng = np.random.default_rng(5)
+    dna = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    lf, rf = dna(250), dna(250)
+    mk = lambda rep: dna(260) + lf + rep + rf + dna(260)
+    noisy = lambda rep: bytes(int(rng.choice(list(b"ACGT"))) if rng.random() < 0.002 else c for c in rep)
+    long_rep = b"CAG" * 3600   # 10 800 bases
+    base = dict(left_flank=lf, right_flank=rf, motifs=[b"CAG"], genotyper="cluster", tr=b"CAG" * 8)
+    loci = [
+        dict(base, reads=[mk(b"") for _ in range(4)] + [mk(noisy(long_rep)) for _ in range(4)]),
+        dict(base, reads=[mk(b"") for _ in range(3)] + [mk(noisy(long_rep[:10200])) for _ in range(3)] + [mk(b"CAG" * 9) for _ in range(3)]),
+    ]
+    b = locus.pack(loci)
+    for mode, out in _run_both(locus, b):
+        _compare(oracle, locus, b, out, locus.Params(), range(len(loci)))
+        if mode in ("host reads", "device"):
+            assert int(out.stats[22]) == len(loci), (mode, out.stats[22:24])
+
+
 def test_cluster_genotyper_deep_loci_and_downsampling(oracle, mods):
     # more than 64 reads per locus: the large instantiations of the device chain (distance matrix in HBM); more reads than max_depth:
     # the uniform downsample in front of the pair list; a locus beyond 256 reads takes the host path

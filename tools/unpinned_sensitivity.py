@@ -3,7 +3,7 @@
 
 The WFA arithmetic of the reference lives in WFA2-lib and its Ward linkage in kodama -- both un-vendored, so the oracle and the product
 restate them from their published definitions.  Inside those restatements a few choices are recalled rather than verified.  This tool
-re-runs synthetic catalogs of configs 2 / 4 / 5 through trgt_locus_batch with each choice flipped (developer switches TRGT_SENS_*, read
+re-runs synthetic catalogs of configs 2 / 4 / 5 through trgt_locus_batch with each choice flipped (developer switches TRGT_SENS_* of the `make DEV=1` library, read
 when a context is created) and reports the fraction of loci whose alleles / read assignment / VCF fields change against the default run:
 
   bialign_min_length 0     WF_BIALIGN_FALLBACK_MIN_LENGTH read as 0 (SURVEY A.7 literally) instead of 100: short sequences go through the
@@ -21,9 +21,16 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the switches exist only in the developer build (make DEV=1 -> trgt_amd/libtrgt_hip_dev.so): use it, building it when it is missing
+# (hipcc cross-compiles; on the GPU box the prebuilt file travels with the snapshot)
+_DEV_SO = os.path.join(ROOT, "trgt_amd", "libtrgt_hip_dev.so")
+os.environ.setdefault("TRGT_HIP_LIB", _DEV_SO)
 import torch
 from trgt_amd import locus, synth, _lib
+if not os.path.exists(_DEV_SO):
+    _lib.build_extension(dev=True)
 
 VARIANTS = [
     ("bialign_min_length 0", dict(TRGT_SENS_BIALIGN_MIN_LEN=0)),

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libtrgt_hip.so")
+# (TRGT_HIP_LIB: another build of the same library, e.g. the developer build `make -C trgt_amd/csrc DEV=1` -> libtrgt_hip_dev.so)
+_SO = os.environ.get("TRGT_HIP_LIB") or os.path.join(_HERE, "libtrgt_hip.so")
 _LIB = None
 _CTX = {}
 
@@ -83,15 +84,16 @@ EXPORTS = [
 ]
 
 
-def build_extension(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 into trgt_amd/libtrgt_hip.so (hipcc cross-compiles on CPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["-B"] if force else [])
+def build_extension(force=False, verbose=False, dev=False):
+    """Compile every HIP translation unit for gfx950 into trgt_amd/libtrgt_hip.so (hipcc cross-compiles on CPU).  dev=True: the
+    developer library trgt_amd/libtrgt_hip_dev.so (make DEV=1: result-changing switches compiled in), returned instead."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["-B"] if force else []) + (["DEV=1"] if dev else [])
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
     if out.returncode != 0:
         raise TrgtHipError("building libtrgt_hip.so failed")
-    return _SO
+    return os.path.join(_HERE, "libtrgt_hip_dev.so") if dev else _SO
 
 
 def lib():

@@ -16,9 +16,11 @@
 
 #include "../../include/trgt_hip.h"
 
-// Planner knobs: none of them changes a result.  They are read from the environment ONCE, when the context is created
-// (trgt_hip_create), so that the parity tests can pin every planner path against the oracle; a release build carries no switch
-// that skips work (TRGT_DBG_SKIP_BT exists only under `make DEV=1`).
+// Planner knobs.  In a release build none of them changes a result: they are read from the environment ONCE, when the context is
+// created (trgt_hip_create), so that the parity tests can pin every planner path against the oracle.  The switches that DO change
+// results -- TRGT_SENS_* (the un-pinned choices flipped, tools/unpinned_sensitivity.py) and TRGT_DBG_SKIP_BT -- are read only under
+// `make DEV=1` (TRGT_DEV_BUILD); in the default build their fields keep the defaults below and the names are not in the binary
+// (tests/test_abi_exports.py checks).
 struct trgt_knobs {
   int flank_threads = 256;   // TRGT_FLANK_THREADS: threads per flank alignment of the back-tracing kernel
   int heavy_band = 96;       // TRGT_HEAVY_BAND: the back-trace of what the pre-filter keeps runs inside the band its penalty allows when that is at most this (0: off)
@@ -55,7 +57,7 @@ struct trgt_knobs {
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency
   int lds_wfa_kb = 7;        // TRGT_WFA_LDS_KB: LDS of the LDS-arena variant for the wavefronts of one alignment
   int lds_wfa_seq = 768;     // TRGT_WFA_LDS_SEQ: ... for its two sequences (padded pattern + text)
-  // tools/unpinned_sensitivity.py: the decisions inside un-vendored dependencies that no reference test pins, flipped one at a time
+  // tools/unpinned_sensitivity.py (make DEV=1 only): the decisions inside un-vendored dependencies that no reference test pins, flipped one at a time
   int sens_bialign_min_len = -1;  // TRGT_SENS_BIALIGN_MIN_LEN: bialign_min_length of the consensus alignments / edit distances (default 100; SURVEY A.7 read literally: 0)
   bool sens_cons_unidir = false;  // TRGT_SENS_CONS_UNIDIR: consensus alignments back-traced unidirectionally (MemoryHigh) instead of by BiWFA
   bool sens_ward_ties = false;    // TRGT_SENS_WARD_TIES: nearest-neighbour ties of the Ward linkage go to the LAST candidate instead of the first

@@ -959,7 +959,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       auto ed_launch = [&](const JobDev* jobs, uint64_t bound, const uint32_t* count, const uint8_t* txt_base, int32_t* score) -> int {
         WfaLaunch LE;
         LE.jobs_dev = jobs; LE.n_jobs_host = std::min<int64_t>((int64_t)std::max<uint64_t>(bound, 1), wg_bound); LE.n_jobs_dev = count; LE.jobs_bound = (int64_t)std::max<uint64_t>(bound, 1);
-        LE.pat_base = d_reads; LE.txt_base = txt_base; LE.max_plen = ed_len; LE.max_tlen = ed_len; LE.max_sum = std::min<int64_t>(2 * ed_len, (int64_t)cl::CL_MAX_OPS + 1);
+        // (a pair is aligned when li * lj <= MAX_OPS: an EMPTY segment pairs with one of any length -- gt_front keeps zero-length repeat
+        //  segments -- so either side reaches max_seg; with both non-empty the sum stays within MAX_OPS + 1.  ADVICE r4: sized by ed_len alone
+        //  the generic kernel's rings were too short for (0, > 10 kb) pairs)
+        LE.pat_base = d_reads; LE.txt_base = txt_base; LE.max_plen = (int64_t)max_seg; LE.max_tlen = (int64_t)max_seg;
+        LE.max_sum = std::max<int64_t>((int64_t)max_seg, std::min<int64_t>(2 * ed_len, (int64_t)cl::CL_MAX_OPS + 1));
         LE.score = score; LE.buffer_set = 2; LE.ws_budget = 512ull << 20;
         return wfa_launch(c, wed, LE);
       };

@@ -350,6 +350,19 @@ __device__ __forceinline__ void wfa_kernel_body(const KArgs& a) {
     const int plen = (int)job.pat_len, tlen = (int)job.txt_len;
     const uint8_t* P = a.pat_base + job.pat_off;
     const uint8_t* Tx = a.txt_base + job.txt_off;
+    // The workspace is planned from the batch maxima the caller states (rings of ring_stride = max_sum + 4 offsets): a job beyond them
+    // would write past its workgroup's slice.  Refuse it loudly (TRGT_WF_OOM, outputs cleared) instead of trusting device-built lists.
+    if ((uint32_t)plen + (uint32_t)tlen + 4u > a.ring_stride) {
+      if (tid == 0) {
+        const uint32_t o = job.out_index;
+        if (a.status) a.status[o] = TRGT_WF_OOM;
+        if (a.score) a.score[o] = INT32_MIN;
+        if (a.n_match) a.n_match[o] = 0;
+        if (a.cigar_len) a.cigar_len[o] = 0;
+        if (a.ops_len) a.ops_len[o] = 0;
+      }
+      continue;
+    }
     // ---- Identical sequences (end-to-end): a read of an allele against the central read / the consensus of its cluster, most of the
     //      time.  The result needs no alignment: one run of matches, penalty 0 -- what the code below returns for such a pair after a
     //      forward extension over the whole length, a base alignment and its back-trace (BiWFA: the breakpoint search ends with "end
