@@ -65,6 +65,7 @@ struct trgt_knobs {
   bool hmm_no_dedupe = false;   // TRGT_HMM_NO_DEDUPE: the second allele of a homozygous locus is labelled by an HMM job of its own (as the reference does) instead of taking the first one's results
   bool hmm_no_long_tb = false;  // TRGT_HMM_NO_LONG_TB: alleles of 1 536 columns and more are traced back by the fill kernel's one lane too (not by hmm_traceback_long_kernel)
   int hmm_long_wgs = 4;  // TRGT_HMM_LONG_WGS: workgroups per long allele in the chunk-map and re-walk passes of the long trace-back (1: one workgroup does everything in one launch)
+  bool hmm_no_ppl = false;  // TRGT_HMM_NO_PPL: no position-per-lane fill (hmm_ppl.hpp) in front of the HMM kernels: every set is filled by hmm_viterbi_kernel with one lane per state, as in round 4
   bool hmm_four_rounds = false;  // TRGT_HMM_FOUR_ROUNDS: the register fill fetches across lanes once per pass of a column (four rounds) instead of twice per column
   bool hmm_lds_fill = false;  // TRGT_HMM_LDS_FILL: one-wave motif sets fill their Viterbi columns through LDS like the larger ones (not in registers)
   int cluster_arena_kb = 0;  // TRGT_CLUSTER_ARENA_KB: developer switch -- the CIGAR / result / scratch arenas of the device-side cluster genotyper capped at this many KB (loci that find no room take the host path: the mixed case of the tests)

@@ -97,7 +97,8 @@ static uint64_t layout_set(const uint32_t* mlen, uint32_t n_motifs, HmmSetDev& d
     }
     n_lanes = (uint32_t)perm.size();
   }
-  d.S = S; d.n_blocks = nb; d.chain_rounds = chain_rounds; d.max_mlen = max_mlen; d.n_lanes = n_lanes; d.pad_ = 0;
+  d.S = S; d.n_blocks = nb; d.chain_rounds = chain_rounds; d.max_mlen = max_mlen; d.n_lanes = n_lanes;
+  d.ppl_lanes = mbytes + 1 <= 64 ? mbytes + 1 : 0;  // (mbytes = the motif lengths summed up: one lane per motif position, one for the skip block)
   uint64_t o = 0;  // offsets relative to this set's blob; the caller rebases them
   d.off_inlp = o; o += 8ull * 4 * S;
   d.off_em = o; o += 8ull * 5 * S;
@@ -436,7 +437,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   extern __shared__ __align__(16) unsigned char lds_all[];
   if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
   const bool four_rounds = (lds_per_job >> 31) != 0u;  // (TRGT_HMM_FOUR_ROUNDS, see the register fill)
-  lds_per_job &= 0x7FFFFFFFu;
+  const bool ppl_filled = ((lds_per_job >> 30) & 1u) != 0u;  // the back-pointers of sets with ppl_lanes are there already (hmm_fill_ppl_kernel ran in front)
+  lds_per_job &= 0x3FFFFFFFu;
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
   const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
@@ -595,6 +597,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* cur = sc1;
   HP_FILL_DECL;
   int sym_next = 0;
+  if (!(ppl_filled && set.ppl_lanes != 0u)) {
   if constexpr (ONE_WAVE) {
     const int hw = (int)(threadIdx.x & 63u), lane_base = hw & ~(SUB - 1);
     const int a_q0 = (lane_base + q0) << 2, a_q1 = (lane_base + q1) << 2, a_q2 = (lane_base + q2) << 2, a_q3 = (lane_base + q3) << 2, a_st0 = lane_base << 2;
@@ -1043,6 +1046,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     double* t = prev; prev = cur; cur = t;
     HP_FILL(5);
   }
+  }  // (fill)
   HP_FILL_END;
   HP_MARK(1);
   // long alleles are traced back by hmm_traceback_long_kernel (many waves per allele, behind this launch on the same stream)
@@ -1227,6 +1231,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   for (int m = tid; m < n_motifs; m += nthr) counts[job.count_off + m] = l_cnt[m];
   HP_MARK(3);
 }
+
+#include "hmm_ppl.hpp"
 
 // ---- trace-back of LONG alleles on many waves (DESIGN_HISTORY 7.3: "block-wise composed trace-back").  The chase of the back-pointers
 // is a serial chain of dependent look-ups -- a third of a long allele's time on one lane.  Here the columns are cut into chunks of
@@ -1808,6 +1814,18 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
 }
 
 
+// The position-per-lane fill (hmm_ppl.hpp) of one class's job list, in front of the class's trace-back launch on the same stream: one
+// launch per group width the class's sets need (lanes_mask: bit 0 = 8 lanes, 1 = 16, 2 = 32, 3 = 64); a launch walks the whole list
+// and takes the jobs of its width (groups of other widths idle: a wave without a job of its own returns at once).
+static void hmm_launch_ppl(hipStream_t ls, unsigned lanes_mask, const HmmJobDev* d_jobs, const HmmSetDev* d_sets, const uint8_t* d_model, const uint8_t* d_seq,
+                           uint8_t* d_bp, uint32_t nj, const uint32_t* n_jobs_dev) {
+  if (lanes_mask & 1u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+  if (lanes_mask & 2u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+  if (lanes_mask & 4u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+  if (lanes_mask & 8u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+}
+static inline unsigned hmm_ppl_bit(const HmmSetDev& sd) { const int g = ppl::lanes_for(sd.ppl_lanes); return g == 8 ? 1u : g == 16 ? 2u : g == 32 ? 4u : g == 64 ? 8u : 0u; }
+
 // All motif-set models of a batch (host side).  Thread-safe: touches no ctx state.
 int hmm_build_models(int32_t n_sets, const uint8_t* motif_blob, const uint32_t* motif_off, const uint32_t* set_motif_begin, HmmModels& out) {
   char msg[160];
@@ -2065,7 +2083,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     jd.path_off = path ? path_off[j] : 0;
     jd.path_cap = (uint32_t)std::min<uint64_t>(trgt_hmm_path_capacity(seq_len[j], sd.max_mlen), 0xFFFFFFFFull);
     const uint64_t spad = (sd.S + 15) & ~15u;
-    jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)seq_len[j] + 2), 16);
+    jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)seq_len[j] + 2), 16);  // (16 bytes in front of the rows: where the position-per-lane fill sends the stores of roles a lane does not have)
     jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
     { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, seq_len[j]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
@@ -2173,9 +2191,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const uint32_t jc = job_class(jobs[i]), cls = jc;
     size_t e = i;
     uint32_t maxS = 0, maxnb = 0, maxq = 0;
+    unsigned ppl_mask = 0;
     while (e < jobs.size() && job_class(jobs[e]) == jc) {
-      maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); maxq = std::max(maxq, jobs[e].seq_len); ++e;
+      maxS = std::max(maxS, sets[jobs[e].set].S); maxnb = std::max(maxnb, sets[jobs[e].set].n_blocks); maxq = std::max(maxq, jobs[e].seq_len);
+      ppl_mask |= hmm_ppl_bit(sets[jobs[e].set]); ++e;
     }
+    if (c->knobs.hmm_no_ppl) ppl_mask = 0;
     const bool half = cls == 0;  // two alleles per wave
     const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
@@ -2200,7 +2221,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u), (const uint32_t*)nullptr, d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u), (const uint32_t*)nullptr, d_long_cls)
     // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
     uint32_t* d_long_cls = nullptr;
     if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)HMM_LONG_MIN) {
@@ -2209,6 +2230,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
       d_long_cls = (uint32_t*)dl + (size_t)n_class * 0 + (i + 8 * (size_t)(n_class - 1));  // [count | job indices] of this class
       TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
     }
+    if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, nj, nullptr);
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && cls == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
@@ -2297,7 +2319,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
         const int64_t sl = 2 * l + a;
         jd.set = (uint32_t)l; jd.seq_len = 0; jd.job_index = (uint32_t)sl; jd.path_cap = 0;
         jd.seq_off = in.seq_off[sl]; jd.path_off = 0; jd.span_off = span_off[sl]; jd.count_off = count_off[sl];
-        jd.bp_off = bp_total; bp_total += align_up(spad * ((uint64_t)in.cap[l] + 2), 16);  // room for the longest allele the locus can have
+        jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)in.cap[l] + 2), 16);  // room for the longest allele the locus can have (+ the dump slot of hmm_fill_ppl_kernel)
         jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)in.cap[l] + 2);
         { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, in.cap[l]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
       }
@@ -2372,7 +2394,9 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   for (uint32_t k = 0; k < 8; ++k) {
     if (!class_n[k]) continue;
     uint32_t maxS = 0, maxnb = 0;
-    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) { const HmmSetDev& sd = sets[cand[i].set]; maxS = std::max(maxS, sd.S); maxnb = std::max(maxnb, sd.n_blocks); }
+    unsigned ppl_mask = 0;
+    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) { const HmmSetDev& sd = sets[cand[i].set]; maxS = std::max(maxS, sd.S); maxnb = std::max(maxnb, sd.n_blocks); ppl_mask |= hmm_ppl_bit(sd); }
+    if (c->knobs.hmm_no_ppl) ppl_mask = 0;
     const bool half = k == 0;
     const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
@@ -2397,7 +2421,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u), (const uint32_t*)(d_count + k), d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u), (const uint32_t*)(d_count + k), d_long_cls)
     uint32_t* d_long_cls = nullptr;
     uint32_t max_cap_cls = 0;
     for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
@@ -2407,6 +2431,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       d_long_cls = (uint32_t*)dl + class_begin[k] + 8 * k;  // [count | job indices] of this class
       TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
     }
+    if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, nj, (const uint32_t*)(d_count + k));
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && k == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);

@@ -19,7 +19,8 @@ struct HmmSetDev {  // device-visible descriptor of one motif set (one locus)
   uint64_t off_blocks;  // u32 [4][n_blocks]  start,end,mlen,motif byte offset
   uint64_t off_motifs;  // sanitised motif bytes
   uint64_t off_perm;    // u16 [n_lanes] lane -> state (0xFFFF: idle lane); only when n_lanes != 0
-  uint32_t n_lanes, pad_;  // lanes of a workgroup when the states are not in lane order (models of more than one wave), else 0
+  uint32_t n_lanes;     // lanes of a workgroup when the states are not in lane order (models of more than one wave), else 0
+  uint32_t ppl_lanes;   // motif positions + 1 (the skip block's) when they fit one wave: the set's Viterbi fill runs with one lane per position (hmm_ppl.hpp); else 0
 };
 
 struct HmmModels {

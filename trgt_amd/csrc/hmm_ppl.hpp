@@ -1,0 +1,243 @@
+// trgt_amd/csrc/hmm_ppl.hpp -- the Viterbi FILL of the motif HMM with one lane per MOTIF POSITION (round 5), included by hmm.hip.
+//
+// Replaces the fill part of Hmm::label (hmm_model.rs:54-114: generate_mats / calc_viterbi_score) for motif sets whose positions fit
+// one wave; the back-pointers it writes (1 B per (column, state), the layout of hmm_viterbi_kernel) are traced back by the kernels
+// that were there before (hmm_viterbi_kernel with its fill skipped, hmm_traceback_long_kernel).
+//
+// Why another layout.  With one lane per STATE (hmm_viterbi_kernel) a column costs the wave ~20 ds_bpermute_b32 -- every state fetches
+// its predecessors from arbitrary lanes -- and a single STR motif (17-26 states) leaves most of the wave idle: two alleles per wave at
+// best.  The model is regular (builder.rs:80-173): position k of a motif block owns a match, an insertion and a deletion state, and
+//   m_k <- {m_(k-1), block start, i_(k-1), d_(k-2)}     i_k <- {i_k, m_k}     d_k <- {m_k, d_(k-1)}     block end <- {m_(n-1), i_(n-1), d_(n-2)}
+// so with lane = position (the three states of a position in ONE lane, the block end in the last position's deletion slot, the skip
+// block as one more position) every predecessor is in the lane itself or the lane before it: DPP wave_shr:1 moves, no crossbar.  The
+// run end is a butterfly maximum over the lanes of the job (DPP quad_perm / row_mirror), the only crossbar fetch left per column is
+// the own block's end.  A job takes G = 8 / 16 / 32 / 64 lanes (positions + 1 <= G), so a wave fills 8 alleles of a 3- to 7-base
+// motif side by side.  Every f64 sum is formed as the reference forms it -- (score + ln p) + emission -- candidates are compared in
+// predecessor-list order with strict '>', and the transition / emission terms are read from the same tables (host libm logarithms).
+#pragma once
+
+namespace ppl {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const int lo = (int)(u & 0xFFFFFFFFull), hi = (int)(u >> 32);
+  const int slo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  const int shi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
+}
+
+// maximum over the G lanes of a job (G a power of two, jobs aligned to G): xor-1, xor-2 inside a quad, mirror inside 8 and 16 lanes by
+// DPP; the last one or two steps of jobs of 32 / 64 lanes through the crossbar
+template <int G>
+__device__ __forceinline__ double group_max(double v, int lane) {
+  v = max_f64(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = max_f64(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = max_f64(v, dpp_f64<0x141>(v));   // row_half_mirror
+  if (G >= 16) v = max_f64(v, dpp_f64<0x140>(v));  // row_mirror
+  if (G >= 32) v = max_f64(v, bperm_f64((lane ^ 16) << 2, v));
+  if (G >= 64) v = max_f64(v, bperm_f64((lane ^ 32) << 2, v));
+  return v;
+}
+
+// ... and the minimum of a small integer over the same lanes
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+template <int G>
+__device__ __forceinline__ int group_min_i32(int v, int lane) {
+  v = min(v, dpp_i32<0xB1>(v));
+  v = min(v, dpp_i32<0x4E>(v));
+  v = min(v, dpp_i32<0x141>(v));
+  if (G >= 16) v = min(v, dpp_i32<0x140>(v));
+  if (G >= 32) v = min(v, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, v));
+  if (G >= 64) v = min(v, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v));
+  return v;
+}
+
+__host__ __device__ inline int lanes_for(uint32_t positions) { return positions == 0 || positions > 64 ? 0 : positions <= 8 ? 8 : positions <= 16 ? 16 : positions <= 32 ? 32 : 64; }
+
+constexpr int CODE_WIN = 256;   // columns of symbol codes per window (+ 2 look-ahead)
+constexpr int CODE_ROW = 272;
+
+template <int G>
+__global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
+                                                          const uint8_t* __restrict__ seq_blob, uint8_t* __restrict__ bp_ws, uint32_t n_launch_jobs,
+                                                          const uint32_t* __restrict__ n_jobs_dev) {
+  constexpr int JPW = 64 / G;
+  __shared__ double l_em[64 * 10];            // per lane: emission terms of its match state [5], of its insertion state [5]
+  __shared__ uint8_t l_code[JPW][CODE_ROW];   // per job: window of symbol codes
+  const int lane = (int)threadIdx.x, grp = lane / G, pos = lane % G, lane_base = grp * G;
+  if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;
+  const uint32_t jidx = blockIdx.x * (uint32_t)JPW + (uint32_t)grp;
+  const double NINF = -__builtin_huge_val();
+  bool has = jidx < n_launch_jobs;
+  HmmJobDev job{}; HmmSetDev set{};
+  job.bp_off = 16; set.S = 8; set.n_blocks = 1;
+  if (has) {
+    job = jobs[jidx];
+    set = sets[job.set];
+    has = lanes_for(set.ppl_lanes) == G && job.seq_len > 0;
+  }
+  if (!__any(has)) return;
+  const int S = (int)set.S, nb = (int)set.n_blocks, Spad = (S + 15) & ~15;
+  const int Lj = has ? (int)job.seq_len + 2 : 0;
+  const double* __restrict__ g_inlp = reinterpret_cast<const double*>(model + set.off_inlp);
+  const double* __restrict__ g_em = reinterpret_cast<const double*>(model + set.off_em);
+  const uint32_t* __restrict__ g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
+  // ---- my position: block b, position k of its n; the skip block is one position behind the motifs'
+  int kind = 0, k = 0, n = 0, ms_st = 0, end_pos = 0;
+  unsigned long long ends_mask = 0ull;  // positions (relative to the job) that hold a block end, in block order
+  if (has) {
+    int acc = 0;
+    for (int b = 0; b + 1 < nb; ++b) {
+      const int ml = (int)g_blocks[2 * nb + b];
+      if (pos >= acc && pos < acc + ml) { kind = 1; k = pos - acc; n = ml; ms_st = (int)g_blocks[0 * nb + b]; end_pos = acc + ml - 1; }
+      acc += ml;
+      ends_mask |= 1ull << (acc - 1);
+    }
+    if (pos == acc) { kind = 2; k = 0; n = 1; ms_st = (int)g_blocks[0 * nb + nb - 1]; end_pos = acc; }
+    ends_mask |= 1ull << acc;
+  }
+  const bool is_pos = kind == 1, is_skip = kind == 2, is_end = (is_pos && k == n - 1) || is_skip;
+  const int st_m = ms_st + 1 + k, st_i = st_m + n, st_d = is_skip ? ms_st + 2 : st_m + 2 * n;
+  auto LP = [&](int slot, int st) -> double { return g_inlp[(size_t)slot * S + st]; };
+  // match state (skip lane: the skip state, its self loop in the insertion slot C with its own score as the source)
+  double lpA = NINF, lpB = NINF, lpC = NINF, lpD = NINF, lpI0 = NINF, lpI1 = NINF, lpO0 = NINF, lpO1 = NINF, lp_step = NINF, lpS0 = NINF, lpS1 = NINF;
+  int adj = 0, chain_slot = 1;
+  if (is_pos) {
+    if (k == 0) { lpB = LP(0, st_m); adj = 1; }
+    else { lpA = LP(0, st_m); lpB = LP(1, st_m); lpC = LP(2, st_m); if (k >= 2) lpD = LP(3, st_m); }
+    lpI0 = LP(0, st_i); lpI1 = LP(1, st_i);
+    if (k < n - 1) { lpO0 = LP(0, st_d); if (k >= 1) { lp_step = LP(1, st_d); chain_slot = 1; } }
+    else { lpO0 = LP(0, st_d); lpO1 = LP(1, st_d); if (n > 1) { lp_step = LP(2, st_d); chain_slot = 2; } }
+    lpS0 = LP(0, ms_st); lpS1 = LP(1, ms_st);
+  } else if (is_skip) {
+    lpB = LP(0, st_m); lpC = LP(1, st_m); adj = 1;
+    lpO0 = LP(0, st_d);
+    lpS0 = LP(0, ms_st); lpS1 = LP(1, ms_st);
+  }
+  const double lp_re = has ? LP(0, S - 2) : NINF, lp_rs0 = has ? LP(0, 1) : NINF, lp_rs1 = has ? LP(1, 1) : NINF;
+  const double em_start0 = has ? g_em[0] : NINF;                                  // the start state's term for '#'
+  // emission tables of my two emitting states -> LDS (all lanes: idle ones hold -inf, so that nothing undefined is ever summed)
+  for (int c = 0; c < 5; ++c) {
+    l_em[lane * 10 + c] = kind ? g_em[(size_t)c * S + st_m] : NINF;
+    l_em[lane * 10 + 5 + c] = is_pos ? g_em[(size_t)c * S + st_i] : NINF;
+  }
+  for (int q = pos; q < CODE_ROW; q += G) l_code[grp][q] = 0;
+  // ---- where my states' back-pointers go: five byte stores per column; a role a lane does not have stores to the job's dump slot
+  //      (the 16 bytes in front of its back-pointer rows).  What is written for a state WITHOUT a score (-inf: no predecessor has
+  //      one) is some valid predecessor slot, not the 0xFF of hmm_viterbi_kernel: the trace-back only ever reads the back-pointers of
+  //      states on the best path, which all have scores, and the chunk maps of the long trace-back walk any byte safely (slots are
+  //      taken modulo 4, block indices clamped).  That saves a compare and a select per state and column.
+  uint8_t* const bp0 = bp_ws + job.bp_off;
+  uint8_t* const dump = bp0 - 16 + (lane & 15);
+  uint8_t* p_m = kind ? bp0 + st_m : dump;
+  uint8_t* p_i = is_pos ? bp0 + st_i : dump;
+  uint8_t* p_d = kind ? bp0 + st_d : dump;
+  uint8_t* p_s = kind && k == 0 ? bp0 + ms_st : dump;
+  const int aux_st = pos == 0 ? 1 : pos == 1 ? S - 2 : pos == 2 ? 0 : S - 1;   // run start | run end | start | end
+  uint8_t* p_x = pos < 4 ? bp0 + aux_st : dump;
+  const int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = pos < 4 ? Spad : 0;
+  // constant back-pointers of the aux states from column 1 on: run start <- run end (slot 1); start: none; end <- run end (slot 0)
+  const int aux_const = pos == 0 ? 1 : pos == 2 ? 0xFF : 0;
+  const bool aux_is_re = pos == 1;
+  // what a winning candidate of my match state is called in the reference's predecessor list (position 0 and the skip state have
+  // no "match before": their list starts with the block start)
+  const int kA = 0, kB = 1 - adj, kC = 2 - adj, kD = 3 - adj;
+  const int my_blk_or_none = is_end ? (int)__builtin_popcountll(ends_mask & ((1ull << pos) - 1ull)) : 255;  // my block's index (block ends only)
+  const double lp_re_lane = is_end ? lp_re : NINF;  // only block ends are candidates of the run end
+  const int a_end = (lane_base + end_pos) << 2;  // my block's end: its last position's deletion slot
+  const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
+  // scalar loop bounds: the longest allele of the wave, the longest deletion chain of the wave
+  int Lw = Lj, steps = is_pos ? n - 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { Lw = max(Lw, __shfl_xor(Lw, o)); steps = max(steps, __shfl_xor(steps, o)); }
+  Lw = __builtin_amdgcn_readfirstlane(Lw); steps = __builtin_amdgcn_readfirstlane(steps);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+
+  // scores of the column before (final): my match / insertion state, my block's start
+  double m = NINF, iv = NINF, msv = NINF;
+  double mA = NINF, iC = NINF, dD = NINF;  // the lane before's match and insertion state, the deletion state two positions back
+  const uint8_t* const codes = l_code[grp];
+  const double* const my_em = l_em + lane * 10;
+  double em_m = NINF, em_i = NINF;
+  int sym1 = 0;
+  auto column = [&](const int i, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    if ((i & (CODE_WIN - 1)) == 0) {  // next window of symbol codes (hmm_code: '#' + allele + '#', invalid bases replaced)
+      for (int q = pos; q < CODE_WIN + 2 && i + q < Lj; q += G) l_code[grp][q] = (uint8_t)hmm_code(seq, i + q, Lj);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const int sym = codes[0];
+      sym1 = codes[1];
+      em_m = my_em[sym]; em_i = my_em[5 + sym];
+    }
+    const int w = i & (CODE_WIN - 1);
+    const double e_m = em_m, e_i = em_i;
+    // (terms of the next column, symbol of the one after: their LDS round trips are not waited for in this column)
+    em_m = my_em[sym1]; em_i = my_em[5 + sym1];
+    sym1 = codes[w + 2];
+    // ---- emitting states (from the column before): first strict maximum in list order = a tournament that keeps the earlier on ties
+    double m_new, i_new;
+    int bp_m, bp_i;
+    if constexpr (FIRST) {
+      m_new = NINF; i_new = NINF; bp_m = 0; bp_i = 0;  // index 0: states with predecessors have no score (hmm_model.rs:69-71)
+    } else {
+      const double vA = (mA + lpA) + e_m, vB = (msv + lpB) + e_m, vC = (iC + lpC) + e_m, vD = (dD + lpD) + e_m;
+      const double ab = max_f64(vA, vB), cd = max_f64(vC, vD);
+      const int c_ab = vB > vA ? kB : kA, c_cd = vD > vC ? kD : kC;
+      m_new = max_f64(ab, cd);
+      bp_m = cd > ab ? c_cd : c_ab;
+      const double w0 = (iv + lpI0) + e_i, w1 = (m + lpI1) + e_i;
+      i_new = max_f64(w0, w1);
+      bp_i = w1 > w0 ? 1 : 0;
+    }
+    // ---- silent states of this column: deletion chain and block end (own candidates, then the lane before, step by step)
+    const double o0 = (m_new + lpO0), o1 = (i_new + lpO1);
+    const double own = max_f64(o0, o1);
+    int bp_d = o1 > o0 ? 1 : 0;
+    double val = own, cand = NINF;
+    for (int t = 0; t < steps; ++t) {
+      cand = (wave_shr1_f64(val) + lp_step);
+      val = max_f64(cand, own);
+    }
+    bp_d = cand > own ? chain_slot : bp_d;
+    const double d_new = val;
+    // ---- run end: the block ends in block order, first strict maximum; every lane of the job has it
+    const double v_re = (d_new + lp_re_lane);
+    const double re_new = group_max<G>(v_re, lane);
+    const double my_end = bperm_f64(a_end, d_new);
+    const int bp_re = group_min_i32<G>(v_re == re_new ? my_blk_or_none : 255, lane);  // the first block that attains it
+    // ---- run start {start state, run end}; the start state has a score in column 0 only
+    double rs; int bp_rs;
+    if constexpr (FIRST) {
+      const double v0 = (em_start0 + lp_rs0), v1 = (re_new + lp_rs1);
+      rs = max_f64(v0, v1);
+      bp_rs = v1 > v0 ? 1 : 0;
+    } else {
+      rs = (re_new + lp_rs1);
+      bp_rs = 1;
+    }
+    // ---- my block's start {run start, own block end}
+    const double s0 = (rs + lpS0), s1 = (my_end + lpS1);
+    const double ms_new = max_f64(s0, s1);
+    const int bp_s = s1 > s0 ? 1 : 0;
+    // ---- run start / run end / start / end state: one store by the first four lanes of the job
+    int bp_x;
+    if constexpr (FIRST) bp_x = pos == 0 ? bp_rs : pos == 1 ? bp_re : pos == 2 ? 0xFE : 0xFF;
+    else bp_x = aux_is_re ? bp_re : aux_const;
+    if (i < Lj) {
+      *p_m = (uint8_t)bp_m; *p_i = (uint8_t)bp_i; *p_d = (uint8_t)bp_d; *p_s = (uint8_t)bp_s; *p_x = (uint8_t)bp_x;
+    }
+    p_m += inc_m; p_i += inc_i; p_d += inc_m; p_s += inc_s; p_x += inc_x;
+    // ---- what the next column's emitting states take from the lane before
+    m = m_new; iv = i_new; msv = ms_new;
+    mA = wave_shr1_f64(m_new);
+    const double i_sh = wave_shr1_f64(i_new);
+    iC = is_skip ? m_new : i_sh;
+    dD = wave_shr1_f64(wave_shr1_f64(d_new));
+  };
+  column(0, std::true_type());
+  for (int i = 1; i < Lw; ++i) column(i, std::false_type());
+}
+
+}  // namespace ppl
