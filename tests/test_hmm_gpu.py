@@ -182,7 +182,10 @@ def test_register_fill_variants_agree(oracle, hmm):
         jobs.append((s, b"N" * 9 + repeat_allele(rng, m, 30, err=0.0) + b"NN"))
     base = _same(oracle, hmm, sets, jobs)
     batch = hmm.pack_hmm_batch(sets, jobs)
-    for env in (dict(TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_LDS_FILL=1), dict(TRGT_HMM_LDS_FILL=1, TRGT_HMM_FOUR_ROUNDS=1)):
+    # (round 5: by default the fill runs with one lane per motif position, hmm_ppl.hpp, in front of those kernels; TRGT_HMM_NO_PPL=1 takes
+    #  the fills of hmm_viterbi_kernel, which the other switches select among)
+    for env in (dict(TRGT_HMM_NO_PPL=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_LDS_FILL=1),
+                dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_LDS_FILL=1, TRGT_HMM_FOUR_ROUNDS=1)):
         ctx = _lib.context_with_env(**env)
         try:
             a = hmm.hmm_batch(batch, ctx=ctx)
@@ -237,3 +240,21 @@ def test_device_resident_inputs(oracle, hmm):
     ref = oracle.hmm_batch(batch, want_path=False)
     assert np.array_equal(got["purity"].view(np.uint64), ref["purity"].view(np.uint64))
     assert np.array_equal(got["counts"], ref["counts"])
+
+
+def test_position_per_lane_fill_shapes(oracle, hmm):
+    # hmm_fill_ppl_kernel: one lane per motif position, 8 / 16 / 32 / 64 lanes per allele.  Sets on every group width and at its edges
+    # (positions + 1 = 8, 9, 16, 17, 32, 33, 64; 65 positions do not fit and take hmm_viterbi_kernel's own fill), one-base motifs (no
+    # deletion states), many blocks (the run end's first-maximum over up to 21 block ends), long motifs (the deletion chain's early
+    # exit), alleles of different lengths side by side in one wave, empty alleles, alleles across the 256-column code window.
+    rng = np.random.default_rng(505)
+    sets = [[b"CAG"], [b"ACGTTGC"], [b"ACGTTGCA"], [b"A"] * 1 + [b"C", b"G", b"T", b"AC", b"AG"], [b"ACGTA", b"CCGGA", b"TTGAC"], [b"ACGTACGTACGTTGCA"],
+            [rand_dna(rng, 31)], [rand_dna(rng, 32)], [rand_dna(rng, 63)], [rand_dna(rng, 64)], [b"A", b"C", b"G", b"T"] * 5, [b"AAGGG", b"AAAAG", b"ACG", b"N", b"GCN"]]
+    jobs = []
+    for s, m in enumerate(sets):
+        for n in (0, 1, 3, 20, 90):
+            jobs.append((s, repeat_allele(rng, m, n, err=0.03)))
+        jobs.append((s, rand_dna(rng, 300)))
+    for n in (254, 255, 256, 257, 258, 511, 512, 513, 700):
+        jobs.append((0, (b"CAG" * 300)[:n]))
+    _same(oracle, hmm, sets, jobs)

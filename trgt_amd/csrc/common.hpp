@@ -99,6 +99,10 @@ struct trgt_hip_ctx {
   struct Pending { int k; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> retired_events;  // resolved timing events: neither destroyed nor re-recorded while calls are being timed (see resolve_timing)
+  // zero arena: the small device counters a call needs cleared (job counters, offset counters, count blocks) are carved out of ONE
+  // buffer that one kernel clears when the call starts (trgt::zero_begin) -- they used to be 15-25 hipMemsetAsync dispatches per call
+  void* zero_arena = nullptr; size_t zero_cap = 0, zero_used = 0, zero_dirty = 0; bool zero_on = false;
+  void* wfa_cells_cur[3] = {nullptr, nullptr, nullptr};  // offset counter of the current logical batch of each buffer set (wfa_launch, keep_cells)
   void* last_wfa_cells_dev = nullptr;
   void* last_filter_cells_dev = nullptr;
   int64_t dbg_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -233,6 +237,7 @@ enum Slot {
   S_CL_LIST, S_CL_MOFF, S_CL_COUNTS, S_CL_REC, S_CL_CLS, S_CL_ESCORE, S_CL_GMAT, S_CL_EDJOBS, S_CL_JOBS, S_CL_GROUPS, S_CL_ED2JOBS, S_CL_ESCORE2, S_CL_CIGAR, S_CL_CLEN,
   S_CL_VOUT, S_CL_VLEN, S_CL_VSCR,  // device-side cluster genotyper (locus_cluster_dev.hpp)
   S_INF_SRC, S_INF_DESC, S_INF_DST, S_INF_STATUS, S_INF_COUNTER,  // device-side BGZF inflate (inflate_dev.hip)
+  S_ZERO_ARENA,  // trgt::zero_begin / zero_take
   S_COUNT
 };
 // pinned host buffer slots
@@ -286,6 +291,52 @@ inline int pin_get(trgt_hip_ctx* c, int slot, size_t bytes, void** out) {
     b.cap = want;
   }
   *out = b.p;
+  return TRGT_OK;
+}
+
+// ---- zero arena.  zero_begin (start of trgt_locus_batch, on the call's stream) clears what the call before handed out; zero_take
+// hands out cleared, 64-byte aligned pieces until the call ends (zero_end).  Every stream a call uses forks off its main stream behind
+// this point, so a piece is clear wherever it is first touched.  Outside a call, or when the arena is used up, zero_take returns nullptr
+// and the caller clears a buffer of its own with hipMemsetAsync as before.
+constexpr size_t ZERO_ARENA_BYTES = 2u << 20;
+static __global__ void zero_arena_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+inline int zero_begin(trgt_hip_ctx* c) {
+  c->zero_on = false;
+  static const bool off = [] { const char* e = getenv("TRGT_NO_ZERO_ARENA"); return e && *e && std::strcmp(e, "0") != 0; }();
+  if (off) return TRGT_OK;
+  void* p = nullptr;
+  if (int rc = dev_get(c, S_ZERO_ARENA, ZERO_ARENA_BYTES, &p)) return rc;
+  const bool fresh = p != c->zero_arena;
+  c->zero_arena = p; c->zero_cap = ZERO_ARENA_BYTES;
+  const size_t dirty = fresh ? ZERO_ARENA_BYTES : std::min(ZERO_ARENA_BYTES, (std::max(c->zero_dirty, c->zero_used) + 4095) & ~(size_t)4095);
+  if (dirty) {
+    const size_t n16 = dirty / 16;
+    hipLaunchKernelGGL(zero_arena_kernel, dim3((unsigned)std::min<size_t>(64, (n16 + 255) / 256)), dim3(256), 0, c->stream, (uint4*)p, n16);
+    TRGT_HIP_TRY(c, hipGetLastError());
+  }
+  c->zero_used = 0; c->zero_dirty = 0; c->zero_on = true;
+  c->wfa_cells_cur[0] = c->wfa_cells_cur[1] = c->wfa_cells_cur[2] = nullptr;
+  return TRGT_OK;
+}
+inline void zero_end(trgt_hip_ctx* c) {
+  if (c->zero_on) { c->zero_dirty = std::max(c->zero_dirty, c->zero_used); c->zero_on = false; }
+  c->wfa_cells_cur[0] = c->wfa_cells_cur[1] = c->wfa_cells_cur[2] = nullptr;  // (pieces of the arena: not valid beyond the call)
+}
+inline void* zero_take(trgt_hip_ctx* c, size_t bytes) {
+  if (!c->zero_on) return nullptr;
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (c->zero_used + need > c->zero_cap) return nullptr;
+  void* p = (uint8_t*)c->zero_arena + c->zero_used;
+  c->zero_used += need;
+  return p;
+}
+// a cleared device buffer of `bytes`: from the arena inside a call, else the pool slot cleared by hipMemsetAsync on `stream`
+inline int dev_get_zeroed(trgt_hip_ctx* c, int slot, size_t bytes, void** out, hipStream_t stream) {
+  if (void* z = zero_take(c, bytes)) { *out = z; return TRGT_OK; }
+  if (int rc = dev_get(c, slot, bytes, out)) return rc;
+  TRGT_HIP_TRY(c, hipMemsetAsync(*out, 0, bytes, stream));
   return TRGT_OK;
 }
 

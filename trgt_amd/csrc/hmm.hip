@@ -239,6 +239,7 @@ struct HmmBuildArgs {
   const uint32_t* seed_row;         // [n_motifs_total] first entry of the motif's row of seed_tab (entry k: ln(seed(n) * (n - k)))
   const double* seed_tab;
   const uint16_t* perm_all; const uint64_t* perm_src;  // lane -> state tables of the sets that have one, [n_sets] offsets into perm_all
+  uint64_t blob_bytes;              // all sets' tables together (the end of the last set's)
   HmmBuildConsts k;
 };
 __global__ void __launch_bounds__(64) hmm_model_build_kernel(const HmmBuildArgs a) {
@@ -322,6 +323,12 @@ __global__ void __launch_bounds__(64) hmm_model_build_kernel(const HmmBuildArgs 
   }
   {  // motif bytes, lane table, padding
     const uint32_t m_lo = a.motif_off[mb], m_hi = a.motif_off[mb + nb - 1];
+    if (tid == 0) {  // the alignment gaps of the set's tables (layout_set): zero, as in the host builder's blob
+      const uint64_t end = (uint32_t)s + 1u < gridDim.x ? a.sets[s + 1].off_inlp : a.blob_bytes;
+      for (uint64_t q = d.off_block + 2ull * (uint64_t)S; q < d.off_blocks; ++q) blob[q] = 0;
+      for (uint64_t q = d.off_motifs + (uint64_t)(m_hi - m_lo); q < d.off_perm; ++q) blob[q] = 0;
+      for (uint64_t q = d.off_perm + 2ull * d.n_lanes; q < end; ++q) blob[q] = 0;
+    }
     for (uint32_t i = (uint32_t)tid; i < m_hi - m_lo; i += 64) mot[i] = a.motif_bytes[m_lo + i];
     if (d.n_lanes) {
       uint16_t* perm = reinterpret_cast<uint16_t*>(blob + d.off_perm);
@@ -1942,7 +1949,7 @@ int hmm_models_on_device(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_b
   void *h = nullptr, *dv = nullptr, *d_blob = nullptr, *d_sets = nullptr;
   int rc;
   if ((rc = pin_get(c, P_HMM_BUILD, lay.total, &h)) || (rc = dev_get(c, S_HMM_BUILD, lay.total, &dv)) ||
-      (rc = dev_get(c, S_HMM_MODEL, (size_t)pos + 16, &d_blob)) || (rc = dev_get(c, S_HMM_DESC, sizeof(HmmSetDev) * (size_t)n_sets, &d_sets)))
+      (rc = dev_get(c, S_HMM_MODEL, (size_t)pos + 16, &d_blob)))
     return out.rc = rc;
   uint8_t* hb = (uint8_t*)h;
   std::memcpy(hb + o_sets, sets.data(), sizeof(HmmSetDev) * (size_t)n_sets);
@@ -1964,13 +1971,14 @@ int hmm_models_on_device(trgt_hip_ctx* c, int32_t n_sets, const uint8_t* motif_b
   }
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
   if ((rc = h2d_small(c, dv, h, lay.total, up, -1))) return out.rc = rc;  // (pinned source; a kernel copy: not queued behind bulk uploads)
-  TRGT_HIP_TRY(c, hipMemcpyAsync(d_sets, (uint8_t*)dv + o_sets, sizeof(HmmSetDev) * (size_t)n_sets, hipMemcpyDeviceToDevice, up));
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_blob, 0, (size_t)pos, up));  // (padding between the tables: the blob compares equal to the host builder's)
+  // (the descriptors stay where they were uploaded -- the build slab lives as long as the models; the padding between a set's tables is
+  //  cleared by the build kernel itself, so that the blob compares equal to the host builder's: a D2D copy and a 20-MB fill per call less)
+  d_sets = (uint8_t*)dv + o_sets;
   HmmBuildArgs a;
   const uint8_t* db = (const uint8_t*)dv;
   a.sets = (const HmmSetDev*)(db + o_sets); a.blob = (uint8_t*)d_blob; a.motif_bytes = db + o_mot; a.motif_off = (const uint32_t*)(db + o_moff);
   a.set_motif_begin = (const uint32_t*)(db + o_smb); a.seed_row = (const uint32_t*)(db + o_srow); a.seed_tab = (const double*)(db + o_stab);
-  a.perm_all = (const uint16_t*)(db + o_perm); a.perm_src = (const uint64_t*)(db + o_psrc); a.k = hmm_build_consts();
+  a.perm_all = (const uint16_t*)(db + o_perm); a.perm_src = (const uint64_t*)(db + o_psrc); a.blob_bytes = pos; a.k = hmm_build_consts();
   hipLaunchKernelGGL(hmm_model_build_kernel, dim3((unsigned)n_sets), dim3(64), 0, up, a);
   TRGT_HIP_TRY(c, hipGetLastError());
   if (done) TRGT_HIP_TRY(c, hipEventRecord(done, up));
@@ -2225,10 +2233,13 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
     uint32_t* d_long_cls = nullptr;
     if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)HMM_LONG_MIN) {
-      void* dl = nullptr;
-      if ((rc = dev_get(c, S_HMM_LONG + so, 8 * ((size_t)jobs.size() + 16) * 4, &dl))) return rc;
-      d_long_cls = (uint32_t*)dl + (size_t)n_class * 0 + (i + 8 * (size_t)(n_class - 1));  // [count | job indices] of this class
-      TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+      if (void* z = zero_take(c, ((size_t)nj + 16) * 4)) d_long_cls = (uint32_t*)z;  // [count | job indices] of this class, the count cleared
+      else {
+        void* dl = nullptr;
+        if ((rc = dev_get(c, S_HMM_LONG + so, 8 * ((size_t)jobs.size() + 16) * 4, &dl))) return rc;
+        d_long_cls = (uint32_t*)dl + (size_t)n_class * 0 + (i + 8 * (size_t)(n_class - 1));
+        TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+      }
     }
     if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, nj, nullptr);
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
@@ -2335,7 +2346,10 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     return rc;
   HmmJobDev* const d_cand = (HmmJobDev*)d_jobs;
   HmmJobDev* const d_list = d_cand + n_cand;
-  uint32_t* const d_count = (uint32_t*)((uint8_t*)d_jobs + 2 * jobs_bytes);
+  // counts | histogram | places taken (64 + 4096 bytes, cleared): a piece of the call's zero arena when there is one
+  void* const z_count = zero_take(c, 64 + 4096);
+  uint32_t* const d_count = z_count ? (uint32_t*)z_count : (uint32_t*)((uint8_t*)d_jobs + 2 * jobs_bytes);
+  uint32_t* const d_verdict = (uint32_t*)((uint8_t*)d_jobs + 2 * jobs_bytes + 64 + 4096);
   {  // on the copy stream: a copy queued on the batch's stream would sit in the copy engine's queue until the genotyper in front of it
      // has run, and hold up every copy issued after it (the next batch's reads)
     hipStream_t us = c->stream_copy ? c->stream_copy : c->stream;
@@ -2362,7 +2376,8 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   for (int64_t l = 0; l < nl; ++l) max_cap = std::max(max_cap, in.cap[l]);
   while ((max_cap >> len_shift) >= 64) ++len_shift;
   // slots that are no candidates at all (loci left to the host path) hold "no allele" too
-  TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
+  if (void* z = o_nsp.staged && (size_t)n_slots * 4 <= (512u << 10) ? zero_take(c, (size_t)n_slots * 4) : nullptr) o_nsp.dev = (uint32_t*)z;
+  else TRGT_HIP_TRY(c, hipMemsetAsync(o_nsp.dev, 0, (size_t)n_slots * 4, c->stream));
   const uint8_t* d_dup = nullptr;
   if (c->knobs.hmm_resolve_one_wg) {
     for (int k = 0; k < 8; ++k) {
@@ -2377,10 +2392,10 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     ra.class_begin[8] = (uint32_t)n_cand;
     ra.skip_locus = in.d_skip; ra.n_alleles = in.d_n_alleles; ra.allele_len = in.d_allele_len;
     ra.jobs = d_list; ra.n_jobs = d_count; ra.n_spans = o_nsp.dev; ra.purity = o_pur.dev;
-    ra.hist = d_count + 16; ra.taken = ra.hist + 512; ra.verdict = ra.taken + 512; ra.len_shift = len_shift;
+    ra.hist = d_count + 16; ra.taken = ra.hist + 512; ra.verdict = d_verdict; ra.len_shift = len_shift;
     ra.seq_blob = in.seq_blob_dev; ra.dup = c->knobs.hmm_no_dedupe ? nullptr : reinterpret_cast<uint8_t*>(ra.verdict + n_cand);
     d_dup = ra.dup;
-    TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64 + 4096, c->stream));
+    if (!z_count) TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 64 + 4096, c->stream));
     const dim3 rg((unsigned)((n_cand + 255) / 256));
     hipLaunchKernelGGL(hmm_resolve_count_kernel, rg, dim3(256), 0, c->stream, ra);
     hipLaunchKernelGGL(hmm_resolve_scatter_kernel, rg, dim3(256), 0, c->stream, ra);
@@ -2426,10 +2441,13 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     uint32_t max_cap_cls = 0;
     for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
     if (!c->knobs.hmm_no_long_tb && (uint64_t)max_cap_cls + 2 >= (uint64_t)HMM_LONG_MIN) {
-      void* dl = nullptr;
-      if ((rc = dev_get(c, S_HMM_LONG + so, ((size_t)n_cand + 8 * 16) * 4, &dl))) return rc;
-      d_long_cls = (uint32_t*)dl + class_begin[k] + 8 * k;  // [count | job indices] of this class
-      TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+      if (void* z = zero_take(c, ((size_t)nj + 16) * 4)) d_long_cls = (uint32_t*)z;  // [count | job indices] of this class, the count cleared
+      else {
+        void* dl = nullptr;
+        if ((rc = dev_get(c, S_HMM_LONG + so, ((size_t)n_cand + 8 * 16) * 4, &dl))) return rc;
+        d_long_cls = (uint32_t*)dl + class_begin[k] + 8 * k;
+        TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
+      }
     }
     if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, nj, (const uint32_t*)(d_count + k));
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }

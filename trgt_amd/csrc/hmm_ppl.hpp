@@ -196,9 +196,22 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     const double own = max_f64(o0, o1);
     int bp_d = o1 > o0 ? 1 : 0;
     double val = own, cand = NINF;
-    for (int t = 0; t < steps; ++t) {
-      cand = (wave_shr1_f64(val) + lp_step);
-      val = max_f64(cand, own);
+    if (steps <= 3) {
+      for (int t = 0; t < steps; ++t) {
+        cand = (wave_shr1_f64(val) + lp_step);
+        val = max_f64(cand, own);
+      }
+    } else {
+      // long motifs: the chain is a fixed-point iteration (every lane takes max(own, the lane before + ln p)): once an iteration changes
+      // no lane of the wave, the values -- and the candidates of that iteration -- are the final ones.  A deletion run rarely beats the
+      // match states for more than a few positions, so a 60-base motif takes a handful of iterations instead of 59.
+      for (int t = 0; t < steps; ++t) {
+        cand = (wave_shr1_f64(val) + lp_step);
+        const double nv = max_f64(cand, own);
+        const bool changed = nv != val;
+        val = nv;
+        if (!__any(changed)) break;
+      }
     }
     bp_d = cand > own ? chain_slot : bp_d;
     const double d_new = val;

@@ -407,9 +407,14 @@ HostPool* host_pool(trgt_hip_ctx* c, int threads) {
 }
 
 // Exclusive prefix over the allele lengths (one workgroup) and the packing of the alleles into one dense buffer for the D2H copy
-__global__ void __launch_bounds__(1024) allele_prefix_kernel(const uint32_t* __restrict__ len, uint64_t* __restrict__ off, int64_t n) {
+// (... and, riding along: the count blocks of the device-side repair and of the cluster genotyper copied into the result slab -- null
+//  source: zeros -- which were a D2D copy or a fill each)
+struct CountCopy { const uint32_t* src1; uint32_t* dst1; uint32_t n1; const uint32_t* src2; uint32_t* dst2; uint32_t n2; };
+__global__ void __launch_bounds__(1024) allele_prefix_kernel(const uint32_t* __restrict__ len, uint64_t* __restrict__ off, int64_t n, const CountCopy cc) {
   __shared__ uint64_t part[1024];
   const int t = threadIdx.x;
+  if ((uint32_t)t < cc.n1) cc.dst1[t] = cc.src1 ? __hip_atomic_load(cc.src1 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if ((uint32_t)t < cc.n2) cc.dst2[t] = cc.src2 ? __hip_atomic_load(cc.src2 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const int64_t per = (n + 1023) / 1024, b = t * per, e = b + per < n ? b + per : n;
   uint64_t sum = 0;
   for (int64_t i = b; i < e; ++i) sum += len[i];
@@ -544,6 +549,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       !out->read_rank || !out->spans3 || !out->span_off || !out->n_spans || !out->motif_counts || !out->count_off || !out->purity)
     return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: null field");
   TRGT_HIP_TRY(c, hipSetDevice(c->device));
+  struct ZeroGuard { trgt_hip_ctx* c; ~ZeroGuard() { trgt::zero_end(c); } } zero_guard{c};
+  { const int zrc = trgt::zero_begin(c); if (zrc) return zrc; }  // (on the call's stream, in front of everything: every other stream forks off behind it)
   const int F = p->flank_len;
   if (F <= 0) return fail(c, TRGT_ERR_INVALID, "trgt_locus_batch: flank_len must be positive");
   const int64_t nr = (int64_t)in->locus_read_begin[nl];
@@ -800,8 +807,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     std::memset(&rp, 0, sizeof rp);
     void *d_vout = nullptr, *d_vlen = nullptr, *d_vscr = nullptr, *d_rcig = nullptr, *d_rclen = nullptr;
     const bool dev_repair = !c->knobs.host_repair;
+    const uint32_t* cl_counts_dev = nullptr;  // count block of the device-side cluster genotyper, when it runs
     if (dev_repair) {
-      { void* d_cnt = nullptr; if ((rc = dev_get(c, S_RP_COUNTS, 256, &d_cnt))) return rc; rp.counts = (uint32_t*)d_cnt; }
+      void* const z_rpc = zero_take(c, 256);  // (cleared with the call's zero arena; else by the kernel below)
+      if (z_rpc) rp.counts = (uint32_t*)z_rpc;
+      else { void* d_cnt = nullptr; if ((rc = dev_get(c, S_RP_COUNTS, 256, &d_cnt))) return rc; rp.counts = (uint32_t*)d_cnt; }
       rp.cap_groups = (uint32_t)std::min<int64_t>(2 * nl, 0x7FFFFFFF); rp.cap_jobs = (uint32_t)nr;
       // (segments beyond what the register-resident kernels take go to the generic engine, whose workgroups are bounded by ws_budget: a batch of
       //  10-kb alleles -- cfg3 -- is repaired on the device too instead of going back to the host: one-context call 22.2 -> 14.4 ms)
@@ -819,7 +829,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
           (rc = dev_get(c, S_RP_VSCR, (size_t)rp.cap_scratch * 4 + 16, &d_vscr)))
         return rc;
       rp.groups = (gt::RGroup*)d_g; rp.jobs = (JobDev*)d_j; rp.loci = (uint32_t*)d_l; rp.pend = (gt::RepairPend*)d_p;
-      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, rp.counts, (uint32_t)gt::RC_WORDS);
+      if (!z_rpc) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, rp.counts, (uint32_t)gt::RC_WORDS);
     }
     const bool small_gt = max_locus_reads <= 64;
     if (small_gt) hipLaunchKernelGGL((gt::locus_genotype_kernel<64, 8 * 1024>), dim3((unsigned)nl), dim3(64), 0, c->stream, ga);
@@ -898,7 +908,6 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       TRGT_HIP_TRY(c, hipGetLastError());
       if ((rc = dbg_sync("vote + finish"))) return rc;
       tl_mark(c, "repair chain enqueued");
-      TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_rpc), rp.counts, gt::RC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
       if (split) {
         TRGT_HIP_TRY(c, hipEventRecord(c->ev_rp, c->stream));  // (the results the host waits for do not wait for the second HMM batch)
         hs.d_skip = (const uint8_t*)dsl(o_skipb);
@@ -909,7 +918,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
         std::swap(c->stream, c->stream2); swap_back_rp.on = false;
         TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rp, 0));
       }
-    } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_rpc), 0, gt::RC_WORDS * 4, c->stream));
+    }
     if (!cl_list.empty()) {
       // ---- Genotyper::Cluster on the device (locus_cluster_dev.hpp): pair list -> edit distances -> linkage / groups / backbones ->
       //      consensus round -> redo or dropped reads -> second round + edit distances -> genotype.  Four alignment launches and two
@@ -940,10 +949,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
           (rc = dev_get(c, S_CL_CLEN, 2 * (size_t)ca.cap_j * 4, &d_clen)) || (rc = dev_get(c, S_CL_VOUT, (size_t)ca.cap_out + 16, &d_vout)) ||
           (rc = dev_get(c, S_CL_VLEN, 2 * (size_t)ca.cap_g * 4, &d_vlen)) || (rc = dev_get(c, S_CL_VSCR, (size_t)ca.cap_scratch * 4 + 16, &d_vscr)))
         return rc;
-      ca.counts = (uint32_t*)d_cnt; ca.rec = (cl::ClRec*)d_rec; ca.cls = (int8_t*)d_cls; ca.escore = (int32_t*)d_es; ca.gmat = (double*)d_gm;
+      void* const z_clc = zero_take(c, 256);  // (cleared with the call's zero arena; else by the kernel below)
+      ca.counts = z_clc ? (uint32_t*)z_clc : (uint32_t*)d_cnt; ca.rec = (cl::ClRec*)d_rec; ca.cls = (int8_t*)d_cls; ca.escore = (int32_t*)d_es; ca.gmat = (double*)d_gm;
       ca.ed_jobs = (JobDev*)d_edj; ca.jobs = (JobDev*)d_j; ca.groups = (gt::RGroup*)d_g; ca.ed2_jobs = (JobDev*)d_ed2; ca.escore2 = (int32_t*)d_es2;
       ca.vote_out = (const uint8_t*)d_vout; ca.vote_len = (const uint32_t*)d_vlen;
-      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, ca.counts, (uint32_t)cl::CC_WORDS);
+      if (!z_clc) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->stream, ca.counts, (uint32_t)cl::CC_WORDS);
       const dim3 cgrid(n_cl);
       if (big) hipLaunchKernelGGL((cl::cluster_front_kernel<gt::GT_MAX_READS>), cgrid, dim3(64), 0, c->stream, ca);
       else hipLaunchKernelGGL((cl::cluster_front_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
@@ -992,9 +1002,11 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       else hipLaunchKernelGGL((cl::cluster_finish_kernel<64>), cgrid, dim3(64), 0, c->stream, ca);
       TRGT_HIP_TRY(c, hipGetLastError());
       tl_mark(c, "cluster chain enqueued");
-      TRGT_HIP_TRY(c, hipMemcpyAsync(dsl(o_clc), ca.counts, cl::CC_WORDS * 4, hipMemcpyDeviceToDevice, c->stream));  // (comes back with the slab)
-    } else TRGT_HIP_TRY(c, hipMemsetAsync(dsl(o_clc), 0, cl::CC_WORDS * 4, c->stream));
-    hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl));
+      cl_counts_dev = ca.counts;
+    }
+    // (the count blocks come back with the slab)
+    const CountCopy cc{dev_repair ? rp.counts : nullptr, (uint32_t*)dsl(o_rpc), (uint32_t)gt::RC_WORDS, cl_counts_dev, (uint32_t*)dsl(o_clc), (uint32_t)cl::CC_WORDS};
+    hipLaunchKernelGGL(allele_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)g.alen, (uint64_t*)g.toff, (int64_t)(2 * nl), cc);
     hipLaunchKernelGGL(allele_pack_kernel, dim3((unsigned)((2 * nl + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)g.blob, g.al_off,
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
     TRGT_HIP_TRY(c, hipGetLastError());

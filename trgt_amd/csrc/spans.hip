@@ -649,10 +649,9 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
   void *d_pos = nullptr, *d_wjobs = nullptr, *d_count = nullptr, *d_span4 = nullptr, *d_nmatch = nullptr;
   int rc;
   if ((rc = dev_get(c, S_FS_POS, n_jobs * 4, &d_pos)) || (rc = dev_get(c, S_FS_WFAJOBS, n_jobs * sizeof(JobDev), &d_wjobs)) ||
-      (rc = dev_get(c, S_FS_COUNT, 4 * SC_WORDS, &d_count)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
+      (rc = dev_get_zeroed(c, S_FS_COUNT, 4 * SC_WORDS, &d_count, c->stream)) || (rc = dev_get(c, S_FS_SPAN, n_jobs * 16, &d_span4)) ||
       (rc = dev_get(c, S_FS_NMATCH, n_jobs * 4, &d_nmatch)))
     return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_count, 0, 4 * SC_WORDS, c->stream));
   ScanArgs sa;
   sa.flank_blob = d_flank; sa.read_blob = d_reads; sa.piece_off = d_piece_off; sa.read_off = d_read_off; sa.read_len = d_read_len;
   sa.read_locus = d_read_locus; sa.n_jobs = n_jobs; sa.flank_len = p.flank_len; sa.pos = (int32_t*)d_pos; sa.n_match = (int32_t*)d_nmatch;
@@ -917,7 +916,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         if ((rc = dev_get(c, S_LW_SUB, cap * sizeof(JobDev), &d_sub)) ||
             (rc = dev_get(c, S_LW_PARENT, cap * 4, &d_parent)) || (rc = dev_get(c, S_LW_SUBKEEP, cap, &d_subkeep)) ||
             (rc = dev_get(c, S_LW_JOBKEEP, n_jobs, &d_jobkeep)) || (rc = dev_get(c, S_LW_KEPT, n_jobs * sizeof(JobDev), &d_kept)) ||
-            (rc = dev_get(c, S_LW_COUNT, 16, &d_lwc)))
+            (rc = dev_get_zeroed(c, S_LW_COUNT, 16, &d_lwc, c->stream)))
           return rc;
         LongWinArgs lw;
         lw.jobs = long_in; lw.n_jobs = (const uint32_t*)d_count + long_in_count; 
@@ -928,7 +927,6 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
         if (long_band && ((rc = dev_get(c, S_LW_SUBBAND, cap * 4, &d_sband)) || (rc = dev_get(c, S_LW_JOBBEST, n_jobs * 4, &d_jbest)) || (rc = dev_get(c, S_LW_JOBREJ, n_jobs * 4, &d_jrej)))) return rc;
         lw.sub_band = (const uint32_t*)d_sband; lw.job_best = (uint32_t*)d_jbest; lw.job_rej = (uint32_t*)d_jrej;
         const dim3 g((unsigned)c->num_cus * 2), b(256);
-        TRGT_HIP_TRY(c, hipMemsetAsync(d_lwc, 0, 16, c->stream));
         hipLaunchKernelGGL(long_windows_kernel, g, b, 0, c->stream, lw);
         TRGT_HIP_TRY(c, hipGetLastError());
         FilterLaunch FW;

@@ -615,11 +615,17 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   void* d_ws = nullptr; void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
-  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_COUNTER_C : L.buffer_set ? S_WFA_COUNTER_B : S_WFA_COUNTER, 16 + 4 * (size_t)blocks + 96, &d_counter))) return rc;  // job counters | slot flags | 24 words of the lean kernels (statistics, their counters)
-  if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_CELLS_C : L.buffer_set ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16 + 4 * (size_t)blocks + 96, c->stream));
+  // job counters | slot flags | 24 words of the lean kernels (statistics, their counters); the offset counter of the batch.  Cleared
+  // pieces of the call's zero arena (inside trgt_locus_batch: no hipMemsetAsync per launch), else pool slots cleared here
+  const size_t counter_bytes = 16 + 4 * (size_t)blocks + 96;
+  const int bset = L.buffer_set == 2 ? 2 : L.buffer_set ? 1 : 0;
+  if ((rc = dev_get_zeroed(c, bset == 2 ? S_WFA_COUNTER_C : bset ? S_WFA_COUNTER_B : S_WFA_COUNTER, counter_bytes, &d_counter, c->stream))) return rc;
+  if (!L.keep_cells) {
+    if ((rc = dev_get_zeroed(c, bset == 2 ? S_WFA_CELLS_C : bset ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells, c->stream))) return rc;
+    c->wfa_cells_cur[bset] = d_cells;
+  } else if (c->wfa_cells_cur[bset]) d_cells = c->wfa_cells_cur[bset];  // a later launch of the same logical batch: keeps counting where the first one did
+  else if ((rc = dev_get(c, bset == 2 ? S_WFA_CELLS_C : bset ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
-  if (!L.keep_cells) TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
   a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
   a.jobs = L.jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host; a.n_jobs_dev = L.n_jobs_dev;
   a.n_jobs2_dev = L.n_jobs2_dev; a.jobs_cap = L.jobs_cap;

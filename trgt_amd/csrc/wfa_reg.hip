@@ -559,9 +559,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   a.score = L.score; a.bound = L.bound; a.keep = L.keep; a.band = L.band;
   void* d_counter = nullptr; void* d_cells = nullptr;
   int rc;
-  if ((rc = dev_get(c, L.set ? S_FLT_COUNTER_B : S_FLT_COUNTER, 16, &d_counter)) || (rc = dev_get(c, L.set ? S_FLT_CELLS_B : S_FLT_CELLS, 16, &d_cells))) return rc;
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
-  TRGT_HIP_TRY(c, hipMemsetAsync(d_cells, 0, 16, c->stream));
+  if ((rc = dev_get_zeroed(c, L.set ? S_FLT_COUNTER_B : S_FLT_COUNTER, 16, &d_counter, c->stream)) || (rc = dev_get_zeroed(c, L.set ? S_FLT_CELLS_B : S_FLT_CELLS, 16, &d_cells, c->stream))) return rc;
   a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
   a.diag_lo = INT32_MIN; a.diag_hi = INT32_MAX;
   // instantiation by the number of diagonals the longest text of the launch needs (jobs that do not fit are kept unseen)
