@@ -69,3 +69,30 @@ def test_native_pool_equals_one_context(oracle):
             locus.run_many(pool, [chunks[0], bad, chunks[2]], flank_dev=fd, reads_dev=rd)
     finally:
         pool.close()
+
+
+def test_native_pool_of_eight_contexts(oracle):
+    # trgt_hip_pool_create with EIGHT entries -- the in-process form of the 8-GPU launch (one context per device of a node),
+    # here eight contexts on the one GPU of the box ([0] * 8) -- so that the eight-worker path (eight threads, eight contexts with their
+    # streams and buffer pools, one queue of batches) has run on hardware before the first real 8-GPU node sees it.  Host reads: every
+    # context uploads its own batches one ahead (submit / wait), which is what a node-level driver would do per device.
+    import torch
+    from trgt_amd import _lib, locus, shard, synth
+    from trgt_amd.driver import split_batch
+    b = synth.generate(2400, first_locus=88000, config=4)
+    chunks = split_batch(b, 150)
+    fd = torch.from_numpy(b["flank_blob"]).cuda()
+    one = _lib.Context(0)
+    ref = [locus.run_batch(c, ctx=one, flank_dev=fd) for c in chunks]
+    one.close()
+    pool = _lib.Pool([0] * 8)
+    try:
+        assert len(pool.contexts) == 8
+        for c in pool.contexts:  # (eight workspaces on one GPU: keep each small)
+            c.check(_lib.lib().trgt_hip_set_workspace_limit(c.handle, 4 << 30))
+        got, ran = locus.run_many(pool, chunks, flank_dev=fd)
+        assert len(set(ran)) >= 4 and all(0 <= w < 8 for w in ran)
+        for c, g, r in zip(chunks, got, ref):
+            assert shard.result_digest(g, c["n_loci"]) == shard.result_digest(r, c["n_loci"])
+    finally:
+        pool.close()

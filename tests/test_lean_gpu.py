@@ -59,13 +59,16 @@ def test_lean_and_generic_kernel_agree_byte_for_byte():
         ctx_generic = _lib.Context()
     finally:
         del os.environ["TRGT_WFA_NO_LEAN"]
+    ctx_mid = _lib.context_with_env(TRGT_WFA_LEAN_MID_TIER=1)  # (round 5: the optional 128-diagonal tier between the 64- and the 256-diagonal kernels)
     for kind, seed in (("consensus", 1), ("alleles", 2), ("str", 3)):
         pats, txts = F.gen_pairs(np.random.default_rng(900 + seed), 1200, kind)
         for build in (lambda c: W.WFAligner.builder(A.Alignment, S.MemoryUltraLow).affine(2, 5, 1).build(c), lambda c: W.WFAligner.builder(A.Score, S.MemoryUltraLow).edit().build(c)):
-            a, b = build(None), build(ctx_generic)
-            ra, rb = a.align_end_to_end_batch(pats, txts, want_ops=False), b.align_end_to_end_batch(pats, txts, want_ops=False)
-            for f in ("status", "score", "n_match", "span4", "cigar_len"):
-                assert np.array_equal(ra[f], rb[f]), (kind, f)
-            for j in range(len(pats)):  # (the slots of the public ABI are worst-case sized: only the first cigar_len entries of each are written)
-                o, n = int(ra["cigar_off"][j]), int(ra["cigar_len"][j])
-                assert np.array_equal(ra["cigar"][o:o + n], rb["cigar"][o:o + n]), (kind, j)
+            a = build(None)
+            ra = a.align_end_to_end_batch(pats, txts, want_ops=False)
+            for other in (ctx_generic, ctx_mid):
+                rb = build(other).align_end_to_end_batch(pats, txts, want_ops=False)
+                for f in ("status", "score", "n_match", "span4", "cigar_len"):
+                    assert np.array_equal(ra[f], rb[f]), (kind, f)
+                for j in range(len(pats)):  # (the slots of the public ABI are worst-case sized: only the first cigar_len entries of each are written)
+                    o, n = int(ra["cigar_off"][j]), int(ra["cigar_len"][j])
+                    assert np.array_equal(ra["cigar"][o:o + n], rb["cigar"][o:o + n]), (kind, j)

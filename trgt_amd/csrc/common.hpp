@@ -52,6 +52,7 @@ struct trgt_knobs {
   bool no_long_window = false;  // TRGT_NO_LONG_WINDOW: the long reads' alignments skip the seed search (shortcuts, seeded windows)
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool no_lean = false;      // TRGT_WFA_NO_LEAN: consensus alignments / edit distances straight to the generic kernel (no register-resident BiWFA kernel in front)
+  bool lean_mid_tier = false;  // TRGT_WFA_LEAN_MID_TIER: a 128-diagonal tier between the 64- and the 256-diagonal lean kernels (measured slower on cfg5: the tiers' tails add up)
   bool lean_one_tier = false;  // TRGT_WFA_LEAN_ONE_TIER: no second tier (256 diagonals) between the register-resident kernel and the generic one
   bool no_lds_wfa = true;    // TRGT_WFA_LDS=1 turns the LDS-arena variant of the BiWFA kernel on (in front of the HBM-arena one).  Off by default:
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency

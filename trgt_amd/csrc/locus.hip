@@ -1011,6 +1011,8 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
                        (const uint32_t*)g.alen, (const uint64_t*)g.toff, (uint8_t*)g.packed, (int64_t)(2 * nl));
     TRGT_HIP_TRY(c, hipGetLastError());
   }
+  ((uint64_t*)h_cells)[6] = 0;  // wavefront offsets of the device-side consensus / edit-distance launches (timing runs only)
+  if (c->timing && c->wfa_cells_cur[2]) { const int d2h_rc = trgt::d2h(c, (uint64_t*)h_cells + 6, c->wfa_cells_cur[2], 8, c->stream); if (d2h_rc) return d2h_rc; }
   { const int d2h_rc = trgt::d2h(c, h_slab, d_slab, slab.total, c->stream); if (d2h_rc) return d2h_rc; }
   TRGT_HIP_TRY(c, hipEventRecord(evA, c->stream));
   c->dbg_ns[2] = now_ns() - t0;  // + stage A enqueued
@@ -1308,6 +1310,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
     c->k_cells[TRGT_K_WFA_FLANK] += (int64_t)((uint64_t*)h_cells)[1];
     c->k_cells[TRGT_K_WFA_FLANK_REST] += (int64_t)(((uint64_t*)h_cells)[0] - ((uint64_t*)h_cells)[1]);
     c->k_cells[TRGT_K_WFA_FILTER] += (int64_t)((uint64_t*)h_cells)[4];
+    c->k_cells[TRGT_K_WFA] += (int64_t)((uint64_t*)h_cells)[6];
   }
   if (dev_gt) {
     const uint8_t* need = (const uint8_t*)gh.need;

@@ -617,10 +617,13 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_WS_C : L.buffer_set ? S_WFA_WS_B : S_WFA_WS, (size_t)(a.ws_per_block * (uint64_t)blocks), &d_ws))) return rc;
   // job counters | slot flags | 24 words of the lean kernels (statistics, their counters); the offset counter of the batch.  Cleared
   // pieces of the call's zero arena (inside trgt_locus_batch: no hipMemsetAsync per launch), else pool slots cleared here
-  const size_t counter_bytes = 16 + 4 * (size_t)blocks + 96;
+  const size_t counter_bytes = 16 + 4 * (size_t)blocks + 160;  // (+ 40 words of the lean kernels: 3 x 8 statistics, 5 counters)
   const int bset = L.buffer_set == 2 ? 2 : L.buffer_set ? 1 : 0;
   if ((rc = dev_get_zeroed(c, bset == 2 ? S_WFA_COUNTER_C : bset ? S_WFA_COUNTER_B : S_WFA_COUNTER, counter_bytes, &d_counter, c->stream))) return rc;
-  if (!L.keep_cells) {
+  // (buffer set 2 = the device-side chains of a locus call -- consensus repair, cluster genotyper: their launches count into one piece,
+  //  read back once per call for the roofline block of the consensus alignments)
+  const bool chain_keep = bset == 2 && c->zero_on && c->wfa_cells_cur[2] != nullptr;
+  if (!L.keep_cells && !chain_keep) {
     if ((rc = dev_get_zeroed(c, bset == 2 ? S_WFA_CELLS_C : bset ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells, c->stream))) return rc;
     c->wfa_cells_cur[bset] = d_cells;
   } else if (c->wfa_cells_cur[bset]) d_cells = c->wfa_cells_cur[bset];  // a later launch of the same logical batch: keeps counting where the first one did
@@ -695,10 +698,10 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     void* d_retry = nullptr;
     if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)jobs_bound * sizeof(JobDev), &d_retry))) return rc;
     void* d_mid = nullptr;
-    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_MID_C : L.buffer_set ? S_WFA_MID_B : S_WFA_MID, (size_t)jobs_bound * sizeof(JobDev), &d_mid))) return rc;
-    unsigned int* const lean_words = (unsigned int*)d_counter + 4 + blocks;  // [0..15] statistics of the two tiers, [16..18] their counters
+    if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_MID_C : L.buffer_set ? S_WFA_MID_B : S_WFA_MID, 2 * (size_t)jobs_bound * sizeof(JobDev), &d_mid))) return rc;  // (two lists: between tiers one / two and two / three)
+    unsigned int* const lean_words = (unsigned int*)d_counter + 4 + blocks;  // [0..23] statistics of the three tiers, [24..28] their counters
     if ((rc = wfa_lean_launch(c, p, L, (JobDev*)d_mid, (JobDev*)d_retry, (unsigned int*)d_counter + 1, (uint32_t)std::min<int64_t>(jobs_bound, 0xFFFFFFF0ll), (unsigned int*)d_counter + 3,
-                              lean_words + 16, (unsigned long long*)d_cells, c->knobs.debug ? lean_words : nullptr)))
+                              lean_words + 24, (unsigned long long*)d_cells, c->knobs.debug ? lean_words : nullptr)))
       return rc;
     a.jobs = (const JobDev*)d_retry; a.n_jobs_dev = (const uint32_t*)d_counter + 1; a.n_jobs2_dev = nullptr; a.jobs_cap = 0;
     a.counter = (unsigned int*)d_counter + 2;
@@ -751,10 +754,10 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
     unsigned int h[4] = {0, 0, 0, 0};
     TRGT_HIP_TRY(c, trgt::stream_wait(c, c->stream));
     TRGT_HIP_TRY(c, hipMemcpy(h, d_counter, 16, hipMemcpyDeviceToHost));
-    unsigned int w[24];
-    TRGT_HIP_TRY(c, hipMemcpy(w, (unsigned int*)d_counter + 4 + blocks, 96, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[wfa] lean kernels: metric %d, %lld jobs at most, %u went on to the second tier, %u to the generic kernel (%u lost)\n", p.metric, (long long)jobs_bound, w[17], h[1], h[3]);
-    for (int t = 0; t < 2; ++t)
+    unsigned int w[40];
+    TRGT_HIP_TRY(c, hipMemcpy(w, (unsigned int*)d_counter + 4 + blocks, 160, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[wfa] lean kernels: metric %d, %lld jobs at most, %u went on to the second tier, %u to the third, %u to the generic kernel (%u lost)\n", p.metric, (long long)jobs_bound, w[25], w[27], h[1], h[3]);
+    for (int t = 0; t < 3; ++t)
       fprintf(stderr, "[wfa]   tier %d handed on: lengths %u, window %u, range %u, history levels %u, history cells %u, runs %u, stack %u, status %u\n", t + 1,
               w[8 * t + 0], w[8 * t + 1], w[8 * t + 2], w[8 * t + 3], w[8 * t + 4], w[8 * t + 5], w[8 * t + 6], w[8 * t + 7]);
   }

@@ -934,30 +934,40 @@ int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& 
   a.pat_base = L.pat_base; a.txt_base = L.txt_base; a.counter = counters;
   a.status = L.status; a.score = L.score; a.n_match = L.n_match; a.span4 = L.span4; a.cigar = L.cigar; a.cigar_len = L.cigar_len; a.ops_len = L.ops_len;
   a.cells_out = cells_out; a.retry_cap = retry_cap; a.retry_lost = retry_lost; a.why_hist = why_hist;
-  const bool two_tiers = mid_jobs != nullptr && !c->knobs.lean_one_tier;
-  a.retry_jobs = two_tiers ? mid_jobs : retry_jobs; a.retry_count = two_tiers ? counters + 1 : retry_count;
-  constexpr int HC1 = 2816, HL1 = 96, SC1 = 1280, HC2 = 25 * 1024, HL2 = 320, SC2 = 6144, HC2E = 4096, SC2E = 2048;  // (edit distances are score-only on the locus path: no history)
-  void (*const fn)(const lean::Args) = p.metric == 1 ? lean::wfa_lean_kernel<1, 1, HC1, HL1, SC1> : lean::wfa_lean_kernel<3, 1, HC1, HL1, SC1>;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 8; }
+  // Up to three tiers: 64 diagonals per wavefront (NS = 1: nearly every alignment), optionally 128 (NS = 2, round 5), 256 (NS = 4).
+  // mid_jobs holds the two lists between them (retry_cap entries each); counters: [0] tier-one job counter, [1] jobs handed to tier two,
+  // [2] its counter, [3] jobs handed to tier three, [4] its counter.
+  const bool more_tiers = mid_jobs != nullptr && !c->knobs.lean_one_tier;
+  // (the middle tier is OFF unless TRGT_WFA_LEAN_MID_TIER=1.  Measured on cfg5, round 5: a launch over what tier one hands on is as long
+  //  as its slowest alignment -- 0.5 to 0.9 ms for a read of one allele against the backbone of the other, whatever the number of
+  //  strips -- and the tiers run one behind the other, so a third kernel ADDS its tail: one-context call 10.1 -> 10.8 ms.)
+  const bool mid_tier = more_tiers && c->knobs.lean_mid_tier;
+  JobDev* const mid2_jobs = mid_jobs ? mid_jobs + retry_cap : nullptr;
+  a.retry_jobs = more_tiers ? mid_jobs : retry_jobs; a.retry_count = more_tiers ? counters + 1 : retry_count;
+  constexpr int HC1 = 2816, HL1 = 96, SC1 = 1280, HCM = 8 * 1024, HLM = 192, SCM = 3072, HC2 = 25 * 1024, HL2 = 320, SC2 = 6144, HCME = 2048, SCME = 2048, HC2E = 4096, SC2E = 2048;  // (edit distances are score-only on the locus path: no history)
   const int64_t bound = L.jobs_bound > 0 ? L.jobs_bound : L.n_jobs_host;
-  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(bound, (int64_t)c->num_cus * occ));
-  if (c->knobs.debug) fprintf(stderr, "[wfa] lean kernel: metric %d, at most %lld jobs, occupancy %d, grid %lld\n", p.metric, (long long)bound, occ, (long long)grid);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
-  hipError_t le = hipGetLastError();
-  if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "lean alignment kernel launch failed: %s", hipGetErrorString(le));
-  if (two_tiers) {
+  auto launch = [&](void (*fn)(const lean::Args), const lean::Args& args, int occ_default, const char* what) -> int {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 64, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = occ_default; }
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(bound, (int64_t)c->num_cus * occ));
+    if (c->knobs.debug) fprintf(stderr, "[wfa] lean kernel (%s): metric %d, at most %lld jobs, occupancy %d, grid %lld\n", what, p.metric, (long long)bound, occ, (long long)grid);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(64), 0, c->stream, args);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "lean alignment kernel (%s) launch failed: %s", what, hipGetErrorString(le));
+    return TRGT_OK;
+  };
+  if (int rc = launch(p.metric == 1 ? lean::wfa_lean_kernel<1, 1, HC1, HL1, SC1> : lean::wfa_lean_kernel<3, 1, HC1, HL1, SC1>, a, 8, "64 diagonals")) return rc;
+  if (more_tiers) {
     lean::Args b = a;
     b.jobs = mid_jobs; b.n_jobs_dev = counters + 1; b.n_jobs = 0; b.counter = counters + 2;
     b.stage = !(no_stage & 2); b.chunk = 1;
-    b.retry_jobs = retry_jobs; b.retry_count = retry_count; b.why_hist = why_hist ? why_hist + 8 : nullptr;
-    void (*const fn2)(const lean::Args) = p.metric == 1 ? lean::wfa_lean_kernel<1, 4, HC2E, HL2, SC2E> : lean::wfa_lean_kernel<3, 4, HC2, HL2, SC2>;
-    int occ2 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, fn2, 64, 0) != hipSuccess || occ2 < 1) { (void)hipGetLastError(); occ2 = 2; }
-    const int64_t grid2 = std::max<int64_t>(1, std::min<int64_t>(bound, (int64_t)c->num_cus * occ2));
-    hipLaunchKernelGGL(fn2, dim3((unsigned)grid2), dim3(64), 0, c->stream, b);
-    le = hipGetLastError();
-    if (le != hipSuccess) return fail(c, TRGT_ERR_HIP, "lean alignment kernel (second tier) launch failed: %s", hipGetErrorString(le));
+    if (mid_tier) {
+      b.retry_jobs = mid2_jobs; b.retry_count = counters + 3; b.why_hist = why_hist ? why_hist + 8 : nullptr;
+      if (int rc = launch(p.metric == 1 ? lean::wfa_lean_kernel<1, 2, HCME, HLM, SCME> : lean::wfa_lean_kernel<3, 2, HCM, HLM, SCM>, b, 4, "128 diagonals")) return rc;
+      b.jobs = mid2_jobs; b.n_jobs_dev = counters + 3; b.counter = counters + 4;
+    }
+    b.retry_jobs = retry_jobs; b.retry_count = retry_count; b.why_hist = why_hist ? why_hist + 16 : nullptr;
+    if (int rc = launch(p.metric == 1 ? lean::wfa_lean_kernel<1, 4, HC2E, HL2, SC2E> : lean::wfa_lean_kernel<3, 4, HC2, HL2, SC2>, b, 2, "256 diagonals")) return rc;
   }
 #ifdef TRGT_LEAN_PROF
   {
