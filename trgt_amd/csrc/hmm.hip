@@ -2020,13 +2020,17 @@ void trgt::hmm_pending_free(HmmPending* p) { delete p; }
 // hmm_collect then copies counts, total and the first HMM_PACKED_FIRST bytes of the packed spans in ONE go -- the host used to wait for
 // the counts, build the offsets, upload them, launch the compaction and wait again (0.5 ms of a 10k-locus call's tail).
 constexpr size_t HMM_PACKED_FIRST = 1u << 20;
-static int pack_behind_kernels(trgt_hip_ctx* c, trgt::HmmPending* P, const uint64_t* tight_off_host, int64_t n_jobs, void* d_bp, uint64_t bp_bytes,
-                               const int32_t* d_spans, const uint32_t* d_nsp, int so) {
-  void* d_tabs = nullptr;
+// (the offsets of the per-job span lists go up on `up` BEFORE the kernels are enqueued -- with the job list, on the copy stream in the
+//  slots path -- and not behind them on the batch's stream, where that upload sat on the critical path of every call's tail: round 5)
+static int pack_tables_upload(trgt_hip_ctx* c, const uint64_t* tight_off_host, int64_t n_jobs, int so, hipStream_t up, void** d_tabs) {
   int rc;
-  if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16 + 16, &d_tabs))) return rc;
+  if ((rc = dev_get(c, S_HMM_MOTIFS + so, (size_t)n_jobs * 16 + 16, d_tabs))) return rc;
+  uint64_t* d_toff = (uint64_t*)*d_tabs + (n_jobs + 1);
+  return h2d_small(c, d_toff, tight_off_host, (size_t)n_jobs * 8, up, S_HMM_MOTIFS + so);
+}
+static int pack_behind_kernels(trgt_hip_ctx* c, trgt::HmmPending* P, void* d_tabs, int64_t n_jobs, void* d_bp, uint64_t bp_bytes,
+                               const int32_t* d_spans, const uint32_t* d_nsp, int so) {
   uint64_t* d_poff = (uint64_t*)d_tabs; uint64_t* d_toff = d_poff + (n_jobs + 1);
-  if ((rc = h2d_small(c, d_toff, tight_off_host, (size_t)n_jobs * 8, c->stream, S_HMM_MOTIFS + so))) return rc;
   hipLaunchKernelGGL(hmm_span_prefix_kernel, dim3(1), dim3(1024), 0, c->stream, d_nsp, d_poff, (uint64_t)n_jobs);
   hipLaunchKernelGGL(hmm_pack_spans_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, c->stream, d_spans, (const uint64_t*)d_toff, d_nsp,
                      (const uint64_t*)d_poff, (int32_t*)d_bp, (uint64_t)n_jobs);
@@ -2171,6 +2175,8 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     std::memcpy(h_jobs, jobs.data(), jobs.size() * sizeof(HmmJobDev));
     if ((rc = h2d_small(c, d_jobs, h_jobs, jobs.size() * sizeof(HmmJobDev), c->stream, -1))) return rc;
   }
+  void* d_pack_tabs = nullptr;
+  if (P->spans_on_host && (rc = pack_tables_upload(c, tight_off.data(), n_jobs, so, c->stream, &d_pack_tabs))) return rc;
   if ((rc = o_path.init(c, S_HMM_PATH + so, path, (size_t)path_total))) return rc;
   if ((rc = o_plen.init(c, S_HMM_PLEN + so, path_len, (size_t)n_jobs))) return rc;
   if (spans_on_host) {
@@ -2265,7 +2271,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
       TRGT_HIP_TRY(c, hipEventRecord(c->hmm_join[sidx], c->hmm_side[sidx]));
       TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->hmm_join[sidx], 0));
     }
-  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), tight_off.data(), n_jobs, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
+  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), d_pack_tabs, n_jobs, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();
   return TRGT_OK;
 }
@@ -2345,6 +2351,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       (rc = dev_get(c, S_HMM_VISITS + so, (size_t)visit_total * 4, &d_visits)))
     return rc;
   HmmJobDev* const d_cand = (HmmJobDev*)d_jobs;
+  void* d_pack_tabs = nullptr;
   HmmJobDev* const d_list = d_cand + n_cand;
   // counts | histogram | places taken (64 + 4096 bytes, cleared): a piece of the call's zero arena when there is one
   void* const z_count = zero_take(c, 64 + 4096);
@@ -2354,6 +2361,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
      // has run, and hold up every copy issued after it (the next batch's reads)
     hipStream_t us = c->stream_copy ? c->stream_copy : c->stream;
     if ((rc = h2d_small(c, d_cand, h_cand, jobs_bytes, us, -1))) return rc;
+    if (P->spans_on_host && (rc = pack_tables_upload(c, P->tight_off.data(), n_slots, so, us, &d_pack_tabs))) return rc;
     if (us != c->stream) {
       if (!c->ev_upload) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
       TRGT_HIP_TRY(c, hipEventRecord(c->ev_upload, us));
@@ -2478,7 +2486,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
     TRGT_HIP_TRY(c, hipGetLastError());
   }
   tl_mark(c, "hmm slots: classes launched");
-  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), P->tight_off.data(), n_slots, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
+  if (P->spans_on_host && (rc = pack_behind_kernels(c, P.get(), d_pack_tabs, n_slots, d_bp, bp_total, o_spans.dev, o_nsp.dev, so))) return rc;
   *out_pending = P.release();
   return TRGT_OK;
 }

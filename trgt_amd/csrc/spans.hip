@@ -375,17 +375,42 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
   const int lane = threadIdx.x & 63;
   const uint64_t n_reads = a.n_jobs >> 1;
   const uint64_t r_begin = (uint64_t)blockIdx.x * SCAN_READS_PER_WG, r_end = r_begin + SCAN_READS_PER_WG < n_reads ? r_begin + SCAN_READS_PER_WG : n_reads;
-  for (uint64_t r = r_begin + (threadIdx.x >> 6); r < r_end; r += 4) {
-  const int F = a.flank_len, n = (int)a.read_len[r];
-  const uint64_t po0 = a.piece_off[2 * (uint64_t)a.read_locus[r]], po1 = a.piece_off[2 * (uint64_t)a.read_locus[r] + 1];
+  // What a read's search needs before its first byte can be looked at -- length, offset, locus, the locus' two piece offsets, the
+  // pieces' first eight bytes -- is a chain of four dependent loads, and with one read at a time per wave that chain (not instruction
+  // issue, not bandwidth) was most of this kernel's time: 300 k reads x ~5 us / 4 k resident waves.  Round 5: lane j fetches it all for
+  // the wave's j-th read up front (four rounds of loads per wave instead of per read); the loop takes it from that lane.
+  const int F = a.flank_len;
+  const bool h8 = F >= 8;
+  uint32_t pf_n = 0, pf_h0 = 0, pf_h1 = 0, pf_h20 = 0, pf_h21 = 0, pf_heavy = 0;
+  uint64_t pf_roff = 0, pf_po0 = 0, pf_po1 = 0;
+  {
+    const uint64_t rj = r_begin + (threadIdx.x >> 6) + 4ull * (uint64_t)lane;
+    if (lane < SCAN_READS_PER_WG / 4 && rj < r_end) {
+      pf_n = a.read_len[rj]; pf_roff = a.read_off[rj];
+      const uint64_t loc = a.read_locus[rj];
+      pf_po0 = a.piece_off[2 * loc]; pf_po1 = a.piece_off[2 * loc + 1];
+      if (a.heavy_len) pf_heavy = a.heavy_len[loc];
+      if ((int)pf_n >= F) {
+        pf_h0 = load_u32(a.flank_blob + pf_po0); pf_h1 = load_u32(a.flank_blob + pf_po1);
+        if (h8) { pf_h20 = load_u32(a.flank_blob + pf_po0 + 4); pf_h21 = load_u32(a.flank_blob + pf_po1 + 4); }
+      }
+    }
+  }
+  auto from_lane32 = [](uint32_t v, int j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+  auto from_lane64 = [&](uint64_t v, int j) -> uint64_t { return (uint64_t)from_lane32((uint32_t)v, j) | ((uint64_t)from_lane32((uint32_t)(v >> 32), j) << 32); };
+  int slot = 0;
+  for (uint64_t r = r_begin + (threadIdx.x >> 6); r < r_end; r += 4, ++slot) {
+  const int n = (int)from_lane32(pf_n, slot);
+  const uint64_t po0 = from_lane64(pf_po0, slot), po1 = from_lane64(pf_po1, slot);
   const uint8_t* __restrict__ piece[2] = {a.flank_blob + po0, a.flank_blob + po1};
-  const uint8_t* __restrict__ read = a.read_blob + a.read_off[r];
+  const uint64_t r_off = from_lane64(pf_roff, slot);
+  const uint32_t heavy_r = from_lane32(pf_heavy, slot);
+  const uint8_t* __restrict__ read = a.read_blob + r_off;
   int found[2] = {-1, -1};
   if (n >= F) {
     const int last = n - F;  // last candidate start
-    const uint32_t head[2] = {load_u32(piece[0]), load_u32(piece[1])};
-    const bool h8 = F >= 8;
-    const uint32_t head2[2] = {h8 ? load_u32(piece[0] + 4) : 0u, h8 ? load_u32(piece[1] + 4) : 0u};
+    const uint32_t head[2] = {from_lane32(pf_h0, slot), from_lane32(pf_h1, slot)};
+    const uint32_t head2[2] = {from_lane32(pf_h20, slot), from_lane32(pf_h21, slot)};
     const int nd = F >> 2;   // full dwords of a piece
     for (int base = 0; base <= last && (found[0] < 0 || found[1] < 0); base += 1024) {
       const int off = base + 16 * lane;
@@ -448,10 +473,10 @@ __global__ void __launch_bounds__(256) flank_scan_wide_kernel(const ScanArgs a) 
       a.pos[j] = found[side]; a.n_match[j] = -1;
       if (found[side] < 0) {  // fall back to the wavefront aligner (span_locater.rs:13-26)
         JobDev jd;
-        jd.pat_off = side ? po1 : po0; jd.txt_off = a.read_off[r];
+        jd.pat_off = side ? po1 : po0; jd.txt_off = r_off;
         jd.cigar_off = 0; jd.ops_off = 0; jd.pat_len = (uint32_t)F; jd.txt_len = (uint32_t)n; jd.out_index = (uint32_t)j; jd.pad = 0;
         if ((uint32_t)n > a.long_tlen) a.wfa_jobs_long[atomicAdd(a.wfa_count + SC_LONG, 1u)] = jd;  // rare: straight to the second list
-        else if (!a.heavy_len || (uint32_t)n < a.heavy_len[a.read_locus[r]]) l_jobs[atomicAdd(&l_n, 1u)] = jd;
+        else if (!a.heavy_len || (uint32_t)n < heavy_r) l_jobs[atomicAdd(&l_n, 1u)] = jd;
         else l_jobs[2 * SCAN_READS_PER_WG - 1 - atomicAdd(&l_n2, 1u)] = jd;
       }
     }
