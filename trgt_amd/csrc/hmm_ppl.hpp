@@ -22,10 +22,13 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
   const int lo = (int)(u & 0xFFFFFFFFull), hi = (int)(u >> 32);
-  const int slo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  const int shi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // (bound_ctrl: a lane without a source reads 0 -- only lane 0 of a wave shift, whose value no position uses -- so the move needs no
+  //  "old" operand and the compiler no copy in front of it)
+  const int slo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  const int shi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
 }
+__device__ __forceinline__ double shr1(double x) { return dpp_f64<0x138>(x); }  // the value of the lane before (wave_shr:1; lane 0: 0.0)
 
 // maximum over the G lanes of a job (G a power of two, jobs aligned to G): xor-1, xor-2 inside a quad, mirror inside 8 and 16 lanes by
 // DPP; the last one or two steps of jobs of 32 / 64 lanes through the crossbar
@@ -42,7 +45,7 @@ __device__ __forceinline__ double group_max(double v, int lane) {
 
 // ... and the minimum of a small integer over the same lanes
 template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
 template <int G>
 __device__ __forceinline__ int group_min_i32(int v, int lane) {
   v = min(v, dpp_i32<0xB1>(v));
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     double val = own, cand = NINF;
     if (steps <= 3) {
       for (int t = 0; t < steps; ++t) {
-        cand = (wave_shr1_f64(val) + lp_step);
+        cand = (shr1(val) + lp_step);
         val = max_f64(cand, own);
       }
     } else {
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       // no lane of the wave, the values -- and the candidates of that iteration -- are the final ones.  A deletion run rarely beats the
       // match states for more than a few positions, so a 60-base motif takes a handful of iterations instead of 59.
       for (int t = 0; t < steps; ++t) {
-        cand = (wave_shr1_f64(val) + lp_step);
+        cand = (shr1(val) + lp_step);
         const double nv = max_f64(cand, own);
         const bool changed = nv != val;
         val = nv;
@@ -244,10 +247,10 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     p_m += inc_m; p_i += inc_i; p_d += inc_m; p_s += inc_s; p_x += inc_x;
     // ---- what the next column's emitting states take from the lane before
     m = m_new; iv = i_new; msv = ms_new;
-    mA = wave_shr1_f64(m_new);
-    const double i_sh = wave_shr1_f64(i_new);
+    mA = shr1(m_new);
+    const double i_sh = shr1(i_new);
     iC = is_skip ? m_new : i_sh;
-    dD = wave_shr1_f64(wave_shr1_f64(d_new));
+    dD = shr1(shr1(d_new));
   };
   column(0, std::true_type());
   for (int i = 1; i < Lw; ++i) column(i, std::false_type());
