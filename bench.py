@@ -288,7 +288,7 @@ def compact_line(res, detail_path=None):
             continue
         leg = _pick(r, ("value", "ms_per_step"))
         leg.update(_pick(r.get("config", {}), ("value_single_context", "ms_per_step_single_context", "loci_per_gpu")))
-        leg["roofline"] = _pick(r.get("roofline", {}), ("kernel", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "bound_measured"))
+        leg["roofline"] = _pick(r.get("roofline", {}), ("kernel", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "bound_measured"))
         leg["cpu_baseline"] = (r.get("cpu_baseline") or {}).get("value")
         leg["parity"] = _pick(r.get("parity", {}), ("parity_checked_loci", "mismatches"))
         legs[k] = leg
@@ -709,7 +709,8 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
         valu_insts = None  # VALU wave-instructions per launch of the same kernel, from the committed SQ counters
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("loci_per_gpu") == n_loci and tj.get("config", 2) == args.config and dom in tj["kernels"]:
+            tj = tj.get("configs", {}).get(str(args.config), tj)  # (config 2 at the top level, the others under "configs")
+            if tj.get("loci_per_gpu") == n_loci and tj.get("config", args.config) == args.config and dom in tj["kernels"]:
                 traffic = int(tj["kernels"][dom]["bytes_per_launch"])
                 valu_insts = tj["kernels"][dom].get("valu_wave_insts_per_launch")
         except (OSError, ValueError, KeyError):

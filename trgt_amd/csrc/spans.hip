@@ -131,9 +131,11 @@ constexpr int WIN_SEGMENTS_DEFAULT = 8;  // (4, 6 and 8 are instantiated; TRGT_W
 // is a superset of the exact occurrences, which is all the argument needs -- a chance match (4^-12 per position) can only widen
 // the window or make the spread test fail.
 template <int WIN_SEGMENTS>
+__device__ __forceinline__ void piece_window_heads(const uint8_t* __restrict__ read, int n, const uint64_t (&h)[WIN_SEGMENTS], const uint32_t (&h3)[WIN_SEGMENTS], int q, int lane,
+                                                   int& kmin_out, int& kmax_out);
+template <int WIN_SEGMENTS>
 __device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, int n, const uint8_t* __restrict__ piece, int q, int lane,
                                              int& kmin_out, int& kmax_out) {
-  int kmin = 0x7FFFFFFF, kmax = -0x7FFFFFFF;
   uint64_t h[WIN_SEGMENTS]; uint32_t h3[WIN_SEGMENTS];
 #pragma unroll
   for (int i = 0; i < WIN_SEGMENTS; ++i) {  // (all loads in flight together)
@@ -141,6 +143,13 @@ __device__ __forceinline__ void piece_window(const uint8_t* __restrict__ read, i
     h[i] = (uint64_t)load_u32(seg + 4) << 32 | load_u32(seg);
     h3[i] = load_u32(seg + 8);
   }
+  piece_window_heads<WIN_SEGMENTS>(read, n, h, h3, q, lane, kmin_out, kmax_out);
+}
+// ... with the twelve head bytes of every segment already in registers (flank_window_kernel fetches them for all jobs of a wave up front)
+template <int WIN_SEGMENTS>
+__device__ __forceinline__ void piece_window_heads(const uint8_t* __restrict__ read, int n, const uint64_t (&h)[WIN_SEGMENTS], const uint32_t (&h3)[WIN_SEGMENTS], int q, int lane,
+                                                   int& kmin_out, int& kmax_out) {
+  int kmin = 0x7FFFFFFF, kmax = -0x7FFFFFFF;
   const int last = n - 12;  // last start of a twelve-base match
   for (int base = 0; base <= last; base += 1024) {
     const int off = base + 16 * lane;
@@ -236,12 +245,42 @@ __global__ void __launch_bounds__(256) flank_window_kernel(const WindowArgs a) {
     if (threadIdx.x == 0) { l_nw = 0; l_nr = 0; l_ns = 0; l_ni = 0; l_nl = 0; }
     __syncthreads();
     const uint32_t c1 = c0 + per_wg < n_light ? c0 + per_wg : n_light;
-    for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4) {
+    // (a job is a chain of dependent loads -- the job, the heads of its piece's segments, the read -- and a wave walks up to sixteen of
+    //  them: lane j fetches the first two links for the wave's j-th job up front, as the scan does, round 5)
+    uint64_t pf_pat = 0, pf_txt = 0, pf_cig = 0, pf_ops = 0;
+    uint32_t pf_plen = 0, pf_tlen = 0, pf_oi = 0, pf_pad = 0, pf_hlo[WIN_SEGMENTS], pf_hhi[WIN_SEGMENTS], pf_h3[WIN_SEGMENTS];
+#pragma unroll
+    for (int sg = 0; sg < WIN_SEGMENTS; ++sg) { pf_hlo[sg] = 0; pf_hhi[sg] = 0; pf_h3[sg] = 0; }
+    {
+      const uint32_t ij = c0 + (uint32_t)wave + 4u * (uint32_t)lane;
+      if (lane < WIN_JOBS_PER_WG / 4 && ij < c1) {
+        const JobDev pj = ij >= n_first ? a.long_jobs[ij - n_first] : a.front ? a.wfa_jobs[ij] : a.wfa_jobs[a.jobs_cap - 1u - ij];
+        pf_pat = pj.pat_off; pf_txt = pj.txt_off; pf_cig = pj.cigar_off; pf_ops = pj.ops_off; pf_plen = pj.pat_len; pf_tlen = pj.txt_len; pf_oi = pj.out_index; pf_pad = pj.pad;
+        if (pj.txt_len >= 12u) {
+#pragma unroll
+          for (int sg = 0; sg < WIN_SEGMENTS; ++sg) {
+            const uint8_t* __restrict__ seg = a.flank_blob + pj.pat_off + sg * a.q;
+            pf_hlo[sg] = load_u32(seg); pf_hhi[sg] = load_u32(seg + 4); pf_h3[sg] = load_u32(seg + 8);
+          }
+        }
+      }
+    }
+    auto lane32 = [](uint32_t v, int j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+    auto lane64 = [&](uint64_t v, int j) -> uint64_t { return (uint64_t)lane32((uint32_t)v, j) | ((uint64_t)lane32((uint32_t)(v >> 32), j) << 32); };
+    int slot = 0;
+    for (uint32_t i = c0 + (uint32_t)wave; i < c1; i += 4, ++slot) {
       const bool is_long = i >= n_first;
-      JobDev jd = is_long ? a.long_jobs[i - n_first] : a.front ? a.wfa_jobs[i] : a.wfa_jobs[a.jobs_cap - 1u - i];
+      JobDev jd;
+      jd.pat_off = lane64(pf_pat, slot); jd.txt_off = lane64(pf_txt, slot); jd.cigar_off = lane64(pf_cig, slot); jd.ops_off = lane64(pf_ops, slot);
+      jd.pat_len = lane32(pf_plen, slot); jd.txt_len = lane32(pf_tlen, slot); jd.out_index = lane32(pf_oi, slot); jd.pad = lane32(pf_pad, slot);
       const int n = (int)jd.txt_len, F = a.flank_len;
       int kmin = 1, kmax = 0;
-      if (n >= 12) piece_window<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, a.flank_blob + jd.pat_off, a.q, lane, kmin, kmax);
+      if (n >= 12) {
+        uint64_t h[WIN_SEGMENTS]; uint32_t h3[WIN_SEGMENTS];
+#pragma unroll
+        for (int sg = 0; sg < WIN_SEGMENTS; ++sg) { h[sg] = (uint64_t)lane32(pf_hlo[sg], slot) | ((uint64_t)lane32(pf_hhi[sg], slot) << 32); h3[sg] = lane32(pf_h3[sg], slot); }
+        piece_window_heads<WIN_SEGMENTS>(a.read_blob + jd.txt_off, n, h, h3, a.q, lane, kmin, kmax);
+      }
       // ---- The alignment of a piece that differs from the read by one or two substitutions, without aligning.  All seeds on ONE
       //      diagonal k with the piece inside the read there, d <= hamming_max = min(segments - 1, (o + e - 1) / x, 4) mismatches on it:
       //      every alignment of penalty <= x d < o + e is gap-free, i.e. a diagonal k' with at most d mismatches; those spoil at most
