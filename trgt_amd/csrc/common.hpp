@@ -25,6 +25,7 @@ struct trgt_knobs {
   int flank_threads = 256;   // TRGT_FLANK_THREADS: threads per flank alignment of the back-tracing kernel
   int heavy_band = 96;       // TRGT_HEAVY_BAND: the back-trace of what the pre-filter keeps runs inside the band its penalty allows when that is at most this (0: off)
   int heavy_threads = 0;     // TRGT_HEAVY_THREADS: ... of its launch over the expensive alignments (0: 192 when flank_threads == 256)
+  int band_threads = 64;     // TRGT_BAND_THREADS: ... of the banded back-trace of what the pre-filter keeps (64, 128 or 256)
   int win_threads = 64;      // TRGT_WIN_THREADS: ... of the windowed launch
   int win_segments = 8;      // TRGT_WIN_SEGMENTS: 4 / 6 / 8 segments for the window search
   int grid_per_cu = 0;       // TRGT_WFA_GRID_PER_CU: persistent workgroups per CU of the dedicated kernel (0: occupancy query)

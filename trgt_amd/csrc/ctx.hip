@@ -85,7 +85,7 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
     auto flag = [](const char* name) { const char* e = getenv(name); return e != nullptr && *e != 0 && std::strcmp(e, "0") != 0; };
     k.flank_threads = num("TRGT_FLANK_THREADS", k.flank_threads); k.heavy_threads = num("TRGT_HEAVY_THREADS", 0); k.heavy_band = std::max(0, std::min(num("TRGT_HEAVY_BAND", k.heavy_band), 256));
-    k.win_threads = num("TRGT_WIN_THREADS", k.win_threads); k.win_segments = num("TRGT_WIN_SEGMENTS", k.win_segments);
+    k.win_threads = num("TRGT_WIN_THREADS", k.win_threads); { const int bt = num("TRGT_BAND_THREADS", k.band_threads); k.band_threads = bt == 128 || bt == 256 ? bt : 64; } k.win_segments = num("TRGT_WIN_SEGMENTS", k.win_segments);
     k.grid_per_cu = num("TRGT_WFA_GRID_PER_CU", 0); k.filter_per_cu = num("TRGT_FILTER_PER_CU", 0);
     k.one_launch = flag("TRGT_WFA_ONE_LAUNCH"); k.no_spec = flag("TRGT_WFA_NO_SPEC"); k.no_window = flag("TRGT_WFA_NO_WINDOW"); k.no_hamming = flag("TRGT_NO_HAMMING"); k.no_indel_shortcut = flag("TRGT_NO_INDEL_SHORTCUT"); k.no_heavy_window = flag("TRGT_NO_HEAVY_WINDOW"); { const char* e = getenv("TRGT_EARLY_ADAPTIVE"); if (e && *e) k.early_adaptive = std::strcmp(e, "0") != 0; }
     k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.one_stream = flag("TRGT_FLANK_ONE_STREAM"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.host_hmm_lists = flag("TRGT_HOST_HMM_LISTS"); k.no_early = flag("TRGT_WFA_NO_EARLY"); k.stage_lock = flag("TRGT_STAGE_LOCK"); k.no_long_filter = flag("TRGT_NO_LONG_FILTER"); k.no_long_window = flag("TRGT_NO_LONG_WINDOW"); k.filter_one_launch = flag("TRGT_FILTER_ONE_LAUNCH"); k.filter_serial = flag("TRGT_FILTER_SERIAL"); k.filter_side = flag("TRGT_FILTER_SIDE"); k.wfa_no_stage = flag("TRGT_WFA_NO_STAGE"); k.wfa_no_wave_variant = flag("TRGT_WFA_NO_WAVE_VARIANT"); k.hmm_resolve_one_wg = flag("TRGT_HMM_RESOLVE_ONE_WG"); k.debug = flag("TRGT_WFA_DEBUG");

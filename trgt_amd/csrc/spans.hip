@@ -885,7 +885,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       WfaLaunch LB = LH;
       LB.jobs_dev = (const JobDev*)d_band; LB.n_jobs_dev = (const uint32_t*)d_count + SC_BAND;
       LB.max_tlen = (int64_t)p.flank_len + 2 * s_max; LB.max_sum = (int64_t)p.flank_len + LB.max_tlen;
-      LB.score = (int32_t*)d_bscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = 64;
+      LB.score = (int32_t*)d_bscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = c->knobs.band_threads;
       if (two_streams) LB.buffer_set = 1;
       trgt_wfa_params wpb = wp;
       wpb.text_begin_free = 2 * s_max;
@@ -1017,7 +1017,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
           WfaLaunch LB = L2;
           LB.jobs_dev = (const JobDev*)d_lband; LB.n_jobs_dev = (const uint32_t*)d_count + SC_LBAND;
           LB.max_tlen = (int64_t)p.flank_len + 2 * s_max; LB.max_sum = (int64_t)p.flank_len + LB.max_tlen;
-          LB.score = (int32_t*)d_lscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = 64;
+          LB.score = (int32_t*)d_lscore; LB.kernel_tag = 3; LB.max_score = s_max; LB.threads = c->knobs.band_threads;
           trgt_wfa_params wpb = wp;
           wpb.text_begin_free = 2 * s_max;
           if ((rc = wfa_launch(c, wpb, LB))) return rc;

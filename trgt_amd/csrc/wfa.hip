@@ -659,11 +659,14 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   const bool flank_pen = pen.x == 2 && pen.o1 == 5 && pen.e1 == 1 && a.kp.span == 1 && a.kp.pbf == 0 && a.kp.pef == 0 && a.kp.tef < 0 && !c->knobs.no_spec;
   const bool fast_spec = flank_pen && a.fast_koff == 0 && a.kp.tbf < 0 && (threads == 256 || threads == 192);
   const bool win_spec = flank_pen && a.fast_koff != 0 && (tag == 2 || tag == 3) && threads == 64;  // the windowed launches of trgt_find_spans_batch
-  if (tag == 3 && !win_spec) return fail(c, TRGT_ERR_INVALID, "wfa: the banded launch exists for the flank configuration only");
+  // (TRGT_BAND_THREADS=256 / 128: the banded back-trace of what the pre-filter keeps with four / two waves per alignment -- its launch is as
+  //  long as its slowest alignment, and a band of 2 s* + 2 s + 1 diagonals is several strips of a wave)
+  const bool band_wide = flank_pen && a.fast_koff != 0 && tag == 3 && (threads == 256 || threads == 128);
+  if (tag == 3 && !win_spec && !band_wide) return fail(c, TRGT_ERR_INVALID, "wfa: the banded launch exists for the flank configuration only");
   void (*const spec_fn[2][3])(const KArgs) = {{wfa_fast_kernel<256, 0>, wfa_fast_kernel<256, 1>, wfa_fast_kernel<256, 2>},
                                               {wfa_fast_kernel<192, 0>, wfa_fast_kernel<192, 1>, wfa_fast_kernel<192, 2>}};
   void (*const gen_fn[3])(const KArgs) = {wfa_fast_kernel<0, 0>, wfa_fast_kernel<0, 1>, wfa_fast_kernel<0, 2>};
-  void (*const fast_fn)(const KArgs) = win_spec ? (tag == 3 ? wfa_fast_kernel<64, 3> : wfa_fast_kernel<64, 2>) : fast_spec ? spec_fn[threads == 192 ? 1 : 0][tag] : gen_fn[tag];
+  void (*const fast_fn)(const KArgs) = band_wide ? (threads == 256 ? wfa_fast_kernel<256, 3> : wfa_fast_kernel<128, 3>) : win_spec ? (tag == 3 ? wfa_fast_kernel<64, 3> : wfa_fast_kernel<64, 2>) : fast_spec ? spec_fn[threads == 192 ? 1 : 0][tag] : gen_fn[tag];
   KTimer t(c, L.timer_slot);
   // `blocks` bounds how many workgroups can be resident (one workspace slot each); the grid covers all jobs
   int64_t grid_blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, L.n_jobs_host));
