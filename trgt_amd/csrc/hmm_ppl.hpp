@@ -156,6 +156,23 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { Lw = max(Lw, __shfl_xor(Lw, o)); steps = max(steps, __shfl_xor(steps, o)); }
   Lw = __builtin_amdgcn_readfirstlane(Lw); steps = __builtin_amdgcn_readfirstlane(steps);
+  // Deletion chains of jobs of 8 / 16 lanes (a job lies inside one row of sixteen lanes): chain state k is max(own_k, d_(k-1) + c_k), i.e.
+  // max over j <= k of own_j + c_(j+1) + ... + c_k summed in that order.  Instead of walking the lanes (a DPP move, an add and a max per
+  // step, each waiting for the one before), lane j adds its OWN way down the chain -- T(t) = T(t-1) + c_(j+t), t additions that depend on
+  // nothing but each other -- and lane k takes T(t) of the lane t places before it by a row rotation, all rotations independent of one
+  // another.  Same sums in the same order (the rounding of an addition is monotone, so the maximum may be taken before or after), same
+  // strict comparison against the own candidates.  c_(j+t) is -inf from the first lane of the next block / job on, so sums that would
+  // leave the block -- and the values a rotation wraps around the row -- are -inf.
+  constexpr int CT = G <= 8 ? 6 : G <= 16 ? 14 : 0;   // chain steps a job of G lanes can need (motif length - 1)
+  double cstep[CT > 0 ? CT : 1];
+  if constexpr (CT > 0) {
+#pragma unroll
+    for (int t = 1; t <= CT; ++t) {
+      const double v = __longlong_as_double(((long long)__shfl_down((int)((unsigned long long)__double_as_longlong(lp_step) >> 32), t) << 32) |
+                                            (unsigned)__shfl_down((int)((unsigned long long)__double_as_longlong(lp_step) & 0xFFFFFFFFull), t));
+      cstep[t - 1] = lane + t < 64 ? v : NINF;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
   // scores of the column before (final): my match / insertion state, my block's start
@@ -199,15 +216,39 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     const double own = max_f64(o0, o1);
     int bp_d = o1 > o0 ? 1 : 0;
     double val = own, cand = NINF;
-    if (steps <= 3) {
+    if constexpr (CT > 0) {
+      double T = own;
+      auto step = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        T = (T + cstep[t - 1]);
+        cand = max_f64(cand, dpp_f64<0x120 + t>(T));   // row_ror:t -- the lane t places before me, inside my row
+      };
+      // (the step count of the wave is a scalar: a chain of uniform branches, no loop-carried DPP control)
+      if (steps >= 1) step(std::integral_constant<int, 1>());
+      if (steps >= 2) step(std::integral_constant<int, 2>());
+      if (steps >= 3) step(std::integral_constant<int, 3>());
+      if (steps >= 4) step(std::integral_constant<int, 4>());
+      if (steps >= 5) step(std::integral_constant<int, 5>());
+      if (steps >= 6) step(std::integral_constant<int, 6>());
+      if constexpr (CT > 6) {
+        if (steps >= 7) step(std::integral_constant<int, 7>());
+        if (steps >= 8) step(std::integral_constant<int, 8>());
+        if (steps >= 9) step(std::integral_constant<int, 9>());
+        if (steps >= 10) step(std::integral_constant<int, 10>());
+        if (steps >= 11) step(std::integral_constant<int, 11>());
+        if (steps >= 12) step(std::integral_constant<int, 12>());
+        if (steps >= 13) step(std::integral_constant<int, 13>());
+        if (steps >= 14) step(std::integral_constant<int, 14>());
+      }
+      val = max_f64(cand, own);
+    } else if (steps <= 3) {
       for (int t = 0; t < steps; ++t) {
         cand = (shr1(val) + lp_step);
         val = max_f64(cand, own);
       }
     } else {
       // long motifs: the chain is a fixed-point iteration (every lane takes max(own, the lane before + ln p)): once an iteration changes
-      // no lane of the wave, the values -- and the candidates of that iteration -- are the final ones.  A deletion run rarely beats the
-      // match states for more than a few positions, so a 60-base motif takes a handful of iterations instead of 59.
+      // no lane of the wave, the values -- and the candidates of that iteration -- are the final ones.
       for (int t = 0; t < steps; ++t) {
         cand = (shr1(val) + lp_step);
         const double nv = max_f64(cand, own);
