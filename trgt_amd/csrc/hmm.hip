@@ -358,7 +358,7 @@ __device__ unsigned long long g_hmm_prof[16];
 #define HP_LONG_DECL
 #define HP_LONG(i)
 #endif
-constexpr int HMM_LONG_MIN = 1536;   // columns from which an allele's trace-back goes to hmm_traceback_long_kernel
+constexpr int HMM_LONG_MIN = 1536;   // columns from which an allele's trace-back goes to hmm_traceback_long_kernel (round 5, tried 512: the cfg3 call 9.5 -> 9.3 ms, but the hundreds of 0.5-2 kb VNTR alleles of a cfg4 step through the many-wave kernel 9.1 -> 11.5 ms)
 constexpr int HMM_LONG_CHUNK = 64;   // columns per chunk map there
 constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer columns during traceback (one-wave models)
 // ... models of several waves (rows of 80 to 320 bytes) stage 16 columns at a time: 1 KB held five columns of a 192-state model, and every
