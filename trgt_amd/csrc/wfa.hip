@@ -698,6 +698,9 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   const bool one_wave_biwfa = a.kp.biwfa && p.span == 0 && threads == 64 && !L.ops && a.fast_wcap == 0 && !L.n_jobs2_dev;
   const bool lean_ok = one_wave_biwfa && !c->knobs.no_lean && (p.metric == 1 || (p.metric == 3 && pen.x == 2 && pen.o1 == 5 && pen.e1 == 1));
   if (lean_ok) {
+    // (with a device-side job count the retry list must hold every job the lean kernels may hand on -- n_jobs_host only
+    //  bounds the workgroups then -- so the caller has to say how many there can be; a list that is too short would drop alignments)
+    if (L.n_jobs_dev && L.jobs_bound <= 0) return fail(c, TRGT_ERR_INVALID, "wfa: a launch with a device-side job count needs jobs_bound (the capacity of the hand-over lists)");
     void* d_retry = nullptr;
     if ((rc = dev_get(c, L.buffer_set == 2 ? S_WFA_RETRY_C : L.buffer_set ? S_WFA_RETRY_B : S_WFA_RETRY, (size_t)jobs_bound * sizeof(JobDev), &d_retry))) return rc;
     void* d_mid = nullptr;
