@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
   uint8_t* p_d = kind ? bp0 + st_d : dump;
   uint8_t* p_s = kind && k == 0 ? bp0 + ms_st : dump;
   const int aux_st = pos == 0 ? 1 : pos == 1 ? S - 2 : pos == 2 ? 0 : S - 1;   // run start | run end | start | end
-  uint8_t* p_x = pos < 4 ? bp0 + aux_st : dump;
-  const int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = pos < 4 ? Spad : 0;
+  uint8_t* p_x = has && pos < 4 ? bp0 + aux_st : dump;
+  const int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = has && pos < 4 ? Spad : 0;
   // constant back-pointers of the aux states from column 1 on: run start <- run end (slot 1); start: none; end <- run end (slot 0)
   const int aux_const = pos == 0 ? 1 : pos == 2 ? 0xFF : 0;
   const bool aux_is_re = pos == 1;
@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { Lw = max(Lw, __shfl_xor(Lw, o)); steps = max(steps, __shfl_xor(steps, o)); }
   Lw = __builtin_amdgcn_readfirstlane(Lw); steps = __builtin_amdgcn_readfirstlane(steps);
+  int Lmin = has ? Lj : 0x7FFFFFFF;  // the shortest allele of the wave: up to there no store needs a test of its own
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) Lmin = min(Lmin, __shfl_xor(Lmin, o));
+  Lmin = __builtin_amdgcn_readfirstlane(Lmin);
   // Deletion chains of jobs of 8 / 16 lanes (a job lies inside one row of sixteen lanes): chain state k is max(own_k, d_(k-1) + c_k), i.e.
   // max over j <= k of own_j + c_(j+1) + ... + c_k summed in that order.  Instead of walking the lanes (a DPP move, an add and a max per
   // step, each waiting for the one before), lane j adds its OWN way down the chain -- T(t) = T(t-1) + c_(j+t), t additions that depend on
@@ -182,15 +186,20 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
   const double* const my_em = l_em + lane * 10;
   double em_m = NINF, em_i = NINF;
   int sym1 = 0;
-  auto column = [&](const int i, auto first_tag) {
+  auto refill = [&](const int i) {  // next window of symbol codes (hmm_code: '#' + allele + '#', invalid bases replaced); i a multiple of CODE_WIN
+    for (int q = pos; q < CODE_WIN + 2 && i + q < Lj; q += G) l_code[grp][q] = (uint8_t)hmm_code(seq, i + q, Lj);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int sym = codes[0];
+    sym1 = codes[1];
+    em_m = my_em[sym]; em_i = my_em[5 + sym];
+  };
+  // One column.  FIRST: column 0; STEPS: the wave's deletion-chain steps as a compile-time number (8- and 16-lane jobs: the column is
+  // then ONE basic block the scheduler can fill) or -1 (a loop); GUARD: stores tested against the job's own length (the columns beyond
+  // the wave's shortest allele)
+  auto column = [&](const int i, auto first_tag, auto steps_tag, auto guard_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if ((i & (CODE_WIN - 1)) == 0) {  // next window of symbol codes (hmm_code: '#' + allele + '#', invalid bases replaced)
-      for (int q = pos; q < CODE_WIN + 2 && i + q < Lj; q += G) l_code[grp][q] = (uint8_t)hmm_code(seq, i + q, Lj);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      const int sym = codes[0];
-      sym1 = codes[1];
-      em_m = my_em[sym]; em_i = my_em[5 + sym];
-    }
+    constexpr int STEPS = decltype(steps_tag)::value;
+    constexpr bool GUARD = decltype(guard_tag)::value;
     const int w = i & (CODE_WIN - 1);
     const double e_m = em_m, e_i = em_i;
     // (terms of the next column, symbol of the one after: their LDS round trips are not waited for in this column)
@@ -220,26 +229,16 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       double T = own;
       auto step = [&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        T = (T + cstep[t - 1]);
-        cand = max_f64(cand, dpp_f64<0x120 + t>(T));   // row_ror:t -- the lane t places before me, inside my row
+        if constexpr (t <= STEPS) {
+          T = (T + cstep[t - 1]);
+          cand = max_f64(cand, dpp_f64<0x120 + t>(T));   // row_ror:t -- the lane t places before me, inside my row
+        }
       };
-      // (the step count of the wave is a scalar: a chain of uniform branches, no loop-carried DPP control)
-      if (steps >= 1) step(std::integral_constant<int, 1>());
-      if (steps >= 2) step(std::integral_constant<int, 2>());
-      if (steps >= 3) step(std::integral_constant<int, 3>());
-      if (steps >= 4) step(std::integral_constant<int, 4>());
-      if (steps >= 5) step(std::integral_constant<int, 5>());
-      if (steps >= 6) step(std::integral_constant<int, 6>());
-      if constexpr (CT > 6) {
-        if (steps >= 7) step(std::integral_constant<int, 7>());
-        if (steps >= 8) step(std::integral_constant<int, 8>());
-        if (steps >= 9) step(std::integral_constant<int, 9>());
-        if (steps >= 10) step(std::integral_constant<int, 10>());
-        if (steps >= 11) step(std::integral_constant<int, 11>());
-        if (steps >= 12) step(std::integral_constant<int, 12>());
-        if (steps >= 13) step(std::integral_constant<int, 13>());
-        if (steps >= 14) step(std::integral_constant<int, 14>());
-      }
+      step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>()); step(std::integral_constant<int, 3>());
+      step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>()); step(std::integral_constant<int, 6>());
+      step(std::integral_constant<int, 7>()); step(std::integral_constant<int, 8>()); step(std::integral_constant<int, 9>());
+      step(std::integral_constant<int, 10>()); step(std::integral_constant<int, 11>()); step(std::integral_constant<int, 12>());
+      step(std::integral_constant<int, 13>()); step(std::integral_constant<int, 14>());
       val = max_f64(cand, own);
     } else if (steps <= 3) {
       for (int t = 0; t < steps; ++t) {
@@ -282,7 +281,7 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     int bp_x;
     if constexpr (FIRST) bp_x = pos == 0 ? bp_rs : pos == 1 ? bp_re : pos == 2 ? 0xFE : 0xFF;
     else bp_x = aux_is_re ? bp_re : aux_const;
-    if (i < Lj) {
+    if (!GUARD || i < Lj) {
       *p_m = (uint8_t)bp_m; *p_i = (uint8_t)bp_i; *p_d = (uint8_t)bp_d; *p_s = (uint8_t)bp_s; *p_x = (uint8_t)bp_x;
     }
     p_m += inc_m; p_i += inc_i; p_d += inc_m; p_s += inc_s; p_x += inc_x;
@@ -293,8 +292,37 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     iC = is_skip ? m_new : i_sh;
     dD = shr1(shr1(d_new));
   };
-  column(0, std::true_type());
-  for (int i = 1; i < Lw; ++i) column(i, std::false_type());
+  auto run = [&](auto steps_tag) {
+    refill(0);
+    column(0, std::true_type(), steps_tag, std::true_type());
+    int i = 1;
+    while (i < Lw) {
+      if ((i & (CODE_WIN - 1)) == 0) refill(i);
+      const int seg_end = min(Lw, (i | (CODE_WIN - 1)) + 1), safe_end = min(seg_end, Lmin);
+      for (; i < safe_end; ++i) column(i, std::false_type(), steps_tag, std::false_type());
+      for (; i < seg_end; ++i) column(i, std::false_type(), steps_tag, std::true_type());
+    }
+  };
+  if constexpr (CT == 0) run(std::integral_constant<int, -1>());
+  else {
+    // (one copy of the loop per chain length: the step count is the wave's, a scalar)
+    switch (steps) {
+      case 0: run(std::integral_constant<int, 0>()); break;
+      case 1: run(std::integral_constant<int, 1>()); break;
+      case 2: run(std::integral_constant<int, 2>()); break;
+      case 3: run(std::integral_constant<int, 3>()); break;
+      case 4: run(std::integral_constant<int, 4>()); break;
+      case 5: run(std::integral_constant<int, 5>()); break;
+      case 6: run(std::integral_constant<int, 6>()); break;
+      default:
+        if constexpr (CT > 6) {
+          if (steps <= 8) run(std::integral_constant<int, 8>());
+          else if (steps <= 10) run(std::integral_constant<int, 10>());
+          else run(std::integral_constant<int, 14>());
+        }
+        break;
+    }
+  }
 }
 
 }  // namespace ppl
