@@ -240,8 +240,9 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       step(std::integral_constant<int, 10>()); step(std::integral_constant<int, 11>()); step(std::integral_constant<int, 12>());
       step(std::integral_constant<int, 13>()); step(std::integral_constant<int, 14>());
       val = max_f64(cand, own);
-    } else if (steps <= 3) {
-      for (int t = 0; t < steps; ++t) {
+    } else if constexpr (STEPS >= 0) {  // (jobs of 32 / 64 lanes, short motifs: the walk along the lanes, its length known when compiled)
+#pragma unroll
+      for (int t = 0; t < STEPS; ++t) {
         cand = (shr1(val) + lp_step);
         val = max_f64(cand, own);
       }
@@ -303,8 +304,18 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       for (; i < seg_end; ++i) column(i, std::false_type(), steps_tag, std::true_type());
     }
   };
-  if constexpr (CT == 0) run(std::integral_constant<int, -1>());
-  else {
+  if constexpr (CT == 0) {
+    switch (steps) {  // (short motifs: one loop copy per chain length; longer ones: the fixed-point loop)
+      case 0: run(std::integral_constant<int, 0>()); break;
+      case 1: run(std::integral_constant<int, 1>()); break;
+      case 2: run(std::integral_constant<int, 2>()); break;
+      case 3: run(std::integral_constant<int, 3>()); break;
+      case 4: run(std::integral_constant<int, 4>()); break;
+      case 5: run(std::integral_constant<int, 5>()); break;
+      case 6: run(std::integral_constant<int, 6>()); break;
+      default: run(std::integral_constant<int, -1>()); break;
+    }
+  } else {
     // (one copy of the loop per chain length: the step count is the wave's, a scalar)
     switch (steps) {
       case 0: run(std::integral_constant<int, 0>()); break;
