@@ -444,8 +444,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   extern __shared__ __align__(16) unsigned char lds_all[];
   if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
   const bool four_rounds = (lds_per_job >> 31) != 0u;  // (TRGT_HMM_FOUR_ROUNDS, see the register fill)
-  const bool ppl_filled = ((lds_per_job >> 30) & 1u) != 0u;  // the back-pointers of sets with ppl_lanes are there already (hmm_fill_ppl_kernel ran in front)
-  lds_per_job &= 0x3FFFFFFFu;
+  const bool ppl_filled = ((lds_per_job >> 30) & 1u) != 0u;
+  const int long_min = ((lds_per_job >> 24) & 0x3Fu) ? (int)((lds_per_job >> 24) & 0x3Fu) * 256 : HMM_LONG_MIN;  // (by the size of the class, hmm_long_min)  // the back-pointers of sets with ppl_lanes are there already (hmm_fill_ppl_kernel ran in front)
+  lds_per_job &= 0x00FFFFFFu;
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
   const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
@@ -1057,7 +1058,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   HP_FILL_END;
   HP_MARK(1);
   // long alleles are traced back by hmm_traceback_long_kernel (many waves per allele, behind this launch on the same stream)
-  if (long_list && job.map_off && L >= HMM_LONG_MIN) {
+  if (long_list && job.map_off && L >= long_min) {
     hmm_sync_mem(sync_n);
     if (tid == 0) long_list[1 + atomicAdd(long_list, 1u)] = jidx;
     return;
@@ -1801,9 +1802,13 @@ __global__ void __launch_bounds__(1024) hmm_span_prefix_kernel(const uint32_t* _
 
 
 // ---- host side of the long trace-back: room for the chunk maps of a job that may be long, and the launch behind a class's fill kernel
-static inline uint64_t hmm_map_words(uint32_t S, uint64_t max_len) {
+// From how many columns on an allele's trace-back goes to the many-wave kernel: 1 536 in a class of thousands of jobs (every long job
+// costs that kernel three launches' worth of chunk maps: the hundreds of 0.5-2 kb VNTR alleles of a catalog step were 27 % slower
+// through it), 512 in a small class (a pathogenic catalog: the one lane of the fill kernel chasing 1 500 columns was 1.2 ms of a call).
+static inline uint32_t hmm_long_min(uint64_t class_jobs) { return class_jobs <= 256 ? 512u : (uint32_t)HMM_LONG_MIN; }  // (2 048 was too many: the 2 000 VNTR candidates of a cfg4 step, 9.2 -> 10.6 ms)
+static inline uint64_t hmm_map_words(uint32_t S, uint64_t max_len, uint32_t long_min) {
   const uint64_t L = max_len + 2;
-  if (L < (uint64_t)HMM_LONG_MIN) return 0;
+  if (L < (uint64_t)long_min) return 0;
   const uint64_t n_chunks = (L + HMM_LONG_CHUNK - 1) / HMM_LONG_CHUNK;
   return n_chunks * (3ull * S + 8ull) + 8;
 }
@@ -2086,6 +2091,12 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
   jobs.resize((size_t)n_jobs);
   uint64_t bp_total = 0, visit_total = 0, seq_total = 0, span_total = 0, count_total = 0, path_total = 0;
   int64_t cells = 0;
+  auto set_class_of = [&](const HmmSetDev& sd_) { return sd_.S <= 32 ? 0u : (std::max(sd_.S, sd_.n_lanes) + 63) / 64; };
+  uint64_t class_jobs[32] = {};
+  for (int64_t j = 0; j < n_jobs; ++j) {
+    if ((int32_t)job_set[j] >= n_sets) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: job %lld bad set", (long long)j);
+    class_jobs[std::min<uint32_t>(set_class_of(sets[job_set[j]]), 31u)] += 1;
+  }
   for (int64_t j = 0; j < n_jobs; ++j) {
     if ((int32_t)job_set[j] >= n_sets) return fail(c, TRGT_ERR_INVALID, "trgt_hmm_batch: job %lld bad set", (long long)j);
     const HmmSetDev& sd = sets[job_set[j]];
@@ -2097,7 +2108,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     const uint64_t spad = (sd.S + 15) & ~15u;
     jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)seq_len[j] + 2), 16);  // (16 bytes in front of the rows: where the position-per-lane fill sends the stores of roles a lane does not have)
     jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
-    { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, seq_len[j]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
+    { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, seq_len[j], hmm_long_min(class_jobs[std::min<uint32_t>(set_class_of(sd), 31u)])); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);
     if (spans3) span_total = std::max<uint64_t>(span_total, span_off[j] + seq_len[j] + 1);
     count_total = std::max<uint64_t>(count_total, count_off[j] + (sd.n_blocks - 1));
@@ -2235,10 +2246,11 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u), (const uint32_t*)nullptr, d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)nullptr, d_long_cls)
     // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
     uint32_t* d_long_cls = nullptr;
-    if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)HMM_LONG_MIN) {
+    const uint32_t long_min_cls = hmm_long_min(e - i);
+    if (!c->knobs.hmm_no_long_tb && (uint64_t)maxq + 2 >= (uint64_t)long_min_cls) {
       if (void* z = zero_take(c, ((size_t)nj + 16) * 4)) d_long_cls = (uint32_t*)z;  // [count | job indices] of this class, the count cleared
       else {
         void* dl = nullptr;
@@ -2338,7 +2350,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
         jd.seq_off = in.seq_off[sl]; jd.path_off = 0; jd.span_off = span_off[sl]; jd.count_off = count_off[sl];
         jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)in.cap[l] + 2), 16);  // room for the longest allele the locus can have (+ the dump slot of hmm_fill_ppl_kernel)
         jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)in.cap[l] + 2);
-        { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, in.cap[l]); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
+        { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, in.cap[l], hmm_long_min(class_n[k])); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
       }
     }
   }
@@ -2444,11 +2456,12 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u), (const uint32_t*)(d_count + k), d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)(d_count + k), d_long_cls)
     uint32_t* d_long_cls = nullptr;
     uint32_t max_cap_cls = 0;
     for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
-    if (!c->knobs.hmm_no_long_tb && (uint64_t)max_cap_cls + 2 >= (uint64_t)HMM_LONG_MIN) {
+    const uint32_t long_min_cls = hmm_long_min(class_n[k]);
+    if (!c->knobs.hmm_no_long_tb && (uint64_t)max_cap_cls + 2 >= (uint64_t)long_min_cls) {
       if (void* z = zero_take(c, ((size_t)nj + 16) * 4)) d_long_cls = (uint32_t*)z;  // [count | job indices] of this class, the count cleared
       else {
         void* dl = nullptr;
