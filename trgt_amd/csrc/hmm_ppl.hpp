@@ -249,7 +249,13 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     } else {
       // long motifs: the chain is a fixed-point iteration (every lane takes max(own, the lane before + ln p)): once an iteration changes
       // no lane of the wave, the values -- and the candidates of that iteration -- are the final ones.
-      for (int t = 0; t < steps; ++t) {
+      // (four steps per convergence test: the test and its branch cost as much as a step)
+      for (int t = 0; t < steps; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          cand = (shr1(val) + lp_step);
+          val = max_f64(cand, own);
+        }
         cand = (shr1(val) + lp_step);
         const double nv = max_f64(cand, own);
         const bool changed = nv != val;
