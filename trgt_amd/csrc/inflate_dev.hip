@@ -154,10 +154,12 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
                 if (nlit > 286 || ndist > 30) { want = EV_ERROR; break; }
                 for (int i = 0; i < 19; ++i) sh.lens[i] = 0;
                 for (uint32_t i = 0; i < ncode; ++i) { refill(); sh.lens[RFL(kClOrder[i])] = (uint8_t)take(3); }
+                if (in_pos > in_len + 8) { want = EV_ERROR; break; }  // (a truncated stream: the header ran past the input -- ADVICE r4)
                 // the code-length code (19 symbols, at most 7 bits), decoded canonically from counts kept in the distance arrays
                 if (!prepare_codes(sh.lens, 19, sh.dist_cnt, sh.dist_sym, sh.code, false, sh.offs, sh.next)) { want = EV_ERROR; break; }
                 uint32_t idx = 0; bool bad = false;
                 while (idx < nlit + ndist) {
+                  if (in_pos > in_len + 8) { bad = true; break; }  // (the window's room covers an intact header only: stop at the end of the input)
                   refill();
                   int l; const int sym = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, l);
                   if (sym < 0) { bad = true; break; }
