@@ -1721,9 +1721,13 @@ __global__ void __launch_bounds__(256) hmm_resolve_count_kernel(const HmmResolve
       if (on && al == 1u && i > 0 && a.cand[i - 1].job_index == slot - 1u && a.allele_len[slot - 1u] == a.allele_len[slot]) {
         const uint8_t* p = a.seq_blob + a.cand[i - 1].seq_off; const uint8_t* q = a.seq_blob + a.cand[i].seq_off;
         const uint32_t n = a.allele_len[slot];
+        // (eight bases per step, all steps' loads independent of the compare: byte by byte this was 200 dependent loads per thread and
+        //  0.18 ms between the genotyper and the HMM of every cfg4 call)
+        uint64_t diff = 0;
         uint32_t t = 0;
-        while (t < n && p[t] == q[t]) ++t;
-        d = t == n ? 1 : 0;
+        for (; t + 8 <= n; t += 8) { uint64_t x, y; __builtin_memcpy(&x, p + t, 8); __builtin_memcpy(&y, q + t, 8); diff |= x ^ y; }
+        for (; t < n; ++t) diff |= (uint64_t)(p[t] ^ q[t]);
+        d = diff == 0 ? 1 : 0;
       }
       a.dup[i] = d;
       if (d) v = 0;
