@@ -145,6 +145,10 @@ struct trgt_hip_ctx {
   // side streams of the HMM launches: [0..2] of buffer set 0, [3..5] of buffer set 1 (the second batch of a call runs next to the first)
   hipStream_t hmm_side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t hmm_fork[2] = {nullptr, nullptr}, hmm_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // the position-per-lane fills of ONE class with several group widths run next to each other too (each is as long as its longest allele):
+  // [buffer set][class slot][extra launch] streams and join events, [buffer set][class slot] fork events
+  hipStream_t hmm_ppl_side[2][4][3] = {};
+  hipEvent_t hmm_ppl_join[2][4][3] = {}, hmm_ppl_fork[2][4] = {};
 };
 
 namespace trgt {

@@ -124,6 +124,14 @@ void trgt_hip_destroy(trgt_hip_ctx* c) {
     if (c->hmm_join[i]) (void)hipEventDestroy(c->hmm_join[i]);
   }
   for (int i = 0; i < 2; ++i) if (c->hmm_fork[i]) (void)hipEventDestroy(c->hmm_fork[i]);
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 4; ++k) {
+      for (int g = 0; g < 3; ++g) {
+        if (c->hmm_ppl_side[b][k][g]) { (void)trgt::stream_wait(c, c->hmm_ppl_side[b][k][g]); (void)hipStreamDestroy(c->hmm_ppl_side[b][k][g]); }
+        if (c->hmm_ppl_join[b][k][g]) (void)hipEventDestroy(c->hmm_ppl_join[b][k][g]);
+      }
+      if (c->hmm_ppl_fork[b][k]) (void)hipEventDestroy(c->hmm_ppl_fork[b][k]);
+    }
   if (c->ev_scan) (void)hipEventDestroy(c->ev_scan);
   if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
   if (c->ev_hwin) (void)hipEventDestroy(c->ev_hwin);

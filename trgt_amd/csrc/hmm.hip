@@ -1833,12 +1833,42 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
 // The position-per-lane fill (hmm_ppl.hpp) of one class's job list, in front of the class's trace-back launch on the same stream: one
 // launch per group width the class's sets need (lanes_mask: bit 0 = 8 lanes, 1 = 16, 2 = 32, 3 = 64); a launch walks the whole list
 // and takes the jobs of its width (groups of other widths idle: a wave without a job of its own returns at once).
-static void hmm_launch_ppl(hipStream_t ls, unsigned lanes_mask, const HmmJobDev* d_jobs, const HmmSetDev* d_sets, const uint8_t* d_model, const uint8_t* d_seq,
-                           uint8_t* d_bp, uint32_t nj, const uint32_t* n_jobs_dev) {
-  if (lanes_mask & 1u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-  if (lanes_mask & 2u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-  if (lanes_mask & 4u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-  if (lanes_mask & 8u) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, ls, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+static int hmm_launch_ppl(trgt_hip_ctx* c, int bset, int class_slot, hipStream_t ls, unsigned lanes_mask, const HmmJobDev* d_jobs, const HmmSetDev* d_sets, const uint8_t* d_model,
+                          const uint8_t* d_seq, uint8_t* d_bp, uint32_t nj, const uint32_t* n_jobs_dev) {
+  auto launch = [&](int g, hipStream_t s) {
+    if (g == 0) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+    else if (g == 1) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+    else if (g == 2) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+    else hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+  };
+  // the widest groups on the class's own stream; the other widths (disjoint jobs) next to it on side streams forked off that stream and
+  // joined back into it: one behind the other they added up their tails (a cfg4 class with 32- and 64-lane sets: 0.53 + 0.47 ms in
+  // front of its trace-back)
+  static const bool serial = [] { const char* e = getenv("TRGT_HMM_PPL_SERIAL"); return e && *e && std::strcmp(e, "0") != 0; }();  // (developer switch, read per process)
+  const bool side_ok = !serial && class_slot >= 0 && class_slot < 4 && (lanes_mask & (lanes_mask - 1u)) != 0u;
+  if (!side_ok) {
+    for (int g = 3; g >= 0; --g) if (lanes_mask & (1u << g)) launch(g, ls);
+    return TRGT_OK;
+  }
+  hipEvent_t& f = c->hmm_ppl_fork[bset][class_slot];
+  if (!f) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&f, hipEventDisableTiming));
+  TRGT_HIP_TRY(c, hipEventRecord(f, ls));
+  int n_side = 0;
+  bool first = true;
+  for (int g = 3; g >= 0; --g) {
+    if (!(lanes_mask & (1u << g))) continue;
+    if (first || n_side >= 3) { launch(g, ls); first = false; continue; }
+    hipStream_t& s = c->hmm_ppl_side[bset][class_slot][n_side];
+    hipEvent_t& j = c->hmm_ppl_join[bset][class_slot][n_side];
+    if (!s) TRGT_HIP_TRY(c, trgt::make_side_stream(c, &s));
+    if (!j) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&j, hipEventDisableTiming));
+    TRGT_HIP_TRY(c, hipStreamWaitEvent(s, f, 0));
+    launch(g, s);
+    TRGT_HIP_TRY(c, hipEventRecord(j, s));
+    ++n_side;
+  }
+  for (int i = 0; i < n_side; ++i) TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_ppl_join[bset][class_slot][i], 0));
+  return TRGT_OK;
 }
 static inline unsigned hmm_ppl_bit(const HmmSetDev& sd) { const int g = ppl::lanes_for(sd.ppl_lanes); return g == 8 ? 1u : g == 16 ? 2u : g == 32 ? 4u : g == 64 ? 8u : 0u; }
 
@@ -2263,7 +2293,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
         TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
       }
     }
-    if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, nj, nullptr);
+    if (ppl_mask && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, nj, nullptr))) return rc;
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && cls == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
@@ -2474,7 +2504,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
         TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
       }
     }
-    if (ppl_mask) hmm_launch_ppl(ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, nj, (const uint32_t*)(d_count + k));
+    if (ppl_mask && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, nj, (const uint32_t*)(d_count + k)))) return rc;
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && k == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
