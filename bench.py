@@ -251,8 +251,8 @@ ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 CONFIG_KEYS = ("workload", "baseline_config", "value_streaming", "value_streaming_bam4", "value_single_context", "ms_per_step_single_context",
                "contexts_per_gpu", "loci_per_gpu", "reads_per_locus", "parallelism", "host_cpu_quota")
-E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "write_loci_per_s", "pipeline_loci_per_s",
-            "pipeline_loci_per_s_bam_level_1", "pipeline_vcf_identical")
+E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "write_loci_per_s", "write_loci_per_s_device_deflate",
+            "pipeline_loci_per_s", "pipeline_loci_per_s_bam_level_1", "pipeline_loci_per_s_device_deflate", "pipeline_vcf_identical")
 
 
 def _short(s, n):
@@ -378,6 +378,15 @@ def run_e2e(args, env):
             w.write(b, o)
         w.close()
         t_wr = time.perf_counter() - t0
+        # ... and with the BGZF blocks of the spanning BAM deflated on the GPU (trgt_writer_params.deflate_device, deflate_dev.hip: fixed
+        # Huffman codes, one wave per block; the host threads then only format records and compute CRCs)
+        t0 = time.perf_counter()
+        w = writers.Writer(rd, os.path.join(d, "outd.vcf"), os.path.join(d, "outd.spanning.bam"), deflate_device=env["local_rank"])
+        for b, o in zip(batches, outs):
+            w.write(b, o)
+        w.close()
+        t_wr_dev = time.perf_counter() - t0
+        bam_bytes_host, bam_bytes_dev = os.path.getsize(os.path.join(d, "out.spanning.bam")), os.path.getsize(os.path.join(d, "outd.spanning.bam"))
         vcf_records = sum(1 for line in open(os.path.join(d, "out.vcf")) if not line.startswith("#"))
         # the genotypes against what the data set was made from: allele lengths per locus are {len(allele 0), len(allele 1)} by construction
         # (checked loosely here -- the parity proper is tests/ -- so that a broken hand-over cannot report a rate)
@@ -410,8 +419,8 @@ def run_e2e(args, env):
                 err.append(e)
             q2.put(None)
 
-        def pipeline(tag, dev_inflate, level):
-            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level)
+        def pipeline(tag, dev_inflate, level, dev_deflate=-1):
+            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate)
             t0 = time.perf_counter()
             th = [threading.Thread(target=stage_ingest, args=(dev_inflate,), daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
             for t in th:
@@ -432,7 +441,8 @@ def run_e2e(args, env):
         t_pipe, same = pipeline("out2", -1, 6)           # as rounds 1-3 measured it: host inflate, htslib's BAM level
         t_pipe_fast, same_fast = pipeline("out3", -1, 1)  # the spanning BAM at level 1 (trgt_writer_params.bam_compress_level: a larger file with the same records)
         t_pipe_dev, same_dev = pipeline("out4", dev, 1)   # ... and the BGZF blocks inflated on the GPU
-        same = same and same_dev and same_fast
+        t_pipe_defl, same_defl = pipeline("out5", -1, 6, dev)  # host inflate, the spanning BAM deflated on the GPU
+        same = same and same_dev and same_fast and same_defl
         r = lambda x: round(x, 1)
         return dict(
             workload="%d cfg2-like loci (motif 2-6 bp, 5-40 copies per allele), %d reads of ~%d bases per locus, one contig; BAM %.1f MB (%d reads, %.0f MB of records), written by trgt_amd/synth_bam.py in %.1f s"
@@ -442,6 +452,8 @@ def run_e2e(args, env):
             ingest_loci_per_s_device_inflate=r(n / t_ing_dev), ingest_device_inflate_same_batches=bool(same_batches),
             pipeline_loci_per_s_bam_level_1=r(n / t_pipe_fast), pipeline_loci_per_s_bam_level_1_device_inflate=r(n / t_pipe_dev),
             gpu_loci_per_s=r(n / t_gpu), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
+            write_loci_per_s_device_deflate=r(n / t_wr_dev), pipeline_loci_per_s_device_deflate=r(n / t_pipe_defl),
+            spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
             bound="host: BGZF inflate + record decoding (ingestion) and deflate (spanning BAM); the GPU stage is >10x faster than either, see DESIGN.md")
     finally:

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 8
+#define TRGT_HIP_ABI_VERSION 9
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -390,6 +390,10 @@ typedef struct trgt_writer_params {
                                  deflate its BGZF blocks; the files do not depend on it */
   int32_t bam_compress_level; /* ABI 8: 6 (default: htslib's level for BAM) ... 1 (fast), 0 = stored DEFLATE blocks: the same records in a
                                  larger file, for pipelines whose spanning BAM is transient; the VCF (.gz) always uses 6 */
+  int32_t deflate_device;     /* ABI 9: -1 (default) = the BGZF blocks of the spanning BAM are deflated by zlib on host threads (what htslib does
+                                 for the reference, write_bam.rs:72-144); >= 0 = GPU ordinal: the full blocks of a batch are deflated on that GPU in
+                                 one go (trgt_deflate_blocks: fixed Huffman codes, ratio about zlib's level 1), a block the device declines by zlib.
+                                 The records are the same; the compressed bytes are not zlib's */
 } trgt_writer_params;
 void trgt_writer_default_params(trgt_writer_params* p);
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);
@@ -442,6 +446,16 @@ int32_t trgt_inflate_raw(const uint8_t* in, int64_t n_in, uint8_t* out, int64_t 
  * inflate_device makes the ingestion use it for the blocks of a whole batch of loci at once. */
 int trgt_inflate_blocks(trgt_hip_ctx* ctx, int64_t n_blocks, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len,
                         uint8_t* dst, const uint64_t* dst_off, const uint32_t* dst_len, uint8_t* status);
+
+/* ABI 9 -- device-side BGZF deflate (trgt_amd/csrc/deflate_dev.hip): n_blocks independent raw DEFLATE streams (the payloads of BGZF
+ * blocks: what htslib's bgzf_write / bgzf_flush deflate one by one for bam::Writer, src/trgt/writers/write_bam.rs:72-144), block b
+ * from src + src_off[b] (src_len[b] <= 65536 bytes) into dst + dst_off[b]; dst_off[b] a multiple of 4, the regions at least
+ * dst_cap[b] + 8 bytes apart (the encoder clears and ORs whole words).  dst_len[b] = bytes written (<= dst_cap[b]: ONE final block with
+ * fixed Huffman codes, readable by any inflate), or 0: declined (the encoding does not fit dst_cap[b] -- data that does not compress):
+ * deflate that block with zlib.  src / dst / dst_len host memory.  One wave per block, one slice of the block per lane.  Synchronous.
+ * trgt_writer_params.deflate_device makes the writer use it for the spanning BAM. */
+int trgt_deflate_blocks(trgt_hip_ctx* ctx, int64_t n_blocks, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len,
+                        uint8_t* dst, const uint64_t* dst_off, const uint32_t* dst_cap, uint32_t* dst_len);
 
 /* ------------------------------------------------- synthetic workload */
 typedef struct trgt_synth_params {

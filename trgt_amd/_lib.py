@@ -70,7 +70,7 @@ class LocusBatchOut(C.Structure):
 
 
 EXPORTS = [
-    "trgt_inflate_raw", "trgt_inflate_blocks",
+    "trgt_inflate_raw", "trgt_inflate_blocks", "trgt_deflate_blocks",
     "trgt_hip_abi_version", "trgt_hip_create", "trgt_hip_destroy", "trgt_hip_last_error", "trgt_hip_set_stream",
     "trgt_hip_set_workspace_limit", "trgt_hip_timing_enable", "trgt_hip_timing_reset", "trgt_hip_timing_get",
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",

@@ -244,6 +244,7 @@ enum Slot {
   S_CL_VOUT, S_CL_VLEN, S_CL_VSCR,  // device-side cluster genotyper (locus_cluster_dev.hpp)
   S_INF_SRC, S_INF_DESC, S_INF_DST, S_INF_STATUS, S_INF_COUNTER,  // device-side BGZF inflate (inflate_dev.hip)
   S_ZERO_ARENA,  // trgt::zero_begin / zero_take
+  S_DEFL_SCRATCH,  // device-side BGZF deflate (deflate_dev.hip): the lanes' bit strings
   S_COUNT
 };
 // pinned host buffer slots

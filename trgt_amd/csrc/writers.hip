@@ -52,15 +52,42 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     return true;
   }
   bool block(const uint8_t* d, size_t n) { std::vector<uint8_t> out; return deflate_block(d, n, out, level) && std::fwrite(out.data(), 1, out.size(), f) == out.size(); }
-  // the full blocks of buf: deflated by `threads` workers (a block is independent of its neighbours), written in order
+  // a BGZF block around a payload that is deflated already (trgt_deflate_blocks): header, payload, CRC-32 and size of the data
+  static void frame_block(const uint8_t* d, size_t n, const uint8_t* payload, size_t clen, std::vector<uint8_t>& out) {
+    const size_t total = 18 + clen + 8;
+    out.resize(total);
+    static const uint8_t head[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    std::memcpy(out.data(), head, 16);
+    out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
+    std::memcpy(out.data() + 18, payload, clen);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, nullptr, 0), d, (uInt)n);
+    for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+  }
+  trgt_hip_ctx* dev = nullptr;   // trgt_writer_params.deflate_device: the full blocks of a flush are deflated on this context's GPU
+  std::vector<uint8_t> dev_out; std::vector<uint64_t> dev_soff, dev_doff; std::vector<uint32_t> dev_slen, dev_cap, dev_len;
+  // the full blocks of buf: deflated by `threads` workers (a block is independent of its neighbours) -- or on the GPU in one go, the
+  // workers then only frame them (CRC-32) and deflate what the device declined -- written in order
   bool flush_full_blocks() {
     const size_t nb = buf.size() / 0xFF00;
     if (!nb) return true;
     std::vector<std::vector<uint8_t>> outs(nb);
     std::atomic<size_t> next{0}; std::atomic<int> failed{0};
+    constexpr size_t DEV_SLOT = 0x10000, DEV_CAP = 0xFF00;  // room per block on the device side: payload + 26 must fit a BGZF block; 256 bytes of slack between the regions
+    bool on_dev = false;
+    if (dev && nb >= 16) {  // (a handful of blocks is not worth the round trip)
+      dev_out.resize(nb * DEV_SLOT + 64); dev_soff.resize(nb); dev_doff.resize(nb); dev_slen.assign(nb, 0xFF00u); dev_cap.assign(nb, (uint32_t)DEV_CAP); dev_len.assign(nb, 0u);
+      for (size_t k = 0; k < nb; ++k) { dev_soff[k] = k * 0xFF00; dev_doff[k] = k * DEV_SLOT; }
+      on_dev = trgt_deflate_blocks(dev, (int64_t)nb, buf.data(), dev_soff.data(), dev_slen.data(), dev_out.data(), dev_doff.data(), dev_cap.data(), dev_len.data()) == TRGT_OK;
+    }
     auto work = [&]() {
-      try { for (;;) { const size_t k = next.fetch_add(1); if (k >= nb) break; if (!deflate_block(buf.data() + k * 0xFF00, 0xFF00, outs[k], level)) failed = 1; } }
-      catch (const std::exception&) { failed = 1; }
+      try {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= nb) break;
+          if (on_dev && dev_len[k] > 0 && dev_len[k] + 26u <= 0x10000u) frame_block(buf.data() + k * 0xFF00, 0xFF00, dev_out.data() + dev_doff[k], dev_len[k], outs[k]);
+          else if (!deflate_block(buf.data() + k * 0xFF00, 0xFF00, outs[k], level)) failed = 1;
+        }
+      } catch (const std::exception&) { failed = 1; }
     };
     const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), nb);
     if (nt <= 1) work();
@@ -135,6 +162,8 @@ struct trgt_writer {
   int32_t flank_len = 50;
   int threads = 1;
   std::vector<std::string> contigs;
+  trgt_hip_ctx* dev = nullptr;  // owned: the context of trgt_writer_params.deflate_device
+  ~trgt_writer() { if (dev) trgt_hip_destroy(dev); }
 };
 
 extern "C" {
@@ -143,7 +172,7 @@ const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_s
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0; p->bam_compress_level = 6;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0; p->bam_compress_level = 6; p->deflate_device = -1;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
@@ -155,6 +184,10 @@ static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p,
   w->threads = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
   w->vcf.threads = w->bam.threads = w->threads;
   w->bam.level = std::min(9, std::max(0, p->bam_compress_level));
+  if (p->deflate_device >= 0 && bam_path) {  // the spanning BAM's blocks on the GPU (the VCF stays with zlib: it is small)
+    if (trgt_hip_create(p->deflate_device, &w->dev) != TRGT_OK) { const std::string m = w->dev ? trgt_hip_last_error(w->dev) : "no such device"; if (w->dev) { trgt_hip_destroy(w->dev); w->dev = nullptr; } return bad("deflate_device: " + m); }
+    w->bam.dev = w->dev;
+  }
   const std::string prog = p->program ? p->program : "trgt", ver = p->version ? p->version : "", cl = p->command_line ? p->command_line : "";
   w->sample = p->sample_name ? p->sample_name : "sample";
   for (int32_t i = 0; i < trgt_ingest_n_contigs(src); ++i) w->contigs.push_back(trgt_ingest_contig_name(src, i));
