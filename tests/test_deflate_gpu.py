@@ -70,4 +70,5 @@ def test_writer_with_device_deflate_writes_the_same_records(tmp_path):
     (ht, hr, hrec), (dt, dr, drec) = read_bam_records(paths["host"]), read_bam_records(paths["dev"])
     assert ht == dt and hr == dr and len(hrec) == len(drec) > 400 * 20
     assert hrec == drec
-    assert os.path.getsize(paths["dev"]) < 2.0 * os.path.getsize(paths["host"])   # a fast level's ratio, not a stored file
+    assert os.path.getsize(paths["dev"]) < 2.5 * os.path.getsize(paths["host"])   # a fast level's ratio (against zlib level 6), not a stored file
+    assert open(paths["dev"], "rb").read() != open(paths["host"], "rb").read()    # ... and not zlib's file: the device's blocks are in it

@@ -96,7 +96,11 @@ __global__ void __launch_bounds__(64) deflate_blocks_kernel(const uint8_t* __res
     uint16_t* const t = tab + lane * TAB;
     for (int i = 0; i < TAB; ++i) t[i] = 0xFFFFu;
     BitOut bo; bo.out = my_words; bo.stride = 64;
+    // the lane's window opens one slice before its own: the positions of the slice before are hashed first (nothing is emitted for
+    // them), so that a match may reach back into bytes another lane encodes -- they precede this lane's in the stream all the same
+    const uint32_t win0 = s0 > slice ? s0 - slice : 0u;
     if (fits) {
+      for (uint32_t p = win0; p < s0 && p + 4 <= n; ++p) t[(load32(in + p) * 2654435761u) >> 24] = (uint16_t)(p - win0);
       uint32_t p = s0;
       while (p < s1) {
         uint32_t len = 0, dist = 0;
@@ -104,9 +108,9 @@ __global__ void __launch_bounds__(64) deflate_blocks_kernel(const uint8_t* __res
           const uint32_t w = load32(in + p);
           const uint32_t h = (w * 2654435761u) >> 24;
           const uint32_t c = t[h];
-          t[h] = (uint16_t)(p - s0);
+          t[h] = (uint16_t)(p - win0);
           if (c != 0xFFFFu) {
-            const uint32_t q = s0 + c;
+            const uint32_t q = win0 + c;
             if (load32(in + q) == w) {
               const uint32_t lim = min(258u, s1 - p);
               len = 4;

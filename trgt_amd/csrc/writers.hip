@@ -97,12 +97,15 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)(nb * 0xFF00));
     return true;
   }
-  bool write(const void* d, size_t n) {
+  // append() + one flush() per batch: the flush then sees all the blocks of the batch at once (enough for the workers, or for the device)
+  bool append(const void* d, size_t n) {
     if (!bgzf) return std::fwrite(d, 1, n, f) == n;
     const uint8_t* p = (const uint8_t*)d;
     buf.insert(buf.end(), p, p + n);
-    return flush_full_blocks();
+    return true;
   }
+  bool flush() { return !bgzf || flush_full_blocks(); }
+  bool write(const void* d, size_t n) { return append(d, n) && flush(); }
   bool close() {
     bool ok = true;
     if (f) {
@@ -410,10 +413,12 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
   for (int t = 0; t < nt; ++t) { vcf_bytes += lines[(size_t)t].size(); bam_bytes += recs[(size_t)t].size(); }
   struct Tr { bool on; double t0, t1; int64_t nl; int nt; size_t v, b; decltype(now)& now; ~Tr() { if (on) std::fprintf(stderr, "[writer] %lld loci, %d threads: formatting %.1f ms (%zu B of VCF, %zu B of BAM records), deflate + write %.1f ms\n", (long long)nl, nt, t1 - t0, v, b, now() - t1); } } tr{trace, t0, t1, nl, nt, vcf_bytes, bam_bytes, now};
   for (int t = 0; t < nt; ++t) {  // (what precedes the first failing locus is written, as a serial writer would have)
-    if (!lines[(size_t)t].empty() && !w->vcf.write(lines[(size_t)t].data(), lines[(size_t)t].size())) return bad("cannot write the VCF");
-    if (!recs[(size_t)t].empty() && !w->bam.write(recs[(size_t)t].data(), recs[(size_t)t].size())) return bad("cannot write the BAM");
-    if (!errs[(size_t)t].empty()) return bad(errs[(size_t)t]);
+    if (!lines[(size_t)t].empty() && !w->vcf.append(lines[(size_t)t].data(), lines[(size_t)t].size())) return bad("cannot write the VCF");
+    if (!recs[(size_t)t].empty() && !w->bam.append(recs[(size_t)t].data(), recs[(size_t)t].size())) return bad("cannot write the BAM");
+    if (!errs[(size_t)t].empty()) { w->vcf.flush(); w->bam.flush(); return bad(errs[(size_t)t]); }
   }
+  if (!w->vcf.flush()) return bad("cannot write the VCF");
+  if (!w->bam.flush()) return bad("cannot write the BAM");
   return TRGT_OK;
 }
 
