@@ -22,6 +22,7 @@ namespace trgt {
 namespace defl {
 
 constexpr int TAB = 256;                    // hash entries per lane
+constexpr uint32_t WINDOW_SLICES = 1;       // slices before its own that a lane's window takes in (hashed first, see the kernel; 3 gave 13.0 MB against 13.1)
 constexpr uint32_t SLICE_MAX = 1024;        // bytes per lane at most (64 KB per block)
 constexpr uint32_t WORDS_MAX = 296;         // 32-bit words a lane may produce: 1024 literals of 9 bits = 288 words, + the flush
 
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(64) deflate_blocks_kernel(const uint8_t* __res
     BitOut bo; bo.out = my_words; bo.stride = 64;
     // the lane's window opens one slice before its own: the positions of the slice before are hashed first (nothing is emitted for
     // them), so that a match may reach back into bytes another lane encodes -- they precede this lane's in the stream all the same
-    const uint32_t win0 = s0 > slice ? s0 - slice : 0u;
+    const uint32_t win0 = s0 > WINDOW_SLICES * slice ? s0 - WINDOW_SLICES * slice : 0u;
     if (fits) {
       for (uint32_t p = win0; p < s0 && p + 4 <= n; ++p) t[(load32(in + p) * 2654435761u) >> 24] = (uint16_t)(p - win0);
       uint32_t p = s0;
