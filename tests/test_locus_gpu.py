@@ -455,7 +455,12 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
     for env, val in (("TRGT_WFA_ONE_LAUNCH", "1"), ("TRGT_WFA_NO_SPEC", "1"), ("TRGT_HOST_GENOTYPER", "1"), ("TRGT_HEAVY_THREADS", "256"),
                      ("TRGT_HEAVY_THREADS", "128"), ("TRGT_FLANK_THREADS", "192"), ("TRGT_WFA_NO_WINDOW", "1"), ("TRGT_WIN_SEGMENTS", "4"),
                      ("TRGT_WIN_SEGMENTS", "6"), ("TRGT_WIN_THREADS", "128"), ("TRGT_WFA_NO_FILTER", "1"), ("TRGT_FILTER_PER_CU", "3"), ("TRGT_HEAVY_BAND", "0"), ("TRGT_HEAVY_BAND", "20"),
-                     ("TRGT_HEAVY_BAND", "256")):
+                     ("TRGT_HEAVY_BAND", "256"),
+                     # round 5: other widths of the banded back-trace's workgroups, the per-launch hipMemsetAsync path in place of the
+                     # zero arena, the round-4 HMM fills, the position-per-lane fills of a class one after the other, other claim sizes and
+                     # the 128-diagonal tier of the lean kernel
+                     ("TRGT_BAND_THREADS", "128"), ("TRGT_BAND_THREADS", "256"), ("TRGT_NO_ZERO_ARENA", "1"), ("TRGT_HMM_NO_PPL", "1"),
+                     ("TRGT_HMM_PPL_SERIAL", "1"), ("TRGT_LEAN_CHUNK", "1"), ("TRGT_LEAN_CHUNK", "16"), ("TRGT_WFA_LEAN_MID_TIER", "1")):
         from trgt_amd import _lib
         vctx = _lib.context_with_env(**{env: val})
         try:

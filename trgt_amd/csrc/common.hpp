@@ -54,6 +54,9 @@ struct trgt_knobs {
   bool no_long_filter = false;  // TRGT_NO_LONG_FILTER: long reads straight to the exact kernel (no window-by-window pre-filter)
   bool no_lean = false;      // TRGT_WFA_NO_LEAN: consensus alignments / edit distances straight to the generic kernel (no register-resident BiWFA kernel in front)
   bool lean_mid_tier = false;  // TRGT_WFA_LEAN_MID_TIER: a 128-diagonal tier between the 64- and the 256-diagonal lean kernels (measured slower on cfg5: the tiers' tails add up)
+  int lean_chunk = 0;          // TRGT_LEAN_CHUNK: alignments per claim of the lean kernels' job counter (0: 2, 4 in a pool; edit distances always 8)
+  bool no_zero_arena = false;  // TRGT_NO_ZERO_ARENA: counters and small lists cleared by a hipMemsetAsync each (round 4) instead of one arena clear per call
+  bool hmm_ppl_serial = false; // TRGT_HMM_PPL_SERIAL: the position-per-lane fills of one class one after the other on the class's stream (no side streams)
   bool lean_one_tier = false;  // TRGT_WFA_LEAN_ONE_TIER: no second tier (256 diagonals) between the register-resident kernel and the generic one
   bool no_lds_wfa = true;    // TRGT_WFA_LDS=1 turns the LDS-arena variant of the BiWFA kernel on (in front of the HBM-arena one).  Off by default:
                              // measured on cfg5 it is no faster -- the generic engine spends its time in instructions, not in HBM latency
@@ -311,8 +314,7 @@ static __global__ void zero_arena_kernel(uint4* __restrict__ p, size_t n16) {
 }
 inline int zero_begin(trgt_hip_ctx* c) {
   c->zero_on = false;
-  static const bool off = [] { const char* e = getenv("TRGT_NO_ZERO_ARENA"); return e && *e && std::strcmp(e, "0") != 0; }();
-  if (off) return TRGT_OK;
+  if (c->knobs.no_zero_arena) return TRGT_OK;
   void* p = nullptr;
   if (int rc = dev_get(c, S_ZERO_ARENA, ZERO_ARENA_BYTES, &p)) return rc;
   const bool fresh = p != c->zero_arena;

@@ -1844,8 +1844,7 @@ static int hmm_launch_ppl(trgt_hip_ctx* c, int bset, int class_slot, hipStream_t
   // the widest groups on the class's own stream; the other widths (disjoint jobs) next to it on side streams forked off that stream and
   // joined back into it: one behind the other they added up their tails (a cfg4 class with 32- and 64-lane sets: 0.53 + 0.47 ms in
   // front of its trace-back)
-  static const bool serial = [] { const char* e = getenv("TRGT_HMM_PPL_SERIAL"); return e && *e && std::strcmp(e, "0") != 0; }();  // (developer switch, read per process)
-  const bool side_ok = !serial && class_slot >= 0 && class_slot < 4 && (lanes_mask & (lanes_mask - 1u)) != 0u;
+  const bool side_ok = !c->knobs.hmm_ppl_serial && class_slot >= 0 && class_slot < 4 && (lanes_mask & (lanes_mask - 1u)) != 0u;
   if (!side_ok) {
     for (int g = 3; g >= 0; --g) if (lanes_mask & (1u << g)) launch(g, ls);
     return TRGT_OK;

@@ -930,7 +930,7 @@ int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& 
   // (round 5, cfg5: two per claim measure the same as one for a lone context -- 10.1 ms per call -- and the contexts of a pool, whose claims
   //  meet on the GPU's atomic units, gain 5-8 % with four: 400 -> 440 k loci/s)
   a.chunk = p.metric == 1 ? 8 : c->in_pool ? 4 : 2;
-  { static const int chunk_env = [] { const char* e = getenv("TRGT_LEAN_CHUNK"); return e && *e ? atoi(e) : 0; }(); if (chunk_env > 0 && p.metric != 1) a.chunk = chunk_env; }  // (developer switch: jobs per claim of the consensus alignments)
+  if (c->knobs.lean_chunk > 0 && p.metric != 1) a.chunk = c->knobs.lean_chunk;  // (developer switch: jobs per claim of the consensus alignments)
   a.scope_alignment = p.scope != 0; a.bi_min_score = p.bialign_min_score; a.bi_min_length = p.bialign_min_length;
   a.heur.on = p.heuristic != 0; a.heur.min_len = p.h_min_wavefront_length; a.heur.max_dist = p.h_max_distance_threshold; a.heur.steps = p.h_steps_between_cutoffs;
   a.jobs = L.jobs_dev; a.n_jobs_dev = L.n_jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host;
