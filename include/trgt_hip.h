@@ -321,7 +321,8 @@ typedef struct trgt_ingest_params {
   int32_t keep_bam4;       /* 0; 1 = also fill read_bam4 / read_bam4_off: the clipped reads as 4-bit codes for TRGT_READS_BAM4 */
   int32_t inflate_device;  /* ABI 8: -1 (default) = BGZF blocks are inflated by the worker threads as they meet them; >= 0 = the blocks the .bai
                               names for the loci of the call are read, inflated on that GPU in one batch (trgt_inflate_blocks) and kept for the
-                              workers, which then only decode records; a block the device declines is inflated by the worker that meets it */
+                              workers, which then only decode records; a block the device declines is inflated by the worker that meets it.  A device
+                              that cannot be used (no such GPU, no pinned memory, a device error) fails the call: no silent host-only run */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;

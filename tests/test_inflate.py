@@ -217,3 +217,16 @@ def test_ingestion_with_device_inflate_gives_the_same_batch(tmp_path):
                 assert np.array_equal(x[k], y[k], equal_nan=True) if x[k].dtype.kind == "f" else np.array_equal(x[k], y[k]), k
             elif isinstance(x[k], list):
                 assert x[k] == y[k], k
+
+
+@pytest.mark.gpu
+def test_ingestion_with_an_unusable_inflate_device_fails_the_call(tmp_path):
+    # trgt_ingest_params.inflate_device names a GPU that does not exist: the call fails with a message (no silent host-only run), and the
+    # reader is usable afterwards
+    from trgt_amd import _lib, ingest, synth_bam
+    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=12, read_len=2000)
+    rd = ingest.Reader(ds["bam"], ds["fasta"])
+    with pytest.raises(_lib.TrgtHipError, match="inflate_device 99"):
+        rd.batch(ds["bed"], inflate_device=99)
+    a, b = rd.batch(ds["bed"]), rd.batch(ds["bed"], inflate_device=0)
+    assert a["n_reads"] == b["n_reads"] > 20 and np.array_equal(a["read_blob"], b["read_blob"])

@@ -572,11 +572,12 @@ struct trgt_ingest {
 // The BGZF blocks between the compressed offsets of `ranges` ([first block, last block] pairs from the .bai chunks of the loci of a
 // call): read, inflated on the device in ONE batch (inflate_dev.hip) and left in pinned host memory for the workers.  Blocks the
 // device declines, and blocks beyond what the index names, are inflated by the worker that meets them, as before.
+// (runs next to the workers: its error message goes to `err`, the caller's own string, not to the handle's, which the workers' loci may set)
 static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uint64_t, uint64_t>>& ranges, double share, SharedBlocks& sb,
-                           std::atomic<const SharedBlocks*>& publish, double* ms) {
+                           std::atomic<const SharedBlocks*>& publish, double* ms, std::string& err) {
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  auto bad = [&](const std::string& m) { h->err = m; return TRGT_ERR_INVALID; };
+  auto bad = [&](const std::string& m) { err = m; return TRGT_ERR_INVALID; };
   if (!h->infl_ctx[0] || h->infl_device != device) {
     for (auto*& x : h->infl_ctx) { if (x) trgt_hip_destroy(x); x = nullptr; }
     for (auto*& x : h->infl_ctx)
@@ -893,8 +894,11 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   double t_prefetch = 0.0;
   std::thread prefetch_thread;
   int prefetch_rc = TRGT_OK;
-  struct JoinPrefetch { std::thread& t; ~JoinPrefetch() { if (t.joinable()) t.join(); } } join_prefetch{prefetch_thread};  // (the staging belongs to the handle: never left running)
+  std::string prefetch_err;  // (the thread's own: h->err belongs to this thread while the workers run)
   std::vector<std::pair<uint64_t, uint64_t>> infl_ranges;
+  // (declared after everything the thread refers to: on an unwind it is joined before any of that goes away; the staging belongs to the
+  //  handle and is never left running)
+  struct JoinPrefetch { std::thread& t; ~JoinPrefetch() { if (t.joinable()) t.join(); } } join_prefetch{prefetch_thread};
   if (p->inflate_device >= 0 && nl > 0) {
     infl_lock.lock();  // (one call at a time in this mode)
     for (auto& l : loci) {
@@ -908,8 +912,8 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     const double share = [] { const char* e = std::getenv("TRGT_INGEST_DEVICE_SHARE"); const double v = e && *e ? std::atof(e) : 40.0; return std::min(100.0, std::max(1.0, v)) / 100.0; }();  // (read per call)
     if (!infl_ranges.empty())
       prefetch_thread = std::thread([&]() {
-        try { prefetch_rc = prefetch_blocks(h, p->inflate_device, infl_ranges, share, shared_blocks, shared_pub, &t_prefetch); }
-        catch (const std::exception& e) { h->err = std::string("trgt_ingest: device inflate: ") + e.what(); prefetch_rc = TRGT_ERR_NOMEM; }
+        try { prefetch_rc = prefetch_blocks(h, p->inflate_device, infl_ranges, share, shared_blocks, shared_pub, &t_prefetch, prefetch_err); }
+        catch (const std::exception& e) { prefetch_err = std::string("trgt_ingest: device inflate: ") + e.what(); prefetch_rc = TRGT_ERR_NOMEM; }
       });
   }
   // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
@@ -990,7 +994,9 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   if (nthr <= 1) work();
   else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
   if (prefetch_thread.joinable()) prefetch_thread.join();
-  if (prefetch_rc) return prefetch_rc;
+  // inflate_device was asked for: a device that cannot be used (no such GPU, no pinned memory, a device error) fails the call -- the
+  // workers' results are complete all the same (they inflate what never became ready), but a caller who named a GPU is told it did no work
+  if (prefetch_rc) { h->err = prefetch_err.empty() ? "trgt_ingest: device inflate failed" : prefetch_err; return prefetch_rc; }
   for (auto& l : loci) if (!l.err.empty()) return bad(l.id + ": " + l.err);
   const double t2 = now();
   // ---- the arrays of trgt_locus_batch_in (+ what the writers need per read)
