@@ -1834,12 +1834,14 @@ static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
 // launch per group width the class's sets need (lanes_mask: bit 0 = 8 lanes, 1 = 16, 2 = 32, 3 = 64); a launch walks the whole list
 // and takes the jobs of its width (groups of other widths idle: a wave without a job of its own returns at once).
 static int hmm_launch_ppl(trgt_hip_ctx* c, int bset, int class_slot, hipStream_t ls, unsigned lanes_mask, const HmmJobDev* d_jobs, const HmmSetDev* d_sets, const uint8_t* d_model,
-                          const uint8_t* d_seq, uint8_t* d_bp, uint32_t nj, const uint32_t* n_jobs_dev) {
+                          const uint8_t* d_seq, uint8_t* d_bp, const ppl::PplSegs& segs) {
+  const uint32_t nj = segs.begin[segs.n_seg];  // job slots of the launch
+  if (!nj) return TRGT_OK;
   auto launch = [&](int g, hipStream_t s) {
-    if (g == 0) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-    else if (g == 1) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-    else if (g == 2) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
-    else hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, nj, n_jobs_dev);
+    if (g == 0) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
+    else if (g == 1) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
+    else if (g == 2) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
+    else hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
   };
   // the widest groups on the class's own stream; the other widths (disjoint jobs) next to it on side streams forked off that stream and
   // joined back into it: one behind the other they added up their tails (a cfg4 class with 32- and 64-lane sets: 0.53 + 0.47 ms in
@@ -1869,6 +1871,7 @@ static int hmm_launch_ppl(trgt_hip_ctx* c, int bset, int class_slot, hipStream_t
   for (int i = 0; i < n_side; ++i) TRGT_HIP_TRY(c, hipStreamWaitEvent(ls, c->hmm_ppl_join[bset][class_slot][i], 0));
   return TRGT_OK;
 }
+static inline ppl::PplSegs hmm_ppl_one_segment(uint32_t nj, const uint32_t* n_jobs_dev) { ppl::PplSegs g{}; g.begin[1] = nj; g.n_seg = 1; g.counts = n_jobs_dev; return g; }
 static inline unsigned hmm_ppl_bit(const HmmSetDev& sd) { const int g = ppl::lanes_for(sd.ppl_lanes); return g == 8 ? 1u : g == 16 ? 2u : g == 32 ? 4u : g == 64 ? 8u : 0u; }
 
 // All motif-set models of a batch (host side).  Thread-safe: touches no ctx state.
@@ -2292,7 +2295,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
         TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
       }
     }
-    if (ppl_mask && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, nj, nullptr))) return rc;
+    if (ppl_mask && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets, (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, hmm_ppl_one_segment(nj, nullptr)))) return rc;
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && cls == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);
@@ -2455,16 +2458,36 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
   }
   TRGT_HIP_TRY(c, hipGetLastError());
   tl_mark(c, "hmm slots: resolve launched");
+  // ---- the position-per-lane fills of ALL classes: one launch per group width over the whole list (a segment per class), the widths next
+  //      to each other (hmm_launch_ppl), the classes' trace-backs behind them.  Per class -- up to four launches on as many streams for
+  //      each of up to four classes -- the stage had more streams than HIP has hardware queues, and what shares a queue runs one after
+  //      the other: in a cfg4 trace the second 64-lane fill began 0.7 ms after the stage did (1.47 ms for the stage; 0.57 + 0.3 are its
+  //      longest fill and trace-back).  TRGT_HMM_PPL_PER_CLASS=1: as before.
+  unsigned class_ppl_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all_ppl_mask = 0;
+  if (!c->knobs.hmm_no_ppl)
+    for (uint32_t k = 0; k < 8; ++k) {
+      for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) class_ppl_mask[k] |= hmm_ppl_bit(sets[cand[i].set]);
+      all_ppl_mask |= class_ppl_mask[k];
+    }
+  const bool ppl_merged = all_ppl_mask != 0 && !c->knobs.hmm_ppl_per_class;
+  if (ppl_merged) {
+    ppl::PplSegs segs{};
+    for (int k = 0; k <= 8; ++k) segs.begin[k] = k < 8 ? (uint32_t)class_begin[k] : (uint32_t)n_cand;
+    segs.n_seg = 8; segs.counts = (const uint32_t*)d_count;
+    KTimer tf(c, TRGT_K_HMM, c->stream);
+    if ((rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, 0, c->stream, all_ppl_mask, (const HmmJobDev*)d_list, (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, segs))) return rc;
+    TRGT_HIP_TRY(c, hipGetLastError());
+    tf.stop(0);
+  }
   if (!c->hmm_fork[buffer_set ? 1 : 0]) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->hmm_fork[buffer_set ? 1 : 0], hipEventDisableTiming));
-  TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork[buffer_set ? 1 : 0], c->stream));  // (behind the resolve kernel, in front of the first launch)
+  TRGT_HIP_TRY(c, hipEventRecord(c->hmm_fork[buffer_set ? 1 : 0], c->stream));  // (behind the resolve kernel and the merged fills, in front of the first class launch)
   int n_class = 0;
   unsigned side_used = 0;
   for (uint32_t k = 0; k < 8; ++k) {
     if (!class_n[k]) continue;
     uint32_t maxS = 0, maxnb = 0;
-    unsigned ppl_mask = 0;
-    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) { const HmmSetDev& sd = sets[cand[i].set]; maxS = std::max(maxS, sd.S); maxnb = std::max(maxnb, sd.n_blocks); ppl_mask |= hmm_ppl_bit(sd); }
-    if (c->knobs.hmm_no_ppl) ppl_mask = 0;
+    for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) { const HmmSetDev& sd = sets[cand[i].set]; maxS = std::max(maxS, sd.S); maxnb = std::max(maxnb, sd.n_blocks); }
+    const unsigned ppl_mask = class_ppl_mask[k];
     const bool half = k == 0;
     const size_t lds_job = (hmm_lds_bytes(maxS, maxnb) + 15) & ~(size_t)15;
     const size_t lds = half ? 2 * lds_job : lds_job;
@@ -2503,7 +2526,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
         TRGT_HIP_TRY(c, hipMemsetAsync(d_long_cls, 0, 4, ls));
       }
     }
-    if (ppl_mask && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, nj, (const uint32_t*)(d_count + k)))) return rc;
+    if (ppl_mask && !ppl_merged && (rc = hmm_launch_ppl(c, buffer_set ? 1 : 0, (n_class - 1) & 3, ls, ppl_mask, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, hmm_ppl_one_segment(nj, (const uint32_t*)(d_count + k))))) return rc;
     if (half) { if (regs) TRGT_HMM_LAUNCH(32, true); else TRGT_HMM_LAUNCH(32, false); }
     else if (regs && k == 1) TRGT_HMM_LAUNCH(64, true);
     else TRGT_HMM_LAUNCH(64, false);

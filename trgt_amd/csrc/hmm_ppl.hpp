@@ -62,18 +62,28 @@ __host__ __device__ inline int lanes_for(uint32_t positions) { return positions 
 constexpr int CODE_WIN = 256;   // columns of symbol codes per window (+ 2 look-ahead)
 constexpr int CODE_ROW = 272;
 
+// The job slots of a launch: n_seg segments of one list, segment k = slots [begin[k], begin[k + 1]) of which the first counts[k] hold
+// jobs (counts NULL: all of them).  One class of the host-built list is one segment; the device-resolved list of a locus batch has
+// one segment per class (capacity: the candidates of the class; count: what the resolve kernel kept), filled by ONE launch per width.
+struct PplSegs { uint32_t begin[9]; uint32_t n_seg; const uint32_t* counts; };
+
 template <int G>
 __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
-                                                          const uint8_t* __restrict__ seq_blob, uint8_t* __restrict__ bp_ws, uint32_t n_launch_jobs,
-                                                          const uint32_t* __restrict__ n_jobs_dev) {
+                                                          const uint8_t* __restrict__ seq_blob, uint8_t* __restrict__ bp_ws, const PplSegs segs) {
   constexpr int JPW = 64 / G;
   __shared__ double l_em[64 * 10];            // per lane: emission terms of its match state [5], of its insertion state [5]
   __shared__ uint8_t l_code[JPW][CODE_ROW];   // per job: window of symbol codes
   const int lane = (int)threadIdx.x, grp = lane / G, pos = lane % G, lane_base = grp * G;
-  if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;
   const uint32_t jidx = blockIdx.x * (uint32_t)JPW + (uint32_t)grp;
   const double NINF = -__builtin_huge_val();
-  bool has = jidx < n_launch_jobs;
+  // the segment of the job list this slot lies in, and whether the segment holds a job there (a choice among values: an index into the
+  // kernel argument would move it to scratch memory)
+  uint32_t sb = segs.begin[0], se = segs.begin[1], sk = 0;
+#pragma unroll
+  for (int t = 1; t < 8; ++t) if ((uint32_t)t < segs.n_seg && jidx >= segs.begin[t]) { sb = segs.begin[t]; se = segs.begin[t + 1]; sk = (uint32_t)t; }
+  uint32_t seg_jobs = se - sb;
+  if (segs.counts) seg_jobs = min(seg_jobs, segs.counts[sk]);
+  bool has = jidx >= sb && jidx - sb < seg_jobs;
   HmmJobDev job{}; HmmSetDev set{};
   job.bp_off = 16; set.S = 8; set.n_blocks = 1;
   if (has) {
