@@ -22,8 +22,11 @@ envrun TRGT_HMM_NO_PPL=1 4 40000 $((F + 800000))
 envrun TRGT_HMM_NO_PPL=1 3 1000 $((F + 800000)) 70
 envrun TRGT_NO_ZERO_ARENA=1 4 40000 $((F + 900000))
 envrun TRGT_NO_ZERO_ARENA=1 5 10000 $((F + 900000)) 2000
+envrun TRGT_HMM_PPL_PER_CLASS=1 4 40000 $((F + 1000000))
+envrun TRGT_HMM_PPL_PER_CLASS=1 3 1000 $((F + 1000000)) 70
 python tests/tools/hmm_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/wfa_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/window_fuzz.py 2>&1 | grep RESULT >> $O
 python tests/tools/shortcut_fuzz.py 2>&1 | grep RESULT >> $O
+python tests/tools/deflate_fuzz.py 10000 11 2>&1 | grep deflate_fuzz >> $O
 cat $O
