@@ -89,7 +89,10 @@ int trgt_hip_set_workspace_limit(trgt_hip_ctx* ctx, uint64_t bytes);
 #define TRGT_K_WFA_FLANK_REST 4 /* ... the launch(es) over the remaining fallback alignments */
 #define TRGT_K_WFA_FILTER 5   /* register-resident pre-filter of those expensive alignments (penalty + match bound, no back-trace);
                                  TRGT_K_WFA_FLANK then covers only the alignments the filter keeps */
-#define TRGT_K_COUNT 6
+#define TRGT_K_FLANK_WINDOW 6 /* seed search + seeded windows of the fallback alignments (flank_window_kernel).  A slot of its own since ABI 9: its launches
+                                 sit on the stream next to the pre-filter's and mostly WAIT for that kernel's persistent workgroups (0.08-0.14 ms of work
+                                 bracketed by up to 2.5 ms): event time here is not execution time, and it must not be added to the scan's */
+#define TRGT_K_COUNT 7
 int trgt_hip_timing_enable(trgt_hip_ctx* ctx, int on);
 int trgt_hip_timing_reset(trgt_hip_ctx* ctx);
 /* accumulated device time (ms), number of launches, and DP work items (wavefront offsets / Viterbi cells) */

@@ -851,7 +851,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       if (!c->ev_hwin) TRGT_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_hwin, hipEventDisableTiming));
       WindowArgs wh = window_args();
       wh.front = 1; wh.rest_jobs = (JobDev*)d_noseed;
-      KTimer t(c, TRGT_K_FLANK_SCAN);
+      KTimer t(c, TRGT_K_FLANK_WINDOW);
       launch_window(wh);
       TRGT_HIP_TRY(c, hipGetLastError());
       t.stop(0);
@@ -919,7 +919,7 @@ int find_spans_device(trgt_hip_ctx* c, const trgt_span_params& p, int64_t n_loci
       //  search took 0.34 instead of 0.08 ms)
       if (heavy_window) TRGT_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_hwin, 0));
       {
-        KTimer t(c, TRGT_K_FLANK_SCAN);
+        KTimer t(c, TRGT_K_FLANK_WINDOW);
         WindowArgs wl2 = window_args();
         if (has_long && !c->knobs.no_long_window) {  // the long reads' alignments meet the seed search too: shortcuts and windows do not care how long the read is
           if ((rc = dev_get(c, S_FS_LONGNOSEED, n_jobs * sizeof(JobDev), &d_long_noseed))) return rc;
