@@ -30,16 +30,42 @@ __device__ __forceinline__ double dpp_f64(double x) {
 }
 __device__ __forceinline__ double shr1(double x) { return dpp_f64<0x138>(x); }  // the value of the lane before (wave_shr:1; lane 0: 0.0)
 
+// a DPP move that leaves the lanes of the rows outside ROWS (and lanes without a source) at `ident`
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64_rows(double x, double ident) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x), d = (unsigned long long)__double_as_longlong(ident);
+  const int slo = __builtin_amdgcn_update_dpp((int)(d & 0xFFFFFFFFull), (int)(u & 0xFFFFFFFFull), CTRL, ROWS, 0xF, false);
+  const int shi = __builtin_amdgcn_update_dpp((int)(d >> 32), (int)(u >> 32), CTRL, ROWS, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo));
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xFFFFFFFFull), l), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // maximum over the G lanes of a job (G a power of two, jobs aligned to G): xor-1, xor-2 inside a quad, mirror inside 8 and 16 lanes by
-// DPP; the last one or two steps of jobs of 32 / 64 lanes through the crossbar
+// DPP -- every lane of a row of sixteen then holds the row's maximum.  Jobs of 32 / 64 lanes: the rows are combined by row_bcast:15
+// (lane 15 of a row to the row behind it) and row_bcast:31, and the last row's value comes back to everybody through a scalar register
+// (v_readlane).  No crossbar: the two ds_bpermute round trips of the butterfly's last steps were ~250 cycles of a 64-lane column,
+// twice (this and the minimum below).
 template <int G>
 __device__ __forceinline__ double group_max(double v, int lane) {
   v = max_f64(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
   v = max_f64(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
   v = max_f64(v, dpp_f64<0x141>(v));   // row_half_mirror
   if (G >= 16) v = max_f64(v, dpp_f64<0x140>(v));  // row_mirror
-  if (G >= 32) v = max_f64(v, bperm_f64((lane ^ 16) << 2, v));
-  if (G >= 64) v = max_f64(v, bperm_f64((lane ^ 32) << 2, v));
+  if constexpr (G >= 32) {
+    const double ninf = -__builtin_huge_val();
+    v = max_f64(v, dpp_f64_rows<0x142, 0xA>(v, ninf));  // row_bcast:15 into rows 1 and 3: row 1 = rows 0-1, row 3 = rows 2-3
+    if constexpr (G >= 64) {
+      v = max_f64(v, dpp_f64_rows<0x143, 0xC>(v, ninf));  // row_bcast:31 into rows 2 and 3: row 3 = the wave
+      return readlane_f64(v, 63);
+    } else {
+      const double a = readlane_f64(v, 31), b = readlane_f64(v, 63);
+      return lane < 32 ? a : b;
+    }
+  }
   return v;
 }
 
@@ -52,8 +78,16 @@ __device__ __forceinline__ int group_min_i32(int v, int lane) {
   v = min(v, dpp_i32<0x4E>(v));
   v = min(v, dpp_i32<0x141>(v));
   if (G >= 16) v = min(v, dpp_i32<0x140>(v));
-  if (G >= 32) v = min(v, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, v));
-  if (G >= 64) v = min(v, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v));
+  if constexpr (G >= 32) {  // (the rows combined as in group_max)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x142, 0xA, 0xF, false));
+    if constexpr (G >= 64) {
+      v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x143, 0xC, 0xF, false));
+      return __builtin_amdgcn_readlane(v, 63);
+    } else {
+      const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+      return lane < 32 ? a : b;
+    }
+  }
   return v;
 }
 
@@ -65,7 +99,7 @@ constexpr int CODE_ROW = 272;
 // The job slots of a launch: n_seg segments of one list, segment k = slots [begin[k], begin[k + 1]) of which the first counts[k] hold
 // jobs (counts NULL: all of them).  One class of the host-built list is one segment; the device-resolved list of a locus batch has
 // one segment per class (capacity: the candidates of the class; count: what the resolve kernel kept), filled by ONE launch per width.
-struct PplSegs { uint32_t begin[9]; uint32_t n_seg; const uint32_t* counts; };
+struct PplSegs { uint32_t begin[9]; uint32_t n_seg; const uint32_t* counts; uint32_t first_slot[4], end_slot[4]; };  // [first_slot[g], end_slot[g]): the slots a launch of width 8 << g looks at (the segments that hold such jobs)
 
 template <int G>
 __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
@@ -74,7 +108,8 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
   __shared__ double l_em[64 * 10];            // per lane: emission terms of its match state [5], of its insertion state [5]
   __shared__ uint8_t l_code[JPW][CODE_ROW];   // per job: window of symbol codes
   const int lane = (int)threadIdx.x, grp = lane / G, pos = lane % G, lane_base = grp * G;
-  const uint32_t jidx = blockIdx.x * (uint32_t)JPW + (uint32_t)grp;
+  constexpr int GI = G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3;
+  const uint32_t jidx = segs.first_slot[GI] + blockIdx.x * (uint32_t)JPW + (uint32_t)grp;
   const double NINF = -__builtin_huge_val();
   // the segment of the job list this slot lies in, and whether the segment holds a job there (a choice among values: an index into the
   // kernel argument would move it to scratch memory)
@@ -83,7 +118,7 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
   for (int t = 1; t < 8; ++t) if ((uint32_t)t < segs.n_seg && jidx >= segs.begin[t]) { sb = segs.begin[t]; se = segs.begin[t + 1]; sk = (uint32_t)t; }
   uint32_t seg_jobs = se - sb;
   if (segs.counts) seg_jobs = min(seg_jobs, segs.counts[sk]);
-  bool has = jidx >= sb && jidx - sb < seg_jobs;
+  bool has = jidx >= sb && jidx - sb < seg_jobs && jidx < segs.end_slot[GI];
   HmmJobDev job{}; HmmSetDev set{};
   job.bp_off = 16; set.S = 8; set.n_blocks = 1;
   if (has) {
