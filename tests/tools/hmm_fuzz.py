@@ -86,7 +86,9 @@ def main():
             if kind == "str":
                 ms = [motif(rng, 2, 6)]
             elif kind == "long motifs":
-                ms = [motif(rng, 7, 30) for _ in range(int(rng.integers(1, 4)))]
+                # (one VNTR motif of up to 62 bases: 32- and 64-lane jobs of the position-per-lane fill whose deletion chain goes row by
+                #  row, hmm_ppl.hpp; or a few shorter ones: often more positions than a wave has lanes, the older fill)
+                ms = [motif(rng, 7, 62)] if rng.random() < 0.5 else [motif(rng, 7, 30) for _ in range(int(rng.integers(1, 4)))]
             else:
                 ms = [motif(rng, 1, 12) for _ in range(int(rng.integers(1, 11)))]
             sets.append(ms)

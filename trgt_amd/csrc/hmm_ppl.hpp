@@ -93,6 +93,7 @@ __device__ __forceinline__ int group_min_i32(int v, int lane) {
 
 __host__ __device__ inline int lanes_for(uint32_t positions) { return positions == 0 || positions > 64 ? 0 : positions <= 8 ? 8 : positions <= 16 ? 16 : positions <= 32 ? 32 : 64; }
 
+constexpr int ROW_CHAIN_MIN = 16;  // deletion chains of this many steps and more (jobs of 32 / 64 lanes) go row by row; shorter ones stay a fixed-point walk
 constexpr int CODE_WIN = 256;   // columns of symbol codes per window (+ 2 look-ahead)
 constexpr int CODE_ROW = 272;
 
@@ -222,6 +223,28 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       cstep[t - 1] = lane + t < 64 ? v : NINF;
     }
   }
+  // Jobs of 32 / 64 lanes with long motifs (VNTR loci: the chain of a column really is as long as the motif -- every state off the
+  // alignment's own diagonal is best reached by deleting on from it): the chain in two phases.  (A) inside the rows of sixteen lanes,
+  // the rotations of the narrow jobs (sums that would leave the ROW are -inf); (B) row after row, what enters a row from the last
+  // lane of the row before: every lane adds ITS prefix of the row's steps to that value, one addition per step and no choice --
+  // the steps behind its own are +0.0, which changes no sum (the scores are sums of logarithms: never -0.0).  Same sums in the same
+  // order as the walk along the lanes: the value a row passes on is a maximum of such sums, and rounding is monotone.
+  constexpr bool ROWS = CT == 0;
+  double crow_a[ROWS ? 15 : 1], crow_b[ROWS ? 16 : 1];
+  if constexpr (ROWS) {
+    if (steps >= ROW_CHAIN_MIN) {
+      auto lane_f64 = [&](double x, int src) { return bperm_f64(src << 2, x); };
+#pragma unroll
+      for (int t = 1; t <= 15; ++t) { const double v = lane_f64(lp_step, min(lane + t, 63)); crow_a[t - 1] = (lane & 15) + t <= 15 ? v : NINF; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const double v = lane_f64(lp_step, (lane & ~15) + u); crow_b[u] = u <= (lane & 15) ? v : 0.0; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 15; ++t) crow_a[t] = NINF;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) crow_b[u] = 0.0;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
   // scores of the column before (final): my match / insertion state, my block's start
@@ -285,6 +308,29 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       step(std::integral_constant<int, 10>()); step(std::integral_constant<int, 11>()); step(std::integral_constant<int, 12>());
       step(std::integral_constant<int, 13>()); step(std::integral_constant<int, 14>());
       val = max_f64(cand, own);
+    } else if constexpr (STEPS == -2) {  // (jobs of 32 / 64 lanes, long motifs: rows of sixteen, see crow_a / crow_b)
+      double T = own;
+      auto stepA = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        T = (T + crow_a[t - 1]);
+        cand = max_f64(cand, dpp_f64<0x120 + t>(T));   // row_ror:t
+      };
+      stepA(std::integral_constant<int, 1>()); stepA(std::integral_constant<int, 2>()); stepA(std::integral_constant<int, 3>());
+      stepA(std::integral_constant<int, 4>()); stepA(std::integral_constant<int, 5>()); stepA(std::integral_constant<int, 6>());
+      stepA(std::integral_constant<int, 7>()); stepA(std::integral_constant<int, 8>()); stepA(std::integral_constant<int, 9>());
+      stepA(std::integral_constant<int, 10>()); stepA(std::integral_constant<int, 11>()); stepA(std::integral_constant<int, 12>());
+      stepA(std::integral_constant<int, 13>()); stepA(std::integral_constant<int, 14>()); stepA(std::integral_constant<int, 15>());
+      val = max_f64(cand, own);
+      auto rowB = [&](auto mask_tag) {
+        constexpr int MASK = decltype(mask_tag)::value;
+        double carry = dpp_f64_rows<0x142, MASK>(val, NINF);  // row_bcast:15: the (final) value of the last lane of the row before
+#pragma unroll
+        for (int u = 0; u < 16; ++u) carry = (carry + crow_b[u]);
+        cand = max_f64(cand, carry);
+        val = max_f64(val, carry);
+      };
+      if constexpr (G == 32) rowB(std::integral_constant<int, 0xA>());  // (two jobs per wave: rows 1 and 3 are their second rows)
+      else { rowB(std::integral_constant<int, 0x2>()); rowB(std::integral_constant<int, 0x4>()); rowB(std::integral_constant<int, 0x8>()); }
     } else if constexpr (STEPS >= 0) {  // (jobs of 32 / 64 lanes, short motifs: the walk along the lanes, its length known when compiled)
 #pragma unroll
       for (int t = 0; t < STEPS; ++t) {
@@ -364,7 +410,10 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
       case 4: run(std::integral_constant<int, 4>()); break;
       case 5: run(std::integral_constant<int, 5>()); break;
       case 6: run(std::integral_constant<int, 6>()); break;
-      default: run(std::integral_constant<int, -1>()); break;
+      default:
+        if (steps >= ROW_CHAIN_MIN) run(std::integral_constant<int, -2>());
+        else run(std::integral_constant<int, -1>());
+        break;
     }
   } else {
     // (one copy of the loop per chain length: the step count is the wave's, a scalar)
