@@ -91,6 +91,20 @@ __device__ __forceinline__ int group_min_i32(int v, int lane) {
   return v;
 }
 
+// maximum / minimum of an integer over the wave, to a scalar: row scan by DPP, the rows combined by row_bcast:15 / :31, lane 63 read back
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce_i32(int v) {
+  constexpr int ident = MAX ? (int)0x80000000 : 0x7FFFFFFF;
+  auto op = [](int a, int b) { return MAX ? max(a, b) : min(a, b); };
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112 /* row_shr:2 */, 0xF, 0xF, false));
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114 /* row_shr:4 */, 0xF, 0xF, false));
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118 /* row_shr:8 */, 0xF, 0xF, false));
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false));
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __host__ __device__ inline int lanes_for(uint32_t positions) { return positions == 0 || positions > 64 ? 0 : positions <= 8 ? 8 : positions <= 16 ? 16 : positions <= 32 ? 32 : 64; }
 
 constexpr int ROW_CHAIN_MIN = 16;  // deletion chains of this many steps and more (jobs of 32 / 64 lanes) go row by row; shorter ones stay a fixed-point walk
@@ -103,7 +117,7 @@ constexpr int CODE_ROW = 272;
 struct PplSegs { uint32_t begin[9]; uint32_t n_seg; const uint32_t* counts; uint32_t first_slot[4], end_slot[4]; };  // [first_slot[g], end_slot[g]): the slots a launch of width 8 << g looks at (the segments that hold such jobs)
 
 template <int G>
-__global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
+__global__ void __launch_bounds__(64, (G <= 16 ? 3 : 2)) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
                                                           const uint8_t* __restrict__ seq_blob, uint8_t* __restrict__ bp_ws, const PplSegs segs) {
   constexpr int JPW = 64 / G;
   __shared__ double l_em[64 * 10];            // per lane: emission terms of its match state [5], of its insertion state [5]
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
   uint8_t* p_s = kind && k == 0 ? bp0 + ms_st : dump;
   const int aux_st = pos == 0 ? 1 : pos == 1 ? S - 2 : pos == 2 ? 0 : S - 1;   // run start | run end | start | end
   uint8_t* p_x = has && pos < 4 ? bp0 + aux_st : dump;
-  const int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = has && pos < 4 ? Spad : 0;
+  int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = has && pos < 4 ? Spad : 0;  // (0 once the job's last column is written: see run)
   // constant back-pointers of the aux states from column 1 on: run start <- run end (slot 1); start: none; end <- run end (slot 0)
   const int aux_const = pos == 0 ? 1 : pos == 2 ? 0xFF : 0;
   const bool aux_is_re = pos == 1;
@@ -390,49 +404,60 @@ __global__ void __launch_bounds__(64) hmm_fill_ppl_kernel(const HmmJobDev* __res
     iC = is_skip ? m_new : i_sh;
     dD = shr1(shr1(d_new));
   };
-  auto run = [&](auto steps_tag) {
-    refill(0);
-    column(0, std::true_type(), steps_tag, std::true_type());
-    int i = 1;
-    while (i < Lw) {
-      if ((i & (CODE_WIN - 1)) == 0) refill(i);
-      const int seg_end = min(Lw, (i | (CODE_WIN - 1)) + 1), safe_end = min(seg_end, Lmin);
-      for (; i < safe_end; ++i) column(i, std::false_type(), steps_tag, std::false_type());
-      for (; i < seg_end; ++i) column(i, std::false_type(), steps_tag, std::true_type());
-    }
+  // The columns in segments of SEG: before each one the wave looks at the jobs that still have columns.  Its chain length is THEIR
+  // longest motif's, the stores need no test up to THEIR shortest allele -- a finished job's lanes store to its dump slot from then
+  // on.  (Decided once per wave, a 10-kb allele of a 3-base motif next to a short allele of a 12-base motif paid fourteen rotations
+  // and the guarded -- slower -- column for all of its columns: the 16-lane class of cfg3 3.0 ms.)
+  constexpr int SEG = 128;
+  static_assert(CODE_WIN % SEG == 0, "a segment lies inside one window of symbol codes");
+  int Lmin_live = Lmin;
+  auto run = [&](auto steps_tag, int i, const int seg_end) {
+    const int safe_end = min(seg_end, Lmin_live);
+    if (i == 0) { column(0, std::true_type(), steps_tag, std::true_type()); i = 1; }
+    for (; i < safe_end; ++i) column(i, std::false_type(), steps_tag, std::false_type());
+    for (; i < seg_end; ++i) column(i, std::false_type(), steps_tag, std::true_type());
   };
-  if constexpr (CT == 0) {
-    switch (steps) {  // (short motifs: one loop copy per chain length; longer ones: the fixed-point loop)
-      case 0: run(std::integral_constant<int, 0>()); break;
-      case 1: run(std::integral_constant<int, 1>()); break;
-      case 2: run(std::integral_constant<int, 2>()); break;
-      case 3: run(std::integral_constant<int, 3>()); break;
-      case 4: run(std::integral_constant<int, 4>()); break;
-      case 5: run(std::integral_constant<int, 5>()); break;
-      case 6: run(std::integral_constant<int, 6>()); break;
-      default:
-        if (steps >= ROW_CHAIN_MIN) run(std::integral_constant<int, -2>());
-        else run(std::integral_constant<int, -1>());
-        break;
+  for (int i = 0; i < Lw;) {
+    if ((i & (CODE_WIN - 1)) == 0) refill(i);
+    const int seg_end = min(Lw, (i | (SEG - 1)) + 1);
+    const bool live = has && i < Lj;
+    if (!live) { p_m = dump; p_i = dump; p_d = dump; p_s = dump; p_x = dump; inc_m = 0; inc_i = 0; inc_s = 0; inc_x = 0; }
+    const int st = wave_reduce_i32<true>(live && is_pos ? n - 1 : 0);
+    Lmin_live = wave_reduce_i32<false>(live ? Lj : 0x7FFFFFFF);
+    if constexpr (CT == 0) {
+      switch (st) {  // (short motifs: one loop copy per chain length; longer ones: the fixed-point loop or the rows)
+        case 0: run(std::integral_constant<int, 0>(), i, seg_end); break;
+        case 1: run(std::integral_constant<int, 1>(), i, seg_end); break;
+        case 2: run(std::integral_constant<int, 2>(), i, seg_end); break;
+        case 3: run(std::integral_constant<int, 3>(), i, seg_end); break;
+        case 4: run(std::integral_constant<int, 4>(), i, seg_end); break;
+        case 5: run(std::integral_constant<int, 5>(), i, seg_end); break;
+        case 6: run(std::integral_constant<int, 6>(), i, seg_end); break;
+        default:
+          if (st >= ROW_CHAIN_MIN) run(std::integral_constant<int, -2>(), i, seg_end);
+          else run(std::integral_constant<int, -1>(), i, seg_end);
+          break;
+      }
+    } else {
+      // (one copy of the loop per chain length: the step count is the wave's, a scalar)
+      switch (st) {
+        case 0: run(std::integral_constant<int, 0>(), i, seg_end); break;
+        case 1: run(std::integral_constant<int, 1>(), i, seg_end); break;
+        case 2: run(std::integral_constant<int, 2>(), i, seg_end); break;
+        case 3: run(std::integral_constant<int, 3>(), i, seg_end); break;
+        case 4: run(std::integral_constant<int, 4>(), i, seg_end); break;
+        case 5: run(std::integral_constant<int, 5>(), i, seg_end); break;
+        case 6: run(std::integral_constant<int, 6>(), i, seg_end); break;
+        default:
+          if constexpr (CT > 6) {
+            if (st <= 8) run(std::integral_constant<int, 8>(), i, seg_end);
+            else if (st <= 10) run(std::integral_constant<int, 10>(), i, seg_end);
+            else run(std::integral_constant<int, 14>(), i, seg_end);
+          }
+          break;
+      }
     }
-  } else {
-    // (one copy of the loop per chain length: the step count is the wave's, a scalar)
-    switch (steps) {
-      case 0: run(std::integral_constant<int, 0>()); break;
-      case 1: run(std::integral_constant<int, 1>()); break;
-      case 2: run(std::integral_constant<int, 2>()); break;
-      case 3: run(std::integral_constant<int, 3>()); break;
-      case 4: run(std::integral_constant<int, 4>()); break;
-      case 5: run(std::integral_constant<int, 5>()); break;
-      case 6: run(std::integral_constant<int, 6>()); break;
-      default:
-        if constexpr (CT > 6) {
-          if (steps <= 8) run(std::integral_constant<int, 8>());
-          else if (steps <= 10) run(std::integral_constant<int, 10>());
-          else run(std::integral_constant<int, 14>());
-        }
-        break;
-    }
+    i = seg_end;
   }
 }
 
