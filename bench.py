@@ -251,7 +251,7 @@ ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 CONFIG_KEYS = ("workload", "baseline_config", "value_streaming", "value_streaming_bam4", "value_single_context", "ms_per_step_single_context",
                "contexts_per_gpu", "loci_per_gpu", "reads_per_locus", "parallelism", "host_cpu_quota")
-E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "write_loci_per_s", "write_loci_per_s_device_deflate",
+E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "gpu_loci_per_s_two_contexts", "gpu_loci_per_s_four_contexts", "write_loci_per_s", "write_loci_per_s_device_deflate",
             "pipeline_loci_per_s", "pipeline_loci_per_s_bam_level_1", "pipeline_loci_per_s_device_deflate", "pipeline_vcf_identical")
 
 
@@ -335,7 +335,7 @@ def run_e2e(args, env):
     import shutil
     import tempfile
     import threading
-    from trgt_amd import _lib, ingest, locus, synth_bam, writers
+    from trgt_amd import _lib, ingest, locus, shard, synth_bam, writers
     cores = os.cpu_count() or 8
     n, chunk = args.e2e_loci, 1000
     d = tempfile.mkdtemp(prefix="trgt_e2e_")
@@ -372,6 +372,22 @@ def run_e2e(args, env):
         t0 = time.perf_counter()
         outs = [gpu(v) for v in views]
         t_gpu = time.perf_counter() - t0
+        # ... and the same chunks through a pool of contexts draining them (trgt_locus_batch_many, what `value` is measured with): a
+        # 1 000-locus call is a chain of ~40 latency-bound launches, two or four of them in flight fill each other's gaps
+        t_gpu_pool = {}
+        for n_ctx in (2, 4):
+            pl = _lib.Pool([env["local_rank"]] * n_ctx)
+            try:
+                locus.run_many(pl, views[:n_ctx], params)
+                t0 = time.perf_counter()
+                outs_p, _ = locus.run_many(pl, views, params)
+                t_gpu_pool[n_ctx] = time.perf_counter() - t0
+                for a, b2 in zip(outs, outs_p):
+                    if shard.result_digest(a, int(a.n_alleles.shape[0])) != shard.result_digest(b2, int(b2.n_alleles.shape[0])):
+                        raise SystemExit("bench.py: the e2e chunks through a pool gave different results")
+                del outs_p
+            finally:
+                pl.close()
         t0 = time.perf_counter()
         w = writers.Writer(rd, os.path.join(d, "out.vcf"), os.path.join(d, "out.spanning.bam"))
         for b, o in zip(batches, outs):
@@ -451,7 +467,7 @@ def run_e2e(args, env):
             ingest_loci_per_s=r(n / t_ing), ingest_loci_per_s_one_thread=r(1.0 / t_ing1), ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing),
             ingest_loci_per_s_device_inflate=r(n / t_ing_dev), ingest_device_inflate_same_batches=bool(same_batches),
             pipeline_loci_per_s_bam_level_1=r(n / t_pipe_fast), pipeline_loci_per_s_bam_level_1_device_inflate=r(n / t_pipe_dev),
-            gpu_loci_per_s=r(n / t_gpu), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
+            gpu_loci_per_s=r(n / t_gpu), gpu_loci_per_s_two_contexts=r(n / t_gpu_pool[2]), gpu_loci_per_s_four_contexts=r(n / t_gpu_pool[4]), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
             write_loci_per_s_device_deflate=r(n / t_wr_dev), pipeline_loci_per_s_device_deflate=r(n / t_pipe_defl),
             spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
