@@ -109,7 +109,11 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
   bool close() {
     bool ok = true;
     if (f) {
-      if (bgzf) { if (!buf.empty()) ok = block(buf.data(), buf.size()); buf.clear(); ok = block(nullptr, 0) && ok; }  // + the empty EOF block
+      if (bgzf) {  // what is left: full blocks first (an append without its flush, after an error), then the short one, + the empty EOF block
+        ok = flush_full_blocks();
+        if (!buf.empty()) ok = block(buf.data(), buf.size()) && ok;
+        buf.clear(); ok = block(nullptr, 0) && ok;
+      }
       ok = std::fclose(f) == 0 && ok; f = nullptr;
     }
     return ok;
