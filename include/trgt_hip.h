@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 9
+#define TRGT_HIP_ABI_VERSION 10
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -312,7 +312,8 @@ int trgt_locus_batch_many(trgt_hip_pool* pool, const trgt_locus_params* p, int64
  *   +- flank_len, secondary / supplementary records dropped, rq < min_read_qual dropped and counted, at most 3 * max_depth reads kept
  *   -- beyond that a reservoir driven by StdRng::seed_from_u64(42)), HiFiRead::from_hts_rec (src/trgt/reads/read.rs:98-141: bases, base
  *   qualities, rq / HP tags, 5mC calls of the MM / ML tags per CpG, mismatch offsets of snp.rs:51-79) and clip_reads (tr.rs:186-196 ->
- *   clip_region.rs:19-184, radius 2 * flank_len).  Host code (zlib + the .bai / .fai indexes), loci read by a pool of threads. */
+ *   clip_region.rs:19-184, radius 2 * flank_len).  Host code (zlib + the .bai / .fai indexes), loci read by a pool of threads -- or, with
+ *   trgt_ingest_params.ingest_device, kernels behind the device inflate (the inflated BAM bytes never leave HBM). */
 typedef struct trgt_ingest trgt_ingest;
 typedef struct trgt_ingest_params {
   int32_t flank_len;       /* 250  --flank-len: flanks of the Locus and the search flank of extract_reads */
@@ -322,10 +323,17 @@ typedef struct trgt_ingest_params {
   int32_t genotyper;       /* 0 size, 1 cluster: copied into trgt_ingest_batch::genotyper for every locus */
   int32_t default_ploidy;  /* 2 (the karyotype logic of locus.rs:216-240 stays with the caller: overwrite ploidy[] for X / Y loci) */
   int32_t keep_bam4;       /* 0; 1 = also fill read_bam4 / read_bam4_off: the clipped reads as 4-bit codes for TRGT_READS_BAM4 */
-  int32_t inflate_device;  /* ABI 8: -1 (default) = BGZF blocks are inflated by the worker threads as they meet them; >= 0 = the blocks the .bai
-                              names for the loci of the call are read, inflated on that GPU in one batch (trgt_inflate_blocks) and kept for the
-                              workers, which then only decode records; a block the device declines is inflated by the worker that meets it.  A device
-                              that cannot be used (no such GPU, no pinned memory, a device error) fails the call: no silent host-only run */
+  int32_t ingest_device;   /* ABI 10 (replaces ABI 8's inflate_device, whose inflated bytes went back to the host workers): -1 (default) = the host
+                              path, worker threads with zlib.  >= 0 = GPU ordinal: the BGZF blocks the .bai names for the loci of the call are read
+                              into pinned memory, inflated on that GPU (trgt_inflate_blocks' kernel) with their CRC-32 / ISIZE checked, and the record
+                              walk of extract_reads, the filters, HiFiRead::from_hts_rec (rq / HP / MM / ML tags, mismatch offsets) and clip_to_region
+                              run as kernels on the inflated bytes in HBM (trgt_amd/csrc/ingest_dev.hip): only the clipped reads come back, and the
+                              ASCII read blob stays in HBM as well (trgt_ingest_batch::read_blob_dev) for trgt_locus_batch.  Same arrays, bit for
+                              bit, as the host path.  A call the kernels do not take -- a block that fails its CRC or does not inflate, a record that
+                              leaves its range, a locus with more reads than the reservoir of 3 * max_depth (StdRng's stream runs on the host), MM
+                              strings beyond the kernel's caps -- is redone as a whole by the host path, which yields the data or the error
+                              (trgt_ingest_device_stats counts them).  A device that cannot be used fails the call: no silent host-only run.
+                              Calls from several host threads on one reader overlap (three slots of device state) */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;
@@ -353,6 +361,9 @@ typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch
   const uint8_t* read_bam4; const uint64_t* read_bam4_off; uint64_t read_bam4_bytes;
   /* -- catalog lines that gave no locus: one "Error at BED line N: ..." message each (locus.rs:93-137 reports them and goes on) */
   int64_t n_skipped; const char* skipped_blob; const uint64_t* skipped_off;   /* [n_skipped + 1] offsets into skipped_blob */
+  /* -- ABI 10, with trgt_ingest_params.ingest_device: the ASCII reads once more in HBM of GPU read_blob_device (same bytes and offsets as
+   *    read_blob; owned by the batch): trgt_locus_batch_in::read_blob may point here, nothing is uploaded then.  NULL / -1 otherwise. */
+  const uint8_t* read_blob_dev; int32_t read_blob_device;
   void* owner;
 } trgt_ingest_batch;
 void trgt_ingest_default_params(trgt_ingest_params* p);
@@ -364,7 +375,11 @@ const char* trgt_ingest_last_error(const trgt_ingest* h);
  * stream_loci_into_channel does (src/trgt/locus.rs:93-137) */
 int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, const char* bed_path, int64_t first_locus,
                                    int64_t max_loci, trgt_ingest_batch** out);
-void trgt_ingest_free(trgt_ingest_batch* b);
+void trgt_ingest_free(trgt_ingest_batch* b);   /* batches of a reader are freed before trgt_ingest_close when they hold device memory */
+/* ABI 10: what ingest_device did so far: out[0] calls that asked for the device, [1] of those, calls redone by the host path, [2] the reason of
+ * the last one (1 a BGZF block, 2 the record walk, 3 the reservoir, 4 MM / ML caps), [3] BGZF blocks inflated for the device path, [4] of
+ * those, blocks its kernel declined (zlib took them) */
+void trgt_ingest_device_stats(const trgt_ingest* h, int64_t out[5]);
 
 /* the header of the BAM behind a reader: its text and its reference sequences (what the writers take over) */
 const char* trgt_ingest_header_text(const trgt_ingest* h);

@@ -195,38 +195,3 @@ def test_device_damaged_streams_are_never_inflated_wrongly():
                 ref = None
             assert ref is not None and d.eof and ref == g and len(g) == n_out, kind
     assert ok >= 50
-
-
-@pytest.mark.gpu
-def test_ingestion_with_device_inflate_gives_the_same_batch(tmp_path):
-    from trgt_amd import ingest, synth_bam
-    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=60, read_len=3000)
-    rd = ingest.Reader(ds["bam"], ds["fasta"])
-    a = rd.batch(ds["bed"], keep_bam4=1)
-    b = rd.batch(ds["bed"], keep_bam4=1, inflate_device=0)
-    os.environ["TRGT_INGEST_DEVICE_SHARE"] = "100"  # every block the index names goes to the device (default: the last 40 % of the span)
-    try:
-        c = rd.batch(ds["bed"], first_locus=10, max_loci=25, inflate_device=0)   # a second call: staging reused, readers kept
-    finally:
-        del os.environ["TRGT_INGEST_DEVICE_SHARE"]
-    a2 = rd.batch(ds["bed"], first_locus=10, max_loci=25)
-    for x, y in ((a, b), (a2, c)):
-        assert x["n_loci"] == y["n_loci"] and x["n_reads"] == y["n_reads"] and x["n_reads"] > 100
-        for k in x:
-            if isinstance(x[k], np.ndarray):
-                assert np.array_equal(x[k], y[k], equal_nan=True) if x[k].dtype.kind == "f" else np.array_equal(x[k], y[k]), k
-            elif isinstance(x[k], list):
-                assert x[k] == y[k], k
-
-
-@pytest.mark.gpu
-def test_ingestion_with_an_unusable_inflate_device_fails_the_call(tmp_path):
-    # trgt_ingest_params.inflate_device names a GPU that does not exist: the call fails with a message (no silent host-only run), and the
-    # reader is usable afterwards
-    from trgt_amd import _lib, ingest, synth_bam
-    ds = synth_bam.write_dataset(str(tmp_path / "ds"), n_loci=12, read_len=2000)
-    rd = ingest.Reader(ds["bam"], ds["fasta"])
-    with pytest.raises(_lib.TrgtHipError, match="inflate_device 99"):
-        rd.batch(ds["bed"], inflate_device=99)
-    a, b = rd.batch(ds["bed"]), rd.batch(ds["bed"], inflate_device=0)
-    assert a["n_reads"] == b["n_reads"] > 20 and np.array_equal(a["read_blob"], b["read_blob"])

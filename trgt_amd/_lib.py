@@ -76,7 +76,7 @@ EXPORTS = [
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
     "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_reads_pack_bam4",
     "trgt_hip_pool_create", "trgt_hip_pool_destroy", "trgt_hip_pool_size", "trgt_hip_pool_context", "trgt_hip_pool_last_error", "trgt_locus_batch_many",
-    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free",
+    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free", "trgt_ingest_device_stats",
     "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
     "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error",
     "trgt_cigar_ref_len", "trgt_cigar_query_len", "trgt_cigar_total_query_len", "trgt_read_mismatch_offsets", "trgt_read_meth", "trgt_read_clip_to_region",
@@ -262,6 +262,17 @@ def context(device=0):
     if device not in _CTX:
         _CTX[device] = Context(device)
     return _CTX[device]
+
+
+class DevPtr:
+    """A raw device address (trgt_ingest_batch::read_blob_dev) wherever a torch tensor in HBM is accepted (reads_dev=...); `owner` keeps
+    the native object that owns the memory alive."""
+
+    def __init__(self, addr, owner=None):
+        self.addr, self.owner = int(addr), owner
+
+    def data_ptr(self):
+        return self.addr
 
 
 def ptr(a):

@@ -336,6 +336,12 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   return TRGT_OK;
 }
 
+void inflate_launch(void* hip_stream, const uint8_t* d_src, const infl::BlockDesc* d_blocks, uint32_t n, uint8_t* d_dst, uint8_t* d_status, unsigned* d_counter,
+                    unsigned waves) {
+  if (!n) return;
+  hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(std::min<unsigned>(n, std::max(1u, waves))), dim3(64), 0, (hipStream_t)hip_stream, d_src, d_blocks, n, d_dst, d_status, d_counter);
+}
+
 }  // namespace trgt
 
 // include/trgt_hip.h: "device-side BGZF inflate"

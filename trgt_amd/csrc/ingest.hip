@@ -34,24 +34,12 @@
 #include "../../include/trgt_hip.h"
 #include "inflate_dev.hpp"
 #include "inflate_fast.hpp"
+#include "ingest_dev.hpp"
+#include <condition_variable>
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------- BGZF
-// The blocks of a whole call inflated in one batch on the device (trgt_ingest_params.inflate_device): read-only while the workers run.
-struct SharedBlocks {
-  struct E { uint64_t coff; uint32_t csize, isize; const uint8_t* data; int32_t group; uint8_t ok; };
-  std::vector<E> blocks;  // sorted by coff; immutable once the store is published
-  std::vector<uint8_t> status;                   // per block, written by the device run of its group
-  std::atomic<int> group_ready[4] = {{0}, {0}, {0}, {0}};  // a group's blocks may be used once its run is through (release / acquire)
-  const E* find(uint64_t coff) const {
-    auto it = std::lower_bound(blocks.begin(), blocks.end(), coff, [](const E& e, uint64_t c) { return e.coff < c; });
-    if (it == blocks.end() || it->coff != coff) return nullptr;
-    if (!group_ready[it->group].load(std::memory_order_acquire)) return nullptr;  // still on the device: the worker inflates it itself
-    return status[(size_t)(it - blocks.begin())] == 1 ? &*it : nullptr;
-  }
-};
-
 struct Bgzf {
   // A few inflated blocks are kept (least recently used one replaced): the .bai sends the query of a locus back to the first record of
   // the 16 kb window its region starts in, so neighbouring loci of a dense catalog walk over the same blocks, and a worker that takes
@@ -72,9 +60,7 @@ struct Bgzf {
   Bgzf(const Bgzf&) = delete;
   Bgzf& operator=(const Bgzf&) = delete;
   ~Bgzf() { if (fd >= 0) ::close(fd); if (zs_ready) inflateEnd(&zs); }
-  const std::atomic<const SharedBlocks*>* shared = nullptr;  // blocks the device inflates for this call (published when their list is known; looked up behind the reader's own cache)
-  const uint8_t* cur_data = nullptr; size_t cur_size = 0;  // the current block's bytes: an entry of `cache` or of `shared`
-  uint64_t n_shared = 0;
+  const uint8_t* cur_data = nullptr; size_t cur_size = 0;  // the current block's bytes: an entry of `cache`
   bool open(const char* path) { fd = ::open(path, O_RDONLY); if (fd < 0) { err = std::string("cannot open ") + path; return false; } return true; }
   bool load(uint64_t coff) {
     size_t lru = 0;
@@ -82,7 +68,6 @@ struct Bgzf {
       if (cache[i].coff == coff) { cur = i; cache[i].stamp = ++clock; block_coff = coff; block_csize = cache[i].csize; pos = 0; ++n_hits; cur_data = cache[i].data.data(); cur_size = cache[i].data.size(); return true; }
       if (cache[i].stamp < cache[lru].stamp) lru = i;
     }
-    if (const SharedBlocks* sb = shared ? shared->load(std::memory_order_acquire) : nullptr) if (const SharedBlocks::E* e = sb->find(coff)) { cur_data = e->data; cur_size = e->isize; block_coff = coff; block_csize = e->csize; pos = 0; ++n_shared; return true; }
     uint8_t h[18];
     const ssize_t got = ::pread(fd, h, 18, (off_t)coff);
     Block& B = cache[lru];
@@ -124,6 +109,9 @@ struct Bgzf {
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.avail_out != 0) { err = "corrupt BGZF block"; return false; }
     }
+    // the footer's CRC-32 of the inflated bytes (htslib's bgzf_read_block refuses a block whose CRC does not match: a damaged block whose
+    // length happens to fit must not be read as records)
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), B.data.data(), isize) != (raw[total - 8] | (raw[total - 7] << 8) | (raw[total - 6] << 16) | ((uint32_t)raw[total - 5] << 24))) { err = "corrupt BGZF block (CRC-32 mismatch)"; return false; }
     ++n_inflated;
     B.coff = coff; B.csize = total; B.stamp = ++clock; cur = lru;
     block_coff = coff; block_csize = total; pos = 0; cur_data = B.data.data(); cur_size = B.data.size();
@@ -557,60 +545,64 @@ struct trgt_ingest {
   // where the last one stopped finds the blocks of the chunk boundary inflated, and no call pays for fresh pages again
   std::mutex idle_mu;
   std::vector<std::unique_ptr<Bgzf>> idle_readers;
-  // trgt_ingest_params.inflate_device: a context on that GPU and pinned staging for the compressed and the inflated blocks of a call
-  std::mutex infl_mu;
-  static constexpr int INFL_CTX = 3;  // contexts (streams, device buffers) the blocks of a call are spread over: the copies of one overlap the kernel of another
-  trgt_hip_ctx* infl_ctx[INFL_CTX] = {nullptr, nullptr, nullptr}; int infl_device = -1;
-  void *pin_src = nullptr, *pin_dst = nullptr; size_t pin_src_cap = 0, pin_dst_cap = 0;
+  // trgt_ingest_params.ingest_device (ABI 10): slots of device state (a stream, device buffers, pinned staging) -- a call takes a free one, so
+  // calls from several host threads overlap their file reads, uploads, kernels and downloads -- and the pool the batches' slabs return to
+  static constexpr int DEV_SLOTS = 3;
+  std::mutex dev_mu; std::condition_variable dev_cv;
+  struct DevSlot { trgt::ingd::Slot* s = nullptr; bool busy = false; };
+  DevSlot dev_slots[DEV_SLOTS]; int dev_device = -1;
+  std::shared_ptr<trgt::ingd::SlabPool> slab_pool = std::make_shared<trgt::ingd::SlabPool>();
+  std::atomic<int64_t> dev_calls{0}, dev_fallbacks{0}, dev_last_reason{0}, dev_blocks{0}, dev_blocks_host{0};
   ~trgt_ingest() {
-    if (pin_src) (void)hipHostFree(pin_src);
-    if (pin_dst) (void)hipHostFree(pin_dst);
-    for (auto* x : infl_ctx) if (x) trgt_hip_destroy(x);
+    for (auto& d : dev_slots) if (d.s) trgt::ingd::slot_destroy(d.s);
   }
 };
 
-// The BGZF blocks between the compressed offsets of `ranges` ([first block, last block] pairs from the .bai chunks of the loci of a
-// call): read, inflated on the device in ONE batch (inflate_dev.hip) and left in pinned host memory for the workers.  Blocks the
-// device declines, and blocks beyond what the index names, are inflated by the worker that meets them, as before.
-// (runs next to the workers: its error message goes to `err`, the caller's own string, not to the handle's, which the workers' loci may set)
-static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uint64_t, uint64_t>>& ranges, double share, SharedBlocks& sb,
-                           std::atomic<const SharedBlocks*>& publish, double* ms, std::string& err) {
+// ---- trgt_ingest_params.ingest_device: the reads of a batch of loci through the kernels of ingest_dev.hip.  Host work: the .bai chunks of
+// every locus, the compressed ranges they span read into pinned memory (a few threads), the BGZF headers walked (block table, footers'
+// CRC-32 / ISIZE; the blocks of a range are laid end to end in the inflated buffer, so a record may run across blocks as in the file),
+// every chunk's virtual offsets turned into positions in that buffer.
+// rc TRGT_OK: res.fallback == 0 -> the arrays of `res` are the batch's; != 0 -> the host path runs (and reports what is wrong); < 0: error
+struct DevLocusIn { int tid; int64_t start, end; };
+static int device_reads(trgt_ingest* h, const trgt_ingest_params* p, const std::vector<DevLocusIn>& dl, trgt::ingd::RunOut& res, std::string& err, bool trace) {
+  namespace ingd = trgt::ingd;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   auto bad = [&](const std::string& m) { err = m; return TRGT_ERR_INVALID; };
-  if (!h->infl_ctx[0] || h->infl_device != device) {
-    for (auto*& x : h->infl_ctx) { if (x) trgt_hip_destroy(x); x = nullptr; }
-    for (auto*& x : h->infl_ctx)
-      if (trgt_hip_create(device, &x)) { x = nullptr; return bad("trgt_ingest: inflate_device " + std::to_string(device) + ": no usable gfx950 device"); }
-    h->infl_device = device;
+  // a free slot of device state
+  int si = -1;
+  {
+    std::unique_lock<std::mutex> g(h->dev_mu);
+    if (h->dev_device != p->ingest_device) {
+      h->dev_cv.wait(g, [&] { for (auto& d : h->dev_slots) if (d.busy) return false; return true; });
+      for (auto& d : h->dev_slots) if (d.s) { ingd::slot_destroy(d.s); d.s = nullptr; }
+      h->dev_device = p->ingest_device;
+    }
+    h->dev_cv.wait(g, [&] { for (int i = 0; i < trgt_ingest::DEV_SLOTS; ++i) if (!h->dev_slots[i].busy) { si = i; return true; } return false; });
+    if (!h->dev_slots[si].s && !(h->dev_slots[si].s = ingd::slot_create(p->ingest_device, err))) return TRGT_ERR_NO_DEVICE;
+    h->dev_slots[si].busy = true;
   }
-  (void)hipSetDevice(device);
+  struct Release { trgt_ingest* h; int si; ~Release() { { std::lock_guard<std::mutex> g(h->dev_mu); h->dev_slots[si].busy = false; } h->dev_cv.notify_all(); } } release{h, si};
+  ingd::Slot* slot = h->dev_slots[si].s;
+  const size_t nl = dl.size();
+  std::vector<ingd::LocusDesc> ld(nl);
+  std::vector<std::pair<uint64_t, uint64_t>> cv;  // the chunks' virtual offsets
+  for (size_t li = 0; li < nl; ++li) {
+    ingd::LocusDesc& d = ld[li];
+    d.tid = dl[li].tid; d.pad = 0;
+    d.beg = std::max<int64_t>(0, dl[li].start - p->flank_len); d.end = dl[li].end + p->flank_len;
+    d.region_start = dl[li].start; d.region_end = dl[li].end;
+    d.clip_start = dl[li].start - 2ll * p->flank_len; d.clip_end = dl[li].end + 2ll * p->flank_len;
+    d.chunk_begin = (int32_t)cv.size();
+    if (d.tid >= 0) for (auto& ch : h->bai.query(d.tid, d.beg, d.end)) cv.push_back(ch);
+    d.chunk_end = (int32_t)cv.size();
+  }
+  std::vector<std::pair<uint64_t, uint64_t>> ranges, merged;
+  for (auto& c : cv) ranges.emplace_back(c.first >> 16, c.second >> 16);
   std::sort(ranges.begin(), ranges.end());
-  std::vector<std::pair<uint64_t, uint64_t>> merged;
   for (auto& r : ranges) {
     if (!merged.empty() && r.first <= merged.back().second + 0x10000) merged.back().second = std::max(merged.back().second, r.second);
     else merged.push_back(r);
-  }
-  // The device takes the END of the compressed span (the workers walk the loci -- and the file -- from the front and meet it in the
-  // middle): `share` of the bytes, cut at a block start the index names (the first block of a chunk)
-  if (share < 1.0) {
-    uint64_t total = 0;
-    for (auto& m : merged) total += m.second - m.first + 0x10000;
-    uint64_t want = (uint64_t)((double)total * std::max(0.0, share)), acc = 0, cut = ~0ull;
-    for (size_t i = merged.size(); i-- > 0 && cut == ~0ull;) {
-      const uint64_t len = merged[i].second - merged[i].first + 0x10000;
-      if (acc + len < want) { acc += len; continue; }
-      const uint64_t pos = merged[i].second + 0x10000 - (want - acc);  // byte position of the cut inside this range
-      auto it = std::lower_bound(ranges.begin(), ranges.end(), std::make_pair(pos, (uint64_t)0));
-      cut = it != ranges.end() && it->first <= merged[i].second ? it->first : (i + 1 < merged.size() ? merged[i + 1].first : ~0ull);
-    }
-    std::vector<std::pair<uint64_t, uint64_t>> tail;
-    for (auto& m : merged) {
-      if (m.second < cut) continue;
-      tail.emplace_back(std::max(m.first, cut), m.second);
-    }
-    merged.swap(tail);
-    if (merged.empty()) { if (ms) *ms = now() - t0; return TRGT_OK; }
   }
   const int fd = ::open(h->bam_path.c_str(), O_RDONLY);
   if (fd < 0) return bad("cannot open " + h->bam_path);
@@ -625,22 +617,14 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
     src_at[i] = src_total;
     if (c1 > c0) src_total += ((c1 - c0) + 63) & ~63ull;
   }
-  auto pin = [&](void*& p, size_t& cap, size_t need) {
-    if (cap >= need) return true;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    const size_t want = need + need / 4 + (1u << 20);
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
-    cap = want;
-    return true;
-  };
-  if (!pin(h->pin_src, h->pin_src_cap, (size_t)src_total + 64)) return bad("trgt_ingest: no pinned memory for the compressed blocks");
-  uint8_t* const src = (uint8_t*)h->pin_src;
+  uint8_t* const src = ingd::slot_src(slot, (size_t)src_total + 64, err);
+  if (!src) return TRGT_ERR_NOMEM;
   {  // the compressed ranges, read by a few threads (page cache or disk), in pieces
     struct Piece { uint64_t off; uint8_t* dst; size_t n; };
     std::vector<Piece> pieces;
     for (size_t i = 0; i < merged.size(); ++i) {
       const uint64_t c0 = merged[i].first, c1 = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
-      for (uint64_t o = c0; o < c1; o += 8u << 20) pieces.push_back({o, src + src_at[i] + (o - c0), (size_t)std::min<uint64_t>(c1 - o, 8u << 20)});
+      for (uint64_t o = c0; o < c1; o += 4u << 20) pieces.push_back({o, src + src_at[i] + (o - c0), (size_t)std::min<uint64_t>(c1 - o, 4u << 20)});
     }
     std::atomic<size_t> next{0}; std::atomic<int> failed{0};
     auto rd = [&]() {
@@ -654,75 +638,75 @@ static int prefetch_blocks(trgt_ingest* h, int device, std::vector<std::pair<uin
         }
       }
     };
-    const int nt = (int)std::min<size_t>(4, pieces.size());
+    const int want = p->threads > 0 ? p->threads : 8;
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, std::min(want, 8)), pieces.size());
     if (nt <= 1) rd();
     else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(rd); for (auto& t : th) t.join(); }
     if (failed) return bad("trgt_ingest: reading the compressed blocks failed");
   }
   const double t_read = now();
-  // block boundaries (every header names its block's size), payloads and inflated sizes
-  std::vector<trgt::infl::BlockDesc> descs;
-  uint64_t dst_total = 0;
-  sb.blocks.clear();
+  // ---- block table: payloads, where they inflate to, the footers
+  std::vector<trgt::infl::BlockDesc> blocks; std::vector<uint32_t> crcs;
+  struct Known { uint64_t coff, lin; uint32_t isize, range; };
+  std::vector<Known> known;  // every block met (also empty ones), sorted by coff
+  std::vector<uint64_t> lin_end(merged.size());
+  uint64_t lin = 0;
+  auto fall = [&](int why) { res = ingd::RunOut(); res.fallback = why; return TRGT_OK; };
   for (size_t i = 0; i < merged.size(); ++i) {
     const uint64_t c0 = merged[i].first, cend = std::min<uint64_t>(fsize, merged[i].second + 0x10000 + 64);
     uint64_t coff = c0;
-    while (coff <= merged[i].second && coff + 18 <= cend) {
+    while (coff <= merged[i].second && coff < fsize) {
+      if (coff + 18 > cend) return fall(ingd::FB_BLOCK);
       const uint8_t* hp = src + src_at[i] + (coff - c0);
-      if (hp[0] != 31 || hp[1] != 139 || hp[2] != 8 || !(hp[3] & 4)) break;  // (not a block start: the workers will say what is wrong)
+      if (hp[0] != 31 || hp[1] != 139 || hp[2] != 8 || !(hp[3] & 4)) return fall(ingd::FB_BLOCK);  // (the host path says what is wrong)
       const uint32_t xlen = hp[10] | (hp[11] << 8);
-      if (coff + 12 + xlen > cend) break;
+      if (coff + 12 + xlen > cend) return fall(ingd::FB_BLOCK);
       uint32_t bsize = 0; bool found = false;
       for (uint32_t k = 0; k + 4 <= xlen;) {
         const uint32_t slen = hp[12 + k + 2] | (hp[12 + k + 3] << 8);
         if (hp[12 + k] == 'B' && hp[12 + k + 1] == 'C' && slen == 2 && k + 6 <= xlen) { bsize = hp[12 + k + 4] | (hp[12 + k + 5] << 8); found = true; break; }
         k += 4 + slen;
       }
-      if (!found) break;
+      if (!found) return fall(ingd::FB_BLOCK);
       const uint32_t total = bsize + 1, hdr = 12 + xlen;
-      if (total < hdr + 8 || coff + total > cend) break;
-      const uint32_t isize = hp[total - 4] | (hp[total - 3] << 8) | (hp[total - 2] << 16) | ((uint32_t)hp[total - 1] << 24);
-      if (isize > 0 && isize <= 0x10000) {
-        descs.push_back(trgt::infl::BlockDesc{src_at[i] + (coff - c0) + hdr, dst_total, total - hdr - 8, isize});
-        sb.blocks.push_back(SharedBlocks::E{coff, total, isize, nullptr, 0});
-        dst_total += ((uint64_t)isize + 63) & ~63ull;
+      if (total < hdr + 8 || coff + total > cend) return fall(ingd::FB_BLOCK);
+      const uint32_t isize = le32(hp + total - 4);
+      if (isize > 0x10000) return fall(ingd::FB_BLOCK);
+      known.push_back(Known{coff, lin, isize, (uint32_t)i});
+      if (isize) {
+        blocks.push_back(trgt::infl::BlockDesc{src_at[i] + (coff - c0) + hdr, lin, total - hdr - 8, isize});
+        crcs.push_back(le32(hp + total - 8));
+        lin += isize;
       }
       coff += total;
     }
+    lin_end[i] = lin;
+    lin = ((lin + 63) & ~63ull) + 64;  // (a gap between the ranges: nothing of one is read as the other's)
   }
-  if (descs.empty()) { if (ms) *ms = now() - t0; return TRGT_OK; }
-  if (!pin(h->pin_dst, h->pin_dst_cap, (size_t)dst_total + 64)) return bad("trgt_ingest: no pinned memory for the inflated blocks");
-  // the blocks in file order, cut into up to INFL_CTX runs of about equal compressed size: a thread and a context each (upload, kernel and
-  // download of one run overlap those of the others); the list is published first, a run's blocks become usable when it is through
-  const int G = (int)std::min<size_t>((size_t)trgt_ingest::INFL_CTX, (descs.size() + 255) / 256);
-  std::vector<size_t> cut((size_t)G + 1, 0);
-  for (int g = 1; g < G; ++g) {
-    const uint64_t want = descs[0].src_off + (src_total - descs[0].src_off) * (uint64_t)g / (uint64_t)G;
-    cut[(size_t)g] = (size_t)(std::lower_bound(descs.begin(), descs.end(), want, [](const trgt::infl::BlockDesc& d, uint64_t w) { return d.src_off < w; }) - descs.begin());
-  }
-  cut[(size_t)G] = descs.size();
-  for (int g = 0; g < G; ++g) for (size_t b = cut[(size_t)g]; b < cut[(size_t)g + 1]; ++b) { sb.blocks[b].group = g; sb.blocks[b].data = (const uint8_t*)h->pin_dst + descs[b].dst_off; }
-  sb.status.assign(descs.size(), 0);
-  for (auto& f : sb.group_ready) f.store(0, std::memory_order_relaxed);
-  publish.store(&sb, std::memory_order_release);
   const double t_walk = now();
-  std::vector<int> rcs((size_t)G, 0);
-  auto run = [&](int g) {
-    const size_t b0 = cut[(size_t)g], b1 = cut[(size_t)g + 1];
-    if (b1 > b0) {
-      std::vector<trgt::infl::BlockDesc> d(descs.begin() + (ptrdiff_t)b0, descs.begin() + (ptrdiff_t)b1);
-      const uint64_t s0 = d.front().src_off & ~63ull, d0 = d.front().dst_off;
-      const uint64_t s1 = d.back().src_off + d.back().src_len, d1 = d.back().dst_off + d.back().dst_len;
-      for (auto& x : d) { x.src_off -= s0; x.dst_off -= d0; }
-      rcs[(size_t)g] = trgt::inflate_blocks_device(h->infl_ctx[g], (int64_t)d.size(), src + s0, s1 - s0, d.data(), (uint8_t*)h->pin_dst + d0, d1 - d0, sb.status.data() + b0);
-    }
-    if (!rcs[(size_t)g]) sb.group_ready[g].store(1, std::memory_order_release);
+  // ---- the chunks as positions in the inflated bytes
+  std::vector<ingd::ChunkDesc> cd(cv.size());
+  auto find = [&](uint64_t coff) -> const Known* {
+    auto it = std::lower_bound(known.begin(), known.end(), coff, [](const Known& k, uint64_t c) { return k.coff < c; });
+    return it != known.end() && it->coff == coff ? &*it : nullptr;
   };
-  if (G <= 1) run(0);
-  else { std::vector<std::thread> th; for (int g = G - 1; g >= 0; --g) th.emplace_back(run, g); for (auto& t : th) t.join(); }
-  for (int g = 0; g < G; ++g) if (rcs[(size_t)g]) return bad(std::string("trgt_ingest: device inflate failed: ") + trgt_hip_last_error(h->infl_ctx[g]));
-  if (std::getenv("TRGT_INGEST_TRACE")) std::fprintf(stderr, "[ingest]   device inflate: %zu ranges, %zu blocks, %.1f MB read in %.1f ms, headers %.1f ms, upload + kernel + download of %.1f MB %.1f ms\n", merged.size(), descs.size(), (double)src_total / 1e6, t_read - t0, t_walk - t_read, (double)dst_total / 1e6, now() - t_walk);
-  if (ms) *ms = now() - t0;
+  for (size_t c = 0; c < cv.size(); ++c) {
+    const Known* a = find(cv[c].first >> 16);
+    if (!a || (cv[c].first & 0xFFFF) > a->isize) return fall(ingd::FB_WALK);
+    const Known* b = find(cv[c].second >> 16);
+    cd[c].lin0 = a->lin + (cv[c].first & 0xFFFF);
+    cd[c].lin_limit = lin_end[a->range];
+    cd[c].lin1 = b && b->range == a->range ? std::min<uint64_t>(b->lin + std::min<uint64_t>(cv[c].second & 0xFFFF, b->isize), cd[c].lin_limit) : cd[c].lin_limit;
+  }
+  ingd::RunIn in;
+  in.src_bytes = src_total; in.n_blocks = (int64_t)blocks.size(); in.blocks = blocks.data(); in.crc = crcs.data(); in.infl_bytes = lin;
+  in.n_loci = (int64_t)nl; in.loci = ld.data(); in.n_chunks = (int64_t)cd.size(); in.chunks = cd.data();
+  in.reservoir = (uint32_t)(3ll * p->max_depth); in.min_rq = p->min_read_qual; in.keep_bam4 = p->keep_bam4 != 0;
+  const int rc = ingd::slot_run(slot, in, *h->slab_pool, res, err);
+  if (rc) return rc;
+  h->dev_blocks += (int64_t)blocks.size(); h->dev_blocks_host += (int64_t)res.blocks_host_inflated;
+  if (trace) std::fprintf(stderr, "[ingest]   device: %zu ranges, %zu blocks (%.1f MB -> %.1f MB), file %.1f ms, headers %.1f ms, upload+inflate+crc %.1f ms (%llu blocks by zlib), walk %.1f ms, reads %.1f ms, download %.1f ms, fallback %d\n",
+                          merged.size(), blocks.size(), (double)src_total / 1e6, (double)lin / 1e6, t_read - t0, t_walk - t_read, res.ms_inflate, (unsigned long long)res.blocks_host_inflated, res.ms_walk, res.ms_reads, res.ms_download, res.fallback);
   return TRGT_OK;
 }
 
@@ -741,6 +725,9 @@ struct BatchStore {  // owner of the arrays a trgt_ingest_batch points to
   std::vector<uint8_t> bam4;
   std::vector<uint64_t> bam4_off;
   std::string skipped; std::vector<uint64_t> skipped_off;
+  // ingest_device: the per-read arrays are pieces of one device slab + its pinned mirror (back to the reader's pool when the batch is freed)
+  trgt::ingd::Slab slab; std::shared_ptr<trgt::ingd::SlabPool> slab_pool;
+  ~BatchStore() { if (slab_pool) slab_pool->give(slab); }
   trgt_ingest_batch pub;
 };
 
@@ -795,9 +782,17 @@ static int ingest_open_impl(const char* bam_path, const char* fasta_path, trgt_i
 
 void trgt_ingest_close(trgt_ingest* h) { delete h; }
 
+// ABI 10: what trgt_ingest_params.ingest_device did so far -- [0] calls that asked for the device, [1] of those, calls that went back to the
+// host path, [2] the reason of the last one (trgt::ingd::FB_*: 1 block, 2 record walk, 3 reservoir, 4 MM / ML caps), [3] BGZF blocks through
+// the device path, [4] of those, blocks the inflate kernel declined (inflated by zlib, uploaded)
+void trgt_ingest_device_stats(const trgt_ingest* h, int64_t out[5]) {
+  if (!h || !out) return;
+  out[0] = h->dev_calls.load(); out[1] = h->dev_fallbacks.load(); out[2] = h->dev_last_reason.load(); out[3] = h->dev_blocks.load(); out[4] = h->dev_blocks_host.load();
+}
+
 void trgt_ingest_default_params(trgt_ingest_params* p) {
   if (!p) return;
-  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0; p->inflate_device = -1;
+  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0; p->ingest_device = -1;
 }
 
 void trgt_ingest_free(trgt_ingest_batch* b) {
@@ -887,40 +882,25 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   }
   const int64_t nl = (int64_t)loci.size();
   const double t1 = now();
-  // ---- trgt_ingest_params.inflate_device: the blocks the index names for these loci, inflated on the GPU in one batch
-  SharedBlocks shared_blocks;
-  std::atomic<const SharedBlocks*> shared_pub{nullptr};
-  std::unique_lock<std::mutex> infl_lock(h->infl_mu, std::defer_lock);
-  double t_prefetch = 0.0;
-  std::thread prefetch_thread;
-  int prefetch_rc = TRGT_OK;
-  std::string prefetch_err;  // (the thread's own: h->err belongs to this thread while the workers run)
-  std::vector<std::pair<uint64_t, uint64_t>> infl_ranges;
-  // (declared after everything the thread refers to: on an unwind it is joined before any of that goes away; the staging belongs to the
-  //  handle and is never left running)
-  struct JoinPrefetch { std::thread& t; ~JoinPrefetch() { if (t.joinable()) t.join(); } } join_prefetch{prefetch_thread};
-  if (p->inflate_device >= 0 && nl > 0) {
-    infl_lock.lock();  // (one call at a time in this mode)
-    for (auto& l : loci) {
-      auto it = h->ref_id.find(l.contig);
-      if (it == h->ref_id.end()) continue;
-      for (auto& ch : h->bai.query(it->second, std::max<int64_t>(0, l.start - p->flank_len), l.end + p->flank_len)) infl_ranges.emplace_back(ch.first >> 16, ch.second >> 16);
-    }
-    // The device inflates a SHARE of the blocks (from the end of the span, TRGT_INGEST_DEVICE_SHARE per cent, default 40) while the workers
-    // start at once on the rest: a stream inflates at 7 MB/s on the device whatever the decoder does, so the GPU adds to the host
-    // threads rather than replacing them.  100: everything on the device, the workers wait for nothing and inflate what is not ready.
-    const double share = [] { const char* e = std::getenv("TRGT_INGEST_DEVICE_SHARE"); const double v = e && *e ? std::atof(e) : 40.0; return std::min(100.0, std::max(1.0, v)) / 100.0; }();  // (read per call)
-    if (!infl_ranges.empty())
-      prefetch_thread = std::thread([&]() {
-        try { prefetch_rc = prefetch_blocks(h, p->inflate_device, infl_ranges, share, shared_blocks, shared_pub, &t_prefetch, prefetch_err); }
-        catch (const std::exception& e) { prefetch_err = std::string("trgt_ingest: device inflate: ") + e.what(); prefetch_rc = TRGT_ERR_NOMEM; }
-      });
+  // ---- trgt_ingest_params.ingest_device: the reads of these loci through the kernels of ingest_dev.hip; what they do not take (res.fallback)
+  // goes through the host path below, which yields the data or the error message
+  trgt::ingd::RunOut dev;
+  bool from_device = false;
+  if (p->ingest_device >= 0 && nl > 0) {
+    std::vector<DevLocusIn> dl((size_t)nl);
+    for (int64_t li = 0; li < nl; ++li) { auto it = h->ref_id.find(loci[(size_t)li].contig); dl[(size_t)li] = DevLocusIn{it == h->ref_id.end() ? -1 : it->second, loci[(size_t)li].start, loci[(size_t)li].end}; }
+    std::string derr;
+    const int rc = device_reads(h, p, dl, dev, derr, trace);
+    if (rc) { h->err = derr.empty() ? "trgt_ingest: device ingestion failed" : derr; return rc; }  // a device that cannot be used fails the call: no silent host-only run
+    ++h->dev_calls;
+    if (dev.fallback) { ++h->dev_fallbacks; h->dev_last_reason = dev.fallback; }
+    else from_device = true;
   }
   // ---- reads: extract_reads + clip_reads per locus, loci spread over threads (one file handle each)
   int nthr = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));  // (more than 32 workers lose: tools/ingest_scaling.py)
   nthr = (int)std::max<int64_t>(1, std::min<int64_t>(nthr, nl));
   std::atomic<int64_t> next{0};
-  std::atomic<uint64_t> n_inflated{0}, n_cache_hits{0}, n_from_device{0};
+  std::atomic<uint64_t> n_inflated{0}, n_cache_hits{0};
   // a worker takes a run of consecutive catalog lines (sorted catalogs: neighbours share BGZF blocks, see Bgzf), short enough that
   // every thread still gets several runs
   const int64_t run = std::max<int64_t>(1, std::min<int64_t>(8, nl / (4ll * nthr)));
@@ -933,9 +913,8 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     }
     struct Back { trgt_ingest* h; std::unique_ptr<Bgzf>& z; ~Back() { if (z && z->err.empty()) { std::lock_guard<std::mutex> g(h->idle_mu); h->idle_readers.push_back(std::move(z)); } } } back{h, zp};
     Bgzf& z = *zp;
-    z.shared = p->inflate_device >= 0 ? &shared_pub : nullptr;
-    z.block_coff = ~0ull; z.block_csize = 0; z.cur_data = nullptr; z.cur_size = 0; z.pos = 0;  // (a kept reader may point at a shared block of an earlier call)
-    const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits, shared0 = z.n_shared;
+    z.block_coff = ~0ull; z.block_csize = 0; z.cur_data = nullptr; z.cur_size = 0; z.pos = 0;
+    const uint64_t inflated0 = z.n_inflated, hits0 = z.n_hits;
     RawRec rec;
     for (;;) {
       const int64_t l0 = next.fetch_add(run);
@@ -984,19 +963,15 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
       l.reads.swap(clipped);
      }
     }
-    n_inflated += z.n_inflated - inflated0; n_cache_hits += z.n_hits - hits0; n_from_device += z.n_shared - shared0;
-    z.shared = nullptr;
+    n_inflated += z.n_inflated - inflated0; n_cache_hits += z.n_hits - hits0;
   };
   std::atomic<int> worker_failed{0};
   auto work = [&]() {  // (an exception must not leave a thread, nor cross the C ABI)
     try { work_body(); } catch (const std::exception& e) { worker_failed = 1; for (auto& l : loci) if (l.err.empty()) { l.err = std::string("reading the BAM: ") + e.what(); break; } }
   };
-  if (nthr <= 1) work();
+  if (from_device) {}
+  else if (nthr <= 1) work();
   else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(work); for (auto& t : th) t.join(); }
-  if (prefetch_thread.joinable()) prefetch_thread.join();
-  // inflate_device was asked for: a device that cannot be used (no such GPU, no pinned memory, a device error) fails the call -- the
-  // workers' results are complete all the same (they inflate what never became ready), but a caller who named a GPU is told it did no work
-  if (prefetch_rc) { h->err = prefetch_err.empty() ? "trgt_ingest: device inflate failed" : prefetch_err; return prefetch_rc; }
   for (auto& l : loci) if (!l.err.empty()) return bad(l.id + ": " + l.err);
   const double t2 = now();
   // ---- the arrays of trgt_locus_batch_in (+ what the writers need per read)
@@ -1016,14 +991,15 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
     S->ploidy.push_back((uint8_t)p->default_ploidy); S->genotyper.push_back((uint8_t)p->genotyper);
     S->contigs += l.contig; S->contig_off.push_back(S->contigs.size()); S->ids += l.id; S->id_off.push_back(S->ids.size());
     S->strucs += l.struc; S->struc_off.push_back(S->strucs.size());
-    S->region_start.push_back(l.start); S->region_end.push_back(l.end); S->n_filtered.push_back(l.n_filt); S->n_seen.push_back(l.n_seen);
+    S->region_start.push_back(l.start); S->region_end.push_back(l.end);
+    S->n_filtered.push_back(from_device ? dev.out.n_filt[li] : l.n_filt); S->n_seen.push_back(from_device ? dev.out.n_seen[li] : l.n_seen);
     At n = at[(size_t)li];
     for (auto& r : l.reads) {
       ++n.read; n.bytes += r.bases.size(); n.name += r.id.size(); n.snp += r.mismatch_offsets.size(); n.meth += r.has_meth ? r.meth.size() : 0;
       n.cig += r.cigar.size(); n.bam4 += (r.bases.size() + 1) / 2;
     }
     at[(size_t)li + 1] = n;
-    S->lrb.push_back(n.read);
+    S->lrb.push_back(from_device ? dev.out.lrb[li + 1] : n.read);
   }
   const At tot = at[(size_t)nl];
   const size_t nr = (size_t)tot.read;
@@ -1069,12 +1045,14 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   };
   {
     auto guarded = [&]() { try { fill(); } catch (const std::exception&) { fill_failed = 1; } };
-    if (nthr <= 1) guarded();
+    if (from_device) {}
+    else if (nthr <= 1) guarded();
     else { std::vector<std::thread> th; for (int t = 0; t < nthr; ++t) th.emplace_back(guarded); for (auto& t : th) t.join(); }
   }
   if (fill_failed) return bad("trgt_ingest: assembling the batch failed");
   trgt_ingest_batch& B = S->pub;
   std::memset(&B, 0, sizeof B);
+  B.read_blob_device = -1;
   auto u8 = [](const std::string& s) { return (const uint8_t*)s.data(); };
   if (S->flank.empty()) S->flank.push_back('\0');
   if (S->tr.empty()) S->tr.push_back('\0');
@@ -1099,7 +1077,20 @@ static int ingest_batch_impl(trgt_ingest* h, const trgt_ingest_params* p, const 
   for (auto& m : skipped) { S->skipped += m; S->skipped_off.push_back(S->skipped.size()); }
   B.n_skipped = (int64_t)skipped.size(); B.skipped_blob = S->skipped.data(); B.skipped_off = S->skipped_off.data();
   if (p->keep_bam4) { B.read_bam4 = S->bam4.data(); B.read_bam4_off = S->bam4_off.data(); B.read_bam4_bytes = tot.bam4; }
-  if (trace) std::fprintf(stderr, "[ingest] %lld loci, %d threads (runs of %lld): catalog+genome %.1f ms, reads %.1f ms (%llu blocks inflated by the workers, %llu found in their caches, %llu taken from the device batch of %zu blocks: %.1f ms), arrays %.1f ms\n", (long long)nl, nthr, (long long)run, t1 - t0, t2 - t1, (unsigned long long)n_inflated.load(), (unsigned long long)n_cache_hits.load(), (unsigned long long)n_from_device.load(), shared_blocks.blocks.size(), t_prefetch, now() - t2);
+  if (from_device) {  // the per-read arrays are pieces of the slab the kernels filled (pinned mirror); the ASCII reads stay in HBM as well
+    const trgt::ingd::HostOut& D = dev.out;
+    S->slab = dev.slab; dev.slab = trgt::ingd::Slab(); S->slab_pool = h->slab_pool;
+    B.n_reads = D.n_reads; B.read_bytes = std::max<uint64_t>(1, D.read_bytes);
+    B.read_blob = D.reads; B.read_off = D.read_off; B.read_len = D.read_len; B.read_qual = D.rq;
+    B.qual_blob = D.quals; B.name_blob = D.names; B.name_off = D.name_off;
+    B.is_reverse = D.is_reverse; B.mapq = D.mapq; B.hp_tag = D.hp; B.has_meth = D.has_meth;
+    B.start_offset = D.start_offset; B.end_offset = D.end_offset;
+    B.mismatch_offsets = D.snp; B.mismatch_off = D.snp_off; B.meth = D.meth; B.meth_off = D.meth_off;
+    B.cigar = D.cig; B.cigar_off = D.cig_off; B.cigar_ref_pos = D.cig_ref_pos;
+    if (p->keep_bam4) { B.read_bam4 = D.bam4; B.read_bam4_off = D.bam4_off; B.read_bam4_bytes = D.bam4_bytes; }
+    B.read_blob_dev = D.dev_reads; B.read_blob_device = p->ingest_device;
+  }
+  if (trace) std::fprintf(stderr, "[ingest] %lld loci, %d threads (runs of %lld): catalog+genome %.1f ms, reads %.1f ms (%s; %llu blocks inflated by the workers, %llu found in their caches), arrays %.1f ms\n", (long long)nl, nthr, (long long)run, t1 - t0, t2 - t1, from_device ? "on the device" : "host workers", (unsigned long long)n_inflated.load(), (unsigned long long)n_cache_hits.load(), now() - t2);
   B.owner = S.release();
   *out = &reinterpret_cast<BatchStore*>(B.owner)->pub;
   return TRGT_OK;

@@ -10,7 +10,7 @@ from . import _lib
 
 class IngestParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("max_depth", C.c_int32), ("min_read_qual", C.c_double), ("threads", C.c_int32),
-                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32), ("inflate_device", C.c_int32)]
+                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32), ("ingest_device", C.c_int32)]
 
 
 _P8, _P16, _P32, _P64, _PD, _PC = (C.POINTER(t) for t in (C.c_uint8, C.c_int16, C.c_uint32, C.c_uint64, C.c_double, C.c_char))
@@ -36,6 +36,7 @@ class IngestBatch(C.Structure):
                 ("cigar", _P32), ("cigar_off", _P64), ("cigar_ref_pos", _PI64),
                 ("read_bam4", _P8), ("read_bam4_off", _P64), ("read_bam4_bytes", C.c_uint64),
                 ("n_skipped", C.c_int64), ("skipped_blob", _PC), ("skipped_off", _P64),
+                ("read_blob_dev", C.c_void_p), ("read_blob_device", C.c_int32),
                 ("owner", C.c_void_p)]
 
 
@@ -91,6 +92,15 @@ class Reader:
                 L.trgt_ingest_close(self.handle)
                 self.handle = C.c_void_p()
             raise _lib.TrgtHipError("trgt_ingest_open: %s" % msg)
+
+    def device_stats(self):
+        """trgt_ingest_device_stats: calls that asked for ingest_device, calls redone by the host path, reason of the last one, BGZF blocks
+        through the device path, blocks its inflate kernel declined."""
+        v = (C.c_int64 * 5)()
+        self._L.trgt_ingest_device_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self._L.trgt_ingest_device_stats.restype = None
+        self._L.trgt_ingest_device_stats(self.handle, v)
+        return dict(calls=int(v[0]), fallbacks=int(v[1]), last_reason=int(v[2]), blocks=int(v[3]), blocks_by_zlib=int(v[4]))
 
     def close(self):
         if self.handle:
@@ -148,6 +158,8 @@ class Reader:
         if b.read_bam4:  # keep_bam4=1: the reads once more as 4-bit codes; bam4_view(batch) is the batch that hands those to the GPU
             out["read_bam4"] = _arr(b.read_bam4, max(int(b.read_bam4_bytes), 1), u8)
             out["read_bam4_off"] = _arr(b.read_bam4_off, max(nr, 1), u64)
+        if b.read_blob_dev:  # ingest_device: the ASCII reads are in HBM as well (owned by the native batch: keep_native=True to use them)
+            out["read_blob_dev"], out["read_blob_device"] = int(b.read_blob_dev), int(b.read_blob_device)
         out["skipped"] = _strings(b.skipped_blob, b.skipped_off, int(b.n_skipped))  # "Error at BED line N: ..." per catalog line without a locus
         if keep_native:  # the writers (trgt_amd/writers.py) take the native batch itself
             out["_native"] = NativeBatch(self._L, h)
@@ -182,6 +194,14 @@ def inflate_blocks(ctx, streams, sizes):
         assert (pad == 0xA5).all(), "wrote beyond a block's output"
         out.append(dst[a:a + k].tobytes() if status[i] == 1 else None)
     return out, status
+
+
+def device_reads(batch):
+    """The ASCII reads a batch of Reader.batch(..., ingest_device=d, keep_native=True) left in HBM, as the reads_dev argument of
+    trgt_amd.locus.run_batch / run_many (nothing is uploaded then); None for a batch of the host path."""
+    if not batch.get("read_blob_dev"):
+        return None
+    return _lib.DevPtr(batch["read_blob_dev"], batch.get("_native"))
 
 
 def bam4_view(batch):
