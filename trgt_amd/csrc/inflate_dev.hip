@@ -21,9 +21,9 @@
 namespace trgt {
 namespace infl {
 
-constexpr uint32_t RING = 8192, RING_MASK = RING - 1, SEG = 4096;  // the last 8 KB of output in LDS; older bytes are read back from the flushed output
-constexpr uint32_t IN_WIN = 3072;        // compressed bytes staged in LDS
-constexpr uint32_t HDR_ROOM = 1024;      // a dynamic block header (<= 19 * 3 + 320 * 14 bits) is parsed without a reload in between
+constexpr uint32_t RING = 2048, RING_MASK = RING - 1, SEG = 1024;  // the last 2 KB of output in LDS; older bytes are read back from the flushed output
+constexpr uint32_t IN_WIN = 1024;        // compressed bytes staged in LDS
+constexpr uint32_t HDR_ROOM = 576;       // a dynamic block header (<= 14 + 19 * 3 + 320 * 14 bits = 569 bytes) is parsed without a reload in between
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
 
 enum : uint32_t { EV_NONE = 0, EV_RELOAD = 1, EV_FLUSH = 2, EV_BUILD = 3, EV_COPY = 4, EV_DONE = 5, EV_ERROR = 6 };
@@ -35,7 +35,8 @@ struct Shared {
   uint32_t copy_src, copy_dst, copy_len;  // EV_COPY: stored bytes src[copy_src ..) -> out[copy_dst ..)
   uint32_t nlit, ndist;   // EV_BUILD
   uint32_t block;         // the claimed block
-  uint16_t lit_tab[1 << LIT_BITS], dist_tab[1 << DIST_BITS];  // symbol << 4 | code length (0: longer than the table's bits)
+  uint16_t lit_tab[1 << LIT_BITS], dist_tab[1 << DIST_BITS];  // symbol << 4 | code length (0: longer than the table's bits): staging of the table fill
+  uint32_t lit32[1 << LIT_BITS], dist32[1 << DIST_BITS];      // what the symbol loop reads: see lit_entry / dist_entry
   uint16_t lit_cnt[16], dist_cnt[16];     // codes per length (canonical decoding of the long codes, and the checks)
   uint16_t lit_sym[288], dist_sym[32];    // symbols in code order
   uint16_t code[320];                     // canonical code of every symbol (table fill)
@@ -50,6 +51,28 @@ struct Shared {
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // RFC 1951 3.2.7
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __builtin_bitreverse32(v) >> (32 - n); }
+
+// Table entries of the symbol loop (round 6: the loop is bound by scalar instruction issue -- one SALU instruction per cycle and CU -- so
+// everything a symbol implies is worked out once per table, not once per symbol).  Bits 0-3: bits of the code (0: longer than the table's
+// index, decoded canonically); literal / length table: F_LIT with the byte in 16-23, F_PAIR when a second literal's code fits the index as
+// well (its byte in 24-31, bits 0-3 then count both codes), F_EOB, else a length: extra bits in 4-7, base length in 16-31; distance table:
+// extra bits in 4-7, base distance in 16-31.  F_BAD: a symbol DEFLATE does not define.
+constexpr uint32_t F_LIT = 1u << 8, F_EOB = 1u << 9, F_PAIR = 1u << 10, F_BAD = 1u << 11;
+__device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t l) {
+  if (sym < 256u) return l | F_LIT | (sym << 16);
+  if (sym == 256u) return l | F_EOB;
+  if (sym > 285u) return l | F_BAD;
+  if (sym < 265u) return l | ((sym - 254u) << 16);
+  if (sym == 285u) return l | (258u << 16);
+  const uint32_t eb = (sym - 261u) >> 2;
+  return l | (eb << 4) | ((3u + ((4u + ((sym - 265u) & 3u)) << eb)) << 16);
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t ds, uint32_t l) {
+  if (ds > 29u) return l | F_BAD;
+  if (ds < 4u) return l | ((ds + 1u) << 16);
+  const uint32_t eb = (ds >> 1) - 1u;
+  return l | (eb << 4) | ((((2u + (ds & 1u)) << eb) + 1u) << 16);
+}
 
 // canonical decoding bit by bit (codes longer than the table's bits: rare symbols by construction)
 __device__ __forceinline__ int slow_decode(const uint16_t* cnt, const uint16_t* sym, uint64_t bits, int& len_out) {
@@ -83,7 +106,7 @@ __device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, 
   return true;
 }
 
-__global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                             uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;
@@ -192,53 +215,54 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
             in_pos += piece; op += piece; stored_left -= piece;
             want = EV_COPY;
           } else {
-            // ---- symbols of a Huffman block
-            if (window_low(16)) { want = EV_RELOAD; break; }
-            refill();
-            uint32_t e = RFL(sh.lit_tab[bitbuf & ((1u << LIT_BITS) - 1u)]);
-            int l = (int)(e & 15u), sym = (int)(e >> 4);
-            if (l == 0) { sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); if (sym < 0) { want = EV_ERROR; break; } }
-            take((uint32_t)l);
-            if (sym < 256) {
-              if (op >= out_len) { want = EV_ERROR; break; }
-              sh.out[op & RING_MASK] = (uint8_t)sym; ++op;
-              if ((op & (SEG - 1)) == 0) want = EV_FLUSH;
-              continue;
-            }
-            if (sym == 256) { phase = 0; if (final_block) want = EV_DONE; continue; }
-            if (sym > 285) { want = EV_ERROR; break; }
-            refill();
-            uint32_t len;
-            if (sym < 265) len = (uint32_t)sym - 254u;
-            else if (sym == 285) len = 258;
-            else { const uint32_t eb = ((uint32_t)sym - 261u) >> 2; len = 3u + ((4u + (((uint32_t)sym - 265u) & 3u)) << eb) + take(eb); }
-            e = RFL(sh.dist_tab[bitbuf & ((1u << DIST_BITS) - 1u)]);
-            int dl = (int)(e & 15u), ds = (int)(e >> 4);
-            if (dl == 0) { ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); if (ds < 0) { want = EV_ERROR; break; } }
-            take((uint32_t)dl);
-            if (ds > 29) { want = EV_ERROR; break; }
-            refill();
-            uint32_t dist;
-            if (ds < 4) dist = (uint32_t)ds + 1u;
-            else { const uint32_t eb = ((uint32_t)ds >> 1) - 1u; dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + take(eb); }
-            if (dist > op || op + len > out_len) { want = EV_ERROR; break; }
-            const uint32_t before = op;
-            // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
-            // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
-            // A source byte still in the ring (not overwritten before this copy ends: its position + RING >= op + len) comes from LDS;
-            // an older one was flushed (every finished segment goes out before decoding continues) and is read back from the output.
-            for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (dist >= 64: a round only reads what earlier rounds or earlier symbols wrote)
-              const uint32_t k = k0 + (uint32_t)lane;
-              if (k < len) {
-                const uint32_t sp = dist >= 64u ? op + k - dist : op - dist + k % dist;
-                uint8_t v;
-                if (sp + RING >= op + len) v = sh.out[sp & RING_MASK];
-                else v = __hip_atomic_load(outp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh.out[(op + k) & RING_MASK] = v;
+            // ---- symbols of a Huffman block: a loop of its own that is left only for an event (its iterations carry no state-machine
+            // bookkeeping: the symbol loop is bound by scalar instruction issue).  One bound covers "the window runs low" and "the input is over"
+            const bool to_end = wb + IN_WIN >= in_len + 8;
+            const uint32_t safe_end = to_end ? in_len + 8 : wb + IN_WIN - 16;
+            for (;;) {
+              if (in_pos > safe_end) { want = to_end ? (uint32_t)EV_ERROR : (uint32_t)EV_RELOAD; break; }
+              refill();  // (>= 32 bits: a literal / length code and its extra bits take at most 15 + 5)
+              uint32_t e = RFL(sh.lit32[bitbuf & ((1u << LIT_BITS) - 1u)]);
+              if (!(e & 15u)) { int l; const int sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); if (sym < 0) { want = EV_ERROR; break; } e = lit_entry((uint32_t)sym, (uint32_t)l); }
+              take(e & 15u);
+              if (e & F_LIT) {
+                const uint32_t before = op;
+                sh.out[op & RING_MASK] = (uint8_t)(e >> 16); ++op;
+                if (e & F_PAIR) { sh.out[op & RING_MASK] = (uint8_t)(e >> 24); ++op; }
+                if (op > out_len) { want = EV_ERROR; break; }
+                if ((before ^ op) & SEG) { want = EV_FLUSH; break; }
+                continue;
               }
+              if (e & (F_EOB | F_BAD)) { if (e & F_BAD) want = EV_ERROR; else { phase = 0; if (final_block) want = EV_DONE; } break; }
+              const uint32_t len = (e >> 16) + take((e >> 4) & 15u);
+              refill();  // (a distance code and its extra bits: at most 15 + 13)
+              uint32_t d = RFL(sh.dist32[bitbuf & ((1u << DIST_BITS) - 1u)]);
+              if (!(d & 15u)) { int dl; const int ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); if (ds < 0) { want = EV_ERROR; break; } d = dist_entry((uint32_t)ds, (uint32_t)dl); }
+              if (d & F_BAD) { want = EV_ERROR; break; }
+              take(d & 15u);
+              const uint32_t dist = (d >> 16) + take((d >> 4) & 15u);
+              if (dist > op || op + len > out_len) { want = EV_ERROR; break; }
+              const uint32_t before = op;
+              // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
+              // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
+              // A source byte still in the ring (not overwritten before this copy ends: its position + RING >= op + len) comes from LDS;
+              // an older one was flushed (every finished segment goes out before decoding continues) and is read back from the output.
+              if (len <= 64u && dist >= len && op - dist + RING >= op + len) {  // the common case in one round: no overlap, the source still in the ring
+                if ((uint32_t)lane < len) sh.out[(op + (uint32_t)lane) & RING_MASK] = sh.out[(op - dist + (uint32_t)lane) & RING_MASK];
+              } else
+              for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (dist >= 64: a round only reads what earlier rounds or earlier symbols wrote)
+                const uint32_t k = k0 + (uint32_t)lane;
+                if (k < len) {
+                  const uint32_t sp = dist >= 64u ? op + k - dist : dist == 1u ? op - 1u : op - dist + k % dist;
+                  uint8_t v;
+                  if (sp + RING >= op + len) v = sh.out[sp & RING_MASK];
+                  else v = __hip_atomic_load(outp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  sh.out[(op + k) & RING_MASK] = v;
+                }
+              }
+              op += len;
+              if ((before ^ op) & SEG) { want = EV_FLUSH; break; }
             }
-            op += len;
-            if ((before ^ op) & SEG) want = EV_FLUSH;
           }
         }
         if (want == EV_RELOAD) {
@@ -283,6 +307,24 @@ __global__ void __launch_bounds__(64) inflate_blocks_kernel(const uint8_t* __res
           const uint16_t entry = (uint16_t)(((is_dist ? s - nlit : s) << 4) | l);
           for (uint32_t i = rev_bits(sh.code[s], (int)l); i < (1u << bits); i += 1u << l) tab[i] = entry;
         }
+        __syncthreads();
+        // the entries the symbol loop reads; two literals in one entry where the second one's code lies inside the index as well
+        for (uint32_t i = (uint32_t)lane; i < (1u << LIT_BITS); i += 64) {
+          const uint32_t e16 = sh.lit_tab[i], l = e16 & 15u, sym = e16 >> 4;
+          uint32_t e = 0;
+          if (l) {
+            e = lit_entry(sym, l);
+            if (sym < 256u && l < (uint32_t)LIT_BITS) {
+              const uint32_t e2 = sh.lit_tab[i >> l], l2 = e2 & 15u, s2 = e2 >> 4;
+              if (l2 && s2 < 256u && l + l2 <= (uint32_t)LIT_BITS) e = (l + l2) | F_LIT | F_PAIR | (sym << 16) | (s2 << 24);
+            }
+          }
+          sh.lit32[i] = e;
+        }
+        for (uint32_t i = (uint32_t)lane; i < (1u << DIST_BITS); i += 64) {
+          const uint32_t e16 = sh.dist_tab[i], l = e16 & 15u;
+          sh.dist32[i] = l ? dist_entry(e16 >> 4, l) : 0u;
+        }
       }
       __syncthreads();
       {  // finished segments of the ring go out; at the end, the tail
@@ -326,7 +368,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   else if (preserve_dst) TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, dst, (size_t)dst_bytes, hipMemcpyHostToDevice, c->stream));  // (the bytes between the blocks come back as they were)
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_desc, descs, (size_t)n * sizeof(infl::BlockDesc), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 10);
+  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 12);
   hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
                      (uint8_t*)d_status, (unsigned int*)d_counter);
   TRGT_HIP_TRY(c, hipGetLastError());

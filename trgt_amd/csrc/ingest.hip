@@ -705,8 +705,8 @@ static int device_reads(trgt_ingest* h, const trgt_ingest_params* p, const std::
   const int rc = ingd::slot_run(slot, in, *h->slab_pool, res, err);
   if (rc) return rc;
   h->dev_blocks += (int64_t)blocks.size(); h->dev_blocks_host += (int64_t)res.blocks_host_inflated;
-  if (trace) std::fprintf(stderr, "[ingest]   device: %zu ranges, %zu blocks (%.1f MB -> %.1f MB), file %.1f ms, headers %.1f ms, upload+inflate+crc %.1f ms (%llu blocks by zlib), walk %.1f ms, reads %.1f ms, download %.1f ms, fallback %d\n",
-                          merged.size(), blocks.size(), (double)src_total / 1e6, (double)lin / 1e6, t_read - t0, t_walk - t_read, res.ms_inflate, (unsigned long long)res.blocks_host_inflated, res.ms_walk, res.ms_reads, res.ms_download, res.fallback);
+  if (trace) std::fprintf(stderr, "[ingest]   device: %zu ranges, %zu blocks (%.1f MB -> %.1f MB), file %.1f ms, headers %.1f ms, upload+inflate+crc %.1f ms (%llu blocks by zlib), walk %.1f ms, read sizes %.1f ms, slab + fill launch %.1f ms, fill + download %.1f ms, fallback %d\n",
+                          merged.size(), blocks.size(), (double)src_total / 1e6, (double)lin / 1e6, t_read - t0, t_walk - t_read, res.ms_inflate, (unsigned long long)res.blocks_host_inflated, res.ms_walk, res.ms_reads, res.ms_upload, res.ms_download, res.fallback);
   return TRGT_OK;
 }
 
