@@ -35,7 +35,6 @@ struct Shared {
   uint32_t copy_src, copy_dst, copy_len;  // EV_COPY: stored bytes src[copy_src ..) -> out[copy_dst ..)
   uint32_t nlit, ndist;   // EV_BUILD
   uint32_t block;         // the claimed block
-  uint16_t lit_tab[1 << LIT_BITS], dist_tab[1 << DIST_BITS];  // symbol << 4 | code length (0: longer than the table's bits): staging of the table fill
   uint32_t lit32[1 << LIT_BITS], dist32[1 << DIST_BITS];      // what the symbol loop reads: see lit_entry / dist_entry
   uint16_t lit_cnt[16], dist_cnt[16];     // codes per length (canonical decoding of the long codes, and the checks)
   uint16_t lit_sym[288], dist_sym[32];    // symbols in code order
@@ -77,6 +76,7 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t ds, uint32_t l) {
 // canonical decoding bit by bit (codes longer than the table's bits: rare symbols by construction)
 __device__ __forceinline__ int slow_decode(const uint16_t* cnt, const uint16_t* sym, uint64_t bits, int& len_out) {
   int code = 0, first = 0, index = 0;
+#pragma unroll 1
   for (int len = 1; len <= 15; ++len) {
     code |= (int)(bits & 1); bits >>= 1;
     const int c = (int)RFL(cnt[len]);
@@ -217,52 +217,57 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
           } else {
             // ---- symbols of a Huffman block: a loop of its own that is left only for an event (its iterations carry no state-machine
             // bookkeeping: the symbol loop is bound by scalar instruction issue).  One bound covers "the window runs low" and "the input is over"
+            // (written with one back edge and one exit: breaks out of nested branches make the compiler carry flag registers through
+            //  every iteration)
             const bool to_end = wb + IN_WIN >= in_len + 8;
             const uint32_t safe_end = to_end ? in_len + 8 : wb + IN_WIN - 16;
-            for (;;) {
-              if (in_pos > safe_end) { want = to_end ? (uint32_t)EV_ERROR : (uint32_t)EV_RELOAD; break; }
+            const uint32_t low_ev = to_end ? (uint32_t)EV_ERROR : (uint32_t)EV_RELOAD;
+            uint32_t ev = in_pos > safe_end ? low_ev : (uint32_t)EV_NONE;
+            while (ev == EV_NONE) {
               refill();  // (>= 32 bits: a literal / length code and its extra bits take at most 15 + 5)
               uint32_t e = RFL(sh.lit32[bitbuf & ((1u << LIT_BITS) - 1u)]);
-              if (!(e & 15u)) { int l; const int sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); if (sym < 0) { want = EV_ERROR; break; } e = lit_entry((uint32_t)sym, (uint32_t)l); }
+              if (!(e & 15u)) { int l; const int sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); e = sym < 0 ? (F_BAD | 1u) : lit_entry((uint32_t)sym, (uint32_t)l); }
               take(e & 15u);
+              const uint32_t before = op;
               if (e & F_LIT) {
-                const uint32_t before = op;
                 sh.out[op & RING_MASK] = (uint8_t)(e >> 16); ++op;
                 if (e & F_PAIR) { sh.out[op & RING_MASK] = (uint8_t)(e >> 24); ++op; }
-                if (op > out_len) { want = EV_ERROR; break; }
-                if ((before ^ op) & SEG) { want = EV_FLUSH; break; }
-                continue;
-              }
-              if (e & (F_EOB | F_BAD)) { if (e & F_BAD) want = EV_ERROR; else { phase = 0; if (final_block) want = EV_DONE; } break; }
-              const uint32_t len = (e >> 16) + take((e >> 4) & 15u);
-              refill();  // (a distance code and its extra bits: at most 15 + 13)
-              uint32_t d = RFL(sh.dist32[bitbuf & ((1u << DIST_BITS) - 1u)]);
-              if (!(d & 15u)) { int dl; const int ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); if (ds < 0) { want = EV_ERROR; break; } d = dist_entry((uint32_t)ds, (uint32_t)dl); }
-              if (d & F_BAD) { want = EV_ERROR; break; }
-              take(d & 15u);
-              const uint32_t dist = (d >> 16) + take((d >> 4) & 15u);
-              if (dist > op || op + len > out_len) { want = EV_ERROR; break; }
-              const uint32_t before = op;
-              // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
-              // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
-              // A source byte still in the ring (not overwritten before this copy ends: its position + RING >= op + len) comes from LDS;
-              // an older one was flushed (every finished segment goes out before decoding continues) and is read back from the output.
-              if (len <= 64u && dist >= len && op - dist + RING >= op + len) {  // the common case in one round: no overlap, the source still in the ring
-                if ((uint32_t)lane < len) sh.out[(op + (uint32_t)lane) & RING_MASK] = sh.out[(op - dist + (uint32_t)lane) & RING_MASK];
-              } else
-              for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (dist >= 64: a round only reads what earlier rounds or earlier symbols wrote)
-                const uint32_t k = k0 + (uint32_t)lane;
-                if (k < len) {
-                  const uint32_t sp = dist >= 64u ? op + k - dist : dist == 1u ? op - 1u : op - dist + k % dist;
-                  uint8_t v;
-                  if (sp + RING >= op + len) v = sh.out[sp & RING_MASK];
-                  else v = __hip_atomic_load(outp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  sh.out[(op + k) & RING_MASK] = v;
+              } else if (e & (F_EOB | F_BAD)) {
+                if (e & F_BAD) ev = EV_ERROR;
+                else { phase = 0; ev = final_block ? (uint32_t)EV_DONE : (uint32_t)EV_BUILD; }  // (EV_BUILD stands for "leave the loop, nothing to do": reset below)
+              } else {
+                const uint32_t len = (e >> 16) + take((e >> 4) & 15u);
+                refill();  // (a distance code and its extra bits: at most 15 + 13)
+                uint32_t d = RFL(sh.dist32[bitbuf & ((1u << DIST_BITS) - 1u)]);
+                if (!(d & 15u)) { int dl; const int ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); d = ds < 0 ? (F_BAD | 1u) : dist_entry((uint32_t)ds, (uint32_t)dl); }
+                take(d & 15u);
+                const uint32_t dist = (d >> 16) + take((d >> 4) & 15u);
+                if ((d & F_BAD) || dist > op || op + len > out_len) ev = EV_ERROR;
+                else {
+                  // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
+                  // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
+                  // A source byte still in the ring (not overwritten before this copy ends: its position + RING >= op + len) comes from LDS;
+                  // an older one was flushed (every finished segment goes out before decoding continues) and is read back from the output.
+                  if (len <= 64u && dist >= len && op - dist + RING >= op + len) {  // the common case in one round: no overlap, the source still in the ring
+                    if ((uint32_t)lane < len) sh.out[(op + (uint32_t)lane) & RING_MASK] = sh.out[(op - dist + (uint32_t)lane) & RING_MASK];
+                  } else {
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {  // (dist >= 64: a round only reads what earlier rounds or earlier symbols wrote)
+                      const uint32_t k = k0 + (uint32_t)lane;
+                      if (k < len) {
+                        const uint32_t sp = dist >= 64u ? op + k - dist : dist == 1u ? op - 1u : op - dist + k % dist;
+                        uint8_t v;
+                        if (sp + RING >= op + len) v = sh.out[sp & RING_MASK];
+                        else v = __hip_atomic_load(outp + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sh.out[(op + k) & RING_MASK] = v;
+                      }
+                    }
+                  }
+                  op += len;
                 }
               }
-              op += len;
-              if ((before ^ op) & SEG) { want = EV_FLUSH; break; }
+              if (ev == EV_NONE) ev = op > out_len ? (uint32_t)EV_ERROR : ((before ^ op) & SEG) ? (uint32_t)EV_FLUSH : in_pos > safe_end ? low_ev : (uint32_t)EV_NONE;
             }
+            want = ev == EV_BUILD ? (uint32_t)EV_NONE : ev;
           }
         }
         if (want == EV_RELOAD) {
@@ -294,8 +299,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         for (uint32_t i = (uint32_t)lane; i < cl; i += 64) sh.out[(o + i) & RING_MASK] = in[cs + i];
       } else if (ev == EV_BUILD) {
         const uint32_t nlit = sh.nlit, ndist = sh.ndist;
-        for (uint32_t i = (uint32_t)lane; i < (1u << LIT_BITS); i += 64) sh.lit_tab[i] = 0;
-        for (uint32_t i = (uint32_t)lane; i < (1u << DIST_BITS); i += 64) sh.dist_tab[i] = 0;
+        for (uint32_t i = (uint32_t)lane; i < (1u << LIT_BITS); i += 64) sh.lit32[i] = 0;
+        for (uint32_t i = (uint32_t)lane; i < (1u << DIST_BITS); i += 64) sh.dist32[i] = 0;
         __syncthreads();
         for (uint32_t s = (uint32_t)lane; s < nlit + ndist; s += 64) {
           const uint32_t l = sh.lens[s];
@@ -303,27 +308,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8)))
           const bool is_dist = s >= nlit;
           const uint32_t bits = is_dist ? (uint32_t)DIST_BITS : (uint32_t)LIT_BITS;
           if (l > bits) continue;
-          uint16_t* tab = is_dist ? sh.dist_tab : sh.lit_tab;
-          const uint16_t entry = (uint16_t)(((is_dist ? s - nlit : s) << 4) | l);
+          uint32_t* tab = is_dist ? sh.dist32 : sh.lit32;
+          const uint32_t entry = (is_dist ? dist_entry(s - nlit, l) : lit_entry(s, l)) | (l << 12);  // (bits 12-15: the code's own length, which pairing leaves alone)
           for (uint32_t i = rev_bits(sh.code[s], (int)l); i < (1u << bits); i += 1u << l) tab[i] = entry;
         }
         __syncthreads();
-        // the entries the symbol loop reads; two literals in one entry where the second one's code lies inside the index as well
+        // two literals in one entry where the second one's code lies inside the index as well.  In place: a lane reads the byte, the
+        // literal flag and bits 12-15 of another entry, which no lane changes
         for (uint32_t i = (uint32_t)lane; i < (1u << LIT_BITS); i += 64) {
-          const uint32_t e16 = sh.lit_tab[i], l = e16 & 15u, sym = e16 >> 4;
-          uint32_t e = 0;
-          if (l) {
-            e = lit_entry(sym, l);
-            if (sym < 256u && l < (uint32_t)LIT_BITS) {
-              const uint32_t e2 = sh.lit_tab[i >> l], l2 = e2 & 15u, s2 = e2 >> 4;
-              if (l2 && s2 < 256u && l + l2 <= (uint32_t)LIT_BITS) e = (l + l2) | F_LIT | F_PAIR | (sym << 16) | (s2 << 24);
-            }
+          const uint32_t e = sh.lit32[i], l = (e >> 12) & 15u;
+          if ((e & F_LIT) && l < (uint32_t)LIT_BITS) {
+            const uint32_t e2 = sh.lit32[i >> l], l2 = (e2 >> 12) & 15u;
+            if ((e2 & F_LIT) && l + l2 <= (uint32_t)LIT_BITS) sh.lit32[i] = (e & 0x00FFF000u) | (l + l2) | F_LIT | F_PAIR | ((e2 & 0x00FF0000u) << 8);
           }
-          sh.lit32[i] = e;
-        }
-        for (uint32_t i = (uint32_t)lane; i < (1u << DIST_BITS); i += 64) {
-          const uint32_t e16 = sh.dist_tab[i], l = e16 & 15u;
-          sh.dist32[i] = l ? dist_entry(e16 >> 4, l) : 0u;
         }
       }
       __syncthreads();
@@ -368,7 +365,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   else if (preserve_dst) TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, dst, (size_t)dst_bytes, hipMemcpyHostToDevice, c->stream));  // (the bytes between the blocks come back as they were)
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_desc, descs, (size_t)n * sizeof(infl::BlockDesc), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 12);
+  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 15);
   hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
                      (uint8_t*)d_status, (unsigned int*)d_counter);
   TRGT_HIP_TRY(c, hipGetLastError());
