@@ -246,13 +246,13 @@ def _pick(d, keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
 
 
-ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_at_reference_work", "bound_measured", "valu_issue_frac",
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_io_only", "frac_traffic", "frac_at_reference_work", "bound_measured", "valu_issue_frac",
                  "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "dp_cells_per_launch")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 CONFIG_KEYS = ("workload", "baseline_config", "value_streaming", "value_streaming_bam4", "value_single_context", "ms_per_step_single_context",
                "contexts_per_gpu", "loci_per_gpu", "reads_per_locus", "parallelism", "host_cpu_quota")
-E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_device_inflate", "gpu_loci_per_s", "gpu_loci_per_s_two_contexts", "gpu_loci_per_s_four_contexts", "write_loci_per_s", "write_loci_per_s_device_deflate",
-            "pipeline_loci_per_s", "pipeline_loci_per_s_bam_level_1", "pipeline_loci_per_s_device_deflate", "pipeline_vcf_identical")
+E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_host", "gpu_loci_per_s", "gpu_loci_per_s_two_contexts", "gpu_loci_per_s_four_contexts", "write_loci_per_s", "write_loci_per_s_device_deflate",
+            "pipeline_loci_per_s", "pipeline_loci_per_s_device_ingest_host_deflate", "pipeline_loci_per_s_host_ingest", "pipeline_vcf_identical")
 
 
 def _short(s, n):
@@ -288,7 +288,7 @@ def compact_line(res, detail_path=None):
             continue
         leg = _pick(r, ("value", "ms_per_step"))
         leg.update(_pick(r.get("config", {}), ("value_single_context", "ms_per_step_single_context", "loci_per_gpu")))
-        leg["roofline"] = _pick(r.get("roofline", {}), ("kernel", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "bound_measured"))
+        leg["roofline"] = _pick(r.get("roofline", {}), ("kernel", "frac", "frac_io_only", "frac_traffic", "valu_issue_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "bound_measured"))
         leg["cpu_baseline"] = (r.get("cpu_baseline") or {}).get("value")
         leg["parity"] = _pick(r.get("parity", {}), ("parity_checked_loci", "mismatches"))
         legs[k] = leg
@@ -327,10 +327,12 @@ def write_detail(res, path=None):
 
 def run_e2e(args, env):
     """BAM -> VCF on this box: a synthetic coordinate-sorted BAM of full-length reads over cfg2-like loci (trgt_amd/synth_bam.py) through
-    the native ingestion (trgt_ingest_batch_from_catalog: .bai lookup, BGZF inflate, record decoding, clip_to_region; all host cores, 4-bit
-    reads kept), the locus path (reads handed over as host buffers, 4-bit) and the native VCF + spanning-BAM writer (trgt_writer_write).
-    Every stage is timed on its own over the same chunks, then the three run as a pipeline (one thread per stage, chunk queues between
-    them): that wall time is what a user of the whole tool would see.  None of this is `value`."""
+    the native ingestion (trgt_ingest_batch_from_catalog), the locus path and the native VCF + spanning-BAM writer (trgt_writer_write).
+    Ingestion two ways: the host path (.bai lookup, BGZF inflate with zlib, record decoding, clip_to_region on all host cores) and the
+    device path (trgt_ingest_params.ingest_device, round 6: the compressed blocks go to the GPU, inflate + CRC-32 + record walk + clipping are
+    kernels, only the clipped reads come back and the ASCII reads stay in HBM for the locus stage; INGEST_CALLERS host threads keep
+    that many chunks in flight).  Every stage is timed on its own over the same chunks, then the three run as a pipeline (chunk queues
+    between them): that wall time is what a user of the whole tool would see.  None of this is `value`."""
     import queue
     import shutil
     import tempfile
@@ -338,42 +340,100 @@ def run_e2e(args, env):
     from trgt_amd import _lib, ingest, locus, shard, synth_bam, writers
     cores = os.cpu_count() or 8
     n, chunk = args.e2e_loci, 1000
+    INGEST_CALLERS = 3  # (the slots of device state a reader has: file read, upload, kernels and download of consecutive chunks overlap)
     d = tempfile.mkdtemp(prefix="trgt_e2e_")
     try:
         t0 = time.perf_counter()
         ds = synth_bam.write_dataset(d, n_loci=n, read_len=args.e2e_read_len)
         t_gen = time.perf_counter() - t0
         rd = ingest.Reader(ds["bam"], ds["fasta"])
-        firsts = list(range(0, n, chunk))
-        ing_threads = min(32, cores)  # measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64, 10 k with 256 -- under the box's CFS quota of 16 CPUs (cpu_quota()): 15 x one thread is all the quota gives
-        ing = lambda a, th=ing_threads, dev=-1: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1, inflate_device=dev)
-        ing(0)  # page cache, thread start-up
+        firsts = firsts_all = list(range(0, n, chunk))
+        PIPE_PASSES = 3  # the pipelines walk the catalog this many times: with four chunks the fill and the drain of the three stages are half of the run
+        dev = env["local_rank"]
+        ing_threads = min(32, cores)  # host path, measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64 -- under the box's CFS quota of 16 CPUs (cpu_quota())
+        ing_host = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
+        ing_dev = lambda a: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=8, ingest_device=dev)
+
+        def ordered(fn, callers, firsts=None):
+            """fn(first) over the chunks by `callers` threads, results in chunk order (a generator: chunk i is handed out as soon as it and all
+            chunks before it are there; at most callers + 2 results wait)"""
+            firsts = firsts if firsts is not None else firsts_all
+            done, cv, st_, err = {}, threading.Condition(), dict(nxt=0, handed=0), []
+
+            def work():
+                while True:
+                    with cv:
+                        while st_["nxt"] < len(firsts) and st_["nxt"] - st_["handed"] > callers + 1 and not err:
+                            cv.wait(0.01)
+                        i = st_["nxt"]
+                        st_["nxt"] += 1
+                    if i >= len(firsts) or err:
+                        return
+                    try:
+                        r = fn(firsts[i])
+                    except Exception as e:  # noqa: BLE001
+                        err.append(e)
+                        r = None
+                    with cv:
+                        done[i] = r
+                        cv.notify_all()
+            th = [threading.Thread(target=work, daemon=True) for _ in range(callers)]
+            for t in th:
+                t.start()
+            for i in range(len(firsts)):
+                with cv:
+                    while i not in done and not err:
+                        cv.wait(0.05)
+                    if err:
+                        raise err[0]
+                    r = done.pop(i)
+                    st_["handed"] = i + 1
+                    cv.notify_all()
+                yield r
+            for t in th:
+                t.join()
+
+        ing_host(0)  # page cache, thread start-up
         t0 = time.perf_counter()
-        one = ing(0, 1)
+        one = ing_host(0, 1)
         t_ing1 = (time.perf_counter() - t0) / max(1, one["n_loci"])
         t0 = time.perf_counter()
-        batches = [ing(a) for a in firsts]
-        t_ing = time.perf_counter() - t0
-        # ... and with the BGZF blocks of a chunk inflated on the GPU in one batch (trgt_ingest_params.inflate_device, inflate_dev.hip): the
-        # workers then only decode records
-        dev = env["local_rank"]
-        ing(0, ing_threads, dev)
+        batches = [ing_host(a) for a in firsts]
+        t_ing_host = time.perf_counter() - t0
+        # ... the device path: one caller, then INGEST_CALLERS callers
+        ing_dev(0)
         t0 = time.perf_counter()
-        batches_d = [ing(a, ing_threads, dev) for a in firsts]
-        t_ing_dev = time.perf_counter() - t0
-        same_batches = all(int(x["n_reads"]) == int(y["n_reads"]) and np.array_equal(x["read_blob"], y["read_blob"]) and np.array_equal(x["read_off"], y["read_off"]) for x, y in zip(batches, batches_d))
+        batches_d = [ing_dev(a) for a in firsts]
+        t_ing_dev1 = time.perf_counter() - t0
+        same_batches = all(int(x["n_reads"]) == int(y["n_reads"]) and np.array_equal(x["read_blob"], y["read_blob"]) and np.array_equal(x["read_off"], y["read_off"]) and
+                           np.array_equal(x["qual_blob"], y["qual_blob"]) and np.array_equal(x["cigar"], y["cigar"]) and np.array_equal(x["mismatch_offsets"], y["mismatch_offsets"])
+                           for x, y in zip(batches, batches_d))
         del batches_d
+        t0 = time.perf_counter()
+        batches_d = list(ordered(ing_dev, INGEST_CALLERS))
+        t_ing_dev = time.perf_counter() - t0
+        st = rd.device_stats()
+        if st["fallbacks"]:
+            raise SystemExit("bench.py: the device ingestion fell back to the host path (%r)" % (st,))
         views = [ingest.bam4_view(b) for b in batches]
         ctx = _lib.Context(env["local_rank"])
         params = locus.Params(host_threads=min(8, cores))
         gpu = lambda v: locus.run_batch(v, params, ctx)
+        gpu_dev = lambda b: locus.run_batch(b, params, ctx, reads_dev=ingest.device_reads(b))  # the reads the ingestion left in HBM: nothing is uploaded
         for v in views[:2]:
             gpu(v)
         t0 = time.perf_counter()
         outs = [gpu(v) for v in views]
         t_gpu = time.perf_counter() - t0
-        # ... and the same chunks through a pool of contexts draining them (trgt_locus_batch_many, what `value` is measured with): a
-        # 1 000-locus call is a chain of ~40 latency-bound launches, two or four of them in flight fill each other's gaps
+        gpu_dev(batches_d[0])
+        t0 = time.perf_counter()
+        outs_d = [gpu_dev(b) for b in batches_d]
+        t_gpu_dev = time.perf_counter() - t0
+        for a, b2 in zip(outs, outs_d):
+            if shard.result_digest(a, int(a.n_alleles.shape[0])) != shard.result_digest(b2, int(b2.n_alleles.shape[0])):
+                raise SystemExit("bench.py: the e2e chunks from HBM-resident reads gave different results")
+        del outs_d
+        # ... and the same chunks through a pool of contexts draining them (trgt_locus_batch_many, what `value` is measured with)
         t_gpu_pool = {}
         for n_ctx in (2, 4):
             pl = _lib.Pool([env["local_rank"]] * n_ctx)
@@ -394,51 +454,50 @@ def run_e2e(args, env):
             w.write(b, o)
         w.close()
         t_wr = time.perf_counter() - t0
-        # ... and with the BGZF blocks of the spanning BAM deflated on the GPU (trgt_writer_params.deflate_device, deflate_dev.hip: fixed
-        # Huffman codes, one wave per block; the host threads then only format records and compute CRCs)
+        # ... and with the BGZF blocks of the spanning BAM deflated on the GPU (trgt_writer_params.deflate_device, deflate_dev.hip)
         t0 = time.perf_counter()
         w = writers.Writer(rd, os.path.join(d, "outd.vcf"), os.path.join(d, "outd.spanning.bam"), deflate_device=env["local_rank"])
-        for b, o in zip(batches, outs):
+        for b, o in zip(batches_d, outs):  # (the batches of the device path: the writer reads their pinned arrays)
             w.write(b, o)
         w.close()
         t_wr_dev = time.perf_counter() - t0
         bam_bytes_host, bam_bytes_dev = os.path.getsize(os.path.join(d, "out.spanning.bam")), os.path.getsize(os.path.join(d, "outd.spanning.bam"))
         vcf_records = sum(1 for line in open(os.path.join(d, "out.vcf")) if not line.startswith("#"))
-        # the genotypes against what the data set was made from: allele lengths per locus are {len(allele 0), len(allele 1)} by construction
-        # (checked loosely here -- the parity proper is tests/ -- so that a broken hand-over cannot report a rate)
+        # the genotypes against what the data set was made from (checked loosely here -- the parity proper is tests/ -- so that a broken
+        # hand-over cannot report a rate)
         called, at = 0, 0
         for b, o in zip(views, outs):
             k = int(b["n_loci"])
             got = np.sort(o.allele_len[:2 * k].reshape(k, 2).astype(np.int64), axis=1)
             called += int(((got == np.sort(ds["allele_len"][at:at + k], axis=1)).all(axis=1) & (o.n_alleles[:k] == 2)).sum())
             at += k
-        del outs, views, batches
-        # ---- pipeline: ingest | GPU | write, chunk queues of depth 2
-        q1, q2, err = queue.Queue(2), queue.Queue(2), []
+        del outs, views, batches, batches_d
 
-        def stage_ingest(dev_inflate=-1):
-            try:
-                for a in firsts:
-                    q1.put(ing(a, ing_threads, dev_inflate))
-            except Exception as e:  # noqa: BLE001
-                err.append(e)
-            q1.put(None)
-
-        def stage_gpu():
-            try:
-                while True:
-                    b = q1.get()
-                    if b is None:
-                        break
-                    q2.put((b, gpu(ingest.bam4_view(b))))
-            except Exception as e:  # noqa: BLE001
-                err.append(e)
-            q2.put(None)
-
-        def pipeline(tag, dev_inflate, level, dev_deflate=-1):
+        # ---- pipeline: ingest | GPU | write
+        def pipeline(tag, device_ingest, level, dev_deflate=-1):
             w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate)
+            q1, q2, err = queue.Queue(3), queue.Queue(2), []
+
+            def stage_ingest():
+                try:
+                    for b in (ordered(ing_dev, INGEST_CALLERS, firsts * PIPE_PASSES) if device_ingest else (ing_host(a) for a in firsts * PIPE_PASSES)):
+                        q1.put(b)
+                except BaseException as e:  # noqa: BLE001
+                    err.append(e)
+                q1.put(None)
+
+            def stage_gpu():
+                try:
+                    while True:
+                        b = q1.get()
+                        if b is None:
+                            break
+                        q2.put((b, gpu_dev(b) if device_ingest else gpu(ingest.bam4_view(b))))
+                except BaseException as e:  # noqa: BLE001
+                    err.append(e)
+                q2.put(None)
             t0 = time.perf_counter()
-            th = [threading.Thread(target=stage_ingest, args=(dev_inflate,), daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
+            th = [threading.Thread(target=stage_ingest, daemon=True), threading.Thread(target=stage_gpu, daemon=True)]
             for t in th:
                 t.start()
             while True:
@@ -452,26 +511,28 @@ def run_e2e(args, env):
             dt = time.perf_counter() - t0
             if err:
                 raise err[0]
-            return dt, open(os.path.join(d, "out.vcf")).read() == open(os.path.join(d, tag + ".vcf")).read()
+            body = lambda path: [line for line in open(path) if not line.startswith("#")]
+            return dt / PIPE_PASSES, body(os.path.join(d, "out.vcf")) * PIPE_PASSES == body(os.path.join(d, tag + ".vcf"))
 
-        t_pipe, same = pipeline("out2", -1, 6)           # as rounds 1-3 measured it: host inflate, htslib's BAM level
-        t_pipe_fast, same_fast = pipeline("out3", -1, 1)  # the spanning BAM at level 1 (trgt_writer_params.bam_compress_level: a larger file with the same records)
-        t_pipe_dev, same_dev = pipeline("out4", dev, 1)   # ... and the BGZF blocks inflated on the GPU
-        t_pipe_defl, same_defl = pipeline("out5", -1, 6, dev)  # host inflate, the spanning BAM deflated on the GPU
-        same = same and same_dev and same_fast and same_defl
+        t_pipe_host, same = pipeline("out2", False, 6)            # as rounds 1-5 measured it: host ingestion, htslib's BAM level, zlib
+        t_pipe_hostd, same_b = pipeline("out3", False, 6, dev)    # ... the spanning BAM deflated on the GPU
+        t_pipe_dev6, same_c = pipeline("out4", True, 6)           # device ingestion, the spanning BAM by zlib at level 6
+        t_pipe, same_d = pipeline("out5", True, 6, dev)           # device ingestion + device deflate: the host only reads the file, formats records and writes
+        same = same and same_b and same_c and same_d
         r = lambda x: round(x, 1)
         return dict(
             workload="%d cfg2-like loci (motif 2-6 bp, 5-40 copies per allele), %d reads of ~%d bases per locus, one contig; BAM %.1f MB (%d reads, %.0f MB of records), written by trgt_amd/synth_bam.py in %.1f s"
                      % (n, 30, args.e2e_read_len, ds["bam_bytes"] / 1e6, ds["n_reads"], ds["bases"] / 1e6, t_gen),
-            chunk_loci=chunk, ingest_threads=ing_threads, host_cores=cores, host_cpu_quota=cpu_quota(),
-            ingest_loci_per_s=r(n / t_ing), ingest_loci_per_s_one_thread=r(1.0 / t_ing1), ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing),
-            ingest_loci_per_s_device_inflate=r(n / t_ing_dev), ingest_device_inflate_same_batches=bool(same_batches),
-            pipeline_loci_per_s_bam_level_1=r(n / t_pipe_fast), pipeline_loci_per_s_bam_level_1_device_inflate=r(n / t_pipe_dev),
-            gpu_loci_per_s=r(n / t_gpu), gpu_loci_per_s_two_contexts=r(n / t_gpu_pool[2]), gpu_loci_per_s_four_contexts=r(n / t_gpu_pool[4]), write_loci_per_s=r(n / t_wr), pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3),
-            write_loci_per_s_device_deflate=r(n / t_wr_dev), pipeline_loci_per_s_device_deflate=r(n / t_pipe_defl),
+            chunk_loci=chunk, pipeline_passes=PIPE_PASSES, ingest_threads=ing_threads, ingest_callers=INGEST_CALLERS, host_cores=cores, host_cpu_quota=cpu_quota(),
+            ingest_loci_per_s=r(n / t_ing_dev), ingest_loci_per_s_one_caller=r(n / t_ing_dev1), ingest_loci_per_s_host=r(n / t_ing_host), ingest_loci_per_s_host_one_thread=r(1.0 / t_ing1),
+            ingest_record_mb_per_s=r(ds["bases"] / 1e6 / t_ing_dev), ingest_device_same_batches=bool(same_batches), ingest_device_stats=st,
+            gpu_loci_per_s=r(n / t_gpu_dev), gpu_loci_per_s_host_reads=r(n / t_gpu), gpu_loci_per_s_two_contexts=r(n / t_gpu_pool[2]), gpu_loci_per_s_four_contexts=r(n / t_gpu_pool[4]),
+            write_loci_per_s=r(n / t_wr), write_loci_per_s_device_deflate=r(n / t_wr_dev),
+            pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3), pipeline_loci_per_s_device_ingest_host_deflate=r(n / t_pipe_dev6),
+            pipeline_loci_per_s_host_ingest=r(n / t_pipe_host), pipeline_loci_per_s_host_ingest_device_deflate=r(n / t_pipe_hostd),
             spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
-            bound="host: BGZF inflate + record decoding (ingestion) and deflate (spanning BAM); the GPU stage is >10x faster than either, see DESIGN.md")
+            bound="the device inflate (one wave per BGZF block, bound by scalar instruction issue) and the writer's record formatting; see DESIGN.md")
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -788,6 +849,8 @@ def run_one(args, env, cpu_seconds=20.0, all_cores=True):
                        "host_threads_all_ranks": host_threads * args.contexts * world, "gpu_waits": ("poll, spin %s us, nap %s us" % (os.environ.get("TRGT_POLL_SPIN_US", "2000"), os.environ.get("TRGT_POLL_NAP_US", "20"))) if os.environ.get("TRGT_POLL_WAIT", "0") not in ("", "0") else "hipEventSynchronize (spins)", "host_cpus_busy_per_rank": round(cpus_busy, 2) if cpus_busy is not None else None, "workspace_limit_gb_per_context": args.ws_limit_gb or 32.0},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         # what the HBM counters saw (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch) as a fraction of peak: the utilisation proper
+                         "frac_traffic": round(gbs(traffic) / HBM_PEAK_GBS, 6) if traffic else None,
                          # the bound that binds, and the fractions that say the HBM pricing is nominal
                          "bound_measured": "valu-issue" if dom in ("wfa_filter", "wfa_flank", "wfa_flank_rest", "flank_scan") else ("scalar-issue / latency" if dom == "wfa_consensus" else "latency (dependent chain per column)"),
                          "valu_issue_frac": valu_issue_frac, "valu_wave_insts_per_launch": valu_insts,

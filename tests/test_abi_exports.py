@@ -69,3 +69,11 @@ def test_release_library_has_no_result_changing_switch():
     blob = open(os.path.join(ROOT, "trgt_amd", "libtrgt_hip.so"), "rb").read()
     assert b"TRGT_SENS_" not in blob and b"TRGT_DBG_SKIP_BT" not in blob
     assert b"TRGT_WFA_NO_FILTER" in blob   # (the planner knobs, which change no result, are there)
+    # the release library reads at most 30 switches -- exactly the ones _lib.RELEASE_KNOBS lists; the settled A/Bs and
+    # probes (71 names until round 5) are read by the developer build only, which the tests use to create the contexts that pin them
+    import re
+    from trgt_amd import _lib
+    names = set(m.decode() for m in re.findall(rb"TRGT_[A-Z0-9_]{3,}", blob)) - {"TRGT_ERR_", "TRGT_HIP_LIB"}
+    names = {n for n in names if not n.startswith(("TRGT_ERR", "TRGT_K_", "TRGT_WF_", "TRGT_OK", "TRGT_READS"))}
+    assert names == set(_lib.RELEASE_KNOBS), sorted(names ^ set(_lib.RELEASE_KNOBS))
+    assert len(names) <= 30

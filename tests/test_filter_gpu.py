@@ -172,21 +172,18 @@ def test_two_launches_by_text_length_and_forced_instantiations(oracle, monkeypat
     rng = np.random.default_rng(77)
     pats, txts = _flank_jobs(rng, 1400, tlen_lo=300, tlen_hi=890)
     base, ref = _check(oracle, pats, txts)  # (>= 1024 jobs, longest text above 773 bases: two launches)
-    monkeypatch.setenv("TRGT_FILTER_ONE_LAUNCH", "1")
     from trgt_amd import _lib
     one = flank_filter_batch(pats, txts, 175, ctx=_lib.context_with_env(TRGT_FILTER_ONE_LAUNCH=1))
     for k in ("score", "bound", "keep"):
         assert np.array_equal(base[k], one[k]), k
     assert base["offsets"] == one["offsets"]
     for force, max_diag in ((91, 1152), (52, 1280), (42, 1024), (71, 896)):
-        monkeypatch.setenv("TRGT_FILTER_FORCE", str(force))
-        r = flank_filter_batch(pats, txts, 175)
+        r = flank_filter_batch(pats, txts, 175, ctx=_lib.context_with_env(TRGT_FILTER_FORCE=force))  # (developer switches: contexts created by the developer build)
         for j in range(len(pats)):
             if len(pats[j]) + len(txts[j]) + 1 <= max_diag:
                 assert (int(r["score"][j]), int(r["bound"][j]), int(r["keep"][j])) == (int(base["score"][j]), int(base["bound"][j]), int(base["keep"][j])), (force, j)
             else:
                 assert int(r["keep"][j]) == 1, (force, j)
-    monkeypatch.delenv("TRGT_FILTER_FORCE")
 
 
 @pytest.mark.parametrize("seed", [11, 12])

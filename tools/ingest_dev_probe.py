@@ -43,9 +43,10 @@ def run(callers, **kw):
 
 
 if os.environ.get("PROBE_DEVICE_ONLY"):  # (for a kernel trace: the device path alone, one caller)
+    callers = int(os.environ["PROBE_DEVICE_ONLY"])
     for _ in range(3):
-        dt, nr = run(1, ingest_device=0, threads=8)
-        print("device path, 1 caller: %7.0f loci/s (%d reads)" % (n / dt, nr), flush=True)
+        dt, nr = run(callers, ingest_device=0, threads=8)
+        print("device path, %d caller(s): %7.0f loci/s (%d reads)" % (callers, n / dt, nr), flush=True)
     sys.exit(0)
 run(1, threads=16)
 for threads in (16, 32):

@@ -151,11 +151,14 @@ def lib():
 class Context:
     """One GPU + one HIP stream (mirrors the thread_local aligners of src/commands/genotype.rs:94-103)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, creator=None):
+        # creator: the library whose trgt_hip_create reads the planner knobs (the developer build reads all of them: context_with_env);
+        # every other call goes through the release library, whose code honours the knobs a context carries
         h = _VP()
-        rc = lib().trgt_hip_create(int(device), C.byref(h))
+        L = creator or lib()
+        rc = L.trgt_hip_create(int(device), C.byref(h))
         if rc != 0:
-            raise TrgtHipError("trgt_hip_create(device=%d) failed (%d): %s" % (device, rc, lib().trgt_hip_last_error(None).decode()))
+            raise TrgtHipError("trgt_hip_create(device=%d) failed (%d): %s" % (device, rc, L.trgt_hip_last_error(None).decode()))
         self.handle = h
         self.device = device
 
@@ -241,14 +244,50 @@ class Pool:
             pass
 
 
+# the planner switches the RELEASE library reads (tests/test_abi_exports.py pins this list against `strings libtrgt_hip.so`); every other
+# TRGT_* switch -- settled A/Bs, probes -- is read only by the developer build (make -C trgt_amd/csrc DEV=1 -> libtrgt_hip_dev.so)
+RELEASE_KNOBS = frozenset("TRGT_" + k for k in (
+    "CLUSTER_ARENA_KB HEAVY_BAND HMM_NO_DEDUPE HMM_NO_LONG_TB HMM_NO_PPL HOST_CLUSTER HOST_GENOTYPER HOST_REPAIR INGEST_TRACE MALLOC_TUNE NO_HAMMING "
+    "NO_INDEL_SHORTCUT NO_LONG_FILTER NO_ZERO_ARENA POLL_NAP_US POLL_SPIN_US POLL_WAIT REPAIR_MAX_SEG STAGE_LOCK TIMELINE WFA_DEBUG WFA_NO_EARLY "
+    "WFA_NO_FILTER WFA_NO_LEAN WFA_NO_WINDOW WRITER_TRACE").split())
+_DEV_SO = os.path.join(_HERE, "libtrgt_hip_dev.so")
+_DEV_LIB = None
+
+
+def dev_lib():
+    """The developer build (reads every planner switch), used only to CREATE contexts; None when it is not built."""
+    global _DEV_LIB
+    if _DEV_LIB is None and os.path.exists(_DEV_SO):
+        L = C.CDLL(_DEV_SO)
+        L.trgt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.trgt_hip_last_error.argtypes = [C.c_void_p]
+        L.trgt_hip_last_error.restype = C.c_char_p
+        _DEV_LIB = L
+    return _DEV_LIB
+
+
+def build_dev_extension():
+    """make -C trgt_amd/csrc DEV=1 (objects under csrc/dev/): libtrgt_hip_dev.so"""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "DEV=1", "-j8"], stdout=subprocess.DEVNULL)
+    return _DEV_SO
+
+
 def context_with_env(device=0, **env):
     """A NEW context created while the given TRGT_* planner knobs are set in the environment: the library reads them once, in
-    trgt_hip_create (none of them changes a result; the parity tests use them to pin every planner path)."""
+    trgt_hip_create (none of them changes a result; the parity tests use them to pin every planner path).  A switch outside
+    RELEASE_KNOBS is read by the developer build only: the context is then created by libtrgt_hip_dev.so (pytest skips when it is not
+    built) and used through the release library like any other."""
+    creator = None
+    if any(k not in RELEASE_KNOBS for k in env):
+        creator = dev_lib()
+        if creator is None:
+            import pytest
+            pytest.skip("developer switches %s need trgt_amd/libtrgt_hip_dev.so (make -C trgt_amd/csrc DEV=1)" % sorted(k for k in env if k not in RELEASE_KNOBS))
     old = {k: os.environ.get(k) for k in env}
     try:
         for k, v in env.items():
             os.environ[k] = str(v)
-        return Context(device)
+        return Context(device, creator)
     finally:
         for k, v in old.items():
             if v is None:

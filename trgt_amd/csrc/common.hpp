@@ -21,7 +21,16 @@
 // results -- TRGT_SENS_* (the un-pinned choices flipped, tools/unpinned_sensitivity.py) and TRGT_DBG_SKIP_BT -- are read only under
 // `make DEV=1` (TRGT_DEV_BUILD); in the default build their fields keep the defaults below and the names are not in the binary
 // (tests/test_abi_exports.py checks).
+// Developer switches (settled A/Bs, probes) are read only in `make DEV=1` builds: in the release library the expression is a null pointer
+// and the name is not in the binary.
+#ifdef TRGT_DEV_BUILD
+#define TRGT_DEV_ENV(name) getenv(name)
+#else
+#define TRGT_DEV_ENV(name) ((const char*)nullptr)
+#endif
+
 struct trgt_knobs {
+  int filter_force = 0;      // TRGT_FILTER_FORCE (DEV): one instantiation of the pre-filter for the whole launch (42 / 52 / 71 / 91), developer probe
   int flank_threads = 256;   // TRGT_FLANK_THREADS: threads per flank alignment of the back-tracing kernel
   int heavy_band = 96;       // TRGT_HEAVY_BAND: the back-trace of what the pre-filter keeps runs inside the band its penalty allows when that is at most this (0: off)
   int heavy_threads = 0;     // TRGT_HEAVY_THREADS: ... of its launch over the expensive alignments (0: 192 when flank_threads == 256)
@@ -417,7 +426,7 @@ inline hipError_t stream_wait(trgt_hip_ctx* c, hipStream_t stream) {
 // caller may then reuse src at once); < 0: src is pinned and stays untouched until the stream has passed the copy.
 inline int h2d_small(trgt_hip_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t stream, int stage_slot) {
   if (bytes == 0) return TRGT_OK;
-  static const size_t kmax = [] { const char* e = getenv("TRGT_H2D_KERNEL_MAX"); return e && *e ? (size_t)atoll(e) : H2D_KERNEL_MAX; }();
+  static const size_t kmax = [] { const char* e = TRGT_DEV_ENV("TRGT_H2D_KERNEL_MAX"); return e && *e ? (size_t)atoll(e) : H2D_KERNEL_MAX; }();
   if (bytes > kmax) { TRGT_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return TRGT_OK; }
   const void* from = src;
   if (stage_slot >= 0 && !is_pinned_host_ptr(src)) {

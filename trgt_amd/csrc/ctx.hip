@@ -84,15 +84,25 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
     trgt_knobs& k = c->knobs;
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
     auto flag = [](const char* name) { const char* e = getenv(name); return e != nullptr && *e != 0 && std::strcmp(e, "0") != 0; };
-    k.flank_threads = num("TRGT_FLANK_THREADS", k.flank_threads); k.heavy_threads = num("TRGT_HEAVY_THREADS", 0); k.heavy_band = std::max(0, std::min(num("TRGT_HEAVY_BAND", k.heavy_band), 256));
-    k.win_threads = num("TRGT_WIN_THREADS", k.win_threads); { const int bt = num("TRGT_BAND_THREADS", k.band_threads); k.band_threads = bt == 128 || bt == 256 ? bt : 64; } k.win_segments = num("TRGT_WIN_SEGMENTS", k.win_segments);
-    k.grid_per_cu = num("TRGT_WFA_GRID_PER_CU", 0); k.filter_per_cu = num("TRGT_FILTER_PER_CU", 0);
-    k.one_launch = flag("TRGT_WFA_ONE_LAUNCH"); k.no_spec = flag("TRGT_WFA_NO_SPEC"); k.no_window = flag("TRGT_WFA_NO_WINDOW"); k.no_hamming = flag("TRGT_NO_HAMMING"); k.no_indel_shortcut = flag("TRGT_NO_INDEL_SHORTCUT"); k.no_heavy_window = flag("TRGT_NO_HEAVY_WINDOW"); { const char* e = getenv("TRGT_EARLY_ADAPTIVE"); if (e && *e) k.early_adaptive = std::strcmp(e, "0") != 0; }
-    k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.one_stream = flag("TRGT_FLANK_ONE_STREAM"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.host_hmm_lists = flag("TRGT_HOST_HMM_LISTS"); k.no_early = flag("TRGT_WFA_NO_EARLY"); k.stage_lock = flag("TRGT_STAGE_LOCK"); k.no_long_filter = flag("TRGT_NO_LONG_FILTER"); k.no_long_window = flag("TRGT_NO_LONG_WINDOW"); k.filter_one_launch = flag("TRGT_FILTER_ONE_LAUNCH"); k.filter_serial = flag("TRGT_FILTER_SERIAL"); k.filter_side = flag("TRGT_FILTER_SIDE"); k.wfa_no_stage = flag("TRGT_WFA_NO_STAGE"); k.wfa_no_wave_variant = flag("TRGT_WFA_NO_WAVE_VARIANT"); k.hmm_resolve_one_wg = flag("TRGT_HMM_RESOLVE_ONE_WG"); k.debug = flag("TRGT_WFA_DEBUG");
+    // DEV_FLAG / DEV_NUM: switches whose A/B is settled (tools/README.md) -- read in `make DEV=1` builds only; the release library keeps
+    // their code paths at the defaults and does not carry their names (tests/test_abi_exports.py counts what it carries)
+#ifdef TRGT_DEV_BUILD
+#define DEV_FLAG(name) flag(name)
+#define DEV_NUM(name, dflt) num(name, dflt)
+#else
+#define DEV_FLAG(name) false
+#define DEV_NUM(name, dflt) (dflt)
+#endif
+    (void)num; (void)flag;
+    k.flank_threads = DEV_NUM("TRGT_FLANK_THREADS", k.flank_threads); k.heavy_threads = DEV_NUM("TRGT_HEAVY_THREADS", 0); k.heavy_band = std::max(0, std::min(num("TRGT_HEAVY_BAND", k.heavy_band), 256));
+    k.win_threads = DEV_NUM("TRGT_WIN_THREADS", k.win_threads); { const int bt = DEV_NUM("TRGT_BAND_THREADS", k.band_threads); k.band_threads = bt == 128 || bt == 256 ? bt : 64; } k.win_segments = DEV_NUM("TRGT_WIN_SEGMENTS", k.win_segments);
+    k.grid_per_cu = DEV_NUM("TRGT_WFA_GRID_PER_CU", 0); k.filter_per_cu = DEV_NUM("TRGT_FILTER_PER_CU", 0);
+    k.one_launch = DEV_FLAG("TRGT_WFA_ONE_LAUNCH"); k.no_spec = DEV_FLAG("TRGT_WFA_NO_SPEC"); k.no_window = flag("TRGT_WFA_NO_WINDOW"); k.no_hamming = flag("TRGT_NO_HAMMING"); k.no_indel_shortcut = flag("TRGT_NO_INDEL_SHORTCUT"); k.no_heavy_window = DEV_FLAG("TRGT_NO_HEAVY_WINDOW"); { const char* e = TRGT_DEV_ENV("TRGT_EARLY_ADAPTIVE"); if (e && *e) k.early_adaptive = std::strcmp(e, "0") != 0; }
+    k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.one_stream = DEV_FLAG("TRGT_FLANK_ONE_STREAM"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.host_hmm_lists = DEV_FLAG("TRGT_HOST_HMM_LISTS"); k.no_early = flag("TRGT_WFA_NO_EARLY"); k.stage_lock = flag("TRGT_STAGE_LOCK"); k.no_long_filter = flag("TRGT_NO_LONG_FILTER"); k.no_long_window = DEV_FLAG("TRGT_NO_LONG_WINDOW"); k.filter_force = DEV_NUM("TRGT_FILTER_FORCE", 0); k.filter_one_launch = DEV_FLAG("TRGT_FILTER_ONE_LAUNCH"); k.filter_serial = DEV_FLAG("TRGT_FILTER_SERIAL"); k.filter_side = DEV_FLAG("TRGT_FILTER_SIDE"); k.wfa_no_stage = DEV_FLAG("TRGT_WFA_NO_STAGE"); k.wfa_no_wave_variant = DEV_FLAG("TRGT_WFA_NO_WAVE_VARIANT"); k.hmm_resolve_one_wg = DEV_FLAG("TRGT_HMM_RESOLVE_ONE_WG"); k.debug = flag("TRGT_WFA_DEBUG");
     k.timeline = flag("TRGT_TIMELINE");
-    k.host_repair = flag("TRGT_HOST_REPAIR"); k.host_cluster = flag("TRGT_HOST_CLUSTER"); k.cluster_arena_kb = num("TRGT_CLUSTER_ARENA_KB", 0); k.hmm_lds_fill = flag("TRGT_HMM_LDS_FILL"); k.hmm_four_rounds = flag("TRGT_HMM_FOUR_ROUNDS"); k.hmm_no_ppl = flag("TRGT_HMM_NO_PPL"); k.hmm_long_wgs = std::max(1, std::min(num("TRGT_HMM_LONG_WGS", k.hmm_long_wgs), 16)); k.hmm_no_long_tb = flag("TRGT_HMM_NO_LONG_TB"); k.hmm_no_dedupe = flag("TRGT_HMM_NO_DEDUPE"); k.repair_max_seg = num("TRGT_REPAIR_MAX_SEG", k.repair_max_seg); k.split_hmm = flag("TRGT_SPLIT_HMM"); k.repair_blocks = num("TRGT_REPAIR_BLOCKS", k.repair_blocks);
-    k.no_lean = flag("TRGT_WFA_NO_LEAN"); k.lean_one_tier = flag("TRGT_WFA_LEAN_ONE_TIER"); k.lean_mid_tier = flag("TRGT_WFA_LEAN_MID_TIER"); k.lean_chunk = num("TRGT_LEAN_CHUNK", 0); k.no_zero_arena = flag("TRGT_NO_ZERO_ARENA"); k.hmm_ppl_serial = flag("TRGT_HMM_PPL_SERIAL"); k.hmm_ppl_per_class = flag("TRGT_HMM_PPL_PER_CLASS");
-    k.no_lds_wfa = !flag("TRGT_WFA_LDS"); k.lds_wfa_kb = num("TRGT_WFA_LDS_KB", k.lds_wfa_kb); k.lds_wfa_seq = num("TRGT_WFA_LDS_SEQ", k.lds_wfa_seq);
+    k.host_repair = flag("TRGT_HOST_REPAIR"); k.host_cluster = flag("TRGT_HOST_CLUSTER"); k.cluster_arena_kb = num("TRGT_CLUSTER_ARENA_KB", 0); k.hmm_lds_fill = DEV_FLAG("TRGT_HMM_LDS_FILL"); k.hmm_four_rounds = DEV_FLAG("TRGT_HMM_FOUR_ROUNDS"); k.hmm_no_ppl = flag("TRGT_HMM_NO_PPL"); k.hmm_long_wgs = std::max(1, std::min(DEV_NUM("TRGT_HMM_LONG_WGS", k.hmm_long_wgs), 16)); k.hmm_no_long_tb = flag("TRGT_HMM_NO_LONG_TB"); k.hmm_no_dedupe = flag("TRGT_HMM_NO_DEDUPE"); k.repair_max_seg = num("TRGT_REPAIR_MAX_SEG", k.repair_max_seg); k.split_hmm = DEV_FLAG("TRGT_SPLIT_HMM"); k.repair_blocks = DEV_NUM("TRGT_REPAIR_BLOCKS", k.repair_blocks);
+    k.no_lean = flag("TRGT_WFA_NO_LEAN"); k.lean_one_tier = DEV_FLAG("TRGT_WFA_LEAN_ONE_TIER"); k.lean_mid_tier = DEV_FLAG("TRGT_WFA_LEAN_MID_TIER"); k.lean_chunk = DEV_NUM("TRGT_LEAN_CHUNK", 0); k.no_zero_arena = flag("TRGT_NO_ZERO_ARENA"); k.hmm_ppl_serial = DEV_FLAG("TRGT_HMM_PPL_SERIAL"); k.hmm_ppl_per_class = DEV_FLAG("TRGT_HMM_PPL_PER_CLASS");
+    k.no_lds_wfa = !DEV_FLAG("TRGT_WFA_LDS"); k.lds_wfa_kb = DEV_NUM("TRGT_WFA_LDS_KB", k.lds_wfa_kb); k.lds_wfa_seq = DEV_NUM("TRGT_WFA_LDS_SEQ", k.lds_wfa_seq);
 #ifdef TRGT_DEV_BUILD
     // switches that CHANGE results exist only in `make DEV=1` builds (tools/unpinned_sensitivity.py builds one for itself)
     k.sens_bialign_min_len = num("TRGT_SENS_BIALIGN_MIN_LEN", -1); k.sens_cons_unidir = flag("TRGT_SENS_CONS_UNIDIR"); k.sens_ward_ties = flag("TRGT_SENS_WARD_TIES"); k.sens_lw_order = flag("TRGT_SENS_LW_ORDER");

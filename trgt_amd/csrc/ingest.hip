@@ -37,6 +37,14 @@
 #include "ingest_dev.hpp"
 #include <condition_variable>
 
+#ifndef TRGT_DEV_ENV   // (common.hpp: developer switches are read in `make DEV=1` builds only)
+#ifdef TRGT_DEV_BUILD
+#define TRGT_DEV_ENV(name) getenv(name)
+#else
+#define TRGT_DEV_ENV(name) ((const char*)nullptr)
+#endif
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------- BGZF
@@ -95,7 +103,7 @@ struct Bgzf {
     B.coff = ~0ull;  // (not a valid entry while it is being overwritten)
     B.data.resize(isize);
     bool isize_done = false;
-    static const bool zlib_only = std::getenv("TRGT_ZLIB_INFLATE") != nullptr;  // (the decoder of inflate_fast.hpp is tried first; zlib takes every block it declines)
+    static const bool zlib_only = TRGT_DEV_ENV("TRGT_ZLIB_INFLATE") != nullptr;  // (the decoder of inflate_fast.hpp is tried first; zlib takes every block it declines)
     if (isize && !zlib_only) {
       if (!tables) tables.reset(new trgt::inflate_fast::Tables());
       if (!trgt::inflate_fast::inflate_block(raw.data() + hdr, total - hdr - 8, B.data.data(), isize, *tables)) ++n_declined;

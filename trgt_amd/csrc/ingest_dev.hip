@@ -733,7 +733,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   ING_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(Counters), st));
   ING_TRY(hipMemsetAsync(s->d_status.p, 0, (size_t)nb + 64, st));
   // ---- inflate + CRC-32
-  static const unsigned waves_per_cu = [] { const char* e = std::getenv("TRGT_INFLATE_WAVES_PER_CU"); const int v = e && *e ? std::atoi(e) : 0; return (unsigned)(v > 0 ? v : 15); }();
+  static const unsigned waves_per_cu = [] { const char* e = TRGT_DEV_ENV("TRGT_INFLATE_WAVES_PER_CU"); const int v = e && *e ? std::atoi(e) : 0; return (unsigned)(v > 0 ? v : 15); }();
   int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   trgt::inflate_launch((void*)st, (const uint8_t*)s->d_src.p, (const infl::BlockDesc*)s->d_blocks.p, nb, (uint8_t*)s->d_infl.p, (uint8_t*)s->d_status.p, (unsigned*)s->d_counter.p,
                        (unsigned)cus * waves_per_cu);

@@ -374,7 +374,7 @@ __global__ void repair_check_kernel(const gt::RepairBufs rp, uint64_t read_bytes
 
 static uint32_t* g_trace_dump = nullptr;
 static uint32_t* repair_trace_buf() {
-  if (!getenv("TRGT_REPAIR_TRACE")) return nullptr;
+  if (!TRGT_DEV_ENV("TRGT_REPAIR_TRACE")) return nullptr;
   if (!g_trace_dump) (void)hipHostMalloc((void**)&g_trace_dump, 4096, hipHostMallocDefault);
   return g_trace_dump;
 }
@@ -463,7 +463,7 @@ extern "C" void trgt_locus_default_params(trgt_locus_params* p) {  // cli.rs:271
 static std::mutex g_upload_mutex[16];
 static hipStream_t g_upload_stream[16];
 static hipStream_t bulk_upload_stream(trgt_hip_ctx* c) {
-  static const bool shared = [] { const char* e = getenv("TRGT_SHARED_UPLOAD_STREAM"); return !(e && *e == '0'); }();
+  static const bool shared = [] { const char* e = TRGT_DEV_ENV("TRGT_SHARED_UPLOAD_STREAM"); return !(e && *e == '0'); }();
   if (!shared) return c->stream_copy;
   const size_t d = (size_t)c->device % 16;
   if (!g_upload_stream[d] && hipStreamCreateWithFlags(&g_upload_stream[d], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream_copy; }
@@ -481,13 +481,13 @@ static int issue_pending_uploads(trgt_hip_ctx* c) {
     if (st.d_reads) {
       // in pieces: one copy command of hundreds of MB holds the engine until it is through, and the small copies of the other contexts
       // of a pool queue behind it (TRGT_UPLOAD_CHUNK_MB, default 32; 0 = one command)
-      static const size_t piece = [] { const char* e = getenv("TRGT_UPLOAD_CHUNK_MB"); const long v = e && *e ? atol(e) : 32; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
+      static const size_t piece = [] { const char* e = TRGT_DEV_ENV("TRGT_UPLOAD_CHUNK_MB"); const long v = e && *e ? atol(e) : 32; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
       const size_t total = (size_t)st.read_bytes;
       // TRGT_UPLOAD_KERNEL=<workgroups>: the read bytes are pulled by a copy KERNEL of that many workgroups instead of the copy engine
       // (pinned sources only).  The engine keeps the link's read queue full, and every dispatch of every context -- its queue packet and
       // its arguments are fetched from host memory -- waits behind that queue; a kernel with a bounded number of loads in flight leaves
       // the queue short.  0 = the copy engine.
-      static const int kernel_wgs = [] { const char* e = getenv("TRGT_UPLOAD_KERNEL"); return e && *e ? atoi(e) : 0; }();
+      static const int kernel_wgs = [] { const char* e = TRGT_DEV_ENV("TRGT_UPLOAD_KERNEL"); return e && *e ? atoi(e) : 0; }();
       if (kernel_wgs > 0 && is_pinned_host_ptr(st.in->read_blob)) {
         hipLaunchKernelGGL(h2d_copy_kernel, dim3((unsigned)kernel_wgs), dim3(256), 0, up, const_cast<uint8_t*>(st.d_reads), st.in->read_blob, total);
         TRGT_HIP_TRY(c, hipGetLastError());
@@ -887,7 +887,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       };
       if ((rc = dbg_sync("genotyper"))) return rc;
       if (uint32_t* trace_host = repair_trace_buf()) { std::memset(trace_host, 0, 4096); hipLaunchKernelGGL(repair_trace_kernel, dim3(1), dim3(64), 0, c->stream, rp, trace_host); }
-      static const bool repair_check = getenv("TRGT_REPAIR_CHECK") != nullptr;
+      static const bool repair_check = TRGT_DEV_ENV("TRGT_REPAIR_CHECK") != nullptr;
       if (repair_check) {
         hipLaunchKernelGGL(repair_check_kernel, dim3(64), dim3(256), 0, c->stream, rp, (uint64_t)read_total);
         uint32_t h[gt::RC_WORDS];
@@ -1031,7 +1031,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
   // ---------------- wait for the GPU, publish spans
   {
     { const hipError_t ea = trgt::event_wait(evA);
-      if (g_trace_dump && getenv("TRGT_REPAIR_TRACE")) { const uint32_t* h = g_trace_dump; fprintf(stderr, "[repair trace] evA %s counts:", hipGetErrorString(ea)); for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", h[i]);
+      if (g_trace_dump && TRGT_DEV_ENV("TRGT_REPAIR_TRACE")) { const uint32_t* h = g_trace_dump; fprintf(stderr, "[repair trace] evA %s counts:", hipGetErrorString(ea)); for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", h[i]);
         fprintf(stderr, "\n"); }
       if (ea != hipSuccess) return trgt::fail(c, TRGT_ERR_HIP, "trgt::event_wait(evA) failed: %s", hipGetErrorString(ea)); }
     if (stage_a_token.owns_lock()) stage_a_token.unlock();
@@ -1706,7 +1706,7 @@ extern "C" int trgt_hip_pool_create(const int32_t* devices, int32_t n_contexts, 
   *out = nullptr;
   try {
     std::unique_ptr<trgt_hip_pool> P(new trgt_hip_pool());
-    const char* pe = getenv("TRGT_POOL_PRIORITIES");
+    const char* pe = TRGT_DEV_ENV("TRGT_POOL_PRIORITIES");
     const bool priorities = !(pe && *pe == '0');
     for (int32_t i = 0; i < n_contexts; ++i) {
       trgt_hip_ctx* c = nullptr;
@@ -1749,7 +1749,7 @@ extern "C" int trgt_locus_batch_many(trgt_hip_pool* P, const trgt_locus_params* 
     std::atomic<int64_t> next{0};
     std::atomic<int> first_rc{0};
     std::mutex err_mutex;
-    const bool trace = getenv("TRGT_POOL_TRACE") != nullptr;  // (one line per batch on stderr: context, batch, start and end in ms)
+    const bool trace = TRGT_DEV_ENV("TRGT_POOL_TRACE") != nullptr;  // (one line per batch on stderr: context, batch, start and end in ms)
     const int64_t t_many0 = now_ns();
     auto worker = [&](size_t w) {
       trgt_hip_ctx* c = P->ctx[w];

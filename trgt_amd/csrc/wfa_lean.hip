@@ -923,7 +923,7 @@ int wfa_lean_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& 
                     unsigned int* retry_lost, unsigned int* counters, unsigned long long* cells_out, unsigned int* why_hist) {
   lean::Args a;
   std::memset(&a, 0, sizeof a);
-  static const int no_stage = [] { const char* e = getenv("TRGT_WFA_LEAN_NO_STAGE"); return e ? atoi(e) : 0; }();  // developer switch: 1 / 2 / 3 = tier one / two / both read the sequences from global memory
+  static const int no_stage = [] { const char* e = TRGT_DEV_ENV("TRGT_WFA_LEAN_NO_STAGE"); return e ? atoi(e) : 0; }();  // developer switch: 1 / 2 / 3 = tier one / two / both read the sequences from global memory
   a.stage = !(no_stage & 1);
   // jobs per claim: consensus alignments differ in cost by two orders of magnitude (a wave that draws several expensive ones is the tail of
   // the launch: measured 0.47 ms with one job per claim against 0.9 ms with eight), edit distances of read pairs are alike

@@ -570,8 +570,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   void (*fn)(const FilterArgs) = diag <= 4 * 256 ? wfa_filter_kernel<4, 2> : diag <= 9 * 128 ? wfa_filter_kernel<9, 1> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2> : wfa_filter_kernel<6, 2>;
   void (*fn4)(const FilterArgs) = wfa_filter_kernel<4, 2>;
   if (targeted) { fn = diag <= 4 * 256 ? wfa_filter_kernel<4, 2, 1, 1> : diag <= 5 * 256 ? wfa_filter_kernel<5, 2, 1, 1> : wfa_filter_kernel<6, 2, 1, 1>; fn4 = wfa_filter_kernel<4, 2, 1, 1>; }
-  if (const char* force = targeted ? nullptr : getenv("TRGT_FILTER_FORCE")) {  // developer probe (tools/filter_inst_probe.py): one instantiation for the whole launch
-    const int f = atoi(force);
+  if (const int f = targeted ? 0 : c->knobs.filter_force) {  // developer probe (tools/filter_inst_probe.py; TRGT_FILTER_FORCE in `make DEV=1` builds): one instantiation for the whole launch
     fn = f == 71 ? wfa_filter_kernel<7, 1> : f == 91 ? wfa_filter_kernel<9, 1> : f == 42 ? wfa_filter_kernel<4, 2> : f == 52 ? wfa_filter_kernel<5, 2> : fn;
   }
   // One-wave workgroups: resident waves per CU from the kernel's own register and LDS footprint (the occupancy query answers
@@ -596,7 +595,7 @@ int flank_filter_launch(trgt_hip_ctx* c, const FilterLaunch& L) {
   // instantiation runs a fifth fewer instructions per level than in the five-strip one.  (Skipping the dead strips inside one kernel
   // was slower: DESIGN.md 5.)  The long ones first; each launch claims the whole list with a counter of its own and passes over the
   // other's jobs.
-  const bool split = diag > 4 * 256 && L.n_jobs_host >= 1024 && !c->knobs.filter_one_launch && !getenv("TRGT_FILTER_FORCE");
+  const bool split = diag > 4 * 256 && L.n_jobs_host >= 1024 && !c->knobs.filter_one_launch && !c->knobs.filter_force;
   if (split) {
     // (a ladder of four instantiations -- 1536 / 1280 / 1152 / 1024 diagonals -- was no better than these two on the catalog mix:
     //  every launch has a tail)
