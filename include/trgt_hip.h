@@ -420,6 +420,9 @@ int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const 
 int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_locus_batch_out* out);
 int trgt_writer_close(trgt_writer* w);   /* flushes, writes the BGZF end-of-file blocks, frees the handle */
 const char* trgt_writer_last_error(const trgt_writer* w);
+/* ABI 10: BGZF blocks of the spanning BAM so far: out[0] deflated on the device (deflate_device), [1] declined by it (zlib took them), [2] by
+ * zlib because no device was named or a flush held fewer than 16 full blocks.  A device deflate that FAILS fails trgt_writer_write. */
+void trgt_writer_device_stats(const trgt_writer* w, int64_t out[3]);
 
 /* ------------------------------------------------- per-read helpers of the ingestion / writer steps, exported on their own
  * (host code; the functions trgt_ingest_* and trgt_writer_* use internally -- a host that keeps its own BAM reader can call them, and the

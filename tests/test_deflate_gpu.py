@@ -64,6 +64,8 @@ def test_writer_with_device_deflate_writes_the_same_records(tmp_path):
     for tag, dev in (("host", -1), ("dev", 0)):
         w = writers.Writer(rd, tmp_path / (tag + ".vcf"), tmp_path / (tag + ".bam"), deflate_device=dev)
         w.write(b, out)
+        st = w.device_stats()   # (a caller who named a GPU can tell that it did the work)
+        assert (st["device"] > 50 and st["declined"] == 0 and st["host"] == 0) if dev >= 0 else (st["device"] == 0 and st["host"] > 50), st
         w.close()
         paths[tag] = str(tmp_path / (tag + ".bam"))
     assert open(tmp_path / "host.vcf").read() == open(tmp_path / "dev.vcf").read()

@@ -199,6 +199,36 @@ def test_register_fill_variants_agree(oracle, hmm):
             assert np.array_equal(a["path"][po:po + pl], base["path"][po:po + pl]), (env, j)
 
 
+def test_position_per_lane_fill_against_the_state_fill_on_long_alleles(oracle, hmm):
+    # the position-per-lane fill writes SOME valid predecessor slot for states without a score where the fill of
+    # hmm_viterbi_kernel writes 0xFF; every consumer must ignore those bytes.  Alleles long enough for the staged trace-back (>= 512
+    # columns) and for the chunk-map path (>= 1 536 columns: hmm_traceback_long_kernel), small and large motif sets, with errors (states
+    # off the path carry no score): both fills must give the same paths, spans, counts and purity bits -- and the oracle's.
+    from trgt_amd import _lib
+    rng = np.random.default_rng(4242)
+    sets = [[b"CAG"], [b"AAGGG", b"AAAAG"], [b"GGCCTG", b"CCG", b"A"], [b"ACGTACGTACGTACGTAC"],
+            [b"AAAAG", b"AAAGG", b"AAGGG", b"AAGAG", b"AGAGG", b"AACGG", b"GGGAC", b"AAAGGG", b"AAAAGG", b"AAGAC"]]
+    jobs = []
+    for s, m in enumerate(sets):
+        for n_bases in (520, 700, 1540, 2100, 3300):
+            jobs.append((s, repeat_allele(rng, m, n_bases, err=0.03)))
+    base = _same(oracle, hmm, sets, jobs)
+    assert max(len(a) for _, a in jobs) >= 1536 and min(len(a) for _, a in jobs) >= 400
+    batch = hmm.pack_hmm_batch(sets, jobs)
+    for env in (dict(TRGT_HMM_NO_PPL=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_NO_LONG_TB=1), dict(TRGT_HMM_NO_LONG_TB=1)):
+        ctx = _lib.context_with_env(**env)
+        try:
+            a = hmm.hmm_batch(batch, ctx=ctx)
+        finally:
+            ctx.close()
+        for k in ("n_spans", "path_len", "edit", "maxd", "counts", "spans"):
+            assert np.array_equal(a[k], base[k]), (env, k)
+        assert np.array_equal(a["purity"].view(np.uint64), base["purity"].view(np.uint64)), env
+        for j in range(len(jobs)):
+            po, pl = int(batch["path_off"][j]), int(a["path_len"][j])
+            assert np.array_equal(a["path"][po:po + pl], base["path"][po:po + pl]), (env, j)
+
+
 def test_visit_list_overflow_and_length_buckets(oracle, hmm):
     # one-base motifs make one motif visit per base: more than the kernel keeps in LDS (the rest go through its global
     # workspace); alleles of 0..2500 bases of several models land in every length bucket / launch class of one batch

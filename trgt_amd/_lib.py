@@ -76,7 +76,7 @@ EXPORTS = [
     "trgt_wfa_default_params", "trgt_wfa_batch", "trgt_flank_filter_batch", "trgt_find_spans_batch", "trgt_hmm_batch", "trgt_hmm_path_capacity", "trgt_hmm_models_check",
     "trgt_locus_batch", "trgt_locus_batch_submit", "trgt_locus_batch_wait", "trgt_locus_default_params", "trgt_reads_pack_bam4",
     "trgt_hip_pool_create", "trgt_hip_pool_destroy", "trgt_hip_pool_size", "trgt_hip_pool_context", "trgt_hip_pool_last_error", "trgt_locus_batch_many",
-    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free", "trgt_ingest_device_stats",
+    "trgt_ingest_open", "trgt_ingest_close", "trgt_ingest_last_error", "trgt_ingest_default_params", "trgt_ingest_batch_from_catalog", "trgt_ingest_free", "trgt_ingest_device_stats", "trgt_writer_device_stats",
     "trgt_ingest_header_text", "trgt_ingest_n_contigs", "trgt_ingest_contig_name", "trgt_ingest_contig_length",
     "trgt_writer_default_params", "trgt_writer_open", "trgt_writer_write", "trgt_writer_close", "trgt_writer_last_error",
     "trgt_cigar_ref_len", "trgt_cigar_query_len", "trgt_cigar_total_query_len", "trgt_read_mismatch_offsets", "trgt_read_meth", "trgt_read_clip_to_region",

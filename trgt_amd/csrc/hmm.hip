@@ -2143,7 +2143,10 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
     jd.path_off = path ? path_off[j] : 0;
     jd.path_cap = (uint32_t)std::min<uint64_t>(trgt_hmm_path_capacity(seq_len[j], sd.max_mlen), 0xFFFFFFFFull);
     const uint64_t spad = (sd.S + 15) & ~15u;
-    jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)seq_len[j] + 2), 16);  // (16 bytes in front of the rows: where the position-per-lane fill sends the stores of roles a lane does not have)
+    // Invariant (hmm_ppl.hpp): every job's rows start 16 bytes into its piece -- bytes [bp_off - 16, bp_off) take the stores of roles a lane of the
+    // position-per-lane fill does not have, and a wave's lanes without a job store to bytes 0..15 of the workspace through the fake
+    // bp_off = 16; no row of any job may ever start below 16 (tests/test_hmm_gpu.py compares both fills on long alleles)
+    jd.bp_off = bp_total + 16; bp_total += 16 + align_up(spad * ((uint64_t)seq_len[j] + 2), 16);
     jd.visit_off = visit_total; visit_total += 3ull * ((uint64_t)seq_len[j] + 2);
     { const uint64_t mw = c->knobs.hmm_no_long_tb ? 0 : hmm_map_words(sd.S, seq_len[j], hmm_long_min(class_jobs[std::min<uint32_t>(set_class_of(sd), 31u)])); jd.map_off = mw ? visit_total + 4 : 0; visit_total += mw ? mw + 4 : 0; }
     seq_total = std::max<uint64_t>(seq_total, seq_off[j] + seq_len[j]);

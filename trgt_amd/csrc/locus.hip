@@ -875,7 +875,7 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       LR.jobs_dev = rp.jobs; LR.n_jobs_host = (int64_t)std::min<uint64_t>(rp.cap_jobs, (uint64_t)std::max(64, c->knobs.repair_blocks)); LR.n_jobs_dev = rp.counts + gt::RC_JOBS; LR.jobs_bound = rp.cap_jobs;
       LR.pat_base = d_reads; LR.txt_base = d_reads;
       LR.max_plen = rp.max_seg; LR.max_tlen = rp.max_seg; LR.max_sum = 2 * (int64_t)rp.max_seg;
-      LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2; LR.ws_budget = 512ull << 20;
+      LR.cigar = (uint32_t*)d_rcig; LR.cigar_len = (uint32_t*)d_rclen; LR.buffer_set = 2; LR.ws_budget = 512ull << 20; LR.refused = rp.counts + gt::RC_REFUSED;
       auto dbg_sync = [&](const char* what) -> int {  // TRGT_WFA_DEBUG: which kernel of the chain a device fault belongs to
         if (!c->knobs.debug) return TRGT_OK;
         const hipError_t e = trgt::stream_wait(c, c->stream);
@@ -974,14 +974,14 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
         //  the generic kernel's rings were too short for (0, > 10 kb) pairs)
         LE.pat_base = d_reads; LE.txt_base = txt_base; LE.max_plen = (int64_t)max_seg; LE.max_tlen = (int64_t)max_seg;
         LE.max_sum = std::max<int64_t>((int64_t)max_seg, std::min<int64_t>(2 * ed_len, (int64_t)cl::CL_MAX_OPS + 1));
-        LE.score = score; LE.buffer_set = 2; LE.ws_budget = 512ull << 20;
+        LE.score = score; LE.buffer_set = 2; LE.ws_budget = 512ull << 20; LE.refused = ca.counts + cl::CC_REFUSED;
         return wfa_launch(c, wed, LE);
       };
       auto cons_launch = [&](uint32_t first_job, const uint32_t* count, uint32_t first_group, const uint32_t* group_count) -> int {
         WfaLaunch LC;
         LC.jobs_dev = ca.jobs + first_job; LC.n_jobs_host = std::min<int64_t>((int64_t)ca.cap_j, wg_bound); LC.n_jobs_dev = count; LC.jobs_bound = (int64_t)ca.cap_j;
         LC.pat_base = d_reads; LC.txt_base = d_reads; LC.max_plen = max_seg; LC.max_tlen = max_seg; LC.max_sum = 2 * (int64_t)max_seg;
-        LC.cigar = (uint32_t*)d_cig; LC.cigar_len = (uint32_t*)d_clen; LC.buffer_set = 2; LC.ws_budget = 512ull << 20;
+        LC.cigar = (uint32_t*)d_cig; LC.cigar_len = (uint32_t*)d_clen; LC.buffer_set = 2; LC.ws_budget = 512ull << 20; LC.refused = ca.counts + cl::CC_REFUSED;
         if (int r = wfa_launch(c, wco, LC)) return r;
         vote::VoteArgs va{(const vote::Group*)(ca.groups + first_group), 0u, group_count, d_reads, ca.jobs, (const uint32_t*)d_cig, (const uint32_t*)d_clen,
                           (uint32_t*)d_vscr, (uint8_t*)d_vout, (uint32_t*)d_vlen + first_group};
@@ -1062,6 +1062,10 @@ static int locus_batch_run(trgt_hip_ctx* c, const trgt_locus_params* p, const tr
       });
     }
     for (int64_t l = 0; l < nl; ++l) if (need[l]) R.push_back(l);
+    // an alignment job of a device-built list that the generic kernel refused (longer than the workspace planned from the batch's maxima)
+    // left INT32_MIN / an empty CIGAR behind: nothing downstream may use that -- the call fails (never seen in the sweeps)
+    if (const uint32_t refused = ((const uint32_t*)hsl(o_rpc))[gt::RC_REFUSED] + ((const uint32_t*)hsl(o_clc))[cl::CC_REFUSED])
+      return fail(c, TRGT_ERR_UNSUPPORTED, "trgt_locus_batch: %u alignment job(s) of the device-side genotyper chains exceed the planned workspace", refused);
     stat_cons_jobs += (int64_t)((const uint32_t*)hsl(o_rpc))[gt::RC_JOBS];  // consensus alignments of the device-side repair
     { const uint32_t* cc = (const uint32_t*)hsl(o_clc);  // ... and of the device-side cluster genotyper, with its edit distances
       stat_cons_jobs += (int64_t)cc[cl::CC_J1] + (int64_t)cc[cl::CC_J2]; stat_ed_jobs += (int64_t)cc[cl::CC_ED] + (int64_t)cc[cl::CC_ED2]; }

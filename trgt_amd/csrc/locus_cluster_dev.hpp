@@ -28,7 +28,7 @@ namespace cl {
 constexpr uint64_t CL_MAX_OPS = 10000;  // genotype_cluster.rs:236
 
 enum { CC_ED = 0, CC_J1 = 1, CC_G1 = 2, CC_J2 = 3, CC_CIGAR = 4 /* u64 */, CC_OUT = 6 /* u64 */, CC_SCRATCH = 8 /* u64 */, CC_G2 = 10, CC_ED2 = 11, CC_FAILED = 12,
-       CC_DONE = 13, CC_WORDS = 16 };
+       CC_DONE = 13, CC_REFUSED = 14 /* alignment jobs of the chain the generic kernel refused */, CC_WORDS = 16 };
 
 struct ClRec {  // one cluster locus between the kernels of the chain
   int32_t n;          // spanning reads kept

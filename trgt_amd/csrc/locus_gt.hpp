@@ -33,7 +33,7 @@ struct RGroup {  // = vote::Group (consensus_vote.hpp; the layouts are asserted 
 struct RepairPend {  // what the genotyper had decided for a locus that waits for its repaired alleles
   int32_t n_gt, n_pick; uint32_t size[2]; int32_t civ[4]; int32_t rep[2] /* rank of the pick */; int32_t grp[2] /* vote group, -1: the pick stands */;
 };
-enum { RC_GROUPS = 0, RC_JOBS = 1, RC_LOCI = 2, RC_FAILED = 3, RC_CIGAR = 4 /* u64 */, RC_OUT = 6 /* u64 */, RC_SCRATCH = 8 /* u64 */, RC_WORDS = 16 };
+enum { RC_GROUPS = 0, RC_JOBS = 1, RC_LOCI = 2, RC_FAILED = 3, RC_CIGAR = 4 /* u64 */, RC_OUT = 6 /* u64 */, RC_SCRATCH = 8 /* u64 */, RC_REFUSED = 10 /* alignment jobs of the chain the generic kernel refused (beyond its planned workspace) */, RC_WORDS = 16 };
 struct RepairBufs {
   uint32_t* counts;  // [RC_WORDS]; nullptr: no device-side repair (every such locus takes the host path)
   RGroup* groups; JobDev* jobs; uint32_t* loci; RepairPend* pend;

@@ -355,6 +355,7 @@ __device__ __forceinline__ void wfa_kernel_body(const KArgs& a) {
     if ((uint32_t)plen + (uint32_t)tlen + 4u > a.ring_stride) {
       if (tid == 0) {
         const uint32_t o = job.out_index;
+        if (a.refused) atomicAdd(a.refused, 1u);
         if (a.status) a.status[o] = TRGT_WF_OOM;
         if (a.score) a.score[o] = INT32_MIN;
         if (a.n_match) a.n_match[o] = 0;
@@ -629,7 +630,7 @@ int wfa_launch(trgt_hip_ctx* c, const trgt_wfa_params& p, const WfaLaunch& L) {
   } else if (c->wfa_cells_cur[bset]) d_cells = c->wfa_cells_cur[bset];  // a later launch of the same logical batch: keeps counting where the first one did
   else if ((rc = dev_get(c, bset == 2 ? S_WFA_CELLS_C : bset ? S_WFA_CELLS_B : S_WFA_CELLS, 32, &d_cells))) return rc;
   a.slot_flags = (unsigned int*)d_counter + 4; a.n_slots_ws = (uint32_t)blocks; a.jobs_per_block = 0xFFFFFFFFu;  // persistent workgroups: measured 15-45 % faster than short-lived ones
-  a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells;
+  a.ws = (uint8_t*)d_ws; a.counter = (unsigned int*)d_counter; a.cells_out = (unsigned long long*)d_cells; a.refused = L.refused;
   a.jobs = L.jobs_dev; a.n_jobs = (uint32_t)L.n_jobs_host; a.n_jobs_dev = L.n_jobs_dev;
   a.n_jobs2_dev = L.n_jobs2_dev; a.jobs_cap = L.jobs_cap;
   a.pat_base = L.pat_base; a.txt_base = L.txt_base;

@@ -51,6 +51,7 @@ struct KArgs {
   uint32_t uni_slots, arena_uni_cap, ring_stride, rle_cap, lds_seq_cap, fast_wcap, fast_ring_bytes, fast_dbg, fast_koff /* bias of the diagonal index in the ring; 0 = pattern length + 2 */;
   int32_t* status; int32_t* score; int32_t* n_match; uint32_t* span4; uint32_t* cigar; uint32_t* cigar_len; uint8_t* ops; uint32_t* ops_len;
   unsigned long long* cells_out;
+  unsigned int* refused;  // WfaLaunch::refused (may be null)
   // LDS-arena variant: byte offsets inside the dynamic LDS and capacities; jobs it cannot hold go to the retry list (the HBM variant)
   uint32_t la_rle_tmp, la_rle_out, la_rle_cap, la_region, la_region_bytes, la_gdesc_slots, la_seq_max;
   JobDev* retry_jobs; unsigned int* retry_count;

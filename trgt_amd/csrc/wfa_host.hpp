@@ -39,6 +39,8 @@ struct WfaLaunch {  // everything device-resident
   int buffer_set = 0;  // 0 / 1 / 2: which workspace / counter buffers of the ctx to use (launches may be in flight on two streams; 2 = the device-side consensus repair, whose buffers must not be re-sized while the flank location is still running on sets 0 / 1)
   int32_t* status = nullptr; int32_t* score = nullptr; int32_t* n_match = nullptr; uint32_t* span4 = nullptr;
   uint32_t* cigar = nullptr; uint32_t* cigar_len = nullptr; uint8_t* ops = nullptr; uint32_t* ops_len = nullptr;
+  unsigned int* refused = nullptr;  // device word that counts the jobs the kernel refuses (longer than the planned workspace): device-built lists carry one
+                                    // that comes back with the call's count block, so that such a job fails the call instead of leaving an INT32_MIN behind
 };
 
 // Enqueue the WFA kernel on the ctx stream (asynchronous).  The number of wavefront offsets computed is

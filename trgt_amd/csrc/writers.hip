@@ -64,6 +64,8 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
   }
   trgt_hip_ctx* dev = nullptr;   // trgt_writer_params.deflate_device: the full blocks of a flush are deflated on this context's GPU
+  std::string dev_err;           // a device deflate that FAILED fails the write (no silent host-only run, like ingest_device); this says why
+  int64_t n_dev = 0, n_declined = 0, n_host = 0;  // blocks the device deflated / declined (zlib took them) / zlib deflated because the flush was too small or no device was named
   std::vector<uint8_t> dev_out; std::vector<uint64_t> dev_soff, dev_doff; std::vector<uint32_t> dev_slen, dev_cap, dev_len;
   // the full blocks of buf: deflated by `threads` workers (a block is independent of its neighbours) -- or on the GPU in one go, the
   // workers then only frame them (CRC-32) and deflate what the device declined -- written in order
@@ -77,8 +79,11 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     if (dev && nb >= 16) {  // (a handful of blocks is not worth the round trip)
       dev_out.resize(nb * DEV_SLOT + 64); dev_soff.resize(nb); dev_doff.resize(nb); dev_slen.assign(nb, 0xFF00u); dev_cap.assign(nb, (uint32_t)DEV_CAP); dev_len.assign(nb, 0u);
       for (size_t k = 0; k < nb; ++k) { dev_soff[k] = k * 0xFF00; dev_doff[k] = k * DEV_SLOT; }
-      on_dev = trgt_deflate_blocks(dev, (int64_t)nb, buf.data(), dev_soff.data(), dev_slen.data(), dev_out.data(), dev_doff.data(), dev_cap.data(), dev_len.data()) == TRGT_OK;
-    }
+      const int rc = trgt_deflate_blocks(dev, (int64_t)nb, buf.data(), dev_soff.data(), dev_slen.data(), dev_out.data(), dev_doff.data(), dev_cap.data(), dev_len.data());
+      if (rc != TRGT_OK) { dev_err = std::string("deflate_device: ") + trgt_hip_last_error(dev); return false; }
+      on_dev = true;
+      for (size_t k = 0; k < nb; ++k) { if (dev_len[k] > 0 && dev_len[k] + 26u <= 0x10000u) ++n_dev; else ++n_declined; }
+    } else n_host += (int64_t)nb;
     auto work = [&]() {
       try {
         for (;;) {
@@ -176,6 +181,9 @@ struct trgt_writer {
 extern "C" {
 
 const char* trgt_writer_last_error(const trgt_writer* w) { return w ? w->err.c_str() : "null handle"; }
+// ABI 10: BGZF blocks of the spanning BAM so far -- out[0] deflated on the device, [1] declined by it (zlib took them), [2] deflated by zlib
+// because no device was named or the flush held fewer than 16 full blocks
+void trgt_writer_device_stats(const trgt_writer* w, int64_t out[3]) { if (w && out) { out[0] = w->bam.n_dev; out[1] = w->bam.n_declined; out[2] = w->bam.n_host; } }
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
@@ -422,7 +430,7 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
     if (!errs[(size_t)t].empty()) { w->vcf.flush(); w->bam.flush(); return bad(errs[(size_t)t]); }
   }
   if (!w->vcf.flush()) return bad("cannot write the VCF");
-  if (!w->bam.flush()) return bad("cannot write the BAM");
+  if (!w->bam.flush()) return bad(w->bam.dev_err.empty() ? "cannot write the BAM" : w->bam.dev_err);
   return TRGT_OK;
 }
 

@@ -129,7 +129,9 @@ class BatchOutputs:
             starts = np.asarray(lrb[:-1], np.int64)
             nonempty = np.asarray(lrb[1:], np.int64) > starts
             if nonempty.any():
-                seg_max = np.maximum.reduceat(np.asarray(rl, np.uint32), starts[nonempty])  # (segments of consecutive non-empty loci: the empty ones in between own no reads)
+                # (segments of consecutive non-empty loci: the empty ones in between own no reads; read_len is cut at the batch's read count,
+                #  reduceat takes its last segment to the END of the array, and a padded / reused array is longer than that)
+                seg_max = np.maximum.reduceat(np.asarray(rl[:int(lrb[nl])], np.uint32), starts[nonempty])
                 cap[nonempty] = seg_max + 8
         self.allele_cap = cap
         cap2 = np.repeat(cap.astype(np.uint64), 2)

@@ -42,6 +42,15 @@ class Writer:
         if rc != 0:
             raise _lib.TrgtHipError("trgt_writer_write: %s" % self._L.trgt_writer_last_error(self.handle).decode())
 
+    def device_stats(self):
+        """trgt_writer_device_stats: BGZF blocks of the spanning BAM deflated on the device / declined by it / deflated by zlib for lack of a
+        device or of blocks (a flush of fewer than 16)."""
+        v = (C.c_int64 * 3)()
+        self._L.trgt_writer_device_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self._L.trgt_writer_device_stats.restype = None
+        self._L.trgt_writer_device_stats(self.handle, v)
+        return dict(device=int(v[0]), declined=int(v[1]), host=int(v[2]))
+
     def close(self):
         if self.handle:
             rc = self._L.trgt_writer_close(self.handle)
