@@ -400,6 +400,12 @@ def run_e2e(args, env):
         t0 = time.perf_counter()
         batches = [ing_host(a) for a in firsts]
         t_ing_host = time.perf_counter() - t0
+        # (the rates below are over PIPE_PASSES walks of the catalog: twelve chunks, not four -- with callers in flight the first chunk's
+        #  latency is a quarter of a four-chunk run)
+        t0 = time.perf_counter()
+        for a in firsts * (PIPE_PASSES - 1):
+            ing_host(a)
+        t_ing_host = (t_ing_host + time.perf_counter() - t0) / PIPE_PASSES
         # ... the device path: one caller, then INGEST_CALLERS callers
         ing_dev(0)
         t0 = time.perf_counter()
@@ -410,8 +416,10 @@ def run_e2e(args, env):
                            for x, y in zip(batches, batches_d))
         del batches_d
         t0 = time.perf_counter()
+        for b in ordered(ing_dev, INGEST_CALLERS, firsts * PIPE_PASSES):
+            del b
+        t_ing_dev = (time.perf_counter() - t0) / PIPE_PASSES
         batches_d = list(ordered(ing_dev, INGEST_CALLERS))
-        t_ing_dev = time.perf_counter() - t0
         st = rd.device_stats()
         if st["fallbacks"]:
             raise SystemExit("bench.py: the device ingestion fell back to the host path (%r)" % (st,))
@@ -474,9 +482,12 @@ def run_e2e(args, env):
         del outs, views, batches, batches_d
 
         # ---- pipeline: ingest | GPU | write
+        stage_ms = {}
+
         def pipeline(tag, device_ingest, level, dev_deflate=-1):
             w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate)
             q1, q2, err = queue.Queue(3), queue.Queue(2), []
+            busy = dict(gpu=0.0, gpu_wait=0.0, write=0.0, write_wait=0.0)  # seconds a stage worked / waited for its input (the ingest stage is the callers')
 
             def stage_ingest():
                 try:
@@ -489,10 +500,15 @@ def run_e2e(args, env):
             def stage_gpu():
                 try:
                     while True:
+                        ta = time.perf_counter()
                         b = q1.get()
+                        tb = time.perf_counter()
                         if b is None:
                             break
-                        q2.put((b, gpu_dev(b) if device_ingest else gpu(ingest.bam4_view(b))))
+                        o = gpu_dev(b) if device_ingest else gpu(ingest.bam4_view(b))
+                        busy["gpu"] += time.perf_counter() - tb
+                        busy["gpu_wait"] += tb - ta
+                        q2.put((b, o))
                 except BaseException as e:  # noqa: BLE001
                     err.append(e)
                 q2.put(None)
@@ -501,10 +517,14 @@ def run_e2e(args, env):
             for t in th:
                 t.start()
             while True:
+                ta = time.perf_counter()
                 item = q2.get()
+                tb = time.perf_counter()
                 if item is None:
                     break
                 w.write(*item)
+                busy["write"] += time.perf_counter() - tb
+                busy["write_wait"] += tb - ta
             w.close()
             for t in th:
                 t.join()
@@ -512,6 +532,7 @@ def run_e2e(args, env):
             if err:
                 raise err[0]
             body = lambda path: [line for line in open(path) if not line.startswith("#")]
+            stage_ms[tag] = {k: round(1e3 * v / (len(firsts) * PIPE_PASSES), 2) for k, v in busy.items()}  # per chunk
             return dt / PIPE_PASSES, body(os.path.join(d, "out.vcf")) * PIPE_PASSES == body(os.path.join(d, tag + ".vcf"))
 
         t_pipe_host, same = pipeline("out2", False, 6)            # as rounds 1-5 measured it: host ingestion, htslib's BAM level, zlib
@@ -531,6 +552,7 @@ def run_e2e(args, env):
             pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3), pipeline_loci_per_s_device_ingest_host_deflate=r(n / t_pipe_dev6),
             pipeline_loci_per_s_host_ingest=r(n / t_pipe_host), pipeline_loci_per_s_host_ingest_device_deflate=r(n / t_pipe_hostd),
             spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
+            pipeline_stage_ms_per_chunk=dict(host_ingest=stage_ms["out2"], host_ingest_device_deflate=stage_ms["out3"], device_ingest_host_deflate=stage_ms["out4"], device_ingest_device_deflate=stage_ms["out5"]),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
             bound="the device inflate (one wave per BGZF block, bound by scalar instruction issue) and the writer's record formatting; see DESIGN.md")
     finally:

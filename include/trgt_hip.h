@@ -334,6 +334,10 @@ typedef struct trgt_ingest_params {
                               strings beyond the kernel's caps -- is redone as a whole by the host path, which yields the data or the error
                               (trgt_ingest_device_stats counts them).  A device that cannot be used fails the call: no silent host-only run.
                               Calls from several host threads on one reader overlap (three slots of device state) */
+  int32_t inflate_waves_per_cu; /* ABI 10, with ingest_device: BGZF blocks in flight per CU of the inflate kernel (one wave each, 10 KB of LDS; its waves
+                              live as long as the launch).  0 = 12: the kernel is bound by scalar instruction issue, so 12 run as fast as the 15
+                              that fit, and the LDS and registers left over let the kernels of trgt_locus_batch on the same GPU start next to
+                              it instead of behind it; 15 = the whole CU for a GPU that only ingests */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;

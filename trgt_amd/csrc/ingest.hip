@@ -709,7 +709,7 @@ static int device_reads(trgt_ingest* h, const trgt_ingest_params* p, const std::
   ingd::RunIn in;
   in.src_bytes = src_total; in.n_blocks = (int64_t)blocks.size(); in.blocks = blocks.data(); in.crc = crcs.data(); in.infl_bytes = lin;
   in.n_loci = (int64_t)nl; in.loci = ld.data(); in.n_chunks = (int64_t)cd.size(); in.chunks = cd.data();
-  in.reservoir = (uint32_t)(3ll * p->max_depth); in.min_rq = p->min_read_qual; in.keep_bam4 = p->keep_bam4 != 0;
+  in.reservoir = (uint32_t)(3ll * p->max_depth); in.min_rq = p->min_read_qual; in.keep_bam4 = p->keep_bam4 != 0; in.waves_per_cu = p->inflate_waves_per_cu;
   const int rc = ingd::slot_run(slot, in, *h->slab_pool, res, err);
   if (rc) return rc;
   h->dev_blocks += (int64_t)blocks.size(); h->dev_blocks_host += (int64_t)res.blocks_host_inflated;
@@ -800,7 +800,7 @@ void trgt_ingest_device_stats(const trgt_ingest* h, int64_t out[5]) {
 
 void trgt_ingest_default_params(trgt_ingest_params* p) {
   if (!p) return;
-  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0; p->ingest_device = -1;
+  p->flank_len = 250; p->max_depth = 250; p->min_read_qual = 0.98; p->threads = 0; p->genotyper = 0; p->default_ploidy = 2; p->keep_bam4 = 0; p->ingest_device = -1; p->inflate_waves_per_cu = 0;
 }
 
 void trgt_ingest_free(trgt_ingest_batch* b) {

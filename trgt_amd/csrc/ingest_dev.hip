@@ -678,7 +678,10 @@ Slot* slot_create(int device, std::string& err) {
   (void)hipSetDevice(device);
   std::unique_ptr<Slot> s(new Slot());
   s->device = device;
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); err = "trgt_ingest: hipStreamCreate failed"; return nullptr; }
+  // (the least urgent priority: the launches of trgt_locus_batch on the same GPU go first wherever a CU has room for both)
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); err = "trgt_ingest: hipStreamCreate failed"; return nullptr; }
   return s.release();
 }
 void slot_destroy(Slot* s) { delete s; }
@@ -733,7 +736,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   ING_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(Counters), st));
   ING_TRY(hipMemsetAsync(s->d_status.p, 0, (size_t)nb + 64, st));
   // ---- inflate + CRC-32
-  static const unsigned waves_per_cu = [] { const char* e = TRGT_DEV_ENV("TRGT_INFLATE_WAVES_PER_CU"); const int v = e && *e ? std::atoi(e) : 0; return (unsigned)(v > 0 ? v : 15); }();
+  const unsigned waves_per_cu = in.waves_per_cu > 0 ? (unsigned)std::min(in.waves_per_cu, 15) : 12u;
   int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   trgt::inflate_launch((void*)st, (const uint8_t*)s->d_src.p, (const infl::BlockDesc*)s->d_blocks.p, nb, (uint8_t*)s->d_infl.p, (uint8_t*)s->d_status.p, (unsigned*)s->d_counter.p,
                        (unsigned)cus * waves_per_cu);

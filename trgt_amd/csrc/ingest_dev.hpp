@@ -55,7 +55,7 @@ struct RunIn {
   uint64_t infl_bytes = 0;
   int64_t n_loci = 0; const LocusDesc* loci = nullptr;
   int64_t n_chunks = 0; const ChunkDesc* chunks = nullptr;
-  uint32_t reservoir = 750; double min_rq = 0.98; bool keep_bam4 = false;
+  uint32_t reservoir = 750; double min_rq = 0.98; bool keep_bam4 = false; int waves_per_cu = 0;
 };
 // Why a call went back to the host path (RunOut::fallback)
 enum : int { FB_NONE = 0, FB_BLOCK = 1 /* a block the device could not inflate or whose CRC-32 / ISIZE does not match */, FB_WALK = 2 /* a record the walk refuses */,

@@ -10,7 +10,7 @@ from . import _lib
 
 class IngestParams(C.Structure):
     _fields_ = [("flank_len", C.c_int32), ("max_depth", C.c_int32), ("min_read_qual", C.c_double), ("threads", C.c_int32),
-                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32), ("ingest_device", C.c_int32)]
+                ("genotyper", C.c_int32), ("default_ploidy", C.c_int32), ("keep_bam4", C.c_int32), ("ingest_device", C.c_int32), ("inflate_waves_per_cu", C.c_int32)]
 
 
 _P8, _P16, _P32, _P64, _PD, _PC = (C.POINTER(t) for t in (C.c_uint8, C.c_int16, C.c_uint32, C.c_uint64, C.c_double, C.c_char))
