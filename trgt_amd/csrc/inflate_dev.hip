@@ -106,7 +106,7 @@ __device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, 
   return true;
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                             uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;

@@ -34,6 +34,7 @@
 #include "../../include/trgt_hip.h"
 #include "inflate_dev.hpp"
 #include "inflate_fast.hpp"
+#include "crc32_fast.hpp"
 #include "ingest_dev.hpp"
 #include <condition_variable>
 
@@ -119,7 +120,7 @@ struct Bgzf {
     }
     // the footer's CRC-32 of the inflated bytes (htslib's bgzf_read_block refuses a block whose CRC does not match: a damaged block whose
     // length happens to fit must not be read as records)
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), B.data.data(), isize) != (raw[total - 8] | (raw[total - 7] << 8) | (raw[total - 6] << 16) | ((uint32_t)raw[total - 5] << 24))) { err = "corrupt BGZF block (CRC-32 mismatch)"; return false; }
+    if (trgt::crc32_fast(B.data.data(), isize) != (raw[total - 8] | (raw[total - 7] << 8) | (raw[total - 6] << 16) | ((uint32_t)raw[total - 5] << 24))) { err = "corrupt BGZF block (CRC-32 mismatch)"; return false; }
     ++n_inflated;
     B.coff = coff; B.csize = total; B.stamp = ++clock; cur = lru;
     block_coff = coff; block_csize = total; pos = 0; cur_data = B.data.data(); cur_size = B.data.size();

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "crc32_fast.hpp"
 #include "ingest_dev.hpp"
 
 namespace trgt {
@@ -757,7 +758,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
     if (inflateInit2(&zs, -15) != Z_OK) { out.fallback = FB_BLOCK; return TRGT_OK; }
     zs.next_in = (Bytef*)s->src_pin.p + bd.src_off; zs.avail_in = bd.src_len; zs.next_out = tmp.data(); zs.avail_out = bd.dst_len;
     const int rc = inflate(&zs, Z_FINISH);
-    const bool good = rc == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), tmp.data(), bd.dst_len) == in.crc[b];
+    const bool good = rc == Z_STREAM_END && zs.avail_out == 0 && trgt::crc32_fast(tmp.data(), bd.dst_len) == in.crc[b];
     inflateEnd(&zs);
     if (!good) { out.fallback = FB_BLOCK; return TRGT_OK; }
     ING_TRY(hipMemcpyAsync((uint8_t*)s->d_infl.p + bd.dst_off, tmp.data(), bd.dst_len, hipMemcpyHostToDevice, st));

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "crc32_fast.hpp"
 #include "../../include/trgt_hip.h"
 
 extern "C" {
@@ -46,7 +47,7 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     static const uint8_t head[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
     std::memcpy(out.data(), head, 16);
     out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, nullptr, 0), d, (uInt)n);
+    const uint32_t crc = n ? trgt::crc32_fast(d, n) : 0u;
     for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
     out.resize(total);
     return true;
@@ -60,7 +61,7 @@ struct BgzfOut {  // a file, plain or as a series of BGZF blocks (cut every 0xFF
     std::memcpy(out.data(), head, 16);
     out[16] = (uint8_t)((total - 1) & 0xFF); out[17] = (uint8_t)((total - 1) >> 8);
     std::memcpy(out.data() + 18, payload, clen);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, nullptr, 0), d, (uInt)n);
+    const uint32_t crc = n ? trgt::crc32_fast(d, n) : 0u;
     for (int i = 0; i < 4; ++i) { out[18 + clen + i] = (uint8_t)(crc >> (8 * i)); out[22 + clen + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
   }
   trgt_hip_ctx* dev = nullptr;   // trgt_writer_params.deflate_device: the full blocks of a flush are deflated on this context's GPU
