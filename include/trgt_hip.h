@@ -111,7 +111,11 @@ typedef struct trgt_wfa_params {
   int32_t pattern_begin_free, pattern_end_free, text_begin_free, text_end_free; /* -1 = that sequence's length */
   int32_t scope;       /* AlignmentScope: 0 Score, 1 Alignment (:52-56) */
   int32_t memory_mode; /* MemoryModel: 0 High, 1 Med, 2 Low, 3 UltraLow = BiWFA (:4-10) */
-  int32_t heuristic;   /* 0 Heuristic::None, 1 Heuristic::WFadaptive (:68-77); others -> TRGT_ERR_UNSUPPORTED */
+  int32_t heuristic;   /* 0 Heuristic::None, 1 Heuristic::WFadaptive (:68-77).  CONTRACT for the rest of the enum -- 2 WFmash, 3 XDrop, 4 ZDrop,
+                          5 BandedStatic, 6 BandedAdaptive (set_heuristic, :707-780): trgt_wfa_batch returns TRGT_ERR_UNSUPPORTED for the whole
+                          batch and touches no output.  No call site of the genotype path uses them (genotype.rs:66-92 builds its three aligners
+                          with None / the default WFadaptive), WFA2-lib's sources are not in the reference tree and no reference test pins what
+                          they compute (wfaligner.rs:1428-1434 only sets them): an implementation here could not be checked against anything */
   int32_t h_min_wavefront_length, h_max_distance_threshold, h_steps_between_cutoffs;
   int32_t bialign_min_score;  /* WF_BIALIGN_FALLBACK_MIN_SCORE, 250 */
   int32_t bialign_min_length; /* WF_BIALIGN_FALLBACK_MIN_LENGTH, 100 (0 disables) */

@@ -48,7 +48,9 @@ def test_wfa_batch_rejects_bad_requests_and_recovers(env):
         return p
 
     pats, txts = [b"ACGTACGTAC", b"GGGG"], [b"ACGTTCGTAC", b"GGCGG"]
-    for kw, want, word in ((dict(metric=7), INVALID, "metric"), (dict(heuristic=2), UNSUPPORTED, "Heuristic"),
+    # (heuristics 2 .. 6 = WFmash, XDrop, ZDrop, BandedStatic, BandedAdaptive: the header's contract for the rest of the enum, wfaligner.rs:707-780)
+    for kw, want, word in ((dict(metric=7), INVALID, "metric"), (dict(heuristic=2), UNSUPPORTED, "Heuristic"), (dict(heuristic=3), UNSUPPORTED, "Heuristic"),
+                           (dict(heuristic=4), UNSUPPORTED, "Heuristic"), (dict(heuristic=5), UNSUPPORTED, "Heuristic"), (dict(heuristic=6), UNSUPPORTED, "Heuristic"),
                            (dict(memory_mode=3, span=1), UNSUPPORTED, "BiWFA"), (dict(gap_ext1=0), INVALID, "positive"),
                            (dict(mismatch=-2), INVALID, "positive")):
         rc, status, _ = _wfa_call(_lib, ctx, params(**kw), pats, txts)

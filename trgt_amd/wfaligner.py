@@ -209,7 +209,9 @@ class WFAligner:
             p.heuristic = 1
             p.h_min_wavefront_length, p.h_max_distance_threshold, p.h_steps_between_cutoffs = self.heuristic.args
         else:
-            p.heuristic = 99  # rejected by the library: only None / WFadaptive are implemented
+            # the rest of the enum by the header's numbers (include/trgt_hip.h): the library answers TRGT_ERR_UNSUPPORTED for the whole
+            # batch and touches no output -- the documented contract for the heuristics no call site of the genotype path uses
+            p.heuristic = {"WFmash": 2, "XDrop": 3, "ZDrop": 4, "BandedStatic": 5, "BandedAdaptive": 6}.get(self.heuristic.kind, 99)
         return p
 
     # ---- batch forms
