@@ -334,8 +334,8 @@ typedef struct trgt_ingest_params {
                               run as kernels on the inflated bytes in HBM (trgt_amd/csrc/ingest_dev.hip): only the clipped reads come back, and the
                               ASCII read blob stays in HBM as well (trgt_ingest_batch::read_blob_dev) for trgt_locus_batch.  Same arrays, bit for
                               bit, as the host path.  A call the kernels do not take -- a block that fails its CRC or does not inflate, a record that
-                              leaves its range, a locus with more reads than the reservoir of 3 * max_depth (StdRng's stream runs on the host), MM
-                              strings beyond the kernel's caps -- is redone as a whole by the host path, which yields the data or the error
+                              leaves its range, MM strings beyond the kernel's caps (a read longer than 65 535 bases, more than 4 096 calls in one MM
+                              entry) -- is redone as a whole by the host path, which yields the data or the error
                               (trgt_ingest_device_stats counts them).  A device that cannot be used fails the call: no silent host-only run.
                               Calls from several host threads on one reader overlap (three slots of device state) */
   int32_t inflate_waves_per_cu; /* ABI 10, with ingest_device: BGZF blocks in flight per CU of the inflate kernel (one wave each, 10 KB of LDS; its waves
@@ -385,7 +385,7 @@ int trgt_ingest_batch_from_catalog(trgt_ingest* h, const trgt_ingest_params* p, 
                                    int64_t max_loci, trgt_ingest_batch** out);
 void trgt_ingest_free(trgt_ingest_batch* b);   /* batches of a reader are freed before trgt_ingest_close when they hold device memory */
 /* ABI 10: what ingest_device did so far: out[0] calls that asked for the device, [1] of those, calls redone by the host path, [2] the reason of
- * the last one (1 a BGZF block, 2 the record walk, 3 the reservoir, 4 MM / ML caps), [3] BGZF blocks inflated for the device path, [4] of
+ * the last one (1 a BGZF block, 2 the record walk, 4 MM / ML caps), [3] BGZF blocks inflated for the device path, [4] of
  * those, blocks its kernel declined (zlib took them) */
 void trgt_ingest_device_stats(const trgt_ingest* h, int64_t out[5]);
 

@@ -107,17 +107,17 @@ def test_calls_from_several_threads_overlap_and_agree(tmp_path):
     assert rd.device_stats()["fallbacks"] == 0
 
 
-def test_a_locus_deeper_than_the_reservoir_goes_back_to_the_host(tmp_path):
+def test_a_locus_deeper_than_the_reservoir_is_down_sampled_like_the_host_path(tmp_path):
+    # more reads than 3 * max_depth: every further read replaces a random slot, by the same random stream as the host's StdRng(42)
     from trgt_amd import ingest
     from test_ingest import _synthetic
-    bam, fa, bed, recs, genome = _synthetic(tmp_path, deep=40)
+    bam, fa, bed, recs, genome = _synthetic(tmp_path, deep=200)
     rd = ingest.Reader(bam, fa)
-    host, dev, fell_back, st = _both(rd, bed, max_depth=10)  # reservoir 30 < 41 reads over the second locus
-    assert fell_back == 1 and st["last_reason"] == 3
-    _same_batches(host, dev)
-    host, dev, fell_back, _ = _both(rd, bed, max_depth=20)    # reservoir 60: everything fits
-    assert not fell_back
-    _same_batches(host, dev)
+    for depth in (10, 20, 50, 250):   # reservoirs of 30, 60, 150 (all smaller than the 201 reads over the second locus) and 750
+        host, dev, fell_back, st = _both(rd, bed, max_depth=depth)
+        assert not fell_back, st
+        _same_batches(host, dev)
+        assert int(host["n_reads_seen"][1]) == 201 and int(host["locus_read_begin"][2] - host["locus_read_begin"][1]) <= 3 * depth
 
 
 def test_a_block_with_a_wrong_crc_is_refused(tmp_path):

@@ -792,7 +792,7 @@ static int ingest_open_impl(const char* bam_path, const char* fasta_path, trgt_i
 void trgt_ingest_close(trgt_ingest* h) { delete h; }
 
 // ABI 10: what trgt_ingest_params.ingest_device did so far -- [0] calls that asked for the device, [1] of those, calls that went back to the
-// host path, [2] the reason of the last one (trgt::ingd::FB_*: 1 block, 2 record walk, 3 reservoir, 4 MM / ML caps), [3] BGZF blocks through
+// host path, [2] the reason of the last one (trgt::ingd::FB_*: 1 block, 2 record walk, 4 MM / ML caps), [3] BGZF blocks through
 // the device path, [4] of those, blocks the inflate kernel declined (inflated by zlib, uploaded)
 void trgt_ingest_device_stats(const trgt_ingest* h, int64_t out[5]) {
   if (!h || !out) return;

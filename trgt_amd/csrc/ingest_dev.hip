@@ -3,7 +3,8 @@
 //   crc32_blocks_kernel   CRC-32 of every inflated BGZF block against its footer (what htslib's bgzf_read_block checks for
 //                         bam::IndexedReader, src/trgt/workflows/tr.rs:268-305)
 //   walk_kernel           extract_reads (tr.rs:268-361): per locus the record chain of its .bai chunks, the stop at the first record
-//                         beyond the window, the secondary / supplementary and rq filters, the list of the kept records
+//                         beyond the window, the secondary / supplementary and rq filters, the list of the kept records -- with the
+//                         reservoir of 3 * max_depth reads and its random replacements (StdRng::seed_from_u64(42)) for deeper loci
 //   read_sizes_kernel     HiFiRead::from_hts_rec (reads/read.rs:98-141) + clip_to_region (reads/clip_region.rs:19-184) as sizes: the
 //                         CIGAR of a read as prefix sums over a wave (where the clip window cuts it, which operation is split), the
 //                         mismatch offsets of snp.rs:51-79 counted, the aux tags located
@@ -12,8 +13,8 @@
 //   read_fill_kernel      the clipped bases (4-bit codes -> ASCII, and the 4-bit form once more), qualities, names, clipped CIGAR,
 //                         mismatch offsets, methylation values and the per-read scalars
 // One wave per locus / per read; a wave's lanes share the serial work of a record by ballots and scans, not by diverging.  Anything a
-// kernel does not take (a block it cannot inflate, a record that runs out of its range, more reads than the reservoir, MM strings beyond
-// the LDS caps) sends the WHOLE call back to the host path of ingest.hip, which then produces the data or the error message.
+// kernel does not take (a block it cannot inflate, a record that runs out of its range, MM strings beyond the LDS caps) sends the WHOLE
+// call back to the host path of ingest.hip, which then produces the data or the error message.
 #include <zlib.h>
 
 #include <chrono>
@@ -146,6 +147,45 @@ __global__ void __launch_bounds__(64) crc32_blocks_kernel(const uint8_t* __restr
   if (lane == 0 && (r ^ 0xFFFFFFFFu) != want[b]) status[b] = 2;
 }
 
+// ------------------------------------------------------------------------------------------------ the reservoir's random stream
+// extract_reads (tr.rs:311-335) keeps 3 * max_depth reads; every further read replaces a random one of them with probability
+// reservoir / (n + 1), drawn from rand 0.9's StdRng::seed_from_u64(42): ChaCha12 keyed by a PCG32 stream over the seed, its 32-bit words
+// read in order, ranges by Canon's widening multiplication.  The restatement of ingest.hip's StdRng for one lane (the words of the
+// 64-word buffer there are four consecutive blocks: the same stream block by block); unpinned like the host's (no fixture reaches it).
+struct DevRng {
+  uint32_t key[8]; uint32_t buf[16]; uint32_t at; uint64_t counter;
+  __device__ void seed(uint64_t state) {
+    const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+    for (int i = 0; i < 8; ++i) {
+      state = state * MUL + INC;
+      const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+      key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    at = 16; counter = 0;
+  }
+  __device__ void block() {
+    const uint32_t s0[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                             (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+    for (int i = 0; i < 16; ++i) x[i] = s0[i];
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    auto qr = [&](int a, int b, int c, int d) {
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < 6; ++r) { qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15); qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14); }
+    for (int i = 0; i < 16; ++i) buf[i] = x[i] + s0[i];
+    ++counter; at = 0;
+  }
+  __device__ uint32_t next_u32() { if (at >= 16) block(); return buf[at++]; }
+  __device__ uint32_t range(uint32_t n) {  // 0 .. n (exclusive), n >= 1
+    const uint64_t m = (uint64_t)next_u32() * n;
+    uint32_t hi = (uint32_t)(m >> 32); const uint32_t lo = (uint32_t)m;
+    if (lo > (uint32_t)(0u - n)) { const uint32_t hi2 = (uint32_t)(((uint64_t)next_u32() * n) >> 32); if ((uint64_t)lo + hi2 > 0xFFFFFFFFull) ++hi; }
+    return hi;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ the record walk of a locus
 struct WalkOut { uint32_t n_kept, n_filt, status, pad; };
 enum : uint32_t { WS_OK = 0, WS_ERROR = 1, WS_OVERFLOW = 2 };
@@ -155,6 +195,8 @@ __global__ void __launch_bounds__(64) walk_kernel(const uint8_t* __restrict__ in
   __shared__ uint64_t tile[64];
   __shared__ uint32_t s_cnt, s_flags;
   __shared__ uint64_t s_next;
+  __shared__ DevRng rng;  // (lane 0's; seeded when the reservoir first overflows)
+  bool rng_ready = false;
   const uint32_t li = blockIdx.x;
   if (li >= n_loci) return;
   const int lane = lane_id();
@@ -208,8 +250,20 @@ __global__ void __launch_bounds__(64) walk_kernel(const uint8_t* __restrict__ in
       const uint64_t km = ballot64(keep), fm = ballot64(filt);
       n_filt += (uint32_t)__popcll(fm);
       if (keep) { const uint32_t idx = n_reads + (uint32_t)__popcll(km & lanes_below(lane)); if (idx < reservoir) rec_list[(uint64_t)li * reservoir + idx] = q; }
+      if (n_reads + (uint32_t)__popcll(km) > reservoir) {
+        // the reservoir is full: every further read, in file order, replaces slot j = range(reads so far) when j < reservoir (lane 0)
+        __syncthreads();
+        if (!rng_ready) { if (lane == 0) rng.seed(42); rng_ready = true; }
+        if (lane == 0) {
+          uint32_t seen = n_reads;
+          for (uint64_t rest = km; rest; rest &= rest - 1, ++seen) {
+            if (seen < reservoir) continue;
+            const uint32_t j = rng.range(seen);
+            if (j < reservoir) rec_list[(uint64_t)li * reservoir + j] = tile[__builtin_ctzll(rest)];
+          }
+        }
+      }
       n_reads += (uint32_t)__popcll(km);
-      if (n_reads > reservoir) status = WS_OVERFLOW;
       if (flags & 4u) status = WS_ERROR;
       if (flags & 2u) stop = true;
       if (flags & 1u) chunk_done = true;
@@ -775,8 +829,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   uint64_t n_pre = 0;
   for (uint32_t l = 0; l < nl; ++l) {
     if (h_walk[l].status == WS_ERROR) { out.fallback = FB_WALK; return TRGT_OK; }
-    if (h_walk[l].status == WS_OVERFLOW) { out.fallback = FB_RESERVOIR; return TRGT_OK; }
-    h_first[l] = n_pre; n_pre += h_walk[l].n_kept;
+    h_first[l] = n_pre; n_pre += std::min(h_walk[l].n_kept, in.reservoir);  // (n_kept counts every read that passed the filters: beyond the reservoir they replaced others)
   }
   h_first[nl] = n_pre;
   if (n_pre >= (1ull << 31)) { out.fallback = FB_WALK; return TRGT_OK; }

@@ -59,7 +59,7 @@ struct RunIn {
 };
 // Why a call went back to the host path (RunOut::fallback)
 enum : int { FB_NONE = 0, FB_BLOCK = 1 /* a block the device could not inflate or whose CRC-32 / ISIZE does not match */, FB_WALK = 2 /* a record the walk refuses */,
-             FB_RESERVOIR = 3 /* more reads than the reservoir holds: StdRng's stream runs on the host */, FB_METH = 4 /* MM / ML beyond the kernel's LDS caps */ };
+             FB_RESERVOIR = 3 /* (unused since the reservoir's random stream runs in walk_kernel) */, FB_METH = 4 /* MM / ML beyond the kernel's LDS caps */ };
 struct RunOut { int fallback = FB_NONE; Slab slab; HostOut out; double ms_upload = 0, ms_inflate = 0, ms_walk = 0, ms_reads = 0, ms_download = 0; uint64_t blocks_host_inflated = 0; };
 
 class Slot;
