@@ -178,6 +178,29 @@ def test_reservoir_caps_deep_loci(tmp_path):
     assert [again["read_name"][r] for r in _reads_of(again, 1)[1]] == names  # a fixed seed: the same sample every time
 
 
+def test_reservoir_slots_are_rebuilt_from_scratch(tmp_path):
+    # round 6 (found by tests/tools/ingest_fuzz.py against the device path): a read that replaces a reservoir slot and has no rq tag must
+    # come out with read_qual None (NaN), not with the value of the read it replaced -- HiFiRead::from_hts_rec builds a new read every time
+    from trgt_amd import ingest
+    rng = np.random.default_rng(9)
+    genome = "".join(rng.choice(list("ACGT"), 6000))
+    fa = str(tmp_path / "g.fa")
+    write_fasta(fa, [("chr1", genome)])
+    bed = str(tmp_path / "c.bed")
+    open(bed, "w").write("chr1\t3000\t3030\tID=L;MOTIFS=CAG;STRUC=(CAG)n\n")
+    recs = [dict(name="r%03d" % i, tid=0, pos=2500 + (i % 40), cigar=[("M", 900)], seq="".join(rng.choice(list("ACGT"), 900)),
+                 tags={"rq": ("f", 0.999)} if i % 3 else {}) for i in range(120)]
+    recs.sort(key=lambda r: r["pos"])
+    bam = str(tmp_path / "r.bam")
+    write_bam(bam, [("chr1", 6000)], recs)
+    b = ingest.Reader(bam, fa).batch(bed, max_depth=5, min_read_qual=0.5)
+    assert int(b["n_reads_seen"][0]) == 120 and b["n_reads"] == 15
+    tagged = {r["name"]: bool(r["tags"]) for r in recs}
+    for name, rq in zip(b["read_name"], b["read_qual"]):
+        assert np.isnan(rq) != tagged[name], (name, rq)
+    assert np.isnan(b["read_qual"]).any() and (~np.isnan(b["read_qual"])).any()
+
+
 def test_errors_are_reported(tmp_path):
     from trgt_amd import _lib, ingest
     with pytest.raises(_lib.TrgtHipError):

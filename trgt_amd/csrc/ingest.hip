@@ -421,6 +421,7 @@ void make_read(const RawRec& r, int64_t region_start, int64_t region_end, Read& 
   out.quals.assign(d + r.o_qual, d + r.o_qual + r.l_seq);
   out.mapq = r.mapq;
   { const uint8_t* a = find_aux(r, "HP"); out.hp = a && a[0] == 'C' ? (int)a[1] : -1; }  // get_hp_tag (read.rs:167-172): Aux::U8 only
+  out.rq = std::numeric_limits<double>::quiet_NaN();  // (a reservoir slot is overwritten in place: a read without the tag must not keep its predecessor's value -- found by tests/tools/ingest_fuzz.py, round 6)
   { const uint8_t* a = find_aux(r, "rq"); float f; if (a && a[0] == 'f') { std::memcpy(&f, a + 1, 4); out.rq = (double)f; } }
   {  // get_meth (read.rs:55-96)
     std::vector<std::pair<uint32_t, uint8_t>> mods;
