@@ -44,6 +44,30 @@ def test_contract_line_is_small_and_complete(tmp_path):
     assert json.load(open(path)) == full
 
 
+def test_contract_line_says_what_binds():
+    # next to the nominal SURVEY 8(d) fraction the line carries, for the headline kernel and for every leg, what actually
+    # moves (frac_io_only), what the HBM counters saw as a fraction of peak (frac_traffic, where a PMC profile is committed) and the
+    # measured bound; driven from this round's full record (profiles/r06f_bench_detail.json)
+    bench = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06f_bench_detail.json")))
+    line = bench.compact_line(full)
+    assert len(line.encode()) < 4096, len(line)
+    d = json.loads(line)
+    r = d["roofline"]
+    for k in ("frac", "frac_io_only", "frac_traffic", "valu_issue_frac", "bound_measured", "traffic", "bound"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["bound_measured"] == "valu-issue"
+    assert r["frac_io_only"] < r["frac_traffic"] < 0.05 < r["frac"]   # 0.2 % / 0.6 % of peak actually moved; the nominal pricing says 0.8
+    assert abs(r["frac_traffic"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-4
+    for k, leg in d["configs"].items():
+        assert "frac_io_only" in leg["roofline"] and "bound_measured" in leg["roofline"], k
+    assert "frac_traffic" in d["configs"]["4"]["roofline"]
+    e = d["e2e"]
+    for k in ("ingest_loci_per_s", "ingest_loci_per_s_host", "pipeline_loci_per_s", "pipeline_loci_per_s_host_ingest", "gpu_loci_per_s", "write_loci_per_s"):
+        assert e[k] > 0, k
+    assert e["ingest_loci_per_s"] > 2 * e["ingest_loci_per_s_host"] and e["pipeline_loci_per_s"] > 2 * e["pipeline_loci_per_s_host_ingest"] and e["pipeline_vcf_identical"]
+
+
 def test_contract_line_without_legs_or_baseline():
     bench = _bench()
     full = json.load(open(os.path.join(ROOT, "profiles", "r04last_bench_default.json")))
