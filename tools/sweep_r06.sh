@@ -5,7 +5,7 @@
 TAG=${1:-r06}; F=${2:-100000000}
 O=gpurun_out/${TAG}_parity_sweep.txt; mkdir -p gpurun_out; : > $O
 run() { echo "# parity_sweep.py $*" >> $O; python tests/tools/parity_sweep.py "$@" 2>&1 | grep -E "RESULT|MISMATCH" | head -20 >> $O; }
-envrun() { local e="$1"; shift; echo "# ($e) parity_sweep.py $*" >> $O; env $e python tests/tools/parity_sweep.py "$@" 2>&1 | grep -E "RESULT|MISMATCH" | head -20 | sed "s/^/($e) /" >> $O; }
+envrun() { local e="$1"; shift; echo "# ($e) parity_sweep.py $*" >> $O; env $e python tests/tools/parity_sweep.py "$@" 2>&1 | grep -E "RESULT|MISMATCH" | head -20 | sed "s|^|($e) |" >> $O; }
 run 2 300000 $F
 run 4 300000 $F
 run 5 100000 $F 2000

@@ -714,6 +714,8 @@ class Slot {
  public:
   int device = -1;
   hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;  // blocking-sync event: a caller SLEEPS while its slot's kernels run (a spinning wait per caller would eat three of the
+                              // host's CPUs -- sixteen per process on the GPU boxes, shared with the file reads, the locus stage's host threads and the writer)
   PinBuf src_pin, small_pin;
   DevBuf d_src, d_blocks, d_crc, d_infl, d_status, d_counter, d_loci, d_chunks, d_list, d_walk, d_first, d_info, d_off, d_counters, d_scratch, d_lrb, d_tab;
   bool tab_ready = false;
@@ -721,9 +723,14 @@ class Slot {
     if (device >= 0) (void)hipSetDevice(device);
     for (DevBuf* b : {&d_src, &d_blocks, &d_crc, &d_infl, &d_status, &d_counter, &d_loci, &d_chunks, &d_list, &d_walk, &d_first, &d_info, &d_off, &d_counters, &d_scratch, &d_lrb, &d_tab}) b->release();
     src_pin.release(); small_pin.release();
+    if (done) (void)hipEventDestroy(done);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
+static inline hipError_t slot_wait(Slot* s) {
+  const hipError_t e = hipEventRecord(s->done, s->stream);
+  return e != hipSuccess ? e : hipEventSynchronize(s->done);
+}
 
 Slot* slot_create(int device, std::string& err) {
   int n = 0;
@@ -737,6 +744,7 @@ Slot* slot_create(int device, std::string& err) {
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); err = "trgt_ingest: hipStreamCreate failed"; return nullptr; }
+  if (hipEventCreateWithFlags(&s->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); err = "trgt_ingest: hipEventCreate failed"; return nullptr; }
   return s.release();
 }
 void slot_destroy(Slot* s) { delete s; }
@@ -799,7 +807,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
                              (const CrcTables*)s->d_tab.p, (uint8_t*)s->d_status.p);
   ING_TRY(hipGetLastError());
   ING_TRY(hipMemcpyAsync(h_status, s->d_status.p, nb, hipMemcpyDeviceToHost, st));
-  ING_TRY(hipStreamSynchronize(st));
+  ING_TRY(slot_wait(s));
   const double t1 = now();
   // a block the device declined goes through zlib here (rare: the kernel takes every stream zlib level 1-9 writes); a block that does not
   // inflate to its ISIZE or whose CRC-32 differs sends the call to the host path, which reports it
@@ -816,7 +824,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
     inflateEnd(&zs);
     if (!good) { out.fallback = FB_BLOCK; return TRGT_OK; }
     ING_TRY(hipMemcpyAsync((uint8_t*)s->d_infl.p + bd.dst_off, tmp.data(), bd.dst_len, hipMemcpyHostToDevice, st));
-    ING_TRY(hipStreamSynchronize(st));
+    ING_TRY(slot_wait(s));
     ++out.blocks_host_inflated;
   }
   // ---- the record walk
@@ -824,7 +832,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
                              (uint64_t*)s->d_list.p, (WalkOut*)s->d_walk.p);
   ING_TRY(hipGetLastError());
   ING_TRY(hipMemcpyAsync(h_walk, s->d_walk.p, (size_t)nl * sizeof(WalkOut), hipMemcpyDeviceToHost, st));
-  ING_TRY(hipStreamSynchronize(st));
+  ING_TRY(slot_wait(s));
   const double t2 = now();
   uint64_t n_pre = 0;
   for (uint32_t l = 0; l < nl; ++l) {
@@ -843,14 +851,14 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   scan();
   ING_TRY(hipGetLastError());
   ING_TRY(hipMemcpyAsync(h_counters, s->d_counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  ING_TRY(hipStreamSynchronize(st));
+  ING_TRY(slot_wait(s));
   if (h_counters->n_tagged) {  // reads with MM + ML: get_meth, then the sizes once more
     ING_NEED(s->d_scratch, (size_t)h_counters->meth_scratch + 64);
     hipLaunchKernelGGL(read_meth_kernel, dim3((unsigned)n_pre), dim3(64), 0, st, (const uint8_t*)s->d_infl.p, n_pre, (ReadInfo*)s->d_info.p, (uint8_t*)s->d_scratch.p, (Counters*)s->d_counters.p);
     scan();
     ING_TRY(hipGetLastError());
     ING_TRY(hipMemcpyAsync(h_counters, s->d_counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    ING_TRY(hipStreamSynchronize(st));
+    ING_TRY(slot_wait(s));
     if (h_counters->meth_flag) { out.fallback = FB_METH; return TRGT_OK; }
   }
   const double t3 = now();
@@ -880,7 +888,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   ING_TRY(hipMemcpyAsync(D + a_lrb, s->d_lrb.p, ((size_t)nl + 1) * 8, hipMemcpyDeviceToDevice, st));
   const double t4 = now();
   ING_TRY(hipMemcpyAsync(H, D, at, hipMemcpyDeviceToHost, st));
-  ING_TRY(hipStreamSynchronize(st));
+  ING_TRY(slot_wait(s));
   {  // per locus counters: known to the host since the walk
     int32_t* nf = (int32_t*)(H + a_nfilt); int64_t* ns = (int64_t*)(H + a_nseen);
     for (uint32_t l = 0; l < nl; ++l) { nf[l] = (int32_t)h_walk[l].n_filt; ns[l] = (int64_t)h_walk[l].n_kept; }
