@@ -81,7 +81,7 @@ def test_wfaligner_mirror_pure_python_parts():
     assert W.WFAligner.decode_sam_cigar([135, 24, 39]) == [(8, "="), (1, "X"), (2, "=")]
     assert W.WFAligner.decode_sam_cigar([176]) == [(11, "M")]
     p = al._params("endsfree", 0, 0, -1, -1)
-    assert (p.span, p.text_begin_free, p.text_end_free, p.memory_mode, p.heuristic) == (1, -1, -1, 2, 99)
+    assert (p.span, p.text_begin_free, p.text_end_free, p.memory_mode, p.heuristic) == (1, -1, -1, 2, 5)    # BandedStatic: its own number, the library answers TRGT_ERR_UNSUPPORTED
     sc = W.WFAligner.builder(W.AlignmentScope.Score, W.MemoryModel.MemoryUltraLow).edit().build()
     assert sc._params("end2end").metric == 1 and sc._params("end2end").heuristic == 1  # default wfadaptive stays (:374-376)
     sc._last = dict(ops=b"", n_match=0, cigar=[], span=[0, 0, 0, 0], score=3, plen=0, tlen=0)
