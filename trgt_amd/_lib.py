@@ -247,7 +247,7 @@ class Pool:
 # the planner switches the RELEASE library reads (tests/test_abi_exports.py pins this list against `strings libtrgt_hip.so`); every other
 # TRGT_* switch -- settled A/Bs, probes -- is read only by the developer build (make -C trgt_amd/csrc DEV=1 -> libtrgt_hip_dev.so)
 RELEASE_KNOBS = frozenset("TRGT_" + k for k in (
-    "CLUSTER_ARENA_KB HEAVY_BAND HMM_NO_DEDUPE HMM_NO_LONG_TB HMM_NO_PPL HOST_CLUSTER HOST_GENOTYPER HOST_REPAIR INGEST_TRACE MALLOC_TUNE NO_HAMMING "
+    "CLUSTER_ARENA_KB HEAVY_BAND HMM_NO_DEDUPE INFLATE_COMPILER_LOOP HMM_NO_LONG_TB HMM_NO_PPL HOST_CLUSTER HOST_GENOTYPER HOST_REPAIR INGEST_TRACE MALLOC_TUNE NO_HAMMING "
     "NO_INDEL_SHORTCUT NO_LONG_FILTER NO_ZERO_ARENA POLL_NAP_US POLL_SPIN_US POLL_WAIT REPAIR_MAX_SEG STAGE_LOCK TIMELINE WFA_DEBUG WFA_NO_EARLY "
     "WFA_NO_FILTER WFA_NO_LEAN WFA_NO_WINDOW WRITER_TRACE").split())
 _DEV_SO = os.path.join(_HERE, "libtrgt_hip_dev.so")

@@ -15,13 +15,15 @@
 // number of streams in flight is what sets the rate (32 KB of ring: four per CU, 7.7 GB/s).
 // A stream this decoder does not like (bad code lengths, distance too far back, output not exactly the announced size) is DECLINED
 // (status 0): the caller hands that block to zlib, which produces the data or the error message.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "inflate_dev.hpp"
 
 namespace trgt {
 namespace infl {
 
-constexpr uint32_t RING = 2048, RING_MASK = RING - 1, SEG = 1024;  // the last 2 KB of output in LDS; older bytes are read back from the flushed output
+constexpr uint32_t RING = 4096, RING_MASK = RING - 1, SEG = 2048;  // the last 4 KB of output in LDS (2 KB until the hand-written loop: a fifth of a BAM block's matches reach further back than that, an eighth further than 4 KB); older bytes are read back from the flushed output
 constexpr uint32_t IN_WIN = 1024;        // compressed bytes staged in LDS
 constexpr uint32_t HDR_ROOM = 576;       // a dynamic block header (<= 14 + 19 * 3 + 320 * 14 bits = 569 bytes) is parsed without a reload in between
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
@@ -106,10 +108,212 @@ __device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, 
   return true;
 }
 
+// The symbol loop by hand (round 6, second half).  The compiler's scalar code for the loop costs 67 SALU instructions per symbol (a CU
+// issues ONE per cycle) -- flag registers for every merge of the nested branches, 64-bit window arithmetic for bit-buffer refills at
+// arbitrary byte positions, five separate range checks per match -- and every match that reaches beyond the ring (a fifth of the matches
+// of a BAM block: distances are spread evenly up to 32 KB) went through the general copy with its modulo arithmetic.  This loop keeps
+// the decoder's state in fixed scalar registers and handles what almost every symbol is: a literal (or a pair), a match of at most 64
+// bytes from the LDS ring (overlapping its destination or not), a match of at most 64 bytes from the flushed output -- ~ 18 scalar
+// instructions per literal iteration, ~ 50 per match.  Everything else (codes longer than the table's index, end of block, undefined
+// symbols, copies of more than 64 bytes, sources that straddle the ring's edge, a window that runs low) LEAVES the loop with the state
+// of the reference decoder intact and says where it stopped; the C++ code does that one symbol.
+//   Preconditions (the caller's): in_pos is a multiple of 4 (refills are aligned dword reads of the window), op < stop <= out_len - 258
+//   (no symbol can pass the end of the output), stop at most the next segment boundary (the ring is flushed segment by segment).
+//   Returns 0: op reached stop (at a symbol boundary); 1: at a symbol boundary, the next symbol is the caller's (or the window is low);
+//   2: a length has been decoded into len, its distance code is the next thing in the bit buffer; 3: len and dist decoded, copy not done.
+__device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bitcnt, uint32_t& ip_lds, uint32_t& op, uint32_t& len, uint32_t& dist, uint32_t ip_limit,
+                                                 uint32_t op_stop, uint32_t lit_base, uint32_t dist_base, uint32_t ring_base, uint32_t lane, const uint8_t* outp) {
+  uint32_t code, e, n, t0, t1, v0, v1, v2;
+  static_assert(RING == 4096 && LIT_BITS == 10 && DIST_BITS == 8, "constants of the hand-written loop");
+  asm volatile(
+      "s_mov_b64 s[60:61], %[bb]\n\t"
+      "s_mov_b32 s65, 0\n\t"
+      "s_mov_b32 %[code], 0\n"
+      ".Ltop%=:\n\t"
+      "s_cmp_gt_u32 %[bc], 31\n\t"
+      "s_cbranch_scc1 .Llook%=\n\t"
+      // ---- refill at a symbol boundary: 32 bits from the aligned dword at ip (the window must not be low)
+      "s_cmp_gt_u32 %[ip], %[iplim]\n\t"
+      "s_cbranch_scc1 .Lexit1%=\n\t"
+      "v_mov_b32 %[v0], %[ip]\n\t"
+      "ds_read_b32 %[v0], %[v0]\n\t"
+      "s_add_i32 %[ip], %[ip], 4\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 s64, %[v0]\n\t"
+      "s_lshl_b64 s[62:63], s[64:65], %[bc]\n\t"
+      "s_or_b32 %[bc], %[bc], 32\n\t"
+      "s_or_b64 s[60:61], s[60:61], s[62:63]\n"
+      ".Llook%=:\n\t"
+      "s_and_b32 %[t0], s60, 0x3ff\n\t"
+      "s_lshl2_add_u32 %[t0], %[t0], %[litb]\n\t"
+      "v_mov_b32 %[v0], %[t0]\n\t"
+      "ds_read_b32 %[v0], %[v0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[v0]\n\t"
+      "s_and_b32 %[n], %[e], 15\n\t"
+      "s_cbranch_scc0 .Lexit1%=\n\t"          // a code longer than the index: the caller's
+      "s_bitcmp1_b32 %[e], 8\n\t"             // F_LIT
+      "s_cbranch_scc0 .Lnolit%=\n\t"
+      // ---- one literal (bits 16-23 of the entry, still in v0) or two (F_PAIR: the second in bits 24-31)
+      "s_and_b32 %[t0], %[op], 0xfff\n\t"
+      "v_mov_b32 %[v1], %[t0]\n\t"
+      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "ds_write_b8_d16_hi %[v1], %[v0]\n\t"
+      "s_add_i32 %[op], %[op], 1\n\t"
+      "s_bitcmp1_b32 %[e], 10\n\t"            // F_PAIR
+      "s_cbranch_scc0 .Llitdone%=\n\t"
+      "s_and_b32 %[t0], %[op], 0xfff\n\t"
+      "v_mov_b32 %[v1], %[t0]\n\t"
+      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "v_lshrrev_b32 %[v2], 24, %[v0]\n\t"
+      "ds_write_b8 %[v1], %[v2]\n\t"
+      "s_add_i32 %[op], %[op], 1\n"
+      ".Llitdone%=:\n\t"
+      "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[n]\n\t"
+      "s_cmp_lt_u32 %[op], %[opstop]\n\t"
+      "s_cbranch_scc1 .Ltop%=\n\t"
+      "s_branch .Lout%=\n"
+      ".Lnolit%=:\n\t"
+      "s_and_b32 %[t0], %[e], 0xa00\n\t"      // F_EOB | F_BAD: the caller's (nothing consumed)
+      "s_cbranch_scc1 .Lexit1%=\n\t"
+      // ---- a length: base in bits 16-31, extra bits in 4-7
+      "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[n]\n\t"
+      "s_bfe_u32 %[t0], %[e], 0x40004\n\t"
+      "s_bfm_b32 %[t1], %[t0], 0\n\t"
+      "s_and_b32 %[t1], s60, %[t1]\n\t"
+      "s_lshr_b32 %[len], %[e], 16\n\t"
+      "s_add_i32 %[len], %[len], %[t1]\n\t"
+      "s_lshr_b64 s[60:61], s[60:61], %[t0]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[t0]\n\t"
+      // a distance code and its extra bits take at most 15 + 13 bits (the window's margin covers this refill: see the caller)
+      "s_cmp_gt_u32 %[bc], 27\n\t"
+      "s_cbranch_scc1 .Ldist%=\n\t"
+      "v_mov_b32 %[v0], %[ip]\n\t"
+      "ds_read_b32 %[v0], %[v0]\n\t"
+      "s_add_i32 %[ip], %[ip], 4\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 s64, %[v0]\n\t"
+      "s_lshl_b64 s[62:63], s[64:65], %[bc]\n\t"
+      "s_or_b32 %[bc], %[bc], 32\n\t"
+      "s_or_b64 s[60:61], s[60:61], s[62:63]\n"
+      ".Ldist%=:\n\t"
+      "s_and_b32 %[t0], s60, 0xff\n\t"
+      "s_lshl2_add_u32 %[t0], %[t0], %[distb]\n\t"
+      "v_mov_b32 %[v0], %[t0]\n\t"
+      "ds_read_b32 %[v0], %[v0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[e], %[v0]\n\t"
+      "s_and_b32 %[n], %[e], 15\n\t"
+      "s_cbranch_scc0 .Lexit2%=\n\t"          // a long distance code
+      "s_bitcmp1_b32 %[e], 11\n\t"            // F_BAD
+      "s_cbranch_scc1 .Lexit2%=\n\t"
+      "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[n]\n\t"
+      "s_bfe_u32 %[t0], %[e], 0x40004\n\t"
+      "s_bfm_b32 %[t1], %[t0], 0\n\t"
+      "s_and_b32 %[t1], s60, %[t1]\n\t"
+      "s_lshr_b32 %[dist], %[e], 16\n\t"
+      "s_add_i32 %[dist], %[dist], %[t1]\n\t"
+      "s_lshr_b64 s[60:61], s[60:61], %[t0]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[t0]\n\t"
+      "s_cmp_gt_u32 %[dist], %[op]\n\t"       // before the start of the output: the caller reports it
+      "s_cbranch_scc1 .Lexit3%=\n\t"
+      "s_min_u32 %[t0], %[dist], 64\n\t"
+      "s_cmp_lt_u32 %[t0], %[len]\n\t"
+      "s_cbranch_scc1 .Lslow%=\n\t"           // more than 64 bytes, or a source that overlaps its destination
+      "s_cmpk_gt_u32 %[dist], 0xfc0\n\t"      // RING - 64
+      "s_cbranch_scc1 .Lfar%=\n\t"
+      // ---- the copy in one round by the whole wave: len <= 64, len <= dist (no overlap), dist + len <= RING (the source is in the ring)
+      "s_sub_i32 %[t0], %[op], %[dist]\n\t"
+      "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
+      "s_and_saveexec_b64 s[66:67], vcc\n\t"
+      "v_add_u32 %[v0], %[t0], %[lane]\n\t"
+      "v_and_b32 %[v0], 0xfff, %[v0]\n\t"
+      "v_add_u32 %[v0], %[ringb], %[v0]\n\t"
+      "ds_read_u8 %[v2], %[v0]\n\t"
+      "v_add_u32 %[v1], %[op], %[lane]\n\t"
+      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
+      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_write_b8 %[v1], %[v2]\n\t"
+      "s_mov_b64 exec, s[66:67]\n"
+      ".Lcopied%=:\n\t"
+      "s_add_i32 %[op], %[op], %[len]\n\t"
+      "s_cmp_lt_u32 %[op], %[opstop]\n\t"
+      "s_cbranch_scc1 .Ltop%=\n\t"
+      "s_branch .Lout%=\n"
+      // ---- a source beyond the ring: dist >= RING means every byte of it has been flushed (segments go out as they fill, and the flush is
+      //      fenced), so the wave reads the output it wrote itself; RING - 64 < dist < RING may straddle the ring's edge: the caller's
+      ".Lfar%=:\n\t"
+      "s_cmpk_lt_u32 %[dist], 0x1000\n\t"
+      "s_cbranch_scc1 .Lexit3%=\n\t"
+      "s_sub_i32 %[t0], %[op], %[dist]\n\t"
+      "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
+      "s_and_saveexec_b64 s[66:67], vcc\n\t"
+      "v_add_u32 %[v0], %[t0], %[lane]\n\t"
+      "global_load_ubyte %[v2], %[v0], %[outp] sc1\n\t"
+      "v_add_u32 %[v1], %[op], %[lane]\n\t"
+      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
+      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "ds_write_b8 %[v1], %[v2]\n\t"
+      "s_mov_b64 exec, s[66:67]\n\t"
+      "s_branch .Lcopied%=\n"
+      // ---- dist < len <= 64: the dist bytes in front of op repeat.  Round r copies the bytes [dist (2^r - 1), dist (2^(r+1) - 1)) from
+      //      dist 2^r places before them -- a multiple of the period, and everything that far back is written: log2(len / dist) rounds
+      ".Lslow%=:\n\t"
+      "s_cmp_gt_u32 %[len], 64\n\t"
+      "s_cbranch_scc1 .Lexit3%=\n\t"
+      "s_mov_b32 %[t0], 0\n\t"                // done
+      "s_mov_b32 %[t1], %[dist]\n"            // step
+      ".Lround%=:\n\t"
+      "s_add_i32 %[n], %[t0], %[t1]\n\t"
+      "s_min_u32 %[n], %[n], %[len]\n\t"
+      "v_cmp_le_u32 vcc, %[t0], %[lane]\n\t"
+      "s_and_saveexec_b64 s[66:67], vcc\n\t"
+      "v_cmp_gt_u32 vcc, %[n], %[lane]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "v_add_u32 %[v1], %[op], %[lane]\n\t"
+      "v_subrev_u32 %[v0], %[t1], %[v1]\n\t"
+      "v_and_b32 %[v0], 0xfff, %[v0]\n\t"
+      "v_add_u32 %[v0], %[ringb], %[v0]\n\t"
+      "ds_read_u8 %[v2], %[v0]\n\t"
+      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
+      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_write_b8 %[v1], %[v2]\n\t"
+      "s_mov_b64 exec, s[66:67]\n\t"
+      "s_mov_b32 %[t0], %[n]\n\t"
+      "s_lshl_b32 %[t1], %[t1], 1\n\t"
+      "s_cmp_lt_u32 %[t0], %[len]\n\t"
+      "s_cbranch_scc1 .Lround%=\n\t"
+      "s_branch .Lcopied%=\n"
+      ".Lexit3%=:\n\t"
+      "s_mov_b32 %[code], 3\n\t"
+      "s_branch .Lout%=\n"
+      ".Lexit2%=:\n\t"
+      "s_mov_b32 %[code], 2\n\t"
+      "s_branch .Lout%=\n"
+      ".Lexit1%=:\n\t"
+      "s_mov_b32 %[code], 1\n"
+      ".Lout%=:\n\t"
+      "s_mov_b64 %[bb], s[60:61]\n\t"
+      : [bb] "+s"(bitbuf), [bc] "+s"(bitcnt), [ip] "+s"(ip_lds), [op] "+s"(op), [len] "+s"(len), [dist] "+s"(dist), [code] "=&s"(code), [e] "=&s"(e), [n] "=&s"(n),
+        [t0] "=&s"(t0), [t1] "=&s"(t1), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2)
+      : [iplim] "s"(ip_limit), [opstop] "s"(op_stop), [litb] "s"(lit_base), [distb] "s"(dist_base), [ringb] "s"(ring_base), [lane] "v"(lane), [outp] "s"(outp)
+      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc", "memory");
+  return code;
+}
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
-                                                            uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter) {
+                                                            uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter, uint32_t fast) {
   __shared__ Shared sh;
   const int lane = threadIdx.x;
+  typedef __attribute__((address_space(3))) void* lds_ptr;  // LDS byte addresses for the hand-written loop
+  const uint32_t win_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.in_win, lit_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.lit32, dist_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.dist32,
+                 ring_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.out;
   for (;;) {
     __syncthreads();
     if (lane == 0) sh.block = atomicAdd(counter, 1u);
@@ -224,25 +428,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
             const uint32_t low_ev = to_end ? (uint32_t)EV_ERROR : (uint32_t)EV_RELOAD;
             uint32_t ev = in_pos > safe_end ? low_ev : (uint32_t)EV_NONE;
             while (ev == EV_NONE) {
-              refill();  // (>= 32 bits: a literal / length code and its extra bits take at most 15 + 5)
-              uint32_t e = RFL(sh.lit32[bitbuf & ((1u << LIT_BITS) - 1u)]);
-              if (!(e & 15u)) { int l; const int sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); e = sym < 0 ? (F_BAD | 1u) : lit_entry((uint32_t)sym, (uint32_t)l); }
-              take(e & 15u);
               const uint32_t before = op;
-              if (e & F_LIT) {
-                sh.out[op & RING_MASK] = (uint8_t)(e >> 16); ++op;
-                if (e & F_PAIR) { sh.out[op & RING_MASK] = (uint8_t)(e >> 24); ++op; }
-              } else if (e & (F_EOB | F_BAD)) {
-                if (e & F_BAD) ev = EV_ERROR;
-                else { phase = 0; ev = final_block ? (uint32_t)EV_DONE : (uint32_t)EV_BUILD; }  // (EV_BUILD stands for "leave the loop, nothing to do": reset below)
-              } else {
-                const uint32_t len = (e >> 16) + take((e >> 4) & 15u);
+              uint32_t stage = 1, len = 0, dist = 0;  // 1: at a symbol boundary; 2: a length is decoded, its distance code comes next; 3: length and distance decoded
+              if (fast && op + 258u < out_len) {
+                // the hand-written loop (fast_symbols) wants in_pos on a dword boundary: whole bytes go into the bit buffer until it is
+                while ((in_pos & 3u) && bitcnt <= 56u) { bitbuf |= (uint64_t)RFL(sh.in_win[in_pos - wb]) << bitcnt; bitcnt += 8; ++in_pos; }
+                if (!(in_pos & 3u)) {
+                  uint32_t ip = win_lds + (in_pos - wb);
+                  const uint32_t seg_end = (op | (SEG - 1u)) + 1u, tail = out_len - 258u;
+                  stage = fast_symbols(bitbuf, bitcnt, ip, op, len, dist, win_lds + (safe_end - wb), seg_end < tail ? seg_end : tail, lit_lds, dist_lds, ring_lds, (uint32_t)lane, outp);
+                  in_pos = wb + (ip - win_lds);
+                }
+              }
+              if (stage == 1) {
+                if (in_pos > safe_end) ev = low_ev;  // (the loop above stopped for the window)
+                else {
+                  refill();  // (>= 32 bits: a literal / length code and its extra bits take at most 15 + 5)
+                  uint32_t e = RFL(sh.lit32[bitbuf & ((1u << LIT_BITS) - 1u)]);
+                  if (!(e & 15u)) { int l; const int sym = slow_decode(sh.lit_cnt, sh.lit_sym, bitbuf, l); e = sym < 0 ? (F_BAD | 1u) : lit_entry((uint32_t)sym, (uint32_t)l); }
+                  take(e & 15u);
+                  if (e & F_LIT) {
+                    sh.out[op & RING_MASK] = (uint8_t)(e >> 16); ++op;
+                    if (e & F_PAIR) { sh.out[op & RING_MASK] = (uint8_t)(e >> 24); ++op; }
+                  } else if (e & (F_EOB | F_BAD)) {
+                    if (e & F_BAD) ev = EV_ERROR;
+                    else { phase = 0; ev = final_block ? (uint32_t)EV_DONE : (uint32_t)EV_BUILD; }  // (EV_BUILD stands for "leave the loop, nothing to do": reset below)
+                  } else {
+                    len = (e >> 16) + take((e >> 4) & 15u);
+                    stage = 2;
+                  }
+                }
+              }
+              if (stage == 2) {
                 refill();  // (a distance code and its extra bits: at most 15 + 13)
                 uint32_t d = RFL(sh.dist32[bitbuf & ((1u << DIST_BITS) - 1u)]);
                 if (!(d & 15u)) { int dl; const int ds = slow_decode(sh.dist_cnt, sh.dist_sym, bitbuf, dl); d = ds < 0 ? (F_BAD | 1u) : dist_entry((uint32_t)ds, (uint32_t)dl); }
                 take(d & 15u);
-                const uint32_t dist = (d >> 16) + take((d >> 4) & 15u);
-                if ((d & F_BAD) || dist > op || op + len > out_len) ev = EV_ERROR;
+                dist = (d >> 16) + take((d >> 4) & 15u);
+                if (d & F_BAD) ev = EV_ERROR;
+                else stage = 3;
+              }
+              if (stage == 3) {
+                if (dist > op || op + len > out_len) ev = EV_ERROR;
                 else {
                   // the copy by the whole wave: lane i takes byte i of a round of 64.  A source that overlaps its destination (dist < len)
                   // repeats the dist bytes in front of op: byte k comes from op - dist + k mod dist, all of them written already
@@ -265,7 +492,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                   op += len;
                 }
               }
-              if (ev == EV_NONE) ev = op > out_len ? (uint32_t)EV_ERROR : ((before ^ op) & SEG) ? (uint32_t)EV_FLUSH : in_pos > safe_end ? low_ev : (uint32_t)EV_NONE;
+              // (a different segment: the hand-written loop stops right behind a boundary, one more symbol of this loop may follow it)
+              if (ev == EV_NONE) ev = op > out_len ? (uint32_t)EV_ERROR : ((before ^ op) >= SEG) ? (uint32_t)EV_FLUSH : in_pos > safe_end ? low_ev : (uint32_t)EV_NONE;
             }
             want = ev == EV_BUILD ? (uint32_t)EV_NONE : ev;
           }
@@ -348,6 +576,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 
 // n raw DEFLATE streams src[src_off .. + src_len) -> dst[dst_off .. + dst_len) (host or device memory), status[b] = 1 inflated, 0 declined.
 // Synchronous: returns when dst and status are complete.
+// TRGT_INFLATE_COMPILER_LOOP=1: every symbol through the compiler's loop (the A/B of the hand-written one, and a mode of the tests)
+// (read per launch: a test runs both loops in one process)
+static uint32_t inflate_fast_flag() { return std::getenv("TRGT_INFLATE_COMPILER_LOOP") ? 0u : 1u; }
+
 int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64_t src_bytes, const infl::BlockDesc* descs, uint8_t* dst, uint64_t dst_bytes,
                           uint8_t* status, bool preserve_dst) {
   if (n <= 0) return TRGT_OK;
@@ -367,7 +599,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
   const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 15);
   hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
-                     (uint8_t*)d_status, (unsigned int*)d_counter);
+                     (uint8_t*)d_status, (unsigned int*)d_counter, inflate_fast_flag());
   TRGT_HIP_TRY(c, hipGetLastError());
   if (!dst_dev) TRGT_HIP_TRY(c, hipMemcpyAsync(dst, d_dst, (size_t)dst_bytes, hipMemcpyDeviceToHost, c->stream));
   TRGT_HIP_TRY(c, hipMemcpyAsync(status, d_status, (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -378,7 +610,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
 void inflate_launch(void* hip_stream, const uint8_t* d_src, const infl::BlockDesc* d_blocks, uint32_t n, uint8_t* d_dst, uint8_t* d_status, unsigned* d_counter,
                     unsigned waves) {
   if (!n) return;
-  hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(std::min<unsigned>(n, std::max(1u, waves))), dim3(64), 0, (hipStream_t)hip_stream, d_src, d_blocks, n, d_dst, d_status, d_counter);
+  hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(std::min<unsigned>(n, std::max(1u, waves))), dim3(64), 0, (hipStream_t)hip_stream, d_src, d_blocks, n, d_dst, d_status, d_counter, inflate_fast_flag());
 }
 
 }  // namespace trgt
