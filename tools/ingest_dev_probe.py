@@ -45,7 +45,8 @@ def run(callers, **kw):
 if os.environ.get("PROBE_DEVICE_ONLY"):  # (for a kernel trace: the device path alone, one caller)
     callers = int(os.environ["PROBE_DEVICE_ONLY"])
     for _ in range(3):
-        dt, nr = run(callers, ingest_device=0, threads=8)
+        kw = {"inflate_waves_per_cu": int(os.environ["PROBE_WAVES"])} if os.environ.get("PROBE_WAVES") else {}
+        dt, nr = run(callers, ingest_device=0, threads=8, **kw)
         print("device path, %d caller(s): %7.0f loci/s (%d reads)" % (callers, n / dt, nr), flush=True)
     sys.exit(0)
 run(1, threads=16)

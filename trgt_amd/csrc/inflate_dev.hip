@@ -23,14 +23,29 @@
 namespace trgt {
 namespace infl {
 
-constexpr uint32_t RING = 4096, RING_MASK = RING - 1, SEG = 2048;  // the last 4 KB of output in LDS (2 KB until the hand-written loop: a fifth of a BAM block's matches reach further back than that, an eighth further than 4 KB); older bytes are read back from the flushed output
-constexpr uint32_t IN_WIN = 1024;        // compressed bytes staged in LDS
+#ifndef TRGT_INFL_RING
+#define TRGT_INFL_RING 2048
+#endif
+#if TRGT_INFL_RING == 4096
+#define INFL_RMASK "0xfff"
+#define INFL_RNEAR "0xfc0"   /* RING - 64 */
+#define INFL_RSIZE "0x1000"
+#elif TRGT_INFL_RING == 2048
+#define INFL_RMASK "0x7ff"
+#define INFL_RNEAR "0x7c0"
+#define INFL_RSIZE "0x800"
+#else
+#error "TRGT_INFL_RING: 2048 or 4096"
+#endif
+constexpr uint32_t RING = TRGT_INFL_RING, RING_MASK = RING - 1, SEG = RING / 2;  // the last 4 KB of output in LDS (2 KB until the hand-written loop: a fifth of a BAM block's matches reach further back than that, an eighth further than 4 KB); older bytes are read back from the flushed output
+constexpr uint32_t IN_WIN = RING == 2048 ? 896 : 1024;  // compressed bytes staged in LDS (with the 2-KB ring a block's LDS is 10 240 bytes: sixteen blocks per CU)
 constexpr uint32_t HDR_ROOM = 576;       // a dynamic block header (<= 14 + 19 * 3 + 320 * 14 bits = 569 bytes) is parsed without a reload in between
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
 
 enum : uint32_t { EV_NONE = 0, EV_RELOAD = 1, EV_FLUSH = 2, EV_BUILD = 3, EV_COPY = 4, EV_DONE = 5, EV_ERROR = 6 };
 
 struct Shared {
+  alignas(16) uint8_t out[RING];  // first: at LDS address 0 (the kernel's only LDS object), which the hand-written loop relies on (checked at the kernel's start)
   uint32_t ev;            // what lane 0 asks the wave for
   uint32_t win_base;      // source offset of in_win[0]
   uint32_t op;            // bytes produced so far
@@ -44,7 +59,6 @@ struct Shared {
   uint8_t lens[320], lens2[320];
   uint16_t offs[16], next[16];            // prepare_codes
   alignas(16) uint8_t in_win[IN_WIN + 32];  // (+ what the refills of one symbol may read past a window that already reaches the end of the input)
-  alignas(16) uint8_t out[RING];
 };
 
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -122,27 +136,50 @@ __device__ inline bool prepare_codes(const uint8_t* lens, int n, uint16_t* cnt, 
 //   Returns 0: op reached stop (at a symbol boundary); 1: at a symbol boundary, the next symbol is the caller's (or the window is low);
 //   2: a length has been decoded into len, its distance code is the next thing in the bit buffer; 3: len and dist decoded, copy not done.
 __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bitcnt, uint32_t& ip_lds, uint32_t& op, uint32_t& len, uint32_t& dist, uint32_t ip_limit,
-                                                 uint32_t op_stop, uint32_t lit_base, uint32_t dist_base, uint32_t ring_base, uint32_t lane, const uint8_t* outp) {
-  uint32_t code, e, n, t0, t1, v0, v1, v2;
-  static_assert(RING == 4096 && LIT_BITS == 10 && DIST_BITS == 8, "constants of the hand-written loop");
+                                                 uint32_t op_stop, uint32_t lit_base, uint32_t dist_base, uint32_t lane, const uint8_t* outp) {
+  uint32_t code, e, n, t0, t1, pd, v0, v1, v2, vn, vpd, vpa;
+  static_assert(LIT_BITS == 10 && DIST_BITS == 8, "constants of the hand-written loop");
+  // COMPLETE: the copy from the flushed output that is still in flight (pd != -1: its destination is [pd, pd + its length), the loaded
+  // bytes arrive in vpd, their ring addresses are in vpa, its lanes in s[68:69]) is written to the ring
+#ifdef INFL_EXP_NOWAIT  /* timing experiment only (wrong bytes): what the kernel would take if no copy from the flushed output were ever waited for */
+#define INFL_VMWAIT ""
+#else
+#define INFL_VMWAIT "s_waitcnt vmcnt(0)\n\t"
+#endif
+#define INFL_COMPLETE                      \
+  INFL_VMWAIT                              \
+  "s_mov_b64 s[66:67], exec\n\t"           \
+  "s_mov_b64 exec, s[68:69]\n\t"           \
+  "ds_write_b8 %[vpa], %[vpd]\n\t"         \
+  "s_mov_b64 exec, s[66:67]\n\t"           \
+  "s_mov_b32 %[pd], -1\n\t"
+  // REFILL: 32 more bits.  The dword was asked for when the one before it was consumed (vn), so the LDS round trip is over by now; the
+  // next one is asked for right away
+#define INFL_REFILL                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                         \
+  "v_readfirstlane_b32 s64, %[vn]\n\t"               \
+  "s_add_i32 %[ip], %[ip], 4\n\t"                    \
+  "v_mov_b32 %[v1], %[ip]\n\t"                       \
+  "ds_read_b32 %[vn], %[v1]\n\t"                     \
+  "s_lshl_b64 s[62:63], s[64:65], %[bc]\n\t"         \
+  "s_or_b32 %[bc], %[bc], 32\n\t"                    \
+  "s_or_b64 s[60:61], s[60:61], s[62:63]\n"
   asm volatile(
       "s_mov_b64 s[60:61], %[bb]\n\t"
       "s_mov_b32 s65, 0\n\t"
-      "s_mov_b32 %[code], 0\n"
+      "s_mov_b32 %[code], 0\n\t"
+      "s_mov_b32 %[pd], -1\n\t"
+      "s_mov_b32 s70, 0\n\t"                  // end of the destination of the copy in flight
+      "v_mov_b32 %[v1], %[ip]\n\t"
+      "ds_read_b32 %[vn], %[v1]\n"
       ".Ltop%=:\n\t"
       "s_cmp_gt_u32 %[bc], 31\n\t"
-      "s_cbranch_scc1 .Llook%=\n\t"
-      // ---- refill at a symbol boundary: 32 bits from the aligned dword at ip (the window must not be low)
+      "s_cbranch_scc1 .Llook%=\n"
+      // ---- refill at a symbol boundary (the window must not be low)
+      ".Lfill%=:\n\t"
       "s_cmp_gt_u32 %[ip], %[iplim]\n\t"
       "s_cbranch_scc1 .Lexit1%=\n\t"
-      "v_mov_b32 %[v0], %[ip]\n\t"
-      "ds_read_b32 %[v0], %[v0]\n\t"
-      "s_add_i32 %[ip], %[ip], 4\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 s64, %[v0]\n\t"
-      "s_lshl_b64 s[62:63], s[64:65], %[bc]\n\t"
-      "s_or_b32 %[bc], %[bc], 32\n\t"
-      "s_or_b64 s[60:61], s[60:61], s[62:63]\n"
+      INFL_REFILL
       ".Llook%=:\n\t"
       "s_and_b32 %[t0], s60, 0x3ff\n\t"
       "s_lshl2_add_u32 %[t0], %[t0], %[litb]\n\t"
@@ -155,16 +192,14 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "s_bitcmp1_b32 %[e], 8\n\t"             // F_LIT
       "s_cbranch_scc0 .Lnolit%=\n\t"
       // ---- one literal (bits 16-23 of the entry, still in v0) or two (F_PAIR: the second in bits 24-31)
-      "s_and_b32 %[t0], %[op], 0xfff\n\t"
+      "s_and_b32 %[t0], %[op], " INFL_RMASK "\n\t"
       "v_mov_b32 %[v1], %[t0]\n\t"
-      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
       "ds_write_b8_d16_hi %[v1], %[v0]\n\t"
       "s_add_i32 %[op], %[op], 1\n\t"
       "s_bitcmp1_b32 %[e], 10\n\t"            // F_PAIR
       "s_cbranch_scc0 .Llitdone%=\n\t"
-      "s_and_b32 %[t0], %[op], 0xfff\n\t"
+      "s_and_b32 %[t0], %[op], " INFL_RMASK "\n\t"
       "v_mov_b32 %[v1], %[t0]\n\t"
-      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
       "v_lshrrev_b32 %[v2], 24, %[v0]\n\t"
       "ds_write_b8 %[v1], %[v2]\n\t"
       "s_add_i32 %[op], %[op], 1\n"
@@ -172,32 +207,27 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
       "s_sub_i32 %[bc], %[bc], %[n]\n\t"
       "s_cmp_lt_u32 %[op], %[opstop]\n\t"
-      "s_cbranch_scc1 .Ltop%=\n\t"
-      "s_branch .Lout%=\n"
-      ".Lnolit%=:\n\t"
-      "s_and_b32 %[t0], %[e], 0xa00\n\t"      // F_EOB | F_BAD: the caller's (nothing consumed)
-      "s_cbranch_scc1 .Lexit1%=\n\t"
+      "s_cbranch_scc0 .Lout%=\n\t"
+      "s_cmp_gt_u32 %[bc], 31\n\t"
+      "s_cbranch_scc1 .Llook%=\n\t"
+      "s_branch .Lfill%=\n"
+      ".Lnolit%=:\n\t"                        // (end of block, undefined symbols and lengths that can pass 64 have empty entries: they left above)
       // ---- a length: base in bits 16-31, extra bits in 4-7
       "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
       "s_sub_i32 %[bc], %[bc], %[n]\n\t"
+      "s_lshr_b32 %[len], %[e], 16\n\t"
       "s_bfe_u32 %[t0], %[e], 0x40004\n\t"
+      "s_cbranch_scc0 .Llenok%=\n\t"         // (lengths 3 .. 10 have no extra bits: most matches)
       "s_bfm_b32 %[t1], %[t0], 0\n\t"
       "s_and_b32 %[t1], s60, %[t1]\n\t"
-      "s_lshr_b32 %[len], %[e], 16\n\t"
       "s_add_i32 %[len], %[len], %[t1]\n\t"
       "s_lshr_b64 s[60:61], s[60:61], %[t0]\n\t"
-      "s_sub_i32 %[bc], %[bc], %[t0]\n\t"
+      "s_sub_i32 %[bc], %[bc], %[t0]\n"
+      ".Llenok%=:\n\t"
       // a distance code and its extra bits take at most 15 + 13 bits (the window's margin covers this refill: see the caller)
       "s_cmp_gt_u32 %[bc], 27\n\t"
       "s_cbranch_scc1 .Ldist%=\n\t"
-      "v_mov_b32 %[v0], %[ip]\n\t"
-      "ds_read_b32 %[v0], %[v0]\n\t"
-      "s_add_i32 %[ip], %[ip], 4\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 s64, %[v0]\n\t"
-      "s_lshl_b64 s[62:63], s[64:65], %[bc]\n\t"
-      "s_or_b32 %[bc], %[bc], 32\n\t"
-      "s_or_b64 s[60:61], s[60:61], s[62:63]\n"
+      INFL_REFILL
       ".Ldist%=:\n\t"
       "s_and_b32 %[t0], s60, 0xff\n\t"
       "s_lshl2_add_u32 %[t0], %[t0], %[distb]\n\t"
@@ -207,8 +237,6 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "v_readfirstlane_b32 %[e], %[v0]\n\t"
       "s_and_b32 %[n], %[e], 15\n\t"
       "s_cbranch_scc0 .Lexit2%=\n\t"          // a long distance code
-      "s_bitcmp1_b32 %[e], 11\n\t"            // F_BAD
-      "s_cbranch_scc1 .Lexit2%=\n\t"
       "s_lshr_b64 s[60:61], s[60:61], %[n]\n\t"
       "s_sub_i32 %[bc], %[bc], %[n]\n\t"
       "s_bfe_u32 %[t0], %[e], 0x40004\n\t"
@@ -220,52 +248,67 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "s_sub_i32 %[bc], %[bc], %[t0]\n\t"
       "s_cmp_gt_u32 %[dist], %[op]\n\t"       // before the start of the output: the caller reports it
       "s_cbranch_scc1 .Lexit3%=\n\t"
-      "s_min_u32 %[t0], %[dist], 64\n\t"
-      "s_cmp_lt_u32 %[t0], %[len]\n\t"
-      "s_cbranch_scc1 .Lslow%=\n\t"           // more than 64 bytes, or a source that overlaps its destination
-      "s_cmpk_gt_u32 %[dist], 0xfc0\n\t"      // RING - 64
+      "s_cmp_lt_u32 %[dist], %[len]\n\t"
+      "s_cbranch_scc1 .Lslow%=\n\t"           // a source that overlaps its destination (len <= 58 here: longer ones never enter)
+      "s_cmpk_gt_u32 %[dist], " INFL_RNEAR "\n\t"  // RING - 64
       "s_cbranch_scc1 .Lfar%=\n\t"
       // ---- the copy in one round by the whole wave: len <= 64, len <= dist (no overlap), dist + len <= RING (the source is in the ring)
       "s_sub_i32 %[t0], %[op], %[dist]\n\t"
+      // (a source that touches the destination of the copy in flight waits for it: [t0, t0 + len) against [pd, s70); pd = -1: none)
+      "s_add_i32 %[t1], %[t0], %[len]\n\t"
+      "s_cmp_gt_u32 %[t1], %[pd]\n\t"
+      "s_cbranch_scc0 .Lfree%=\n\t"
+      "s_cmp_lt_u32 %[t0], s70\n\t"
+      "s_cbranch_scc0 .Lfree%=\n\t"
+      INFL_COMPLETE
+      ".Lfree%=:\n\t"
       "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
       "s_and_saveexec_b64 s[66:67], vcc\n\t"
       "v_add_u32 %[v0], %[t0], %[lane]\n\t"
-      "v_and_b32 %[v0], 0xfff, %[v0]\n\t"
-      "v_add_u32 %[v0], %[ringb], %[v0]\n\t"
+      "v_and_b32 %[v0], " INFL_RMASK ", %[v0]\n\t"
       "ds_read_u8 %[v2], %[v0]\n\t"
       "v_add_u32 %[v1], %[op], %[lane]\n\t"
-      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
-      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "v_and_b32 %[v1], " INFL_RMASK ", %[v1]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "ds_write_b8 %[v1], %[v2]\n\t"
       "s_mov_b64 exec, s[66:67]\n"
       ".Lcopied%=:\n\t"
       "s_add_i32 %[op], %[op], %[len]\n\t"
       "s_cmp_lt_u32 %[op], %[opstop]\n\t"
-      "s_cbranch_scc1 .Ltop%=\n\t"
-      "s_branch .Lout%=\n"
+      "s_cbranch_scc0 .Lout%=\n\t"
+      "s_cmp_gt_u32 %[bc], 31\n\t"
+      "s_cbranch_scc1 .Llook%=\n\t"
+      "s_branch .Lfill%=\n"
       // ---- a source beyond the ring: dist >= RING means every byte of it has been flushed (segments go out as they fill, and the flush is
-      //      fenced), so the wave reads the output it wrote itself; RING - 64 < dist < RING may straddle the ring's edge: the caller's
+      //      fenced), so the wave reads the output it wrote itself; RING - 64 < dist < RING may straddle the ring's edge: the caller's.
+      //      The load is NOT waited for (a round trip to L2 / HBM is worth several symbols): the bytes are written to the ring when a
+      //      later copy reads their destination, when the next such load is issued, or when the loop is left
       ".Lfar%=:\n\t"
-      "s_cmpk_lt_u32 %[dist], 0x1000\n\t"
+      "s_cmpk_lt_u32 %[dist], " INFL_RSIZE "\n\t"
       "s_cbranch_scc1 .Lexit3%=\n\t"
+      "s_cmp_eq_u32 %[pd], -1\n\t"
+      "s_cbranch_scc1 .Lfargo%=\n\t"
+      INFL_COMPLETE
+      ".Lfargo%=:\n\t"
       "s_sub_i32 %[t0], %[op], %[dist]\n\t"
       "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
       "s_and_saveexec_b64 s[66:67], vcc\n\t"
+      "s_mov_b64 s[68:69], exec\n\t"
       "v_add_u32 %[v0], %[t0], %[lane]\n\t"
-      "global_load_ubyte %[v2], %[v0], %[outp] sc1\n\t"
-      "v_add_u32 %[v1], %[op], %[lane]\n\t"
-      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
-      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
-      "s_waitcnt vmcnt(0)\n\t"
-      "ds_write_b8 %[v1], %[v2]\n\t"
+      "global_load_ubyte %[vpd], %[v0], %[outp] sc1\n\t"
+      "v_add_u32 %[vpa], %[op], %[lane]\n\t"
+      "v_and_b32 %[vpa], " INFL_RMASK ", %[vpa]\n\t"
       "s_mov_b64 exec, s[66:67]\n\t"
+      "s_mov_b32 %[pd], %[op]\n\t"
+      "s_add_i32 s70, %[op], %[len]\n\t"
       "s_branch .Lcopied%=\n"
       // ---- dist < len <= 64: the dist bytes in front of op repeat.  Round r copies the bytes [dist (2^r - 1), dist (2^(r+1) - 1)) from
       //      dist 2^r places before them -- a multiple of the period, and everything that far back is written: log2(len / dist) rounds
       ".Lslow%=:\n\t"
-      "s_cmp_gt_u32 %[len], 64\n\t"
-      "s_cbranch_scc1 .Lexit3%=\n\t"
+      "s_cmp_eq_u32 %[pd], -1\n\t"            // (dist < 64: the source may well be what the copy in flight writes)
+      "s_cbranch_scc1 .Lrounds%=\n\t"
+      INFL_COMPLETE
+      ".Lrounds%=:\n\t"
       "s_mov_b32 %[t0], 0\n\t"                // done
       "s_mov_b32 %[t1], %[dist]\n"            // step
       ".Lround%=:\n\t"
@@ -277,11 +320,9 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "s_and_b64 exec, exec, vcc\n\t"
       "v_add_u32 %[v1], %[op], %[lane]\n\t"
       "v_subrev_u32 %[v0], %[t1], %[v1]\n\t"
-      "v_and_b32 %[v0], 0xfff, %[v0]\n\t"
-      "v_add_u32 %[v0], %[ringb], %[v0]\n\t"
+      "v_and_b32 %[v0], " INFL_RMASK ", %[v0]\n\t"
       "ds_read_u8 %[v2], %[v0]\n\t"
-      "v_and_b32 %[v1], 0xfff, %[v1]\n\t"
-      "v_add_u32 %[v1], %[ringb], %[v1]\n\t"
+      "v_and_b32 %[v1], " INFL_RMASK ", %[v1]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "ds_write_b8 %[v1], %[v2]\n\t"
       "s_mov_b64 exec, s[66:67]\n\t"
@@ -299,11 +340,18 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       ".Lexit1%=:\n\t"
       "s_mov_b32 %[code], 1\n"
       ".Lout%=:\n\t"
+      "s_cmp_eq_u32 %[pd], -1\n\t"
+      "s_cbranch_scc1 .Lleave%=\n\t"
+      INFL_COMPLETE
+      ".Lleave%=:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"              // (the dword asked for ahead of time: nobody may find it in flight)
       "s_mov_b64 %[bb], s[60:61]\n\t"
       : [bb] "+s"(bitbuf), [bc] "+s"(bitcnt), [ip] "+s"(ip_lds), [op] "+s"(op), [len] "+s"(len), [dist] "+s"(dist), [code] "=&s"(code), [e] "=&s"(e), [n] "=&s"(n),
-        [t0] "=&s"(t0), [t1] "=&s"(t1), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2)
-      : [iplim] "s"(ip_limit), [opstop] "s"(op_stop), [litb] "s"(lit_base), [distb] "s"(dist_base), [ringb] "s"(ring_base), [lane] "v"(lane), [outp] "s"(outp)
-      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "vcc", "scc", "memory");
+        [t0] "=&s"(t0), [t1] "=&s"(t1), [pd] "=&s"(pd), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [vn] "=&v"(vn), [vpd] "=&v"(vpd), [vpa] "=&v"(vpa)
+      : [iplim] "s"(ip_limit), [opstop] "s"(op_stop), [litb] "s"(lit_base), [distb] "s"(dist_base), [lane] "v"(lane), [outp] "s"(outp)
+      : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "vcc", "scc", "memory");
+#undef INFL_COMPLETE
+#undef INFL_REFILL
   return code;
 }
 
@@ -314,6 +362,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
   typedef __attribute__((address_space(3))) void* lds_ptr;  // LDS byte addresses for the hand-written loop
   const uint32_t win_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.in_win, lit_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.lit32, dist_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.dist32,
                  ring_lds = (uint32_t)(uintptr_t)(lds_ptr)sh.out;
+  if (ring_lds != 0u) fast = 0u;  // (the hand-written loop addresses the ring without a base)
   for (;;) {
     __syncthreads();
     if (lane == 0) sh.block = atomicAdd(counter, 1u);
@@ -436,7 +485,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 if (!(in_pos & 3u)) {
                   uint32_t ip = win_lds + (in_pos - wb);
                   const uint32_t seg_end = (op | (SEG - 1u)) + 1u, tail = out_len - 258u;
-                  stage = fast_symbols(bitbuf, bitcnt, ip, op, len, dist, win_lds + (safe_end - wb), seg_end < tail ? seg_end : tail, lit_lds, dist_lds, ring_lds, (uint32_t)lane, outp);
+                  stage = fast_symbols(bitbuf, bitcnt, ip, op, len, dist, win_lds + (safe_end - wb), seg_end < tail ? seg_end : tail, lit_lds, dist_lds, (uint32_t)lane, outp);
                   in_pos = wb + (ip - win_lds);
                 }
               }
@@ -538,6 +587,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
           if (l > bits) continue;
           uint32_t* tab = is_dist ? sh.dist32 : sh.lit32;
           const uint32_t entry = (is_dist ? dist_entry(s - nlit, l) : lit_entry(s, l)) | (l << 12);  // (bits 12-15: the code's own length, which pairing leaves alone)
+          // end of block, undefined symbols and lengths that can pass 64 bytes (symbols 275 ..: 51 + 15) keep EMPTY entries: both loops then
+          // decode them canonically (slow_decode), and the hand-written loop needs no test for them
+          if ((entry & (F_EOB | F_BAD)) || (!is_dist && s >= 275u)) continue;
           for (uint32_t i = rev_bits(sh.code[s], (int)l); i < (1u << bits); i += 1u << l) tab[i] = entry;
         }
         __syncthreads();
@@ -561,7 +613,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
             else for (uint32_t q = i; q < upto; ++q) outp[q] = sh.out[q & RING_MASK];
           }
           flushed = upto;
-          __threadfence();  // (far matches read these bytes back)
+          // Far matches read these bytes back -- THIS wave does, through the L2 its own stores went to (loads marked sc1: past the CU's
+          // L1), so all it takes is that the stores have completed.  __threadfence() here was an agent-scope release: buffer_wbl2 +
+          // buffer_inv, a write-back and an invalidation of the XCD's whole L2 by every wave at every segment (~ 200 000 per launch) --
+          // every copy from the flushed output then missed the L2 it had just been written to
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
       if (ev == EV_DONE) break;
@@ -597,7 +653,7 @@ int inflate_blocks_device(trgt_hip_ctx* c, int64_t n, const uint8_t* src, uint64
   else if (preserve_dst) TRGT_HIP_TRY(c, hipMemcpyAsync(d_dst, dst, (size_t)dst_bytes, hipMemcpyHostToDevice, c->stream));  // (the bytes between the blocks come back as they were)
   TRGT_HIP_TRY(c, hipMemcpyAsync(d_desc, descs, (size_t)n * sizeof(infl::BlockDesc), hipMemcpyHostToDevice, c->stream));
   TRGT_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 16, c->stream));
-  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 15);
+  const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)c->num_cus * 16);
   hipLaunchKernelGGL(infl::inflate_blocks_kernel, dim3(grid), dim3(64), 0, c->stream, (const uint8_t*)d_src, (const infl::BlockDesc*)d_desc, (uint32_t)n, (uint8_t*)d_dst,
                      (uint8_t*)d_status, (unsigned int*)d_counter, inflate_fast_flag());
   TRGT_HIP_TRY(c, hipGetLastError());

@@ -557,7 +557,7 @@ struct trgt_ingest {
   std::vector<std::unique_ptr<Bgzf>> idle_readers;
   // trgt_ingest_params.ingest_device (ABI 10): slots of device state (a stream, device buffers, pinned staging) -- a call takes a free one, so
   // calls from several host threads overlap their file reads, uploads, kernels and downloads -- and the pool the batches' slabs return to
-  static constexpr int DEV_SLOTS = 3;
+  static constexpr int DEV_SLOTS = 6;
   std::mutex dev_mu; std::condition_variable dev_cv;
   struct DevSlot { trgt::ingd::Slot* s = nullptr; bool busy = false; };
   DevSlot dev_slots[DEV_SLOTS]; int dev_device = -1;

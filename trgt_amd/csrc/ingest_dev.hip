@@ -799,7 +799,7 @@ int slot_run(Slot* s, const RunIn& in, SlabPool& pool, RunOut& out, std::string&
   ING_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(Counters), st));
   ING_TRY(hipMemsetAsync(s->d_status.p, 0, (size_t)nb + 64, st));
   // ---- inflate + CRC-32
-  const unsigned waves_per_cu = in.waves_per_cu > 0 ? (unsigned)std::min(in.waves_per_cu, 15) : 12u;
+  const unsigned waves_per_cu = in.waves_per_cu > 0 ? (unsigned)std::min(in.waves_per_cu, 16) : 12u;
   int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   trgt::inflate_launch((void*)st, (const uint8_t*)s->d_src.p, (const infl::BlockDesc*)s->d_blocks.p, nb, (uint8_t*)s->d_infl.p, (uint8_t*)s->d_status.p, (unsigned*)s->d_counter.p,
                        (unsigned)cus * waves_per_cu);
