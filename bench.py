@@ -340,7 +340,8 @@ def run_e2e(args, env):
     from trgt_amd import _lib, ingest, locus, shard, synth_bam, writers
     cores = os.cpu_count() or 8
     n, chunk = args.e2e_loci, 1000
-    INGEST_CALLERS = 3  # (the slots of device state a reader has: file read, upload, kernels and download of consecutive chunks overlap)
+    INGEST_CALLERS = int(os.environ.get("BENCH_INGEST_CALLERS", "3"))  # (a reader has six slots of device state: file read, upload, kernels and download of consecutive chunks overlap)
+    INFLATE_WAVES = int(os.environ.get("BENCH_INFLATE_WAVES", "0"))  # (0: the library's default)
     d = tempfile.mkdtemp(prefix="trgt_e2e_")
     try:
         t0 = time.perf_counter()
@@ -352,7 +353,7 @@ def run_e2e(args, env):
         dev = env["local_rank"]
         ing_threads = min(32, cores)  # host path, measured (tools/ingest_scaling.py): 1.3 k loci/s with 1 thread, 8.4 k with 8, 16 k with 16, 20 k with 32, 14 k with 64 -- under the box's CFS quota of 16 CPUs (cpu_quota())
         ing_host = lambda a, th=ing_threads: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=th, keep_bam4=1)
-        ing_dev = lambda a: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=8, ingest_device=dev)
+        ing_dev = lambda a: rd.batch(ds["bed"], first_locus=a, max_loci=chunk, keep_native=True, copy=False, read_names=False, threads=8, ingest_device=dev, inflate_waves_per_cu=INFLATE_WAVES)
 
         def ordered(fn, callers, firsts=None):
             """fn(first) over the chunks by `callers` threads, results in chunk order (a generator: chunk i is handed out as soon as it and all

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64) deflate_blocks_kernel(const uint8_t* __res
       uint32_t* const ow = reinterpret_cast<uint32_t*>(out);
       const uint32_t n_ow = (out_bytes + 3u) / 4u + 1u;  // (the caller leaves room for the word the last OR may touch: dst_cap + 8 bytes are its)
       for (uint32_t i = (uint32_t)lane; i < n_ow; i += 64) ow[i] = 0u;
-      __threadfence();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zeros are at the L2 the atomics below work in: one wave, no other reader -- not an agent-scope fence, which writes back and invalidates the XCD's L2)
       __syncthreads();
       if (lane == 0) atomicOr(ow, 3u);  // BFINAL = 1, BTYPE = 01 (fixed Huffman codes)
       const uint32_t n_words = (my_bits + 31u) / 32u;
