@@ -166,8 +166,12 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
     if (lane == 0) j = atomicAdd(a.counter, 1u);
     j = (uint32_t)rfl_i((int)j);
     if (j >= n_jobs) break;
-    const JobDev job = a.jobs[j];
-    const int plen = rfl_i((int)job.pat_len), tlen = rfl_i((int)job.txt_len);
+    // (the job's fields as scalars: held as a struct its twelve dwords are loaded per lane, live across the level loop for the epilogue and
+    //  spilled there -- with the per-lane counters below that was the kernel's 88 bytes of scratch per lane, half of its HBM traffic)
+    const JobDev* const jp = a.jobs + j;
+    const int plen = rfl_i((int)jp->pat_len), tlen = rfl_i((int)jp->txt_len);
+    const uint64_t pat_off = ((uint64_t)(uint32_t)rfl_i((int)(jp->pat_off >> 32)) << 32) | (uint32_t)rfl_i((int)(uint32_t)jp->pat_off);
+    const uint64_t txt_off = ((uint64_t)(uint32_t)rfl_i((int)(jp->txt_off >> 32)) << 32) | (uint32_t)rfl_i((int)(uint32_t)jp->txt_off);
     if (plen + tlen + 1 <= a.diag_lo || plen + tlen + 1 > a.diag_hi) continue;  // another launch's job
     int keep = 0, score_out = INT32_MIN, bound_out = -1;
     uint32_t band = 0;  // (kept jobs: bit 31 | penalty << 16 | biased end diagonal when the run completed)
@@ -176,9 +180,9 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
     if (fits) {
       // ---- the two sequences as sliding windows (one wave: its LDS operations execute in order, no barrier needed)
       if (lane == 0) Pw[0] = NULL_WIN;
-      stage(a.pat_base + job.pat_off, plen, Pw + 1, PWN - 1, PAT_PAD, dirty);
+      stage(a.pat_base + pat_off, plen, Pw + 1, PWN - 1, PAT_PAD, dirty);
       for (int i = lane; i < plen + 1; i += 64) Tw[i] = TXT_PAD;  // text positions < 0: only NULL cells look there
-      stage(a.txt_base + job.txt_off, tlen, Tw + plen + 1, TWN - (plen + 1), TXT_PAD, dirty);
+      stage(a.txt_base + txt_off, tlen, Tw + plen + 1, TWN - (plen + 1), TXT_PAD, dirty);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     const bool is_dirty = __builtin_amdgcn_ballot_w64(dirty != 0u) != 0ull;
@@ -527,14 +531,14 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
       }
     }
     if (lane == 0) {
-      const uint32_t o = job.out_index;
+      const uint32_t o = jp->out_index;
       if (a.score) a.score[o] = score_out;
       if (a.bound) a.bound[o] = bound_out;
       if (a.keep) a.keep[o] = (uint8_t)keep;
       if (a.band) a.band[o] = band;
-      if (keep && a.keep_jobs) { JobDev kj = job; kj.pad = (band >> 31) ? band : 0u; a.keep_jobs[atomicAdd(a.keep_count, 1u)] = kj; }
-      kept_acc += (unsigned long long)keep;
+      if (keep && a.keep_jobs) { JobDev kj = *jp; kj.pad = (band >> 31) ? band : 0u; a.keep_jobs[atomicAdd(a.keep_count, 1u)] = kj; }
     }
+    kept_acc += (unsigned long long)keep;  // (uniform, like cells_acc: a scalar)
   }
   if (lane == 0 && a.cells_out && cells_acc) atomicAdd(a.cells_out, cells_acc);
   if (lane == 0 && a.cells_out && kept_acc) atomicAdd(a.cells_out + 1, kept_acc);  // [1]: alignments kept
