@@ -185,7 +185,8 @@ def test_register_fill_variants_agree(oracle, hmm):
     # (round 5: by default the fill runs with one lane per motif position, hmm_ppl.hpp, in front of those kernels; TRGT_HMM_NO_PPL=1 takes
     #  the fills of hmm_viterbi_kernel, which the other switches select among)
     for env in (dict(TRGT_HMM_NO_PPL=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_FOUR_ROUNDS=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_LDS_FILL=1),
-                dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_LDS_FILL=1, TRGT_HMM_FOUR_ROUNDS=1)):
+                dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_LDS_FILL=1, TRGT_HMM_FOUR_ROUNDS=1),
+                dict(TRGT_HMM_PPL_WIDE=1)):  # (round 6: the position-per-lane fill's rows of one byte per state; default: one byte per lane)
         ctx = _lib.context_with_env(**env)
         try:
             a = hmm.hmm_batch(batch, ctx=ctx)
@@ -215,7 +216,8 @@ def test_position_per_lane_fill_against_the_state_fill_on_long_alleles(oracle, h
     base = _same(oracle, hmm, sets, jobs)
     assert max(len(a) for _, a in jobs) >= 1536 and min(len(a) for _, a in jobs) >= 400
     batch = hmm.pack_hmm_batch(sets, jobs)
-    for env in (dict(TRGT_HMM_NO_PPL=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_NO_LONG_TB=1), dict(TRGT_HMM_NO_LONG_TB=1)):
+    for env in (dict(TRGT_HMM_NO_PPL=1), dict(TRGT_HMM_NO_PPL=1, TRGT_HMM_NO_LONG_TB=1), dict(TRGT_HMM_NO_LONG_TB=1),
+                dict(TRGT_HMM_PPL_WIDE=1), dict(TRGT_HMM_PPL_WIDE=1, TRGT_HMM_NO_LONG_TB=1)):
         ctx = _lib.context_with_env(**env)
         try:
             a = hmm.hmm_batch(batch, ctx=ctx)

@@ -466,7 +466,7 @@ def test_flank_launch_variants_agree(oracle, mods, monkeypatch):
                      # zero arena, the round-4 HMM fills, the position-per-lane fills of a class one after the other, other claim sizes and
                      # the 128-diagonal tier of the lean kernel
                      ("TRGT_BAND_THREADS", "128"), ("TRGT_BAND_THREADS", "256"), ("TRGT_NO_ZERO_ARENA", "1"), ("TRGT_HMM_NO_PPL", "1"),
-                     ("TRGT_HMM_PPL_SERIAL", "1"), ("TRGT_HMM_PPL_PER_CLASS", "1"), ("TRGT_LEAN_CHUNK", "1"), ("TRGT_LEAN_CHUNK", "16"), ("TRGT_WFA_LEAN_MID_TIER", "1")):
+                     ("TRGT_HMM_PPL_SERIAL", "1"), ("TRGT_HMM_PPL_PER_CLASS", "1"), ("TRGT_HMM_PPL_WIDE", "1"), ("TRGT_LEAN_CHUNK", "1"), ("TRGT_LEAN_CHUNK", "16"), ("TRGT_WFA_LEAN_MID_TIER", "1")):
         from trgt_amd import _lib
         vctx = _lib.context_with_env(**{env: val})
         try:

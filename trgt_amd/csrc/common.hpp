@@ -66,6 +66,7 @@ struct trgt_knobs {
   int lean_chunk = 0;          // TRGT_LEAN_CHUNK: alignments per claim of the lean kernels' job counter (0: 2, 4 in a pool; edit distances always 8)
   bool no_zero_arena = false;  // TRGT_NO_ZERO_ARENA: counters and small lists cleared by a hipMemsetAsync each (round 4) instead of one arena clear per call
   bool hmm_ppl_per_class = false;  // TRGT_HMM_PPL_PER_CLASS: the position-per-lane fills of a locus batch launched class by class (until late in round 5) instead of once per group width over all classes
+  bool hmm_ppl_wide = false;   // TRGT_HMM_PPL_WIDE: the position-per-lane fill writes the round-5 rows of one byte per state (default: one byte per lane)
   bool hmm_ppl_serial = false; // TRGT_HMM_PPL_SERIAL: the position-per-lane fills of one class one after the other on the class's stream (no side streams)
   bool lean_one_tier = false;  // TRGT_WFA_LEAN_ONE_TIER: no second tier (256 diagonals) between the register-resident kernel and the generic one
   bool no_lds_wfa = true;    // TRGT_WFA_LDS=1 turns the LDS-arena variant of the BiWFA kernel on (in front of the HBM-arena one).  Off by default:

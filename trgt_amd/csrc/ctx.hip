@@ -101,7 +101,7 @@ int trgt_hip_create(int device, trgt_hip_ctx** out) {
     k.no_filter = flag("TRGT_WFA_NO_FILTER"); k.one_stream = DEV_FLAG("TRGT_FLANK_ONE_STREAM"); k.host_genotyper = flag("TRGT_HOST_GENOTYPER"); k.host_hmm_lists = DEV_FLAG("TRGT_HOST_HMM_LISTS"); k.no_early = flag("TRGT_WFA_NO_EARLY"); k.stage_lock = flag("TRGT_STAGE_LOCK"); k.no_long_filter = flag("TRGT_NO_LONG_FILTER"); k.no_long_window = DEV_FLAG("TRGT_NO_LONG_WINDOW"); k.filter_force = DEV_NUM("TRGT_FILTER_FORCE", 0); k.filter_one_launch = DEV_FLAG("TRGT_FILTER_ONE_LAUNCH"); k.filter_serial = DEV_FLAG("TRGT_FILTER_SERIAL"); k.filter_side = DEV_FLAG("TRGT_FILTER_SIDE"); k.wfa_no_stage = DEV_FLAG("TRGT_WFA_NO_STAGE"); k.wfa_no_wave_variant = DEV_FLAG("TRGT_WFA_NO_WAVE_VARIANT"); k.hmm_resolve_one_wg = DEV_FLAG("TRGT_HMM_RESOLVE_ONE_WG"); k.debug = flag("TRGT_WFA_DEBUG");
     k.timeline = flag("TRGT_TIMELINE");
     k.host_repair = flag("TRGT_HOST_REPAIR"); k.host_cluster = flag("TRGT_HOST_CLUSTER"); k.cluster_arena_kb = num("TRGT_CLUSTER_ARENA_KB", 0); k.hmm_lds_fill = DEV_FLAG("TRGT_HMM_LDS_FILL"); k.hmm_four_rounds = DEV_FLAG("TRGT_HMM_FOUR_ROUNDS"); k.hmm_no_ppl = flag("TRGT_HMM_NO_PPL"); k.hmm_long_wgs = std::max(1, std::min(DEV_NUM("TRGT_HMM_LONG_WGS", k.hmm_long_wgs), 16)); k.hmm_no_long_tb = flag("TRGT_HMM_NO_LONG_TB"); k.hmm_no_dedupe = flag("TRGT_HMM_NO_DEDUPE"); k.repair_max_seg = num("TRGT_REPAIR_MAX_SEG", k.repair_max_seg); k.split_hmm = DEV_FLAG("TRGT_SPLIT_HMM"); k.repair_blocks = DEV_NUM("TRGT_REPAIR_BLOCKS", k.repair_blocks);
-    k.no_lean = flag("TRGT_WFA_NO_LEAN"); k.lean_one_tier = DEV_FLAG("TRGT_WFA_LEAN_ONE_TIER"); k.lean_mid_tier = DEV_FLAG("TRGT_WFA_LEAN_MID_TIER"); k.lean_chunk = DEV_NUM("TRGT_LEAN_CHUNK", 0); k.no_zero_arena = flag("TRGT_NO_ZERO_ARENA"); k.hmm_ppl_serial = DEV_FLAG("TRGT_HMM_PPL_SERIAL"); k.hmm_ppl_per_class = DEV_FLAG("TRGT_HMM_PPL_PER_CLASS");
+    k.no_lean = flag("TRGT_WFA_NO_LEAN"); k.lean_one_tier = DEV_FLAG("TRGT_WFA_LEAN_ONE_TIER"); k.lean_mid_tier = DEV_FLAG("TRGT_WFA_LEAN_MID_TIER"); k.lean_chunk = DEV_NUM("TRGT_LEAN_CHUNK", 0); k.no_zero_arena = flag("TRGT_NO_ZERO_ARENA"); k.hmm_ppl_serial = DEV_FLAG("TRGT_HMM_PPL_SERIAL"); k.hmm_ppl_wide = DEV_FLAG("TRGT_HMM_PPL_WIDE"); k.hmm_ppl_per_class = DEV_FLAG("TRGT_HMM_PPL_PER_CLASS");
     k.no_lds_wfa = !DEV_FLAG("TRGT_WFA_LDS"); k.lds_wfa_kb = DEV_NUM("TRGT_WFA_LDS_KB", k.lds_wfa_kb); k.lds_wfa_seq = DEV_NUM("TRGT_WFA_LDS_SEQ", k.lds_wfa_seq);
 #ifdef TRGT_DEV_BUILD
     // switches that CHANGE results exist only in `make DEV=1` builds (tools/unpinned_sensitivity.py builds one for itself)

@@ -364,7 +364,7 @@ constexpr int HMM_STAGE_BYTES = 1024;  // LDS staging window for back-pointer co
 // ... models of several waves (rows of 80 to 320 bytes) stage 16 columns at a time: 1 KB held five columns of a 192-state model, and every
 // chunk costs a global round trip and two barriers
 __host__ __device__ constexpr int hmm_stage_bytes(int spad) { return spad > 64 ? (16 * spad > HMM_STAGE_BYTES ? 16 * spad : HMM_STAGE_BYTES) : HMM_STAGE_BYTES; }
-constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 8 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4], block, flags, bp column
+constexpr int HMM_LDS_PER_STATE = 16 + 16 + 40 + 4 + 16 + 2 + 1 + 1;  // two score columns, lp[2], em[5], info, inst[4] (32-bit entries), block, flags, bp column
 
 __device__ __forceinline__ int hmm_code(const uint8_t* __restrict__ seq, int i, int L) {
   // '#'+seq+'#' with encode_base (hmm_model.rs:243-252) after replace_invalid_bases(seq, ATCG) (utils.rs:29-42)
@@ -427,6 +427,36 @@ __device__ __forceinline__ double bperm_f64(int addr, double x) {
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
+// ---- the packed back-pointer rows of hmm_fill_ppl_kernel<G, true> (hmm_ppl.hpp): one byte per LANE (motif position) and column.
+__host__ __device__ inline int hmm_ppl_group(uint32_t positions) { return positions == 0 || positions > 64 ? 0 : positions <= 8 ? 8 : positions <= 16 ? 16 : positions <= 32 ? 32 : 64; }
+// Where the back-pointer of state `st` lies in such a row: lane | shift << 6 | mask << 9 (mask 0: a state whose back-pointer is a constant 0 --
+// the end state -- or is never read; the run end's block index is spread over the lanes 1-3: hmm_bp_run_end).  blocks: [4][nb] start state,
+// end state, motif length, first position (= lane) of every block; blk: the state's block (-1: outside the blocks).
+__device__ __forceinline__ uint32_t hmm_bp_loc(int st, int nb, int blk, const uint32_t* blocks) {
+  if (st == 1) return 0u | (6u << 6) | (3u << 9);               // run start: lane 0, bits 6-7
+  if (blk < 0) return 0u;
+  const int ms = (int)blocks[blk], n = (int)blocks[2 * nb + blk], off = st - ms;
+  const uint32_t pos0 = blocks[3 * nb + blk];
+  if (off == 0) return pos0 | (5u << 6) | (1u << 9);            // block start: bit 5 of the block's first lane
+  if (blk == nb - 1) return off == 1 ? (pos0 | (0u << 6) | (3u << 9)) : (pos0 | (3u << 6) | (3u << 9));  // skip state | skip block's end
+  if (off <= n) return (pos0 + (uint32_t)(off - 1)) | (0u << 6) | (3u << 9);              // match state k
+  if (off <= 2 * n) return (pos0 + (uint32_t)(off - n - 1)) | (2u << 6) | (1u << 9);      // insertion state k
+  return (pos0 + (uint32_t)(off - 2 * n - 1)) | (3u << 6) | (3u << 9);                    // deletion state k / block end (k = n - 1)
+}
+__device__ __forceinline__ uint32_t hmm_bp_unpack(uint32_t byte, uint32_t loc) { return (byte >> ((loc >> 6) & 7u)) & (loc >> 9); }
+__device__ __forceinline__ uint32_t hmm_bp_run_end(uint32_t row_word) { return ((row_word >> 14) & 3u) | ((row_word >> 20) & 0xCu) | ((row_word >> 26) & 0x30u); }
+// loc of the end state of block b (the deletion slot of its last position; the skip block has one position)
+__device__ __forceinline__ uint32_t hmm_bp_loc_block_end(int b, int nb, const uint32_t* blocks) {
+  const uint32_t n = blocks[2 * nb + b];
+  return (blocks[3 * nb + b] + (n ? n - 1u : 0u)) | (3u << 6) | (3u << 9);
+}
+// predecessor entries of the trace-backs: predecessor state | its "emits" bit << 15 | its hmm_bp_loc << 16 (what the chase needs to know
+// about a state is there when it arrives in it: one LDS round trip per step)
+__device__ __forceinline__ uint32_t hmm_pred_entry(uint32_t pr, int S, int nb, const uint8_t* g_flags, const int16_t* g_block, const uint32_t* g_blocks) {
+  if (pr >= (uint32_t)S) return pr;
+  return pr | ((uint32_t)(g_flags[pr] & 1) << 15) | (hmm_bp_loc((int)pr, nb, (int)g_block[pr], g_blocks) << 16);
+}
+
 // ONE_WAVE (models of at most 64 states: one state per lane of ONE wave, or two alleles of at most 32 states in its halves): the score
 // columns of the fill live in REGISTERS -- a state's predecessors are fetched from their lanes (ds_bpermute: one LDS-crossbar round per
 // pass, nothing written) instead of through two LDS arrays (a write, a fence and a read per pass), and what the run-end lane worked out
@@ -445,8 +475,9 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   if (n_jobs_dev) n_launch_jobs = *n_jobs_dev;  // a job list resolved on the device (hmm_resolve_kernel): the grid covers all candidates
   const bool four_rounds = (lds_per_job >> 31) != 0u;  // (TRGT_HMM_FOUR_ROUNDS, see the register fill)
   const bool ppl_filled = ((lds_per_job >> 30) & 1u) != 0u;
+  const bool ppl_packed = ((lds_per_job >> 23) & 1u) != 0u;  // ... in rows of one byte per lane (hmm_fill_ppl_kernel<G, true>)
   const int long_min = ((lds_per_job >> 24) & 0x3Fu) ? (int)((lds_per_job >> 24) & 0x3Fu) * 256 : HMM_LONG_MIN;  // (by the size of the class, hmm_long_min)  // the back-pointers of sets with ppl_lanes are there already (hmm_fill_ppl_kernel ran in front)
-  lds_per_job &= 0x00FFFFFFu;
+  lds_per_job &= 0x007FFFFFu;
   const int grp = SUB == 32 ? (int)(threadIdx.x >> 5) : 0;
   const int tid = SUB == 32 ? (int)(threadIdx.x & 31) : (int)threadIdx.x, nthr = SUB == 32 ? 32 : (int)blockDim.x;
   const int sync_n = SUB == 32 ? 64 : (int)blockDim.x;  // see hmm_sync: a single wave needs no barrier
@@ -476,13 +507,13 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   int* tb = reinterpret_cast<int*>(lds);  // traceback state shared between the walker and the stagers
   int &tb_state = tb[0], &tb_idx = tb[1], &tb_done = tb[2], &tb_npath = tb[3], &tb_nvisit = tb[4], &tb_edit = tb[5],
       &tb_ref = tb[6], &tb_next = tb[7], &tb_vb1 = tb[8];
-  double* sc0 = reinterpret_cast<double*>(lds + 64);
+  uint32_t* l_inst = reinterpret_cast<uint32_t*>(lds + 64);           // [S][4] hmm_pred_entry (predecessor b of state s at 4 s + b: 16 bytes per state, one read)
+  double* sc0 = reinterpret_cast<double*>(l_inst + 4 * S);
   double* sc1 = sc0 + S;
   double* l_lp = sc1 + S;                                             // [2][S] ln transition probabilities of predecessors 0 and 1
   double* l_em = l_lp + 2 * S;                                        // [5][S] ln emission probabilities by symbol code: one LDS read per column instead of a select tree
   uint32_t* l_info = reinterpret_cast<uint32_t*>(l_em + 5 * S);       // [S] what the traceback needs to know about a state, in one word
-  uint16_t* l_inst = reinterpret_cast<uint16_t*>(l_info + S);         // [S][4] (predecessor b of state s at 4 s + b: no multiply in the trace-back)
-  int16_t* l_block = reinterpret_cast<int16_t*>(l_inst + 4 * S);     // [S]
+  int16_t* l_block = reinterpret_cast<int16_t*>(l_info + S);         // [S]
   uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_block + S);        // [S]
   uint8_t* l_bpcol = l_flags + S;                                     // [S] back-pointers of states evaluated by another lane
   uint32_t* l_blocks = reinterpret_cast<uint32_t*>(lds + 64 + (((size_t)HMM_LDS_PER_STATE * S + 15) & ~(size_t)15));  // [4][nb]
@@ -505,7 +536,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   for (int i = tid; i < n_motifs; i += nthr) l_cnt[i] = 0;
   const uint8_t* const motif_bytes = l_mot;
   // (bit 15 of a predecessor entry: that state emits a base -- the trace-back then knows it on arrival, without a look-up of its own)
-  for (int i = tid; i < 4 * S; i += nthr) { const uint16_t pr = g_inst[i]; l_inst[4 * (i % S) + i / S] = (uint16_t)(pr | ((pr < S ? (uint16_t)(model[set.off_flags + pr] & 1) : (uint16_t)0) << 15)); }
+  for (int i = tid; i < 4 * S; i += nthr) l_inst[4 * (i % S) + i / S] = hmm_pred_entry(g_inst[i], S, nb, model + set.off_flags, g_block, g_blocks);
   for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
   for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
@@ -1076,7 +1107,13 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   //      90 instructions per step: 750 cycles, a third of the kernel.)  What a step needs from its neighbours is little: the state
   //      walked just before it (the implied leading deletions of a block start) and the column of the last block end before it (the
   //      bases of the visit a block start closes): a lane shift and a ballot.
-  const int cols_per_chunk = max(1, hmm_stage_bytes(Spad) / Spad);
+  // rows of the back-pointer workspace: one byte per state (this kernel's own fill, the round-5 layout of the position-per-lane fill) or
+  // one byte per lane of the job's group (hmm_fill_ppl_kernel<G, true>)
+  const bool packed = ppl_filled && ppl_packed && set.ppl_lanes != 0u;
+  const int rstride = packed ? hmm_ppl_group(set.ppl_lanes) : Spad;
+  const int cols_per_chunk = packed ? hmm_stage_bytes(Spad) / rstride - 2 : max(1, hmm_stage_bytes(Spad) / Spad);
+  int& tb_loc = tb[11];  // hmm_bp_loc of tb_state
+  if (tid == 0) tb_loc = 0;  // (the end state: a constant 0)
   uint16_t* pbuf = path ? path + job.path_off : nullptr;
   uint32_t* const g_vis = visit_ws + job.visit_off;  // visits HMM_VIS_LDS, HMM_VIS_LDS + 1, ... at their own index
   const int pcap = (int)job.path_cap;
@@ -1087,11 +1124,11 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const unsigned long long below = gmask & ((1ull << hwlane) - 1ull);
   while (true) {
     if (tb_done) break;
-    const int c1 = tb_idx + 1, c0 = max(0, c1 - cols_per_chunk);
+    const int c1 = tb_idx + 1, c0 = packed ? (max(0, c1 - cols_per_chunk) & ~1) : max(0, c1 - cols_per_chunk);  // (rows of 8 bytes: an even column starts a 16-byte piece)
     {
-      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * Spad);
+      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * rstride);
       uint4* dst = reinterpret_cast<uint4*>(l_stage);
-      const int n16 = (c1 - c0) * Spad / 16;
+      const int n16 = ((c1 - c0) * rstride + 15) / 16;
       for (int i = tid; i < n16; i += nthr) dst[i] = src[i];
       // ... and the symbol codes of the same columns, plus those a motif copy starting in the last of them reaches into
       win0 = c0;
@@ -1101,21 +1138,25 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
     for (;;) {
       if (tid == 0) {  // ---- the chase
         int state = tb_state, idx = tb_idx, n = 0;
-        int row = (idx - c0) * Spad;  // offset of column idx in the staged chunk
+        int row = (idx - c0) * rstride;  // offset of column idx in the staged chunk
         int emits = (int)((l_info[state] >> 3) & 1u);
+        uint32_t loc = (uint32_t)tb_loc;
         while (state != 0 && idx >= c0 && n < HMM_REC) {
           l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
-          const int b = l_stage[row + state];
-          const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);  // (4-byte aligned: S may be odd)
-          const uint2 pred4 = make_uint2(pin[0], pin[1]);  // all four predecessors: no second round trip behind b
-          const uint32_t pw = (b & 2) ? pred4.y : pred4.x;
-          uint32_t pe = (b & 1) ? pw >> 16 : pw & 0xFFFFu;  // predecessor | its "emits" bit << 15
-          if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + b]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15); }  // the run end: from a block end
-          if (emits) { --idx; row -= Spad; }
-          emits = (int)(pe >> 15);
+          const uint4 pred4 = *reinterpret_cast<const uint4*>(l_inst + 4 * state);  // all four predecessors: no second round trip behind b
+          int b;
+          if (packed) {
+            b = (int)hmm_bp_unpack(l_stage[row + (int)(loc & 63u)], loc);
+            if (state == S - 2) b = (int)hmm_bp_run_end(*reinterpret_cast<const uint32_t*>(l_stage + row));
+          } else b = l_stage[row + state];
+          uint32_t pe = (b & 2) ? ((b & 1) ? pred4.w : pred4.z) : ((b & 1) ? pred4.y : pred4.x);  // predecessor | its "emits" bit << 15 | its hmm_bp_loc << 16
+          if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + b]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15) | (hmm_bp_loc_block_end(b, nb, l_blocks) << 16); }  // the run end: from a block end
+          if (emits) { --idx; row -= rstride; }
+          emits = (int)((pe >> 15) & 1u);
           state = (int)(pe & 0x7FFFu);
+          loc = pe >> 16;
         }
-        tb_state = state; tb_idx = idx; tb_nrec = n;
+        tb_state = state; tb_idx = idx; tb_nrec = n; tb_loc = (int)loc;
         tb_more = state == 0 ? 2 : (idx >= c0 ? 1 : 0);
       }
       hmm_sync(sync_n);
@@ -1259,7 +1300,9 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model, const uint8_t* __restrict__ seq_blob,
     const uint8_t* __restrict__ bp_ws, uint32_t* __restrict__ visit_ws, uint16_t* __restrict__ path, uint32_t* __restrict__ path_len,
     int32_t* __restrict__ spans3, uint32_t* __restrict__ n_spans, uint32_t* __restrict__ counts, double* __restrict__ purity,
-    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, const uint32_t* __restrict__ long_list, const int phase, const int G) {
+    int32_t* __restrict__ edit_out, int32_t* __restrict__ maxd_out, const uint32_t* __restrict__ long_list, const int phase_arg, const int G) {
+  const int phase = phase_arg & 0xFF;
+  const bool ppl_packed = ((phase_arg >> 8) & 1) != 0;  // the position-per-lane fill wrote rows of one byte per lane (hmm_fill_ppl_kernel<G, true>)
   // phase 0: the whole trace-back by one workgroup per allele.  Phases 1 / 2 / 3 are the same code as three launches with G workgroups
   // per allele in (A) and (C) -- an allele's chunks are independent there, and a class has few long alleles for 256 CUs: 1: (A) with
   // the maps in the job's workspace; 2: (B) by one workgroup; 3: (C), the totals in the four words in front of the maps, and the
@@ -1279,14 +1322,14 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     const int C = HMM_LONG_CHUNK, n_chunks = (L + C - 1) / C;
     // ---- LDS: totals | tables | per wave: staged back-pointer columns, the steps of a round
     int* tot = reinterpret_cast<int*>(lds_long);  // [0] edit, [1] ref, [2] np, [3] nv
-    uint16_t* l_inst = reinterpret_cast<uint16_t*>(lds_long + 64);                       // [S][4] predecessor | emits << 15
-    uint32_t* l_info = reinterpret_cast<uint32_t*>(l_inst + 4 * S);                      // [S]
+    uint32_t* l_inst = reinterpret_cast<uint32_t*>(lds_long + 64);                       // [S][4] hmm_pred_entry
+    uint32_t* l_info = l_inst + 4 * S;                                                   // [S]
     uint32_t* l_blocks = l_info + S;                                                     // [4][nb]
     uint32_t* l_cnt = l_blocks + 4 * nb;                                                 // [nb]
     uint8_t* l_flags = reinterpret_cast<uint8_t*>(l_cnt + nb);                           // [S]
     const int mot_bytes = (S - 7 - n_motifs) / 3;
     uint8_t* l_mot = l_flags + ((S + 3) & ~3);
-    unsigned char* wave_base = lds_long + ((64 + (size_t)8 * S + 4 * S + 16 * nb + 4 * nb + ((S + 3) & ~3) + ((mot_bytes + 15) & ~15) + 15) & ~(size_t)15);
+    unsigned char* wave_base = lds_long + ((64 + (size_t)16 * S + 4 * S + 16 * nb + 4 * nb + ((S + 3) & ~3) + ((mot_bytes + 15) & ~15) + 15) & ~(size_t)15);
     uint8_t* l_stage = wave_base + (size_t)wave * (HMM_LONG_STG + 512);
     uint32_t* const l_map = reinterpret_cast<uint32_t*>(wave_base + (size_t)NW * (HMM_LONG_STG + 512));
     const bool map_lds = phase == 0 && ((size_t)3 * S + 8) * (size_t)n_chunks * 4 <= (size_t)HMM_LONG_MAP_LDS;
@@ -1296,7 +1339,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     const int16_t* g_block = reinterpret_cast<const int16_t*>(model + set.off_block);
     const uint32_t* g_blocks = reinterpret_cast<const uint32_t*>(model + set.off_blocks);
     const uint8_t* g_motifs = model + set.off_motifs;
-    for (int i = tid; i < 4 * S; i += HMM_LONG_THREADS) { const uint16_t pr = g_inst[i]; l_inst[4 * (i % S) + i / S] = (uint16_t)(pr | ((pr < S ? (uint16_t)(model[set.off_flags + pr] & 1) : (uint16_t)0) << 15)); }
+    for (int i = tid; i < 4 * S; i += HMM_LONG_THREADS) l_inst[4 * (i % S) + i / S] = hmm_pred_entry(g_inst[i], S, nb, model + set.off_flags, g_block, g_blocks);
     for (int i = tid; i < S; i += HMM_LONG_THREADS) l_flags[i] = model[set.off_flags + i];
     for (int i = tid; i < 4 * nb; i += HMM_LONG_THREADS) l_blocks[i] = g_blocks[i];
     for (int i = tid; i < mot_bytes; i += HMM_LONG_THREADS) l_mot[i] = g_motifs[i];
@@ -1326,20 +1369,27 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
     uint32_t* const g_vis = visit_ws + job.visit_off;
     uint32_t* const g_map = map_lds ? l_map : visit_ws + job.map_off;                 // [n_chunks][S] HmmChunkMap
     HmmChunkRec* const g_crec = reinterpret_cast<HmmChunkRec*>(g_map + (size_t)3 * S * n_chunks);  // [n_chunks]
-    const int sub_cols = max(1, HMM_LONG_STG / Spad);
+    const bool packed = ppl_packed && set.ppl_lanes != 0u;
+    const int rstride = packed ? hmm_ppl_group(set.ppl_lanes) : Spad;   // bytes per column (rows of one byte per state, or per lane of the job's group)
+    const int sub_cols = max(1, HMM_LONG_STG / rstride);
+    // the back-pointer of `state` (loc: its hmm_bp_loc) in the staged row at `row`
+    auto bp_at = [&](int row, int state, uint32_t loc) -> int {
+      if (!packed) return (int)l_stage[row + state];
+      if (state == S - 2) return (int)hmm_bp_run_end(*reinterpret_cast<const uint32_t*>(l_stage + row));
+      return (int)hmm_bp_unpack(l_stage[row + (int)(loc & 63u)], loc);
+    };
     // one step of the chase: the predecessor of `state` in column `idx` (b: its back-pointer)
     // (all four predecessor entries of the state are read before its back-pointer is known -- one LDS round trip per step, not two)
-    auto pred_of = [&](int state, int b, uint32_t p01, uint32_t p23) -> uint32_t {
-      const uint32_t pw = (b & 2) ? p23 : p01;
-      uint32_t pe = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
-      if (state == S - 2) { const uint32_t be_ = l_blocks[1 * nb + (b < nb ? b : 0)]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15); }
+    auto pred_of = [&](int state, int b, const uint4& p4) -> uint32_t {
+      uint32_t pe = (b & 2) ? ((b & 1) ? p4.w : p4.z) : ((b & 1) ? p4.y : p4.x);
+      if (state == S - 2) { const int bb = b < nb ? b : 0; const uint32_t be_ = l_blocks[1 * nb + bb]; pe = be_ | ((uint32_t)(l_flags[be_] & 1) << 15) | (hmm_bp_loc_block_end(bb, nb, l_blocks) << 16); }
       return pe;
     };
-    // wave-cooperative staging of the back-pointer columns [c0, c1) (16-byte pieces; the rows are Spad = 16 k bytes)
+    // wave-cooperative staging of the back-pointer columns [c0, c1) (16-byte pieces; c0 is a multiple of the chunk length: 16-byte aligned rows)
     auto stage_cols = [&](int c0, int c1) {
-      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * Spad);
+      const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)c0 * rstride);
       uint4* dst = reinterpret_cast<uint4*>(l_stage);
-      const int n16 = (c1 - c0) * Spad / 16;
+      const int n16 = ((c1 - c0) * rstride + 15) / 16;
       for (int i = lane; i < n16; i += 64) dst[i] = src[i];
     };
     HP_LONG_DECL;
@@ -1351,6 +1401,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
       const int bot = j * C, top = min(L - 1, bot + C - 1);
       const int s0 = 64 * q + lane;
       int state = s0 < S ? s0 : 0, idx = top;
+      uint32_t loc = packed && s0 < S ? hmm_bp_loc(s0, nb, (int)g_block[s0], l_blocks) : 0u;
       int nsteps = 0, nstarts = 0, last_end = -1, last_state = state;
       const int step_cap = (top - bot + 1) * (int)(set.max_mlen + 8) + S;  // (entry states the path cannot be in may hold arbitrary back-pointers)
       for (int c1 = top + 1; c1 > bot;) {
@@ -1360,15 +1411,16 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         while (__ballot(state != 0 && idx >= c0 && nsteps < step_cap) != 0ull) {
           if (state != 0 && idx >= c0 && nsteps < step_cap) {
-            const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
-            const uint32_t inf = l_info[state], p01 = pin[0], p23 = pin[1];
-            const int b = l_stage[(idx - c0) * Spad + state];
+            const uint4 p4 = *reinterpret_cast<const uint4*>(l_inst + 4 * state);
+            const uint32_t inf = l_info[state];
+            const int b = bp_at((idx - c0) * rstride, state, loc);
             const int kind = (int)(inf & 7u);
             ++nsteps; nstarts += kind == 1; if (kind == 2) last_end = idx; last_state = state;
-            const uint32_t pe = pred_of(state, b, p01, p23);
+            const uint32_t pe = pred_of(state, b, p4);
             if ((inf >> 3) & 1u) --idx;
             const int nx = (int)(pe & 0x7FFFu);
             state = nx < S ? nx : 0;
+            loc = nx < S ? pe >> 16 : 0u;
           }
         }
         c1 = c0;
@@ -1421,6 +1473,7 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
       const HmmChunkRec cr = g_crec[j];
       const int bot = j * C, top = min(L - 1, bot + C - 1);
       int state = (int)cr.entry, idx = top, np_c = (int)cr.np0, nv_c = (int)cr.nv0, vb_c = cr.vb0, nxt_c = cr.nxt0;
+      uint32_t loc = packed && state < S ? hmm_bp_loc(state, nb, (int)g_block[state], l_blocks) : 0u;
       for (int c1 = top + 1; c1 > bot && state != 0;) {
         const int c0 = max(bot, c1 - sub_cols);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1432,13 +1485,13 @@ __global__ void __launch_bounds__(HMM_LONG_THREADS) hmm_traceback_long_kernel(
           int emits = __builtin_amdgcn_readfirstlane((int)((l_info[state] >> 3) & 1u));  // (afterwards: bit 15 of the predecessor entry)
           while (state != 0 && idx >= c0 && n < 64) {
             l_rec[2 * n] = (uint32_t)state; l_rec[2 * n + 1] = (uint32_t)idx; ++n;
-            const uint32_t* pin = reinterpret_cast<const uint32_t*>(l_inst + 4 * state);
-            const uint32_t p01 = pin[0], p23 = pin[1];
-            const int b = __builtin_amdgcn_readfirstlane((int)l_stage[(idx - c0) * Spad + state]);
-            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)pred_of(state, b, p01, p23));
+            const uint4 p4 = *reinterpret_cast<const uint4*>(l_inst + 4 * state);
+            const int b = __builtin_amdgcn_readfirstlane(bp_at((idx - c0) * rstride, state, loc));
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)pred_of(state, b, p4));
             if (emits) --idx;
-            emits = (int)(pe >> 15);
+            emits = (int)((pe >> 15) & 1u);
             state = (int)(pe & 0x7FFFu);
+            loc = pe >> 16;
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           {  // ---- what the noted steps mean, one lane per step (events.rs:17-86, purity.rs:6-41, operations.rs:26-57)
@@ -1817,7 +1870,7 @@ static inline uint64_t hmm_map_words(uint32_t S, uint64_t max_len, uint32_t long
   return n_chunks * (3ull * S + 8ull) + 8;
 }
 static size_t hmm_long_lds_bytes(uint32_t S, uint32_t nb) {
-  size_t o = 64 + (size_t)12 * S + (size_t)20 * nb + ((S + 3) & ~3u) + (((size_t)S / 3 + 15) & ~(size_t)15) + 32;
+  size_t o = 64 + (size_t)20 * S + (size_t)20 * nb + ((S + 3) & ~3u) + (((size_t)S / 3 + 15) & ~(size_t)15) + 32;
   return ((o + 15) & ~(size_t)15) + (size_t)(HMM_LONG_THREADS / 64) * (HMM_LONG_STG + 512) + HMM_LONG_MAP_LDS;
 }
 static size_t hmm_lds_bytes(uint32_t S, uint32_t nb) {
@@ -1839,10 +1892,15 @@ static int hmm_launch_ppl(trgt_hip_ctx* c, int bset, int class_slot, hipStream_t
   auto launch = [&](int g, hipStream_t s) {
     const uint32_t nj = segs.end_slot[g] > segs.first_slot[g] ? segs.end_slot[g] - segs.first_slot[g] : 0u;  // job slots this width looks at
     if (!nj) return;
-    if (g == 0) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<8>), dim3((nj + 7) / 8), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
-    else if (g == 1) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<16>), dim3((nj + 3) / 4), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
-    else if (g == 2) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<32>), dim3((nj + 1) / 2), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
-    else hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<64>), dim3(nj), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs);
+    // (rows of one byte per lane; TRGT_HMM_PPL_WIDE in `make DEV=1` builds: the round-5 rows of one byte per state)
+#define TRGT_PPL_LAUNCH(GG, NB)                                                                                                                         \
+    do { if (c->knobs.hmm_ppl_wide) hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<GG, false>), dim3(NB), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs); \
+         else hipLaunchKernelGGL((ppl::hmm_fill_ppl_kernel<GG, true>), dim3(NB), dim3(64), 0, s, d_jobs, d_sets, d_model, d_seq, d_bp, segs); } while (0)
+    if (g == 0) TRGT_PPL_LAUNCH(8, (nj + 7) / 8);
+    else if (g == 1) TRGT_PPL_LAUNCH(16, (nj + 3) / 4);
+    else if (g == 2) TRGT_PPL_LAUNCH(32, (nj + 1) / 2);
+    else TRGT_PPL_LAUNCH(64, nj);
+#undef TRGT_PPL_LAUNCH
   };
   // the widest groups on the class's own stream; the other widths (disjoint jobs) next to it on side streams forked off that stream and
   // joined back into it: one behind the other they added up their tails (a cfg4 class with 32- and 64-lane sets: 0.53 + 0.47 ms in
@@ -2286,7 +2344,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,   \
                        (const uint8_t*)d_model, d_seq, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)nullptr, d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | (ppl_mask && !c->knobs.hmm_ppl_wide ? 0x00800000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)nullptr, d_long_cls)
     // (the class's list of long alleles: filled by the fill kernel, worked off by the trace-back kernel right behind it)
     uint32_t* d_long_cls = nullptr;
     const uint32_t long_min_cls = hmm_long_min(e - i);
@@ -2312,7 +2370,7 @@ int trgt::hmm_enqueue(trgt_hip_ctx* c, const HmmModels* premade, int32_t n_sets,
       for (int ph = G > 1 ? 1 : 0; ph <= (G > 1 ? 3 : 0); ++ph)
         hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u) * (unsigned)(ph == 1 || ph == 3 ? G : 1)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_jobs + i, (const HmmSetDev*)d_sets,
                            (const uint8_t*)d_model, d_seq, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
-                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph, ph == 1 || ph == 3 ? G : 1);
+                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph | (ppl_mask && !c->knobs.hmm_ppl_wide ? 0x100 : 0), ph == 1 || ph == 3 ? G : 1);
       TRGT_HIP_TRY(c, hipGetLastError());
     }
     t.stop(i == 0 ? cells : 0);
@@ -2524,7 +2582,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
 #define TRGT_HMM_LAUNCH(SB, OW)                                                                                                    \
     hipLaunchKernelGGL((hmm_viterbi_kernel<SB, OW>), grid, block, lds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets, \
                        (const uint8_t*)mp->d_blob, in.seq_blob_dev, (uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, \
-                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)(d_count + k), d_long_cls)
+                       o_nsp.dev, o_cnt.dev, o_pur.dev, o_edit.dev, o_maxd.dev, nj, (uint32_t)lds_job | (c->knobs.hmm_four_rounds ? 0x80000000u : 0u) | (ppl_mask ? 0x40000000u : 0u) | (ppl_mask && !c->knobs.hmm_ppl_wide ? 0x00800000u : 0u) | ((long_min_cls / 256u) << 24), (const uint32_t*)(d_count + k), d_long_cls)
     uint32_t* d_long_cls = nullptr;
     uint32_t max_cap_cls = 0;
     for (uint32_t i = class_begin[k]; i < class_begin[k + 1]; i += 2) max_cap_cls = std::max(max_cap_cls, in.cap[cand[i].set]);
@@ -2551,7 +2609,7 @@ int trgt::hmm_enqueue_slots(trgt_hip_ctx* c, const HmmModels* mp, const HmmSlots
       for (int ph = G > 1 ? 1 : 0; ph <= (G > 1 ? 3 : 0); ++ph)
         hipLaunchKernelGGL(hmm_traceback_long_kernel, dim3((unsigned)std::min<uint32_t>(nj, 64u) * (unsigned)(ph == 1 || ph == 3 ? G : 1)), dim3(HMM_LONG_THREADS), llds, ls, (const HmmJobDev*)d_list + class_begin[k], (const HmmSetDev*)mp->d_sets,
                            (const uint8_t*)mp->d_blob, in.seq_blob_dev, (const uint8_t*)d_bp, (uint32_t*)d_visits, o_path.dev, o_plen.dev, o_spans.dev, o_nsp.dev, o_cnt.dev, o_pur.dev,
-                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph, ph == 1 || ph == 3 ? G : 1);
+                           o_edit.dev, o_maxd.dev, (const uint32_t*)d_long_cls, ph | (ppl_mask && !c->knobs.hmm_ppl_wide ? 0x100 : 0), ph == 1 || ph == 3 ? G : 1);
       TRGT_HIP_TRY(c, hipGetLastError());
     }
     t.stop(0);

@@ -116,7 +116,12 @@ constexpr int CODE_ROW = 272;
 // one segment per class (capacity: the candidates of the class; count: what the resolve kernel kept), filled by ONE launch per width.
 struct PplSegs { uint32_t begin[9]; uint32_t n_seg; const uint32_t* counts; uint32_t first_slot[4], end_slot[4]; };  // [first_slot[g], end_slot[g]): the slots a launch of width 8 << g looks at (the segments that hold such jobs)
 
-template <int G>
+// PACK (round 6): ONE byte per lane and column -- the back-pointers of the position's match (bits 0-1), insertion (2) and deletion /
+// block-end slot (3-4), of its block's start (5; the block's first position) and two bits of the job's run start / run end (6-7: lane 0
+// the run start, lanes 1-3 bits 0-1 / 2-3 / 4-5 of the run end's block index) -- rows of G bytes: one store per lane and column instead
+// of five byte stores into rows of one byte per STATE (three states per position), a third of the bytes written and read back.  The
+// trace-backs translate (state -> lane, shift, mask: bp_loc in hmm.hip).  PACK = false keeps the round-5 layout (TRGT_HMM_PPL_WIDE).
+template <int G, bool PACK>
 __global__ void __launch_bounds__(64, (G <= 16 ? 3 : 2)) hmm_fill_ppl_kernel(const HmmJobDev* __restrict__ jobs, const HmmSetDev* __restrict__ sets, const uint8_t* __restrict__ model,
                                                           const uint8_t* __restrict__ seq_blob, uint8_t* __restrict__ bp_ws, const PplSegs segs) {
   constexpr int JPW = 64 / G;
@@ -201,6 +206,8 @@ __global__ void __launch_bounds__(64, (G <= 16 ? 3 : 2)) hmm_fill_ppl_kernel(con
   const int aux_st = pos == 0 ? 1 : pos == 1 ? S - 2 : pos == 2 ? 0 : S - 1;   // run start | run end | start | end
   uint8_t* p_x = has && pos < 4 ? bp0 + aux_st : dump;
   int inc_m = kind ? Spad : 0, inc_i = is_pos ? Spad : 0, inc_s = kind && k == 0 ? Spad : 0, inc_x = has && pos < 4 ? Spad : 0;  // (0 once the job's last column is written: see run)
+  if constexpr (PACK) { p_m = has ? bp0 + pos : dump; inc_m = has ? G : 0; }  // the lane's one byte of a row of G (every lane of a job has one)
+  const int re_shift = pos >= 1 && pos <= 3 ? 2 * (pos - 1) : 31;  // which two bits of the run end's block index this lane keeps (31: none)
   // constant back-pointers of the aux states from column 1 on: run start <- run end (slot 1); start: none; end <- run end (slot 0)
   const int aux_const = pos == 0 ? 1 : pos == 2 ? 0xFF : 0;
   const bool aux_is_re = pos == 1;
@@ -393,10 +400,17 @@ __global__ void __launch_bounds__(64, (G <= 16 ? 3 : 2)) hmm_fill_ppl_kernel(con
     int bp_x;
     if constexpr (FIRST) bp_x = pos == 0 ? bp_rs : pos == 1 ? bp_re : pos == 2 ? 0xFE : 0xFF;
     else bp_x = aux_is_re ? bp_re : aux_const;
-    if (!GUARD || i < Lj) {
-      *p_m = (uint8_t)bp_m; *p_i = (uint8_t)bp_i; *p_d = (uint8_t)bp_d; *p_s = (uint8_t)bp_s; *p_x = (uint8_t)bp_x;
+    if constexpr (PACK) {
+      const int aux = pos == 0 ? bp_rs : (bp_re >> re_shift) & 3;
+      const int packed = bp_m | (bp_i << 2) | (bp_d << 3) | (bp_s << 5) | (aux << 6);
+      if (!GUARD || i < Lj) *p_m = (uint8_t)packed;
+      p_m += inc_m;
+    } else {
+      if (!GUARD || i < Lj) {
+        *p_m = (uint8_t)bp_m; *p_i = (uint8_t)bp_i; *p_d = (uint8_t)bp_d; *p_s = (uint8_t)bp_s; *p_x = (uint8_t)bp_x;
+      }
+      p_m += inc_m; p_i += inc_i; p_d += inc_m; p_s += inc_s; p_x += inc_x;
     }
-    p_m += inc_m; p_i += inc_i; p_d += inc_m; p_s += inc_s; p_x += inc_x;
     // ---- what the next column's emitting states take from the lane before
     m = m_new; iv = i_new; msv = ms_new;
     mA = shr1(m_new);
