@@ -537,8 +537,11 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const uint8_t* const motif_bytes = l_mot;
   // (bit 15 of a predecessor entry: that state emits a base -- the trace-back then knows it on arrival, without a look-up of its own)
   for (int i = tid; i < 4 * S; i += nthr) l_inst[4 * (i % S) + i / S] = hmm_pred_entry(g_inst[i], S, nb, model + set.off_flags, g_block, g_blocks);
-  for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; }
-  for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
+  // (a job whose back-pointers the position-per-lane fill has written is only traced back here: the transition / emission tables and the
+  //  per-state registers of this kernel's own fill are not loaded for it -- a dozen rounds of global loads per job)
+  const bool own_fill = !(ppl_filled && set.ppl_lanes != 0u);
+  for (int i = tid; i < S; i += nthr) { l_block[i] = g_block[i]; l_flags[i] = model[set.off_flags + i]; if (own_fill) { l_lp[i] = g_inlp[i]; l_lp[S + i] = g_inlp[S + i]; } }
+  if (own_fill) for (int i = tid; i < 5 * S; i += nthr) l_em[i] = g_em[i];
   for (int i = tid; i < 4 * nb; i += nthr) l_blocks[i] = g_blocks[i];
 
   // ---- my state's tables in registers
@@ -546,10 +549,14 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int st_lane = set.n_lanes ? (int)reinterpret_cast<const uint16_t*>(model + set.off_perm)[tid] : tid;
   const bool act = st_lane < S;
   const int st = act ? st_lane : 0;
-  const int n_in = model[set.off_nin + st];
-  const int level = model[set.off_level + st];
-  double lp0 = g_inlp[0 * S + st], lp1 = g_inlp[1 * S + st], lp2 = g_inlp[2 * S + st], lp3 = g_inlp[3 * S + st];
-  const int p0 = g_inst[0 * S + st], p1 = g_inst[1 * S + st], p2 = g_inst[2 * S + st], p3 = g_inst[3 * S + st];
+  const int n_in = own_fill ? (int)model[set.off_nin + st] : 0;
+  const int level = own_fill ? (int)model[set.off_level + st] : 0;
+  double lp0 = 0.0, lp1 = 0.0, lp2 = 0.0, lp3 = 0.0;
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  if (own_fill) {
+    lp0 = g_inlp[0 * S + st]; lp1 = g_inlp[1 * S + st]; lp2 = g_inlp[2 * S + st]; lp3 = g_inlp[3 * S + st];
+    p0 = g_inst[0 * S + st]; p1 = g_inst[1 * S + st]; p2 = g_inst[2 * S + st]; p3 = g_inst[3 * S + st];
+  }
   // predecessor slots that do not exist read score 0 of state 0 and are ignored (n_in guards the comparison)
   const int q0 = (n_in != 0xFF && n_in > 0) ? p0 : 0, q1 = (n_in != 0xFF && n_in > 1) ? p1 : 0, q2 = (n_in != 0xFF && n_in > 2) ? p2 : 0, q3 = (n_in != 0xFF && n_in > 3) ? p3 : 0;
   const uint8_t* __restrict__ seq = seq_blob + job.seq_off;
@@ -616,8 +623,8 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   const int my_ms = my_blk >= 0 ? (int)l_blocks[0 * nb + my_blk] : 0, my_me = my_blk >= 0 ? (int)l_blocks[1 * nb + my_blk] : 0;
   const double ms_lp0 = my_blk >= 0 ? l_lp[my_ms] : NINF, ms_lp1 = my_blk >= 0 ? l_lp[S + my_ms] : NINF;
   bool bad = false, use_loc0 = false, use_loc1 = false;
-  if (act && my_blk >= 0) bad = model[set.off_nin + my_ms] != 2 || g_inst[0 * S + my_ms] != 1 || g_inst[1 * S + my_ms] != my_me;
-  if (act && level == 0 && n_in != 0xFF) {
+  if (own_fill && act && my_blk >= 0) bad = model[set.off_nin + my_ms] != 2 || g_inst[0 * S + my_ms] != 1 || g_inst[1 * S + my_ms] != my_me;
+  if (own_fill && act && level == 0 && n_in != 0xFF) {
     for (int b = 0; b < n_in && b < 4; ++b) {
       const int pb = b == 0 ? p0 : b == 1 ? p1 : b == 2 ? p2 : p3;
       const int pblk = pb < S ? (int)l_block[pb] : -1;
@@ -636,7 +643,7 @@ __global__ void hmm_viterbi_kernel(const HmmJobDev* __restrict__ jobs, const Hmm
   double* cur = sc1;
   HP_FILL_DECL;
   int sym_next = 0;
-  if (!(ppl_filled && set.ppl_lanes != 0u)) {
+  if (own_fill) {
   if constexpr (ONE_WAVE) {
     const int hw = (int)(threadIdx.x & 63u), lane_base = hw & ~(SUB - 1);
     const int a_q0 = (lane_base + q0) << 2, a_q1 = (lane_base + q1) << 2, a_q2 = (lane_base + q2) << 2, a_q3 = (lane_base + q3) << 2, a_st0 = lane_base << 2;
