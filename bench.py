@@ -555,7 +555,7 @@ def run_e2e(args, env):
             spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
             pipeline_stage_ms_per_chunk=dict(host_ingest=stage_ms["out2"], host_ingest_device_deflate=stage_ms["out3"], device_ingest_host_deflate=stage_ms["out4"], device_ingest_device_deflate=stage_ms["out5"]),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
-            bound="the device inflate (one wave per BGZF block, bound by scalar instruction issue) and the writer's record formatting; see DESIGN.md")
+            bound="the writer's record formatting on the host cores of the quota (its stage is the busiest of the pipeline), then the ingestion: the device inflate is one wave per BGZF block and a launch lasts ceil(blocks / resident waves) block times of ~ 3.8 ms; see DESIGN.md")
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
