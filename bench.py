@@ -342,6 +342,7 @@ def run_e2e(args, env):
     n, chunk = args.e2e_loci, 1000
     INGEST_CALLERS = int(os.environ.get("BENCH_INGEST_CALLERS", "3"))  # (a reader has six slots of device state: file read, upload, kernels and download of consecutive chunks overlap)
     INFLATE_WAVES = int(os.environ.get("BENCH_INFLATE_WAVES", "0"))  # (0: the library's default)
+    WRITER_THREADS = int(os.environ.get("BENCH_WRITER_THREADS", "0"))  # (0: the library's default)
     d = tempfile.mkdtemp(prefix="trgt_e2e_")
     try:
         t0 = time.perf_counter()
@@ -458,14 +459,14 @@ def run_e2e(args, env):
             finally:
                 pl.close()
         t0 = time.perf_counter()
-        w = writers.Writer(rd, os.path.join(d, "out.vcf"), os.path.join(d, "out.spanning.bam"))
+        w = writers.Writer(rd, os.path.join(d, "out.vcf"), os.path.join(d, "out.spanning.bam"), threads=WRITER_THREADS)
         for b, o in zip(batches, outs):
             w.write(b, o)
         w.close()
         t_wr = time.perf_counter() - t0
         # ... and with the BGZF blocks of the spanning BAM deflated on the GPU (trgt_writer_params.deflate_device, deflate_dev.hip)
         t0 = time.perf_counter()
-        w = writers.Writer(rd, os.path.join(d, "outd.vcf"), os.path.join(d, "outd.spanning.bam"), deflate_device=env["local_rank"])
+        w = writers.Writer(rd, os.path.join(d, "outd.vcf"), os.path.join(d, "outd.spanning.bam"), deflate_device=env["local_rank"], threads=WRITER_THREADS)
         for b, o in zip(batches_d, outs):  # (the batches of the device path: the writer reads their pinned arrays)
             w.write(b, o)
         w.close()
@@ -486,7 +487,7 @@ def run_e2e(args, env):
         stage_ms = {}
 
         def pipeline(tag, device_ingest, level, dev_deflate=-1):
-            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate)
+            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate, threads=WRITER_THREADS)
             q1, q2, err = queue.Queue(3), queue.Queue(2), []
             busy = dict(gpu=0.0, gpu_wait=0.0, write=0.0, write_wait=0.0)  # seconds a stage worked / waited for its input (the ingest stage is the callers')
 

@@ -224,9 +224,11 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
       "s_lshr_b64 s[60:61], s[60:61], %[t0]\n\t"
       "s_sub_i32 %[bc], %[bc], %[t0]\n"
       ".Llenok%=:\n\t"
-      // a distance code and its extra bits take at most 15 + 13 bits (the window's margin covers this refill: see the caller)
+      // a distance code and its extra bits take at most 15 + 13 bits
       "s_cmp_gt_u32 %[bc], 27\n\t"
       "s_cbranch_scc1 .Ldist%=\n\t"
+      "s_cmp_gt_u32 %[ip], %[iplim]\n\t"     // (EVERY refill asks whether the window is low: a run of matches of ~ 32 bits each refills here symbol
+      "s_cbranch_scc1 .Lexit2%=\n\t"         //  after symbol and seldom at a boundary -- unchecked, such a run can walk out of the window)
       INFL_REFILL
       ".Ldist%=:\n\t"
       "s_and_b32 %[t0], s60, 0xff\n\t"
@@ -355,6 +357,10 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
   return code;
 }
 
+// (Tried and not kept, profiles/r06h_ab_inflate_gather.txt: the table look-ups of SEVERAL symbols in one LDS round trip -- lane 32 + j reads the
+//  literal / length entry for the bits behind the first j of the buffer, lane j the distance entry, the entries of a round of symbols come
+//  out of that register by v_readlane, the buffer is shifted once per round.  Same instruction count per symbol, 7.46 against 7.53 ms per
+//  launch: what a wave pays per symbol is instruction issue next to its neighbours on the SIMD, not the look-ups' round trips.)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) inflate_blocks_kernel(const uint8_t* __restrict__ src, const BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                             uint8_t* __restrict__ dst, uint8_t* __restrict__ status, unsigned int* __restrict__ counter, uint32_t fast) {
   __shared__ Shared sh;
