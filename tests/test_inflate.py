@@ -195,3 +195,62 @@ def test_device_damaged_streams_are_never_inflated_wrongly():
                 ref = None
             assert ref is not None and d.eof and ref == g and len(g) == n_out, kind
     assert ok >= 50
+
+
+# ---- a stream built by hand for the window bookkeeping of the device decoder's hand-written loop: after 25 000 stored bytes, 950 matches
+#      that take EXACTLY 32 bits each (an 8-bit length code + 3 extra bits, an 8-bit distance code + 13 extra bits) behind 0 .. 15 two-bit
+#      literals that set the phase of the bit buffer.  In some phases such a run never refills at a symbol boundary, only between a length
+#      and its distance -- the refill that did not ask whether the window of compressed bytes was low until the end of round 6.
+def _run_of_32_bit_matches(n_lead, rng):
+    class W:
+        def __init__(self): self.acc = 0; self.n = 0; self.out = bytearray()
+        def bits(self, v, n):          # LSB first
+            self.acc |= v << self.n; self.n += n
+            while self.n >= 8: self.out.append(self.acc & 0xFF); self.acc >>= 8; self.n -= 8
+        def code(self, c, n):          # a Huffman code: most significant bit first
+            self.bits(int(format(c, "0%db" % n)[::-1], 2), n)
+        def flush(self):
+            if self.n: self.out.append(self.acc & 0xFF); self.acc = 0; self.n = 0
+
+    def canonical(lens):
+        codes, code = {}, 0
+        for l in range(1, 16):
+            for s, sl in enumerate(lens):
+                if sl == l: codes[s] = (code, l); code += 1
+            code <<= 1
+        return codes
+    w = W()
+    stored = bytes(rng.integers(0, 256, 25000, dtype=np.uint8))
+    w.bits(0, 1); w.bits(0, 2); w.flush()                      # BFINAL = 0, BTYPE = 00
+    w.out += struct.pack("<HH", len(stored), len(stored) ^ 0xFFFF) + stored
+    lit = [0] * 274
+    lit[65] = 1; lit[256] = 2; lit[273] = 8
+    for s in range(63): lit[s] = 8                              # 1/2 + 1/4 + 64/256 = 1: a complete code
+    dst = [0] * 30
+    for s, l in enumerate((1, 2, 3, 4, 5, 6, 7, 8)): dst[s] = l
+    dst[29] = 8
+    lc, dc, cl = canonical(lit), canonical(dst), canonical([4] * 16)
+    w.bits(1, 1); w.bits(2, 2)                                 # BFINAL = 1, BTYPE = 10
+    w.bits(274 - 257, 5); w.bits(30 - 1, 5); w.bits(19 - 4, 4)
+    for s in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15): w.bits(0 if s >= 16 else 4, 3)
+    for l in lit + dst: w.code(*cl[l])
+    for _ in range(n_lead): w.code(*lc[65])
+    for _ in range(950):
+        w.code(*lc[273]); w.bits(int(rng.integers(0, 8)), 3)   # lengths 35 .. 42
+        w.code(*dc[29]); w.bits(int(rng.integers(0, 400)), 13)  # distances 24 577 .. 24 976
+    w.code(*lc[256]); w.flush()
+    return bytes(w.out)
+
+
+@pytest.mark.gpu
+def test_device_run_of_matches_that_refill_only_between_length_and_distance():
+    from trgt_amd import _lib, ingest
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(77)
+    streams = [_run_of_32_bit_matches(k, rng) for k in range(16)]
+    want = [zlib.decompress(s, -15) for s in streams]
+    assert all(25000 + 35 * 950 <= len(x) <= 65536 for x in want)
+    for rep in range(3):  # (what a wrong read past the window finds there varies from launch to launch)
+        got, status = ingest.inflate_blocks(ctx, streams, [len(x) for x in want])
+        for k, (g, x, st) in enumerate(zip(got, want, status)):
+            assert st == 1 and g == x, (rep, k, int(st))
