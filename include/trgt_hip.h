@@ -337,11 +337,12 @@ typedef struct trgt_ingest_params {
                               leaves its range, MM strings beyond the kernel's caps (a read longer than 65 535 bases, more than 4 096 calls in one MM
                               entry) -- is redone as a whole by the host path, which yields the data or the error
                               (trgt_ingest_device_stats counts them).  A device that cannot be used fails the call: no silent host-only run.
-                              Calls from several host threads on one reader overlap (three slots of device state) */
+                              Calls from several host threads on one reader overlap (six slots of device state) */
   int32_t inflate_waves_per_cu; /* ABI 10, with ingest_device: BGZF blocks in flight per CU of the inflate kernel (one wave each, 10 KB of LDS; its waves
-                              live as long as the launch).  0 = 12: the kernel is bound by scalar instruction issue, so 12 run as fast as the 15
-                              that fit, and the LDS and registers left over let the kernels of trgt_locus_batch on the same GPU start next to
-                              it instead of behind it; 15 = the whole CU for a GPU that only ingests */
+                              live as long as the launch).  0 = 12.  A block takes its wave the same ~ 3.8 ms whatever the occupancy, so a launch
+                              lasts ceil(blocks / waves) block times: for the ~ 4 200 blocks of a 1 000-locus chunk anything from 9 per CU on is
+                              two rounds; 12 leave LDS and registers for the kernels of trgt_locus_batch on the same GPU to start next to it
+                              instead of behind it; 16 = the whole CU for a GPU that only ingests (values above 16 are taken as 16) */
 } trgt_ingest_params;
 typedef struct trgt_ingest_batch {  /* everything host memory owned by the batch; free with trgt_ingest_free */
   int64_t n_loci, n_reads, n_motifs;
