@@ -103,6 +103,13 @@ __device__ __forceinline__ uint32_t shl_from(uint32_t own, uint32_t above) {
 }
 
 constexpr uint32_t PAT_PAD = 0x01010101u, TXT_PAD = 0x02020202u, NULL_WIN = 0xFFFFFFFFu;
+// TRGT_FLT_PAD (an A/B build, not the default: DESIGN.md 5): the text windows padded by one dword per 32, so that lanes reading at equal v --
+// four dwords apart -- fall into 32 different banks instead of eight.  Costs two or three VALU instructions per read.
+#ifdef TRGT_FLT_PAD
+__device__ __forceinline__ int tw_phys(int i) { return i + (i >> 5); }
+#else
+__device__ __forceinline__ int tw_phys(int i) { return i; }
+#endif
 constexpr int PWN = 264;       // pattern windows: index v + 1 (0: the NULL window), plen <= 254
 constexpr int TW_EXTRA = 264;  // text windows: index (v + 1) + kb, i.e. text position + plen + 1
 constexpr int SMAX = 300;      // more levels than any flank alignment can take (a pattern of <= 254 bases is deleted for <= 5 + 254)
@@ -130,16 +137,25 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
   // uses a compile-time choice.
   constexpr int G = (X == OE) ? X : ((X % 2 == 0 && OE % 2 == 0) ? 2 : 1), DEP = R / G, IX = X / G - 1, IO = OE / G - 1;
   static_assert(R % G == 0 && X % G == 0 && OE % G == 0 && G <= 2, "ring classes");
+#ifdef TRGT_FLT_PAD
+  __shared__ uint32_t lds[PWN + TWN + TWN / 32 + 2];
+#else
   __shared__ uint32_t lds[PWN + TWN];
+#endif
   uint32_t* const Pw = lds;
   uint32_t* const Tw = lds + PWN;
   const int lane = (int)threadIdx.x;
   const uint32_t* const twl = Tw + lane * LW;  // + (v + 1) + C_p: the window of diagonal kb = C_p + lane * LW at offset v + k
+#ifdef TRGT_FLT_PAD
+#define TWR(x) Tw[tw_phys(lane * LW + (int)(x))]
+#else
+#define TWR(x) twl[x]
+#endif
   const uint32_t n_jobs = a.n_jobs_dev ? min(*a.n_jobs_dev, a.n_jobs) : a.n_jobs;  // (never past the list the host sized)
   unsigned long long cells_acc = 0, kept_acc = 0;
 
   // 4-byte sliding windows of `len` bytes at src into W[i] (i = 0 .. n_win - 1), bytes beyond the sequence = pad
-  auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W, int n_win, uint32_t pad, uint32_t& dirty) {
+  auto stage = [&](const uint8_t* __restrict__ src, int len, uint32_t* __restrict__ W, int n_win, uint32_t pad, uint32_t& dirty, int w0, bool text) {  // (text windows: W = Tw, window i at tw_phys(w0 + i))
     for (int i0 = 4 * lane; i0 < n_win; i0 += 256) {
       uint32_t d0 = pad, d1 = pad;
       if (i0 + 8 <= len) {
@@ -154,10 +170,11 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
             else d1 = (d1 & ~(0xFFu << (8 * (b - 4)))) | (c << (8 * (b - 4)));
           }
       }
-      W[i0] = d0;
-      if (i0 + 1 < n_win) W[i0 + 1] = __builtin_amdgcn_alignbyte(d1, d0, 1);
-      if (i0 + 2 < n_win) W[i0 + 2] = __builtin_amdgcn_alignbyte(d1, d0, 2);
-      if (i0 + 3 < n_win) W[i0 + 3] = __builtin_amdgcn_alignbyte(d1, d0, 3);
+      auto at = [&](int i) -> uint32_t& { return W[text ? tw_phys(w0 + i) : w0 + i]; };
+      at(i0) = d0;
+      if (i0 + 1 < n_win) at(i0 + 1) = __builtin_amdgcn_alignbyte(d1, d0, 1);
+      if (i0 + 2 < n_win) at(i0 + 2) = __builtin_amdgcn_alignbyte(d1, d0, 2);
+      if (i0 + 3 < n_win) at(i0 + 3) = __builtin_amdgcn_alignbyte(d1, d0, 3);
     }
   };
 
@@ -180,9 +197,9 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
     if (fits) {
       // ---- the two sequences as sliding windows (one wave: its LDS operations execute in order, no barrier needed)
       if (lane == 0) Pw[0] = NULL_WIN;
-      stage(a.pat_base + pat_off, plen, Pw + 1, PWN - 1, PAT_PAD, dirty);
-      for (int i = lane; i < plen + 1; i += 64) Tw[i] = TXT_PAD;  // text positions < 0: only NULL cells look there
-      stage(a.txt_base + txt_off, tlen, Tw + plen + 1, TWN - (plen + 1), TXT_PAD, dirty);
+      stage(a.pat_base + pat_off, plen, Pw, PWN - 1, PAT_PAD, dirty, 1, false);
+      for (int i = lane; i < plen + 1; i += 64) Tw[tw_phys(i)] = TXT_PAD;  // text positions < 0: only NULL cells look there
+      stage(a.txt_base + txt_off, tlen, Tw, TWN - (plen + 1), TXT_PAD, dirty, plen + 1, true);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     const bool is_dirty = __builtin_amdgcn_ballot_w64(dirty != 0u) != 0ull;
@@ -193,7 +210,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
       auto window_step = [&](uint32_t key, int C) __attribute__((always_inline)) -> uint32_t {
         const uint32_t va = (key >> 8) & 0xFFu, vb = key >> 24;
         // the four LDS reads of the pair go out together, one wait for all of them
-        const uint32_t pa = Pw[va], ta = twl[va + C], pb = Pw[vb], tb = twl[vb + C + 1];
+        const uint32_t pa = Pw[va], ta = TWR(va + C), pb = Pw[vb], tb = TWR(vb + C + 1);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 DS reads
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // then the VALU work
         const uint32_t na = min(ffbl_or_m1(pa ^ ta) >> 3, 4u);
@@ -217,7 +234,7 @@ __global__ void __launch_bounds__(64, (NS * B <= 8 ? TRGT_FLT_W4 : NS * B <= 10 
             const uint32_t key = Mx[t * B + jj];
             const uint32_t va = (key >> 8) & 0xFFu, vb = key >> 24;
             const int C = t * SW + 2 * jj;
-            pw[2 * jj] = Pw[va]; tw[2 * jj] = twl[va + C]; pw[2 * jj + 1] = Pw[vb]; tw[2 * jj + 1] = twl[vb + C + 1];
+            pw[2 * jj] = Pw[va]; tw[2 * jj] = TWR(va + C); pw[2 * jj + 1] = Pw[vb]; tw[2 * jj + 1] = TWR(vb + C + 1);
           }
           __builtin_amdgcn_sched_group_barrier(0x100, 4 * B, 0);
 #pragma unroll
