@@ -10,7 +10,7 @@ echo "== parity of the padded build"; TRGT_HIP_LIB=$PAD python -m pytest tests/t
 for rep in 1 2; do for lib in default pad; do
   if [ $lib = pad ]; then export TRGT_HIP_LIB=$PAD; else unset TRGT_HIP_LIB; fi
   rm -rf $O/kt; rocprofv3 --kernel-trace --stats -d $O/kt -o b -- python bench.py --config 2 --steps 20 --warmup 2 --contexts 1 --no-streaming --no-cpu-baseline > $O/bench_$lib.json 2> $O/bench.err
-  echo "== $lib (run $rep): $(tail -1 $O/bench_$lib.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-context value', d['value'], 'ms/step', d['ms_per_step'], 'parity', d['parity'])")"
+  echo "== $lib (run $rep): $(tail -1 $O/bench_$lib.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-context value', d['value'], 'ms/step', d['ms_per_step'], 'parity', d.get('parity'))")"
   python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) | grep "wfa_filter" | cut -c1-60,92-150
 done; done
 for lib in default pad; do
