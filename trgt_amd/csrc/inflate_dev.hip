@@ -141,13 +141,8 @@ __device__ __forceinline__ uint32_t fast_symbols(uint64_t& bitbuf, uint32_t& bit
   static_assert(LIT_BITS == 10 && DIST_BITS == 8, "constants of the hand-written loop");
   // COMPLETE: the copy from the flushed output that is still in flight (pd != -1: its destination is [pd, pd + its length), the loaded
   // bytes arrive in vpd, their ring addresses are in vpa, its lanes in s[68:69]) is written to the ring
-#ifdef INFL_EXP_NOWAIT  /* timing experiment only (wrong bytes): what the kernel would take if no copy from the flushed output were ever waited for */
-#define INFL_VMWAIT ""
-#else
-#define INFL_VMWAIT "s_waitcnt vmcnt(0)\n\t"
-#endif
 #define INFL_COMPLETE                      \
-  INFL_VMWAIT                              \
+  "s_waitcnt vmcnt(0)\n\t"                 \
   "s_mov_b64 s[66:67], exec\n\t"           \
   "s_mov_b64 exec, s[68:69]\n\t"           \
   "ds_write_b8 %[vpa], %[vpd]\n\t"         \
