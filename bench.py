@@ -252,7 +252,7 @@ CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 CONFIG_KEYS = ("workload", "baseline_config", "value_streaming", "value_streaming_bam4", "value_single_context", "ms_per_step_single_context",
                "contexts_per_gpu", "loci_per_gpu", "reads_per_locus", "parallelism", "host_cpu_quota")
 E2E_KEYS = ("ingest_loci_per_s", "ingest_loci_per_s_host", "gpu_loci_per_s", "gpu_loci_per_s_two_contexts", "gpu_loci_per_s_four_contexts", "write_loci_per_s", "write_loci_per_s_device_deflate",
-            "pipeline_loci_per_s", "pipeline_loci_per_s_device_ingest_host_deflate", "pipeline_loci_per_s_host_ingest", "pipeline_vcf_identical")
+            "pipeline_loci_per_s", "pipeline_loci_per_s_synchronous_writer", "pipeline_loci_per_s_device_ingest_host_deflate", "pipeline_loci_per_s_host_ingest", "pipeline_vcf_identical")
 
 
 def _short(s, n):
@@ -343,6 +343,7 @@ def run_e2e(args, env):
     INGEST_CALLERS = int(os.environ.get("BENCH_INGEST_CALLERS", "3"))  # (a reader has six slots of device state: file read, upload, kernels and download of consecutive chunks overlap)
     INFLATE_WAVES = int(os.environ.get("BENCH_INFLATE_WAVES", "0"))  # (0: the library's default)
     WRITER_THREADS = int(os.environ.get("BENCH_WRITER_THREADS", "0"))  # (0: the library's default)
+    WRITE_BEHIND = int(os.environ.get("BENCH_WRITE_BEHIND", "1"))
     d = tempfile.mkdtemp(prefix="trgt_e2e_")
     try:
         t0 = time.perf_counter()
@@ -485,8 +486,9 @@ def run_e2e(args, env):
         # ---- pipeline: ingest | GPU | write
         stage_ms = {}
 
-        def pipeline(tag, device_ingest, level, dev_deflate=-1):
-            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate, threads=WRITER_THREADS)
+        def pipeline(tag, device_ingest, level, dev_deflate=-1, write_behind=0):
+            w = writers.Writer(rd, os.path.join(d, tag + ".vcf"), os.path.join(d, tag + ".spanning.bam"), bam_compress_level=level, deflate_device=dev_deflate, threads=WRITER_THREADS,
+                               write_behind=write_behind)
             q1, q2, err = queue.Queue(3), queue.Queue(2), []
             busy = dict(gpu=0.0, gpu_wait=0.0, write=0.0, write_wait=0.0)  # seconds a stage worked / waited for its input (the ingest stage is the callers')
 
@@ -539,7 +541,10 @@ def run_e2e(args, env):
         t_pipe_host, same = pipeline("out2", False, 6)            # as rounds 1-5 measured it: host ingestion, htslib's BAM level, zlib
         t_pipe_hostd, same_b = pipeline("out3", False, 6, dev)    # ... the spanning BAM deflated on the GPU
         t_pipe_dev6, same_c = pipeline("out4", True, 6)           # device ingestion, the spanning BAM by zlib at level 6
-        t_pipe, same_d = pipeline("out5", True, 6, dev)           # device ingestion + device deflate: the host only reads the file, formats records and writes
+        t_pipe_sync, same_e = pipeline("out6", True, 6, dev)      # device ingestion + device deflate: the host only reads the file, formats records and writes
+        # ... and with the writer's write-behind (ABI 11): a batch is deflated and written while the next one is formatted -- the pipeline's figure
+        t_pipe, same_d = pipeline("out5", True, 6, dev, WRITE_BEHIND)
+        same = same and same_e
         same = same and same_b and same_c and same_d
         r = lambda x: round(x, 1)
         return dict(
@@ -551,12 +556,14 @@ def run_e2e(args, env):
             gpu_loci_per_s=r(n / t_gpu_dev), gpu_loci_per_s_host_reads=r(n / t_gpu), gpu_loci_per_s_two_contexts=r(n / t_gpu_pool[2]), gpu_loci_per_s_four_contexts=r(n / t_gpu_pool[4]),
             write_loci_per_s=r(n / t_wr), write_loci_per_s_device_deflate=r(n / t_wr_dev),
             stage_walk_s=dict(gpu=walks_gpu_dev, gpu_host_reads=walks_gpu, write=walks_wr, write_device_deflate=walks_wr_dev),  # (every walk over the four chunks; the rates above are the medians)
-            pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3), pipeline_loci_per_s_device_ingest_host_deflate=r(n / t_pipe_dev6),
+            pipeline_loci_per_s=r(n / t_pipe), pipeline_s=round(t_pipe, 3), pipeline_write_behind=bool(WRITE_BEHIND), pipeline_loci_per_s_synchronous_writer=r(n / t_pipe_sync),
+            pipeline_loci_per_s_device_ingest_host_deflate=r(n / t_pipe_dev6),
             pipeline_loci_per_s_host_ingest=r(n / t_pipe_host), pipeline_loci_per_s_host_ingest_device_deflate=r(n / t_pipe_hostd),
             spanning_bam_mb=round(bam_bytes_host / 1e6, 1), spanning_bam_mb_device_deflate=round(bam_bytes_dev / 1e6, 1),
-            pipeline_stage_ms_per_chunk=dict(host_ingest=stage_ms["out2"], host_ingest_device_deflate=stage_ms["out3"], device_ingest_host_deflate=stage_ms["out4"], device_ingest_device_deflate=stage_ms["out5"]),
+            pipeline_stage_ms_per_chunk=dict(host_ingest=stage_ms["out2"], host_ingest_device_deflate=stage_ms["out3"], device_ingest_host_deflate=stage_ms["out4"], device_ingest_device_deflate=stage_ms["out6"],
+                                             device_ingest_device_deflate_write_behind=stage_ms["out5"]),
             vcf_records=vcf_records, loci_with_both_true_allele_lengths=called, pipeline_vcf_identical=bool(same),
-            bound="the writer's record formatting on the host cores of the quota (its stage is the busiest of the pipeline), then the ingestion: the device inflate is one wave per BGZF block and a launch lasts ceil(blocks / resident waves) block times of ~ 3.8 ms; see DESIGN.md")
+            bound="the three stages are within 2 ms per chunk of each other with the writer's write-behind (synchronous, the writer's record formatting on the host cores of the quota is the busiest); the ingestion: the device inflate is one wave per BGZF block and a launch lasts ceil(blocks / resident waves) block times of ~ 3.8 ms; see DESIGN.md")
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

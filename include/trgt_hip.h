@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define TRGT_HIP_ABI_VERSION 10
+#define TRGT_HIP_ABI_VERSION 11
 
 #define TRGT_OK 0
 #define TRGT_ERR_INVALID (-1)     /* bad argument */
@@ -422,6 +422,11 @@ typedef struct trgt_writer_params {
                                  for the reference, write_bam.rs:72-144); >= 0 = GPU ordinal: the full blocks of a batch are deflated on that GPU in
                                  one go (trgt_deflate_blocks: fixed Huffman codes, ratio about zlib's level 1), a block the device declines by zlib.
                                  The records are the same; the compressed bytes are not zlib's */
+  int32_t write_behind;       /* ABI 11: 0 (default) = trgt_writer_write returns when the batch's bytes have been handed to the files.  1 = it
+                                 returns once the batch is FORMATTED (nothing of the batch or of the results is referenced afterwards); a thread
+                                 of the writer's own appends, deflates and writes the pieces while the caller goes on -- one batch in flight,
+                                 the files are the same byte for byte.  An error of that part (a file that cannot be written, a device deflate
+                                 that fails) is returned by the NEXT trgt_writer_write or by trgt_writer_close */
 } trgt_writer_params;
 void trgt_writer_default_params(trgt_writer_params* p);
 int trgt_writer_open(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out);

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(L, n), "libtrgt_hip.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert L.trgt_hip_abi_version() == 10
+    assert L.trgt_hip_abi_version() == 11
 
 
 def test_no_cpu_fallback_without_gpu():

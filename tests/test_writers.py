@@ -1,6 +1,9 @@
 """Native writers (trgt_amd/csrc/writers.hip) on a synthetic BAM with haplotype tags, 5mC calls and mismatching flank bases, fed with
 hand-made genotyping results (no GPU): VCF lines incl. the AM field (write_vcf.rs:95-397; get_meth / assign_read / get_tr_meth,
 tr.rs:196-262, 363-398) and the spanning-reads BAM (write_bam.rs:72-144; clip_bases.rs:9-120) against restatements in Python."""
+import os
+
+import pytest
 import numpy as np
 
 from bamtools import read_bam_records
@@ -141,3 +144,41 @@ def test_vcf_and_spanning_bam_from_handmade_results(tmp_path):
     _, _, got_u = read_bam_records(str(tmp_path / "u.bam"))
     assert [(g["name"], g["flag"]) for g in got_u] == [(g["name"], g["flag"] & ~4) for g in got]
     assert [{k: v for k, v in g.items() if k != "flag"} for g in got_u] == [{k: v for k, v in g.items() if k != "flag"} for g in got]
+    # ---- write_behind (ABI 11): the batch is formatted in the call, deflated and written behind it; the files are the same byte for byte
+    # (three batches, so that writes wait for the batch before them; both compression levels of the BAM)
+    for level in (6, 1):
+        for wb in (0, 1):
+            w = writers.Writer(rd, tmp_path / ("wb%d_%d.vcf" % (wb, level)), tmp_path / ("wb%d_%d.bam" % (wb, level)), output_flank_len=40, sample_name="S1",
+                               command_line="cmd", bam_compress_level=level, write_behind=wb, threads=3)
+            for _ in range(3):
+                w.write(b, out)
+            w.close()
+        for ext in ("vcf", "bam"):
+            assert open(tmp_path / ("wb0_%d.%s" % (level, ext)), "rb").read() == open(tmp_path / ("wb1_%d.%s" % (level, ext)), "rb").read(), (level, ext)
+    assert len([l for l in open(tmp_path / "wb1_6.vcf").read().splitlines() if not l.startswith("#")]) == 6
+
+
+def test_write_behind_reports_a_failed_write_at_the_next_call_or_the_close(tmp_path):
+    """trgt_writer_params.write_behind: what the writer's own thread runs into (here: /dev/full, every flush fails) comes back from the
+    next trgt_writer_write or from trgt_writer_close, never silently"""
+    from trgt_amd import _lib, ingest, locus, writers
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    bam, fa, bed, recs, genome = _synthetic(tmp_path)
+    rd = ingest.Reader(bam, fa)
+    b = rd.batch(bed, keep_native=True)
+    out = locus.BatchOutputs(b)
+    out.span_start[:] = -1; out.span_end[:] = -1; out.read_rank[:] = -1; out.classification[:] = -1
+    for wb in (0, 1):
+        w = writers.Writer(rd, "/dev/full", None, write_behind=wb)
+        failed = 0
+        for _ in range(3):  # (plain VCF through stdio: the buffer reaches the device at a flush or at the close)
+            try:
+                w.write(b, out)
+            except _lib.TrgtHipError:
+                failed += 1
+        try:
+            w.close()
+        except _lib.TrgtHipError:
+            failed += 1
+        assert failed >= 1, wb

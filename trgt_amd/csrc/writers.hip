@@ -176,7 +176,12 @@ struct trgt_writer {
   int threads = 1;
   std::vector<std::string> contigs;
   trgt_hip_ctx* dev = nullptr;  // owned: the context of trgt_writer_params.deflate_device
-  ~trgt_writer() { if (dev) trgt_hip_destroy(dev); }
+  // write_behind (ABI 11): the formatted pieces of a batch are appended, deflated and written by a thread of the writer's own while the
+  // caller formats the next batch; one batch in flight; what that thread reports is returned by the next write or by the close
+  bool write_behind = false;
+  std::thread bg; int bg_rc = TRGT_OK; std::string bg_err;
+  int bg_wait() { if (bg.joinable()) bg.join(); if (bg_rc != TRGT_OK && !bg_err.empty()) { err = bg_err; bg_err.clear(); } const int rc = bg_rc; bg_rc = TRGT_OK; return rc; }
+  ~trgt_writer() { if (bg.joinable()) bg.join(); if (dev) trgt_hip_destroy(dev); }
 };
 
 extern "C" {
@@ -188,7 +193,7 @@ void trgt_writer_device_stats(const trgt_writer* w, int64_t out[3]) { if (w && o
 
 void trgt_writer_default_params(trgt_writer_params* p) {
   if (!p) return;
-  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0; p->bam_compress_level = 6; p->deflate_device = -1;
+  p->output_flank_len = 50; p->sample_name = "sample"; p->program = "trgt"; p->version = "3.0.0"; p->command_line = ""; p->keep_unmapped_flag = 1; p->threads = 0; p->bam_compress_level = 6; p->deflate_device = -1; p->write_behind = 0;
 }
 
 static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p, const char* vcf_path, const char* bam_path, trgt_writer** out) {
@@ -198,6 +203,7 @@ static int writer_open_impl(const trgt_ingest* src, const trgt_writer_params* p,
   auto bad = [&](const std::string& m) { w->err = m; *out = w.release(); return TRGT_ERR_INVALID; };
   w->flank_len = p->output_flank_len; w->keep_unmapped = p->keep_unmapped_flag != 0;
   w->threads = p->threads > 0 ? p->threads : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  w->write_behind = p->write_behind != 0;
   w->vcf.threads = w->bam.threads = w->threads;
   w->bam.level = std::min(9, std::max(0, p->bam_compress_level));
   if (p->deflate_device >= 0 && bam_path) {  // the spanning BAM's blocks on the GPU (the VCF stays with zlib: it is small)
@@ -425,13 +431,32 @@ static int writer_write_impl(trgt_writer* w, const trgt_ingest_batch* b, const t
   size_t vcf_bytes = 0, bam_bytes = 0;
   for (int t = 0; t < nt; ++t) { vcf_bytes += lines[(size_t)t].size(); bam_bytes += recs[(size_t)t].size(); }
   struct Tr { bool on; double t0, t1; int64_t nl; int nt; size_t v, b; decltype(now)& now; ~Tr() { if (on) std::fprintf(stderr, "[writer] %lld loci, %d threads: formatting %.1f ms (%zu B of VCF, %zu B of BAM records), deflate + write %.1f ms\n", (long long)nl, nt, t1 - t0, v, b, now() - t1); } } tr{trace, t0, t1, nl, nt, vcf_bytes, bam_bytes, now};
-  for (int t = 0; t < nt; ++t) {  // (what precedes the first failing locus is written, as a serial writer would have)
-    if (!lines[(size_t)t].empty() && !w->vcf.append(lines[(size_t)t].data(), lines[(size_t)t].size())) return bad("cannot write the VCF");
-    if (!recs[(size_t)t].empty() && !w->bam.append(recs[(size_t)t].data(), recs[(size_t)t].size())) return bad("cannot write the BAM");
-    if (!errs[(size_t)t].empty()) { w->vcf.flush(); w->bam.flush(); return bad(errs[(size_t)t]); }
+  // what precedes the first failing locus is written, as a serial writer would have; msg: what went wrong (empty: nothing)
+  auto flush_pieces = [](trgt_writer* ww, std::vector<std::string>& ln, std::vector<std::vector<uint8_t>>& rc, std::vector<std::string>& er, std::string& msg) -> int {
+    for (size_t t = 0; t < ln.size(); ++t) {
+      if (!ln[t].empty() && !ww->vcf.append(ln[t].data(), ln[t].size())) { msg = "cannot write the VCF"; return TRGT_ERR_INVALID; }
+      if (!rc[t].empty() && !ww->bam.append(rc[t].data(), rc[t].size())) { msg = "cannot write the BAM"; return TRGT_ERR_INVALID; }
+      if (!er[t].empty()) { ww->vcf.flush(); ww->bam.flush(); msg = er[t]; return TRGT_ERR_INVALID; }
+    }
+    if (!ww->vcf.flush()) { msg = "cannot write the VCF"; return TRGT_ERR_INVALID; }
+    if (!ww->bam.flush()) { msg = ww->bam.dev_err.empty() ? "cannot write the BAM" : ww->bam.dev_err; return TRGT_ERR_INVALID; }
+    return TRGT_OK;
+  };
+  if (w->write_behind) {
+    // the batch before this one must be on its way out (one in flight): its verdict is this call's when it failed
+    if (const int prc = w->bg_wait()) return prc;
+    struct Pieces { std::vector<std::string> lines, errs; std::vector<std::vector<uint8_t>> recs; };
+    auto pcs = std::make_shared<Pieces>();
+    pcs->lines = std::move(lines); pcs->errs = std::move(errs); pcs->recs = std::move(recs);
+    tr.on = false;  // (the phase line would time the hand-over, not the flush)
+    w->bg = std::thread([w, pcs, flush_pieces]() {
+      try { std::string msg; w->bg_rc = flush_pieces(w, pcs->lines, pcs->recs, pcs->errs, msg); if (w->bg_rc != TRGT_OK) w->bg_err = msg; }
+      catch (const std::exception& e) { w->bg_rc = TRGT_ERR_NOMEM; w->bg_err = std::string("trgt_writer_write: ") + e.what(); }
+    });
+    return TRGT_OK;
   }
-  if (!w->vcf.flush()) return bad("cannot write the VCF");
-  if (!w->bam.flush()) return bad(w->bam.dev_err.empty() ? "cannot write the BAM" : w->bam.dev_err);
+  std::string msg;
+  if (const int frc = flush_pieces(w, lines, recs, errs, msg)) return bad(msg);
   return TRGT_OK;
 }
 
@@ -464,9 +489,10 @@ int trgt_writer_write(trgt_writer* w, const trgt_ingest_batch* b, const trgt_loc
 
 int trgt_writer_close(trgt_writer* w) {
   if (!w) return TRGT_OK;
+  const int brc = w->bg_wait();  // (write_behind: the last batch's pieces)
   const bool ok1 = w->vcf.close(), ok2 = !w->has_bam || w->bam.close();
   delete w;
-  return ok1 && ok2 ? TRGT_OK : TRGT_ERR_INVALID;
+  return brc != TRGT_OK ? brc : ok1 && ok2 ? TRGT_OK : TRGT_ERR_INVALID;
 }
 
 }  // extern "C"

@@ -12,12 +12,12 @@ from .ingest import IngestBatch
 class WriterParams(C.Structure):
     _fields_ = [("output_flank_len", C.c_int32), ("sample_name", C.c_char_p), ("program", C.c_char_p), ("version", C.c_char_p),
                 ("command_line", C.c_char_p), ("keep_unmapped_flag", C.c_int32), ("threads", C.c_int32), ("bam_compress_level", C.c_int32),
-                ("deflate_device", C.c_int32)]
+                ("deflate_device", C.c_int32), ("write_behind", C.c_int32)]
 
 
 class Writer:
     def __init__(self, reader, vcf_path, bam_path=None, output_flank_len=50, sample_name="sample", program="trgt", version="3.0.0",
-                 command_line="", keep_unmapped_flag=1, threads=0, bam_compress_level=6, deflate_device=-1):
+                 command_line="", keep_unmapped_flag=1, threads=0, bam_compress_level=6, deflate_device=-1, write_behind=0):
         L = _lib.lib()
         L.trgt_writer_open.argtypes = [C.c_void_p, C.POINTER(WriterParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.trgt_writer_write.argtypes = [C.c_void_p, C.POINTER(IngestBatch), C.c_void_p]
@@ -26,7 +26,7 @@ class Writer:
         L.trgt_writer_last_error.restype = C.c_char_p
         self._L = L
         self._keep = [s.encode() for s in (sample_name, program, version, command_line)]
-        p = WriterParams(output_flank_len, *self._keep, int(keep_unmapped_flag), int(threads), int(bam_compress_level), int(deflate_device))
+        p = WriterParams(output_flank_len, *self._keep, int(keep_unmapped_flag), int(threads), int(bam_compress_level), int(deflate_device), int(write_behind))
         self.handle = C.c_void_p()
         rc = L.trgt_writer_open(reader.handle, C.byref(p), str(vcf_path).encode(), str(bam_path).encode() if bam_path else None, C.byref(self.handle))
         if rc != 0:
